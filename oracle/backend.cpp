@@ -1,0 +1,1479 @@
+// ORACLE (test infrastructure only — never linked into or called by the product path).
+// CPU restatement of the sliding-window back-end:
+//   vins_estimator/src/estimator/estimator.cpp:15-374,922-1716,1749-2009
+//   vins_estimator/src/feature_manager/feature_manager.cpp:31-123,197-233,302-324,386-543,660-768
+//   vins_estimator/src/factor/{integration_base.h,imu_factor.h,projection_factor.cpp,projection_td_factor.cpp,
+//                              pose_local_parameterization.cpp,marginalization_factor.cpp}
+//   vins_estimator/src/initial/initial_aligment.cpp:3-36
+// The Ceres trust-region solve (estimator.cpp:1348-1363: DENSE_SCHUR + traditional DOGLEG, 8 iterations) is
+// restated from SURVEY.md Appendix B.5. "parity unpinned": Ceres/Eigen are absent from this image.
+#include <array>
+#include "oracle.h"
+#include <cfloat>
+#include <numeric>
+
+namespace ovio {
+using namespace om;
+
+enum { O_P = 0, O_R = 3, O_V = 6, O_BA = 9, O_BG = 12 };
+
+// ------------------------------------------------------------------ IntegrationBase (integration_base.h)
+Integration::Integration(const Config &c, const V3 &a0, const V3 &g0, const V3 &ba, const V3 &bg)
+    : acc_n(c.acc_n), acc_w(c.acc_w), gyr_n(c.gyr_n), gyr_w(c.gyr_w), acc_0(a0), gyr_0(g0), linearized_acc(a0),
+      linearized_gyr(g0), linearized_ba(ba), linearized_bg(bg) {
+    std::memset(jacobian, 0, sizeof(jacobian));
+    std::memset(covariance, 0, sizeof(covariance));
+    for (int i = 0; i < 15; i++) jacobian[i][i] = 1;
+}
+void Integration::push_back(double dt, const V3 &acc, const V3 &gyr) {  // :32-38
+    dt_buf.push_back(dt);
+    acc_buf.push_back(acc);
+    gyr_buf.push_back(gyr);
+    propagate(dt, acc, gyr);
+}
+void Integration::repropagate(const V3 &ba, const V3 &bg) {  // :40-54
+    sum_dt = 0;
+    acc_0 = linearized_acc;
+    gyr_0 = linearized_gyr;
+    delta_p = V3();
+    delta_q = Q();
+    delta_v = V3();
+    linearized_ba = ba;
+    linearized_bg = bg;
+    std::memset(jacobian, 0, sizeof(jacobian));
+    std::memset(covariance, 0, sizeof(covariance));
+    for (int i = 0; i < 15; i++) jacobian[i][i] = 1;
+    for (size_t i = 0; i < dt_buf.size(); i++) propagate(dt_buf[i], acc_buf[i], gyr_buf[i]);
+}
+static void setblk(double M[15][18], int r, int c, const M3 &B) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[r + i][c + j] = B(i, j);
+}
+static void setblk15(double M[15][15], int r, int c, const M3 &B) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) M[r + i][c + j] = B(i, j);
+}
+void Integration::propagate(double dt, const V3 &acc_1, const V3 &gyr_1) {  // :56-162 (midPointIntegration)
+    V3 un_acc_0 = rot(delta_q, acc_0 - linearized_ba);
+    V3 un_gyr = 0.5 * (gyr_0 + gyr_1) - linearized_bg;
+    Q rq = delta_q * Q(1, un_gyr.x * dt / 2, un_gyr.y * dt / 2, un_gyr.z * dt / 2);
+    V3 un_acc_1 = rot(rq, acc_1 - linearized_ba);
+    V3 un_acc = 0.5 * (un_acc_0 + un_acc_1);
+    V3 rp = delta_p + delta_v * dt + 0.5 * un_acc * dt * dt;
+    V3 rv = delta_v + un_acc * dt;
+
+    V3 w_x = un_gyr, a_0_x = acc_0 - linearized_ba, a_1_x = acc_1 - linearized_ba;
+    M3 R_w_x = skew(w_x), R_a_0_x = skew(a_0_x), R_a_1_x = skew(a_1_x);
+    M3 Rq = toR(delta_q), Rr = toR(rq), I = M3::I();
+    M3 ImW = I - dt * R_w_x;
+    double F[15][15], V[15][18];
+    std::memset(F, 0, sizeof(F));
+    std::memset(V, 0, sizeof(V));
+    setblk15(F, 0, 0, I);
+    setblk15(F, 0, 3, (-0.25 * dt * dt) * (Rq * R_a_0_x) + (-0.25 * dt * dt) * (Rr * R_a_1_x * ImW));
+    setblk15(F, 0, 6, dt * I);
+    setblk15(F, 0, 9, (-0.25 * dt * dt) * (Rq + Rr));
+    setblk15(F, 0, 12, (-0.25 * dt * dt * -dt) * (Rr * R_a_1_x));
+    setblk15(F, 3, 3, ImW);
+    setblk15(F, 3, 12, (-dt) * I);
+    setblk15(F, 6, 3, (-0.5 * dt) * (Rq * R_a_0_x) + (-0.5 * dt) * (Rr * R_a_1_x * ImW));
+    setblk15(F, 6, 6, I);
+    setblk15(F, 6, 9, (-0.5 * dt) * (Rq + Rr));
+    setblk15(F, 6, 12, (-0.5 * dt * -dt) * (Rr * R_a_1_x));
+    setblk15(F, 9, 9, I);
+    setblk15(F, 12, 12, I);
+    M3 V03 = (0.25 * dt * dt * 0.5 * dt) * (-(Rr * R_a_1_x));
+    M3 V63 = (0.5 * dt * 0.5 * dt) * (-(Rr * R_a_1_x));
+    setblk(V, 0, 0, (0.25 * dt * dt) * Rq);
+    setblk(V, 0, 3, V03);
+    setblk(V, 0, 6, (0.25 * dt * dt) * Rr);
+    setblk(V, 0, 9, V03);
+    setblk(V, 3, 3, (0.5 * dt) * I);
+    setblk(V, 3, 9, (0.5 * dt) * I);
+    setblk(V, 6, 0, (0.5 * dt) * Rq);
+    setblk(V, 6, 3, V63);
+    setblk(V, 6, 6, (0.5 * dt) * Rr);
+    setblk(V, 6, 9, V63);
+    setblk(V, 9, 12, dt * I);
+    setblk(V, 12, 15, dt * I);
+    double noise[18];
+    for (int i = 0; i < 3; i++) {
+        noise[i] = acc_n * acc_n; noise[3 + i] = gyr_n * gyr_n; noise[6 + i] = acc_n * acc_n;
+        noise[9 + i] = gyr_n * gyr_n; noise[12 + i] = acc_w * acc_w; noise[15 + i] = gyr_w * gyr_w;
+    }
+    double FJ[15][15], FP[15][15], NP[15][15];
+    for (int i = 0; i < 15; i++)
+        for (int j = 0; j < 15; j++) {
+            double s = 0, s2 = 0;
+            for (int k = 0; k < 15; k++) { s += F[i][k] * jacobian[k][j]; s2 += F[i][k] * covariance[k][j]; }
+            FJ[i][j] = s; FP[i][j] = s2;
+        }
+    for (int i = 0; i < 15; i++)
+        for (int j = 0; j < 15; j++) {
+            double s = 0;
+            for (int k = 0; k < 15; k++) s += FP[i][k] * F[j][k];
+            double t = 0;
+            for (int k = 0; k < 18; k++) t += V[i][k] * noise[k] * V[j][k];
+            NP[i][j] = s + t;
+        }
+    std::memcpy(jacobian, FJ, sizeof(FJ));
+    std::memcpy(covariance, NP, sizeof(NP));
+    delta_p = rp;
+    delta_q = normalized(rq);
+    delta_v = rv;
+    sum_dt += dt;
+    acc_0 = acc_1;
+    gyr_0 = gyr_1;
+}
+static M3 blk(const double J[15][15], int r, int c) {
+    M3 B;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) B(i, j) = J[r + i][c + j];
+    return B;
+}
+void Integration::evaluate(const V3 &G, const V3 &Pi, const Q &Qi, const V3 &Vi, const V3 &Bai, const V3 &Bgi,
+                           const V3 &Pj, const Q &Qj, const V3 &Vj, const V3 &Baj, const V3 &Bgj, double r[15]) const {
+    // :164-195
+    M3 dp_dba = blk(jacobian, O_P, O_BA), dp_dbg = blk(jacobian, O_P, O_BG), dq_dbg = blk(jacobian, O_R, O_BG),
+       dv_dba = blk(jacobian, O_V, O_BA), dv_dbg = blk(jacobian, O_V, O_BG);
+    V3 dba = Bai - linearized_ba, dbg = Bgi - linearized_bg;
+    Q cq = delta_q * deltaQ(dq_dbg * dbg);
+    V3 cv = delta_v + dv_dba * dba + dv_dbg * dbg;
+    V3 cp = delta_p + dp_dba * dba + dp_dbg * dbg;
+    Q Qi_inv = inverse(Qi);
+    V3 rp = rot(Qi_inv, 0.5 * G * sum_dt * sum_dt + Pj - Pi - Vi * sum_dt) - cp;
+    V3 rq = 2.0 * (inverse(cq) * (Qi_inv * Qj)).vec();
+    V3 rv = rot(Qi_inv, G * sum_dt + Vj - Vi) - cv;
+    V3 rba = Baj - Bai, rbg = Bgj - Bgi;
+    for (int i = 0; i < 3; i++) { r[O_P + i] = rp[i]; r[O_R + i] = rq[i]; r[O_V + i] = rv[i]; r[O_BA + i] = rba[i]; r[O_BG + i] = rbg[i]; }
+}
+
+static void Qleft(const Q &q, double M[4][4]) {  // utility.h:46-54
+    M[0][0] = q.w; M[0][1] = -q.x; M[0][2] = -q.y; M[0][3] = -q.z;
+    M3 S = skew(q.vec());
+    double v[3] = {q.x, q.y, q.z};
+    for (int i = 0; i < 3; i++) {
+        M[1 + i][0] = v[i];
+        for (int j = 0; j < 3; j++) M[1 + i][1 + j] = (i == j ? q.w : 0.0) + S(i, j);
+    }
+}
+static void Qright(const Q &q, double M[4][4]) {  // utility.h:56-64
+    M[0][0] = q.w; M[0][1] = -q.x; M[0][2] = -q.y; M[0][3] = -q.z;
+    M3 S = skew(q.vec());
+    double v[3] = {q.x, q.y, q.z};
+    for (int i = 0; i < 3; i++) {
+        M[1 + i][0] = v[i];
+        for (int j = 0; j < 3; j++) M[1 + i][1 + j] = (i == j ? q.w : 0.0) - S(i, j);
+    }
+}
+static M3 br33(const double M[4][4]) { M3 B; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) B(i, j) = M[1 + i][1 + j]; return B; }
+
+// IMUFactor::Evaluate imu_factor.h:20-205
+void eval_imu(const Integration &pre, const V3 &G, const double *pi, const double *sbi, const double *pj, const double *sbj,
+              double r[15], double *J_pi, double *J_sbi, double *J_pj, double *J_sbj) {
+    V3 Pi(pi[0], pi[1], pi[2]); Q Qi(pi[6], pi[3], pi[4], pi[5]);
+    V3 Vi(sbi[0], sbi[1], sbi[2]), Bai(sbi[3], sbi[4], sbi[5]), Bgi(sbi[6], sbi[7], sbi[8]);
+    V3 Pj(pj[0], pj[1], pj[2]); Q Qj(pj[6], pj[3], pj[4], pj[5]);
+    V3 Vj(sbj[0], sbj[1], sbj[2]), Baj(sbj[3], sbj[4], sbj[5]), Bgj(sbj[6], sbj[7], sbj[8]);
+    double raw[15];
+    pre.evaluate(G, Pi, Qi, Vi, Bai, Bgi, Pj, Qj, Vj, Baj, Bgj, raw);
+    // sqrt_info = LLT(cov^-1).matrixL().transpose()
+    Mat C(15, 15);
+    for (int i = 0; i < 15; i++) for (int j = 0; j < 15; j++) C(i, j) = 0.5 * (pre.covariance[i][j] + pre.covariance[j][i]);
+    Mat Lc = C;
+    double sqrt_info[15][15];
+    std::memset(sqrt_info, 0, sizeof(sqrt_info));
+    if (chol(Lc)) {
+        // cov^-1 = Lc^-T Lc^-1
+        Mat Li(15, 15);
+        for (int c = 0; c < 15; c++) {
+            std::vector<double> e(15, 0.0);
+            e[c] = 1;
+            for (int i = 0; i < 15; i++) {
+                double s = e[i];
+                for (int k = 0; k < i; k++) s -= Lc(i, k) * e[k];
+                e[i] = s / Lc(i, i);
+            }
+            for (int i = 0; i < 15; i++) Li(i, c) = e[i];
+        }
+        Mat Ci(15, 15);
+        for (int i = 0; i < 15; i++)
+            for (int j = 0; j < 15; j++) {
+                double s = 0;
+                for (int k = 0; k < 15; k++) s += Li(k, i) * Li(k, j);
+                Ci(i, j) = s;
+            }
+        if (chol(Ci))
+            for (int i = 0; i < 15; i++) for (int j = i; j < 15; j++) sqrt_info[i][j] = Ci(j, i);  // L^T
+    }
+    for (int i = 0; i < 15; i++) {
+        double s = 0;
+        for (int k = 0; k < 15; k++) s += sqrt_info[i][k] * raw[k];
+        r[i] = s;
+    }
+    if (!J_pi) return;
+    double sum_dt = pre.sum_dt;
+    M3 dp_dba = blk(pre.jacobian, O_P, O_BA), dp_dbg = blk(pre.jacobian, O_P, O_BG), dq_dbg = blk(pre.jacobian, O_R, O_BG),
+       dv_dba = blk(pre.jacobian, O_V, O_BA), dv_dbg = blk(pre.jacobian, O_V, O_BG);
+    Q Qi_inv = inverse(Qi), Qj_inv = inverse(Qj);
+    M3 RiT = toR(Qi_inv);
+    Q cq = pre.delta_q * deltaQ(dq_dbg * (Bgi - pre.linearized_bg));
+    double Ji[15][7], Jsi[15][9], Jj[15][7], Jsj[15][9];
+    std::memset(Ji, 0, sizeof(Ji)); std::memset(Jsi, 0, sizeof(Jsi)); std::memset(Jj, 0, sizeof(Jj)); std::memset(Jsj, 0, sizeof(Jsj));
+    auto put = [](double *base, int ld, int r0, int c0, const M3 &B) {
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) base[(r0 + i) * ld + c0 + j] = B(i, j);
+    };
+    double L4[4][4], R4[4][4];
+    // pose_i
+    put(&Ji[0][0], 7, O_P, O_P, -RiT);
+    put(&Ji[0][0], 7, O_P, O_R, skew(rot(Qi_inv, 0.5 * G * sum_dt * sum_dt + Pj - Pi - Vi * sum_dt)));
+    Qleft(Qj_inv * Qi, L4); Qright(cq, R4);
+    {
+        double LR[4][4];
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += L4[i][k] * R4[k][j]; LR[i][j] = s; }
+        put(&Ji[0][0], 7, O_R, O_R, -br33(LR));
+    }
+    put(&Ji[0][0], 7, O_V, O_R, skew(rot(Qi_inv, G * sum_dt + Vj - Vi)));
+    // speedbias_i
+    put(&Jsi[0][0], 9, O_P, O_V - O_V, (-sum_dt) * RiT);
+    put(&Jsi[0][0], 9, O_P, O_BA - O_V, -dp_dba);
+    put(&Jsi[0][0], 9, O_P, O_BG - O_V, -dp_dbg);
+    Qleft(Qj_inv * Qi * pre.delta_q, L4);
+    put(&Jsi[0][0], 9, O_R, O_BG - O_V, -(br33(L4) * dq_dbg));
+    put(&Jsi[0][0], 9, O_V, O_V - O_V, -RiT);
+    put(&Jsi[0][0], 9, O_V, O_BA - O_V, -dv_dba);
+    put(&Jsi[0][0], 9, O_V, O_BG - O_V, -dv_dbg);
+    put(&Jsi[0][0], 9, O_BA, O_BA - O_V, -M3::I());
+    put(&Jsi[0][0], 9, O_BG, O_BG - O_V, -M3::I());
+    // pose_j
+    put(&Jj[0][0], 7, O_P, O_P, RiT);
+    Qleft(inverse(cq) * Qi_inv * Qj, L4);
+    put(&Jj[0][0], 7, O_R, O_R, br33(L4));
+    // speedbias_j
+    put(&Jsj[0][0], 9, O_V, O_V - O_V, RiT);
+    put(&Jsj[0][0], 9, O_BA, O_BA - O_V, M3::I());
+    put(&Jsj[0][0], 9, O_BG, O_BG - O_V, M3::I());
+    auto premul = [&](const double *Jin, int nc, double *out) {
+        for (int i = 0; i < 15; i++)
+            for (int j = 0; j < nc; j++) {
+                double s = 0;
+                for (int k = i; k < 15; k++) s += sqrt_info[i][k] * Jin[k * nc + j];
+                out[i * nc + j] = s;
+            }
+    };
+    premul(&Ji[0][0], 7, J_pi);
+    premul(&Jsi[0][0], 9, J_sbi);
+    premul(&Jj[0][0], 7, J_pj);
+    premul(&Jsj[0][0], 9, J_sbj);
+}
+
+// ProjectionFactor / ProjectionTdFactor  (projection_factor.cpp:22-130, projection_td_factor.cpp:34-150)
+void eval_projection(const Config &c, const double *pi, const double *pj, const double *ex, double inv_dep, double td,
+                     const Obs &oi, const Obs &oj, bool use_td, double r[2], double *J_i, double *J_j, double *J_ex,
+                     double *J_l, double *J_td) {
+    V3 Pi(pi[0], pi[1], pi[2]); Q Qi(pi[6], pi[3], pi[4], pi[5]);
+    V3 Pj(pj[0], pj[1], pj[2]); Q Qj(pj[6], pj[3], pj[4], pj[5]);
+    V3 tic(ex[0], ex[1], ex[2]); Q qic(ex[6], ex[3], ex[4], ex[5]);
+    V3 pts_i(oi.x, oi.y, oi.z), pts_j(oj.x, oj.y, oj.z);
+    V3 vel_i(oi.vx, oi.vy, 0), vel_j(oj.vx, oj.vy, 0);
+    if (use_td) {
+        double ROW = (double)c.height;
+        double row_i = oi.v - ROW / 2, row_j = oj.v - ROW / 2;
+        pts_i = pts_i - (td - oi.cur_td + c.tr / ROW * row_i) * vel_i;
+        pts_j = pts_j - (td - oj.cur_td + c.tr / ROW * row_j) * vel_j;
+    }
+    double sq = c.focal_length / 1.5;  // sqrt_info = FOCAL_LENGTH/1.5 * I (estimator.cpp:23-24)
+    V3 pts_camera_i = pts_i / inv_dep;
+    V3 pts_imu_i = rot(qic, pts_camera_i) + tic;
+    V3 pts_w = rot(Qi, pts_imu_i) + Pi;
+    V3 pts_imu_j = rot(inverse(Qj), pts_w - Pj);
+    V3 pts_camera_j = rot(inverse(qic), pts_imu_j - tic);
+    double dep_j = pts_camera_j.z;
+    r[0] = sq * (pts_camera_j.x / dep_j - pts_j.x);
+    r[1] = sq * (pts_camera_j.y / dep_j - pts_j.y);
+    if (!J_i) return;
+    M3 Ri = toR(Qi), Rj = toR(Qj), ric = toR(qic);
+    double red[2][3] = {{sq / dep_j, 0, -sq * pts_camera_j.x / (dep_j * dep_j)},
+                        {0, sq / dep_j, -sq * pts_camera_j.y / (dep_j * dep_j)}};
+    auto red_mul = [&](const M3 &A, const M3 &B, double *out) {  // out(2×7) = red * [A | B], last col 0
+        for (int i = 0; i < 2; i++) {
+            for (int j = 0; j < 3; j++) {
+                double s = 0, t = 0;
+                for (int k = 0; k < 3; k++) { s += red[i][k] * A(k, j); t += red[i][k] * B(k, j); }
+                out[i * 7 + j] = s;
+                out[i * 7 + 3 + j] = t;
+            }
+            out[i * 7 + 6] = 0;
+        }
+    };
+    M3 ricT = T(ric), RjT = T(Rj);
+    red_mul(ricT * RjT, ricT * RjT * Ri * (-skew(pts_imu_i)), J_i);
+    red_mul(ricT * (-RjT), ricT * skew(pts_imu_j), J_j);
+    {
+        M3 tmp_r = ricT * RjT * Ri * ric;
+        M3 A = ricT * (RjT * Ri - M3::I());
+        M3 B = -(tmp_r * skew(pts_camera_i)) + skew(tmp_r * pts_camera_i) +
+               skew(ricT * (RjT * (Ri * tic + Pi - Pj) - tic));
+        red_mul(A, B, J_ex);
+    }
+    {
+        M3 tmp_r = ricT * RjT * Ri * ric;
+        V3 v = tmp_r * pts_i * (-1.0 / (inv_dep * inv_dep));
+        for (int i = 0; i < 2; i++) J_l[i] = red[i][0] * v.x + red[i][1] * v.y + red[i][2] * v.z;
+        if (J_td) {
+            if (use_td) {
+                V3 w = tmp_r * vel_i / inv_dep * -1.0;
+                for (int i = 0; i < 2; i++) J_td[i] = red[i][0] * w.x + red[i][1] * w.y + red[i][2] * w.z;
+                J_td[0] += sq * vel_j.x;
+                J_td[1] += sq * vel_j.y;
+            } else
+                J_td[0] = J_td[1] = 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ Estimator
+Estimator::Estimator(const Config &c) : cfg(c), W(c.window_size) {
+    for (int i = 0; i <= MAXW; i++) pre_integrations[i] = nullptr;
+    clearState();
+    // setParameter() estimator.cpp:15-41
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) ric(i, j) = c.ric[i * 3 + j];
+    tic = V3(c.tic[0], c.tic[1], c.tic[2]);
+    td = c.td;
+    g = V3(0, 0, c.g_norm);
+}
+Estimator::~Estimator() {
+    for (int i = 0; i <= MAXW; i++) delete pre_integrations[i];
+}
+void Estimator::clearState() {  // estimator.cpp:43-116
+    imu_buf.clear();
+    imu_head = 0;
+    for (int i = 0; i <= MAXW; i++) {
+        Rs[i] = M3::I();
+        Ps[i] = Vs[i] = Bas[i] = Bgs[i] = V3();
+        Headers[i] = 0;
+        delete pre_integrations[i];
+        pre_integrations[i] = nullptr;
+    }
+    tic = V3();
+    ric = M3::I();
+    first_imu = false;
+    frame_count = 0;
+    solver_flag = 0;
+    td = cfg.td;
+    openExEstimation = false;
+    has_prior = false;
+    feature.clear();
+    failure_occur = false;
+    initFirstPoseFlag = false;
+    prevTime = -1;
+    latest_Bg = V3();
+}
+void Estimator::inputIMU(double t, const V3 &acc, const V3 &gyr) {  // :1749-1766 (predict() path is output-only)
+    imu_buf.push_back(ImuSample{t, acc, gyr});
+}
+bool Estimator::IMUAvailable(double t) const {  // :1882-1888
+    return imu_head < imu_buf.size() && t <= imu_buf.back().t;
+}
+void Estimator::predictMotion(double t0, double t1, double R[9]) {  // :1790-1860
+    M3 rel = M3::I();
+    auto out = [&]() { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = rel(i, j); };
+    if (imu_head >= imu_buf.size()) { out(); return; }
+    if (t1 <= imu_buf.back().t) {
+        size_t k = imu_head;
+        while (k < imu_buf.size() && imu_buf[k].t <= t0) k++;
+        bool first = true;
+        double prev_t = 0;
+        V3 prev_gyr;
+        while (k < imu_buf.size() && imu_buf[k].t <= t1) {
+            double t = imu_buf[k].t;
+            V3 w = imu_buf[k].gyr;
+            k++;
+            if (first) { prev_t = t; first = false; prev_gyr = w; continue; }
+            double dt = t - prev_t;
+            prev_t = t;
+            V3 un_gyr = 0.5 * (prev_gyr + w) - latest_Bg;
+            prev_gyr = w;
+            V3 aa = (T(ric) * un_gyr) * dt;  // RIC.back().transpose() * un_gyr * dt
+            double ang = norm(aa);
+            // AngleAxisd(|aa|, aa.normalized()).toRotationMatrix().transpose(); zero vector normalises to zero -> identity
+            M3 Rk = M3::I();
+            if (ang > 0) {
+                V3 ax = aa / ang;
+                double s = std::sin(ang), c = std::cos(ang);
+                M3 K = skew(ax);
+                Rk = M3::I() + s * K + (1 - c) * (K * K);
+            }
+            rel = rel * T(Rk);
+        }
+    }
+    out();
+}
+void Estimator::processIMU(double dt, const V3 &acc, const V3 &gyr) {  // :118-154
+    if (!first_imu) { first_imu = true; acc_0 = acc; gyr_0 = gyr; }
+    if (!pre_integrations[frame_count])
+        pre_integrations[frame_count] = new Integration(cfg, acc_0, gyr_0, Bas[frame_count], Bgs[frame_count]);
+    if (frame_count != 0) {
+        pre_integrations[frame_count]->push_back(dt, acc, gyr);
+        int j = frame_count;
+        V3 un_acc_0 = Rs[j] * (acc_0 - Bas[j]) - g;
+        V3 un_gyr = 0.5 * (gyr_0 + gyr) - Bgs[j];
+        Rs[j] = Rs[j] * toR(deltaQ(un_gyr * dt));
+        V3 un_acc_1 = Rs[j] * (acc - Bas[j]) - g;
+        V3 un_acc = 0.5 * (un_acc_0 + un_acc_1);
+        Ps[j] = Ps[j] + dt * Vs[j] + 0.5 * dt * dt * un_acc;
+        Vs[j] = Vs[j] + dt * un_acc;
+    }
+    acc_0 = acc;
+    gyr_0 = gyr;
+}
+void Estimator::initFirstIMUPose(const std::vector<ImuSample> &v) {  // :1890-1909
+    initFirstPoseFlag = true;
+    V3 aver;
+    for (auto &s : v) aver = aver + s.acc;
+    aver = aver / (double)v.size();
+    M3 R0 = g2R(aver);
+    double yaw = R2ypr(R0).x;
+    R0 = ypr2R(V3(-yaw, 0, 0)) * R0;
+    Rs[0] = R0;
+}
+
+// ------------------------------------------------------------------ feature manager
+static inline bool in_problem(const Landmark &l, int W) { return l.obs.size() >= 2 && l.start_frame < W - 2; }
+int Estimator::getFeatureCount() {  // feature_manager.cpp:31-49
+    int cnt = 0;
+    for (auto &it : feature) {
+        if (it.is_dynamic) continue;
+        it.used_num = (int)it.obs.size();
+        if (in_problem(it, W)) cnt++;
+    }
+    return cnt;
+}
+bool Estimator::addFeatureCheckParallax(int fc, std::map<int, std::array<double, 7>> &image, double td_) {  // :56-123
+    double parallax_sum = 0;
+    int parallax_num = 0;
+    last_track_num = 0;
+    for (auto iter = image.begin(); iter != image.end();) {
+        const auto &p = iter->second;
+        unsigned short mm = depth_img[(size_t)(int)p[4] * cfg.width + (int)p[3]];
+        double dm = mm / 1000.0;
+        if (0 < dm && dm < cfg.depth_min) { iter = image.erase(iter); continue; }
+        int fid = iter->first;
+        auto it = std::find_if(feature.begin(), feature.end(), [fid](const Landmark &l) { return l.feature_id == fid; });
+        Obs o{p[0], p[1], p[2], p[3], p[4], p[5], p[6], td_, dm};
+        if (it == feature.end()) {
+            Landmark l;
+            l.feature_id = fid;
+            l.start_frame = fc;
+            l.obs.push_back(o);
+            feature.push_back(l);
+        } else {
+            it->obs.push_back(o);
+            last_track_num++;
+        }
+        ++iter;
+    }
+    if (fc < 2 || last_track_num < 20) return true;
+    for (auto &l : feature)
+        if (l.start_frame <= fc - 2 && l.start_frame + (int)l.obs.size() - 1 >= fc - 1) {
+            parallax_sum += compensatedParallax2(l, fc);
+            parallax_num++;
+        }
+    if (parallax_num == 0) return true;
+    return parallax_sum / parallax_num >= cfg.min_parallax_px / cfg.focal_length;
+}
+double Estimator::compensatedParallax2(const Landmark &l, int fc) const {  // :732-768
+    const Obs &fi = l.obs[fc - 2 - l.start_frame], &fj = l.obs[fc - 1 - l.start_frame];
+    double u_j = fj.x, v_j = fj.y;
+    double dep_i = fi.z, u_i = fi.x / dep_i, v_i = fi.y / dep_i;
+    double du = u_i - u_j, dv = v_i - v_j;
+    return std::max(0.0, std::sqrt(std::min(du * du + dv * dv, du * du + dv * dv)));
+}
+void Estimator::setDepth(const std::vector<double> &x) {  // :197-223
+    int idx = -1;
+    for (auto &l : feature) {
+        if (l.is_dynamic) continue;
+        l.used_num = (int)l.obs.size();
+        if (!in_problem(l, W)) continue;
+        l.estimated_depth = 1.0 / x[++idx];
+        l.solve_flag = l.estimated_depth < 0 ? 2 : 1;
+    }
+}
+std::vector<double> Estimator::getDepthVector() {  // :302-324
+    std::vector<double> d;
+    for (auto &l : feature) {
+        if (l.is_dynamic) continue;
+        l.used_num = (int)l.obs.size();
+        if (!in_problem(l, W)) continue;
+        d.push_back(1. / l.estimated_depth);
+    }
+    return d;
+}
+void Estimator::removeFailures() {  // :225-233
+    for (auto it = feature.begin(); it != feature.end();) {
+        if (it->solve_flag == 2) it = feature.erase(it); else ++it;
+    }
+}
+void Estimator::triangulateWithDepth() {  // :386-543
+    for (auto &l : feature) {
+        if (l.estimated_depth > 0) continue;
+        if (l.is_dynamic) continue;
+        l.used_num = (int)l.obs.size();
+        if (!in_problem(l, W)) continue;
+        int imu_i = l.start_frame;
+        V3 tr = Ps[imu_i] + Rs[imu_i] * tic;
+        M3 Rr = Rs[imu_i] * ric;
+        std::vector<double> verified, rough;
+        int no_depth_num = 0;
+        int K = (int)l.obs.size();
+        for (int k = 0; k < K; k++) {
+            if (l.obs[k].depth == 0) { no_depth_num++; continue; }
+            V3 t0 = Ps[imu_i + k] + Rs[imu_i + k] * tic;
+            M3 R0 = Rs[imu_i + k] * ric;
+            V3 point0 = V3(l.obs[k].x, l.obs[k].y, l.obs[k].z) * l.obs[k].depth;
+            V3 t2r = T(Rr) * (t0 - tr);
+            M3 R2r = T(Rr) * R0;
+            for (int j = 0; j < K; j++) {
+                if (k == j) continue;
+                V3 t1 = Ps[imu_i + j] + Rs[imu_i + j] * tic;
+                M3 R1 = Rs[imu_i + j] * ric;
+                V3 t20 = T(R0) * (t1 - t0);
+                M3 R20 = T(R0) * R1;
+                V3 pp = T(R20) * point0 - T(R20) * t20;
+                double rx = l.obs[j].x - pp.x / pp.z, ry = l.obs[j].y - pp.y / pp.z;
+                if (std::sqrt(rx * rx + ry * ry) < 10.0 / 460) {
+                    V3 pr = R2r * point0 + t2r;
+                    if (l.obs[k].depth > cfg.depth_max) rough.push_back(pr.z); else verified.push_back(pr.z);
+                }
+            }
+        }
+        if (verified.empty()) {
+            if (rough.empty()) {
+                if (no_depth_num == K) {
+                    // DLT: smallest right singular vector of svd_A == smallest eigenvector of A^T A
+                    Mat AtA(4, 4);
+                    V3 t0 = Ps[imu_i] + Rs[imu_i] * tic;
+                    M3 R0 = Rs[imu_i] * ric;
+                    for (int k = 0; k < K; k++) {
+                        int imu_j = imu_i + k;
+                        V3 t1 = Ps[imu_j] + Rs[imu_j] * tic;
+                        M3 R1 = Rs[imu_j] * ric;
+                        V3 t = T(R0) * (t1 - t0);
+                        M3 R = T(R0) * R1;
+                        double Pm[3][4];
+                        M3 Rt = T(R);
+                        V3 mt = -(Rt * t);
+                        for (int a = 0; a < 3; a++) { for (int b = 0; b < 3; b++) Pm[a][b] = Rt(a, b); Pm[a][3] = mt[a]; }
+                        V3 f(l.obs[k].x, l.obs[k].y, l.obs[k].z);
+                        f = f / norm(f);
+                        double row[2][4];
+                        for (int b = 0; b < 4; b++) { row[0][b] = f.x * Pm[2][b] - f.z * Pm[0][b]; row[1][b] = f.y * Pm[2][b] - f.z * Pm[1][b]; }
+                        for (int rr = 0; rr < 2; rr++)
+                            for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) AtA(a, b) += row[rr][a] * row[rr][b];
+                    }
+                    std::vector<double> w;
+                    Mat V;
+                    sym_eig(AtA, w, V);
+                    double svd_method = V(2, 0) / V(3, 0);
+                    l.estimated_depth = svd_method < cfg.depth_min ? cfg.depth_max : svd_method;
+                    l.estimate_flag = 2;
+                } else
+                    continue;
+            } else {
+                l.estimated_depth = std::accumulate(rough.begin(), rough.end(), 0.0) / rough.size();
+                l.estimate_flag = 0;
+            }
+        } else {
+            l.estimated_depth = std::accumulate(verified.begin(), verified.end(), 0.0) / verified.size();
+            l.estimate_flag = 1;
+        }
+        if (l.estimated_depth < 0.1) { l.estimated_depth = cfg.init_depth; l.estimate_flag = 0; }
+    }
+}
+void Estimator::removeBackShiftDepth(const M3 &mR, const V3 &mP, const M3 &nR, const V3 &nP) {  // :660-691
+    for (auto it = feature.begin(); it != feature.end();) {
+        if (it->start_frame != 0) { it->start_frame--; ++it; continue; }
+        V3 uv_i(it->obs[0].x, it->obs[0].y, it->obs[0].z);
+        it->obs.erase(it->obs.begin());
+        if (it->obs.size() < 2) { it = feature.erase(it); continue; }
+        V3 pts_i = uv_i * it->estimated_depth;
+        V3 w_pts_i = mR * pts_i + mP;
+        V3 pts_j = T(nR) * (w_pts_i - nP);
+        it->estimated_depth = pts_j.z > 0 ? pts_j.z : cfg.init_depth;
+        ++it;
+    }
+}
+void Estimator::removeBack() {  // :693-708
+    for (auto it = feature.begin(); it != feature.end();) {
+        if (it->start_frame != 0) { it->start_frame--; ++it; continue; }
+        it->obs.erase(it->obs.begin());
+        if (it->obs.empty()) it = feature.erase(it); else ++it;
+    }
+}
+void Estimator::removeFront(int fc) {  // :710-730
+    for (auto it = feature.begin(); it != feature.end();) {
+        if (it->start_frame == fc) { it->start_frame--; ++it; continue; }
+        int j = W - 1 - it->start_frame;
+        if (it->endFrame() < fc - 1) { ++it; continue; }
+        it->obs.erase(it->obs.begin() + j);
+        if (it->obs.empty()) it = feature.erase(it); else ++it;
+    }
+}
+
+// ------------------------------------------------------------------ init helper (initial_aligment.cpp:3-36)
+void Estimator::solveGyroscopeBias() {
+    double A[3][3] = {{0}}, b[3] = {0};
+    for (int i = 0; i < W; i++) {
+        int j = i + 1;
+        Q q_ij = fromR(T(Rs[i]) * Rs[j]);
+        M3 tA = blk(pre_integrations[j]->jacobian, O_R, O_BG);
+        V3 tb = 2.0 * (inverse(pre_integrations[j]->delta_q) * q_ij).vec();
+        M3 AtA = T(tA) * tA;
+        V3 Atb = T(tA) * tb;
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) A[r][c] += AtA(r, c); b[r] += Atb[r]; }
+    }
+    // A.ldlt().solve(b) — 3×3 SPD; Gaussian elimination with symmetric pivot order
+    double M[3][4];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) M[r][c] = A[r][c]; M[r][3] = b[r]; }
+    for (int i = 0; i < 3; i++) {
+        int p = i;
+        for (int r = i + 1; r < 3; r++) if (std::fabs(M[r][i]) > std::fabs(M[p][i])) p = r;
+        for (int c = 0; c < 4; c++) std::swap(M[i][c], M[p][c]);
+        if (M[i][i] == 0) continue;
+        for (int r = i + 1; r < 3; r++) {
+            double f = M[r][i] / M[i][i];
+            for (int c = i; c < 4; c++) M[r][c] -= f * M[i][c];
+        }
+    }
+    double x[3] = {0, 0, 0};
+    for (int i = 2; i >= 0; i--) {
+        double s = M[i][3];
+        for (int c = i + 1; c < 3; c++) s -= M[i][c] * x[c];
+        x[i] = M[i][i] != 0 ? s / M[i][i] : 0;
+    }
+    V3 dbg(x[0], x[1], x[2]);
+    for (int i = 0; i <= W; i++) Bgs[i] = Bgs[i] + dbg;
+}
+
+// ------------------------------------------------------------------ state <-> flat arrays
+void Estimator::vector2double() {  // estimator.cpp:936-981
+    for (int i = 0; i <= W; i++) {
+        para_Pose[i][0] = Ps[i].x; para_Pose[i][1] = Ps[i].y; para_Pose[i][2] = Ps[i].z;
+        Q q = fromR(Rs[i]);
+        para_Pose[i][3] = q.x; para_Pose[i][4] = q.y; para_Pose[i][5] = q.z; para_Pose[i][6] = q.w;
+        for (int k = 0; k < 3; k++) { para_SpeedBias[i][k] = Vs[i][k]; para_SpeedBias[i][3 + k] = Bas[i][k]; para_SpeedBias[i][6 + k] = Bgs[i][k]; }
+    }
+    para_Ex_Pose[0] = tic.x; para_Ex_Pose[1] = tic.y; para_Ex_Pose[2] = tic.z;
+    Q q = fromR(ric);
+    para_Ex_Pose[3] = q.x; para_Ex_Pose[4] = q.y; para_Ex_Pose[5] = q.z; para_Ex_Pose[6] = q.w;
+    para_Feature = getDepthVector();
+    if (cfg.estimate_td) para_Td = td;
+}
+void Estimator::double2vector() {  // estimator.cpp:985-1111
+    V3 origin_R0 = R2ypr(Rs[0]);
+    V3 origin_P0 = Ps[0];
+    if (failure_occur) {
+        origin_R0 = R2ypr(last_R0);
+        origin_P0 = last_P0;
+        failure_occur = false;
+    }
+    auto poseQ = [&](int i) { return Q(para_Pose[i][6], para_Pose[i][3], para_Pose[i][4], para_Pose[i][5]); };
+    V3 origin_R00 = R2ypr(toR(poseQ(0)));
+    double y_diff = origin_R0.x - origin_R00.x;
+    M3 rot_diff = ypr2R(V3(y_diff, 0, 0));
+    if (std::fabs(std::fabs(origin_R0.y) - 90) < 1.0 || std::fabs(std::fabs(origin_R00.y) - 90) < 1.0)
+        rot_diff = Rs[0] * T(toR(poseQ(0)));
+    for (int i = 0; i <= W; i++) {
+        Rs[i] = rot_diff * toR(normalized(poseQ(i)));
+        Ps[i] = rot_diff * V3(para_Pose[i][0] - para_Pose[0][0], para_Pose[i][1] - para_Pose[0][1], para_Pose[i][2] - para_Pose[0][2]) + origin_P0;
+        Vs[i] = rot_diff * V3(para_SpeedBias[i][0], para_SpeedBias[i][1], para_SpeedBias[i][2]);
+        Bas[i] = V3(para_SpeedBias[i][3], para_SpeedBias[i][4], para_SpeedBias[i][5]);
+        Bgs[i] = V3(para_SpeedBias[i][6], para_SpeedBias[i][7], para_SpeedBias[i][8]);
+    }
+    tic = V3(para_Ex_Pose[0], para_Ex_Pose[1], para_Ex_Pose[2]);
+    ric = toR(normalized(Q(para_Ex_Pose[6], para_Ex_Pose[3], para_Ex_Pose[4], para_Ex_Pose[5])));
+    setDepth(para_Feature);
+    if (cfg.estimate_td) td = para_Td;
+}
+
+// ------------------------------------------------------------------ the solve (Ceres restatement)
+namespace {
+struct LmRef { Landmark *l; int idx; bool is_const; double ub; };
+struct NormalEq {
+    int P, F;
+    Mat H;                    // P×P
+    std::vector<double> g;    // P
+    std::vector<double> Hll, gl;  // F
+    Mat Hpl;                  // F×P
+    double cost;
+};
+}  // namespace
+
+static void pose_dx(const double *x, const double *x0, double *dx) {  // marginalization_factor.cpp:374-393
+    for (int k = 0; k < 3; k++) dx[k] = x[k] - x0[k];
+    Q q0(x0[6], x0[3], x0[4], x0[5]), q(x[6], x[3], x[4], x[5]);
+    Q d = inverse(q0) * q;
+    V3 v = 2.0 * d.vec();
+    if (!(d.w >= 0)) v = -v;
+    dx[3] = v.x; dx[4] = v.y; dx[5] = v.z;
+}
+
+// Evaluate all factors at the flat parameters and accumulate the (robustified) normal equations.
+// Tangent layout: pose k at 6k, speed-bias k at 6(W+1)+9k, ex at 15(W+1), td at 15(W+1)+6.
+static void build_normal_eq(Estimator &e, const double pose[][7], const double sb[][9], const double *ex, double tdv,
+                            const std::vector<double> &feat, std::vector<LmRef> &lms, NormalEq &ne, bool withJ) {
+    const int W = e.W;
+    const int P = 15 * (W + 1) + 7;
+    const int oP = 0, oS = 6 * (W + 1), oE = 15 * (W + 1), oT = 15 * (W + 1) + 6;
+    ne.P = P; ne.F = (int)lms.size();
+    if (withJ) {
+        ne.H = Mat(P, P); ne.g.assign(P, 0.0); ne.Hll.assign(ne.F, 0.0); ne.gl.assign(ne.F, 0.0); ne.Hpl = Mat(ne.F, P);
+    }
+    double cost = 0;
+    // prior (MarginalizationFactor::Evaluate)
+    if (e.has_prior) {
+        int n = e.prior_n;
+        std::vector<double> dx(n, 0.0);
+        std::vector<int> map(n, 0);
+        for (int k = 0; k < W; k++) { pose_dx(pose[k], &e.prior_x0[k * 7], &dx[6 * k]); for (int d = 0; d < 6; d++) map[6 * k + d] = oP + 6 * k + d; }
+        for (int d = 0; d < 9; d++) { dx[6 * W + d] = sb[0][d] - e.prior_x0[W * 7 + d]; map[6 * W + d] = oS + d; }
+        pose_dx(ex, &e.prior_x0[W * 7 + 9], &dx[6 * W + 9]);
+        for (int d = 0; d < 6; d++) map[6 * W + 9 + d] = oE + d;
+        dx[6 * W + 15] = tdv - e.prior_x0[W * 7 + 16];
+        map[6 * W + 15] = oT;
+        // absent blocks have zero Jacobian columns; zero their dx so stale x0 never contributes
+        for (int k = 0; k < W; k++) if (!e.prior_present[k]) for (int d = 0; d < 6; d++) dx[6 * k + d] = 0;
+        if (!e.prior_present[W]) for (int d = 0; d < 9; d++) dx[6 * W + d] = 0;
+        if (!e.prior_present[W + 1]) for (int d = 0; d < 6; d++) dx[6 * W + 9 + d] = 0;
+        if (!e.prior_present[W + 2]) dx[6 * W + 15] = 0;
+        std::vector<double> r(n);
+        for (int i = 0; i < n; i++) {
+            double s = e.prior_r[i];
+            for (int j = 0; j < n; j++) s += e.prior_J(i, j) * dx[j];
+            r[i] = s;
+            cost += 0.5 * s * s;
+        }
+        if (withJ) {
+            for (int a = 0; a < n; a++) {
+                double gs = 0;
+                for (int i = 0; i < n; i++) gs += e.prior_J(i, a) * r[i];
+                ne.g[map[a]] += gs;
+                for (int b = 0; b < n; b++) {
+                    double s = 0;
+                    for (int i = 0; i < n; i++) s += e.prior_J(i, a) * e.prior_J(i, b);
+                    ne.H(map[a], map[b]) += s;
+                }
+            }
+        }
+    }
+    // IMU factors
+    for (int i = 0; i < W; i++) {
+        int j = i + 1;
+        if (e.pre_integrations[j]->sum_dt > 10.0) continue;
+        double r[15], Ji[15 * 7], Jsi[15 * 9], Jj[15 * 7], Jsj[15 * 9];
+        eval_imu(*e.pre_integrations[j], e.g, pose[i], sb[i], pose[j], sb[j], r, withJ ? Ji : nullptr, Jsi, Jj, Jsj);
+        for (int k = 0; k < 15; k++) cost += 0.5 * r[k] * r[k];
+        if (withJ) {
+            // assemble 15×30 local Jacobian: [pose_i(6) sb_i(9) pose_j(6) sb_j(9)]
+            double J[15][30];
+            int idx[30];
+            for (int k = 0; k < 15; k++) {
+                for (int d = 0; d < 6; d++) { J[k][d] = Ji[k * 7 + d]; J[k][15 + d] = Jj[k * 7 + d]; }
+                for (int d = 0; d < 9; d++) { J[k][6 + d] = Jsi[k * 9 + d]; J[k][21 + d] = Jsj[k * 9 + d]; }
+            }
+            for (int d = 0; d < 6; d++) { idx[d] = oP + 6 * i + d; idx[15 + d] = oP + 6 * j + d; }
+            for (int d = 0; d < 9; d++) { idx[6 + d] = oS + 9 * i + d; idx[21 + d] = oS + 9 * j + d; }
+            for (int a = 0; a < 30; a++) {
+                double gs = 0;
+                for (int k = 0; k < 15; k++) gs += J[k][a] * r[k];
+                ne.g[idx[a]] += gs;
+                for (int b = 0; b < 30; b++) {
+                    double s = 0;
+                    for (int k = 0; k < 15; k++) s += J[k][a] * J[k][b];
+                    ne.H(idx[a], idx[b]) += s;
+                }
+            }
+        }
+    }
+    // projection factors with CauchyLoss(1.0)
+    int nres = 0;
+    for (auto &lr : lms) {
+        Landmark &l = *lr.l;
+        int imu_i = l.start_frame;
+        double inv_dep = feat[lr.idx];
+        for (int k = 1; k < (int)l.obs.size(); k++) {
+            int imu_j = imu_i + k;
+            double r[2], Ji[14], Jj[14], Je[14], Jl[2], Jt[2];
+            eval_projection(e.cfg, pose[imu_i], pose[imu_j], ex, inv_dep, tdv, l.obs[0], l.obs[k], e.cfg.estimate_td != 0, r,
+                            withJ ? Ji : nullptr, Jj, Je, Jl, Jt);
+            nres++;
+            double s = r[0] * r[0] + r[1] * r[1];
+            cost += 0.5 * std::log(1.0 + s);  // rho(s) = log(1+s)
+            if (!withJ) continue;
+            double wgt = std::sqrt(1.0 / (1.0 + s));  // sqrt(rho'); rho'' < 0 => alpha = 0 (Triggs correction degenerate branch)
+            double J[2][20];
+            int idx[20];
+            for (int a = 0; a < 2; a++) {
+                for (int d = 0; d < 6; d++) { J[a][d] = wgt * Ji[a * 7 + d]; J[a][6 + d] = wgt * Jj[a * 7 + d]; J[a][12 + d] = wgt * Je[a * 7 + d]; }
+                J[a][18] = wgt * Jt[a];
+                J[a][19] = wgt * Jl[a];
+                r[a] *= wgt;
+            }
+            for (int d = 0; d < 6; d++) { idx[d] = oP + 6 * imu_i + d; idx[6 + d] = oP + 6 * imu_j + d; idx[12 + d] = oE + d; }
+            idx[18] = oT;
+            for (int a = 0; a < 19; a++) {
+                ne.g[idx[a]] += J[0][a] * r[0] + J[1][a] * r[1];
+                for (int b = 0; b < 19; b++) ne.H(idx[a], idx[b]) += J[0][a] * J[0][b] + J[1][a] * J[1][b];
+                ne.Hpl(lr.idx, idx[a]) += J[0][a] * J[0][19] + J[1][a] * J[1][19];
+            }
+            ne.Hll[lr.idx] += J[0][19] * J[0][19] + J[1][19] * J[1][19];
+            ne.gl[lr.idx] += J[0][19] * r[0] + J[1][19] * r[1];
+        }
+    }
+    e.last_stats.n_residuals = nres;
+    ne.cost = cost;
+}
+
+void Estimator::solve() {
+    const int P = 15 * (W + 1) + 7;
+    const int oE = 15 * (W + 1), oT = 15 * (W + 1) + 6;
+    // in-problem landmarks, list order (estimator.cpp:1243-1302)
+    std::vector<LmRef> lms;
+    {
+        int idx = -1;
+        for (auto &l : feature) {
+            if (l.is_dynamic) continue;
+            l.used_num = (int)l.obs.size();
+            if (!in_problem(l, W)) continue;
+            ++idx;
+            LmRef r;
+            r.l = &l; r.idx = idx;
+            r.is_const = (l.estimate_flag == 1 && cfg.fix_depth);
+            r.ub = (l.estimate_flag == 2) ? 2.0 / cfg.depth_max : DBL_MAX;
+            lms.push_back(r);
+        }
+    }
+    const int F = (int)lms.size();
+    // constness (estimator.cpp:1187-1212)
+    std::vector<uint8_t> active(P, 1);
+    bool ex_active;
+    if ((cfg.estimate_extrinsic && frame_count == W && norm(Vs[0]) > 0.2) || openExEstimation) { openExEstimation = true; ex_active = true; }
+    else ex_active = false;
+    bool td_active = cfg.estimate_td && !(norm(Vs[0]) < 0.2);
+    for (int d = 0; d < 6; d++) active[oE + d] = ex_active;
+    active[oT] = td_active;
+    std::vector<int> act;
+    for (int i = 0; i < P; i++) if (active[i]) act.push_back(i);
+    const int Pa = (int)act.size();
+    std::vector<int> lact;
+    for (int k = 0; k < F; k++) if (!lms[k].is_const) lact.push_back(k);
+    const int Fa = (int)lact.size();
+
+    // current point
+    double pose[MAXW + 1][7], sb[MAXW + 1][9], ex[7], tdv = cfg.estimate_td ? para_Td : td;
+    std::memcpy(pose, para_Pose, sizeof(pose)); std::memcpy(sb, para_SpeedBias, sizeof(sb)); std::memcpy(ex, para_Ex_Pose, sizeof(ex));
+    std::vector<double> feat = para_Feature;
+
+    NormalEq ne, ne2;
+    build_normal_eq(*this, pose, sb, ex, tdv, feat, lms, ne, true);
+    last_stats = SolveStats();
+    last_stats.initial_cost = ne.cost;
+    last_stats.n_landmarks = F; last_stats.n_var_landmarks = Fa;
+
+    // Jacobi column scaling, computed once at the initial point: 1/(1+||J_j||)
+    std::vector<double> sp(Pa), sl(Fa);
+    for (int a = 0; a < Pa; a++) sp[a] = 1.0 / (1.0 + std::sqrt(ne.H(act[a], act[a])));
+    for (int k = 0; k < Fa; k++) sl[k] = 1.0 / (1.0 + std::sqrt(ne.Hll[lact[k]]));
+
+    double radius = 1e4, mu = 1e-8;
+    bool reuse = false;
+    int invalid = 0;
+    // scaled reduced quantities
+    Mat Hs(Pa, Pa), Hpls(Fa, Pa);
+    std::vector<double> gs(Pa), gls(Fa), Hlls(Fa), dgp(Pa), dgl(Fa), gradp(Pa), gradl(Fa), gnp(Pa), gnl(Fa);
+    double alpha = 0, dogleg_norm = 0;
+    double cost = ne.cost;
+    auto gmax = [&]() {
+        double m = 0;
+        for (int a = 0; a < Pa; a++) m = std::max(m, std::fabs(ne.g[act[a]]));
+        for (int k = 0; k < Fa; k++) m = std::max(m, std::fabs(ne.gl[lact[k]]));
+        return m;
+    };
+    int iter = 0;
+    if (gmax() > 1e-10)
+    for (iter = 1; iter <= cfg.max_iterations; iter++) {
+        last_stats.iterations = iter;
+        if (!reuse) {
+            for (int a = 0; a < Pa; a++) {
+                gs[a] = sp[a] * ne.g[act[a]];
+                for (int b = 0; b < Pa; b++) Hs(a, b) = sp[a] * sp[b] * ne.H(act[a], act[b]);
+            }
+            for (int k = 0; k < Fa; k++) {
+                gls[k] = sl[k] * ne.gl[lact[k]];
+                Hlls[k] = sl[k] * sl[k] * ne.Hll[lact[k]];
+                for (int a = 0; a < Pa; a++) Hpls(k, a) = sl[k] * sp[a] * ne.Hpl(lact[k], act[a]);
+            }
+            for (int a = 0; a < Pa; a++) dgp[a] = std::sqrt(std::min(std::max(Hs(a, a), 1e-6), 1e32));
+            for (int k = 0; k < Fa; k++) dgl[k] = std::sqrt(std::min(std::max(Hlls[k], 1e-6), 1e32));
+            double g2 = 0;
+            for (int a = 0; a < Pa; a++) { gradp[a] = gs[a] / dgp[a]; g2 += gradp[a] * gradp[a]; }
+            for (int k = 0; k < Fa; k++) { gradl[k] = gls[k] / dgl[k]; g2 += gradl[k] * gradl[k]; }
+            // Cauchy point: alpha = |grad|^2 / |J D^-1 grad|^2
+            std::vector<double> sgp(Pa), sgl(Fa);
+            for (int a = 0; a < Pa; a++) sgp[a] = gradp[a] / dgp[a];
+            for (int k = 0; k < Fa; k++) sgl[k] = gradl[k] / dgl[k];
+            double jg2 = 0;
+            for (int a = 0; a < Pa; a++) { double s = 0; for (int b = 0; b < Pa; b++) s += Hs(a, b) * sgp[b]; jg2 += sgp[a] * s; }
+            for (int k = 0; k < Fa; k++) {
+                double s = 0;
+                for (int a = 0; a < Pa; a++) s += Hpls(k, a) * sgp[a];
+                jg2 += 2.0 * sgl[k] * s + sgl[k] * sgl[k] * Hlls[k];
+            }
+            alpha = g2 / jg2;
+            // Gauss-Newton step through the landmark Schur complement, regularised by mu * D^2
+            bool ok = false;
+            while (mu < 1.0) {
+                Mat S(Pa, Pa);
+                std::vector<double> rhs(Pa);
+                for (int a = 0; a < Pa; a++) { rhs[a] = gs[a]; for (int b = 0; b < Pa; b++) S(a, b) = Hs(a, b); S(a, a) += mu * dgp[a] * dgp[a]; }
+                std::vector<double> hll(Fa);
+                for (int k = 0; k < Fa; k++) {
+                    hll[k] = Hlls[k] + mu * dgl[k] * dgl[k];
+                    double inv = 1.0 / hll[k];
+                    for (int a = 0; a < Pa; a++) {
+                        double f = Hpls(k, a) * inv;
+                        if (f == 0.0) continue;
+                        rhs[a] -= f * gls[k];
+                        for (int b = 0; b < Pa; b++) S(a, b) -= f * Hpls(k, b);
+                    }
+                }
+                if (chol(S)) {
+                    chol_solve(S, rhs);
+                    bool fin = true;
+                    for (int a = 0; a < Pa; a++) fin &= std::isfinite(rhs[a]);
+                    if (fin) {
+                        for (int a = 0; a < Pa; a++) gnp[a] = -rhs[a] * dgp[a];
+                        for (int k = 0; k < Fa; k++) {
+                            double s = gls[k];
+                            for (int a = 0; a < Pa; a++) s -= Hpls(k, a) * rhs[a];
+                            gnl[k] = -(s / hll[k]) * dgl[k];
+                        }
+                        ok = true;
+                        break;
+                    }
+                }
+                mu *= 10.0;
+            }
+            if (!ok) break;  // linear solver failure at max mu: give up (Ceres: LINEAR_SOLVER_FAILURE)
+            reuse = true;
+        }
+        // traditional dogleg in the D-scaled space
+        double gnorm = 0, gnn = 0, gdot = 0;
+        for (int a = 0; a < Pa; a++) { gnorm += gradp[a] * gradp[a]; gnn += gnp[a] * gnp[a]; gdot += gradp[a] * gnp[a]; }
+        for (int k = 0; k < Fa; k++) { gnorm += gradl[k] * gradl[k]; gnn += gnl[k] * gnl[k]; gdot += gradl[k] * gnl[k]; }
+        gnorm = std::sqrt(gnorm); gnn = std::sqrt(gnn);
+        std::vector<double> stp(Pa), stl(Fa);
+        if (gnn <= radius) {
+            for (int a = 0; a < Pa; a++) stp[a] = gnp[a];
+            for (int k = 0; k < Fa; k++) stl[k] = gnl[k];
+            dogleg_norm = gnn;
+        } else if (gnorm * alpha >= radius) {
+            double f = -(radius / gnorm);
+            for (int a = 0; a < Pa; a++) stp[a] = f * gradp[a];
+            for (int k = 0; k < Fa; k++) stl[k] = f * gradl[k];
+            dogleg_norm = radius;
+        } else {
+            double b_dot_a = -alpha * gdot;
+            double a_sq = (alpha * gnorm) * (alpha * gnorm);
+            double bma = a_sq - 2 * b_dot_a + gnn * gnn;
+            double c = b_dot_a - a_sq;
+            double d = std::sqrt(c * c + bma * (radius * radius - a_sq));
+            double beta = (c <= 0) ? (d - c) / bma : (radius * radius - a_sq) / (d + c);
+            double n2 = 0;
+            for (int a = 0; a < Pa; a++) { stp[a] = (-alpha * (1.0 - beta)) * gradp[a] + beta * gnp[a]; n2 += stp[a] * stp[a]; }
+            for (int k = 0; k < Fa; k++) { stl[k] = (-alpha * (1.0 - beta)) * gradl[k] + beta * gnl[k]; n2 += stl[k] * stl[k]; }
+            dogleg_norm = std::sqrt(n2);
+        }
+        for (int a = 0; a < Pa; a++) stp[a] /= dgp[a];
+        for (int k = 0; k < Fa; k++) stl[k] /= dgl[k];
+        // model cost change = -(step^T g' + 1/2 step^T H' step)
+        double lin = 0, quad = 0;
+        for (int a = 0; a < Pa; a++) { lin += stp[a] * gs[a]; double s = 0; for (int b = 0; b < Pa; b++) s += Hs(a, b) * stp[b]; quad += stp[a] * s; }
+        for (int k = 0; k < Fa; k++) {
+            lin += stl[k] * gls[k];
+            double s = 0;
+            for (int a = 0; a < Pa; a++) s += Hpls(k, a) * stp[a];
+            quad += 2.0 * stl[k] * s + stl[k] * stl[k] * Hlls[k];
+        }
+        double model_change = -(lin + 0.5 * quad);
+        if (!(model_change > 0)) {
+            if (++invalid >= 5) break;
+            mu *= 10.0;
+            reuse = false;
+            continue;
+        }
+        invalid = 0;
+        // candidate = Plus(x, step .* scale)
+        double cpose[MAXW + 1][7], csb[MAXW + 1][9], cex[7], ctd = tdv;
+        std::memcpy(cpose, pose, sizeof(pose)); std::memcpy(csb, sb, sizeof(sb)); std::memcpy(cex, ex, sizeof(ex));
+        std::vector<double> cfeat = feat;
+        std::vector<double> delta(P, 0.0);
+        for (int a = 0; a < Pa; a++) delta[act[a]] = stp[a] * sp[a];
+        auto plus_pose = [](double *x, const double *d) {  // PoseLocalParameterization::Plus
+            x[0] += d[0]; x[1] += d[1]; x[2] += d[2];
+            Q q(x[6], x[3], x[4], x[5]);
+            Q r = normalized(q * deltaQ(V3(d[3], d[4], d[5])));
+            x[3] = r.x; x[4] = r.y; x[5] = r.z; x[6] = r.w;
+        };
+        for (int k = 0; k <= W; k++) {
+            plus_pose(cpose[k], &delta[6 * k]);
+            for (int d = 0; d < 9; d++) csb[k][d] += delta[6 * (W + 1) + 9 * k + d];
+        }
+        if (ex_active) plus_pose(cex, &delta[oE]);
+        if (td_active) ctd += delta[oT];
+        for (int k = 0; k < Fa; k++) {
+            int li = lact[k];
+            cfeat[li] += stl[k] * sl[k];
+            if (cfeat[li] > lms[li].ub) cfeat[li] = lms[li].ub;  // projection onto the box (line search omitted)
+        }
+        build_normal_eq(*this, cpose, csb, cex, ctd, cfeat, lms, ne2, true);
+        // parameter tolerance
+        double xn = 0, dn = 0;
+        for (int k = 0; k <= W; k++) {
+            for (int d = 0; d < 7; d++) { xn += pose[k][d] * pose[k][d]; double t = pose[k][d] - cpose[k][d]; dn += t * t; }
+            for (int d = 0; d < 9; d++) { xn += sb[k][d] * sb[k][d]; double t = sb[k][d] - csb[k][d]; dn += t * t; }
+        }
+        if (ex_active) for (int d = 0; d < 7; d++) { xn += ex[d] * ex[d]; double t = ex[d] - cex[d]; dn += t * t; }
+        if (td_active) { xn += tdv * tdv; dn += (tdv - ctd) * (tdv - ctd); }
+        for (int k = 0; k < Fa; k++) { int li = lact[k]; xn += feat[li] * feat[li]; double t = feat[li] - cfeat[li]; dn += t * t; }
+        if (std::sqrt(dn) <= 1e-8 * (std::sqrt(xn) + 1e-8)) break;
+        if (std::fabs(cost - ne2.cost) <= 1e-6 * cost) break;
+        double rel = (cost - ne2.cost) / model_change;
+        if (rel > 1e-3) {
+            std::memcpy(pose, cpose, sizeof(pose)); std::memcpy(sb, csb, sizeof(sb)); std::memcpy(ex, cex, sizeof(ex));
+            tdv = ctd;
+            feat = cfeat;
+            std::swap(ne, ne2);
+            cost = ne.cost;
+            last_stats.successful++;
+            if (rel < 0.25) radius *= 0.5;
+            if (rel > 0.75) radius = std::max(radius, 3.0 * dogleg_norm);
+            mu = std::max(1e-8, 2.0 * mu / 10.0);
+            reuse = false;
+            if (gmax() <= 1e-10) break;
+        } else {
+            radius *= 0.5;
+            reuse = true;
+        }
+    }
+    last_stats.final_cost = cost;
+    std::memcpy(para_Pose, pose, sizeof(pose)); std::memcpy(para_SpeedBias, sb, sizeof(sb)); std::memcpy(para_Ex_Pose, ex, sizeof(ex));
+    if (cfg.estimate_td) para_Td = tdv;
+    para_Feature = feat;
+}
+
+// ------------------------------------------------------------------ marginalisation (marginalization_factor.cpp:181-315)
+static void marg_finish(Estimator &e, Mat &A, std::vector<double> &b, int m, int n) {
+    const double eps = 1e-8;
+    // Amm^-1 via symmetric eigen-decomposition with truncation
+    Mat Amm(m, m);
+    for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Amm(i, j) = 0.5 * (A(i, j) + A(j, i));
+    std::vector<double> w;
+    Mat V;
+    sym_eig(Amm, w, V);
+    Mat Ainv(m, m);
+    for (int i = 0; i < m; i++)
+        for (int j = 0; j < m; j++) {
+            double s = 0;
+            for (int k = 0; k < m; k++) if (w[k] > eps) s += V(i, k) * V(j, k) / w[k];
+            Ainv(i, j) = s;
+        }
+    // Arm * Amm_inv
+    Mat T1(n, m);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < m; j++) {
+            double s = 0;
+            for (int k = 0; k < m; k++) s += A(m + i, k) * Ainv(k, j);
+            T1(i, j) = s;
+        }
+    Mat Ar(n, n);
+    std::vector<double> br(n);
+    for (int i = 0; i < n; i++) {
+        double s = b[m + i];
+        for (int k = 0; k < m; k++) s -= T1(i, k) * b[k];
+        br[i] = s;
+        for (int j = 0; j < n; j++) {
+            double t = A(m + i, m + j);
+            for (int k = 0; k < m; k++) t -= T1(i, k) * A(k, m + j);
+            Ar(i, j) = t;
+        }
+    }
+    Mat As(n, n);
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) As(i, j) = 0.5 * (Ar(i, j) + Ar(j, i));
+    std::vector<double> w2;
+    Mat V2;
+    sym_eig(As, w2, V2);
+    e.prior_n = n;
+    e.prior_J = Mat(n, n);
+    e.prior_r.assign(n, 0.0);
+    for (int k = 0; k < n; k++) {
+        double S = w2[k] > eps ? w2[k] : 0.0, Sinv = w2[k] > eps ? 1.0 / w2[k] : 0.0;
+        double ss = std::sqrt(S), si = std::sqrt(Sinv);
+        double vb = 0;
+        for (int i = 0; i < n; i++) { e.prior_J(k, i) = ss * V2(i, k); vb += V2(i, k) * br[i]; }
+        e.prior_r[k] = si * vb;
+    }
+}
+
+void Estimator::marginalize_old() {  // estimator.cpp:1376-1502
+    const int n = 6 * W + 16;
+    // m blocks: pose0(6) sb0(9) then landmarks with start_frame==0 (list order)
+    std::vector<LmRef> lms;
+    {
+        int idx = -1;
+        for (auto &l : feature) {
+            if (l.is_dynamic) continue;
+            l.used_num = (int)l.obs.size();
+            if (!in_problem(l, W)) continue;
+            ++idx;
+            if (l.start_frame != 0) continue;
+            LmRef r; r.l = &l; r.idx = idx; r.is_const = false; r.ub = DBL_MAX;
+            lms.push_back(r);
+        }
+    }
+    const int m = 15 + (int)lms.size();
+    const int pos = m + n;
+    Mat A(pos, pos);
+    std::vector<double> b(pos, 0.0);
+    std::vector<uint8_t> present(W + 3, 0);
+    const int rP = m, rS = m + 6 * W, rE = m + 6 * W + 9, rT = m + 6 * W + 15;
+    auto poseIdx = [&](int k) { return k == 0 ? 0 : rP + 6 * (k - 1); };  // window pose k -> A index
+    double tdv = cfg.estimate_td ? para_Td : td;
+    auto accumulate = [&](int nr, int nc, const double *J, const double *r, const int *idx) {
+        for (int a = 0; a < nc; a++) {
+            double gsum = 0;
+            for (int k = 0; k < nr; k++) gsum += J[k * nc + a] * r[k];
+            b[idx[a]] += gsum;
+            for (int c = 0; c < nc; c++) {
+                double s = 0;
+                for (int k = 0; k < nr; k++) s += J[k * nc + a] * J[k * nc + c];
+                A(idx[a], idx[c]) += s;
+            }
+        }
+    };
+    if (has_prior) {
+        int pn = prior_n;
+        std::vector<double> dx(pn, 0.0);
+        std::vector<int> map(pn, 0);
+        for (int k = 0; k < W; k++) { pose_dx(para_Pose[k], &prior_x0[k * 7], &dx[6 * k]); for (int d = 0; d < 6; d++) map[6 * k + d] = poseIdx(k) + d; }
+        for (int d = 0; d < 9; d++) { dx[6 * W + d] = para_SpeedBias[0][d] - prior_x0[W * 7 + d]; map[6 * W + d] = 6 + d; }
+        pose_dx(para_Ex_Pose, &prior_x0[W * 7 + 9], &dx[6 * W + 9]);
+        for (int d = 0; d < 6; d++) map[6 * W + 9 + d] = rE + d;
+        dx[6 * W + 15] = tdv - prior_x0[W * 7 + 16];
+        map[6 * W + 15] = rT;
+        for (int k = 0; k < W; k++) if (!prior_present[k]) for (int d = 0; d < 6; d++) dx[6 * k + d] = 0;
+        if (!prior_present[W]) for (int d = 0; d < 9; d++) dx[6 * W + d] = 0;
+        if (!prior_present[W + 1]) for (int d = 0; d < 6; d++) dx[6 * W + 9 + d] = 0;
+        if (!prior_present[W + 2]) dx[6 * W + 15] = 0;
+        std::vector<double> r(pn);
+        for (int i = 0; i < pn; i++) { double s = prior_r[i]; for (int j = 0; j < pn; j++) s += prior_J(i, j) * dx[j]; r[i] = s; }
+        accumulate(pn, pn, prior_J.d.data(), r.data(), map.data());
+        for (int k = 1; k < W; k++) if (prior_present[k]) present[k - 1] = 1;
+        if (prior_present[W + 1]) present[W + 1] = 1;
+        if (prior_present[W + 2]) present[W + 2] = 1;
+    }
+    if (pre_integrations[1]->sum_dt < 10.0) {
+        double r[15], Ji[15 * 7], Jsi[15 * 9], Jj[15 * 7], Jsj[15 * 9];
+        eval_imu(*pre_integrations[1], g, para_Pose[0], para_SpeedBias[0], para_Pose[1], para_SpeedBias[1], r, Ji, Jsi, Jj, Jsj);
+        double J[15 * 30];
+        int idx[30];
+        for (int k = 0; k < 15; k++) {
+            for (int d = 0; d < 6; d++) { J[k * 30 + d] = Ji[k * 7 + d]; J[k * 30 + 15 + d] = Jj[k * 7 + d]; }
+            for (int d = 0; d < 9; d++) { J[k * 30 + 6 + d] = Jsi[k * 9 + d]; J[k * 30 + 21 + d] = Jsj[k * 9 + d]; }
+        }
+        for (int d = 0; d < 6; d++) { idx[d] = d; idx[15 + d] = poseIdx(1) + d; }
+        for (int d = 0; d < 9; d++) { idx[6 + d] = 6 + d; idx[21 + d] = rS + d; }
+        accumulate(15, 30, J, r, idx);
+        present[0] = 1;
+        present[W] = 1;
+    }
+    for (size_t li = 0; li < lms.size(); li++) {
+        Landmark &l = *lms[li].l;
+        double inv_dep = para_Feature[lms[li].idx];
+        for (int k = 1; k < (int)l.obs.size(); k++) {
+            int imu_j = k;
+            double r[2], Ji[14], Jj[14], Je[14], Jl[2], Jt[2];
+            eval_projection(cfg, para_Pose[0], para_Pose[imu_j], para_Ex_Pose, inv_dep, tdv, l.obs[0], l.obs[k], cfg.estimate_td != 0, r, Ji, Jj, Je, Jl, Jt);
+            // ResidualBlockInfo::Evaluate loss re-weighting (marginalization_factor.cpp:39-72) with CauchyLoss(1.0)
+            double sq_norm = r[0] * r[0] + r[1] * r[1];
+            double rho1 = 1.0 / (1.0 + sq_norm), rho2 = -rho1 * rho1;
+            double sqrt_rho1 = std::sqrt(rho1), residual_scaling, alpha_sq_norm;
+            if (sq_norm == 0.0 || rho2 <= 0.0) { residual_scaling = sqrt_rho1; alpha_sq_norm = 0.0; }
+            else { double D = 1.0 + 2.0 * sq_norm * rho2 / rho1; double al = 1.0 - std::sqrt(D); residual_scaling = sqrt_rho1 / (1 - al); alpha_sq_norm = al / sq_norm; }
+            double J[2 * 20];
+            int idx[20];
+            for (int a = 0; a < 2; a++) {
+                for (int d = 0; d < 6; d++) { J[a * 20 + d] = Ji[a * 7 + d]; J[a * 20 + 6 + d] = Jj[a * 7 + d]; J[a * 20 + 12 + d] = Je[a * 7 + d]; }
+                J[a * 20 + 18] = Jt[a];
+                J[a * 20 + 19] = Jl[a];
+            }
+            for (int c = 0; c < 20; c++) {
+                double rtJ = r[0] * J[c] + r[1] * J[20 + c];
+                J[c] = sqrt_rho1 * (J[c] - alpha_sq_norm * r[0] * rtJ);
+                J[20 + c] = sqrt_rho1 * (J[20 + c] - alpha_sq_norm * r[1] * rtJ);
+            }
+            r[0] *= residual_scaling; r[1] *= residual_scaling;
+            for (int d = 0; d < 6; d++) { idx[d] = d; idx[6 + d] = poseIdx(imu_j) + d; idx[12 + d] = rE + d; }
+            idx[18] = rT;
+            idx[19] = 15 + (int)li;
+            if (cfg.estimate_td) accumulate(2, 20, J, r, idx);
+            else {
+                // ProjectionFactor has no td block: drop column 18
+                double J2[2 * 19];
+                int idx2[19];
+                for (int a = 0; a < 2; a++) for (int c = 0, o = 0; c < 20; c++) if (c != 18) J2[a * 19 + o++] = J[a * 20 + c];
+                for (int c = 0, o = 0; c < 20; c++) if (c != 18) idx2[o++] = idx[c];
+                accumulate(2, 19, J2, r, idx2);
+            }
+            present[imu_j - 1] = 1;
+            present[W + 1] = 1;
+            if (cfg.estimate_td) present[W + 2] = 1;
+        }
+    }
+    marg_finish(*this, A, b, m, n);
+    // keep_block_data: values at marginalisation time, shifted i -> i-1 (addr_shift, estimator.cpp:1483-1497)
+    prior_x0.assign(W * 7 + 17, 0.0);
+    for (int k = 1; k <= W; k++) for (int d = 0; d < 7; d++) prior_x0[(k - 1) * 7 + d] = para_Pose[k][d];
+    for (int d = 0; d < 9; d++) prior_x0[W * 7 + d] = para_SpeedBias[1][d];
+    for (int d = 0; d < 7; d++) prior_x0[W * 7 + 9 + d] = para_Ex_Pose[d];
+    prior_x0[W * 7 + 16] = tdv;
+    prior_present = present;
+    has_prior = true;
+}
+
+void Estimator::marginalize_second_new() {  // estimator.cpp:1503-1574
+    if (!(has_prior && prior_present[W - 1])) return;
+    const int n = 6 * W + 16;
+    const int m = 6, pos = m + n;
+    Mat A(pos, pos);
+    std::vector<double> b(pos, 0.0);
+    double tdv = cfg.estimate_td ? para_Td : td;
+    int pn = prior_n;
+    std::vector<double> dx(pn, 0.0);
+    std::vector<int> map(pn, 0);
+    // prior slot k -> new index: k == W-1 -> m block; others keep their canonical slot (new slot W-1 stays empty)
+    for (int k = 0; k < W; k++) {
+        pose_dx(para_Pose[k], &prior_x0[k * 7], &dx[6 * k]);
+        for (int d = 0; d < 6; d++) map[6 * k + d] = (k == W - 1) ? d : m + 6 * k + d;
+    }
+    for (int d = 0; d < 9; d++) { dx[6 * W + d] = para_SpeedBias[0][d] - prior_x0[W * 7 + d]; map[6 * W + d] = m + 6 * W + d; }
+    pose_dx(para_Ex_Pose, &prior_x0[W * 7 + 9], &dx[6 * W + 9]);
+    for (int d = 0; d < 6; d++) map[6 * W + 9 + d] = m + 6 * W + 9 + d;
+    dx[6 * W + 15] = tdv - prior_x0[W * 7 + 16];
+    map[6 * W + 15] = m + 6 * W + 15;
+    for (int k = 0; k < W; k++) if (!prior_present[k]) for (int d = 0; d < 6; d++) dx[6 * k + d] = 0;
+    if (!prior_present[W]) for (int d = 0; d < 9; d++) dx[6 * W + d] = 0;
+    if (!prior_present[W + 1]) for (int d = 0; d < 6; d++) dx[6 * W + 9 + d] = 0;
+    if (!prior_present[W + 2]) dx[6 * W + 15] = 0;
+    std::vector<double> r(pn);
+    for (int i = 0; i < pn; i++) { double s = prior_r[i]; for (int j = 0; j < pn; j++) s += prior_J(i, j) * dx[j]; r[i] = s; }
+    for (int a = 0; a < pn; a++) {
+        double gsum = 0;
+        for (int k = 0; k < pn; k++) gsum += prior_J(k, a) * r[k];
+        b[map[a]] += gsum;
+        for (int c = 0; c < pn; c++) {
+            double s = 0;
+            for (int k = 0; k < pn; k++) s += prior_J(k, a) * prior_J(k, c);
+            A(map[a], map[c]) += s;
+        }
+    }
+    marg_finish(*this, A, b, m, n);
+    std::vector<double> x0(W * 7 + 17, 0.0);
+    for (int k = 0; k < W - 1; k++) for (int d = 0; d < 7; d++) x0[k * 7 + d] = para_Pose[k][d];
+    for (int d = 0; d < 7; d++) x0[(W - 1) * 7 + d] = para_Pose[W][d];  // slot W-1 <- pose W (absent)
+    for (int d = 0; d < 9; d++) x0[W * 7 + d] = para_SpeedBias[0][d];
+    for (int d = 0; d < 7; d++) x0[W * 7 + 9 + d] = para_Ex_Pose[d];
+    x0[W * 7 + 16] = tdv;
+    prior_x0 = x0;
+    prior_present[W - 1] = 0;
+}
+
+void Estimator::optimization() {  // estimator.cpp:1161-1578
+    vector2double();
+    solve();
+    double2vector();
+    if (frame_count < W) return;
+    if (marginalization_flag == 0) {
+        vector2double();
+        marginalize_old();
+    } else {
+        if (has_prior && prior_present[W - 1]) {
+            vector2double();
+            marginalize_second_new();
+        }
+    }
+}
+
+// ------------------------------------------------------------------ window management
+void Estimator::slideWindow() {  // estimator.cpp:1580-1689
+    if (marginalization_flag == 0) {
+        back_R0 = Rs[0];
+        back_P0 = Ps[0];
+        if (frame_count == W) {
+            for (int i = 0; i < W; i++) {
+                Headers[i] = Headers[i + 1];
+                std::swap(Ps[i], Ps[i + 1]);
+                std::swap(Rs[i], Rs[i + 1]);
+                std::swap(pre_integrations[i], pre_integrations[i + 1]);
+                std::swap(Vs[i], Vs[i + 1]);
+                std::swap(Bas[i], Bas[i + 1]);
+                std::swap(Bgs[i], Bgs[i + 1]);
+            }
+            Headers[W] = Headers[W - 1];
+            Ps[W] = Ps[W - 1]; Rs[W] = Rs[W - 1]; Vs[W] = Vs[W - 1]; Bas[W] = Bas[W - 1]; Bgs[W] = Bgs[W - 1];
+            delete pre_integrations[W];
+            pre_integrations[W] = new Integration(cfg, acc_0, gyr_0, Bas[W], Bgs[W]);
+            slideWindowOld();
+        }
+    } else {
+        if (frame_count == W) {
+            Headers[W - 1] = Headers[W];
+            Ps[W - 1] = Ps[W]; Rs[W - 1] = Rs[W];
+            Integration *last = pre_integrations[W];
+            for (size_t i = 0; i < last->dt_buf.size(); i++)
+                pre_integrations[W - 1]->push_back(last->dt_buf[i], last->acc_buf[i], last->gyr_buf[i]);
+            Vs[W - 1] = Vs[W]; Bas[W - 1] = Bas[W]; Bgs[W - 1] = Bgs[W];
+            delete pre_integrations[W];
+            pre_integrations[W] = new Integration(cfg, acc_0, gyr_0, Bas[W], Bgs[W]);
+            slideWindowNew();
+        }
+    }
+}
+void Estimator::slideWindowNew() { removeFront(frame_count); }  // :1692-1696
+void Estimator::slideWindowOld() {                               // :1699-1716
+    if (solver_flag == 1) {
+        M3 R0 = back_R0 * ric, R1 = Rs[0] * ric;
+        V3 P0 = back_P0 + back_R0 * tic, P1 = Ps[0] + Rs[0] * tic;
+        removeBackShiftDepth(R0, P0, R1, P1);
+    } else
+        removeBack();
+}
+
+void Estimator::movingConsistencyCheck() {  // estimator.cpp:1944-2009
+    for (auto &l : feature) {
+        l.used_num = (int)l.obs.size();
+        if (!in_problem(l, W)) continue;
+        double depth = l.estimated_depth;
+        if (depth < 0) continue;
+        double err = 0, err3D = 0;
+        int errCnt = 0;
+        int imu_i = l.start_frame;
+        V3 pts_i(l.obs[0].x, l.obs[0].y, l.obs[0].z);
+        for (int k = 1; k < (int)l.obs.size(); k++) {
+            int imu_j = imu_i + k;
+            V3 pts_j(l.obs[k].x, l.obs[k].y, l.obs[k].z);
+            V3 pts_w = Rs[imu_i] * (ric * (depth * pts_i) + tic) + Ps[imu_i];
+            V3 pts_cj = T(ric) * (T(Rs[imu_j]) * (pts_w - Ps[imu_j]) - tic);
+            double rx = pts_cj.x / pts_cj.z - pts_j.x, ry = pts_cj.y / pts_cj.z - pts_j.y;
+            err += std::sqrt(rx * rx + ry * ry);
+            err3D += norm(pts_cj - pts_j) / depth;  // sic: metric point vs normalised observation (:1956-1963)
+            errCnt++;
+        }
+        if (errCnt > 0) l.is_dynamic = (cfg.focal_length * err / errCnt > 10 || err3D / errCnt > 2.0);
+    }
+}
+bool Estimator::failureDetection() {  // estimator.cpp:1113-1159
+    if (norm(Bas[W]) > 2.5) return true;
+    if (norm(Bgs[W]) > 1.0) return true;
+    V3 tmp_P = Ps[W];
+    if (norm(tmp_P - last_P) > 5) return true;
+    if (std::fabs(tmp_P.z - last_P.z) > 1) return true;
+    return false;
+}
+
+int Estimator::processImage(std::map<int, std::array<double, 7>> &image, const uint16_t *depth, double stamp) {  // :156-374
+    depth_img = depth;  // FeatureManager::inputDepth
+    double curTime = stamp + td;
+    if (!IMUAvailable(curTime)) return 1;  // upstream busy-waits (:178-183); the adapter keeps the wait loop
+    marginalization_flag = addFeatureCheckParallax(frame_count, image, td) ? 0 : 1;
+    Headers[frame_count] = stamp;
+    {
+        // getIMUInterval :1910-1942
+        std::vector<ImuSample> v;
+        while (imu_head < imu_buf.size() && imu_buf[imu_head].t <= prevTime) imu_head++;
+        while (imu_head < imu_buf.size() && imu_buf[imu_head].t < curTime) v.push_back(imu_buf[imu_head++]);
+        v.push_back(imu_buf[imu_head]);
+        if (!initFirstPoseFlag) initFirstIMUPose(v);
+        for (size_t i = 0; i < v.size(); i++) {
+            double dt;
+            if (i == 0) dt = v[i].t - prevTime;
+            else if (i == v.size() - 1) dt = curTime - v[i - 1].t;
+            else dt = v[i].t - v[i - 1].t;
+            processIMU(dt, v[i].acc, v[i].gyr);
+        }
+        prevTime = curTime;
+        if (imu_head > 4096) { imu_buf.erase(imu_buf.begin(), imu_buf.begin() + imu_head); imu_head = 0; }
+    }
+    if (solver_flag == 0) {
+        // static_init / depth branch :260-316
+        triangulateWithDepth();
+        if (frame_count == W) {
+            solveGyroscopeBias();
+            for (int j = 0; j <= W; j++) pre_integrations[j]->repropagate(V3(), Bgs[j]);
+            optimization();
+            latest_Bg = Bgs[frame_count];  // updateLatestStates :1768-1788 (only latest_Bg feeds back into the hot path)
+            solver_flag = 1;
+            slideWindow();
+            last_R = Rs[W]; last_P = Ps[W]; last_R0 = Rs[0]; last_P0 = Ps[0];
+        }
+        if (frame_count < W) {
+            frame_count++;
+            int p = frame_count - 1;
+            Ps[frame_count] = Ps[p]; Vs[frame_count] = Vs[p]; Rs[frame_count] = Rs[p]; Bas[frame_count] = Bas[p]; Bgs[frame_count] = Bgs[p];
+        }
+    } else {
+        triangulateWithDepth();
+        optimization();
+        movingConsistencyCheck();
+        if (failureDetection()) {
+            // failure_occur = true; clearState(); setParameter();  -- clearState() resets failure_occur (:103)
+            clearState();
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) ric(i, j) = cfg.ric[i * 3 + j];
+            tic = V3(cfg.tic[0], cfg.tic[1], cfg.tic[2]);
+            td = cfg.td;
+            reboot_count++;
+            return 2;
+        }
+        slideWindow();
+        removeFailures();
+        last_R = Rs[W]; last_P = Ps[W]; last_R0 = Rs[0]; last_P0 = Ps[0];
+        latest_Bg = Bgs[frame_count];
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ nodelet-side driver
+int Pipeline::feed(const uint8_t *gray, const uint16_t *depth, double t) {
+    if (!est.IMUAvailable(t + est.td)) return -1;  // caller contract: IMU pushed through t + td (upstream busy-waits, estimator.cpp:178-183)
+    if (first_image_flag) {  // estimator_nodelet.cpp:234-240
+        first_image_flag = false;
+        last_image_time = t;
+        return 0;
+    }
+    double R[9];
+    est.predictMotion(last_image_time, t + est.td, R);  // :309-313
+    tracker.readImage(gray, t, R, true);
+    last_image_time = t;
+    tracker.updateIDs();  // :324-330
+    std::map<int, std::array<double, 7>> image;  // :336-363
+    for (size_t j = 0; j < tracker.ids.size(); j++)
+        if (tracker.track_cnt[j] > 1)
+            image[tracker.ids[j]] = {(double)tracker.cur_un_pts[j].x, (double)tracker.cur_un_pts[j].y, 1.0, (double)tracker.cur_pts[j].x,
+                                     (double)tracker.cur_pts[j].y, (double)tracker.pts_velocity[j].x, (double)tracker.pts_velocity[j].y};
+    if (!init_pub) { init_pub = true; return 0; }          // :365-368
+    if (!init_feature) { init_feature = true; return 0; }  // :371-377
+    if (image.empty()) return 0;
+    int rc = est.processImage(image, depth, t);
+    if (rc == 1) return 0;
+    frames_processed++;
+    return 1;
+}
+
+}  // namespace ovio

@@ -1,0 +1,202 @@
+// ORACLE (test infrastructure only — never linked into or called by the product path).
+// Flat C API over the CPU restatement so that tests/ and bench.py's cpu_baseline leg can drive it via ctypes.
+#include <array>
+#include "oracle.h"
+
+using namespace ovio;
+using namespace om;
+
+extern "C" {
+
+int ovio_config_size() { return (int)sizeof(Config); }
+void ovio_config_default(Config *c) { *c = Config(); }
+
+// ---------------------------------------------------------------- full pipeline (tracker + estimator + nodelet glue)
+void *ovio_pipeline_create(const Config *c) { return new Pipeline(*c); }
+void ovio_pipeline_destroy(void *h) { delete (Pipeline *)h; }
+void ovio_push_imu(void *h, double t, const double *acc, const double *gyr) {
+    ((Pipeline *)h)->est.inputIMU(t, V3(acc[0], acc[1], acc[2]), V3(gyr[0], gyr[1], gyr[2]));
+}
+void ovio_push_imu_n(void *h, int n, const double *t, const double *acc, const double *gyr) {
+    for (int i = 0; i < n; i++)
+        ((Pipeline *)h)->est.inputIMU(t[i], V3(acc[3 * i], acc[3 * i + 1], acc[3 * i + 2]), V3(gyr[3 * i], gyr[3 * i + 1], gyr[3 * i + 2]));
+}
+int ovio_feed(void *h, const uint8_t *gray, const uint16_t *depth, double t) { return ((Pipeline *)h)->feed(gray, depth, t); }
+
+// out: [solver_flag, frame_count, marginalization_flag, td, n_landmarks, last_track_num, reboot_count, frames_processed,
+//       iterations, successful, initial_cost, final_cost, n_lm_in_problem, n_residuals, n_var_landmarks, has_prior]
+void ovio_get_status(void *h, double *out) {
+    Pipeline *p = (Pipeline *)h;
+    Estimator &e = p->est;
+    out[0] = e.solver_flag; out[1] = e.frame_count; out[2] = e.marginalization_flag; out[3] = e.td;
+    out[4] = (double)e.feature.size(); out[5] = e.last_track_num; out[6] = e.reboot_count; out[7] = p->frames_processed;
+    out[8] = e.last_stats.iterations; out[9] = e.last_stats.successful; out[10] = e.last_stats.initial_cost;
+    out[11] = e.last_stats.final_cost; out[12] = e.last_stats.n_landmarks; out[13] = e.last_stats.n_residuals;
+    out[14] = e.last_stats.n_var_landmarks; out[15] = e.has_prior;
+}
+// window arrays, each (W+1) rows: P(3) Q(wxyz 4) V(3) Ba(3) Bg(3) stamp(1) = 17 doubles per frame
+void ovio_get_window(void *h, double *out) {
+    Estimator &e = ((Pipeline *)h)->est;
+    for (int i = 0; i <= e.W; i++) {
+        double *o = out + 17 * i;
+        Q q = fromR(e.Rs[i]);
+        o[0] = e.Ps[i].x; o[1] = e.Ps[i].y; o[2] = e.Ps[i].z;
+        o[3] = q.w; o[4] = q.x; o[5] = q.y; o[6] = q.z;
+        o[7] = e.Vs[i].x; o[8] = e.Vs[i].y; o[9] = e.Vs[i].z;
+        o[10] = e.Bas[i].x; o[11] = e.Bas[i].y; o[12] = e.Bas[i].z;
+        o[13] = e.Bgs[i].x; o[14] = e.Bgs[i].y; o[15] = e.Bgs[i].z;
+        o[16] = e.Headers[i];
+    }
+}
+void ovio_get_extrinsic(void *h, double *out) {  // tic(3) + ric row-major (9) + td
+    Estimator &e = ((Pipeline *)h)->est;
+    out[0] = e.tic.x; out[1] = e.tic.y; out[2] = e.tic.z;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) out[3 + i * 3 + j] = e.ric(i, j);
+    out[12] = e.td;
+}
+// landmark table: per landmark [id, start_frame, n_obs, estimated_depth, estimate_flag, solve_flag, is_dynamic]
+int ovio_get_landmarks(void *h, int cap, double *out) {
+    Estimator &e = ((Pipeline *)h)->est;
+    int n = 0;
+    for (auto &l : e.feature) {
+        if (n >= cap) break;
+        double *o = out + 7 * n++;
+        o[0] = l.feature_id; o[1] = l.start_frame; o[2] = (double)l.obs.size(); o[3] = l.estimated_depth;
+        o[4] = l.estimate_flag; o[5] = l.solve_flag; o[6] = l.is_dynamic;
+    }
+    return (int)e.feature.size();
+}
+
+static int tracker_get(Tracker &t, int cap, int *ids, int *cnt, float *cur, float *un, float *vel) {
+    int n = (int)t.ids.size();
+    for (int i = 0; i < n && i < cap; i++) {
+        ids[i] = t.ids[i]; cnt[i] = t.track_cnt[i];
+        cur[2 * i] = t.cur_pts[i].x; cur[2 * i + 1] = t.cur_pts[i].y;
+        un[2 * i] = t.cur_un_pts[i].x; un[2 * i + 1] = t.cur_un_pts[i].y;
+        vel[2 * i] = t.pts_velocity[i].x; vel[2 * i + 1] = t.pts_velocity[i].y;
+    }
+    return n;
+}
+int ovio_get_tracks(void *h, int cap, int *ids, int *cnt, float *cur, float *un, float *vel) {
+    return tracker_get(((Pipeline *)h)->tracker, cap, ids, cnt, cur, un, vel);
+}
+
+// ---------------------------------------------------------------- stand-alone tracker (front-end parity)
+void *ovio_tracker_create(const Config *c) { return new Tracker(*c); }
+void ovio_tracker_destroy(void *h) { delete (Tracker *)h; }
+void ovio_tracker_read(void *h, const uint8_t *gray, double t, const double *R, int publish) {
+    Tracker *tr = (Tracker *)h;
+    tr->readImage(gray, t, R, publish != 0);
+    tr->updateIDs();
+}
+int ovio_tracker_get(void *h, int cap, int *ids, int *cnt, float *cur, float *un, float *vel) {
+    return tracker_get(*(Tracker *)h, cap, ids, cnt, cur, un, vel);
+}
+int ovio_tracker_grid(void *h, int *rects /*4 per cell*/, int *threshold) {
+    Tracker *tr = (Tracker *)h;
+    for (size_t i = 0; i < tr->grids_rect.size(); i++) {
+        rects[4 * i] = tr->grids_rect[i].x; rects[4 * i + 1] = tr->grids_rect[i].y;
+        rects[4 * i + 2] = tr->grids_rect[i].w; rects[4 * i + 3] = tr->grids_rect[i].h;
+    }
+    *threshold = tr->grids_threshold;
+    return (int)tr->grids_rect.size();
+}
+
+// ---------------------------------------------------------------- primitives (known-answer tests)
+void ovio_cam_lift(const Config *c, int n, const double *uv, double *xy) {
+    for (int i = 0; i < n; i++) cam_lift(*c, uv[2 * i], uv[2 * i + 1], xy[2 * i], xy[2 * i + 1]);
+}
+void ovio_cam_project(const Config *c, int n, const double *XYZ, double *uv) {
+    for (int i = 0; i < n; i++) cam_project(*c, XYZ[3 * i], XYZ[3 * i + 1], XYZ[3 * i + 2], uv[2 * i], uv[2 * i + 1]);
+}
+void ovio_pyr_down(const uint8_t *src, int w, int h, uint8_t *dst) {
+    Image s, d;
+    s.w = w; s.h = h; s.d.assign(src, src + (size_t)w * h);
+    pyr_down(s, d);
+    std::memcpy(dst, d.d.data(), d.d.size());
+}
+int ovio_fast_score(const uint8_t *patch7x7) { return fast_corner_score(patch7x7 + 3 * 7 + 3, 7, 10); }
+int ovio_fast_roi(const uint8_t *img, int W, int H, int rx, int ry, int rw, int rh, int cap, float *out /*x,y,score*/) {
+    std::vector<KeyPt> k;
+    fast_detect_roi(img, W, H, rx, ry, rw, rh, k);
+    for (size_t i = 0; i < k.size() && (int)i < cap; i++) { out[3 * i] = k[i].x; out[3 * i + 1] = k[i].y; out[3 * i + 2] = k[i].response; }
+    return (int)k.size();
+}
+void ovio_circle_hw(int radius, int *hw) {
+    std::vector<int> v;
+    circle_halfwidths(radius, v);
+    for (int i = 0; i <= radius; i++) hw[i] = v[i];
+}
+void ovio_lk(const uint8_t *prev, const uint8_t *next, int w, int h, int maxLevel, int n, const float *prevPts, float *nextPts,
+             uint8_t *status, int useInitial) {
+    std::vector<Image> P(maxLevel + 1), N(maxLevel + 1);
+    P[0].w = N[0].w = w; P[0].h = N[0].h = h;
+    P[0].d.assign(prev, prev + (size_t)w * h);
+    N[0].d.assign(next, next + (size_t)w * h);
+    for (int l = 1; l <= maxLevel; l++) { pyr_down(P[l - 1], P[l]); pyr_down(N[l - 1], N[l]); }
+    std::vector<P2f> pp(n), np(n);
+    for (int i = 0; i < n; i++) { pp[i] = P2f{prevPts[2 * i], prevPts[2 * i + 1]}; np[i] = P2f{nextPts[2 * i], nextPts[2 * i + 1]}; }
+    std::vector<uint8_t> st;
+    lk_track(P, N, pp, np, st, maxLevel, useInitial != 0);
+    for (int i = 0; i < n; i++) { nextPts[2 * i] = np[i].x; nextPts[2 * i + 1] = np[i].y; status[i] = st[i]; }
+}
+void ovio_ransac(const Config *c, int n, const float *p1, const float *p2, uint8_t *status) {
+    std::vector<P2f> a(n), b(n);
+    for (int i = 0; i < n; i++) { a[i] = P2f{p1[2 * i], p1[2 * i + 1]}; b[i] = P2f{p2[2 * i], p2[2 * i + 1]}; }
+    std::vector<uint8_t> st;
+    ransac_fundamental(*c, a, b, st);
+    for (int i = 0; i < n; i++) status[i] = st[i];
+}
+// obs: 9 doubles each (x,y,z,u,v,vx,vy,cur_td,depth). J out: Ji(14) Jj(14) Jex(14) Jl(2) Jtd(2)
+void ovio_eval_projection(const Config *c, const double *pi, const double *pj, const double *ex, double inv_dep, double td,
+                          const double *oi, const double *oj, int use_td, double *r, double *J) {
+    Obs a{oi[0], oi[1], oi[2], oi[3], oi[4], oi[5], oi[6], oi[7], oi[8]}, b{oj[0], oj[1], oj[2], oj[3], oj[4], oj[5], oj[6], oj[7], oj[8]};
+    eval_projection(*c, pi, pj, ex, inv_dep, td, a, b, use_td != 0, r, J ? J : nullptr, J ? J + 14 : nullptr, J ? J + 28 : nullptr,
+                    J ? J + 42 : nullptr, J ? J + 44 : nullptr);
+}
+// pre-integration: n samples (dt, acc, gyr); first acc0/gyr0; out: delta_p(3) delta_q(wxyz) delta_v(3) sum_dt jac(225) cov(225)
+void *ovio_preint_create(const Config *c, const double *acc0, const double *gyr0, const double *ba, const double *bg) {
+    return new Integration(*c, V3(acc0[0], acc0[1], acc0[2]), V3(gyr0[0], gyr0[1], gyr0[2]), V3(ba[0], ba[1], ba[2]), V3(bg[0], bg[1], bg[2]));
+}
+void ovio_preint_destroy(void *h) { delete (Integration *)h; }
+void ovio_preint_push(void *h, double dt, const double *acc, const double *gyr) {
+    ((Integration *)h)->push_back(dt, V3(acc[0], acc[1], acc[2]), V3(gyr[0], gyr[1], gyr[2]));
+}
+void ovio_preint_repropagate(void *h, const double *ba, const double *bg) {
+    ((Integration *)h)->repropagate(V3(ba[0], ba[1], ba[2]), V3(bg[0], bg[1], bg[2]));
+}
+void ovio_preint_get(void *h, double *out) {
+    Integration *p = (Integration *)h;
+    out[0] = p->delta_p.x; out[1] = p->delta_p.y; out[2] = p->delta_p.z;
+    out[3] = p->delta_q.w; out[4] = p->delta_q.x; out[5] = p->delta_q.y; out[6] = p->delta_q.z;
+    out[7] = p->delta_v.x; out[8] = p->delta_v.y; out[9] = p->delta_v.z;
+    out[10] = p->sum_dt;
+    for (int i = 0; i < 15; i++) for (int j = 0; j < 15; j++) { out[11 + i * 15 + j] = p->jacobian[i][j]; out[11 + 225 + i * 15 + j] = p->covariance[i][j]; }
+}
+// r(15), J: Ji(105) Jsi(135) Jj(105) Jsj(135)
+void ovio_eval_imu(void *h, double g_norm, const double *pi, const double *sbi, const double *pj, const double *sbj, double *r, double *J) {
+    eval_imu(*(Integration *)h, V3(0, 0, g_norm), pi, sbi, pj, sbj, r, J ? J : nullptr, J ? J + 105 : nullptr, J ? J + 240 : nullptr,
+             J ? J + 345 : nullptr);
+}
+// symmetric eigen (for tests of the stand-in solver)
+void ovio_sym_eig(int n, const double *A, double *w, double *V) {
+    Mat M(n, n), Vm;
+    for (int i = 0; i < n * n; i++) M.d[i] = A[i];
+    std::vector<double> ww;
+    sym_eig(M, ww, Vm);
+    for (int i = 0; i < n; i++) w[i] = ww[i];
+    for (int i = 0; i < n * n; i++) V[i] = Vm.d[i];
+}
+// prior accessors (marginalisation tests): returns n; J (n×n row-major), r (n), present (W+3)
+int ovio_get_prior(void *h, double *J, double *r, double *x0, uint8_t *present) {
+    Estimator &e = ((Pipeline *)h)->est;
+    if (!e.has_prior) return 0;
+    int n = e.prior_n;
+    if (J) for (int i = 0; i < n * n; i++) J[i] = e.prior_J.d[i];
+    if (r) for (int i = 0; i < n; i++) r[i] = e.prior_r[i];
+    if (x0) for (size_t i = 0; i < e.prior_x0.size(); i++) x0[i] = e.prior_x0[i];
+    if (present) for (size_t i = 0; i < e.prior_present.size(); i++) present[i] = e.prior_present[i];
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,275 @@
+// ORACLE (test infrastructure only — never linked into or called by the product path).
+// Small dense-algebra helpers for the CPU restatement of the VINS-RGBD-FAST hot path.
+// Parity status: "parity unpinned" — the reference ships no tests/golden vectors and its
+// third-party arithmetic (OpenCV / Ceres / Eigen) cannot be built in this image.
+//
+// Mirrors the handful of Eigen operations the reference uses:
+//   Utility::deltaQ/Qleft/Qright/R2ypr/ypr2R/g2R   vins_estimator/src/utility/utility.h:11-108, utility.cpp:5-15
+//   Eigen::Quaterniond(Matrix3d), toRotationMatrix, FromTwoVectors (Eigen/Geometry, un-vendored)
+//   LLT / LDLT / SelfAdjointEigenSolver / JacobiSVD call sites listed in SURVEY.md §8c
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include <cstdio>
+
+namespace om {
+
+struct V3 {
+    double x = 0, y = 0, z = 0;
+    V3() {}
+    V3(double a, double b, double c) : x(a), y(b), z(c) {}
+    double &operator[](int i) { return (&x)[i]; }
+    double operator[](int i) const { return (&x)[i]; }
+};
+inline V3 operator+(const V3 &a, const V3 &b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline V3 operator-(const V3 &a, const V3 &b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline V3 operator-(const V3 &a) { return V3(-a.x, -a.y, -a.z); }
+inline V3 operator*(double s, const V3 &a) { return V3(s * a.x, s * a.y, s * a.z); }
+inline V3 operator*(const V3 &a, double s) { return V3(s * a.x, s * a.y, s * a.z); }
+inline V3 operator/(const V3 &a, double s) { return V3(a.x / s, a.y / s, a.z / s); }
+inline double dot(const V3 &a, const V3 &b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 cross(const V3 &a, const V3 &b) {
+    return V3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+inline double norm(const V3 &a) { return std::sqrt(dot(a, a)); }
+
+struct M3 {
+    double m[3][3];
+    M3() { std::memset(m, 0, sizeof(m)); }
+    static M3 I() { M3 r; r.m[0][0] = r.m[1][1] = r.m[2][2] = 1; return r; }
+    double &operator()(int i, int j) { return m[i][j]; }
+    double operator()(int i, int j) const { return m[i][j]; }
+    V3 col(int j) const { return V3(m[0][j], m[1][j], m[2][j]); }
+};
+inline M3 operator*(const M3 &a, const M3 &b) {
+    M3 r;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += a.m[i][k] * b.m[k][j];
+            r.m[i][j] = s;
+        }
+    return r;
+}
+inline V3 operator*(const M3 &a, const V3 &v) {
+    return V3(a.m[0][0] * v.x + a.m[0][1] * v.y + a.m[0][2] * v.z,
+              a.m[1][0] * v.x + a.m[1][1] * v.y + a.m[1][2] * v.z,
+              a.m[2][0] * v.x + a.m[2][1] * v.y + a.m[2][2] * v.z);
+}
+inline M3 operator*(double s, const M3 &a) { M3 r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = s * a.m[i][j]; return r; }
+inline M3 operator+(const M3 &a, const M3 &b) { M3 r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = a.m[i][j] + b.m[i][j]; return r; }
+inline M3 operator-(const M3 &a, const M3 &b) { M3 r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = a.m[i][j] - b.m[i][j]; return r; }
+inline M3 operator-(const M3 &a) { M3 r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = -a.m[i][j]; return r; }
+inline M3 T(const M3 &a) { M3 r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.m[i][j] = a.m[j][i]; return r; }
+inline M3 skew(const V3 &q) {  // utility.h:26-34
+    M3 r;
+    r.m[0][1] = -q.z; r.m[0][2] = q.y;
+    r.m[1][0] = q.z;  r.m[1][2] = -q.x;
+    r.m[2][0] = -q.y; r.m[2][1] = q.x;
+    return r;
+}
+
+// Hamilton quaternion, Eigen conventions (w,x,y,z constructor order, q*v rotates).
+struct Q {
+    double w = 1, x = 0, y = 0, z = 0;
+    Q() {}
+    Q(double w_, double x_, double y_, double z_) : w(w_), x(x_), y(y_), z(z_) {}
+    V3 vec() const { return V3(x, y, z); }
+};
+inline Q operator*(const Q &a, const Q &b) {
+    return Q(a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z,
+             a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+             a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+             a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x);
+}
+inline Q normalized(const Q &q) {
+    double n = std::sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    return Q(q.w / n, q.x / n, q.y / n, q.z / n);
+}
+// Eigen's inverse(): conjugate / squaredNorm
+inline Q inverse(const Q &q) {
+    double n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+    return Q(q.w / n2, -q.x / n2, -q.y / n2, -q.z / n2);
+}
+// Eigen's toRotationMatrix (no normalisation inside, as Eigen)
+inline M3 toR(const Q &q) {
+    M3 r;
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    r.m[0][0] = 1 - (tyy + tzz); r.m[0][1] = txy - twz;       r.m[0][2] = txz + twy;
+    r.m[1][0] = txy + twz;       r.m[1][1] = 1 - (txx + tzz); r.m[1][2] = tyz - twx;
+    r.m[2][0] = txz - twy;       r.m[2][1] = tyz + twx;       r.m[2][2] = 1 - (txx + tyy);
+    return r;
+}
+// Eigen's q * v  (Quaternion::_transformVector)
+inline V3 rot(const Q &q, const V3 &v) {
+    V3 u = q.vec();
+    V3 uv = cross(u, v);
+    uv = uv + uv;
+    return v + q.w * uv + cross(u, uv);
+}
+// Eigen's Quaternion(Matrix3)
+inline Q fromR(const M3 &m) {
+    Q q;
+    double t = m(0, 0) + m(1, 1) + m(2, 2);
+    if (t > 0) {
+        t = std::sqrt(t + 1.0);
+        q.w = 0.5 * t;
+        t = 0.5 / t;
+        q.x = (m(2, 1) - m(1, 2)) * t;
+        q.y = (m(0, 2) - m(2, 0)) * t;
+        q.z = (m(1, 0) - m(0, 1)) * t;
+    } else {
+        int i = 0;
+        if (m(1, 1) > m(0, 0)) i = 1;
+        if (m(2, 2) > m(i, i)) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + 1.0);
+        double qv[3];
+        qv[i] = 0.5 * t;
+        t = 0.5 / t;
+        q.w = (m(k, j) - m(j, k)) * t;
+        qv[j] = (m(j, i) + m(i, j)) * t;
+        qv[k] = (m(k, i) + m(i, k)) * t;
+        q.x = qv[0]; q.y = qv[1]; q.z = qv[2];
+    }
+    return q;
+}
+inline Q deltaQ(const V3 &theta) { return Q(1.0, theta.x / 2, theta.y / 2, theta.z / 2); }  // utility.h:11-24 (unnormalised)
+
+inline V3 R2ypr(const M3 &R) {  // utility.h:66-81 (degrees)
+    V3 n = R.col(0), o = R.col(1), a = R.col(2);
+    double y = std::atan2(n.y, n.x);
+    double p = std::atan2(-n.z, n.x * std::cos(y) + n.y * std::sin(y));
+    double r = std::atan2(a.x * std::sin(y) - a.y * std::cos(y), -o.x * std::sin(y) + o.y * std::cos(y));
+    return V3(y / M_PI * 180.0, p / M_PI * 180.0, r / M_PI * 180.0);
+}
+inline M3 ypr2R(const V3 &ypr) {  // utility.h:83-108
+    double y = ypr.x / 180.0 * M_PI, p = ypr.y / 180.0 * M_PI, r = ypr.z / 180.0 * M_PI;
+    M3 Rz, Ry, Rx;
+    Rz(0, 0) = std::cos(y); Rz(0, 1) = -std::sin(y); Rz(1, 0) = std::sin(y); Rz(1, 1) = std::cos(y); Rz(2, 2) = 1;
+    Ry(0, 0) = std::cos(p); Ry(0, 2) = std::sin(p); Ry(1, 1) = 1; Ry(2, 0) = -std::sin(p); Ry(2, 2) = std::cos(p);
+    Rx(0, 0) = 1; Rx(1, 1) = std::cos(r); Rx(1, 2) = -std::sin(r); Rx(2, 1) = std::sin(r); Rx(2, 2) = std::cos(r);
+    return Rz * Ry * Rx;
+}
+// Eigen's Quaternion::FromTwoVectors for unit inputs (non-antiparallel branch; the
+// antiparallel branch needs an SVD in Eigen and is unreachable for accelerometer gravity).
+inline Q fromTwoVectors(const V3 &a, const V3 &b) {
+    V3 v0 = a / norm(a), v1 = b / norm(b);
+    double c = dot(v1, v0);
+    if (c < -1.0 + 1e-12) {  // pick any orthogonal axis
+        V3 ax = std::fabs(v0.x) < 0.9 ? cross(v0, V3(1, 0, 0)) : cross(v0, V3(0, 1, 0));
+        ax = ax / norm(ax);
+        return Q(0, ax.x, ax.y, ax.z);
+    }
+    V3 axis = cross(v0, v1);
+    double s = std::sqrt((1.0 + c) * 2.0);
+    double invs = 1.0 / s;
+    return Q(s * 0.5, axis.x * invs, axis.y * invs, axis.z * invs);
+}
+inline M3 g2R(const V3 &g) {  // utility.cpp:5-15
+    M3 R0 = toR(fromTwoVectors(g, V3(0, 0, 1)));
+    double yaw = R2ypr(R0).x;
+    return ypr2R(V3(-yaw, 0, 0)) * R0;
+}
+
+// ---------------------------------------------------------------- dynamic row-major matrix
+struct Mat {
+    int r = 0, c = 0;
+    std::vector<double> d;
+    Mat() {}
+    Mat(int r_, int c_) : r(r_), c(c_), d((size_t)r_ * c_, 0.0) {}
+    double &operator()(int i, int j) { return d[(size_t)i * c + j]; }
+    double operator()(int i, int j) const { return d[(size_t)i * c + j]; }
+    void zero() { std::fill(d.begin(), d.end(), 0.0); }
+};
+
+// Cyclic Jacobi eigen-decomposition of a symmetric n×n matrix (stand-in for
+// Eigen::SelfAdjointEigenSolver; agreement is to round-off, order = ascending).
+// A is destroyed; V columns are eigenvectors.
+inline void sym_eig(Mat &A, std::vector<double> &w, Mat &V) {
+    int n = A.r;
+    V = Mat(n, n);
+    for (int i = 0; i < n; i++) V(i, i) = 1;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; i++) {
+            diag += A(i, i) * A(i, i);
+            for (int j = i + 1; j < n; j++) off += A(i, j) * A(i, j);
+        }
+        if (off <= 1e-30 * (diag + 1e-300) || off == 0.0) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                double apq = A(p, q);
+                if (apq == 0.0) continue;
+                double app = A(p, p), aqq = A(q, q);
+                double tau = (aqq - app) / (2.0 * apq);
+                double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+                double cs = 1.0 / std::sqrt(1.0 + t * t), sn = t * cs;
+                for (int k = 0; k < n; k++) {
+                    double akp = A(k, p), akq = A(k, q);
+                    A(k, p) = cs * akp - sn * akq;
+                    A(k, q) = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    double apk = A(p, k), aqk = A(q, k);
+                    A(p, k) = cs * apk - sn * aqk;
+                    A(q, k) = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    double vkp = V(k, p), vkq = V(k, q);
+                    V(k, p) = cs * vkp - sn * vkq;
+                    V(k, q) = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    w.resize(n);
+    std::vector<int> idx(n);
+    for (int i = 0; i < n; i++) { w[i] = A(i, i); idx[i] = i; }
+    std::sort(idx.begin(), idx.end(), [&](int a, int b) { return w[a] < w[b]; });
+    Mat V2(n, n);
+    std::vector<double> w2(n);
+    for (int j = 0; j < n; j++) {
+        w2[j] = w[idx[j]];
+        for (int i = 0; i < n; i++) V2(i, j) = V(i, idx[j]);
+    }
+    w = w2;
+    V = V2;
+}
+
+// In-place Cholesky (lower) of symmetric positive definite A (n×n). Returns false on failure.
+inline bool chol(Mat &A) {
+    int n = A.r;
+    for (int j = 0; j < n; j++) {
+        double s = A(j, j);
+        for (int k = 0; k < j; k++) s -= A(j, k) * A(j, k);
+        if (!(s > 0.0) || !std::isfinite(s)) return false;
+        double l = std::sqrt(s);
+        A(j, j) = l;
+        for (int i = j + 1; i < n; i++) {
+            double t = A(i, j);
+            for (int k = 0; k < j; k++) t -= A(i, k) * A(j, k);
+            A(i, j) = t / l;
+        }
+    }
+    return true;
+}
+inline void chol_solve(const Mat &L, std::vector<double> &b) {
+    int n = L.r;
+    for (int i = 0; i < n; i++) {
+        double s = b[i];
+        for (int k = 0; k < i; k++) s -= L(i, k) * b[k];
+        b[i] = s / L(i, i);
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double s = b[i];
+        for (int k = i + 1; k < n; k++) s -= L(k, i) * b[k];
+        b[i] = s / L(i, i);
+    }
+}
+
+}  // namespace om

@@ -1,0 +1,256 @@
+// ORACLE (test infrastructure only — never linked into or called by the product path).
+// CPU restatement of the VINS-RGBD-FAST hot path:
+//   front-end  FeatureTracker::readImage        vins_estimator/src/feature_tracker/feature_tracker.cpp:263-439
+//   back-end   Estimator::processImage          vins_estimator/src/estimator/estimator.cpp:156-374
+//              Estimator::optimization          vins_estimator/src/estimator/estimator.cpp:1161-1578
+// Parity status: "parity unpinned" (no golden vectors upstream; OpenCV/Ceres/Eigen are absent).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <list>
+#include <map>
+#include <vector>
+#include "om.h"
+
+namespace ovio {
+
+// Mirrors the globals of vins_estimator/src/utility/parameters.h:11-79 that the hot path reads,
+// per instance instead of process-global.
+struct Config {
+    int width = 640, height = 480;     // COL, ROW
+    int max_cnt = 150, min_dist = 15;  // MAX_CNT, MIN_DIST
+    int grid_rows = 5, grid_cols = 6;  // NUM_GRID_ROWS/COLS
+    int window_size = 10;              // WINDOW_SIZE (compile-time 10 upstream, parameters.h:12)
+    int max_landmarks = 1000;          // NUM_OF_F (parameters.h:14)
+    int fix_depth = 1;                 // FIX_DEPTH
+    int estimate_extrinsic = 0;        // ESTIMATE_EXTRINSIC (0/1 supported)
+    int estimate_td = 0;               // ESTIMATE_TD
+    int max_iterations = 8;            // NUM_ITERATIONS
+    int ransac_max_iters = 1000;
+    int lk_max_level = 1;              // IMU-aided call uses maxLevel=1 (feature_tracker.cpp:303)
+    int reserved0 = 0;
+    double fx = 604.5821781259577, fy = 604.2544712985845, cx = 321.2638233484251, cy = 239.70969315130674;
+    double k1 = 0.13387871564774004, k2 = -0.2731913133377051, p1 = 0.0020296263577681264, p2 = -0.00044384544608203714;
+    double focal_length = 460.0;       // FOCAL_LENGTH
+    double f_threshold = 1.0;          // F_THRESHOLD
+    double depth_min = 0.3, depth_max = 6.0;
+    double acc_n = 0.1, acc_w = 0.001, gyr_n = 0.01, gyr_w = 0.0001, g_norm = 9.805;
+    double ric[9] = {0.02629567, -0.00713751, 0.99962873, -0.99934346, 0.02474397, 0.02646484, -0.02492368, -0.99966834, -0.00648216};
+    double tic[3] = {0.17336835, 0.049596, -0.10574841};
+    double td = 0.0, tr = 0.0;         // TD, TR (rolling shutter readout)
+    double min_parallax_px = 10.0;     // keyframe_parallax
+    double init_depth = 5.0;           // INIT_DEPTH (parameters.cpp:215)
+};
+
+struct P2f { float x, y; };
+
+struct KeyPt { float x, y, response; };
+
+struct Image {
+    int w = 0, h = 0;
+    std::vector<uint8_t> d;
+};
+
+// ------------------------------------------------------------------------------------ camera
+// camera_model/src/camera_models/PinholeCamera.cc:449-510 (liftProjective), :519-542 (spaceToPlane),
+// :645-662 (distortion)
+void cam_distortion(const Config &c, double x, double y, double &dx, double &dy);
+void cam_lift(const Config &c, double u, double v, double &x, double &y);  // z = 1
+void cam_project(const Config &c, double X, double Y, double Z, double &u, double &v);
+
+// ------------------------------------------------------------------------------------ vision primitives
+void pyr_down(const Image &src, Image &dst);
+// FAST-9/16 threshold 10 + NMS on a ROI, row-major order, ROI-relative coordinates
+void fast_detect_roi(const uint8_t *img, int W, int H, int rx, int ry, int rw, int rh, std::vector<KeyPt> &out);
+int fast_corner_score(const uint8_t *p, int stride, int thr);  // returns 0 if not a corner
+void circle_halfwidths(int radius, std::vector<int> &hw);      // cv::circle(filled) raster shape
+void lk_track(const std::vector<Image> &prev, const std::vector<Image> &next, const std::vector<P2f> &prevPts,
+              std::vector<P2f> &nextPts, std::vector<uint8_t> &status, int maxLevel, bool useInitialFlow);
+void ransac_fundamental(const Config &c, const std::vector<P2f> &p1, const std::vector<P2f> &p2,
+                        std::vector<uint8_t> &status);
+
+// ------------------------------------------------------------------------------------ FeatureTracker
+struct Tracker {
+    Config cfg;
+    std::vector<Image> cur_pyr, forw_pyr;
+    bool has_img = false;
+    std::vector<uint8_t> mask;
+    std::vector<P2f> cur_pts, forw_pts, predict_pts, unstable_pts, cur_un_pts, pts_velocity;
+    std::vector<int> ids, track_cnt;
+    std::map<int, P2f> cur_un_pts_map, prev_un_pts_map;
+    double cur_time = 0, prev_time = 0;
+    int n_id = 0;
+    // grid detector (feature_tracker.cpp:33-94)
+    struct Rect { int x, y, w, h; };
+    std::vector<Rect> grids_rect;
+    std::vector<int> grids_track_num;
+    std::vector<uint8_t> grids_texture_status;
+    int grid_height = 0, grid_width = 0, grid_res_height = 0, grid_res_width = 0, grids_threshold = 0;
+    std::vector<int> circle_hw;
+
+    explicit Tracker(const Config &c);
+    void readImage(const uint8_t *img, double t, const double R[9], bool publish);
+    void updateIDs();
+    bool inBorder(const P2f &pt) const;
+    void rejectWithF();
+    void setMask();
+    std::vector<KeyPt> gridDetect(int grid_id);
+    void addPoints(const std::vector<KeyPt> &kps);
+    void undistortedPoints();
+    void predictPtsInNextFrame(const double R[9]);
+    void drawCircle(const P2f &pt);
+    uint8_t maskAt(const P2f &pt) const;
+};
+
+// ------------------------------------------------------------------------------------ back-end types
+// factor/integration_base.h:9-217
+struct Integration {
+    double acc_n, acc_w, gyr_n, gyr_w;
+    om::V3 acc_0, gyr_0, linearized_acc, linearized_gyr, linearized_ba, linearized_bg;
+    double jacobian[15][15], covariance[15][15];
+    double sum_dt = 0;
+    om::V3 delta_p, delta_v;
+    om::Q delta_q;
+    std::vector<double> dt_buf;
+    std::vector<om::V3> acc_buf, gyr_buf;
+    Integration(const Config &c, const om::V3 &a0, const om::V3 &g0, const om::V3 &ba, const om::V3 &bg);
+    void push_back(double dt, const om::V3 &acc, const om::V3 &gyr);
+    void propagate(double dt, const om::V3 &acc1, const om::V3 &gyr1);
+    void repropagate(const om::V3 &ba, const om::V3 &bg);
+    void evaluate(const om::V3 &G, const om::V3 &Pi, const om::Q &Qi, const om::V3 &Vi, const om::V3 &Bai, const om::V3 &Bgi,
+                  const om::V3 &Pj, const om::Q &Qj, const om::V3 &Vj, const om::V3 &Baj, const om::V3 &Bgj,
+                  double r[15]) const;
+};
+
+struct Obs {  // feature_manager.h:40-65 FeaturePerFrame
+    double x, y, z;  // normalised point (z = 1)
+    double u, v;
+    double vx, vy;
+    double cur_td;
+    double depth;
+};
+struct Landmark {  // feature_manager.h:67-87 FeaturePerId
+    int feature_id;
+    int start_frame;
+    std::vector<Obs> obs;
+    int used_num = 0;
+    bool is_dynamic = false;
+    double estimated_depth = -1.0;
+    int estimate_flag = 0;
+    int solve_flag = 0;
+    int endFrame() const { return start_frame + (int)obs.size() - 1; }
+};
+
+struct ImuSample { double t; om::V3 acc, gyr; };
+
+enum { MAXW = 20 };
+
+// Result of one solve (for tests / diagnostics)
+struct SolveStats {
+    int iterations = 0, successful = 0;
+    double initial_cost = 0, final_cost = 0;
+    int n_landmarks = 0, n_residuals = 0, n_var_landmarks = 0;
+};
+
+struct Estimator {
+    Config cfg;
+    int W;
+    // window state (estimator.h:121-171)
+    om::V3 Ps[MAXW + 1], Vs[MAXW + 1], Bas[MAXW + 1], Bgs[MAXW + 1];
+    om::M3 Rs[MAXW + 1];
+    double Headers[MAXW + 1];
+    Integration *pre_integrations[MAXW + 1];
+    om::V3 acc_0, gyr_0, g;
+    om::M3 ric;
+    om::V3 tic;
+    double td;
+    bool first_imu = false, initFirstPoseFlag = false, openExEstimation = false, failure_occur = false;
+    int frame_count = 0;
+    int solver_flag = 0;           // 0 INITIAL, 1 NON_LINEAR
+    int marginalization_flag = 0;  // 0 MARGIN_OLD, 1 MARGIN_SECOND_NEW
+    double prevTime = -1;
+    std::vector<ImuSample> imu_buf;  // queue (front = index imu_head)
+    size_t imu_head = 0;
+    om::V3 latest_Bg;
+    om::M3 last_R, last_R0, back_R0;
+    om::V3 last_P, last_P0, back_P0;
+    // feature manager
+    std::list<Landmark> feature;
+    int last_track_num = 0;
+    const uint16_t *depth_img = nullptr;
+    // flat parameter arrays (estimator.h para_*)
+    double para_Pose[MAXW + 1][7], para_SpeedBias[MAXW + 1][9], para_Ex_Pose[7], para_Td;
+    std::vector<double> para_Feature;
+    // prior, canonical layout (DESIGN.md "prior layout"): [pose slots 0..W-1 (6 each) | speedbias slot 0 (9) | ex (6) | td (1)]
+    bool has_prior = false;
+    int prior_n = 0;
+    om::Mat prior_J;              // n×n  linearized_jacobians
+    std::vector<double> prior_r;  // n    linearized_residuals
+    std::vector<double> prior_x0; // keep_block_data in canonical global layout: W*7 + 9 + 7 + 1
+    std::vector<uint8_t> prior_present;  // per block: W poses, sb0, ex, td
+    SolveStats last_stats;
+    int reboot_count = 0;
+
+    explicit Estimator(const Config &c);
+    ~Estimator();
+    void clearState();
+    void inputIMU(double t, const om::V3 &acc, const om::V3 &gyr);
+    void predictMotion(double t0, double t1, double R[9]);
+    bool IMUAvailable(double t) const;
+    // image: ascending-id map of 7-vectors (x,y,1,u,v,vx,vy); returns 0 ok, 1 need imu, 2 rebooted
+    int processImage(std::map<int, std::array<double, 7>> &image, const uint16_t *depth, double stamp);
+
+    // internals
+    void processIMU(double dt, const om::V3 &acc, const om::V3 &gyr);
+    void initFirstIMUPose(const std::vector<ImuSample> &v);
+    bool addFeatureCheckParallax(int frame_count, std::map<int, std::array<double, 7>> &image, double td);
+    double compensatedParallax2(const Landmark &l, int frame_count) const;
+    int getFeatureCount();
+    void triangulateWithDepth();
+    void solveGyroscopeBias();
+    void vector2double();
+    void double2vector();
+    void optimization();
+    void solve();
+    void marginalize_old();
+    void marginalize_second_new();
+    void slideWindow();
+    void slideWindowOld();
+    void slideWindowNew();
+    void removeBackShiftDepth(const om::M3 &mR, const om::V3 &mP, const om::M3 &nR, const om::V3 &nP);
+    void removeBack();
+    void removeFront(int frame_count);
+    void removeFailures();
+    void movingConsistencyCheck();
+    bool failureDetection();
+    void setDepth(const std::vector<double> &x);
+    std::vector<double> getDepthVector();
+};
+
+// factor evaluation (exposed for known-answer tests)
+// ProjectionFactor / ProjectionTdFactor: factor/projection_factor.cpp:22-130, projection_td_factor.cpp:34-150
+// Jacobians row-major 2×7,2×7,2×7,2×1,2×1 (td ignored when use_td == 0)
+void eval_projection(const Config &c, const double *pose_i, const double *pose_j, const double *ex, double inv_dep, double td,
+                     const Obs &oi, const Obs &oj, bool use_td, double r[2], double *J_i, double *J_j, double *J_ex,
+                     double *J_l, double *J_td);
+// IMUFactor::Evaluate factor/imu_factor.h:20-205; Jacobians row-major 15×7, 15×9, 15×7, 15×9
+void eval_imu(const Integration &pre, const om::V3 &G, const double *pose_i, const double *sb_i, const double *pose_j,
+              const double *sb_j, double r[15], double *J_pi, double *J_sbi, double *J_pj, double *J_sbj);
+
+// ------------------------------------------------------------------------------------ nodelet-side driver
+// Restates the parts of estimator_nodelet.cpp:192-459 (process_tracker) and :462-568 (process) that sit between
+// the two entry points: first-image skip, updateID loop, feature-map packaging (track_cnt>1, ascending id),
+// init_pub / init_feature skipping. Frequency control is pinned to "publish every frame".
+struct Pipeline {
+    Config cfg;
+    Tracker tracker;
+    Estimator est;
+    bool first_image_flag = true, init_pub = false, init_feature = false;
+    double last_image_time = 0;
+    int frames_processed = 0;
+    explicit Pipeline(const Config &c) : cfg(c), tracker(c), est(c) {}
+    // returns 1 if processImage ran for this frame
+    int feed(const uint8_t *gray, const uint16_t *depth, double t);
+};
+
+}  // namespace ovio
