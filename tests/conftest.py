@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def P():
+    import vio_ct
+    return vio_ct.pkg()
+
+
+@pytest.fixture(scope="session")
+def orc():
+    import vio_ct
+    return vio_ct.oracle()

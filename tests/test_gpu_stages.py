@@ -1,0 +1,164 @@
+"""GPU parity of the single stages (through the C ABI) against the CPU oracle on identical inputs.
+Integer / fixed-point stages must be bit-exact; FP64 factor math agrees to round-off (tolerances stated per test)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import vio_ct
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def frames(P):
+    cfg = P.default_config()
+    sc = vio_ct.synth_like(cfg)
+    syn = P.Synth(sc)
+    return cfg, sc, [syn.render_host(3, t) for t in (2.5, 2.6)]
+
+
+def test_pyr_down_bit_exact(P, orc, frames):
+    cfg, sc, fr = frames
+    g = fr[0][0]
+    h, w = g.shape
+    for img in (g, np.ascontiguousarray(g[:241, :333])):
+        hh, ww = img.shape
+        ref = np.zeros(((hh + 1) // 2, (ww + 1) // 2), np.uint8)
+        out = np.zeros_like(ref)
+        orc.ovio_pyr_down(img.ctypes.data, ww, hh, ref.ctypes.data)
+        assert P.lib().vio_stage_pyr_down(img.ctypes.data, ww, hh, out.ctypes.data) == 0
+        assert np.array_equal(ref, out)
+
+
+def test_fast_roi_bit_exact(P, orc, frames):
+    cfg, sc, fr = frames
+    g = fr[0][0]
+    H, W = g.shape
+    total = 0
+    for (rx, ry, rw, rh) in [(0, 0, 109, 99), (103, 93, 112, 102), (527, 381, 113, 99), (315, 189, 112, 102), (10, 20, 7, 7), (0, 0, 30, 9)]:
+        cap = 4096
+        a, b = np.zeros((cap, 3), np.float32), np.zeros((cap, 3), np.float32)
+        na = orc.ovio_fast_roi(g.ctypes.data, W, H, rx, ry, rw, rh, cap, a.ctypes.data)
+        nb = P.lib().vio_stage_fast_roi(g.ctypes.data, W, H, rx, ry, rw, rh, cap, b.ctypes.data)
+        assert na == nb
+        assert np.array_equal(a[:na], b[:nb])
+        total += na
+    assert total > 20  # the synthetic texture must actually produce corners
+
+
+def _corners(orc, g, n=120):
+    H, W = g.shape
+    out = np.zeros((8192, 3), np.float32)
+    k = orc.ovio_fast_roi(g.ctypes.data, W, H, 0, 0, W, H, 8192, out.ctypes.data)
+    pts = out[:k]
+    pts = pts[(pts[:, 0] > 30) & (pts[:, 0] < W - 30) & (pts[:, 1] > 30) & (pts[:, 1] < H - 30)]
+    idx = np.argsort(-pts[:, 2], kind="stable")[:n]
+    return np.ascontiguousarray(pts[idx, :2])
+
+
+@pytest.mark.parametrize("max_level", [1, 3])
+def test_lk_bit_exact(P, orc, frames, max_level):
+    cfg, sc, fr = frames
+    g0, g1 = fr[0][0], fr[1][0]
+    H, W = g0.shape
+    prev = _corners(orc, g0)
+    # add border / out-of-image cases
+    prev = np.vstack([prev, [[2.5, 3.5], [W - 2.0, H - 3.0], [W / 2, 1.0]]]).astype(np.float32)
+    n = len(prev)
+    rng = np.random.default_rng(0)
+    init = (prev + rng.uniform(-2, 2, prev.shape)).astype(np.float32)
+    a, b = init.copy(), init.copy()
+    sa, sb = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    orc.ovio_lk(g0.ctypes.data, g1.ctypes.data, W, H, max_level, n, prev.ctypes.data, a.ctypes.data, sa.ctypes.data, 1)
+    assert P.lib().vio_stage_lk(g0.ctypes.data, g1.ctypes.data, W, H, max_level, n, prev.ctypes.data, b.ctypes.data, sb.ctypes.data) == 0
+    assert np.array_equal(sa, sb)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), float(np.abs(a - b).max())
+    assert sa.sum() > n // 2
+    moved = np.linalg.norm(a[sa > 0] - prev[sa > 0], axis=1)
+    assert moved.mean() > 0.5  # the two frames really differ
+
+
+def test_ransac_same_inliers(P, orc):
+    cfg = P.default_config()
+    rng = np.random.default_rng(1)
+    n = 150
+    # synthetic two-view geometry in virtual-pinhole pixels (f = 460, c = (320,240))
+    X = np.c_[rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(2, 6, n)]
+    th = 0.05
+    R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+    t = np.array([0.15, 0.02, 0.05])
+    X2 = (R @ X.T).T + t
+    p1 = np.ascontiguousarray((460 * X[:, :2] / X[:, 2:3] + [320, 240]).astype(np.float32))
+    p2 = np.ascontiguousarray((460 * X2[:, :2] / X2[:, 2:3] + [320, 240]).astype(np.float32))
+    p2 += rng.normal(0, 0.2, p2.shape).astype(np.float32)
+    bad = rng.choice(n, 25, replace=False)
+    p2[bad] += rng.uniform(8, 30, (25, 2)).astype(np.float32)
+    for pts2 in (p2, p1.copy()):  # second case: zero motion (rank-deficient samples)
+        sa, sb = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        orc.ovio_ransac(C.byref(cfg), n, p1.ctypes.data, pts2.ctypes.data, sa.ctypes.data)
+        assert P.lib().vio_stage_ransac(C.byref(cfg), n, p1.ctypes.data, pts2.ctypes.data, sb.ctypes.data) == 0
+        assert np.array_equal(sa, sb)
+    sa = np.zeros(n, np.uint8)
+    orc.ovio_ransac(C.byref(cfg), n, p1.ctypes.data, p2.ctypes.data, sa.ctypes.data)
+    assert sa[bad].sum() <= 2 and sa.sum() >= 110
+
+
+def _rand_pose(rng, scale=1.0):
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    if q[3] < 0:
+        q = -q
+    return np.r_[rng.normal(size=3) * scale, q]  # x y z qx qy qz qw
+
+
+def test_imu_factor_matches_oracle(P, orc):
+    cfg = P.default_config()
+    rng = np.random.default_rng(2)
+    n = 20
+    dt = np.full(n, 0.005)
+    acc = rng.normal(0, 1.0, (n, 3)) + [0, 0, 9.8]
+    gyr = rng.normal(0, 0.3, (n, 3))
+    acc0, gyr0 = acc[0] + 0.01, gyr[0] - 0.01
+    ba, bg = rng.normal(0, 0.02, 3), rng.normal(0, 0.002, 3)
+    pi, pj = _rand_pose(rng), _rand_pose(rng)
+    sbi, sbj = rng.normal(0, 0.3, 9), rng.normal(0, 0.3, 9)
+    sbi[3:] *= 0.05; sbj[3:] *= 0.05
+    h = C.c_void_p(orc.ovio_preint_create(C.byref(cfg), acc0.ctypes.data, gyr0.ctypes.data, ba.ctypes.data, bg.ctypes.data))
+    for k in range(n):
+        orc.ovio_preint_push(h, dt[k], acc[k].ctypes.data, gyr[k].ctypes.data)
+    ref_pre = np.zeros(461); orc.ovio_preint_get(h, ref_pre.ctypes.data)
+    ref_r, ref_J = np.zeros(15), np.zeros(480)
+    orc.ovio_eval_imu(h, cfg.g_norm, pi.ctypes.data, sbi.ctypes.data, pj.ctypes.data, sbj.ctypes.data, ref_r.ctypes.data, ref_J.ctypes.data)
+    orc.ovio_preint_destroy(h)
+    pre, r, J = np.zeros(461), np.zeros(15), np.zeros(480)
+    rc = P.lib().vio_stage_imu_factor(C.byref(cfg), n, dt.ctypes.data, acc.ctypes.data, gyr.ctypes.data, acc0.ctypes.data, gyr0.ctypes.data,
+                                      ba.ctypes.data, bg.ctypes.data, pi.ctypes.data, sbi.ctypes.data, pj.ctypes.data, sbj.ctypes.data,
+                                      pre.ctypes.data, r.ctypes.data, J.ctypes.data)
+    assert rc == 0
+    # pre-integration: same operation order -> agreement to a few ulp (tolerance 1e-12 relative to the largest entry)
+    assert np.abs(pre - ref_pre).max() <= 1e-12 * max(1.0, np.abs(ref_pre).max())
+    # whitened residual / Jacobians go through a 15x15 inverse + Cholesky: 1e-8 relative
+    assert np.abs(r - ref_r).max() <= 1e-8 * max(1.0, np.abs(ref_r).max())
+    assert np.abs(J - ref_J).max() <= 1e-8 * max(1.0, np.abs(ref_J).max())
+
+
+@pytest.mark.parametrize("use_td", [0, 1])
+def test_projection_factor_matches_oracle(P, orc, use_td):
+    cfg = P.default_config(tr=0.01)
+    rng = np.random.default_rng(3 + use_td)
+    for _ in range(5):
+        pi = _rand_pose(rng, 0.5); pj = pi.copy(); pj[:3] += rng.normal(0, 0.1, 3)
+        dq = np.r_[rng.normal(0, 0.02, 3), 1.0]; dq /= np.linalg.norm(dq)
+        pj[3:] = pi[3:] + 0  # same rotation, small translation keeps the point in front of both cameras
+        ex = np.r_[np.array(cfg.tic[:]), 0.5, -0.5, 0.5, -0.5]
+        oi = np.r_[rng.uniform(-0.4, 0.4, 2), 1.0, rng.uniform(0, 640), rng.uniform(0, 480), rng.normal(0, 0.1, 2), 0.001, 2.0]
+        oj = np.r_[rng.uniform(-0.4, 0.4, 2), 1.0, rng.uniform(0, 640), rng.uniform(0, 480), rng.normal(0, 0.1, 2), -0.002, 2.0]
+        inv_dep, td = 1.0 / rng.uniform(1.5, 6.0), 0.003
+        r0, J0, r1, J1 = np.zeros(2), np.zeros(46), np.zeros(2), np.zeros(46)
+        orc.ovio_eval_projection(C.byref(cfg), pi.ctypes.data, pj.ctypes.data, ex.ctypes.data, inv_dep, td, oi.ctypes.data, oj.ctypes.data,
+                                 use_td, r0.ctypes.data, J0.ctypes.data)
+        rc = P.lib().vio_stage_projection(C.byref(cfg), pi.ctypes.data, pj.ctypes.data, ex.ctypes.data, inv_dep, td, oi.ctypes.data,
+                                          oj.ctypes.data, use_td, r1.ctypes.data, J1.ctypes.data)
+        assert rc == 0
+        assert np.abs(r1 - r0).max() <= 1e-11 * max(1.0, np.abs(r0).max())
+        assert np.abs(J1 - J0).max() <= 1e-11 * max(1.0, np.abs(J0).max())

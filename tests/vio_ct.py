@@ -1,0 +1,219 @@
+"""Test helpers: ctypes binding of the CPU oracle (oracle/liboracle.so), sequence drivers and trajectory metrics.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/ (it is the checker, never the
+thing measured or shipped)."""
+import ctypes as C
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+def pkg():
+    return importlib.import_module("vins-rgbd-fast_amd")
+
+
+def build_oracle():
+    r = subprocess.run(["make", "-C", ORACLE_DIR], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    return ORACLE_SO
+
+
+_orc = None
+
+
+def oracle():
+    global _orc
+    if _orc is None:
+        if not os.path.exists(ORACLE_SO):
+            build_oracle()
+        L = C.CDLL(ORACLE_SO)
+        L.ovio_pipeline_create.restype = C.c_void_p
+        L.ovio_tracker_create.restype = C.c_void_p
+        L.ovio_preint_create.restype = C.c_void_p
+        for name, args in {
+            "ovio_pipeline_create": [C.c_void_p], "ovio_pipeline_destroy": [C.c_void_p],
+            "ovio_push_imu_n": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+            "ovio_feed": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
+            "ovio_get_status": [C.c_void_p, C.c_void_p], "ovio_get_window": [C.c_void_p, C.c_void_p],
+            "ovio_get_extrinsic": [C.c_void_p, C.c_void_p], "ovio_get_landmarks": [C.c_void_p, C.c_int, C.c_void_p],
+            "ovio_get_tracks": [C.c_void_p, C.c_int] + [C.c_void_p] * 5,
+            "ovio_tracker_create": [C.c_void_p], "ovio_tracker_destroy": [C.c_void_p],
+            "ovio_tracker_read": [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int],
+            "ovio_tracker_get": [C.c_void_p, C.c_int] + [C.c_void_p] * 5,
+            "ovio_tracker_grid": [C.c_void_p, C.c_void_p, C.c_void_p],
+            "ovio_cam_lift": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+            "ovio_cam_project": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+            "ovio_pyr_down": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+            "ovio_fast_score": [C.c_void_p],
+            "ovio_fast_roi": [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p],
+            "ovio_circle_hw": [C.c_int, C.c_void_p],
+            "ovio_lk": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int],
+            "ovio_ransac": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+            "ovio_eval_projection": [C.c_void_p] * 4 + [C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+            "ovio_preint_create": [C.c_void_p] * 5, "ovio_preint_destroy": [C.c_void_p],
+            "ovio_preint_push": [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p],
+            "ovio_preint_repropagate": [C.c_void_p, C.c_void_p, C.c_void_p], "ovio_preint_get": [C.c_void_p, C.c_void_p],
+            "ovio_eval_imu": [C.c_void_p, C.c_double] + [C.c_void_p] * 6,
+            "ovio_sym_eig": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
+            "ovio_get_prior": [C.c_void_p] * 5,
+        }.items():
+            getattr(L, name).argtypes = args
+        assert L.ovio_config_size() == C.sizeof(pkg().Config), "oracle Config and vio_config layouts differ"
+        _orc = L
+    return _orc
+
+
+class OraclePipeline:
+    def __init__(self, cfg):
+        self.L = oracle()
+        self.cfg = cfg
+        self.W = cfg.window_size
+        self.h = C.c_void_p(self.L.ovio_pipeline_create(C.byref(cfg)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ovio_pipeline_destroy(self.h)
+            self.h = None
+
+    def push_imu(self, t, acc, gyr):
+        t = np.ascontiguousarray(t, np.float64); acc = np.ascontiguousarray(acc, np.float64); gyr = np.ascontiguousarray(gyr, np.float64)
+        self.L.ovio_push_imu_n(self.h, len(t), t.ctypes.data, acc.ctypes.data, gyr.ctypes.data)
+
+    def feed(self, gray, depth, t):
+        return self.L.ovio_feed(self.h, gray.ctypes.data, depth.ctypes.data, float(t))
+
+    def status(self):
+        s = np.zeros(16)
+        self.L.ovio_get_status(self.h, s.ctypes.data)
+        keys = ["solver_flag", "frame_count", "marginalization_flag", "td", "n_landmarks", "last_track_num", "reboot_count",
+                "frames_processed", "iterations", "successful_steps", "initial_cost", "final_cost", "n_in_problem", "n_residuals",
+                "n_var_landmarks", "has_prior"]
+        return dict(zip(keys, s))
+
+    def window(self):
+        w = np.zeros((self.W + 1, 17))
+        self.L.ovio_get_window(self.h, w.ctypes.data)
+        return w
+
+    def tracks(self, cap=2048):
+        ids, cnt = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        cur, un, vel = np.zeros((cap, 2), np.float32), np.zeros((cap, 2), np.float32), np.zeros((cap, 2), np.float32)
+        n = self.L.ovio_get_tracks(self.h, cap, ids.ctypes.data, cnt.ctypes.data, cur.ctypes.data, un.ctypes.data, vel.ctypes.data)
+        return ids[:n], cnt[:n], cur[:n], un[:n], vel[:n]
+
+    def landmarks(self, cap=4096):
+        out = np.zeros((cap, 7))
+        n = self.L.ovio_get_landmarks(self.h, cap, out.ctypes.data)
+        return out[:min(n, cap)]
+
+    def prior(self):
+        n = 6 * self.W + 16
+        J, r, x0, pres = np.zeros((n, n)), np.zeros(n), np.zeros(self.W * 7 + 17), np.zeros(self.W + 3, np.uint8)
+        k = self.L.ovio_get_prior(self.h, J.ctypes.data, r.ctypes.data, x0.ctypes.data, pres.ctypes.data)
+        return (J, r, x0, pres) if k else None
+
+
+class OracleTracker:
+    def __init__(self, cfg):
+        self.L = oracle()
+        self.h = C.c_void_p(self.L.ovio_tracker_create(C.byref(cfg)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ovio_tracker_destroy(self.h)
+            self.h = None
+
+    def read(self, gray, t, R=None, publish=True):
+        R = np.eye(3) if R is None else np.ascontiguousarray(R, np.float64)
+        self.L.ovio_tracker_read(self.h, gray.ctypes.data, float(t), R.ctypes.data, 1 if publish else 0)
+
+    def tracks(self, cap=2048):
+        ids, cnt = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        cur, un, vel = np.zeros((cap, 2), np.float32), np.zeros((cap, 2), np.float32), np.zeros((cap, 2), np.float32)
+        n = self.L.ovio_tracker_get(self.h, cap, ids.ctypes.data, cnt.ctypes.data, cur.ctypes.data, un.ctypes.data, vel.ctypes.data)
+        return ids[:n], cnt[:n], cur[:n], un[:n], vel[:n]
+
+
+def synth_like(cfg, **kw):
+    """vio_synth_config consistent with a vio_config (same intrinsics / extrinsics / gravity)."""
+    P = pkg()
+    sc = P.default_synth(**kw)
+    sc.width, sc.height = cfg.width, cfg.height
+    for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "g_norm"):
+        setattr(sc, k, getattr(cfg, k))
+    for i in range(9):
+        sc.ric[i] = cfg.ric[i]
+    for i in range(3):
+        sc.tic[i] = cfg.tic[i]
+    return sc
+
+
+def frame_times(sc, n):
+    return np.arange(n) / sc.cam_rate
+
+
+def imu_until(t_imu, k0, t_frame, imu_rate):
+    """index one past the last IMU sample to push before feeding the frame at t_frame (one sample beyond the stamp)."""
+    k = k0
+    lim = t_frame + 1.5 / imu_rate
+    while k < len(t_imu) and t_imu[k] < lim:
+        k += 1
+    return k
+
+
+def yaw_align(est, gt):
+    """least-squares yaw + translation alignment of est onto gt (gravity-aligned 4-DoF), returns aligned est."""
+    ec, gc = est - est.mean(0), gt - gt.mean(0)
+    num = (ec[:, 0] * gc[:, 1] - ec[:, 1] * gc[:, 0]).sum()
+    den = (ec[:, 0] * gc[:, 0] + ec[:, 1] * gc[:, 1]).sum()
+    th = np.arctan2(num, den)
+    c, s = np.cos(th), np.sin(th)
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    return (R @ ec.T).T + gt.mean(0)
+
+
+def ate_rmse(est, gt):
+    al = yaw_align(np.asarray(est), np.asarray(gt))
+    return float(np.sqrt(((al - gt) ** 2).sum(1).mean()))
+
+
+def run_oracle_sequence(cfg, sc, seq, n_frames, frames=None):
+    """Drive the oracle over n_frames of sequence seq. frames: optional list of (gray, depth) to reuse.
+    Returns dict(traj=[(frame, P(3), Q(4), V(3))], gt=..., status=[...], frames=[...])."""
+    P = pkg()
+    syn = P.Synth(sc)
+    o = OraclePipeline(cfg)
+    nimu = int(n_frames / sc.cam_rate * sc.imu_rate) + 64
+    ti, ai, gi = syn.imu(seq, nimu)
+    k = 0
+    out = dict(traj=[], gt=[], status=[], frames=[], processed=[])
+    for f, tf in enumerate(frame_times(sc, n_frames)):
+        k2 = imu_until(ti, k, tf, sc.imu_rate)
+        if k2 > k:
+            o.push_imu(ti[k:k2], ai[k:k2], gi[k:k2])
+        k = k2
+        if frames is not None:
+            g, d = frames[f]
+        else:
+            g, d = syn.render_host(seq, tf)
+        out["frames"].append((g, d))
+        r = o.feed(g, d, tf)
+        st = o.status()
+        out["status"].append(st)
+        out["processed"].append(r)
+        if st["solver_flag"] == 1 and r == 1:
+            w = o.window()
+            out["traj"].append((f, w[cfg.window_size, :3].copy(), w[cfg.window_size, 3:7].copy(), w[cfg.window_size, 7:10].copy()))
+            out["gt"].append(syn.pose(seq, tf)[0])
+    out["oracle"] = o
+    return out

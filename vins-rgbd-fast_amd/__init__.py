@@ -1,0 +1,323 @@
+"""MI355X-native VIO hot path — Python host side (ctypes over the C ABI in include/vio_abi.h).
+
+The package directory name contains hyphens, so import it with
+``importlib.import_module("vins-rgbd-fast_amd")`` (``__graft_entry__.load_package()`` does that).
+
+Nothing here computes on the CPU: every call ends in ``libvio_hip.so`` and fails with ``VioError`` when the
+extension is missing or no GPU is present.  PyTorch is optional and only used as a source of device pointers.
+
+Mirrors of the reference interface (same names / argument meaning):
+  FeatureTracker.readImage / updateID      vins_estimator/src/feature_tracker/feature_tracker.h:36-47
+  Estimator.inputIMU / processImage / ...   vins_estimator/src/estimator/estimator.h:29-60
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libvio_hip.so")
+
+VIO_OK, VIO_NEED_IMU, VIO_REBOOTED = 0, 1, 2
+VIO_EINVAL, VIO_EDEVICE, VIO_ECAPACITY = -1, -2, -3
+
+
+class VioError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    """vio_config (include/vio_abi.h); same field order as oracle ovio::Config."""
+    _fields_ = [(n, C.c_int32) for n in (
+        "width", "height", "max_cnt", "min_dist", "grid_rows", "grid_cols", "window_size", "max_landmarks", "fix_depth",
+        "estimate_extrinsic", "estimate_td", "max_iterations", "ransac_max_iters", "lk_max_level", "reserved0")] + \
+        [(n, C.c_double) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "focal_length", "f_threshold", "depth_min",
+                                   "depth_max", "acc_n", "acc_w", "gyr_n", "gyr_w", "g_norm")] + \
+        [("ric", C.c_double * 9), ("tic", C.c_double * 3)] + \
+        [(n, C.c_double) for n in ("td", "tr", "min_parallax_px", "init_depth")]
+
+
+class SynthConfig(C.Structure):
+    """vio_synth_config (include/vio_synth.h)."""
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32)] + \
+        [(n, C.c_double) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2")] + \
+        [("ric", C.c_double * 9), ("tic", C.c_double * 3)] + \
+        [(n, C.c_double) for n in ("g_norm", "imu_rate", "cam_rate", "t_static", "acc_noise", "gyr_noise", "acc_bias_walk",
+                                   "gyr_bias_walk")] + [("seed", C.c_uint64)]
+
+
+class Status(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "code", "solver_flag", "frame_count", "marginalization_flag", "n_landmarks", "last_track_num", "n_tracks", "processed",
+        "iterations", "successful_steps", "n_in_problem", "n_residuals", "n_var_landmarks", "has_prior", "reboot_count",
+        "frames_processed")] + [(n, C.c_double) for n in ("initial_cost", "final_cost", "td")]
+
+
+def build(verbose=False):
+    """Compile libvio_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-j8", "-C", os.path.join(_HERE, "csrc")], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise VioError("hipcc build failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+    if verbose:
+        print(r.stdout[-2000:])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libvio_hip.so (no CPU fallback: raises if the extension is missing)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise VioError("libvio_hip.so is not built: run __graft_entry__.build() (the product path has no CPU fallback)")
+        L = C.CDLL(_LIB_PATH)
+        L.vio_create.restype = C.c_void_p
+        L.vio_create.argtypes = [C.POINTER(Config), C.c_int, C.c_int]
+        L.vio_destroy.argtypes = [C.c_void_p]
+        L.vio_last_error.restype = C.c_char_p
+        L.vio_reset.argtypes = [C.c_void_p]
+        L.vio_push_imu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vio_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.vio_track.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.vio_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.vio_sync.argtypes = [C.c_void_p]
+        L.vio_get_stream.restype = C.c_void_p
+        L.vio_get_stream.argtypes = [C.c_void_p]
+        L.vio_get_status.argtypes = [C.c_void_p, C.c_int, C.POINTER(Status)]
+        L.vio_get_window.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.vio_get_odometry.argtypes = [C.c_void_p, C.c_void_p]
+        L.vio_get_extrinsic.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.vio_get_tracks.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
+        L.vio_get_landmarks.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.vio_get_prior.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
+        L.vio_get_timings.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.vio_synth_pose.argtypes = [C.POINTER(SynthConfig), C.c_uint64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vio_synth_imu.argtypes = [C.POINTER(SynthConfig), C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vio_synth_render_host.argtypes = [C.POINTER(SynthConfig), C.c_uint64, C.c_double, C.c_void_p, C.c_void_p]
+        L.vio_synth_render_device.argtypes = [C.POINTER(SynthConfig), C.c_int, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vio_stage_pyr_down.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.vio_stage_fast_roi.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
+        L.vio_stage_lk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vio_stage_ransac.argtypes = [C.POINTER(Config), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vio_stage_imu_factor.argtypes = [C.POINTER(Config), C.c_int] + [C.c_void_p] * 14
+        L.vio_stage_projection.argtypes = [C.POINTER(Config)] + [C.c_void_p] * 3 + [C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                                                                  C.c_int, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def default_config(**kw):
+    c = Config()
+    lib().vio_config_default(C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def canonical_config(**kw):
+    """BASELINE config 2/3: 640x480, 150 features, 5x6 grid, W = 10; landmarks are optimisation variables
+    (fix_depth 0, depth range as in config/realsense/vio_campus.yaml which is the upstream 150-feature setting)."""
+    d = dict(fix_depth=0, depth_max=10.0)
+    d.update(kw)
+    return default_config(**d)
+
+
+def default_synth(**kw):
+    c = SynthConfig()
+    lib().vio_synth_config_default(C.byref(c))
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):  # torch tensor (device or host)
+        return a.data_ptr()
+    return a
+
+
+class Synth:
+    """Synthetic RGB-D + IMU workload."""
+
+    def __init__(self, cfg=None):
+        self.cfg = cfg or default_synth()
+        self.L = lib()
+
+    def pose(self, seq, t):
+        p, R, v = np.zeros(3), np.zeros(9), np.zeros(3)
+        self.L.vio_synth_pose(C.byref(self.cfg), seq, t, p.ctypes.data, R.ctypes.data, v.ctypes.data)
+        return p, R.reshape(3, 3), v
+
+    def imu(self, seq, n):
+        t, a, g = np.zeros(n), np.zeros((n, 3)), np.zeros((n, 3))
+        self.L.vio_synth_imu(C.byref(self.cfg), seq, n, t.ctypes.data, a.ctypes.data, g.ctypes.data)
+        return t, a, g
+
+    def render_host(self, seq, t):
+        g = np.zeros((self.cfg.height, self.cfg.width), np.uint8)
+        d = np.zeros((self.cfg.height, self.cfg.width), np.uint16)
+        self.L.vio_synth_render_host(C.byref(self.cfg), seq, t, g.ctypes.data, d.ctypes.data)
+        return g, d
+
+    def render_device(self, n_seq, seq0, t, d_gray, d_depth, stream=None):
+        rc = self.L.vio_synth_render_device(C.byref(self.cfg), n_seq, seq0, t, _ptr(d_gray), _ptr(d_depth), stream)
+        if rc != 0:
+            raise VioError("vio_synth_render_device failed (%d)" % rc)
+
+
+class VioBatch:
+    """A batch of S independent sequences resident in HBM (vio_batch)."""
+
+    def __init__(self, cfg=None, n_seq=1, imu_capacity=8192):
+        self.L = lib()
+        self.cfg = cfg or default_config()
+        self.S = n_seq
+        self.W = self.cfg.window_size
+        self.h = self.L.vio_create(C.byref(self.cfg), n_seq, imu_capacity)
+        if not self.h:
+            raise VioError("vio_create failed: %s" % self.L.vio_last_error().decode())
+        self.h = C.c_void_p(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.vio_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise VioError("%s failed (%d): %s" % (what, rc, self.L.vio_last_error().decode()))
+        return rc
+
+    def push_imu(self, seq, t, acc, gyr):
+        t = np.ascontiguousarray(t, np.float64).reshape(-1)
+        acc = np.ascontiguousarray(acc, np.float64).reshape(-1, 3)
+        gyr = np.ascontiguousarray(gyr, np.float64).reshape(-1, 3)
+        self._chk(self.L.vio_push_imu(self.h, seq, len(t), t.ctypes.data, acc.ctypes.data, gyr.ctypes.data), "vio_push_imu")
+
+    def feed(self, gray, depth, stamps, on_device=False):
+        stamps = np.ascontiguousarray(stamps, np.float64).reshape(-1)
+        assert len(stamps) == self.S
+        self._keep = (gray, depth, stamps)
+        self._chk(self.L.vio_feed(self.h, _ptr(gray), _ptr(depth), stamps.ctypes.data, 1 if on_device else 0), "vio_feed")
+
+    def track(self, gray, stamps, publish=True, on_device=False):
+        stamps = np.ascontiguousarray(stamps, np.float64).reshape(-1)
+        self._keep = (gray, stamps)
+        self._chk(self.L.vio_track(self.h, _ptr(gray), stamps.ctypes.data, 1 if publish else 0, 1 if on_device else 0), "vio_track")
+
+    def process(self, depth, on_device=False):
+        self._keep2 = depth
+        self._chk(self.L.vio_process(self.h, _ptr(depth), 1 if on_device else 0), "vio_process")
+
+    def sync(self):
+        self._chk(self.L.vio_sync(self.h), "vio_sync")
+
+    def reset(self):
+        self._chk(self.L.vio_reset(self.h), "vio_reset")
+
+    def stream(self):
+        return self.L.vio_get_stream(self.h)
+
+    def status(self, seq=0):
+        s = Status()
+        self._chk(self.L.vio_get_status(self.h, seq, C.byref(s)), "vio_get_status")
+        return s
+
+    def window(self, seq=0):
+        w = np.zeros((self.W + 1, 17))
+        self._chk(self.L.vio_get_window(self.h, seq, w.ctypes.data), "vio_get_window")
+        return w
+
+    def odometry(self):
+        o = np.zeros((self.S, 11))
+        self._chk(self.L.vio_get_odometry(self.h, o.ctypes.data), "vio_get_odometry")
+        return o
+
+    def extrinsic(self, seq=0):
+        e = np.zeros(13)
+        self._chk(self.L.vio_get_extrinsic(self.h, seq, e.ctypes.data), "vio_get_extrinsic")
+        return e
+
+    def tracks(self, seq=0, cap=2048):
+        ids, cnt = np.zeros(cap, np.int32), np.zeros(cap, np.int32)
+        cur, un, vel = np.zeros((cap, 2), np.float32), np.zeros((cap, 2), np.float32), np.zeros((cap, 2), np.float32)
+        n = self._chk(self.L.vio_get_tracks(self.h, seq, cap, ids.ctypes.data, cnt.ctypes.data, cur.ctypes.data, un.ctypes.data,
+                                            vel.ctypes.data), "vio_get_tracks")
+        return ids[:n], cnt[:n], cur[:n], un[:n], vel[:n]
+
+    def landmarks(self, seq=0, cap=4096):
+        out = np.zeros((cap, 7))
+        n = self._chk(self.L.vio_get_landmarks(self.h, seq, cap, out.ctypes.data), "vio_get_landmarks")
+        return out[:min(n, cap)]
+
+    def prior(self, seq=0):
+        n = 6 * self.W + 16
+        J, r, x0, pres = np.zeros((n, n)), np.zeros(n), np.zeros(self.W * 7 + 17), np.zeros(self.W + 3, np.uint8)
+        k = self._chk(self.L.vio_get_prior(self.h, seq, J.ctypes.data, r.ctypes.data, x0.ctypes.data, pres.ctypes.data), "vio_get_prior")
+        return (J, r, x0, pres) if k else None
+
+    def timings(self):
+        t = np.zeros(8)
+        n = self._chk(self.L.vio_get_timings(self.h, 8, t.ctypes.data), "vio_get_timings")
+        return t[:n]
+
+
+# ------------------------------------------------------------------------------------------------ reference-shaped mirrors
+class FeatureTracker:
+    """FeatureTracker (feature_tracker.h:31-97) backed by one HBM-resident sequence."""
+
+    def __init__(self, batch, seq=0):
+        self.b, self.seq = batch, seq
+        self.ids = self.track_cnt = self.cur_pts = self.cur_un_pts = self.pts_velocity = None
+
+    def readImage(self, img, cur_time, relative_R=None, publish=True):
+        """readImage(const cv::Mat&, double, const Matrix3d&): relative_R is computed on the device from the pushed IMU
+        samples (Estimator::predictMotion), so it is not an input here."""
+        assert self.b.S == 1, "the per-sequence mirror drives single-sequence batches"
+        self.b.track(np.ascontiguousarray(img, np.uint8), [cur_time], publish=publish)
+        self.ids, self.track_cnt, self.cur_pts, self.cur_un_pts, self.pts_velocity = self.b.tracks(self.seq)
+
+    def updateID(self, i):
+        """ids are assigned on the device inside readImage; kept for call-site compatibility (estimator_nodelet.cpp:324-330)."""
+        return i < len(self.ids)
+
+
+class Estimator:
+    """Estimator (estimator.h:25-201) call surface backed by one HBM-resident sequence."""
+
+    def __init__(self, cfg=None, imu_capacity=8192):
+        self.batch = VioBatch(cfg, 1, imu_capacity)
+        self.featureTracker = FeatureTracker(self.batch)
+
+    def inputIMU(self, t, linearAcceleration, angularVelocity):
+        self.batch.push_imu(0, [t], [linearAcceleration], [angularVelocity])
+
+    def processImage(self, depth_mm):
+        """processImage(map<int, Matrix<double,7,1>>&, header): the feature map was packaged on the device by readImage."""
+        self.batch.process(np.ascontiguousarray(depth_mm, np.uint16))
+        return self.batch.status(0).code
+
+    def clearState(self):
+        self.batch.reset()
+
+    setParameter = clearState
+
+    @property
+    def solver_flag(self):
+        return self.batch.status(0).solver_flag
+
+    def window(self):
+        return self.batch.window(0)

@@ -1,0 +1,1896 @@
+// Back-end kernels (gfx950, FP64): Estimator::processImage (vins_estimator/src/estimator/estimator.cpp:156-374) batched
+// over S sequences, one workgroup per sequence, four launches per frame:
+//   be_ingest  addFeatureCheckParallax (feature_manager.cpp:56-123), getIMUInterval/processIMU (estimator.cpp:118-154,
+//              1910-1942, IntegrationBase::propagate), triangulateWithDepth (feature_manager.cpp:386-543)
+//   be_solve   optimization() (estimator.cpp:1161-1368): the Ceres DENSE_SCHUR + traditional-DOGLEG solve replaced by a
+//              bespoke trust-region (dogleg / LM-regularised Gauss-Newton) solver: batched residual/Jacobian evaluation,
+//              frame-pair blocked J^T J, landmark Schur complement, dense Cholesky, step control as SURVEY.md App. B.5
+//   be_marg    marginalisation (estimator.cpp:1370-1575, marginalization_factor.cpp:181-315) in the canonical layout
+//   be_finish  movingConsistencyCheck, failureDetection, slideWindow, removeFailures, odometry row
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "be_factors.h"
+
+using namespace dm;
+
+namespace {
+
+struct Ctx {
+    const DevCfg *C;
+    int s, W, P, LW, NL, NPR;
+    BeSeq *be;
+    FeSeq *fe;
+    PreInt *pre;
+    int *lm_id, *lm_start, *lm_nobs, *lm_est, *lm_solve, *lm_dyn, *lm_order, *lm_free, *lm_tmp, *lm_pidx, *lm_aidx;
+    double *lm_depth, *lm_obs, *feat, *cfeat;
+    double *H, *Sc, *Hpl, *vec, *Hll, *gl, *lvec, *res;
+    int *res_lm, *res_k, *pair_start, *pair_list;
+    double *pairblk, *imu_raw;
+    double *prior_J, *prior_r, *prior_x0, *prior_H;
+    double *margA, *margB, *margV, *margW;
+    int nres_cap;
+};
+
+__device__ Ctx make_ctx(const Batch &B, int s) {
+    Ctx c;
+    const DevCfg &C = *B.cfg;
+    c.C = B.cfg; c.s = s; c.W = C.W; c.P = C.P; c.LW = C.LW; c.NL = C.NL; c.NPR = C.NPRIOR;
+    c.be = B.be + s; c.fe = B.fe + s;
+    c.pre = B.pre + (size_t)s * (C.W + 2);
+    size_t o = (size_t)s * C.NL;
+    c.lm_id = B.lm_id + o; c.lm_start = B.lm_start + o; c.lm_nobs = B.lm_nobs + o; c.lm_est = B.lm_est_flag + o;
+    c.lm_solve = B.lm_solve_flag + o; c.lm_dyn = B.lm_dyn + o; c.lm_order = B.lm_order + o; c.lm_free = B.lm_free + o;
+    c.lm_tmp = B.lm_tmp + o; c.lm_pidx = B.lm_pidx + o; c.lm_aidx = B.lm_aidx + o;
+    c.lm_depth = B.lm_depth + o; c.feat = B.para_feat + o; c.cfeat = B.cand_feat + o;
+    c.lm_obs = B.lm_obs + o * (C.W + 1) * VIO_OBS_D;
+    c.H = B.H + (size_t)s * C.LW * C.LW; c.Sc = B.Sc + (size_t)s * C.LW * C.LW; c.Hpl = B.Hpl + o * C.LW;
+    c.vec = B.vec + (size_t)s * VEC_SLOTS * C.LW;
+    c.Hll = B.Hll + o; c.gl = B.gl + o; c.lvec = B.lvec + o * 8;
+    c.nres_cap = 4 * C.NL;
+    c.res = B.res + (size_t)s * c.nres_cap * 42;
+    c.res_lm = B.res_lm + (size_t)s * c.nres_cap; c.res_k = B.res_k + (size_t)s * c.nres_cap;
+    int np = (C.W + 1) * (C.W + 1);
+    c.pair_start = B.pair_start + (size_t)s * (np + 1); c.pair_list = B.pair_list + (size_t)s * c.nres_cap;
+    c.pairblk = B.pairblk + (size_t)s * np * 210;
+    c.imu_raw = B.imu_raw + (size_t)s * C.W * 15 * 31;
+    int n = C.NPRIOR;
+    c.prior_J = B.prior_J + (size_t)s * n * n; c.prior_r = B.prior_r + (size_t)s * n;
+    c.prior_x0 = B.prior_x0 + (size_t)s * (C.W * 7 + 17); c.prior_H = B.prior_H + (size_t)s * n * n;
+    int mq = 15 + n;
+    c.margA = B.margA + (size_t)s * mq * mq; c.margB = B.margB + (size_t)s * mq;
+    c.margV = B.margV + (size_t)s * n * n; c.margW = B.margW + (size_t)s * (n + 16) * (n + 16);
+    return c;
+}
+
+__device__ __forceinline__ double *obs_ptr(const Ctx &c, int slot, int frame) {
+    int W1 = c.W + 1;
+    int ph = (frame + c.be->ring_base) % W1;
+    return c.lm_obs + ((size_t)slot * W1 + ph) * VIO_OBS_D;
+}
+__device__ __forceinline__ bool in_problem(const Ctx &c, int slot) {
+    return !c.lm_dyn[slot] && c.lm_nobs[slot] >= 2 && c.lm_start[slot] < c.W - 2;
+}
+
+// deterministic block-wide sum; all threads get the result. sred: blockDim doubles of LDS
+__device__ double block_sum(double v, double *sred) {
+    int t = threadIdx.x;
+    __syncthreads();
+    sred[t] = v;
+    __syncthreads();
+    for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
+        if (t < off) sred[t] += sred[t + off];
+        __syncthreads();
+    }
+    double r = sred[0];
+    __syncthreads();
+    return r;
+}
+__device__ int block_scan_flags(const int *flags, int n, int *offs, int *scratch) {
+    int nt = blockDim.x, t = threadIdx.x;
+    int chunk = (n + nt - 1) / nt;
+    int b = t * chunk, e = min(n, b + chunk);
+    int sum = 0;
+    for (int i = b; i < e; i++) sum += flags[i];
+    __syncthreads();
+    scratch[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        for (int i = 0; i < nt; i++) { int v = scratch[i]; scratch[i] = acc; acc += v; }
+        scratch[nt] = acc;
+    }
+    __syncthreads();
+    int o = scratch[t];
+    for (int i = b; i < e; i++) { offs[i] = o; o += flags[i]; }
+    int total = scratch[nt];
+    __syncthreads();
+    return total;
+}
+
+// ------------------------------------------------------------------ IntegrationBase::propagate, block-cooperative
+// LDS workspace: sJ sP sFJ sFP (225 each) sF (225) sV (270)
+struct PreWork { double J[225], Pm[225], FJ[225], FP[225], F[225], V[270]; };
+__device__ void preint_load(const PreInt &p, PreWork &w) {
+    for (int i = threadIdx.x; i < 225; i += blockDim.x) { w.J[i] = p.jac[i]; w.Pm[i] = p.cov[i]; }
+    __syncthreads();
+}
+__device__ void preint_store(PreInt &p, const PreWork &w) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 225; i += blockDim.x) { p.jac[i] = w.J[i]; p.cov[i] = w.Pm[i]; }
+    __syncthreads();
+}
+// one propagate(dt, acc, gyr) on the LDS-resident jacobian/covariance; p's small state is updated by thread 0
+__device__ void preint_propagate(PreInt &p, PreWork &w, const vio_config &c, double dt, v3 acc1, v3 gyr1) {
+    const int t = threadIdx.x;
+    if (t == 0) {
+        bf::PreintStep o = bf::preint_midpoint(p, dt, acc1, gyr1, w.F, w.V);
+        st3(p.dp, o.dp); st3(p.dv, o.dv);
+        quat q = qnormalized(o.dq);
+        p.dq[0] = q.w; p.dq[1] = q.x; p.dq[2] = q.y; p.dq[3] = q.z;
+        p.sum_dt += dt;
+        st3(p.acc0, acc1); st3(p.gyr0, gyr1);
+    }
+    __syncthreads();
+    if (t < 225) {
+        int i = t / 15, j = t - i * 15;
+        double s = 0, s2 = 0;
+        for (int k = 0; k < 15; k++) { s += w.F[i * 15 + k] * w.J[k * 15 + j]; s2 += w.F[i * 15 + k] * w.Pm[k * 15 + j]; }
+        w.FJ[t] = s; w.FP[t] = s2;
+    }
+    __syncthreads();
+    if (t < 225) {
+        int i = t / 15, j = t - i * 15;
+        double s = 0;
+        for (int k = 0; k < 15; k++) s += w.FP[i * 15 + k] * w.F[j * 15 + k];
+        double nn[6] = {c.acc_n * c.acc_n, c.gyr_n * c.gyr_n, c.acc_n * c.acc_n, c.gyr_n * c.gyr_n, c.acc_w * c.acc_w, c.gyr_w * c.gyr_w};
+        double tt = 0;
+        for (int k = 0; k < 18; k++) tt += w.V[i * 18 + k] * nn[k / 3] * w.V[j * 18 + k];
+        w.J[t] = w.FJ[t];
+        w.Pm[t] = s + tt;
+    }
+    __syncthreads();
+}
+
+// 4x4 / small symmetric cyclic Jacobi (row-cyclic, as oracle/om.h sym_eig); A destroyed, eigenvalues unsorted in A diag
+__device__ void jacobi_small(double *A, double *V, int n) {
+    for (int i = 0; i < n * n; i++) V[i] = 0;
+    for (int i = 0; i < n; i++) V[i * n + i] = 1;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; i++) {
+            diag += A[i * n + i] * A[i * n + i];
+            for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+        }
+        if (off <= 1e-30 * (diag + 1e-300) || off == 0.0) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                double app = A[p * n + p], aqq = A[q * n + q];
+                double tau = (aqq - app) / (2.0 * apq);
+                double tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                double cs = 1.0 / sqrt(1.0 + tt * tt), sn = tt * cs;
+                for (int k = 0; k < n; k++) {
+                    double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = cs * akp - sn * akq;
+                    A[k * n + q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = cs * apk - sn * aqk;
+                    A[q * n + k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = cs * vkp - sn * vkq;
+                    V[k * n + q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+}
+
+// Parallel two-sided Jacobi (round-robin ordering) on a symmetric n x n matrix A (ld = n), V = eigenvectors (columns).
+// All threads of the block participate. cs/sn: LDS arrays of n/2+1 doubles; sred: blockDim doubles.
+__device__ void jacobi_block(double *A, double *V, int n, double *cs, double *sn, int *pp, int *qq, double *sred) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    for (int i = t; i < n * n; i += nt) V[i] = ((i / n) == (i % n)) ? 1.0 : 0.0;
+    __syncthreads();
+    const int m = (n + 1) & ~1;  // even number of players (one bye if n is odd)
+    const int half = m / 2;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0, dg = 0;
+        for (int i = t; i < n * n; i += nt) {
+            int r = i / n, cc = i - r * n;
+            double v = A[i];
+            if (r == cc) dg += v * v; else if (cc > r) off += v * v;
+        }
+        off = block_sum(off, sred);
+        dg = block_sum(dg, sred);
+        if (off <= 1e-30 * (dg + 1e-300) || off == 0.0) break;
+        for (int round = 0; round < m - 1; round++) {
+            // chess-tournament pairing: player m-1 fixed, others rotate
+            if (t < half) {
+                int a = (t == 0) ? m - 1 : (round + t) % (m - 1);
+                int b = (round + m - 1 - t) % (m - 1);
+                if (t == 0) b = round % (m - 1);
+                int p = min(a, b), q = max(a, b);
+                double c1 = 1.0, s1 = 0.0;
+                if (q < n) {
+                    double apq = A[p * n + q];
+                    if (apq != 0.0) {
+                        double app = A[p * n + p], aqq = A[q * n + q];
+                        double tau = (aqq - app) / (2.0 * apq);
+                        double tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c1 = 1.0 / sqrt(1.0 + tt * tt);
+                        s1 = tt * c1;
+                    }
+                } else { p = -1; }
+                pp[t] = p; qq[t] = q; cs[t] = c1; sn[t] = s1;
+            }
+            __syncthreads();
+            // columns: A <- A J, V <- V J
+            for (int w = t; w < half * n; w += nt) {
+                int k = w / n, r = w - k * n;
+                int p = pp[k], q = qq[k];
+                if (p < 0 || sn[k] == 0.0) continue;
+                double c1 = cs[k], s1 = sn[k];
+                double akp = A[r * n + p], akq = A[r * n + q];
+                A[r * n + p] = c1 * akp - s1 * akq;
+                A[r * n + q] = s1 * akp + c1 * akq;
+                double vkp = V[r * n + p], vkq = V[r * n + q];
+                V[r * n + p] = c1 * vkp - s1 * vkq;
+                V[r * n + q] = s1 * vkp + c1 * vkq;
+            }
+            __syncthreads();
+            // rows: A <- J^T A
+            for (int w = t; w < half * n; w += nt) {
+                int k = w / n, cc = w - k * n;
+                int p = pp[k], q = qq[k];
+                if (p < 0 || sn[k] == 0.0) continue;
+                double c1 = cs[k], s1 = sn[k];
+                double apk = A[p * n + cc], aqk = A[q * n + cc];
+                A[p * n + cc] = c1 * apk - s1 * aqk;
+                A[q * n + cc] = s1 * apk + c1 * aqk;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+}
+
+// in-place lower Cholesky of the n x n matrix A (ld), right-looking; returns false if a pivot is not positive
+__device__ bool chol_block(double *A, int n, int ld, int *sh_flag) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    if (t == 0) *sh_flag = 1;
+    __syncthreads();
+    for (int j = 0; j < n; j++) {
+        if (t == 0) {
+            double d = A[j * ld + j];
+            if (!(d > 0.0) || !isfinite(d)) *sh_flag = 0; else A[j * ld + j] = sqrt(d);
+        }
+        __syncthreads();
+        if (!*sh_flag) return false;
+        double l = A[j * ld + j];
+        for (int i = j + 1 + t; i < n; i += nt) A[i * ld + j] /= l;
+        __syncthreads();
+        int m = n - j - 1;
+        for (int w = t; w < m * m; w += nt) {
+            int r = w / m, cc = w - r * m;
+            if (cc > r) continue;
+            int i = j + 1 + r, k = j + 1 + cc;
+            A[i * ld + k] -= A[i * ld + j] * A[k * ld + j];
+        }
+        __syncthreads();
+    }
+    return true;
+}
+// solve L L^T x = b with one wavefront (lanes own strided entries of x held in LDS xs)
+__device__ void chol_solve_wave(const double *L, int n, int ld, double *xs) {
+    const int t = threadIdx.x;
+    if (t < 64) {
+        for (int j = 0; j < n; j++) {
+            double xj = xs[j] / L[j * ld + j];
+            __builtin_amdgcn_wave_barrier();
+            if (t == 0) xs[j] = xj;
+            for (int i = j + 1 + t; i < n; i += 64) xs[i] -= L[i * ld + j] * xj;
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
+        for (int j = n - 1; j >= 0; j--) {
+            double xj = xs[j] / L[j * ld + j];
+            __builtin_amdgcn_wave_barrier();
+            if (t == 0) xs[j] = xj;
+            for (int i = t; i < j; i += 64) xs[i] -= L[j * ld + i] * xj;
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
+    }
+    __syncthreads();
+}
+
+// stable compaction of the landmark order list; flags[k] = keep. Freed slots go back to the free stack.
+__device__ void lm_compact(Ctx &c, int *flags, int *offs, int *scratch) {
+    int n = c.be->n_lm;
+    int kept = block_scan_flags(flags, n, offs, scratch);
+    const int t = threadIdx.x, nt = blockDim.x;
+    int nfree0 = c.be->n_free;
+    for (int k = t; k < n; k += nt) c.lm_tmp[k] = c.lm_order[k];
+    __syncthreads();
+    for (int k = t; k < n; k += nt) {
+        int slot = c.lm_tmp[k];
+        if (flags[k]) c.lm_order[offs[k]] = slot;
+        else c.lm_free[nfree0 + (k - offs[k])] = slot;
+    }
+    __syncthreads();
+    if (t == 0) { c.be->n_lm = kept; c.be->n_free = nfree0 + (n - kept); }
+    __syncthreads();
+}
+
+}  // namespace
+
+// ====================================================================================================== be_ingest
+__global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t *depth_base, size_t depth_stride) {
+    const int s = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+    Ctx c = make_ctx(B, s);
+    const DevCfg &C = *B.cfg;
+    const vio_config &cfg = C.c;
+    BeSeq &be = *c.be;
+    FeSeq &fe = *c.fe;
+    const int W = c.W;
+    __shared__ int sh_i[8];
+    __shared__ double sh_d[8];
+    __shared__ int scratch[260];
+    __shared__ double sred[256];
+    __shared__ PreWork pw;
+    if (t == 0) { be.do_solve = 0; be.do_marg = 0; be.processed = 0; }
+    if (fe.n_forw < 0 || !fe.publish_ok) return;
+    // ---- IMU availability (estimator.cpp:178-183, :1882-1888)
+    const double *it = B.imu_t + (size_t)s * C.NIMU;
+    const double *ia = B.imu_acc + (size_t)s * C.NIMU * 3, *ig = B.imu_gyr + (size_t)s * C.NIMU * 3;
+    double stamp = be.cur_stamp, curTime = stamp + be.td;
+    {
+        bool have = be.imu_count > be.imu_head;
+        double back_t = have ? it[(be.imu_count - 1) % C.NIMU] : -1e300;
+        if (!(have && curTime <= back_t)) {
+            if (t == 0) be.status_code = VIO_NEED_IMU;
+            return;
+        }
+    }
+    const uint16_t *depth = depth_base + (size_t)s * depth_stride;
+    const int fc = be.frame_count;
+    // ---- addFeatureCheckParallax (feature_manager.cpp:56-123)
+    int nobs = fe.n_obs, nlm = be.n_lm;
+    const int *o_id = B.obs_id + (size_t)s * C.NP;
+    const double *o = B.obs + (size_t)s * C.NP * 7;
+    int *flag = c.lm_tmp;         // new-landmark flags per observation (NP <= NL is checked at create)
+    int *offs = c.lm_pidx;        // temporary
+    int tracked = 0;
+    for (int j = t; j < nobs; j += nt) {
+        const double *p = o + (size_t)j * 7;
+        unsigned short mm = depth[(size_t)(int)p[4] * cfg.width + (int)p[3]];
+        double dmm = mm / 1000.0;
+        int isnew = 0;
+        if (!(0 < dmm && dmm < cfg.depth_min)) {
+            int fid = o_id[j];
+            int lo = 0, hi = nlm - 1, found = -1;
+            while (lo <= hi) {
+                int mid = (lo + hi) >> 1;
+                int v = c.lm_id[c.lm_order[mid]];
+                if (v == fid) { found = c.lm_order[mid]; break; }
+                if (v < fid) lo = mid + 1; else hi = mid - 1;
+            }
+            if (found >= 0) {
+                int k = c.lm_nobs[found];
+                if (k <= W) {
+                    double *q = obs_ptr(c, found, c.lm_start[found] + k);
+                    for (int d = 0; d < 7; d++) q[d] = p[d];
+                    q[7] = be.td; q[8] = dmm;
+                    c.lm_nobs[found] = k + 1;
+                }
+                tracked++;
+            } else
+                isnew = 1;
+        }
+        flag[j] = isnew;
+    }
+    __syncthreads();
+    {
+        double tr = block_sum((double)tracked, sred);
+        if (t == 0) be.last_track_num = (int)tr;
+    }
+    int nnew = block_scan_flags(flag, nobs, offs, scratch);
+    {
+        int nfree = be.n_free;
+        int can = min(nnew, nfree);
+        for (int j = t; j < nobs; j += nt) {
+            if (!flag[j] || offs[j] >= can) continue;
+            int slot = c.lm_free[nfree - 1 - offs[j]];
+            const double *p = o + (size_t)j * 7;
+            unsigned short mm = depth[(size_t)(int)p[4] * cfg.width + (int)p[3]];
+            c.lm_id[slot] = o_id[j]; c.lm_start[slot] = fc; c.lm_nobs[slot] = 1; c.lm_est[slot] = 0; c.lm_solve[slot] = 0;
+            c.lm_dyn[slot] = 0; c.lm_depth[slot] = -1.0;
+            double *q = obs_ptr(c, slot, fc);
+            for (int d = 0; d < 7; d++) q[d] = p[d];
+            q[7] = be.td; q[8] = mm / 1000.0;
+            c.lm_order[nlm + offs[j]] = slot;
+        }
+        __syncthreads();
+        if (t == 0) {
+            be.n_lm = nlm + can; be.n_free = nfree - can;
+            if (can < nnew) be.overflow |= 1;
+        }
+        __syncthreads();
+        nlm = be.n_lm;
+    }
+    // parallax (:100-122, :732-768)
+    {
+        double psum = 0, pnum = 0;
+        if (!(fc < 2 || be.last_track_num < 20)) {
+            for (int k = t; k < nlm; k += nt) {
+                int slot = c.lm_order[k];
+                int st = c.lm_start[slot], no = c.lm_nobs[slot];
+                if (st <= fc - 2 && st + no - 1 >= fc - 1) {
+                    const double *fi = obs_ptr(c, slot, fc - 2), *fj = obs_ptr(c, slot, fc - 1);
+                    double dep_i = fi[2], u_i = fi[0] / dep_i, v_i = fi[1] / dep_i;
+                    double du = u_i - fj[0], dv = v_i - fj[1];
+                    psum += fmax(0.0, sqrt(fmin(du * du + dv * dv, du * du + dv * dv)));
+                    pnum += 1.0;
+                }
+            }
+        }
+        psum = block_sum(psum, sred);
+        pnum = block_sum(pnum, sred);
+        if (t == 0) {
+            bool kf;
+            if (fc < 2 || be.last_track_num < 20) kf = true;
+            else if (pnum == 0) kf = true;
+            else kf = psum / pnum >= cfg.min_parallax_px / cfg.focal_length;
+            be.marginalization_flag = kf ? 0 : 1;
+            be.Headers[fc] = stamp;
+        }
+        __syncthreads();
+    }
+    // ---- getIMUInterval + processIMU (estimator.cpp:185-200, 1910-1942, 118-154)
+    if (t == 0) {
+        int head = be.imu_head;
+        while (head < be.imu_count && it[head % C.NIMU] <= be.prevTime) head++;
+        int k = head;
+        while (k < be.imu_count && it[k % C.NIMU] < curTime) k++;
+        sh_i[0] = head;          // first sample of the interval
+        sh_i[1] = k - head + 1;  // number of samples incl. the first one with t >= curTime
+        be.imu_head = k;         // that last sample is not popped
+        be.n_imu_frame = sh_i[1];
+        if (!be.initFirstPoseFlag) {  // initFirstIMUPose :1890-1909
+            v3 aver = mk(0, 0, 0);
+            for (int q = 0; q < sh_i[1]; q++) aver = add(aver, ld3(ia + (size_t)((head + q) % C.NIMU) * 3));
+            aver = scl(1.0 / (double)sh_i[1], aver);
+            m3 R0 = g2R(aver);
+            double yaw = R2ypr(R0).x;
+            R0 = mul(ypr2R(mk(-yaw, 0, 0)), R0);
+            stm(be.Rs[0], R0);
+            be.initFirstPoseFlag = 1;
+        }
+    }
+    __syncthreads();
+    {
+        int head = sh_i[0], n = sh_i[1];
+        PreInt &P = c.pre[be.pre_idx[fc]];
+        if (t == 0) {
+            v3 a0 = ld3(ia + (size_t)(head % C.NIMU) * 3), g0 = ld3(ig + (size_t)(head % C.NIMU) * 3);
+            if (!be.first_imu) { be.first_imu = 1; st3(be.acc_0, a0); st3(be.gyr_0, g0); }
+            if (!P.valid) bf::preint_init(P, ld3(be.acc_0), ld3(be.gyr_0), ld3(be.Bas[fc]), ld3(be.Bgs[fc]));
+        }
+        __syncthreads();
+        if (fc != 0) preint_load(P, pw);
+        for (int q = 0; q < n; q++) {
+            int idx = (head + q) % C.NIMU;
+            double tq = it[idx];
+            double dt;
+            if (q == 0) dt = tq - be.prevTime;
+            else if (q == n - 1) dt = curTime - it[(head + q - 1) % C.NIMU];
+            else dt = tq - it[(head + q - 1) % C.NIMU];
+            v3 acc = ld3(ia + (size_t)idx * 3), gyr = ld3(ig + (size_t)idx * 3);
+            if (fc != 0) {
+                if (t == 0) {
+                    int nb = P.n_buf;
+                    if (nb < VIO_IMU_SLOT_CAP) { P.dt_buf[nb] = dt; st3(P.acc_buf[nb], acc); st3(P.gyr_buf[nb], gyr); P.n_buf = nb + 1; }
+                    else be.overflow |= 2;
+                }
+                preint_propagate(P, pw, cfg, dt, acc, gyr);
+                if (t == 0) {
+                    int j = fc;
+                    v3 acc_0 = ld3(be.acc_0), gyr_0 = ld3(be.gyr_0), g = ld3(be.g);
+                    m3 Rj = ldm(be.Rs[j]);
+                    v3 Ba = ld3(be.Bas[j]), Bg = ld3(be.Bgs[j]);
+                    v3 un_acc_0 = sub(mul(Rj, sub(acc_0, Ba)), g);
+                    v3 un_gyr = sub(scl(0.5, add(gyr_0, gyr)), Bg);
+                    Rj = mul(Rj, q2R(deltaQ(scl(dt, un_gyr))));
+                    v3 un_acc_1 = sub(mul(Rj, sub(acc, Ba)), g);
+                    v3 un_acc = scl(0.5, add(un_acc_0, un_acc_1));
+                    v3 Pj = ld3(be.Ps[j]), Vj = ld3(be.Vs[j]);
+                    Pj = add(add(Pj, scl(dt, Vj)), scl(dt * dt, scl(0.5, un_acc)));
+                    Vj = add(Vj, scl(dt, un_acc));
+                    stm(be.Rs[j], Rj); st3(be.Ps[j], Pj); st3(be.Vs[j], Vj);
+                }
+            }
+            if (t == 0) { st3(be.acc_0, acc); st3(be.gyr_0, gyr); }
+            __syncthreads();
+        }
+        if (fc != 0) preint_store(P, pw);
+        if (t == 0) be.prevTime = curTime;
+        __syncthreads();
+    }
+    // ---- triangulateWithDepth (feature_manager.cpp:386-543), one thread per landmark
+    {
+        m3 ric = ldm(be.ric);
+        v3 tic = ld3(be.tic);
+        for (int k = t; k < nlm; k += nt) {
+            int slot = c.lm_order[k];
+            if (c.lm_depth[slot] > 0) continue;
+            if (!in_problem(c, slot)) continue;
+            int imu_i = c.lm_start[slot], K = c.lm_nobs[slot];
+            v3 trr = add(ld3(be.Ps[imu_i]), mul(ldm(be.Rs[imu_i]), tic));
+            m3 Rr = mul(ldm(be.Rs[imu_i]), ric);
+            double vsum = 0, rsum = 0;
+            int vn = 0, rn = 0, no_depth = 0;
+            for (int a = 0; a < K; a++) {
+                const double *oa = obs_ptr(c, slot, imu_i + a);
+                if (oa[8] == 0) { no_depth++; continue; }
+                v3 t0 = add(ld3(be.Ps[imu_i + a]), mul(ldm(be.Rs[imu_i + a]), tic));
+                m3 R0 = mul(ldm(be.Rs[imu_i + a]), ric);
+                v3 point0 = scl(oa[8], mk(oa[0], oa[1], oa[2]));
+                point0 = mk(oa[0] * oa[8], oa[1] * oa[8], oa[2] * oa[8]);
+                v3 t2r = mul(tr(Rr), sub(t0, trr));
+                m3 R2r = mul(tr(Rr), R0);
+                for (int b = 0; b < K; b++) {
+                    if (a == b) continue;
+                    const double *ob = obs_ptr(c, slot, imu_i + b);
+                    v3 t1 = add(ld3(be.Ps[imu_i + b]), mul(ldm(be.Rs[imu_i + b]), tic));
+                    m3 R1 = mul(ldm(be.Rs[imu_i + b]), ric);
+                    v3 t20 = mul(tr(R0), sub(t1, t0));
+                    m3 R20 = mul(tr(R0), R1);
+                    v3 pp = sub(mul(tr(R20), point0), mul(tr(R20), t20));
+                    double rx = ob[0] - pp.x / pp.z, ry = ob[1] - pp.y / pp.z;
+                    if (sqrt(rx * rx + ry * ry) < 10.0 / 460) {
+                        v3 pr = add(mul(R2r, point0), t2r);
+                        if (oa[8] > cfg.depth_max) { rsum += pr.z; rn++; } else { vsum += pr.z; vn++; }
+                    }
+                }
+            }
+            double dep;
+            int ef;
+            if (vn == 0) {
+                if (rn == 0) {
+                    if (no_depth == K) {
+                        double AtA[16], Vv[16];
+                        for (int q = 0; q < 16; q++) AtA[q] = 0;
+                        v3 t0 = add(ld3(be.Ps[imu_i]), mul(ldm(be.Rs[imu_i]), tic));
+                        m3 R0 = mul(ldm(be.Rs[imu_i]), ric);
+                        for (int a = 0; a < K; a++) {
+                            const double *oa = obs_ptr(c, slot, imu_i + a);
+                            v3 t1 = add(ld3(be.Ps[imu_i + a]), mul(ldm(be.Rs[imu_i + a]), tic));
+                            m3 R1 = mul(ldm(be.Rs[imu_i + a]), ric);
+                            v3 tt = mul(tr(R0), sub(t1, t0));
+                            m3 Rt = tr(mul(tr(R0), R1));
+                            v3 mt = neg(mul(Rt, tt));
+                            double Pm[12];
+                            for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) Pm[r * 4 + q] = Rt.a[r * 3 + q]; Pm[r * 4 + 3] = get(mt, r); }
+                            v3 f = mk(oa[0], oa[1], oa[2]);
+                            f = scl(1.0 / nrm(f), f);
+                            f = mk(oa[0] / nrm(mk(oa[0], oa[1], oa[2])), oa[1] / nrm(mk(oa[0], oa[1], oa[2])), oa[2] / nrm(mk(oa[0], oa[1], oa[2])));
+                            double row[8];
+                            for (int q = 0; q < 4; q++) { row[q] = f.x * Pm[8 + q] - f.z * Pm[q]; row[4 + q] = f.y * Pm[8 + q] - f.z * Pm[4 + q]; }
+                            for (int rr = 0; rr < 2; rr++)
+                                for (int x = 0; x < 4; x++) for (int y = 0; y < 4; y++) AtA[x * 4 + y] += row[rr * 4 + x] * row[rr * 4 + y];
+                        }
+                        jacobi_small(AtA, Vv, 4);
+                        int mi = 0;
+                        for (int q = 1; q < 4; q++) if (AtA[q * 5] < AtA[mi * 5]) mi = q;
+                        double svd_method = Vv[2 * 4 + mi] / Vv[3 * 4 + mi];
+                        dep = svd_method < cfg.depth_min ? cfg.depth_max : svd_method;
+                        ef = 2;
+                    } else
+                        continue;
+                } else { dep = rsum / rn; ef = 0; }
+            } else { dep = vsum / vn; ef = 1; }
+            if (dep < 0.1) { dep = cfg.init_depth; ef = 0; }
+            c.lm_depth[slot] = dep;
+            c.lm_est[slot] = ef;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        be.processed = 1;
+        be.frames_processed++;
+        if (be.solver_flag == 0) {
+            if (fc == W) { be.do_solve = 1; be.do_marg = 1; }
+        } else { be.do_solve = 1; be.do_marg = 1; }
+    }
+}
+
+// ====================================================================================================== be_solve
+namespace {
+
+struct Params { double pose[(VIO_MAXW + 1) * 7], sb[(VIO_MAXW + 1) * 9], ex[7], td; };
+
+// prior residual row i at parameters X: r0 + J dx; dx assembled in LDS sdx (n)
+__device__ void prior_dx(const Ctx &c, const Params &X, double *sdx) {
+    const int t = threadIdx.x, W = c.W;
+    const BeSeq &be = *c.be;
+    if (t <= W + 2) {
+        if (t < W) {
+            double d[6];
+            bf::pose_dx(&X.pose[t * 7], &c.prior_x0[t * 7], d);
+            for (int k = 0; k < 6; k++) sdx[6 * t + k] = be.prior_present[t] ? d[k] : 0.0;
+        } else if (t == W) {
+            for (int k = 0; k < 9; k++) sdx[6 * W + k] = be.prior_present[W] ? X.sb[k] - c.prior_x0[W * 7 + k] : 0.0;
+        } else if (t == W + 1) {
+            double d[6];
+            bf::pose_dx(X.ex, &c.prior_x0[W * 7 + 9], d);
+            for (int k = 0; k < 6; k++) sdx[6 * W + 9 + k] = be.prior_present[W + 1] ? d[k] : 0.0;
+        } else
+            sdx[6 * W + 15] = be.prior_present[W + 2] ? X.td - c.prior_x0[W * 7 + 16] : 0.0;
+    }
+    __syncthreads();
+}
+// tangent index of prior slot a
+__device__ __forceinline__ int prior_map(int a, int W) {
+    if (a < 6 * W) return a;                                  // pose k at 6k
+    if (a < 6 * W + 9) return 6 * (W + 1) + (a - 6 * W);     // speed-bias 0
+    if (a < 6 * W + 15) return 15 * (W + 1) + (a - 6 * W - 9);
+    return 15 * (W + 1) + 6;
+}
+
+// evaluate every residual at X. withJ: store weighted Jacobians/residuals for assembly. Returns total cost.
+__device__ double evaluate(const Ctx &c, const Params &X, const double *feat, bool withJ, int nres, double *sred, double *sdx, double *srp) {
+    const int t = threadIdx.x, nt = blockDim.x, W = c.W, n = c.NPR;
+    const BeSeq &be = *c.be;
+    const vio_config &cfg = c.C->c;
+    double cost = 0;
+    // prior
+    if (be.has_prior) {
+        prior_dx(c, X, sdx);
+        for (int i = t; i < n; i += nt) {
+            double sacc = c.prior_r[i];
+            for (int j = 0; j < n; j++) sacc += c.prior_J[i * n + j] * sdx[j];
+            srp[i] = sacc;
+            cost += 0.5 * sacc * sacc;
+        }
+    }
+    // IMU factors
+    v3 G = ld3(be.g);
+    for (int i = t; i < W; i += nt) {
+        int j = i + 1;
+        const PreInt &p = c.pre[be.pre_idx[j]];
+        double *out = c.imu_raw + (size_t)i * 15 * 31;
+        if (p.sum_dt > 10.0) { for (int k = 0; k < 15; k++) out[k * 31 + 30] = 0; continue; }
+        double raw[15];
+        bf::imu_raw_residual(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], raw);
+        for (int r = 0; r < 15; r++) {
+            double sacc = 0;
+            for (int k = 0; k < 15; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k];
+            out[r * 31 + 30] = sacc;
+            cost += 0.5 * sacc * sacc;
+        }
+        if (withJ) {
+            double Jr[450];
+            bf::imu_raw_jacobian(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], Jr);
+            for (int q = 0; q < 450; q++) out[(q / 30) * 31 + (q % 30)] = Jr[q];  // raw, whitened in a second pass
+        }
+    }
+    // projection factors, CauchyLoss(1.0)
+    for (int r = t; r < nres; r += nt) {
+        int slot = c.res_lm[r], k = c.res_k[r];
+        int imu_i = c.lm_start[slot], imu_j = imu_i + k;
+        double rr[2], J[40];
+        bf::eval_projection(cfg, &X.pose[imu_i * 7], &X.pose[imu_j * 7], X.ex, feat[c.lm_pidx[slot]], X.td, obs_ptr(c, slot, imu_i),
+                            obs_ptr(c, slot, imu_j), cfg.estimate_td != 0, rr, withJ ? J : nullptr);
+        double sq = rr[0] * rr[0] + rr[1] * rr[1];
+        cost += 0.5 * log(1.0 + sq);
+        if (withJ) {
+            double wgt = sqrt(1.0 / (1.0 + sq));
+            double *out = c.res + (size_t)r * 42;
+            for (int q = 0; q < 40; q++) out[q] = wgt * J[q];
+            out[40] = wgt * rr[0];
+            out[41] = wgt * rr[1];
+        }
+    }
+    return block_sum(cost, sred);
+}
+
+// pair-block entry index of the packed symmetric 20x20
+__device__ __forceinline__ int sym_idx(int a, int b) {
+    if (a > b) { int x = a; a = b; b = x; }
+    return a * 20 - a * (a - 1) / 2 + (b - a);
+}
+__device__ __forceinline__ int local_of(int a, int i, int j, int W) {
+    // tangent index a within the vision set -> local column of pair (i,j) or -1
+    int np = 6 * (W + 1);
+    if (a < np) {
+        int f = a / 6, d = a - f * 6;
+        if (f == i) return d;
+        if (f == j) return 6 + d;
+        return -1;
+    }
+    int e = a - 15 * (W + 1);
+    return 12 + e;  // ex 0..5 -> 12..17, td (6) -> 18
+}
+
+// assemble H (P x P, ld LW), g (vec slot 0), Hpl / Hll / gl from the stored residual Jacobians
+__device__ void assemble(const Ctx &c, const Params &X, int nres, int Fa, const int *alist, double *srp) {
+    const int t = threadIdx.x, nt = blockDim.x, W = c.W, P = c.P, LW = c.LW, n = c.NPR;
+    const BeSeq &be = *c.be;
+    double *H = c.H, *g = c.vec;
+    for (int i = t; i < P * LW; i += nt) H[i] = 0;
+    for (int i = t; i < LW; i += nt) g[i] = 0;
+    __syncthreads();
+    // prior: H += J^T J (precomputed), g += J^T r
+    if (be.has_prior) {
+        for (int w = t; w < n * n; w += nt) {
+            int a = w / n, b = w - a * n;
+            H[prior_map(a, W) * LW + prior_map(b, W)] = c.prior_H[w];
+        }
+        for (int a = t; a < n; a += nt) {
+            double sacc = 0;
+            for (int i = 0; i < n; i++) sacc += c.prior_J[i * n + a] * srp[i];
+            g[prior_map(a, W)] = sacc;
+        }
+    }
+    __syncthreads();
+    // IMU: whiten raw Jacobians (sqrt_info upper-triangular), then 30x30 blocks; even factors then odd factors
+    for (int w = t; w < W * 450; w += nt) {
+        int i = w / 450, q = w - i * 450, r = q / 30, col = q - r * 30;
+        const PreInt &p = c.pre[be.pre_idx[i + 1]];
+        const double *raw = c.imu_raw + (size_t)i * 15 * 31;
+        double sacc = 0;
+        for (int k = r; k < 15; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k * 31 + col];
+        c.pairblk[w] = sacc;  // temporary home of the whitened Jacobians (pairblk is rebuilt afterwards)
+    }
+    __syncthreads();
+    for (int parity = 0; parity < 2; parity++) {
+        for (int w = t; w < W * 930; w += nt) {
+            int i = w / 930;
+            if ((i & 1) != parity) continue;
+            const PreInt &p = c.pre[be.pre_idx[i + 1]];
+            if (p.sum_dt > 10.0) continue;
+            int q = w - i * 930;
+            const double *Jw = c.pairblk + (size_t)i * 450;
+            const double *raw = c.imu_raw + (size_t)i * 15 * 31;
+            int a = q / 31, b = q - a * 31;
+            int ia = a < 6 ? 6 * i + a : (a < 15 ? 6 * (W + 1) + 9 * i + (a - 6) : (a < 21 ? 6 * (i + 1) + (a - 15) : 6 * (W + 1) + 9 * (i + 1) + (a - 21)));
+            double sacc = 0;
+            if (b < 30) {
+                int ib = b < 6 ? 6 * i + b : (b < 15 ? 6 * (W + 1) + 9 * i + (b - 6) : (b < 21 ? 6 * (i + 1) + (b - 15) : 6 * (W + 1) + 9 * (i + 1) + (b - 21)));
+                for (int k = 0; k < 15; k++) sacc += Jw[k * 30 + a] * Jw[k * 30 + b];
+                H[ia * LW + ib] += sacc;
+            } else {
+                for (int k = 0; k < 15; k++) sacc += Jw[k * 30 + a] * raw[k * 31 + 30];
+                g[ia] += sacc;
+            }
+        }
+        __syncthreads();
+    }
+    // vision: frame-pair blocks G_p = [J19 r]^T [J19 r] (packed symmetric 20x20)
+    const int W1 = W + 1;
+    for (int w = t; w < W1 * W1 * 210; w += nt) {
+        int p = w / 210, e = w - p * 210;
+        int i = p / W1, j = p - i * W1;
+        if (!(i < j)) continue;
+        int a = 0, rem = e;
+        while (rem >= 20 - a) { rem -= 20 - a; a++; }
+        int b = a + rem;
+        int ca = a < 19 ? a : -1, cb = b < 19 ? b : -1;  // column 19 of the block is the residual
+        double sacc = 0;
+        for (int q = c.pair_start[p]; q < c.pair_start[p + 1]; q++) {
+            const double *Jr = c.res + (size_t)c.pair_list[q] * 42;
+            double a0 = ca >= 0 ? Jr[ca] : Jr[40], a1 = ca >= 0 ? Jr[20 + ca] : Jr[41];
+            double b0 = cb >= 0 ? Jr[cb] : Jr[40], b1 = cb >= 0 ? Jr[20 + cb] : Jr[41];
+            sacc += a0 * b0 + a1 * b1;
+        }
+        c.pairblk[(size_t)p * 210 + e] = sacc;
+    }
+    __syncthreads();
+    {
+        const int nv = 6 * W1 + 7;
+        for (int w = t; w < nv * (nv + 1); w += nt) {
+            int ra = w / (nv + 1), rb = w - ra * (nv + 1);
+            int a = ra < 6 * W1 ? ra : 15 * W1 + (ra - 6 * W1);
+            int b = rb < nv ? (rb < 6 * W1 ? rb : 15 * W1 + (rb - 6 * W1)) : -1;
+            double sacc = 0;
+            for (int i = 0; i < W1; i++)
+                for (int j = i + 1; j < W1; j++) {
+                    int p = i * W1 + j;
+                    if (c.pair_start[p + 1] == c.pair_start[p]) continue;
+                    int la = local_of(a, i, j, W);
+                    if (la < 0) continue;
+                    int lb = b >= 0 ? local_of(b, i, j, W) : 19;
+                    if (lb < 0) continue;
+                    sacc += c.pairblk[(size_t)p * 210 + sym_idx(la, lb)];
+                }
+            if (b >= 0) H[a * LW + b] += sacc; else g[a] += sacc;
+        }
+    }
+    // landmark coupling rows (dense, zero padded), Hll, gl
+    for (int w = t; w < Fa * LW; w += nt) {
+        int ka = w / LW, col = w - ka * LW;
+        int slot = alist[ka];
+        int st = c.lm_start[slot], no = c.lm_nobs[slot];
+        double sacc = 0;
+        if (col < P) {
+            int np = 6 * W1;
+            int r0 = c.lm_tmp[slot];  // first residual index of this landmark
+            if (col < np) {
+                int f = col / 6, d = col - f * 6;
+                if (f == st) {
+                    for (int k = 1; k < no; k++) { const double *Jr = c.res + (size_t)(r0 + k - 1) * 42; sacc += Jr[d] * Jr[19] + Jr[20 + d] * Jr[39]; }
+                } else if (f > st && f < st + no) {
+                    const double *Jr = c.res + (size_t)(r0 + (f - st) - 1) * 42;
+                    sacc = Jr[6 + d] * Jr[19] + Jr[26 + d] * Jr[39];
+                }
+            } else if (col >= 15 * W1) {
+                int e = 12 + (col - 15 * W1);
+                for (int k = 1; k < no; k++) { const double *Jr = c.res + (size_t)(r0 + k - 1) * 42; sacc += Jr[e] * Jr[19] + Jr[20 + e] * Jr[39]; }
+            }
+        }
+        c.Hpl[(size_t)ka * LW + col] = sacc;
+    }
+    for (int ka = t; ka < Fa; ka += nt) {
+        int slot = alist[ka];
+        int no = c.lm_nobs[slot], r0 = c.lm_tmp[slot];
+        double hll = 0, gg = 0;
+        for (int k = 1; k < no; k++) {
+            const double *Jr = c.res + (size_t)(r0 + k - 1) * 42;
+            hll += Jr[19] * Jr[19] + Jr[39] * Jr[39];
+            gg += Jr[19] * Jr[40] + Jr[39] * Jr[41];
+        }
+        c.Hll[ka] = hll;
+        c.gl[ka] = gg;
+    }
+    __syncthreads();
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void be_solve_kernel(Batch B) {
+    const int s = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+    Ctx c = make_ctx(B, s);
+    const DevCfg &C = *B.cfg;
+    const vio_config &cfg = C.c;
+    BeSeq &be = *c.be;
+    if (!be.do_solve) return;
+    const int W = c.W, P = c.P, LW = c.LW, W1 = W + 1;
+    __shared__ Params X, Xc;
+    __shared__ double sred[256];
+    __shared__ double sdx[6 * VIO_MAXW + 16], srp[6 * VIO_MAXW + 16];
+    __shared__ int scratch[260];
+    __shared__ int sh_i[8];
+    __shared__ double sh_d[8];
+    __shared__ PreWork pw;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *xs = (double *)smem;  // LW doubles: triangular-solve workspace
+
+    // ---- static initialisation extras (estimator.cpp:266-283): solveGyroscopeBias + repropagate
+    if (be.solver_flag == 0) {
+        if (t == 0) {
+            double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+            for (int i = 0; i < W; i++) {
+                int j = i + 1;
+                const PreInt &p = c.pre[be.pre_idx[j]];
+                quat q_ij = R2q(mul(tr(ldm(be.Rs[i])), ldm(be.Rs[j])));
+                m3 tA = bf::get33(p.jac, 15, bf::O_R, bf::O_BG);
+                v3 tb = scl(2.0, qvec(qmul(qinv(mkq(p.dq[0], p.dq[1], p.dq[2], p.dq[3])), q_ij)));
+                m3 AtA = mul(tr(tA), tA);
+                v3 Atb = mul(tr(tA), tb);
+                for (int r = 0; r < 9; r++) A[r] += AtA.a[r];
+                b[0] += Atb.x; b[1] += Atb.y; b[2] += Atb.z;
+            }
+            double M[12];
+            for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) M[r * 4 + q] = A[r * 3 + q]; M[r * 4 + 3] = b[r]; }
+            for (int i = 0; i < 3; i++) {
+                int p = i;
+                for (int r = i + 1; r < 3; r++) if (fabs(M[r * 4 + i]) > fabs(M[p * 4 + i])) p = r;
+                for (int q = 0; q < 4; q++) { double tmp = M[i * 4 + q]; M[i * 4 + q] = M[p * 4 + q]; M[p * 4 + q] = tmp; }
+                if (M[i * 4 + i] == 0) continue;
+                for (int r = i + 1; r < 3; r++) {
+                    double f = M[r * 4 + i] / M[i * 4 + i];
+                    for (int q = i; q < 4; q++) M[r * 4 + q] -= f * M[i * 4 + q];
+                }
+            }
+            double x[3] = {0, 0, 0};
+            for (int i = 2; i >= 0; i--) {
+                double sacc = M[i * 4 + 3];
+                for (int q = i + 1; q < 3; q++) sacc -= M[i * 4 + q] * x[q];
+                x[i] = M[i * 4 + i] != 0 ? sacc / M[i * 4 + i] : 0;
+            }
+            for (int i = 0; i <= W; i++) { be.Bgs[i][0] += x[0]; be.Bgs[i][1] += x[1]; be.Bgs[i][2] += x[2]; }
+        }
+        __syncthreads();
+        for (int j = 0; j <= W; j++) {  // pre_integrations[j]->repropagate(Vector3d::Zero(), Bgs[j])
+            PreInt &p = c.pre[be.pre_idx[j]];
+            if (!p.valid) continue;
+            if (t == 0) {
+                int nb = p.n_buf;
+                v3 la = ld3(p.lin_acc), lg = ld3(p.lin_gyr);
+                p.sum_dt = 0;
+                st3(p.acc0, la); st3(p.gyr0, lg);
+                p.dp[0] = p.dp[1] = p.dp[2] = 0; p.dv[0] = p.dv[1] = p.dv[2] = 0;
+                p.dq[0] = 1; p.dq[1] = p.dq[2] = p.dq[3] = 0;
+                p.lin_ba[0] = p.lin_ba[1] = p.lin_ba[2] = 0;
+                st3(p.lin_bg, ld3(be.Bgs[j]));
+                p.n_buf = nb;
+            }
+            for (int i = t; i < 225; i += nt) { pw.J[i] = ((i / 15) == (i % 15)) ? 1.0 : 0.0; pw.Pm[i] = 0; }
+            __syncthreads();
+            for (int q = 0; q < p.n_buf; q++) preint_propagate(p, pw, cfg, p.dt_buf[q], ld3(p.acc_buf[q]), ld3(p.gyr_buf[q]));
+            preint_store(p, pw);
+        }
+    }
+
+    // ---- vector2double (estimator.cpp:936-981)
+    if (t <= W) {
+        int i = t;
+        X.pose[i * 7 + 0] = be.Ps[i][0]; X.pose[i * 7 + 1] = be.Ps[i][1]; X.pose[i * 7 + 2] = be.Ps[i][2];
+        quat q = R2q(ldm(be.Rs[i]));
+        X.pose[i * 7 + 3] = q.x; X.pose[i * 7 + 4] = q.y; X.pose[i * 7 + 5] = q.z; X.pose[i * 7 + 6] = q.w;
+        for (int k = 0; k < 3; k++) { X.sb[i * 9 + k] = be.Vs[i][k]; X.sb[i * 9 + 3 + k] = be.Bas[i][k]; X.sb[i * 9 + 6 + k] = be.Bgs[i][k]; }
+    }
+    if (t == W + 1) {
+        X.ex[0] = be.tic[0]; X.ex[1] = be.tic[1]; X.ex[2] = be.tic[2];
+        quat q = R2q(ldm(be.ric));
+        X.ex[3] = q.x; X.ex[4] = q.y; X.ex[5] = q.z; X.ex[6] = q.w;
+        X.td = be.td;
+    }
+    // ---- landmark indexing: in-problem (para_Feature index), variable landmarks, residual list
+    int nlm = be.n_lm;
+    int *tmpA = c.pair_list, *tmpB = c.pair_list + c.NL;       // scan temporaries (pair_list proper is built afterwards)
+    int *alist = c.pair_list + c.nres_cap - c.NL;              // variable-landmark slots, kept for the whole solve
+    __syncthreads();
+    for (int k = t; k < nlm; k += nt) tmpA[k] = in_problem(c, c.lm_order[k]) ? 1 : 0;
+    __syncthreads();
+    int F = block_scan_flags(tmpA, nlm, tmpB, scratch);
+    for (int k = t; k < nlm; k += nt) {
+        int slot = c.lm_order[k];
+        c.lm_pidx[slot] = tmpA[k] ? tmpB[k] : -1;
+        if (tmpA[k]) c.feat[tmpB[k]] = 1.0 / c.lm_depth[slot];
+    }
+    __syncthreads();
+    // variable landmarks (not SetParameterBlockConstant): estimator.cpp:1278-1298
+    for (int k = t; k < nlm; k += nt) {
+        int slot = c.lm_order[k];
+        tmpA[k] = (c.lm_pidx[slot] >= 0 && !(c.lm_est[slot] == 1 && cfg.fix_depth)) ? 1 : 0;
+    }
+    __syncthreads();
+    int Fa = block_scan_flags(tmpA, nlm, tmpB, scratch);
+    for (int k = t; k < nlm; k += nt) {
+        int slot = c.lm_order[k];
+        c.lm_aidx[slot] = tmpA[k] ? tmpB[k] : -1;
+        if (tmpA[k]) alist[tmpB[k]] = slot;
+    }
+    __syncthreads();
+    // residual list: (nobs-1) residuals per in-problem landmark, list order (estimator.cpp:1243-1302)
+    for (int k = t; k < nlm; k += nt) { int slot = c.lm_order[k]; tmpA[k] = c.lm_pidx[slot] >= 0 ? c.lm_nobs[slot] - 1 : 0; }
+    __syncthreads();
+    int nres = block_scan_flags(tmpA, nlm, tmpB, scratch);
+    const int nres_max = c.nres_cap - 2 * c.NL;
+    if (nres > nres_max) { nres = nres_max; if (t == 0) be.overflow |= 8; }
+    for (int k = t; k < nlm; k += nt) {
+        int slot = c.lm_order[k];
+        int r0 = tmpB[k], cnt = tmpA[k];
+        c.lm_tmp[slot] = r0;  // first residual index of this landmark
+        for (int q = 0; q < cnt; q++)
+            if (r0 + q < nres) { c.res_lm[r0 + q] = slot; c.res_k[r0 + q] = q + 1; }
+    }
+    __syncthreads();
+    // frame-pair lists (deterministic order): one thread per pair walks the residual list
+    {
+        for (int p = t; p < W1 * W1; p += nt) {
+            int i = p / W1, j = p - i * W1;
+            int cnt = 0;
+            if (i < j)
+                for (int r = 0; r < nres; r++) { int slot = c.res_lm[r]; if (c.lm_start[slot] == i && c.res_k[r] == j - i) cnt++; }
+            c.pair_start[p] = cnt;
+        }
+        __syncthreads();
+        if (t == 0) {
+            int acc = 0;
+            for (int p = 0; p < W1 * W1; p++) { int v = c.pair_start[p]; c.pair_start[p] = acc; acc += v; }
+            c.pair_start[W1 * W1] = acc;
+        }
+        __syncthreads();
+        for (int p = t; p < W1 * W1; p += nt) {
+            int i = p / W1, j = p - i * W1;
+            if (!(i < j)) continue;
+            int o = c.pair_start[p];
+            for (int r = 0; r < nres; r++) { int slot = c.res_lm[r]; if (c.lm_start[slot] == i && c.res_k[r] == j - i) c.pair_list[o++] = r; }
+        }
+        __syncthreads();
+    }
+    // prior_H = J^T J ; IMU sqrt_info
+    const int n = c.NPR;
+    if (be.has_prior) {
+        for (int w = t; w < n * n; w += nt) {
+            int a = w / n, b = w - a * n;
+            double sacc = 0;
+            for (int i = 0; i < n; i++) sacc += c.prior_J[i * n + a] * c.prior_J[i * n + b];
+            c.prior_H[w] = sacc;
+        }
+    }
+    for (int j = 1 + t; j <= W; j += nt) { PreInt &p = c.pre[be.pre_idx[j]]; bf::imu_sqrt_info(p.cov, p.sqrt_info); }
+    // constness (estimator.cpp:1187-1212)
+    if (t == 0) {
+        double v0 = nrm(ld3(be.Vs[0]));
+        int ex_active;
+        if ((cfg.estimate_extrinsic && be.frame_count == W && v0 > 0.2) || be.openExEstimation) { be.openExEstimation = 1; ex_active = 1; }
+        else ex_active = 0;
+        int td_active = cfg.estimate_td && !(v0 < 0.2);
+        sh_i[0] = ex_active; sh_i[1] = td_active;
+        be.n_in_problem = F; be.n_var_landmarks = Fa; be.n_residuals = nres;
+        be.iterations = 0; be.successful = 0;
+    }
+    __syncthreads();
+    const int ex_active = sh_i[0], td_active = sh_i[1];
+    const int oE = 15 * W1, oT = 15 * W1 + 6;
+
+    // vec slots
+    double *g = c.vec, *sp = c.vec + 1 * LW, *dgp = c.vec + 2 * LW, *gradp = c.vec + 3 * LW, *gnp = c.vec + 4 * LW, *stp = c.vec + 5 * LW,
+           *gs = c.vec + 6 * LW, *tmpv = c.vec + 7 * LW, *delta = c.vec + 8 * LW;
+    double *sl = c.lvec, *dgl = c.lvec + c.NL, *gradl = c.lvec + 2 * c.NL, *gnl = c.lvec + 3 * c.NL, *stl = c.lvec + 4 * c.NL,
+           *hllr = c.lvec + 5 * c.NL, *gls = c.lvec + 6 * c.NL, *Hlls = c.lvec + 7 * c.NL;
+
+    double cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp);
+    assemble(c, X, nres, Fa, alist, srp);
+    if (t == 0) be.initial_cost = cost;
+    // inactive tangent dims: remove their rows/columns
+    auto mask_inactive = [&]() {
+        for (int w = t; w < P * 7; w += nt) {
+            int r = w / 7, d = w - r * 7;
+            int col = oE + d;
+            bool off = d < 6 ? !ex_active : !td_active;
+            if (off) { c.H[r * LW + col] = 0; c.H[col * LW + r] = 0; }
+        }
+        if (t < 7) { bool off = t < 6 ? !ex_active : !td_active; if (off) g[oE + t] = 0; }
+        for (int w = t; w < Fa * 7; w += nt) {
+            int ka = w / 7, d = w - ka * 7;
+            bool off = d < 6 ? !ex_active : !td_active;
+            if (off) c.Hpl[(size_t)ka * LW + oE + d] = 0;
+        }
+        __syncthreads();
+    };
+    mask_inactive();
+    // Jacobi scaling (once): 1/(1+||J_j||)
+    for (int a = t; a < P; a += nt) {
+        bool act = a < oE ? true : (a < oT ? ex_active != 0 : td_active != 0);
+        sp[a] = act ? 1.0 / (1.0 + sqrt(c.H[a * LW + a])) : 0.0;
+    }
+    for (int k = t; k < Fa; k += nt) sl[k] = 1.0 / (1.0 + sqrt(c.Hll[k]));
+    __syncthreads();
+
+    double radius = 1e4, mu = 1e-8, alpha = 0, dogleg_norm = 0;
+    bool reuse = false, need_eval = false;
+    int invalid = 0;
+    auto gmax = [&]() {
+        double m = 0;
+        for (int a = t; a < P; a += nt) m = fmax(m, sp[a] != 0.0 ? fabs(g[a]) : 0.0);
+        for (int k = t; k < Fa; k += nt) m = fmax(m, fabs(c.gl[k]));
+        __syncthreads();
+        sred[t] = m;
+        __syncthreads();
+        for (int off = nt >> 1; off > 0; off >>= 1) { if (t < off) sred[t] = fmax(sred[t], sred[t + off]); __syncthreads(); }
+        double r = sred[0];
+        __syncthreads();
+        return r;
+    };
+    int iters_done = 0, succ = 0;
+    if (gmax() > 1e-10)
+    for (int iter = 1; iter <= cfg.max_iterations; iter++) {
+        iters_done = iter;
+        if (!reuse) {
+            if (need_eval) {
+                cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp);
+                assemble(c, X, nres, Fa, alist, srp);
+                mask_inactive();
+                need_eval = false;
+                if (gmax() <= 1e-10) { iters_done = iter - 1; break; }
+            }
+            // scaled gradient / diagonal (DoglegStrategy::ComputeStep)
+            for (int a = t; a < P; a += nt) {
+                double hs = sp[a] * sp[a] * c.H[a * LW + a];
+                gs[a] = sp[a] * g[a];
+                dgp[a] = sqrt(fmin(fmax(hs, 1e-6), 1e32));
+                gradp[a] = gs[a] / dgp[a];
+            }
+            for (int k = t; k < Fa; k += nt) {
+                Hlls[k] = sl[k] * sl[k] * c.Hll[k];
+                gls[k] = sl[k] * c.gl[k];
+                dgl[k] = sqrt(fmin(fmax(Hlls[k], 1e-6), 1e32));
+                gradl[k] = gls[k] / dgl[k];
+            }
+            __syncthreads();
+            // Cauchy point
+            double g2 = 0, jg2 = 0;
+            for (int a = t; a < P; a += nt) {
+                g2 += gradp[a] * gradp[a];
+                double sga = gradp[a] / dgp[a];
+                double sacc = 0;
+                for (int b = 0; b < P; b++) sacc += sp[a] * sp[b] * c.H[a * LW + b] * (gradp[b] / dgp[b]);
+                jg2 += sga * sacc;
+            }
+            for (int k = t; k < Fa; k += nt) {
+                g2 += gradl[k] * gradl[k];
+                double sgl = gradl[k] / dgl[k];
+                double sacc = 0;
+                for (int a = 0; a < P; a++) sacc += sl[k] * sp[a] * c.Hpl[(size_t)k * LW + a] * (gradp[a] / dgp[a]);
+                jg2 += 2.0 * sgl * sacc + sgl * sgl * Hlls[k];
+            }
+            g2 = block_sum(g2, sred);
+            jg2 = block_sum(jg2, sred);
+            alpha = g2 / jg2;
+            // Gauss-Newton step via the landmark Schur complement, regularised by mu * D^2
+            bool ok = false;
+            while (mu < 1.0) {
+                for (int k = t; k < Fa; k += nt) hllr[k] = Hlls[k] + mu * dgl[k] * dgl[k];
+                __syncthreads();
+                for (int w = t; w < P * P; w += nt) {
+                    int a = w / P, b = w - a * P;
+                    if (b > a) continue;
+                    double sacc = sp[a] * sp[b] * c.H[a * LW + b];
+                    if (a == b) { sacc += mu * dgp[a] * dgp[a]; if (sp[a] == 0.0) sacc = 1.0; }
+                    double sub_ = 0;
+                    double fa = sp[a], fb = sp[b];
+                    for (int k = 0; k < Fa; k++) {
+                        double wa = c.Hpl[(size_t)k * LW + a], wb = c.Hpl[(size_t)k * LW + b];
+                        sub_ += (sl[k] * fa * wa) * (sl[k] * fb * wb) / hllr[k];
+                    }
+                    c.Sc[a * LW + b] = sacc - sub_;
+                }
+                for (int a = t; a < P; a += nt) {
+                    double sacc = gs[a];
+                    for (int k = 0; k < Fa; k++) sacc -= (sl[k] * sp[a] * c.Hpl[(size_t)k * LW + a]) / hllr[k] * gls[k];
+                    xs[a] = sacc;
+                }
+                __syncthreads();
+                if (chol_block(c.Sc, P, LW, &sh_i[2])) {
+                    chol_solve_wave(c.Sc, P, LW, xs);
+                    double bad = 0;
+                    for (int a = t; a < P; a += nt) if (!isfinite(xs[a])) bad += 1;
+                    bad = block_sum(bad, sred);
+                    if (bad == 0) {
+                        for (int a = t; a < P; a += nt) gnp[a] = -xs[a] * dgp[a];
+                        for (int k = t; k < Fa; k += nt) {
+                            double sacc = gls[k];
+                            for (int a = 0; a < P; a++) sacc -= sl[k] * sp[a] * c.Hpl[(size_t)k * LW + a] * xs[a];
+                            gnl[k] = -(sacc / hllr[k]) * dgl[k];
+                        }
+                        __syncthreads();
+                        ok = true;
+                        break;
+                    }
+                }
+                mu *= 10.0;
+            }
+            if (!ok) break;
+            reuse = true;
+        }
+        // traditional dogleg in the D-scaled space
+        double gnorm = 0, gnn = 0, gdot = 0;
+        for (int a = t; a < P; a += nt) { gnorm += gradp[a] * gradp[a]; gnn += gnp[a] * gnp[a]; gdot += gradp[a] * gnp[a]; }
+        for (int k = t; k < Fa; k += nt) { gnorm += gradl[k] * gradl[k]; gnn += gnl[k] * gnl[k]; gdot += gradl[k] * gnl[k]; }
+        gnorm = sqrt(block_sum(gnorm, sred));
+        gnn = sqrt(block_sum(gnn, sred));
+        gdot = block_sum(gdot, sred);
+        double ca = 0, cb = 0;  // step = ca * grad + cb * gn
+        if (gnn <= radius) { ca = 0; cb = 1; dogleg_norm = gnn; }
+        else if (gnorm * alpha >= radius) { ca = -(radius / gnorm); cb = 0; dogleg_norm = radius; }
+        else {
+            double b_dot_a = -alpha * gdot;
+            double a_sq = (alpha * gnorm) * (alpha * gnorm);
+            double bma = a_sq - 2 * b_dot_a + gnn * gnn;
+            double cc = b_dot_a - a_sq;
+            double d = sqrt(cc * cc + bma * (radius * radius - a_sq));
+            double beta = (cc <= 0) ? (d - cc) / bma : (radius * radius - a_sq) / (d + cc);
+            ca = -alpha * (1.0 - beta); cb = beta;
+            dogleg_norm = -1;
+        }
+        double n2 = 0;
+        for (int a = t; a < P; a += nt) { double v = ca * gradp[a] + cb * gnp[a]; n2 += v * v; stp[a] = v / dgp[a]; }
+        for (int k = t; k < Fa; k += nt) { double v = ca * gradl[k] + cb * gnl[k]; n2 += v * v; stl[k] = v / dgl[k]; }
+        n2 = block_sum(n2, sred);
+        if (dogleg_norm < 0) dogleg_norm = sqrt(n2);
+        // model cost change
+        double lin = 0, quad = 0;
+        for (int a = t; a < P; a += nt) {
+            lin += stp[a] * gs[a];
+            double sacc = 0;
+            for (int b = 0; b < P; b++) sacc += sp[a] * sp[b] * c.H[a * LW + b] * stp[b];
+            quad += stp[a] * sacc;
+        }
+        for (int k = t; k < Fa; k += nt) {
+            lin += stl[k] * gls[k];
+            double sacc = 0;
+            for (int a = 0; a < P; a++) sacc += sl[k] * sp[a] * c.Hpl[(size_t)k * LW + a] * stp[a];
+            quad += 2.0 * stl[k] * sacc + stl[k] * stl[k] * Hlls[k];
+        }
+        lin = block_sum(lin, sred);
+        quad = block_sum(quad, sred);
+        double model_change = -(lin + 0.5 * quad);
+        if (!(model_change > 0)) {
+            if (++invalid >= 5) break;
+            mu *= 10.0;
+            reuse = false;
+            continue;
+        }
+        invalid = 0;
+        // candidate = Plus(x, step .* scale)
+        for (int a = t; a < P; a += nt) delta[a] = stp[a] * sp[a];
+        __syncthreads();
+        if (t <= W) {
+            for (int k = 0; k < 7; k++) Xc.pose[t * 7 + k] = X.pose[t * 7 + k];
+            bf::pose_plus(&Xc.pose[t * 7], &delta[6 * t]);
+            for (int k = 0; k < 9; k++) Xc.sb[t * 9 + k] = X.sb[t * 9 + k] + delta[6 * W1 + 9 * t + k];
+        }
+        if (t == W + 1) {
+            for (int k = 0; k < 7; k++) Xc.ex[k] = X.ex[k];
+            if (ex_active) bf::pose_plus(Xc.ex, &delta[oE]);
+            Xc.td = X.td + (td_active ? delta[oT] : 0.0);
+        }
+        for (int k = t; k < F; k += nt) c.cfeat[k] = c.feat[k];
+        __syncthreads();
+        for (int k = t; k < Fa; k += nt) {
+            int slot = alist[k], pi = c.lm_pidx[slot];
+            double v = c.feat[pi] + stl[k] * sl[k];
+            double ub = (c.lm_est[slot] == 2) ? 2.0 / cfg.depth_max : 1.7976931348623157e308;
+            if (v > ub) v = ub;
+            c.cfeat[pi] = v;
+        }
+        __syncthreads();
+        double ccost = evaluate(c, Xc, c.cfeat, false, nres, sred, sdx, srp);
+        // parameter tolerance
+        double xn = 0, dn = 0;
+        if (t <= W) {
+            for (int k = 0; k < 7; k++) { double v = X.pose[t * 7 + k]; xn += v * v; double d = v - Xc.pose[t * 7 + k]; dn += d * d; }
+            for (int k = 0; k < 9; k++) { double v = X.sb[t * 9 + k]; xn += v * v; double d = v - Xc.sb[t * 9 + k]; dn += d * d; }
+        }
+        if (t == W + 1) {
+            if (ex_active) for (int k = 0; k < 7; k++) { double v = X.ex[k]; xn += v * v; double d = v - Xc.ex[k]; dn += d * d; }
+            if (td_active) { xn += X.td * X.td; dn += (X.td - Xc.td) * (X.td - Xc.td); }
+        }
+        for (int k = t; k < Fa; k += nt) { int pi = c.lm_pidx[alist[k]]; double v = c.feat[pi]; xn += v * v; double d = v - c.cfeat[pi]; dn += d * d; }
+        xn = block_sum(xn, sred);
+        dn = block_sum(dn, sred);
+        if (sqrt(dn) <= 1e-8 * (sqrt(xn) + 1e-8)) break;
+        if (fabs(cost - ccost) <= 1e-6 * cost) break;
+        double rel = (cost - ccost) / model_change;
+        if (rel > 1e-3) {
+            __syncthreads();
+            if (t <= W) { for (int k = 0; k < 7; k++) X.pose[t * 7 + k] = Xc.pose[t * 7 + k]; for (int k = 0; k < 9; k++) X.sb[t * 9 + k] = Xc.sb[t * 9 + k]; }
+            if (t == W + 1) { for (int k = 0; k < 7; k++) X.ex[k] = Xc.ex[k]; X.td = Xc.td; }
+            for (int k = t; k < F; k += nt) c.feat[k] = c.cfeat[k];
+            __syncthreads();
+            cost = ccost;
+            succ++;
+            if (rel < 0.25) radius *= 0.5;
+            if (rel > 0.75) radius = fmax(radius, 3.0 * dogleg_norm);
+            mu = fmax(1e-8, 2.0 * mu / 10.0);
+            reuse = false;
+            need_eval = true;
+        } else {
+            radius *= 0.5;
+            reuse = true;
+        }
+    }
+    __syncthreads();
+    // ---- write back flat parameters + double2vector (estimator.cpp:985-1111)
+    if (t == 0) {
+        be.final_cost = cost; be.iterations = iters_done; be.successful = succ;
+        v3 origin_R0 = R2ypr(ldm(be.Rs[0]));
+        v3 origin_P0 = ld3(be.Ps[0]);
+        quat q0 = mkq(X.pose[6], X.pose[3], X.pose[4], X.pose[5]);
+        v3 origin_R00 = R2ypr(q2R(q0));
+        double y_diff = origin_R0.x - origin_R00.x;
+        m3 rot_diff = ypr2R(mk(y_diff, 0, 0));
+        if (fabs(fabs(origin_R0.y) - 90) < 1.0 || fabs(fabs(origin_R00.y) - 90) < 1.0) rot_diff = mul(ldm(be.Rs[0]), tr(q2R(q0)));
+        sh_d[0] = 0;
+        for (int q = 0; q < 9; q++) sdx[q] = rot_diff.a[q];
+        sdx[9] = origin_P0.x; sdx[10] = origin_P0.y; sdx[11] = origin_P0.z;
+    }
+    __syncthreads();
+    if (t <= W) {
+        int i = t;
+        m3 rot_diff = ldm(sdx);
+        v3 origin_P0 = mk(sdx[9], sdx[10], sdx[11]);
+        quat qi = qnormalized(mkq(X.pose[i * 7 + 6], X.pose[i * 7 + 3], X.pose[i * 7 + 4], X.pose[i * 7 + 5]));
+        stm(be.Rs[i], mul(rot_diff, q2R(qi)));
+        st3(be.Ps[i], add(mul(rot_diff, mk(X.pose[i * 7] - X.pose[0], X.pose[i * 7 + 1] - X.pose[1], X.pose[i * 7 + 2] - X.pose[2])), origin_P0));
+        st3(be.Vs[i], mul(rot_diff, mk(X.sb[i * 9], X.sb[i * 9 + 1], X.sb[i * 9 + 2])));
+        for (int k = 0; k < 3; k++) { be.Bas[i][k] = X.sb[i * 9 + 3 + k]; be.Bgs[i][k] = X.sb[i * 9 + 6 + k]; }
+    }
+    if (t == W + 1) {
+        be.tic[0] = X.ex[0]; be.tic[1] = X.ex[1]; be.tic[2] = X.ex[2];
+        stm(be.ric, q2R(qnormalized(mkq(X.ex[6], X.ex[3], X.ex[4], X.ex[5]))));
+        if (cfg.estimate_td) be.td = X.td;
+    }
+    // setDepth (feature_manager.cpp:197-223)
+    for (int k = t; k < nlm; k += nt) {
+        int slot = c.lm_order[k];
+        int pi = c.lm_pidx[slot];
+        if (pi < 0) continue;
+        double d = 1.0 / c.feat[pi];
+        c.lm_depth[slot] = d;
+        c.lm_solve[slot] = d < 0 ? 2 : 1;
+    }
+}
+
+// ====================================================================================================== be_marg
+// Marginalisation in the canonical layout. Landmarks seen first in frame 0 are eliminated analytically (their block of
+// A_mm is diagonal), then pose_0/speedbias_0 (15) through a truncated eigen-decomposition, then the kept block is
+// re-factorised as J^T J by a second (parallel Jacobi) eigen-decomposition (marginalization_factor.cpp:276-308).
+__global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
+    const int s = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+    Ctx c = make_ctx(B, s);
+    const DevCfg &C = *B.cfg;
+    const vio_config &cfg = C.c;
+    BeSeq &be = *c.be;
+    if (!be.do_marg || be.frame_count < c.W) return;
+    const int W = c.W, W1 = W + 1, n = c.NPR;
+    const double eps = 1e-8;
+    __shared__ Params X;
+    __shared__ double sred[256];
+    __shared__ double sdx[6 * VIO_MAXW + 16], srp[6 * VIO_MAXW + 16];
+    __shared__ double cs[VIO_MAXW * 3 + 10], sn[VIO_MAXW * 3 + 10];
+    __shared__ int pp[VIO_MAXW * 3 + 10], qq[VIO_MAXW * 3 + 10];
+    __shared__ int scratch[260];
+    __shared__ double A15[225], V15[225], Pinv[225];
+    __shared__ int newpresent[VIO_MAXW + 3];
+    const bool second_new = be.marginalization_flag != 0;
+    if (second_new && !(be.has_prior && be.prior_present[W - 1])) return;
+    // vector2double
+    if (t <= W) {
+        int i = t;
+        X.pose[i * 7 + 0] = be.Ps[i][0]; X.pose[i * 7 + 1] = be.Ps[i][1]; X.pose[i * 7 + 2] = be.Ps[i][2];
+        quat q = R2q(ldm(be.Rs[i]));
+        X.pose[i * 7 + 3] = q.x; X.pose[i * 7 + 4] = q.y; X.pose[i * 7 + 5] = q.z; X.pose[i * 7 + 6] = q.w;
+        for (int k = 0; k < 3; k++) { X.sb[i * 9 + k] = be.Vs[i][k]; X.sb[i * 9 + 3 + k] = be.Bas[i][k]; X.sb[i * 9 + 6 + k] = be.Bgs[i][k]; }
+    }
+    if (t == W + 1) {
+        X.ex[0] = be.tic[0]; X.ex[1] = be.tic[1]; X.ex[2] = be.tic[2];
+        quat q = R2q(ldm(be.ric));
+        X.ex[3] = q.x; X.ex[4] = q.y; X.ex[5] = q.z; X.ex[6] = q.w;
+        X.td = be.td;
+    }
+    if (t < W + 3) newpresent[t] = 0;
+    __syncthreads();
+    // reduced system over q = [m-block (md) | kept block (n)]
+    const int md = second_new ? 6 : 15;
+    const int mq = md + n;
+    double *A = c.margA, *b = c.margB;
+    for (int i = t; i < mq * mq; i += nt) A[i] = 0;
+    for (int i = t; i < mq; i += nt) b[i] = 0;
+    __syncthreads();
+    // index maps (canonical kept layout: pose slots 0..W-1, sb, ex, td)
+    const int rS = md + 6 * W, rE = md + 6 * W + 9, rT = md + 6 * W + 15;
+    // prior
+    if (be.has_prior) {
+        prior_dx(c, X, sdx);
+        for (int i = t; i < n; i += nt) {
+            double sacc = c.prior_r[i];
+            for (int j = 0; j < n; j++) sacc += c.prior_J[i * n + j] * sdx[j];
+            srp[i] = sacc;
+        }
+        __syncthreads();
+        auto pmap = [&](int a) -> int {
+            if (a < 6 * W) {
+                int k = a / 6, d = a - 6 * k;
+                if (second_new) return k == W - 1 ? d : md + 6 * k + d;
+                return k == 0 ? d : md + 6 * (k - 1) + d;
+            }
+            if (a < 6 * W + 9) return second_new ? rS + (a - 6 * W) : 6 + (a - 6 * W);
+            if (a < 6 * W + 15) return rE + (a - 6 * W - 9);
+            return rT;
+        };
+        for (int w = t; w < n * n; w += nt) {
+            int a = w / n, bb = w - a * n;
+            double sacc = 0;
+            for (int i = 0; i < n; i++) sacc += c.prior_J[i * n + a] * c.prior_J[i * n + bb];
+            A[pmap(a) * mq + pmap(bb)] += sacc;
+        }
+        for (int a = t; a < n; a += nt) {
+            double sacc = 0;
+            for (int i = 0; i < n; i++) sacc += c.prior_J[i * n + a] * srp[i];
+            b[pmap(a)] += sacc;
+        }
+        if (t == 0) {
+            if (second_new) {
+                for (int k = 0; k < W - 1; k++) newpresent[k] = be.prior_present[k];
+                newpresent[W - 1] = 0;
+                newpresent[W] = be.prior_present[W];
+            } else {
+                for (int k = 1; k < W; k++) if (be.prior_present[k]) newpresent[k - 1] = 1;
+            }
+            if (be.prior_present[W + 1]) newpresent[W + 1] = 1;
+            if (be.prior_present[W + 2]) newpresent[W + 2] = 1;
+        }
+        __syncthreads();
+    }
+    if (!second_new) {
+        // IMU factor (0,1)
+        PreInt &p1 = c.pre[be.pre_idx[1]];
+        if (p1.sum_dt < 10.0) {
+            double *Jw = c.pairblk;         // 15x30 whitened
+            double *raw = c.imu_raw;        // 15x31
+            if (t == 0) {
+                bf::imu_sqrt_info(p1.cov, p1.sqrt_info);
+                double r15[15], Jr[450];
+                v3 G = ld3(be.g);
+                bf::imu_raw_residual(p1, G, &X.pose[0], &X.sb[0], &X.pose[7], &X.sb[9], r15);
+                bf::imu_raw_jacobian(p1, G, &X.pose[0], &X.sb[0], &X.pose[7], &X.sb[9], Jr);
+                for (int r = 0; r < 15; r++) {
+                    double sacc = 0;
+                    for (int k = 0; k < 15; k++) sacc += p1.sqrt_info[r * 15 + k] * r15[k];
+                    raw[r * 31 + 30] = sacc;
+                    for (int q = 0; q < 30; q++) raw[r * 31 + q] = Jr[r * 30 + q];
+                }
+            }
+            __syncthreads();
+            for (int w = t; w < 450; w += nt) {
+                int r = w / 30, col = w - r * 30;
+                double sacc = 0;
+                for (int k = r; k < 15; k++) sacc += p1.sqrt_info[r * 15 + k] * raw[k * 31 + col];
+                Jw[w] = sacc;
+            }
+            __syncthreads();
+            for (int w = t; w < 930; w += nt) {
+                int a = w / 31, bb = w - a * 31;
+                int ia = a < 15 ? a : (a < 21 ? md + (a - 15) : rS + (a - 21));
+                double sacc = 0;
+                if (bb < 30) {
+                    int ib = bb < 15 ? bb : (bb < 21 ? md + (bb - 15) : rS + (bb - 21));
+                    for (int k = 0; k < 15; k++) sacc += Jw[k * 30 + a] * Jw[k * 30 + bb];
+                    A[ia * mq + ib] += sacc;
+                } else {
+                    for (int k = 0; k < 15; k++) sacc += Jw[k * 30 + a] * raw[k * 31 + 30];
+                    b[ia] += sacc;
+                }
+            }
+            if (t == 0) { newpresent[0] = 1; newpresent[W] = 1; }
+            __syncthreads();
+        }
+        // projection factors of landmarks first observed in frame 0; each landmark is eliminated on the fly:
+        // contribution = J_q^T J_q - c c^T / d  with c = J_q^T J_l, d = J_l^T J_l (pseudo-inverse: dropped if d <= eps)
+        int nlm = be.n_lm;
+        int *flag = c.lm_tmp, *offs = c.res_k;
+        for (int k = t; k < nlm; k += nt) { int slot = c.lm_order[k]; flag[k] = (in_problem(c, slot) && c.lm_start[slot] == 0) ? 1 : 0; }
+        __syncthreads();
+        int F0 = block_scan_flags(flag, nlm, offs, scratch);
+        int *list0 = c.pair_list;
+        for (int k = t; k < nlm; k += nt) if (flag[k]) list0[offs[k]] = c.lm_order[k];
+        __syncthreads();
+        // per landmark: evaluate residuals with loss correction, store J (2x20) r (2) per residual into c.res (cap checked)
+        const int per = W;  // max residuals per landmark
+        int F0c = min(F0, c.nres_cap / per);
+        for (int w = t; w < F0c * per; w += nt) {
+            int li = w / per, k = w - li * per + 1;
+            int slot = list0[li];
+            double *out = c.res + (size_t)w * 42;
+            if (k >= c.lm_nobs[slot]) { out[40] = 0; out[41] = 0; for (int q = 0; q < 40; q++) out[q] = 0; continue; }
+            double rr[2], J[40];
+            double inv_dep = 1.0 / c.lm_depth[slot];
+            bf::eval_projection(cfg, &X.pose[0], &X.pose[k * 7], X.ex, inv_dep, X.td, obs_ptr(c, slot, 0), obs_ptr(c, slot, k), cfg.estimate_td != 0, rr, J);
+            double sq_norm = rr[0] * rr[0] + rr[1] * rr[1];
+            double rho1 = 1.0 / (1.0 + sq_norm), rho2 = -rho1 * rho1;
+            double sqrt_rho1 = sqrt(rho1), residual_scaling, alpha_sq_norm;
+            if (sq_norm == 0.0 || rho2 <= 0.0) { residual_scaling = sqrt_rho1; alpha_sq_norm = 0.0; }
+            else { double D = 1.0 + 2.0 * sq_norm * rho2 / rho1; double al = 1.0 - sqrt(D); residual_scaling = sqrt_rho1 / (1 - al); alpha_sq_norm = al / sq_norm; }
+            for (int col = 0; col < 20; col++) {
+                double rtJ = rr[0] * J[col] + rr[1] * J[20 + col];
+                out[col] = sqrt_rho1 * (J[col] - alpha_sq_norm * rr[0] * rtJ);
+                out[20 + col] = sqrt_rho1 * (J[20 + col] - alpha_sq_norm * rr[1] * rtJ);
+            }
+            out[40] = rr[0] * residual_scaling;
+            out[41] = rr[1] * residual_scaling;
+        }
+        __syncthreads();
+        // column map of a residual's 19 non-landmark columns into q: pose0 -> 0..5, pose_k -> md+6(k-1), ex, td
+        // accumulate A_qq and b_q: thread per (a,b) over the union index set is irregular; use per-landmark dense rows:
+        // c_l (mq), d_l, b_l, then A -= c c^T/d after adding the plain J^T J per residual.
+        double *Cl = c.Hpl;  // F0c x LW' rows (reuse): needs mq + 2 <= LW  (mq = 15 + 6W + 16 = 6W+31 <= 15W+22 = P)
+        const int ldc = c.LW;
+        for (int w = t; w < F0c * ldc; w += nt) Cl[w] = 0;
+        __syncthreads();
+        for (int w = t; w < F0c * mq; w += nt) {
+            int li = w / mq, col = w - li * mq;
+            int slot = list0[li];
+            int no = c.lm_nobs[slot];
+            // which local column of which residuals feed q-column `col`?
+            double sacc = 0;
+            if (col < 6) { for (int k = 1; k < no; k++) { const double *Jr = c.res + (size_t)(li * per + k - 1) * 42; sacc += Jr[col] * Jr[19] + Jr[20 + col] * Jr[39]; } }
+            else if (col >= md && col < md + 6 * W) {
+                int kf = (col - md) / 6 + 1, d = (col - md) % 6;
+                if (kf < no) { const double *Jr = c.res + (size_t)(li * per + kf - 1) * 42; sacc = Jr[6 + d] * Jr[19] + Jr[26 + d] * Jr[39]; }
+            } else if (col >= rE && col < rE + 6) {
+                int e = 12 + (col - rE);
+                for (int k = 1; k < no; k++) { const double *Jr = c.res + (size_t)(li * per + k - 1) * 42; sacc += Jr[e] * Jr[19] + Jr[20 + e] * Jr[39]; }
+            } else if (col == rT && cfg.estimate_td) {
+                for (int k = 1; k < no; k++) { const double *Jr = c.res + (size_t)(li * per + k - 1) * 42; sacc += Jr[18] * Jr[19] + Jr[38] * Jr[39]; }
+            }
+            Cl[(size_t)li * ldc + col] = sacc;
+        }
+        for (int li = t; li < F0c; li += nt) {
+            int slot = list0[li];
+            int no = c.lm_nobs[slot];
+            double d = 0, bl = 0;
+            for (int k = 1; k < no; k++) { const double *Jr = c.res + (size_t)(li * per + k - 1) * 42; d += Jr[19] * Jr[19] + Jr[39] * Jr[39]; bl += Jr[19] * Jr[40] + Jr[39] * Jr[41]; }
+            c.Hll[li] = d;
+            c.gl[li] = bl;
+        }
+        __syncthreads();
+        // A_qq += sum_res J_q^T J_q  - sum_l c_l c_l^T / d_l ;  thread per (a,b)
+        auto qcol = [&](int col, int k, int &loc) -> bool {  // q-column -> local column of the residual with obs index k
+            if (col < 6) { loc = col; return true; }
+            if (col >= md && col < md + 6 * W) { int kf = (col - md) / 6 + 1; if (kf != k) return false; loc = 6 + (col - md) % 6; return true; }
+            if (col >= rE && col < rE + 6) { loc = 12 + (col - rE); return true; }
+            if (col == rT) { if (!cfg.estimate_td) return false; loc = 18; return true; }
+            return false;
+        };
+        for (int w = t; w < mq * (mq + 1); w += nt) {
+            int a = w / (mq + 1), bb = w - a * (mq + 1);
+            bool a_vis = a < 6 || (a >= md && a < md + 6 * W) || (a >= rE);
+            if (!a_vis) continue;
+            double sacc = 0;
+            for (int li = 0; li < F0c; li++) {
+                int no = c.lm_nobs[list0[li]];
+                double d = c.Hll[li];
+                double dinv = d > eps ? 1.0 / d : 0.0;
+                double ca = Cl[(size_t)li * ldc + a];
+                if (bb < mq) {
+                    for (int k = 1; k < no; k++) {
+                        int la, lb;
+                        if (!qcol(a, k, la) || !qcol(bb, k, lb)) continue;
+                        const double *Jr = c.res + (size_t)(li * per + k - 1) * 42;
+                        sacc += Jr[la] * Jr[lb] + Jr[20 + la] * Jr[20 + lb];
+                    }
+                    sacc -= ca * Cl[(size_t)li * ldc + bb] * dinv;
+                } else {
+                    for (int k = 1; k < no; k++) {
+                        int la;
+                        if (!qcol(a, k, la)) continue;
+                        const double *Jr = c.res + (size_t)(li * per + k - 1) * 42;
+                        sacc += Jr[la] * Jr[40] + Jr[20 + la] * Jr[41];
+                    }
+                    sacc -= ca * c.gl[li] * dinv;
+                }
+            }
+            if (bb < mq) A[a * mq + bb] += sacc; else b[a] += sacc;
+        }
+        if (t == 0) {
+            for (int li = 0; li < F0c; li++) {
+                int no = c.lm_nobs[list0[li]];
+                for (int k = 1; k < no; k++) newpresent[k - 1] = 1;
+                if (no > 1) { newpresent[W + 1] = 1; if (cfg.estimate_td) newpresent[W + 2] = 1; }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- eliminate the m-block (md x md) with a truncated eigen-decomposition
+    for (int w = t; w < md * md; w += nt) { int i = w / md, j = w - i * md; A15[w] = 0.5 * (A[i * mq + j] + A[j * mq + i]); }
+    __syncthreads();
+    if (t == 0) {
+        jacobi_small(A15, V15, md);
+        for (int i = 0; i < md; i++)
+            for (int j = 0; j < md; j++) {
+                double sacc = 0;
+                for (int k = 0; k < md; k++) { double w = A15[k * md + k]; if (w > eps) sacc += V15[i * md + k] * V15[j * md + k] / w; }
+                Pinv[i * md + j] = sacc;
+            }
+    }
+    __syncthreads();
+    double *T1 = c.margW;             // n x md : A_rm * Amm_inv
+    for (int w = t; w < n * md; w += nt) {
+        int i = w / md, j = w - i * md;
+        double sacc = 0;
+        for (int k = 0; k < md; k++) sacc += A[(md + i) * mq + k] * Pinv[k * md + j];
+        T1[w] = sacc;
+    }
+    __syncthreads();
+    double *Ar = c.margV;             // reuse as A_r first (n x n), eigenvectors go to margW+...
+    double *br = c.vec;               // n
+    for (int w = t; w < n * n; w += nt) {
+        int i = w / n, j = w - i * n;
+        double tt = A[(md + i) * mq + md + j];
+        for (int k = 0; k < md; k++) tt -= T1[i * md + k] * A[k * mq + md + j];
+        Ar[w] = tt;
+    }
+    for (int i = t; i < n; i += nt) {
+        double sacc = b[md + i];
+        for (int k = 0; k < md; k++) sacc -= T1[i * md + k] * b[k];
+        br[i] = sacc;
+    }
+    __syncthreads();
+    double *As = c.margA;             // n x n symmetrised copy (margA is free now)
+    for (int w = t; w < n * n; w += nt) { int i = w / n, j = w - i * n; As[w] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
+    __syncthreads();
+    double *Vv = c.margV;
+    jacobi_block(As, Vv, n, cs, sn, pp, qq, sred);
+    // linearized_jacobians = sqrt(S) V^T ; linearized_residuals = S^-1/2 V^T b
+    for (int w = t; w < n * n; w += nt) {
+        int k = w / n, i = w - k * n;
+        double wv = As[k * n + k];
+        double S = wv > eps ? wv : 0.0;
+        c.prior_J[w] = sqrt(S) * Vv[i * n + k];
+    }
+    for (int k = t; k < n; k += nt) {
+        double wv = As[k * n + k];
+        double Sinv = wv > eps ? 1.0 / wv : 0.0;
+        double vb = 0;
+        for (int i = 0; i < n; i++) vb += Vv[i * n + k] * br[i];
+        c.prior_r[k] = sqrt(Sinv) * vb;
+    }
+    // keep_block_data in the shifted (canonical) layout
+    if (t < W) {
+        int src = second_new ? (t == W - 1 ? W : t) : t + 1;
+        for (int d = 0; d < 7; d++) c.prior_x0[t * 7 + d] = X.pose[src * 7 + d];
+    }
+    if (t == W) for (int d = 0; d < 9; d++) c.prior_x0[W * 7 + d] = X.sb[(second_new ? 0 : 1) * 9 + d];
+    if (t == W + 1) { for (int d = 0; d < 7; d++) c.prior_x0[W * 7 + 9 + d] = X.ex[d]; c.prior_x0[W * 7 + 16] = X.td; }
+    __syncthreads();
+    if (t < W + 3) be.prior_present[t] = newpresent[t];
+    if (t == 0) be.has_prior = 1;
+}
+
+// ====================================================================================================== be_finish
+__global__ __launch_bounds__(256) void be_finish_kernel(Batch B) {
+    const int s = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+    Ctx c = make_ctx(B, s);
+    const DevCfg &C = *B.cfg;
+    const vio_config &cfg = C.c;
+    BeSeq &be = *c.be;
+    const int W = c.W, W1 = W + 1;
+    __shared__ int scratch[260];
+    __shared__ int sh_i[4];
+    __shared__ PreWork pw;
+    double *od = B.odom + (size_t)s * 11;
+    if (!be.processed) return;
+    int nlm = be.n_lm;
+    int *flag = c.lm_pidx, *offs = c.lm_aidx;  // free after the solve
+    const int fc = be.frame_count;
+    const int sflag0 = be.solver_flag;
+    __syncthreads();
+    if (sflag0 == 0) {
+        if (fc == W && be.do_solve) {
+            if (t == 0) { st3(be.latest_Bg, ld3(be.Bgs[fc])); be.solver_flag = 1; }
+            __syncthreads();
+        } else {
+            // frame_count < WINDOW_SIZE: copy the state forward (estimator.cpp:306-315)
+            if (t == 0 && fc < W) {
+                int n = fc + 1;
+                for (int k = 0; k < 3; k++) { be.Ps[n][k] = be.Ps[fc][k]; be.Vs[n][k] = be.Vs[fc][k]; be.Bas[n][k] = be.Bas[fc][k]; be.Bgs[n][k] = be.Bgs[fc][k]; }
+                for (int k = 0; k < 9; k++) be.Rs[n][k] = be.Rs[fc][k];
+                be.frame_count = n;
+            }
+            return;
+        }
+    } else {
+        // movingConsistencyCheck (estimator.cpp:1965-2009)
+        m3 ric = ldm(be.ric);
+        v3 tic = ld3(be.tic);
+        for (int k = t; k < nlm; k += nt) {
+            int slot = c.lm_order[k];
+            if (!(c.lm_nobs[slot] >= 2 && c.lm_start[slot] < W - 2)) continue;
+            double depth = c.lm_depth[slot];
+            if (depth < 0) continue;
+            int imu_i = c.lm_start[slot], no = c.lm_nobs[slot];
+            const double *oi = obs_ptr(c, slot, imu_i);
+            v3 pts_i = mk(oi[0], oi[1], oi[2]);
+            double err = 0, err3 = 0;
+            int cnt = 0;
+            for (int q = 1; q < no; q++) {
+                int imu_j = imu_i + q;
+                const double *oj = obs_ptr(c, slot, imu_j);
+                v3 pts_j = mk(oj[0], oj[1], oj[2]);
+                v3 pts_w = add(mul(ldm(be.Rs[imu_i]), add(mul(ric, scl(depth, pts_i)), tic)), ld3(be.Ps[imu_i]));
+                v3 pts_cj = mul(tr(ric), sub(mul(tr(ldm(be.Rs[imu_j])), sub(pts_w, ld3(be.Ps[imu_j]))), tic));
+                double rx = pts_cj.x / pts_cj.z - pts_j.x, ry = pts_cj.y / pts_cj.z - pts_j.y;
+                err += sqrt(rx * rx + ry * ry);
+                err3 += nrm(sub(pts_cj, pts_j)) / depth;
+                cnt++;
+            }
+            if (cnt > 0) c.lm_dyn[slot] = (cfg.focal_length * err / cnt > 10 || err3 / cnt > 2.0) ? 1 : 0;
+        }
+        __syncthreads();
+        // failureDetection (estimator.cpp:1113-1159)
+        if (t == 0) {
+            int fail = 0;
+            if (nrm(ld3(be.Bas[W])) > 2.5) fail = 1;
+            if (nrm(ld3(be.Bgs[W])) > 1.0) fail = 1;
+            v3 tmpP = ld3(be.Ps[W]);
+            if (nrm(sub(tmpP, ld3(be.last_P))) > 5) fail = 1;
+            if (fabs(tmpP.z - be.last_P[2]) > 1) fail = 1;
+            sh_i[0] = fail;
+        }
+        __syncthreads();
+        if (sh_i[0]) {
+            // clearState() + setParameter() (estimator.cpp:345-353, 43-116, 15-41)
+            for (int k = t; k < c.NL; k += nt) c.lm_free[k] = c.NL - 1 - k;
+            if (t == 0) {
+                for (int i = 0; i <= W + 1; i++) c.pre[i].valid = 0;
+                for (int i = 0; i <= W; i++) {
+                    for (int k = 0; k < 3; k++) { be.Ps[i][k] = 0; be.Vs[i][k] = 0; be.Bas[i][k] = 0; be.Bgs[i][k] = 0; }
+                    stm(be.Rs[i], eye());
+                    be.Headers[i] = 0;
+                    be.pre_idx[i] = i;
+                }
+                for (int k = 0; k < 9; k++) be.ric[k] = cfg.ric[k];
+                for (int k = 0; k < 3; k++) { be.tic[k] = cfg.tic[k]; be.latest_Bg[k] = 0; }
+                be.td = cfg.td;
+                be.first_imu = 0; be.frame_count = 0; be.solver_flag = 0; be.openExEstimation = 0; be.has_prior = 0;
+                be.initFirstPoseFlag = 0; be.prevTime = -1; be.n_lm = 0; be.n_free = c.NL; be.ring_base = 0;
+                be.imu_head = be.imu_count;  // clearState() empties imu_buf
+                be.reboot_count++;
+                be.status_code = VIO_REBOOTED;
+            }
+            return;
+        }
+    }
+    // ---- slideWindow (estimator.cpp:1580-1689)
+    if (be.marginalization_flag == 0) {
+        if (t == 0) {
+            for (int k = 0; k < 9; k++) be.back_R0[k] = be.Rs[0][k];
+            for (int k = 0; k < 3; k++) be.back_P0[k] = be.Ps[0][k];
+            int first = be.pre_idx[0];
+            for (int i = 0; i < W; i++) {
+                be.Headers[i] = be.Headers[i + 1];
+                for (int k = 0; k < 3; k++) { be.Ps[i][k] = be.Ps[i + 1][k]; be.Vs[i][k] = be.Vs[i + 1][k]; be.Bas[i][k] = be.Bas[i + 1][k]; be.Bgs[i][k] = be.Bgs[i + 1][k]; }
+                for (int k = 0; k < 9; k++) be.Rs[i][k] = be.Rs[i + 1][k];
+                be.pre_idx[i] = be.pre_idx[i + 1];
+            }
+            be.pre_idx[W] = first;
+            // slot W keeps the newest state; its pre-integration restarts from acc_0 / gyr_0 (:1614-1630)
+            bf::preint_init(c.pre[first], ld3(be.acc_0), ld3(be.gyr_0), ld3(be.Bas[W]), ld3(be.Bgs[W]));
+        }
+        __syncthreads();
+        // slideWindowOld -> removeBackShiftDepth (feature_manager.cpp:660-691); solver_flag is NON_LINEAR here
+        m3 R0 = mul(ldm(be.back_R0), ldm(be.ric)), R1 = mul(ldm(be.Rs[0]), ldm(be.ric));
+        v3 P0 = add(ld3(be.back_P0), mul(ldm(be.back_R0), ld3(be.tic))), P1 = add(ld3(be.Ps[0]), mul(ldm(be.Rs[0]), ld3(be.tic)));
+        for (int k = t; k < nlm; k += nt) {
+            int slot = c.lm_order[k];
+            int keep = 1;
+            if (c.lm_start[slot] != 0) c.lm_start[slot]--;
+            else {
+                const double *o0 = obs_ptr(c, slot, 0);
+                v3 uv_i = mk(o0[0], o0[1], o0[2]);
+                int no = c.lm_nobs[slot] - 1;
+                c.lm_nobs[slot] = no;
+                if (no < 2) keep = 0;
+                else {
+                    v3 pts_i = scl(c.lm_depth[slot], uv_i);
+                    v3 w_pts_i = add(mul(R0, pts_i), P0);
+                    v3 pts_j = mul(tr(R1), sub(w_pts_i, P1));
+                    c.lm_depth[slot] = pts_j.z > 0 ? pts_j.z : cfg.init_depth;
+                }
+            }
+            flag[k] = keep;
+        }
+        __syncthreads();
+        if (t == 0) be.ring_base = (be.ring_base + 1) % W1;  // frame f becomes frame f-1 without moving observations
+        __syncthreads();
+        lm_compact(c, flag, offs, scratch);
+    } else {
+        // MARGIN_SECOND_NEW: merge the IMU samples of frame W into W-1 (:1651-1687)
+        PreInt &dst = c.pre[be.pre_idx[W - 1]];
+        PreInt &src = c.pre[be.pre_idx[W]];
+        if (t == 0) {
+            be.Headers[W - 1] = be.Headers[W];
+            for (int k = 0; k < 3; k++) { be.Ps[W - 1][k] = be.Ps[W][k]; be.Vs[W - 1][k] = be.Vs[W][k]; be.Bas[W - 1][k] = be.Bas[W][k]; be.Bgs[W - 1][k] = be.Bgs[W][k]; }
+            for (int k = 0; k < 9; k++) be.Rs[W - 1][k] = be.Rs[W][k];
+        }
+        preint_load(dst, pw);
+        int nsrc = src.n_buf;
+        for (int q = 0; q < nsrc; q++) {
+            double dt = src.dt_buf[q];
+            v3 acc = ld3(src.acc_buf[q]), gyr = ld3(src.gyr_buf[q]);
+            if (t == 0) {
+                int nb = dst.n_buf;
+                if (nb < VIO_IMU_SLOT_CAP) { dst.dt_buf[nb] = dt; st3(dst.acc_buf[nb], acc); st3(dst.gyr_buf[nb], gyr); dst.n_buf = nb + 1; }
+            }
+            preint_propagate(dst, pw, cfg, dt, acc, gyr);
+        }
+        preint_store(dst, pw);
+        if (t == 0) bf::preint_init(src, ld3(be.acc_0), ld3(be.gyr_0), ld3(be.Bas[W]), ld3(be.Bgs[W]));
+        __syncthreads();
+        // slideWindowNew -> removeFront(frame_count) (feature_manager.cpp:710-730)
+        for (int k = t; k < nlm; k += nt) {
+            int slot = c.lm_order[k];
+            int keep = 1;
+            int st = c.lm_start[slot], no = c.lm_nobs[slot];
+            if (st == W) {
+                double *d = obs_ptr(c, slot, W - 1);
+                const double *sr = obs_ptr(c, slot, W);
+                for (int q = 0; q < VIO_OBS_D; q++) d[q] = sr[q];
+                c.lm_start[slot] = st - 1;
+            } else {
+                int endf = st + no - 1;
+                if (endf >= W - 1) {
+                    if (endf == W) {
+                        double *d = obs_ptr(c, slot, W - 1);
+                        const double *sr = obs_ptr(c, slot, W);
+                        for (int q = 0; q < VIO_OBS_D; q++) d[q] = sr[q];
+                    }
+                    c.lm_nobs[slot] = no - 1;
+                    if (no - 1 == 0) keep = 0;
+                }
+            }
+            flag[k] = keep;
+        }
+        __syncthreads();
+        lm_compact(c, flag, offs, scratch);
+    }
+    // ---- removeFailures (feature_manager.cpp:225-233); not called on the initialisation frame (estimator.cpp:282-290)
+    if (sflag0 == 1) {
+        nlm = be.n_lm;
+        for (int k = t; k < nlm; k += nt) flag[k] = c.lm_solve[c.lm_order[k]] == 2 ? 0 : 1;
+        __syncthreads();
+        lm_compact(c, flag, offs, scratch);
+    }
+    if (t == 0) {
+        for (int k = 0; k < 9; k++) { be.last_R[k] = be.Rs[W][k]; be.last_R0[k] = be.Rs[0][k]; }
+        for (int k = 0; k < 3; k++) { be.last_P[k] = be.Ps[W][k]; be.last_P0[k] = be.Ps[0][k]; }
+        st3(be.latest_Bg, ld3(be.Bgs[W]));
+        // CSV row of visualization.cpp:214-225
+        quat q = R2q(ldm(be.Rs[W]));
+        od[0] = be.Headers[W];
+        od[1] = be.Ps[W][0]; od[2] = be.Ps[W][1]; od[3] = be.Ps[W][2];
+        od[4] = q.w; od[5] = q.x; od[6] = q.y; od[7] = q.z;
+        od[8] = be.Vs[W][0]; od[9] = be.Vs[W][1]; od[10] = be.Vs[W][2];
+    }
+}
+
+// ====================================================================================================== stage tests
+// IntegrationBase::push_back x n followed by IMUFactor::Evaluate, through the same device code the pipeline uses.
+__global__ __launch_bounds__(256) void be_stage_imu_kernel(vio_config cfg, PreInt *P, int n, const double *dt, const double *acc,
+                                                            const double *gyr, const double *par /*pi7 sbi9 pj7 sbj9*/, double g_norm,
+                                                            double *preint_out, double *r15, double *J480) {
+    __shared__ PreWork pw;
+    const int t = threadIdx.x;
+    preint_load(*P, pw);
+    for (int q = 0; q < n; q++) preint_propagate(*P, pw, cfg, dt[q], ld3(acc + 3 * q), ld3(gyr + 3 * q));
+    preint_store(*P, pw);
+    if (t == 0) {
+        PreInt &p = *P;
+        preint_out[0] = p.dp[0]; preint_out[1] = p.dp[1]; preint_out[2] = p.dp[2];
+        for (int k = 0; k < 4; k++) preint_out[3 + k] = p.dq[k];
+        preint_out[7] = p.dv[0]; preint_out[8] = p.dv[1]; preint_out[9] = p.dv[2];
+        preint_out[10] = p.sum_dt;
+        for (int k = 0; k < 225; k++) { preint_out[11 + k] = p.jac[k]; preint_out[236 + k] = p.cov[k]; }
+        bf::imu_sqrt_info(p.cov, p.sqrt_info);
+        double raw[15], Jr[450];
+        v3 G = mk(0, 0, g_norm);
+        bf::imu_raw_residual(p, G, par, par + 7, par + 16, par + 23, raw);
+        bf::imu_raw_jacobian(p, G, par, par + 7, par + 16, par + 23, Jr);
+        for (int r = 0; r < 15; r++) {
+            double sacc = 0;
+            for (int k = 0; k < 15; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k];
+            r15[r] = sacc;
+        }
+        // whitened Jacobians in the reference's global layout: 15x7, 15x9, 15x7, 15x9 (7th pose column = 0)
+        for (int r = 0; r < 15; r++)
+            for (int col = 0; col < 30; col++) {
+                double sacc = 0;
+                for (int k = r; k < 15; k++) sacc += p.sqrt_info[r * 15 + k] * Jr[k * 30 + col];
+                if (col < 6) J480[r * 7 + col] = sacc;
+                else if (col < 15) J480[105 + r * 9 + (col - 6)] = sacc;
+                else if (col < 21) J480[240 + r * 7 + (col - 15)] = sacc;
+                else J480[345 + r * 9 + (col - 21)] = sacc;
+            }
+        for (int r = 0; r < 15; r++) { J480[r * 7 + 6] = 0; J480[240 + r * 7 + 6] = 0; }
+    }
+}
+__global__ void be_stage_projection_kernel(vio_config cfg, const double *in /*pi7 pj7 ex7 inv_dep td oi9 oj9*/, int use_td, double *r2, double *J46) {
+    if (threadIdx.x != 0) return;
+    double J[40];
+    bf::eval_projection(cfg, in, in + 7, in + 14, in[21], in[22], in + 23, in + 32, use_td != 0, r2, J);
+    for (int a = 0; a < 2; a++) {
+        for (int d = 0; d < 6; d++) { J46[a * 7 + d] = J[a * 20 + d]; J46[14 + a * 7 + d] = J[a * 20 + 6 + d]; J46[28 + a * 7 + d] = J[a * 20 + 12 + d]; }
+        J46[a * 7 + 6] = 0; J46[14 + a * 7 + 6] = 0; J46[28 + a * 7 + 6] = 0;
+        J46[42 + a] = J[a * 20 + 19];
+        J46[44 + a] = J[a * 20 + 18];
+    }
+}

@@ -1,0 +1,158 @@
+// Small fixed-size FP64 algebra for the device kernels (gfx950). Everything is __host__ __device__ so the
+// per-thread math can also be exercised from host-side self tests; the kernels are the only product callers.
+// Conventions follow the reference's Eigen usage: Hamilton quaternions stored (w,x,y,z), row-major 3x3.
+// Reference helpers restated here: vins_estimator/src/utility/utility.h:11-108, utility.cpp:5-15.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define DM_HD __host__ __device__ __forceinline__
+#else
+#define DM_HD inline
+#endif
+
+namespace dm {
+
+struct v3 { double x, y, z; };
+struct m3 { double a[9]; };
+struct quat { double w, x, y, z; };
+
+DM_HD v3 mk(double x, double y, double z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+DM_HD v3 add(v3 a, v3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DM_HD v3 sub(v3 a, v3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DM_HD v3 scl(double s, v3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+DM_HD v3 neg(v3 a) { return mk(-a.x, -a.y, -a.z); }
+DM_HD double dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DM_HD v3 cross(v3 a, v3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DM_HD double nrm(v3 a) { return sqrt(dot(a, a)); }
+DM_HD double get(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+DM_HD v3 ld3(const double *p) { return mk(p[0], p[1], p[2]); }
+DM_HD void st3(double *p, v3 a) { p[0] = a.x; p[1] = a.y; p[2] = a.z; }
+
+DM_HD m3 eye() { m3 r; for (int i = 0; i < 9; i++) r.a[i] = 0; r.a[0] = r.a[4] = r.a[8] = 1; return r; }
+DM_HD m3 zero3() { m3 r; for (int i = 0; i < 9; i++) r.a[i] = 0; return r; }
+DM_HD m3 ldm(const double *p) { m3 r; for (int i = 0; i < 9; i++) r.a[i] = p[i]; return r; }
+DM_HD void stm(double *p, const m3 &m) { for (int i = 0; i < 9; i++) p[i] = m.a[i]; }
+DM_HD m3 mul(const m3 &A, const m3 &B) {
+    m3 r;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += A.a[i * 3 + k] * B.a[k * 3 + j];
+            r.a[i * 3 + j] = s;
+        }
+    return r;
+}
+DM_HD v3 mul(const m3 &A, v3 v) {
+    return mk(A.a[0] * v.x + A.a[1] * v.y + A.a[2] * v.z, A.a[3] * v.x + A.a[4] * v.y + A.a[5] * v.z,
+              A.a[6] * v.x + A.a[7] * v.y + A.a[8] * v.z);
+}
+DM_HD m3 tr(const m3 &A) { m3 r; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) r.a[i * 3 + j] = A.a[j * 3 + i]; return r; }
+DM_HD m3 scl(double s, const m3 &A) { m3 r; for (int i = 0; i < 9; i++) r.a[i] = s * A.a[i]; return r; }
+DM_HD m3 add(const m3 &A, const m3 &B) { m3 r; for (int i = 0; i < 9; i++) r.a[i] = A.a[i] + B.a[i]; return r; }
+DM_HD m3 sub(const m3 &A, const m3 &B) { m3 r; for (int i = 0; i < 9; i++) r.a[i] = A.a[i] - B.a[i]; return r; }
+DM_HD m3 neg(const m3 &A) { m3 r; for (int i = 0; i < 9; i++) r.a[i] = -A.a[i]; return r; }
+DM_HD m3 skew(v3 q) {  // utility.h:26-34
+    m3 r = zero3();
+    r.a[1] = -q.z; r.a[2] = q.y; r.a[3] = q.z; r.a[5] = -q.x; r.a[6] = -q.y; r.a[7] = q.x;
+    return r;
+}
+
+DM_HD quat mkq(double w, double x, double y, double z) { quat q; q.w = w; q.x = x; q.y = y; q.z = z; return q; }
+DM_HD v3 qvec(quat q) { return mk(q.x, q.y, q.z); }
+DM_HD quat qmul(quat a, quat b) {
+    return mkq(a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+               a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x);
+}
+DM_HD quat qnormalized(quat q) {
+    double n = sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+    return mkq(q.w / n, q.x / n, q.y / n, q.z / n);
+}
+DM_HD quat qinv(quat q) {  // Eigen inverse(): conjugate / squaredNorm
+    double n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+    return mkq(q.w / n2, -q.x / n2, -q.y / n2, -q.z / n2);
+}
+DM_HD m3 q2R(quat q) {  // Eigen toRotationMatrix (no normalisation)
+    m3 r;
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    r.a[0] = 1 - (tyy + tzz); r.a[1] = txy - twz;       r.a[2] = txz + twy;
+    r.a[3] = txy + twz;       r.a[4] = 1 - (txx + tzz); r.a[5] = tyz - twx;
+    r.a[6] = txz - twy;       r.a[7] = tyz + twx;       r.a[8] = 1 - (txx + tyy);
+    return r;
+}
+DM_HD v3 qrot(quat q, v3 v) {  // Eigen q * v
+    v3 u = qvec(q);
+    v3 uv = cross(u, v);
+    uv = add(uv, uv);
+    return add(add(v, scl(q.w, uv)), cross(u, uv));
+}
+DM_HD quat R2q(const m3 &m) {  // Eigen Quaternion(Matrix3)
+    quat q;
+    double t = m.a[0] + m.a[4] + m.a[8];
+    if (t > 0) {
+        t = sqrt(t + 1.0);
+        q.w = 0.5 * t;
+        t = 0.5 / t;
+        q.x = (m.a[7] - m.a[5]) * t;
+        q.y = (m.a[2] - m.a[6]) * t;
+        q.z = (m.a[3] - m.a[1]) * t;
+    } else {
+        int i = 0;
+        if (m.a[4] > m.a[0]) i = 1;
+        if (m.a[8] > m.a[i * 4]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m.a[i * 4] - m.a[j * 4] - m.a[k * 4] + 1.0);
+        double qv[3];
+        qv[i] = 0.5 * t;
+        t = 0.5 / t;
+        q.w = (m.a[k * 3 + j] - m.a[j * 3 + k]) * t;
+        qv[j] = (m.a[j * 3 + i] + m.a[i * 3 + j]) * t;
+        qv[k] = (m.a[k * 3 + i] + m.a[i * 3 + k]) * t;
+        q.x = qv[0]; q.y = qv[1]; q.z = qv[2];
+    }
+    return q;
+}
+DM_HD quat deltaQ(v3 th) { return mkq(1.0, th.x / 2, th.y / 2, th.z / 2); }  // utility.h:11-24
+
+DM_HD v3 R2ypr(const m3 &R) {  // utility.h:66-81, degrees
+    const double PI = 3.14159265358979323846;
+    v3 n = mk(R.a[0], R.a[3], R.a[6]), o = mk(R.a[1], R.a[4], R.a[7]), a = mk(R.a[2], R.a[5], R.a[8]);
+    double y = atan2(n.y, n.x);
+    double p = atan2(-n.z, n.x * cos(y) + n.y * sin(y));
+    double r = atan2(a.x * sin(y) - a.y * cos(y), -o.x * sin(y) + o.y * cos(y));
+    return mk(y / PI * 180.0, p / PI * 180.0, r / PI * 180.0);
+}
+DM_HD m3 ypr2R(v3 ypr) {  // utility.h:83-108
+    const double PI = 3.14159265358979323846;
+    double y = ypr.x / 180.0 * PI, p = ypr.y / 180.0 * PI, r = ypr.z / 180.0 * PI;
+    m3 Rz = zero3(), Ry = zero3(), Rx = zero3();
+    Rz.a[0] = cos(y); Rz.a[1] = -sin(y); Rz.a[3] = sin(y); Rz.a[4] = cos(y); Rz.a[8] = 1;
+    Ry.a[0] = cos(p); Ry.a[2] = sin(p); Ry.a[4] = 1; Ry.a[6] = -sin(p); Ry.a[8] = cos(p);
+    Rx.a[0] = 1; Rx.a[4] = cos(r); Rx.a[5] = -sin(r); Rx.a[7] = sin(r); Rx.a[8] = cos(r);
+    return mul(mul(Rz, Ry), Rx);
+}
+DM_HD quat fromTwoVectors(v3 a, v3 b) {  // Eigen FromTwoVectors, non-antiparallel branch
+    v3 v0 = scl(1.0 / nrm(a), a), v1 = scl(1.0 / nrm(b), b);
+    double c = dot(v1, v0);
+    if (c < -1.0 + 1e-12) {
+        v3 ax = fabs(v0.x) < 0.9 ? cross(v0, mk(1, 0, 0)) : cross(v0, mk(0, 1, 0));
+        ax = scl(1.0 / nrm(ax), ax);
+        return mkq(0, ax.x, ax.y, ax.z);
+    }
+    v3 axis = cross(v0, v1);
+    double s = sqrt((1.0 + c) * 2.0);
+    double invs = 1.0 / s;
+    return mkq(s * 0.5, axis.x * invs, axis.y * invs, axis.z * invs);
+}
+DM_HD m3 g2R(v3 g) {  // utility.cpp:5-15
+    m3 R0 = q2R(fromTwoVectors(g, mk(0, 0, 1)));
+    double yaw = R2ypr(R0).x;
+    return mul(ypr2R(mk(-yaw, 0, 0)), R0);
+}
+
+}  // namespace dm

@@ -1,0 +1,1077 @@
+// Front-end kernels (gfx950): FeatureTracker::readImage (vins_estimator/src/feature_tracker/feature_tracker.cpp:263-439)
+// batched over S sequences.  One launch chain per camera frame:
+//   fe_begin   predictMotion (estimator.cpp:1790-1860) + first-image / IMU-availability gating
+//   fe_pyramid cv::pyrDown levels of the new frame (+ level-0 copy into the ping-pong buffer)
+//   fe_lk      calcOpticalFlowPyrLK 21x21, one wavefront per feature, patches staged in LDS, wave reductions
+//   fe_select  status/border cull, track_cnt++, rejectWithF (7-point RANSAC), setMask, per-grid counts
+//   fe_fast    grid-FAST: FAST-9/16 score + NMS per deficit cell in an LDS tile (gridDetect :105-171, first half)
+//   fe_add     mask filter + top-k + addPoints per cell in order, undistortedPoints, updateID, feature-map packaging
+// All arithmetic follows SURVEY.md Appendix B so results are bit-identical to oracle/frontend.cpp
+// (integer sums are exact, float/double ops are IEEE with -ffp-contract=off).
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+__device__ __forceinline__ int cv_round(float v) { return __float2int_rn(v); }
+__device__ __forceinline__ int cv_floor(float v) { return (int)floorf(v); }
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+    for (int off = 32; off > 0; off >>= 1) {
+        int lo = __shfl_xor((int)(v & 0xffffffffLL), off, 64);
+        int hi = __shfl_xor((int)(v >> 32), off, 64);
+        v += ((long long)hi << 32) | (unsigned int)lo;
+    }
+    return v;
+}
+
+// camera (camera_model/src/camera_models/PinholeCamera.cc:449-542,645-662)
+__device__ __forceinline__ void cam_distortion(const vio_config &c, double x, double y, double &dx, double &dy) {
+    double mx2 = x * x, my2 = y * y, mxy = x * y;
+    double rho2 = mx2 + my2;
+    double rad = c.k1 * rho2 + c.k2 * rho2 * rho2;
+    dx = x * rad + 2.0 * c.p1 * mxy + c.p2 * (rho2 + 2.0 * mx2);
+    dy = y * rad + 2.0 * c.p2 * mxy + c.p1 * (rho2 + 2.0 * my2);
+}
+__device__ void cam_lift(const vio_config &c, double u, double v, double &x, double &y) {
+    double inv_K11 = 1.0 / c.fx, inv_K13 = -c.cx / c.fx, inv_K22 = 1.0 / c.fy, inv_K23 = -c.cy / c.fy;
+    double mx_d = inv_K11 * u + inv_K13, my_d = inv_K22 * v + inv_K23, dx, dy;
+    cam_distortion(c, mx_d, my_d, dx, dy);
+    double mx_u = mx_d - dx, my_u = my_d - dy;
+    for (int i = 1; i < 8; i++) {
+        cam_distortion(c, mx_u, my_u, dx, dy);
+        mx_u = mx_d - dx;
+        my_u = my_d - dy;
+    }
+    x = mx_u;
+    y = my_u;
+}
+__device__ void cam_project(const vio_config &c, double X, double Y, double Z, double &u, double &v) {
+    double px = X / Z, py = Y / Z, dx, dy;
+    cam_distortion(c, px, py, dx, dy);
+    u = c.fx * (px + dx) + c.cx;
+    v = c.fy * (py + dy) + c.cy;
+}
+
+// mask(p) == 0 <=> p lies in the cv::circle(filled, r = MIN_DIST) raster of some accepted centre
+__device__ __forceinline__ bool in_disk(const int *hw, int r, int px, int py, int cx, int cy) {
+    int dy = py - cy;
+    dy = dy < 0 ? -dy : dy;
+    if (dy > r) return false;
+    int dx = px - cx;
+    dx = dx < 0 ? -dx : dx;
+    return dx <= hw[dy];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ fe_begin
+// grid S, 64 threads.  mode: 0 = vio_feed (nodelet gating), 1 = vio_track only (no gating)
+__global__ void fe_begin_kernel(Batch B, const double *stamps, int gate) {
+    int s = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const DevCfg &C = *B.cfg;
+    FeSeq &fe = B.fe[s];
+    BeSeq &be = B.be[s];
+    double t = stamps[s];
+    fe.n_deficit = 0;
+    fe.n_obs = 0;
+    fe.publish_ok = 0;
+    be.processed = 0;
+    be.status_code = VIO_OK;
+    be.cur_stamp = t;
+    // ring bookkeeping: drop samples that were overwritten
+    if (be.imu_count - be.imu_head > C.NIMU) be.imu_head = be.imu_count - C.NIMU;
+    const double *it = B.imu_t + (size_t)s * C.NIMU;
+    const double *ig = B.imu_gyr + (size_t)s * C.NIMU * 3;
+    bool have = be.imu_count > be.imu_head;
+    double back_t = have ? it[(be.imu_count - 1) % C.NIMU] : -1e300;
+    if (gate) {
+        // caller contract of vio_feed: IMU pushed through stamp + td (upstream busy-waits, estimator.cpp:178-183)
+        if (!(have && t + be.td <= back_t)) {
+            be.status_code = VIO_NEED_IMU;
+            fe.first_image_flag = fe.first_image_flag;  // nothing consumed
+            fe.n_forw = -1;                             // tells the later kernels to skip this sequence
+            return;
+        }
+        if (fe.first_image_flag) {  // estimator_nodelet.cpp:234-240
+            fe.first_image_flag = 0;
+            fe.last_image_time = t;
+            fe.n_forw = -1;
+            return;
+        }
+    }
+    // Estimator::predictMotion(last_image_time, t + td)  estimator.cpp:1790-1860
+    dm::m3 rel = dm::eye();
+    double t0 = fe.last_image_time, t1 = t + be.td;
+    if (have && t1 <= back_t) {
+        int k = be.imu_head;
+        while (k < be.imu_count && it[k % C.NIMU] <= t0) k++;
+        bool first = true;
+        double prev_t = 0;
+        dm::v3 prev_gyr = dm::mk(0, 0, 0);
+        dm::m3 ricT = dm::tr(dm::ldm(be.ric));
+        dm::v3 bg = dm::ld3(be.latest_Bg);
+        while (k < be.imu_count && it[k % C.NIMU] <= t1) {
+            double tk = it[k % C.NIMU];
+            dm::v3 w = dm::ld3(ig + (size_t)(k % C.NIMU) * 3);
+            k++;
+            if (first) { prev_t = tk; first = false; prev_gyr = w; continue; }
+            double dt = tk - prev_t;
+            prev_t = tk;
+            dm::v3 un_gyr = dm::sub(dm::scl(0.5, dm::add(prev_gyr, w)), bg);
+            prev_gyr = w;
+            dm::v3 aa = dm::scl(dt, dm::mul(ricT, un_gyr));
+            double ang = dm::nrm(aa);
+            dm::m3 Rk = dm::eye();
+            if (ang > 0) {
+                dm::v3 ax = dm::scl(1.0 / ang, aa);
+                double sn = sin(ang), cs = cos(ang);
+                dm::m3 K = dm::skew(ax);
+                Rk = dm::add(dm::add(dm::eye(), dm::scl(sn, K)), dm::scl(1 - cs, dm::mul(K, K)));
+            }
+            rel = dm::mul(rel, dm::tr(Rk));
+        }
+    }
+    dm::stm(fe.R_rel, rel);
+    fe.last_image_time = t;
+    fe.cur_time = t;
+    fe.n_forw = 0;
+    fe.n_unstable = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ fe_pyramid
+// cv::pyrDown: [1 4 6 4 1]^2/256, BORDER_REFLECT_101, (sum+128)>>8.  grid (tiles_x, tiles_y, S), 256 threads.
+// Each workgroup produces a 64x16 tile of dst from a (2*64+3)x(2*16+3) LDS tile of src (coalesced row loads);
+// when copy0 != NULL the 128x32 source pixels owned by the tile are also copied to the level-0 ping-pong buffer.
+#define PD_TW 64
+#define PD_TH 16
+__device__ void pyrdown_tile(const uint8_t *src, int sw, int sh, uint8_t *dst, uint8_t *l0) {
+    int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    __shared__ uint8_t tile[2 * PD_TH + 3][2 * PD_TW + 4];
+    __shared__ int hrow[2 * PD_TH + 3][PD_TW];
+    int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
+    int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
+    const int TWS = 2 * PD_TW + 3, THS = 2 * PD_TH + 3;
+    for (int q = threadIdx.x; q < TWS * THS; q += 256) {
+        int ty = q / TWS, tx = q - ty * TWS;
+        int gx = sx0 + tx, gy = sy0 + ty;
+        uint8_t v = src[(size_t)reflect101(gy, sh) * sw + reflect101(gx, sw)];
+        tile[ty][tx] = v;
+        if (l0 && tx >= 2 && tx < 2 + 2 * PD_TW && ty >= 2 && ty < 2 + 2 * PD_TH && gx < sw && gy < sh) l0[(size_t)gy * sw + gx] = v;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < THS * PD_TW; q += 256) {
+        int ty = q / PD_TW, x = q - ty * PD_TW;
+        const uint8_t *r = &tile[ty][2 * x];
+        hrow[ty][x] = r[0] + 4 * r[1] + 6 * r[2] + 4 * r[3] + r[4];
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < PD_TH * PD_TW; q += 256) {
+        int y = q / PD_TW, x = q - y * PD_TW;
+        int gx = ox + x, gy = oy + y;
+        if (gx < dw && gy < dh) {
+            int acc = hrow[2 * y][x] + 4 * hrow[2 * y + 1][x] + 6 * hrow[2 * y + 2][x] + 4 * hrow[2 * y + 3][x] + hrow[2 * y + 4][x];
+            dst[(size_t)gy * dw + gx] = (uint8_t)((acc + 128) >> 8);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void fe_pyrdown_kernel(Batch B, const uint8_t *src_base, size_t src_stride, int sw, int sh,
+                                                         int dst_level, int write_level0) {
+    const DevCfg &C = *B.cfg;
+    int s = blockIdx.z;
+    FeSeq &fe = B.fe[s];
+    if (fe.n_forw < 0) return;
+    int forw = fe.has_img ? (fe.cur_buf ^ 1) : fe.cur_buf;
+    const uint8_t *src = src_base ? src_base + (size_t)s * src_stride
+                                  : B.pyr + ((size_t)s * 2 + forw) * C.pyr_bytes + C.lvl_off[dst_level - 1];
+    uint8_t *dst = B.pyr + ((size_t)s * 2 + forw) * C.pyr_bytes + C.lvl_off[dst_level];
+    uint8_t *l0 = write_level0 ? B.img + ((size_t)s * 2 + forw) * (size_t)sw * sh : nullptr;
+    pyrdown_tile(src, sw, sh, dst, l0);
+}
+__global__ __launch_bounds__(256) void fe_pyrdown_stage_kernel(const uint8_t *src, int sw, int sh, uint8_t *dst) {
+    pyrdown_tile(src, sw, sh, dst, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------ fe_predict
+// predictPtsInNextFrame (feature_tracker.cpp:595-608). grid (ceil(NP/256), S)
+__global__ void fe_predict_kernel(Batch B) {
+    const DevCfg &C = *B.cfg;
+    int s = blockIdx.y;
+    FeSeq &fe = B.fe[s];
+    if (fe.n_forw < 0) return;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= fe.n_pts) return;
+    float2 p = B.cur_pts[(size_t)s * C.NP + i];
+    double x, y;
+    cam_lift(C.c, p.x, p.y, x, y);
+    const double *R = fe.R_rel;
+    double X = R[0] * x + R[1] * y + R[2], Y = R[3] * x + R[4] * y + R[5], Z = R[6] * x + R[7] * y + R[8];
+    double u, v;
+    cam_project(C.c, X, Y, Z, u, v);
+    B.forw_pts[(size_t)s * C.NP + i] = make_float2((float)u, (float)v);
+}
+
+// ------------------------------------------------------------------------------------------------ fe_lk
+// One wavefront (64 lanes) per feature; each lane owns 7 of the 441 window pixels.
+struct LkImagesUnused {
+    const uint8_t *prev[4];
+    const uint8_t *next[4];
+    int w[4], h[4];
+};
+
+__device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, float2 &nextPtIO, uint8_t &statusOut,
+                             uint8_t *win /*24*24*/, short2 *der /*22*22*/, uint8_t *jw /*22*22*/) {
+    const int WIN = VIO_WIN;
+    const int W_BITS = 14;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const int lane = threadIdx.x & 63;
+    float2 nextPts = nextPtIO;
+    uint8_t status = 1;
+    short Iv[7], Ixv[7], Iyv[7];
+    for (int level = maxLevel; level >= 0; level--) {
+        const uint8_t *I = im.prev[level], *J = im.next[level];
+        const int w = im.w[level], h = im.h[level];
+        float sc = (float)(1. / (1 << level));
+        float2 prevPt = make_float2(prevPtIn.x * sc, prevPtIn.y * sc);
+        float2 nextPt;
+        if (level == maxLevel) nextPt = make_float2(nextPts.x * sc, nextPts.y * sc);  // OPTFLOW_USE_INITIAL_FLOW
+        else nextPt = make_float2(nextPts.x * 2.f, nextPts.y * 2.f);
+        nextPts = nextPt;
+        const float halfWin = 10.f;
+        prevPt.x -= halfWin; prevPt.y -= halfWin;
+        int ipx = cv_floor(prevPt.x), ipy = cv_floor(prevPt.y);
+        if (ipx < -WIN || ipx >= w || ipy < -WIN || ipy >= h) {
+            if (level == 0) status = 0;
+            continue;
+        }
+        float a = prevPt.x - ipx, b = prevPt.y - ipy;
+        int iw00 = cv_round((1.f - a) * (1.f - b) * (1 << W_BITS));
+        int iw01 = cv_round(a * (1.f - b) * (1 << W_BITS));
+        int iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
+        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        __syncthreads();
+        for (int q = lane; q < 24 * 24; q += 64) {
+            int wy = q / 24, wx = q - wy * 24;
+            win[q] = I[(size_t)reflect101(ipy - 1 + wy, h) * w + reflect101(ipx - 1 + wx, w)];
+        }
+        __syncthreads();
+        for (int q = lane; q < 22 * 22; q += 64) {
+            int dy = q / 22, dx = q - dy * 22;
+            int gx = ipx + dx, gy = ipy + dy;
+            short2 d = make_short2(0, 0);
+            if (gx >= 0 && gy >= 0 && gx < w && gy < h) {  // derivative buffer has a constant-0 border
+                const uint8_t *r0 = win + dy * 24 + dx, *r1 = r0 + 24, *r2 = r1 + 24;
+                d.x = (short)(3 * (r0[2] - r0[0]) + 10 * (r1[2] - r1[0]) + 3 * (r2[2] - r2[0]));
+                d.y = (short)(3 * (r2[0] - r0[0]) + 10 * (r2[1] - r0[1]) + 3 * (r2[2] - r0[2]));
+            }
+            der[q] = d;
+        }
+        __syncthreads();
+        long long sA11 = 0, sA12 = 0, sA22 = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            int p = lane + 64 * k;
+            int y = p / WIN, x = p - y * WIN;
+            int iv = 0, ix = 0, iy = 0;
+            if (p < WIN * WIN) {
+                const uint8_t *r = win + (y + 1) * 24 + (x + 1);
+                iv = descale(r[0] * iw00 + r[1] * iw01 + r[24] * iw10 + r[25] * iw11, W_BITS - 5);
+                const short2 *d = der + y * 22 + x;
+                ix = descale(d[0].x * iw00 + d[1].x * iw01 + d[22].x * iw10 + d[23].x * iw11, W_BITS);
+                iy = descale(d[0].y * iw00 + d[1].y * iw01 + d[22].y * iw10 + d[23].y * iw11, W_BITS);
+                sA11 += (long long)ix * ix;
+                sA12 += (long long)ix * iy;
+                sA22 += (long long)iy * iy;
+            }
+            Iv[k] = (short)iv; Ixv[k] = (short)ix; Iyv[k] = (short)iy;
+        }
+        sA11 = wave_sum_i64(sA11); sA12 = wave_sum_i64(sA12); sA22 = wave_sum_i64(sA22);
+        float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * WIN * WIN);
+        if (minEig < 1e-4f || D < 1.1920928955078125e-07f) {
+            if (level == 0) status = 0;
+            continue;
+        }
+        D = 1.f / D;
+        nextPt.x -= halfWin; nextPt.y -= halfWin;
+        float2 prevDelta = make_float2(0.f, 0.f);
+        for (int j = 0; j < 30; j++) {
+            int inx = cv_floor(nextPt.x), iny = cv_floor(nextPt.y);
+            if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) {
+                if (level == 0) status = 0;
+                break;
+            }
+            a = nextPt.x - inx; b = nextPt.y - iny;
+            iw00 = cv_round((1.f - a) * (1.f - b) * (1 << W_BITS));
+            iw01 = cv_round(a * (1.f - b) * (1 << W_BITS));
+            iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            __syncthreads();
+            for (int q = lane; q < 22 * 22; q += 64) {
+                int wy = q / 22, wx = q - wy * 22;
+                jw[q] = J[(size_t)reflect101(iny + wy, h) * w + reflect101(inx + wx, w)];
+            }
+            __syncthreads();
+            long long sb1 = 0, sb2 = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                int p = lane + 64 * k;
+                if (p < WIN * WIN) {
+                    int y = p / WIN, x = p - y * WIN;
+                    const uint8_t *r = jw + y * 22 + x;
+                    int diff = descale(r[0] * iw00 + r[1] * iw01 + r[22] * iw10 + r[23] * iw11, W_BITS - 5) - Iv[k];
+                    sb1 += (long long)diff * Ixv[k];
+                    sb2 += (long long)diff * Iyv[k];
+                }
+            }
+            sb1 = wave_sum_i64(sb1); sb2 = wave_sum_i64(sb2);
+            float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            float2 delta = make_float2((float)((A12 * b2 - A22 * b1) * D), (float)((A12 * b1 - A11 * b2) * D));
+            nextPt.x += delta.x; nextPt.y += delta.y;
+            nextPts = make_float2(nextPt.x + halfWin, nextPt.y + halfWin);
+            if ((double)delta.x * delta.x + (double)delta.y * delta.y <= 0.01 * 0.01) break;
+            if (j > 0 && fabsf(delta.x + prevDelta.x) < 0.01 && fabsf(delta.y + prevDelta.y) < 0.01) {
+                nextPts.x -= delta.x * 0.5f;
+                nextPts.y -= delta.y * 0.5f;
+                break;
+            }
+            prevDelta = delta;
+        }
+    }
+    nextPtIO = nextPts;
+    statusOut = status;
+}
+
+// grid (NP, S), 64 threads
+__global__ __launch_bounds__(64) void fe_lk_kernel(Batch B) {
+    const DevCfg &C = *B.cfg;
+    int s = blockIdx.y, i = blockIdx.x;
+    FeSeq &fe = B.fe[s];
+    if (fe.n_forw < 0 || i >= fe.n_pts) return;
+    __shared__ uint8_t win[24 * 24];
+    __shared__ short2 der[22 * 22];
+    __shared__ uint8_t jw[22 * 22];
+    int cur = fe.cur_buf, forw = fe.has_img ? (cur ^ 1) : cur;
+    LkImages im;
+    size_t hw = (size_t)C.c.width * C.c.height;
+    im.prev[0] = B.img + ((size_t)s * 2 + cur) * hw;
+    im.next[0] = B.img + ((size_t)s * 2 + forw) * hw;
+    im.w[0] = C.c.width; im.h[0] = C.c.height;
+    for (int l = 1; l <= C.c.lk_max_level; l++) {
+        im.prev[l] = B.pyr + ((size_t)s * 2 + cur) * C.pyr_bytes + C.lvl_off[l];
+        im.next[l] = B.pyr + ((size_t)s * 2 + forw) * C.pyr_bytes + C.lvl_off[l];
+        im.w[l] = C.lvl_w[l]; im.h[l] = C.lvl_h[l];
+    }
+    float2 np = B.forw_pts[(size_t)s * C.NP + i];
+    uint8_t st;
+    lk_one_point(im, C.c.lk_max_level, B.cur_pts[(size_t)s * C.NP + i], np, st, win, der, jw);
+    if (threadIdx.x == 0) {
+        B.forw_pts[(size_t)s * C.NP + i] = np;
+        B.lk_status[(size_t)s * C.NP + i] = st;
+    }
+}
+
+// stand-alone variant for the stage test: explicit images, points from arrays
+__global__ __launch_bounds__(64) void fe_lk_stage_kernel(LkImages im, int maxLevel, int n, const float2 *prevPts, float2 *nextPts,
+                                                         uint8_t *status) {
+    int i = blockIdx.x;
+    if (i >= n) return;
+    __shared__ uint8_t win[24 * 24];
+    __shared__ short2 der[22 * 22];
+    __shared__ uint8_t jw[22 * 22];
+    float2 np = nextPts[i];
+    uint8_t st;
+    lk_one_point(im, maxLevel, prevPts[i], np, st, win, der, jw);
+    if (threadIdx.x == 0) { nextPts[i] = np; status[i] = st; }
+}
+
+// ------------------------------------------------------------------------------------------------ RANSAC pieces
+namespace {
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t &s) {
+    s += 0x9E3779B97F4A7C15ULL;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double det3(const double *F) {
+    return F[0] * (F[4] * F[8] - F[5] * F[7]) - F[1] * (F[3] * F[8] - F[5] * F[6]) + F[2] * (F[3] * F[7] - F[4] * F[6]);
+}
+__device__ int solve_cubic_det(double c3, double c2, double c1, double c0, double roots[3]) {
+    double mx = fmax(fmax(fabs(c3), fabs(c2)), fmax(fabs(c1), fabs(c0)));
+    if (mx == 0.0) return 0;
+    if (fabs(c3) < 1e-12 * mx) {
+        if (fabs(c2) < 1e-12 * mx) {
+            if (fabs(c1) < 1e-12 * mx) return 0;
+            roots[0] = -c0 / c1;
+            return 1;
+        }
+        double disc = c1 * c1 - 4 * c2 * c0;
+        if (disc < 0) return 0;
+        double sq = sqrt(disc);
+        roots[0] = (-c1 + sq) / (2 * c2);
+        roots[1] = (-c1 - sq) / (2 * c2);
+        return 2;
+    }
+    double a = c2 / c3, b = c1 / c3, c = c0 / c3;
+    double Bd = 1.0 + fmax(fabs(a), fmax(fabs(b), fabs(c)));
+    double lo = -Bd, hi = Bd;
+    for (int i = 0; i < 100; i++) {
+        double mid = 0.5 * (lo + hi);
+        double f = ((mid + a) * mid + b) * mid + c;
+        if (f > 0) hi = mid; else lo = mid;
+    }
+    double r = 0.5 * (lo + hi);
+    for (int i = 0; i < 2; i++) {
+        double f = ((r + a) * r + b) * r + c, fp = (3 * r + 2 * a) * r + b;
+        if (fp != 0.0) r -= f / fp;
+    }
+    roots[0] = r;
+    double p = a + r, q = b + r * p;
+    double disc = p * p - 4 * q;
+    if (disc < 0) return 1;
+    double sq = sqrt(disc);
+    roots[1] = (-p + sq) * 0.5;
+    roots[2] = (-p - sq) * 0.5;
+    return 3;
+}
+// 7-point solver on a 7x9 system stored row-major in A (destroyed). Returns #models, F[3][9]
+__device__ int seven_point(double *A /*63*/, double *F /*27*/) {
+    int perm[9];
+    for (int i = 0; i < 9; i++) perm[i] = i;
+    double amax = 0;
+    for (int i = 0; i < 63; i++) amax = fmax(amax, fabs(A[i]));
+    const double tol = 1e-12 * amax;
+    int rank = 0;
+    for (int i = 0; i < 7; i++) {
+        int pr = i, pc = i;
+        double best = -1;
+        for (int r = i; r < 7; r++)
+            for (int c = i; c < 9; c++)
+                if (fabs(A[r * 9 + c]) > best) { best = fabs(A[r * 9 + c]); pr = r; pc = c; }
+        if (!(best > tol)) break;
+        if (pr != i) for (int c = 0; c < 9; c++) { double t = A[pr * 9 + c]; A[pr * 9 + c] = A[i * 9 + c]; A[i * 9 + c] = t; }
+        if (pc != i) {
+            for (int r = 0; r < 7; r++) { double t = A[r * 9 + pc]; A[r * 9 + pc] = A[r * 9 + i]; A[r * 9 + i] = t; }
+            int t = perm[pc]; perm[pc] = perm[i]; perm[i] = t;
+        }
+        double inv = 1.0 / A[i * 9 + i];
+        for (int c = 0; c < 9; c++) A[i * 9 + c] *= inv;
+        for (int r = 0; r < 7; r++) {
+            if (r == i) continue;
+            double f = A[r * 9 + i];
+            if (f == 0.0) continue;
+            for (int c = 0; c < 9; c++) A[r * 9 + c] -= f * A[i * 9 + c];
+        }
+        rank = i + 1;
+    }
+    double f1[9], f2[9];
+    for (int i = 0; i < 9; i++) f1[i] = f2[i] = 0;
+    for (int i = 0; i < rank; i++) { f1[perm[i]] = -A[i * 9 + 7]; f2[perm[i]] = -A[i * 9 + 8]; }
+    f1[perm[7]] = 1;
+    f2[perm[8]] = 1;
+    double c0 = det3(f1), c3 = det3(f2), c1 = 0, c2 = 0;
+    for (int r = 0; r < 3; r++) {
+        double t[9];
+        for (int q = 0; q < 9; q++) t[q] = f1[q];
+        for (int c = 0; c < 3; c++) t[r * 3 + c] = f2[r * 3 + c];
+        c1 += det3(t);
+        for (int q = 0; q < 9; q++) t[q] = f2[q];
+        for (int c = 0; c < 3; c++) t[r * 3 + c] = f1[r * 3 + c];
+        c2 += det3(t);
+    }
+    double roots[3];
+    int nr = solve_cubic_det(c3, c2, c1, c0, roots);
+    for (int k = 0; k < nr; k++)
+        for (int i = 0; i < 9; i++) F[k * 9 + i] = f1[i] + roots[k] * f2[i];
+    return nr;
+}
+__device__ __forceinline__ bool f_inlier(const double *f, double x1, double y1, double x2, double y2, double thr2) {
+    double a = f[0] * x1 + f[1] * y1 + f[2], b = f[3] * x1 + f[4] * y1 + f[5], cc = f[6] * x1 + f[7] * y1 + f[8];
+    double s2 = 1.0 / (a * a + b * b), d2 = x2 * a + y2 * b + cc;
+    double a1 = f[0] * x2 + f[3] * y2 + f[6], b1 = f[1] * x2 + f[4] * y2 + f[7], c1 = f[2] * x2 + f[5] * y2 + f[8];
+    double s1 = 1.0 / (a1 * a1 + b1 * b1), d1 = x1 * a1 + y1 * b1 + c1;
+    double err = fmax(d1 * d1 * s1, d2 * d2 * s2);
+    return err <= thr2;
+}
+__device__ int ransac_update_iters(double p, double ep, int modelPoints, int maxIters) {
+    p = fmin(fmax(p, 0.), 1.);
+    ep = fmin(fmax(ep, 0.), 1.);
+    double num = fmax(1. - p, 2.2250738585072014e-308);
+    double denom = 1. - pow(1. - ep, (double)modelPoints);
+    if (denom < 2.2250738585072014e-308) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)rint(num / denom);
+}
+
+// block-wide helpers (256 threads)
+__device__ int block_exclusive_scan(const int *flags, int n, int *offs, int *scratch /*blockDim+1*/) {
+    // each thread owns a contiguous chunk; returns total
+    int nt = blockDim.x, t = threadIdx.x;
+    int chunk = (n + nt - 1) / nt;
+    int b = t * chunk, e = min(n, b + chunk);
+    int sum = 0;
+    for (int i = b; i < e; i++) sum += flags[i] ? 1 : 0;
+    scratch[t] = sum;
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        for (int i = 0; i < nt; i++) { int v = scratch[i]; scratch[i] = acc; acc += v; }
+        scratch[nt] = acc;
+    }
+    __syncthreads();
+    int o = scratch[t];
+    for (int i = b; i < e; i++) { offs[i] = o; o += flags[i] ? 1 : 0; }
+    int total = scratch[nt];
+    __syncthreads();
+    return total;
+}
+
+// RANSAC over normalised correspondences held in LDS; writes status flags. All 256 threads participate.
+struct RansacShared {
+    double F[64 * 27];
+    int nm[64];
+    int cnt[64 * 3];
+    double bestF[9];
+    int niters, maxGood, base, done;
+};
+__device__ void ransac_block(const vio_config &c, int N, const double *X1, const double *Y1, const double *X2, const double *Y2,
+                             int *status, RansacShared &R, int *iters_out) {
+    const int t = threadIdx.x;
+    const double thr = c.f_threshold / c.focal_length, thr2 = thr * thr;
+    if (t == 0) { R.niters = c.ransac_max_iters; R.maxGood = 0; R.base = 0; R.done = 0; }
+    __syncthreads();
+    while (true) {
+        int base = R.base, niters = R.niters;
+        if (base >= niters) break;
+        if (t < 64) {
+            int it = base + t;
+            int nm = 0;
+            if (it < niters) {
+                uint64_t sd = 0x5649464D41545258ULL + (uint64_t)it * 0xD1B54A32D192ED03ULL;
+                int idx[7];
+                for (int k = 0; k < 7;) {
+                    int r = (int)(splitmix64(sd) % (uint64_t)N);
+                    bool dup = false;
+                    for (int j = 0; j < k; j++) dup |= (idx[j] == r);
+                    if (!dup) idx[k++] = r;
+                }
+                double A[63];
+                for (int i = 0; i < 7; i++) {
+                    double x1 = X1[idx[i]], y1 = Y1[idx[i]], x2 = X2[idx[i]], y2 = Y2[idx[i]];
+                    A[i * 9 + 0] = x2 * x1; A[i * 9 + 1] = x2 * y1; A[i * 9 + 2] = x2;
+                    A[i * 9 + 3] = y2 * x1; A[i * 9 + 4] = y2 * y1; A[i * 9 + 5] = y2;
+                    A[i * 9 + 6] = x1;      A[i * 9 + 7] = y1;      A[i * 9 + 8] = 1.0;
+                }
+                nm = seven_point(A, &R.F[t * 27]);
+            }
+            R.nm[t] = nm;
+        }
+        __syncthreads();
+        for (int pi = t; pi < 192; pi += blockDim.x) {
+            int hh = pi / 3, m = pi - hh * 3;
+            int good = 0;
+            if (m < R.nm[hh]) {
+                const double *f = &R.F[hh * 27 + m * 9];
+                for (int i = 0; i < N; i++) good += f_inlier(f, X1[i], Y1[i], X2[i], Y2[i], thr2) ? 1 : 0;
+            }
+            R.cnt[pi] = good;
+        }
+        __syncthreads();
+        if (t == 0) {
+            int ni = R.niters, mg = R.maxGood;
+            for (int hh = 0; hh < 64; hh++) {
+                int it = base + hh;
+                if (it >= ni) break;
+                for (int m = 0; m < R.nm[hh]; m++) {
+                    int good = R.cnt[hh * 3 + m];
+                    if (good > max(mg, 6)) {
+                        mg = good;
+                        for (int q = 0; q < 9; q++) R.bestF[q] = R.F[hh * 27 + m * 9 + q];
+                        ni = ransac_update_iters(0.99, (double)(N - good) / N, 7, ni);
+                    }
+                }
+            }
+            R.niters = ni;
+            R.maxGood = mg;
+            R.base = base + 64;
+        }
+        __syncthreads();
+    }
+    int mg = R.maxGood;
+    for (int i = t; i < N; i += blockDim.x) status[i] = (mg > 0 && f_inlier(R.bestF, X1[i], Y1[i], X2[i], Y2[i], thr2)) ? 1 : 0;
+    if (t == 0 && iters_out) *iters_out = R.niters;
+    __syncthreads();
+}
+
+}  // namespace
+
+// stage test entry: RANSAC on float pixel correspondences (virtual pinhole), grid 1, 256 threads, dynamic LDS 4*8*n + 4*n
+__global__ __launch_bounds__(256) void fe_ransac_stage_kernel(vio_config c, int n, const float2 *p1, const float2 *p2, uint8_t *status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *X1 = (double *)smem, *Y1 = X1 + n, *X2 = Y1 + n, *Y2 = X2 + n;
+    int *st = (int *)(Y2 + n);
+    __shared__ RansacShared R;
+    double hc = c.width / 2.0, hr = c.height / 2.0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        X1[i] = ((double)p1[i].x - hc) / c.focal_length; Y1[i] = ((double)p1[i].y - hr) / c.focal_length;
+        X2[i] = ((double)p2[i].x - hc) / c.focal_length; Y2[i] = ((double)p2[i].y - hr) / c.focal_length;
+        st[i] = 0;
+    }
+    __syncthreads();
+    if (n >= 8) ransac_block(c, n, X1, Y1, X2, Y2, st, R, nullptr);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) status[i] = (uint8_t)st[i];
+}
+
+// ------------------------------------------------------------------------------------------------ fe_select
+// grid S, 256 threads, dynamic LDS:  per point: cur(8) forw(8) un(8) id(4) cnt(4) flag(4) offs(4) perm(4) + 4 doubles
+__global__ __launch_bounds__(256) void fe_select_kernel(Batch B, int publish) {
+    const DevCfg &C = *B.cfg;
+    const vio_config &c = C.c;
+    const int s = blockIdx.x, t = threadIdx.x, NP = C.NP;
+    FeSeq &fe = B.fe[s];
+    if (fe.n_forw < 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *X1 = (double *)smem, *Y1 = X1 + NP, *X2 = Y1 + NP, *Y2 = X2 + NP;
+    float2 *cur = (float2 *)(Y2 + NP), *forw = cur + NP, *un = forw + NP, *tmp2 = un + NP;
+    int *id = (int *)(tmp2 + NP), *cnt = id + NP, *flag = cnt + NP, *offs = flag + NP, *perm = offs + NP, *tmpi = perm + NP;
+    int *scratch = tmpi + NP;                 // 257
+    int2 *acc = (int2 *)(scratch + 260);      // NP + NP (accepted + unstable)
+    __shared__ RansacShared R;
+    __shared__ int sh_n, sh_nacc, sh_nun;
+    __shared__ int gcount[VIO_MAX_CELLS];
+
+    float2 *g_cur = B.cur_pts + (size_t)s * NP, *g_forw = B.forw_pts + (size_t)s * NP, *g_un = B.cur_un_pts + (size_t)s * NP;
+    int *g_id = B.ids + (size_t)s * NP, *g_cnt = B.track_cnt + (size_t)s * NP;
+    float2 *g_unst = B.unstable_pts + (size_t)s * NP;
+    int n = fe.n_pts;
+    for (int i = t; i < n; i += blockDim.x) {
+        cur[i] = g_cur[i]; forw[i] = g_forw[i]; un[i] = g_un[i]; id[i] = g_id[i]; cnt[i] = g_cnt[i];
+    }
+    if (t == 0) { sh_nun = 0; sh_nacc = 0; }
+    __syncthreads();
+    // ---- status / border culling (feature_tracker.cpp:313-329)
+    if (n > 0) {
+        const uint8_t *st = B.lk_status + (size_t)s * NP;
+        for (int i = t; i < n; i += blockDim.x) {
+            int ix = cv_round(forw[i].x), iy = cv_round(forw[i].y);
+            bool inb = 1 <= ix && ix < c.width - 1 && 1 <= iy && iy < c.height - 1;
+            bool ok = st[i] != 0;
+            if (!ok && inb) { int k = atomicAdd(&sh_nun, 1); g_unst[k] = forw[i]; }  // order irrelevant (mask circles only)
+            flag[i] = (ok && inb) ? 1 : 0;
+        }
+        __syncthreads();
+        int total = block_exclusive_scan(flag, n, offs, scratch);
+        // stable compaction through temporaries
+        float2 c0, f0, u0; int i0, k0;
+        for (int b = 0; b < n; b += blockDim.x) {
+            int i = b + t;
+            bool v = i < n && flag[i];
+            if (v) { c0 = cur[i]; f0 = forw[i]; u0 = un[i]; i0 = id[i]; k0 = cnt[i]; }
+            int o = v ? offs[i] : 0;
+            __syncthreads();
+            if (v) { cur[o] = c0; forw[o] = f0; un[o] = u0; id[o] = i0; cnt[o] = k0; }
+            __syncthreads();
+        }
+        n = total;
+    }
+    for (int i = t; i < n; i += blockDim.x) cnt[i]++;  // :348-349
+    __syncthreads();
+
+    int n_deficit = 0;
+    if (publish) {
+        // ---- rejectWithF (:441-473)
+        if (n >= 8) {
+            double hc = c.width / 2.0, hr = c.height / 2.0;
+            for (int i = t; i < n; i += blockDim.x) {
+                double x, y;
+                cam_lift(c, cur[i].x, cur[i].y, x, y);
+                float ux = (float)(c.focal_length * x + hc), uy = (float)(c.focal_length * y + hr);
+                X1[i] = ((double)ux - hc) / c.focal_length; Y1[i] = ((double)uy - hr) / c.focal_length;
+                cam_lift(c, forw[i].x, forw[i].y, x, y);
+                ux = (float)(c.focal_length * x + hc); uy = (float)(c.focal_length * y + hr);
+                X2[i] = ((double)ux - hc) / c.focal_length; Y2[i] = ((double)uy - hr) / c.focal_length;
+            }
+            __syncthreads();
+            ransac_block(c, n, X1, Y1, X2, Y2, flag, R, &fe.ransac_iters);
+            int total = block_exclusive_scan(flag, n, offs, scratch);
+            float2 c0, f0, u0; int i0, k0;
+            for (int b = 0; b < n; b += blockDim.x) {
+                int i = b + t;
+                bool v = i < n && flag[i];
+                if (v) { c0 = cur[i]; f0 = forw[i]; u0 = un[i]; i0 = id[i]; k0 = cnt[i]; }
+                int o = v ? offs[i] : 0;
+                __syncthreads();
+                if (v) { cur[o] = c0; forw[o] = f0; un[o] = u0; id[o] = i0; cnt[o] = k0; }
+                __syncthreads();
+            }
+            n = total;
+        }
+        // ---- setMask (:173-208): sort by track_cnt desc (ties: original order), greedy keep with MIN_DIST circles
+        for (int i = t; i < n; i += blockDim.x) {
+            int ci = cnt[i], r = 0;
+            for (int j = 0; j < n; j++) r += (cnt[j] > ci || (cnt[j] == ci && j < i)) ? 1 : 0;
+            perm[r] = i;
+        }
+        __syncthreads();
+        if (t < 64) {  // one wavefront walks the sorted list; lanes test the accepted centres in parallel
+            volatile int2 *vacc = acc;
+            int nacc = 0;
+            const int r = c.min_dist;
+            for (int q = 0; q < n; q++) {
+                int i = perm[q];
+                int px = cv_round(forw[i].x), py = cv_round(forw[i].y);
+                bool hit = false;
+                for (int k = t; k < nacc; k += 64) hit |= in_disk(C.circle_hw, r, px, py, vacc[k].x, vacc[k].y);
+                bool any = __any(hit);
+                if (!any) {
+                    if (t == 0) { vacc[nacc].x = px; vacc[nacc].y = py; tmpi[nacc] = i; }
+                    nacc++;
+                }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+            }
+            if (t == 0) sh_nacc = nacc;
+        }
+        __syncthreads();
+        int nk = sh_nacc;
+        {
+            float2 f0; int i0, k0;
+            for (int b = 0; b < nk; b += blockDim.x) {
+                int q = b + t;
+                bool v = q < nk;
+                if (v) { int i = tmpi[q]; f0 = forw[i]; i0 = id[i]; k0 = cnt[i]; }
+                __syncthreads();
+                if (v) { tmp2[q] = f0; offs[q] = i0; flag[q] = k0; }
+                __syncthreads();
+            }
+            for (int q = t; q < nk; q += blockDim.x) { forw[q] = tmp2[q]; id[q] = offs[q]; cnt[q] = flag[q]; }
+            __syncthreads();
+        }
+        n = nk;
+        // circles at unstable points (:204-207)
+        int nun = sh_nun;
+        for (int k = t; k < nun; k += blockDim.x) acc[n + k] = make_int2(cv_round(g_unst[k].x), cv_round(g_unst[k].y));
+        __syncthreads();
+        // ---- per-grid tracked counts and deficit cells (:360-395)
+        int n_max_cnt = c.max_cnt - n;
+        if (n_max_cnt > 0) {
+            for (int k = t; k < C.ncells; k += blockDim.x) gcount[k] = 0;
+            __syncthreads();
+            for (int i = t; i < n; i += blockDim.x) {
+                int col = (int)forw[i].x / C.grid_w, row = (int)forw[i].y / C.grid_h;
+                if (col == c.grid_cols) --col;
+                if (row == c.grid_rows) --row;
+                atomicAdd(&gcount[col + c.grid_cols * row], 1);
+            }
+            __syncthreads();
+            if (t == 0) {
+                for (int k = 0; k < C.ncells; k++) {
+                    fe.grids_track_num[k] = gcount[k];
+                    if (gcount[k] < C.grids_threshold && fe.grids_texture_status[k]) { fe.deficit_cells[n_deficit++] = k; fe.cell_ncand[k] = 0; }
+                    else { fe.grids_texture_status[k] = 1; fe.cell_ncand[k] = -1; }
+                }
+            }
+        } else if (t == 0) {
+            for (int k = 0; k < C.ncells; k++) fe.cell_ncand[k] = -1;
+        }
+        // accepted centres to HBM for fe_add
+        int2 *g_acc = B.accept_xy + (size_t)s * 2 * NP;
+        for (int k = t; k < n + nun; k += blockDim.x) g_acc[k] = acc[k];
+        if (t == 0) fe.n_accept = n + nun;
+    } else if (t == 0) {
+        for (int k = 0; k < C.ncells; k++) fe.cell_ncand[k] = -1;
+        fe.n_accept = 0;
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += blockDim.x) { g_forw[i] = forw[i]; g_id[i] = id[i]; g_cnt[i] = cnt[i]; }
+    if (t == 0) { fe.n_forw = n; fe.n_deficit = n_deficit; fe.n_unstable = sh_nun; }
+}
+
+// ------------------------------------------------------------------------------------------------ fe_fast
+// FAST-9/16 (threshold 10) + 3x3 NMS on one grid cell ROI staged in LDS. grid (ncells, S), 256 threads.
+namespace {
+__device__ __forceinline__ int fast_score_lds(const uint8_t *p, int stride) {
+    const int thr = 10;
+    int v = p[0];
+    int d[25];
+    d[0] = v - p[3 * stride];       d[1] = v - p[3 * stride + 1];   d[2] = v - p[2 * stride + 2];   d[3] = v - p[stride + 3];
+    d[4] = v - p[3];                d[5] = v - p[-stride + 3];      d[6] = v - p[-2 * stride + 2];  d[7] = v - p[-3 * stride + 1];
+    d[8] = v - p[-3 * stride];      d[9] = v - p[-3 * stride - 1];  d[10] = v - p[-2 * stride - 2]; d[11] = v - p[-stride - 3];
+    d[12] = v - p[-3];              d[13] = v - p[stride - 3];      d[14] = v - p[2 * stride - 2];  d[15] = v - p[3 * stride - 1];
+    // quick reject: any 9-arc contains at least two of the four compass pixels
+    int nb = (d[0] < -thr) + (d[4] < -thr) + (d[8] < -thr) + (d[12] < -thr);
+    int nd = (d[0] > thr) + (d[4] > thr) + (d[8] > thr) + (d[12] > thr);
+    if (nb < 2 && nd < 2) return 0;
+#pragma unroll
+    for (int k = 16; k < 25; k++) d[k] = d[k - 16];
+    int best = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int mn = d[k], mx = d[k];
+#pragma unroll
+        for (int j = 1; j < 9; j++) { mn = min(mn, d[k + j]); mx = max(mx, d[k + j]); }
+        best = max(best, max(mn, -mx));
+    }
+    return best > thr ? best - 1 : 0;
+}
+
+__device__ int fast_cell(const uint8_t *img, int W, GridRect r, uint8_t *tile, uint8_t *score, int *rowoff, uint32_t *out, int cap) {
+    const int t = threadIdx.x;
+    const int rw = r.w, rh = r.h;
+    for (int q = t; q < rw * rh; q += blockDim.x) {
+        int y = q / rw, x = q - y * rw;
+        tile[q] = img[(size_t)(r.y + y) * W + r.x + x];
+        score[q] = 0;
+    }
+    __syncthreads();
+    for (int q = t; q < (rw - 6) * (rh - 6); q += blockDim.x) {
+        int y = q / (rw - 6) + 3, x = q % (rw - 6) + 3;
+        score[y * rw + x] = (uint8_t)fast_score_lds(tile + y * rw + x, rw);
+    }
+    __syncthreads();
+    // NMS + row-major ordered emission: count per row, prefix, emit
+    for (int y = t; y < rh; y += blockDim.x) {
+        int cntr = 0;
+        if (y >= 3 && y < rh - 3)
+            for (int x = 3; x < rw - 3; x++) {
+                const uint8_t *cpt = score + y * rw + x;
+                int sc = cpt[0];
+                if (sc && sc > cpt[-1] && sc > cpt[1] && sc > cpt[-rw - 1] && sc > cpt[-rw] && sc > cpt[-rw + 1] && sc > cpt[rw - 1] &&
+                    sc > cpt[rw] && sc > cpt[rw + 1])
+                    cntr++;
+            }
+        rowoff[y] = cntr;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        for (int y = 0; y < rh; y++) { int v = rowoff[y]; rowoff[y] = acc; acc += v; }
+        rowoff[rh] = acc;
+    }
+    __syncthreads();
+    for (int y = t; y < rh; y += blockDim.x) {
+        if (y < 3 || y >= rh - 3) continue;
+        int o = rowoff[y];
+        for (int x = 3; x < rw - 3; x++) {
+            const uint8_t *cpt = score + y * rw + x;
+            int sc = cpt[0];
+            if (sc && sc > cpt[-1] && sc > cpt[1] && sc > cpt[-rw - 1] && sc > cpt[-rw] && sc > cpt[-rw + 1] && sc > cpt[rw - 1] &&
+                sc > cpt[rw] && sc > cpt[rw + 1]) {
+                if (o < cap) out[o] = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)sc << 24);
+                o++;
+            }
+        }
+    }
+    int total = rowoff[rh];
+    __syncthreads();
+    return total;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void fe_fast_kernel(Batch B) {
+    const DevCfg &C = *B.cfg;
+    int s = blockIdx.y, cell = blockIdx.x;
+    FeSeq &fe = B.fe[s];
+    if (fe.n_forw < 0 || fe.cell_ncand[cell] < 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    GridRect r = C.rect[cell];
+    uint8_t *tile = smem, *score = tile + ((r.w * r.h + 15) & ~15);
+    int *rowoff = (int *)(score + ((r.w * r.h + 15) & ~15));
+    int forw = fe.has_img ? (fe.cur_buf ^ 1) : fe.cur_buf;
+    const uint8_t *img = B.img + ((size_t)s * 2 + forw) * (size_t)C.c.width * C.c.height;
+    uint32_t *out = B.cand + ((size_t)s * C.ncells + cell) * VIO_FAST_CAP;
+    int total = fast_cell(img, C.c.width, r, tile, score, rowoff, out, VIO_FAST_CAP);
+    if (threadIdx.x == 0) {
+        if (total > VIO_FAST_CAP) { total = VIO_FAST_CAP; atomicOr(&B.be[s].overflow, 4); }
+        fe.cell_ncand[cell] = total;
+    }
+}
+
+__global__ __launch_bounds__(256) void fe_fast_stage_kernel(const uint8_t *img, int W, GridRect r, uint32_t *out, int cap, int *count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint8_t *tile = smem, *score = tile + ((r.w * r.h + 15) & ~15);
+    int *rowoff = (int *)(score + ((r.w * r.h + 15) & ~15));
+    int total = fast_cell(img, W, r, tile, score, rowoff, out, cap);
+    if (threadIdx.x == 0) *count = total;
+}
+
+// ------------------------------------------------------------------------------------------------ fe_add
+// Per sequence, cells in order: mask filter (runByPixelsMask), top-k by response (replace-min scan), addPoints greedy;
+// then cur <- forw, undistortedPoints, velocity, updateID, feature-map packaging in ascending id.
+// grid S, 256 threads, dynamic LDS.
+__global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int publish, int gate) {
+    const DevCfg &C = *B.cfg;
+    const vio_config &c = C.c;
+    const int s = blockIdx.x, t = threadIdx.x, NP = C.NP;
+    FeSeq &fe = B.fe[s];
+    if (fe.n_forw < 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int2 *acc = (int2 *)smem;                         // 2*NP
+    int *flag = (int *)(acc + 2 * NP);                // VIO_FAST_CAP
+    int *offs = flag + VIO_FAST_CAP;                  // VIO_FAST_CAP
+    uint32_t *filt = (uint32_t *)(offs + VIO_FAST_CAP);  // VIO_FAST_CAP
+    int *scratch = (int *)(filt + VIO_FAST_CAP);      // 260
+    uint32_t *keep = (uint32_t *)(scratch + 260);     // 64
+    __shared__ int sh_nacc, sh_n, sh_nkeep;
+
+    float2 *g_forw = B.forw_pts + (size_t)s * NP, *g_cur = B.cur_pts + (size_t)s * NP, *g_un = B.cur_un_pts + (size_t)s * NP,
+           *g_vel = B.pts_velocity + (size_t)s * NP, *g_pun = B.prev_un_pt + (size_t)s * NP;
+    int *g_id = B.ids + (size_t)s * NP, *g_cnt = B.track_cnt + (size_t)s * NP, *g_pid = B.prev_un_id + (size_t)s * NP;
+    int n = fe.n_forw;
+    if (publish && fe.n_deficit > 0) {
+        const int2 *g_acc = B.accept_xy + (size_t)s * 2 * NP;
+        int nacc0 = fe.n_accept;
+        for (int k = t; k < nacc0; k += blockDim.x) acc[k] = g_acc[k];
+        if (t == 0) { sh_nacc = nacc0; sh_n = n; }
+        __syncthreads();
+        const int r = c.min_dist;
+        for (int dc = 0; dc < fe.n_deficit; dc++) {
+            int cell = fe.deficit_cells[dc];
+            GridRect rc = C.rect[cell];
+            int nc = fe.cell_ncand[cell];
+            const uint32_t *cand = B.cand + ((size_t)s * C.ncells + cell) * VIO_FAST_CAP;
+            int nacc = sh_nacc;
+            // KeyPointsFilter::runByPixelsMask
+            for (int k = t; k < nc; k += blockDim.x) {
+                uint32_t v = cand[k];
+                int px = rc.x + (int)(v & 0xFFF), py = rc.y + (int)((v >> 12) & 0xFFF);
+                bool hit = false;
+                for (int a = 0; a < nacc; a++) hit |= in_disk(C.circle_hw, r, px, py, acc[a].x, acc[a].y);
+                flag[k] = hit ? 0 : 1;
+            }
+            __syncthreads();
+            int nf = block_exclusive_scan(flag, nc, offs, scratch);
+            for (int k = t; k < nc; k += blockDim.x) if (flag[k]) filt[offs[k]] = cand[k];
+            __syncthreads();
+            if (nf == 0) {  // :120-124
+                if (t == 0) fe.grids_texture_status[cell] = 0;
+                __syncthreads();
+                continue;
+            }
+            // top-k by response, replace-min scan (:127-167); survivors stay in slot order
+            int K = C.grids_threshold - fe.grids_track_num[cell] + 2;
+            if (t == 0) {
+                if (nf <= K) {
+                    for (int k = 0; k < nf; k++) keep[k] = filt[k];
+                    sh_nkeep = nf;
+                } else {
+                    int min_id = 0;
+                    for (int j = 0; j < nf; j++) {
+                        uint32_t v = filt[j];
+                        int resp = (int)(v >> 24);
+                        if (j < K) {
+                            keep[j] = v;
+                            if (resp < (int)(keep[min_id] >> 24)) min_id = j;
+                        } else if (resp > (int)(keep[min_id] >> 24)) {
+                            keep[min_id] = v;
+                            for (int k = 0; k < K; k++)
+                                if ((int)(keep[k] >> 24) < (int)(keep[min_id] >> 24)) min_id = k;
+                        }
+                    }
+                    sh_nkeep = K;
+                }
+            }
+            __syncthreads();
+            // addPoints (:220-233), one wavefront
+            if (t < 64) {
+                volatile int2 *vacc = acc;
+                int na = sh_nacc, nn = sh_n, nk = sh_nkeep;
+                for (int q = 0; q < nk; q++) {
+                    uint32_t v = keep[q];
+                    int px = rc.x + (int)(v & 0xFFF), py = rc.y + (int)((v >> 12) & 0xFFF);
+                    bool hit = false;
+                    for (int k = t; k < na; k += 64) hit |= in_disk(C.circle_hw, r, px, py, vacc[k].x, vacc[k].y);
+                    bool any = __any(hit);
+                    if (!any && nn < NP) {
+                        if (t == 0) {
+                            vacc[na].x = px; vacc[na].y = py;
+                                g_forw[nn] = make_float2((float)px, (float)py); g_id[nn] = -1; g_cnt[nn] = 1;
+                        }
+                        na++;
+                        nn++;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    __threadfence_block();
+                }
+                if (t == 0) { sh_nacc = na; sh_n = nn; }
+            }
+            __syncthreads();
+        }
+        n = sh_n;
+    }
+    __syncthreads();
+    // ---- cur <- forw; undistortedPoints (:542-593); updateID (:485-495)
+    double dt = fe.cur_time - fe.prev_time;
+    int nprev = fe.n_prev_map;
+    int *newflag = flag, *newoff = offs;  // n <= NP <= VIO_FAST_CAP is checked at create time
+    for (int i = t; i < n; i += blockDim.x) {
+        float2 p = g_forw[i];
+        g_cur[i] = p;
+        double x, y;
+        cam_lift(c, p.x, p.y, x, y);
+        float2 u = make_float2((float)x, (float)y);
+        g_un[i] = u;
+        float2 vel = make_float2(0.f, 0.f);
+        int idv = g_id[i];
+        if (nprev > 0 && idv != -1) {
+            for (int k = 0; k < nprev; k++)
+                if (g_pid[k] == idv) {
+                    double vx = (u.x - g_pun[k].x) / dt, vy = (u.y - g_pun[k].y) / dt;
+                    vel = make_float2((float)vx, (float)vy);
+                    break;
+                }
+        }
+        g_vel[i] = vel;
+        newflag[i] = idv == -1 ? 1 : 0;
+    }
+    __syncthreads();
+    // prev_un_pts_map = cur_un_pts_map: ids as they are *before* updateID
+    for (int i = t; i < n; i += blockDim.x) { g_pid[i] = g_id[i]; g_pun[i] = g_un[i]; }
+    __syncthreads();
+    int nnew = block_exclusive_scan(newflag, n, newoff, scratch);
+    int nid0 = fe.n_id;
+    for (int i = t; i < n; i += blockDim.x) if (newflag[i]) g_id[i] = nid0 + newoff[i];
+    __syncthreads();
+    // ---- feature-map packaging (estimator_nodelet.cpp:336-363): track_cnt > 1, ascending id (std::map order)
+    int nobs = 0;
+    if (publish) {
+        for (int i = t; i < n; i += blockDim.x) newflag[i] = g_cnt[i] > 1 ? 1 : 0;
+        __syncthreads();
+        nobs = block_exclusive_scan(newflag, n, newoff, scratch);
+        int *o_id = B.obs_id + (size_t)s * NP;
+        double *o = B.obs + (size_t)s * NP * 7;
+        for (int i = t; i < n; i += blockDim.x) {
+            if (!newflag[i]) continue;
+            int my = g_id[i], rank = 0;
+            for (int j = 0; j < n; j++) rank += (newflag[j] && g_id[j] < my) ? 1 : 0;
+            o_id[rank] = my;
+            double *q = o + (size_t)rank * 7;
+            q[0] = g_un[i].x; q[1] = g_un[i].y; q[2] = 1.0; q[3] = g_cur[i].x; q[4] = g_cur[i].y; q[5] = g_vel[i].x; q[6] = g_vel[i].y;
+        }
+    }
+    if (t == 0) {
+        fe.n_pts = n;
+        fe.n_forw = n;
+        fe.n_prev_map = n;
+        fe.n_id = nid0 + nnew;
+        fe.prev_time = fe.cur_time;
+        if (fe.has_img) fe.cur_buf ^= 1;
+        fe.has_img = 1;
+        fe.n_obs = nobs;
+        int ok = 0;
+        if (publish) {
+            if (!gate) ok = nobs > 0;
+            else if (!fe.init_pub) fe.init_pub = 1;              // estimator_nodelet.cpp:365-368
+            else if (!fe.init_feature) fe.init_feature = 1;      // :371-377
+            else ok = nobs > 0;
+        }
+        fe.publish_ok = ok;
+    }
+}

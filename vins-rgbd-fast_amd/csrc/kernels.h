@@ -1,0 +1,32 @@
+// Kernel entry points shared between the translation units of libvio_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vio_state.h"
+#include "../../include/vio_synth.h"
+
+struct LkImages {
+    const uint8_t *prev[4];
+    const uint8_t *next[4];
+    int w[4], h[4];
+};
+
+__global__ void fe_begin_kernel(Batch B, const double *stamps, int gate);
+__global__ void fe_pyrdown_kernel(Batch B, const uint8_t *src_base, size_t src_stride, int sw, int sh, int dst_level, int write_level0);
+__global__ void fe_pyrdown_stage_kernel(const uint8_t *src, int sw, int sh, uint8_t *dst);
+__global__ void fe_predict_kernel(Batch B);
+__global__ void fe_lk_kernel(Batch B);
+__global__ void fe_lk_stage_kernel(LkImages im, int maxLevel, int n, const float2 *prevPts, float2 *nextPts, uint8_t *status);
+__global__ void fe_ransac_stage_kernel(vio_config c, int n, const float2 *p1, const float2 *p2, uint8_t *status);
+__global__ void fe_select_kernel(Batch B, int publish);
+__global__ void fe_fast_kernel(Batch B);
+__global__ void fe_fast_stage_kernel(const uint8_t *img, int W, GridRect r, uint32_t *out, int cap, int *count);
+__global__ void fe_add_kernel(Batch B, int publish, int gate);
+__global__ void be_ingest_kernel(Batch B, const uint16_t *depth_base, size_t depth_stride);
+__global__ void be_solve_kernel(Batch B);
+__global__ void be_marg_kernel(Batch B);
+__global__ void be_finish_kernel(Batch B);
+__global__ void be_stage_imu_kernel(vio_config cfg, PreInt *P, int n, const double *dt, const double *acc, const double *gyr,
+                                    const double *par, double g_norm, double *preint_out, double *r15, double *J480);
+__global__ void be_stage_projection_kernel(vio_config cfg, const double *in, int use_td, double *r2, double *J46);
+__global__ void imu_scatter_kernel(Batch B, int total, const int *seq_of, const double *t, const double *acc, const double *gyr);
+__global__ void synth_render_kernel(vio_synth_config c, int S, uint64_t seq0, const float *rays, const float *poses, uint8_t *gray, uint16_t *depth);

@@ -6,6 +6,7 @@
 #include <math.h>
 
 #if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
 #define VIO_HD __host__ __device__ __forceinline__
 #else
 #define VIO_HD inline

@@ -1,0 +1,711 @@
+// Host side of the C ABI (include/vio_abi.h): owns the HBM state of a batch and launches the kernel chain.
+// There is no CPU fallback: every entry point fails with VIO_EDEVICE when HIP is unavailable.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <mutex>
+#include <string>
+#include <string.h>
+#include <vector>
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+#define HIPCHK(x)                                                                                        \
+    do {                                                                                                 \
+        hipError_t e_ = (x);                                                                             \
+        if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return VIO_EDEVICE; } \
+    } while (0)
+
+void circle_halfwidths(int radius, int *hw) {  // cv::circle(filled), OpenCV drawing.cpp Circle()
+    for (int i = 0; i <= radius; i++) hw[i] = -1;
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        if (dx > hw[dy]) hw[dy] = dx;
+        if (dy > hw[dx]) hw[dx] = dy;
+        dy++;
+        err += plus;
+        plus += 2;
+        int mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+    }
+}
+
+}  // namespace
+
+struct vio_batch {
+    DevCfg hc;  // host copy
+    Batch B;
+    int S;
+    hipStream_t stream;
+    hipEvent_t ev[4];
+    std::vector<void *> allocs;
+    uint8_t *d_gray_stage = nullptr;
+    uint16_t *d_depth_stage = nullptr;
+    double *d_stamps = nullptr;
+    // pending IMU samples (host staging)
+    std::mutex imu_mu;
+    std::vector<int> p_seq;
+    std::vector<double> p_t, p_acc, p_gyr;
+    int *d_pseq = nullptr;
+    double *d_pt = nullptr, *d_pacc = nullptr, *d_pgyr = nullptr;
+    size_t d_pcap = 0;
+    std::vector<double> last_imu_t;
+    size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0;
+    bool timing_valid = false;
+};
+
+__global__ void imu_scatter_kernel(Batch B, int total, const int *seq_of, const double *t, const double *acc, const double *gyr) {
+    // samples are grouped by sequence in push order; one thread per sequence walks its run (keeps ring order)
+    int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B.S) return;
+    const DevCfg &C = *B.cfg;
+    BeSeq &be = B.be[s];
+    int cnt = be.imu_count;
+    for (int i = 0; i < total; i++) {
+        if (seq_of[i] != s) continue;
+        int slot = cnt % C.NIMU;
+        B.imu_t[(size_t)s * C.NIMU + slot] = t[i];
+        for (int k = 0; k < 3; k++) {
+            B.imu_acc[((size_t)s * C.NIMU + slot) * 3 + k] = acc[3 * i + k];
+            B.imu_gyr[((size_t)s * C.NIMU + slot) * 3 + k] = gyr[3 * i + k];
+        }
+        cnt++;
+    }
+    be.imu_count = cnt;
+}
+
+namespace {
+
+template <class T> int dalloc(vio_batch *h, T **p, size_t n) {
+    void *q = nullptr;
+    size_t bytes = n * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    HIPCHK(hipMalloc(&q, bytes));
+    HIPCHK(hipMemset(q, 0, bytes));
+    h->allocs.push_back(q);
+    *p = (T *)q;
+    return VIO_OK;
+}
+
+int init_state(vio_batch *h) {
+    const DevCfg &C = h->hc;
+    int S = h->S, W = C.W;
+    std::vector<FeSeq> fe(S);
+    std::vector<BeSeq> be(S);
+    memset(fe.data(), 0, sizeof(FeSeq) * S);
+    memset(be.data(), 0, sizeof(BeSeq) * S);
+    for (int s = 0; s < S; s++) {
+        FeSeq &f = fe[s];
+        f.first_image_flag = 1;
+        for (int k = 0; k < C.ncells; k++) f.grids_texture_status[k] = 1;
+        f.R_rel[0] = f.R_rel[4] = f.R_rel[8] = 1;
+        BeSeq &b = be[s];
+        for (int i = 0; i <= VIO_MAXW; i++) { b.Rs[i][0] = b.Rs[i][4] = b.Rs[i][8] = 1; b.pre_idx[i] = i; }
+        for (int k = 0; k < 9; k++) b.ric[k] = C.c.ric[k];
+        for (int k = 0; k < 3; k++) b.tic[k] = C.c.tic[k];
+        b.td = C.c.td;
+        b.g[2] = C.c.g_norm;
+        b.prevTime = -1;
+        b.n_free = C.NL;
+    }
+    HIPCHK(hipMemcpy(h->B.fe, fe.data(), sizeof(FeSeq) * S, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->B.be, be.data(), sizeof(BeSeq) * S, hipMemcpyHostToDevice));
+    std::vector<int> fr((size_t)S * C.NL);
+    for (int s = 0; s < S; s++) for (int k = 0; k < C.NL; k++) fr[(size_t)s * C.NL + k] = C.NL - 1 - k;
+    HIPCHK(hipMemcpy(h->B.lm_free, fr.data(), fr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(h->B.pre, 0, sizeof(PreInt) * (size_t)S * (W + 2)));
+    HIPCHK(hipMemset(h->B.odom, 0, sizeof(double) * (size_t)S * 11));
+    h->last_imu_t.assign(S, -1e300);
+    h->p_seq.clear(); h->p_t.clear(); h->p_acc.clear(); h->p_gyr.clear();
+    return VIO_OK;
+}
+
+int flush_imu(vio_batch *h) {
+    std::lock_guard<std::mutex> lk(h->imu_mu);
+    size_t n = h->p_seq.size();
+    if (n == 0) return VIO_OK;
+    if (n > h->d_pcap) {
+        size_t cap = n * 2 + 1024;
+        if (h->d_pseq) { (void)hipFree(h->d_pseq); (void)hipFree(h->d_pt); (void)hipFree(h->d_pacc); (void)hipFree(h->d_pgyr); }
+        HIPCHK(hipMalloc((void **)&h->d_pseq, cap * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&h->d_pt, cap * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&h->d_pacc, cap * 3 * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&h->d_pgyr, cap * 3 * sizeof(double)));
+        h->d_pcap = cap;
+    }
+    HIPCHK(hipMemcpyAsync(h->d_pseq, h->p_seq.data(), n * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_pt, h->p_t.data(), n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_pacc, h->p_acc.data(), n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_pgyr, h->p_gyr.data(), n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    imu_scatter_kernel<<<(h->S + 63) / 64, 64, 0, h->stream>>>(h->B, (int)n, h->d_pseq, h->d_pt, h->d_pacc, h->d_pgyr);
+    HIPCHK(hipStreamSynchronize(h->stream));  // host staging vectors are reused below
+    h->p_seq.clear(); h->p_t.clear(); h->p_acc.clear(); h->p_gyr.clear();
+    return VIO_OK;
+}
+
+int launch_frontend(vio_batch *h, const uint8_t *d_gray, int publish, int gate) {
+    const DevCfg &C = h->hc;
+    const int S = h->S, Wd = C.c.width, Ht = C.c.height;
+    hipStream_t st = h->stream;
+    fe_begin_kernel<<<S, 64, 0, st>>>(h->B, h->d_stamps, gate);
+    // pyramid: level 1 from the new frame (+ level-0 copy), further levels from the previous one
+    {
+        int sw = Wd, sh = Ht;
+        for (int l = 1; l <= C.c.lk_max_level; l++) {
+            int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+            dim3 grid((dw + 63) / 64, (dh + 15) / 16, S);
+            fe_pyrdown_kernel<<<grid, 256, 0, st>>>(h->B, l == 1 ? d_gray : nullptr, (size_t)Wd * Ht, sw, sh, l, l == 1 ? 1 : 0);
+            sw = dw; sh = dh;
+        }
+    }
+    fe_predict_kernel<<<dim3((C.NP + 255) / 256, S), 256, 0, st>>>(h->B);
+    fe_lk_kernel<<<dim3(C.NP, S), 64, 0, st>>>(h->B);
+    fe_select_kernel<<<S, 256, h->lds_select, st>>>(h->B, publish);
+    if (publish) fe_fast_kernel<<<dim3(C.ncells, S), 256, h->lds_fast, st>>>(h->B);
+    fe_add_kernel<<<S, 256, h->lds_add, st>>>(h->B, publish, gate);
+    HIPCHK(hipGetLastError());
+    return VIO_OK;
+}
+int launch_backend(vio_batch *h, const uint16_t *d_depth) {
+    const DevCfg &C = h->hc;
+    const int S = h->S;
+    hipStream_t st = h->stream;
+    be_ingest_kernel<<<S, 256, 0, st>>>(h->B, d_depth, (size_t)C.c.width * C.c.height);
+    be_solve_kernel<<<S, 256, h->lds_solve, st>>>(h->B);
+    be_marg_kernel<<<S, 256, 0, st>>>(h->B);
+    be_finish_kernel<<<S, 256, 0, st>>>(h->B);
+    HIPCHK(hipGetLastError());
+    return VIO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *vio_last_error(void) { return g_err.c_str(); }
+
+void vio_config_default(vio_config *c) {
+    memset(c, 0, sizeof(*c));
+    c->width = 640; c->height = 480;
+    c->max_cnt = 150; c->min_dist = 15;
+    c->grid_rows = 5; c->grid_cols = 6;
+    c->window_size = 10;
+    c->max_landmarks = 1000;
+    c->fix_depth = 1;
+    c->estimate_extrinsic = 0;
+    c->estimate_td = 0;
+    c->max_iterations = 8;
+    c->ransac_max_iters = 1000;
+    c->lk_max_level = 1;
+    c->fx = 604.5821781259577; c->fy = 604.2544712985845; c->cx = 321.2638233484251; c->cy = 239.70969315130674;
+    c->k1 = 0.13387871564774004; c->k2 = -0.2731913133377051; c->p1 = 0.0020296263577681264; c->p2 = -0.00044384544608203714;
+    c->focal_length = 460.0;
+    c->f_threshold = 1.0;
+    c->depth_min = 0.3; c->depth_max = 6.0;
+    c->acc_n = 0.1; c->acc_w = 0.001; c->gyr_n = 0.01; c->gyr_w = 0.0001; c->g_norm = 9.805;
+    const double ric[9] = {0.02629567, -0.00713751, 0.99962873, -0.99934346, 0.02474397, 0.02646484, -0.02492368, -0.99966834, -0.00648216};
+    const double tic[3] = {0.17336835, 0.049596, -0.10574841};
+    memcpy(c->ric, ric, sizeof(ric));
+    memcpy(c->tic, tic, sizeof(tic));
+    c->td = 0.0; c->tr = 0.0;
+    c->min_parallax_px = 10.0;
+    c->init_depth = 5.0;
+}
+
+static int build_devcfg(const vio_config *cfg, int imu_capacity, DevCfg &C) {
+    memset(&C, 0, sizeof(C));
+    C.c = *cfg;
+    const vio_config &c = C.c;
+    if (c.width < 64 || c.height < 64 || c.width > 4095 || c.height > 4095) { g_err = "image size out of range"; return VIO_EINVAL; }
+    if (c.window_size < 4 || c.window_size > VIO_MAXW) { g_err = "window_size must be 4..20"; return VIO_EINVAL; }
+    if (c.grid_rows < 1 || c.grid_cols < 1 || c.grid_rows * c.grid_cols > VIO_MAX_CELLS) { g_err = "too many grid cells"; return VIO_EINVAL; }
+    if (c.min_dist < 1 || c.min_dist > 63) { g_err = "min_dist must be 1..63"; return VIO_EINVAL; }
+    if (c.lk_max_level < 0 || c.lk_max_level > 3) { g_err = "lk_max_level must be 0..3"; return VIO_EINVAL; }
+    if (c.estimate_extrinsic < 0 || c.estimate_extrinsic > 1) { g_err = "estimate_extrinsic must be 0 or 1"; return VIO_EINVAL; }
+    C.W = c.window_size;
+    C.ncells = c.grid_rows * c.grid_cols;
+    C.grids_threshold = c.max_cnt / C.ncells;
+    if (C.grids_threshold <= 0) { g_err = "max_cnt must exceed the number of grid cells (feature_tracker.cpp:88-93)"; return VIO_EINVAL; }
+    // initGridsDetector (feature_tracker.cpp:33-94)
+    C.grid_h = c.height / c.grid_rows;
+    C.grid_w = c.width / c.grid_cols;
+    int res_h = c.height - (c.grid_rows - 1) * C.grid_h, res_w = c.width - (c.grid_cols - 1) * C.grid_w;
+    for (int i = 0; i < c.grid_rows; i++)
+        for (int j = 0; j < c.grid_cols; j++) {
+            GridRect r;
+            r.x = j == 0 ? 0 : j * C.grid_w - 3;
+            r.y = i == 0 ? 0 : i * C.grid_h - 3;
+            int gw = (j == c.grid_cols - 1) ? res_w : C.grid_w, gh = (i == c.grid_rows - 1) ? res_h : C.grid_h;
+            r.w = gw + ((j > 0 && j < c.grid_cols - 1) ? 6 : 3);
+            r.h = gh + ((i > 0 && i < c.grid_rows - 1) ? 6 : 3);
+            if (c.grid_cols == 1) r.w = gw;
+            if (c.grid_rows == 1) r.h = gh;
+            C.rect[i * c.grid_cols + j] = r;
+        }
+    circle_halfwidths(c.min_dist, C.circle_hw);
+    C.NP = (c.max_cnt + C.ncells * (C.grids_threshold + 2) + 8 + 7) & ~7;
+    if (C.NP > VIO_FAST_CAP) { g_err = "max_cnt too large for this build"; return VIO_EINVAL; }
+    C.NL = c.max_landmarks < C.NP ? C.NP : c.max_landmarks;
+    C.NL = (C.NL + 7) & ~7;
+    C.NIMU = imu_capacity < 256 ? 256 : imu_capacity;
+    C.P = 15 * (C.W + 1) + 7;
+    C.NPRIOR = 6 * C.W + 16;
+    C.LW = (C.P + 15) & ~15;
+    int off = 0, sw = c.width, sh = c.height;
+    C.lvl_w[0] = sw; C.lvl_h[0] = sh; C.lvl_off[0] = 0;
+    for (int l = 1; l <= 3; l++) {
+        sw = (sw + 1) / 2; sh = (sh + 1) / 2;
+        C.lvl_w[l] = sw; C.lvl_h[l] = sh; C.lvl_off[l] = off;
+        off += (sw * sh + 63) & ~63;
+    }
+    C.pyr_bytes = off;
+    return VIO_OK;
+}
+
+vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
+    if (!cfg || n_seq < 1) { g_err = "bad arguments"; return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_err = "no HIP device (the product path has no CPU fallback)"; return nullptr; }
+    vio_batch *h = new vio_batch();
+    if (build_devcfg(cfg, imu_capacity, h->hc) != VIO_OK) { delete h; return nullptr; }
+    h->S = n_seq;
+    const DevCfg &C = h->hc;
+    const size_t S = (size_t)n_seq, NP = C.NP, NL = C.NL, W1 = C.W + 1, HW = (size_t)C.c.width * C.c.height;
+    Batch &B = h->B;
+    memset(&B, 0, sizeof(B));
+    B.S = n_seq;
+    int rc = VIO_OK;
+#define DA(ptr, n) if (rc == VIO_OK) rc = dalloc(h, &ptr, (size_t)(n))
+    DA(B.cfg, 1); DA(B.fe, S); DA(B.be, S); DA(B.pre, S * (C.W + 2));
+    DA(B.img, S * 2 * HW); DA(B.pyr, S * 2 * (size_t)C.pyr_bytes);
+    DA(B.cur_pts, S * NP); DA(B.forw_pts, S * NP); DA(B.cur_un_pts, S * NP); DA(B.pts_velocity, S * NP); DA(B.prev_un_pt, S * NP);
+    DA(B.unstable_pts, S * NP); DA(B.tmp_pts, S * NP);
+    DA(B.ids, S * NP); DA(B.track_cnt, S * NP); DA(B.prev_un_id, S * NP); DA(B.tmp_i0, S * NP); DA(B.tmp_i1, S * NP);
+    DA(B.lk_status, S * NP); DA(B.accept_xy, S * 2 * NP); DA(B.cand, S * C.ncells * VIO_FAST_CAP);
+    DA(B.obs_id, S * NP); DA(B.obs, S * NP * 7);
+    DA(B.imu_t, S * C.NIMU); DA(B.imu_acc, S * C.NIMU * 3); DA(B.imu_gyr, S * C.NIMU * 3);
+    DA(B.lm_id, S * NL); DA(B.lm_start, S * NL); DA(B.lm_nobs, S * NL); DA(B.lm_est_flag, S * NL); DA(B.lm_solve_flag, S * NL);
+    DA(B.lm_dyn, S * NL); DA(B.lm_order, S * NL); DA(B.lm_free, S * NL); DA(B.lm_tmp, S * NL); DA(B.lm_pidx, S * NL); DA(B.lm_aidx, S * NL);
+    DA(B.lm_depth, S * NL); DA(B.lm_obs, S * NL * W1 * VIO_OBS_D); DA(B.para_feat, S * NL); DA(B.cand_feat, S * NL);
+    const size_t n = C.NPRIOR, LW = C.LW, nres = 4 * NL, npair = W1 * W1, mq = 15 + n;
+    DA(B.prior_J, S * n * n); DA(B.prior_r, S * n); DA(B.prior_x0, S * (C.W * 7 + 17)); DA(B.prior_H, S * n * n);
+    DA(B.H, S * LW * LW); DA(B.Sc, S * LW * LW); DA(B.Hpl, S * NL * LW); DA(B.vec, S * VEC_SLOTS * LW);
+    DA(B.Hll, S * NL); DA(B.gl, S * NL); DA(B.lvec, S * NL * 8);
+    DA(B.res, S * nres * 42); DA(B.res_lm, S * nres); DA(B.res_k, S * nres); DA(B.res_pair, S);
+    DA(B.pair_start, S * (npair + 1)); DA(B.pair_list, S * nres); DA(B.pairblk, S * npair * 210);
+    DA(B.imu_raw, S * C.W * 15 * 31);
+    DA(B.margA, S * mq * mq); DA(B.margB, S * mq); DA(B.margV, S * n * n); DA(B.margW, S * (n + 16) * (n + 16));
+    DA(B.odom, S * 11); DA(B.timings, 64);
+    DA(h->d_stamps, S);
+#undef DA
+    if (rc == VIO_OK && hipMemcpy(B.cfg, &h->hc, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) { g_err = "cfg upload failed"; rc = VIO_EDEVICE; }
+    if (rc == VIO_OK && hipStreamCreate(&h->stream) != hipSuccess) { g_err = "stream create failed"; rc = VIO_EDEVICE; }
+    for (int i = 0; i < 4 && rc == VIO_OK; i++)
+        if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_err = "event create failed"; rc = VIO_EDEVICE; }
+    if (rc == VIO_OK) rc = init_state(h);
+    if (rc == VIO_OK) {
+        h->lds_select = (size_t)C.NP * 104 + 260 * 4 + 64;
+        h->lds_add = (size_t)C.NP * 16 + 3 * VIO_FAST_CAP * 4 + 260 * 4 + 64 * 4 + 64;
+        int amax = 0;
+        for (int k = 0; k < C.ncells; k++) amax = std::max(amax, ((C.rect[k].w * C.rect[k].h + 15) & ~15));
+        int hmax = 0;
+        for (int k = 0; k < C.ncells; k++) hmax = std::max(hmax, C.rect[k].h);
+        h->lds_fast = (size_t)2 * amax + (size_t)(hmax + 2) * 4 + 16;
+        h->lds_solve = (size_t)C.LW * 8 + 16;
+        (void)hipFuncSetAttribute((const void *)fe_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_select);
+        (void)hipFuncSetAttribute((const void *)fe_add_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_add);
+        (void)hipFuncSetAttribute((const void *)fe_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_fast);
+    }
+    if (rc != VIO_OK) { vio_destroy(h); return nullptr; }
+    return h;
+}
+
+void vio_destroy(vio_batch *h) {
+    if (!h) return;
+    (void)hipDeviceSynchronize();
+    for (void *p : h->allocs) (void)hipFree(p);
+    if (h->d_gray_stage) (void)hipFree(h->d_gray_stage);
+    if (h->d_depth_stage) (void)hipFree(h->d_depth_stage);
+    if (h->d_pseq) { (void)hipFree(h->d_pseq); (void)hipFree(h->d_pt); (void)hipFree(h->d_pacc); (void)hipFree(h->d_pgyr); }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+    delete h;
+}
+
+int vio_reset(vio_batch *h) {
+    if (!h) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    // zero the tracker / landmark / prior state that init_state does not rewrite
+    const DevCfg &C = h->hc;
+    HIPCHK(hipMemset(h->B.lm_order, 0, sizeof(int) * (size_t)h->S * C.NL));
+    return init_state(h);
+}
+
+int vio_push_imu(vio_batch *h, int seq, int n, const double *t, const double *acc, const double *gyr) {
+    if (!h || seq < 0 || seq >= h->S || n < 0) return VIO_EINVAL;
+    std::lock_guard<std::mutex> lk(h->imu_mu);
+    for (int i = 0; i < n; i++) {
+        if (!(t[i] > h->last_imu_t[seq])) continue;  // "imu message in disorder" (estimator_nodelet.cpp:110-114)
+        h->last_imu_t[seq] = t[i];
+        h->p_seq.push_back(seq);
+        h->p_t.push_back(t[i]);
+        for (int k = 0; k < 3; k++) { h->p_acc.push_back(acc[3 * i + k]); h->p_gyr.push_back(gyr[3 * i + k]); }
+    }
+    return VIO_OK;
+}
+
+static int stage_inputs(vio_batch *h, const uint8_t *gray, const uint16_t *depth, const double *stamps, int on_device,
+                        const uint8_t **dg, const uint16_t **dd) {
+    const DevCfg &C = h->hc;
+    size_t HW = (size_t)C.c.width * C.c.height, S = h->S;
+    if (stamps) HIPCHK(hipMemcpyAsync(h->d_stamps, stamps, S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (on_device) { *dg = gray; *dd = depth; return VIO_OK; }
+    if (gray) {
+        if (!h->d_gray_stage) HIPCHK(hipMalloc((void **)&h->d_gray_stage, S * HW));
+        HIPCHK(hipMemcpyAsync(h->d_gray_stage, gray, S * HW, hipMemcpyHostToDevice, h->stream));
+        *dg = h->d_gray_stage;
+    }
+    if (depth) {
+        if (!h->d_depth_stage) HIPCHK(hipMalloc((void **)&h->d_depth_stage, S * HW * 2));
+        HIPCHK(hipMemcpyAsync(h->d_depth_stage, depth, S * HW * 2, hipMemcpyHostToDevice, h->stream));
+        *dd = h->d_depth_stage;
+    }
+    return VIO_OK;
+}
+
+int vio_feed(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, int on_device) {
+    if (!h || !gray || !depth_mm || !stamps) return VIO_EINVAL;
+    int rc = flush_imu(h);
+    if (rc != VIO_OK) return rc;
+    const uint8_t *dg = nullptr;
+    const uint16_t *dd = nullptr;
+    rc = stage_inputs(h, gray, depth_mm, stamps, on_device, &dg, &dd);
+    if (rc != VIO_OK) return rc;
+    HIPCHK(hipEventRecord(h->ev[0], h->stream));
+    rc = launch_frontend(h, dg, 1, 1);
+    if (rc != VIO_OK) return rc;
+    HIPCHK(hipEventRecord(h->ev[1], h->stream));
+    rc = launch_backend(h, dd);
+    if (rc != VIO_OK) return rc;
+    HIPCHK(hipEventRecord(h->ev[2], h->stream));
+    h->timing_valid = true;
+    return VIO_OK;
+}
+
+int vio_track(vio_batch *h, const uint8_t *gray, const double *stamps, int publish, int on_device) {
+    if (!h || !gray || !stamps) return VIO_EINVAL;
+    int rc = flush_imu(h);
+    if (rc != VIO_OK) return rc;
+    const uint8_t *dg = nullptr;
+    const uint16_t *dd = nullptr;
+    rc = stage_inputs(h, gray, nullptr, stamps, on_device, &dg, &dd);
+    if (rc != VIO_OK) return rc;
+    return launch_frontend(h, dg, publish ? 1 : 0, 0);
+}
+
+int vio_process(vio_batch *h, const uint16_t *depth_mm, int on_device) {
+    if (!h || !depth_mm) return VIO_EINVAL;
+    int rc = flush_imu(h);
+    if (rc != VIO_OK) return rc;
+    const uint8_t *dg = nullptr;
+    const uint16_t *dd = nullptr;
+    rc = stage_inputs(h, nullptr, depth_mm, nullptr, on_device, &dg, &dd);
+    if (rc != VIO_OK) return rc;
+    return launch_backend(h, dd);
+}
+
+int vio_sync(vio_batch *h) {
+    if (!h) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return VIO_OK;
+}
+void *vio_get_stream(vio_batch *h) { return h ? (void *)h->stream : nullptr; }
+
+int vio_get_status(vio_batch *h, int seq, vio_status *out) {
+    if (!h || seq < 0 || seq >= h->S || !out) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    static thread_local BeSeq be;
+    static thread_local FeSeq fe;
+    HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&fe, h->B.fe + seq, sizeof(FeSeq), hipMemcpyDeviceToHost));
+    out->code = be.status_code; out->solver_flag = be.solver_flag; out->frame_count = be.frame_count;
+    out->marginalization_flag = be.marginalization_flag; out->n_landmarks = be.n_lm; out->last_track_num = be.last_track_num;
+    out->n_tracks = fe.n_pts; out->processed = be.processed; out->iterations = be.iterations; out->successful_steps = be.successful;
+    out->n_in_problem = be.n_in_problem; out->n_residuals = be.n_residuals; out->n_var_landmarks = be.n_var_landmarks;
+    out->has_prior = be.has_prior; out->reboot_count = be.reboot_count; out->frames_processed = be.frames_processed;
+    out->initial_cost = be.initial_cost; out->final_cost = be.final_cost; out->td = be.td;
+    return VIO_OK;
+}
+
+int vio_get_window(vio_batch *h, int seq, double *out) {
+    if (!h || seq < 0 || seq >= h->S || !out) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    static thread_local BeSeq be;
+    HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
+    for (int i = 0; i <= h->hc.W; i++) {
+        double *o = out + 17 * i;
+        dm::quat q = dm::R2q(dm::ldm(be.Rs[i]));
+        o[0] = be.Ps[i][0]; o[1] = be.Ps[i][1]; o[2] = be.Ps[i][2];
+        o[3] = q.w; o[4] = q.x; o[5] = q.y; o[6] = q.z;
+        for (int k = 0; k < 3; k++) { o[7 + k] = be.Vs[i][k]; o[10 + k] = be.Bas[i][k]; o[13 + k] = be.Bgs[i][k]; }
+        o[16] = be.Headers[i];
+    }
+    return VIO_OK;
+}
+
+int vio_get_odometry(vio_batch *h, double *out) {
+    if (!h || !out) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipMemcpy(out, h->B.odom, sizeof(double) * (size_t)h->S * 11, hipMemcpyDeviceToHost));
+    return VIO_OK;
+}
+
+int vio_get_extrinsic(vio_batch *h, int seq, double *out13) {
+    if (!h || seq < 0 || seq >= h->S || !out13) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    static thread_local BeSeq be;
+    HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; k++) out13[k] = be.tic[k];
+    for (int k = 0; k < 9; k++) out13[3 + k] = be.ric[k];
+    out13[12] = be.td;
+    return VIO_OK;
+}
+
+int vio_get_tracks(vio_batch *h, int seq, int cap, int32_t *ids, int32_t *cnt, float *cur, float *un, float *vel) {
+    if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    static thread_local FeSeq fe;
+    HIPCHK(hipMemcpy(&fe, h->B.fe + seq, sizeof(FeSeq), hipMemcpyDeviceToHost));
+    int n = fe.n_pts, m = n < cap ? n : cap;
+    size_t o = (size_t)seq * h->hc.NP;
+    if (m > 0) {
+        HIPCHK(hipMemcpy(ids, h->B.ids + o, sizeof(int) * m, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(cnt, h->B.track_cnt + o, sizeof(int) * m, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(cur, h->B.cur_pts + o, sizeof(float2) * m, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(un, h->B.cur_un_pts + o, sizeof(float2) * m, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(vel, h->B.pts_velocity + o, sizeof(float2) * m, hipMemcpyDeviceToHost));
+    }
+    return n;
+}
+
+int vio_get_landmarks(vio_batch *h, int seq, int cap, double *out) {
+    if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    static thread_local BeSeq be;
+    HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
+    int NL = h->hc.NL, n = be.n_lm;
+    size_t o = (size_t)seq * NL;
+    std::vector<int> order(NL), id(NL), st(NL), no(NL), ef(NL), sf(NL), dy(NL);
+    std::vector<double> dep(NL);
+    HIPCHK(hipMemcpy(order.data(), h->B.lm_order + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(id.data(), h->B.lm_id + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(st.data(), h->B.lm_start + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(no.data(), h->B.lm_nobs + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ef.data(), h->B.lm_est_flag + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sf.data(), h->B.lm_solve_flag + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dy.data(), h->B.lm_dyn + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dep.data(), h->B.lm_depth + o, sizeof(double) * NL, hipMemcpyDeviceToHost));
+    for (int k = 0; k < n && k < cap; k++) {
+        int s = order[k];
+        double *q = out + 7 * k;
+        q[0] = id[s]; q[1] = st[s]; q[2] = no[s]; q[3] = dep[s]; q[4] = ef[s]; q[5] = sf[s]; q[6] = dy[s];
+    }
+    return n;
+}
+
+int vio_get_prior(vio_batch *h, int seq, double *J, double *r, double *x0, uint8_t *present) {
+    if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    static thread_local BeSeq be;
+    HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
+    if (!be.has_prior) return 0;
+    int n = h->hc.NPRIOR, W = h->hc.W;
+    if (J) HIPCHK(hipMemcpy(J, h->B.prior_J + (size_t)seq * n * n, sizeof(double) * n * n, hipMemcpyDeviceToHost));
+    if (r) HIPCHK(hipMemcpy(r, h->B.prior_r + (size_t)seq * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (x0) HIPCHK(hipMemcpy(x0, h->B.prior_x0 + (size_t)seq * (W * 7 + 17), sizeof(double) * (W * 7 + 17), hipMemcpyDeviceToHost));
+    if (present) for (int k = 0; k < W + 3; k++) present[k] = (uint8_t)be.prior_present[k];
+    return n;
+}
+
+int vio_get_timings(vio_batch *h, int cap, double *out_ms) {
+    if (!h || !out_ms || cap < 3) return VIO_EINVAL;
+    if (!h->timing_valid) return 0;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float a = 0, b = 0;
+    HIPCHK(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+    HIPCHK(hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+    out_ms[0] = a; out_ms[1] = b; out_ms[2] = a + b;
+    return 3;
+}
+
+// ------------------------------------------------------------------------------------------------ stage entry points
+#define STAGE_CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); rc = VIO_EDEVICE; goto done; } } while (0)
+
+int vio_stage_pyr_down(const uint8_t *src, int w, int h, uint8_t *dst) {
+    int rc = VIO_OK, dw = (w + 1) / 2, dh = (h + 1) / 2;
+    uint8_t *ds = nullptr, *dd = nullptr;
+    STAGE_CHK(hipMalloc((void **)&ds, (size_t)w * h));
+    STAGE_CHK(hipMalloc((void **)&dd, (size_t)dw * dh));
+    STAGE_CHK(hipMemcpy(ds, src, (size_t)w * h, hipMemcpyHostToDevice));
+    fe_pyrdown_stage_kernel<<<dim3((dw + 63) / 64, (dh + 15) / 16), 256>>>(ds, w, h, dd);
+    STAGE_CHK(hipDeviceSynchronize());
+    STAGE_CHK(hipMemcpy(dst, dd, (size_t)dw * dh, hipMemcpyDeviceToHost));
+done:
+    if (ds) (void)hipFree(ds);
+    if (dd) (void)hipFree(dd);
+    return rc;
+}
+
+int vio_stage_fast_roi(const uint8_t *img, int W, int H, int rx, int ry, int rw, int rh, int cap, float *out) {
+    int rc = VIO_OK, count = 0;
+    uint8_t *di = nullptr;
+    uint32_t *dout = nullptr;
+    int *dcnt = nullptr;
+    std::vector<uint32_t> hv;
+    GridRect r{rx, ry, rw, rh};
+    size_t lds = (size_t)2 * ((rw * rh + 15) & ~15) + (size_t)(rh + 2) * 4 + 16;
+    if (rw < 7 || rh < 7) return 0;
+    STAGE_CHK(hipMalloc((void **)&di, (size_t)W * H));
+    STAGE_CHK(hipMalloc((void **)&dout, (size_t)cap * 4));
+    STAGE_CHK(hipMalloc((void **)&dcnt, 4));
+    STAGE_CHK(hipMemcpy(di, img, (size_t)W * H, hipMemcpyHostToDevice));
+    (void)hipFuncSetAttribute((const void *)fe_fast_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    fe_fast_stage_kernel<<<1, 256, lds>>>(di, W, r, dout, cap, dcnt);
+    STAGE_CHK(hipDeviceSynchronize());
+    STAGE_CHK(hipMemcpy(&count, dcnt, 4, hipMemcpyDeviceToHost));
+    hv.resize(cap);
+    STAGE_CHK(hipMemcpy(hv.data(), dout, (size_t)cap * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < count && i < cap; i++) { out[3 * i] = (float)(hv[i] & 0xFFF); out[3 * i + 1] = (float)((hv[i] >> 12) & 0xFFF); out[3 * i + 2] = (float)(hv[i] >> 24); }
+    rc = count;
+done:
+    if (di) (void)hipFree(di);
+    if (dout) (void)hipFree(dout);
+    if (dcnt) (void)hipFree(dcnt);
+    return rc;
+}
+
+int vio_stage_lk(const uint8_t *prev, const uint8_t *next, int w, int h, int max_level, int n, const float *prev_pts, float *next_pts,
+                 uint8_t *status) {
+    int rc = VIO_OK;
+    if (max_level < 0 || max_level > 3 || n < 0) return VIO_EINVAL;
+    uint8_t *dp[4] = {0, 0, 0, 0}, *dn[4] = {0, 0, 0, 0}, *dst = nullptr;
+    float2 *dpp = nullptr, *dnp = nullptr;
+    LkImages im;
+    memset(&im, 0, sizeof(im));
+    int lw = w, lh = h;
+    for (int l = 0; l <= max_level; l++) {
+        STAGE_CHK(hipMalloc((void **)&dp[l], (size_t)lw * lh));
+        STAGE_CHK(hipMalloc((void **)&dn[l], (size_t)lw * lh));
+        im.prev[l] = dp[l]; im.next[l] = dn[l]; im.w[l] = lw; im.h[l] = lh;
+        if (l == 0) {
+            STAGE_CHK(hipMemcpy(dp[0], prev, (size_t)w * h, hipMemcpyHostToDevice));
+            STAGE_CHK(hipMemcpy(dn[0], next, (size_t)w * h, hipMemcpyHostToDevice));
+        } else {
+            int pw = im.w[l - 1], ph = im.h[l - 1];
+            fe_pyrdown_stage_kernel<<<dim3((lw + 63) / 64, (lh + 15) / 16), 256>>>(dp[l - 1], pw, ph, dp[l]);
+            fe_pyrdown_stage_kernel<<<dim3((lw + 63) / 64, (lh + 15) / 16), 256>>>(dn[l - 1], pw, ph, dn[l]);
+        }
+        lw = (lw + 1) / 2; lh = (lh + 1) / 2;
+    }
+    STAGE_CHK(hipMalloc((void **)&dpp, sizeof(float2) * (n + 1)));
+    STAGE_CHK(hipMalloc((void **)&dnp, sizeof(float2) * (n + 1)));
+    STAGE_CHK(hipMalloc((void **)&dst, n + 1));
+    STAGE_CHK(hipMemcpy(dpp, prev_pts, sizeof(float2) * n, hipMemcpyHostToDevice));
+    STAGE_CHK(hipMemcpy(dnp, next_pts, sizeof(float2) * n, hipMemcpyHostToDevice));
+    if (n > 0) fe_lk_stage_kernel<<<n, 64>>>(im, max_level, n, dpp, dnp, dst);
+    STAGE_CHK(hipDeviceSynchronize());
+    STAGE_CHK(hipMemcpy(next_pts, dnp, sizeof(float2) * n, hipMemcpyDeviceToHost));
+    STAGE_CHK(hipMemcpy(status, dst, n, hipMemcpyDeviceToHost));
+done:
+    for (int l = 0; l < 4; l++) { if (dp[l]) (void)hipFree(dp[l]); if (dn[l]) (void)hipFree(dn[l]); }
+    if (dpp) (void)hipFree(dpp);
+    if (dnp) (void)hipFree(dnp);
+    if (dst) (void)hipFree(dst);
+    return rc;
+}
+
+int vio_stage_ransac(const vio_config *cfg, int n, const float *p1, const float *p2, uint8_t *status) {
+    int rc = VIO_OK;
+    float2 *d1 = nullptr, *d2 = nullptr;
+    uint8_t *ds = nullptr;
+    size_t lds = (size_t)n * 36 + 64;
+    STAGE_CHK(hipMalloc((void **)&d1, sizeof(float2) * (n + 1)));
+    STAGE_CHK(hipMalloc((void **)&d2, sizeof(float2) * (n + 1)));
+    STAGE_CHK(hipMalloc((void **)&ds, n + 1));
+    STAGE_CHK(hipMemcpy(d1, p1, sizeof(float2) * n, hipMemcpyHostToDevice));
+    STAGE_CHK(hipMemcpy(d2, p2, sizeof(float2) * n, hipMemcpyHostToDevice));
+    (void)hipFuncSetAttribute((const void *)fe_ransac_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    fe_ransac_stage_kernel<<<1, 256, lds>>>(*cfg, n, d1, d2, ds);
+    STAGE_CHK(hipDeviceSynchronize());
+    STAGE_CHK(hipMemcpy(status, ds, n, hipMemcpyDeviceToHost));
+done:
+    if (d1) (void)hipFree(d1);
+    if (d2) (void)hipFree(d2);
+    if (ds) (void)hipFree(ds);
+    return rc;
+}
+
+int vio_stage_imu_factor(const vio_config *cfg, int n, const double *dt, const double *acc, const double *gyr, const double *acc0,
+                         const double *gyr0, const double *ba, const double *bg, const double *pose_i, const double *sb_i,
+                         const double *pose_j, const double *sb_j, double *preint_out, double *r15, double *J480) {
+    int rc = VIO_OK;
+    PreInt *hp = new PreInt();
+    PreInt *dp = nullptr;
+    double *dbuf = nullptr;
+    std::vector<double> hb;
+    memset(hp, 0, sizeof(PreInt));
+    {
+        using namespace dm;
+        // IntegrationBase constructor on the host side of the test harness (plain state initialisation)
+        for (int k = 0; k < 3; k++) { hp->lin_acc[k] = acc0[k]; hp->lin_gyr[k] = gyr0[k]; hp->lin_ba[k] = ba[k]; hp->lin_bg[k] = bg[k]; hp->acc0[k] = acc0[k]; hp->gyr0[k] = gyr0[k]; }
+        hp->dq[0] = 1;
+        for (int i = 0; i < 15; i++) hp->jac[i * 16] = 1;
+        hp->valid = 1;
+    }
+    size_t nd = (size_t)n * 7 + 32 + 461 + 15 + 480;
+    hb.assign(nd, 0.0);
+    for (int i = 0; i < n; i++) { hb[i] = dt[i]; for (int k = 0; k < 3; k++) { hb[n + 3 * i + k] = acc[3 * i + k]; hb[4 * n + 3 * i + k] = gyr[3 * i + k]; } }
+    for (int k = 0; k < 7; k++) { hb[7 * n + k] = pose_i[k]; hb[7 * n + 16 + k] = pose_j[k]; }
+    for (int k = 0; k < 9; k++) { hb[7 * n + 7 + k] = sb_i[k]; hb[7 * n + 23 + k] = sb_j[k]; }
+    STAGE_CHK(hipMalloc((void **)&dp, sizeof(PreInt)));
+    STAGE_CHK(hipMalloc((void **)&dbuf, nd * sizeof(double)));
+    STAGE_CHK(hipMemcpy(dp, hp, sizeof(PreInt), hipMemcpyHostToDevice));
+    STAGE_CHK(hipMemcpy(dbuf, hb.data(), nd * sizeof(double), hipMemcpyHostToDevice));
+    be_stage_imu_kernel<<<1, 256>>>(*cfg, dp, n, dbuf, dbuf + n, dbuf + 4 * n, dbuf + 7 * n, cfg->g_norm, dbuf + 7 * n + 32, dbuf + 7 * n + 32 + 461,
+                                    dbuf + 7 * n + 32 + 461 + 15);
+    STAGE_CHK(hipDeviceSynchronize());
+    STAGE_CHK(hipMemcpy(hb.data(), dbuf, nd * sizeof(double), hipMemcpyDeviceToHost));
+    memcpy(preint_out, &hb[7 * n + 32], 461 * sizeof(double));
+    memcpy(r15, &hb[7 * n + 32 + 461], 15 * sizeof(double));
+    memcpy(J480, &hb[7 * n + 32 + 461 + 15], 480 * sizeof(double));
+done:
+    if (dp) (void)hipFree(dp);
+    if (dbuf) (void)hipFree(dbuf);
+    delete hp;
+    return rc;
+}
+
+int vio_stage_projection(const vio_config *cfg, const double *pose_i, const double *pose_j, const double *ex, double inv_dep, double td,
+                         const double *obs_i, const double *obs_j, int use_td, double *r2, double *J46) {
+    int rc = VIO_OK;
+    double hb[41 + 2 + 46];
+    double *db = nullptr;
+    memcpy(hb, pose_i, 56); memcpy(hb + 7, pose_j, 56); memcpy(hb + 14, ex, 56);
+    hb[21] = inv_dep; hb[22] = td;
+    memcpy(hb + 23, obs_i, 72); memcpy(hb + 32, obs_j, 72);
+    STAGE_CHK(hipMalloc((void **)&db, sizeof(hb)));
+    STAGE_CHK(hipMemcpy(db, hb, sizeof(hb), hipMemcpyHostToDevice));
+    be_stage_projection_kernel<<<1, 64>>>(*cfg, db, use_td, db + 41, db + 43);
+    STAGE_CHK(hipDeviceSynchronize());
+    STAGE_CHK(hipMemcpy(hb, db, sizeof(hb), hipMemcpyDeviceToHost));
+    memcpy(r2, hb + 41, 16);
+    memcpy(J46, hb + 43, 46 * 8);
+done:
+    if (db) (void)hipFree(db);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,142 @@
+// HBM-resident state of a batch of S independent VIO sequences (DESIGN.md "Data layout in HBM").
+// One instance of each per-sequence record per sequence; kernels index them with blockIdx.
+// Reference state being mirrored: FeatureTracker members (feature_tracker.h:67-96), Estimator members
+// (estimator.h:117-201), FeatureManager::feature (feature_manager.h:143), IntegrationBase (integration_base.h:197-216),
+// MarginalizationInfo (marginalization_factor.h:51-76).
+#pragma once
+#include <stdint.h>
+#include "../../include/vio_abi.h"
+#include "dmath.h"
+
+#define VIO_MAXW 20
+#define VIO_IMU_SLOT_CAP 64  // IMU samples kept per window slot for repropagate() (only read until initialisation)
+#define VIO_OBS_D 9          // x y z u v vx vy cur_td depth  (FeaturePerFrame)
+#define VIO_MAX_CELLS 64
+#define VIO_FAST_CAP 1024    // NMS survivors kept per grid cell (before mask filter)
+#define VIO_WIN 21           // LK window
+
+struct GridRect { int x, y, w, h; };
+
+// device-side copy of the configuration + derived constants
+struct DevCfg {
+    vio_config c;
+    int W;              // window size
+    int NP;             // capacity of the tracker point arrays
+    int NL;             // landmark table capacity
+    int NIMU;           // IMU ring capacity
+    int ncells;
+    int grids_threshold;
+    int grid_w, grid_h;
+    GridRect rect[VIO_MAX_CELLS];
+    int circle_hw[64];  // cv::circle(filled) half-widths for radius min_dist (min_dist <= 63)
+    int P;              // tangent dimension 15(W+1)+7
+    int NPRIOR;         // prior dimension 6W+16
+    int LW;             // dense row stride of the landmark coupling matrix (= P rounded up to 16)
+    int lvl_w[4], lvl_h[4], lvl_off[4];  // pyramid levels >= 1 packed in one buffer
+    int pyr_bytes;
+};
+
+// IntegrationBase (integration_base.h)
+struct PreInt {
+    double lin_acc[3], lin_gyr[3], lin_ba[3], lin_bg[3];
+    double acc0[3], gyr0[3];
+    double dp[3], dq[4], dv[3], sum_dt;  // dq = (w,x,y,z)
+    double jac[225], cov[225];
+    double sqrt_info[225];               // LLT(cov^-1).L^T, refreshed before each solve
+    double dt_buf[VIO_IMU_SLOT_CAP], acc_buf[VIO_IMU_SLOT_CAP][3], gyr_buf[VIO_IMU_SLOT_CAP][3];
+    int n_buf, valid;
+};
+
+// per-sequence tracker record (scalars); arrays live in TrackerArrays
+struct FeSeq {
+    double cur_time, prev_time;
+    double R_rel[9];
+    int n_pts;        // size of cur_pts / ids / track_cnt
+    int n_forw;       // working count during a frame
+    int n_unstable;
+    int n_id;
+    int has_img;
+    int cur_buf;      // which ping-pong image buffer holds cur_img
+    int n_prev_map;   // entries of prev_un_pts_map
+    int first_image_flag, init_pub, init_feature;
+    double last_image_time;
+    int n_obs;        // packaged features for the back-end (track_cnt > 1), ascending id
+    int publish_ok;   // 1 if the packaged features should be handed to processImage
+    int n_deficit;
+    int deficit_cells[VIO_MAX_CELLS];
+    int grids_track_num[VIO_MAX_CELLS];
+    int grids_texture_status[VIO_MAX_CELLS];
+    int cell_ncand[VIO_MAX_CELLS];
+    int n_accept;     // accepted mask centres (setMask survivors + unstable + added)
+    int ransac_iters; // diagnostics
+};
+
+struct BeSeq {
+    double Ps[VIO_MAXW + 1][3], Vs[VIO_MAXW + 1][3], Bas[VIO_MAXW + 1][3], Bgs[VIO_MAXW + 1][3];
+    double Rs[VIO_MAXW + 1][9];
+    double Headers[VIO_MAXW + 1];
+    double acc_0[3], gyr_0[3], g[3], ric[9], tic[3], td;
+    double latest_Bg[3];
+    double last_R[9], last_R0[9], last_P[3], last_P0[3], back_R0[9], back_P0[3];
+    double para_Pose[VIO_MAXW + 1][7], para_SB[VIO_MAXW + 1][9], para_Ex[7], para_Td;
+    double prevTime, cur_stamp;
+    double initial_cost, final_cost;
+    int first_imu, initFirstPoseFlag, openExEstimation, frame_count, solver_flag, marginalization_flag;
+    int has_prior, prior_present[VIO_MAXW + 3];
+    int n_lm, n_free, last_track_num, ring_base;
+    int status_code, processed, reboot_count, frames_processed;
+    int iterations, successful, n_in_problem, n_residuals, n_var_landmarks;
+    int imu_head, imu_count;        // ring read index / number of samples ever pushed (absolute counters)
+    int pre_idx[VIO_MAXW + 1];      // window slot -> physical PreInt (pointer swaps of slideWindow)
+    int do_solve, do_marg;          // decisions of the ingest stage for the later kernels
+    int n_imu_frame;                // samples consumed for the current frame
+    int overflow;                   // capacity overflow flags (landmarks / imu slot)
+};
+
+// all HBM pointers of a batch; passed to kernels by value
+struct Batch {
+    DevCfg *cfg;  // device copy
+    int S;
+    FeSeq *fe;
+    BeSeq *be;
+    PreInt *pre;          // [S][W+2]
+    // ---- tracker arrays, stride NP per sequence
+    uint8_t *img;         // [S][2][H*W] ping-pong level 0
+    uint8_t *pyr;         // [S][2][pyr_bytes] levels >= 1
+    float2 *cur_pts, *forw_pts, *cur_un_pts, *pts_velocity, *prev_un_pt, *unstable_pts;
+    float2 *tmp_pts;
+    int *ids, *track_cnt, *prev_un_id, *tmp_i0, *tmp_i1;
+    uint8_t *lk_status;
+    int2 *accept_xy;      // rounded mask circle centres
+    uint32_t *cand;       // [S][ncells][VIO_FAST_CAP] packed x | y<<12 | score<<24 (ROI-relative)
+    int *obs_id;          // [S][NP]
+    double *obs;          // [S][NP][7]
+    // ---- IMU ring [S][NIMU]
+    double *imu_t, *imu_acc, *imu_gyr;
+    // ---- landmark table, stride NL
+    int *lm_id, *lm_start, *lm_nobs, *lm_est_flag, *lm_solve_flag, *lm_dyn, *lm_order, *lm_free, *lm_tmp;
+    int *lm_pidx;         // index among in-problem landmarks (para_Feature index) or -1
+    int *lm_aidx;         // index among variable landmarks or -1
+    double *lm_depth;     // estimated_depth
+    double *lm_obs;       // [S][NL][W+1][VIO_OBS_D], ring-indexed per frame
+    double *para_feat;    // [S][NL] inverse depths (para_Feature)
+    double *cand_feat;    // [S][NL]
+    // ---- prior (canonical layout) per sequence
+    double *prior_J, *prior_r, *prior_x0, *prior_H;  // n*n, n, W*7+17, n*n (J^T J)
+    // ---- solver scratch per sequence
+    double *H, *Sc, *Hpl;     // P*P, P*P, NL*LW
+    double *vec;              // [S][VEC_SLOTS][LW]
+    double *Hll, *gl, *lvec;  // [S][NL], [S][NL], [S][8][NL]
+    double *res;              // per residual: weighted J (2x20) and r (2): [S][NRES][42]
+    int *res_pair, *res_lm, *res_k;   // pair id / landmark slot / obs index per residual
+    int *pair_start, *pair_list;      // counting sort by frame pair
+    double *pairblk;                  // [S][npairs][210] packed symmetric 20x20
+    double *imu_raw;                  // [S][W][15*31] raw / whitened IMU Jacobians + residual
+    double *margA, *margB, *margV, *margW;  // marginalisation workspaces
+    // ---- outputs
+    double *odom;         // [S][11]
+    float *timings;
+};
+
+#define VEC_SLOTS 24
+#define NRES_PER_LM VIO_MAXW
