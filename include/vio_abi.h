@@ -106,6 +106,8 @@ int vio_get_status(vio_batch *h, int seq, vio_status *out);
 int vio_get_window(vio_batch *h, int seq, double *out);
 /* the CSV row of visualization.cpp:214-225 for every sequence: [S][11] = stamp, P(3), Q(w,x,y,z), V(3) of frame W */
 int vio_get_odometry(vio_batch *h, double *out);
+/* every CSV row written so far for sequence seq (HBM ring of 2048 rows): returns the number of rows produced */
+int vio_get_odometry_history(vio_batch *h, int seq, int cap, double *out);
 /* tic(3), ric(9 row-major), td */
 int vio_get_extrinsic(vio_batch *h, int seq, double *out13);
 /* FeatureTracker public vectors after readImage (estimator_nodelet.cpp:337-343): returns count */
@@ -120,6 +122,11 @@ int vio_get_prior(vio_batch *h, int seq, double *J_nxn, double *r_n, double *x0,
 /* Per-stage device time of the last vio_feed in milliseconds (hipEvent on the batch stream):
  * out[0] front-end, out[1] back-end, out[2] total; plus kernel-level entries, see DESIGN.md. Returns count. */
 int vio_get_timings(vio_batch *h, int cap, double *out_ms);
+/* Per-kernel HIP-event timing of the next max_steps vio_feed calls, recorded on the batch stream.
+ * vio_profile_end: out_ms[11] = average ms of fe_begin, fe_pyrdown, fe_predict, fe_lk, fe_select, fe_fast, fe_add,
+ * be_ingest, be_solve, be_marg, be_finish; returns the number of recorded steps. */
+int vio_profile_begin(vio_batch *h, int max_steps);
+int vio_profile_end(vio_batch *h, int cap, double *out_ms);
 /* stream the batch launches on (hipStream_t) so callers can bracket it with their own events */
 void *vio_get_stream(vio_batch *h);
 

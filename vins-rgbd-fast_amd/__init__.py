@@ -94,6 +94,8 @@ def lib():
         L.vio_get_landmarks.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.vio_get_prior.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
         L.vio_get_timings.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.vio_profile_begin.argtypes = [C.c_void_p, C.c_int]
+        L.vio_profile_end.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.vio_synth_pose.argtypes = [C.POINTER(SynthConfig), C.c_uint64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vio_synth_imu.argtypes = [C.POINTER(SynthConfig), C.c_uint64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vio_synth_render_host.argtypes = [C.POINTER(SynthConfig), C.c_uint64, C.c_double, C.c_void_p, C.c_void_p]
@@ -246,6 +248,12 @@ class VioBatch:
         self._chk(self.L.vio_get_odometry(self.h, o.ctypes.data), "vio_get_odometry")
         return o
 
+    def odometry_history(self, seq=0, cap=2048):
+        o = np.zeros((cap, 11))
+        self.L.vio_get_odometry_history.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        n = self._chk(self.L.vio_get_odometry_history(self.h, seq, cap, o.ctypes.data), "vio_get_odometry_history")
+        return o[:min(n, cap)]
+
     def extrinsic(self, seq=0):
         e = np.zeros(13)
         self._chk(self.L.vio_get_extrinsic(self.h, seq, e.ctypes.data), "vio_get_extrinsic")
@@ -268,6 +276,17 @@ class VioBatch:
         J, r, x0, pres = np.zeros((n, n)), np.zeros(n), np.zeros(self.W * 7 + 17), np.zeros(self.W + 3, np.uint8)
         k = self._chk(self.L.vio_get_prior(self.h, seq, J.ctypes.data, r.ctypes.data, x0.ctypes.data, pres.ctypes.data), "vio_get_prior")
         return (J, r, x0, pres) if k else None
+
+    KERNELS = ("fe_begin", "fe_pyrdown", "fe_predict", "fe_lk", "fe_select", "fe_fast", "fe_add", "be_ingest", "be_solve", "be_marg",
+               "be_finish")
+
+    def profile_begin(self, max_steps):
+        self._chk(self.L.vio_profile_begin(self.h, max_steps), "vio_profile_begin")
+
+    def profile_end(self):
+        t = np.zeros(len(self.KERNELS))
+        n = self._chk(self.L.vio_profile_end(self.h, len(t), t.ctypes.data), "vio_profile_end")
+        return n, dict(zip(self.KERNELS, t.tolist()))
 
     def timings(self):
         t = np.zeros(8)

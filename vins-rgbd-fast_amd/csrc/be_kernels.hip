@@ -1840,6 +1840,12 @@ __global__ __launch_bounds__(256) void be_finish_kernel(Batch B) {
         od[1] = be.Ps[W][0]; od[2] = be.Ps[W][1]; od[3] = be.Ps[W][2];
         od[4] = q.w; od[5] = q.x; od[6] = q.y; od[7] = q.z;
         od[8] = be.Vs[W][0]; od[9] = be.Vs[W][1]; od[10] = be.Vs[W][2];
+        int hc = B.odom_count[s];
+        if (hc < B.hist_cap) {
+            double *hrow = B.odom_hist + ((size_t)s * B.hist_cap + hc) * 11;
+            for (int k = 0; k < 11; k++) hrow[k] = od[k];
+        }
+        B.odom_count[s] = hc + 1;
     }
 }
 

@@ -55,7 +55,12 @@ struct vio_batch {
     std::vector<double> last_imu_t;
     size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0;
     bool timing_valid = false;
+    // per-kernel event pool (vio_profile_begin / vio_profile_end)
+    std::vector<hipEvent_t> pev;
+    int prof_steps = 0, prof_cur = -1;
 };
+#define VIO_NK 11  // kernels per vio_feed: fe_begin pyrdown predict lk select fast add | be_ingest solve marg finish
+#define PEV(h, k) do { if ((h)->prof_cur >= 0 && (h)->prof_cur < (h)->prof_steps) (void)hipEventRecord((h)->pev[(size_t)(h)->prof_cur * (VIO_NK + 1) + (k)], (h)->stream); } while (0)
 
 __global__ void imu_scatter_kernel(Batch B, int total, const int *seq_of, const double *t, const double *acc, const double *gyr) {
     // samples are grouped by sequence in push order; one thread per sequence walks its run (keeps ring order)
@@ -118,6 +123,7 @@ int init_state(vio_batch *h) {
     HIPCHK(hipMemcpy(h->B.lm_free, fr.data(), fr.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(h->B.pre, 0, sizeof(PreInt) * (size_t)S * (W + 2)));
     HIPCHK(hipMemset(h->B.odom, 0, sizeof(double) * (size_t)S * 11));
+    HIPCHK(hipMemset(h->B.odom_count, 0, sizeof(int) * (size_t)S));
     h->last_imu_t.assign(S, -1e300);
     h->p_seq.clear(); h->p_t.clear(); h->p_acc.clear(); h->p_gyr.clear();
     return VIO_OK;
@@ -150,7 +156,9 @@ int launch_frontend(vio_batch *h, const uint8_t *d_gray, int publish, int gate) 
     const DevCfg &C = h->hc;
     const int S = h->S, Wd = C.c.width, Ht = C.c.height;
     hipStream_t st = h->stream;
+    PEV(h, 0);
     fe_begin_kernel<<<S, 64, 0, st>>>(h->B, h->d_stamps, gate);
+    PEV(h, 1);
     // pyramid: level 1 from the new frame (+ level-0 copy), further levels from the previous one
     {
         int sw = Wd, sh = Ht;
@@ -161,11 +169,17 @@ int launch_frontend(vio_batch *h, const uint8_t *d_gray, int publish, int gate) 
             sw = dw; sh = dh;
         }
     }
+    PEV(h, 2);
     fe_predict_kernel<<<dim3((C.NP + 255) / 256, S), 256, 0, st>>>(h->B);
+    PEV(h, 3);
     fe_lk_kernel<<<dim3(C.NP, S), 64, 0, st>>>(h->B);
+    PEV(h, 4);
     fe_select_kernel<<<S, 256, h->lds_select, st>>>(h->B, publish);
+    PEV(h, 5);
     if (publish) fe_fast_kernel<<<dim3(C.ncells, S), 256, h->lds_fast, st>>>(h->B);
+    PEV(h, 6);
     fe_add_kernel<<<S, 256, h->lds_add, st>>>(h->B, publish, gate);
+    PEV(h, 7);
     HIPCHK(hipGetLastError());
     return VIO_OK;
 }
@@ -174,9 +188,14 @@ int launch_backend(vio_batch *h, const uint16_t *d_depth) {
     const int S = h->S;
     hipStream_t st = h->stream;
     be_ingest_kernel<<<S, 256, 0, st>>>(h->B, d_depth, (size_t)C.c.width * C.c.height);
+    PEV(h, 8);
     be_solve_kernel<<<S, 256, h->lds_solve, st>>>(h->B);
+    PEV(h, 9);
     be_marg_kernel<<<S, 256, 0, st>>>(h->B);
+    PEV(h, 10);
     be_finish_kernel<<<S, 256, 0, st>>>(h->B);
+    PEV(h, 11);
+    if (h->prof_cur >= 0) h->prof_cur++;
     HIPCHK(hipGetLastError());
     return VIO_OK;
 }
@@ -299,6 +318,8 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     DA(B.imu_raw, S * C.W * 15 * 31);
     DA(B.margA, S * mq * mq); DA(B.margB, S * mq); DA(B.margV, S * n * n); DA(B.margW, S * (n + 16) * (n + 16));
     DA(B.odom, S * 11); DA(B.timings, 64);
+    B.hist_cap = 2048;
+    DA(B.odom_hist, S * (size_t)B.hist_cap * 11); DA(B.odom_count, S);
     DA(h->d_stamps, S);
 #undef DA
     if (rc == VIO_OK && hipMemcpy(B.cfg, &h->hc, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) { g_err = "cfg upload failed"; rc = VIO_EDEVICE; }
@@ -330,6 +351,7 @@ void vio_destroy(vio_batch *h) {
     if (h->d_gray_stage) (void)hipFree(h->d_gray_stage);
     if (h->d_depth_stage) (void)hipFree(h->d_depth_stage);
     if (h->d_pseq) { (void)hipFree(h->d_pseq); (void)hipFree(h->d_pt); (void)hipFree(h->d_pacc); (void)hipFree(h->d_pgyr); }
+    for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
@@ -463,6 +485,17 @@ int vio_get_odometry(vio_batch *h, double *out) {
     return VIO_OK;
 }
 
+int vio_get_odometry_history(vio_batch *h, int seq, int cap, double *out) {
+    if (!h || seq < 0 || seq >= h->S || !out) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int n = 0;
+    HIPCHK(hipMemcpy(&n, h->B.odom_count + seq, sizeof(int), hipMemcpyDeviceToHost));
+    int m = n < cap ? n : cap;
+    if (m > h->B.hist_cap) m = h->B.hist_cap;
+    if (m > 0) HIPCHK(hipMemcpy(out, h->B.odom_hist + (size_t)seq * h->B.hist_cap * 11, sizeof(double) * (size_t)m * 11, hipMemcpyDeviceToHost));
+    return n;
+}
+
 int vio_get_extrinsic(vio_batch *h, int seq, double *out13) {
     if (!h || seq < 0 || seq >= h->S || !out13) return VIO_EINVAL;
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -539,6 +572,36 @@ int vio_get_timings(vio_batch *h, int cap, double *out_ms) {
     HIPCHK(hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
     out_ms[0] = a; out_ms[1] = b; out_ms[2] = a + b;
     return 3;
+}
+
+// per-kernel HIP-event profile of the next max_steps vio_feed calls (events sit on the batch stream)
+int vio_profile_begin(vio_batch *h, int max_steps) {
+    if (!h || max_steps < 1) return VIO_EINVAL;
+    size_t need = (size_t)max_steps * (VIO_NK + 1);
+    while (h->pev.size() < need) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        h->pev.push_back(e);
+    }
+    h->prof_steps = max_steps;
+    h->prof_cur = 0;
+    return VIO_OK;
+}
+// out_ms[k] = average duration of kernel k over the recorded steps (ms); returns the number of recorded steps
+int vio_profile_end(vio_batch *h, int cap, double *out_ms) {
+    if (!h || !out_ms || cap < VIO_NK) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    int n = h->prof_cur < h->prof_steps ? h->prof_cur : h->prof_steps;
+    for (int k = 0; k < VIO_NK; k++) out_ms[k] = 0;
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < VIO_NK; k++) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, h->pev[(size_t)i * (VIO_NK + 1) + k], h->pev[(size_t)i * (VIO_NK + 1) + k + 1]));
+            out_ms[k] += ms;
+        }
+    for (int k = 0; k < VIO_NK; k++) out_ms[k] = n > 0 ? out_ms[k] / n : 0;
+    h->prof_cur = -1;
+    return n;
 }
 
 // ------------------------------------------------------------------------------------------------ stage entry points

@@ -135,6 +135,9 @@ struct Batch {
     double *margA, *margB, *margV, *margW;  // marginalisation workspaces
     // ---- outputs
     double *odom;         // [S][11]
+    double *odom_hist;    // [S][hist_cap][11]: one CSV row per processed NON_LINEAR frame (visualization.cpp:214-225)
+    int *odom_count;      // [S]
+    int hist_cap;
     float *timings;
 };
 
