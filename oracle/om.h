@@ -196,17 +196,17 @@ inline void sym_eig(Mat &A, std::vector<double> &w, Mat &V) {
     V = Mat(n, n);
     for (int i = 0; i < n; i++) V(i, i) = 1;
     for (int sweep = 0; sweep < 60; sweep++) {
-        double off = 0, diag = 0;
-        for (int i = 0; i < n; i++) {
-            diag += A(i, i) * A(i, i);
-            for (int j = i + 1; j < n; j++) off += A(i, j) * A(i, j);
-        }
-        if (off <= 1e-30 * (diag + 1e-300) || off == 0.0) break;
+        // threshold Jacobi: rotate only if |a_pq| > 1e-15 sqrt(|a_pp a_qq|) and > 1e-18 max|a_ii|; stop after a sweep without rotations
+        double dmax = 0;
+        for (int i = 0; i < n; i++) dmax = std::max(dmax, std::fabs(A(i, i)));
+        const double absfloor = 1e-18 * dmax;
+        int nrot = 0;
         for (int p = 0; p < n - 1; p++)
             for (int q = p + 1; q < n; q++) {
                 double apq = A(p, q);
-                if (apq == 0.0) continue;
                 double app = A(p, p), aqq = A(q, q);
+                if (!(std::fabs(apq) > absfloor && std::fabs(apq) > 1e-15 * std::sqrt(std::fabs(app * aqq)))) continue;
+                nrot++;
                 double tau = (aqq - app) / (2.0 * apq);
                 double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
                 double cs = 1.0 / std::sqrt(1.0 + t * t), sn = t * cs;
@@ -226,6 +226,7 @@ inline void sym_eig(Mat &A, std::vector<double> &w, Mat &V) {
                     V(k, q) = sn * vkp + cs * vkq;
                 }
             }
+        if (nrot == 0) break;
     }
     w.resize(n);
     std::vector<int> idx(n);

@@ -13,11 +13,15 @@
 
 using namespace dm;
 
+// phase timers (debug): thread 0 of sequence 0 accumulates 100 MHz wall-clock ticks into B.timings[k]
+#define PH_INIT long long ph_t0 = (s == 0 && threadIdx.x == 0) ? (long long)wall_clock64() : 0
+#define PH(k) do { if (s == 0 && threadIdx.x == 0) { long long n_ = (long long)wall_clock64(); B.timings[k] += (float)(n_ - ph_t0); ph_t0 = n_; } } while (0)
+
 namespace {
 
 struct Ctx {
     const DevCfg *C;
-    int s, W, P, LW, NL, NPR;
+    int s, W, P, LW, NL, NLs, NPR;
     BeSeq *be;
     FeSeq *fe;
     PreInt *pre;
@@ -34,7 +38,7 @@ struct Ctx {
 __device__ Ctx make_ctx(const Batch &B, int s) {
     Ctx c;
     const DevCfg &C = *B.cfg;
-    c.C = B.cfg; c.s = s; c.W = C.W; c.P = C.P; c.LW = C.LW; c.NL = C.NL; c.NPR = C.NPRIOR;
+    c.C = B.cfg; c.s = s; c.W = C.W; c.P = C.P; c.LW = C.LW; c.NL = C.NL; c.NLs = C.NL + 8; c.NPR = C.NPRIOR;
     c.be = B.be + s; c.fe = B.fe + s;
     c.pre = B.pre + (size_t)s * (C.W + 2);
     size_t o = (size_t)s * C.NL;
@@ -43,9 +47,9 @@ __device__ Ctx make_ctx(const Batch &B, int s) {
     c.lm_tmp = B.lm_tmp + o; c.lm_pidx = B.lm_pidx + o; c.lm_aidx = B.lm_aidx + o;
     c.lm_depth = B.lm_depth + o; c.feat = B.para_feat + o; c.cfeat = B.cand_feat + o;
     c.lm_obs = B.lm_obs + o * (C.W + 1) * VIO_OBS_D;
-    c.H = B.H + (size_t)s * C.LW * C.LW; c.Sc = B.Sc + (size_t)s * C.LW * C.LW; c.Hpl = B.Hpl + o * C.LW;
+    c.H = B.H + (size_t)s * C.LW * C.LW; c.Sc = B.Sc + (size_t)s * C.LW * C.LW; c.Hpl = B.Hpl + (size_t)s * (C.NL + 8) * C.LW;
     c.vec = B.vec + (size_t)s * VEC_SLOTS * C.LW;
-    c.Hll = B.Hll + o; c.gl = B.gl + o; c.lvec = B.lvec + o * 8;
+    c.Hll = B.Hll + (size_t)s * (C.NL + 8); c.gl = B.gl + (size_t)s * (C.NL + 8); c.lvec = B.lvec + (size_t)s * (C.NL + 8) * 8;
     c.nres_cap = 4 * C.NL;
     c.res = B.res + (size_t)s * c.nres_cap * 42;
     c.res_lm = B.res_lm + (size_t)s * c.nres_cap; c.res_k = B.res_k + (size_t)s * c.nres_cap;
@@ -85,24 +89,27 @@ __device__ double block_sum(double v, double *sred) {
     __syncthreads();
     return r;
 }
-__device__ int block_scan_flags(const int *flags, int n, int *offs, int *scratch) {
+__device__ int block_scan_flags(const int *flags, int n, int *offs, int *scratch /* 2*blockDim + 2 ints */) {
     int nt = blockDim.x, t = threadIdx.x;
     int chunk = (n + nt - 1) / nt;
     int b = t * chunk, e = min(n, b + chunk);
     int sum = 0;
     for (int i = b; i < e; i++) sum += flags[i];
     __syncthreads();
-    scratch[t] = sum;
+    int *cur = scratch, *nxt = scratch + nt;
+    cur[t] = sum;
     __syncthreads();
-    if (t == 0) {
-        int acc = 0;
-        for (int i = 0; i < nt; i++) { int v = scratch[i]; scratch[i] = acc; acc += v; }
-        scratch[nt] = acc;
+    for (int off = 1; off < nt; off <<= 1) {  // Hillis-Steele inclusive scan
+        int v = cur[t];
+        if (t >= off) v += cur[t - off];
+        nxt[t] = v;
+        __syncthreads();
+        int *tmp = cur; cur = nxt; nxt = tmp;
     }
-    __syncthreads();
-    int o = scratch[t];
+    int incl = cur[t];
+    int total = cur[nt - 1];
+    int o = incl - sum;
     for (int i = b; i < e; i++) { offs[i] = o; o += flags[i]; }
-    int total = scratch[nt];
     __syncthreads();
     return total;
 }
@@ -114,9 +121,39 @@ __device__ void preint_load(const PreInt &p, PreWork &w) {
     for (int i = threadIdx.x; i < 225; i += blockDim.x) { w.J[i] = p.jac[i]; w.Pm[i] = p.cov[i]; }
     __syncthreads();
 }
-__device__ void preint_store(PreInt &p, const PreWork &w) {
+// Also refreshes the whitening matrix of the IMU factor: M = chol(cov)^-1 (lower triangular), M^T M = cov^-1.
+// The reference uses LLT(cov^-1).L^T (imu_factor.h:66-69); both satisfy M^T M = cov^-1, so J^T J, J^T r and |r|^2 - the only
+// quantities the solver and the marginalisation consume - are identical up to round-off (DESIGN.md "equivalent whitening").
+__device__ void preint_store(PreInt &p, PreWork &w) {
+    const int t = threadIdx.x;
     __syncthreads();
-    for (int i = threadIdx.x; i < 225; i += blockDim.x) { p.jac[i] = w.J[i]; p.cov[i] = w.Pm[i]; }
+    for (int i = t; i < 225; i += blockDim.x) { p.jac[i] = w.J[i]; p.cov[i] = w.Pm[i]; }
+    if (t < 225) { int i = t / 15, j = t - i * 15; w.FJ[t] = 0.5 * (w.Pm[i * 15 + j] + w.Pm[j * 15 + i]); }
+    __syncthreads();
+    for (int j = 0; j < 15; j++) {
+        if (t == 0) { double d = w.FJ[j * 15 + j]; w.FJ[j * 15 + j] = (d > 0.0 && isfinite(d)) ? sqrt(d) : 0.0; }
+        __syncthreads();
+        double l = w.FJ[j * 15 + j];
+        if (t > j && t < 15) w.FJ[t * 15 + j] = l > 0.0 ? w.FJ[t * 15 + j] / l : 0.0;
+        __syncthreads();
+        if (t < 225) { int i = t / 15, k = t - i * 15; if (k > j && i >= k) w.FJ[t] -= w.FJ[i * 15 + j] * w.FJ[k * 15 + j]; }
+        __syncthreads();
+    }
+    if (t < 225) w.FP[t] = 0;
+    __syncthreads();
+    if (t < 15) {
+        double x[15];
+        bool ok = true;
+        for (int i = 0; i < 15; i++) ok = ok && w.FJ[i * 15 + i] > 0.0;
+        for (int i = 0; i < 15; i++) {
+            double sacc = (i == t) ? 1.0 : 0.0;
+            for (int k = 0; k < i; k++) sacc -= w.FJ[i * 15 + k] * x[k];
+            x[i] = ok ? sacc / w.FJ[i * 15 + i] : 0.0;
+            w.FP[i * 15 + t] = x[i];
+        }
+    }
+    __syncthreads();
+    if (t < 225) p.sqrt_info[t] = w.FP[t];
     __syncthreads();
 }
 // one propagate(dt, acc, gyr) on the LDS-resident jacobian/covariance; p's small state is updated by thread 0
@@ -191,22 +228,26 @@ __device__ void jacobi_small(double *A, double *V, int n) {
 
 // Parallel two-sided Jacobi (round-robin ordering) on a symmetric n x n matrix A (ld = n), V = eigenvectors (columns).
 // All threads of the block participate. cs/sn: LDS arrays of n/2+1 doubles; sred: blockDim doubles.
-__device__ void jacobi_block(double *A, double *V, int n, double *cs, double *sn, int *pp, int *qq, double *sred) {
+__device__ int jacobi_block(double *A, double *V, int n, int ld, double *cs, double *sn, int *pp, int *qq, double *sred) {
+    int sweeps_done = 0;
     const int t = threadIdx.x, nt = blockDim.x;
-    for (int i = t; i < n * n; i += nt) V[i] = ((i / n) == (i % n)) ? 1.0 : 0.0;
+    for (int i = t; i < n * n; i += nt) V[(i / n) * ld + (i % n)] = ((i / n) == (i % n)) ? 1.0 : 0.0;
     __syncthreads();
     const int m = (n + 1) & ~1;  // even number of players (one bye if n is odd)
     const int half = m / 2;
     for (int sweep = 0; sweep < 30; sweep++) {
-        double off = 0, dg = 0;
-        for (int i = t; i < n * n; i += nt) {
-            int r = i / n, cc = i - r * n;
-            double v = A[i];
-            if (r == cc) dg += v * v; else if (cc > r) off += v * v;
-        }
-        off = block_sum(off, sred);
-        dg = block_sum(dg, sred);
-        if (off <= 1e-30 * (dg + 1e-300) || off == 0.0) break;
+        // threshold Jacobi: a pair is rotated only if |a_pq| > 1e-15 sqrt(|a_pp a_qq|) and > 1e-18 max|a_ii|;
+        // the sweep loop ends when a whole sweep applied no rotation
+        double dmax = 0;
+        for (int i = t; i < n; i += nt) dmax = fmax(dmax, fabs(A[i * ld + i]));
+        __syncthreads();
+        sred[t] = dmax;
+        __syncthreads();
+        for (int o2 = nt >> 1; o2 > 0; o2 >>= 1) { if (t < o2) sred[t] = fmax(sred[t], sred[t + o2]); __syncthreads(); }
+        dmax = sred[0];
+        __syncthreads();
+        const double absfloor = 1e-18 * dmax;
+        double nrot = 0;
         for (int round = 0; round < m - 1; round++) {
             // chess-tournament pairing: player m-1 fixed, others rotate
             if (t < half) {
@@ -216,9 +257,10 @@ __device__ void jacobi_block(double *A, double *V, int n, double *cs, double *sn
                 int p = min(a, b), q = max(a, b);
                 double c1 = 1.0, s1 = 0.0;
                 if (q < n) {
-                    double apq = A[p * n + q];
-                    if (apq != 0.0) {
-                        double app = A[p * n + p], aqq = A[q * n + q];
+                    double apq = A[p * ld + q];
+                    double app = A[p * ld + p], aqq = A[q * ld + q];
+                    if (fabs(apq) > absfloor && fabs(apq) > 1e-15 * sqrt(fabs(app * aqq))) {
+                        nrot += 1.0;
                         double tau = (aqq - app) / (2.0 * apq);
                         double tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
                         c1 = 1.0 / sqrt(1.0 + tt * tt);
@@ -234,12 +276,12 @@ __device__ void jacobi_block(double *A, double *V, int n, double *cs, double *sn
                 int p = pp[k], q = qq[k];
                 if (p < 0 || sn[k] == 0.0) continue;
                 double c1 = cs[k], s1 = sn[k];
-                double akp = A[r * n + p], akq = A[r * n + q];
-                A[r * n + p] = c1 * akp - s1 * akq;
-                A[r * n + q] = s1 * akp + c1 * akq;
-                double vkp = V[r * n + p], vkq = V[r * n + q];
-                V[r * n + p] = c1 * vkp - s1 * vkq;
-                V[r * n + q] = s1 * vkp + c1 * vkq;
+                double akp = A[r * ld + p], akq = A[r * ld + q];
+                A[r * ld + p] = c1 * akp - s1 * akq;
+                A[r * ld + q] = s1 * akp + c1 * akq;
+                double vkp = V[r * ld + p], vkq = V[r * ld + q];
+                V[r * ld + p] = c1 * vkp - s1 * vkq;
+                V[r * ld + q] = s1 * vkp + c1 * vkq;
             }
             __syncthreads();
             // rows: A <- J^T A
@@ -248,11 +290,169 @@ __device__ void jacobi_block(double *A, double *V, int n, double *cs, double *sn
                 int p = pp[k], q = qq[k];
                 if (p < 0 || sn[k] == 0.0) continue;
                 double c1 = cs[k], s1 = sn[k];
-                double apk = A[p * n + cc], aqk = A[q * n + cc];
-                A[p * n + cc] = c1 * apk - s1 * aqk;
-                A[q * n + cc] = s1 * apk + c1 * aqk;
+                double apk = A[p * ld + cc], aqk = A[q * ld + cc];
+                A[p * ld + cc] = c1 * apk - s1 * aqk;
+                A[q * ld + cc] = s1 * apk + c1 * aqk;
             }
             __syncthreads();
+        }
+        nrot = block_sum(nrot, sred);
+        sweeps_done = sweep + 1;
+        if (nrot == 0.0) break;
+    }
+    __syncthreads();
+    return sweeps_done;
+}
+
+// Symmetric eigen-decomposition (Householder tridiagonalisation + implicit-shift QL, the algorithm class of
+// Eigen::SelfAdjointEigenSolver used at marginalization_factor.cpp:277,298).  V (n x n, ld) holds A on entry (lower
+// triangle is read) and the eigenvectors (columns) on exit; d = eigenvalues (unsorted), e = workspace; d/e in LDS.
+// The reduction is block-parallel; the QL iteration runs in one wavefront (lanes own rows of V, no block barriers).
+__device__ void sym_eig_tridiag(double *V, int n, int ld, double *d, double *e, double *gtmp, double *sred) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    for (int j = t; j < n; j += nt) d[j] = V[(n - 1) * ld + j];
+    __syncthreads();
+    for (int i = n - 1; i > 0; i--) {
+        double sc = 0;
+        for (int k = t; k < i; k += nt) sc += fabs(d[k]);
+        sc = block_sum(sc, sred);
+        if (sc == 0.0) {
+            if (t == 0) e[i] = d[i - 1];
+            __syncthreads();
+            for (int j = t; j < i; j += nt) { d[j] = V[(i - 1) * ld + j]; V[i * ld + j] = 0.0; V[j * ld + i] = 0.0; }
+            if (t == 0) d[i] = 0.0;
+            __syncthreads();
+            continue;
+        }
+        double h = 0;
+        for (int k = t; k < i; k += nt) { double v = d[k] / sc; d[k] = v; h += v * v; }
+        h = block_sum(h, sred);
+        double f = d[i - 1];
+        double g = sqrt(h);
+        if (f > 0) g = -g;
+        h -= f * g;
+        __syncthreads();
+        if (t == 0) { e[i] = sc * g; d[i - 1] = f - g; }
+        __syncthreads();
+        // e[0..i) = A_sub * d using the lower triangle; V[j][i] = d[j]
+        for (int j = t; j < i; j += nt) {
+            double acc = 0;
+            for (int k = 0; k < i; k++) acc += (k <= j ? V[j * ld + k] : V[k * ld + j]) * d[k];
+            V[j * ld + i] = d[j];
+            e[j] = acc / h;
+        }
+        __syncthreads();
+        double ff = 0;
+        for (int j = t; j < i; j += nt) ff += e[j] * d[j];
+        ff = block_sum(ff, sred);
+        double hh = ff / (h + h);
+        for (int j = t; j < i; j += nt) e[j] -= hh * d[j];
+        __syncthreads();
+        for (int w = t; w < i * i; w += nt) {
+            int k = w / i, j = w - k * i;
+            if (j <= k) V[k * ld + j] -= (d[j] * e[k] + e[j] * d[k]);
+        }
+        __syncthreads();
+        for (int j = t; j < i; j += nt) { d[j] = V[(i - 1) * ld + j]; V[i * ld + j] = 0.0; }
+        if (t == 0) d[i] = h;
+        __syncthreads();
+    }
+    // accumulate the Householder transformations
+    for (int i = 0; i < n - 1; i++) {
+        if (t == 0) { V[(n - 1) * ld + i] = V[i * ld + i]; V[i * ld + i] = 1.0; }
+        double h = d[i + 1];
+        __syncthreads();
+        if (h != 0.0) {
+            for (int k = t; k <= i; k += nt) d[k] = V[k * ld + i + 1] / h;
+            __syncthreads();
+            for (int j = t; j <= i; j += nt) {
+                double g = 0;
+                for (int k = 0; k <= i; k++) g += V[k * ld + i + 1] * V[k * ld + j];
+                gtmp[j] = g;
+            }
+            __syncthreads();
+            for (int w = t; w < (i + 1) * (i + 1); w += nt) {
+                int k = w / (i + 1), j = w - k * (i + 1);
+                V[k * ld + j] -= gtmp[j] * d[k];
+            }
+            __syncthreads();
+        }
+        for (int k = t; k <= i; k += nt) V[k * ld + i + 1] = 0.0;
+        __syncthreads();
+    }
+    for (int j = t; j < n; j += nt) { d[j] = V[(n - 1) * ld + j]; V[(n - 1) * ld + j] = 0.0; }
+    __syncthreads();
+    if (t == 0) { V[(n - 1) * ld + n - 1] = 1.0; e[0] = 0.0; }
+    __syncthreads();
+}
+
+// implicit QL on the tridiagonal (d, e) with eigenvector accumulation into V; one wavefront, lanes own rows k, k+64, ...
+__device__ void tridiag_ql_wave(double *V, int n, int ld, double *d, double *e) {
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {
+        for (int i = 1 + lane; i < n; i += 64) { double v = e[i]; __builtin_amdgcn_wave_barrier(); e[i - 1] = v; }
+        // (shifting through LDS lane-parallel: read all first, then write)
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        if (lane == 0) e[n - 1] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        double f = 0.0, tst1 = 0.0;
+        const double eps = 2.220446049250313e-16;
+        for (int l = 0; l < n; l++) {
+            tst1 = fmax(tst1, fabs(d[l]) + fabs(e[l]));
+            int m = l;
+            while (m < n) { if (fabs(e[m]) <= eps * tst1) break; m++; }
+            if (m > l) {
+                int iter = 0;
+                do {
+                    iter++;
+                    double g = d[l];
+                    double p = (d[l + 1] - g) / (2.0 * e[l]);
+                    double r = sqrt(p * p + 1.0);
+                    if (p < 0) r = -r;
+                    double dl = e[l] / (p + r), dl1 = e[l] * (p + r);
+                    double h = g - dl;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) { d[l] = dl; d[l + 1] = dl1; }
+                    for (int i = l + 2 + lane; i < n; i += 64) d[i] -= h;
+                    __builtin_amdgcn_wave_barrier();
+                    __threadfence_block();
+                    f += h;
+                    p = d[m];
+                    double c = 1.0, c2 = 1.0, c3 = 1.0, el1 = e[l + 1], s = 0.0, s2 = 0.0;
+                    for (int i = m - 1; i >= l; i--) {
+                        c3 = c2; c2 = c; s2 = s;
+                        double ei = e[i], di = d[i];
+                        g = c * ei;
+                        h = c * p;
+                        r = sqrt(p * p + ei * ei);
+                        double e_ip1 = s * r;
+                        s = ei / r;
+                        c = p / r;
+                        p = c * di - s * g;
+                        double d_ip1 = h + s * (c * g + s * di);
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane == 0) { e[i + 1] = e_ip1; d[i + 1] = d_ip1; }
+                        for (int k = lane; k < n; k += 64) {
+                            double hv = V[k * ld + i + 1], vi = V[k * ld + i];
+                            V[k * ld + i + 1] = s * vi + c * hv;
+                            V[k * ld + i] = c * vi - s * hv;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        __threadfence_block();
+                    }
+                    p = -s * s2 * c3 * el1 * e[l] / dl1;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) { e[l] = s * p; d[l] = c * p; }
+                    __builtin_amdgcn_wave_barrier();
+                    __threadfence_block();
+                } while (fabs(e[l]) > eps * tst1 && iter < 60);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) { d[l] = d[l] + f; e[l] = 0.0; }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
         }
     }
     __syncthreads();
@@ -308,6 +508,198 @@ __device__ void chol_solve_wave(const double *L, int n, int ld, double *xs) {
     __syncthreads();
 }
 
+// ------------------------------------------------------------------ dense linear algebra on the scaled system
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+#define VIO_LWMAX 336  // >= LW for W = 20
+
+// lower-triangle tile index -> (ti, tj), ti >= tj
+__device__ __forceinline__ void tri_decode(int idx, int &ti, int &tj) {
+    int r = 0;
+    while (idx >= r + 1) { idx -= r + 1; r++; }
+    ti = r; tj = idx;
+}
+
+// S = Hs + mu*diag(dgp^2) - sum_k (Ws[k][:] * inv[k])^T Ws[k][:]   (lower tiles only), v_mfma_f64_16x16x4_f64.
+// Hs: scaled H (ld), Ws: scaled landmark coupling rows (ld), Kpad rows (multiple of 4, rows >= Fa are zero), inv[k] = 1/hllr[k].
+__device__ void schur_mfma(const double *Hs, const double *Ws, const double *inv, const double *dgp, const double *sp, double mu,
+                           int Kpad, int n /*multiple of 16*/, int ld, double *Sc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nb = n >> 4, ntile = nb * (nb + 1) / 2;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int tile = wave; tile < ntile; tile += nw) {
+        int ti, tj;
+        tri_decode(tile, ti, tj);
+        v4f64 acc;
+        for (int r = 0; r < 4; r++) {
+            int row = 16 * ti + lk + 4 * r, col = 16 * tj + li;
+            double v = Hs[(size_t)row * ld + col];
+            if (row == col) { v += mu * dgp[row] * dgp[row]; if (sp[row] == 0.0) v = 1.0; }
+            acc[r] = v;
+        }
+        const double *wa = Ws + 16 * ti + li, *wb = Ws + 16 * tj + li;
+        for (int k0 = 0; k0 < Kpad; k0 += 4) {
+            int kk = k0 + lk;
+            double a = -(wa[(size_t)kk * ld] * inv[kk]);
+            double b = wb[(size_t)kk * ld];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        for (int r = 0; r < 4; r++) Sc[(size_t)(16 * ti + lk + 4 * r) * ld + 16 * tj + li] = acc[r];
+    }
+    __syncthreads();
+}
+
+// Blocked (16) right-looking Cholesky of the lower triangle of A (n x n, n multiple of 16): diagonal block by one
+// wavefront in LDS, panel solve one row per thread, trailing update L21 L21^T on the FP64 matrix cores.
+__device__ bool chol_blocked(double *A, int n, int ld, int *sh_flag) {
+    __shared__ double Lpp[256];
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    const int nb = n >> 4;
+    if (t == 0) *sh_flag = 1;
+    __syncthreads();
+    for (int p = 0; p < nb; p++) {
+        const int o = 16 * p;
+        if (t < 256) Lpp[t] = A[(size_t)(o + (t >> 4)) * ld + o + (t & 15)];
+        __syncthreads();
+        if (wave == 0) {
+            double *L = Lpp;
+            bool ok = true;
+            for (int j = 0; j < 16 && ok; j++) {
+                double d = L[j * 16 + j];
+                if (!(d > 0.0) || !isfinite(d)) { ok = false; break; }
+                double l = sqrt(d);
+                if (lane > j && lane < 16) L[lane * 16 + j] = L[lane * 16 + j] / l;
+                if (lane == j) L[j * 16 + j] = l;
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+                for (int q = lane; q < 256; q += 64) {
+                    int i = q >> 4, k = q & 15;
+                    if (k > j && i >= k) L[q] = L[q] - L[i * 16 + j] * L[k * 16 + j];
+                }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+            }
+            if (!ok && lane == 0) *sh_flag = 0;
+        }
+        __syncthreads();
+        if (!*sh_flag) return false;
+        if (t < 256) { int i = t >> 4, k = t & 15; if (k <= i) A[(size_t)(o + i) * ld + o + k] = Lpp[t]; }
+        for (int r = o + 16 + t; r < n; r += nt) {
+            double x[16];
+            double *row = A + (size_t)r * ld + o;
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) {
+                double s = row[cc];
+#pragma unroll
+                for (int k = 0; k < cc; k++) s -= x[k] * Lpp[cc * 16 + k];
+                x[cc] = s / Lpp[cc * 16 + cc];
+            }
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) row[cc] = x[cc];
+        }
+        __syncthreads();
+        const int m = nb - 1 - p, ntile = m * (m + 1) / 2;
+        const int li = lane & 15, lk = lane >> 4;
+        for (int tile = wave; tile < ntile; tile += nw) {
+            int ti, tj;
+            tri_decode(tile, ti, tj);
+            ti += p + 1; tj += p + 1;
+            v4f64 acc;
+            for (int r = 0; r < 4; r++) acc[r] = A[(size_t)(16 * ti + lk + 4 * r) * ld + 16 * tj + li];
+            const double *pa = A + (size_t)(16 * ti + li) * ld + o, *pb = A + (size_t)(16 * tj + li) * ld + o;
+            for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * kk + lk], pb[4 * kk + lk], acc, 0, 0, 0);
+            for (int r = 0; r < 4; r++) A[(size_t)(16 * ti + lk + 4 * r) * ld + 16 * tj + li] = acc[r];
+        }
+        __syncthreads();
+    }
+    return true;
+}
+// Solve L L^T x = b in place (xs in LDS), block-wise: 16x16 triangular solves by one wavefront, updates by all threads.
+__device__ void chol_solve_blocked(const double *L, int n, int ld, double *xs) {
+    __shared__ double Lpp[256];
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6;
+    const int nb = n >> 4;
+    for (int p = 0; p < nb; p++) {  // forward: L y = b
+        const int o = 16 * p;
+        if (t < 256) Lpp[t] = L[(size_t)(o + (t >> 4)) * ld + o + (t & 15)];
+        __syncthreads();
+        if (wave == 0) {
+            double *x = xs;
+            for (int j = 0; j < 16; j++) {
+                double xj = x[o + j] / Lpp[j * 16 + j];
+                __builtin_amdgcn_wave_barrier();
+                if (lane == j) x[o + j] = xj;
+                if (lane > j && lane < 16) x[o + lane] = x[o + lane] - Lpp[lane * 16 + j] * xj;
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+            }
+        }
+        __syncthreads();
+        for (int r = o + 16 + t; r < n; r += nt) {
+            const double *row = L + (size_t)r * ld + o;
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) s += row[k] * xs[o + k];
+            xs[r] -= s;
+        }
+        __syncthreads();
+    }
+    for (int p = nb - 1; p >= 0; p--) {  // backward: L^T x = y
+        const int o = 16 * p;
+        if (t < 256) Lpp[t] = L[(size_t)(o + (t >> 4)) * ld + o + (t & 15)];
+        __syncthreads();
+        if (wave == 0) {
+            double *x = xs;
+            for (int j = 15; j >= 0; j--) {
+                double xj = x[o + j] / Lpp[j * 16 + j];
+                __builtin_amdgcn_wave_barrier();
+                if (lane == j) x[o + j] = xj;
+                if (lane < j) x[o + lane] = x[o + lane] - Lpp[j * 16 + lane] * xj;
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+            }
+        }
+        __syncthreads();
+        for (int r = t; r < o; r += nt) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) s += L[(size_t)(o + k) * ld + r] * xs[o + k];
+            xs[r] -= s;
+        }
+        __syncthreads();
+    }
+}
+
+// out[a] = sum_b M[b][a] * v[b] for a < n (M symmetric or "column sum" of a row-major matrix with nrows rows), split over
+// blockDim/256 row groups and combined through LDS part[(blockDim/256)*VIO_LWMAX]
+__device__ void colsum(const double *M, int ld, int nrows, const double *v, int n, double *out) {
+    __shared__ double part[4 * VIO_LWMAX];
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int groups = nt >> 8, g = t >> 8, a0 = t & 255;
+    for (int a = a0; a < n; a += 256) {
+        double s = 0;
+        for (int b = g; b < nrows; b += groups) s += M[(size_t)b * ld + a] * v[b];
+        part[g * VIO_LWMAX + a] = s;
+    }
+    __syncthreads();
+    for (int a = t; a < n; a += nt) {
+        double s = 0;
+        for (int q = 0; q < groups; q++) s += part[q * VIO_LWMAX + a];
+        out[a] = s;
+    }
+    __syncthreads();
+}
+// out[k] = sum_a M[k][a] * v[a], one wavefront per row
+__device__ void rowdot(const double *M, int ld, int nrows, const double *v, int n, double *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int k = wave; k < nrows; k += nw) {
+        double s = 0;
+        for (int a = lane; a < n; a += 64) s += M[(size_t)k * ld + a] * v[a];
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) out[k] = s;
+    }
+    __syncthreads();
+}
+
 // stable compaction of the landmark order list; flags[k] = keep. Freed slots go back to the free stack.
 __device__ void lm_compact(Ctx &c, int *flags, int *offs, int *scratch) {
     int n = c.be->n_lm;
@@ -339,7 +731,7 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
     const int W = c.W;
     __shared__ int sh_i[8];
     __shared__ double sh_d[8];
-    __shared__ int scratch[260];
+    __shared__ int scratch[2 * 256 + 8];
     __shared__ double sred[256];
     __shared__ PreWork pw;
     if (t == 0) { be.do_solve = 0; be.do_marg = 0; be.processed = 0; }
@@ -668,7 +1060,7 @@ __device__ double evaluate(const Ctx &c, const Params &X, const double *feat, bo
         bf::imu_raw_residual(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], raw);
         for (int r = 0; r < 15; r++) {
             double sacc = 0;
-            for (int k = 0; k < 15; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k];
+            for (int k = 0; k <= r; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k];
             out[r * 31 + 30] = sacc;
             cost += 0.5 * sacc * sacc;
         }
@@ -743,7 +1135,7 @@ __device__ void assemble(const Ctx &c, const Params &X, int nres, int Fa, const 
         const PreInt &p = c.pre[be.pre_idx[i + 1]];
         const double *raw = c.imu_raw + (size_t)i * 15 * 31;
         double sacc = 0;
-        for (int k = r; k < 15; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k * 31 + col];
+        for (int k = 0; k <= r; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k * 31 + col];
         c.pairblk[w] = sacc;  // temporary home of the whitened Jacobians (pairblk is rebuilt afterwards)
     }
     __syncthreads();
@@ -851,7 +1243,7 @@ __device__ void assemble(const Ctx &c, const Params &X, int nres, int Fa, const 
 
 }  // namespace
 
-__global__ __launch_bounds__(256) void be_solve_kernel(Batch B) {
+__global__ __launch_bounds__(1024) void be_solve_kernel(Batch B) {
     const int s = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
     Ctx c = make_ctx(B, s);
     const DevCfg &C = *B.cfg;
@@ -860,15 +1252,17 @@ __global__ __launch_bounds__(256) void be_solve_kernel(Batch B) {
     if (!be.do_solve) return;
     const int W = c.W, P = c.P, LW = c.LW, W1 = W + 1;
     __shared__ Params X, Xc;
-    __shared__ double sred[256];
+    __shared__ double sred[1024];
     __shared__ double sdx[6 * VIO_MAXW + 16], srp[6 * VIO_MAXW + 16];
-    __shared__ int scratch[260];
+    __shared__ int scratch[2 * 1024 + 8];
     __shared__ int sh_i[8];
     __shared__ double sh_d[8];
     __shared__ PreWork pw;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *xs = (double *)smem;  // LW doubles: triangular-solve workspace
 
+    PH_INIT;
+    const long long ts0 = wall_clock64();
     // ---- static initialisation extras (estimator.cpp:266-283): solveGyroscopeBias + repropagate
     if (be.solver_flag == 0) {
         if (t == 0) {
@@ -940,10 +1334,12 @@ __global__ __launch_bounds__(256) void be_solve_kernel(Batch B) {
         X.ex[3] = q.x; X.ex[4] = q.y; X.ex[5] = q.z; X.ex[6] = q.w;
         X.td = be.td;
     }
+    PH(0);
     // ---- landmark indexing: in-problem (para_Feature index), variable landmarks, residual list
     int nlm = be.n_lm;
     int *tmpA = c.pair_list, *tmpB = c.pair_list + c.NL;       // scan temporaries (pair_list proper is built afterwards)
     int *alist = c.pair_list + c.nres_cap - c.NL;              // variable-landmark slots, kept for the whole solve
+    int *plist = c.pair_list + c.nres_cap - 2 * c.NL;          // in-problem landmark slots in list order
     __syncthreads();
     for (int k = t; k < nlm; k += nt) tmpA[k] = in_problem(c, c.lm_order[k]) ? 1 : 0;
     __syncthreads();
@@ -951,7 +1347,7 @@ __global__ __launch_bounds__(256) void be_solve_kernel(Batch B) {
     for (int k = t; k < nlm; k += nt) {
         int slot = c.lm_order[k];
         c.lm_pidx[slot] = tmpA[k] ? tmpB[k] : -1;
-        if (tmpA[k]) c.feat[tmpB[k]] = 1.0 / c.lm_depth[slot];
+        if (tmpA[k]) { c.feat[tmpB[k]] = 1.0 / c.lm_depth[slot]; plist[tmpB[k]] = slot; }
     }
     __syncthreads();
     // variable landmarks (not SetParameterBlockConstant): estimator.cpp:1278-1298
@@ -981,14 +1377,23 @@ __global__ __launch_bounds__(256) void be_solve_kernel(Batch B) {
             if (r0 + q < nres) { c.res_lm[r0 + q] = slot; c.res_k[r0 + q] = q + 1; }
     }
     __syncthreads();
-    // frame-pair lists (deterministic order): one thread per pair walks the residual list
+    PH(1);
+    // frame-pair lists in deterministic (landmark list) order: one wavefront per frame pair walks the in-problem landmarks
     {
-        for (int p = t; p < W1 * W1; p += nt) {
+        const int lane = t & 63, wave = t >> 6, nw = nt >> 6;
+        for (int p = t; p <= W1 * W1; p += nt) c.pair_start[p] = 0;
+        __syncthreads();
+        for (int p = wave; p < W1 * W1; p += nw) {
             int i = p / W1, j = p - i * W1;
+            if (!(i < j)) continue;
             int cnt = 0;
-            if (i < j)
-                for (int r = 0; r < nres; r++) { int slot = c.res_lm[r]; if (c.lm_start[slot] == i && c.res_k[r] == j - i) cnt++; }
-            c.pair_start[p] = cnt;
+            for (int k0 = 0; k0 < F; k0 += 64) {
+                int k = k0 + lane;
+                bool hit = false;
+                if (k < F) { int slot = plist[k]; hit = c.lm_start[slot] == i && c.lm_nobs[slot] > j - i && c.lm_tmp[slot] + (j - i - 1) < nres; }
+                cnt += __popcll(__ballot(hit));
+            }
+            if (lane == 0) c.pair_start[p] = cnt;
         }
         __syncthreads();
         if (t == 0) {
@@ -997,14 +1402,23 @@ __global__ __launch_bounds__(256) void be_solve_kernel(Batch B) {
             c.pair_start[W1 * W1] = acc;
         }
         __syncthreads();
-        for (int p = t; p < W1 * W1; p += nt) {
+        for (int p = wave; p < W1 * W1; p += nw) {
             int i = p / W1, j = p - i * W1;
             if (!(i < j)) continue;
             int o = c.pair_start[p];
-            for (int r = 0; r < nres; r++) { int slot = c.res_lm[r]; if (c.lm_start[slot] == i && c.res_k[r] == j - i) c.pair_list[o++] = r; }
+            for (int k0 = 0; k0 < F; k0 += 64) {
+                int k = k0 + lane;
+                bool hit = false;
+                int r = 0;
+                if (k < F) { int slot = plist[k]; r = c.lm_tmp[slot] + (j - i - 1); hit = c.lm_start[slot] == i && c.lm_nobs[slot] > j - i && r < nres; }
+                unsigned long long m = __ballot(hit);
+                if (hit) c.pair_list[o + __popcll(m & ((1ULL << lane) - 1ULL))] = r;
+                o += __popcll(m);
+            }
         }
         __syncthreads();
     }
+    PH(2);
     // prior_H = J^T J ; IMU sqrt_info
     const int n = c.NPR;
     if (be.has_prior) {
@@ -1015,7 +1429,6 @@ __global__ __launch_bounds__(256) void be_solve_kernel(Batch B) {
             c.prior_H[w] = sacc;
         }
     }
-    for (int j = 1 + t; j <= W; j += nt) { PreInt &p = c.pre[be.pre_idx[j]]; bf::imu_sqrt_info(p.cov, p.sqrt_info); }
     // constness (estimator.cpp:1187-1212)
     if (t == 0) {
         double v0 = nrm(ld3(be.Vs[0]));
@@ -1033,42 +1446,28 @@ __global__ __launch_bounds__(256) void be_solve_kernel(Batch B) {
 
     // vec slots
     double *g = c.vec, *sp = c.vec + 1 * LW, *dgp = c.vec + 2 * LW, *gradp = c.vec + 3 * LW, *gnp = c.vec + 4 * LW, *stp = c.vec + 5 * LW,
-           *gs = c.vec + 6 * LW, *tmpv = c.vec + 7 * LW, *delta = c.vec + 8 * LW;
-    double *sl = c.lvec, *dgl = c.lvec + c.NL, *gradl = c.lvec + 2 * c.NL, *gnl = c.lvec + 3 * c.NL, *stl = c.lvec + 4 * c.NL,
-           *hllr = c.lvec + 5 * c.NL, *gls = c.lvec + 6 * c.NL, *Hlls = c.lvec + 7 * c.NL;
+           *gs = c.vec + 6 * LW, *tmpv = c.vec + 7 * LW, *delta = c.vec + 8 * LW, *sgp = c.vec + 9 * LW;
+    double *sl = c.lvec, *dgl = c.lvec + c.NLs, *gradl = c.lvec + 2 * c.NLs, *gnl = c.lvec + 3 * c.NLs, *stl = c.lvec + 4 * c.NLs,
+           *inv = c.lvec + 5 * c.NLs, *gls = c.lvec + 6 * c.NLs, *Hlls = c.lvec + 7 * c.NLs;
+    double *tmpl = c.gl;  // gl is consumed by scale_system; reused as a landmark-length temporary afterwards
+    const int Kpad = (Fa + 3) & ~3;
 
+    PH(3);
     double cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp);
+    PH(4);
     assemble(c, X, nres, Fa, alist, srp);
+    PH(5);
     if (t == 0) be.initial_cost = cost;
-    // inactive tangent dims: remove their rows/columns
-    auto mask_inactive = [&]() {
-        for (int w = t; w < P * 7; w += nt) {
-            int r = w / 7, d = w - r * 7;
-            int col = oE + d;
-            bool off = d < 6 ? !ex_active : !td_active;
-            if (off) { c.H[r * LW + col] = 0; c.H[col * LW + r] = 0; }
-        }
-        if (t < 7) { bool off = t < 6 ? !ex_active : !td_active; if (off) g[oE + t] = 0; }
-        for (int w = t; w < Fa * 7; w += nt) {
-            int ka = w / 7, d = w - ka * 7;
-            bool off = d < 6 ? !ex_active : !td_active;
-            if (off) c.Hpl[(size_t)ka * LW + oE + d] = 0;
-        }
-        __syncthreads();
-    };
-    mask_inactive();
-    // Jacobi scaling (once): 1/(1+||J_j||)
-    for (int a = t; a < P; a += nt) {
-        bool act = a < oE ? true : (a < oT ? ex_active != 0 : td_active != 0);
+    // Jacobi scaling (once): 1/(1+||J_j||); constant blocks (ex / td when not estimated) get scale 0 = removed from the problem
+    for (int a = t; a < LW; a += nt) {
+        bool act = a < P && (a < oE ? true : (a < oT ? ex_active != 0 : td_active != 0));
         sp[a] = act ? 1.0 / (1.0 + sqrt(c.H[a * LW + a])) : 0.0;
     }
-    for (int k = t; k < Fa; k += nt) sl[k] = 1.0 / (1.0 + sqrt(c.Hll[k]));
+    for (int k = t; k < Kpad; k += nt) sl[k] = k < Fa ? 1.0 / (1.0 + sqrt(c.Hll[k])) : 0.0;
     __syncthreads();
-
-    double radius = 1e4, mu = 1e-8, alpha = 0, dogleg_norm = 0;
-    bool reuse = false, need_eval = false;
-    int invalid = 0;
-    auto gmax = [&]() {
+    // gradient max-norm over the active variables (unscaled), then scale the system in place:
+    // H <- S H S, Hpl <- Sl Hpl S, gs = S g, gls = Sl gl, Hlls = Sl^2 Hll
+    auto gmax_and_scale = [&]() -> double {
         double m = 0;
         for (int a = t; a < P; a += nt) m = fmax(m, sp[a] != 0.0 ? fabs(g[a]) : 0.0);
         for (int k = t; k < Fa; k += nt) m = fmax(m, fabs(c.gl[k]));
@@ -1078,89 +1477,83 @@ __global__ __launch_bounds__(256) void be_solve_kernel(Batch B) {
         for (int off = nt >> 1; off > 0; off >>= 1) { if (t < off) sred[t] = fmax(sred[t], sred[t + off]); __syncthreads(); }
         double r = sred[0];
         __syncthreads();
+        for (int w = t; w < LW * LW; w += nt) { int a = w / LW, b = w - a * LW; c.H[w] = (a < P && b < P) ? sp[a] * sp[b] * c.H[w] : 0.0; }
+        for (int w = t; w < Kpad * LW; w += nt) { int k = w / LW, a = w - k * LW; c.Hpl[w] = (k < Fa) ? sl[k] * sp[a] * c.Hpl[w] : 0.0; }
+        for (int a = t; a < LW; a += nt) gs[a] = a < P ? sp[a] * g[a] : 0.0;
+        for (int k = t; k < Kpad; k += nt) { gls[k] = k < Fa ? sl[k] * c.gl[k] : 0.0; Hlls[k] = k < Fa ? sl[k] * sl[k] * c.Hll[k] : 0.0; }
+        __syncthreads();
         return r;
     };
+
+    double radius = 1e4, mu = 1e-8, alpha = 0, dogleg_norm = 0;
+    bool reuse = false, need_eval = false;
+    int invalid = 0;
     int iters_done = 0, succ = 0;
-    if (gmax() > 1e-10)
+    if (gmax_and_scale() > 1e-10)
     for (int iter = 1; iter <= cfg.max_iterations; iter++) {
         iters_done = iter;
         if (!reuse) {
             if (need_eval) {
+                PH(13);
                 cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp);
+                PH(4);
                 assemble(c, X, nres, Fa, alist, srp);
-                mask_inactive();
+                PH(5);
                 need_eval = false;
-                if (gmax() <= 1e-10) { iters_done = iter - 1; break; }
+                if (gmax_and_scale() <= 1e-10) { iters_done = iter - 1; break; }
+                PH(6);
             }
             // scaled gradient / diagonal (DoglegStrategy::ComputeStep)
-            for (int a = t; a < P; a += nt) {
-                double hs = sp[a] * sp[a] * c.H[a * LW + a];
-                gs[a] = sp[a] * g[a];
+            for (int a = t; a < LW; a += nt) {
+                double hs = c.H[a * LW + a];
                 dgp[a] = sqrt(fmin(fmax(hs, 1e-6), 1e32));
                 gradp[a] = gs[a] / dgp[a];
+                sgp[a] = gradp[a] / dgp[a];
             }
-            for (int k = t; k < Fa; k += nt) {
-                Hlls[k] = sl[k] * sl[k] * c.Hll[k];
-                gls[k] = sl[k] * c.gl[k];
+            for (int k = t; k < Kpad; k += nt) {
                 dgl[k] = sqrt(fmin(fmax(Hlls[k], 1e-6), 1e32));
                 gradl[k] = gls[k] / dgl[k];
             }
             __syncthreads();
-            // Cauchy point
+            // Cauchy point: alpha = |grad|^2 / |J D^-1 grad|^2
+            colsum(c.H, LW, P, sgp, P, tmpv);          // Hs * sg
+            rowdot(c.Hpl, LW, Fa, sgp, P, tmpl);              // Ws * sg_p
             double g2 = 0, jg2 = 0;
-            for (int a = t; a < P; a += nt) {
-                g2 += gradp[a] * gradp[a];
-                double sga = gradp[a] / dgp[a];
-                double sacc = 0;
-                for (int b = 0; b < P; b++) sacc += sp[a] * sp[b] * c.H[a * LW + b] * (gradp[b] / dgp[b]);
-                jg2 += sga * sacc;
-            }
+            for (int a = t; a < P; a += nt) { g2 += gradp[a] * gradp[a]; jg2 += sgp[a] * tmpv[a]; }
             for (int k = t; k < Fa; k += nt) {
-                g2 += gradl[k] * gradl[k];
                 double sgl = gradl[k] / dgl[k];
-                double sacc = 0;
-                for (int a = 0; a < P; a++) sacc += sl[k] * sp[a] * c.Hpl[(size_t)k * LW + a] * (gradp[a] / dgp[a]);
-                jg2 += 2.0 * sgl * sacc + sgl * sgl * Hlls[k];
+                g2 += gradl[k] * gradl[k];
+                jg2 += 2.0 * sgl * tmpl[k] + sgl * sgl * Hlls[k];
             }
             g2 = block_sum(g2, sred);
             jg2 = block_sum(jg2, sred);
             alpha = g2 / jg2;
-            // Gauss-Newton step via the landmark Schur complement, regularised by mu * D^2
+            PH(7);
+            // Gauss-Newton step via the landmark Schur complement (FP64 matrix cores), regularised by mu * D^2
             bool ok = false;
             while (mu < 1.0) {
-                for (int k = t; k < Fa; k += nt) hllr[k] = Hlls[k] + mu * dgl[k] * dgl[k];
+                for (int k = t; k < Kpad; k += nt) inv[k] = k < Fa ? 1.0 / (Hlls[k] + mu * dgl[k] * dgl[k]) : 0.0;
                 __syncthreads();
-                for (int w = t; w < P * P; w += nt) {
-                    int a = w / P, b = w - a * P;
-                    if (b > a) continue;
-                    double sacc = sp[a] * sp[b] * c.H[a * LW + b];
-                    if (a == b) { sacc += mu * dgp[a] * dgp[a]; if (sp[a] == 0.0) sacc = 1.0; }
-                    double sub_ = 0;
-                    double fa = sp[a], fb = sp[b];
-                    for (int k = 0; k < Fa; k++) {
-                        double wa = c.Hpl[(size_t)k * LW + a], wb = c.Hpl[(size_t)k * LW + b];
-                        sub_ += (sl[k] * fa * wa) * (sl[k] * fb * wb) / hllr[k];
-                    }
-                    c.Sc[a * LW + b] = sacc - sub_;
-                }
-                for (int a = t; a < P; a += nt) {
-                    double sacc = gs[a];
-                    for (int k = 0; k < Fa; k++) sacc -= (sl[k] * sp[a] * c.Hpl[(size_t)k * LW + a]) / hllr[k] * gls[k];
-                    xs[a] = sacc;
-                }
+                schur_mfma(c.H, c.Hpl, inv, dgp, sp, mu, Kpad, LW, LW, c.Sc);
+                PH(8);
+                for (int k = t; k < Kpad; k += nt) tmpl[k] = inv[k] * gls[k];
                 __syncthreads();
-                if (chol_block(c.Sc, P, LW, &sh_i[2])) {
-                    chol_solve_wave(c.Sc, P, LW, xs);
+                colsum(c.Hpl, LW, Fa, tmpl, P, tmpv);  // Ws^T (gls / hll)
+                for (int a = t; a < LW; a += nt) xs[a] = a < P ? gs[a] - tmpv[a] : 0.0;
+                __syncthreads();
+                bool chol_ok = chol_blocked(c.Sc, LW, LW, &sh_i[2]);
+                PH(9);
+                if (chol_ok) {
+                    chol_solve_blocked(c.Sc, LW, LW, xs);
+                    PH(10);
                     double bad = 0;
                     for (int a = t; a < P; a += nt) if (!isfinite(xs[a])) bad += 1;
                     bad = block_sum(bad, sred);
                     if (bad == 0) {
-                        for (int a = t; a < P; a += nt) gnp[a] = -xs[a] * dgp[a];
-                        for (int k = t; k < Fa; k += nt) {
-                            double sacc = gls[k];
-                            for (int a = 0; a < P; a++) sacc -= sl[k] * sp[a] * c.Hpl[(size_t)k * LW + a] * xs[a];
-                            gnl[k] = -(sacc / hllr[k]) * dgl[k];
-                        }
+                        for (int a = t; a < LW; a += nt) { gnp[a] = -xs[a] * dgp[a]; tmpv[a] = xs[a]; }
+                        __syncthreads();
+                        rowdot(c.Hpl, LW, Fa, tmpv, P, tmpl);  // Ws * y_p
+                        for (int k = t; k < Fa; k += nt) gnl[k] = -((gls[k] - tmpl[k]) * inv[k]) * dgl[k];
                         __syncthreads();
                         ok = true;
                         break;
@@ -1192,27 +1585,20 @@ __global__ __launch_bounds__(256) void be_solve_kernel(Batch B) {
             dogleg_norm = -1;
         }
         double n2 = 0;
-        for (int a = t; a < P; a += nt) { double v = ca * gradp[a] + cb * gnp[a]; n2 += v * v; stp[a] = v / dgp[a]; }
-        for (int k = t; k < Fa; k += nt) { double v = ca * gradl[k] + cb * gnl[k]; n2 += v * v; stl[k] = v / dgl[k]; }
+        for (int a = t; a < LW; a += nt) { double v = ca * gradp[a] + cb * gnp[a]; if (a < P) n2 += v * v; stp[a] = a < P ? v / dgp[a] : 0.0; }
+        for (int k = t; k < Kpad; k += nt) { double v = k < Fa ? ca * gradl[k] + cb * gnl[k] : 0.0; n2 += v * v; stl[k] = k < Fa ? v / dgl[k] : 0.0; }
         n2 = block_sum(n2, sred);
         if (dogleg_norm < 0) dogleg_norm = sqrt(n2);
-        // model cost change
+        // model cost change = -(step^T g' + 1/2 step^T H' step)
+        colsum(c.H, LW, P, stp, P, tmpv);
+        rowdot(c.Hpl, LW, Fa, stp, P, tmpl);
         double lin = 0, quad = 0;
-        for (int a = t; a < P; a += nt) {
-            lin += stp[a] * gs[a];
-            double sacc = 0;
-            for (int b = 0; b < P; b++) sacc += sp[a] * sp[b] * c.H[a * LW + b] * stp[b];
-            quad += stp[a] * sacc;
-        }
-        for (int k = t; k < Fa; k += nt) {
-            lin += stl[k] * gls[k];
-            double sacc = 0;
-            for (int a = 0; a < P; a++) sacc += sl[k] * sp[a] * c.Hpl[(size_t)k * LW + a] * stp[a];
-            quad += 2.0 * stl[k] * sacc + stl[k] * stl[k] * Hlls[k];
-        }
+        for (int a = t; a < P; a += nt) { lin += stp[a] * gs[a]; quad += stp[a] * tmpv[a]; }
+        for (int k = t; k < Fa; k += nt) { lin += stl[k] * gls[k]; quad += 2.0 * stl[k] * tmpl[k] + stl[k] * stl[k] * Hlls[k]; }
         lin = block_sum(lin, sred);
         quad = block_sum(quad, sred);
         double model_change = -(lin + 0.5 * quad);
+        PH(11);
         if (!(model_change > 0)) {
             if (++invalid >= 5) break;
             mu *= 10.0;
@@ -1244,6 +1630,7 @@ __global__ __launch_bounds__(256) void be_solve_kernel(Batch B) {
         }
         __syncthreads();
         double ccost = evaluate(c, Xc, c.cfeat, false, nres, sred, sdx, srp);
+        PH(12);
         // parameter tolerance
         double xn = 0, dn = 0;
         if (t <= W) {
@@ -1279,9 +1666,11 @@ __global__ __launch_bounds__(256) void be_solve_kernel(Batch B) {
         }
     }
     __syncthreads();
+    PH(13);
     // ---- write back flat parameters + double2vector (estimator.cpp:985-1111)
     if (t == 0) {
         be.final_cost = cost; be.iterations = iters_done; be.successful = succ;
+        be.dbg[4] = (int)(wall_clock64() - ts0);
         v3 origin_R0 = R2ypr(ldm(be.Rs[0]));
         v3 origin_P0 = ld3(be.Ps[0]);
         quat q0 = mkq(X.pose[6], X.pose[3], X.pose[4], X.pose[5]);
@@ -1338,11 +1727,13 @@ __global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
     __shared__ double sdx[6 * VIO_MAXW + 16], srp[6 * VIO_MAXW + 16];
     __shared__ double cs[VIO_MAXW * 3 + 10], sn[VIO_MAXW * 3 + 10];
     __shared__ int pp[VIO_MAXW * 3 + 10], qq[VIO_MAXW * 3 + 10];
-    __shared__ int scratch[260];
+    __shared__ int scratch[2 * 256 + 8];
     __shared__ double A15[225], V15[225], Pinv[225];
     __shared__ int newpresent[VIO_MAXW + 3];
     const bool second_new = be.marginalization_flag != 0;
     if (second_new && !(be.has_prior && be.prior_present[W - 1])) return;
+    PH_INIT;
+    const long long tk0 = wall_clock64();
     // vector2double
     if (t <= W) {
         int i = t;
@@ -1411,6 +1802,7 @@ __global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
         }
         __syncthreads();
     }
+    PH(16);
     if (!second_new) {
         // IMU factor (0,1)
         PreInt &p1 = c.pre[be.pre_idx[1]];
@@ -1418,14 +1810,13 @@ __global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
             double *Jw = c.pairblk;         // 15x30 whitened
             double *raw = c.imu_raw;        // 15x31
             if (t == 0) {
-                bf::imu_sqrt_info(p1.cov, p1.sqrt_info);
                 double r15[15], Jr[450];
                 v3 G = ld3(be.g);
                 bf::imu_raw_residual(p1, G, &X.pose[0], &X.sb[0], &X.pose[7], &X.sb[9], r15);
                 bf::imu_raw_jacobian(p1, G, &X.pose[0], &X.sb[0], &X.pose[7], &X.sb[9], Jr);
                 for (int r = 0; r < 15; r++) {
                     double sacc = 0;
-                    for (int k = 0; k < 15; k++) sacc += p1.sqrt_info[r * 15 + k] * r15[k];
+                    for (int k = 0; k <= r; k++) sacc += p1.sqrt_info[r * 15 + k] * r15[k];
                     raw[r * 31 + 30] = sacc;
                     for (int q = 0; q < 30; q++) raw[r * 31 + q] = Jr[r * 30 + q];
                 }
@@ -1434,7 +1825,7 @@ __global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
             for (int w = t; w < 450; w += nt) {
                 int r = w / 30, col = w - r * 30;
                 double sacc = 0;
-                for (int k = r; k < 15; k++) sacc += p1.sqrt_info[r * 15 + k] * raw[k * 31 + col];
+                for (int k = 0; k <= r; k++) sacc += p1.sqrt_info[r * 15 + k] * raw[k * 31 + col];
                 Jw[w] = sacc;
             }
             __syncthreads();
@@ -1454,6 +1845,7 @@ __global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
             if (t == 0) { newpresent[0] = 1; newpresent[W] = 1; }
             __syncthreads();
         }
+        PH(17);
         // projection factors of landmarks first observed in frame 0; each landmark is eliminated on the fly:
         // contribution = J_q^T J_q - c c^T / d  with c = J_q^T J_l, d = J_l^T J_l (pseudo-inverse: dropped if d <= eps)
         int nlm = be.n_lm;
@@ -1489,6 +1881,7 @@ __global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
             out[41] = rr[1] * residual_scaling;
         }
         __syncthreads();
+        PH(18);
         // column map of a residual's 19 non-landmark columns into q: pose0 -> 0..5, pose_k -> md+6(k-1), ex, td
         // accumulate A_qq and b_q: thread per (a,b) over the union index set is irregular; use per-landmark dense rows:
         // c_l (mq), d_l, b_l, then A -= c c^T/d after adding the plain J^T J per residual.
@@ -1523,43 +1916,50 @@ __global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
             c.gl[li] = bl;
         }
         __syncthreads();
-        // A_qq += sum_res J_q^T J_q  - sum_l c_l c_l^T / d_l ;  thread per (a,b)
-        auto qcol = [&](int col, int k, int &loc) -> bool {  // q-column -> local column of the residual with obs index k
-            if (col < 6) { loc = col; return true; }
-            if (col >= md && col < md + 6 * W) { int kf = (col - md) / 6 + 1; if (kf != k) return false; loc = 6 + (col - md) % 6; return true; }
-            if (col >= rE && col < rE + 6) { loc = 12 + (col - rE); return true; }
-            if (col == rT) { if (!cfg.estimate_td) return false; loc = 18; return true; }
-            return false;
+        PH(19);
+        // frame blocks G_j = sum over the residuals observing frame j of [J19 r]^T [J19 r] (packed symmetric 20x20)
+        for (int w = t; w < W * 210; w += nt) {
+            int j = w / 210 + 1, e = w - (j - 1) * 210;
+            int a = 0, rem = e;
+            while (rem >= 20 - a) { rem -= 20 - a; a++; }
+            int bcol = a + rem;
+            int ca = a < 19 ? a : -1, cb = bcol < 19 ? bcol : -1;
+            double sacc = 0;
+            for (int li = 0; li < F0c; li++) {
+                if (j >= c.lm_nobs[list0[li]]) continue;
+                const double *Jr = c.res + (size_t)(li * per + j - 1) * 42;
+                double a0 = ca >= 0 ? Jr[ca] : Jr[40], a1 = ca >= 0 ? Jr[20 + ca] : Jr[41];
+                double b0 = cb >= 0 ? Jr[cb] : Jr[40], b1 = cb >= 0 ? Jr[20 + cb] : Jr[41];
+                sacc += a0 * b0 + a1 * b1;
+            }
+            c.pairblk[w] = sacc;
+        }
+        for (int li = t; li < F0c; li += nt) { double d = c.Hll[li]; c.Hll[li] = d > eps ? 1.0 / d : 0.0; }  // pseudo-inverse of the diagonal block
+        __syncthreads();
+        // A_qq += sum_j G_j (scattered) - C^T D^+ C ; b_q likewise.  q-column -> local column of a frame-j residual:
+        auto qloc = [&](int col, int j) -> int {
+            if (col < 6) return col;
+            if (col >= md && col < md + 6 * W) return ((col - md) / 6 + 1 == j) ? 6 + (col - md) % 6 : -1;
+            if (col >= rE && col < rE + 6) return 12 + (col - rE);
+            if (col == rT) return cfg.estimate_td ? 18 : -1;
+            return -1;
         };
         for (int w = t; w < mq * (mq + 1); w += nt) {
             int a = w / (mq + 1), bb = w - a * (mq + 1);
             bool a_vis = a < 6 || (a >= md && a < md + 6 * W) || (a >= rE);
             if (!a_vis) continue;
             double sacc = 0;
-            for (int li = 0; li < F0c; li++) {
-                int no = c.lm_nobs[list0[li]];
-                double d = c.Hll[li];
-                double dinv = d > eps ? 1.0 / d : 0.0;
-                double ca = Cl[(size_t)li * ldc + a];
-                if (bb < mq) {
-                    for (int k = 1; k < no; k++) {
-                        int la, lb;
-                        if (!qcol(a, k, la) || !qcol(bb, k, lb)) continue;
-                        const double *Jr = c.res + (size_t)(li * per + k - 1) * 42;
-                        sacc += Jr[la] * Jr[lb] + Jr[20 + la] * Jr[20 + lb];
-                    }
-                    sacc -= ca * Cl[(size_t)li * ldc + bb] * dinv;
-                } else {
-                    for (int k = 1; k < no; k++) {
-                        int la;
-                        if (!qcol(a, k, la)) continue;
-                        const double *Jr = c.res + (size_t)(li * per + k - 1) * 42;
-                        sacc += Jr[la] * Jr[40] + Jr[20 + la] * Jr[41];
-                    }
-                    sacc -= ca * c.gl[li] * dinv;
-                }
+            for (int j = 1; j <= W; j++) {
+                int la = qloc(a, j);
+                if (la < 0) continue;
+                int lb = bb < mq ? qloc(bb, j) : 19;
+                if (lb < 0) continue;
+                sacc += c.pairblk[(size_t)(j - 1) * 210 + sym_idx(la, lb)];
             }
-            if (bb < mq) A[a * mq + bb] += sacc; else b[a] += sacc;
+            double sub_ = 0;
+            if (bb < mq) { for (int li = 0; li < F0c; li++) sub_ += Cl[(size_t)li * ldc + a] * Cl[(size_t)li * ldc + bb] * c.Hll[li]; }
+            else { for (int li = 0; li < F0c; li++) sub_ += Cl[(size_t)li * ldc + a] * c.gl[li] * c.Hll[li]; }
+            if (bb < mq) A[a * mq + bb] += sacc - sub_; else b[a] += sacc - sub_;
         }
         if (t == 0) {
             for (int li = 0; li < F0c; li++) {
@@ -1570,17 +1970,16 @@ __global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
         }
         __syncthreads();
     }
+    PH(20);
     // ---- eliminate the m-block (md x md) with a truncated eigen-decomposition
     for (int w = t; w < md * md; w += nt) { int i = w / md, j = w - i * md; A15[w] = 0.5 * (A[i * mq + j] + A[j * mq + i]); }
     __syncthreads();
-    if (t == 0) {
-        jacobi_small(A15, V15, md);
-        for (int i = 0; i < md; i++)
-            for (int j = 0; j < md; j++) {
-                double sacc = 0;
-                for (int k = 0; k < md; k++) { double w = A15[k * md + k]; if (w > eps) sacc += V15[i * md + k] * V15[j * md + k] / w; }
-                Pinv[i * md + j] = sacc;
-            }
+    jacobi_block(A15, V15, md, md, cs, sn, pp, qq, sred);
+    for (int w = t; w < md * md; w += nt) {
+        int i = w / md, j = w - i * md;
+        double sacc = 0;
+        for (int k = 0; k < md; k++) { double ev = A15[k * md + k]; if (ev > eps) sacc += V15[i * md + k] * V15[j * md + k] / ev; }
+        Pinv[w] = sacc;
     }
     __syncthreads();
     double *T1 = c.margW;             // n x md : A_rm * Amm_inv
@@ -1605,23 +2004,34 @@ __global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
         br[i] = sacc;
     }
     __syncthreads();
-    double *As = c.margA;             // n x n symmetrised copy (margA is free now)
-    for (int w = t; w < n * n; w += nt) { int i = w / n, j = w - i * n; As[w] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
+    PH(21);
+    // symmetrised A_r and its eigenvectors live in LDS when they fit (n <= 96), else in HBM scratch
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_marg[];
+    const bool in_lds = n <= 96;
+    const int ldj = in_lds ? (n | 1) : n;  // odd leading dimension: conflict-free 64-bit LDS column access
+    double *As = in_lds ? (double *)smem_marg : c.margA;
+    double *Vv = in_lds ? (double *)smem_marg + n * ldj : c.margW + (size_t)n * 16;
+    for (int w = t; w < n * n; w += nt) { int i = w / n, j = w - i * n; As[i * ldj + j] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
     __syncthreads();
-    double *Vv = c.margV;
-    jacobi_block(As, Vv, n, cs, sn, pp, qq, sred);
+    long long tj0 = wall_clock64();
+    __shared__ double ev_d[6 * VIO_MAXW + 16], ev_e[6 * VIO_MAXW + 16], ev_g[6 * VIO_MAXW + 16];
+    sym_eig_tridiag(As, n, ldj, ev_d, ev_e, ev_g, sred);
+    tridiag_ql_wave(As, n, ldj, ev_d, ev_e);
+    Vv = As;  // eigenvectors overwrite the matrix
+    if (t == 0) { be.dbg[0] = 0; be.dbg[1] = (int)(wall_clock64() - tj0); be.dbg[2] = second_new ? 1 : 0; }
+    PH(22);
     // linearized_jacobians = sqrt(S) V^T ; linearized_residuals = S^-1/2 V^T b
     for (int w = t; w < n * n; w += nt) {
         int k = w / n, i = w - k * n;
-        double wv = As[k * n + k];
+        double wv = ev_d[k];
         double S = wv > eps ? wv : 0.0;
-        c.prior_J[w] = sqrt(S) * Vv[i * n + k];
+        c.prior_J[w] = sqrt(S) * Vv[i * ldj + k];
     }
     for (int k = t; k < n; k += nt) {
-        double wv = As[k * n + k];
+        double wv = ev_d[k];
         double Sinv = wv > eps ? 1.0 / wv : 0.0;
         double vb = 0;
-        for (int i = 0; i < n; i++) vb += Vv[i * n + k] * br[i];
+        for (int i = 0; i < n; i++) vb += Vv[i * ldj + k] * br[i];
         c.prior_r[k] = sqrt(Sinv) * vb;
     }
     // keep_block_data in the shifted (canonical) layout
@@ -1633,7 +2043,8 @@ __global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
     if (t == W + 1) { for (int d = 0; d < 7; d++) c.prior_x0[W * 7 + 9 + d] = X.ex[d]; c.prior_x0[W * 7 + 16] = X.td; }
     __syncthreads();
     if (t < W + 3) be.prior_present[t] = newpresent[t];
-    if (t == 0) be.has_prior = 1;
+    if (t == 0) { be.has_prior = 1; be.dbg[3] = (int)(wall_clock64() - tk0); }
+    PH(23);
 }
 
 // ====================================================================================================== be_finish
@@ -1644,7 +2055,7 @@ __global__ __launch_bounds__(256) void be_finish_kernel(Batch B) {
     const vio_config &cfg = C.c;
     BeSeq &be = *c.be;
     const int W = c.W, W1 = W + 1;
-    __shared__ int scratch[260];
+    __shared__ int scratch[2 * 256 + 8];
     __shared__ int sh_i[4];
     __shared__ PreWork pw;
     double *od = B.odom + (size_t)s * 11;
@@ -1866,21 +2277,20 @@ __global__ __launch_bounds__(256) void be_stage_imu_kernel(vio_config cfg, PreIn
         preint_out[7] = p.dv[0]; preint_out[8] = p.dv[1]; preint_out[9] = p.dv[2];
         preint_out[10] = p.sum_dt;
         for (int k = 0; k < 225; k++) { preint_out[11 + k] = p.jac[k]; preint_out[236 + k] = p.cov[k]; }
-        bf::imu_sqrt_info(p.cov, p.sqrt_info);
         double raw[15], Jr[450];
         v3 G = mk(0, 0, g_norm);
         bf::imu_raw_residual(p, G, par, par + 7, par + 16, par + 23, raw);
         bf::imu_raw_jacobian(p, G, par, par + 7, par + 16, par + 23, Jr);
         for (int r = 0; r < 15; r++) {
             double sacc = 0;
-            for (int k = 0; k < 15; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k];
+            for (int k = 0; k <= r; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k];
             r15[r] = sacc;
         }
         // whitened Jacobians in the reference's global layout: 15x7, 15x9, 15x7, 15x9 (7th pose column = 0)
         for (int r = 0; r < 15; r++)
             for (int col = 0; col < 30; col++) {
                 double sacc = 0;
-                for (int k = r; k < 15; k++) sacc += p.sqrt_info[r * 15 + k] * Jr[k * 30 + col];
+                for (int k = 0; k <= r; k++) sacc += p.sqrt_info[r * 15 + k] * Jr[k * 30 + col];
                 if (col < 6) J480[r * 7 + col] = sacc;
                 else if (col < 15) J480[105 + r * 9 + (col - 6)] = sacc;
                 else if (col < 21) J480[240 + r * 7 + (col - 15)] = sacc;

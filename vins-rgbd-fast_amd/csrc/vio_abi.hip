@@ -53,7 +53,7 @@ struct vio_batch {
     double *d_pt = nullptr, *d_pacc = nullptr, *d_pgyr = nullptr;
     size_t d_pcap = 0;
     std::vector<double> last_imu_t;
-    size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0;
+    size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0, lds_marg = 0;
     bool timing_valid = false;
     // per-kernel event pool (vio_profile_begin / vio_profile_end)
     std::vector<hipEvent_t> pev;
@@ -189,9 +189,9 @@ int launch_backend(vio_batch *h, const uint16_t *d_depth) {
     hipStream_t st = h->stream;
     be_ingest_kernel<<<S, 256, 0, st>>>(h->B, d_depth, (size_t)C.c.width * C.c.height);
     PEV(h, 8);
-    be_solve_kernel<<<S, 256, h->lds_solve, st>>>(h->B);
+    be_solve_kernel<<<S, 1024, h->lds_solve, st>>>(h->B);
     PEV(h, 9);
-    be_marg_kernel<<<S, 256, 0, st>>>(h->B);
+    be_marg_kernel<<<S, 256, h->lds_marg, st>>>(h->B);
     PEV(h, 10);
     be_finish_kernel<<<S, 256, 0, st>>>(h->B);
     PEV(h, 11);
@@ -311,8 +311,8 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     DA(B.lm_depth, S * NL); DA(B.lm_obs, S * NL * W1 * VIO_OBS_D); DA(B.para_feat, S * NL); DA(B.cand_feat, S * NL);
     const size_t n = C.NPRIOR, LW = C.LW, nres = 4 * NL, npair = W1 * W1, mq = 15 + n;
     DA(B.prior_J, S * n * n); DA(B.prior_r, S * n); DA(B.prior_x0, S * (C.W * 7 + 17)); DA(B.prior_H, S * n * n);
-    DA(B.H, S * LW * LW); DA(B.Sc, S * LW * LW); DA(B.Hpl, S * NL * LW); DA(B.vec, S * VEC_SLOTS * LW);
-    DA(B.Hll, S * NL); DA(B.gl, S * NL); DA(B.lvec, S * NL * 8);
+    DA(B.H, S * LW * LW); DA(B.Sc, S * LW * LW); DA(B.Hpl, S * (NL + 8) * LW); DA(B.vec, S * VEC_SLOTS * LW);
+    DA(B.Hll, S * (NL + 8)); DA(B.gl, S * (NL + 8)); DA(B.lvec, S * (NL + 8) * 8);
     DA(B.res, S * nres * 42); DA(B.res_lm, S * nres); DA(B.res_k, S * nres); DA(B.res_pair, S);
     DA(B.pair_start, S * (npair + 1)); DA(B.pair_list, S * nres); DA(B.pairblk, S * npair * 210);
     DA(B.imu_raw, S * C.W * 15 * 31);
@@ -336,6 +336,8 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
         for (int k = 0; k < C.ncells; k++) hmax = std::max(hmax, C.rect[k].h);
         h->lds_fast = (size_t)2 * amax + (size_t)(hmax + 2) * 4 + 16;
         h->lds_solve = (size_t)C.LW * 8 + 16;
+        h->lds_marg = C.NPRIOR <= 96 ? (size_t)2 * C.NPRIOR * (C.NPRIOR | 1) * 8 + 16 : 16;
+        (void)hipFuncSetAttribute((const void *)be_marg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_marg);
         (void)hipFuncSetAttribute((const void *)fe_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_select);
         (void)hipFuncSetAttribute((const void *)fe_add_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_add);
         (void)hipFuncSetAttribute((const void *)fe_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_fast);
@@ -572,6 +574,24 @@ int vio_get_timings(vio_batch *h, int cap, double *out_ms) {
     HIPCHK(hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
     out_ms[0] = a; out_ms[1] = b; out_ms[2] = a + b;
     return 3;
+}
+
+int vio_debug_seq(vio_batch *h, int seq, int *out16) {
+    if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    static thread_local BeSeq be;
+    HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 16; k++) out16[k] = be.dbg[k];
+    return VIO_OK;
+}
+
+// debug: accumulated in-kernel phase ticks (100 MHz) of sequence 0; reset != 0 clears them
+int vio_debug_phases(vio_batch *h, float *out64, int reset) {
+    if (!h) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (out64) HIPCHK(hipMemcpy(out64, h->B.timings, 64 * sizeof(float), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(hipMemset(h->B.timings, 0, 64 * sizeof(float)));
+    return VIO_OK;
 }
 
 // per-kernel HIP-event profile of the next max_steps vio_feed calls (events sit on the batch stream)

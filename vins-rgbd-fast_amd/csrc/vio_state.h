@@ -91,6 +91,7 @@ struct BeSeq {
     int do_solve, do_marg;          // decisions of the ingest stage for the later kernels
     int n_imu_frame;                // samples consumed for the current frame
     int overflow;                   // capacity overflow flags (landmarks / imu slot)
+    int dbg[16];                    // debug counters (sweeps, ticks)
 };
 
 // all HBM pointers of a batch; passed to kernels by value
