@@ -217,6 +217,56 @@ DM_HD void imu_raw_jacobian(const PreInt &p, v3 G, const double *pi, const doubl
     put33(J, 30, O_BG, 27, eye());
 }
 
+// One column group of the raw IMU Jacobian, written straight into a 15 x ld row-major buffer (columns as in
+// imu_raw_jacobian): part 0 = pose_i (cols 0-5), 1 = speedbias_i (6-14), 2 = pose_j (15-20), 3 = speedbias_j (21-29).
+// Lets four threads share one factor.
+DM_HD void imu_raw_jacobian_part(const PreInt &p, v3 G, const double *pi, const double *sbi, const double *pj, const double *sbj, int part,
+                                 double *J, int ld) {
+    const int c0 = part == 0 ? 0 : (part == 1 ? 6 : (part == 2 ? 15 : 21)), nc = (part & 1) ? 9 : 6;
+    for (int r = 0; r < 15; r++) for (int c = 0; c < nc; c++) J[r * ld + c0 + c] = 0;
+    v3 Pi = ld3(pi), Vi = ld3(sbi), Bgi = ld3(sbi + 6);
+    v3 Pj = ld3(pj), Vj = ld3(sbj);
+    quat Qi = mkq(pi[6], pi[3], pi[4], pi[5]), Qj = mkq(pj[6], pj[3], pj[4], pj[5]);
+    double sdt = p.sum_dt;
+    quat Qi_inv = qinv(Qi), Qj_inv = qinv(Qj);
+    m3 RiT = q2R(Qi_inv);
+    quat delta_q = mkq(p.dq[0], p.dq[1], p.dq[2], p.dq[3]);
+    m3 dq_dbg = get33(p.jac, 15, O_R, O_BG);
+    double L4[16], R4[16], LR[16];
+    if (part == 0) {
+        quat cq = qmul(delta_q, deltaQ(mul(dq_dbg, sub(Bgi, ld3(p.lin_bg)))));
+        put33(J, ld, O_P, 0, neg(RiT));
+        put33(J, ld, O_P, 3, skew(qrot(Qi_inv, sub(sub(add(scl(sdt * sdt, scl(0.5, G)), Pj), Pi), scl(sdt, Vi)))));
+        Qleft(qmul(Qj_inv, Qi), L4);
+        Qright(cq, R4);
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { double s = 0; for (int k = 0; k < 4; k++) s += L4[i * 4 + k] * R4[k * 4 + j]; LR[i * 4 + j] = s; }
+        put33(J, ld, O_R, 3, neg(br33(LR)));
+        put33(J, ld, O_V, 3, skew(qrot(Qi_inv, sub(add(scl(sdt, G), Vj), Vi))));
+    } else if (part == 1) {
+        m3 dp_dba = get33(p.jac, 15, O_P, O_BA), dp_dbg = get33(p.jac, 15, O_P, O_BG), dv_dba = get33(p.jac, 15, O_V, O_BA),
+           dv_dbg = get33(p.jac, 15, O_V, O_BG);
+        put33(J, ld, O_P, 6, scl(-sdt, RiT));
+        put33(J, ld, O_P, 9, neg(dp_dba));
+        put33(J, ld, O_P, 12, neg(dp_dbg));
+        Qleft(qmul(qmul(Qj_inv, Qi), delta_q), L4);
+        put33(J, ld, O_R, 12, neg(mul(br33(L4), dq_dbg)));
+        put33(J, ld, O_V, 6, neg(RiT));
+        put33(J, ld, O_V, 9, neg(dv_dba));
+        put33(J, ld, O_V, 12, neg(dv_dbg));
+        put33(J, ld, O_BA, 9, neg(eye()));
+        put33(J, ld, O_BG, 12, neg(eye()));
+    } else if (part == 2) {
+        quat cq = qmul(delta_q, deltaQ(mul(dq_dbg, sub(Bgi, ld3(p.lin_bg)))));
+        put33(J, ld, O_P, 15, RiT);
+        Qleft(qmul(qmul(qinv(cq), Qi_inv), Qj), L4);
+        put33(J, ld, O_R, 18, br33(L4));
+    } else {
+        put33(J, ld, O_V, 21, RiT);
+        put33(J, ld, O_BA, 24, eye());
+        put33(J, ld, O_BG, 27, eye());
+    }
+}
+
 // ProjectionFactor / ProjectionTdFactor::Evaluate. obs = 9 doubles (x y z u v vx vy cur_td depth).
 // J (optional) = 2x20 row-major, columns [pose_i(6) pose_j(6) ex(6) td(1) inv_depth(1)] in tangent coordinates.
 DM_HD void eval_projection(const vio_config &c, const double *pi, const double *pj, const double *ex, double inv_dep, double td,

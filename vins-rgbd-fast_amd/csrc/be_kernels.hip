@@ -75,18 +75,26 @@ __device__ __forceinline__ bool in_problem(const Ctx &c, int slot) {
     return !c.lm_dyn[slot] && c.lm_nobs[slot] >= 2 && c.lm_start[slot] < c.W - 2;
 }
 
-// deterministic block-wide sum; all threads get the result. sred: blockDim doubles of LDS
+// deterministic block-wide sum; all threads get the result. sred: >= 16 doubles of LDS.
+// wavefront shuffle reduction, then a fixed-order sum over the per-wave partials (2 barriers).
 __device__ double block_sum(double v, double *sred) {
-    int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = (blockDim.x + 63) >> 6;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     __syncthreads();
-    sred[t] = v;
+    if (lane == 0) sred[wave] = v;
     __syncthreads();
-    for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
-        if (t < off) sred[t] += sred[t + off];
-        __syncthreads();
-    }
+    double r = 0;
+    for (int k = 0; k < nw; k++) r += sred[k];
+    return r;
+}
+__device__ double block_max(double v, double *sred) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = (blockDim.x + 63) >> 6;
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    __syncthreads();
+    if (lane == 0) sred[wave] = v;
+    __syncthreads();
     double r = sred[0];
-    __syncthreads();
+    for (int k = 1; k < nw; k++) r = fmax(r, sred[k]);
     return r;
 }
 __device__ int block_scan_flags(const int *flags, int n, int *offs, int *scratch /* 2*blockDim + 2 ints */) {
@@ -240,11 +248,7 @@ __device__ int jacobi_block(double *A, double *V, int n, int ld, double *cs, dou
         // the sweep loop ends when a whole sweep applied no rotation
         double dmax = 0;
         for (int i = t; i < n; i += nt) dmax = fmax(dmax, fabs(A[i * ld + i]));
-        __syncthreads();
-        sred[t] = dmax;
-        __syncthreads();
-        for (int o2 = nt >> 1; o2 > 0; o2 >>= 1) { if (t < o2) sred[t] = fmax(sred[t], sred[t + o2]); __syncthreads(); }
-        dmax = sred[0];
+        dmax = block_max(dmax, sred);
         __syncthreads();
         const double absfloor = 1e-18 * dmax;
         double nrot = 0;
@@ -671,8 +675,7 @@ __device__ void chol_solve_blocked(const double *L, int n, int ld, double *xs) {
 
 // out[a] = sum_b M[b][a] * v[b] for a < n (M symmetric or "column sum" of a row-major matrix with nrows rows), split over
 // blockDim/256 row groups and combined through LDS part[(blockDim/256)*VIO_LWMAX]
-__device__ void colsum(const double *M, int ld, int nrows, const double *v, int n, double *out) {
-    __shared__ double part[4 * VIO_LWMAX];
+__device__ void colsum(const double *M, int ld, int nrows, const double *v, int n, double *out, double *part) {
     const int t = threadIdx.x, nt = blockDim.x;
     const int groups = nt >> 8, g = t >> 8, a0 = t & 255;
     for (int a = a0; a < n; a += 256) {
@@ -1049,26 +1052,25 @@ __device__ double evaluate(const Ctx &c, const Params &X, const double *feat, bo
             cost += 0.5 * sacc * sacc;
         }
     }
-    // IMU factors
+    // IMU factors: five threads per factor (whitened residual + four Jacobian column groups). Spread over the upper lanes
+    // of the block so that they do not serialise with the projection residuals handled by the low thread ids.
     v3 G = ld3(be.g);
-    for (int i = t; i < W; i += nt) {
-        int j = i + 1;
+    for (int w = (nt - 1 - t); w < W * 5; w += nt) {
+        int i = w / 5, part = w - i * 5, j = i + 1;
         const PreInt &p = c.pre[be.pre_idx[j]];
         double *out = c.imu_raw + (size_t)i * 15 * 31;
-        if (p.sum_dt > 10.0) { for (int k = 0; k < 15; k++) out[k * 31 + 30] = 0; continue; }
-        double raw[15];
-        bf::imu_raw_residual(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], raw);
-        for (int r = 0; r < 15; r++) {
-            double sacc = 0;
-            for (int k = 0; k <= r; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k];
-            out[r * 31 + 30] = sacc;
-            cost += 0.5 * sacc * sacc;
-        }
-        if (withJ) {
-            double Jr[450];
-            bf::imu_raw_jacobian(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], Jr);
-            for (int q = 0; q < 450; q++) out[(q / 30) * 31 + (q % 30)] = Jr[q];  // raw, whitened in a second pass
-        }
+        if (p.sum_dt > 10.0) { if (part == 0) for (int k = 0; k < 15; k++) out[k * 31 + 30] = 0; continue; }
+        if (part == 0) {
+            double raw[15];
+            bf::imu_raw_residual(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], raw);
+            for (int r = 0; r < 15; r++) {
+                double sacc = 0;
+                for (int k = 0; k <= r; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k];
+                out[r * 31 + 30] = sacc;
+                cost += 0.5 * sacc * sacc;
+            }
+        } else if (withJ)
+            bf::imu_raw_jacobian_part(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], part - 1, out, 31);  // raw, whitened in assemble
     }
     // projection factors, CauchyLoss(1.0)
     for (int r = t; r < nres; r += nt) {
@@ -1108,14 +1110,24 @@ __device__ __forceinline__ int local_of(int a, int i, int j, int W) {
     return 12 + e;  // ex 0..5 -> 12..17, td (6) -> 18
 }
 
-// assemble H (P x P, ld LW), g (vec slot 0), Hpl / Hll / gl from the stored residual Jacobians
-__device__ void assemble(const Ctx &c, const Params &X, int nres, int Fa, const int *alist, double *srp) {
+// compact index of the frame pair (i < j)
+__device__ __forceinline__ int pair_slot(int i, int j, int W1) { return i * W1 - i * (i + 1) / 2 + (j - i - 1); }
+
+// assemble H (P x P, ld LW), g (vec slot 0), Hpl / Hll / gl from the stored residual Jacobians.
+// work: LDS scratch (>= max(W*450, npairs*210) doubles when it fits, see be_solve); pb = frame-pair blocks (LDS or HBM)
+__device__ void assemble(const Batch &B, const Ctx &c, const Params &X, int nres, int Fa, const int *alist, double *srp, double *work,
+                         double *pb) {
+    const int s = c.s;
+    PH_INIT;
     const int t = threadIdx.x, nt = blockDim.x, W = c.W, P = c.P, LW = c.LW, n = c.NPR;
+    const int lane = t & 63, wave = t >> 6, nw = nt >> 6;
     const BeSeq &be = *c.be;
     double *H = c.H, *g = c.vec;
     for (int i = t; i < P * LW; i += nt) H[i] = 0;
     for (int i = t; i < LW; i += nt) g[i] = 0;
+    for (int i = t; i < Fa * LW; i += nt) c.Hpl[i] = 0;
     __syncthreads();
+    PH(32);
     // prior: H += J^T J (precomputed), g += J^T r
     if (be.has_prior) {
         for (int w = t; w < n * n; w += nt) {
@@ -1129,14 +1141,16 @@ __device__ void assemble(const Ctx &c, const Params &X, int nres, int Fa, const 
         }
     }
     __syncthreads();
-    // IMU: whiten raw Jacobians (sqrt_info upper-triangular), then 30x30 blocks; even factors then odd factors
+    PH(33);
+    // IMU: whiten raw Jacobians with M = chol(cov)^-1 (lower triangular) into LDS, then 30x30 blocks; even then odd factors
+    double *Jw = work;  // [W][450]
     for (int w = t; w < W * 450; w += nt) {
         int i = w / 450, q = w - i * 450, r = q / 30, col = q - r * 30;
         const PreInt &p = c.pre[be.pre_idx[i + 1]];
         const double *raw = c.imu_raw + (size_t)i * 15 * 31;
         double sacc = 0;
         for (int k = 0; k <= r; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k * 31 + col];
-        c.pairblk[w] = sacc;  // temporary home of the whitened Jacobians (pairblk is rebuilt afterwards)
+        Jw[w] = sacc;
     }
     __syncthreads();
     for (int parity = 0; parity < 2; parity++) {
@@ -1146,42 +1160,59 @@ __device__ void assemble(const Ctx &c, const Params &X, int nres, int Fa, const 
             const PreInt &p = c.pre[be.pre_idx[i + 1]];
             if (p.sum_dt > 10.0) continue;
             int q = w - i * 930;
-            const double *Jw = c.pairblk + (size_t)i * 450;
+            const double *Jf = Jw + i * 450;
             const double *raw = c.imu_raw + (size_t)i * 15 * 31;
             int a = q / 31, b = q - a * 31;
             int ia = a < 6 ? 6 * i + a : (a < 15 ? 6 * (W + 1) + 9 * i + (a - 6) : (a < 21 ? 6 * (i + 1) + (a - 15) : 6 * (W + 1) + 9 * (i + 1) + (a - 21)));
             double sacc = 0;
             if (b < 30) {
                 int ib = b < 6 ? 6 * i + b : (b < 15 ? 6 * (W + 1) + 9 * i + (b - 6) : (b < 21 ? 6 * (i + 1) + (b - 15) : 6 * (W + 1) + 9 * (i + 1) + (b - 21)));
-                for (int k = 0; k < 15; k++) sacc += Jw[k * 30 + a] * Jw[k * 30 + b];
+                for (int k = 0; k < 15; k++) sacc += Jf[k * 30 + a] * Jf[k * 30 + b];
                 H[ia * LW + ib] += sacc;
             } else {
-                for (int k = 0; k < 15; k++) sacc += Jw[k * 30 + a] * raw[k * 31 + 30];
+                for (int k = 0; k < 15; k++) sacc += Jf[k * 30 + a] * raw[k * 31 + 30];
                 g[ia] += sacc;
             }
         }
         __syncthreads();
     }
-    // vision: frame-pair blocks G_p = [J19 r]^T [J19 r] (packed symmetric 20x20)
+    PH(34);
+    // vision: frame-pair blocks G_p = [J19 r]^T [J19 r] (packed symmetric 20x20) on the FP64 matrix cores:
+    // one wavefront per frame pair, K = 2 rows per residual, three 16x16 accumulators (cols 0-15 / 16-19 of the 20 columns)
     const int W1 = W + 1;
-    for (int w = t; w < W1 * W1 * 210; w += nt) {
-        int p = w / 210, e = w - p * 210;
-        int i = p / W1, j = p - i * W1;
-        if (!(i < j)) continue;
-        int a = 0, rem = e;
-        while (rem >= 20 - a) { rem -= 20 - a; a++; }
-        int b = a + rem;
-        int ca = a < 19 ? a : -1, cb = b < 19 ? b : -1;  // column 19 of the block is the residual
-        double sacc = 0;
-        for (int q = c.pair_start[p]; q < c.pair_start[p + 1]; q++) {
-            const double *Jr = c.res + (size_t)c.pair_list[q] * 42;
-            double a0 = ca >= 0 ? Jr[ca] : Jr[40], a1 = ca >= 0 ? Jr[20 + ca] : Jr[41];
-            double b0 = cb >= 0 ? Jr[cb] : Jr[40], b1 = cb >= 0 ? Jr[20 + cb] : Jr[41];
-            sacc += a0 * b0 + a1 * b1;
+    {
+        const int li = lane & 15, lk = lane >> 4;
+        for (int p = wave; p < W1 * W1; p += nw) {
+            int i = p / W1, j = p - i * W1;
+            if (!(i < j)) continue;
+            const int q0 = c.pair_start[p], np_ = c.pair_start[p + 1] - q0;
+            double *out = pb + (size_t)pair_slot(i, j, W1) * 210;
+            if (np_ == 0) { for (int e = lane; e < 210; e += 64) out[e] = 0; continue; }
+            v4f64 a00 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
+            const int K = 2 * np_;
+            for (int k0 = 0; k0 < K; k0 += 4) {
+                int kk = k0 + lk;
+                double x0 = 0, x1 = 0;
+                if (kk < K) {
+                    const double *Jr = c.res + (size_t)c.pair_list[q0 + (kk >> 1)] * 42;
+                    int ro = (kk & 1) * 20;
+                    x0 = Jr[ro + li];
+                    x1 = li < 3 ? Jr[ro + 16 + li] : (li == 3 ? Jr[40 + (kk & 1)] : 0.0);
+                }
+                a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, a00, 0, 0, 0);
+                a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, a10, 0, 0, 0);
+                a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, a11, 0, 0, 0);
+            }
+            for (int r = 0; r < 4; r++) {
+                int row = lk + 4 * r, col = li;  // C/D layout of v_mfma_f64_16x16x4_f64
+                if (col <= row) out[sym_idx(col, row)] = a00[r];
+                if (row < 4) out[sym_idx(col, 16 + row)] = a10[r];
+                if (row < 4 && col < 4 && col <= row) out[sym_idx(16 + col, 16 + row)] = a11[r];
+            }
         }
-        c.pairblk[(size_t)p * 210 + e] = sacc;
     }
     __syncthreads();
+    PH(35);
     {
         const int nv = 6 * W1 + 7;
         for (int w = t; w < nv * (nv + 1); w += nt) {
@@ -1189,62 +1220,85 @@ __device__ void assemble(const Ctx &c, const Params &X, int nres, int Fa, const 
             int a = ra < 6 * W1 ? ra : 15 * W1 + (ra - 6 * W1);
             int b = rb < nv ? (rb < 6 * W1 ? rb : 15 * W1 + (rb - 6 * W1)) : -1;
             double sacc = 0;
-            for (int i = 0; i < W1; i++)
-                for (int j = i + 1; j < W1; j++) {
-                    int p = i * W1 + j;
-                    if (c.pair_start[p + 1] == c.pair_start[p]) continue;
-                    int la = local_of(a, i, j, W);
-                    if (la < 0) continue;
-                    int lb = b >= 0 ? local_of(b, i, j, W) : 19;
-                    if (lb < 0) continue;
-                    sacc += c.pairblk[(size_t)p * 210 + sym_idx(la, lb)];
-                }
+            const int fa = ra < 6 * W1 ? ra / 6 : -1, fb = (rb < 6 * W1) ? rb / 6 : -1;
+            if (fa >= 0 && fb >= 0 && fa != fb) {
+                int i = min(fa, fb), j = max(fa, fb);
+                sacc = pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(local_of(a, i, j, W), local_of(b, i, j, W))];
+            } else {
+                for (int i = 0; i < W1; i++)
+                    for (int j = i + 1; j < W1; j++) {
+                        if (fa >= 0 && fa != i && fa != j) continue;
+                        if (fb >= 0 && fb != i && fb != j) continue;
+                        int p = i * W1 + j;
+                        if (c.pair_start[p + 1] == c.pair_start[p]) continue;
+                        int la = local_of(a, i, j, W);
+                        int lb = b >= 0 ? local_of(b, i, j, W) : 19;
+                        sacc += pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(la, lb)];
+                    }
+            }
             if (b >= 0) H[a * LW + b] += sacc; else g[a] += sacc;
         }
     }
-    // landmark coupling rows (dense, zero padded), Hll, gl
-    for (int w = t; w < Fa * LW; w += nt) {
-        int ka = w / LW, col = w - ka * LW;
-        int slot = alist[ka];
-        int st = c.lm_start[slot], no = c.lm_nobs[slot];
-        double sacc = 0;
-        if (col < P) {
-            int np = 6 * W1;
-            int r0 = c.lm_tmp[slot];  // first residual index of this landmark
-            if (col < np) {
-                int f = col / 6, d = col - f * 6;
-                if (f == st) {
-                    for (int k = 1; k < no; k++) { const double *Jr = c.res + (size_t)(r0 + k - 1) * 42; sacc += Jr[d] * Jr[19] + Jr[20 + d] * Jr[39]; }
-                } else if (f > st && f < st + no) {
-                    const double *Jr = c.res + (size_t)(r0 + (f - st) - 1) * 42;
-                    sacc = Jr[6 + d] * Jr[19] + Jr[26 + d] * Jr[39];
-                }
-            } else if (col >= 15 * W1) {
-                int e = 12 + (col - 15 * W1);
-                for (int k = 1; k < no; k++) { const double *Jr = c.res + (size_t)(r0 + k - 1) * 42; sacc += Jr[e] * Jr[19] + Jr[20 + e] * Jr[39]; }
-            }
-        }
-        c.Hpl[(size_t)ka * LW + col] = sacc;
-    }
+    PH(36);
+    // landmark coupling rows (dense, zero padded above), Hll, gl: one thread per variable landmark walks its residuals
     for (int ka = t; ka < Fa; ka += nt) {
         int slot = alist[ka];
-        int no = c.lm_nobs[slot], r0 = c.lm_tmp[slot];
-        double hll = 0, gg = 0;
+        int st = c.lm_start[slot], no = c.lm_nobs[slot], r0 = c.lm_tmp[slot];
+        double *row = c.Hpl + (size_t)ka * LW;
+        double si[6] = {0, 0, 0, 0, 0, 0}, se[7] = {0, 0, 0, 0, 0, 0, 0}, hll = 0, gg = 0;
         for (int k = 1; k < no; k++) {
+            if (r0 + k - 1 >= nres) break;
             const double *Jr = c.res + (size_t)(r0 + k - 1) * 42;
-            hll += Jr[19] * Jr[19] + Jr[39] * Jr[39];
-            gg += Jr[19] * Jr[40] + Jr[39] * Jr[41];
+            double l0 = Jr[19], l1 = Jr[39];
+            for (int d = 0; d < 6; d++) {
+                si[d] += Jr[d] * l0 + Jr[20 + d] * l1;
+                row[6 * (st + k) + d] = Jr[6 + d] * l0 + Jr[26 + d] * l1;
+                se[d] += Jr[12 + d] * l0 + Jr[32 + d] * l1;
+            }
+            se[6] += Jr[18] * l0 + Jr[38] * l1;
+            hll += l0 * l0 + l1 * l1;
+            gg += l0 * Jr[40] + l1 * Jr[41];
         }
+        for (int d = 0; d < 6; d++) { row[6 * st + d] = si[d]; row[15 * W1 + d] = se[d]; }
+        row[15 * W1 + 6] = se[6];
         c.Hll[ka] = hll;
         c.gl[ka] = gg;
     }
     __syncthreads();
+    PH(37);
 }
 
 }  // namespace
 
+__device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem_marg);
+__device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw);
+
+// solve -> marginalise -> window slide for one sequence per workgroup (1024 threads); fusing the three stages makes the
+// step time the maximum over sequences of the *sum* of the stage times instead of the sum of per-stage maxima.
+__device__ void solve_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem, PreWork &pw);
+
 __global__ __launch_bounds__(1024) void be_solve_kernel(Batch B) {
-    const int s = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+    const int s = blockIdx.x;
+    __shared__ int scratch[2 * 1024 + 8];
+    __shared__ double sred[64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PreWork &pw = *(PreWork *)(smem + 16 * ((B.cfg->LW * 8 + 15) / 16));  // aliases the work region (used before it)
+    solve_body(B, s, scratch, sred, smem, pw);
+}
+// marginalisation + window slide: 256 threads (barrier-heavy eigen-decomposition; measured faster than 1024)
+__global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
+    const int s = blockIdx.x;
+    __shared__ int scratch[2 * 256 + 8];
+    __shared__ double sred[64];
+    __shared__ PreWork pw;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    marg_body(B, s, scratch, sred, smem);
+    __syncthreads();
+    finish_body(B, s, scratch, pw);
+}
+
+__device__ void solve_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem, PreWork &pw) {
+    const int t = threadIdx.x, nt = blockDim.x;
     Ctx c = make_ctx(B, s);
     const DevCfg &C = *B.cfg;
     const vio_config &cfg = C.c;
@@ -1252,14 +1306,13 @@ __global__ __launch_bounds__(1024) void be_solve_kernel(Batch B) {
     if (!be.do_solve) return;
     const int W = c.W, P = c.P, LW = c.LW, W1 = W + 1;
     __shared__ Params X, Xc;
-    __shared__ double sred[1024];
     __shared__ double sdx[6 * VIO_MAXW + 16], srp[6 * VIO_MAXW + 16];
-    __shared__ int scratch[2 * 1024 + 8];
     __shared__ int sh_i[8];
     __shared__ double sh_d[8];
-    __shared__ PreWork pw;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *xs = (double *)smem;  // LW doubles: triangular-solve workspace
+    double *work = xs + LW;       // LDS scratch: whitened IMU Jacobians, then the frame-pair blocks
+    const int npairs = (W + 1) * W / 2;
+    double *pb = (npairs * 210 <= 12288) ? work : c.pairblk;  // 55 pairs x 210 doubles = 92 KB for W = 10
 
     PH_INIT;
     const long long ts0 = wall_clock64();
@@ -1455,7 +1508,7 @@ __global__ __launch_bounds__(1024) void be_solve_kernel(Batch B) {
     PH(3);
     double cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp);
     PH(4);
-    assemble(c, X, nres, Fa, alist, srp);
+    assemble(B, c, X, nres, Fa, alist, srp, work, pb);
     PH(5);
     if (t == 0) be.initial_cost = cost;
     // Jacobi scaling (once): 1/(1+||J_j||); constant blocks (ex / td when not estimated) get scale 0 = removed from the problem
@@ -1471,12 +1524,7 @@ __global__ __launch_bounds__(1024) void be_solve_kernel(Batch B) {
         double m = 0;
         for (int a = t; a < P; a += nt) m = fmax(m, sp[a] != 0.0 ? fabs(g[a]) : 0.0);
         for (int k = t; k < Fa; k += nt) m = fmax(m, fabs(c.gl[k]));
-        __syncthreads();
-        sred[t] = m;
-        __syncthreads();
-        for (int off = nt >> 1; off > 0; off >>= 1) { if (t < off) sred[t] = fmax(sred[t], sred[t + off]); __syncthreads(); }
-        double r = sred[0];
-        __syncthreads();
+        double r = block_max(m, sred);
         for (int w = t; w < LW * LW; w += nt) { int a = w / LW, b = w - a * LW; c.H[w] = (a < P && b < P) ? sp[a] * sp[b] * c.H[w] : 0.0; }
         for (int w = t; w < Kpad * LW; w += nt) { int k = w / LW, a = w - k * LW; c.Hpl[w] = (k < Fa) ? sl[k] * sp[a] * c.Hpl[w] : 0.0; }
         for (int a = t; a < LW; a += nt) gs[a] = a < P ? sp[a] * g[a] : 0.0;
@@ -1497,7 +1545,7 @@ __global__ __launch_bounds__(1024) void be_solve_kernel(Batch B) {
                 PH(13);
                 cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp);
                 PH(4);
-                assemble(c, X, nres, Fa, alist, srp);
+                assemble(B, c, X, nres, Fa, alist, srp, work, pb);
                 PH(5);
                 need_eval = false;
                 if (gmax_and_scale() <= 1e-10) { iters_done = iter - 1; break; }
@@ -1516,7 +1564,7 @@ __global__ __launch_bounds__(1024) void be_solve_kernel(Batch B) {
             }
             __syncthreads();
             // Cauchy point: alpha = |grad|^2 / |J D^-1 grad|^2
-            colsum(c.H, LW, P, sgp, P, tmpv);          // Hs * sg
+            colsum(c.H, LW, P, sgp, P, tmpv, work);          // Hs * sg
             rowdot(c.Hpl, LW, Fa, sgp, P, tmpl);              // Ws * sg_p
             double g2 = 0, jg2 = 0;
             for (int a = t; a < P; a += nt) { g2 += gradp[a] * gradp[a]; jg2 += sgp[a] * tmpv[a]; }
@@ -1538,7 +1586,7 @@ __global__ __launch_bounds__(1024) void be_solve_kernel(Batch B) {
                 PH(8);
                 for (int k = t; k < Kpad; k += nt) tmpl[k] = inv[k] * gls[k];
                 __syncthreads();
-                colsum(c.Hpl, LW, Fa, tmpl, P, tmpv);  // Ws^T (gls / hll)
+                colsum(c.Hpl, LW, Fa, tmpl, P, tmpv, work);  // Ws^T (gls / hll)
                 for (int a = t; a < LW; a += nt) xs[a] = a < P ? gs[a] - tmpv[a] : 0.0;
                 __syncthreads();
                 bool chol_ok = chol_blocked(c.Sc, LW, LW, &sh_i[2]);
@@ -1590,7 +1638,7 @@ __global__ __launch_bounds__(1024) void be_solve_kernel(Batch B) {
         n2 = block_sum(n2, sred);
         if (dogleg_norm < 0) dogleg_norm = sqrt(n2);
         // model cost change = -(step^T g' + 1/2 step^T H' step)
-        colsum(c.H, LW, P, stp, P, tmpv);
+        colsum(c.H, LW, P, stp, P, tmpv, work);
         rowdot(c.Hpl, LW, Fa, stp, P, tmpl);
         double lin = 0, quad = 0;
         for (int a = t; a < P; a += nt) { lin += stp[a] * gs[a]; quad += stp[a] * tmpv[a]; }
@@ -1713,8 +1761,8 @@ __global__ __launch_bounds__(1024) void be_solve_kernel(Batch B) {
 // Marginalisation in the canonical layout. Landmarks seen first in frame 0 are eliminated analytically (their block of
 // A_mm is diagonal), then pose_0/speedbias_0 (15) through a truncated eigen-decomposition, then the kept block is
 // re-factorised as J^T J by a second (parallel Jacobi) eigen-decomposition (marginalization_factor.cpp:276-308).
-__global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
-    const int s = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+__device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem_marg) {
+    const int t = threadIdx.x, nt = blockDim.x;
     Ctx c = make_ctx(B, s);
     const DevCfg &C = *B.cfg;
     const vio_config &cfg = C.c;
@@ -1723,11 +1771,9 @@ __global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
     const int W = c.W, W1 = W + 1, n = c.NPR;
     const double eps = 1e-8;
     __shared__ Params X;
-    __shared__ double sred[256];
     __shared__ double sdx[6 * VIO_MAXW + 16], srp[6 * VIO_MAXW + 16];
     __shared__ double cs[VIO_MAXW * 3 + 10], sn[VIO_MAXW * 3 + 10];
     __shared__ int pp[VIO_MAXW * 3 + 10], qq[VIO_MAXW * 3 + 10];
-    __shared__ int scratch[2 * 256 + 8];
     __shared__ double A15[225], V15[225], Pinv[225];
     __shared__ int newpresent[VIO_MAXW + 3];
     const bool second_new = be.marginalization_flag != 0;
@@ -2006,7 +2052,6 @@ __global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
     __syncthreads();
     PH(21);
     // symmetrised A_r and its eigenvectors live in LDS when they fit (n <= 96), else in HBM scratch
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_marg[];
     const bool in_lds = n <= 96;
     const int ldj = in_lds ? (n | 1) : n;  // odd leading dimension: conflict-free 64-bit LDS column access
     double *As = in_lds ? (double *)smem_marg : c.margA;
@@ -2048,16 +2093,14 @@ __global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
 }
 
 // ====================================================================================================== be_finish
-__global__ __launch_bounds__(256) void be_finish_kernel(Batch B) {
-    const int s = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+__device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
+    const int t = threadIdx.x, nt = blockDim.x;
     Ctx c = make_ctx(B, s);
     const DevCfg &C = *B.cfg;
     const vio_config &cfg = C.c;
     BeSeq &be = *c.be;
     const int W = c.W, W1 = W + 1;
-    __shared__ int scratch[2 * 256 + 8];
     __shared__ int sh_i[4];
-    __shared__ PreWork pw;
     double *od = B.odom + (size_t)s * 11;
     if (!be.processed) return;
     int nlm = be.n_lm;

@@ -2,6 +2,7 @@
 // There is no CPU fallback: every entry point fails with VIO_EDEVICE when HIP is unavailable.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 #include <mutex>
 #include <string>
 #include <string.h>
@@ -189,11 +190,11 @@ int launch_backend(vio_batch *h, const uint16_t *d_depth) {
     hipStream_t st = h->stream;
     be_ingest_kernel<<<S, 256, 0, st>>>(h->B, d_depth, (size_t)C.c.width * C.c.height);
     PEV(h, 8);
-    be_solve_kernel<<<S, 1024, h->lds_solve, st>>>(h->B);
+    static int be_threads = getenv("VIO_BE_THREADS") ? atoi(getenv("VIO_BE_THREADS")) : 1024;
+    be_solve_kernel<<<S, be_threads, h->lds_solve, st>>>(h->B);
     PEV(h, 9);
-    be_marg_kernel<<<S, 256, h->lds_marg, st>>>(h->B);
+    be_marg_kernel<<<S, 256, h->lds_marg, st>>>(h->B);  // marginalisation + window slide (be_finish is fused into it)
     PEV(h, 10);
-    be_finish_kernel<<<S, 256, 0, st>>>(h->B);
     PEV(h, 11);
     if (h->prof_cur >= 0) h->prof_cur++;
     HIPCHK(hipGetLastError());
@@ -335,9 +336,18 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
         int hmax = 0;
         for (int k = 0; k < C.ncells; k++) hmax = std::max(hmax, C.rect[k].h);
         h->lds_fast = (size_t)2 * amax + (size_t)(hmax + 2) * 4 + 16;
-        h->lds_solve = (size_t)C.LW * 8 + 16;
-        h->lds_marg = C.NPRIOR <= 96 ? (size_t)2 * C.NPRIOR * (C.NPRIOR | 1) * 8 + 16 : 16;
+        {
+            size_t npairs = (size_t)(C.W + 1) * C.W / 2;
+            size_t workd = std::max((size_t)C.W * 450, npairs * 210 <= 12288 ? npairs * 210 : (size_t)0);
+            workd = std::max(workd, (size_t)1400 /* PreWork */);
+            workd = std::max(workd, (size_t)4 * 336);
+            if (C.NPRIOR <= 96) workd = std::max(workd, (size_t)C.NPRIOR * (C.NPRIOR | 1) + 2);
+            h->lds_solve = ((size_t)C.LW + 2 + workd) * 8 + 16;
+            (void)hipFuncSetAttribute((const void *)be_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve);
+        }
+        h->lds_marg = C.NPRIOR <= 96 ? (size_t)C.NPRIOR * (C.NPRIOR | 1) * 8 + 64 : 64;
         (void)hipFuncSetAttribute((const void *)be_marg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_marg);
+
         (void)hipFuncSetAttribute((const void *)fe_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_select);
         (void)hipFuncSetAttribute((const void *)fe_add_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_add);
         (void)hipFuncSetAttribute((const void *)fe_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_fast);
