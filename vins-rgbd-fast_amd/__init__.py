@@ -277,8 +277,7 @@ class VioBatch:
         k = self._chk(self.L.vio_get_prior(self.h, seq, J.ctypes.data, r.ctypes.data, x0.ctypes.data, pres.ctypes.data), "vio_get_prior")
         return (J, r, x0, pres) if k else None
 
-    KERNELS = ("fe_begin", "fe_pyrdown", "fe_predict", "fe_lk", "fe_select", "fe_fast", "fe_add", "be_ingest", "be_solve", "be_marg",
-               "be_finish")
+    KERNELS = ("fe_begin", "fe_pyrdown", "fe_predict", "fe_lk", "fe_select", "fe_fast", "fe_add", "be_ingest", "be_solve", "be_marg")
 
     def profile_begin(self, max_steps):
         self._chk(self.L.vio_profile_begin(self.h, max_steps), "vio_profile_begin")

@@ -310,83 +310,98 @@ __device__ int jacobi_block(double *A, double *V, int n, int ld, double *cs, dou
 
 // Symmetric eigen-decomposition (Householder tridiagonalisation + implicit-shift QL, the algorithm class of
 // Eigen::SelfAdjointEigenSolver used at marginalization_factor.cpp:277,298).  V (n x n, ld) holds A on entry (lower
-// triangle is read) and the eigenvectors (columns) on exit; d = eigenvalues (unsorted), e = workspace; d/e in LDS.
-// The reduction is block-parallel; the QL iteration runs in one wavefront (lanes own rows of V, no block barriers).
-__device__ void sym_eig_tridiag(double *V, int n, int ld, double *d, double *e, double *gtmp, double *sred) {
-    const int t = threadIdx.x, nt = blockDim.x;
-    for (int j = t; j < n; j += nt) d[j] = V[(n - 1) * ld + j];
-    __syncthreads();
-    for (int i = n - 1; i > 0; i--) {
-        double sc = 0;
-        for (int k = t; k < i; k += nt) sc += fabs(d[k]);
-        sc = block_sum(sc, sred);
-        if (sc == 0.0) {
-            if (t == 0) e[i] = d[i - 1];
-            __syncthreads();
-            for (int j = t; j < i; j += nt) { d[j] = V[(i - 1) * ld + j]; V[i * ld + j] = 0.0; V[j * ld + i] = 0.0; }
-            if (t == 0) d[i] = 0.0;
-            __syncthreads();
-            continue;
-        }
-        double h = 0;
-        for (int k = t; k < i; k += nt) { double v = d[k] / sc; d[k] = v; h += v * v; }
-        h = block_sum(h, sred);
-        double f = d[i - 1];
-        double g = sqrt(h);
-        if (f > 0) g = -g;
-        h -= f * g;
-        __syncthreads();
-        if (t == 0) { e[i] = sc * g; d[i - 1] = f - g; }
-        __syncthreads();
-        // e[0..i) = A_sub * d using the lower triangle; V[j][i] = d[j]
-        for (int j = t; j < i; j += nt) {
-            double acc = 0;
-            for (int k = 0; k < i; k++) acc += (k <= j ? V[j * ld + k] : V[k * ld + j]) * d[k];
-            V[j * ld + i] = d[j];
-            e[j] = acc / h;
-        }
-        __syncthreads();
-        double ff = 0;
-        for (int j = t; j < i; j += nt) ff += e[j] * d[j];
-        ff = block_sum(ff, sred);
-        double hh = ff / (h + h);
-        for (int j = t; j < i; j += nt) e[j] -= hh * d[j];
-        __syncthreads();
-        for (int w = t; w < i * i; w += nt) {
-            int k = w / i, j = w - k * i;
-            if (j <= k) V[k * ld + j] -= (d[j] * e[k] + e[j] * d[k]);
-        }
-        __syncthreads();
-        for (int j = t; j < i; j += nt) { d[j] = V[(i - 1) * ld + j]; V[i * ld + j] = 0.0; }
-        if (t == 0) d[i] = h;
-        __syncthreads();
-    }
-    // accumulate the Householder transformations
-    for (int i = 0; i < n - 1; i++) {
-        if (t == 0) { V[(n - 1) * ld + i] = V[i * ld + i]; V[i * ld + i] = 1.0; }
-        double h = d[i + 1];
-        __syncthreads();
-        if (h != 0.0) {
-            for (int k = t; k <= i; k += nt) d[k] = V[k * ld + i + 1] / h;
-            __syncthreads();
-            for (int j = t; j <= i; j += nt) {
-                double g = 0;
-                for (int k = 0; k <= i; k++) g += V[k * ld + i + 1] * V[k * ld + j];
-                gtmp[j] = g;
+// triangle is read) and the eigenvectors (columns) on exit; d = eigenvalues (unsorted), e / gtmp = workspaces; all in LDS.
+// Everything runs in ONE wavefront: the algorithm is a chain of O(n) dependent steps, and wave-level ordering (no
+// workgroup barriers) is what makes it fast; the other waves of the block wait at the final barrier.
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+#define WAVE_SYNC() do { __builtin_amdgcn_wave_barrier(); __threadfence_block(); } while (0)
+__device__ void sym_eig_tridiag(double *__restrict__ V, int n, int ld, double *__restrict__ d, double *__restrict__ e, double *__restrict__ gtmp, double *sred) {
+    (void)sred;
+    if (threadIdx.x < 64) {
+        const int t = threadIdx.x, nt = 64;
+        for (int j = t; j < n; j += nt) d[j] = V[(n - 1) * ld + j];
+        WAVE_SYNC();
+        for (int i = n - 1; i > 0; i--) {
+            double sc = 0;
+            for (int k = t; k < i; k += nt) sc += fabs(d[k]);
+            sc = wave_sum(sc);
+            if (sc == 0.0) {
+                if (t == 0) e[i] = d[i - 1];
+                WAVE_SYNC();
+                for (int j = t; j < i; j += nt) { d[j] = V[(i - 1) * ld + j]; V[i * ld + j] = 0.0; V[j * ld + i] = 0.0; }
+                if (t == 0) d[i] = 0.0;
+                WAVE_SYNC();
+                continue;
             }
-            __syncthreads();
-            for (int w = t; w < (i + 1) * (i + 1); w += nt) {
-                int k = w / (i + 1), j = w - k * (i + 1);
-                V[k * ld + j] -= gtmp[j] * d[k];
+            double h = 0;
+            for (int k = t; k < i; k += nt) { double v = d[k] / sc; d[k] = v; h += v * v; }
+            h = wave_sum(h);
+            WAVE_SYNC();
+            double f = d[i - 1];
+            double g = sqrt(h);
+            if (f > 0) g = -g;
+            h -= f * g;
+            WAVE_SYNC();
+            if (t == 0) { e[i] = sc * g; d[i - 1] = f - g; }
+            WAVE_SYNC();
+            // e[0..i) = A_sub * d using the lower triangle; V[j][i] = d[j]
+            for (int j = t; j < i; j += nt) {
+                double acc = 0;
+#pragma unroll 8
+                for (int k = 0; k < i; k++) acc += (k <= j ? V[j * ld + k] : V[k * ld + j]) * d[k];
+                V[j * ld + i] = d[j];
+                e[j] = acc / h;
             }
-            __syncthreads();
+            WAVE_SYNC();
+            double ff = 0;
+            for (int j = t; j < i; j += nt) ff += e[j] * d[j];
+            ff = wave_sum(ff);
+            double hh = ff / (h + h);
+            for (int j = t; j < i; j += nt) e[j] -= hh * d[j];
+            WAVE_SYNC();
+            for (int k = t; k < i; k += nt) {  // row k of the lower triangle
+                double dk = d[k], ek = e[k];
+#pragma unroll 8
+                for (int j = 0; j <= k; j++) V[k * ld + j] -= (d[j] * ek + e[j] * dk);
+            }
+            WAVE_SYNC();
+            for (int j = t; j < i; j += nt) { d[j] = V[(i - 1) * ld + j]; V[i * ld + j] = 0.0; }
+            if (t == 0) d[i] = h;
+            WAVE_SYNC();
         }
-        for (int k = t; k <= i; k += nt) V[k * ld + i + 1] = 0.0;
-        __syncthreads();
+        // accumulate the Householder transformations
+        for (int i = 0; i < n - 1; i++) {
+            if (t == 0) { V[(n - 1) * ld + i] = V[i * ld + i]; V[i * ld + i] = 1.0; }
+            double h = d[i + 1];
+            WAVE_SYNC();
+            if (h != 0.0) {
+                for (int k = t; k <= i; k += nt) d[k] = V[k * ld + i + 1] / h;
+                WAVE_SYNC();
+                for (int j = t; j <= i; j += nt) {
+                    double g = 0;
+#pragma unroll 8
+                    for (int k = 0; k <= i; k++) g += V[k * ld + i + 1] * V[k * ld + j];
+                    gtmp[j] = g;
+                }
+                WAVE_SYNC();
+                for (int k = t; k <= i; k += nt) {
+                    double dk = d[k];
+#pragma unroll 8
+                    for (int j = 0; j <= i; j++) V[k * ld + j] -= gtmp[j] * dk;
+                }
+                WAVE_SYNC();
+            }
+            for (int k = t; k <= i; k += nt) V[k * ld + i + 1] = 0.0;
+            WAVE_SYNC();
+        }
+        for (int j = t; j < n; j += nt) { d[j] = V[(n - 1) * ld + j]; V[(n - 1) * ld + j] = 0.0; }
+        WAVE_SYNC();
+        if (t == 0) { V[(n - 1) * ld + n - 1] = 1.0; e[0] = 0.0; }
+        WAVE_SYNC();
     }
-    for (int j = t; j < n; j += nt) { d[j] = V[(n - 1) * ld + j]; V[(n - 1) * ld + j] = 0.0; }
-    __syncthreads();
-    if (t == 0) { V[(n - 1) * ld + n - 1] = 1.0; e[0] = 0.0; }
     __syncthreads();
 }
 
@@ -425,6 +440,8 @@ __device__ void tridiag_ql_wave(double *V, int n, int ld, double *d, double *e) 
                     f += h;
                     p = d[m];
                     double c = 1.0, c2 = 1.0, c3 = 1.0, el1 = e[l + 1], s = 0.0, s2 = 0.0;
+                    const int r0 = lane < n ? lane : 0, r1 = lane + 64 < n ? lane + 64 : r0;  // n <= 128; duplicates write equal values
+                    double car0 = V[r0 * ld + m], car1 = V[r1 * ld + m];
                     for (int i = m - 1; i >= l; i--) {
                         c3 = c2; c2 = c; s2 = s;
                         double ei = e[i], di = d[i];
@@ -436,16 +453,17 @@ __device__ void tridiag_ql_wave(double *V, int n, int ld, double *d, double *e) 
                         c = p / r;
                         p = c * di - s * g;
                         double d_ip1 = h + s * (c * g + s * di);
-                        __builtin_amdgcn_wave_barrier();
-                        if (lane == 0) { e[i + 1] = e_ip1; d[i + 1] = d_ip1; }
-                        for (int k = lane; k < n; k += 64) {
-                            double hv = V[k * ld + i + 1], vi = V[k * ld + i];
-                            V[k * ld + i + 1] = s * vi + c * hv;
-                            V[k * ld + i] = c * vi - s * hv;
+                        if (lane == 0) { e[i + 1] = e_ip1; d[i + 1] = d_ip1; }  // read again only after the sweep's fence
+                        {   // rows lane and lane+64 of V: the rotated column i is carried in registers to the next rotation
+                            double vi0 = V[r0 * ld + i], vi1 = V[r1 * ld + i];
+                            V[r0 * ld + i + 1] = s * vi0 + c * car0;
+                            V[r1 * ld + i + 1] = s * vi1 + c * car1;
+                            car0 = c * vi0 - s * car0;
+                            car1 = c * vi1 - s * car1;
                         }
-                        __builtin_amdgcn_wave_barrier();
-                        __threadfence_block();
                     }
+                    V[r0 * ld + l] = car0;
+                    V[r1 * ld + l] = car1;
                     p = -s * s2 * c3 * el1 * e[l] / dl1;
                     __builtin_amdgcn_wave_barrier();
                     if (lane == 0) { e[l] = s * p; d[l] = c * p; }
@@ -737,12 +755,16 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
     __shared__ int scratch[2 * 256 + 8];
     __shared__ double sred[256];
     __shared__ PreWork pw;
-    if (t == 0) { be.do_solve = 0; be.do_marg = 0; be.processed = 0; }
+    if (t == 0) {
+        be.do_solve = 0; be.do_marg = 0; be.processed = 0; be.status_code = fe.n_forw == -2 ? VIO_NEED_IMU : VIO_OK; be.cur_stamp = fe.cur_time;
+        if (be.imu_count - be.imu_head > C.NIMU) be.imu_head = be.imu_count - C.NIMU;  // samples overwritten in the ring
+    }
+    __syncthreads();
     if (fe.n_forw < 0 || !fe.publish_ok) return;
     // ---- IMU availability (estimator.cpp:178-183, :1882-1888)
     const double *it = B.imu_t + (size_t)s * C.NIMU;
     const double *ia = B.imu_acc + (size_t)s * C.NIMU * 3, *ig = B.imu_gyr + (size_t)s * C.NIMU * 3;
-    double stamp = be.cur_stamp, curTime = stamp + be.td;
+    double stamp = fe.cur_time, curTime = stamp + be.td;
     {
         bool have = be.imu_count > be.imu_head;
         double back_t = have ? it[(be.imu_count - 1) % C.NIMU] : -1e300;
@@ -1740,6 +1762,9 @@ __device__ void solve_body(const Batch &B, int s, int *scratch, double *sred, un
         st3(be.Ps[i], add(mul(rot_diff, mk(X.pose[i * 7] - X.pose[0], X.pose[i * 7 + 1] - X.pose[1], X.pose[i * 7 + 2] - X.pose[2])), origin_P0));
         st3(be.Vs[i], mul(rot_diff, mk(X.sb[i * 9], X.sb[i * 9 + 1], X.sb[i * 9 + 2])));
         for (int k = 0; k < 3; k++) { be.Bas[i][k] = X.sb[i * 9 + 3 + k]; be.Bgs[i][k] = X.sb[i * 9 + 6 + k]; }
+        // updateLatestStates (estimator.cpp:1768-1776): latest_Bg feeds predictMotion of the next frame, whose front-end may
+        // start as soon as this kernel is done (overlapping the marginalisation)
+        if (i == W) for (int k = 0; k < 3; k++) be.latest_Bg[k] = X.sb[i * 9 + 6 + k];
     }
     if (t == W + 1) {
         be.tic[0] = X.ex[0]; be.tic[1] = X.ex[1]; be.tic[2] = X.ex[2];
@@ -2061,7 +2086,9 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
     long long tj0 = wall_clock64();
     __shared__ double ev_d[6 * VIO_MAXW + 16], ev_e[6 * VIO_MAXW + 16], ev_g[6 * VIO_MAXW + 16];
     sym_eig_tridiag(As, n, ldj, ev_d, ev_e, ev_g, sred);
+    if (t == 0) be.dbg[5] = (int)(wall_clock64() - tj0);
     tridiag_ql_wave(As, n, ldj, ev_d, ev_e);
+    if (t == 0) be.dbg[6] = (int)(wall_clock64() - tj0);
     Vv = As;  // eigenvectors overwrite the matrix
     if (t == 0) { be.dbg[0] = 0; be.dbg[1] = (int)(wall_clock64() - tj0); be.dbg[2] = second_new ? 1 : 0; }
     PH(22);
@@ -2110,7 +2137,7 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
     __syncthreads();
     if (sflag0 == 0) {
         if (fc == W && be.do_solve) {
-            if (t == 0) { st3(be.latest_Bg, ld3(be.Bgs[fc])); be.solver_flag = 1; }
+            if (t == 0) be.solver_flag = 1;
             __syncthreads();
         } else {
             // frame_count < WINDOW_SIZE: copy the state forward (estimator.cpp:306-315)
@@ -2287,7 +2314,6 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
     if (t == 0) {
         for (int k = 0; k < 9; k++) { be.last_R[k] = be.Rs[W][k]; be.last_R0[k] = be.Rs[0][k]; }
         for (int k = 0; k < 3; k++) { be.last_P[k] = be.Ps[W][k]; be.last_P0[k] = be.Ps[0][k]; }
-        st3(be.latest_Bg, ld3(be.Bgs[W]));
         // CSV row of visualization.cpp:214-225
         quat q = R2q(ldm(be.Rs[W]));
         od[0] = be.Headers[W];

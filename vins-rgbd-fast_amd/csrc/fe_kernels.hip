@@ -74,26 +74,22 @@ __global__ void fe_begin_kernel(Batch B, const double *stamps, int gate) {
     if (threadIdx.x != 0) return;
     const DevCfg &C = *B.cfg;
     FeSeq &fe = B.fe[s];
-    BeSeq &be = B.be[s];
+    const BeSeq &be = B.be[s];  // read-only here: the previous frame's marginalisation may still be running on the other stream
     double t = stamps[s];
     fe.n_deficit = 0;
     fe.n_obs = 0;
     fe.publish_ok = 0;
-    be.processed = 0;
-    be.status_code = VIO_OK;
-    be.cur_stamp = t;
     // ring bookkeeping: drop samples that were overwritten
-    if (be.imu_count - be.imu_head > C.NIMU) be.imu_head = be.imu_count - C.NIMU;
+    int imu_head = be.imu_head;
+    if (be.imu_count - imu_head > C.NIMU) imu_head = be.imu_count - C.NIMU;
     const double *it = B.imu_t + (size_t)s * C.NIMU;
     const double *ig = B.imu_gyr + (size_t)s * C.NIMU * 3;
-    bool have = be.imu_count > be.imu_head;
+    bool have = be.imu_count > imu_head;
     double back_t = have ? it[(be.imu_count - 1) % C.NIMU] : -1e300;
     if (gate) {
         // caller contract of vio_feed: IMU pushed through stamp + td (upstream busy-waits, estimator.cpp:178-183)
         if (!(have && t + be.td <= back_t)) {
-            be.status_code = VIO_NEED_IMU;
-            fe.first_image_flag = fe.first_image_flag;  // nothing consumed
-            fe.n_forw = -1;                             // tells the later kernels to skip this sequence
+            fe.n_forw = -2;  // nothing consumed; tells the later kernels to skip this sequence (be_ingest reports VIO_NEED_IMU)
             return;
         }
         if (fe.first_image_flag) {  // estimator_nodelet.cpp:234-240
@@ -107,7 +103,7 @@ __global__ void fe_begin_kernel(Batch B, const double *stamps, int gate) {
     dm::m3 rel = dm::eye();
     double t0 = fe.last_image_time, t1 = t + be.td;
     if (have && t1 <= back_t) {
-        int k = be.imu_head;
+        int k = imu_head;
         while (k < be.imu_count && it[k % C.NIMU] <= t0) k++;
         bool first = true;
         double prev_t = 0;

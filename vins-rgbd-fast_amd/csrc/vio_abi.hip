@@ -40,7 +40,10 @@ struct vio_batch {
     DevCfg hc;  // host copy
     Batch B;
     int S;
-    hipStream_t stream;
+    hipStream_t stream;     // back-end (and uploads that feed it)
+    hipStream_t fe_stream;  // front-end: frame k+1 tracks while frame k is still being marginalised
+    hipEvent_t ev_solve, ev_fe, ev_be;
+    bool have_solve_ev = false;
     hipEvent_t ev[4];
     std::vector<void *> allocs;
     uint8_t *d_gray_stage = nullptr;
@@ -60,8 +63,9 @@ struct vio_batch {
     std::vector<hipEvent_t> pev;
     int prof_steps = 0, prof_cur = -1;
 };
-#define VIO_NK 11  // kernels per vio_feed: fe_begin pyrdown predict lk select fast add | be_ingest solve marg finish
-#define PEV(h, k) do { if ((h)->prof_cur >= 0 && (h)->prof_cur < (h)->prof_steps) (void)hipEventRecord((h)->pev[(size_t)(h)->prof_cur * (VIO_NK + 1) + (k)], (h)->stream); } while (0)
+#define VIO_NK 10  // kernels per vio_feed: fe_begin pyrdown predict lk select fast add | be_ingest solve marg(+finish)
+#define VIO_NEV 12 // events per step: 0..7 bracket the front-end kernels on fe_stream, 8..11 the back-end kernels on stream
+#define PEV(h, k) do { if ((h)->prof_cur >= 0 && (h)->prof_cur < (h)->prof_steps) (void)hipEventRecord((h)->pev[(size_t)(h)->prof_cur * VIO_NEV + (k)], (k) <= 7 ? (h)->fe_stream : (h)->stream); } while (0)
 
 __global__ void imu_scatter_kernel(Batch B, int total, const int *seq_of, const double *t, const double *acc, const double *gyr) {
     // samples are grouped by sequence in push order; one thread per sequence walks its run (keeps ring order)
@@ -156,7 +160,7 @@ int flush_imu(vio_batch *h) {
 int launch_frontend(vio_batch *h, const uint8_t *d_gray, int publish, int gate) {
     const DevCfg &C = h->hc;
     const int S = h->S, Wd = C.c.width, Ht = C.c.height;
-    hipStream_t st = h->stream;
+    hipStream_t st = h->fe_stream;
     PEV(h, 0);
     fe_begin_kernel<<<S, 64, 0, st>>>(h->B, h->d_stamps, gate);
     PEV(h, 1);
@@ -188,13 +192,15 @@ int launch_backend(vio_batch *h, const uint16_t *d_depth) {
     const DevCfg &C = h->hc;
     const int S = h->S;
     hipStream_t st = h->stream;
-    be_ingest_kernel<<<S, 256, 0, st>>>(h->B, d_depth, (size_t)C.c.width * C.c.height);
     PEV(h, 8);
+    be_ingest_kernel<<<S, 256, 0, st>>>(h->B, d_depth, (size_t)C.c.width * C.c.height);
+    PEV(h, 9);
     static int be_threads = getenv("VIO_BE_THREADS") ? atoi(getenv("VIO_BE_THREADS")) : 1024;
     be_solve_kernel<<<S, be_threads, h->lds_solve, st>>>(h->B);
-    PEV(h, 9);
-    be_marg_kernel<<<S, 256, h->lds_marg, st>>>(h->B);  // marginalisation + window slide (be_finish is fused into it)
     PEV(h, 10);
+    (void)hipEventRecord(h->ev_solve, st);  // the next frame's front-end may start here (it only needs latest_Bg / td / ric)
+    h->have_solve_ev = true;
+    be_marg_kernel<<<S, 256, h->lds_marg, st>>>(h->B);  // marginalisation + window slide (be_finish is fused into it)
     PEV(h, 11);
     if (h->prof_cur >= 0) h->prof_cur++;
     HIPCHK(hipGetLastError());
@@ -324,10 +330,13 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     DA(h->d_stamps, S);
 #undef DA
     if (rc == VIO_OK && hipMemcpy(B.cfg, &h->hc, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) { g_err = "cfg upload failed"; rc = VIO_EDEVICE; }
-    if (rc == VIO_OK && hipStreamCreate(&h->stream) != hipSuccess) { g_err = "stream create failed"; rc = VIO_EDEVICE; }
+    if (rc == VIO_OK && (hipStreamCreate(&h->stream) != hipSuccess || hipStreamCreate(&h->fe_stream) != hipSuccess)) { g_err = "stream create failed"; rc = VIO_EDEVICE; }
+    if (rc == VIO_OK && (hipEventCreateWithFlags(&h->ev_solve, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ev_fe, hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&h->ev_be, hipEventDisableTiming) != hipSuccess)) { g_err = "event create failed"; rc = VIO_EDEVICE; }
     for (int i = 0; i < 4 && rc == VIO_OK; i++)
         if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_err = "event create failed"; rc = VIO_EDEVICE; }
     if (rc == VIO_OK) rc = init_state(h);
+    if (rc == VIO_OK) (void)hipEventRecord(h->ev_be, h->stream);
     if (rc == VIO_OK) {
         h->lds_select = (size_t)C.NP * 104 + 260 * 4 + 64;
         h->lds_add = (size_t)C.NP * 16 + 3 * VIO_FAST_CAP * 4 + 260 * 4 + 64 * 4 + 64;
@@ -365,12 +374,14 @@ void vio_destroy(vio_batch *h) {
     if (h->d_pseq) { (void)hipFree(h->d_pseq); (void)hipFree(h->d_pt); (void)hipFree(h->d_pacc); (void)hipFree(h->d_pgyr); }
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->fe_stream) (void)hipStreamDestroy(h->fe_stream);
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
 }
 
 int vio_reset(vio_batch *h) {
     if (!h) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->fe_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     // zero the tracker / landmark / prior state that init_state does not rewrite
     const DevCfg &C = h->hc;
@@ -395,11 +406,11 @@ static int stage_inputs(vio_batch *h, const uint8_t *gray, const uint16_t *depth
                         const uint8_t **dg, const uint16_t **dd) {
     const DevCfg &C = h->hc;
     size_t HW = (size_t)C.c.width * C.c.height, S = h->S;
-    if (stamps) HIPCHK(hipMemcpyAsync(h->d_stamps, stamps, S * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (stamps) HIPCHK(hipMemcpyAsync(h->d_stamps, stamps, S * sizeof(double), hipMemcpyHostToDevice, h->fe_stream));
     if (on_device) { *dg = gray; *dd = depth; return VIO_OK; }
     if (gray) {
         if (!h->d_gray_stage) HIPCHK(hipMalloc((void **)&h->d_gray_stage, S * HW));
-        HIPCHK(hipMemcpyAsync(h->d_gray_stage, gray, S * HW, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_gray_stage, gray, S * HW, hipMemcpyHostToDevice, h->fe_stream));
         *dg = h->d_gray_stage;
     }
     if (depth) {
@@ -410,18 +421,31 @@ static int stage_inputs(vio_batch *h, const uint8_t *gray, const uint16_t *depth
     return VIO_OK;
 }
 
+// front-end of this frame may overlap the marginalisation of the previous one: it waits only for the previous solve
+static int fe_wait(vio_batch *h) {
+    if (h->have_solve_ev) HIPCHK(hipStreamWaitEvent(h->fe_stream, h->ev_solve, 0));
+    return VIO_OK;
+}
+static int be_wait(vio_batch *h) {
+    HIPCHK(hipEventRecord(h->ev_fe, h->fe_stream));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_fe, 0));
+    return VIO_OK;
+}
+
 int vio_feed(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, int on_device) {
     if (!h || !gray || !depth_mm || !stamps) return VIO_EINVAL;
     int rc = flush_imu(h);
     if (rc != VIO_OK) return rc;
+    if ((rc = fe_wait(h)) != VIO_OK) return rc;
     const uint8_t *dg = nullptr;
     const uint16_t *dd = nullptr;
     rc = stage_inputs(h, gray, depth_mm, stamps, on_device, &dg, &dd);
     if (rc != VIO_OK) return rc;
-    HIPCHK(hipEventRecord(h->ev[0], h->stream));
+    HIPCHK(hipEventRecord(h->ev[0], h->fe_stream));
     rc = launch_frontend(h, dg, 1, 1);
     if (rc != VIO_OK) return rc;
-    HIPCHK(hipEventRecord(h->ev[1], h->stream));
+    HIPCHK(hipEventRecord(h->ev[1], h->fe_stream));
+    if ((rc = be_wait(h)) != VIO_OK) return rc;
     rc = launch_backend(h, dd);
     if (rc != VIO_OK) return rc;
     HIPCHK(hipEventRecord(h->ev[2], h->stream));
@@ -433,11 +457,15 @@ int vio_track(vio_batch *h, const uint8_t *gray, const double *stamps, int publi
     if (!h || !gray || !stamps) return VIO_EINVAL;
     int rc = flush_imu(h);
     if (rc != VIO_OK) return rc;
+    if ((rc = fe_wait(h)) != VIO_OK) return rc;
+    HIPCHK(hipStreamWaitEvent(h->fe_stream, h->ev_be, 0));  // stand-alone use: no overlap with a pending vio_process
     const uint8_t *dg = nullptr;
     const uint16_t *dd = nullptr;
     rc = stage_inputs(h, gray, nullptr, stamps, on_device, &dg, &dd);
     if (rc != VIO_OK) return rc;
-    return launch_frontend(h, dg, publish ? 1 : 0, 0);
+    rc = launch_frontend(h, dg, publish ? 1 : 0, 0);
+    if (rc != VIO_OK) return rc;
+    return be_wait(h);
 }
 
 int vio_process(vio_batch *h, const uint16_t *depth_mm, int on_device) {
@@ -448,11 +476,15 @@ int vio_process(vio_batch *h, const uint16_t *depth_mm, int on_device) {
     const uint16_t *dd = nullptr;
     rc = stage_inputs(h, nullptr, depth_mm, nullptr, on_device, &dg, &dd);
     if (rc != VIO_OK) return rc;
-    return launch_backend(h, dd);
+    rc = launch_backend(h, dd);
+    if (rc != VIO_OK) return rc;
+    HIPCHK(hipEventRecord(h->ev_be, h->stream));
+    return VIO_OK;
 }
 
 int vio_sync(vio_batch *h) {
     if (!h) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->fe_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return VIO_OK;
 }
@@ -460,6 +492,7 @@ void *vio_get_stream(vio_batch *h) { return h ? (void *)h->stream : nullptr; }
 
 int vio_get_status(vio_batch *h, int seq, vio_status *out) {
     if (!h || seq < 0 || seq >= h->S || !out) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->fe_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     static thread_local BeSeq be;
     static thread_local FeSeq fe;
@@ -476,6 +509,7 @@ int vio_get_status(vio_batch *h, int seq, vio_status *out) {
 
 int vio_get_window(vio_batch *h, int seq, double *out) {
     if (!h || seq < 0 || seq >= h->S || !out) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->fe_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     static thread_local BeSeq be;
     HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
@@ -492,6 +526,7 @@ int vio_get_window(vio_batch *h, int seq, double *out) {
 
 int vio_get_odometry(vio_batch *h, double *out) {
     if (!h || !out) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->fe_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipMemcpy(out, h->B.odom, sizeof(double) * (size_t)h->S * 11, hipMemcpyDeviceToHost));
     return VIO_OK;
@@ -499,6 +534,7 @@ int vio_get_odometry(vio_batch *h, double *out) {
 
 int vio_get_odometry_history(vio_batch *h, int seq, int cap, double *out) {
     if (!h || seq < 0 || seq >= h->S || !out) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->fe_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     int n = 0;
     HIPCHK(hipMemcpy(&n, h->B.odom_count + seq, sizeof(int), hipMemcpyDeviceToHost));
@@ -510,6 +546,7 @@ int vio_get_odometry_history(vio_batch *h, int seq, int cap, double *out) {
 
 int vio_get_extrinsic(vio_batch *h, int seq, double *out13) {
     if (!h || seq < 0 || seq >= h->S || !out13) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->fe_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     static thread_local BeSeq be;
     HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
@@ -521,6 +558,7 @@ int vio_get_extrinsic(vio_batch *h, int seq, double *out13) {
 
 int vio_get_tracks(vio_batch *h, int seq, int cap, int32_t *ids, int32_t *cnt, float *cur, float *un, float *vel) {
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->fe_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     static thread_local FeSeq fe;
     HIPCHK(hipMemcpy(&fe, h->B.fe + seq, sizeof(FeSeq), hipMemcpyDeviceToHost));
@@ -538,6 +576,7 @@ int vio_get_tracks(vio_batch *h, int seq, int cap, int32_t *ids, int32_t *cnt, f
 
 int vio_get_landmarks(vio_batch *h, int seq, int cap, double *out) {
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->fe_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     static thread_local BeSeq be;
     HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
@@ -563,6 +602,7 @@ int vio_get_landmarks(vio_batch *h, int seq, int cap, double *out) {
 
 int vio_get_prior(vio_batch *h, int seq, double *J, double *r, double *x0, uint8_t *present) {
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->fe_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     static thread_local BeSeq be;
     HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
@@ -578,6 +618,7 @@ int vio_get_prior(vio_batch *h, int seq, double *J, double *r, double *x0, uint8
 int vio_get_timings(vio_batch *h, int cap, double *out_ms) {
     if (!h || !out_ms || cap < 3) return VIO_EINVAL;
     if (!h->timing_valid) return 0;
+    HIPCHK(hipStreamSynchronize(h->fe_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     float a = 0, b = 0;
     HIPCHK(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
@@ -588,6 +629,7 @@ int vio_get_timings(vio_batch *h, int cap, double *out_ms) {
 
 int vio_debug_seq(vio_batch *h, int seq, int *out16) {
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->fe_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     static thread_local BeSeq be;
     HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
@@ -598,6 +640,7 @@ int vio_debug_seq(vio_batch *h, int seq, int *out16) {
 // debug: accumulated in-kernel phase ticks (100 MHz) of sequence 0; reset != 0 clears them
 int vio_debug_phases(vio_batch *h, float *out64, int reset) {
     if (!h) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->fe_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (out64) HIPCHK(hipMemcpy(out64, h->B.timings, 64 * sizeof(float), hipMemcpyDeviceToHost));
     if (reset) HIPCHK(hipMemset(h->B.timings, 0, 64 * sizeof(float)));
@@ -607,7 +650,7 @@ int vio_debug_phases(vio_batch *h, float *out64, int reset) {
 // per-kernel HIP-event profile of the next max_steps vio_feed calls (events sit on the batch stream)
 int vio_profile_begin(vio_batch *h, int max_steps) {
     if (!h || max_steps < 1) return VIO_EINVAL;
-    size_t need = (size_t)max_steps * (VIO_NK + 1);
+    size_t need = (size_t)max_steps * VIO_NEV;
     while (h->pev.size() < need) {
         hipEvent_t e;
         HIPCHK(hipEventCreate(&e));
@@ -620,13 +663,16 @@ int vio_profile_begin(vio_batch *h, int max_steps) {
 // out_ms[k] = average duration of kernel k over the recorded steps (ms); returns the number of recorded steps
 int vio_profile_end(vio_batch *h, int cap, double *out_ms) {
     if (!h || !out_ms || cap < VIO_NK) return VIO_EINVAL;
+    HIPCHK(hipStreamSynchronize(h->fe_stream));
+    HIPCHK(hipStreamSynchronize(h->fe_stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     int n = h->prof_cur < h->prof_steps ? h->prof_cur : h->prof_steps;
+    static const int e0[VIO_NK] = {0, 1, 2, 3, 4, 5, 6, 8, 9, 10}, e1[VIO_NK] = {1, 2, 3, 4, 5, 6, 7, 9, 10, 11};
     for (int k = 0; k < VIO_NK; k++) out_ms[k] = 0;
     for (int i = 0; i < n; i++)
         for (int k = 0; k < VIO_NK; k++) {
             float ms = 0;
-            HIPCHK(hipEventElapsedTime(&ms, h->pev[(size_t)i * (VIO_NK + 1) + k], h->pev[(size_t)i * (VIO_NK + 1) + k + 1]));
+            HIPCHK(hipEventElapsedTime(&ms, h->pev[(size_t)i * VIO_NEV + e0[k]], h->pev[(size_t)i * VIO_NEV + e1[k]]));
             out_ms[k] += ms;
         }
     for (int k = 0; k < VIO_NK; k++) out_ms[k] = n > 0 ? out_ms[k] / n : 0;
