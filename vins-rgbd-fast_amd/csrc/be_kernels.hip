@@ -541,8 +541,9 @@ __device__ __forceinline__ void tri_decode(int idx, int &ti, int &tj) {
     ti = r; tj = idx;
 }
 
-// S = Hs + mu*diag(dgp^2) - sum_k (Ws[k][:] * inv[k])^T Ws[k][:]   (lower tiles only), v_mfma_f64_16x16x4_f64.
-// Hs: scaled H (ld), Ws: scaled landmark coupling rows (ld), Kpad rows (multiple of 4, rows >= Fa are zero), inv[k] = 1/hllr[k].
+// S = S_p H S_p + mu*diag(dgp^2) - sum_k inv[k] (S_p Hpl[k][:])^T (S_p Hpl[k][:])   (lower tiles only), v_mfma_f64_16x16x4_f64.
+// Hs / Ws: the UNSCALED H and landmark coupling rows (ld); the Jacobi column scaling sp is applied while loading the MFMA
+// operands. Kpad rows (multiple of 4, rows >= Fa are zero), inv[k] = sl[k]^2 / hllr[k].
 __device__ void schur_mfma(const double *Hs, const double *Ws, const double *inv, const double *dgp, const double *sp, double mu,
                            int Kpad, int n /*multiple of 16*/, int ld, double *Sc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -554,15 +555,16 @@ __device__ void schur_mfma(const double *Hs, const double *Ws, const double *inv
         v4f64 acc;
         for (int r = 0; r < 4; r++) {
             int row = 16 * ti + lk + 4 * r, col = 16 * tj + li;
-            double v = Hs[(size_t)row * ld + col];
+            double v = sp[row] * sp[col] * Hs[(size_t)row * ld + col];
             if (row == col) { v += mu * dgp[row] * dgp[row]; if (sp[row] == 0.0) v = 1.0; }
             acc[r] = v;
         }
         const double *wa = Ws + 16 * ti + li, *wb = Ws + 16 * tj + li;
+        const double spa = sp[16 * ti + li], spb = sp[16 * tj + li];
         for (int k0 = 0; k0 < Kpad; k0 += 4) {
             int kk = k0 + lk;
-            double a = -(wa[(size_t)kk * ld] * inv[kk]);
-            double b = wb[(size_t)kk * ld];
+            double a = -(wa[(size_t)kk * ld] * spa * inv[kk]);
+            double b = wb[(size_t)kk * ld] * spb;
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
         }
         for (int r = 0; r < 4; r++) Sc[(size_t)(16 * ti + lk + 4 * r) * ld + 16 * tj + li] = acc[r];
@@ -570,10 +572,154 @@ __device__ void schur_mfma(const double *Hs, const double *Ws, const double *inv
     __syncthreads();
 }
 
+// ------------------------------------------------------------------ Schur complement + Cholesky with S resident in LDS
+// S (n x n, n = 16 nb) is kept as its nb(nb+1)/2 lower 16x16 tiles in LDS; element (r, c) of tile (ti, tj) lives at
+// tile_base + r*16 + (c ^ r): the XOR swizzle makes both row-wise and column-wise 64-bit accesses bank-conflict free.
+__device__ __forceinline__ int tl_idx(int ti, int tj, int r, int c) { return ((ti * (ti + 1) / 2 + tj) << 8) + (r << 4) + (c ^ r); }
+
+__device__ void schur_mfma_lds(const double *Hs, const double *Ws, const double *inv, const double *dgp, const double *sp, double mu,
+                               int Kpad, int n, int ld, double *T) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nb = n >> 4, ntile = nb * (nb + 1) / 2;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int tile = wave; tile < ntile; tile += nw) {
+        int ti, tj;
+        tri_decode(tile, ti, tj);
+        v4f64 acc;
+        for (int r = 0; r < 4; r++) {
+            int row = 16 * ti + lk + 4 * r, col = 16 * tj + li;
+            double v = sp[row] * sp[col] * Hs[(size_t)row * ld + col];
+            if (row == col) { v += mu * dgp[row] * dgp[row]; if (sp[row] == 0.0) v = 1.0; }
+            acc[r] = v;
+        }
+        const double *wa = Ws + 16 * ti + li, *wb = Ws + 16 * tj + li;
+        const double spa = sp[16 * ti + li], spb = sp[16 * tj + li];
+        for (int k0 = 0; k0 < Kpad; k0 += 4) {
+            int kk = k0 + lk;
+            double a = -(wa[(size_t)kk * ld] * spa * inv[kk]);
+            double b = wb[(size_t)kk * ld] * spb;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        for (int r = 0; r < 4; r++) T[tl_idx(ti, tj, lk + 4 * r, li)] = acc[r];
+    }
+    __syncthreads();
+}
+
+__device__ bool chol_tiles(double *T, int nb, int *sh_flag) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    if (t == 0) *sh_flag = 1;
+    __syncthreads();
+    for (int p = 0; p < nb; p++) {
+        // (a) 16x16 diagonal block: lanes 0..15 of one wavefront hold one row each in registers, shuffles broadcast pivots
+        if (wave == 0) {
+            const int row = lane & 15;
+            double a[16];
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) a[cc] = T[tl_idx(p, p, row, cc)];
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                double ajj = __shfl(a[j], j, 64);
+                if (!(ajj > 0.0) || !isfinite(ajj)) ok = false;
+                double l = sqrt(ajj);
+                if (row == j) a[j] = l; else if (row > j) a[j] = a[j] / l;
+#pragma unroll
+                for (int k = j + 1; k < 16; k++) {
+                    double akj = __shfl(a[j], k, 64);
+                    if (row >= k) a[k] -= a[j] * akj;
+                }
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int cc = 0; cc < 16; cc++) if (cc <= row) T[tl_idx(p, p, row, cc)] = a[cc];
+            }
+            if (!ok && lane == 0) *sh_flag = 0;
+        }
+        __syncthreads();
+        if (!*sh_flag) return false;
+        // (b) panel: rows of the tiles below solve x L_pp^T = a
+        for (int q = t; q < 16 * (nb - 1 - p); q += nt) {
+            int ti = p + 1 + (q >> 4), r = q & 15;
+            double x[16];
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) {
+                double s = T[tl_idx(ti, p, r, cc)];
+#pragma unroll
+                for (int k = 0; k < cc; k++) s -= x[k] * T[tl_idx(p, p, cc, k)];
+                x[cc] = s / T[tl_idx(p, p, cc, cc)];
+            }
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) T[tl_idx(ti, p, r, cc)] = x[cc];
+        }
+        __syncthreads();
+        // (c) trailing update S22 -= L21 L21^T on the FP64 matrix cores
+        const int m = nb - 1 - p, ntile = m * (m + 1) / 2;
+        const int li = lane & 15, lk = lane >> 4;
+        for (int tile = wave; tile < ntile; tile += nw) {
+            int ti, tj;
+            tri_decode(tile, ti, tj);
+            ti += p + 1; tj += p + 1;
+            v4f64 acc;
+            for (int r = 0; r < 4; r++) acc[r] = T[tl_idx(ti, tj, lk + 4 * r, li)];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[tl_idx(ti, p, li, 4 * kk + lk)], T[tl_idx(tj, p, li, 4 * kk + lk)], acc, 0, 0, 0);
+            for (int r = 0; r < 4; r++) T[tl_idx(ti, tj, lk + 4 * r, li)] = acc[r];
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
+__device__ void chol_solve_tiles(const double *T, int nb, double *xs) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6;
+    for (int p = 0; p < nb; p++) {  // forward: L y = b
+        if (wave == 0) {
+            const int row = lane & 15;
+            double b = xs[16 * p + row];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                double xj = __shfl(b, j, 64) / T[tl_idx(p, p, j, j)];
+                if (row == j) b = xj; else if (row > j) b -= T[tl_idx(p, p, row, j)] * xj;
+            }
+            if (lane < 16) xs[16 * p + row] = b;
+        }
+        __syncthreads();
+        for (int q = t; q < 16 * (nb - 1 - p); q += nt) {
+            int ti = p + 1 + (q >> 4), r = q & 15;
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) s += T[tl_idx(ti, p, r, k)] * xs[16 * p + k];
+            xs[16 * ti + r] -= s;
+        }
+        __syncthreads();
+    }
+    for (int p = nb - 1; p >= 0; p--) {  // backward: L^T x = y
+        if (wave == 0) {
+            const int row = lane & 15;
+            double b = xs[16 * p + row];
+#pragma unroll
+            for (int j = 15; j >= 0; j--) {
+                double xj = __shfl(b, j, 64) / T[tl_idx(p, p, j, j)];
+                if (row == j) b = xj; else if (row < j) b -= T[tl_idx(p, p, j, row)] * xj;
+            }
+            if (lane < 16) xs[16 * p + row] = b;
+        }
+        __syncthreads();
+        for (int q = t; q < 16 * p; q += nt) {
+            int tj = q >> 4, cc = q & 15;
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) s += T[tl_idx(p, tj, k, cc)] * xs[16 * p + k];
+            xs[q] -= s;
+        }
+        __syncthreads();
+    }
+}
+
 // Blocked (16) right-looking Cholesky of the lower triangle of A (n x n, n multiple of 16): diagonal block by one
 // wavefront in LDS, panel solve one row per thread, trailing update L21 L21^T on the FP64 matrix cores.
-__device__ bool chol_blocked(double *A, int n, int ld, int *sh_flag) {
-    __shared__ double Lpp[256];
+__device__ bool chol_blocked(double *A, int n, int ld, int *sh_flag, double *Lpp) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
     const int nb = n >> 4;
     if (t == 0) *sh_flag = 1;
@@ -636,8 +782,7 @@ __device__ bool chol_blocked(double *A, int n, int ld, int *sh_flag) {
     return true;
 }
 // Solve L L^T x = b in place (xs in LDS), block-wise: 16x16 triangular solves by one wavefront, updates by all threads.
-__device__ void chol_solve_blocked(const double *L, int n, int ld, double *xs) {
-    __shared__ double Lpp[256];
+__device__ void chol_solve_blocked(const double *L, int n, int ld, double *xs, double *Lpp) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6;
     const int nb = n >> 4;
     for (int p = 0; p < nb; p++) {  // forward: L y = b
@@ -1147,7 +1292,7 @@ __device__ void assemble(const Batch &B, const Ctx &c, const Params &X, int nres
     double *H = c.H, *g = c.vec;
     for (int i = t; i < P * LW; i += nt) H[i] = 0;
     for (int i = t; i < LW; i += nt) g[i] = 0;
-    for (int i = t; i < Fa * LW; i += nt) c.Hpl[i] = 0;
+    for (int i = t; i < ((Fa + 3) & ~3) * LW; i += nt) c.Hpl[i] = 0;
     __syncthreads();
     PH(32);
     // prior: H += J^T J (precomputed), g += J^T r
@@ -1335,6 +1480,7 @@ __device__ void solve_body(const Batch &B, int s, int *scratch, double *sred, un
     double *work = xs + LW;       // LDS scratch: whitened IMU Jacobians, then the frame-pair blocks
     const int npairs = (W + 1) * W / 2;
     double *pb = (npairs * 210 <= 12288) ? work : c.pairblk;  // 55 pairs x 210 doubles = 92 KB for W = 10
+    const bool tiles_in_lds = ((LW >> 4) * ((LW >> 4) + 1) / 2) * 256 <= 16896 && !(B.flags & 1);  // S as 66 lower tiles = 132 KB for W = 10
 
     PH_INIT;
     const long long ts0 = wall_clock64();
@@ -1521,13 +1667,14 @@ __device__ void solve_body(const Batch &B, int s, int *scratch, double *sred, un
 
     // vec slots
     double *g = c.vec, *sp = c.vec + 1 * LW, *dgp = c.vec + 2 * LW, *gradp = c.vec + 3 * LW, *gnp = c.vec + 4 * LW, *stp = c.vec + 5 * LW,
-           *gs = c.vec + 6 * LW, *tmpv = c.vec + 7 * LW, *delta = c.vec + 8 * LW, *sgp = c.vec + 9 * LW;
+           *gs = c.vec + 6 * LW, *tmpv = c.vec + 7 * LW, *delta = c.vec + 8 * LW, *sgp = c.vec + 9 * LW, *hsgp = c.vec + 10 * LW,
+           *yp = c.vec + 11 * LW, *up = c.vec + 12 * LW, *tmpv2 = c.vec + 13 * LW;
     double *sl = c.lvec, *dgl = c.lvec + c.NLs, *gradl = c.lvec + 2 * c.NLs, *gnl = c.lvec + 3 * c.NLs, *stl = c.lvec + 4 * c.NLs,
            *inv = c.lvec + 5 * c.NLs, *gls = c.lvec + 6 * c.NLs, *Hlls = c.lvec + 7 * c.NLs;
-    double *tmpl = c.gl;  // gl is consumed by scale_system; reused as a landmark-length temporary afterwards
     const int Kpad = (Fa + 3) & ~3;
+    double *hsgl = c.res + (size_t)c.nres_cap * 42 - 4 * (size_t)c.NLs;   // tail of the residual buffer (nres <= nres_cap - 2 NL)
+    double *yl = hsgl + c.NLs, *ul = yl + c.NLs, *tmpl = ul + c.NLs;
 
-    PH(3);
     double cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp);
     PH(4);
     assemble(B, c, X, nres, Fa, alist, srp, work, pb);
@@ -1540,17 +1687,29 @@ __device__ void solve_body(const Batch &B, int s, int *scratch, double *sred, un
     }
     for (int k = t; k < Kpad; k += nt) sl[k] = k < Fa ? 1.0 / (1.0 + sqrt(c.Hll[k])) : 0.0;
     __syncthreads();
-    // gradient max-norm over the active variables (unscaled), then scale the system in place:
-    // H <- S H S, Hpl <- Sl Hpl S, gs = S g, gls = Sl gl, Hlls = Sl^2 Hll
-    auto gmax_and_scale = [&]() -> double {
+    // H / Hpl stay unscaled in HBM; the column scaling S is applied to the vectors (and inside the Schur MFMA operand loads):
+    //   Hs v = S H (S v).  Returns the max-norm of the active gradient.
+    auto prepare_point = [&]() -> double {
         double m = 0;
         for (int a = t; a < P; a += nt) m = fmax(m, sp[a] != 0.0 ? fabs(g[a]) : 0.0);
         for (int k = t; k < Fa; k += nt) m = fmax(m, fabs(c.gl[k]));
         double r = block_max(m, sred);
-        for (int w = t; w < LW * LW; w += nt) { int a = w / LW, b = w - a * LW; c.H[w] = (a < P && b < P) ? sp[a] * sp[b] * c.H[w] : 0.0; }
-        for (int w = t; w < Kpad * LW; w += nt) { int k = w / LW, a = w - k * LW; c.Hpl[w] = (k < Fa) ? sl[k] * sp[a] * c.Hpl[w] : 0.0; }
-        for (int a = t; a < LW; a += nt) gs[a] = a < P ? sp[a] * g[a] : 0.0;
-        for (int k = t; k < Kpad; k += nt) { gls[k] = k < Fa ? sl[k] * c.gl[k] : 0.0; Hlls[k] = k < Fa ? sl[k] * sl[k] * c.Hll[k] : 0.0; }
+        for (int a = t; a < LW; a += nt) {
+            double hs = a < P ? sp[a] * sp[a] * c.H[a * LW + a] : 0.0;
+            gs[a] = a < P ? sp[a] * g[a] : 0.0;
+            dgp[a] = sqrt(fmin(fmax(hs, 1e-6), 1e32));
+            gradp[a] = gs[a] / dgp[a];
+            sgp[a] = gradp[a] / dgp[a];
+            up[a] = sp[a] * sgp[a];
+        }
+        for (int k = t; k < Kpad; k += nt) {
+            double hl = k < Fa ? sl[k] * sl[k] * c.Hll[k] : 0.0;
+            Hlls[k] = hl;
+            gls[k] = k < Fa ? sl[k] * c.gl[k] : 0.0;
+            dgl[k] = sqrt(fmin(fmax(hl, 1e-6), 1e32));
+            gradl[k] = gls[k] / dgl[k];
+            ul[k] = sl[k] * (gradl[k] / dgl[k]);
+        }
         __syncthreads();
         return r;
     };
@@ -1559,7 +1718,7 @@ __device__ void solve_body(const Batch &B, int s, int *scratch, double *sred, un
     bool reuse = false, need_eval = false;
     int invalid = 0;
     int iters_done = 0, succ = 0;
-    if (gmax_and_scale() > 1e-10)
+    if (prepare_point() > 1e-10)
     for (int iter = 1; iter <= cfg.max_iterations; iter++) {
         iters_done = iter;
         if (!reuse) {
@@ -1570,30 +1729,24 @@ __device__ void solve_body(const Batch &B, int s, int *scratch, double *sred, un
                 assemble(B, c, X, nres, Fa, alist, srp, work, pb);
                 PH(5);
                 need_eval = false;
-                if (gmax_and_scale() <= 1e-10) { iters_done = iter - 1; break; }
+                if (prepare_point() <= 1e-10) { iters_done = iter - 1; break; }
                 PH(6);
             }
-            // scaled gradient / diagonal (DoglegStrategy::ComputeStep)
+            // Cauchy point: alpha = |grad|^2 / |J D^-1 grad|^2, and H_full * (D^-1 grad) is kept for the model evaluation
+            colsum(c.H, LW, P, up, P, tmpv, work);            // H (S sg_p)
+            colsum(c.Hpl, LW, Fa, ul, P, tmpv2, work);        // Hpl^T (Sl sg_l)
+            rowdot(c.Hpl, LW, Fa, up, P, tmpl);               // Hpl (S sg_p)
+            double g2 = 0, jg2 = 0;
             for (int a = t; a < LW; a += nt) {
-                double hs = c.H[a * LW + a];
-                dgp[a] = sqrt(fmin(fmax(hs, 1e-6), 1e32));
-                gradp[a] = gs[a] / dgp[a];
-                sgp[a] = gradp[a] / dgp[a];
+                double v = a < P ? sp[a] * (tmpv[a] + tmpv2[a]) : 0.0;
+                hsgp[a] = v;
+                if (a < P) { g2 += gradp[a] * gradp[a]; jg2 += sgp[a] * v; }
             }
             for (int k = t; k < Kpad; k += nt) {
-                dgl[k] = sqrt(fmin(fmax(Hlls[k], 1e-6), 1e32));
-                gradl[k] = gls[k] / dgl[k];
-            }
-            __syncthreads();
-            // Cauchy point: alpha = |grad|^2 / |J D^-1 grad|^2
-            colsum(c.H, LW, P, sgp, P, tmpv, work);          // Hs * sg
-            rowdot(c.Hpl, LW, Fa, sgp, P, tmpl);              // Ws * sg_p
-            double g2 = 0, jg2 = 0;
-            for (int a = t; a < P; a += nt) { g2 += gradp[a] * gradp[a]; jg2 += sgp[a] * tmpv[a]; }
-            for (int k = t; k < Fa; k += nt) {
-                double sgl = gradl[k] / dgl[k];
-                g2 += gradl[k] * gradl[k];
-                jg2 += 2.0 * sgl * tmpl[k] + sgl * sgl * Hlls[k];
+                double sgl = k < Fa ? gradl[k] / dgl[k] : 0.0;
+                double v = k < Fa ? sl[k] * tmpl[k] + Hlls[k] * sgl : 0.0;
+                hsgl[k] = v;
+                if (k < Fa) { g2 += gradl[k] * gradl[k]; jg2 += sgl * v; }
             }
             g2 = block_sum(g2, sred);
             jg2 = block_sum(jg2, sred);
@@ -1602,28 +1755,43 @@ __device__ void solve_body(const Batch &B, int s, int *scratch, double *sred, un
             // Gauss-Newton step via the landmark Schur complement (FP64 matrix cores), regularised by mu * D^2
             bool ok = false;
             while (mu < 1.0) {
-                for (int k = t; k < Kpad; k += nt) inv[k] = k < Fa ? 1.0 / (Hlls[k] + mu * dgl[k] * dgl[k]) : 0.0;
+                for (int k = t; k < Kpad; k += nt) {
+                    double iv = k < Fa ? 1.0 / (Hlls[k] + mu * dgl[k] * dgl[k]) : 0.0;
+                    inv[k] = iv;
+                    tmpl[k] = sl[k] * iv * gls[k];
+                }
                 __syncthreads();
-                schur_mfma(c.H, c.Hpl, inv, dgp, sp, mu, Kpad, LW, LW, c.Sc);
-                PH(8);
-                for (int k = t; k < Kpad; k += nt) tmpl[k] = inv[k] * gls[k];
+                colsum(c.Hpl, LW, Fa, tmpl, P, tmpv, work);  // Hpl^T (Sl gls / hll); uses the work region before S moves in
+                for (int a = t; a < LW; a += nt) xs[a] = a < P ? gs[a] - sp[a] * tmpv[a] : 0.0;
+                for (int k = t; k < Kpad; k += nt) tmpl[k] = sl[k] * sl[k] * inv[k];  // per-row factor of the rank-K update
                 __syncthreads();
-                colsum(c.Hpl, LW, Fa, tmpl, P, tmpv, work);  // Ws^T (gls / hll)
-                for (int a = t; a < LW; a += nt) xs[a] = a < P ? gs[a] - tmpv[a] : 0.0;
-                __syncthreads();
-                bool chol_ok = chol_blocked(c.Sc, LW, LW, &sh_i[2]);
+                bool chol_ok;
+                if (tiles_in_lds) {
+                    schur_mfma_lds(c.H, c.Hpl, tmpl, dgp, sp, mu, Kpad, LW, LW, work);
+                    PH(8);
+                    chol_ok = chol_tiles(work, LW >> 4, &sh_i[2]);
+                } else {
+                    schur_mfma(c.H, c.Hpl, tmpl, dgp, sp, mu, Kpad, LW, LW, c.Sc);
+                    PH(8);
+                    chol_ok = chol_blocked(c.Sc, LW, LW, &sh_i[2], work);
+                }
                 PH(9);
                 if (chol_ok) {
-                    chol_solve_blocked(c.Sc, LW, LW, xs);
+                    if (tiles_in_lds) chol_solve_tiles(work, LW >> 4, xs);
+                    else chol_solve_blocked(c.Sc, LW, LW, xs, work);
                     PH(10);
                     double bad = 0;
                     for (int a = t; a < P; a += nt) if (!isfinite(xs[a])) bad += 1;
                     bad = block_sum(bad, sred);
                     if (bad == 0) {
-                        for (int a = t; a < LW; a += nt) { gnp[a] = -xs[a] * dgp[a]; tmpv[a] = xs[a]; }
+                        for (int a = t; a < LW; a += nt) { yp[a] = xs[a]; gnp[a] = -xs[a] * dgp[a]; tmpv[a] = sp[a] * xs[a]; }
                         __syncthreads();
-                        rowdot(c.Hpl, LW, Fa, tmpv, P, tmpl);  // Ws * y_p
-                        for (int k = t; k < Fa; k += nt) gnl[k] = -((gls[k] - tmpl[k]) * inv[k]) * dgl[k];
+                        rowdot(c.Hpl, LW, Fa, tmpv, P, tmpl);  // Hpl (S y_p)
+                        for (int k = t; k < Kpad; k += nt) {
+                            double y = k < Fa ? (gls[k] - sl[k] * tmpl[k]) * inv[k] : 0.0;
+                            yl[k] = y;
+                            gnl[k] = -y * dgl[k];
+                        }
                         __syncthreads();
                         ok = true;
                         break;
@@ -1654,19 +1822,32 @@ __device__ void solve_body(const Batch &B, int s, int *scratch, double *sred, un
             ca = -alpha * (1.0 - beta); cb = beta;
             dogleg_norm = -1;
         }
-        double n2 = 0;
-        for (int a = t; a < LW; a += nt) { double v = ca * gradp[a] + cb * gnp[a]; if (a < P) n2 += v * v; stp[a] = a < P ? v / dgp[a] : 0.0; }
-        for (int k = t; k < Kpad; k += nt) { double v = k < Fa ? ca * gradl[k] + cb * gnl[k] : 0.0; n2 += v * v; stl[k] = k < Fa ? v / dgl[k] : 0.0; }
+        // step = ca * D^-1 grad - cb * y ;  H_full step = ca * H_full (D^-1 grad) - cb * (g' - mu D^2 y)   [(H_full + mu D^2) y = g']
+        double n2 = 0, lin = 0, quad = 0;
+        for (int a = t; a < LW; a += nt) {
+            double v = ca * gradp[a] + cb * gnp[a];
+            double st = a < P ? v / dgp[a] : 0.0;
+            stp[a] = st;
+            if (a < P) {
+                n2 += v * v;
+                lin += st * gs[a];
+                quad += st * (ca * hsgp[a] - cb * (gs[a] - mu * dgp[a] * dgp[a] * yp[a]));
+            }
+        }
+        for (int k = t; k < Kpad; k += nt) {
+            double v = k < Fa ? ca * gradl[k] + cb * gnl[k] : 0.0;
+            double st = k < Fa ? v / dgl[k] : 0.0;
+            stl[k] = st;
+            if (k < Fa) {
+                n2 += v * v;
+                lin += st * gls[k];
+                quad += st * (ca * hsgl[k] - cb * (gls[k] - mu * dgl[k] * dgl[k] * yl[k]));
+            }
+        }
         n2 = block_sum(n2, sred);
-        if (dogleg_norm < 0) dogleg_norm = sqrt(n2);
-        // model cost change = -(step^T g' + 1/2 step^T H' step)
-        colsum(c.H, LW, P, stp, P, tmpv, work);
-        rowdot(c.Hpl, LW, Fa, stp, P, tmpl);
-        double lin = 0, quad = 0;
-        for (int a = t; a < P; a += nt) { lin += stp[a] * gs[a]; quad += stp[a] * tmpv[a]; }
-        for (int k = t; k < Fa; k += nt) { lin += stl[k] * gls[k]; quad += 2.0 * stl[k] * tmpl[k] + stl[k] * stl[k] * Hlls[k]; }
         lin = block_sum(lin, sred);
         quad = block_sum(quad, sred);
+        if (dogleg_norm < 0) dogleg_norm = sqrt(n2);
         double model_change = -(lin + 0.5 * quad);
         PH(11);
         if (!(model_change > 0)) {

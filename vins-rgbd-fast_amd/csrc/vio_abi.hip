@@ -326,6 +326,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     DA(B.margA, S * mq * mq); DA(B.margB, S * mq); DA(B.margV, S * n * n); DA(B.margW, S * (n + 16) * (n + 16));
     DA(B.odom, S * 11); DA(B.timings, 64);
     B.hist_cap = 2048;
+    B.flags = getenv("VIO_FLAGS") ? atoi(getenv("VIO_FLAGS")) : 0;
     DA(B.odom_hist, S * (size_t)B.hist_cap * 11); DA(B.odom_count, S);
     DA(h->d_stamps, S);
 #undef DA
@@ -351,6 +352,10 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
             workd = std::max(workd, (size_t)1400 /* PreWork */);
             workd = std::max(workd, (size_t)4 * 336);
             if (C.NPRIOR <= 96) workd = std::max(workd, (size_t)C.NPRIOR * (C.NPRIOR | 1) + 2);
+            {
+                size_t nb = (size_t)C.LW >> 4, tiles = nb * (nb + 1) / 2 * 256;
+                if (tiles <= 16896) workd = std::max(workd, tiles);  // Schur complement / Cholesky tiles resident in LDS
+            }
             h->lds_solve = ((size_t)C.LW + 2 + workd) * 8 + 16;
             (void)hipFuncSetAttribute((const void *)be_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve);
         }

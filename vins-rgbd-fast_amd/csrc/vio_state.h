@@ -139,6 +139,7 @@ struct Batch {
     double *odom_hist;    // [S][hist_cap][11]: one CSV row per processed NON_LINEAR frame (visualization.cpp:214-225)
     int *odom_count;      // [S]
     int hist_cap;
+    int flags;            // debug switches (VIO_FLAGS): 1 = keep the Schur complement in HBM instead of LDS tiles
     float *timings;
 };
 
