@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--seqs", type=int, default=128, help="sequences per GPU")
-    ap.add_argument("--cpu-seqs", type=int, default=3, help="sequences replayed through the CPU oracle on rank 0 (0 = skip)")
+    ap.add_argument("--cpu-seqs", type=int, default=8, help="sequences replayed through the CPU oracle on rank 0 (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -65,6 +65,7 @@ def main():
     if not os.path.exists(os.path.join(ROOT, "vins-rgbd-fast_amd", "libvio_hip.so")):
         ge.build()
     import vio_ct
+    shard = __import__("importlib").import_module("vins-rgbd-fast_amd.shard")
 
     cfg = P.canonical_config()
     sc = vio_ct.synth_like(cfg)
@@ -72,7 +73,7 @@ def main():
     H, Wd = cfg.height, cfg.width
     n_pre = 16  # first-image skip + init_pub + init_feature + (window_size + 1) frames -> NON_LINEAR, + margin
     F = n_pre + Wm + K
-    seq0 = rank * S
+    seq0 = shard.sequence_shard(rank, world, S)[0]
     syn = P.Synth(sc)
     dev = torch.device("cuda", local_rank)
     gray = torch.empty((F, S, H, Wd), dtype=torch.uint8, device=dev)
@@ -108,11 +109,7 @@ def main():
     if world > 1:
         dist.barrier()
     nprof, kms = b.profile_end()
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed_local = t1 - t0
 
     # ---- validity + accuracy (outside the timed region)
     stats = [b.status(s) for s in range(S)]
@@ -127,6 +124,9 @@ def main():
             continue
         gt = np.array([syn.pose(seq0 + s, float(t))[0] for t in h[:, 0]])
         ates.append(vio_ct.ate_rmse(h[:, 1:4], gt))
+    sq_err = float(np.sum([a * a for a in ates]))
+    total_frames, elapsed, sq_err_all, n_ate_all = shard.job_totals(S * K, elapsed_local, sq_err, len(ates), device=dev)
+    worst = int(np.argmax(ates)) if ates else -1
     iters = float(np.mean([st.iterations for st in stats]))
     nres = float(np.mean([st.n_residuals for st in stats]))
     nvar = float(np.mean([st.n_var_landmarks for st in stats]))
@@ -187,7 +187,15 @@ def main():
                    cpu_seconds=tcpu)
         parity = dict(traj_rmse_hip_vs_oracle_m=float(np.max(rm)) if rm else None, sequences=ncs)
 
-    total_frames = world * S * K
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
+    if os.path.exists(tpath):  # written by profiles/collect.sh from separate rocprofv3 --pmc passes over this same command
+        tj = json.load(open(tpath))
+        ent = tj.get("kernels", {}).get(roof["kernel"])
+        if ent and tj.get("sequences_per_gpu") == S:
+            traffic = ent["hbm_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/round1_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)"
+    roof["traffic"] = traffic
     out = {
         "metric": "VIO frames/sec (640x480, 150 feats, 10-KF window)",
         "value": total_frames / elapsed,
@@ -206,7 +214,9 @@ def main():
                    "sequences_per_gpu": S, "image": [Wd, H], "max_cnt": cfg.max_cnt, "window_size": cfg.window_size,
                    "parallelism": "independent sequences sharded per GPU, no data-path collective"},
         "valid": all_processed,
-        "ate_m": {"mean": float(np.mean(ates)) if ates else None, "max": float(np.max(ates)) if ates else None, "sequences": len(ates)},
+        "ate_m": {"mean": float(np.mean(ates)) if ates else None, "max": float(np.max(ates)) if ates else None, "sequences": len(ates),
+                  "median": float(np.median(ates)) if ates else None, "worst_sequence": seq0 + worst,
+                  "job_rms": shard.ate_from_sums(sq_err_all, n_ate_all)},
         "solver": {"mean_iterations": iters, "mean_residuals": nres, "mean_var_landmarks": nvar, "mean_tracks": ntrk, "reboots": reboots},
         "kernels_ms": kms,
         "frontend_ms": fe_ms,

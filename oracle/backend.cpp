@@ -1070,7 +1070,7 @@ void Estimator::solve() {
 }
 
 // ------------------------------------------------------------------ marginalisation (marginalization_factor.cpp:181-315)
-static void marg_finish(Estimator &e, Mat &A, std::vector<double> &b, int m, int n) {
+void marg_finish(Estimator &e, Mat &A, std::vector<double> &b, int m, int n) {
     const double eps = 1e-8;
     // Amm^-1 via symmetric eigen-decomposition with truncation
     Mat Amm(m, m);

@@ -6,6 +6,8 @@
 using namespace ovio;
 using namespace om;
 
+namespace ovio { void marg_finish(Estimator &e, Mat &A, std::vector<double> &b, int m, int n); }  // backend.cpp
+
 extern "C" {
 
 int ovio_config_size() { return (int)sizeof(Config); }
@@ -186,6 +188,18 @@ void ovio_sym_eig(int n, const double *A, double *w, double *V) {
     sym_eig(M, ww, Vm);
     for (int i = 0; i < n; i++) w[i] = ww[i];
     for (int i = 0; i < n * n; i++) V[i] = Vm.d[i];
+}
+// MarginalizationInfo::marginalize() tail (marginalization_factor.cpp:262-315) on a caller-supplied A (N×N, N = m+n), b:
+// J (n×n row-major), r (n)
+void ovio_marg_finish(int m, int n, const double *A, const double *b, double *J, double *r) {
+    Config c;
+    Estimator e(c);
+    Mat M(m + n, m + n);
+    for (int i = 0; i < (m + n) * (m + n); i++) M.d[i] = A[i];
+    std::vector<double> bb(b, b + m + n);
+    marg_finish(e, M, bb, m, n);
+    for (int i = 0; i < n * n; i++) J[i] = e.prior_J.d[i];
+    for (int i = 0; i < n; i++) r[i] = e.prior_r[i];
 }
 // prior accessors (marginalisation tests): returns n; J (n×n row-major), r (n), present (W+3)
 int ovio_get_prior(void *h, double *J, double *r, double *x0, uint8_t *present) {

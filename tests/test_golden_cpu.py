@@ -1,0 +1,80 @@
+"""The CPU oracle against the committed fixtures in tests/golden/ (generator: tests/golden/make_golden.py).
+*_definition.npz hold expected values computed from the definitions by independent numpy code; *_regression.npz hold the
+oracle's own outputs (drift detection; the same files pin the HIP path in test_gpu_golden.py)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import test_oracle_kat as K
+import vio_ct
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_fast_definition_fixture(orc):
+    d = np.load(os.path.join(G, "fast_definition.npz"))
+    img = np.ascontiguousarray(d["img"])
+    H, W = img.shape
+    out = np.zeros((4096, 3), np.float32)
+    for i, (rx, ry, rw, rh) in enumerate(d["rois"]):
+        n = orc.ovio_fast_roi(img.ctypes.data, W, H, int(rx), int(ry), int(rw), int(rh), 4096, out.ctypes.data)
+        assert np.array_equal(out[:n].astype(np.int32), d[f"kp{i}"].reshape(-1, 3))
+
+
+def test_pyrdown_definition_fixture(orc):
+    d = np.load(os.path.join(G, "pyrdown_definition.npz"))
+    img = np.ascontiguousarray(d["img"])
+    h, w = img.shape
+    out = np.zeros_like(d["out"])
+    orc.ovio_pyr_down(img.ctypes.data, w, h, out.ctypes.data)
+    assert np.array_equal(out, d["out"])
+
+
+def test_lk_regression_fixture(orc):
+    d = np.load(os.path.join(G, "lk_regression.npz"))
+    a, b, prev = np.ascontiguousarray(d["prev_img"]), np.ascontiguousarray(d["next_img"]), np.ascontiguousarray(d["prev"])
+    h, w = a.shape
+    for lvl in (1, 3):
+        nxt = (prev + np.float32(0.5)).astype(np.float32)
+        st = np.zeros(len(prev), np.uint8)
+        orc.ovio_lk(a.ctypes.data, b.ctypes.data, w, h, lvl, len(prev), prev.ctypes.data, nxt.ctypes.data, st.ctypes.data, 1)
+        assert np.array_equal(st, d[f"status{lvl}"])
+        assert np.array_equal(nxt.view(np.uint32), d[f"next{lvl}"].view(np.uint32))
+        ok = st > 0
+        assert np.abs((nxt - prev)[ok][:-2] - np.float32([1.7, -0.9])).max() < 0.05  # interior points recover the true shift
+
+
+def test_factor_regression_fixture(P, orc):
+    d = np.load(os.path.join(G, "factors_regression.npz"))
+    cfg = P.default_config(tr=0.0)
+    h = K._preint(orc, cfg, d["dt"], d["acc"], d["gyr"], np.ascontiguousarray(d["acc"][0]), np.ascontiguousarray(d["gyr"][0]),
+                  np.ascontiguousarray(d["ba"]), np.ascontiguousarray(d["bg"]))
+    pre = np.zeros(461)
+    orc.ovio_preint_get(h, pre.ctypes.data)
+    r, J = K._imu_eval(orc, h, cfg.g_norm, d["pose_i"], d["sb_i"], d["pose_j"], d["sb_j"])
+    orc.ovio_preint_destroy(h)
+    assert np.abs(pre - d["preint"]).max() <= 1e-13 * np.abs(d["preint"]).max()
+    assert np.abs(r - d["imu_r"]).max() <= 1e-9 * np.abs(d["imu_r"]).max()
+    assert np.abs(J - d["imu_J"]).max() <= 1e-9 * np.abs(d["imu_J"]).max()
+    for row in d["proj"]:
+        use_td, inv_dep, td = int(row[0]), row[1], row[2]
+        qi, qj, ex, oi, oj = row[3:10], row[10:17], row[17:24], row[24:33], row[33:42]
+        rr, JJ = K._proj_eval(orc, cfg, qi, qj, ex, inv_dep, td, oi, oj, use_td)
+        assert np.abs(np.r_[rr, JJ] - row[42:]).max() <= 1e-12 * np.abs(row[42:]).max()
+
+
+def test_pipeline_regression_fixture(P):
+    """whole hot path on the CPU: rendered frames + IMU of synthetic sequence 3 -> identical published trajectory"""
+    d = np.load(os.path.join(G, "pipeline_regression.npz"))
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    o = vio_ct.run_oracle_sequence(cfg, sc, int(d["seq"]), int(d["n_frames"]))
+    assert np.array_equal(np.array([x[0] for x in o["traj"]], np.int32), d["frames"])
+    st = np.array([[s["solver_flag"], s["frame_count"], s["marginalization_flag"], s["n_landmarks"]] for s in o["status"]], np.int32)
+    assert np.array_equal(st, d["status"])
+    Pw = np.array([x[1] for x in o["traj"]])
+    assert np.abs(Pw - d["P"]).max() < 1e-9  # same binary -> bit-equal in practice; libm differences stay far below this
+    ids, cnt, cur, _, _ = o["oracle"].tracks()
+    assert np.array_equal(ids, d["track_ids"]) and np.array_equal(cnt, d["track_cnt"])
+    assert vio_ct.ate_rmse(Pw, d["gt"]) < 0.02

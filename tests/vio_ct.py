@@ -66,6 +66,7 @@ def oracle():
             "ovio_eval_imu": [C.c_void_p, C.c_double] + [C.c_void_p] * 6,
             "ovio_sym_eig": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
             "ovio_get_prior": [C.c_void_p] * 5,
+            "ovio_marg_finish": [C.c_int, C.c_int] + [C.c_void_p] * 4,
         }.items():
             getattr(L, name).argtypes = args
         assert L.ovio_config_size() == C.sizeof(pkg().Config), "oracle Config and vio_config layouts differ"

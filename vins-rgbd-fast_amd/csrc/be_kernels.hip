@@ -1442,7 +1442,7 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw);
 
 // solve -> marginalise -> window slide for one sequence per workgroup (1024 threads); fusing the three stages makes the
 // step time the maximum over sequences of the *sum* of the stage times instead of the sum of per-stage maxima.
-__device__ void solve_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem, PreWork &pw);
+__device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem, PreWork &pw);
 
 __global__ __launch_bounds__(1024) void be_solve_kernel(Batch B) {
     const int s = blockIdx.x;
@@ -1450,6 +1450,15 @@ __global__ __launch_bounds__(1024) void be_solve_kernel(Batch B) {
     __shared__ double sred[64];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     PreWork &pw = *(PreWork *)(smem + 16 * ((B.cfg->LW * 8 + 15) / 16));  // aliases the work region (used before it)
+    solve_body(B, s, scratch, sred, smem, pw);
+}
+// the same body compiled for 512 threads: 256 VGPRs per lane instead of 128 (no scratch spills), half the waves
+__global__ __launch_bounds__(512) void be_solve_kernel_512(Batch B) {
+    const int s = blockIdx.x;
+    __shared__ int scratch[2 * 1024 + 8];
+    __shared__ double sred[64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    PreWork &pw = *(PreWork *)(smem + 16 * ((B.cfg->LW * 8 + 15) / 16));
     solve_body(B, s, scratch, sred, smem, pw);
 }
 // marginalisation + window slide: 256 threads (barrier-heavy eigen-decomposition; measured faster than 1024)
@@ -1464,7 +1473,7 @@ __global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
     finish_body(B, s, scratch, pw);
 }
 
-__device__ void solve_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem, PreWork &pw) {
+__device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem, PreWork &pw) {
     const int t = threadIdx.x, nt = blockDim.x;
     Ctx c = make_ctx(B, s);
     const DevCfg &C = *B.cfg;

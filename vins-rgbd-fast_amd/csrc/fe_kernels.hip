@@ -154,7 +154,9 @@ __device__ void pyrdown_tile(const uint8_t *src, int sw, int sh, uint8_t *dst, u
     for (int q = threadIdx.x; q < TWS * THS; q += 256) {
         int ty = q / TWS, tx = q - ty * TWS;
         int gx = sx0 + tx, gy = sy0 + ty;
-        uint8_t v = src[(size_t)reflect101(gy, sh) * sw + reflect101(gx, sw)];
+        // pixels further than one reflection outside the image feed no valid output: clamp only keeps the address legal
+        int ry = min(max(reflect101(gy, sh), 0), sh - 1), rx = min(max(reflect101(gx, sw), 0), sw - 1);
+        uint8_t v = src[(size_t)ry * sw + rx];
         tile[ty][tx] = v;
         if (l0 && tx >= 2 && tx < 2 + 2 * PD_TW && ty >= 2 && ty < 2 + 2 * PD_TH && gx < sw && gy < sh) l0[(size_t)gy * sw + gx] = v;
     }

@@ -23,6 +23,7 @@ __global__ void fe_fast_stage_kernel(const uint8_t *img, int W, GridRect r, uint
 __global__ void fe_add_kernel(Batch B, int publish, int gate);
 __global__ void be_ingest_kernel(Batch B, const uint16_t *depth_base, size_t depth_stride);
 __global__ void be_solve_kernel(Batch B);
+__global__ void be_solve_kernel_512(Batch B);
 __global__ void be_marg_kernel(Batch B);
 __global__ void be_stage_imu_kernel(vio_config cfg, PreInt *P, int n, const double *dt, const double *acc, const double *gyr,
                                     const double *par, double g_norm, double *preint_out, double *r15, double *J480);

@@ -196,7 +196,8 @@ int launch_backend(vio_batch *h, const uint16_t *d_depth) {
     be_ingest_kernel<<<S, 256, 0, st>>>(h->B, d_depth, (size_t)C.c.width * C.c.height);
     PEV(h, 9);
     static int be_threads = getenv("VIO_BE_THREADS") ? atoi(getenv("VIO_BE_THREADS")) : 1024;
-    be_solve_kernel<<<S, be_threads, h->lds_solve, st>>>(h->B);
+    if (be_threads <= 512) be_solve_kernel_512<<<S, be_threads, h->lds_solve, st>>>(h->B);
+    else be_solve_kernel<<<S, be_threads, h->lds_solve, st>>>(h->B);
     PEV(h, 10);
     (void)hipEventRecord(h->ev_solve, st);  // the next frame's front-end may start here (it only needs latest_Bg / td / ric)
     h->have_solve_ev = true;
@@ -358,6 +359,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
             }
             h->lds_solve = ((size_t)C.LW + 2 + workd) * 8 + 16;
             (void)hipFuncSetAttribute((const void *)be_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve);
+            (void)hipFuncSetAttribute((const void *)be_solve_kernel_512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve);
         }
         h->lds_marg = C.NPRIOR <= 96 ? (size_t)C.NPRIOR * (C.NPRIOR | 1) * 8 + 64 : 64;
         (void)hipFuncSetAttribute((const void *)be_marg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_marg);
