@@ -39,6 +39,36 @@ def frontend_bytes(w, h, n, levels):
     return 2 * w * h + sum(w * h // 4 ** l for l in range(1, levels + 1)) + n * (levels + 1) * 2 * 23 * 23
 
 
+def aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K):
+    """frames/s of the same step at another batch size (auxiliary data point; all 256 CUs busy at S = 256)."""
+    H, Wd = cfg.height, cfg.width
+    F = n_pre + Wm + K
+    syn = P.Synth(sc)
+    gray = torch.empty((F, S, H, Wd), dtype=torch.uint8, device=dev)
+    depth = torch.empty((F, S, H, Wd), dtype=torch.uint16, device=dev)
+    times = vio_ct.frame_times(sc, F)
+    for f in range(F):
+        syn.render_device(S, 0, float(times[f]), gray[f], depth[f])
+    nimu = int(F / sc.cam_rate * sc.imu_rate) + 64
+    b = P.VioBatch(cfg, S, imu_capacity=nimu + 64)
+    for s in range(S):
+        b.push_imu(s, *syn.imu(s, nimu))
+    for f in range(n_pre + Wm):
+        b.feed(gray[f], depth[f], np.full(S, times[f]), on_device=True)
+    b.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(K):
+        f = n_pre + Wm + k
+        b.feed(gray[f], depth[f], np.full(S, times[f]), on_device=True)
+    b.sync()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ok = all(b.status(s).solver_flag == 1 for s in range(S))
+    b.close()
+    return dict(sequences_per_gpu=S, frames_per_s=S * K / el, ms_per_step=el / K * 1e3, valid=bool(ok))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,6 +76,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--seqs", type=int, default=128, help="sequences per GPU")
     ap.add_argument("--cpu-seqs", type=int, default=8, help="sequences replayed through the CPU oracle on rank 0 (0 = skip)")
+    ap.add_argument("--aux", action="store_true", help="also measure S=256 sequences per GPU (reported as aux_s256, never as value)")
+    ap.add_argument("--pcie-steps", type=int, default=6, help="extra steps fed from HOST buffers after the timed region (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -72,7 +104,8 @@ def main():
     S, K, Wm = args.seqs, args.steps, args.warmup
     H, Wd = cfg.height, cfg.width
     n_pre = 16  # first-image skip + init_pub + init_feature + (window_size + 1) frames -> NON_LINEAR, + margin
-    F = n_pre + Wm + K
+    Kp = max(args.pcie_steps, 0)
+    F = n_pre + Wm + K + Kp
     seq0 = shard.sequence_shard(rank, world, S)[0]
     syn = P.Synth(sc)
     dev = torch.device("cuda", local_rank)
@@ -111,10 +144,24 @@ def main():
     nprof, kms = b.profile_end()
     elapsed_local = t1 - t0
 
+    # ---- PCIe-inclusive rate (never `value`): the same call handed pageable HOST buffers, S x 0.92 MB uploaded per step
+    pcie = None
+    if Kp > 0:
+        hg = [gray[n_pre + Wm + K + k].cpu().numpy() for k in range(Kp)]
+        hd = [depth[n_pre + Wm + K + k].cpu().numpy() for k in range(Kp)]
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for k in range(Kp):
+            b.feed(hg[k], hd[k], np.full(S, times[n_pre + Wm + K + k]), on_device=False)
+        b.sync()
+        c1 = time.perf_counter()
+        pcie = dict(frames_per_s=S * Kp / (c1 - c0), ms_per_step=(c1 - c0) / Kp * 1e3, steps=Kp,
+                    note="vio_feed(on_device=0): pageable numpy buffers, %.1f MB uploaded per step" % (S * H * Wd * 3 / 1e6))
+
     # ---- validity + accuracy (outside the timed region)
     stats = [b.status(s) for s in range(S)]
     fp1 = np.array([st.frames_processed for st in stats])
-    all_processed = bool(np.all(fp1 - fp0 == K) and np.all(nl == 1))
+    all_processed = bool(np.all(fp1 - fp0 == K + Kp) and np.all(nl == 1))
     ates = []
     hist = {}
     for s in range(S):
@@ -185,7 +232,7 @@ def main():
                    sample="%d sequences x %d steady-state frames of the same rendered workload through oracle/ (-O3, 1 thread; "
                           "the reference binary needs ROS/OpenCV/Ceres and cannot be built here)" % (ncs, nfr // max(ncs, 1)),
                    cpu_seconds=tcpu)
-        parity = dict(traj_rmse_hip_vs_oracle_m=float(np.max(rm)) if rm else None, sequences=ncs)
+        parity = dict(traj_rmse_hip_vs_oracle_m=float(np.max(rm)) if rm else None, sequences=ncs, per_sequence=rm)
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
@@ -224,7 +271,10 @@ def main():
         "roofline": roof,
         "cpu_baseline": cpu,
         "parity": parity,
+        "pcie_inclusive": pcie,
     }
+    if args.aux and rank == 0:
+        out["aux_s256"] = aux_rate(P, vio_ct, torch, cfg, sc, dev, 256, n_pre, Wm, K)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -927,6 +927,19 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
     int *flag = c.lm_tmp;         // new-landmark flags per observation (NP <= NL is checked at create)
     int *offs = c.lm_pidx;        // temporary
     int tracked = 0;
+    // id -> slot lookup (feature_manager.cpp:66-67 find_if over the list).  The list is NOT sorted by id: a landmark removed by
+    // outlier rejection while the tracker keeps its id is re-appended at the end.  Open-addressing hash table in LDS.
+    extern __shared__ int htab[];  // [2 * HT]: keys, values
+    const int HT = C.lm_hash_size;
+    for (int q = t; q < HT; q += nt) htab[q] = -1;
+    __syncthreads();
+    for (int k = t; k < nlm; k += nt) {
+        int slot = c.lm_order[k], id = c.lm_id[slot];
+        unsigned hsh = ((unsigned)id * 2654435761u) & (unsigned)(HT - 1);
+        while (atomicCAS(&htab[hsh], -1, id) != -1) hsh = (hsh + 1) & (unsigned)(HT - 1);
+        htab[HT + hsh] = slot;
+    }
+    __syncthreads();
     for (int j = t; j < nobs; j += nt) {
         const double *p = o + (size_t)j * 7;
         unsigned short mm = depth[(size_t)(int)p[4] * cfg.width + (int)p[3]];
@@ -934,12 +947,11 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
         int isnew = 0;
         if (!(0 < dmm && dmm < cfg.depth_min)) {
             int fid = o_id[j];
-            int lo = 0, hi = nlm - 1, found = -1;
-            while (lo <= hi) {
-                int mid = (lo + hi) >> 1;
-                int v = c.lm_id[c.lm_order[mid]];
-                if (v == fid) { found = c.lm_order[mid]; break; }
-                if (v < fid) lo = mid + 1; else hi = mid - 1;
+            int found = -1;
+            unsigned hsh = ((unsigned)fid * 2654435761u) & (unsigned)(HT - 1);
+            while (htab[hsh] != -1) {
+                if (htab[hsh] == fid) { found = htab[HT + hsh]; break; }
+                hsh = (hsh + 1) & (unsigned)(HT - 1);
             }
             if (found >= 0) {
                 int k = c.lm_nobs[found];

@@ -193,9 +193,9 @@ int launch_backend(vio_batch *h, const uint16_t *d_depth) {
     const int S = h->S;
     hipStream_t st = h->stream;
     PEV(h, 8);
-    be_ingest_kernel<<<S, 256, 0, st>>>(h->B, d_depth, (size_t)C.c.width * C.c.height);
+    be_ingest_kernel<<<S, 256, (size_t)C.lm_hash_size * 8, st>>>(h->B, d_depth, (size_t)C.c.width * C.c.height);
     PEV(h, 9);
-    static int be_threads = getenv("VIO_BE_THREADS") ? atoi(getenv("VIO_BE_THREADS")) : 1024;
+    static int be_threads = getenv("VIO_BE_THREADS") ? atoi(getenv("VIO_BE_THREADS")) : 512;
     if (be_threads <= 512) be_solve_kernel_512<<<S, be_threads, h->lds_solve, st>>>(h->B);
     else be_solve_kernel<<<S, be_threads, h->lds_solve, st>>>(h->B);
     PEV(h, 10);
@@ -277,6 +277,8 @@ static int build_devcfg(const vio_config *cfg, int imu_capacity, DevCfg &C) {
     if (C.NP > VIO_FAST_CAP) { g_err = "max_cnt too large for this build"; return VIO_EINVAL; }
     C.NL = c.max_landmarks < C.NP ? C.NP : c.max_landmarks;
     C.NL = (C.NL + 7) & ~7;
+    C.lm_hash_size = 256;
+    while (C.lm_hash_size < 2 * C.NL) C.lm_hash_size <<= 1;
     C.NIMU = imu_capacity < 256 ? 256 : imu_capacity;
     C.P = 15 * (C.W + 1) + 7;
     C.NPRIOR = 6 * C.W + 16;
@@ -363,6 +365,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
         }
         h->lds_marg = C.NPRIOR <= 96 ? (size_t)C.NPRIOR * (C.NPRIOR | 1) * 8 + 64 : 64;
         (void)hipFuncSetAttribute((const void *)be_marg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_marg);
+        (void)hipFuncSetAttribute((const void *)be_ingest_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C.lm_hash_size * 8);
 
         (void)hipFuncSetAttribute((const void *)fe_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_select);
         (void)hipFuncSetAttribute((const void *)fe_add_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_add);

@@ -23,6 +23,7 @@ struct DevCfg {
     int W;              // window size
     int NP;             // capacity of the tracker point arrays
     int NL;             // landmark table capacity
+    int lm_hash_size;   // power of two >= 2 * NL: id -> slot hash table built in LDS by be_ingest
     int NIMU;           // IMU ring capacity
     int ncells;
     int grids_threshold;
