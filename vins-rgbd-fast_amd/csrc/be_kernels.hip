@@ -15,11 +15,14 @@ using namespace dm;
 
 // phase timers (debug): thread 0 of sequence 0 accumulates 100 MHz wall-clock ticks into B.timings[k]
 #define PH_INIT long long ph_t0 = (s == 0 && threadIdx.x == 0) ? (long long)wall_clock64() : 0
+#define PHT_INIT(tid) long long pht_t0 = (c.s == 0 && (int)threadIdx.x == (tid)) ? (long long)wall_clock64() : 0
+#define PHT(k, tid) do { if (c.s == 0 && (int)threadIdx.x == (tid)) { long long n_ = (long long)wall_clock64(); c.timings[k] += (float)(n_ - pht_t0); pht_t0 = n_; } } while (0)
 #define PH(k) do { if (s == 0 && threadIdx.x == 0) { long long n_ = (long long)wall_clock64(); B.timings[k] += (float)(n_ - ph_t0); ph_t0 = n_; } } while (0)
 
 namespace {
 
 struct Ctx {
+    float *timings;
     const DevCfg *C;
     int s, W, P, LW, NL, NLs, NPR;
     BeSeq *be;
@@ -38,6 +41,7 @@ struct Ctx {
 __device__ Ctx make_ctx(const Batch &B, int s) {
     Ctx c;
     const DevCfg &C = *B.cfg;
+    c.timings = B.timings;
     c.C = B.cfg; c.s = s; c.W = C.W; c.P = C.P; c.LW = C.LW; c.NL = C.NL; c.NLs = C.NL + 8; c.NPR = C.NPRIOR;
     c.be = B.be + s; c.fe = B.fe + s;
     c.pre = B.pre + (size_t)s * (C.W + 2);
@@ -442,25 +446,31 @@ __device__ void tridiag_ql_wave(double *V, int n, int ld, double *d, double *e) 
                     double c = 1.0, c2 = 1.0, c3 = 1.0, el1 = e[l + 1], s = 0.0, s2 = 0.0;
                     const int r0 = lane < n ? lane : 0, r1 = lane + 64 < n ? lane + 64 : r0;  // n <= 128; duplicates write equal values
                     double car0 = V[r0 * ld + m], car1 = V[r1 * ld + m];
+                    // software pipeline: e[i-1], d[i-1] and the next V column are fetched before this rotation's stores
+                    double ei = e[m - 1], di = d[m - 1];
+                    double vi0 = V[r0 * ld + m - 1], vi1 = V[r1 * ld + m - 1];
                     for (int i = m - 1; i >= l; i--) {
                         c3 = c2; c2 = c; s2 = s;
-                        double ei = e[i], di = d[i];
+                        const int in = i > l ? i - 1 : i;
+                        const double ei_n = e[in], di_n = d[in];
+                        const double vn0 = V[r0 * ld + in], vn1 = V[r1 * ld + in];
                         g = c * ei;
                         h = c * p;
-                        r = sqrt(p * p + ei * ei);
+                        const double rr2 = p * p + ei * ei;
+                        const double rinv = rr2 > 0.0 ? rsqrt(rr2) : 0.0;   // one slow op on the serial chain instead of sqrt + divide
+                        r = rr2 * rinv;
                         double e_ip1 = s * r;
-                        s = ei / r;
-                        c = p / r;
+                        s = ei * rinv;
+                        c = p * rinv;
                         p = c * di - s * g;
                         double d_ip1 = h + s * (c * g + s * di);
                         if (lane == 0) { e[i + 1] = e_ip1; d[i + 1] = d_ip1; }  // read again only after the sweep's fence
-                        {   // rows lane and lane+64 of V: the rotated column i is carried in registers to the next rotation
-                            double vi0 = V[r0 * ld + i], vi1 = V[r1 * ld + i];
-                            V[r0 * ld + i + 1] = s * vi0 + c * car0;
-                            V[r1 * ld + i + 1] = s * vi1 + c * car1;
-                            car0 = c * vi0 - s * car0;
-                            car1 = c * vi1 - s * car1;
-                        }
+                        // rows lane and lane+64 of V: the rotated column i is carried in registers to the next rotation
+                        V[r0 * ld + i + 1] = s * vi0 + c * car0;
+                        V[r1 * ld + i + 1] = s * vi1 + c * car1;
+                        car0 = c * vi0 - s * car0;
+                        car1 = c * vi1 - s * car1;
+                        ei = ei_n; di = di_n; vi0 = vn0; vi1 = vn1;
                     }
                     V[r0 * ld + l] = car0;
                     V[r1 * ld + l] = car1;
@@ -602,6 +612,73 @@ __device__ void schur_mfma_lds(const double *Hs, const double *Ws, const double 
         }
         for (int r = 0; r < 4; r++) T[tl_idx(ti, tj, lk + 4 * r, li)] = acc[r];
     }
+    __syncthreads();
+}
+
+// Same Schur complement, landmark rows staged through LDS once: every wavefront keeps the accumulators of its (<= MAXT)
+// tiles in registers for the whole k loop, the 16-row chunks of Hpl (scaled by sp on the way in) are double-buffered in the
+// tile region itself (it is only written at the end).  Global traffic drops from 2 * ntile * Kpad * 16 doubles (every
+// tile re-reading its two column panels) to Kpad * n doubles.
+#define SCH_CH 16
+template <int MAXT>
+__device__ void schur_mfma_staged(const double *Hs, const double *Ws, const double *inv, const double *dgp, const double *sp, double mu,
+                                  int Kpad, int n, int ld, double *T) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    const int nb = n >> 4, ntile = nb * (nb + 1) / 2;
+    const int li = lane & 15, lk = lane >> 4;
+    const int lds = n + 8;  // padded row stride of the staged chunk (bank spread of the 4 k-rows)
+    double *buf0 = T, *buf1 = T + SCH_CH * lds;
+    v4f64 acc[MAXT];
+    int tis[MAXT], tjs[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; i++) {
+        int tile = wave + i * nw;
+        int ti = 0, tj = 0;
+        if (tile < ntile) tri_decode(tile, ti, tj);
+        tis[i] = ti; tjs[i] = tj;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int row = 16 * ti + lk + 4 * r, col = 16 * tj + li;
+            double v = sp[row] * sp[col] * Hs[(size_t)row * ld + col];
+            if (row == col) { v += mu * dgp[row] * dgp[row]; if (sp[row] == 0.0) v = 1.0; }
+            acc[i][r] = v;
+        }
+    }
+    const int nchunk = (Kpad + SCH_CH - 1) / SCH_CH;
+    auto stage = [&](int ch, double *buf) {
+        for (int q = t; q < SCH_CH * n; q += nt) {
+            int r = q / n, cc = q - r * n, kk = ch * SCH_CH + r;
+            buf[r * lds + cc] = kk < Kpad ? Ws[(size_t)kk * ld + cc] * sp[cc] : 0.0;
+        }
+    };
+    stage(0, buf0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ch++) {
+        double *cur = (ch & 1) ? buf1 : buf0, *nxt = (ch & 1) ? buf0 : buf1;
+        if (ch + 1 < nchunk) stage(ch + 1, nxt);
+        double iv[SCH_CH / 4];
+#pragma unroll
+        for (int ks = 0; ks < SCH_CH / 4; ks++) { int kk = ch * SCH_CH + 4 * ks + lk; iv[ks] = kk < Kpad ? inv[kk] : 0.0; }
+#pragma unroll
+        for (int i = 0; i < MAXT; i++) {
+            if (wave + i * nw < ntile) {
+                const double *pa = cur + lk * lds + 16 * tis[i] + li, *pb = cur + lk * lds + 16 * tjs[i] + li;
+#pragma unroll
+                for (int ks = 0; ks < SCH_CH / 4; ks++) {
+                    double a = -(pa[4 * ks * lds] * iv[ks]);
+                    double b = pb[4 * ks * lds];
+                    acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MAXT; i++)
+        if (wave + i * nw < ntile) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) T[tl_idx(tis[i], tjs[i], lk + 4 * r, li)] = acc[i][r];
+        }
     __syncthreads();
 }
 
@@ -866,6 +943,55 @@ __device__ void rowdot(const double *M, int ld, int nrows, const double *v, int 
     __syncthreads();
 }
 
+// One pass over a row-major matrix M (nrows x n, leading dimension ld) producing either or both of
+//   out_row[k] = M[k][:] . v          (v != nullptr)
+//   out_col[a] = sum_k u[k] M[k][a]   (u != nullptr)
+// One wavefront per row (lanes own columns lane, lane + 64, ...): row dots through shuffles, column sums in registers and
+// combined over the wavefronts through LDS part[nw * VIO_LWMAX].  Ends with a block barrier.
+template <int NC>
+__device__ void matvec_pass_t(const double *M, int ld, int nrows, int n, const double *u, const double *v, double *out_col, double *out_row,
+                              double *part) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    double cs[NC], vv[NC];
+#pragma unroll
+    for (int j = 0; j < NC; j++) { int a = lane + 64 * j; cs[j] = 0; vv[j] = (v && a < n) ? v[a] : 0.0; }
+#pragma unroll 2
+    for (int k = wave; k < nrows; k += nw) {
+        const double *r = M + (size_t)k * ld;
+        double m[NC];
+#pragma unroll
+        for (int j = 0; j < NC; j++) { int a = lane + 64 * j; m[j] = a < n ? r[a] : 0.0; }
+        if (v) {
+            double rd = 0;
+#pragma unroll
+            for (int j = 0; j < NC; j++) rd += m[j] * vv[j];
+            for (int off = 32; off > 0; off >>= 1) rd += __shfl_xor(rd, off, 64);
+            if (lane == 0) out_row[k] = rd;
+        }
+        if (u) {
+            const double uk = u[k];
+#pragma unroll
+            for (int j = 0; j < NC; j++) cs[j] += uk * m[j];
+        }
+    }
+    if (u) {
+#pragma unroll
+        for (int j = 0; j < NC; j++) { int a = lane + 64 * j; if (a < n) part[wave * VIO_LWMAX + a] = cs[j]; }
+        __syncthreads();
+        for (int a = t; a < n; a += nt) {
+            double sacc = 0;
+            for (int q = 0; q < nw; q++) sacc += part[q * VIO_LWMAX + a];
+            out_col[a] = sacc;
+        }
+    }
+    __syncthreads();
+}
+__device__ void matvec_pass(const double *M, int ld, int nrows, int n, const double *u, const double *v, double *out_col, double *out_row,
+                            double *part) {
+    if (n <= 192) matvec_pass_t<3>(M, ld, nrows, n, u, v, out_col, out_row, part);
+    else matvec_pass_t<6>(M, ld, nrows, n, u, v, out_col, out_row, part);
+}
+
 // stable compaction of the landmark order list; flags[k] = keep. Freed slots go back to the free stack.
 __device__ void lm_compact(Ctx &c, int *flags, int *offs, int *scratch) {
     int n = c.be->n_lm;
@@ -888,7 +1014,7 @@ __device__ void lm_compact(Ctx &c, int *flags, int *offs, int *scratch) {
 
 // ====================================================================================================== be_ingest
 __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t *depth_base, size_t depth_stride) {
-    const int s = blockIdx.x, t = threadIdx.x, nt = blockDim.x;
+    const int s = blockIdx.x + B.s0, t = threadIdx.x, nt = blockDim.x;
     Ctx c = make_ctx(B, s);
     const DevCfg &C = *B.cfg;
     const vio_config &cfg = C.c;
@@ -1221,6 +1347,7 @@ __device__ double evaluate(const Ctx &c, const Params &X, const double *feat, bo
     const BeSeq &be = *c.be;
     const vio_config &cfg = c.C->c;
     double cost = 0;
+    PHT_INIT(withJ ? (int)(t == 0 ? 0 : nt - 1) : -1);
     // prior
     if (be.has_prior) {
         prior_dx(c, X, sdx);
@@ -1231,6 +1358,8 @@ __device__ double evaluate(const Ctx &c, const Params &X, const double *feat, bo
             cost += 0.5 * sacc * sacc;
         }
     }
+    PHT(40, 0);
+    PHT(42, nt - 1);
     // IMU factors: five threads per factor (whitened residual + four Jacobian column groups). Spread over the upper lanes
     // of the block so that they do not serialise with the projection residuals handled by the low thread ids.
     v3 G = ld3(be.g);
@@ -1251,6 +1380,8 @@ __device__ double evaluate(const Ctx &c, const Params &X, const double *feat, bo
         } else if (withJ)
             bf::imu_raw_jacobian_part(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], part - 1, out, 31);  // raw, whitened in assemble
     }
+    PHT(43, nt - 1);
+    PHT(46, 0);
     // projection factors, CauchyLoss(1.0)
     for (int r = t; r < nres; r += nt) {
         int slot = c.res_lm[r], k = c.res_k[r];
@@ -1268,7 +1399,11 @@ __device__ double evaluate(const Ctx &c, const Params &X, const double *feat, bo
             out[41] = wgt * rr[1];
         }
     }
-    return block_sum(cost, sred);
+    PHT(41, 0);
+    PHT(44, nt - 1);
+    cost = block_sum(cost, sred);
+    PHT(45, 0);
+    return cost;
 }
 
 // pair-block entry index of the packed symmetric 20x20
@@ -1321,39 +1456,67 @@ __device__ void assemble(const Batch &B, const Ctx &c, const Params &X, int nres
     }
     __syncthreads();
     PH(33);
-    // IMU: whiten raw Jacobians with M = chol(cov)^-1 (lower triangular) into LDS, then 30x30 blocks; even then odd factors
-    double *Jw = work;  // [W][450]
-    for (int w = t; w < W * 450; w += nt) {
-        int i = w / 450, q = w - i * 450, r = q / 30, col = q - r * 30;
-        const PreInt &p = c.pre[be.pre_idx[i + 1]];
-        const double *raw = c.imu_raw + (size_t)i * 15 * 31;
-        double sacc = 0;
-        for (int k = 0; k <= r; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k * 31 + col];
-        Jw[w] = sacc;
-    }
-    __syncthreads();
-    for (int parity = 0; parity < 2; parity++) {
-        for (int w = t; w < W * 930; w += nt) {
-            int i = w / 930;
-            if ((i & 1) != parity) continue;
-            const PreInt &p = c.pre[be.pre_idx[i + 1]];
-            if (p.sum_dt > 10.0) continue;
-            int q = w - i * 930;
-            const double *Jf = Jw + i * 450;
-            const double *raw = c.imu_raw + (size_t)i * 15 * 31;
-            int a = q / 31, b = q - a * 31;
-            int ia = a < 6 ? 6 * i + a : (a < 15 ? 6 * (W + 1) + 9 * i + (a - 6) : (a < 21 ? 6 * (i + 1) + (a - 15) : 6 * (W + 1) + 9 * (i + 1) + (a - 21)));
-            double sacc = 0;
-            if (b < 30) {
-                int ib = b < 6 ? 6 * i + b : (b < 15 ? 6 * (W + 1) + 9 * i + (b - 6) : (b < 21 ? 6 * (i + 1) + (b - 15) : 6 * (W + 1) + 9 * (i + 1) + (b - 21)));
-                for (int k = 0; k < 15; k++) sacc += Jf[k * 30 + a] * Jf[k * 30 + b];
-                H[ia * LW + ib] += sacc;
-            } else {
-                for (int k = 0; k < 15; k++) sacc += Jf[k * 30 + a] * raw[k * 31 + 30];
-                g[ia] += sacc;
+    // IMU: one wavefront per factor.  [J r] (15 x 31, r already whitened by evaluate) is whitened with M = chol(cov)^-1 from a
+    // per-wave LDS slice and squared on the FP64 matrix cores (K = 16, three 16x16 accumulators); even factors first, then odd
+    // ones (neighbouring factors share the pose / speed-bias block of the frame between them).
+    {
+        const int li = lane & 15, lk = lane >> 4;
+        const int nconc = max(1, min(nw, (W * 450) / 704));
+        for (int parity = 0; parity < 2; parity++) {
+            for (int base = 0; 2 * base + parity < W; base += nconc) {
+                const int i = 2 * (base + wave) + parity;
+                bool act = wave < nconc && i < W;
+                const PreInt *pp = act ? &c.pre[be.pre_idx[i + 1]] : nullptr;
+                if (act && pp->sum_dt > 10.0) act = false;
+                double *raw_l = work + (wave < nconc ? wave : 0) * 704, *M_l = raw_l + 472;
+                if (act) {
+                    const double *raw = c.imu_raw + (size_t)i * 15 * 31;
+                    for (int q = lane; q < 465; q += 64) raw_l[q] = raw[q];
+                    for (int q = lane; q < 225; q += 64) M_l[q] = pp->sqrt_info[q];
+                }
+                __syncthreads();
+                if (act) {
+                    v4f64 a00 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) {
+                        const int kk = 4 * ks + lk;
+                        double x0 = 0, x1 = 0;
+                        if (kk < 15) {
+                            const int c1 = 16 + li;
+                            for (int k = 0; k <= kk; k++) {
+                                double m = M_l[kk * 15 + k];
+                                x0 += m * raw_l[k * 31 + li];
+                                if (c1 < 30) x1 += m * raw_l[k * 31 + c1];
+                            }
+                            if (c1 == 30) x1 = raw_l[kk * 31 + 30];
+                        }
+                        a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, a00, 0, 0, 0);
+                        a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, a10, 0, 0, 0);
+                        a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, a11, 0, 0, 0);
+                    }
+                    auto gidx = [&](int a) {
+                        return a < 6 ? 6 * i + a : (a < 15 ? 6 * (W + 1) + 9 * i + (a - 6) : (a < 21 ? 6 * (i + 1) + (a - 15) : 6 * (W + 1) + 9 * (i + 1) + (a - 21)));
+                    };
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = lk + 4 * r, col = li;  // C/D layout: acc[r] = element (row, col)
+                        const int ic = gidx(col);
+                        H[gidx(row) * LW + ic] += a00[r];
+                        const int r1 = 16 + row, c1 = 16 + col;
+                        if (r1 < 30) {
+                            const int ir = gidx(r1);
+                            H[ir * LW + ic] += a10[r];
+                            H[ic * LW + ir] += a10[r];
+                            if (c1 < 30) H[ir * LW + gidx(c1)] += a11[r];
+                        } else if (r1 == 30) {
+                            g[ic] += a10[r];
+                            if (c1 < 30) g[gidx(c1)] += a11[r];
+                        }
+                    }
+                }
+                __syncthreads();
             }
         }
-        __syncthreads();
     }
     PH(34);
     // vision: frame-pair blocks G_p = [J19 r]^T [J19 r] (packed symmetric 20x20) on the FP64 matrix cores:
@@ -1369,18 +1532,33 @@ __device__ void assemble(const Batch &B, const Ctx &c, const Params &X, int nres
             if (np_ == 0) { for (int e = lane; e < 210; e += 64) out[e] = 0; continue; }
             v4f64 a00 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
             const int K = 2 * np_;
-            for (int k0 = 0; k0 < K; k0 += 4) {
-                int kk = k0 + lk;
-                double x0 = 0, x1 = 0;
-                if (kk < K) {
-                    const double *Jr = c.res + (size_t)c.pair_list[q0 + (kk >> 1)] * 42;
-                    int ro = (kk & 1) * 20;
-                    x0 = Jr[ro + li];
-                    x1 = li < 3 ? Jr[ro + 16 + li] : (li == 3 ? Jr[40 + (kk & 1)] : 0.0);
+            // residual indices of the pair are fetched 64 at a time (one coalesced load) and broadcast with shuffles; the
+            // k loop is unrolled by 4 with unconditional (clamped) loads so that 8 row loads are in flight per MFMA batch
+            for (int base = 0; base < np_; base += 64) {
+                const int nchunk = min(64, np_ - base);
+                const int myidx = c.pair_list[q0 + base + min(lane, nchunk - 1)];
+                const int Kc = 2 * nchunk;
+                for (int k0 = 0; k0 < Kc; k0 += 16) {
+                    double x0[4], x1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        int kk = k0 + 4 * u + lk;
+                        bool valid = kk < Kc;
+                        int ridx = __shfl(myidx, min(kk, Kc - 1) >> 1, 64);
+                        const double *Jr = c.res + (size_t)ridx * 42;
+                        int sub = kk & 1, ro = sub * 20;
+                        double v0 = Jr[ro + li];
+                        double v1 = Jr[li < 3 ? ro + 16 + li : 40 + sub];
+                        x0[u] = valid ? v0 : 0.0;
+                        x1[u] = (valid && li < 4) ? v1 : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u], x0[u], a00, 0, 0, 0);
+                        a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x0[u], a10, 0, 0, 0);
+                        a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x1[u], a11, 0, 0, 0);
+                    }
                 }
-                a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, a00, 0, 0, 0);
-                a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, a10, 0, 0, 0);
-                a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, a11, 0, 0, 0);
             }
             for (int r = 0; r < 4; r++) {
                 int row = lk + 4 * r, col = li;  // C/D layout of v_mfma_f64_16x16x4_f64
@@ -1403,11 +1581,20 @@ __device__ void assemble(const Batch &B, const Ctx &c, const Params &X, int nres
             if (fa >= 0 && fb >= 0 && fa != fb) {
                 int i = min(fa, fb), j = max(fa, fb);
                 sacc = pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(local_of(a, i, j, W), local_of(b, i, j, W))];
+            } else if (fa >= 0 || fb >= 0) {
+                // diagonal pose block, or pose x (extrinsic / td / gradient): only the W pairs that contain that frame
+                const int f = fa >= 0 ? fa : fb;
+                for (int o = 0; o < W1; o++) {
+                    if (o == f) continue;
+                    int i = min(f, o), j = max(f, o), p = i * W1 + j;
+                    if (c.pair_start[p + 1] == c.pair_start[p]) continue;
+                    int la = local_of(a, i, j, W);
+                    int lb = b >= 0 ? local_of(b, i, j, W) : 19;
+                    sacc += pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(la, lb)];
+                }
             } else {
                 for (int i = 0; i < W1; i++)
                     for (int j = i + 1; j < W1; j++) {
-                        if (fa >= 0 && fa != i && fa != j) continue;
-                        if (fb >= 0 && fb != i && fb != j) continue;
                         int p = i * W1 + j;
                         if (c.pair_start[p + 1] == c.pair_start[p]) continue;
                         int la = local_of(a, i, j, W);
@@ -1457,7 +1644,7 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw);
 __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem, PreWork &pw);
 
 __global__ __launch_bounds__(1024) void be_solve_kernel(Batch B) {
-    const int s = blockIdx.x;
+    const int s = blockIdx.x + B.s0;
     __shared__ int scratch[2 * 1024 + 8];
     __shared__ double sred[64];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1466,7 +1653,7 @@ __global__ __launch_bounds__(1024) void be_solve_kernel(Batch B) {
 }
 // the same body compiled for 512 threads: 256 VGPRs per lane instead of 128 (no scratch spills), half the waves
 __global__ __launch_bounds__(512) void be_solve_kernel_512(Batch B) {
-    const int s = blockIdx.x;
+    const int s = blockIdx.x + B.s0;
     __shared__ int scratch[2 * 1024 + 8];
     __shared__ double sred[64];
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1475,7 +1662,7 @@ __global__ __launch_bounds__(512) void be_solve_kernel_512(Batch B) {
 }
 // marginalisation + window slide: 256 threads (barrier-heavy eigen-decomposition; measured faster than 1024)
 __global__ __launch_bounds__(256) void be_marg_kernel(Batch B) {
-    const int s = blockIdx.x;
+    const int s = blockIdx.x + B.s0;
     __shared__ int scratch[2 * 256 + 8];
     __shared__ double sred[64];
     __shared__ PreWork pw;
@@ -1754,9 +1941,8 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                 PH(6);
             }
             // Cauchy point: alpha = |grad|^2 / |J D^-1 grad|^2, and H_full * (D^-1 grad) is kept for the model evaluation
-            colsum(c.H, LW, P, up, P, tmpv, work);            // H (S sg_p)
-            colsum(c.Hpl, LW, Fa, ul, P, tmpv2, work);        // Hpl^T (Sl sg_l)
-            rowdot(c.Hpl, LW, Fa, up, P, tmpl);               // Hpl (S sg_p)
+            matvec_pass(c.H, LW, P, P, nullptr, up, nullptr, tmpv, work);   // H (S sg_p): H is symmetric, row dots
+            matvec_pass(c.Hpl, LW, Fa, P, ul, up, tmpv2, tmpl, work);       // Hpl^T (Sl sg_l) and Hpl (S sg_p) in one pass
             double g2 = 0, jg2 = 0;
             for (int a = t; a < LW; a += nt) {
                 double v = a < P ? sp[a] * (tmpv[a] + tmpv2[a]) : 0.0;
@@ -1782,13 +1968,17 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                     tmpl[k] = sl[k] * iv * gls[k];
                 }
                 __syncthreads();
-                colsum(c.Hpl, LW, Fa, tmpl, P, tmpv, work);  // Hpl^T (Sl gls / hll); uses the work region before S moves in
+                matvec_pass(c.Hpl, LW, Fa, P, tmpl, nullptr, tmpv, nullptr, work);  // Hpl^T (Sl gls / hll); uses the work region before S moves in
                 for (int a = t; a < LW; a += nt) xs[a] = a < P ? gs[a] - sp[a] * tmpv[a] : 0.0;
                 for (int k = t; k < Kpad; k += nt) tmpl[k] = sl[k] * sl[k] * inv[k];  // per-row factor of the rank-K update
                 __syncthreads();
                 bool chol_ok;
                 if (tiles_in_lds) {
-                    schur_mfma_lds(c.H, c.Hpl, tmpl, dgp, sp, mu, Kpad, LW, LW, work);
+                    {
+                        const int ntile_ = (LW >> 4) * ((LW >> 4) + 1) / 2, nw_ = nt >> 6;
+                        if (ntile_ <= 9 * nw_ && 2 * SCH_CH * (LW + 8) <= ntile_ * 256) schur_mfma_staged<9>(c.H, c.Hpl, tmpl, dgp, sp, mu, Kpad, LW, LW, work);
+                        else schur_mfma_lds(c.H, c.Hpl, tmpl, dgp, sp, mu, Kpad, LW, LW, work);
+                    }
                     PH(8);
                     chol_ok = chol_tiles(work, LW >> 4, &sh_i[2]);
                 } else {
@@ -1807,7 +1997,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                     if (bad == 0) {
                         for (int a = t; a < LW; a += nt) { yp[a] = xs[a]; gnp[a] = -xs[a] * dgp[a]; tmpv[a] = sp[a] * xs[a]; }
                         __syncthreads();
-                        rowdot(c.Hpl, LW, Fa, tmpv, P, tmpl);  // Hpl (S y_p)
+                        matvec_pass(c.Hpl, LW, Fa, P, nullptr, tmpv, nullptr, tmpl, nullptr);  // Hpl (S y_p)
                         for (int k = t; k < Kpad; k += nt) {
                             double y = k < Fa ? (gls[k] - sl[k] * tmpl[k]) * inv[k] : 0.0;
                             yl[k] = y;
@@ -2051,11 +2241,9 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
             if (a < 6 * W + 15) return rE + (a - 6 * W - 9);
             return rT;
         };
-        for (int w = t; w < n * n; w += nt) {
+        for (int w = t; w < n * n; w += nt) {  // J^T J of the prior is kept next to J (prior_H, written when the prior was built)
             int a = w / n, bb = w - a * n;
-            double sacc = 0;
-            for (int i = 0; i < n; i++) sacc += c.prior_J[i * n + a] * c.prior_J[i * n + bb];
-            A[pmap(a) * mq + pmap(bb)] += sacc;
+            A[pmap(a) * mq + pmap(bb)] += c.prior_H[w];
         }
         for (int a = t; a < n; a += nt) {
             double sacc = 0;
@@ -2190,22 +2378,42 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
         }
         __syncthreads();
         PH(19);
-        // frame blocks G_j = sum over the residuals observing frame j of [J19 r]^T [J19 r] (packed symmetric 20x20)
-        for (int w = t; w < W * 210; w += nt) {
-            int j = w / 210 + 1, e = w - (j - 1) * 210;
-            int a = 0, rem = e;
-            while (rem >= 20 - a) { rem -= 20 - a; a++; }
-            int bcol = a + rem;
-            int ca = a < 19 ? a : -1, cb = bcol < 19 ? bcol : -1;
-            double sacc = 0;
-            for (int li = 0; li < F0c; li++) {
-                if (j >= c.lm_nobs[list0[li]]) continue;
-                const double *Jr = c.res + (size_t)(li * per + j - 1) * 42;
-                double a0 = ca >= 0 ? Jr[ca] : Jr[40], a1 = ca >= 0 ? Jr[20 + ca] : Jr[41];
-                double b0 = cb >= 0 ? Jr[cb] : Jr[40], b1 = cb >= 0 ? Jr[20 + cb] : Jr[41];
-                sacc += a0 * b0 + a1 * b1;
+        // frame blocks G_j = sum over the residuals observing frame j of [J19 r]^T [J19 r] (packed symmetric 20x20) on the FP64
+        // matrix cores: one wavefront per frame, K = 2 rows per landmark (rows of landmarks that do not see frame j are zero)
+        {
+            const int lane = t & 63, wave = t >> 6, nw = nt >> 6, li = lane & 15, lk = lane >> 4;
+            for (int j = 1 + wave; j <= W; j += nw) {
+                v4f64 a00 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
+                const int K = 2 * F0c;
+                for (int k0 = 0; k0 < K; k0 += 16) {
+                    double x0[4], x1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        int kk = k0 + 4 * u + lk;
+                        bool valid = kk < K;
+                        int lm = min(kk, K - 1) >> 1, sub = kk & 1;
+                        const double *Jr = c.res + (size_t)(lm * per + j - 1) * 42;
+                        double v0 = Jr[sub * 20 + li];
+                        double v1 = Jr[li < 3 ? sub * 20 + 16 + li : 40 + sub];
+                        x0[u] = valid ? v0 : 0.0;
+                        x1[u] = (valid && li < 4) ? v1 : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u], x0[u], a00, 0, 0, 0);
+                        a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x0[u], a10, 0, 0, 0);
+                        a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x1[u], a11, 0, 0, 0);
+                    }
+                }
+                double *out = c.pairblk + (size_t)(j - 1) * 210;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int row = lk + 4 * r, col = li;
+                    if (col <= row) out[sym_idx(col, row)] = a00[r];
+                    if (row < 4) out[sym_idx(col, 16 + row)] = a10[r];
+                    if (row < 4 && col < 4 && col <= row) out[sym_idx(16 + col, 16 + row)] = a11[r];
+                }
             }
-            c.pairblk[w] = sacc;
         }
         for (int li = t; li < F0c; li += nt) { double d = c.Hll[li]; c.Hll[li] = d > eps ? 1.0 / d : 0.0; }  // pseudo-inverse of the diagonal block
         __syncthreads();
@@ -2229,10 +2437,46 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
                 if (lb < 0) continue;
                 sacc += c.pairblk[(size_t)(j - 1) * 210 + sym_idx(la, lb)];
             }
-            double sub_ = 0;
-            if (bb < mq) { for (int li = 0; li < F0c; li++) sub_ += Cl[(size_t)li * ldc + a] * Cl[(size_t)li * ldc + bb] * c.Hll[li]; }
-            else { for (int li = 0; li < F0c; li++) sub_ += Cl[(size_t)li * ldc + a] * c.gl[li] * c.Hll[li]; }
-            if (bb < mq) A[a * mq + bb] += sacc - sub_; else b[a] += sacc - sub_;
+            if (bb < mq) A[a * mq + bb] += sacc;
+            else {
+                double sub_ = 0;
+                for (int li = 0; li < F0c; li++) sub_ += Cl[(size_t)li * ldc + a] * c.gl[li] * c.Hll[li];
+                b[a] += sacc - sub_;
+            }
+        }
+        __syncthreads();
+        // A_qq -= C^T D^+ C : rank-F0c update on the FP64 matrix cores, lower 16x16 tiles mirrored into the upper triangle
+        {
+            const int lane = t & 63, wave = t >> 6, nw = nt >> 6, li = lane & 15, lk = lane >> 4;
+            const int nbq = (mq + 15) >> 4, ntile = nbq * (nbq + 1) / 2;
+            for (int tile = wave; tile < ntile; tile += nw) {
+                int ti, tj;
+                tri_decode(tile, ti, tj);
+                v4f64 acc = {0, 0, 0, 0};
+                const int ca = min(16 * ti + li, ldc - 1), cb = min(16 * tj + li, ldc - 1);
+                for (int k0 = 0; k0 < F0c; k0 += 16) {
+                    double xa[4], xb[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        int kk = k0 + 4 * u + lk;
+                        bool valid = kk < F0c;
+                        int kc = min(kk, F0c - 1);
+                        double va = Cl[(size_t)kc * ldc + ca], vb = Cl[(size_t)kc * ldc + cb], dinv = c.Hll[kc];
+                        xa[u] = valid ? -(va * dinv) : 0.0;
+                        xb[u] = valid ? vb : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], xb[u], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int row = 16 * ti + lk + 4 * r, col = 16 * tj + li;
+                    if (row < mq && col < mq && (ti != tj || col <= row)) {
+                        A[row * mq + col] += acc[r];
+                        if (row != col) A[col * mq + row] += acc[r];
+                    }
+                }
+            }
         }
         if (t == 0) {
             for (int li = 0; li < F0c; li++) {

@@ -70,7 +70,7 @@ __device__ __forceinline__ bool in_disk(const int *hw, int r, int px, int py, in
 // ------------------------------------------------------------------------------------------------ fe_begin
 // grid S, 64 threads.  mode: 0 = vio_feed (nodelet gating), 1 = vio_track only (no gating)
 __global__ void fe_begin_kernel(Batch B, const double *stamps, int gate) {
-    int s = blockIdx.x;
+    int s = blockIdx.x + B.s0;
     if (threadIdx.x != 0) return;
     const DevCfg &C = *B.cfg;
     FeSeq &fe = B.fe[s];
@@ -179,7 +179,7 @@ __device__ void pyrdown_tile(const uint8_t *src, int sw, int sh, uint8_t *dst, u
 __global__ __launch_bounds__(256) void fe_pyrdown_kernel(Batch B, const uint8_t *src_base, size_t src_stride, int sw, int sh,
                                                          int dst_level, int write_level0) {
     const DevCfg &C = *B.cfg;
-    int s = blockIdx.z;
+    int s = blockIdx.z + B.s0;
     FeSeq &fe = B.fe[s];
     if (fe.n_forw < 0) return;
     int forw = fe.has_img ? (fe.cur_buf ^ 1) : fe.cur_buf;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void fe_pyrdown_stage_kernel(const uint8_t *sr
 // predictPtsInNextFrame (feature_tracker.cpp:595-608). grid (ceil(NP/256), S)
 __global__ void fe_predict_kernel(Batch B) {
     const DevCfg &C = *B.cfg;
-    int s = blockIdx.y;
+    int s = blockIdx.y + B.s0;
     FeSeq &fe = B.fe[s];
     if (fe.n_forw < 0) return;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -347,7 +347,7 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
 // grid (NP, S), 64 threads
 __global__ __launch_bounds__(64) void fe_lk_kernel(Batch B) {
     const DevCfg &C = *B.cfg;
-    int s = blockIdx.y, i = blockIdx.x;
+    int s = blockIdx.y + B.s0, i = blockIdx.x;
     FeSeq &fe = B.fe[s];
     if (fe.n_forw < 0 || i >= fe.n_pts) return;
     __shared__ uint8_t win[24 * 24];
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void fe_ransac_stage_kernel(vio_config c, int 
 __global__ __launch_bounds__(256) void fe_select_kernel(Batch B, int publish) {
     const DevCfg &C = *B.cfg;
     const vio_config &c = C.c;
-    const int s = blockIdx.x, t = threadIdx.x, NP = C.NP;
+    const int s = blockIdx.x + B.s0, t = threadIdx.x, NP = C.NP;
     FeSeq &fe = B.fe[s];
     if (fe.n_forw < 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -875,7 +875,7 @@ __device__ int fast_cell(const uint8_t *img, int W, GridRect r, uint8_t *tile, u
 
 __global__ __launch_bounds__(256) void fe_fast_kernel(Batch B) {
     const DevCfg &C = *B.cfg;
-    int s = blockIdx.y, cell = blockIdx.x;
+    int s = blockIdx.y + B.s0, cell = blockIdx.x;
     FeSeq &fe = B.fe[s];
     if (fe.n_forw < 0 || fe.cell_ncand[cell] < 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256) void fe_fast_stage_kernel(const uint8_t *img, 
 __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int publish, int gate) {
     const DevCfg &C = *B.cfg;
     const vio_config &c = C.c;
-    const int s = blockIdx.x, t = threadIdx.x, NP = C.NP;
+    const int s = blockIdx.x + B.s0, t = threadIdx.x, NP = C.NP;
     FeSeq &fe = B.fe[s];
     if (fe.n_forw < 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

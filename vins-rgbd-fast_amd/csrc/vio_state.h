@@ -99,6 +99,7 @@ struct BeSeq {
 struct Batch {
     DevCfg *cfg;  // device copy
     int S;
+    int s0;               // first sequence of the launching group: kernels use s = blockIdx + s0
     FeSeq *fe;
     BeSeq *be;
     PreInt *pre;          // [S][W+2]
