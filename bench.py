@@ -206,7 +206,7 @@ def main():
     parity = None
     if rank == 0 and args.cpu_seqs > 0:
         ncs = min(args.cpu_seqs, S)
-        tcpu, nfr, rm = 0.0, 0, []
+        tcpu, nfr, rm, ate_pairs = 0.0, 0, [], []
         for s in range(ncs):
             o = vio_ct.OraclePipeline(cfg)
             ti, ai, gi = syn.imu(seq0 + s, nimu)
@@ -228,17 +228,24 @@ def main():
             m = min(len(traj), len(hh))
             if m > 0:
                 rm.append(float(np.sqrt(((np.array(traj[:m]) - hh[:m, 1:4]) ** 2).sum(1).mean())))
+            if m >= 5:
+                gt = np.array([syn.pose(seq0 + s, float(t))[0] for t in hh[:m, 0]])
+                ate_pairs.append((vio_ct.ate_rmse(hh[:m, 1:4], gt), vio_ct.ate_rmse(np.array(traj[:m]), gt)))
         cpu = dict(value=nfr / tcpu if tcpu > 0 else None, unit="frames/s", cores=1, kind="port",
                    sample="%d sequences x %d steady-state frames of the same rendered workload through oracle/ (-O3, 1 thread; "
                           "the reference binary needs ROS/OpenCV/Ceres and cannot be built here)" % (ncs, nfr // max(ncs, 1)),
                    cpu_seconds=tcpu)
-        parity = dict(traj_rmse_hip_vs_oracle_m=float(np.max(rm)) if rm else None, sequences=ncs, per_sequence=rm)
+        ah = float(np.mean([a for a, _ in ate_pairs])) if ate_pairs else None
+        ao = float(np.mean([b for _, b in ate_pairs])) if ate_pairs else None
+        parity = dict(traj_rmse_hip_vs_oracle_m=float(np.max(rm)) if rm else None, sequences=ncs, per_sequence=rm,
+                      ate_hip_m=ah, ate_oracle_m=ao, ate_rel_diff=(abs(ah - ao) / ao if ao else None),
+                      note="north-star tolerance: ATE of the HIP path within 1 % of the reference algorithm (oracle) on identical input")
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
     if os.path.exists(tpath):  # written by profiles/collect.sh from separate rocprofv3 --pmc passes over this same command
         tj = json.load(open(tpath))
-        ent = tj.get("kernels", {}).get(roof["kernel"])
+        ent = next((v for k, v in tj.get("kernels", {}).items() if k.startswith(dom)), None)  # be_solve -> be_solve_kernel_512
         if ent and tj.get("sequences_per_gpu") == S:
             traffic = ent["hbm_bytes_per_launch"]
             roof["traffic_source"] = "profiles/round1_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)"

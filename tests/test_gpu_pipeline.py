@@ -99,3 +99,26 @@ def test_pipeline_matches_oracle(P, variant):
         a, q = o["oracle"].tracks(), b.tracks(i)
         assert np.array_equal(a[0], q[0]) and np.array_equal(a[1], q[1])
         assert np.abs(a[2] - q[2]).max() < 5e-3  # LK stops at 0.01 px; device sin/cos in predictMotion differ by ulps
+
+
+def test_pipeline_config5_shape(P):
+    """BASELINE configs[4] shape on one sequence: 1280x720, 300 features, 20-keyframe window, 7x8 grid (intrinsics scaled x2 / x1.5).
+    Exercises the large-window code paths (Schur complement / Cholesky in HBM instead of LDS tiles, 210 frame pairs, n_prior = 136).
+    Same bar as the canonical configuration: identical decisions, window positions within 1e-5 m of the oracle."""
+    cfg = P.canonical_config(width=1280, height=720, max_cnt=300, window_size=20, grid_rows=7, grid_cols=8, max_landmarks=2048,
+                             fx=604.5821781259577 * 2, fy=604.2544712985845 * 1.5, cx=321.2638233484251 * 2, cy=239.70969315130674 * 1.5)
+    sc = vio_ct.synth_like(cfg)
+    seqs, n_frames = [1], 34
+    oruns = [vio_ct.run_oracle_sequence(cfg, sc, s, n_frames) for s in seqs]
+    b, traj, stat = _run_hip(P, cfg, sc, seqs, n_frames, [r["frames"] for r in oruns])
+    o = oruns[0]
+    assert len(traj[0]) == len(o["traj"]) >= 8
+    for f in range(n_frames):
+        so, sh = o["status"][f], stat[0][f]
+        assert int(so["solver_flag"]) == sh.solver_flag and int(so["frame_count"]) == sh.frame_count, f
+        assert int(so["n_landmarks"]) == sh.n_landmarks, (f, so["n_landmarks"], sh.n_landmarks)
+        if sh.solver_flag == 1 and sh.processed:
+            assert int(so["n_residuals"]) == sh.n_residuals and int(so["marginalization_flag"]) == sh.marginalization_flag, f
+    po = np.array([x[1] for x in o["traj"]]); ph = np.array([x[1] for x in traj[0]])
+    assert np.abs(po - ph).max() < 1e-5, float(np.abs(po - ph).max())
+    assert vio_ct.ate_rmse(ph, np.array(o["gt"])) < 0.03

@@ -54,7 +54,7 @@ __device__ Ctx make_ctx(const Batch &B, int s) {
     c.H = B.H + (size_t)s * C.LW * C.LW; c.Sc = B.Sc + (size_t)s * C.LW * C.LW; c.Hpl = B.Hpl + (size_t)s * (C.NL + 8) * C.LW;
     c.vec = B.vec + (size_t)s * VEC_SLOTS * C.LW;
     c.Hll = B.Hll + (size_t)s * (C.NL + 8); c.gl = B.gl + (size_t)s * (C.NL + 8); c.lvec = B.lvec + (size_t)s * (C.NL + 8) * 8;
-    c.nres_cap = 4 * C.NL;
+    c.nres_cap = C.NRES;
     c.res = B.res + (size_t)s * c.nres_cap * 42;
     c.res_lm = B.res_lm + (size_t)s * c.nres_cap; c.res_k = B.res_k + (size_t)s * c.nres_cap;
     int np = (C.W + 1) * (C.W + 1);

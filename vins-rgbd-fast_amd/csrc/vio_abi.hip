@@ -299,6 +299,8 @@ static int build_devcfg(const vio_config *cfg, int imu_capacity, DevCfg &C) {
     C.NL = (C.NL + 7) & ~7;
     C.lm_hash_size = 256;
     while (C.lm_hash_size < 2 * C.NL) C.lm_hash_size <<= 1;
+    C.NRES = std::max(4 * C.NL, C.W * C.NP + 2 * C.NL);
+    C.NRES = (C.NRES + 63) & ~63;
     C.NIMU = imu_capacity < 256 ? 256 : imu_capacity;
     C.P = 15 * (C.W + 1) + 7;
     C.NPRIOR = 6 * C.W + 16;
@@ -339,7 +341,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     DA(B.lm_id, S * NL); DA(B.lm_start, S * NL); DA(B.lm_nobs, S * NL); DA(B.lm_est_flag, S * NL); DA(B.lm_solve_flag, S * NL);
     DA(B.lm_dyn, S * NL); DA(B.lm_order, S * NL); DA(B.lm_free, S * NL); DA(B.lm_tmp, S * NL); DA(B.lm_pidx, S * NL); DA(B.lm_aidx, S * NL);
     DA(B.lm_depth, S * NL); DA(B.lm_obs, S * NL * W1 * VIO_OBS_D); DA(B.para_feat, S * NL); DA(B.cand_feat, S * NL);
-    const size_t n = C.NPRIOR, LW = C.LW, nres = 4 * NL, npair = W1 * W1, mq = 15 + n;
+    const size_t n = C.NPRIOR, LW = C.LW, nres = C.NRES, npair = W1 * W1, mq = 15 + n;
     DA(B.prior_J, S * n * n); DA(B.prior_r, S * n); DA(B.prior_x0, S * (C.W * 7 + 17)); DA(B.prior_H, S * n * n);
     DA(B.H, S * LW * LW); DA(B.Sc, S * LW * LW); DA(B.Hpl, S * (NL + 8) * LW); DA(B.vec, S * VEC_SLOTS * LW);
     DA(B.Hll, S * (NL + 8)); DA(B.gl, S * (NL + 8)); DA(B.lvec, S * (NL + 8) * 8);
@@ -555,7 +557,8 @@ int vio_get_status(vio_batch *h, int seq, vio_status *out) {
     static thread_local FeSeq fe;
     HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&fe, h->B.fe + seq, sizeof(FeSeq), hipMemcpyDeviceToHost));
-    out->code = be.status_code; out->solver_flag = be.solver_flag; out->frame_count = be.frame_count;
+    out->code = (be.overflow && be.status_code == VIO_OK) ? VIO_ECAPACITY : be.status_code;  // a table overflowed: results are truncated, say so
+    out->solver_flag = be.solver_flag; out->frame_count = be.frame_count;
     out->marginalization_flag = be.marginalization_flag; out->n_landmarks = be.n_lm; out->last_track_num = be.last_track_num;
     out->n_tracks = fe.n_pts; out->processed = be.processed; out->iterations = be.iterations; out->successful_steps = be.successful;
     out->n_in_problem = be.n_in_problem; out->n_residuals = be.n_residuals; out->n_var_landmarks = be.n_var_landmarks;

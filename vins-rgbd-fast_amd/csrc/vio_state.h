@@ -24,6 +24,7 @@ struct DevCfg {
     int NP;             // capacity of the tracker point arrays
     int NL;             // landmark table capacity
     int lm_hash_size;   // power of two >= 2 * NL: id -> slot hash table built in LDS by be_ingest
+    int NRES;           // residual slots per sequence: W * NP in-problem observations + 2 * NL list scratch at the tail
     int NIMU;           // IMU ring capacity
     int ncells;
     int grids_threshold;
