@@ -409,6 +409,115 @@ __device__ void sym_eig_tridiag(double *__restrict__ V, int n, int ld, double *_
     __syncthreads();
 }
 
+// Householder tridiagonalisation with accumulation (same recurrences as sym_eig_tridiag), spread over the whole workgroup:
+// the O(i) reductions are computed redundantly by every wavefront (no writes, no barrier), the two O(i^2) pieces of each step --
+// the symmetric matrix-vector product and the rank-2 update -- are split over all threads.  part: LDS [nw * EIG_LD].
+#define EIG_LD (6 * VIO_MAXW + 16)
+__device__ void sym_eig_tridiag_mt(double *V, int n, int ld, double *d, double *e, double *gtmp, double *part) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    for (int j = t; j < n; j += nt) d[j] = V[(n - 1) * ld + j];
+    __syncthreads();
+    for (int i = n - 1; i > 0; i--) {
+        double sc = 0;
+        for (int k = lane; k < i; k += 64) sc += fabs(d[k]);
+        sc = wave_sum(sc);
+        if (sc == 0.0) {
+            __syncthreads();
+            if (t == 0) { e[i] = d[i - 1]; }
+            __syncthreads();
+            for (int j = t; j < i; j += nt) { d[j] = V[(i - 1) * ld + j]; V[i * ld + j] = 0.0; V[j * ld + i] = 0.0; }
+            if (t == 0) d[i] = 0.0;
+            __syncthreads();
+            continue;
+        }
+        double h = 0;
+        for (int k = lane; k < i; k += 64) { double v = d[k] / sc; h += v * v; }
+        h = wave_sum(h);
+        const double f = d[i - 1] / sc;
+        double g = sqrt(h);
+        if (f > 0) g = -g;
+        h -= f * g;
+        // u[k] = scaled Householder vector (not yet stored): d[k] / sc, last entry f - g
+        // partial products: lanes own rows j (and j + 64, ...), wavefronts split the k range
+        {
+            const int kc = (i + nw - 1) / nw, kb = wave * kc, ke = min(i, kb + kc);
+            for (int j = lane; j < i; j += 64) {
+                double acc = 0;
+#pragma unroll 4
+                for (int k = kb; k < ke; k++) {
+                    double uk = (k == i - 1) ? (f - g) : d[k] / sc;
+                    acc += (k <= j ? V[j * ld + k] : V[k * ld + j]) * uk;
+                }
+                part[wave * EIG_LD + j] = acc;
+            }
+        }
+        __syncthreads();
+        for (int j = t; j < i; j += nt) {
+            double acc = 0;
+            for (int q = 0; q < nw; q++) acc += part[q * EIG_LD + j];
+            double uj = (j == i - 1) ? (f - g) : d[j] / sc;
+            e[j] = acc / h;
+            d[j] = uj;
+            V[j * ld + i] = uj;
+        }
+        if (t == 0) e[i] = sc * g;
+        __syncthreads();
+        double ff = 0;
+        for (int j = lane; j < i; j += 64) ff += e[j] * d[j];
+        ff = wave_sum(ff);
+        const double hh = ff / (h + h);
+        __syncthreads();  // everybody has read e[] before it is updated
+        for (int j = t; j < i; j += nt) e[j] -= hh * d[j];
+        __syncthreads();
+        for (int idx = t; idx < i * i; idx += nt) {
+            int k = idx / i, j = idx - k * i;
+            if (j <= k) V[k * ld + j] -= (d[j] * e[k] + e[j] * d[k]);
+        }
+        __syncthreads();
+        for (int j = t; j < i; j += nt) { d[j] = V[(i - 1) * ld + j]; V[i * ld + j] = 0.0; }
+        if (t == 0) d[i] = h;
+        __syncthreads();
+    }
+    // accumulate the Householder transformations
+    for (int i = 0; i < n - 1; i++) {
+        if (t == 0) { V[(n - 1) * ld + i] = V[i * ld + i]; V[i * ld + i] = 1.0; }
+        const double h = d[i + 1];
+        __syncthreads();
+        if (h != 0.0) {
+            {
+                const int m = i + 1, kc = (m + nw - 1) / nw, kb = wave * kc, ke = min(m, kb + kc);
+                for (int j = lane; j < m; j += 64) {
+                    double g = 0;
+#pragma unroll 4
+                    for (int k = kb; k < ke; k++) g += V[k * ld + i + 1] * V[k * ld + j];
+                    part[wave * EIG_LD + j] = g;
+                }
+            }
+            __syncthreads();
+            for (int j = t; j <= i; j += nt) {
+                double g = 0;
+                for (int q = 0; q < nw; q++) g += part[q * EIG_LD + j];
+                gtmp[j] = g;
+            }
+            __syncthreads();
+            {
+                const int m = i + 1;
+                for (int idx = t; idx < m * m; idx += nt) {
+                    int k = idx / m, j = idx - k * m;
+                    V[k * ld + j] -= gtmp[j] * (V[k * ld + i + 1] / h);
+                }
+            }
+            __syncthreads();
+        }
+        for (int k = t; k <= i; k += nt) V[k * ld + i + 1] = 0.0;
+        __syncthreads();
+    }
+    for (int j = t; j < n; j += nt) { d[j] = V[(n - 1) * ld + j]; V[(n - 1) * ld + j] = 0.0; }
+    __syncthreads();
+    if (t == 0) { V[(n - 1) * ld + n - 1] = 1.0; e[0] = 0.0; }
+    __syncthreads();
+}
+
 // implicit QL on the tridiagonal (d, e) with eigenvector accumulation into V; one wavefront, lanes own rows k, k+64, ...
 __device__ void tridiag_ql_wave(double *V, int n, int ld, double *d, double *e) {
     const int lane = threadIdx.x & 63;
@@ -1448,11 +1557,9 @@ __device__ void assemble(const Batch &B, const Ctx &c, const Params &X, int nres
             int a = w / n, b = w - a * n;
             H[prior_map(a, W) * LW + prior_map(b, W)] = c.prior_H[w];
         }
-        for (int a = t; a < n; a += nt) {
-            double sacc = 0;
-            for (int i = 0; i < n; i++) sacc += c.prior_J[i * n + a] * srp[i];
-            g[prior_map(a, W)] = sacc;
-        }
+        // g_prior = J^T r_p: one pass over J (rows over wavefronts), then scattered
+        matvec_pass(c.prior_J, n, n, n, srp, nullptr, work, nullptr, work + VIO_LWMAX);
+        for (int a = t; a < n; a += nt) g[prior_map(a, W)] = work[a];
     }
     __syncthreads();
     PH(33);
@@ -2531,7 +2638,9 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
     __syncthreads();
     long long tj0 = wall_clock64();
     __shared__ double ev_d[6 * VIO_MAXW + 16], ev_e[6 * VIO_MAXW + 16], ev_g[6 * VIO_MAXW + 16];
-    sym_eig_tridiag(As, n, ldj, ev_d, ev_e, ev_g, sred);
+    __shared__ double ev_part[4 * EIG_LD];
+    if ((nt >> 6) <= 4) sym_eig_tridiag_mt(As, n, ldj, ev_d, ev_e, ev_g, ev_part);
+    else sym_eig_tridiag(As, n, ldj, ev_d, ev_e, ev_g, sred);
     if (t == 0) be.dbg[5] = (int)(wall_clock64() - tj0);
     tridiag_ql_wave(As, n, ldj, ev_d, ev_e);
     if (t == 0) be.dbg[6] = (int)(wall_clock64() - tj0);
