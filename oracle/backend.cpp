@@ -333,8 +333,15 @@ void eval_projection(const Config &c, const double *pi, const double *pj, const 
 Estimator::Estimator(const Config &c) : cfg(c), W(c.window_size) {
     for (int i = 0; i <= MAXW; i++) pre_integrations[i] = nullptr;
     clearState();
+    // readParameters() re-orthonormalises the extrinsic rotation through a normalised quaternion (parameters.cpp:202-209)
+    {
+        M3 Rc;
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rc(i, j) = c.ric[i * 3 + j];
+        Rc = toR(normalized(fromR(Rc)));
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) cfg.ric[i * 3 + j] = Rc(i, j);
+    }
     // setParameter() estimator.cpp:15-41
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) ric(i, j) = c.ric[i * 3 + j];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) ric(i, j) = cfg.ric[i * 3 + j];
     tic = V3(c.tic[0], c.tic[1], c.tic[2]);
     td = c.td;
     g = V3(0, 0, c.g_norm);

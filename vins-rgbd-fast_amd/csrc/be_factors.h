@@ -332,6 +332,89 @@ DM_HD void eval_projection(const vio_config &c, const double *pi, const double *
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Frame-pair form of the projection factors.  Every residual between frames (i, j) shares
+//   A1 = ric^T Rj^T,  A2 = A1 Ri,  M = A2 ric,  t = A1 (Ri tic + Pi - Pj) - ric^T tic     (pts_camera_j = M pts_camera_i + t)
+// so the per-residual work of projection_factor.cpp:22-130 / projection_td_factor.cpp:34-150 reduces to a few 3-vector products
+// (same algebra, different association: results agree with eval_projection to round-off).
+struct PairGeo { double A1[9], A2[9], M[9], t[3]; };
+
+DM_HD void pair_geo(const double *pi, const double *pj, const double *ex, PairGeo &g) {
+    v3 Pi = ld3(pi), Pj = ld3(pj), tic = ld3(ex);
+    m3 Ri = q2R(mkq(pi[6], pi[3], pi[4], pi[5])), Rj = q2R(mkq(pj[6], pj[3], pj[4], pj[5])), ric = q2R(mkq(ex[6], ex[3], ex[4], ex[5]));
+    m3 ricT = tr(ric);
+    m3 A1 = mul(ricT, tr(Rj)), A2 = mul(A1, Ri), M = mul(A2, ric);
+    v3 t = sub(mul(A1, add(mul(Ri, tic), sub(Pi, Pj))), mul(ricT, tic));
+    stm(g.A1, A1); stm(g.A2, A2); stm(g.M, M); st3(g.t, t);
+}
+// row (1x3) times skew(w)
+DM_HD v3 rowskew(v3 r, v3 w) { return mk(r.y * w.z - r.z * w.y, r.z * w.x - r.x * w.z, r.x * w.y - r.y * w.x); }
+DM_HD v3 rowmul(v3 r, const double *A) {  // row (1x3) times a 3x3 row-major matrix
+    return mk(r.x * A[0] + r.y * A[3] + r.z * A[6], r.x * A[1] + r.y * A[4] + r.z * A[7], r.x * A[2] + r.y * A[5] + r.z * A[8]);
+}
+DM_HD v3 matvec9(const double *A, v3 v) { return mk(A[0] * v.x + A[1] * v.y + A[2] * v.z, A[3] * v.x + A[4] * v.y + A[5] * v.z, A[6] * v.x + A[7] * v.y + A[8] * v.z); }
+
+// ricm = ric (row-major 3x3), tic: extrinsic.  r[2]; J (optional) 2x20 row-major as in eval_projection.  With cauchy = true the
+// Jacobian is multiplied by the CauchyLoss(1) weight sqrt(1 / (1 + |r|^2)), which is returned in *wgt (r itself is left unweighted).
+DM_HD void eval_projection_pair(const vio_config &c, const PairGeo &g, const double *ricm, const double *ticp, double inv_dep, double td,
+                                const double *oi, const double *oj, bool use_td, double *r, double *J, bool cauchy, double *wgt) {
+    v3 pts_i = mk(oi[0], oi[1], oi[2]), pts_j = mk(oj[0], oj[1], oj[2]);
+    v3 vel_i = mk(oi[5], oi[6], 0), vel_j = mk(oj[5], oj[6], 0);
+    if (use_td) {
+        double ROW = (double)c.height;
+        double row_i = oi[4] - ROW / 2, row_j = oj[4] - ROW / 2;
+        pts_i = sub(pts_i, scl(td - oi[7] + c.tr / ROW * row_i, vel_i));
+        pts_j = sub(pts_j, scl(td - oj[7] + c.tr / ROW * row_j, vel_j));
+    }
+    const double sq = c.focal_length / 1.5;
+    v3 pc_i = mk(pts_i.x / inv_dep, pts_i.y / inv_dep, pts_i.z / inv_dep);
+    v3 tt = ld3(g.t);
+    v3 pc_j = add(matvec9(g.M, pc_i), tt);
+    const double dep_j = pc_j.z;
+    r[0] = sq * (pc_j.x / dep_j - pts_j.x);
+    r[1] = sq * (pc_j.y / dep_j - pts_j.y);
+    if (!J) return;
+    double s = 1.0;
+    if (cauchy) { s = sqrt(1.0 / (1.0 + (r[0] * r[0] + r[1] * r[1]))); *wgt = s; }
+    v3 red0 = mk(s * sq / dep_j, 0, -s * sq * pc_j.x / (dep_j * dep_j)), red1 = mk(0, s * sq / dep_j, -s * sq * pc_j.y / (dep_j * dep_j));
+    v3 tic = ld3(ticp);
+    v3 pim_i = add(matvec9(ricm, pc_i), tic), pim_j = add(matvec9(ricm, pc_j), tic);
+    // rho = red * A2, rho1 = red * A1, rhoT = red * ric^T, rhoM = red * M
+    v3 a0 = rowmul(red0, g.A1), a1 = rowmul(red1, g.A1);
+    v3 b0 = rowmul(red0, g.A2), b1 = rowmul(red1, g.A2);
+    v3 m0 = rowmul(red0, g.M), m1 = rowmul(red1, g.M);
+    // red * ric^T : (ric^T)[k][c] = ric[c][k]
+    v3 c0 = mk(red0.x * ricm[0] + red0.y * ricm[1] + red0.z * ricm[2], red0.x * ricm[3] + red0.y * ricm[4] + red0.z * ricm[5],
+               red0.x * ricm[6] + red0.y * ricm[7] + red0.z * ricm[8]);
+    v3 c1 = mk(red1.x * ricm[0] + red1.y * ricm[1] + red1.z * ricm[2], red1.x * ricm[3] + red1.y * ricm[4] + red1.z * ricm[5],
+               red1.x * ricm[6] + red1.y * ricm[7] + red1.z * ricm[8]);
+    v3 npi = neg(pim_i);
+    // pose_i: [red A1 | red A2 (-skew(pts_imu_i))]
+    st3(J + 0, a0); st3(J + 20, a1);
+    st3(J + 3, rowskew(b0, npi)); st3(J + 23, rowskew(b1, npi));
+    // pose_j: [-red A1 | red ric^T skew(pts_imu_j)]
+    st3(J + 6, neg(a0)); st3(J + 26, neg(a1));
+    st3(J + 9, rowskew(c0, pim_j)); st3(J + 29, rowskew(c1, pim_j));
+    // extrinsic: [red (A2 - ric^T) | red (-M skew(pc_i) + skew(pc_j))]
+    st3(J + 12, sub(b0, c0)); st3(J + 32, sub(b1, c1));
+    st3(J + 15, sub(rowskew(red0, pc_j), rowskew(m0, pc_i))); st3(J + 35, sub(rowskew(red1, pc_j), rowskew(m1, pc_i)));
+    // inverse depth: red * M * pts_i * (-1 / lambda^2)
+    {
+        v3 v = scl(-1.0 / (inv_dep * inv_dep), matvec9(g.M, pts_i));
+        J[19] = dot(red0, v);
+        J[39] = dot(red1, v);
+    }
+    if (use_td) {
+        v3 w0 = matvec9(g.M, vel_i);
+        v3 w = mk(w0.x / inv_dep * -1.0, w0.y / inv_dep * -1.0, w0.z / inv_dep * -1.0);
+        J[18] = dot(red0, w) + s * sq * vel_j.x;
+        J[38] = dot(red1, w) + s * sq * vel_j.y;
+    } else {
+        J[18] = 0;
+        J[38] = 0;
+    }
+}
+
 // MarginalizationFactor::Evaluate pose delta (marginalization_factor.cpp:374-393)
 DM_HD void pose_dx(const double *x, const double *x0, double *dx) {
     for (int k = 0; k < 3; k++) dx[k] = x[k] - x0[k];

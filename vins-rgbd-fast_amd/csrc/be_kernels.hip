@@ -30,7 +30,7 @@ struct Ctx {
     PreInt *pre;
     int *lm_id, *lm_start, *lm_nobs, *lm_est, *lm_solve, *lm_dyn, *lm_order, *lm_free, *lm_tmp, *lm_pidx, *lm_aidx;
     double *lm_depth, *lm_obs, *feat, *cfeat;
-    double *H, *Sc, *Hpl, *vec, *Hll, *gl, *lvec, *res;
+    double *H, *Sc, *Hpl, *vec, *Hll, *gl, *lvec, *res, *pairgeo;
     int *res_lm, *res_k, *pair_start, *pair_list;
     double *pairblk, *imu_raw;
     double *prior_J, *prior_r, *prior_x0, *prior_H;
@@ -51,6 +51,7 @@ __device__ Ctx make_ctx(const Batch &B, int s) {
     c.lm_tmp = B.lm_tmp + o; c.lm_pidx = B.lm_pidx + o; c.lm_aidx = B.lm_aidx + o;
     c.lm_depth = B.lm_depth + o; c.feat = B.para_feat + o; c.cfeat = B.cand_feat + o;
     c.lm_obs = B.lm_obs + o * (C.W + 1) * VIO_OBS_D;
+    c.pairgeo = B.pairgeo + (size_t)s * ((size_t)(C.W + 1) * (C.W + 1) + 1) * 32;
     c.H = B.H + (size_t)s * C.LW * C.LW; c.Sc = B.Sc + (size_t)s * C.LW * C.LW; c.Hpl = B.Hpl + (size_t)s * (C.NL + 8) * C.LW;
     c.vec = B.vec + (size_t)s * VEC_SLOTS * C.LW;
     c.Hll = B.Hll + (size_t)s * (C.NL + 8); c.gl = B.gl + (size_t)s * (C.NL + 8); c.lvec = B.lvec + (size_t)s * (C.NL + 8) * 8;
@@ -1491,21 +1492,40 @@ __device__ double evaluate(const Ctx &c, const Params &X, const double *feat, bo
     }
     PHT(43, nt - 1);
     PHT(46, 0);
-    // projection factors, CauchyLoss(1.0)
-    for (int r = t; r < nres; r += nt) {
-        int slot = c.res_lm[r], k = c.res_k[r];
-        int imu_i = c.lm_start[slot], imu_j = imu_i + k;
-        double rr[2], J[40];
-        bf::eval_projection(cfg, &X.pose[imu_i * 7], &X.pose[imu_j * 7], X.ex, feat[c.lm_pidx[slot]], X.td, obs_ptr(c, slot, imu_i),
-                            obs_ptr(c, slot, imu_j), cfg.estimate_td != 0, rr, withJ ? J : nullptr);
-        double sq = rr[0] * rr[0] + rr[1] * rr[1];
-        cost += 0.5 * log(1.0 + sq);
-        if (withJ) {
-            double wgt = sqrt(1.0 / (1.0 + sq));
+    // projection factors, CauchyLoss(1.0): frame-pair geometry first (one thread per pair with residuals), then one thread per
+    // residual with a handful of 3-vector products (be_factors.h eval_projection_pair)
+    {
+        const int W1 = W + 1;
+        for (int p = t; p <= W1 * W1; p += nt) {
+            if (p == W1 * W1) {
+                m3 ric = q2R(mkq(X.ex[6], X.ex[3], X.ex[4], X.ex[5]));
+                stm(c.pairgeo + (size_t)p * 32, ric);
+                continue;
+            }
+            int i = p / W1, j = p - i * W1;
+            if (!(i < j) || c.pair_start[p + 1] == c.pair_start[p]) continue;
+            bf::PairGeo g;
+            bf::pair_geo(&X.pose[i * 7], &X.pose[j * 7], X.ex, g);
+            double *o = c.pairgeo + (size_t)p * 32;
+            for (int q = 0; q < 9; q++) { o[q] = g.A1[q]; o[9 + q] = g.A2[q]; o[18 + q] = g.M[q]; }
+            o[27] = g.t[0]; o[28] = g.t[1]; o[29] = g.t[2];
+        }
+        __syncthreads();
+        const double *ricm = c.pairgeo + (size_t)W1 * W1 * 32;
+        for (int r = t; r < nres; r += nt) {
+            int slot = c.res_lm[r], k = c.res_k[r];
+            int imu_i = c.lm_start[slot], imu_j = imu_i + k;
+            const bf::PairGeo &g = *(const bf::PairGeo *)(c.pairgeo + (size_t)(imu_i * W1 + imu_j) * 32);
+            double rr[2], wgt = 1.0;
             double *out = c.res + (size_t)r * 42;
-            for (int q = 0; q < 40; q++) out[q] = wgt * J[q];
-            out[40] = wgt * rr[0];
-            out[41] = wgt * rr[1];
+            bf::eval_projection_pair(cfg, g, ricm, X.ex, feat[c.lm_pidx[slot]], X.td, obs_ptr(c, slot, imu_i), obs_ptr(c, slot, imu_j),
+                                     cfg.estimate_td != 0, rr, withJ ? out : nullptr, true, &wgt);
+            double sq = rr[0] * rr[0] + rr[1] * rr[1];
+            cost += 0.5 * log(1.0 + sq);
+            if (withJ) {
+                out[40] = wgt * rr[0];
+                out[41] = wgt * rr[1];
+            }
         }
     }
     PHT(41, 0);
@@ -2925,8 +2945,14 @@ __global__ __launch_bounds__(256) void be_stage_imu_kernel(vio_config cfg, PreIn
 }
 __global__ void be_stage_projection_kernel(vio_config cfg, const double *in /*pi7 pj7 ex7 inv_dep td oi9 oj9*/, int use_td, double *r2, double *J46) {
     if (threadIdx.x != 0) return;
-    double J[40];
-    bf::eval_projection(cfg, in, in + 7, in + 14, in[21], in[22], in + 23, in + 32, use_td != 0, r2, J);
+    // the same frame-pair formulation the solver uses (evaluate()); bf::eval_projection is the per-residual form used by the
+    // marginalisation and by outlier rejection
+    double J[40], wgt;
+    bf::PairGeo g;
+    bf::pair_geo(in, in + 7, in + 14, g);
+    double ricm[9];
+    stm(ricm, q2R(mkq(in[14 + 6], in[14 + 3], in[14 + 4], in[14 + 5])));
+    bf::eval_projection_pair(cfg, g, ricm, in + 14, in[21], in[22], in + 23, in + 32, use_td != 0, r2, J, false, &wgt);
     for (int a = 0; a < 2; a++) {
         for (int d = 0; d < 6; d++) { J46[a * 7 + d] = J[a * 20 + d]; J46[14 + a * 7 + d] = J[a * 20 + 6 + d]; J46[28 + a * 7 + d] = J[a * 20 + 12 + d]; }
         J46[a * 7 + 6] = 0; J46[14 + a * 7 + 6] = 0; J46[28 + a * 7 + 6] = 0;

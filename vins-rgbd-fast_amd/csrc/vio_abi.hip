@@ -272,6 +272,10 @@ static int build_devcfg(const vio_config *cfg, int imu_capacity, DevCfg &C) {
     if (c.min_dist < 1 || c.min_dist > 63) { g_err = "min_dist must be 1..63"; return VIO_EINVAL; }
     if (c.lk_max_level < 0 || c.lk_max_level > 3) { g_err = "lk_max_level must be 0..3"; return VIO_EINVAL; }
     if (c.estimate_extrinsic < 0 || c.estimate_extrinsic > 1) { g_err = "estimate_extrinsic must be 0 or 1"; return VIO_EINVAL; }
+    {   // readParameters() re-orthonormalises the extrinsic rotation through a normalised quaternion (parameters.cpp:202-209)
+        dm::m3 Rc = dm::q2R(dm::qnormalized(dm::R2q(dm::ldm(c.ric))));
+        dm::stm(C.c.ric, Rc);
+    }
     C.W = c.window_size;
     C.ncells = c.grid_rows * c.grid_cols;
     C.grids_threshold = c.max_cnt / C.ncells;
@@ -348,6 +352,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     DA(B.res, S * nres * 42); DA(B.res_lm, S * nres); DA(B.res_k, S * nres); DA(B.res_pair, S);
     DA(B.pair_start, S * (npair + 1)); DA(B.pair_list, S * nres); DA(B.pairblk, S * npair * 210);
     DA(B.imu_raw, S * C.W * 15 * 31);
+    DA(B.pairgeo, S * (npair + 1) * 32);
     DA(B.margA, S * mq * mq); DA(B.margB, S * mq); DA(B.margV, S * n * n); DA(B.margW, S * (n + 16) * (n + 16));
     DA(B.odom, S * 11); DA(B.timings, 64);
     B.hist_cap = 2048;
