@@ -1,0 +1,170 @@
+"""CPU tests of the ROS-free configuration / dataset I/O: YAML keys of readParameters, the result CSV
+format of pubOdometry, recording round trip."""
+import glob
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+import vio_ct
+
+YAML = """%YAML:1.0
+# written for this test: the key set of parameters.cpp:81-243 with values of our own
+imu: 1
+static_init: 1
+imu_topic: "/imu0"     # strings may carry a # inside quotes: "/a#b"
+image_topic: "/cam/color"
+output_path: "/tmp/out"
+depth_min_dist: 0.25
+depth_max_dist: 7.5
+fix_depth: 0
+num_grid_rows: 7
+num_grid_cols: 8
+model_type: PINHOLE
+image_width: 848
+image_height: 480
+distortion_parameters:
+   k1: 0.01
+   k2: -0.02
+   p1: 0.003
+   p2: -0.004
+projection_parameters:
+   fx: 430.5
+   fy: 431.5
+   cx: 424.25
+   cy: 240.75
+estimate_extrinsic: 1
+extrinsicRotation: !!opencv-matrix
+   rows: 3
+   cols: 3
+   dt: d
+   data: [ 0.0, 0.0, 1.0,
+           -1.0, 0.0, 0.0,
+           0.0, -1.0, 0.0 ]
+extrinsicTranslation: !!opencv-matrix
+   rows: 3
+   cols: 1
+   dt: d
+   data: [ 0.1, 0.02, -0.03 ]
+max_cnt: 150
+min_dist: 15
+freq: 10
+F_threshold: 1.5
+show_track: 0
+equalize: 0
+fisheye: 0
+max_solver_time: 0.04
+max_num_iterations: 6
+keyframe_parallax: 8.0
+acc_n: 0.2
+gyr_n: 0.02
+acc_w: 0.002
+gyr_w: 0.0002
+g_norm: 9.81
+estimate_td: 1
+td: -0.005
+rolling_shutter: 1
+rolling_shutter_tr: 0.033
+"""
+
+
+@pytest.fixture(scope="module")
+def io():
+    return importlib.import_module("vins-rgbd-fast_amd.dataio")
+
+
+def test_yaml_keys_map_to_vio_config(P, io):
+    cfg, extra = io.config_from_yaml(YAML, P)
+    assert (cfg.width, cfg.height, cfg.max_cnt, cfg.min_dist, cfg.grid_rows, cfg.grid_cols) == (848, 480, 150, 15, 7, 8)
+    assert (cfg.fix_depth, cfg.estimate_extrinsic, cfg.estimate_td, cfg.max_iterations) == (0, 1, 1, 6)
+    assert (cfg.fx, cfg.fy, cfg.cx, cfg.cy) == (430.5, 431.5, 424.25, 240.75)
+    assert (cfg.k1, cfg.k2, cfg.p1, cfg.p2) == (0.01, -0.02, 0.003, -0.004)
+    assert (cfg.depth_min, cfg.depth_max, cfg.f_threshold, cfg.min_parallax_px) == (0.25, 7.5, 1.5, 8.0)
+    assert (cfg.acc_n, cfg.gyr_n, cfg.acc_w, cfg.gyr_w, cfg.g_norm) == (0.2, 0.02, 0.002, 0.0002, 9.81)
+    assert list(cfg.ric) == [0, 0, 1, -1, 0, 0, 0, -1, 0] and list(cfg.tic) == [0.1, 0.02, -0.03]
+    assert (cfg.td, cfg.tr) == (-0.005, 0.033)
+    assert extra["freq"] == 10 and extra["output_path"] == "/tmp/out" and extra["notes"] == []
+    y = io.parse_opencv_yaml(YAML)
+    assert y["imu_topic"] == "/imu0" and y["extrinsicRotation"].shape == (3, 3) and y["extrinsicTranslation"].shape == (3, 1)
+
+
+@pytest.mark.parametrize("line,what", [("imu: 0", "VO mode"), ("static_init: 0", "dynamic"), ("fisheye: 1", "fisheye"),
+                                       ("equalize: 1", "CLAHE"), ("estimate_extrinsic: 2", "extrinsic")])
+def test_out_of_scope_settings_fail_loudly(P, io, line, what):
+    key = line.split(":")[0]
+    txt = "\n".join(l for l in YAML.splitlines() if not l.startswith(key + ":")) + "\n" + line + "\n"
+    with pytest.raises(ValueError):
+        io.config_from_yaml(txt, P)
+    cfg, extra = io.config_from_yaml(txt, P, strict=False)
+    assert len(extra["notes"]) == 1
+
+
+def test_reference_config_files_parse(P, io):
+    """every configuration the reference ships parses (this container only: /root/reference is absent on the GPU box)"""
+    files = sorted(glob.glob("/root/reference/config/**/*.yaml", recursive=True))
+    files = [f for f in files if "vio" in os.path.basename(f) or "rgbd" in os.path.basename(f).lower()]
+    if not files:
+        pytest.skip("reference tree not present")
+    n_ok = 0
+    for f in files:
+        y = io.parse_opencv_yaml(open(f).read())
+        if "max_cnt" not in y:
+            continue
+        cfg, extra = io.config_from_yaml(f, P, strict=False)
+        assert cfg.width >= 320 and cfg.height >= 240 and cfg.max_cnt > 0 and cfg.fx > 100
+        R = np.array(cfg.ric[:]).reshape(3, 3)
+        assert abs(np.linalg.det(R) - 1) < 1e-3
+        n_ok += 1
+    assert n_ok >= 3
+    cfg, _ = io.config_from_yaml("/root/reference/config/realsense/vio.yaml", P, strict=False)
+    d = P.default_config()
+    assert (cfg.width, cfg.height, cfg.grid_rows, cfg.grid_cols) == (640, 480, 5, 6)
+    for k in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "g_norm", "gyr_n", "acc_w", "gyr_w"):
+        assert getattr(cfg, k) == getattr(d, k), k  # vio_config_default mirrors this file (except max_cnt / min_dist / acc_n: DESIGN.md)
+    assert list(cfg.ric) == list(d.ric) and list(cfg.tic) == list(d.tic)
+
+
+def test_csv_row_format(io, tmp_path):
+    row = io.format_odometry_row(1403636579.763555527, [1.234567, -0.000004, 10.0], [0.707106781, 0.0, -0.707106781, 0.000001], [0.1, -2.5, 3.333335])
+    assert row == "1403636579763555584,1.23457,-0.00000,10.00000,0.70711,0.00000,-0.70711,0.00000,0.10000,-2.50000,3.33333,\n"
+    p = tmp_path / "r.csv"
+    w = io.OdometryCsvWriter(str(p), append=False)
+    w.write_rows(np.arange(22, dtype=np.float64).reshape(2, 11) * 0.5)
+    w.close()
+    back = io.read_odometry_csv(str(p))
+    assert back.shape == (2, 11) and np.allclose(back, np.arange(22).reshape(2, 11) * 0.5, atol=1e-5)
+
+
+def test_gray_conversion_is_opencv_fixed_point(io):
+    rgb = np.zeros((2, 3, 3), np.uint8)
+    rgb[0, 0] = (255, 255, 255); rgb[0, 1] = (255, 0, 0); rgb[0, 2] = (0, 255, 0); rgb[1, 0] = (0, 0, 255); rgb[1, 1] = (12, 200, 99)
+    g = io.rgb_to_gray(rgb)
+    assert g[0, 0] == 255 and g[0, 1] == 76 and g[0, 2] == 150 and g[1, 0] == 29
+    assert g[1, 1] == (12 * 4899 + 200 * 9617 + 99 * 1868 + 8192) >> 14
+    assert np.array_equal(io.rgb_to_gray(g), g)
+
+
+def test_recording_round_trip(P, io, tmp_path):
+    cfg = P.default_config()
+    sc = vio_ct.synth_like(cfg)
+    syn = P.Synth(sc)
+    stamps = [0.0, 0.1, 0.2]
+    fr = [syn.render_host(2, t) for t in stamps]
+    ti, ai, gi = syn.imu(2, 60)
+    io.write_recording(str(tmp_path), stamps, [f[0] for f in fr], [f[1] for f in fr], ti, ai, gi)
+    rec = io.RgbdImuDirectory(str(tmp_path))
+    assert len(rec) == 3 and np.array_equal(rec.imu_t, ti) and np.array_equal(rec.imu_acc, ai) and np.array_equal(rec.imu_gyr, gi)
+    for k in range(3):
+        t, g, d = rec.frame(k)
+        assert t == stamps[k] and np.array_equal(g, fr[k][0]) and np.array_equal(d, fr[k][1]) and d.dtype == np.uint16
+
+
+def test_ate_alignment(io):
+    rng = np.random.default_rng(0)
+    gt = rng.normal(size=(50, 3))
+    th = 0.7
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    est = (R @ gt.T).T + [3.0, -2.0, 0.5]
+    assert io.ate_rmse(est, gt) < 1e-12
+    assert abs(io.ate_rmse(est + [0, 0, 0.1] * (np.arange(50) % 2)[:, None], gt) - 0.05) < 1e-3

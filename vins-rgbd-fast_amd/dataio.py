@@ -1,0 +1,314 @@
+"""Configuration and dataset I/O without ROS.
+
+  * ``config_from_yaml``  the keys ``readParameters`` reads (vins_estimator/src/utility/parameters.cpp:81-243) from the
+    reference's OpenCV-flavoured YAML (``%YAML:1.0`` header, ``!!opencv-matrix`` blocks) into a ``vio_config``;
+  * ``OdometryCsvWriter``  the result file of ``pubOdometry`` (utility/visualization.cpp:214-225), byte for byte;
+  * ``RgbdImuDirectory``   a rosbag-free recording: ``rgb.txt`` / ``depth.txt`` (TUM RGB-D association files: ``stamp path``)
+    plus ``imu.txt`` (``stamp ax ay az gx gy gz``), 8-bit colour or grey PNG and 16-bit depth PNG in millimetres;
+  * ``replay``             feeds such a recording through the C ABI exactly like the nodelet does for one camera
+    (IMU up to the frame stamp + td, then the colour + depth pair) and writes the CSV;
+  * ``ate_rmse``           absolute trajectory error after yaw + translation alignment (gravity-aligned 4-DoF).
+
+Host-side plumbing only: every frame still ends in ``libvio_hip.so``."""
+import os
+import re
+
+import numpy as np
+
+
+# --------------------------------------------------------------------------------------------------------------- YAML
+def _scalar(tok):
+    tok = tok.strip()
+    if len(tok) >= 2 and tok[0] == tok[-1] and tok[0] in "\"'":
+        return tok[1:-1]
+    try:
+        return int(tok)
+    except ValueError:
+        pass
+    try:
+        return float(tok)
+    except ValueError:
+        return tok
+
+
+def _strip_comment(line):
+    out, q = [], None
+    for ch in line:
+        if q:
+            if ch == q:
+                q = None
+        elif ch in "\"'":
+            q = ch
+        elif ch == "#":
+            break
+        out.append(ch)
+    return "".join(out).rstrip()
+
+
+def parse_opencv_yaml(text):
+    """Minimal reader for the cv::FileStorage YAML subset the reference's configs use: ``key: scalar``, one level of nested
+    maps by indentation, flow sequences ``[a, b, ...]`` (possibly spanning lines) and ``!!opencv-matrix`` maps, which become
+    numpy arrays of shape (rows, cols)."""
+    lines = []
+    for raw in text.splitlines():
+        if raw.startswith("%YAML") or raw.strip() == "---":
+            continue
+        s = _strip_comment(raw)
+        if s.strip():
+            lines.append(s)
+    # join flow sequences that span several lines
+    joined, buf = [], None
+    for s in lines:
+        if buf is not None:
+            buf += " " + s.strip()
+            if buf.count("[") == buf.count("]"):
+                joined.append(buf)
+                buf = None
+            continue
+        if s.count("[") > s.count("]"):
+            buf = s
+        else:
+            joined.append(s)
+    if buf is not None:
+        raise ValueError("unterminated flow sequence in YAML")
+    root, stack = {}, [(-1, {})]
+    stack[0] = (-1, root)
+    pending_matrix = {}
+    for s in joined:
+        indent = len(s) - len(s.lstrip(" "))
+        m = re.match(r"^\s*([A-Za-z_][\w\-]*)\s*:\s*(.*)$", s)
+        if not m:
+            raise ValueError("cannot parse YAML line: %r" % s)
+        key, val = m.group(1), m.group(2).strip()
+        while stack and indent <= stack[-1][0]:
+            stack.pop()
+        parent = stack[-1][1]
+        if val == "" or val.startswith("!!"):
+            node = {}
+            if val.startswith("!!opencv-matrix"):
+                pending_matrix[id(node)] = (parent, key)
+            parent[key] = node
+            stack.append((indent, node))
+        elif val.startswith("["):
+            parent[key] = [_scalar(x) for x in val.strip("[]").split(",") if x.strip()]
+        else:
+            parent[key] = _scalar(val)
+    for nid, (parent, key) in pending_matrix.items():
+        node = parent[key]
+        parent[key] = np.array(node["data"], dtype=np.float64).reshape(int(node["rows"]), int(node["cols"]))
+    return root
+
+
+def config_from_yaml(path_or_text, P=None, strict=True):
+    """vio_config from a reference configuration file (parameters.cpp:81-243).  Settings that select code paths outside the
+    built hot path raise ValueError when strict (VO mode ``imu: 0``, dynamic initialisation ``static_init: 0``, fisheye,
+    CLAHE, ``estimate_extrinsic: 2``); with strict=False they are returned in the second element as a list of notes."""
+    if P is None:
+        import importlib
+        P = importlib.import_module("vins-rgbd-fast_amd")
+    text = open(path_or_text).read() if os.path.exists(str(path_or_text)) else str(path_or_text)
+    y = parse_opencv_yaml(text)
+    c = P.default_config()
+    notes = []
+
+    def need(cond, msg):
+        if cond:
+            if strict:
+                raise ValueError(msg)
+            notes.append(msg)
+
+    g = y.get
+    c.width, c.height = int(g("image_width", c.width)), int(g("image_height", c.height))
+    c.max_cnt, c.min_dist = int(g("max_cnt", c.max_cnt)), int(g("min_dist", c.min_dist))
+    c.grid_rows, c.grid_cols = int(g("num_grid_rows", c.grid_rows)), int(g("num_grid_cols", c.grid_cols))
+    c.f_threshold = float(g("F_threshold", c.f_threshold))
+    c.depth_min, c.depth_max = float(g("depth_min_dist", c.depth_min)), float(g("depth_max_dist", c.depth_max))
+    if "fix_depth" in y:
+        c.fix_depth = int(y["fix_depth"])
+    c.max_iterations = int(g("max_num_iterations", c.max_iterations))
+    c.min_parallax_px = float(g("keyframe_parallax", c.min_parallax_px))
+    for k in ("acc_n", "acc_w", "gyr_n", "gyr_w", "g_norm"):
+        if k in y:
+            setattr(c, k, float(y[k]))
+    pp, dp = y.get("projection_parameters", {}), y.get("distortion_parameters", {})
+    for k in ("fx", "fy", "cx", "cy"):
+        if k in pp:
+            setattr(c, k, float(pp[k]))
+    for k in ("k1", "k2", "p1", "p2"):
+        if k in dp:
+            setattr(c, k, float(dp[k]))
+    need(str(g("model_type", "PINHOLE")).upper() != "PINHOLE", "only the PINHOLE camera model is on the hot path")
+    c.estimate_extrinsic = int(g("estimate_extrinsic", 0))
+    need(c.estimate_extrinsic == 2, "estimate_extrinsic: 2 (online extrinsic initialisation) is out of scope")
+    if "extrinsicRotation" in y:
+        R = np.asarray(y["extrinsicRotation"], np.float64).reshape(3, 3)
+        for i in range(9):
+            c.ric[i] = float(R.ravel()[i])
+    if "extrinsicTranslation" in y:
+        T = np.asarray(y["extrinsicTranslation"], np.float64).ravel()
+        for i in range(3):
+            c.tic[i] = float(T[i])
+    c.td = float(g("td", 0.0))
+    c.estimate_td = int(g("estimate_td", 0))
+    c.tr = float(g("rolling_shutter_tr", 0.0)) if int(g("rolling_shutter", 0)) else 0.0
+    need(int(g("imu", 1)) == 0, "imu: 0 (VO mode) is out of scope (SURVEY.md 8f rank 3)")
+    need(int(g("static_init", 1)) == 0, "static_init: 0 needs the dynamic initialisation (SURVEY.md 8f rank 1), not built yet")
+    need(int(g("fisheye", 0)) != 0, "fisheye masks are out of scope")
+    need(int(g("equalize", 0)) != 0, "equalize (CLAHE) is out of scope")
+    extra = dict(freq=int(g("freq", 0)), frontend_freq=int(g("frontend_freq", 0)), output_path=g("output_path", ""),
+                 max_solver_time=float(g("max_solver_time", 0.0)), notes=notes)
+    return c, extra
+
+
+# ---------------------------------------------------------------------------------------------------------------- CSV
+def format_odometry_row(stamp, P, Q_wxyz, V):
+    """One line of VINS_RESULT_PATH (visualization.cpp:214-225): stamp in ns with precision 0, then P, Q(w,x,y,z), V with
+    precision 5 (ios::fixed), comma separated with a trailing comma."""
+    vals = list(P) + list(Q_wxyz) + list(V)
+    return "%.0f," % (float(stamp) * 1e9) + ",".join("%.5f" % float(v) for v in vals) + ",\n"
+
+
+class OdometryCsvWriter:
+    def __init__(self, path, append=True):
+        self.f = open(path, "a" if append else "w")
+
+    def write(self, stamp, P, Q_wxyz, V):
+        self.f.write(format_odometry_row(stamp, P, Q_wxyz, V))
+
+    def write_rows(self, rows11):
+        """rows of vio_get_odometry / vio_get_odometry_history: stamp, P(3), Q(w,x,y,z), V(3)"""
+        for r in np.asarray(rows11, np.float64).reshape(-1, 11):
+            self.write(r[0], r[1:4], r[4:8], r[8:11])
+
+    def close(self):
+        self.f.close()
+
+
+def read_odometry_csv(path):
+    rows = []
+    for line in open(path):
+        tok = [t for t in line.strip().split(",") if t != ""]
+        if len(tok) >= 11:
+            rows.append([float(t) for t in tok[:11]])
+    a = np.array(rows, np.float64).reshape(-1, 11)
+    a[:, 0] *= 1e-9
+    return a
+
+
+# ------------------------------------------------------------------------------------------------------------ dataset
+def rgb_to_gray(img):
+    """cv::cvtColor(RGB2GRAY) on 8-bit data: fixed point (R*4899 + G*9617 + B*1868 + 8192) >> 14 -- what cv_bridge's
+    toCvCopy(.., MONO8) does to the colour frame in the nodelet (estimator_nodelet.cpp:277-290)."""
+    a = np.asarray(img)
+    if a.ndim == 2:
+        return np.ascontiguousarray(a.astype(np.uint8))
+    a = a[..., :3].astype(np.int32)
+    return np.ascontiguousarray(((a[..., 0] * 4899 + a[..., 1] * 9617 + a[..., 2] * 1868 + 8192) >> 14).astype(np.uint8))
+
+
+def _read_assoc(path):
+    out = []
+    for line in open(path):
+        line = line.strip()
+        if not line or line.startswith("#"):
+            continue
+        tok = line.replace(",", " ").split()
+        out.append((float(tok[0]), tok[1]))
+    return out
+
+
+class RgbdImuDirectory:
+    """A rosbag-free recording: rgb.txt + depth.txt (``stamp relative/path.png``) and imu.txt (``stamp ax ay az gx gy gz``).
+    Colour and depth frames are paired like the nodelet's ApproximateTime synchroniser with a fixed tolerance."""
+
+    def __init__(self, root, max_dt=0.02):
+        self.root = root
+        rgb, dep = _read_assoc(os.path.join(root, "rgb.txt")), _read_assoc(os.path.join(root, "depth.txt"))
+        dt = np.array([t for t, _ in dep])
+        self.pairs = []
+        for t, f in rgb:
+            if len(dt) == 0:
+                break
+            k = int(np.argmin(np.abs(dt - t)))
+            if abs(dt[k] - t) <= max_dt:
+                self.pairs.append((t, f, dep[k][1]))
+        imu = np.loadtxt(os.path.join(root, "imu.txt"), comments="#", ndmin=2)
+        if imu.shape[1] < 7:
+            raise ValueError("imu.txt needs 7 columns: stamp ax ay az gx gy gz")
+        self.imu_t, self.imu_acc, self.imu_gyr = imu[:, 0].copy(), np.ascontiguousarray(imu[:, 1:4]), np.ascontiguousarray(imu[:, 4:7])
+
+    def __len__(self):
+        return len(self.pairs)
+
+    def frame(self, k):
+        from PIL import Image
+        t, fc, fd = self.pairs[k]
+        gray = rgb_to_gray(np.array(Image.open(os.path.join(self.root, fc))))
+        depth = np.array(Image.open(os.path.join(self.root, fd)))
+        if depth.dtype != np.uint16:
+            depth = depth.astype(np.uint16)
+        return t, gray, np.ascontiguousarray(depth)
+
+
+def write_recording(root, stamps, grays, depths, imu_t, imu_acc, imu_gyr):
+    """Inverse of RgbdImuDirectory (used by the tests and handy for exporting synthetic sequences)."""
+    from PIL import Image
+    os.makedirs(os.path.join(root, "rgb"), exist_ok=True)
+    os.makedirs(os.path.join(root, "depth"), exist_ok=True)
+    with open(os.path.join(root, "rgb.txt"), "w") as fr, open(os.path.join(root, "depth.txt"), "w") as fd:
+        fr.write("# stamp filename\n")
+        fd.write("# stamp filename\n")
+        for t, g, d in zip(stamps, grays, depths):
+            name = "%.6f.png" % t
+            Image.fromarray(np.asarray(g, np.uint8)).save(os.path.join(root, "rgb", name))
+            Image.fromarray(np.asarray(d, np.uint16)).save(os.path.join(root, "depth", name))
+            fr.write("%.9f rgb/%s\n" % (t, name))
+            fd.write("%.9f depth/%s\n" % (t, name))
+    np.savetxt(os.path.join(root, "imu.txt"), np.c_[imu_t, imu_acc, imu_gyr], fmt="%.17g", header="stamp ax ay az gx gy gz")
+
+
+def replay(batch, rec, csv_path=None, seq=0, on_frame=None):
+    """Feed a recording through a single-sequence slot of a VioBatch the way the nodelet does: push IMU through the frame stamp
+    (one sample beyond, so that IMUAvailable holds), feed the pair, append a CSV row whenever the estimator is NON_LINEAR.
+    Returns the rows [stamp, P, Q(wxyz), V]."""
+    rows, k = [], 0
+    wr = OdometryCsvWriter(csv_path, append=False) if csv_path else None
+    S = batch.S
+    for f in range(len(rec)):
+        t, gray, depth = rec.frame(f)
+        k2 = k
+        while k2 < len(rec.imu_t) and rec.imu_t[k2] <= t + 1e-9:
+            k2 += 1
+        k2 = min(len(rec.imu_t), k2 + 1)
+        if k2 > k:
+            batch.push_imu(seq, rec.imu_t[k:k2], rec.imu_acc[k:k2], rec.imu_gyr[k:k2])
+            k = k2
+        g = np.repeat(gray[None], S, 0) if S > 1 else gray[None]
+        d = np.repeat(depth[None], S, 0) if S > 1 else depth[None]
+        batch.feed(g, d, [t] * S)
+        st = batch.status(seq)
+        if st.solver_flag == 1 and st.processed:
+            row = batch.odometry()[seq]
+            rows.append(row.copy())
+            if wr:
+                wr.write(row[0], row[1:4], row[4:8], row[8:11])
+        if on_frame:
+            on_frame(f, st)
+    if wr:
+        wr.close()
+    return np.array(rows).reshape(-1, 11)
+
+
+# ---------------------------------------------------------------------------------------------------------------- ATE
+def yaw_align(est, gt):
+    est, gt = np.asarray(est, np.float64), np.asarray(gt, np.float64)
+    ec, gc = est - est.mean(0), gt - gt.mean(0)
+    th = np.arctan2((ec[:, 0] * gc[:, 1] - ec[:, 1] * gc[:, 0]).sum(), (ec[:, 0] * gc[:, 0] + ec[:, 1] * gc[:, 1]).sum())
+    c, s = np.cos(th), np.sin(th)
+    R = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+    return (R @ ec.T).T + gt.mean(0)
+
+
+def ate_rmse(est, gt):
+    al = yaw_align(est, gt)
+    return float(np.sqrt(((al - np.asarray(gt)) ** 2).sum(1).mean()))
