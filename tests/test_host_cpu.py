@@ -41,6 +41,13 @@ def test_headers_are_plain_c():
         assert r.returncode == 0, r.stderr
 
 
+def test_cpp_adapter_header_compiles_standalone():
+    """include/vio_adapter.hpp (C++ mirror of FeatureTracker / Estimator over the C ABI) is plain C++11 with no dependencies."""
+    r = subprocess.run(["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "adapter_demo.cpp")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_struct_layouts_agree(P, orc):
     assert orc.ovio_config_size() == C.sizeof(P.Config)
     a, b = P.Config(), P.Config()
