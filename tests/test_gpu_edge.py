@@ -1,0 +1,138 @@
+"""Edge cases of the boundary on the GPU, each against the oracle on identical inputs: IMU starvation (VIO_NEED_IMU), failure
+detection + reboot, vio_reset, online extrinsic refinement (ESTIMATE_EXTRINSIC = 1)."""
+import numpy as np
+import pytest
+
+import vio_ct
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(P, n, seq, **kw):
+    cfg = P.canonical_config(**kw)
+    sc = vio_ct.synth_like(cfg)
+    syn = P.Synth(sc)
+    frames = [syn.render_host(seq, float(t)) for t in vio_ct.frame_times(sc, n)]
+    imu = syn.imu(seq, int(n / sc.cam_rate * sc.imu_rate) + 64)
+    return cfg, sc, syn, frames, imu
+
+
+def test_imu_starvation_returns_need_imu_and_consumes_nothing(P):
+    """estimator.cpp:178-183 busy-waits for IMU; the C ABI reports VIO_NEED_IMU and leaves the state untouched.  Feeding the same
+    frame again after the IMU arrived must give exactly the trajectory of an undisturbed run."""
+    n, seq = 22, 9
+    cfg, sc, syn, frames, (ti, ai, gi) = _setup(P, n, seq)
+    ref = vio_ct.run_oracle_sequence(cfg, sc, seq, n, frames)
+    b = P.VioBatch(cfg, 1)
+    o = vio_ct.OraclePipeline(cfg)
+    k = 0
+    starved = 0
+    for f, tf in enumerate(vio_ct.frame_times(sc, n)):
+        g, d = frames[f]
+        if f in (5, 15):  # the frame arrives before its IMU
+            b.feed(g[None], d[None], [tf])
+            st = b.status(0)
+            assert st.code == P.VIO_NEED_IMU and st.processed == 0
+            assert o.feed(g, d, tf) == -1
+            starved += 1
+        k2 = vio_ct.imu_until(ti, k, tf, sc.imu_rate)
+        if k2 > k:
+            b.push_imu(0, ti[k:k2], ai[k:k2], gi[k:k2])
+            o.push_imu(ti[k:k2], ai[k:k2], gi[k:k2])
+        k = k2
+        b.feed(g[None], d[None], [tf])
+        o.feed(g, d, tf)
+        st, so = b.status(0), ref["status"][f]
+        assert st.code == P.VIO_OK
+        assert (st.solver_flag, st.frame_count, st.n_landmarks) == (int(so["solver_flag"]), int(so["frame_count"]), int(so["n_landmarks"])), f
+    assert starved == 2
+    w, wo, wr = b.window(0), o.window(), ref["oracle"].window()
+    assert np.abs(wo[:, :3] - wr[:, :3]).max() < 1e-12          # the oracle itself is unaffected by the retry
+    assert np.abs(w[:, :3] - wr[:, :3]).max() < 1e-5
+
+
+def test_failure_detection_reboots_like_the_reference(P):
+    """failureDetection (estimator.cpp:1113-1159) -> clearState + setParameter (:345-353).  Blank frames starve the tracker
+    (last_track_num < 2); both sides must reboot on the same frame and re-initialise identically afterwards."""
+    n, seq = 44, 11
+    cfg, sc, syn, frames, (ti, ai, gi) = _setup(P, n, seq)
+    blank = (np.full_like(frames[0][0], 90), frames[0][1])
+    for f in (18, 19, 20, 21, 22):
+        frames[f] = blank
+    # ... while the accelerometer reports a violent 80 m/s^2 offset: without vision the propagated position runs away
+    # (|P - last_P| > 5 m / bias estimate > 2.5 m/s^2), which is what failureDetection looks for
+    ai = ai.copy()
+    ai[(ti > 1.8) & (ti < 2.3), 0] += 80.0
+    b = P.VioBatch(cfg, 1)
+    o = vio_ct.OraclePipeline(cfg)
+    k, reboots, codes = 0, [], []
+    for f, tf in enumerate(vio_ct.frame_times(sc, n)):
+        k2 = vio_ct.imu_until(ti, k, tf, sc.imu_rate)
+        if k2 > k:
+            b.push_imu(0, ti[k:k2], ai[k:k2], gi[k:k2])
+            o.push_imu(ti[k:k2], ai[k:k2], gi[k:k2])
+        k = k2
+        g, d = frames[f]
+        b.feed(g[None], d[None], [tf])
+        ro = o.feed(g, d, tf)
+        st, so = b.status(0), o.status()
+        codes.append(st.code)
+        assert (st.solver_flag, st.frame_count, st.reboot_count) == (int(so["solver_flag"]), int(so["frame_count"]), int(so["reboot_count"])), f
+        assert st.n_landmarks == int(so["n_landmarks"]), f
+        if int(so["reboot_count"]) > len(reboots):
+            reboots.append(f)
+            assert st.code == P.VIO_REBOOTED
+        elif ro == 0 and f > 3:
+            assert st.processed == 0  # blank frame: empty feature map, processImage is not called (estimator_nodelet.cpp:378-384)
+    assert len(reboots) >= 1 and b.status(0).reboot_count == len(reboots)
+    assert b.status(0).solver_flag == 1  # re-initialised
+    assert np.abs(b.window(0)[:, :3] - o.window()[:, :3]).max() < 1e-5
+
+
+def test_reset_equals_fresh_handle(P):
+    n, seq = 20, 12
+    cfg, sc, syn, frames, (ti, ai, gi) = _setup(P, n, seq)
+
+    def run(b, upto):
+        k = 0
+        for f, tf in enumerate(vio_ct.frame_times(sc, upto)):
+            k2 = vio_ct.imu_until(ti, k, tf, sc.imu_rate)
+            if k2 > k:
+                b.push_imu(0, ti[k:k2], ai[k:k2], gi[k:k2])
+            k = k2
+            b.feed(frames[f][0][None], frames[f][1][None], [tf])
+        return b.window(0).copy(), b.status(0)
+    fresh, st_f = run(P.VioBatch(cfg, 1), n)
+    b = P.VioBatch(cfg, 1)
+    run(b, 9)
+    b.reset()
+    st0 = b.status(0)
+    assert (st0.solver_flag, st0.frame_count, st0.n_landmarks, st0.n_tracks) == (0, 0, 0, 0)
+    again, st_a = run(b, n)
+    # vio_push_imu drops samples older than the last one seen ("imu message in disorder"), so the replayed IMU is accepted
+    # only if reset also cleared that clock: identical results prove it did
+    assert np.array_equal(fresh, again) and st_f.n_landmarks == st_a.n_landmarks
+
+
+def test_online_extrinsic_refinement_matches_oracle(P):
+    """ESTIMATE_EXTRINSIC = 1: para_Ex_Pose becomes a variable once the window is full and the platform moves (estimator.cpp:1196-1211)."""
+    n, seq = 40, 13
+    cfg, sc, syn, frames, (ti, ai, gi) = _setup(P, n, seq, estimate_extrinsic=1)
+    # start from a slightly wrong extrinsic translation so that the refinement has something to do
+    cfg.tic[0] += 0.01
+    cfg.tic[2] -= 0.008
+    ref = vio_ct.run_oracle_sequence(cfg, sc, seq, n, frames)
+    b = P.VioBatch(cfg, 1)
+    k = 0
+    for f, tf in enumerate(vio_ct.frame_times(sc, n)):
+        k2 = vio_ct.imu_until(ti, k, tf, sc.imu_rate)
+        if k2 > k:
+            b.push_imu(0, ti[k:k2], ai[k:k2], gi[k:k2])
+        k = k2
+        b.feed(frames[f][0][None], frames[f][1][None], [tf])
+    eo = np.zeros(13)
+    vio_ct.oracle().ovio_get_extrinsic(ref["oracle"].h, eo.ctypes.data)
+    eh = b.extrinsic(0)
+    assert np.abs(eh - eo).max() < 1e-5
+    assert np.abs(eh[:3] - np.array(cfg.tic[:])).max() > 1e-4  # the extrinsic really moved
+    assert np.abs(b.window(0)[:, :3] - ref["oracle"].window()[:, :3]).max() < 2e-5
