@@ -87,10 +87,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    # VIO_BENCH_DEVICE / VIO_BENCH_BACKEND exist only to dry-run the N > 1 control flow on a 1-GPU box (both ranks on cuda:0 over gloo)
+    if os.environ.get("VIO_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["VIO_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
+    backend = os.environ.get("VIO_BENCH_BACKEND", "nccl")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")  # RCCL over xGMI; used only for the barrier and the final throughput gather
+        dist.init_process_group(backend)  # "nccl" = RCCL over xGMI; used only for the barrier and the final throughput gather
 
     import __graft_entry__ as ge
     P = ge.load_package()
@@ -172,7 +176,7 @@ def main():
         gt = np.array([syn.pose(seq0 + s, float(t))[0] for t in h[:, 0]])
         ates.append(vio_ct.ate_rmse(h[:, 1:4], gt))
     sq_err = float(np.sum([a * a for a in ates]))
-    total_frames, elapsed, sq_err_all, n_ate_all = shard.job_totals(S * K, elapsed_local, sq_err, len(ates), device=dev)
+    total_frames, elapsed, sq_err_all, n_ate_all = shard.job_totals(S * K, elapsed_local, sq_err, len(ates), device=dev if backend == "nccl" else None)
     worst = int(np.argmax(ates)) if ates else -1
     iters = float(np.mean([st.iterations for st in stats]))
     nres = float(np.mean([st.n_residuals for st in stats]))
