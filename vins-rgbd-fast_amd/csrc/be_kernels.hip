@@ -2050,7 +2050,32 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
     };
 
     double radius = 1e4, mu = 1e-8, alpha = 0, dogleg_norm = 0;
-    bool reuse = false, need_eval = false;
+    // Cauchy point, computed lazily: the dogleg only needs it when the Gauss-Newton step leaves the trust region (rare with the
+    // initial radius 1e4).  It depends on H, g only, which stay valid until the next assemble(); the LDS work region is free then.
+    bool cauchy_valid = false;
+    auto compute_cauchy = [&]() {
+        // Cauchy point: alpha = |grad|^2 / |J D^-1 grad|^2, and H_full * (D^-1 grad) is kept for the model evaluation
+        matvec_pass(c.H, LW, P, P, nullptr, up, nullptr, tmpv, work);   // H (S sg_p): H is symmetric, row dots
+        matvec_pass(c.Hpl, LW, Fa, P, ul, up, tmpv2, tmpl, work);       // Hpl^T (Sl sg_l) and Hpl (S sg_p) in one pass
+        double g2 = 0, jg2 = 0;
+        for (int a = t; a < LW; a += nt) {
+            double v = a < P ? sp[a] * (tmpv[a] + tmpv2[a]) : 0.0;
+            hsgp[a] = v;
+            if (a < P) { g2 += gradp[a] * gradp[a]; jg2 += sgp[a] * v; }
+        }
+        for (int k = t; k < Kpad; k += nt) {
+            double sgl = k < Fa ? gradl[k] / dgl[k] : 0.0;
+            double v = k < Fa ? sl[k] * tmpl[k] + Hlls[k] * sgl : 0.0;
+            hsgl[k] = v;
+            if (k < Fa) { g2 += gradl[k] * gradl[k]; jg2 += sgl * v; }
+        }
+        g2 = block_sum(g2, sred);
+        jg2 = block_sum(jg2, sred);
+        alpha = g2 / jg2;
+        cauchy_valid = true;
+    };
+
+    bool reuse = false, need_eval = false, have_J = false;
     int invalid = 0;
     int iters_done = 0, succ = 0;
     if (prepare_point() > 1e-10)
@@ -2059,7 +2084,8 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
         if (!reuse) {
             if (need_eval) {
                 PH(13);
-                cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp);
+                if (!have_J) cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp);
+                have_J = false;
                 PH(4);
                 assemble(B, c, X, nres, Fa, alist, srp, work, pb);
                 PH(5);
@@ -2067,25 +2093,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                 if (prepare_point() <= 1e-10) { iters_done = iter - 1; break; }
                 PH(6);
             }
-            // Cauchy point: alpha = |grad|^2 / |J D^-1 grad|^2, and H_full * (D^-1 grad) is kept for the model evaluation
-            matvec_pass(c.H, LW, P, P, nullptr, up, nullptr, tmpv, work);   // H (S sg_p): H is symmetric, row dots
-            matvec_pass(c.Hpl, LW, Fa, P, ul, up, tmpv2, tmpl, work);       // Hpl^T (Sl sg_l) and Hpl (S sg_p) in one pass
-            double g2 = 0, jg2 = 0;
-            for (int a = t; a < LW; a += nt) {
-                double v = a < P ? sp[a] * (tmpv[a] + tmpv2[a]) : 0.0;
-                hsgp[a] = v;
-                if (a < P) { g2 += gradp[a] * gradp[a]; jg2 += sgp[a] * v; }
-            }
-            for (int k = t; k < Kpad; k += nt) {
-                double sgl = k < Fa ? gradl[k] / dgl[k] : 0.0;
-                double v = k < Fa ? sl[k] * tmpl[k] + Hlls[k] * sgl : 0.0;
-                hsgl[k] = v;
-                if (k < Fa) { g2 += gradl[k] * gradl[k]; jg2 += sgl * v; }
-            }
-            g2 = block_sum(g2, sred);
-            jg2 = block_sum(jg2, sred);
-            alpha = g2 / jg2;
-            PH(7);
+            cauchy_valid = false;
             // Gauss-Newton step via the landmark Schur complement (FP64 matrix cores), regularised by mu * D^2
             bool ok = false;
             while (mu < 1.0) {
@@ -2148,6 +2156,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
         gnn = sqrt(block_sum(gnn, sred));
         gdot = block_sum(gdot, sred);
         double ca = 0, cb = 0;  // step = ca * grad + cb * gn
+        if (!(gnn <= radius) && !cauchy_valid) { PH(11); compute_cauchy(); PH(7); }
         if (gnn <= radius) { ca = 0; cb = 1; dogleg_norm = gnn; }
         else if (gnorm * alpha >= radius) { ca = -(radius / gnorm); cb = 0; dogleg_norm = radius; }
         else {
@@ -2169,7 +2178,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
             if (a < P) {
                 n2 += v * v;
                 lin += st * gs[a];
-                quad += st * (ca * hsgp[a] - cb * (gs[a] - mu * dgp[a] * dgp[a] * yp[a]));
+                quad += st * ((ca != 0.0 ? ca * hsgp[a] : 0.0) - cb * (gs[a] - mu * dgp[a] * dgp[a] * yp[a]));
             }
         }
         for (int k = t; k < Kpad; k += nt) {
@@ -2179,7 +2188,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
             if (k < Fa) {
                 n2 += v * v;
                 lin += st * gls[k];
-                quad += st * (ca * hsgl[k] - cb * (gls[k] - mu * dgl[k] * dgl[k] * yl[k]));
+                quad += st * ((ca != 0.0 ? ca * hsgl[k] : 0.0) - cb * (gls[k] - mu * dgl[k] * dgl[k] * yl[k]));
             }
         }
         n2 = block_sum(n2, sred);
@@ -2218,7 +2227,10 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
             c.cfeat[pi] = v;
         }
         __syncthreads();
-        double ccost = evaluate(c, Xc, c.cfeat, false, nres, sred, sdx, srp);
+        // The candidate is evaluated WITH Jacobians (res / imu_raw / srp are only read by assemble(), which is not called again if the
+        // step is rejected): an accepted point then goes straight to assemble() instead of being evaluated a second time.
+        const bool cand_with_J = iter < cfg.max_iterations;
+        double ccost = evaluate(c, Xc, c.cfeat, cand_with_J, nres, sred, sdx, srp);
         PH(12);
         // parameter tolerance
         double xn = 0, dn = 0;
@@ -2249,6 +2261,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
             mu = fmax(1e-8, 2.0 * mu / 10.0);
             reuse = false;
             need_eval = true;
+            have_J = cand_with_J;
         } else {
             radius *= 0.5;
             reuse = true;
