@@ -80,11 +80,45 @@ __device__ __forceinline__ bool in_problem(const Ctx &c, int slot) {
     return !c.lm_dyn[slot] && c.lm_nobs[slot] >= 2 && c.lm_start[slot] < c.W - 2;
 }
 
+// ---- wavefront reductions on DPP + readlane instead of ds_bpermute shuffles (each __shfl_xor costs an LDS-crossbar round trip).
+// Steps: quad_perm xor 1, xor 2, row_half_mirror, row_mirror leave the 16-lane row sum in every lane of the row; the four row
+// sums are then read through SGPRs.  Fixed summation order -> deterministic.
+__device__ __forceinline__ double dpp_f64(double v, const int ctrl_tag) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (ctrl_tag) {
+    case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+    case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); break; // row_half_mirror
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true); break; // row_mirror
+    }
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rl_f64(double v, int src_lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_f64(v, 0);
+    v += dpp_f64(v, 1);
+    v += dpp_f64(v, 2);
+    v += dpp_f64(v, 3);
+    return (rl_f64(v, 0) + rl_f64(v, 16)) + (rl_f64(v, 32) + rl_f64(v, 48));
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {
+    v = fmax(v, dpp_f64(v, 0));
+    v = fmax(v, dpp_f64(v, 1));
+    v = fmax(v, dpp_f64(v, 2));
+    v = fmax(v, dpp_f64(v, 3));
+    return fmax(fmax(rl_f64(v, 0), rl_f64(v, 16)), fmax(rl_f64(v, 32), rl_f64(v, 48)));
+}
+
 // deterministic block-wide sum; all threads get the result. sred: >= 16 doubles of LDS.
 // wavefront shuffle reduction, then a fixed-order sum over the per-wave partials (2 barriers).
 __device__ double block_sum(double v, double *sred) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = (blockDim.x + 63) >> 6;
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    v = wave_sum_dpp(v);
     __syncthreads();
     if (lane == 0) sred[wave] = v;
     __syncthreads();
@@ -94,7 +128,7 @@ __device__ double block_sum(double v, double *sred) {
 }
 __device__ double block_max(double v, double *sred) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = (blockDim.x + 63) >> 6;
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    v = wave_max_dpp(v);
     __syncthreads();
     if (lane == 0) sred[wave] = v;
     __syncthreads();
@@ -319,8 +353,7 @@ __device__ int jacobi_block(double *A, double *V, int n, int ld, double *cs, dou
 // Everything runs in ONE wavefront: the algorithm is a chain of O(n) dependent steps, and wave-level ordering (no
 // workgroup barriers) is what makes it fast; the other waves of the block wait at the final barrier.
 __device__ __forceinline__ double wave_sum(double v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    return wave_sum_dpp(v);
 }
 #define WAVE_SYNC() do { __builtin_amdgcn_wave_barrier(); __threadfence_block(); } while (0)
 __device__ void sym_eig_tridiag(double *__restrict__ V, int n, int ld, double *__restrict__ d, double *__restrict__ e, double *__restrict__ gtmp, double *sred) {
@@ -792,37 +825,62 @@ __device__ void schur_mfma_staged(const double *Hs, const double *Ws, const doub
     __syncthreads();
 }
 
-__device__ bool chol_tiles(double *T, int nb, int *sh_flag) {
+// broadcast of one lane's double through SGPRs (v_readlane_b32 x 2): far lower latency than the ds_bpermute behind __shfl.
+// The lane index must be wave-uniform (here: a compile-time constant of an unrolled loop).
+__device__ __forceinline__ double bcast_lane(double v, int src_lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Look-ahead: while the other wavefronts run the trailing update of step p, wavefront 0 updates tile (p+1, p+1) first and factors
+// it straight away, so the serial 16-step diagonal factorisation is off the critical path.  dinv[16 nb] receives 1 / l_jj.
+__device__ bool chol_tiles(double *T, int nb, int *sh_flag, double *dinv) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    // 16x16 diagonal block: lanes 0..15 of wavefront 0 hold one row each in registers, shuffles broadcast pivots
+    auto factor_diag = [&](int p) {
+        const int row = lane & 15;
+        double a[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; cc++) a[cc] = T[tl_idx(p, p, row, cc)];
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            double ajj = bcast_lane(a[j], j);
+            if (!(ajj > 0.0) || !isfinite(ajj)) ok = false;
+            double rl = rsqrt(ajj);       // one slow operation per pivot: l = a * rsqrt(a), 1 / l = rsqrt(a)
+            double l = ajj * rl;
+            if (row == j) { a[j] = l; if (lane < 16) dinv[16 * p + j] = rl; }
+            else if (row > j) a[j] = a[j] * rl;
+#pragma unroll
+            for (int k = j + 1; k < 16; k++) {
+                double akj = bcast_lane(a[j], k);
+                if (row >= k) a[k] -= a[j] * akj;
+            }
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) if (cc <= row) T[tl_idx(p, p, row, cc)] = a[cc];
+        }
+        if (!ok && lane == 0) *sh_flag = 0;
+    };
+    auto update_tile = [&](int ti, int tj, int p) {
+        v4f64 acc;
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = T[tl_idx(ti, tj, lk + 4 * r, li)];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[tl_idx(ti, p, li, 4 * kk + lk)], T[tl_idx(tj, p, li, 4 * kk + lk)], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) T[tl_idx(ti, tj, lk + 4 * r, li)] = acc[r];
+    };
     if (t == 0) *sh_flag = 1;
     __syncthreads();
+    if (wave == 0) factor_diag(0);
+    __syncthreads();
     for (int p = 0; p < nb; p++) {
-        // (a) 16x16 diagonal block: lanes 0..15 of one wavefront hold one row each in registers, shuffles broadcast pivots
-        if (wave == 0) {
-            const int row = lane & 15;
-            double a[16];
-#pragma unroll
-            for (int cc = 0; cc < 16; cc++) a[cc] = T[tl_idx(p, p, row, cc)];
-            bool ok = true;
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                double ajj = __shfl(a[j], j, 64);
-                if (!(ajj > 0.0) || !isfinite(ajj)) ok = false;
-                double l = sqrt(ajj);
-                if (row == j) a[j] = l; else if (row > j) a[j] = a[j] / l;
-#pragma unroll
-                for (int k = j + 1; k < 16; k++) {
-                    double akj = __shfl(a[j], k, 64);
-                    if (row >= k) a[k] -= a[j] * akj;
-                }
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int cc = 0; cc < 16; cc++) if (cc <= row) T[tl_idx(p, p, row, cc)] = a[cc];
-            }
-            if (!ok && lane == 0) *sh_flag = 0;
-        }
-        __syncthreads();
         if (!*sh_flag) return false;
         // (b) panel: rows of the tiles below solve x L_pp^T = a
         for (int q = t; q < 16 * (nb - 1 - p); q += nt) {
@@ -830,35 +888,46 @@ __device__ bool chol_tiles(double *T, int nb, int *sh_flag) {
             double x[16];
 #pragma unroll
             for (int cc = 0; cc < 16; cc++) {
-                double s = T[tl_idx(ti, p, r, cc)];
+                double sacc = T[tl_idx(ti, p, r, cc)];
 #pragma unroll
-                for (int k = 0; k < cc; k++) s -= x[k] * T[tl_idx(p, p, cc, k)];
-                x[cc] = s / T[tl_idx(p, p, cc, cc)];
+                for (int k = 0; k < cc; k++) sacc -= x[k] * T[tl_idx(p, p, cc, k)];
+                x[cc] = sacc * dinv[16 * p + cc];
             }
 #pragma unroll
             for (int cc = 0; cc < 16; cc++) T[tl_idx(ti, p, r, cc)] = x[cc];
         }
         __syncthreads();
-        // (c) trailing update S22 -= L21 L21^T on the FP64 matrix cores
+        // (c) trailing update S22 -= L21 L21^T on the FP64 matrix cores; tile 0 = (p+1, p+1) belongs to wavefront 0
         const int m = nb - 1 - p, ntile = m * (m + 1) / 2;
-        const int li = lane & 15, lk = lane >> 4;
-        for (int tile = wave; tile < ntile; tile += nw) {
-            int ti, tj;
-            tri_decode(tile, ti, tj);
-            ti += p + 1; tj += p + 1;
-            v4f64 acc;
-            for (int r = 0; r < 4; r++) acc[r] = T[tl_idx(ti, tj, lk + 4 * r, li)];
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[tl_idx(ti, p, li, 4 * kk + lk)], T[tl_idx(tj, p, li, 4 * kk + lk)], acc, 0, 0, 0);
-            for (int r = 0; r < 4; r++) T[tl_idx(ti, tj, lk + 4 * r, li)] = acc[r];
+        if (nw > 1) {
+            if (wave == 0) {
+                if (ntile > 0) {
+                    update_tile(p + 1, p + 1, p);
+                    WAVE_SYNC();
+                    factor_diag(p + 1);
+                }
+            } else {
+                for (int tile = wave; tile < ntile; tile += nw - 1) {  // tiles 1.. over wavefronts 1..nw-1
+                    int ti, tj;
+                    tri_decode(tile, ti, tj);
+                    update_tile(ti + p + 1, tj + p + 1, p);
+                }
+            }
+        } else {
+            for (int tile = 0; tile < ntile; tile++) {
+                int ti, tj;
+                tri_decode(tile, ti, tj);
+                update_tile(ti + p + 1, tj + p + 1, p);
+            }
+            WAVE_SYNC();
+            if (ntile > 0) factor_diag(p + 1);
         }
         __syncthreads();
     }
-    return true;
+    return *sh_flag != 0;
 }
 
-__device__ void chol_solve_tiles(const double *T, int nb, double *xs) {
+__device__ void chol_solve_tiles(const double *T, int nb, double *xs, const double *dinv) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6;
     for (int p = 0; p < nb; p++) {  // forward: L y = b
         if (wave == 0) {
@@ -866,7 +935,7 @@ __device__ void chol_solve_tiles(const double *T, int nb, double *xs) {
             double b = xs[16 * p + row];
 #pragma unroll
             for (int j = 0; j < 16; j++) {
-                double xj = __shfl(b, j, 64) / T[tl_idx(p, p, j, j)];
+                double xj = bcast_lane(b, j) * dinv[16 * p + j];
                 if (row == j) b = xj; else if (row > j) b -= T[tl_idx(p, p, row, j)] * xj;
             }
             if (lane < 16) xs[16 * p + row] = b;
@@ -874,10 +943,10 @@ __device__ void chol_solve_tiles(const double *T, int nb, double *xs) {
         __syncthreads();
         for (int q = t; q < 16 * (nb - 1 - p); q += nt) {
             int ti = p + 1 + (q >> 4), r = q & 15;
-            double s = 0;
+            double sacc = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) s += T[tl_idx(ti, p, r, k)] * xs[16 * p + k];
-            xs[16 * ti + r] -= s;
+            for (int k = 0; k < 16; k++) sacc += T[tl_idx(ti, p, r, k)] * xs[16 * p + k];
+            xs[16 * ti + r] -= sacc;
         }
         __syncthreads();
     }
@@ -887,7 +956,7 @@ __device__ void chol_solve_tiles(const double *T, int nb, double *xs) {
             double b = xs[16 * p + row];
 #pragma unroll
             for (int j = 15; j >= 0; j--) {
-                double xj = __shfl(b, j, 64) / T[tl_idx(p, p, j, j)];
+                double xj = bcast_lane(b, j) * dinv[16 * p + j];
                 if (row == j) b = xj; else if (row < j) b -= T[tl_idx(p, p, j, row)] * xj;
             }
             if (lane < 16) xs[16 * p + row] = b;
@@ -895,10 +964,10 @@ __device__ void chol_solve_tiles(const double *T, int nb, double *xs) {
         __syncthreads();
         for (int q = t; q < 16 * p; q += nt) {
             int tj = q >> 4, cc = q & 15;
-            double s = 0;
+            double sacc = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) s += T[tl_idx(p, tj, k, cc)] * xs[16 * p + k];
-            xs[q] -= s;
+            for (int k = 0; k < 16; k++) sacc += T[tl_idx(p, tj, k, cc)] * xs[16 * p + k];
+            xs[q] -= sacc;
         }
         __syncthreads();
     }
@@ -1047,7 +1116,7 @@ __device__ void rowdot(const double *M, int ld, int nrows, const double *v, int 
     for (int k = wave; k < nrows; k += nw) {
         double s = 0;
         for (int a = lane; a < n; a += 64) s += M[(size_t)k * ld + a] * v[a];
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        s = wave_sum_dpp(s);
         if (lane == 0) out[k] = s;
     }
     __syncthreads();
@@ -1075,7 +1144,7 @@ __device__ void matvec_pass_t(const double *M, int ld, int nrows, int n, const d
             double rd = 0;
 #pragma unroll
             for (int j = 0; j < NC; j++) rd += m[j] * vv[j];
-            for (int off = 32; off > 0; off >>= 1) rd += __shfl_xor(rd, off, 64);
+            rd = wave_sum_dpp(rd);
             if (lane == 0) out_row[k] = rd;
         }
         if (u) {
@@ -1815,6 +1884,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
     double *work = xs + LW;       // LDS scratch: whitened IMU Jacobians, then the frame-pair blocks
     const int npairs = (W + 1) * W / 2;
     double *pb = (npairs * 210 <= 12288) ? work : c.pairblk;  // 55 pairs x 210 doubles = 92 KB for W = 10
+    __shared__ double chol_dinv[VIO_LWMAX];  // reciprocal Cholesky diagonal (LDS-tile path)
     const bool tiles_in_lds = ((LW >> 4) * ((LW >> 4) + 1) / 2) * 256 <= 16896 && !(B.flags & 1);  // S as 66 lower tiles = 132 KB for W = 10
 
     PH_INIT;
@@ -2115,7 +2185,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                         else schur_mfma_lds(c.H, c.Hpl, tmpl, dgp, sp, mu, Kpad, LW, LW, work);
                     }
                     PH(8);
-                    chol_ok = chol_tiles(work, LW >> 4, &sh_i[2]);
+                    chol_ok = chol_tiles(work, LW >> 4, &sh_i[2], chol_dinv);
                 } else {
                     schur_mfma(c.H, c.Hpl, tmpl, dgp, sp, mu, Kpad, LW, LW, c.Sc);
                     PH(8);
@@ -2123,7 +2193,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                 }
                 PH(9);
                 if (chol_ok) {
-                    if (tiles_in_lds) chol_solve_tiles(work, LW >> 4, xs);
+                    if (tiles_in_lds) chol_solve_tiles(work, LW >> 4, xs, chol_dinv);
                     else chol_solve_blocked(c.Sc, LW, LW, xs, work);
                     PH(10);
                     double bad = 0;
