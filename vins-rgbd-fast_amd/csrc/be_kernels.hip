@@ -1530,9 +1530,9 @@ __device__ double evaluate(const Ctx &c, const Params &X, const double *feat, bo
     // prior
     if (be.has_prior) {
         prior_dx(c, X, sdx);
+        matvec_pass(c.prior_J, n, n, n, nullptr, sdx, nullptr, srp, nullptr);  // J dx: one wavefront per row
         for (int i = t; i < n; i += nt) {
-            double sacc = c.prior_r[i];
-            for (int j = 0; j < n; j++) sacc += c.prior_J[i * n + j] * sdx[j];
+            double sacc = c.prior_r[i] + srp[i];
             srp[i] = sacc;
             cost += 0.5 * sacc * sacc;
         }
@@ -1581,6 +1581,7 @@ __device__ double evaluate(const Ctx &c, const Params &X, const double *feat, bo
         }
         __syncthreads();
         const double *ricm = c.pairgeo + (size_t)W1 * W1 * 32;
+#pragma unroll 2
         for (int r = t; r < nres; r += nt) {
             int slot = c.res_lm[r], k = c.res_k[r];
             int imu_i = c.lm_start[slot], imu_j = imu_i + k;
