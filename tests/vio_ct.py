@@ -18,7 +18,10 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 
 
 def pkg():
-    return importlib.import_module("vins-rgbd-fast_amd")
+    P = importlib.import_module("vins-rgbd-fast_amd")
+    if not os.path.exists(os.path.join(ROOT, "vins-rgbd-fast_amd", "libvio_hip.so")):
+        P.build()  # fresh checkout without built artefacts: hipcc cross-compiles for gfx950 (no CPU fallback either way)
+    return P
 
 
 def build_oracle():
