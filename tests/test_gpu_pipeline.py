@@ -122,3 +122,23 @@ def test_pipeline_config5_shape(P):
     po = np.array([x[1] for x in o["traj"]]); ph = np.array([x[1] for x in traj[0]])
     assert np.abs(po - ph).max() < 1e-5, float(np.abs(po - ph).max())
     assert vio_ct.ate_rmse(ph, np.array(o["gt"])) < 0.03
+
+
+def test_pipeline_848x480_grid7x8(P):
+    """The reference's own 150-feature configuration shape (config/realsense/vio_campus.yaml: 848x480, 7x8 grid, min_dist 15):
+    non-square cell sizes, a width that is not a multiple of the pyramid tile, 56 FAST cells."""
+    cfg = P.canonical_config(width=848, height=480, grid_rows=7, grid_cols=8, fx=430.0, fy=430.0, cx=424.0, cy=240.0,
+                             k1=0.0, k2=0.0, p1=0.0, p2=0.0)
+    sc = vio_ct.synth_like(cfg)
+    seqs, n_frames = [31], 30
+    oruns = [vio_ct.run_oracle_sequence(cfg, sc, s, n_frames) for s in seqs]
+    b, traj, stat = _run_hip(P, cfg, sc, seqs, n_frames, [r["frames"] for r in oruns])
+    o = oruns[0]
+    assert len(traj[0]) == len(o["traj"]) >= 10
+    for f in range(n_frames):
+        so, sh = o["status"][f], stat[0][f]
+        assert (int(so["solver_flag"]), int(so["frame_count"]), int(so["n_landmarks"])) == (sh.solver_flag, sh.frame_count, sh.n_landmarks), f
+    po = np.array([x[1] for x in o["traj"]]); ph = np.array([x[1] for x in traj[0]])
+    assert np.abs(po - ph).max() < 1e-5, float(np.abs(po - ph).max())
+    a, q = o["oracle"].tracks(), b.tracks(0)
+    assert np.array_equal(a[0], q[0]) and np.array_equal(a[1], q[1]) and len(a[0]) > 100
