@@ -192,15 +192,18 @@ def main():
     fe_bytes_seq = frontend_bytes(Wd, H, cfg.max_cnt, cfg.lk_max_level)
     be_ms = sum(v for k, v in kms.items() if k.startswith("be_"))
     fe_ms = sum(v for k, v in kms.items() if k.startswith("fe_"))
+    ksym = dom + "_kernel"
+    if dom == "be_solve" and int(os.environ.get("VIO_BE_THREADS", "512")) <= 512:
+        ksym = "be_solve_kernel_512"  # the 512-thread build of the solve kernel (256 VGPRs per lane) is the default
     if dom.startswith("be_"):
         ach = be_flops_seq * S / (kms[dom] * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel=dom + "_kernel", achieved=ach, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS,
+        roof = dict(bound="mfma", kernel=ksym, achieved=ach, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS,
                     traffic=None, ms=kms[dom],
                     note="FP64 path; algorithmic back-end flops per launch (SURVEY.md 8d with measured I, O, F) / average launch duration; "
                          "peak = FP64 vector/matrix 78.6 TFLOP/s")
     else:
         ach = fe_bytes_seq * S / (kms[dom] * 1e-3) / 1e9
-        roof = dict(bound="hbm", kernel=dom + "_kernel", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
+        roof = dict(bound="hbm", kernel=ksym, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
                     ms=kms[dom], note="algorithmic front-end bytes per launch (SURVEY.md 8d) / average launch duration")
     roof["frontend_GBps"] = fe_bytes_seq * S / (fe_ms * 1e-3) / 1e9 if fe_ms > 0 else None
     roof["backend_TFLOPs"] = be_flops_seq * S / (be_ms * 1e-3) / 1e12 if be_ms > 0 else None

@@ -15,8 +15,6 @@ using namespace dm;
 
 // phase timers (debug): thread 0 of sequence 0 accumulates 100 MHz wall-clock ticks into B.timings[k]
 #define PH_INIT long long ph_t0 = (s == 0 && threadIdx.x == 0) ? (long long)wall_clock64() : 0
-#define PHT_INIT(tid) long long pht_t0 = (c.s == 0 && (int)threadIdx.x == (tid)) ? (long long)wall_clock64() : 0
-#define PHT(k, tid) do { if (c.s == 0 && (int)threadIdx.x == (tid)) { long long n_ = (long long)wall_clock64(); c.timings[k] += (float)(n_ - pht_t0); pht_t0 = n_; } } while (0)
 #define PH(k) do { if (s == 0 && threadIdx.x == 0) { long long n_ = (long long)wall_clock64(); B.timings[k] += (float)(n_ - ph_t0); ph_t0 = n_; } } while (0)
 
 namespace {
@@ -1526,7 +1524,6 @@ __device__ double evaluate(const Ctx &c, const Params &X, const double *feat, bo
     const BeSeq &be = *c.be;
     const vio_config &cfg = c.C->c;
     double cost = 0;
-    PHT_INIT(withJ ? (int)(t == 0 ? 0 : nt - 1) : -1);
     // prior
     if (be.has_prior) {
         prior_dx(c, X, sdx);
@@ -1537,8 +1534,6 @@ __device__ double evaluate(const Ctx &c, const Params &X, const double *feat, bo
             cost += 0.5 * sacc * sacc;
         }
     }
-    PHT(40, 0);
-    PHT(42, nt - 1);
     // IMU factors: five threads per factor (whitened residual + four Jacobian column groups). Spread over the upper lanes
     // of the block so that they do not serialise with the projection residuals handled by the low thread ids.
     v3 G = ld3(be.g);
@@ -1559,8 +1554,6 @@ __device__ double evaluate(const Ctx &c, const Params &X, const double *feat, bo
         } else if (withJ)
             bf::imu_raw_jacobian_part(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], part - 1, out, 31);  // raw, whitened in assemble
     }
-    PHT(43, nt - 1);
-    PHT(46, 0);
     // projection factors, CauchyLoss(1.0): frame-pair geometry first (one thread per pair with residuals), then one thread per
     // residual with a handful of 3-vector products (be_factors.h eval_projection_pair)
     {
@@ -1598,10 +1591,7 @@ __device__ double evaluate(const Ctx &c, const Params &X, const double *feat, bo
             }
         }
     }
-    PHT(41, 0);
-    PHT(44, nt - 1);
     cost = block_sum(cost, sred);
-    PHT(45, 0);
     return cost;
 }
 

@@ -214,11 +214,6 @@ __global__ void fe_predict_kernel(Batch B) {
 
 // ------------------------------------------------------------------------------------------------ fe_lk
 // One wavefront (64 lanes) per feature; each lane owns 7 of the 441 window pixels.
-struct LkImagesUnused {
-    const uint8_t *prev[4];
-    const uint8_t *next[4];
-    int w[4], h[4];
-};
 
 __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, float2 &nextPtIO, uint8_t &statusOut,
                              uint8_t *win /*24*24*/, short2 *der /*22*22*/, uint8_t *jw /*22*22*/) {
