@@ -75,6 +75,23 @@ struct vio_batch {
 #define VIO_NEV 12 // events per step: 0..7 bracket the front-end kernels on fe_stream, 8..11 the back-end kernels on stream
 #define PEV(h, k) do { if (g.s0 == 0 && (h)->prof_cur >= 0 && (h)->prof_cur < (h)->prof_steps) (void)hipEventRecord((h)->pev[(size_t)(h)->prof_cur * VIO_NEV + (k)], (k) <= 7 ? g.fe_stream : g.stream); } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the kernel, not of a handle: with several handles of different
+// configurations alive, keep the largest value ever requested (monotonic), otherwise the handle created last would shrink the
+// limit under the others.
+static int raise_lds_limit(const void *fn, size_t bytes) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void *, size_t>> seen;
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &e : seen)
+        if (e.first == fn) {
+            if (bytes <= e.second) return 0;
+            e.second = bytes;
+            return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
+        }
+    seen.push_back({fn, bytes});
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
+}
+
 static int sync_all(vio_batch *h) {
     for (auto &g : h->groups) {
         HIPCHK(hipStreamSynchronize(g.fe_stream));
@@ -403,16 +420,16 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
                 if (tiles <= 16896) workd = std::max(workd, tiles);  // Schur complement / Cholesky tiles resident in LDS
             }
             h->lds_solve = ((size_t)C.LW + 2 + workd) * 8 + 16;
-            (void)hipFuncSetAttribute((const void *)be_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve);
-            (void)hipFuncSetAttribute((const void *)be_solve_kernel_512, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve);
+            (void)raise_lds_limit((const void *)be_solve_kernel, (size_t)(h->lds_solve));
+            (void)raise_lds_limit((const void *)be_solve_kernel_512, (size_t)(h->lds_solve));
         }
         h->lds_marg = C.NPRIOR <= 96 ? (size_t)C.NPRIOR * (C.NPRIOR | 1) * 8 + 64 : 64;
-        (void)hipFuncSetAttribute((const void *)be_marg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_marg);
-        (void)hipFuncSetAttribute((const void *)be_ingest_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C.lm_hash_size * 8);
+        (void)raise_lds_limit((const void *)be_marg_kernel, (size_t)(h->lds_marg));
+        (void)raise_lds_limit((const void *)be_ingest_kernel, (size_t)(C.lm_hash_size * 8));
 
-        (void)hipFuncSetAttribute((const void *)fe_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_select);
-        (void)hipFuncSetAttribute((const void *)fe_add_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_add);
-        (void)hipFuncSetAttribute((const void *)fe_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_fast);
+        (void)raise_lds_limit((const void *)fe_select_kernel, (size_t)(h->lds_select));
+        (void)raise_lds_limit((const void *)fe_add_kernel, (size_t)(h->lds_add));
+        (void)raise_lds_limit((const void *)fe_fast_kernel, (size_t)(h->lds_fast));
     }
     if (rc != VIO_OK) { vio_destroy(h); return nullptr; }
     return h;
@@ -764,7 +781,7 @@ int vio_stage_fast_roi(const uint8_t *img, int W, int H, int rx, int ry, int rw,
     STAGE_CHK(hipMalloc((void **)&dout, (size_t)cap * 4));
     STAGE_CHK(hipMalloc((void **)&dcnt, 4));
     STAGE_CHK(hipMemcpy(di, img, (size_t)W * H, hipMemcpyHostToDevice));
-    (void)hipFuncSetAttribute((const void *)fe_fast_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)raise_lds_limit((const void *)fe_fast_stage_kernel, (size_t)(lds));
     fe_fast_stage_kernel<<<1, 256, lds>>>(di, W, r, dout, cap, dcnt);
     STAGE_CHK(hipDeviceSynchronize());
     STAGE_CHK(hipMemcpy(&count, dcnt, 4, hipMemcpyDeviceToHost));
@@ -829,7 +846,7 @@ int vio_stage_ransac(const vio_config *cfg, int n, const float *p1, const float 
     STAGE_CHK(hipMalloc((void **)&ds, n + 1));
     STAGE_CHK(hipMemcpy(d1, p1, sizeof(float2) * n, hipMemcpyHostToDevice));
     STAGE_CHK(hipMemcpy(d2, p2, sizeof(float2) * n, hipMemcpyHostToDevice));
-    (void)hipFuncSetAttribute((const void *)fe_ransac_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)raise_lds_limit((const void *)fe_ransac_stage_kernel, (size_t)(lds));
     fe_ransac_stage_kernel<<<1, 256, lds>>>(*cfg, n, d1, d2, ds);
     STAGE_CHK(hipDeviceSynchronize());
     STAGE_CHK(hipMemcpy(status, ds, n, hipMemcpyDeviceToHost));
