@@ -1,0 +1,1030 @@
+// Block / wavefront primitives and the dense FP64 linear algebra of the back-end kernels (included by be_kernels.hip only):
+//   * DPP + v_readlane wavefront reductions, block sums / scans
+//   * symmetric eigen-solvers (Jacobi for the 15x15 block, Householder tridiagonalisation + implicit QL for the prior)
+//   * landmark Schur complement on v_mfma_f64_16x16x4_f64 (HBM, LDS-tile and LDS-staged variants)
+//   * blocked Cholesky + triangular solves (LDS 16x16 tiles with XOR swizzle, HBM fallback for large windows)
+//   * one-pass mat-vec helpers
+// Everything is __device__ code for gfx950; no host fallbacks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vio_state.h"
+
+namespace {
+
+// ---- wavefront reductions on DPP + readlane instead of ds_bpermute shuffles (each __shfl_xor costs an LDS-crossbar round trip).
+// Steps: quad_perm xor 1, xor 2, row_half_mirror, row_mirror leave the 16-lane row sum in every lane of the row; the four row
+// sums are then read through SGPRs.  Fixed summation order -> deterministic.
+__device__ __forceinline__ double dpp_f64(double v, const int ctrl_tag) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    switch (ctrl_tag) {
+    case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+    case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); break; // row_half_mirror
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true); break; // row_mirror
+    }
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double rl_f64(double v, int src_lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_f64(v, 0);
+    v += dpp_f64(v, 1);
+    v += dpp_f64(v, 2);
+    v += dpp_f64(v, 3);
+    return (rl_f64(v, 0) + rl_f64(v, 16)) + (rl_f64(v, 32) + rl_f64(v, 48));
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {
+    v = fmax(v, dpp_f64(v, 0));
+    v = fmax(v, dpp_f64(v, 1));
+    v = fmax(v, dpp_f64(v, 2));
+    v = fmax(v, dpp_f64(v, 3));
+    return fmax(fmax(rl_f64(v, 0), rl_f64(v, 16)), fmax(rl_f64(v, 32), rl_f64(v, 48)));
+}
+
+// deterministic block-wide sum; all threads get the result. sred: >= 16 doubles of LDS.
+// wavefront shuffle reduction, then a fixed-order sum over the per-wave partials (2 barriers).
+__device__ double block_sum(double v, double *sred) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum_dpp(v);
+    __syncthreads();
+    if (lane == 0) sred[wave] = v;
+    __syncthreads();
+    double r = 0;
+    for (int k = 0; k < nw; k++) r += sred[k];
+    return r;
+}
+__device__ double block_max(double v, double *sred) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max_dpp(v);
+    __syncthreads();
+    if (lane == 0) sred[wave] = v;
+    __syncthreads();
+    double r = sred[0];
+    for (int k = 1; k < nw; k++) r = fmax(r, sred[k]);
+    return r;
+}
+__device__ int block_scan_flags(const int *flags, int n, int *offs, int *scratch /* 2*blockDim + 2 ints */) {
+    int nt = blockDim.x, t = threadIdx.x;
+    int chunk = (n + nt - 1) / nt;
+    int b = t * chunk, e = min(n, b + chunk);
+    int sum = 0;
+    for (int i = b; i < e; i++) sum += flags[i];
+    __syncthreads();
+    int *cur = scratch, *nxt = scratch + nt;
+    cur[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {  // Hillis-Steele inclusive scan
+        int v = cur[t];
+        if (t >= off) v += cur[t - off];
+        nxt[t] = v;
+        __syncthreads();
+        int *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    int incl = cur[t];
+    int total = cur[nt - 1];
+    int o = incl - sum;
+    for (int i = b; i < e; i++) { offs[i] = o; o += flags[i]; }
+    __syncthreads();
+    return total;
+}
+
+__device__ void jacobi_small(double *A, double *V, int n) {
+    for (int i = 0; i < n * n; i++) V[i] = 0;
+    for (int i = 0; i < n; i++) V[i * n + i] = 1;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < n; i++) {
+            diag += A[i * n + i] * A[i * n + i];
+            for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
+        }
+        if (off <= 1e-30 * (diag + 1e-300) || off == 0.0) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                double app = A[p * n + p], aqq = A[q * n + q];
+                double tau = (aqq - app) / (2.0 * apq);
+                double tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                double cs = 1.0 / sqrt(1.0 + tt * tt), sn = tt * cs;
+                for (int k = 0; k < n; k++) {
+                    double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = cs * akp - sn * akq;
+                    A[k * n + q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = cs * apk - sn * aqk;
+                    A[q * n + k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = cs * vkp - sn * vkq;
+                    V[k * n + q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+}
+
+// Parallel two-sided Jacobi (round-robin ordering) on a symmetric n x n matrix A (ld = n), V = eigenvectors (columns).
+// All threads of the block participate. cs/sn: LDS arrays of n/2+1 doubles; sred: blockDim doubles.
+__device__ int jacobi_block(double *A, double *V, int n, int ld, double *cs, double *sn, int *pp, int *qq, double *sred) {
+    int sweeps_done = 0;
+    const int t = threadIdx.x, nt = blockDim.x;
+    for (int i = t; i < n * n; i += nt) V[(i / n) * ld + (i % n)] = ((i / n) == (i % n)) ? 1.0 : 0.0;
+    __syncthreads();
+    const int m = (n + 1) & ~1;  // even number of players (one bye if n is odd)
+    const int half = m / 2;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        // threshold Jacobi: a pair is rotated only if |a_pq| > 1e-15 sqrt(|a_pp a_qq|) and > 1e-18 max|a_ii|;
+        // the sweep loop ends when a whole sweep applied no rotation
+        double dmax = 0;
+        for (int i = t; i < n; i += nt) dmax = fmax(dmax, fabs(A[i * ld + i]));
+        dmax = block_max(dmax, sred);
+        __syncthreads();
+        const double absfloor = 1e-18 * dmax;
+        double nrot = 0;
+        for (int round = 0; round < m - 1; round++) {
+            // chess-tournament pairing: player m-1 fixed, others rotate
+            if (t < half) {
+                int a = (t == 0) ? m - 1 : (round + t) % (m - 1);
+                int b = (round + m - 1 - t) % (m - 1);
+                if (t == 0) b = round % (m - 1);
+                int p = min(a, b), q = max(a, b);
+                double c1 = 1.0, s1 = 0.0;
+                if (q < n) {
+                    double apq = A[p * ld + q];
+                    double app = A[p * ld + p], aqq = A[q * ld + q];
+                    if (fabs(apq) > absfloor && fabs(apq) > 1e-15 * sqrt(fabs(app * aqq))) {
+                        nrot += 1.0;
+                        double tau = (aqq - app) / (2.0 * apq);
+                        double tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c1 = 1.0 / sqrt(1.0 + tt * tt);
+                        s1 = tt * c1;
+                    }
+                } else { p = -1; }
+                pp[t] = p; qq[t] = q; cs[t] = c1; sn[t] = s1;
+            }
+            __syncthreads();
+            // columns: A <- A J, V <- V J
+            for (int w = t; w < half * n; w += nt) {
+                int k = w / n, r = w - k * n;
+                int p = pp[k], q = qq[k];
+                if (p < 0 || sn[k] == 0.0) continue;
+                double c1 = cs[k], s1 = sn[k];
+                double akp = A[r * ld + p], akq = A[r * ld + q];
+                A[r * ld + p] = c1 * akp - s1 * akq;
+                A[r * ld + q] = s1 * akp + c1 * akq;
+                double vkp = V[r * ld + p], vkq = V[r * ld + q];
+                V[r * ld + p] = c1 * vkp - s1 * vkq;
+                V[r * ld + q] = s1 * vkp + c1 * vkq;
+            }
+            __syncthreads();
+            // rows: A <- J^T A
+            for (int w = t; w < half * n; w += nt) {
+                int k = w / n, cc = w - k * n;
+                int p = pp[k], q = qq[k];
+                if (p < 0 || sn[k] == 0.0) continue;
+                double c1 = cs[k], s1 = sn[k];
+                double apk = A[p * ld + cc], aqk = A[q * ld + cc];
+                A[p * ld + cc] = c1 * apk - s1 * aqk;
+                A[q * ld + cc] = s1 * apk + c1 * aqk;
+            }
+            __syncthreads();
+        }
+        nrot = block_sum(nrot, sred);
+        sweeps_done = sweep + 1;
+        if (nrot == 0.0) break;
+    }
+    __syncthreads();
+    return sweeps_done;
+}
+
+// Symmetric eigen-decomposition (Householder tridiagonalisation + implicit-shift QL, the algorithm class of
+// Eigen::SelfAdjointEigenSolver used at marginalization_factor.cpp:277,298).  V (n x n, ld) holds A on entry (lower
+// triangle is read) and the eigenvectors (columns) on exit; d = eigenvalues (unsorted), e / gtmp = workspaces; all in LDS.
+// Everything runs in ONE wavefront: the algorithm is a chain of O(n) dependent steps, and wave-level ordering (no
+// workgroup barriers) is what makes it fast; the other waves of the block wait at the final barrier.
+__device__ __forceinline__ double wave_sum(double v) {
+    return wave_sum_dpp(v);
+}
+#define WAVE_SYNC() do { __builtin_amdgcn_wave_barrier(); __threadfence_block(); } while (0)
+__device__ void sym_eig_tridiag(double *__restrict__ V, int n, int ld, double *__restrict__ d, double *__restrict__ e, double *__restrict__ gtmp, double *sred) {
+    (void)sred;
+    if (threadIdx.x < 64) {
+        const int t = threadIdx.x, nt = 64;
+        for (int j = t; j < n; j += nt) d[j] = V[(n - 1) * ld + j];
+        WAVE_SYNC();
+        for (int i = n - 1; i > 0; i--) {
+            double sc = 0;
+            for (int k = t; k < i; k += nt) sc += fabs(d[k]);
+            sc = wave_sum(sc);
+            if (sc == 0.0) {
+                if (t == 0) e[i] = d[i - 1];
+                WAVE_SYNC();
+                for (int j = t; j < i; j += nt) { d[j] = V[(i - 1) * ld + j]; V[i * ld + j] = 0.0; V[j * ld + i] = 0.0; }
+                if (t == 0) d[i] = 0.0;
+                WAVE_SYNC();
+                continue;
+            }
+            double h = 0;
+            for (int k = t; k < i; k += nt) { double v = d[k] / sc; d[k] = v; h += v * v; }
+            h = wave_sum(h);
+            WAVE_SYNC();
+            double f = d[i - 1];
+            double g = sqrt(h);
+            if (f > 0) g = -g;
+            h -= f * g;
+            WAVE_SYNC();
+            if (t == 0) { e[i] = sc * g; d[i - 1] = f - g; }
+            WAVE_SYNC();
+            // e[0..i) = A_sub * d using the lower triangle; V[j][i] = d[j]
+            for (int j = t; j < i; j += nt) {
+                double acc = 0;
+#pragma unroll 8
+                for (int k = 0; k < i; k++) acc += (k <= j ? V[j * ld + k] : V[k * ld + j]) * d[k];
+                V[j * ld + i] = d[j];
+                e[j] = acc / h;
+            }
+            WAVE_SYNC();
+            double ff = 0;
+            for (int j = t; j < i; j += nt) ff += e[j] * d[j];
+            ff = wave_sum(ff);
+            double hh = ff / (h + h);
+            for (int j = t; j < i; j += nt) e[j] -= hh * d[j];
+            WAVE_SYNC();
+            for (int k = t; k < i; k += nt) {  // row k of the lower triangle
+                double dk = d[k], ek = e[k];
+#pragma unroll 8
+                for (int j = 0; j <= k; j++) V[k * ld + j] -= (d[j] * ek + e[j] * dk);
+            }
+            WAVE_SYNC();
+            for (int j = t; j < i; j += nt) { d[j] = V[(i - 1) * ld + j]; V[i * ld + j] = 0.0; }
+            if (t == 0) d[i] = h;
+            WAVE_SYNC();
+        }
+        // accumulate the Householder transformations
+        for (int i = 0; i < n - 1; i++) {
+            if (t == 0) { V[(n - 1) * ld + i] = V[i * ld + i]; V[i * ld + i] = 1.0; }
+            double h = d[i + 1];
+            WAVE_SYNC();
+            if (h != 0.0) {
+                for (int k = t; k <= i; k += nt) d[k] = V[k * ld + i + 1] / h;
+                WAVE_SYNC();
+                for (int j = t; j <= i; j += nt) {
+                    double g = 0;
+#pragma unroll 8
+                    for (int k = 0; k <= i; k++) g += V[k * ld + i + 1] * V[k * ld + j];
+                    gtmp[j] = g;
+                }
+                WAVE_SYNC();
+                for (int k = t; k <= i; k += nt) {
+                    double dk = d[k];
+#pragma unroll 8
+                    for (int j = 0; j <= i; j++) V[k * ld + j] -= gtmp[j] * dk;
+                }
+                WAVE_SYNC();
+            }
+            for (int k = t; k <= i; k += nt) V[k * ld + i + 1] = 0.0;
+            WAVE_SYNC();
+        }
+        for (int j = t; j < n; j += nt) { d[j] = V[(n - 1) * ld + j]; V[(n - 1) * ld + j] = 0.0; }
+        WAVE_SYNC();
+        if (t == 0) { V[(n - 1) * ld + n - 1] = 1.0; e[0] = 0.0; }
+        WAVE_SYNC();
+    }
+    __syncthreads();
+}
+
+// Householder tridiagonalisation with accumulation (same recurrences as sym_eig_tridiag), spread over the whole workgroup:
+// the O(i) reductions are computed redundantly by every wavefront (no writes, no barrier), the two O(i^2) pieces of each step --
+// the symmetric matrix-vector product and the rank-2 update -- are split over all threads.  part: LDS [nw * EIG_LD].
+#define EIG_LD (6 * VIO_MAXW + 16)
+__device__ void sym_eig_tridiag_mt(double *V, int n, int ld, double *d, double *e, double *gtmp, double *part) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    for (int j = t; j < n; j += nt) d[j] = V[(n - 1) * ld + j];
+    __syncthreads();
+    for (int i = n - 1; i > 0; i--) {
+        double sc = 0;
+        for (int k = lane; k < i; k += 64) sc += fabs(d[k]);
+        sc = wave_sum(sc);
+        if (sc == 0.0) {
+            __syncthreads();
+            if (t == 0) { e[i] = d[i - 1]; }
+            __syncthreads();
+            for (int j = t; j < i; j += nt) { d[j] = V[(i - 1) * ld + j]; V[i * ld + j] = 0.0; V[j * ld + i] = 0.0; }
+            if (t == 0) d[i] = 0.0;
+            __syncthreads();
+            continue;
+        }
+        double h = 0;
+        for (int k = lane; k < i; k += 64) { double v = d[k] / sc; h += v * v; }
+        h = wave_sum(h);
+        const double f = d[i - 1] / sc;
+        double g = sqrt(h);
+        if (f > 0) g = -g;
+        h -= f * g;
+        // u[k] = scaled Householder vector (not yet stored): d[k] / sc, last entry f - g
+        // partial products: lanes own rows j (and j + 64, ...), wavefronts split the k range
+        {
+            const int kc = (i + nw - 1) / nw, kb = wave * kc, ke = min(i, kb + kc);
+            for (int j = lane; j < i; j += 64) {
+                double acc = 0;
+#pragma unroll 4
+                for (int k = kb; k < ke; k++) {
+                    double uk = (k == i - 1) ? (f - g) : d[k] / sc;
+                    acc += (k <= j ? V[j * ld + k] : V[k * ld + j]) * uk;
+                }
+                part[wave * EIG_LD + j] = acc;
+            }
+        }
+        __syncthreads();
+        for (int j = t; j < i; j += nt) {
+            double acc = 0;
+            for (int q = 0; q < nw; q++) acc += part[q * EIG_LD + j];
+            double uj = (j == i - 1) ? (f - g) : d[j] / sc;
+            e[j] = acc / h;
+            d[j] = uj;
+            V[j * ld + i] = uj;
+        }
+        if (t == 0) e[i] = sc * g;
+        __syncthreads();
+        double ff = 0;
+        for (int j = lane; j < i; j += 64) ff += e[j] * d[j];
+        ff = wave_sum(ff);
+        const double hh = ff / (h + h);
+        __syncthreads();  // everybody has read e[] before it is updated
+        for (int j = t; j < i; j += nt) e[j] -= hh * d[j];
+        __syncthreads();
+        for (int idx = t; idx < i * i; idx += nt) {
+            int k = idx / i, j = idx - k * i;
+            if (j <= k) V[k * ld + j] -= (d[j] * e[k] + e[j] * d[k]);
+        }
+        __syncthreads();
+        for (int j = t; j < i; j += nt) { d[j] = V[(i - 1) * ld + j]; V[i * ld + j] = 0.0; }
+        if (t == 0) d[i] = h;
+        __syncthreads();
+    }
+    // accumulate the Householder transformations
+    for (int i = 0; i < n - 1; i++) {
+        if (t == 0) { V[(n - 1) * ld + i] = V[i * ld + i]; V[i * ld + i] = 1.0; }
+        const double h = d[i + 1];
+        __syncthreads();
+        if (h != 0.0) {
+            {
+                const int m = i + 1, kc = (m + nw - 1) / nw, kb = wave * kc, ke = min(m, kb + kc);
+                for (int j = lane; j < m; j += 64) {
+                    double g = 0;
+#pragma unroll 4
+                    for (int k = kb; k < ke; k++) g += V[k * ld + i + 1] * V[k * ld + j];
+                    part[wave * EIG_LD + j] = g;
+                }
+            }
+            __syncthreads();
+            for (int j = t; j <= i; j += nt) {
+                double g = 0;
+                for (int q = 0; q < nw; q++) g += part[q * EIG_LD + j];
+                gtmp[j] = g;
+            }
+            __syncthreads();
+            {
+                const int m = i + 1;
+                for (int idx = t; idx < m * m; idx += nt) {
+                    int k = idx / m, j = idx - k * m;
+                    V[k * ld + j] -= gtmp[j] * (V[k * ld + i + 1] / h);
+                }
+            }
+            __syncthreads();
+        }
+        for (int k = t; k <= i; k += nt) V[k * ld + i + 1] = 0.0;
+        __syncthreads();
+    }
+    for (int j = t; j < n; j += nt) { d[j] = V[(n - 1) * ld + j]; V[(n - 1) * ld + j] = 0.0; }
+    __syncthreads();
+    if (t == 0) { V[(n - 1) * ld + n - 1] = 1.0; e[0] = 0.0; }
+    __syncthreads();
+}
+
+// implicit QL on the tridiagonal (d, e) with eigenvector accumulation into V; one wavefront, lanes own rows k, k+64, ...
+__device__ void tridiag_ql_wave(double *V, int n, int ld, double *d, double *e) {
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {
+        for (int i = 1 + lane; i < n; i += 64) { double v = e[i]; __builtin_amdgcn_wave_barrier(); e[i - 1] = v; }
+        // (shifting through LDS lane-parallel: read all first, then write)
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        if (lane == 0) e[n - 1] = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        double f = 0.0, tst1 = 0.0;
+        const double eps = 2.220446049250313e-16;
+        for (int l = 0; l < n; l++) {
+            tst1 = fmax(tst1, fabs(d[l]) + fabs(e[l]));
+            int m = l;
+            while (m < n) { if (fabs(e[m]) <= eps * tst1) break; m++; }
+            if (m > l) {
+                int iter = 0;
+                do {
+                    iter++;
+                    double g = d[l];
+                    double p = (d[l + 1] - g) / (2.0 * e[l]);
+                    double r = sqrt(p * p + 1.0);
+                    if (p < 0) r = -r;
+                    double dl = e[l] / (p + r), dl1 = e[l] * (p + r);
+                    double h = g - dl;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) { d[l] = dl; d[l + 1] = dl1; }
+                    for (int i = l + 2 + lane; i < n; i += 64) d[i] -= h;
+                    __builtin_amdgcn_wave_barrier();
+                    __threadfence_block();
+                    f += h;
+                    p = d[m];
+                    double c = 1.0, c2 = 1.0, c3 = 1.0, el1 = e[l + 1], s = 0.0, s2 = 0.0;
+                    const int r0 = lane < n ? lane : 0, r1 = lane + 64 < n ? lane + 64 : r0;  // n <= 128; duplicates write equal values
+                    double car0 = V[r0 * ld + m], car1 = V[r1 * ld + m];
+                    // software pipeline: e[i-1], d[i-1] and the next V column are fetched before this rotation's stores
+                    double ei = e[m - 1], di = d[m - 1];
+                    double vi0 = V[r0 * ld + m - 1], vi1 = V[r1 * ld + m - 1];
+                    for (int i = m - 1; i >= l; i--) {
+                        c3 = c2; c2 = c; s2 = s;
+                        const int in = i > l ? i - 1 : i;
+                        const double ei_n = e[in], di_n = d[in];
+                        const double vn0 = V[r0 * ld + in], vn1 = V[r1 * ld + in];
+                        g = c * ei;
+                        h = c * p;
+                        const double rr2 = p * p + ei * ei;
+                        const double rinv = rr2 > 0.0 ? rsqrt(rr2) : 0.0;   // one slow op on the serial chain instead of sqrt + divide
+                        r = rr2 * rinv;
+                        double e_ip1 = s * r;
+                        s = ei * rinv;
+                        c = p * rinv;
+                        p = c * di - s * g;
+                        double d_ip1 = h + s * (c * g + s * di);
+                        if (lane == 0) { e[i + 1] = e_ip1; d[i + 1] = d_ip1; }  // read again only after the sweep's fence
+                        // rows lane and lane+64 of V: the rotated column i is carried in registers to the next rotation
+                        V[r0 * ld + i + 1] = s * vi0 + c * car0;
+                        V[r1 * ld + i + 1] = s * vi1 + c * car1;
+                        car0 = c * vi0 - s * car0;
+                        car1 = c * vi1 - s * car1;
+                        ei = ei_n; di = di_n; vi0 = vn0; vi1 = vn1;
+                    }
+                    V[r0 * ld + l] = car0;
+                    V[r1 * ld + l] = car1;
+                    p = -s * s2 * c3 * el1 * e[l] / dl1;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) { e[l] = s * p; d[l] = c * p; }
+                    __builtin_amdgcn_wave_barrier();
+                    __threadfence_block();
+                } while (fabs(e[l]) > eps * tst1 && iter < 60);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) { d[l] = d[l] + f; e[l] = 0.0; }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
+    }
+    __syncthreads();
+}
+
+// in-place lower Cholesky of the n x n matrix A (ld), right-looking; returns false if a pivot is not positive
+__device__ bool chol_block(double *A, int n, int ld, int *sh_flag) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    if (t == 0) *sh_flag = 1;
+    __syncthreads();
+    for (int j = 0; j < n; j++) {
+        if (t == 0) {
+            double d = A[j * ld + j];
+            if (!(d > 0.0) || !isfinite(d)) *sh_flag = 0; else A[j * ld + j] = sqrt(d);
+        }
+        __syncthreads();
+        if (!*sh_flag) return false;
+        double l = A[j * ld + j];
+        for (int i = j + 1 + t; i < n; i += nt) A[i * ld + j] /= l;
+        __syncthreads();
+        int m = n - j - 1;
+        for (int w = t; w < m * m; w += nt) {
+            int r = w / m, cc = w - r * m;
+            if (cc > r) continue;
+            int i = j + 1 + r, k = j + 1 + cc;
+            A[i * ld + k] -= A[i * ld + j] * A[k * ld + j];
+        }
+        __syncthreads();
+    }
+    return true;
+}
+// solve L L^T x = b with one wavefront (lanes own strided entries of x held in LDS xs)
+__device__ void chol_solve_wave(const double *L, int n, int ld, double *xs) {
+    const int t = threadIdx.x;
+    if (t < 64) {
+        for (int j = 0; j < n; j++) {
+            double xj = xs[j] / L[j * ld + j];
+            __builtin_amdgcn_wave_barrier();
+            if (t == 0) xs[j] = xj;
+            for (int i = j + 1 + t; i < n; i += 64) xs[i] -= L[i * ld + j] * xj;
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
+        for (int j = n - 1; j >= 0; j--) {
+            double xj = xs[j] / L[j * ld + j];
+            __builtin_amdgcn_wave_barrier();
+            if (t == 0) xs[j] = xj;
+            for (int i = t; i < j; i += 64) xs[i] -= L[j * ld + i] * xj;
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ dense linear algebra on the scaled system
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+#define VIO_LWMAX 336  // >= LW for W = 20
+
+// lower-triangle tile index -> (ti, tj), ti >= tj
+__device__ __forceinline__ void tri_decode(int idx, int &ti, int &tj) {
+    int r = 0;
+    while (idx >= r + 1) { idx -= r + 1; r++; }
+    ti = r; tj = idx;
+}
+
+// S = S_p H S_p + mu*diag(dgp^2) - sum_k inv[k] (S_p Hpl[k][:])^T (S_p Hpl[k][:])   (lower tiles only), v_mfma_f64_16x16x4_f64.
+// Hs / Ws: the UNSCALED H and landmark coupling rows (ld); the Jacobi column scaling sp is applied while loading the MFMA
+// operands. Kpad rows (multiple of 4, rows >= Fa are zero), inv[k] = sl[k]^2 / hllr[k].
+__device__ void schur_mfma(const double *Hs, const double *Ws, const double *inv, const double *dgp, const double *sp, double mu,
+                           int Kpad, int n /*multiple of 16*/, int ld, double *Sc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nb = n >> 4, ntile = nb * (nb + 1) / 2;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int tile = wave; tile < ntile; tile += nw) {
+        int ti, tj;
+        tri_decode(tile, ti, tj);
+        v4f64 acc;
+        for (int r = 0; r < 4; r++) {
+            int row = 16 * ti + lk + 4 * r, col = 16 * tj + li;
+            double v = sp[row] * sp[col] * Hs[(size_t)row * ld + col];
+            if (row == col) { v += mu * dgp[row] * dgp[row]; if (sp[row] == 0.0) v = 1.0; }
+            acc[r] = v;
+        }
+        const double *wa = Ws + 16 * ti + li, *wb = Ws + 16 * tj + li;
+        const double spa = sp[16 * ti + li], spb = sp[16 * tj + li];
+        for (int k0 = 0; k0 < Kpad; k0 += 4) {
+            int kk = k0 + lk;
+            double a = -(wa[(size_t)kk * ld] * spa * inv[kk]);
+            double b = wb[(size_t)kk * ld] * spb;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        for (int r = 0; r < 4; r++) Sc[(size_t)(16 * ti + lk + 4 * r) * ld + 16 * tj + li] = acc[r];
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------ Schur complement + Cholesky with S resident in LDS
+// S (n x n, n = 16 nb) is kept as its nb(nb+1)/2 lower 16x16 tiles in LDS; element (r, c) of tile (ti, tj) lives at
+// tile_base + r*16 + (c ^ r): the XOR swizzle makes both row-wise and column-wise 64-bit accesses bank-conflict free.
+__device__ __forceinline__ int tl_idx(int ti, int tj, int r, int c) { return ((ti * (ti + 1) / 2 + tj) << 8) + (r << 4) + (c ^ r); }
+
+__device__ void schur_mfma_lds(const double *Hs, const double *Ws, const double *inv, const double *dgp, const double *sp, double mu,
+                               int Kpad, int n, int ld, double *T) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nb = n >> 4, ntile = nb * (nb + 1) / 2;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int tile = wave; tile < ntile; tile += nw) {
+        int ti, tj;
+        tri_decode(tile, ti, tj);
+        v4f64 acc;
+        for (int r = 0; r < 4; r++) {
+            int row = 16 * ti + lk + 4 * r, col = 16 * tj + li;
+            double v = sp[row] * sp[col] * Hs[(size_t)row * ld + col];
+            if (row == col) { v += mu * dgp[row] * dgp[row]; if (sp[row] == 0.0) v = 1.0; }
+            acc[r] = v;
+        }
+        const double *wa = Ws + 16 * ti + li, *wb = Ws + 16 * tj + li;
+        const double spa = sp[16 * ti + li], spb = sp[16 * tj + li];
+        for (int k0 = 0; k0 < Kpad; k0 += 4) {
+            int kk = k0 + lk;
+            double a = -(wa[(size_t)kk * ld] * spa * inv[kk]);
+            double b = wb[(size_t)kk * ld] * spb;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+        for (int r = 0; r < 4; r++) T[tl_idx(ti, tj, lk + 4 * r, li)] = acc[r];
+    }
+    __syncthreads();
+}
+
+// Same Schur complement, landmark rows staged through LDS once: every wavefront keeps the accumulators of its (<= MAXT)
+// tiles in registers for the whole k loop, the 16-row chunks of Hpl (scaled by sp on the way in) are double-buffered in the
+// tile region itself (it is only written at the end).  Global traffic drops from 2 * ntile * Kpad * 16 doubles (every
+// tile re-reading its two column panels) to Kpad * n doubles.
+#define SCH_CH 16
+template <int MAXT>
+__device__ void schur_mfma_staged(const double *Hs, const double *Ws, const double *inv, const double *dgp, const double *sp, double mu,
+                                  int Kpad, int n, int ld, double *T) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    const int nb = n >> 4, ntile = nb * (nb + 1) / 2;
+    const int li = lane & 15, lk = lane >> 4;
+    const int lds = n + 8;  // padded row stride of the staged chunk (bank spread of the 4 k-rows)
+    double *buf0 = T, *buf1 = T + SCH_CH * lds;
+    v4f64 acc[MAXT];
+    int tis[MAXT], tjs[MAXT];
+#pragma unroll
+    for (int i = 0; i < MAXT; i++) {
+        int tile = wave + i * nw;
+        int ti = 0, tj = 0;
+        if (tile < ntile) tri_decode(tile, ti, tj);
+        tis[i] = ti; tjs[i] = tj;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int row = 16 * ti + lk + 4 * r, col = 16 * tj + li;
+            double v = sp[row] * sp[col] * Hs[(size_t)row * ld + col];
+            if (row == col) { v += mu * dgp[row] * dgp[row]; if (sp[row] == 0.0) v = 1.0; }
+            acc[i][r] = v;
+        }
+    }
+    const int nchunk = (Kpad + SCH_CH - 1) / SCH_CH;
+    auto stage = [&](int ch, double *buf) {
+        for (int q = t; q < SCH_CH * n; q += nt) {
+            int r = q / n, cc = q - r * n, kk = ch * SCH_CH + r;
+            buf[r * lds + cc] = kk < Kpad ? Ws[(size_t)kk * ld + cc] * sp[cc] : 0.0;
+        }
+    };
+    stage(0, buf0);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ch++) {
+        double *cur = (ch & 1) ? buf1 : buf0, *nxt = (ch & 1) ? buf0 : buf1;
+        if (ch + 1 < nchunk) stage(ch + 1, nxt);
+        double iv[SCH_CH / 4];
+#pragma unroll
+        for (int ks = 0; ks < SCH_CH / 4; ks++) { int kk = ch * SCH_CH + 4 * ks + lk; iv[ks] = kk < Kpad ? inv[kk] : 0.0; }
+#pragma unroll
+        for (int i = 0; i < MAXT; i++) {
+            if (wave + i * nw < ntile) {
+                const double *pa = cur + lk * lds + 16 * tis[i] + li, *pb = cur + lk * lds + 16 * tjs[i] + li;
+#pragma unroll
+                for (int ks = 0; ks < SCH_CH / 4; ks++) {
+                    double a = -(pa[4 * ks * lds] * iv[ks]);
+                    double b = pb[4 * ks * lds];
+                    acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < MAXT; i++)
+        if (wave + i * nw < ntile) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) T[tl_idx(tis[i], tjs[i], lk + 4 * r, li)] = acc[i][r];
+        }
+    __syncthreads();
+}
+
+// broadcast of one lane's double through SGPRs (v_readlane_b32 x 2): far lower latency than the ds_bpermute behind __shfl.
+// The lane index must be wave-uniform (here: a compile-time constant of an unrolled loop).
+__device__ __forceinline__ double bcast_lane(double v, int src_lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src_lane);
+    hi = __builtin_amdgcn_readlane(hi, src_lane);
+    return __hiloint2double(hi, lo);
+}
+
+// Look-ahead: while the other wavefronts run the trailing update of step p, wavefront 0 updates tile (p+1, p+1) first and factors
+// it straight away, so the serial 16-step diagonal factorisation is off the critical path.  dinv[16 nb] receives 1 / l_jj.
+__device__ bool chol_tiles(double *T, int nb, int *sh_flag, double *dinv) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    // 16x16 diagonal block: lanes 0..15 of wavefront 0 hold one row each in registers, shuffles broadcast pivots
+    auto factor_diag = [&](int p) {
+        const int row = lane & 15;
+        double a[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; cc++) a[cc] = T[tl_idx(p, p, row, cc)];
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            double ajj = bcast_lane(a[j], j);
+            if (!(ajj > 0.0) || !isfinite(ajj)) ok = false;
+            double rl = rsqrt(ajj);       // one slow operation per pivot: l = a * rsqrt(a), 1 / l = rsqrt(a)
+            double l = ajj * rl;
+            if (row == j) { a[j] = l; if (lane < 16) dinv[16 * p + j] = rl; }
+            else if (row > j) a[j] = a[j] * rl;
+#pragma unroll
+            for (int k = j + 1; k < 16; k++) {
+                double akj = bcast_lane(a[j], k);
+                if (row >= k) a[k] -= a[j] * akj;
+            }
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) if (cc <= row) T[tl_idx(p, p, row, cc)] = a[cc];
+        }
+        if (!ok && lane == 0) *sh_flag = 0;
+    };
+    auto update_tile = [&](int ti, int tj, int p) {
+        v4f64 acc;
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[r] = T[tl_idx(ti, tj, lk + 4 * r, li)];
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[tl_idx(ti, p, li, 4 * kk + lk)], T[tl_idx(tj, p, li, 4 * kk + lk)], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) T[tl_idx(ti, tj, lk + 4 * r, li)] = acc[r];
+    };
+    if (t == 0) *sh_flag = 1;
+    __syncthreads();
+    if (wave == 0) factor_diag(0);
+    __syncthreads();
+    for (int p = 0; p < nb; p++) {
+        if (!*sh_flag) return false;
+        // (b) panel: rows of the tiles below solve x L_pp^T = a
+        for (int q = t; q < 16 * (nb - 1 - p); q += nt) {
+            int ti = p + 1 + (q >> 4), r = q & 15;
+            double x[16];
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) {
+                double sacc = T[tl_idx(ti, p, r, cc)];
+#pragma unroll
+                for (int k = 0; k < cc; k++) sacc -= x[k] * T[tl_idx(p, p, cc, k)];
+                x[cc] = sacc * dinv[16 * p + cc];
+            }
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) T[tl_idx(ti, p, r, cc)] = x[cc];
+        }
+        __syncthreads();
+        // (c) trailing update S22 -= L21 L21^T on the FP64 matrix cores; tile 0 = (p+1, p+1) belongs to wavefront 0
+        const int m = nb - 1 - p, ntile = m * (m + 1) / 2;
+        if (nw > 1) {
+            if (wave == 0) {
+                if (ntile > 0) {
+                    update_tile(p + 1, p + 1, p);
+                    WAVE_SYNC();
+                    factor_diag(p + 1);
+                }
+            } else {
+                for (int tile = wave; tile < ntile; tile += nw - 1) {  // tiles 1.. over wavefronts 1..nw-1
+                    int ti, tj;
+                    tri_decode(tile, ti, tj);
+                    update_tile(ti + p + 1, tj + p + 1, p);
+                }
+            }
+        } else {
+            for (int tile = 0; tile < ntile; tile++) {
+                int ti, tj;
+                tri_decode(tile, ti, tj);
+                update_tile(ti + p + 1, tj + p + 1, p);
+            }
+            WAVE_SYNC();
+            if (ntile > 0) factor_diag(p + 1);
+        }
+        __syncthreads();
+    }
+    return *sh_flag != 0;
+}
+
+__device__ void chol_solve_tiles(const double *T, int nb, double *xs, const double *dinv) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6;
+    for (int p = 0; p < nb; p++) {  // forward: L y = b
+        if (wave == 0) {
+            const int row = lane & 15;
+            double b = xs[16 * p + row];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                double xj = bcast_lane(b, j) * dinv[16 * p + j];
+                if (row == j) b = xj; else if (row > j) b -= T[tl_idx(p, p, row, j)] * xj;
+            }
+            if (lane < 16) xs[16 * p + row] = b;
+        }
+        __syncthreads();
+        for (int q = t; q < 16 * (nb - 1 - p); q += nt) {
+            int ti = p + 1 + (q >> 4), r = q & 15;
+            double sacc = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) sacc += T[tl_idx(ti, p, r, k)] * xs[16 * p + k];
+            xs[16 * ti + r] -= sacc;
+        }
+        __syncthreads();
+    }
+    for (int p = nb - 1; p >= 0; p--) {  // backward: L^T x = y
+        if (wave == 0) {
+            const int row = lane & 15;
+            double b = xs[16 * p + row];
+#pragma unroll
+            for (int j = 15; j >= 0; j--) {
+                double xj = bcast_lane(b, j) * dinv[16 * p + j];
+                if (row == j) b = xj; else if (row < j) b -= T[tl_idx(p, p, j, row)] * xj;
+            }
+            if (lane < 16) xs[16 * p + row] = b;
+        }
+        __syncthreads();
+        for (int q = t; q < 16 * p; q += nt) {
+            int tj = q >> 4, cc = q & 15;
+            double sacc = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) sacc += T[tl_idx(p, tj, k, cc)] * xs[16 * p + k];
+            xs[q] -= sacc;
+        }
+        __syncthreads();
+    }
+}
+
+// Blocked (16) right-looking Cholesky of the lower triangle of A (n x n, n multiple of 16): diagonal block by one
+// wavefront in LDS, panel solve one row per thread, trailing update L21 L21^T on the FP64 matrix cores.
+__device__ bool chol_blocked(double *A, int n, int ld, int *sh_flag, double *Lpp) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    const int nb = n >> 4;
+    if (t == 0) *sh_flag = 1;
+    __syncthreads();
+    for (int p = 0; p < nb; p++) {
+        const int o = 16 * p;
+        if (t < 256) Lpp[t] = A[(size_t)(o + (t >> 4)) * ld + o + (t & 15)];
+        __syncthreads();
+        if (wave == 0) {
+            double *L = Lpp;
+            bool ok = true;
+            for (int j = 0; j < 16 && ok; j++) {
+                double d = L[j * 16 + j];
+                if (!(d > 0.0) || !isfinite(d)) { ok = false; break; }
+                double l = sqrt(d);
+                if (lane > j && lane < 16) L[lane * 16 + j] = L[lane * 16 + j] / l;
+                if (lane == j) L[j * 16 + j] = l;
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+                for (int q = lane; q < 256; q += 64) {
+                    int i = q >> 4, k = q & 15;
+                    if (k > j && i >= k) L[q] = L[q] - L[i * 16 + j] * L[k * 16 + j];
+                }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+            }
+            if (!ok && lane == 0) *sh_flag = 0;
+        }
+        __syncthreads();
+        if (!*sh_flag) return false;
+        if (t < 256) { int i = t >> 4, k = t & 15; if (k <= i) A[(size_t)(o + i) * ld + o + k] = Lpp[t]; }
+        for (int r = o + 16 + t; r < n; r += nt) {
+            double x[16];
+            double *row = A + (size_t)r * ld + o;
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) {
+                double s = row[cc];
+#pragma unroll
+                for (int k = 0; k < cc; k++) s -= x[k] * Lpp[cc * 16 + k];
+                x[cc] = s / Lpp[cc * 16 + cc];
+            }
+#pragma unroll
+            for (int cc = 0; cc < 16; cc++) row[cc] = x[cc];
+        }
+        __syncthreads();
+        const int m = nb - 1 - p, ntile = m * (m + 1) / 2;
+        const int li = lane & 15, lk = lane >> 4;
+        for (int tile = wave; tile < ntile; tile += nw) {
+            int ti, tj;
+            tri_decode(tile, ti, tj);
+            ti += p + 1; tj += p + 1;
+            v4f64 acc;
+            for (int r = 0; r < 4; r++) acc[r] = A[(size_t)(16 * ti + lk + 4 * r) * ld + 16 * tj + li];
+            const double *pa = A + (size_t)(16 * ti + li) * ld + o, *pb = A + (size_t)(16 * tj + li) * ld + o;
+            for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pa[4 * kk + lk], pb[4 * kk + lk], acc, 0, 0, 0);
+            for (int r = 0; r < 4; r++) A[(size_t)(16 * ti + lk + 4 * r) * ld + 16 * tj + li] = acc[r];
+        }
+        __syncthreads();
+    }
+    return true;
+}
+// Solve L L^T x = b in place (xs in LDS), block-wise: 16x16 triangular solves by one wavefront, updates by all threads.
+__device__ void chol_solve_blocked(const double *L, int n, int ld, double *xs, double *Lpp) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6;
+    const int nb = n >> 4;
+    for (int p = 0; p < nb; p++) {  // forward: L y = b
+        const int o = 16 * p;
+        if (t < 256) Lpp[t] = L[(size_t)(o + (t >> 4)) * ld + o + (t & 15)];
+        __syncthreads();
+        if (wave == 0) {
+            double *x = xs;
+            for (int j = 0; j < 16; j++) {
+                double xj = x[o + j] / Lpp[j * 16 + j];
+                __builtin_amdgcn_wave_barrier();
+                if (lane == j) x[o + j] = xj;
+                if (lane > j && lane < 16) x[o + lane] = x[o + lane] - Lpp[lane * 16 + j] * xj;
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+            }
+        }
+        __syncthreads();
+        for (int r = o + 16 + t; r < n; r += nt) {
+            const double *row = L + (size_t)r * ld + o;
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) s += row[k] * xs[o + k];
+            xs[r] -= s;
+        }
+        __syncthreads();
+    }
+    for (int p = nb - 1; p >= 0; p--) {  // backward: L^T x = y
+        const int o = 16 * p;
+        if (t < 256) Lpp[t] = L[(size_t)(o + (t >> 4)) * ld + o + (t & 15)];
+        __syncthreads();
+        if (wave == 0) {
+            double *x = xs;
+            for (int j = 15; j >= 0; j--) {
+                double xj = x[o + j] / Lpp[j * 16 + j];
+                __builtin_amdgcn_wave_barrier();
+                if (lane == j) x[o + j] = xj;
+                if (lane < j) x[o + lane] = x[o + lane] - Lpp[j * 16 + lane] * xj;
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+            }
+        }
+        __syncthreads();
+        for (int r = t; r < o; r += nt) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) s += L[(size_t)(o + k) * ld + r] * xs[o + k];
+            xs[r] -= s;
+        }
+        __syncthreads();
+    }
+}
+
+// out[a] = sum_b M[b][a] * v[b] for a < n (M symmetric or "column sum" of a row-major matrix with nrows rows), split over
+// blockDim/256 row groups and combined through LDS part[(blockDim/256)*VIO_LWMAX]
+__device__ void colsum(const double *M, int ld, int nrows, const double *v, int n, double *out, double *part) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    const int groups = nt >> 8, g = t >> 8, a0 = t & 255;
+    for (int a = a0; a < n; a += 256) {
+        double s = 0;
+        for (int b = g; b < nrows; b += groups) s += M[(size_t)b * ld + a] * v[b];
+        part[g * VIO_LWMAX + a] = s;
+    }
+    __syncthreads();
+    for (int a = t; a < n; a += nt) {
+        double s = 0;
+        for (int q = 0; q < groups; q++) s += part[q * VIO_LWMAX + a];
+        out[a] = s;
+    }
+    __syncthreads();
+}
+// out[k] = sum_a M[k][a] * v[a], one wavefront per row
+__device__ void rowdot(const double *M, int ld, int nrows, const double *v, int n, double *out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int k = wave; k < nrows; k += nw) {
+        double s = 0;
+        for (int a = lane; a < n; a += 64) s += M[(size_t)k * ld + a] * v[a];
+        s = wave_sum_dpp(s);
+        if (lane == 0) out[k] = s;
+    }
+    __syncthreads();
+}
+
+// One pass over a row-major matrix M (nrows x n, leading dimension ld) producing either or both of
+//   out_row[k] = M[k][:] . v          (v != nullptr)
+//   out_col[a] = sum_k u[k] M[k][a]   (u != nullptr)
+// One wavefront per row (lanes own columns lane, lane + 64, ...): row dots through shuffles, column sums in registers and
+// combined over the wavefronts through LDS part[nw * VIO_LWMAX].  Ends with a block barrier.
+template <int NC>
+__device__ void matvec_pass_t(const double *M, int ld, int nrows, int n, const double *u, const double *v, double *out_col, double *out_row,
+                              double *part) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    double cs[NC], vv[NC];
+#pragma unroll
+    for (int j = 0; j < NC; j++) { int a = lane + 64 * j; cs[j] = 0; vv[j] = (v && a < n) ? v[a] : 0.0; }
+#pragma unroll 2
+    for (int k = wave; k < nrows; k += nw) {
+        const double *r = M + (size_t)k * ld;
+        double m[NC];
+#pragma unroll
+        for (int j = 0; j < NC; j++) { int a = lane + 64 * j; m[j] = a < n ? r[a] : 0.0; }
+        if (v) {
+            double rd = 0;
+#pragma unroll
+            for (int j = 0; j < NC; j++) rd += m[j] * vv[j];
+            rd = wave_sum_dpp(rd);
+            if (lane == 0) out_row[k] = rd;
+        }
+        if (u) {
+            const double uk = u[k];
+#pragma unroll
+            for (int j = 0; j < NC; j++) cs[j] += uk * m[j];
+        }
+    }
+    if (u) {
+#pragma unroll
+        for (int j = 0; j < NC; j++) { int a = lane + 64 * j; if (a < n) part[wave * VIO_LWMAX + a] = cs[j]; }
+        __syncthreads();
+        for (int a = t; a < n; a += nt) {
+            double sacc = 0;
+            for (int q = 0; q < nw; q++) sacc += part[q * VIO_LWMAX + a];
+            out_col[a] = sacc;
+        }
+    }
+    __syncthreads();
+}
+__device__ void matvec_pass(const double *M, int ld, int nrows, int n, const double *u, const double *v, double *out_col, double *out_row,
+                            double *part) {
+    if (n <= 192) matvec_pass_t<3>(M, ld, nrows, n, u, v, out_col, out_row, part);
+    else matvec_pass_t<6>(M, ld, nrows, n, u, v, out_col, out_row, part);
+}
+
+}  // namespace
