@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--cpu-seqs", type=int, default=8, help="sequences replayed through the CPU oracle on rank 0 (0 = skip)")
     ap.add_argument("--aux", action="store_true", help="also measure S=256 sequences per GPU (reported as aux_s256, never as value)")
     ap.add_argument("--pcie-steps", type=int, default=6, help="extra steps fed from HOST buffers after the timed region (0 = skip)")
+    ap.add_argument("--stream-steps", type=int, default=10, help="extra steps with the IMU pushed frame by frame (vio_push_imu per sequence per frame)")
     args = ap.parse_args()
 
     import torch
@@ -109,7 +110,8 @@ def main():
     H, Wd = cfg.height, cfg.width
     n_pre = 16  # first-image skip + init_pub + init_feature + (window_size + 1) frames -> NON_LINEAR, + margin
     Kp = max(args.pcie_steps, 0)
-    F = n_pre + Wm + K + Kp
+    Ks = max(args.stream_steps, 0)
+    F = n_pre + Wm + K + Kp + Ks
     seq0 = shard.sequence_shard(rank, world, S)[0]
     syn = P.Synth(sc)
     dev = torch.device("cuda", local_rank)
@@ -120,9 +122,14 @@ def main():
         syn.render_device(S, seq0, float(times[f]), gray[f], depth[f])
     nimu = int(F / sc.cam_rate * sc.imu_rate) + 64
     b = P.VioBatch(cfg, S, imu_capacity=nimu + 64)
+    imu_all = [syn.imu(seq0 + s, nimu) for s in range(S)]
+    t_stream0 = times[F - Ks] if Ks > 0 else 1e300   # IMU up to (and one sample past) the last non-streaming frame goes in up front
+    imu_k = []
     for s in range(S):
-        ti, ai, gi = syn.imu(seq0 + s, nimu)
-        b.push_imu(s, ti, ai, gi)
+        ti, ai, gi = imu_all[s]
+        k = vio_ct.imu_until(ti, 0, times[F - Ks - 1], sc.imu_rate) if Ks > 0 else len(ti)
+        b.push_imu(s, ti[:k], ai[:k], gi[:k])
+        imu_k.append(k)
 
     def feed(f):
         b.feed(gray[f], depth[f], np.full(S, times[f]), on_device=True)
@@ -162,10 +169,31 @@ def main():
         pcie = dict(frames_per_s=S * Kp / (c1 - c0), ms_per_step=(c1 - c0) / Kp * 1e3, steps=Kp,
                     note="vio_feed(on_device=0): pageable numpy buffers, %.1f MB uploaded per step" % (S * H * Wd * 3 / 1e6))
 
+    # ---- streaming leg (never `value`): IMU arrives between frames, 20 samples per sequence pushed through vio_push_imu before
+    # each vio_feed, device-resident images -- the call pattern of the reference's callbacks
+    stream = None
+    if Ks > 0:
+        f0 = F - Ks
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for k in range(Ks):
+            f = f0 + k
+            for s in range(S):
+                ti, ai, gi = imu_all[s]
+                k2 = vio_ct.imu_until(ti, imu_k[s], times[f], sc.imu_rate)
+                if k2 > imu_k[s]:
+                    b.push_imu(s, ti[imu_k[s]:k2], ai[imu_k[s]:k2], gi[imu_k[s]:k2])
+                    imu_k[s] = k2
+            feed(f)
+        b.sync()
+        c1 = time.perf_counter()
+        stream = dict(frames_per_s=S * Ks / (c1 - c0), ms_per_step=(c1 - c0) / Ks * 1e3, steps=Ks,
+                      note="IMU pushed per sequence per frame from Python (host time of %d ctypes calls per step included)" % S)
+
     # ---- validity + accuracy (outside the timed region)
     stats = [b.status(s) for s in range(S)]
     fp1 = np.array([st.frames_processed for st in stats])
-    all_processed = bool(np.all(fp1 - fp0 == K + Kp) and np.all(nl == 1))
+    all_processed = bool(np.all(fp1 - fp0 == K + Kp + Ks) and np.all(nl == 1))
     ates = []
     hist = {}
     for s in range(S):
@@ -286,6 +314,7 @@ def main():
         "cpu_baseline": cpu,
         "parity": parity,
         "pcie_inclusive": pcie,
+        "imu_streaming": stream,
     }
     if args.aux and rank == 0:
         out["aux_s256"] = aux_rate(P, vio_ct, torch, cfg, sc, dev, 256, n_pre, Wm, K)

@@ -61,9 +61,17 @@ struct vio_batch {
     std::mutex imu_mu;
     std::vector<int> p_seq;
     std::vector<double> p_t, p_acc, p_gyr;
-    int *d_pseq = nullptr;
-    double *d_pt = nullptr, *d_pacc = nullptr, *d_pgyr = nullptr;
-    size_t d_pcap = 0;
+    // IMU upload: two pinned host staging sets + device sets used alternately, each guarded by an event, so that vio_push_imu
+    // between frames never forces a device-wide synchronisation (the scatter kernel is ordered on the streams instead)
+    struct ImuStage {
+        int *h_seq = nullptr, *d_seq = nullptr;
+        double *h_t = nullptr, *h_acc = nullptr, *h_gyr = nullptr, *d_t = nullptr, *d_acc = nullptr, *d_gyr = nullptr;
+        size_t cap = 0;
+        hipEvent_t done = nullptr;
+        bool busy = false;
+    } imu_stage[2];
+    int imu_stage_cur = 0;
+    hipEvent_t ev_imu = nullptr;
     std::vector<double> last_imu_t;
     size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0, lds_marg = 0;
     bool timing_valid = false;
@@ -167,27 +175,87 @@ int init_state(vio_batch *h) {
     return VIO_OK;
 }
 
-int flush_imu(vio_batch *h) {
+// Moves the samples accepted by vio_push_imu into the per-sequence HBM rings.  The scatter kernel runs on `st`; the caller has
+// already ordered `st` after the last reader of the rings (be_ingest of the previous frame, via ev_solve / stream order) and orders
+// the next readers (fe_begin, be_ingest) after it.  No host-device synchronisation unless a staging set is still in flight.
+int flush_imu(vio_batch *h, hipStream_t st, bool *launched) {
+    if (launched) *launched = false;
     std::lock_guard<std::mutex> lk(h->imu_mu);
     size_t n = h->p_seq.size();
     if (n == 0) return VIO_OK;
-    if (n > h->d_pcap) {
+    vio_batch::ImuStage &sg = h->imu_stage[h->imu_stage_cur];
+    h->imu_stage_cur ^= 1;
+    if (sg.busy) { HIPCHK(hipEventSynchronize(sg.done)); sg.busy = false; }
+    if (n > sg.cap) {
         size_t cap = n * 2 + 1024;
-        if (h->d_pseq) { (void)hipFree(h->d_pseq); (void)hipFree(h->d_pt); (void)hipFree(h->d_pacc); (void)hipFree(h->d_pgyr); }
-        HIPCHK(hipMalloc((void **)&h->d_pseq, cap * sizeof(int)));
-        HIPCHK(hipMalloc((void **)&h->d_pt, cap * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&h->d_pacc, cap * 3 * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&h->d_pgyr, cap * 3 * sizeof(double)));
-        h->d_pcap = cap;
+        if (sg.h_seq) {
+            (void)hipHostFree(sg.h_seq); (void)hipHostFree(sg.h_t); (void)hipHostFree(sg.h_acc); (void)hipHostFree(sg.h_gyr);
+            (void)hipFree(sg.d_seq); (void)hipFree(sg.d_t); (void)hipFree(sg.d_acc); (void)hipFree(sg.d_gyr);
+        }
+        HIPCHK(hipHostMalloc((void **)&sg.h_seq, cap * sizeof(int), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&sg.h_t, cap * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&sg.h_acc, cap * 3 * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&sg.h_gyr, cap * 3 * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&sg.d_seq, cap * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&sg.d_t, cap * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&sg.d_acc, cap * 3 * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&sg.d_gyr, cap * 3 * sizeof(double)));
+        sg.cap = cap;
+        if (!sg.done) HIPCHK(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
     }
-    { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }  // the ring is shared with running ingest / predict kernels
-    HIPCHK(hipMemcpyAsync(h->d_pseq, h->p_seq.data(), n * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_pt, h->p_t.data(), n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_pacc, h->p_acc.data(), n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(h->d_pgyr, h->p_gyr.data(), n * 3 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    imu_scatter_kernel<<<(h->S + 63) / 64, 64, 0, h->stream>>>(h->B, (int)n, h->d_pseq, h->d_pt, h->d_pacc, h->d_pgyr);
-    HIPCHK(hipStreamSynchronize(h->stream));  // host staging vectors are reused below
+    memcpy(sg.h_seq, h->p_seq.data(), n * sizeof(int));
+    memcpy(sg.h_t, h->p_t.data(), n * sizeof(double));
+    memcpy(sg.h_acc, h->p_acc.data(), n * 3 * sizeof(double));
+    memcpy(sg.h_gyr, h->p_gyr.data(), n * 3 * sizeof(double));
     h->p_seq.clear(); h->p_t.clear(); h->p_acc.clear(); h->p_gyr.clear();
+    HIPCHK(hipMemcpyAsync(sg.d_seq, sg.h_seq, n * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(sg.d_t, sg.h_t, n * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(sg.d_acc, sg.h_acc, n * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(sg.d_gyr, sg.h_gyr, n * 3 * sizeof(double), hipMemcpyHostToDevice, st));
+    imu_scatter_kernel<<<(h->S + 63) / 64, 64, 0, st>>>(h->B, (int)n, sg.d_seq, sg.d_t, sg.d_acc, sg.d_gyr);
+    HIPCHK(hipEventRecord(sg.done, st));
+    sg.busy = true;
+    if (launched) *launched = true;
+    return VIO_OK;
+}
+
+// vio_feed / vio_track: pending IMU goes in on group 0's front-end stream after every group's previous solve (its be_ingest, the
+// last reader of the rings, precedes the solve), and every group's front-end waits for it.
+int flush_imu_frontend(vio_batch *h) {
+    {
+        std::lock_guard<std::mutex> lk(h->imu_mu);
+        if (h->p_seq.empty()) return VIO_OK;
+    }
+    hipStream_t st = h->groups[0].fe_stream;
+    for (auto &g : h->groups) {
+        if (g.have_solve_ev) HIPCHK(hipStreamWaitEvent(st, g.ev_solve, 0));
+        HIPCHK(hipStreamWaitEvent(st, g.ev_be, 0));
+    }
+    bool launched = false;
+    int rc = flush_imu(h, st, &launched);
+    if (rc != VIO_OK || !launched) return rc;
+    if (h->groups.size() > 1) {
+        HIPCHK(hipEventRecord(h->ev_imu, st));
+        for (size_t k = 1; k < h->groups.size(); k++) HIPCHK(hipStreamWaitEvent(h->groups[k].fe_stream, h->ev_imu, 0));
+    }
+    return VIO_OK;
+}
+
+// vio_process (IMU that arrived between vio_track and vio_process): on group 0's back-end stream after every group's front-end
+int flush_imu_backend(vio_batch *h) {
+    {
+        std::lock_guard<std::mutex> lk(h->imu_mu);
+        if (h->p_seq.empty()) return VIO_OK;
+    }
+    hipStream_t st = h->groups[0].stream;
+    for (auto &g : h->groups) HIPCHK(hipStreamWaitEvent(st, g.ev_fe, 0));
+    bool launched = false;
+    int rc = flush_imu(h, st, &launched);
+    if (rc != VIO_OK || !launched) return rc;
+    if (h->groups.size() > 1) {
+        HIPCHK(hipEventRecord(h->ev_imu, st));
+        for (size_t k = 1; k < h->groups.size(); k++) HIPCHK(hipStreamWaitEvent(h->groups[k].stream, h->ev_imu, 0));
+    }
     return VIO_OK;
 }
 
@@ -396,6 +464,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
                 hipEventCreateWithFlags(&g.ev_be, hipEventDisableTiming) != hipSuccess) { g_err = "event create failed"; rc = VIO_EDEVICE; }
         }
         if (rc == VIO_OK) { h->stream = h->groups[0].stream; h->fe_stream = h->groups[0].fe_stream; }
+        if (rc == VIO_OK && hipEventCreateWithFlags(&h->ev_imu, hipEventDisableTiming) != hipSuccess) { g_err = "event create failed"; rc = VIO_EDEVICE; }
     }
     for (int i = 0; i < 4 && rc == VIO_OK; i++)
         if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_err = "event create failed"; rc = VIO_EDEVICE; }
@@ -441,7 +510,14 @@ void vio_destroy(vio_batch *h) {
     for (void *p : h->allocs) (void)hipFree(p);
     if (h->d_gray_stage) (void)hipFree(h->d_gray_stage);
     if (h->d_depth_stage) (void)hipFree(h->d_depth_stage);
-    if (h->d_pseq) { (void)hipFree(h->d_pseq); (void)hipFree(h->d_pt); (void)hipFree(h->d_pacc); (void)hipFree(h->d_pgyr); }
+    for (auto &sg : h->imu_stage) {
+        if (sg.h_seq) {
+            (void)hipHostFree(sg.h_seq); (void)hipHostFree(sg.h_t); (void)hipHostFree(sg.h_acc); (void)hipHostFree(sg.h_gyr);
+            (void)hipFree(sg.d_seq); (void)hipFree(sg.d_t); (void)hipFree(sg.d_acc); (void)hipFree(sg.d_gyr);
+        }
+        if (sg.done) (void)hipEventDestroy(sg.done);
+    }
+    if (h->ev_imu) (void)hipEventDestroy(h->ev_imu);
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
     for (auto &g : h->groups) {
         if (g.stream) (void)hipStreamDestroy(g.stream);
@@ -509,7 +585,7 @@ static int be_wait(vio_batch::Group &g) {
 
 int vio_feed(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, int on_device) {
     if (!h || !gray || !depth_mm || !stamps) return VIO_EINVAL;
-    int rc = flush_imu(h);
+    int rc = flush_imu_frontend(h);
     if (rc != VIO_OK) return rc;
     for (auto &g : h->groups) {
         if ((rc = fe_wait(g)) != VIO_OK) return rc;
@@ -533,7 +609,7 @@ int vio_feed(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const 
 
 int vio_track(vio_batch *h, const uint8_t *gray, const double *stamps, int publish, int on_device) {
     if (!h || !gray || !stamps) return VIO_EINVAL;
-    int rc = flush_imu(h);
+    int rc = flush_imu_frontend(h);
     if (rc != VIO_OK) return rc;
     for (auto &g : h->groups) {
         if ((rc = fe_wait(g)) != VIO_OK) return rc;
@@ -551,7 +627,7 @@ int vio_track(vio_batch *h, const uint8_t *gray, const double *stamps, int publi
 
 int vio_process(vio_batch *h, const uint16_t *depth_mm, int on_device) {
     if (!h || !depth_mm) return VIO_EINVAL;
-    int rc = flush_imu(h);
+    int rc = flush_imu_backend(h);
     if (rc != VIO_OK) return rc;
     for (auto &g : h->groups) {
         const uint8_t *dg = nullptr;
