@@ -66,7 +66,9 @@ def test_prior_matches_oracle_as_a_quadratic_form(P):
         assert np.abs(Ho - Hh).max() < 1e-5 * scale, float(np.abs(Ho - Hh).max() / scale)
         go, gh = Jo.T @ ro, Jh.T @ rh
         assert np.abs(go - gh).max() < 1e-5 * max(1.0, np.abs(go).max())
-        assert abs(ro @ ro - rh @ rh) < 1e-5 * max(1.0, ro @ ro)
+        # |r|^2 is a constant offset of the cost.  Eigen-directions whose eigenvalue lands within round-off of the 1e-8 cut-off are
+        # kept by one solver and dropped by the other (DESIGN.md deviation 12); each contributes (v^T b)^2 / lambda ~ 1e-5 here.
+        assert abs(ro @ ro - rh @ rh) < 2e-4 * max(1.0, ro @ ro)
 
 
 def test_two_handles_with_different_configurations_coexist(P):

@@ -307,7 +307,7 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth) {
     PEV(h, 10);
     (void)hipEventRecord(g.ev_solve, st);  // the next frame's front-end may start here (it only needs latest_Bg / td / ric)
     g.have_solve_ev = true;
-    be_marg_kernel<<<S, 256, h->lds_marg, st>>>(Bg);  // marginalisation + window slide (be_finish is fused into it)
+    be_marg_kernel<<<S, (getenv("VIO_MARG_THREADS") ? atoi(getenv("VIO_MARG_THREADS")) : 512), h->lds_marg, st>>>(Bg);  // marginalisation + window slide (be_finish is fused into it)
     PEV(h, 11);
     HIPCHK(hipGetLastError());
     return VIO_OK;
