@@ -87,14 +87,14 @@ namespace {
 // ------------------------------------------------------------------ IntegrationBase::propagate, block-cooperative
 // LDS workspace: sJ sP sFJ sFP (225 each) sF (225) sV (270)
 struct PreWork { double J[225], Pm[225], FJ[225], FP[225], F[225], V[270]; };
-__device__ void preint_load(const PreInt &p, PreWork &w) {
+__device__ __forceinline__ void preint_load(const PreInt &p, PreWork &w) {
     for (int i = threadIdx.x; i < 225; i += blockDim.x) { w.J[i] = p.jac[i]; w.Pm[i] = p.cov[i]; }
     __syncthreads();
 }
 // Also refreshes the whitening matrix of the IMU factor: M = chol(cov)^-1 (lower triangular), M^T M = cov^-1.
 // The reference uses LLT(cov^-1).L^T (imu_factor.h:66-69); both satisfy M^T M = cov^-1, so J^T J, J^T r and |r|^2 - the only
 // quantities the solver and the marginalisation consume - are identical up to round-off (DESIGN.md "equivalent whitening").
-__device__ void preint_store(PreInt &p, PreWork &w) {
+__device__ __forceinline__ void preint_store(PreInt &p, PreWork &w) {
     const int t = threadIdx.x;
     __syncthreads();
     for (int i = t; i < 225; i += blockDim.x) { p.jac[i] = w.J[i]; p.cov[i] = w.Pm[i]; }
@@ -481,7 +481,7 @@ namespace {
 struct Params { double pose[(VIO_MAXW + 1) * 7], sb[(VIO_MAXW + 1) * 9], ex[7], td; };
 
 // prior residual row i at parameters X: r0 + J dx; dx assembled in LDS sdx (n)
-__device__ void prior_dx(const Ctx &c, const Params &X, double *sdx) {
+__device__ __forceinline__ void prior_dx(const Ctx &c, const Params &X, double *sdx) {
     const int t = threadIdx.x, W = c.W;
     const BeSeq &be = *c.be;
     if (t <= W + 2) {
@@ -509,7 +509,7 @@ __device__ __forceinline__ int prior_map(int a, int W) {
 }
 
 // evaluate every residual at X. withJ: store weighted Jacobians/residuals for assembly. Returns total cost.
-__device__ double evaluate(const Ctx &c, const Params &X, const double *feat, bool withJ, int nres, double *sred, double *sdx, double *srp) {
+__device__ __forceinline__ double evaluate(const Ctx &c, const Params &X, const double *feat, bool withJ, int nres, double *sred, double *sdx, double *srp) {
     const int t = threadIdx.x, nt = blockDim.x, W = c.W, n = c.NPR;
     const BeSeq &be = *c.be;
     const vio_config &cfg = c.C->c;
@@ -608,7 +608,7 @@ __device__ __forceinline__ int pair_slot(int i, int j, int W1) { return i * W1 -
 
 // assemble H (P x P, ld LW), g (vec slot 0), Hpl / Hll / gl from the stored residual Jacobians.
 // work: LDS scratch (>= max(W*450, npairs*210) doubles when it fits, see be_solve); pb = frame-pair blocks (LDS or HBM)
-__device__ void assemble(const Batch &B, const Ctx &c, const Params &X, int nres, int Fa, const int *alist, double *srp, double *work,
+__device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Params &X, int nres, int Fa, const int *alist, double *srp, double *work,
                          double *pb) {
     const int s = c.s;
     PH_INIT;
@@ -1723,10 +1723,21 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
     long long tj0 = wall_clock64();
     __shared__ double ev_d[6 * VIO_MAXW + 16], ev_e[6 * VIO_MAXW + 16], ev_g[6 * VIO_MAXW + 16];
     __shared__ double ev_part[8 * EIG_LD];
-    if ((nt >> 6) <= 8) sym_eig_tridiag_mt(As, n, ldj, ev_d, ev_e, ev_g, ev_part);
-    else sym_eig_tridiag(As, n, ldj, ev_d, ev_e, ev_g, sred);
-    if (t == 0) be.dbg[5] = (int)(wall_clock64() - tj0);
-    tridiag_ql_wave(As, n, ldj, ev_d, ev_e);
+    // two call sites so that the eigen-solver is specialised for the address space of the matrix (ds_* for LDS, global_* for HBM)
+    // instead of falling back to flat loads on a pointer that could be either
+    if (in_lds) {
+        double *Al = (double *)smem_marg;
+        if ((nt >> 6) <= 8) sym_eig_tridiag_mt(Al, n, ldj, ev_d, ev_e, ev_g, ev_part);
+        else sym_eig_tridiag(Al, n, ldj, ev_d, ev_e, ev_g, sred);
+        if (t == 0) be.dbg[5] = (int)(wall_clock64() - tj0);
+        tridiag_ql_wave(Al, n, ldj, ev_d, ev_e);
+    } else {
+        double *Ag = c.margA;
+        if ((nt >> 6) <= 8) sym_eig_tridiag_mt(Ag, n, ldj, ev_d, ev_e, ev_g, ev_part);
+        else sym_eig_tridiag(Ag, n, ldj, ev_d, ev_e, ev_g, sred);
+        if (t == 0) be.dbg[5] = (int)(wall_clock64() - tj0);
+        tridiag_ql_wave(Ag, n, ldj, ev_d, ev_e);
+    }
     if (t == 0) be.dbg[6] = (int)(wall_clock64() - tj0);
     Vv = As;  // eigenvectors overwrite the matrix
     if (t == 0) { be.dbg[0] = 0; be.dbg[1] = (int)(wall_clock64() - tj0); be.dbg[2] = second_new ? 1 : 0; }

@@ -47,7 +47,7 @@ __device__ __forceinline__ double wave_max_dpp(double v) {
 
 // deterministic block-wide sum; all threads get the result. sred: >= 16 doubles of LDS.
 // wavefront shuffle reduction, then a fixed-order sum over the per-wave partials (2 barriers).
-__device__ double block_sum(double v, double *sred) {
+__device__ __forceinline__ double block_sum(double v, double *sred) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = (blockDim.x + 63) >> 6;
     v = wave_sum_dpp(v);
     __syncthreads();
@@ -57,7 +57,7 @@ __device__ double block_sum(double v, double *sred) {
     for (int k = 0; k < nw; k++) r += sred[k];
     return r;
 }
-__device__ double block_max(double v, double *sred) {
+__device__ __forceinline__ double block_max(double v, double *sred) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = (blockDim.x + 63) >> 6;
     v = wave_max_dpp(v);
     __syncthreads();
@@ -212,7 +212,7 @@ __device__ __forceinline__ double wave_sum(double v) {
     return wave_sum_dpp(v);
 }
 #define WAVE_SYNC() do { __builtin_amdgcn_wave_barrier(); __threadfence_block(); } while (0)
-__device__ void sym_eig_tridiag(double *__restrict__ V, int n, int ld, double *__restrict__ d, double *__restrict__ e, double *__restrict__ gtmp, double *sred) {
+__device__ __forceinline__ void sym_eig_tridiag(double *__restrict__ V, int n, int ld, double *__restrict__ d, double *__restrict__ e, double *__restrict__ gtmp, double *sred) {
     (void)sred;
     if (threadIdx.x < 64) {
         const int t = threadIdx.x, nt = 64;
@@ -303,7 +303,7 @@ __device__ void sym_eig_tridiag(double *__restrict__ V, int n, int ld, double *_
 // the O(i) reductions are computed redundantly by every wavefront (no writes, no barrier), the two O(i^2) pieces of each step --
 // the symmetric matrix-vector product and the rank-2 update -- are split over all threads.  part: LDS [nw * EIG_LD].
 #define EIG_LD (6 * VIO_MAXW + 16)
-__device__ void sym_eig_tridiag_mt(double *V, int n, int ld, double *d, double *e, double *gtmp, double *part) {
+__device__ __forceinline__ void sym_eig_tridiag_mt(double *V, int n, int ld, double *d, double *e, double *gtmp, double *part) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
     for (int j = t; j < n; j += nt) d[j] = V[(n - 1) * ld + j];
     __syncthreads();
@@ -409,7 +409,7 @@ __device__ void sym_eig_tridiag_mt(double *V, int n, int ld, double *d, double *
 }
 
 // implicit QL on the tridiagonal (d, e) with eigenvector accumulation into V; one wavefront, lanes own rows k, k+64, ...
-__device__ void tridiag_ql_wave(double *V, int n, int ld, double *d, double *e) {
+__device__ __forceinline__ void tridiag_ql_wave(double *V, int n, int ld, double *d, double *e) {
     const int lane = threadIdx.x & 63;
     if (threadIdx.x < 64) {
         for (int i = 1 + lane; i < n; i += 64) { double v = e[i]; __builtin_amdgcn_wave_barrier(); e[i - 1] = v; }
@@ -553,7 +553,7 @@ __device__ __forceinline__ void tri_decode(int idx, int &ti, int &tj) {
 // S = S_p H S_p + mu*diag(dgp^2) - sum_k inv[k] (S_p Hpl[k][:])^T (S_p Hpl[k][:])   (lower tiles only), v_mfma_f64_16x16x4_f64.
 // Hs / Ws: the UNSCALED H and landmark coupling rows (ld); the Jacobi column scaling sp is applied while loading the MFMA
 // operands. Kpad rows (multiple of 4, rows >= Fa are zero), inv[k] = sl[k]^2 / hllr[k].
-__device__ void schur_mfma(const double *Hs, const double *Ws, const double *inv, const double *dgp, const double *sp, double mu,
+__device__ __forceinline__ void schur_mfma(const double *Hs, const double *Ws, const double *inv, const double *dgp, const double *sp, double mu,
                            int Kpad, int n /*multiple of 16*/, int ld, double *Sc) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int nb = n >> 4, ntile = nb * (nb + 1) / 2;
@@ -586,7 +586,7 @@ __device__ void schur_mfma(const double *Hs, const double *Ws, const double *inv
 // tile_base + r*16 + (c ^ r): the XOR swizzle makes both row-wise and column-wise 64-bit accesses bank-conflict free.
 __device__ __forceinline__ int tl_idx(int ti, int tj, int r, int c) { return ((ti * (ti + 1) / 2 + tj) << 8) + (r << 4) + (c ^ r); }
 
-__device__ void schur_mfma_lds(const double *Hs, const double *Ws, const double *inv, const double *dgp, const double *sp, double mu,
+__device__ __forceinline__ void schur_mfma_lds(const double *Hs, const double *Ws, const double *inv, const double *dgp, const double *sp, double mu,
                                int Kpad, int n, int ld, double *T) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     const int nb = n >> 4, ntile = nb * (nb + 1) / 2;
@@ -620,7 +620,7 @@ __device__ void schur_mfma_lds(const double *Hs, const double *Ws, const double 
 // tile re-reading its two column panels) to Kpad * n doubles.
 #define SCH_CH 16
 template <int MAXT>
-__device__ void schur_mfma_staged(const double *Hs, const double *Ws, const double *inv, const double *dgp, const double *sp, double mu,
+__device__ __forceinline__ void schur_mfma_staged(const double *Hs, const double *Ws, const double *inv, const double *dgp, const double *sp, double mu,
                                   int Kpad, int n, int ld, double *T) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
     const int nb = n >> 4, ntile = nb * (nb + 1) / 2;
@@ -692,7 +692,7 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane) {
 
 // Look-ahead: while the other wavefronts run the trailing update of step p, wavefront 0 updates tile (p+1, p+1) first and factors
 // it straight away, so the serial 16-step diagonal factorisation is off the critical path.  dinv[16 nb] receives 1 / l_jj.
-__device__ bool chol_tiles(double *T, int nb, int *sh_flag, double *dinv) {
+__device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, double *dinv) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
     const int li = lane & 15, lk = lane >> 4;
     // 16x16 diagonal block: lanes 0..15 of wavefront 0 hold one row each in registers, shuffles broadcast pivots
@@ -783,7 +783,7 @@ __device__ bool chol_tiles(double *T, int nb, int *sh_flag, double *dinv) {
     return *sh_flag != 0;
 }
 
-__device__ void chol_solve_tiles(const double *T, int nb, double *xs, const double *dinv) {
+__device__ __forceinline__ void chol_solve_tiles(const double *T, int nb, double *xs, const double *dinv) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6;
     for (int p = 0; p < nb; p++) {  // forward: L y = b
         if (wave == 0) {
@@ -831,7 +831,7 @@ __device__ void chol_solve_tiles(const double *T, int nb, double *xs, const doub
 
 // Blocked (16) right-looking Cholesky of the lower triangle of A (n x n, n multiple of 16): diagonal block by one
 // wavefront in LDS, panel solve one row per thread, trailing update L21 L21^T on the FP64 matrix cores.
-__device__ bool chol_blocked(double *A, int n, int ld, int *sh_flag, double *Lpp) {
+__device__ __forceinline__ bool chol_blocked(double *A, int n, int ld, int *sh_flag, double *Lpp) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
     const int nb = n >> 4;
     if (t == 0) *sh_flag = 1;
@@ -894,7 +894,7 @@ __device__ bool chol_blocked(double *A, int n, int ld, int *sh_flag, double *Lpp
     return true;
 }
 // Solve L L^T x = b in place (xs in LDS), block-wise: 16x16 triangular solves by one wavefront, updates by all threads.
-__device__ void chol_solve_blocked(const double *L, int n, int ld, double *xs, double *Lpp) {
+__device__ __forceinline__ void chol_solve_blocked(const double *L, int n, int ld, double *xs, double *Lpp) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6;
     const int nb = n >> 4;
     for (int p = 0; p < nb; p++) {  // forward: L y = b
@@ -950,7 +950,7 @@ __device__ void chol_solve_blocked(const double *L, int n, int ld, double *xs, d
 
 // out[a] = sum_b M[b][a] * v[b] for a < n (M symmetric or "column sum" of a row-major matrix with nrows rows), split over
 // blockDim/256 row groups and combined through LDS part[(blockDim/256)*VIO_LWMAX]
-__device__ void colsum(const double *M, int ld, int nrows, const double *v, int n, double *out, double *part) {
+__device__ __forceinline__ void colsum(const double *M, int ld, int nrows, const double *v, int n, double *out, double *part) {
     const int t = threadIdx.x, nt = blockDim.x;
     const int groups = nt >> 8, g = t >> 8, a0 = t & 255;
     for (int a = a0; a < n; a += 256) {
@@ -967,7 +967,7 @@ __device__ void colsum(const double *M, int ld, int nrows, const double *v, int 
     __syncthreads();
 }
 // out[k] = sum_a M[k][a] * v[a], one wavefront per row
-__device__ void rowdot(const double *M, int ld, int nrows, const double *v, int n, double *out) {
+__device__ __forceinline__ void rowdot(const double *M, int ld, int nrows, const double *v, int n, double *out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
     for (int k = wave; k < nrows; k += nw) {
         double s = 0;
@@ -984,7 +984,7 @@ __device__ void rowdot(const double *M, int ld, int nrows, const double *v, int 
 // One wavefront per row (lanes own columns lane, lane + 64, ...): row dots through shuffles, column sums in registers and
 // combined over the wavefronts through LDS part[nw * VIO_LWMAX].  Ends with a block barrier.
 template <int NC>
-__device__ void matvec_pass_t(const double *M, int ld, int nrows, int n, const double *u, const double *v, double *out_col, double *out_row,
+__device__ __forceinline__ void matvec_pass_t(const double *M, int ld, int nrows, int n, const double *u, const double *v, double *out_col, double *out_row,
                               double *part) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
     double cs[NC], vv[NC];
@@ -1021,7 +1021,7 @@ __device__ void matvec_pass_t(const double *M, int ld, int nrows, int n, const d
     }
     __syncthreads();
 }
-__device__ void matvec_pass(const double *M, int ld, int nrows, int n, const double *u, const double *v, double *out_col, double *out_row,
+__device__ __forceinline__ void matvec_pass(const double *M, int ld, int nrows, int n, const double *u, const double *v, double *out_col, double *out_row,
                             double *part) {
     if (n <= 192) matvec_pass_t<3>(M, ld, nrows, n, u, v, out_col, out_row, part);
     else matvec_pass_t<6>(M, ld, nrows, n, u, v, out_col, out_row, part);
