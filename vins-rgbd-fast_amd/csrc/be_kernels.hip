@@ -783,29 +783,43 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
         }
     }
     PH(36);
-    // landmark coupling rows (dense, zero padded above), Hll, gl: one thread per variable landmark walks its residuals
-    for (int ka = t; ka < Fa; ka += nt) {
-        int slot = alist[ka];
-        int st = c.lm_start[slot], no = c.lm_nobs[slot], r0 = c.lm_tmp[slot];
+    // landmark coupling rows (dense, zero padded above), Hll, gl: two threads per variable landmark walk its residuals; the even one
+    // owns the pose columns (start frame + observing frames), the odd one the extrinsic / td columns, Hll and gl
+    for (int w = t; w < 2 * Fa; w += nt) {
+        const int ka = w >> 1, half = w & 1;
+        const int slot = alist[ka];
+        const int st = c.lm_start[slot], no = c.lm_nobs[slot], r0 = c.lm_tmp[slot];
         double *row = c.Hpl + (size_t)ka * LW;
-        double si[6] = {0, 0, 0, 0, 0, 0}, se[7] = {0, 0, 0, 0, 0, 0, 0}, hll = 0, gg = 0;
-        for (int k = 1; k < no; k++) {
-            if (r0 + k - 1 >= nres) break;
-            const double *Jr = c.res + (size_t)(r0 + k - 1) * 42;
-            double l0 = Jr[19], l1 = Jr[39];
-            for (int d = 0; d < 6; d++) {
-                si[d] += Jr[d] * l0 + Jr[20 + d] * l1;
-                row[6 * (st + k) + d] = Jr[6 + d] * l0 + Jr[26 + d] * l1;
-                se[d] += Jr[12 + d] * l0 + Jr[32 + d] * l1;
+        if (half == 0) {
+            double si[6] = {0, 0, 0, 0, 0, 0};
+            for (int k = 1; k < no; k++) {
+                if (r0 + k - 1 >= nres) break;
+                const double *Jr = c.res + (size_t)(r0 + k - 1) * 42;
+                const double l0 = Jr[19], l1 = Jr[39];
+#pragma unroll
+                for (int d = 0; d < 6; d++) {
+                    si[d] += Jr[d] * l0 + Jr[20 + d] * l1;
+                    row[6 * (st + k) + d] = Jr[6 + d] * l0 + Jr[26 + d] * l1;
+                }
             }
-            se[6] += Jr[18] * l0 + Jr[38] * l1;
-            hll += l0 * l0 + l1 * l1;
-            gg += l0 * Jr[40] + l1 * Jr[41];
+#pragma unroll
+            for (int d = 0; d < 6; d++) row[6 * st + d] = si[d];
+        } else {
+            double se[7] = {0, 0, 0, 0, 0, 0, 0}, hll = 0, gg = 0;
+            for (int k = 1; k < no; k++) {
+                if (r0 + k - 1 >= nres) break;
+                const double *Jr = c.res + (size_t)(r0 + k - 1) * 42;
+                const double l0 = Jr[19], l1 = Jr[39];
+#pragma unroll
+                for (int d = 0; d < 7; d++) se[d] += Jr[12 + d] * l0 + Jr[32 + d] * l1;
+                hll += l0 * l0 + l1 * l1;
+                gg += l0 * Jr[40] + l1 * Jr[41];
+            }
+#pragma unroll
+            for (int d = 0; d < 7; d++) row[15 * W1 + d] = se[d];
+            c.Hll[ka] = hll;
+            c.gl[ka] = gg;
         }
-        for (int d = 0; d < 6; d++) { row[6 * st + d] = si[d]; row[15 * W1 + d] = se[d]; }
-        row[15 * W1 + 6] = se[6];
-        c.Hll[ka] = hll;
-        c.gl[ka] = gg;
     }
     __syncthreads();
     PH(37);
