@@ -483,3 +483,18 @@ def test_circle_halfwidths(orc):
         for dy in range(rad + 1):
             assert abs(hw[dy] - np.sqrt(rad * rad - dy * dy)) <= 1.0 + 1e-9
         assert (np.diff(hw) <= 0).all()
+
+
+# ------------------------------------------------------------------ end to end on the CPU
+def test_end_to_end_accuracy_against_ground_truth(P):
+    """Whole pipeline on a synthetic sequence with a perfect IMU: the estimate must follow the ground truth to the level the vision
+    noise allows (pixel / millimetre quantisation, LK stops at 0.01 px, 8 solver iterations) and beat the run with IMU noise."""
+    cfg = P.canonical_config()
+    ates = []
+    for kw in (dict(acc_noise=0.0, gyr_noise=0.0, acc_bias_walk=0.0, gyr_bias_walk=0.0), dict()):
+        sc = vio_ct.synth_like(cfg, **kw)
+        o = vio_ct.run_oracle_sequence(cfg, sc, 3, 45)
+        Pw, gt = np.array([x[1] for x in o["traj"]]), np.array(o["gt"])
+        assert len(Pw) >= 30 and all(int(s["reboot_count"]) == 0 for s in o["status"])
+        ates.append(vio_ct.ate_rmse(Pw, gt))
+    assert ates[0] < 0.006 and ates[0] < ates[1] < 0.02, ates
