@@ -69,6 +69,31 @@ def aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K):
     return dict(sequences_per_gpu=S, frames_per_s=S * K / el, ms_per_step=el / K * 1e3, valid=bool(ok))
 
 
+def _cpu_worker(job):
+    """One oracle process (spawned, no GPU): replays `n_frames` of sequence `seq` rendered on the host (identical pixels to the device
+    renderer) and returns (steady-state seconds inside Pipeline::feed, frames)."""
+    seq, n_frames = job
+    import vio_ct
+    P = vio_ct.pkg()
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    syn = P.Synth(sc)
+    o = vio_ct.OraclePipeline(cfg)
+    nimu = int(n_frames / sc.cam_rate * sc.imu_rate) + 64
+    o.push_imu(*syn.imu(seq, nimu))
+    tcpu, nfr = 0.0, 0
+    for f, tf in enumerate(vio_ct.frame_times(sc, n_frames)):
+        g, d = syn.render_host(seq, float(tf))
+        steady = o.status()["solver_flag"] == 1
+        c0 = time.perf_counter()
+        r = o.feed(g, d, float(tf))
+        c1 = time.perf_counter()
+        if steady and r == 1:
+            tcpu += c1 - c0
+            nfr += 1
+    return tcpu, nfr
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,6 +101,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--seqs", type=int, default=128, help="sequences per GPU")
     ap.add_argument("--cpu-seqs", type=int, default=8, help="sequences replayed through the CPU oracle on rank 0 (0 = skip)")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="also time the oracle as one sequence per core on this many processes "
+                    "(0 = skip; reported as cpu_baseline_multicore, the headline cpu_baseline stays the 1-core figure)")
     ap.add_argument("--aux", action="store_true", help="also measure S=256 sequences per GPU (reported as aux_s256, never as value)")
     ap.add_argument("--pcie-steps", type=int, default=6, help="extra steps fed from HOST buffers after the timed region (0 = skip)")
     ap.add_argument("--stream-steps", type=int, default=10, help="extra steps with the IMU pushed frame by frame (vio_push_imu per sequence per frame)")
@@ -316,6 +343,13 @@ def main():
         "pcie_inclusive": pcie,
         "imu_streaming": stream,
     }
+    if rank == 0 and args.cpu_procs > 1:
+        import multiprocessing as mp
+        nproc = min(args.cpu_procs, os.cpu_count() or 1)
+        with mp.get_context("spawn").Pool(nproc) as pool:
+            res = pool.map(_cpu_worker, [(seq0 + 1000 + i, 46) for i in range(nproc)])
+        out["cpu_baseline_multicore"] = dict(value=float(sum(n / t for t, n in res if t > 0)), unit="frames/s", cores=nproc, kind="port",
+                                             sample="%d oracle processes, one sequence each, 46 frames; sum of the per-process steady-state rates" % nproc)
     if args.aux and rank == 0:
         out["aux_s256"] = aux_rate(P, vio_ct, torch, cfg, sc, dev, 256, n_pre, Wm, K)
     if rank == 0:
