@@ -11,6 +11,8 @@
 #include "oracle.h"
 #include <cfloat>
 #include <numeric>
+#include <cstdio>
+#include <cstdlib>
 
 namespace ovio {
 using namespace om;
@@ -1114,6 +1116,15 @@ void marg_finish(Estimator &e, Mat &A, std::vector<double> &b, int m, int n) {
     }
     Mat As(n, n);
     for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) As(i, j) = 0.5 * (Ar(i, j) + Ar(j, i));
+    if (const char *dump = std::getenv("OVIO_DUMP_PRIOR")) {  // test hook: append n, A_s (n x n), b_r (n) as raw doubles
+        if (FILE *fp = std::fopen(dump, "ab")) {
+            double nn = n;
+            std::fwrite(&nn, 8, 1, fp);
+            std::fwrite(As.d.data(), 8, (size_t)n * n, fp);
+            std::fwrite(br.data(), 8, n, fp);
+            std::fclose(fp);
+        }
+    }
     std::vector<double> w2;
     Mat V2;
     sym_eig(As, w2, V2);

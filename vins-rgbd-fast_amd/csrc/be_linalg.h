@@ -829,6 +829,32 @@ __device__ __forceinline__ void chol_solve_tiles(const double *T, int nb, double
     }
 }
 
+// forward substitution only: xs <- L^-1 xs (used for the constant |L^-1 b|^2 = b^T A^-1 b of the prior)
+__device__ __forceinline__ void chol_forward_tiles(const double *T, int nb, double *xs, const double *dinv) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6;
+    for (int p = 0; p < nb; p++) {
+        if (wave == 0) {
+            const int row = lane & 15;
+            double b = xs[16 * p + row];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                double xj = bcast_lane(b, j) * dinv[16 * p + j];
+                if (row == j) b = xj; else if (row > j) b -= T[tl_idx(p, p, row, j)] * xj;
+            }
+            if (lane < 16) xs[16 * p + row] = b;
+        }
+        __syncthreads();
+        for (int q = t; q < 16 * (nb - 1 - p); q += nt) {
+            int ti = p + 1 + (q >> 4), r = q & 15;
+            double sacc = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) sacc += T[tl_idx(ti, p, r, k)] * xs[16 * p + k];
+            xs[16 * ti + r] -= sacc;
+        }
+        __syncthreads();
+    }
+}
+
 // Blocked (16) right-looking Cholesky of the lower triangle of A (n x n, n multiple of 16): diagonal block by one
 // wavefront in LDS, panel solve one row per thread, trailing update L21 L21^T on the FP64 matrix cores.
 __device__ __forceinline__ bool chol_blocked(double *A, int n, int ld, int *sh_flag, double *Lpp) {

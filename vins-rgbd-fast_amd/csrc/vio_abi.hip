@@ -73,7 +73,7 @@ struct vio_batch {
     int imu_stage_cur = 0;
     hipEvent_t ev_imu = nullptr;
     std::vector<double> last_imu_t;
-    size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0, lds_marg = 0;
+    size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0, lds_marg = 0, lds_factor = 0;
     bool timing_valid = false;
     // per-kernel event pool (vio_profile_begin / vio_profile_end)
     std::vector<hipEvent_t> pev;
@@ -431,7 +431,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     DA(B.lm_dyn, S * NL); DA(B.lm_order, S * NL); DA(B.lm_free, S * NL); DA(B.lm_tmp, S * NL); DA(B.lm_pidx, S * NL); DA(B.lm_aidx, S * NL);
     DA(B.lm_depth, S * NL); DA(B.lm_obs, S * NL * W1 * VIO_OBS_D); DA(B.para_feat, S * NL); DA(B.cand_feat, S * NL);
     const size_t n = C.NPRIOR, LW = C.LW, nres = C.NRES, npair = W1 * W1, mq = 15 + n;
-    DA(B.prior_J, S * n * n); DA(B.prior_r, S * n); DA(B.prior_x0, S * (C.W * 7 + 17)); DA(B.prior_H, S * n * n);
+    DA(B.prior_J, S * n * n); DA(B.prior_r, S * n); DA(B.prior_x0, S * (C.W * 7 + 17)); DA(B.prior_H, S * n * n); DA(B.prior_rf, S * n);
     DA(B.H, S * LW * LW); DA(B.Sc, S * LW * LW); DA(B.Hpl, S * (NL + 8) * LW); DA(B.vec, S * VEC_SLOTS * LW);
     DA(B.Hll, S * (NL + 8)); DA(B.gl, S * (NL + 8)); DA(B.lvec, S * (NL + 8) * 8);
     DA(B.res, S * nres * 42); DA(B.res_lm, S * nres); DA(B.res_k, S * nres); DA(B.res_pair, S);
@@ -492,7 +492,12 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
             (void)raise_lds_limit((const void *)be_solve_kernel, (size_t)(h->lds_solve));
             (void)raise_lds_limit((const void *)be_solve_kernel_512, (size_t)(h->lds_solve));
         }
-        h->lds_marg = C.NPRIOR <= 96 ? (size_t)C.NPRIOR * (C.NPRIOR | 1) * 8 + 64 : 64;
+        {
+            size_t nbq = ((size_t)C.NPRIOR + 15) >> 4;
+            h->lds_marg = nbq * (nbq + 1) / 2 * 2048 + 64;  // lower 16x16 tiles of the new prior (Cholesky for its constant term)
+            h->lds_factor = C.NPRIOR <= 96 ? (size_t)C.NPRIOR * (C.NPRIOR | 1) * 8 + 64 : 64;  // on-demand eigen-decomposition (vio_get_prior)
+            (void)raise_lds_limit((const void *)be_prior_factor_kernel, h->lds_factor);
+        }
         (void)raise_lds_limit((const void *)be_marg_kernel, (size_t)(h->lds_marg));
         (void)raise_lds_limit((const void *)be_ingest_kernel, (size_t)(C.lm_hash_size * 8));
 
@@ -759,8 +764,15 @@ int vio_get_prior(vio_batch *h, int seq, double *J, double *r, double *x0, uint8
     HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
     if (!be.has_prior) return 0;
     int n = h->hc.NPRIOR, W = h->hc.W;
+    if (J || r) {
+        // the hot path keeps the prior as a quadratic form (DESIGN.md deviation 13); the factored form the reference stores
+        // (linearized_jacobians / linearized_residuals) is produced here, on the GPU, only when somebody asks for it
+        be_prior_factor_kernel<<<1, 512, h->lds_factor, h->stream>>>(h->B, seq);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     if (J) HIPCHK(hipMemcpy(J, h->B.prior_J + (size_t)seq * n * n, sizeof(double) * n * n, hipMemcpyDeviceToHost));
-    if (r) HIPCHK(hipMemcpy(r, h->B.prior_r + (size_t)seq * n, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (r) HIPCHK(hipMemcpy(r, h->B.prior_rf + (size_t)seq * n, sizeof(double) * n, hipMemcpyDeviceToHost));
     if (x0) HIPCHK(hipMemcpy(x0, h->B.prior_x0 + (size_t)seq * (W * 7 + 17), sizeof(double) * (W * 7 + 17), hipMemcpyDeviceToHost));
     if (present) for (int k = 0; k < W + 3; k++) present[k] = (uint8_t)be.prior_present[k];
     return n;

@@ -93,6 +93,7 @@ struct BeSeq {
     int do_solve, do_marg;          // decisions of the ingest stage for the later kernels
     int n_imu_frame;                // samples consumed for the current frame
     int overflow;                   // capacity overflow flags (landmarks / imu slot)
+    double prior_c0;                // |r|^2 of the prior at its linearisation point (constant cost offset)
     int dbg[16];                    // debug counters (sweeps, ticks)
 };
 
@@ -126,7 +127,9 @@ struct Batch {
     double *para_feat;    // [S][NL] inverse depths (para_Feature)
     double *cand_feat;    // [S][NL]
     // ---- prior (canonical layout) per sequence
-    double *prior_J, *prior_r, *prior_x0, *prior_H;  // n*n, n, W*7+17, n*n (J^T J)
+    // prior as a quadratic form: prior_H = A (n*n), prior_r = b (n), prior_x0 (W*7+17); prior_J / prior_rf receive the factored
+    // form (linearized_jacobians / linearized_residuals) only when vio_get_prior asks for it
+    double *prior_J, *prior_r, *prior_x0, *prior_H, *prior_rf;
     // ---- solver scratch per sequence
     double *H, *Sc, *Hpl;     // P*P, P*P, NL*LW
     double *vec;              // [S][VEC_SLOTS][LW]
