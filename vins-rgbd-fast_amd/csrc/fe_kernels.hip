@@ -18,13 +18,28 @@ __device__ __forceinline__ int cv_round(float v) { return __float2int_rn(v); }
 __device__ __forceinline__ int cv_floor(float v) { return (int)floorf(v); }
 __device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-    for (int off = 32; off > 0; off >>= 1) {
-        int lo = __shfl_xor((int)(v & 0xffffffffLL), off, 64);
-        int hi = __shfl_xor((int)(v >> 32), off, 64);
-        v += ((long long)hi << 32) | (unsigned int)lo;
+// 64-bit integer wavefront sum on DPP moves + v_readlane (exact, so the order does not matter): four DPP steps leave the sum of
+// each 16-lane row in all its lanes, the four row sums are combined through SGPRs.  Replaces 12 ds_bpermute round trips.
+__device__ __forceinline__ long long dpp_i64(long long v, const int ctrl_tag) {
+    int lo = (int)(v & 0xffffffffLL), hi = (int)(v >> 32);
+    switch (ctrl_tag) {
+    case 0: lo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); break;
+    case 1: lo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); break;
+    case 2: lo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); break;
+    default: lo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true); hi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true); break;
     }
-    return v;
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ long long readlane_i64(long long v, int src_lane) {
+    int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffLL), src_lane), hi = __builtin_amdgcn_readlane((int)(v >> 32), src_lane);
+    return ((long long)hi << 32) | (unsigned int)lo;
+}
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+    v += dpp_i64(v, 0);
+    v += dpp_i64(v, 1);
+    v += dpp_i64(v, 2);
+    v += dpp_i64(v, 3);
+    return (readlane_i64(v, 0) + readlane_i64(v, 16)) + (readlane_i64(v, 32) + readlane_i64(v, 48));
 }
 
 // camera (camera_model/src/camera_models/PinholeCamera.cc:449-542,645-662)
@@ -215,8 +230,13 @@ __global__ void fe_predict_kernel(Batch B) {
 // ------------------------------------------------------------------------------------------------ fe_lk
 // One wavefront (64 lanes) per feature; each lane owns 7 of the 441 window pixels.
 
+#define LK_MARGIN 5
+#define LK_REG (22 + 2 * LK_MARGIN)
+// BORDER_REFLECT_101 index, clamped: region pixels further than one reflection outside the image are never part of a window that
+// passes the bounds test, the clamp only keeps their address legal
+__device__ __forceinline__ int reflect101c(int i, int n) { return min(max(reflect101(i, n), 0), n - 1); }
 __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, float2 &nextPtIO, uint8_t &statusOut,
-                             uint8_t *win /*24*24*/, short2 *der /*22*22*/, uint8_t *jw /*22*22*/) {
+                             uint8_t *win /*24*24*/, short2 *der /*22*22*/, uint8_t *jw /*LK_REG^2*/) {
     const int WIN = VIO_WIN;
     const int W_BITS = 14;
     const float FLT_SCALE = 1.f / (1 << 20);
@@ -292,6 +312,8 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
         D = 1.f / D;
         nextPt.x -= halfWin; nextPt.y -= halfWin;
         float2 prevDelta = make_float2(0.f, 0.f);
+        bool reg_ok = false;
+        int rx0 = 0, ry0 = 0;
         for (int j = 0; j < 30; j++) {
             int inx = cv_floor(nextPt.x), iny = cv_floor(nextPt.y);
             if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) {
@@ -303,20 +325,27 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
             iw01 = cv_round(a * (1.f - b) * (1 << W_BITS));
             iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-            __syncthreads();
-            for (int q = lane; q < 22 * 22; q += 64) {
-                int wy = q / 22, wx = q - wy * 22;
-                jw[q] = J[(size_t)reflect101(iny + wy, h) * w + reflect101(inx + wx, w)];
+            // the 22x22 window of J comes out of a (22 + 2 LK_MARGIN)^2 region cached in LDS around the first position of this level;
+            // it is re-centred (one more pass over global memory) only when the iteration walks out of it
+            if (!(reg_ok && inx >= rx0 && iny >= ry0 && inx <= rx0 + 2 * LK_MARGIN && iny <= ry0 + 2 * LK_MARGIN)) {
+                rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
+                __syncthreads();
+                for (int q = lane; q < LK_REG * LK_REG; q += 64) {
+                    int wy = q / LK_REG, wx = q - wy * LK_REG;
+                    jw[q] = J[(size_t)reflect101c(ry0 + wy, h) * w + reflect101c(rx0 + wx, w)];
+                }
+                __syncthreads();
+                reg_ok = true;
             }
-            __syncthreads();
+            const uint8_t *jbase = jw + (iny - ry0) * LK_REG + (inx - rx0);
             long long sb1 = 0, sb2 = 0;
 #pragma unroll
             for (int k = 0; k < 7; k++) {
                 int p = lane + 64 * k;
                 if (p < WIN * WIN) {
                     int y = p / WIN, x = p - y * WIN;
-                    const uint8_t *r = jw + y * 22 + x;
-                    int diff = descale(r[0] * iw00 + r[1] * iw01 + r[22] * iw10 + r[23] * iw11, W_BITS - 5) - Iv[k];
+                    const uint8_t *r = jbase + y * LK_REG + x;
+                    int diff = descale(r[0] * iw00 + r[1] * iw01 + r[LK_REG] * iw10 + r[LK_REG + 1] * iw11, W_BITS - 5) - Iv[k];
                     sb1 += (long long)diff * Ixv[k];
                     sb2 += (long long)diff * Iyv[k];
                 }
@@ -342,12 +371,12 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
 // grid (NP, S), 64 threads
 __global__ __launch_bounds__(64) void fe_lk_kernel(Batch B) {
     const DevCfg &C = *B.cfg;
-    int s = blockIdx.y + B.s0, i = blockIdx.x;
+    int s = blockIdx.y + B.s0;
     FeSeq &fe = B.fe[s];
-    if (fe.n_forw < 0 || i >= fe.n_pts) return;
+    if (fe.n_forw < 0 || (int)blockIdx.x >= fe.n_pts) return;
     __shared__ uint8_t win[24 * 24];
     __shared__ short2 der[22 * 22];
-    __shared__ uint8_t jw[22 * 22];
+    __shared__ uint8_t jw[LK_REG * LK_REG];
     int cur = fe.cur_buf, forw = fe.has_img ? (cur ^ 1) : cur;
     LkImages im;
     size_t hw = (size_t)C.c.width * C.c.height;
@@ -359,12 +388,16 @@ __global__ __launch_bounds__(64) void fe_lk_kernel(Batch B) {
         im.next[l] = B.pyr + ((size_t)s * 2 + forw) * C.pyr_bytes + C.lvl_off[l];
         im.w[l] = C.lvl_w[l]; im.h[l] = C.lvl_h[l];
     }
-    float2 np = B.forw_pts[(size_t)s * C.NP + i];
-    uint8_t st;
-    lk_one_point(im, C.c.lk_max_level, B.cur_pts[(size_t)s * C.NP + i], np, st, win, der, jw);
-    if (threadIdx.x == 0) {
-        B.forw_pts[(size_t)s * C.NP + i] = np;
-        B.lk_status[(size_t)s * C.NP + i] = st;
+    // grid.x is capped (most of the NP track slots are empty): a block walks its features with stride gridDim.x
+    for (int i = blockIdx.x; i < fe.n_pts; i += gridDim.x) {
+        float2 np = B.forw_pts[(size_t)s * C.NP + i];
+        uint8_t st;
+        lk_one_point(im, C.c.lk_max_level, B.cur_pts[(size_t)s * C.NP + i], np, st, win, der, jw);
+        if (threadIdx.x == 0) {
+            B.forw_pts[(size_t)s * C.NP + i] = np;
+            B.lk_status[(size_t)s * C.NP + i] = st;
+        }
+        __syncthreads();
     }
 }
 
@@ -375,7 +408,7 @@ __global__ __launch_bounds__(64) void fe_lk_stage_kernel(LkImages im, int maxLev
     if (i >= n) return;
     __shared__ uint8_t win[24 * 24];
     __shared__ short2 der[22 * 22];
-    __shared__ uint8_t jw[22 * 22];
+    __shared__ uint8_t jw[LK_REG * LK_REG];
     float2 np = nextPts[i];
     uint8_t st;
     lk_one_point(im, maxLevel, prevPts[i], np, st, win, der, jw);
@@ -950,25 +983,54 @@ __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int publish, int g
             }
             // top-k by response, replace-min scan (:127-167); survivors stay in slot order
             int K = C.grids_threshold - fe.grids_track_num[cell] + 2;
-            if (t == 0) {
-                if (nf <= K) {
-                    for (int k = 0; k < nf; k++) keep[k] = filt[k];
-                    sh_nkeep = nf;
+            // One wavefront replays the scan: lane k owns slot k (K <= 64), the running minimum is a DPP / readlane reduction instead
+            // of a K-long rescan by a single thread.  Same semantics as the sequential loop: first minimal slot, except that a freshly
+            // replaced slot keeps the "minimum" title when it ties with an earlier one (the rescan starts from it and uses <).
+            if (t < 64) {
+                if (nf <= K || K > 64) {
+                    if (K > 64 && nf > K) {  // never the case for the supported configurations (grids_threshold + 2 <= 64): serial fallback
+                        if (t == 0) {
+                            int min_id = 0;
+                            for (int j = 0; j < nf; j++) {
+                                uint32_t v = filt[j];
+                                int resp = (int)(v >> 24);
+                                if (j < K) { keep[j] = v; if (resp < (int)(keep[min_id] >> 24)) min_id = j; }
+                                else if (resp > (int)(keep[min_id] >> 24)) {
+                                    keep[min_id] = v;
+                                    for (int k = 0; k < K; k++) if ((int)(keep[k] >> 24) < (int)(keep[min_id] >> 24)) min_id = k;
+                                }
+                            }
+                            sh_nkeep = K;
+                        }
+                    } else {
+                        for (int k = t; k < nf; k += 64) keep[k] = filt[k];
+                        if (t == 0) sh_nkeep = nf;
+                    }
                 } else {
-                    int min_id = 0;
-                    for (int j = 0; j < nf; j++) {
+                    const int lane = t;
+                    uint32_t mine = lane < K ? filt[lane] : 0xFFFFFFFFu;
+                    // key = response * 64 + slot: the minimum key is the first slot with the smallest response
+                    auto wave_min_key = [&](uint32_t val) -> int {
+                        int key = lane < K ? ((int)(val >> 24) << 6) | lane : 0x7FFFFFFF;
+                        for (int off = 32; off > 0; off >>= 1) key = min(key, __shfl_xor(key, off, 64));
+                        return key;
+                    };
+                    int mk = wave_min_key(mine);
+                    int min_id = mk & 63, min_resp = mk >> 6;
+                    for (int j = K; j < nf; j++) {
                         uint32_t v = filt[j];
                         int resp = (int)(v >> 24);
-                        if (j < K) {
-                            keep[j] = v;
-                            if (resp < (int)(keep[min_id] >> 24)) min_id = j;
-                        } else if (resp > (int)(keep[min_id] >> 24)) {
-                            keep[min_id] = v;
-                            for (int k = 0; k < K; k++)
-                                if ((int)(keep[k] >> 24) < (int)(keep[min_id] >> 24)) min_id = k;
+                        if (resp > min_resp) {
+                            if (lane == min_id) mine = v;
+                            int nk2 = wave_min_key(mine);
+                            int cand_id = nk2 & 63, cand_resp = nk2 >> 6;
+                            // rescan starts at the replaced slot and only moves on a strictly smaller response
+                            if (resp == cand_resp) cand_id = min_id;
+                            min_id = cand_id; min_resp = cand_resp;
                         }
                     }
-                    sh_nkeep = K;
+                    if (lane < K) keep[lane] = mine;
+                    if (t == 0) sh_nkeep = K;
                 }
             }
             __syncthreads();

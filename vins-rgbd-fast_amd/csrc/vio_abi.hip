@@ -281,7 +281,7 @@ int launch_frontend(vio_batch *h, vio_batch::Group &g, const uint8_t *d_gray, in
     PEV(h, 2);
     fe_predict_kernel<<<dim3((C.NP + 255) / 256, S), 256, 0, st>>>(Bg);
     PEV(h, 3);
-    fe_lk_kernel<<<dim3(C.NP, S), 64, 0, st>>>(Bg);
+    fe_lk_kernel<<<dim3(std::min(C.NP, C.c.max_cnt + C.c.max_cnt / 2 + 32), S), 64, 0, st>>>(Bg);  // ~1.5 x max_cnt blocks per sequence, strided over n_pts
     PEV(h, 4);
     fe_select_kernel<<<S, 256, h->lds_select, st>>>(Bg, publish);
     PEV(h, 5);
