@@ -1102,10 +1102,15 @@ __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int publish, int g
         nobs = block_exclusive_scan(newflag, n, newoff, scratch);
         int *o_id = B.obs_id + (size_t)s * NP;
         double *o = B.obs + (size_t)s * NP * 7;
+        // ids of the published features staged in LDS (the accepted-point list is no longer needed): the rank sort then runs on LDS
+        // instead of n dependent global loads per thread
+        int *ids_l = (int *)acc;
+        for (int i = t; i < n; i += blockDim.x) ids_l[i] = newflag[i] ? g_id[i] : 0x7FFFFFFF;
+        __syncthreads();
         for (int i = t; i < n; i += blockDim.x) {
             if (!newflag[i]) continue;
-            int my = g_id[i], rank = 0;
-            for (int j = 0; j < n; j++) rank += (newflag[j] && g_id[j] < my) ? 1 : 0;
+            int my = ids_l[i], rank = 0;
+            for (int j = 0; j < n; j++) rank += (ids_l[j] < my) ? 1 : 0;
             o_id[rank] = my;
             double *q = o + (size_t)rank * 7;
             q[0] = g_un[i].x; q[1] = g_un[i].y; q[2] = 1.0; q[3] = g_cur[i].x; q[4] = g_cur[i].y; q[5] = g_vel[i].x; q[6] = g_vel[i].y;
