@@ -546,10 +546,15 @@ __device__ int block_exclusive_scan(const int *flags, int n, int *offs, int *scr
     for (int i = b; i < e; i++) sum += flags[i] ? 1 : 0;
     scratch[t] = sum;
     __syncthreads();
-    if (t == 0) {
-        int acc = 0;
-        for (int i = 0; i < nt; i++) { int v = scratch[i]; scratch[i] = acc; acc += v; }
-        scratch[nt] = acc;
+    if (t < 64) {  // exclusive scan of the per-thread partials by one wavefront (nt / 64 partials per lane, shuffle scan across lanes)
+        const int per = (nt + 63) >> 6, base = t * per;
+        int s0 = 0;
+        for (int q = 0; q < per; q++) if (base + q < nt) s0 += scratch[base + q];
+        int inc = s0;
+        for (int off = 1; off < 64; off <<= 1) { int v = __shfl_up(inc, off, 64); if (t >= off) inc += v; }
+        int acc = inc - s0;
+        for (int q = 0; q < per; q++) if (base + q < nt) { int v = scratch[base + q]; scratch[base + q] = acc; acc += v; }
+        if (t == 63) scratch[nt] = inc;
     }
     __syncthreads();
     int o = scratch[t];
@@ -670,6 +675,8 @@ __global__ __launch_bounds__(256) void fe_select_kernel(Batch B, int publish) {
     int *scratch = tmpi + NP;                 // 257
     int2 *acc = (int2 *)(scratch + 260);      // NP + NP (accepted + unstable)
     __shared__ RansacShared R;
+    __shared__ int hw_s[64];  // cv::circle half-widths out of the global config
+    for (int k = t; k < 64; k += blockDim.x) hw_s[k] = k <= c.min_dist ? C.circle_hw[k] : 0;
     __shared__ int sh_n, sh_nacc, sh_nun;
     __shared__ int gcount[VIO_MAX_CELLS];
 
@@ -754,7 +761,7 @@ __global__ __launch_bounds__(256) void fe_select_kernel(Batch B, int publish) {
                 int i = perm[q];
                 int px = cv_round(forw[i].x), py = cv_round(forw[i].y);
                 bool hit = false;
-                for (int k = t; k < nacc; k += 64) hit |= in_disk(C.circle_hw, r, px, py, vacc[k].x, vacc[k].y);
+                for (int k = t; k < nacc; k += 64) hit |= in_disk(hw_s, r, px, py, vacc[k].x, vacc[k].y);
                 bool any = __any(hit);
                 if (!any) {
                     if (t == 0) { vacc[nacc].x = px; vacc[nacc].y = py; tmpi[nacc] = i; }
@@ -939,6 +946,8 @@ __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int publish, int g
     FeSeq &fe = B.fe[s];
     if (fe.n_forw < 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int hw_s[64];                          // cv::circle half-widths (min_dist <= 63) out of the global config
+    for (int k = t; k < 64; k += blockDim.x) hw_s[k] = k <= c.min_dist ? C.circle_hw[k] : 0;
     int2 *acc = (int2 *)smem;                         // 2*NP
     int *flag = (int *)(acc + 2 * NP);                // VIO_FAST_CAP
     int *offs = flag + VIO_FAST_CAP;                  // VIO_FAST_CAP
@@ -969,7 +978,7 @@ __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int publish, int g
                 uint32_t v = cand[k];
                 int px = rc.x + (int)(v & 0xFFF), py = rc.y + (int)((v >> 12) & 0xFFF);
                 bool hit = false;
-                for (int a = 0; a < nacc; a++) hit |= in_disk(C.circle_hw, r, px, py, acc[a].x, acc[a].y);
+                for (int a = 0; a < nacc; a++) hit |= in_disk(hw_s, r, px, py, acc[a].x, acc[a].y);
                 flag[k] = hit ? 0 : 1;
             }
             __syncthreads();
@@ -1042,7 +1051,7 @@ __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int publish, int g
                     uint32_t v = keep[q];
                     int px = rc.x + (int)(v & 0xFFF), py = rc.y + (int)((v >> 12) & 0xFFF);
                     bool hit = false;
-                    for (int k = t; k < na; k += 64) hit |= in_disk(C.circle_hw, r, px, py, vacc[k].x, vacc[k].y);
+                    for (int k = t; k < na; k += 64) hit |= in_disk(hw_s, r, px, py, vacc[k].x, vacc[k].y);
                     bool any = __any(hit);
                     if (!any && nn < NP) {
                         if (t == 0) {
