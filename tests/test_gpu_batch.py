@@ -114,3 +114,20 @@ def test_create_destroy_cycles_do_not_leak(P):
         if k == 1:
             free0 = free.value
     assert free0 is not None and free.value >= free0 - (8 << 20)  # nothing accumulates after the first cycle (8 MB slack)
+
+
+def test_stream_groups_do_not_change_results(P, monkeypatch):
+    """VIO_GROUP_SEQS splits a handle's sequences into groups with their own stream pairs (front-end of one group overlapping the
+    back-end of another).  Scheduling only: every sequence must come out bit-identical to the single-group run, including with IMU
+    pushed between frames (the stream-ordered scatter kernel has to be ordered against every group)."""
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    seqs, n = list(range(50, 58)), 22
+    monkeypatch.delenv("VIO_GROUP_SEQS", raising=False)
+    ref = _drive(P, cfg, sc, seqs, n)
+    ref_w = [ref.window(i).copy() for i in range(len(seqs))]
+    monkeypatch.setenv("VIO_GROUP_SEQS", "3")   # groups of 3, 3, 2 sequences
+    grp = _drive(P, cfg, sc, seqs, n)
+    for i in range(len(seqs)):
+        assert np.array_equal(grp.window(i), ref_w[i]), i
+        assert np.array_equal(grp.landmarks(i), ref.landmarks(i)), i
