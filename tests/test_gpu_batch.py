@@ -131,3 +131,22 @@ def test_stream_groups_do_not_change_results(P, monkeypatch):
     for i in range(len(seqs)):
         assert np.array_equal(grp.window(i), ref_w[i]), i
         assert np.array_equal(grp.landmarks(i), ref.landmarks(i)), i
+
+
+@pytest.mark.parametrize("env", [{"VIO_BE_THREADS": "1024"}, {"VIO_FLAGS": "1"}, {"VIO_MARG_THREADS": "256"}])
+def test_alternative_kernel_configurations_agree(P, monkeypatch, env):
+    """The non-default builds / paths kept behind environment knobs (1024-thread solve kernel, Schur complement and Cholesky in HBM
+    instead of LDS tiles, 256-thread marginalisation) compute the same thing in a different summation order: the trajectory must agree
+    with the default configuration to round-off amplified over 24 frames (1e-6 m)."""
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    for k in ("VIO_BE_THREADS", "VIO_FLAGS", "VIO_MARG_THREADS"):
+        monkeypatch.delenv(k, raising=False)
+    ref = _drive(P, cfg, sc, [60, 61], 24)
+    ref_w = [ref.window(i).copy() for i in range(2)]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    alt = _drive(P, cfg, sc, [60, 61], 24)
+    for i in range(2):
+        assert alt.status(i).solver_flag == 1
+        assert np.abs(alt.window(i)[:, :3] - ref_w[i][:, :3]).max() < 1e-6, (env, i)

@@ -74,6 +74,7 @@ struct vio_batch {
     hipEvent_t ev_imu = nullptr;
     std::vector<double> last_imu_t;
     size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0, lds_marg = 0, lds_factor = 0;
+    int be_threads = 512, marg_threads = 512;  // VIO_BE_THREADS / VIO_MARG_THREADS, read at vio_create
     bool timing_valid = false;
     // per-kernel event pool (vio_profile_begin / vio_profile_end)
     std::vector<hipEvent_t> pev;
@@ -301,13 +302,13 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth) {
     PEV(h, 8);
     be_ingest_kernel<<<S, 256, (size_t)C.lm_hash_size * 8, st>>>(Bg, d_depth, (size_t)C.c.width * C.c.height);
     PEV(h, 9);
-    static int be_threads = getenv("VIO_BE_THREADS") ? atoi(getenv("VIO_BE_THREADS")) : 512;
+    const int be_threads = h->be_threads;
     if (be_threads <= 512) be_solve_kernel_512<<<S, be_threads, h->lds_solve, st>>>(Bg);
     else be_solve_kernel<<<S, be_threads, h->lds_solve, st>>>(Bg);
     PEV(h, 10);
     (void)hipEventRecord(g.ev_solve, st);  // the next frame's front-end may start here (it only needs latest_Bg / td / ric)
     g.have_solve_ev = true;
-    be_marg_kernel<<<S, (getenv("VIO_MARG_THREADS") ? atoi(getenv("VIO_MARG_THREADS")) : 512), h->lds_marg, st>>>(Bg);  // marginalisation + window slide (be_finish is fused into it)
+    be_marg_kernel<<<S, h->marg_threads, h->lds_marg, st>>>(Bg);  // marginalisation + window slide (be_finish is fused into it)
     PEV(h, 11);
     HIPCHK(hipGetLastError());
     return VIO_OK;
@@ -442,6 +443,8 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     DA(B.odom, S * 11); DA(B.timings, 64);
     B.hist_cap = 2048;
     B.s0 = 0;
+    if (getenv("VIO_BE_THREADS")) h->be_threads = std::min(1024, std::max(64, atoi(getenv("VIO_BE_THREADS")) & ~63));
+    if (getenv("VIO_MARG_THREADS")) h->marg_threads = std::min(512, std::max(64, atoi(getenv("VIO_MARG_THREADS")) & ~63));
     B.flags = getenv("VIO_FLAGS") ? atoi(getenv("VIO_FLAGS")) : 0;
     DA(B.odom_hist, S * (size_t)B.hist_cap * 11); DA(B.odom_count, S);
     DA(h->d_stamps, S);
