@@ -607,8 +607,46 @@ __device__ __forceinline__ int local_of(int a, int i, int j, int W) {
     return 12 + e;  // ex 0..5 -> 12..17, td (6) -> 18
 }
 
+#define PB_U 8  // k groups (of 4 Jacobian rows) loaded per batch in the frame-pair block phase of assemble
 // compact index of the frame pair (i < j)
 __device__ __forceinline__ int pair_slot(int i, int j, int W1) { return i * W1 - i * (i + 1) / 2 + (j - i - 1); }
+
+// One half of a landmark's coupling row (see assemble): `res` = the landmark's residual Jacobians (42 doubles each, observation k
+// at res + 42 (k - 1)), `row` = its Hpl row.  The arrays never overlap; the restrict qualifiers let the loads of the next
+// residual be issued ahead of the row stores of the current one (the loop is bound by the latency of those loads).
+__device__ __forceinline__ void lm_row(const double *__restrict__ res, double *__restrict__ row, double *__restrict__ Hll,
+                                       double *__restrict__ gl, int half, int st, int kend, int ext_off) {
+    if (half == 0) {
+        double si[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+        for (int k = 1; k < kend; k++) {
+            const double *Jr = res + (size_t)(k - 1) * 42;
+            const double l0 = Jr[19], l1 = Jr[39];
+#pragma unroll
+            for (int d = 0; d < 6; d++) {
+                si[d] += Jr[d] * l0 + Jr[20 + d] * l1;
+                row[6 * (st + k) + d] = Jr[6 + d] * l0 + Jr[26 + d] * l1;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 6; d++) row[6 * st + d] = si[d];
+    } else {
+        double se[7] = {0, 0, 0, 0, 0, 0, 0}, hll = 0, gg = 0;
+#pragma unroll 2
+        for (int k = 1; k < kend; k++) {
+            const double *Jr = res + (size_t)(k - 1) * 42;
+            const double l0 = Jr[19], l1 = Jr[39];
+#pragma unroll
+            for (int d = 0; d < 7; d++) se[d] += Jr[12 + d] * l0 + Jr[32 + d] * l1;
+            hll += l0 * l0 + l1 * l1;
+            gg += l0 * Jr[40] + l1 * Jr[41];
+        }
+#pragma unroll
+        for (int d = 0; d < 7; d++) row[ext_off + d] = se[d];
+        *Hll = hll;
+        *gl = gg;
+    }
+}
 
 // assemble H (P x P, ld LW), g (vec slot 0), Hpl / Hll / gl from the stored residual Jacobians.
 // work: LDS scratch (>= max(W*450, npairs*210) doubles when it fits, see be_solve); pb = frame-pair blocks (LDS or HBM)
@@ -712,15 +750,16 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
             v4f64 a00 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
             const int K = 2 * np_;
             // residual indices of the pair are fetched 64 at a time (one coalesced load) and broadcast with shuffles; the
-            // k loop is unrolled by 4 with unconditional (clamped) loads so that 8 row loads are in flight per MFMA batch
+            // k loop is unrolled by PB_U with unconditional (clamped) loads so that 2 * PB_U row loads are in flight per MFMA
+            // batch: the phase is bound by the L2 latency of those loads (a typical pair is one or two batches), not by the MFMAs
             for (int base = 0; base < np_; base += 64) {
                 const int nchunk = min(64, np_ - base);
                 const int myidx = c.pair_list[q0 + base + min(lane, nchunk - 1)];
                 const int Kc = 2 * nchunk;
-                for (int k0 = 0; k0 < Kc; k0 += 16) {
-                    double x0[4], x1[4];
+                for (int k0 = 0; k0 < Kc; k0 += 4 * PB_U) {
+                    double x0[PB_U], x1[PB_U];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < PB_U; u++) {
                         int kk = k0 + 4 * u + lk;
                         bool valid = kk < Kc;
                         int ridx = __shfl(myidx, min(kk, Kc - 1) >> 1, 64);
@@ -732,7 +771,8 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
                         x1[u] = (valid && li < 4) ? v1 : 0.0;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < PB_U; u++) {
+                        if (k0 + 4 * u >= Kc) break;  // wavefront-uniform: the remaining k groups of this batch are all padding
                         a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u], x0[u], a00, 0, 0, 0);
                         a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x0[u], a10, 0, 0, 0);
                         a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x1[u], a11, 0, 0, 0);
@@ -765,8 +805,7 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
                 const int f = fa >= 0 ? fa : fb;
                 for (int o = 0; o < W1; o++) {
                     if (o == f) continue;
-                    int i = min(f, o), j = max(f, o), p = i * W1 + j;
-                    if (c.pair_start[p + 1] == c.pair_start[p]) continue;
+                    int i = min(f, o), j = max(f, o);  // empty pairs hold a zero block (written above): no test, no HBM load here
                     int la = local_of(a, i, j, W);
                     int lb = b >= 0 ? local_of(b, i, j, W) : 19;
                     sacc += pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(la, lb)];
@@ -774,8 +813,6 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
             } else {
                 for (int i = 0; i < W1; i++)
                     for (int j = i + 1; j < W1; j++) {
-                        int p = i * W1 + j;
-                        if (c.pair_start[p + 1] == c.pair_start[p]) continue;
                         int la = local_of(a, i, j, W);
                         int lb = b >= 0 ? local_of(b, i, j, W) : 19;
                         sacc += pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(la, lb)];
@@ -790,38 +827,9 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
     for (int w = t; w < 2 * Fa; w += nt) {
         const int ka = w >> 1, half = w & 1;
         const int slot = alist[ka];
-        const int st = c.lm_start[slot], no = c.lm_nobs[slot], r0 = c.lm_tmp[slot];
-        double *row = c.Hpl + (size_t)ka * LW;
-        if (half == 0) {
-            double si[6] = {0, 0, 0, 0, 0, 0};
-            for (int k = 1; k < no; k++) {
-                if (r0 + k - 1 >= nres) break;
-                const double *Jr = c.res + (size_t)(r0 + k - 1) * 42;
-                const double l0 = Jr[19], l1 = Jr[39];
-#pragma unroll
-                for (int d = 0; d < 6; d++) {
-                    si[d] += Jr[d] * l0 + Jr[20 + d] * l1;
-                    row[6 * (st + k) + d] = Jr[6 + d] * l0 + Jr[26 + d] * l1;
-                }
-            }
-#pragma unroll
-            for (int d = 0; d < 6; d++) row[6 * st + d] = si[d];
-        } else {
-            double se[7] = {0, 0, 0, 0, 0, 0, 0}, hll = 0, gg = 0;
-            for (int k = 1; k < no; k++) {
-                if (r0 + k - 1 >= nres) break;
-                const double *Jr = c.res + (size_t)(r0 + k - 1) * 42;
-                const double l0 = Jr[19], l1 = Jr[39];
-#pragma unroll
-                for (int d = 0; d < 7; d++) se[d] += Jr[12 + d] * l0 + Jr[32 + d] * l1;
-                hll += l0 * l0 + l1 * l1;
-                gg += l0 * Jr[40] + l1 * Jr[41];
-            }
-#pragma unroll
-            for (int d = 0; d < 7; d++) row[15 * W1 + d] = se[d];
-            c.Hll[ka] = hll;
-            c.gl[ka] = gg;
-        }
+        const int st = c.lm_start[slot], r0 = c.lm_tmp[slot];
+        const int kend = min(c.lm_nobs[slot], nres - r0 + 1);  // residual r0 + k - 1 of observation k, capped by the residual list
+        lm_row(c.res + (size_t)r0 * 42, c.Hpl + (size_t)ka * LW, c.Hll + ka, c.gl + ka, half, st, kend, 15 * W1);
     }
     __syncthreads();
     PH(37);
