@@ -510,11 +510,15 @@ __device__ __forceinline__ int prior_map(int a, int W) {
 }
 
 // evaluate every residual at X. withJ: store weighted Jacobians/residuals for assembly. Returns total cost.
-__device__ __forceinline__ double evaluate(const Ctx &c, const Params &X, const double *feat, bool withJ, int nres, double *sred, double *sdx, double *srp) {
+__device__ __forceinline__ double evaluate(const Ctx &c, const Params &X, const double *feat, bool withJ, int nres, double *sred, double *sdx, double *srp,
+                                           double *geo) {
     const int t = threadIdx.x, nt = blockDim.x, W = c.W, n = c.NPR;
     const BeSeq &be = *c.be;
     const vio_config &cfg = c.C->c;
     double cost = 0;
+    const int s = c.s;
+    struct { float *timings; } B = {c.timings};
+    PH_INIT;
     // prior
     if (be.has_prior) {
         prior_dx(c, X, sdx);
@@ -528,14 +532,15 @@ __device__ __forceinline__ double evaluate(const Ctx &c, const Params &X, const 
         }
         if (t == 0) cost += 0.5 * be.prior_c0;
     }
+    PH(40);
     // IMU factors: five threads per factor (whitened residual + four Jacobian column groups). Spread over the upper lanes
     // of the block so that they do not serialise with the projection residuals handled by the low thread ids.
     v3 G = ld3(be.g);
-    for (int w = (nt - 1 - t); w < W * 5; w += nt) {
-        int i = w / 5, part = w - i * 5, j = i + 1;
+    auto imu_item = [&](int i, int part) {
+        const int j = i + 1;
         const PreInt &p = c.pre[be.pre_idx[j]];
         double *out = c.imu_raw + (size_t)i * 15 * 31;
-        if (p.sum_dt > 10.0) { if (part == 0) for (int k = 0; k < 15; k++) out[k * 31 + 30] = 0; continue; }
+        if (p.sum_dt > 10.0) { if (part == 0) for (int k = 0; k < 15; k++) out[k * 31 + 30] = 0; return; }
         if (part == 0) {
             double raw[15];
             bf::imu_raw_residual(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], raw);
@@ -547,32 +552,48 @@ __device__ __forceinline__ double evaluate(const Ctx &c, const Params &X, const 
             }
         } else if (withJ)
             bf::imu_raw_jacobian_part(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], part - 1, out, 31);  // raw, whitened in assemble
+    };
+    {
+        // Five work types per factor (whitened residual + four Jacobian column groups), each a different code path.  With at least
+        // five wavefronts every type gets its own wavefront (the top five, factor i on lane 63 - i), so that the types run side by
+        // side instead of one wavefront executing its divergent branches one after the other; the upper lanes are used because the
+        // low thread ids carry the first projection residuals.
+        const int nwv = nt >> 6, part = nwv - 1 - (t >> 6), i = 63 - (t & 63);
+        if (nwv >= 5 && W <= 64) {
+            if (part < 5 && i < W) imu_item(i, part);
+        } else {
+            for (int w = (nt - 1 - t); w < W * 5; w += nt) imu_item(w / 5, w % 5);
+        }
     }
+    PH(46);
     // projection factors, CauchyLoss(1.0): frame-pair geometry first (one thread per pair with residuals), then one thread per
-    // residual with a handful of 3-vector products (be_factors.h eval_projection_pair)
+    // residual with a handful of 3-vector products (be_factors.h eval_projection_pair).  The pair geometry lives in LDS (`geo`,
+    // (W1^2 + 1) x 32 doubles of the work region, free whenever evaluate runs): every residual gathers 30 doubles of it, and as
+    // per-lane gathers from HBM those were a third of the cache-line lookups that bound this loop.
     {
         const int W1 = W + 1;
         for (int p = t; p <= W1 * W1; p += nt) {
             if (p == W1 * W1) {
                 m3 ric = q2R(mkq(X.ex[6], X.ex[3], X.ex[4], X.ex[5]));
-                stm(c.pairgeo + (size_t)p * 32, ric);
+                stm(geo + (size_t)p * 32, ric);
                 continue;
             }
             int i = p / W1, j = p - i * W1;
             if (!(i < j) || c.pair_start[p + 1] == c.pair_start[p]) continue;
             bf::PairGeo g;
             bf::pair_geo(&X.pose[i * 7], &X.pose[j * 7], X.ex, g);
-            double *o = c.pairgeo + (size_t)p * 32;
+            double *o = geo + (size_t)p * 32;
             for (int q = 0; q < 9; q++) { o[q] = g.A1[q]; o[9 + q] = g.A2[q]; o[18 + q] = g.M[q]; }
             o[27] = g.t[0]; o[28] = g.t[1]; o[29] = g.t[2];
         }
         __syncthreads();
-        const double *ricm = c.pairgeo + (size_t)W1 * W1 * 32;
+        PH(41);
+        const double *ricm = geo + (size_t)W1 * W1 * 32;
 #pragma unroll 2
         for (int r = t; r < nres; r += nt) {
             int slot = c.res_lm[r], k = c.res_k[r];
             int imu_i = c.lm_start[slot], imu_j = imu_i + k;
-            const bf::PairGeo &g = *(const bf::PairGeo *)(c.pairgeo + (size_t)(imu_i * W1 + imu_j) * 32);
+            const bf::PairGeo &g = *(const bf::PairGeo *)(geo + (size_t)(imu_i * W1 + imu_j) * 32);
             double rr[2], wgt = 1.0;
             double *out = c.res + (size_t)r * 42;
             bf::eval_projection_pair(cfg, g, ricm, X.ex, feat[c.lm_pidx[slot]], X.td, obs_ptr(c, slot, imu_i), obs_ptr(c, slot, imu_j),
@@ -585,7 +606,9 @@ __device__ __forceinline__ double evaluate(const Ctx &c, const Params &X, const 
             }
         }
     }
+    PH(44);
     cost = block_sum(cost, sred);
+    PH(45);
     return cost;
 }
 
@@ -616,16 +639,25 @@ __device__ __forceinline__ int pair_slot(int i, int j, int W1) { return i * W1 -
 // residual be issued ahead of the row stores of the current one (the loop is bound by the latency of those loads).
 __device__ __forceinline__ void lm_row(const double *__restrict__ res, double *__restrict__ row, double *__restrict__ Hll,
                                        double *__restrict__ gl, int half, int st, int kend, int ext_off) {
+    // residual records are 336 bytes apart and 16-byte aligned: 16-byte loads halve the number of cache-line lookups of this gather
     if (half == 0) {
         double si[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll 2
         for (int k = 1; k < kend; k++) {
             const double *Jr = res + (size_t)(k - 1) * 42;
+            const double2 *J2 = (const double2 *)Jr;
             const double l0 = Jr[19], l1 = Jr[39];
+            double a[6], b[6], e[6], f[6];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                double2 va = J2[q], vb = J2[3 + q], ve = J2[10 + q], vf = J2[13 + q];
+                a[2 * q] = va.x; a[2 * q + 1] = va.y; b[2 * q] = vb.x; b[2 * q + 1] = vb.y;
+                e[2 * q] = ve.x; e[2 * q + 1] = ve.y; f[2 * q] = vf.x; f[2 * q + 1] = vf.y;
+            }
 #pragma unroll
             for (int d = 0; d < 6; d++) {
-                si[d] += Jr[d] * l0 + Jr[20 + d] * l1;
-                row[6 * (st + k) + d] = Jr[6 + d] * l0 + Jr[26 + d] * l1;
+                si[d] += a[d] * l0 + e[d] * l1;
+                row[6 * (st + k) + d] = b[d] * l0 + f[d] * l1;
             }
         }
 #pragma unroll
@@ -635,11 +667,19 @@ __device__ __forceinline__ void lm_row(const double *__restrict__ res, double *_
 #pragma unroll 2
         for (int k = 1; k < kend; k++) {
             const double *Jr = res + (size_t)(k - 1) * 42;
-            const double l0 = Jr[19], l1 = Jr[39];
+            const double2 *J2 = (const double2 *)Jr;
+            double a[8], e[8];
 #pragma unroll
-            for (int d = 0; d < 7; d++) se[d] += Jr[12 + d] * l0 + Jr[32 + d] * l1;
+            for (int q = 0; q < 4; q++) {
+                double2 va = J2[6 + q], ve = J2[16 + q];   // Jr[12..19], Jr[32..39]
+                a[2 * q] = va.x; a[2 * q + 1] = va.y; e[2 * q] = ve.x; e[2 * q + 1] = ve.y;
+            }
+            const double2 rr = J2[20];                      // weighted residual (Jr[40], Jr[41])
+            const double l0 = a[7], l1 = e[7];
+#pragma unroll
+            for (int d = 0; d < 7; d++) se[d] += a[d] * l0 + e[d] * l1;
             hll += l0 * l0 + l1 * l1;
-            gg += l0 * Jr[40] + l1 * Jr[41];
+            gg += l0 * rr.x + l1 * rr.y;
         }
 #pragma unroll
         for (int d = 0; d < 7; d++) row[ext_off + d] = se[d];
@@ -1077,7 +1117,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
     double *hsgl = c.res + (size_t)c.nres_cap * 42 - 4 * (size_t)c.NLs;   // tail of the residual buffer (nres <= nres_cap - 2 NL)
     double *yl = hsgl + c.NLs, *ul = yl + c.NLs, *tmpl = ul + c.NLs;
 
-    double cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp);
+    double cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp, work);
     PH(4);
     assemble(B, c, X, nres, Fa, alist, srp, work, pb);
     PH(5);
@@ -1151,7 +1191,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
         if (!reuse) {
             if (need_eval) {
                 PH(13);
-                if (!have_J) cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp);
+                if (!have_J) cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp, work);
                 have_J = false;
                 PH(4);
                 assemble(B, c, X, nres, Fa, alist, srp, work, pb);
@@ -1297,7 +1337,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
         // The candidate is evaluated WITH Jacobians (res / imu_raw / srp are only read by assemble(), which is not called again if the
         // step is rejected): an accepted point then goes straight to assemble() instead of being evaluated a second time.
         const bool cand_with_J = iter < cfg.max_iterations;
-        double ccost = evaluate(c, Xc, c.cfeat, cand_with_J, nres, sred, sdx, srp);
+        double ccost = evaluate(c, Xc, c.cfeat, cand_with_J, nres, sred, sdx, srp, work);
         PH(12);
         // parameter tolerance
         double xn = 0, dn = 0;

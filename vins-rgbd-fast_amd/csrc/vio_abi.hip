@@ -486,6 +486,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
             size_t workd = std::max((size_t)C.W * 450, npairs * 210 <= 12288 ? npairs * 210 : (size_t)0);
             workd = std::max(workd, (size_t)1400 /* PreWork */);
             workd = std::max(workd, (size_t)4 * 336);
+            workd = std::max(workd, ((size_t)(C.W + 1) * (C.W + 1) + 1) * 32);  // frame-pair geometry during evaluate()
             if (C.NPRIOR <= 96) workd = std::max(workd, (size_t)C.NPRIOR * (C.NPRIOR | 1) + 2);
             {
                 size_t nb = (size_t)C.LW >> 4, tiles = nb * (nb + 1) / 2 * 256;
