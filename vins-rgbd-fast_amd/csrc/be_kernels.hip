@@ -1163,7 +1163,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
     auto compute_cauchy = [&]() {
         // Cauchy point: alpha = |grad|^2 / |J D^-1 grad|^2, and H_full * (D^-1 grad) is kept for the model evaluation
         matvec_pass(c.H, LW, P, P, nullptr, up, nullptr, tmpv, work);   // H (S sg_p): H is symmetric, row dots
-        matvec_pass(c.Hpl, LW, Fa, P, ul, up, tmpv2, tmpl, work);       // Hpl^T (Sl sg_l) and Hpl (S sg_p) in one pass
+        matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, 7, ul, up, tmpv2, tmpl, work);       // Hpl^T (Sl sg_l) and Hpl (S sg_p) in one pass
         double g2 = 0, jg2 = 0;
         for (int a = t; a < LW; a += nt) {
             double v = a < P ? sp[a] * (tmpv[a] + tmpv2[a]) : 0.0;
@@ -1210,7 +1210,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                     tmpl[k] = sl[k] * iv * gls[k];
                 }
                 __syncthreads();
-                matvec_pass(c.Hpl, LW, Fa, P, tmpl, nullptr, tmpv, nullptr, work);  // Hpl^T (Sl gls / hll); uses the work region before S moves in
+                matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, 7, tmpl, nullptr, tmpv, nullptr, work);  // Hpl^T (Sl gls / hll); uses the work region before S moves in
                 for (int a = t; a < LW; a += nt) xs[a] = a < P ? gs[a] - sp[a] * tmpv[a] : 0.0;
                 for (int k = t; k < Kpad; k += nt) tmpl[k] = sl[k] * sl[k] * inv[k];  // per-row factor of the rank-K update
                 __syncthreads();
@@ -1218,7 +1218,14 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                 if (tiles_in_lds) {
                     {
                         const int ntile_ = (LW >> 4) * ((LW >> 4) + 1) / 2, nw_ = nt >> 6;
-                        if (ntile_ <= 9 * nw_ && 2 * SCH_CH * (LW + 8) <= ntile_ * 256) schur_mfma_staged<9>(c.H, c.Hpl, tmpl, dgp, sp, mu, Kpad, LW, LW, work);
+                        // column tiles of Hpl that can be non-zero: poses (columns 0 .. 6 W1 - 1) and extrinsic / td (15 W1 .. 15 W1 + 6)
+                        unsigned colmask = 0;
+                        for (int cb = 0; cb < (LW >> 4); cb++) {
+                            const int c0 = 16 * cb, c1 = c0 + 15;
+                            if (c0 < 6 * W1 || (c1 >= 15 * W1 && c0 < 15 * W1 + 7)) colmask |= 1u << cb;
+                        }
+                        if (ntile_ <= 9 * nw_ && 2 * SCH_CH * (LW + 8) + 64 <= ntile_ * 256 && (LW >> 4) <= 32)
+                            schur_mfma_staged<9>(c.H, c.Hpl, tmpl, dgp, sp, mu, Kpad, LW, LW, work, colmask);
                         else schur_mfma_lds(c.H, c.Hpl, tmpl, dgp, sp, mu, Kpad, LW, LW, work);
                     }
                     PH(8);
@@ -1239,7 +1246,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                     if (bad == 0) {
                         for (int a = t; a < LW; a += nt) { yp[a] = xs[a]; gnp[a] = -xs[a] * dgp[a]; tmpv[a] = sp[a] * xs[a]; }
                         __syncthreads();
-                        matvec_pass(c.Hpl, LW, Fa, P, nullptr, tmpv, nullptr, tmpl, nullptr);  // Hpl (S y_p)
+                        matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, 7, nullptr, tmpv, nullptr, tmpl, nullptr);  // Hpl (S y_p)
                         for (int k = t; k < Kpad; k += nt) {
                             double y = k < Fa ? (gls[k] - sl[k] * tmpl[k]) * inv[k] : 0.0;
                             yl[k] = y;

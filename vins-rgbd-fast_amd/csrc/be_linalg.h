@@ -618,22 +618,43 @@ __device__ __forceinline__ void schur_mfma_lds(const double *Hs, const double *W
 // tiles in registers for the whole k loop, the 16-row chunks of Hpl (scaled by sp on the way in) are double-buffered in the
 // tile region itself (it is only written at the end).  Global traffic drops from 2 * ntile * Kpad * 16 doubles (every
 // tile re-reading its two column panels) to Kpad * n doubles.
+// colmask: bit c set = column tile c of Ws can be non-zero.  The landmark rows only couple to pose and extrinsic / td columns, the
+// speed-bias columns (more than half of the row) are identically zero: tiles with an all-zero panel keep their H values and get no
+// MFMAs, their columns are not staged, and the active tiles are dealt round-robin over the wavefronts so that the work stays
+// balanced.  Skipping them is exact (they would only add zeros).
 #define SCH_CH 16
 template <int MAXT>
 __device__ __forceinline__ void schur_mfma_staged(const double *Hs, const double *Ws, const double *inv, const double *dgp, const double *sp, double mu,
-                                  int Kpad, int n, int ld, double *T) {
+                                  int Kpad, int n, int ld, double *T, unsigned colmask) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
     const int nb = n >> 4, ntile = nb * (nb + 1) / 2;
     const int li = lane & 15, lk = lane >> 4;
     const int lds = n + 8;  // padded row stride of the staged chunk (bank spread of the 4 k-rows)
     double *buf0 = T, *buf1 = T + SCH_CH * lds;
+    int *order = (int *)(T + 2 * SCH_CH * lds);  // [ntile] tiles, active ones first; [ntile] = their count; then the active column tiles
+    int *ctab = order + ntile + 1;
+    if (t == 0) {
+        int na = 0;
+        for (int pass = 0; pass < 2; pass++)
+            for (int tile = 0; tile < ntile; tile++) {
+                int ti, tj;
+                tri_decode(tile, ti, tj);
+                bool act = ((colmask >> ti) & 1u) && ((colmask >> tj) & 1u);
+                if (act == (pass == 0)) order[na++] = tile;
+                if (pass == 0 && tile == ntile - 1) order[ntile] = na;
+            }
+        int nc = 0;
+        for (int cb = 0; cb < nb; cb++) if ((colmask >> cb) & 1u) ctab[nc++] = cb;
+    }
+    __syncthreads();
+    const int nact = order[ntile], nac = __popc(colmask & ((1u << nb) - 1u));
     v4f64 acc[MAXT];
     int tis[MAXT], tjs[MAXT];
 #pragma unroll
     for (int i = 0; i < MAXT; i++) {
-        int tile = wave + i * nw;
+        int slot = wave + i * nw;
         int ti = 0, tj = 0;
-        if (tile < ntile) tri_decode(tile, ti, tj);
+        if (slot < ntile) tri_decode(order[slot], ti, tj);
         tis[i] = ti; tjs[i] = tj;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -644,9 +665,10 @@ __device__ __forceinline__ void schur_mfma_staged(const double *Hs, const double
         }
     }
     const int nchunk = (Kpad + SCH_CH - 1) / SCH_CH;
+    const int ncol = 16 * nac;
     auto stage = [&](int ch, double *buf) {
-        for (int q = t; q < SCH_CH * n; q += nt) {
-            int r = q / n, cc = q - r * n, kk = ch * SCH_CH + r;
+        for (int q = t; q < SCH_CH * ncol; q += nt) {
+            int r = q / ncol, c2 = q - r * ncol, cc = 16 * ctab[c2 >> 4] + (c2 & 15), kk = ch * SCH_CH + r;
             buf[r * lds + cc] = kk < Kpad ? Ws[(size_t)kk * ld + cc] * sp[cc] : 0.0;
         }
     };
@@ -660,7 +682,7 @@ __device__ __forceinline__ void schur_mfma_staged(const double *Hs, const double
         for (int ks = 0; ks < SCH_CH / 4; ks++) { int kk = ch * SCH_CH + 4 * ks + lk; iv[ks] = kk < Kpad ? inv[kk] : 0.0; }
 #pragma unroll
         for (int i = 0; i < MAXT; i++) {
-            if (wave + i * nw < ntile) {
+            if (wave + i * nw < nact) {
                 const double *pa = cur + lk * lds + 16 * tis[i] + li, *pb = cur + lk * lds + 16 * tjs[i] + li;
 #pragma unroll
                 for (int ks = 0; ks < SCH_CH / 4; ks++) {
@@ -1046,6 +1068,60 @@ __device__ __forceinline__ void matvec_pass_t(const double *M, int ld, int nrows
         }
     }
     __syncthreads();
+}
+// Same pass for a matrix whose rows are non-zero only in columns [0, n0) and [e0, e0 + ne) (the landmark coupling rows: pose
+// columns and extrinsic / td columns, the speed-bias columns in between are identically zero): lanes own the compacted columns,
+// a third of the loads of the dense pass.  out_col is still written for all n columns (zeros outside the two ranges).
+template <int NC>
+__device__ __forceinline__ void matvec_pass_2range_t(const double *M, int ld, int nrows, int n, int n0, int e0, int ne, const double *u, const double *v,
+                                                     double *out_col, double *out_row, double *part) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    const int ncomp = n0 + ne;
+    double cs[NC], vv[NC];
+    int col[NC];
+#pragma unroll
+    for (int j = 0; j < NC; j++) {
+        int q = lane + 64 * j;
+        col[j] = q < n0 ? q : (q < ncomp ? e0 + (q - n0) : -1);
+        cs[j] = 0;
+        vv[j] = (v && col[j] >= 0) ? v[col[j]] : 0.0;
+    }
+#pragma unroll 2
+    for (int k = wave; k < nrows; k += nw) {
+        const double *r = M + (size_t)k * ld;
+        double m[NC];
+#pragma unroll
+        for (int j = 0; j < NC; j++) m[j] = col[j] >= 0 ? r[col[j]] : 0.0;
+        if (v) {
+            double rd = 0;
+#pragma unroll
+            for (int j = 0; j < NC; j++) rd += m[j] * vv[j];
+            rd = wave_sum_dpp(rd);
+            if (lane == 0) out_row[k] = rd;
+        }
+        if (u) {
+            const double uk = u[k];
+#pragma unroll
+            for (int j = 0; j < NC; j++) cs[j] += uk * m[j];
+        }
+    }
+    if (u) {
+#pragma unroll
+        for (int j = 0; j < NC; j++) if (col[j] >= 0) part[wave * VIO_LWMAX + col[j]] = cs[j];
+        __syncthreads();
+        for (int a = t; a < n; a += nt) {
+            double sacc = 0;
+            if (a < n0 || (a >= e0 && a < e0 + ne))
+                for (int q = 0; q < nw; q++) sacc += part[q * VIO_LWMAX + a];
+            out_col[a] = sacc;
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void matvec_pass_2range(const double *M, int ld, int nrows, int n, int n0, int e0, int ne, const double *u, const double *v,
+                                                   double *out_col, double *out_row, double *part) {
+    if (n0 + ne <= 128) matvec_pass_2range_t<2>(M, ld, nrows, n, n0, e0, ne, u, v, out_col, out_row, part);
+    else matvec_pass_t<6>(M, ld, nrows, n, u, v, out_col, out_row, part);  // larger windows: dense pass
 }
 __device__ __forceinline__ void matvec_pass(const double *M, int ld, int nrows, int n, const double *u, const double *v, double *out_col, double *out_row,
                             double *part) {
