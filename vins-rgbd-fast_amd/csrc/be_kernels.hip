@@ -691,7 +691,7 @@ __device__ __forceinline__ void lm_row(const double *__restrict__ res, double *_
 // assemble H (P x P, ld LW), g (vec slot 0), Hpl / Hll / gl from the stored residual Jacobians.
 // work: LDS scratch (>= max(W*450, npairs*210) doubles when it fits, see be_solve); pb = frame-pair blocks (LDS or HBM)
 __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Params &X, int nres, int Fa, const int *alist, double *srp, double *work,
-                         double *pb) {
+                         double *pb, bool hpl_sparse) {
     const int s = c.s;
     PH_INIT;
     const int t = threadIdx.x, nt = blockDim.x, W = c.W, P = c.P, LW = c.LW, n = c.NPR;
@@ -700,7 +700,16 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
     double *H = c.H, *g = c.vec;
     for (int i = t; i < P * LW; i += nt) H[i] = 0;
     for (int i = t; i < LW; i += nt) g[i] = 0;
-    for (int i = t; i < ((Fa + 3) & ~3) * LW; i += nt) c.Hpl[i] = 0;
+    {
+        // landmark rows: with the column-aware Schur staging and mat-vecs (hpl_sparse) only the column tiles that hold pose or
+        // extrinsic / td columns are ever read, the speed-bias columns in between need no zeros (the marginalisation kernel uses
+        // this buffer as scratch, so they do hold garbage); the dense fall-back paths read whole rows
+        const int w0 = hpl_sparse ? min(LW, (6 * (W + 1) + 15) & ~15) : LW, e_lo = max(w0, (15 * (W + 1)) & ~15), wz = w0 + (LW - e_lo);
+        for (int i = t; i < ((Fa + 3) & ~3) * wz; i += nt) {
+            const int row = i / wz, cc = i - row * wz;
+            c.Hpl[(size_t)row * LW + (cc < w0 ? cc : e_lo + (cc - w0))] = 0;
+        }
+    }
     __syncthreads();
     PH(32);
     // prior: H += J^T J (precomputed), g += J^T r
@@ -931,6 +940,10 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
     double *pb = (npairs * 210 <= 12288) ? work : c.pairblk;  // 55 pairs x 210 doubles = 92 KB for W = 10
     __shared__ double chol_dinv[VIO_LWMAX];  // reciprocal Cholesky diagonal (LDS-tile path)
     const bool tiles_in_lds = ((LW >> 4) * ((LW >> 4) + 1) / 2) * 256 <= 16896 && !(B.flags & 1);  // S as 66 lower tiles = 132 KB for W = 10
+    // column-aware Schur staging (schur_mfma_staged) and two-range Hpl mat-vecs in use: see assemble() / the solver loop
+    const bool schur_staged = tiles_in_lds && ((LW >> 4) * ((LW >> 4) + 1) / 2) <= 9 * (nt >> 6) &&
+                              2 * SCH_CH * (LW + 8) + 64 <= ((LW >> 4) * ((LW >> 4) + 1) / 2) * 256 && (LW >> 4) <= 32;
+    const bool hpl_sparse = schur_staged && 6 * W1 + 7 <= 128;
 
     PH_INIT;
     const long long ts0 = wall_clock64();
@@ -1119,7 +1132,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
 
     double cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp, work);
     PH(4);
-    assemble(B, c, X, nres, Fa, alist, srp, work, pb);
+    assemble(B, c, X, nres, Fa, alist, srp, work, pb, hpl_sparse);
     PH(5);
     if (t == 0) be.initial_cost = cost;
     // Jacobi scaling (once): 1/(1+||J_j||); constant blocks (ex / td when not estimated) get scale 0 = removed from the problem
@@ -1176,8 +1189,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
             hsgl[k] = v;
             if (k < Fa) { g2 += gradl[k] * gradl[k]; jg2 += sgl * v; }
         }
-        g2 = block_sum(g2, sred);
-        jg2 = block_sum(jg2, sred);
+        block_sum2(g2, jg2, sred);
         alpha = g2 / jg2;
         cauchy_valid = true;
     };
@@ -1194,7 +1206,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                 if (!have_J) cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp, work);
                 have_J = false;
                 PH(4);
-                assemble(B, c, X, nres, Fa, alist, srp, work, pb);
+                assemble(B, c, X, nres, Fa, alist, srp, work, pb, hpl_sparse);
                 PH(5);
                 need_eval = false;
                 if (prepare_point() <= 1e-10) { iters_done = iter - 1; break; }
@@ -1217,14 +1229,13 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                 bool chol_ok;
                 if (tiles_in_lds) {
                     {
-                        const int ntile_ = (LW >> 4) * ((LW >> 4) + 1) / 2, nw_ = nt >> 6;
                         // column tiles of Hpl that can be non-zero: poses (columns 0 .. 6 W1 - 1) and extrinsic / td (15 W1 .. 15 W1 + 6)
                         unsigned colmask = 0;
                         for (int cb = 0; cb < (LW >> 4); cb++) {
                             const int c0 = 16 * cb, c1 = c0 + 15;
                             if (c0 < 6 * W1 || (c1 >= 15 * W1 && c0 < 15 * W1 + 7)) colmask |= 1u << cb;
                         }
-                        if (ntile_ <= 9 * nw_ && 2 * SCH_CH * (LW + 8) + 64 <= ntile_ * 256 && (LW >> 4) <= 32)
+                        if (schur_staged)
                             schur_mfma_staged<9>(c.H, c.Hpl, tmpl, dgp, sp, mu, Kpad, LW, LW, work, colmask);
                         else schur_mfma_lds(c.H, c.Hpl, tmpl, dgp, sp, mu, Kpad, LW, LW, work);
                     }
@@ -1266,9 +1277,9 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
         double gnorm = 0, gnn = 0, gdot = 0;
         for (int a = t; a < P; a += nt) { gnorm += gradp[a] * gradp[a]; gnn += gnp[a] * gnp[a]; gdot += gradp[a] * gnp[a]; }
         for (int k = t; k < Fa; k += nt) { gnorm += gradl[k] * gradl[k]; gnn += gnl[k] * gnl[k]; gdot += gradl[k] * gnl[k]; }
-        gnorm = sqrt(block_sum(gnorm, sred));
-        gnn = sqrt(block_sum(gnn, sred));
-        gdot = block_sum(gdot, sred);
+        block_sum3(gnorm, gnn, gdot, sred);
+        gnorm = sqrt(gnorm);
+        gnn = sqrt(gnn);
         double ca = 0, cb = 0;  // step = ca * grad + cb * gn
         if (!(gnn <= radius) && !cauchy_valid) { PH(11); compute_cauchy(); PH(7); }
         if (gnn <= radius) { ca = 0; cb = 1; dogleg_norm = gnn; }
@@ -1305,9 +1316,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                 quad += st * ((ca != 0.0 ? ca * hsgl[k] : 0.0) - cb * (gls[k] - mu * dgl[k] * dgl[k] * yl[k]));
             }
         }
-        n2 = block_sum(n2, sred);
-        lin = block_sum(lin, sred);
-        quad = block_sum(quad, sred);
+        block_sum3(n2, lin, quad, sred);
         if (dogleg_norm < 0) dogleg_norm = sqrt(n2);
         double model_change = -(lin + 0.5 * quad);
         PH(11);
@@ -1357,8 +1366,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
             if (td_active) { xn += X.td * X.td; dn += (X.td - Xc.td) * (X.td - Xc.td); }
         }
         for (int k = t; k < Fa; k += nt) { int pi = c.lm_pidx[alist[k]]; double v = c.feat[pi]; xn += v * v; double d = v - c.cfeat[pi]; dn += d * d; }
-        xn = block_sum(xn, sred);
-        dn = block_sum(dn, sred);
+        block_sum2(xn, dn, sred);
         if (sqrt(dn) <= 1e-8 * (sqrt(xn) + 1e-8)) break;
         if (fabs(cost - ccost) <= 1e-6 * cost) break;
         double rel = (cost - ccost) / model_change;

@@ -57,6 +57,22 @@ __device__ __forceinline__ double block_sum(double v, double *sred) {
     for (int k = 0; k < nw; k++) r += sred[k];
     return r;
 }
+// Two / three sums behind one pair of barriers (sred holds 64 doubles, at most 16 wavefronts): each value is reduced in exactly
+// the order block_sum uses, so fusing reductions does not change a single bit.
+__device__ __forceinline__ void block_sum3(double &a, double &b, double &c, double *sred) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = (blockDim.x + 63) >> 6;
+    a = wave_sum_dpp(a); b = wave_sum_dpp(b); c = wave_sum_dpp(c);
+    __syncthreads();
+    if (lane == 0) { sred[wave] = a; sred[16 + wave] = b; sred[32 + wave] = c; }
+    __syncthreads();
+    double ra = 0, rb = 0, rc = 0;
+    for (int k = 0; k < nw; k++) { ra += sred[k]; rb += sred[16 + k]; rc += sred[32 + k]; }
+    a = ra; b = rb; c = rc;
+}
+__device__ __forceinline__ void block_sum2(double &a, double &b, double *sred) {
+    double c = 0;
+    block_sum3(a, b, c, sred);
+}
 __device__ __forceinline__ double block_max(double v, double *sred) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = (blockDim.x + 63) >> 6;
     v = wave_max_dpp(v);
