@@ -482,7 +482,7 @@ namespace {
 struct Params { double pose[(VIO_MAXW + 1) * 7], sb[(VIO_MAXW + 1) * 9], ex[7], td; };
 
 // prior residual row i at parameters X: r0 + J dx; dx assembled in LDS sdx (n)
-__device__ __forceinline__ void prior_dx(const Ctx &c, const Params &X, double *sdx) {
+__device__ __forceinline__ void prior_dx(const Ctx &c, const Params &X, double *sdx, bool sync = true) {
     const int t = threadIdx.x, W = c.W;
     const BeSeq &be = *c.be;
     if (t <= W + 2) {
@@ -499,7 +499,7 @@ __device__ __forceinline__ void prior_dx(const Ctx &c, const Params &X, double *
         } else
             sdx[6 * W + 15] = be.prior_present[W + 2] ? X.td - c.prior_x0[W * 7 + 16] : 0.0;
     }
-    __syncthreads();
+    if (sync) __syncthreads();
 }
 // tangent index of prior slot a
 __device__ __forceinline__ int prior_map(int a, int W) {
@@ -519,19 +519,9 @@ __device__ __forceinline__ double evaluate(const Ctx &c, const Params &X, const 
     const int s = c.s;
     struct { float *timings; } B = {c.timings};
     PH_INIT;
-    // prior
-    if (be.has_prior) {
-        prior_dx(c, X, sdx);
-        // The prior is kept as the quadratic form (A, b, c0) = (J^T J, J^T r, |r|^2) of the reference's linearised factor:
-        // 1/2 |r + J dx|^2 = 1/2 c0 + dx^T b + 1/2 dx^T A dx.  srp receives the gradient q = b + A dx (what assemble / marg add to g).
-        matvec_pass(c.prior_H, n, n, n, nullptr, sdx, nullptr, srp, nullptr);  // A dx: one wavefront per row
-        for (int i = t; i < n; i += nt) {
-            const double b0 = c.prior_r[i], q = b0 + srp[i];
-            srp[i] = q;
-            cost += 0.5 * sdx[i] * (b0 + q);
-        }
-        if (t == 0) cost += 0.5 * be.prior_c0;
-    }
+    // Stage 1 (independent small jobs, one barrier for all of them): prior tangent dx (threads 0 .. W + 2), IMU factors (upper
+    // wavefronts), frame-pair geometry (threads 0 .. W1^2).  Stage 2: prior mat-vec, then the projection residuals.
+    if (be.has_prior) prior_dx(c, X, sdx, false);
     PH(40);
     // IMU factors: five threads per factor (whitened residual + four Jacobian column groups). Spread over the upper lanes
     // of the block so that they do not serialise with the projection residuals handled by the low thread ids.
@@ -588,6 +578,17 @@ __device__ __forceinline__ double evaluate(const Ctx &c, const Params &X, const 
         }
         __syncthreads();
         PH(41);
+        if (be.has_prior) {
+            // The prior is kept as the quadratic form (A, b, c0) = (J^T J, J^T r, |r|^2) of the reference's linearised factor:
+            // 1/2 |r + J dx|^2 = 1/2 c0 + dx^T b + 1/2 dx^T A dx.  srp receives the gradient q = b + A dx (what assemble / marg add to g).
+            matvec_pass(c.prior_H, n, n, n, nullptr, sdx, nullptr, srp, nullptr);  // A dx: one wavefront per row
+            for (int i = t; i < n; i += nt) {
+                const double b0 = c.prior_r[i], q = b0 + srp[i];
+                srp[i] = q;
+                cost += 0.5 * sdx[i] * (b0 + q);
+            }
+            if (t == 0) cost += 0.5 * be.prior_c0;
+        }
         const double *ricm = geo + (size_t)W1 * W1 * 32;
 #pragma unroll 2
         for (int r = t; r < nres; r += nt) {
@@ -839,9 +840,17 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
     __syncthreads();
     PH(35);
     {
-        const int nv = 6 * W1 + 7;
-        for (int w = t; w < nv * (nv + 1); w += nt) {
-            int ra = w / (nv + 1), rb = w - ra * (nv + 1);
+        // one item per unordered pair (ra <= rb) of vision rows plus one per gradient entry: H is symmetric and both mirror
+        // elements receive the same sum (identical terms in identical order), so only half of the element sums are formed
+        const int nv = 6 * W1 + 7, ntri = nv * (nv + 1) / 2;
+        for (int w = t; w < ntri + nv; w += nt) {
+            int ra, rb;
+            if (w < ntri) {
+                int r = (int)((sqrtf(8.0f * (float)w + 1.0f) - 1.0f) * 0.5f);
+                while (r * (r + 1) / 2 > w) r--;
+                while ((r + 1) * (r + 2) / 2 <= w) r++;
+                rb = r; ra = w - r * (r + 1) / 2;
+            } else { ra = w - ntri; rb = nv; }
             int a = ra < 6 * W1 ? ra : 15 * W1 + (ra - 6 * W1);
             int b = rb < nv ? (rb < 6 * W1 ? rb : 15 * W1 + (rb - 6 * W1)) : -1;
             double sacc = 0;
@@ -867,7 +876,11 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
                         sacc += pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(la, lb)];
                     }
             }
-            if (b >= 0) H[a * LW + b] += sacc; else g[a] += sacc;
+            if (b >= 0) {
+                H[a * LW + b] += sacc;
+                if (a != b) H[b * LW + a] += sacc;
+            } else
+                g[a] += sacc;
         }
     }
     PH(36);
