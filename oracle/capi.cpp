@@ -213,4 +213,47 @@ int ovio_get_prior(void *h, double *J, double *r, double *x0, uint8_t *present) 
     return n;
 }
 
+// ---------------------------------------------------------------- visual-inertial alignment (dynamic initialisation, part)
+// frames: n x {R[9] row-major, T[3], sum_dt, delta_p[3], delta_v[3]} = 19 doubles each.  x_out: 3 n + 2 doubles (body velocities
+// per frame, then the last tangent-plane correction).  Returns 1 on success (|g| within 1 m/s^2 of g_norm before refinement).
+int ovio_linear_alignment_with_depth(int n, const double *frames, const double *tic, double g_norm, double *g_out, double *x_out) {
+    std::vector<AlignFrame> f(n);
+    for (int i = 0; i < n; i++) {
+        const double *p = frames + 19 * i;
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) f[i].R(r, c) = p[3 * r + c];
+        f[i].T = V3(p[9], p[10], p[11]);
+        f[i].sum_dt = p[12];
+        f[i].delta_p = V3(p[13], p[14], p[15]);
+        f[i].delta_v = V3(p[16], p[17], p[18]);
+    }
+    V3 g;
+    std::vector<double> x;
+    bool ok = linear_alignment_with_depth(f, V3(tic[0], tic[1], tic[2]), g_norm, g, x);
+    g_out[0] = g.x; g_out[1] = g.y; g_out[2] = g.z;
+    for (size_t i = 0; i < x.size() && i < (size_t)(3 * n + 3); i++) x_out[i] = x[i];
+    return ok ? 1 : 0;
+}
+void ovio_tangent_basis(const double *g0, double *b, double *c) {
+    V3 bb, cc;
+    tangent_basis(V3(g0[0], g0[1], g0[2]), bb, cc);
+    for (int k = 0; k < 3; k++) { b[k] = bb[k]; c[k] = cc[k]; }
+}
+// in/out: Ps[n*3] (camera positions in the SfM frame -> body positions in the gravity-aligned world), Rs[n*9], out Vs[n*3]; g in/out
+void ovio_align_window_to_gravity(int n, double *Ps, double *Rs, double *Vs, const double *x, const double *tic, double *g) {
+    std::vector<V3> P(n), Vv(n);
+    std::vector<M3> R(n);
+    for (int i = 0; i < n; i++) {
+        P[i] = V3(Ps[3 * i], Ps[3 * i + 1], Ps[3 * i + 2]);
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R[i](r, c) = Rs[9 * i + 3 * r + c];
+    }
+    std::vector<double> xv(x, x + 3 * n);
+    V3 gv(g[0], g[1], g[2]);
+    align_window_to_gravity(n, P.data(), R.data(), Vv.data(), xv, V3(tic[0], tic[1], tic[2]), gv);
+    for (int i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) { Ps[3 * i + k] = P[i][k]; Vs[3 * i + k] = Vv[i][k]; }
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rs[9 * i + 3 * r + c] = R[i](r, c);
+    }
+    g[0] = gv.x; g[1] = gv.y; g[2] = gv.z;
+}
+
 }  // extern "C"

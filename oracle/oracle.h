@@ -237,6 +237,21 @@ void eval_projection(const Config &c, const double *pose_i, const double *pose_j
 void eval_imu(const Integration &pre, const om::V3 &G, const double *pose_i, const double *sb_i, const double *pose_j,
               const double *sb_j, double r[15], double *J_pi, double *J_sbi, double *J_pj, double *J_sbj);
 
+// ------------------------------------------------------------------------------------ dynamic initialisation (part)
+// Visual-inertial alignment of the static_init: 0 branch, oracle/initial.cpp.  One AlignFrame per image
+// frame: R = rotation of the BODY in the SfM reference frame, T = position of the CAMERA in it (ImageFrame::R / ::T as filled
+// at estimator.cpp:560-574), and the pre-integration from the previous frame (unused for the first one).
+struct AlignFrame {
+    om::M3 R;
+    om::V3 T;
+    double sum_dt = 0;
+    om::V3 delta_p, delta_v;
+};
+void tangent_basis(const om::V3 &g0, om::V3 &b, om::V3 &c);
+void refine_gravity_with_depth(const std::vector<AlignFrame> &f, const om::V3 &tic, double g_norm, om::V3 &g, std::vector<double> &x);
+bool linear_alignment_with_depth(const std::vector<AlignFrame> &f, const om::V3 &tic, double g_norm, om::V3 &g, std::vector<double> &x);
+void align_window_to_gravity(int n, om::V3 *Ps, om::M3 *Rs, om::V3 *Vs, const std::vector<double> &x, const om::V3 &tic, om::V3 &g);
+
 // ------------------------------------------------------------------------------------ nodelet-side driver
 // Restates the parts of estimator_nodelet.cpp:192-459 (process_tracker) and :462-568 (process) that sit between
 // the two entry points: first-image skip, updateID loop, feature-map packaging (track_cnt>1, ascending id),
