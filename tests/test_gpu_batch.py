@@ -133,10 +133,10 @@ def test_stream_groups_do_not_change_results(P, monkeypatch):
         assert np.array_equal(grp.landmarks(i), ref.landmarks(i)), i
 
 
-@pytest.mark.parametrize("env", [{"VIO_BE_THREADS": "1024"}, {"VIO_FLAGS": "1"}, {"VIO_MARG_THREADS": "256"}])
+@pytest.mark.parametrize("env", [{"VIO_BE_THREADS": "1024"}, {"VIO_FLAGS": "1"}, {"VIO_MARG_THREADS": "256"}, {"VIO_MARG_THREADS": "512"}])
 def test_alternative_kernel_configurations_agree(P, monkeypatch, env):
     """The non-default builds / paths kept behind environment knobs (1024-thread solve kernel, Schur complement and Cholesky in HBM
-    instead of LDS tiles, 256-thread marginalisation) compute the same thing in a different summation order: the trajectory must agree
+    instead of LDS tiles, 256- and 512-thread marginalisation) compute the same thing in a different summation order: the trajectory must agree
     with the default configuration to round-off amplified over 24 frames (1e-6 m)."""
     cfg = P.canonical_config()
     sc = vio_ct.synth_like(cfg)

@@ -29,7 +29,7 @@ struct Ctx {
     PreInt *pre;
     int *lm_id, *lm_start, *lm_nobs, *lm_est, *lm_solve, *lm_dyn, *lm_order, *lm_free, *lm_tmp, *lm_pidx, *lm_aidx;
     double *lm_depth, *lm_obs, *feat, *cfeat;
-    double *H, *Sc, *Hpl, *vec, *Hll, *gl, *lvec, *res, *pairgeo;
+    double *H, *Sc, *Hpl, *vec, *Hll, *gl, *lvec, *res;
     int *res_lm, *res_k, *pair_start, *pair_list;
     double *pairblk, *imu_raw;
     double *prior_J, *prior_r, *prior_x0, *prior_H, *prior_rf;
@@ -50,7 +50,6 @@ __device__ Ctx make_ctx(const Batch &B, int s) {
     c.lm_tmp = B.lm_tmp + o; c.lm_pidx = B.lm_pidx + o; c.lm_aidx = B.lm_aidx + o;
     c.lm_depth = B.lm_depth + o; c.feat = B.para_feat + o; c.cfeat = B.cand_feat + o;
     c.lm_obs = B.lm_obs + o * (C.W + 1) * VIO_OBS_D;
-    c.pairgeo = B.pairgeo + (size_t)s * ((size_t)(C.W + 1) * (C.W + 1) + 1) * 32;
     c.H = B.H + (size_t)s * C.LW * C.LW; c.Sc = B.Sc + (size_t)s * C.LW * C.LW; c.Hpl = B.Hpl + (size_t)s * (C.NL + 8) * C.LW;
     c.vec = B.vec + (size_t)s * VEC_SLOTS * C.LW;
     c.Hll = B.Hll + (size_t)s * (C.NL + 8); c.gl = B.gl + (size_t)s * (C.NL + 8); c.lvec = B.lvec + (size_t)s * (C.NL + 8) * 8;

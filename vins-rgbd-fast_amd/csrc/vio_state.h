@@ -139,7 +139,6 @@ struct Batch {
     int *pair_start, *pair_list;      // counting sort by frame pair
     double *pairblk;                  // [S][npairs][210] packed symmetric 20x20
     double *imu_raw;                  // [S][W][15*31] raw / whitened IMU Jacobians + residual
-    double *pairgeo;                  // [S][(W+1)^2 + 1][32] frame-pair geometry of the projection factors (+ ric)
     double *margA, *margB, *margV, *margW;  // marginalisation workspaces
     // ---- outputs
     double *odom;         // [S][11]
