@@ -233,6 +233,67 @@ int ovio_linear_alignment_with_depth(int n, const double *frames, const double *
     for (size_t i = 0; i < x.size() && i < (size_t)(3 * n + 3); i++) x_out[i] = x[i];
     return ok ? 1 : 0;
 }
+// obj[n*3], img[n*2]; R[9] row-major / t[3] in (guess) and out; camera_point = R X + t
+int ovio_solve_pnp_iterative(int n, const double *obj, const double *img, double *R, double *t) {
+    std::vector<V3> o(n);
+    std::vector<std::array<double, 2>> im(n);
+    for (int i = 0; i < n; i++) { o[i] = V3(obj[3 * i], obj[3 * i + 1], obj[3 * i + 2]); im[i] = {img[2 * i], img[2 * i + 1]}; }
+    M3 Rm;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rm(r, c) = R[3 * r + c];
+    V3 tv(t[0], t[1], t[2]);
+    bool ok = solve_pnp_iterative(o, im, Rm, tv);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R[3 * r + c] = Rm(r, c);
+    t[0] = tv.x; t[1] = tv.y; t[2] = tv.z;
+    return ok ? 1 : 0;
+}
+int ovio_solve_pnp_ransac_epnp(int n, const double *obj, const double *img, int max_iters, double thresh, double confidence, double *R,
+                               double *t, uint8_t *inliers) {
+    std::vector<V3> o(n);
+    std::vector<std::array<double, 2>> im(n);
+    for (int i = 0; i < n; i++) { o[i] = V3(obj[3 * i], obj[3 * i + 1], obj[3 * i + 2]); im[i] = {img[2 * i], img[2 * i + 1]}; }
+    M3 Rm;
+    V3 tv;
+    std::vector<uint8_t> in;
+    bool ok = solve_pnp_ransac_epnp(o, im, max_iters, thresh, confidence, Rm, tv, in);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R[3 * r + c] = Rm(r, c);
+    t[0] = tv.x; t[1] = tv.y; t[2] = tv.z;
+    for (int i = 0; i < n && i < (int)in.size(); i++) inliers[i] = in[i];
+    return ok ? 1 : 0;
+}
+// Vision-only structure of the initialisation window: relativePose + GlobalSFM::construct.
+// Features: start[nf], nobs[nf], obs = concatenated (x, y, depth) per observation (consecutive frames from start).
+// Out: l, q[frame_num*4] (w,x,y,z) and T[frame_num*3] = camera poses in the frame of camera l, pts[nf*4] = (state, X, Y, Z),
+// stats[4] = (BA iterations, initial cost, final cost, converged).  Returns 0 ok, 1 no frame pair with enough parallax, 2 SfM failed.
+int ovio_sfm_window(int window_size, int nf, const int *start, const int *nobs, const double *obs, int *l_out, double *q_out,
+                    double *T_out, double *pts_out, double *stats_out) {
+    std::vector<SfmFeature> f(nf);
+    size_t off = 0;
+    for (int i = 0; i < nf; i++) {
+        f[i].id = i;
+        for (int k = 0; k < nobs[i]; k++, off++) {
+            f[i].observation.push_back({start[i] + k, {obs[3 * off], obs[3 * off + 1]}});
+            f[i].observation_depth.push_back({start[i] + k, obs[3 * off + 2]});
+        }
+    }
+    M3 rR;
+    V3 rT;
+    int l = -1;
+    if (!sfm_relative_pose(window_size, f, rR, rT, l)) return 1;
+    *l_out = l;
+    const int fn = window_size + 1;
+    std::vector<Q> q(fn);
+    std::vector<V3> Tv(fn);
+    std::map<int, V3> tracked;
+    SfmStats st;
+    if (!sfm_construct(fn, q.data(), Tv.data(), l, rR, rT, f, tracked, &st)) return 2;
+    for (int i = 0; i < fn; i++) {
+        q_out[4 * i] = q[i].w; q_out[4 * i + 1] = q[i].x; q_out[4 * i + 2] = q[i].y; q_out[4 * i + 3] = q[i].z;
+        T_out[3 * i] = Tv[i].x; T_out[3 * i + 1] = Tv[i].y; T_out[3 * i + 2] = Tv[i].z;
+    }
+    for (int i = 0; i < nf; i++) { pts_out[4 * i] = f[i].state; for (int k = 0; k < 3; k++) pts_out[4 * i + 1 + k] = f[i].position[k]; }
+    stats_out[0] = st.iterations; stats_out[1] = st.initial_cost; stats_out[2] = st.final_cost; stats_out[3] = st.converged;
+    return 0;
+}
 void ovio_tangent_basis(const double *g0, double *b, double *c) {
     V3 bb, cc;
     tangent_basis(V3(g0[0], g0[1], g0[2]), bb, cc);

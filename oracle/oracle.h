@@ -251,6 +251,22 @@ void tangent_basis(const om::V3 &g0, om::V3 &b, om::V3 &c);
 void refine_gravity_with_depth(const std::vector<AlignFrame> &f, const om::V3 &tic, double g_norm, om::V3 &g, std::vector<double> &x);
 bool linear_alignment_with_depth(const std::vector<AlignFrame> &f, const om::V3 &tic, double g_norm, om::V3 &g, std::vector<double> &x);
 void align_window_to_gravity(int n, om::V3 *Ps, om::M3 *Rs, om::V3 *Vs, const std::vector<double> &x, const om::V3 &tic, om::V3 &g);
+struct SfmFeature {  // initial_sfm.h:12-22
+    bool state = false;
+    int id = 0;
+    std::vector<std::pair<int, std::array<double, 2>>> observation;  // (frame, normalised point)
+    std::vector<std::pair<int, double>> observation_depth;           // (frame, depth in metres)
+    double position[3] = {0, 0, 0};
+};
+struct SfmStats { int iterations = 0, points = 0; double initial_cost = 0, final_cost = 0; bool converged = false; };
+// GlobalSFM::construct: q[i] / T[i] = rotation / position of camera i in the frame of camera l
+bool sfm_construct(int frame_num, om::Q *q, om::V3 *T, int l, const om::M3 &relative_R, const om::V3 &relative_T,
+                   std::vector<SfmFeature> &sfm_f, std::map<int, om::V3> &sfm_tracked_points, SfmStats *stats = nullptr);
+bool sfm_relative_pose(int window_size, const std::vector<SfmFeature> &sfm_f, om::M3 &relative_R, om::V3 &relative_T, int &l);
+// SfM front (restated OpenCV routines, see oracle/initial.cpp): camera_point = R X + t
+bool solve_pnp_iterative(const std::vector<om::V3> &obj, const std::vector<std::array<double, 2>> &img, om::M3 &R, om::V3 &t);
+bool solve_pnp_ransac_epnp(const std::vector<om::V3> &obj, const std::vector<std::array<double, 2>> &img, int max_iters, double thresh,
+                           double confidence, om::M3 &R, om::V3 &t, std::vector<uint8_t> &inliers);
 
 // ------------------------------------------------------------------------------------ nodelet-side driver
 // Restates the parts of estimator_nodelet.cpp:192-459 (process_tracker) and :462-568 (process) that sit between

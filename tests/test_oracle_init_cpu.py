@@ -150,3 +150,118 @@ def test_window_hand_over_is_gravity_aligned_with_zero_yaw(orc):
         assert np.abs(Rk @ Rk.T - np.eye(3)).max() < 1e-12
         # relative rotation between window frames is untouched
         assert np.abs(R0.T @ Rk - truth[0][2].T @ R).max() < 1e-9
+
+
+# ------------------------------------------------------------------------------------------------ SfM front (restated OpenCV / Ceres)
+@pytest.fixture(scope="module")
+def sfm(orc):
+    orc.ovio_solve_pnp_iterative.argtypes = [C.c_int] + [C.c_void_p] * 4
+    orc.ovio_solve_pnp_ransac_epnp.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    orc.ovio_sfm_window.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 8
+    return orc
+
+
+def scene(n, seed):
+    rng = np.random.default_rng(seed)
+    X = np.c_[rng.uniform(-2, 2, n), rng.uniform(-1.5, 1.5, n), rng.uniform(2, 7, n)]
+    Rt, tt = rot([0.3, -1, 0.2], 0.25), np.array([0.3, -0.1, 0.2])
+    Y = X @ Rt.T + tt
+    return rng, np.ascontiguousarray(X), np.ascontiguousarray(Y[:, :2] / Y[:, 2:3]), Rt, tt
+
+
+def test_pnp_refinement_converges_from_a_rough_guess(sfm):
+    """cv::solvePnP(ITERATIVE, useExtrinsicGuess) restated: Levenberg-Marquardt from the guess to the exact pose (the inputs go
+    through float32 like cv::Point3f / Point2f, hence 1e-6 rather than 1e-12)."""
+    rng, X, m, Rt, tt = scene(40, 1)
+    R = np.ascontiguousarray(rot([0.3, -1, 0.2], 0.10))
+    t = np.array([0.15, 0.05, 0.05])
+    assert sfm.ovio_solve_pnp_iterative(len(X), X.ctypes.data, m.ctypes.data, R.ctypes.data, t.ctypes.data) == 1
+    assert np.abs(R - Rt).max() < 1e-6 and np.abs(t - tt).max() < 1e-6
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12
+    # fewer than 4 points: cv::solvePnP asserts; the restatement reports failure
+    assert sfm.ovio_solve_pnp_iterative(3, X.ctypes.data, m.ctypes.data, R.ctypes.data, t.ctypes.data) == 0
+
+
+def test_epnp_ransac_rejects_outliers_and_recovers_the_pose(sfm):
+    rng, X, m, Rt, tt = scene(60, 5)
+    bad = rng.choice(60, 15, replace=False)
+    m2 = m.copy()
+    m2[bad] += rng.uniform(0.05, 0.3, (15, 2)) * rng.choice([-1, 1], (15, 2))
+    R, t, inl = np.zeros((3, 3)), np.zeros(3), np.zeros(60, np.uint8)
+    ok = sfm.ovio_solve_pnp_ransac_epnp(60, X.ctypes.data, m2.ctypes.data, 100, 1 / 460, 0.99, R.ctypes.data, t.ctypes.data, inl.ctypes.data)
+    assert ok == 1
+    assert inl[bad].sum() == 0 and inl.sum() == 45          # every outlier is 23 px or more away, every clean point is exact
+    assert np.abs(R - Rt).max() < 1e-6 and np.abs(t - tt).max() < 1e-6
+    # deterministic: cv::RNG(-1) restated, the same subsets every call
+    R2, t2, inl2 = np.zeros((3, 3)), np.zeros(3), np.zeros(60, np.uint8)
+    sfm.ovio_solve_pnp_ransac_epnp(60, X.ctypes.data, m2.ctypes.data, 100, 1 / 460, 0.99, R2.ctypes.data, t2.ctypes.data, inl2.ctypes.data)
+    assert np.array_equal(R, R2) and np.array_equal(t, t2) and np.array_equal(inl, inl2)
+    # fewer points than the 5-point EPnP model
+    assert sfm.ovio_solve_pnp_ransac_epnp(4, X.ctypes.data, m.ctypes.data, 100, 1 / 460, 0.99, R.ctypes.data, t.ctypes.data, inl.ctypes.data) == 0
+
+
+def window_tracks(W, nf, step, noise_px, depth_noise, seed, rot_rate=0.03):
+    """feature tracks of a camera that moves sideways by `step` metres per frame with a slow rotation"""
+    rng = np.random.default_rng(seed)
+    Rwc = [rot([0, 1, 0], rot_rate * k) @ rot([1, 0, 0], rot_rate / 3 * k) for k in range(W + 1)]
+    pwc = [np.array([step * k, 0.15 * step * np.sin(k), 0.25 * step * k]) for k in range(W + 1)]
+    X = np.c_[rng.uniform(-3, 4, nf), rng.uniform(-2, 2, nf), rng.uniform(2.5, 8, nf)]
+    start, nobs, obs = [], [], []
+    for i in range(nf):
+        s = int(rng.integers(0, 3))
+        e = W if rng.random() < 0.8 else int(rng.integers(s + 1, W + 1))
+        o = []
+        for k in range(s, e + 1):
+            Y = Rwc[k].T @ (X[i] - pwc[k])
+            if Y[2] < 0.2:
+                break
+            nz = rng.normal(0, noise_px / 460, 2) if noise_px > 0 else np.zeros(2)
+            o.append([Y[0] / Y[2] + nz[0], Y[1] / Y[2] + nz[1], Y[2] * (1 + (rng.normal(0, depth_noise) if depth_noise > 0 else 0))])
+        if len(o) >= 2:
+            start.append(s); nobs.append(len(o)); obs += o
+    return (np.array(start, np.int32), np.array(nobs, np.int32), np.ascontiguousarray(np.array(obs)), Rwc, pwc, X)
+
+
+def run_sfm(sfm, W, start, nobs, obs):
+    nf = len(start)
+    l = C.c_int(-1)
+    q, T, pts, st = np.zeros((W + 1, 4)), np.zeros((W + 1, 3)), np.zeros((nf, 4)), np.zeros(4)
+    rc = sfm.ovio_sfm_window(W, nf, start.ctypes.data, nobs.ctypes.data, obs.ctypes.data, C.byref(l), q.ctypes.data, T.ctypes.data,
+                             pts.ctypes.data, st.ctypes.data)
+    return rc, l.value, q, T, pts, st
+
+
+def q2R(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+@pytest.mark.parametrize("noise_px,depth_noise,tol_R,tol_T", [(0.0, 0.0, 2e-6, 2e-5), (0.3, 0.005, 4e-3, 2e-2)])
+def test_sfm_window_recovers_the_camera_poses(sfm, noise_px, depth_noise, tol_R, tol_T):
+    """relativePose + GlobalSFM::construct (PnP chain, depth-checked triangulation, bundle adjustment): poses of all window frames
+    in the frame of camera l.  Exact data: limited by the float32 round trip of the PnP inputs; noisy data: at the noise level."""
+    W = 10
+    start, nobs, obs, Rwc, pwc, X = window_tracks(W, 160, 0.12, noise_px, depth_noise, 2)
+    rc, l, q, T, pts, st = run_sfm(sfm, W, start, nobs, obs)
+    assert rc == 0
+    assert l == 0                                   # first frame whose parallax to the newest frame exceeds 30 px
+    assert pts[:, 0].sum() > 0.9 * len(start)
+    assert st[3] == 1 or st[2] < 5e-3               # ceres CONVERGENCE or final_cost < 5e-3 (initial_sfm.cpp:385)
+    assert st[2] <= st[1] * (1 + 1e-12)
+    for k in range(W + 1):
+        Rrel, prel = Rwc[l].T @ Rwc[k], Rwc[l].T @ (pwc[k] - pwc[l])
+        assert np.abs(q2R(q[k]) - Rrel).max() < tol_R, k
+        assert np.abs(T[k] - prel).max() < tol_T, k
+        assert abs(np.linalg.norm(q[k]) - 1) < 1e-9
+
+
+def test_sfm_window_needs_parallax_and_correspondences(sfm):
+    W = 10
+    # 4 mm and 0.5 mrad per frame: < 30 px of (not rotation-compensated) parallax between any frame and the newest one
+    start, nobs, obs, *_ = window_tracks(W, 160, 0.004, 0.0, 0.0, 3, rot_rate=0.0005)
+    rc, *_ = run_sfm(sfm, W, start, nobs, obs)
+    assert rc == 1
+    start, nobs, obs, *_ = window_tracks(W, 18, 0.12, 0.0, 0.0, 4)      # at most 18 correspondences (> 20 required)
+    rc, *_ = run_sfm(sfm, W, start, nobs, obs)
+    assert rc == 1
