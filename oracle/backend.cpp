@@ -350,6 +350,8 @@ Estimator::Estimator(const Config &c) : cfg(c), W(c.window_size) {
 }
 Estimator::~Estimator() {
     for (int i = 0; i <= MAXW; i++) delete pre_integrations[i];
+    for (auto &it : all_image_frame) delete it.second.pre_integration;
+    delete tmp_pre_integration;
 }
 void Estimator::clearState() {  // estimator.cpp:43-116
     imu_buf.clear();
@@ -374,6 +376,11 @@ void Estimator::clearState() {  // estimator.cpp:43-116
     initFirstPoseFlag = false;
     prevTime = -1;
     latest_Bg = V3();
+    for (auto &it : all_image_frame) delete it.second.pre_integration;
+    all_image_frame.clear();
+    delete tmp_pre_integration;
+    tmp_pre_integration = nullptr;
+    initial_timestamp = 0;
 }
 void Estimator::inputIMU(double t, const V3 &acc, const V3 &gyr) {  // :1749-1766 (predict() path is output-only)
     imu_buf.push_back(ImuSample{t, acc, gyr});
@@ -419,8 +426,10 @@ void Estimator::processIMU(double dt, const V3 &acc, const V3 &gyr) {  // :118-1
     if (!first_imu) { first_imu = true; acc_0 = acc; gyr_0 = gyr; }
     if (!pre_integrations[frame_count])
         pre_integrations[frame_count] = new Integration(cfg, acc_0, gyr_0, Bas[frame_count], Bgs[frame_count]);
+    if (cfg.dynamic_init && solver_flag == 0 && !tmp_pre_integration) tmp_pre_integration = new Integration(cfg, acc_0, gyr_0, Bas[frame_count], Bgs[frame_count]);
     if (frame_count != 0) {
         pre_integrations[frame_count]->push_back(dt, acc, gyr);
+        if (tmp_pre_integration) tmp_pre_integration->push_back(dt, acc, gyr);  // :137 (only the dynamic initialisation reads it)
         int j = frame_count;
         V3 un_acc_0 = Rs[j] * (acc_0 - Bas[j]) - g;
         V3 un_gyr = 0.5 * (gyr_0 + gyr) - Bgs[j];
@@ -1332,9 +1341,18 @@ void Estimator::optimization() {  // estimator.cpp:1161-1578
 // ------------------------------------------------------------------ window management
 void Estimator::slideWindow() {  // estimator.cpp:1580-1689
     if (marginalization_flag == 0) {
+        const double t_0 = Headers[0];
         back_R0 = Rs[0];
         back_P0 = Ps[0];
         if (frame_count == W) {
+            if (!all_image_frame.empty()) {  // :1633-1644: drop every image frame up to and including the old frame 0
+                auto it_0 = all_image_frame.find(t_0);
+                if (it_0 != all_image_frame.end()) {
+                    for (auto it = all_image_frame.begin(); it != it_0; ++it) delete it->second.pre_integration;
+                    delete it_0->second.pre_integration;
+                    all_image_frame.erase(all_image_frame.begin(), std::next(it_0));
+                }
+            }
             for (int i = 0; i < W; i++) {
                 Headers[i] = Headers[i + 1];
                 std::swap(Ps[i], Ps[i + 1]);
@@ -1429,7 +1447,39 @@ int Estimator::processImage(std::map<int, std::array<double, 7>> &image, const u
         prevTime = curTime;
         if (imu_head > 4096) { imu_buf.erase(imu_buf.begin(), imu_buf.begin() + imu_head); imu_head = 0; }
     }
-    if (solver_flag == 0) {
+    if (cfg.dynamic_init && solver_flag == 0) {  // :203-206 (all_image_frame is only read by the dynamic initialisation)
+        ImageFrameO fr;
+        for (auto &kv : image) fr.points[kv.first] = {kv.second[0], kv.second[1]};
+        fr.pre_integration = tmp_pre_integration;
+        all_image_frame[stamp] = fr;
+        tmp_pre_integration = new Integration(cfg, acc_0, gyr_0, Bas[frame_count], Bgs[frame_count]);
+    }
+    if (solver_flag == 0 && cfg.dynamic_init) {
+        // dynamic initialisation :230-259
+        if (frame_count == W) {
+            bool result = false;
+            if (cfg.estimate_extrinsic != 2 && (stamp - initial_timestamp) > 0.1) {
+                init_attempts++;
+                result = initialStructure();
+                if (!result) init_failures++;
+                initial_timestamp = stamp;
+            }
+            if (result) {
+                solver_flag = 1;
+                triangulateWithDepth();  // solveOdometry :921-933
+                optimization();
+                slideWindow();
+                removeFailures();
+                last_R = Rs[W]; last_P = Ps[W]; last_R0 = Rs[0]; last_P0 = Ps[0];
+                for (auto &it : all_image_frame) delete it.second.pre_integration;  // not read again once NON_LINEAR
+                all_image_frame.clear();
+                delete tmp_pre_integration;
+                tmp_pre_integration = nullptr;
+            } else
+                slideWindow();
+        } else
+            frame_count++;
+    } else if (solver_flag == 0) {
         // static_init / depth branch :260-316
         triangulateWithDepth();
         if (frame_count == W) {

@@ -6,8 +6,8 @@
 //   the state hand-over at the end of Estimator::visualInitialAlignWithDepth   estimator/estimator.cpp:839-869
 // The structure-from-motion front of that initialisation (relativePose / solveRelativeRT_PNP / GlobalSFM::construct,
 // estimator.cpp:384-463, 884-920) follows further down with restatements of cv::solvePnP, cv::solvePnPRansac (EPnP) and the
-// Ceres bundle adjustment.  Not built yet: the glue inside Estimator::initialStructure (all_image_frame bookkeeping, the
-// per-image-frame solvePnP loop of estimator.cpp:466-548) and the static_init: 0 branch of processImage.
+// Ceres bundle adjustment, and Estimator::initialStructure / visualInitialAlignWithDepth at the end of the file; the
+// static_init: 0 branch of processImage and the all_image_frame bookkeeping live in backend.cpp (Config::dynamic_init).
 // Parity status: "parity unpinned" (no reference tests / golden vectors; Eigen's LDLT is un-vendored: restated as a pivoted LDL^T).
 #include "oracle.h"
 
@@ -1042,6 +1042,141 @@ bool sfm_relative_pose(int window_size, const std::vector<SfmFeature> &sfm_f, M3
         return true;
     }
     return false;
+}
+
+}  // namespace ovio
+
+// =====================================================================================================================
+// Estimator::initialStructure (estimator.cpp:384-579) and Estimator::visualInitialAlignWithDepth (:799-869)
+namespace ovio {
+
+bool Estimator::initialStructure() {
+    // IMU excitation check (:386-420); sum_g is not initialised upstream: zero here.  Only gates the Bas estimate.
+    bool is_imu_excited = false;
+    {
+        V3 sum_g;
+        const int nf = (int)all_image_frame.size() - 1;
+        for (auto it = std::next(all_image_frame.begin()); it != all_image_frame.end(); ++it)
+            sum_g = sum_g + it->second.pre_integration->delta_v / it->second.pre_integration->sum_dt;
+        V3 aver_g = sum_g * (1.0 / nf);
+        double var = 0;
+        for (auto it = std::next(all_image_frame.begin()); it != all_image_frame.end(); ++it) {
+            V3 d = it->second.pre_integration->delta_v / it->second.pre_integration->sum_dt - aver_g;
+            var += dot(d, d);
+        }
+        var = std::sqrt(var / nf);
+        if (!(var < 0.25)) is_imu_excited = true;
+    }
+    // global SfM (:422-463)
+    std::vector<SfmFeature> sfm_f;
+    for (const Landmark &lm : feature) {
+        SfmFeature f;
+        f.id = lm.feature_id;
+        int imu_j = lm.start_frame - 1;
+        for (const Obs &o : lm.obs) {
+            imu_j++;
+            f.observation.push_back({imu_j, {o.x, o.y}});
+            f.observation_depth.push_back({imu_j, o.depth});
+        }
+        sfm_f.push_back(f);
+    }
+    M3 relative_R;
+    V3 relative_T;
+    int l = 0;
+    if (!sfm_relative_pose(W, sfm_f, relative_R, relative_T, l)) return false;
+    std::vector<Q> Qs(frame_count + 1);
+    std::vector<V3> Ts(frame_count + 1);
+    std::map<int, V3> sfm_tracked_points;
+    if (!sfm_construct(frame_count + 1, Qs.data(), Ts.data(), l, relative_R, relative_T, sfm_f, sfm_tracked_points)) {
+        marginalization_flag = 0;  // MARGIN_OLD
+        return false;
+    }
+    // PnP for every image frame (:466-548)
+    {
+        int i = 0;
+        for (auto it = all_image_frame.begin(); it != all_image_frame.end(); ++it) {
+            if (it->first == Headers[i]) {
+                it->second.is_key_frame = true;
+                it->second.R = toR(Qs[i]) * T(ric);
+                it->second.T = Ts[i];
+                i++;
+                continue;
+            }
+            if (it->first > Headers[i]) i++;
+            M3 R_initial = toR(inverse(Qs[i]));
+            V3 P_initial = -1.0 * (R_initial * Ts[i]);
+            it->second.is_key_frame = false;
+            std::vector<V3> pts3;
+            std::vector<std::array<double, 2>> pts2;
+            for (auto &kv : it->second.points) {
+                auto f = sfm_tracked_points.find(kv.first);
+                if (f == sfm_tracked_points.end()) continue;
+                pts3.push_back(f->second);
+                pts2.push_back(kv.second);
+            }
+            if (pts3.size() < 6) return false;
+            if (!solve_pnp_iterative(pts3, pts2, R_initial, P_initial)) return false;
+            M3 R_pnp = T(R_initial);
+            V3 T_pnp = R_pnp * (-1.0 * P_initial);
+            it->second.R = R_pnp * T(ric);
+            it->second.T = T_pnp;
+        }
+    }
+    if (!visualInitialAlignWithDepth()) return false;
+    if (!is_imu_excited) {  // :552-570 accelerometer bias from the mean specific force
+        V3 sum_a;
+        for (auto it = std::next(all_image_frame.begin()); it != all_image_frame.end(); ++it)
+            sum_a = sum_a + it->second.pre_integration->delta_v / it->second.pre_integration->sum_dt;
+        V3 avg_a = sum_a * (1.0 / ((int)all_image_frame.size() - 1));
+        V3 tmp_Bas = avg_a - T(g2R(avg_a)) * V3(0, 0, cfg.g_norm);  // g2R(avg_a).inverse() * G
+        for (int i = 0; i <= W; i++) Bas[i] = tmp_Bas;
+    }
+    return true;
+}
+
+bool Estimator::visualInitialAlignWithDepth() {
+    // solveGyroscopeBias over all image frames (initial_aligment.cpp:3-36)
+    {
+        double A[3][3] = {{0}}, b[3] = {0};
+        for (auto fi = all_image_frame.begin(); std::next(fi) != all_image_frame.end(); ++fi) {
+            auto fj = std::next(fi);
+            Q q_ij = fromR(T(fi->second.R) * fj->second.R);
+            M3 tA;
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) tA(r, c) = fj->second.pre_integration->jacobian[3 + r][12 + c];  // O_R, O_BG
+            V3 tb = 2.0 * (inverse(fj->second.pre_integration->delta_q) * q_ij).vec();
+            M3 AtA = T(tA) * tA;
+            V3 Atb = T(tA) * tb;
+            for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) A[r][c] += AtA(r, c); b[r] += Atb[r]; }
+        }
+        std::vector<double> Av(9), bv(3);
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) Av[3 * r + c] = A[r][c]; bv[r] = b[r]; }
+        std::vector<double> x = ldlt_solve(Av, bv, 3);
+        V3 dbg(x[0], x[1], x[2]);
+        for (int i = 0; i <= W; i++) Bgs[i] = Bgs[i] + dbg;
+        for (auto fi = all_image_frame.begin(); std::next(fi) != all_image_frame.end(); ++fi)
+            std::next(fi)->second.pre_integration->repropagate(V3(), Bgs[0]);
+    }
+    std::vector<AlignFrame> fr;
+    for (auto &it : all_image_frame) {
+        AlignFrame a;
+        a.R = it.second.R; a.T = it.second.T;
+        if (it.second.pre_integration) { a.sum_dt = it.second.pre_integration->sum_dt; a.delta_p = it.second.pre_integration->delta_p; a.delta_v = it.second.pre_integration->delta_v; }
+        fr.push_back(a);
+    }
+    std::vector<double> x;
+    V3 gg;
+    if (!linear_alignment_with_depth(fr, tic, cfg.g_norm, gg, x)) return false;
+    g = gg;
+    for (int i = 0; i <= W; i++) pre_integrations[i]->repropagate(V3(), Bgs[i]);
+    for (int i = 0; i <= frame_count; i++) {
+        ImageFrameO &f = all_image_frame[Headers[i]];
+        Ps[i] = f.T; Rs[i] = f.R;
+        f.is_key_frame = true;
+    }
+    for (int i = 0; i <= W; i++) pre_integrations[i]->repropagate(V3(), Bgs[i]);  // repeated upstream (:833-836)
+    // positions / velocities / gravity alignment (:839-869); the key-frame counter indexes x (quirk, see align_window_to_gravity)
+    align_window_to_gravity(frame_count + 1, Ps, Rs, Vs, x, tic, g);
+    return true;
 }
 
 }  // namespace ovio

@@ -28,7 +28,8 @@ struct Config {
     int max_iterations = 8;            // NUM_ITERATIONS
     int ransac_max_iters = 1000;
     int lk_max_level = 1;              // IMU-aided call uses maxLevel=1 (feature_tracker.cpp:303)
-    int reserved0 = 0;
+    int dynamic_init = 0;              // = !STATIC_INIT (parameters.cpp:167): 0 = gyro-bias + optimisation on the IMU-propagated window (the built hot
+                                       // path), 1 = SfM + visual-inertial alignment (oracle only).  Occupies vio_config.reserved0 (always 0 in the product).
     double fx = 604.5821781259577, fy = 604.2544712985845, cx = 321.2638233484251, cy = 239.70969315130674;
     double k1 = 0.13387871564774004, k2 = -0.2731913133377051, p1 = 0.0020296263577681264, p2 = -0.00044384544608203714;
     double focal_length = 460.0;       // FOCAL_LENGTH
@@ -190,6 +191,20 @@ struct Estimator {
     std::vector<uint8_t> prior_present;  // per block: W poses, sb0, ex, td
     SolveStats last_stats;
     int reboot_count = 0;
+    // dynamic initialisation (static_init == 0): every image frame since start-up / the oldest window frame (estimator.h all_image_frame)
+    struct ImageFrameO {
+        std::map<int, std::array<double, 2>> points;  // feature id -> normalised point
+        om::M3 R;                                     // body rotation in the SfM frame
+        om::V3 T;                                     // camera position in the SfM frame
+        Integration *pre_integration = nullptr;       // from the previous image frame
+        bool is_key_frame = false;
+    };
+    std::map<double, ImageFrameO> all_image_frame;
+    Integration *tmp_pre_integration = nullptr;
+    double initial_timestamp = 0;
+    int init_attempts = 0, init_failures = 0;         // diagnostics
+    bool initialStructure();
+    bool visualInitialAlignWithDepth();
 
     explicit Estimator(const Config &c);
     ~Estimator();

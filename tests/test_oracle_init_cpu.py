@@ -265,3 +265,38 @@ def test_sfm_window_needs_parallax_and_correspondences(sfm):
     start, nobs, obs, *_ = window_tracks(W, 18, 0.12, 0.0, 0.0, 4)      # at most 18 correspondences (> 20 required)
     rc, *_ = run_sfm(sfm, W, start, nobs, obs)
     assert rc == 1
+
+
+# ------------------------------------------------------------------------------------------------ end to end (oracle pipeline)
+@pytest.mark.parametrize("seq", [3, 11])
+def test_dynamic_initialisation_end_to_end(P, seq):
+    """static_init: 0 branch of processImage (estimator.cpp:230-259) in the oracle: a sequence that moves from the first frame
+    initialises through SfM + visual-inertial alignment as soon as the window is full and then tracks at least as well as the
+    static branch does on the same data.  (vio_config.reserved0 carries the oracle-only switch; the product rejects such
+    configurations, see dataio.config_from_yaml.)"""
+    res = {}
+    for dyn in (1, 0):
+        cfg = P.canonical_config()
+        cfg.reserved0 = dyn
+        sc = vio_ct.synth_like(cfg)
+        sc.t_static = 0.0
+        syn = P.Synth(sc)
+        F = 40
+        o = vio_ct.OraclePipeline(cfg)
+        o.push_imu(*syn.imu(seq, F * 20 + 64))
+        traj, gt, first, v_err = [], [], None, None
+        for f, t in enumerate(vio_ct.frame_times(sc, F)):
+            g, d = syn.render_host(seq, float(t))
+            r = o.feed(g, d, float(t))
+            st = o.status()
+            if st["solver_flag"] == 1 and first is None:
+                first = f
+            if st["solver_flag"] == 1 and r == 1:
+                traj.append(o.window()[cfg.window_size, :3].copy())
+                gt.append(syn.pose(seq, float(t))[0])
+        res[dyn] = (first, vio_ct.ate_rmse(np.array(traj), np.array(gt)), len(traj))
+    first, ate, n = res[1]
+    assert first == 13                      # first-image skip + init_pub + init_feature + 11 window frames
+    assert n == 40 - 13
+    assert ate < 0.03
+    assert ate < 1.5 * res[0][1] + 0.005    # not worse than the static branch on the same moving-start data
