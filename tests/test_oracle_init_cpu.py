@@ -300,3 +300,29 @@ def test_dynamic_initialisation_end_to_end(P, seq):
     assert n == 40 - 13
     assert ate < 0.03
     assert ate < 1.5 * res[0][1] + 0.005    # not worse than the static branch on the same moving-start data
+
+
+def test_dynamic_initialisation_waits_for_parallax(P):
+    """A sequence that rests for 1.5 s: the first full windows have no parallax (relativePose fails, the window keeps sliding and
+    all_image_frame grows beyond the window: the per-image-frame solvePnP loop and the erase in slideWindow are exercised); the
+    initialisation succeeds once the camera has moved."""
+    cfg = P.canonical_config()
+    cfg.reserved0 = 1
+    sc = vio_ct.synth_like(cfg)
+    sc.t_static = 1.5
+    syn = P.Synth(sc)
+    F, seq = 45, 3
+    o = vio_ct.OraclePipeline(cfg)
+    o.push_imu(*syn.imu(seq, F * 20 + 64))
+    traj, gt, first = [], [], None
+    for f, t in enumerate(vio_ct.frame_times(sc, F)):
+        g, d = syn.render_host(seq, float(t))
+        r = o.feed(g, d, float(t))
+        st = o.status()
+        if st["solver_flag"] == 1 and first is None:
+            first = f
+        if st["solver_flag"] == 1 and r == 1:
+            traj.append(o.window()[cfg.window_size, :3].copy())
+            gt.append(syn.pose(seq, float(t))[0])
+    assert first is not None and 15 < first < 30
+    assert vio_ct.ate_rmse(np.array(traj), np.array(gt)) < 0.03
