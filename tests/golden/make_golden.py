@@ -95,6 +95,25 @@ def pipeline_fixture(P):
     print("pipeline: published", len(frames), "ATE", vio_ct.ate_rmse(Pw, np.array(o["gt"])))
 
 
+def dynamic_init_fixture(P):
+    """Moving-start sequence through the oracle's static_init: 0 branch (SfM + visual-inertial alignment): the window right after the
+    initialisation and the published trajectory.  Vectors for the HIP side of SURVEY.md 8f rank 1 (not built yet) and drift detection."""
+    cfg = P.canonical_config()
+    cfg.reserved0 = 1
+    sc = vio_ct.synth_like(cfg)
+    sc.t_static = 0.0
+    n = 30
+    o = vio_ct.run_oracle_sequence(cfg, sc, 3, n)
+    frames = np.array([x[0] for x in o["traj"]], np.int32)
+    Pw = np.array([x[1] for x in o["traj"]])
+    Qw = np.array([x[2] for x in o["traj"]])
+    Vw = np.array([x[3] for x in o["traj"]])
+    st = np.array([[s["solver_flag"], s["frame_count"], s["marginalization_flag"], s["n_landmarks"]] for s in o["status"]], np.int32)
+    np.savez_compressed(os.path.join(HERE, "dynamic_init_regression.npz"), seq=3, n_frames=n, t_static=0.0, frames=frames, P=Pw, Q=Qw, V=Vw,
+                        status=st, gt=np.array(o["gt"]))
+    print("dynamic init: first published frame", frames[0], "ATE", vio_ct.ate_rmse(Pw, np.array(o["gt"])))
+
+
 if __name__ == "__main__":
     P, orc = vio_ct.pkg(), vio_ct.oracle()
     fast_fixture(orc)
@@ -102,3 +121,4 @@ if __name__ == "__main__":
     lk_fixture(orc)
     factor_fixture(P, orc)
     pipeline_fixture(P)
+    dynamic_init_fixture(P)

@@ -78,3 +78,20 @@ def test_pipeline_regression_fixture(P):
     ids, cnt, cur, _, _ = o["oracle"].tracks()
     assert np.array_equal(ids, d["track_ids"]) and np.array_equal(cnt, d["track_cnt"])
     assert vio_ct.ate_rmse(Pw, d["gt"]) < 0.02
+
+
+def test_dynamic_init_regression_fixture(P):
+    """static_init: 0 branch of the oracle on a moving-start sequence (vectors for the future HIP side of SURVEY.md 8f rank 1)"""
+    d = np.load(os.path.join(G, "dynamic_init_regression.npz"))
+    cfg = P.canonical_config()
+    cfg.reserved0 = 1
+    sc = vio_ct.synth_like(cfg)
+    sc.t_static = float(d["t_static"])
+    o = vio_ct.run_oracle_sequence(cfg, sc, int(d["seq"]), int(d["n_frames"]))
+    assert np.array_equal(np.array([x[0] for x in o["traj"]], np.int32), d["frames"])
+    st = np.array([[s["solver_flag"], s["frame_count"], s["marginalization_flag"], s["n_landmarks"]] for s in o["status"]], np.int32)
+    assert np.array_equal(st, d["status"])
+    Pw = np.array([x[1] for x in o["traj"]])
+    Vw = np.array([x[3] for x in o["traj"]])
+    assert np.abs(Pw - d["P"]).max() < 1e-8 and np.abs(Vw - d["V"]).max() < 1e-7
+    assert vio_ct.ate_rmse(Pw, d["gt"]) < 0.02
