@@ -1,20 +1,35 @@
-// Drives the C++ mirror (include/vio_adapter.hpp) the way EstimatorNodelet::process_tracker / process do for one camera, on the
-// synthetic workload.  Build:  g++ -std=c++11 -Iinclude examples/adapter_demo.cpp -Lvins-rgbd-fast_amd -lvio_hip -Wl,-rpath,$PWD/vins-rgbd-fast_amd
-// Prints one line per NON_LINEAR frame: stamp px py pz  (tests/test_gpu_adapter.py compares it with the ctypes path).
+// Drives the C++ mirror (include/vio_adapter.hpp) the way EstimatorNodelet does for one camera, on the synthetic workload:
+// process_tracker (stream checks, frequency control, predictMotion + readImage, updateID loop, feature-map packaging into
+// feature_buf, estimator_nodelet.cpp:192-459) and process (pop feature_buf, inputDepth, processImage, :462-549), with the
+// estimator allowed to lag the tracker by `lag` frames like the reference's second thread does.
+// Build:  g++ -std=c++11 -Iinclude examples/adapter_demo.cpp -Lvins-rgbd-fast_amd -lvio_hip -Wl,-rpath,$PWD/vins-rgbd-fast_amd
+// Usage:  adapter_demo [seq] [n_frames] [cam_rate] [freq] [frontend_freq] [lag]
+// Prints one line per NON_LINEAR frame: stamp px py pz n_tracks  (tests/test_gpu_adapter.py compares it with the oracle).
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <vector>
 
 #include "vio_adapter.hpp"
 #include "vio_synth.h"
 
+struct QueuedFrame {  // feature_buf entry: ((header, depth_msg), image)
+    double header;
+    std::vector<uint16_t> depth;
+    vio_hip::FeatureMap image;
+};
+
 int main(int argc, char **argv) {
     const int seq = argc > 1 ? std::atoi(argv[1]) : 2, n_frames = argc > 2 ? std::atoi(argv[2]) : 22;
+    const double cam_rate = argc > 3 ? std::atof(argv[3]) : 0.0;
+    const int FREQ = argc > 4 ? std::atoi(argv[4]) : 10, FRONTEND_FREQ = argc > 5 ? std::atoi(argv[5]) : 30;
+    const size_t lag = argc > 6 ? (size_t)std::atoi(argv[6]) : 0;
     vio_config cfg;
     vio_config_default(&cfg);
     cfg.fix_depth = 0; cfg.depth_max = 10.0;  // the 150-feature setting used by bench.py (canonical_config)
     vio_synth_config sc;
     vio_synth_config_default(&sc);
+    if (cam_rate > 0) sc.cam_rate = cam_rate;
     const int nimu = (int)(n_frames / sc.cam_rate * sc.imu_rate) + 64;
     std::vector<double> t(nimu), acc(3 * nimu), gyr(3 * nimu);
     vio_synth_imu(&sc, seq, nimu, t.data(), acc.data(), gyr.data());
@@ -23,25 +38,65 @@ int main(int argc, char **argv) {
     try {
         vio_hip::Estimator estimator(cfg);
         vio_hip::FeatureTracker tracker(estimator);
+        vio_hip::FrameGate gate(FREQ, FRONTEND_FREQ);
         estimator.setParameter();
+        std::deque<QueuedFrame> feature_buf;
+        bool init_pub = false, init_feature = false;   // estimator_nodelet.cpp:365-377
         int k = 0;
-        bool first_image_flag = true, init_pub = false, init_feature = false;   // estimator_nodelet.cpp:234-240, :365-377
-        for (int f = 0; f < n_frames; f++) {
-            const double stamp = f / sc.cam_rate;
-            while (k < nimu && t[k] < stamp + 1.5 / sc.imu_rate) { estimator.inputIMU(t[k], &acc[3 * k], &gyr[3 * k]); k++; }  // imu_callback
-            vio_synth_render_host(&sc, seq, stamp, gray.data(), depth.data());
-            if (first_image_flag) { first_image_flag = false; continue; }   // the first image only sets the time base
-            tracker.readImage(gray.data(), stamp);                      // process_tracker (PUB_THIS_FRAME: every frame, freq 0)
-            for (unsigned i = 0;; i++) if (!tracker.updateID(i)) break;
-            if (!init_pub) { init_pub = true; continue; }               // first published frame is dropped
-            if (!init_feature) { init_feature = true; continue; }       // "skip the first detected feature, which doesn't contain optical flow speed"
-            int rc = estimator.processImage(depth.data(), stamp);       // process
-            if (rc == VIO_NEED_IMU) { std::fprintf(stderr, "frame %d: IMU not available\n", f); continue; }
-            if (estimator.solver_flag == vio_hip::Estimator::NON_LINEAR && estimator.last_status().processed) {
-                const int W = estimator.WINDOW_SIZE;
-                std::printf("%.3f %.9f %.9f %.9f %zu\n", stamp, estimator.Ps[W][0], estimator.Ps[W][1], estimator.Ps[W][2], tracker.ids.size());
+        auto process = [&](bool drain) {   // EstimatorNodelet::process: one queued frame per call unless draining
+            while (feature_buf.size() > (drain ? 0 : lag)) {
+                QueuedFrame &f = feature_buf.front();
+                estimator.f_manager.inputDepth(f.depth.data());                 // :537
+                int rc = estimator.processImage(f.image, f.header);             // :539
+                if (rc == VIO_NEED_IMU) { std::fprintf(stderr, "stamp %.3f: IMU not available\n", f.header); return; }
+                if (estimator.solver_flag == vio_hip::Estimator::NON_LINEAR && estimator.last_status().processed) {
+                    const int W = estimator.WINDOW_SIZE;
+                    std::printf("%.4f %.9f %.9f %.9f %zu\n", f.header, estimator.Ps[W][0], estimator.Ps[W][1], estimator.Ps[W][2], f.image.size());
+                }
+                feature_buf.pop_front();
             }
+        };
+        for (int fi = 0; fi < n_frames; fi++) {
+            const double time_color = fi / sc.cam_rate;
+            while (k < nimu && t[k] < time_color + 1.5 / sc.imu_rate) { estimator.inputIMU(t[k], &acc[3 * k], &gyr[3 * k]); k++; }  // imu_callback
+            vio_synth_render_host(&sc, seq, time_color, gray.data(), depth.data());
+            // ---- process_tracker
+            const double last_image_time = gate.last_image_time;
+            const vio_hip::FrameGate::Decision d = gate.step(time_color);
+            if (d == vio_hip::FrameGate::FIRST) continue;
+            if (d == vio_hip::FrameGate::RESET) {          // :243-262
+                feature_buf.clear();
+                estimator.clearState();
+                estimator.setParameter();
+                init_pub = init_feature = false;
+                continue;
+            }
+            if (d == vio_hip::FrameGate::SKIP) continue;
+            const bool PUB_THIS_FRAME = d == vio_hip::FrameGate::PUBLISH;
+            double relative_R[9];
+            estimator.predictMotion(last_image_time, time_color + estimator.td, relative_R);   // :309-313
+            tracker.readImage(gray.data(), time_color, relative_R, PUB_THIS_FRAME);
+            for (unsigned i = 0;; i++) if (!tracker.updateID(i)) break;                      // :324-330
+            if (PUB_THIS_FRAME) {
+                vio_hip::FeatureMap image;                                                   // :336-363
+                for (size_t j = 0; j < tracker.ids.size(); j++)
+                    if (tracker.track_cnt[j] > 1) {
+                        vio_hip::Vector7d v = {{tracker.cur_un_pts[j].x, tracker.cur_un_pts[j].y, 1.0, tracker.cur_pts[j].x, tracker.cur_pts[j].y,
+                                                tracker.pts_velocity[j].x, tracker.pts_velocity[j].y}};
+                        image[tracker.ids[j]] = v;
+                    }
+                if (!init_pub) init_pub = true;                                               // first published frame is dropped
+                else if (!init_feature) init_feature = true;                                  // "skip the first detected feature ..."
+                else if (!image.empty()) {
+                    QueuedFrame q;
+                    q.header = time_color; q.depth = depth; q.image.swap(image);
+                    feature_buf.push_back(std::move(q));
+                } else
+                    gate.emptyMap(time_color);
+            }
+            process(false);
         }
+        process(true);
     } catch (const std::exception &e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

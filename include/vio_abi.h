@@ -6,8 +6,9 @@
  * reference's one-Estimator-per-process use); all state lives in HBM behind the handle, configuration is per handle
  * instead of process-global.  Plain C types only; the caller owns input buffers for the duration of a call.
  *
- * Threading: a handle is not re-entrant.  vio_push_imu may be called from another thread than vio_track/vio_process
- * (internal lock), mirroring Estimator::inputIMU being called from ROS callback threads (estimator.cpp:1749-1766).
+ * Threading: a handle is not re-entrant.  vio_push_imu / vio_push_imu_batch may be called from another thread than
+ * vio_track / vio_process / vio_feed (internal lock), mirroring Estimator::inputIMU being called from ROS callback threads
+ * (estimator.cpp:1749-1766).  vio_last_error is thread-local: it reports the last failure of the CALLING thread.
  */
 #ifndef VIO_ABI_H
 #define VIO_ABI_H
@@ -31,7 +32,7 @@ typedef struct vio_config {
     int32_t width, height;          /* COL, ROW                      image_width / image_height */
     int32_t max_cnt, min_dist;      /* MAX_CNT, MIN_DIST             max_cnt / min_dist */
     int32_t grid_rows, grid_cols;   /* NUM_GRID_ROWS / NUM_GRID_COLS */
-    int32_t window_size;            /* WINDOW_SIZE (compile-time 10 upstream, parameters.h:12); 2..20 here */
+    int32_t window_size;            /* WINDOW_SIZE (compile-time 10 upstream, parameters.h:12); 4..20 here */
     int32_t max_landmarks;          /* NUM_OF_F (parameters.h:14): capacity of the landmark table */
     int32_t fix_depth;              /* FIX_DEPTH */
     int32_t estimate_extrinsic;     /* ESTIMATE_EXTRINSIC: 0 or 1 (2 = calibrate from scratch is out of scope) */
@@ -39,7 +40,9 @@ typedef struct vio_config {
     int32_t max_iterations;         /* NUM_ITERATIONS  max_num_iterations */
     int32_t ransac_max_iters;       /* cv::findFundamentalMat RANSAC iteration cap (1000) */
     int32_t lk_max_level;           /* maxLevel of calcOpticalFlowPyrLK: 1 for the IMU-aided call (feature_tracker.cpp:303) */
-    int32_t reserved0;
+    int32_t dynamic_init;           /* !STATIC_INIT (parameters.cpp:167): 0 = static initialisation (gyro-bias + optimisation on the
+                                       IMU-propagated window, estimator.cpp:266-283), 1 = SfM + visual-inertial alignment
+                                       (initialStructure, estimator.cpp:384-579) */
     double fx, fy, cx, cy, k1, k2, p1, p2; /* pinhole projection_parameters / distortion_parameters */
     double focal_length;            /* FOCAL_LENGTH = 460 (parameters.h:11) */
     double f_threshold;             /* F_THRESHOLD */
@@ -67,6 +70,12 @@ int vio_reset(vio_batch *h);
 
 /* Estimator::inputIMU(t, acc, gyr) (estimator.cpp:1749-1766) for sequence seq; n samples, t strictly increasing. */
 int vio_push_imu(vio_batch *h, int seq, int n, const double *t, const double *acc_xyz, const double *gyr_xyz);
+/* The same for every sequence in one call (SURVEY.md 8b "batched variants taking SoA pointers"): n[s] samples for sequence s,
+ * stored at t[s * stride + i], acc_xyz / gyr_xyz[(s * stride + i) * 3 + k]; n == NULL means `stride` samples for every sequence. */
+int vio_push_imu_batch(vio_batch *h, const int32_t *n, int stride, const double *t, const double *acc_xyz, const double *gyr_xyz);
+/* Estimator::clearState() + setParameter() for ONE sequence: the stream-discontinuity restart of
+ * estimator_nodelet.cpp:243-262 (tracker state, estimator state and pending IMU of that sequence are dropped). */
+int vio_reset_seq(vio_batch *h, int seq);
 
 /* One camera frame for every sequence: the body of EstimatorNodelet::process_tracker for one synchronised
  * colour+depth pair (estimator_nodelet.cpp:234-393) followed by EstimatorNodelet::process (:462-549):
@@ -85,6 +94,38 @@ int vio_track(vio_batch *h, const uint8_t *gray, const double *stamps, int publi
 int vio_process(vio_batch *h, const uint16_t *depth_mm, int on_device);
 int vio_sync(vio_batch *h);
 
+/* Per-sequence frame modes = the outcome of the nodelet's frequency control for one frame (estimator_nodelet.cpp:264-286):
+ * SKIP    the frame is dropped before readImage ("Skip this frame", :266-271): no state changes at all;
+ * TRACK   readImage with PUB_THIS_FRAME == false: LK + culling + track_cnt++ only, no RANSAC / mask / detection
+ *         (feature_tracker.cpp:351), nothing handed to processImage;
+ * PUBLISH readImage with PUB_THIS_FRAME == true + processImage. */
+enum { VIO_FRAME_SKIP = 0, VIO_FRAME_TRACK = 1, VIO_FRAME_PUBLISH = 2 };
+/* vio_feed with a mode per sequence (modes[S], host memory; NULL = PUBLISH for all). */
+int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, const uint8_t *modes, int on_device);
+/* vio_track with a mode per sequence and an optional caller-supplied relative rotation per sequence:
+ * FeatureTracker::readImage(img, cur_time, relative_R) (feature_tracker.h:36-37).  R_rel: [S][9] row-major host memory or NULL;
+ * a NaN in the first element of a sequence's matrix = predict it on the device (Estimator::predictMotion). */
+int vio_track_ex(vio_batch *h, const uint8_t *gray, const double *stamps, const uint8_t *modes, const double *R_rel, int on_device);
+/* Estimator::predictMotion(t0, t1) (estimator.cpp:1790-1860) for sequence seq on the IMU pushed so far: R[9] row-major. */
+int vio_predict_motion(vio_batch *h, int seq, double t0, double t1, double *R9);
+/* Estimator::processImage(image, header) (estimator.h:46, estimator.cpp:156-374) + FeatureManager::inputDepth with a CALLER-SUPPLIED
+ * feature map for sequence seq: n entries in ascending feature id (std::map order), xyz_uv_vel[n][7] = (x, y, z = 1, u, v, vx, vy)
+ * exactly as estimator_nodelet.cpp:336-363 packs them, depth_mm = the CV_16UC1 depth image of THAT frame (host memory), stamp =
+ * header stamp.  This is what the process thread pops from feature_buf (estimator_nodelet.cpp:380-384, 539), so the tracker may
+ * run ahead of the estimator by any number of frames.  n <= the tracker capacity (max_cnt + grid slack, see vio_get_capacity). */
+int vio_process_obs(vio_batch *h, int seq, int n, const int32_t *ids, const double *xyz_uv_vel, const uint16_t *depth_mm, double stamp);
+/* The same for the whole batch: n_obs[S] (a negative count skips the sequence), ids[S][cap], xyz_uv_vel[S][cap][7], depth_mm
+ * [S][height][width], stamps[S]; the feature arrays are host memory, depth_mm is HBM when on_device != 0. */
+int vio_process_obs_batch(vio_batch *h, const int32_t *n_obs, const int32_t *ids, const double *xyz_uv_vel, int cap,
+                          const uint16_t *depth_mm, const double *stamps, int on_device);
+/* The feature map packaged by the last vio_track / vio_feed for sequence seq (what the nodelet would push to feature_buf):
+ * returns the count (0 when the frame was not published), ids ascending. */
+int vio_get_packaged(vio_batch *h, int seq, int cap, int32_t *ids, double *xyz_uv_vel);
+/* sizeof(vio_config) (what = 0) / sizeof(vio_status) (what = 1) as compiled into the library: lets a binding check its struct mirrors */
+int vio_abi_sizeof(int what);
+/* capacities derived from the configuration: out[0] = tracker points per sequence, out[1] = landmark slots, out[2] = IMU ring */
+int vio_get_capacity(vio_batch *h, int32_t *out3);
+
 /* Results read out of the path (SURVEY.md §8b "Results read out").  All getters synchronise first. */
 typedef struct vio_status {
     int32_t code;                 /* VIO_OK / VIO_NEED_IMU / VIO_REBOOTED of the last vio_process */
@@ -99,6 +140,10 @@ typedef struct vio_status {
     int32_t n_in_problem, n_residuals, n_var_landmarks, has_prior;
     int32_t reboot_count, frames_processed;
     double initial_cost, final_cost, td;
+    int32_t overflow_flags;       /* capacity flags of the last frame: 1 landmark table, 2 IMU slot (> 64 samples per frame interval),
+                                     4 FAST candidates of a cell, 8 residual list, 16 IMU ring overwritten (code = VIO_ECAPACITY) */
+    int32_t overflow_frames;      /* frames that raised any capacity flag since the last reset / reboot */
+    int32_t iterations_total, solves_total; /* solver iterations / solves since vio_create */
 } vio_status;
 int vio_get_status(vio_batch *h, int seq, vio_status *out);
 /* window state Ps/Rs/Vs/Bas/Bgs/Headers (estimator.h:121-135): (W+1) rows of 17 doubles
@@ -106,7 +151,8 @@ int vio_get_status(vio_batch *h, int seq, vio_status *out);
 int vio_get_window(vio_batch *h, int seq, double *out);
 /* the CSV row of visualization.cpp:214-225 for every sequence: [S][11] = stamp, P(3), Q(w,x,y,z), V(3) of frame W */
 int vio_get_odometry(vio_batch *h, double *out);
-/* every CSV row written so far for sequence seq (HBM ring of 2048 rows): returns the number of rows produced */
+/* CSV rows written for sequence seq.  The device keeps a ring of the last 2048 rows: out receives the most recent min(rows, 2048,
+ * cap) of them in time order; returns the number of rows produced since vio_create / the last reset (may exceed what fits). */
 int vio_get_odometry_history(vio_batch *h, int seq, int cap, double *out);
 /* tic(3), ric(9 row-major), td */
 int vio_get_extrinsic(vio_batch *h, int seq, double *out13);
@@ -116,15 +162,20 @@ int vio_get_tracks(vio_batch *h, int seq, int cap, int32_t *ids, int32_t *track_
 /* f_manager.feature in list order: 7 doubles per landmark
  * [feature_id, start_frame, n_obs, estimated_depth, estimate_flag, solve_flag, is_dynamic]; returns total count */
 int vio_get_landmarks(vio_batch *h, int seq, int cap, double *out);
+/* the same plus what pubPointCloud reads (visualization.cpp:333-395): 12 doubles per landmark
+ * [feature_id, start_frame, n_obs, estimated_depth, estimate_flag, solve_flag, is_dynamic,
+ *  feature_per_frame[0].point (x, y, z), feature_per_frame[0].depth (metres, 0 = none), feature_per_frame.back().depth] */
+int vio_get_landmarks_ex(vio_batch *h, int seq, int cap, double *out12);
 /* last_marginalization_info in the canonical layout: returns n (0 = none) */
 int vio_get_prior(vio_batch *h, int seq, double *J_nxn, double *r_n, double *x0, uint8_t *present);
 
 /* Per-stage device time of the last vio_feed in milliseconds (hipEvent on the batch stream):
  * out[0] front-end, out[1] back-end, out[2] total; plus kernel-level entries, see DESIGN.md. Returns count. */
 int vio_get_timings(vio_batch *h, int cap, double *out_ms);
-/* Per-kernel HIP-event timing of the next max_steps vio_feed calls, recorded on the batch stream.
- * vio_profile_end: out_ms[11] = average ms of fe_begin, fe_pyrdown, fe_predict, fe_lk, fe_select, fe_fast, fe_add,
- * be_ingest, be_solve, be_marg, be_finish; returns the number of recorded steps. */
+/* Per-kernel HIP-event timing of the next max_steps vio_feed calls, recorded on the batch's streams.
+ * vio_profile_end: out_ms[10] = average ms of fe_begin, fe_pyrdown, fe_predict, fe_lk, fe_select, fe_fast, fe_add,
+ * be_ingest, be_solve, be_marg (be_finish is fused into be_marg); returns the number of recorded steps (steps driven by
+ * vio_track / vio_process instead of vio_feed are not counted). */
 int vio_profile_begin(vio_batch *h, int max_steps);
 int vio_profile_end(vio_batch *h, int cap, double *out_ms);
 /* stream the batch launches on (hipStream_t) so callers can bracket it with their own events */
@@ -150,6 +201,15 @@ int vio_stage_imu_factor(const vio_config *cfg, int n, const double *dt, const d
  * obs = 9 doubles (x,y,z,u,v,vx,vy,cur_td,depth); J = Ji(2x7) Jj(2x7) Jex(2x7) Jl(2) Jtd(2) */
 int vio_stage_projection(const vio_config *cfg, const double *pose_i, const double *pose_j, const double *ex, double inv_dep,
                          double td, const double *obs_i, const double *obs_j, int use_td, double *r2, double *J46);
+/* the same factor through the per-residual device routine the marginalisation and the outlier rejection use (the solver's hot loop
+ * uses the frame-pair form above) */
+int vio_stage_projection_residual(const vio_config *cfg, const double *pose_i, const double *pose_j, const double *ex, double inv_dep,
+                                  double td, const double *obs_i, const double *obs_j, int use_td, double *r2, double *J46);
+/* IMUFactor::Evaluate as the solver consumes it: G961 = [J r]^T [J r] (31 x 31 row-major; columns pose_i(6) speedbias_i(9) pose_j(6)
+ * speedbias_j(9) | residual) through the wavefront code of the solve kernel (split raw Jacobians, on-the-fly whitening, FP64 MFMA) */
+int vio_stage_imu_block(const vio_config *cfg, int n, const double *dt, const double *acc, const double *gyr, const double *acc0,
+                        const double *gyr0, const double *ba, const double *bg, const double *pose_i, const double *sb_i,
+                        const double *pose_j, const double *sb_j, double *G961);
 
 #ifdef __cplusplus
 }

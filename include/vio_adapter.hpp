@@ -2,15 +2,20 @@
 //
 //   vio_hip::Estimator       ~  Estimator       (vins_estimator/src/estimator/estimator.h:29-135)
 //   vio_hip::FeatureTracker  ~  FeatureTracker  (vins_estimator/src/feature_tracker/feature_tracker.h:28-90)
+//   vio_hip::FrameGate       ~  the stream checks + frequency control at the top of EstimatorNodelet::process_tracker
+//                               (vins_estimator/src/estimator_nodelet.cpp:94-95, 234-286)
 //
-// Same member names and argument meaning as the reference, plain C++11 types instead of Eigen / OpenCV / ROS so that this
-// header compiles anywhere (the reference's nodelet would wrap cv::Mat::data / Eigen::Vector3d::data()).  Differences forced by
-// the device-resident design are marked "device:".  One object pair drives one sequence (n_seq = 1), exactly like the nodelet.
+// Same member names, signatures and argument meaning as the reference, plain C++11 types instead of Eigen / OpenCV / ROS so that
+// this header compiles anywhere (the reference's nodelet would wrap cv::Mat::data / Eigen::Vector3d::data()).  Differences forced
+// by the device-resident design are marked "device:".  One object pair drives one sequence (n_seq = 1), exactly like the nodelet.
 // Errors: the reference returns void and aborts through ROS_ASSERT; here failures throw std::runtime_error with vio_last_error().
 #ifndef VIO_ADAPTER_HPP
 #define VIO_ADAPTER_HPP
+#include <array>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -20,6 +25,53 @@
 namespace vio_hip {
 
 struct Point2f { float x, y; };
+typedef std::array<double, 7> Vector7d;                      // Eigen::Matrix<double, 7, 1>: x y z u v vx vy
+typedef std::map<int, Vector7d> FeatureMap;                  // map<int, Eigen::Matrix<double, 7, 1>> (estimator.h:46)
+
+// Stream checks + frequency control of process_tracker (estimator_nodelet.cpp:234-286).  step(t) returns what the nodelet does
+// with the frame stamped t: FIRST (only sets the time base), RESET (stream discontinuity: caller restarts tracker + estimator,
+// :243-262), SKIP ("Skip this frame", before readImage), TRACK (readImage with PUB_THIS_FRAME false) or PUBLISH.
+class FrameGate {
+  public:
+    enum Decision { SKIP = VIO_FRAME_SKIP, TRACK = VIO_FRAME_TRACK, PUBLISH = VIO_FRAME_PUBLISH, FIRST = 3, RESET = 4 };
+    FrameGate(int FREQ, int FRONTEND_FREQ) : freq_(FREQ == 0 ? 100 : FREQ), frontend_freq_(FRONTEND_FREQ) {}   // parameters.cpp:133-134
+    Decision step(double time_color) {
+        if (first_image_flag) {
+            first_image_flag = false;
+            first_image_time = time_color;
+            last_image_time = time_color;
+            return FIRST;
+        }
+        if (time_color - last_image_time > 1.0 || time_color < last_image_time) {
+            first_image_flag = true;
+            last_image_time = 0;
+            pub_count = 1;
+            return RESET;
+        }
+        if (std::round(1.0 * input_count / (time_color - first_image_time)) > frontend_freq_) return SKIP;
+        ++input_count;
+        bool pub = false;
+        if (std::round(1.0 * pub_count / (time_color - first_image_time)) <= freq_) {
+            pub = true;
+            if (std::fabs(1.0 * pub_count / (time_color - first_image_time) - freq_) < 0.01 * freq_) {
+                first_image_time = time_color;
+                pub_count = 0;
+                input_count = 0;
+            }
+        }
+        last_image_time = time_color;
+        if (pub) pub_count++;
+        return pub ? PUBLISH : TRACK;
+    }
+    // a PUBLISH frame whose feature map came out empty restarts the rate window (estimator_nodelet.cpp:386-392)
+    void emptyMap(double time_color) { first_image_time = time_color; pub_count = 0; input_count = 0; }
+    bool first_image_flag = true;
+    double first_image_time = 0, last_image_time = 0;
+    int pub_count = 1, input_count = 0;
+
+  private:
+    int freq_, frontend_freq_;
+};
 
 class Estimator {
   public:
@@ -28,7 +80,7 @@ class Estimator {
     static const int MAX_WINDOW = 20;
 
     // Estimator() + setParameter() (estimator.cpp:9-41); configuration per object instead of the globals of parameters.h
-    explicit Estimator(const vio_config &cfg, int imu_capacity = 1 << 14) : cfg_(cfg) {
+    explicit Estimator(const vio_config &cfg, int imu_capacity = 1 << 14) : f_manager(*this), cfg_(cfg) {
         h_ = vio_create(&cfg_, 1, imu_capacity);
         if (!h_) throw std::runtime_error(std::string("vio_create: ") + vio_last_error());
         WINDOW_SIZE = cfg_.window_size;
@@ -46,11 +98,36 @@ class Estimator {
         check(vio_push_imu(h_, 0, 1, &t, linearAcceleration, angularVelocity), "vio_push_imu");
     }
 
-    // FeatureManager::inputDepth + Estimator::processImage (estimator_nodelet.cpp:534-539, estimator.cpp:156-374).
-    // device: the feature map produced by FeatureTracker::readImage stays in HBM, so only the depth image is passed.
-    // Returns VIO_OK, VIO_NEED_IMU (IMU has not reached header_stamp + td: the reference busy-waits at :178-183; call again
-    // after more inputIMU) or VIO_REBOOTED (failureDetection fired, :345-353).
-    int processImage(const uint16_t *depth_mm, double /*header_stamp: taken from the preceding readImage*/) {
+    // Matrix3d predictMotion(double t0, double t1) (estimator.h:56, estimator.cpp:1790-1860): relative_R row-major
+    void predictMotion(double t0, double t1, double relative_R[9]) { check(vio_predict_motion(h_, 0, t0, t1, relative_R), "vio_predict_motion"); }
+
+    // FeatureManager::inputDepth (feature_manager.cpp:43-46): the nodelet calls estimator.f_manager.inputDepth(depth) right before
+    // processImage (estimator_nodelet.cpp:537-539); the pointer must stay valid until processImage returns
+    struct FeatureManagerMirror {
+        explicit FeatureManagerMirror(Estimator &e) : e_(e) {}
+        void inputDepth(const uint16_t *depth_mm /* ROW x COL CV_16UC1, contiguous */) { e_.depth_ = depth_mm; }
+      private:
+        Estimator &e_;
+    } f_manager;
+
+    // void processImage(const map<int, Eigen::Matrix<double, 7, 1>> &image, const std_msgs::Header &header) (estimator.h:46,
+    // estimator.cpp:156-374).  header = stamp in seconds.  Returns VIO_OK, VIO_NEED_IMU (IMU has not reached header + td: the
+    // reference busy-waits at :178-183; nothing was consumed, call again after more inputIMU) or VIO_REBOOTED (failureDetection
+    // fired, :345-353).  The map is whatever the caller popped from its feature_buf: the tracker may be any number of frames ahead.
+    int processImage(const FeatureMap &image, double header) {
+        if (!depth_) throw std::runtime_error("processImage: f_manager.inputDepth was not called");
+        ids_.clear(); obs_.clear();
+        for (FeatureMap::const_iterator it = image.begin(); it != image.end(); ++it) {   // std::map order = ascending feature id
+            ids_.push_back(it->first);
+            obs_.insert(obs_.end(), it->second.begin(), it->second.end());
+        }
+        check(vio_process_obs(h_, 0, (int)ids_.size(), ids_.data(), obs_.data(), depth_, header), "vio_process_obs");
+        refresh();
+        return status_.code;
+    }
+    // device: short cut without the host round trip of the feature map -- inputDepth + processImage on the map the last
+    // FeatureTracker::readImage packaged in HBM (only valid when the estimator does not lag the tracker)
+    int processLastTracked(const uint16_t *depth_mm) {
         check(vio_process(h_, depth_mm, 0), "vio_process");
         refresh();
         return status_.code;
@@ -66,12 +143,32 @@ class Estimator {
     double tic[3], ric[9], td;
     vio_status last_status() const { return status_; }
 
-    // f_manager.feature (feature_manager.h:63-99) as rows {feature_id, start_frame, n_obs, estimated_depth, estimate_flag, solve_flag, is_dynamic}
+    // f_manager.feature (feature_manager.h:63-99) as rows of 12: {feature_id, start_frame, n_obs, estimated_depth, estimate_flag,
+    // solve_flag, is_dynamic, feature_per_frame[0].point (3), feature_per_frame[0].depth, feature_per_frame.back().depth} --
+    // everything pubPointCloud reads (visualization.cpp:333-395)
     std::vector<double> landmarks() {
-        std::vector<double> out(7 * 4096);
-        int n = vio_get_landmarks(h_, 0, 4096, out.data());
-        check(n, "vio_get_landmarks");
-        out.resize(7 * (size_t)(n < 4096 ? n : 4096));
+        std::vector<double> out(12 * 4096);
+        int n = vio_get_landmarks_ex(h_, 0, 4096, out.data());
+        check(n, "vio_get_landmarks_ex");
+        out.resize(12 * (size_t)(n < 4096 ? n : 4096));
+        return out;
+    }
+    // the world points of pubPointCloud (visualization.cpp:333-366): xyz per landmark that passes its filters
+    std::vector<double> pointCloud() {
+        std::vector<double> lm = landmarks(), out;
+        for (size_t k = 0; k + 12 <= lm.size(); k += 12) {
+            const double *q = &lm[k];
+            const int start = (int)q[1], used = (int)q[2];
+            if (q[6] != 0) continue;
+            if (!(used >= 2 && start < WINDOW_SIZE - 2)) continue;
+            if (start > WINDOW_SIZE * 3.0 / 4.0 || (int)q[5] != 1) continue;
+            const double d = q[10] == 0 ? q[3] : q[10];
+            const double pc[3] = {q[7] * d, q[8] * d, q[9] * d};
+            double pi[3], pw[3];
+            for (int r = 0; r < 3; r++) pi[r] = ric[3 * r] * pc[0] + ric[3 * r + 1] * pc[1] + ric[3 * r + 2] * pc[2] + tic[r];
+            for (int r = 0; r < 3; r++) pw[r] = Rs[start][3 * r] * pi[0] + Rs[start][3 * r + 1] * pi[1] + Rs[start][3 * r + 2] * pi[2] + Ps[start][r];
+            out.insert(out.end(), pw, pw + 3);
+        }
         return out;
     }
     vio_batch *handle() { return h_; }
@@ -88,6 +185,7 @@ class Estimator {
         std::memset(&status_, 0, sizeof(status_));
         for (int i = 0; i <= MAX_WINDOW; i++) Rs[i][0] = Rs[i][4] = Rs[i][8] = 1.0;
         std::memcpy(tic, cfg_.tic, sizeof(tic)); std::memcpy(ric, cfg_.ric, sizeof(ric));
+        depth_ = nullptr;
     }
     void refresh() {
         check(vio_get_status(h_, 0, &status_), "vio_get_status");
@@ -113,19 +211,24 @@ class Estimator {
     vio_config cfg_;
     vio_batch *h_;
     vio_status status_;
+    const uint16_t *depth_ = nullptr;
+    std::vector<int32_t> ids_;
+    std::vector<double> obs_;
 };
 
 class FeatureTracker {
   public:
-    // device: the tracker state lives in the same handle as the estimator (predictMotion reads its IMU buffer and biases)
+    // device: the tracker state lives in the same handle as the estimator (one HBM-resident sequence)
     explicit FeatureTracker(Estimator &estimator) : e_(estimator) {}
 
-    // feature_tracker.h:36-37 readImage(const cv::Mat &_img, double _cur_time, const Matrix3d &_relative_R).
-    // device: relative_R is computed on the GPU by predictMotion (estimator.cpp:1790-1860) from the handle's IMU buffer, the
-    // argument is accepted for signature compatibility and ignored.  PUB_THIS_FRAME (global in the reference) is an argument.
-    void readImage(const uint8_t *img /* ROW x COL mono8, contiguous */, double cur_time, const double * /*relative_R*/ = nullptr,
+    // void readImage(const cv::Mat &_img, double _cur_time, const Matrix3d &_relative_R = Matrix3d::Identity())
+    // (feature_tracker.h:36-37).  relative_R (row-major) is honoured exactly as given (predictPtsInNextFrame, feature_tracker.cpp:
+    // 595-608); relative_R == nullptr lets the device compute Estimator::predictMotion(last image time, cur_time + td) itself,
+    // which saves the round trip.  PUB_THIS_FRAME is a global in the reference (parameters.h:60) and an argument here.
+    void readImage(const uint8_t *img /* ROW x COL mono8, contiguous */, double cur_time, const double *relative_R = nullptr,
                    bool PUB_THIS_FRAME = true) {
-        Estimator::check(vio_track(e_.h_, img, &cur_time, PUB_THIS_FRAME ? 1 : 0, 0), "vio_track");
+        const uint8_t mode = PUB_THIS_FRAME ? VIO_FRAME_PUBLISH : VIO_FRAME_TRACK;
+        Estimator::check(vio_track_ex(e_.h_, img, &cur_time, &mode, relative_R, 0), "vio_track_ex");
         const int cap = 4096;
         ids.assign(cap, 0); track_cnt.assign(cap, 0);
         cur_pts.assign(cap, Point2f()); cur_un_pts.assign(cap, Point2f()); pts_velocity.assign(cap, Point2f());

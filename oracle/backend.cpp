@@ -407,7 +407,9 @@ void Estimator::predictMotion(double t0, double t1, double R[9]) {  // :1790-186
             prev_t = t;
             V3 un_gyr = 0.5 * (prev_gyr + w) - latest_Bg;
             prev_gyr = w;
-            V3 aa = (T(ric) * un_gyr) * dt;  // RIC.back().transpose() * un_gyr * dt
+            M3 RIC;  // the GLOBAL RIC.back() (estimator.cpp:1852): the configured extrinsic, not the refined Estimator::ric
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) RIC(i, j) = cfg.ric[i * 3 + j];
+            V3 aa = (T(RIC) * un_gyr) * dt;  // RIC.back().transpose() * un_gyr * dt
             double ang = norm(aa);
             // AngleAxisd(|aa|, aa.normalized()).toRotationMatrix().transpose(); zero vector normalises to zero -> identity
             M3 Rk = M3::I();
@@ -1518,30 +1520,81 @@ int Estimator::processImage(std::map<int, std::array<double, 7>> &image, const u
 }
 
 // ------------------------------------------------------------------ nodelet-side driver
-int Pipeline::feed(const uint8_t *gray, const uint16_t *depth, double t) {
-    if (!est.IMUAvailable(t + est.td)) return -1;  // caller contract: IMU pushed through t + td (upstream busy-waits, estimator.cpp:178-183)
+// process_tracker for one frame (estimator_nodelet.cpp:234-393) after the stream checks: mode = outcome of the frequency control
+// (0 skip before readImage, 1 readImage with PUB_THIS_FRAME false, 2 readImage + packaging).  R_in: caller-supplied relative_R or
+// NULL = Estimator::predictMotion.  Returns 1 when `image` holds a feature map for processImage.
+int Pipeline::track(const uint8_t *gray, double t, int mode, const double *R_in, std::map<int, std::array<double, 7>> &image) {
+    image.clear();
     if (first_image_flag) {  // estimator_nodelet.cpp:234-240
         first_image_flag = false;
         last_image_time = t;
         return 0;
     }
+    if (mode == 0) return 0;  // "Skip this frame" :266-271 (before readImage: last_image_time keeps its value)
     double R[9];
-    est.predictMotion(last_image_time, t + est.td, R);  // :309-313
-    tracker.readImage(gray, t, R, true);
+    if (R_in) for (int k = 0; k < 9; k++) R[k] = R_in[k];
+    else est.predictMotion(last_image_time, t + est.td, R);  // :309-313
+    tracker.readImage(gray, t, R, mode == 2);
     last_image_time = t;
     tracker.updateIDs();  // :324-330
-    std::map<int, std::array<double, 7>> image;  // :336-363
-    for (size_t j = 0; j < tracker.ids.size(); j++)
+    if (mode != 2) return 0;
+    for (size_t j = 0; j < tracker.ids.size(); j++)  // :336-363
         if (tracker.track_cnt[j] > 1)
             image[tracker.ids[j]] = {(double)tracker.cur_un_pts[j].x, (double)tracker.cur_un_pts[j].y, 1.0, (double)tracker.cur_pts[j].x,
                                      (double)tracker.cur_pts[j].y, (double)tracker.pts_velocity[j].x, (double)tracker.pts_velocity[j].y};
-    if (!init_pub) { init_pub = true; return 0; }          // :365-368
-    if (!init_feature) { init_feature = true; return 0; }  // :371-377
-    if (image.empty()) return 0;
+    if (!init_pub) { init_pub = true; image.clear(); return 0; }          // :365-368
+    if (!init_feature) { init_feature = true; image.clear(); return 0; }  // :371-377
+    return image.empty() ? 0 : 1;
+}
+// EstimatorNodelet::process for one queued feature frame (:462-549): inputDepth + processImage
+int Pipeline::process(std::map<int, std::array<double, 7>> &image, const uint16_t *depth, double t) {
     int rc = est.processImage(image, depth, t);
     if (rc == 1) return 0;
     frames_processed++;
     return 1;
+}
+int Pipeline::feed(const uint8_t *gray, const uint16_t *depth, double t, int mode) {
+    if (!est.IMUAvailable(t + est.td)) return -1;  // caller contract: IMU pushed through t + td (upstream busy-waits, estimator.cpp:178-183)
+    std::map<int, std::array<double, 7>> image;
+    if (!track(gray, t, mode, nullptr, image)) return 0;
+    return process(image, depth, t);
+}
+
+// Frequency control + stream-discontinuity detection of process_tracker (estimator_nodelet.cpp:94-95, 234-286), restated as a
+// stand-alone state machine so that replay drivers on both sides (oracle and product) take identical decisions.
+FrameGate::FrameGate(int freq_, int frontend_freq_) : freq(freq_ == 0 ? 100 : freq_), frontend_freq(frontend_freq_) {}  // parameters.cpp:133-134
+int FrameGate::step(double t) {
+    if (first_image_flag) {  // :234-240
+        first_image_flag = false;
+        first_image_time = t;
+        last_image_time = t;
+        return GATE_FIRST;
+    }
+    if (t - last_image_time > 1.0 || t < last_image_time) {  // :243-262
+        first_image_flag = true;
+        last_image_time = 0;
+        pub_count = 1;
+        return GATE_RESET;
+    }
+    if (std::round(1.0 * input_count / (t - first_image_time)) > frontend_freq) return GATE_SKIP;  // :264-271 (last_image_time untouched)
+    ++input_count;
+    bool pub = false;
+    if (std::round(1.0 * pub_count / (t - first_image_time)) <= freq) {  // :274-284
+        pub = true;
+        if (std::abs(1.0 * pub_count / (t - first_image_time) - freq) < 0.01 * freq) {
+            first_image_time = t;
+            pub_count = 0;
+            input_count = 0;
+        }
+    }
+    last_image_time = t;  // :316
+    if (pub) pub_count++;  // :333
+    return pub ? GATE_PUBLISH : GATE_TRACK;
+}
+void FrameGate::empty_map(double t) {  // :386-392: a published frame whose feature map came out empty restarts the rate window
+    first_image_time = t;
+    pub_count = 0;
+    input_count = 0;
 }
 
 }  // namespace ovio

@@ -24,6 +24,31 @@ void ovio_push_imu_n(void *h, int n, const double *t, const double *acc, const d
         ((Pipeline *)h)->est.inputIMU(t[i], V3(acc[3 * i], acc[3 * i + 1], acc[3 * i + 2]), V3(gyr[3 * i], gyr[3 * i + 1], gyr[3 * i + 2]));
 }
 int ovio_feed(void *h, const uint8_t *gray, const uint16_t *depth, double t) { return ((Pipeline *)h)->feed(gray, depth, t); }
+int ovio_feed_mode(void *h, const uint8_t *gray, const uint16_t *depth, double t, int mode) { return ((Pipeline *)h)->feed(gray, depth, t, mode); }
+// the tracker half: returns the number of packaged features (0 = nothing for processImage); ids ascending, obs 7 doubles each
+int ovio_track(void *h, const uint8_t *gray, double t, int mode, const double *R_in, int cap, int *ids, double *obs) {
+    std::map<int, std::array<double, 7>> image;
+    if (!((Pipeline *)h)->track(gray, t, mode, R_in, image)) return 0;
+    int n = 0;
+    for (auto &kv : image) {
+        if (n >= cap) break;
+        ids[n] = kv.first;
+        for (int k = 0; k < 7; k++) obs[7 * n + k] = kv.second[k];
+        n++;
+    }
+    return (int)image.size();
+}
+// the estimator half on a caller-supplied map: returns 1 processed, 0 need-IMU (nothing consumed)
+int ovio_process_obs(void *h, int n, const int *ids, const double *obs, const uint16_t *depth, double t) {
+    std::map<int, std::array<double, 7>> image;
+    for (int i = 0; i < n; i++) { std::array<double, 7> a; for (int k = 0; k < 7; k++) a[k] = obs[7 * i + k]; image[ids[i]] = a; }
+    return ((Pipeline *)h)->process(image, depth, t);
+}
+void ovio_predict_motion(void *h, double t0, double t1, double *R9) { ((Pipeline *)h)->est.predictMotion(t0, t1, R9); }
+void *ovio_gate_create(int freq, int frontend_freq) { return new FrameGate(freq, frontend_freq); }
+void ovio_gate_destroy(void *g) { delete (FrameGate *)g; }
+int ovio_gate_step(void *g, double t) { return ((FrameGate *)g)->step(t); }
+void ovio_gate_empty_map(void *g, double t) { ((FrameGate *)g)->empty_map(t); }
 
 // out: [solver_flag, frame_count, marginalization_flag, td, n_landmarks, last_track_num, reboot_count, frames_processed,
 //       iterations, successful, initial_cost, final_cost, n_lm_in_problem, n_residuals, n_var_landmarks, has_prior]
@@ -65,6 +90,20 @@ int ovio_get_landmarks(void *h, int cap, double *out) {
         double *o = out + 7 * n++;
         o[0] = l.feature_id; o[1] = l.start_frame; o[2] = (double)l.obs.size(); o[3] = l.estimated_depth;
         o[4] = l.estimate_flag; o[5] = l.solve_flag; o[6] = l.is_dynamic;
+    }
+    return (int)e.feature.size();
+}
+
+// 12 per landmark: the 7 above + feature_per_frame[0].point (3), feature_per_frame[0].depth, feature_per_frame.back().depth
+int ovio_get_landmarks_ex(void *h, int cap, double *out) {
+    Estimator &e = ((Pipeline *)h)->est;
+    int n = 0;
+    for (auto &l : e.feature) {
+        if (n >= cap) break;
+        double *o = out + 12 * n++;
+        o[0] = l.feature_id; o[1] = l.start_frame; o[2] = (double)l.obs.size(); o[3] = l.estimated_depth;
+        o[4] = l.estimate_flag; o[5] = l.solve_flag; o[6] = l.is_dynamic;
+        o[7] = l.obs.front().x; o[8] = l.obs.front().y; o[9] = l.obs.front().z; o[10] = l.obs.front().depth; o[11] = l.obs.back().depth;
     }
     return (int)e.feature.size();
 }

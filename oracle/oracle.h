@@ -286,7 +286,7 @@ bool solve_pnp_ransac_epnp(const std::vector<om::V3> &obj, const std::vector<std
 // ------------------------------------------------------------------------------------ nodelet-side driver
 // Restates the parts of estimator_nodelet.cpp:192-459 (process_tracker) and :462-568 (process) that sit between
 // the two entry points: first-image skip, updateID loop, feature-map packaging (track_cnt>1, ascending id),
-// init_pub / init_feature skipping. Frequency control is pinned to "publish every frame".
+// init_pub / init_feature skipping.  Frequency control is an input (frame mode, see FrameGate).
 struct Pipeline {
     Config cfg;
     Tracker tracker;
@@ -295,8 +295,23 @@ struct Pipeline {
     double last_image_time = 0;
     int frames_processed = 0;
     explicit Pipeline(const Config &c) : cfg(c), tracker(c), est(c) {}
-    // returns 1 if processImage ran for this frame
-    int feed(const uint8_t *gray, const uint16_t *depth, double t);
+    // returns 1 if processImage ran for this frame; mode: 0 skip, 1 track only (PUB_THIS_FRAME false), 2 publish
+    int feed(const uint8_t *gray, const uint16_t *depth, double t, int mode = 2);
+    // the two halves the nodelet runs on separate threads with feature_buf between them (estimator_nodelet.cpp:380-384, 539)
+    int track(const uint8_t *gray, double t, int mode, const double *R_in, std::map<int, std::array<double, 7>> &image);
+    int process(std::map<int, std::array<double, 7>> &image, const uint16_t *depth, double t);
+};
+
+// Frequency control / stream checks of EstimatorNodelet::process_tracker (estimator_nodelet.cpp:94-95, 234-286)
+enum { GATE_SKIP = 0, GATE_TRACK = 1, GATE_PUBLISH = 2, GATE_FIRST = 3, GATE_RESET = 4 };
+struct FrameGate {
+    int freq, frontend_freq;
+    bool first_image_flag = true;
+    double first_image_time = 0, last_image_time = 0;
+    int pub_count = 1, input_count = 0;
+    FrameGate(int freq_, int frontend_freq_);
+    int step(double t);        // decision for the frame stamped t
+    void empty_map(double t);  // call when a PUBLISH frame produced an empty feature map
 };
 
 }  // namespace ovio

@@ -99,7 +99,7 @@ def dynamic_init_fixture(P):
     """Moving-start sequence through the oracle's static_init: 0 branch (SfM + visual-inertial alignment): the window right after the
     initialisation and the published trajectory.  Vectors for the HIP side of SURVEY.md 8f rank 1 (not built yet) and drift detection."""
     cfg = P.canonical_config()
-    cfg.reserved0 = 1
+    cfg.dynamic_init = 1
     sc = vio_ct.synth_like(cfg)
     sc.t_static = 0.0
     n = 30

@@ -168,3 +168,58 @@ def test_ate_alignment(io):
     est = (R @ gt.T).T + [3.0, -2.0, 0.5]
     assert io.ate_rmse(est, gt) < 1e-12
     assert abs(io.ate_rmse(est + [0, 0, 0.1] * (np.arange(50) % 2)[:, None], gt) - 0.05) < 1e-3
+
+
+def _stamp_streams():
+    rng = np.random.default_rng(4)
+    out = []
+    for rate in (10.0, 20.0, 30.0, 60.0):
+        t = 5.0 + np.arange(400) / rate
+        out.append(t)
+        out.append(t + rng.normal(0, 0.1 / rate, t.shape))          # jittered stamps
+    gap = np.r_[np.arange(60) / 30.0, 5.0 + np.arange(60) / 30.0, 4.0 + np.arange(30) / 30.0]   # a hole, then a jump back in time
+    out.append(gap)
+    return out
+
+
+@pytest.mark.parametrize("freq,frontend_freq", [(10, 20), (10, 30), (30, 30), (0, 30), (20, 15)])
+def test_frame_gate_python_equals_oracle_restatement(freq, frontend_freq):
+    """dataio.FrameGate (product host side) against the oracle's restatement of estimator_nodelet.cpp:234-286 on regular, jittered and
+    discontinuous stamp streams, with empty-map events injected at the same frames."""
+    import importlib
+    io = importlib.import_module("vins-rgbd-fast_amd.dataio")
+    import vio_ct
+    for t in _stamp_streams():
+        a, b = io.FrameGate(freq, frontend_freq), vio_ct.OracleGate(freq, frontend_freq)
+        da, db = [], []
+        for k, x in enumerate(t):
+            da.append(a.step(x)); db.append(b.step(x))
+            if k % 37 == 36 and da[-1] == 2:
+                a.empty_map(x); b.empty_map(x)
+        assert da == db
+        if freq == 10 and frontend_freq >= 20:
+            assert 2 in da and 3 in da
+
+
+def test_frame_gate_cpp_header_equals_oracle_restatement(tmp_path):
+    """vio_hip::FrameGate of include/vio_adapter.hpp (what a nodelet links) on the same streams."""
+    import subprocess
+    import vio_ct
+    src = tmp_path / "gate.cpp"
+    src.write_text('#include <cstdio>\n#include <cstdlib>\n#include "vio_adapter.hpp"\nint main(int c, char **v) { vio_hip::FrameGate g(atoi(v[1]), atoi(v[2])); '
+                   'double t; int k = 0; while (scanf("%lf", &t) == 1) { int d = (int)g.step(t); printf("%d\\n", d); if (k % 37 == 36 && d == 2) g.emptyMap(t); k++; } return 0; }\n')
+    exe = str(tmp_path / "gate")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-I" + os.path.join(root, "include"), str(src), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for freq, ff in [(10, 20), (10, 30), (0, 30)]:
+        for t in _stamp_streams():
+            out = subprocess.run([exe, str(freq), str(ff)], input="\n".join("%.17g" % x for x in t), capture_output=True, text=True)
+            dc = [int(x) for x in out.stdout.split()]
+            b = vio_ct.OracleGate(freq, ff)
+            db = []
+            for k, x in enumerate(t):
+                db.append(b.step(x))
+                if k % 37 == 36 and db[-1] == 2:
+                    b.empty_map(x)
+            assert dc == db

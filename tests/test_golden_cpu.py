@@ -84,7 +84,7 @@ def test_dynamic_init_regression_fixture(P):
     """static_init: 0 branch of the oracle on a moving-start sequence (vectors for the future HIP side of SURVEY.md 8f rank 1)"""
     d = np.load(os.path.join(G, "dynamic_init_regression.npz"))
     cfg = P.canonical_config()
-    cfg.reserved0 = 1
+    cfg.dynamic_init = 1
     sc = vio_ct.synth_like(cfg)
     sc.t_static = float(d["t_static"])
     o = vio_ct.run_oracle_sequence(cfg, sc, int(d["seq"]), int(d["n_frames"]))

@@ -1,4 +1,5 @@
-"""The C++ mirror of FeatureTracker / Estimator (include/vio_adapter.hpp) built with g++ and run against the ctypes path."""
+"""The C++ mirror of FeatureTracker / Estimator / the nodelet's frame gate (include/vio_adapter.hpp) built with g++, driven by a
+nodelet-shaped loop (examples/adapter_demo.cpp) and compared with the ORACLE pipeline under the oracle's own frame gate."""
 import os
 import subprocess
 
@@ -11,35 +12,36 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_cpp_adapter_matches_ctypes_path(P, tmp_path):
+def _build(tmp_path):
     exe = str(tmp_path / "adapter_demo")
     pk = os.path.join(ROOT, "vins-rgbd-fast_amd")
     r = subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "adapter_demo.cpp"),
                         "-L" + pk, "-lvio_hip", "-Wl,-rpath," + pk, "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
-    seq, n = 2, 22
-    out = subprocess.run([exe, str(seq), str(n)], capture_output=True, text=True, timeout=300)
+    return exe
+
+
+@pytest.mark.parametrize("cam_rate,freq,frontend_freq,lag,n", [(10.0, 10, 30, 0, 26), (30.0, 10, 20, 2, 120)])
+def test_cpp_nodelet_loop_matches_the_oracle(P, tmp_path, cam_rate, freq, frontend_freq, lag, n):
+    """processImage(image, header) with the map built from the tracker's public vectors exactly like estimator_nodelet.cpp:336-363,
+    predictMotion + readImage(img, t, relative_R), frequency control (30 Hz stream at freq 10 / frontend_freq 20: skipped, tracked-only
+    and published frames) and an estimator that lags the tracker by `lag` queued frames."""
+    exe = _build(tmp_path)
+    seq = 2
+    out = subprocess.run([exe, str(seq), str(n), str(cam_rate), str(freq), str(frontend_freq), str(lag)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr
     rows = np.array([[float(x) for x in line.split()] for line in out.stdout.strip().splitlines()])
-    assert len(rows) >= 6
-    # the same sequence through vio_feed from Python
     cfg = P.canonical_config()
-    sc = P.default_synth()
-    syn = P.Synth(sc)
-    b = P.VioBatch(cfg, 1)
-    ti, ai, gi = syn.imu(seq, int(n / sc.cam_rate * sc.imu_rate) + 64)
-    k, ref = 0, []
-    for f in range(n):
-        tf = f / sc.cam_rate
-        k2 = vio_ct.imu_until(ti, k, tf, sc.imu_rate)
-        if k2 > k:
-            b.push_imu(0, ti[k:k2], ai[k:k2], gi[k:k2])
-        k = k2
-        g, d = syn.render_host(seq, tf)
-        b.feed(g[None], d[None], [tf])
-        st = b.status(0)
-        if st.solver_flag == 1 and st.processed:
-            ref.append(np.r_[tf, b.window(0)[cfg.window_size, :3], len(b.tracks(0)[0])])
-    ref = np.array(ref)
-    assert rows.shape == ref.shape
-    assert np.abs(rows[:, :4] - ref[:, :4]).max() < 2e-9 and np.array_equal(rows[:, 4], ref[:, 4])  # printed with 9 decimals
+    sc = P.default_synth(cam_rate=cam_rate)
+    times = vio_ct.frame_times(sc, n)
+    modes = vio_ct.gate_modes(vio_ct.OracleGate(freq, frontend_freq), times)
+    if cam_rate > 10:
+        assert modes.count(0) > 5 and modes.count(1) > 10
+    sizes = []
+    def hook(f, orc):
+        pass
+    o = vio_ct.run_oracle_sequence(cfg, sc, seq, n, modes=modes)
+    ref = np.array([np.r_[times[f], p] for (f, p, q, v) in o["traj"]])
+    assert len(rows) >= 6 and rows.shape[0] == ref.shape[0], (rows.shape, ref.shape)
+    assert np.abs(rows[:, 0] - ref[:, 0]).max() < 1e-3          # the same frames were processed (stamps printed with 4 decimals)
+    assert np.abs(rows[:, 1:4] - ref[:, 1:4]).max() < 1e-5, float(np.abs(rows[:, 1:4] - ref[:, 1:4]).max())

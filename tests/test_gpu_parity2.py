@@ -1,0 +1,412 @@
+"""Round-2 parity tests on the GPU (VERDICT r1 "next round" item 1): landmark table and solver statistics against the oracle,
+the reference's vio.yaml parameter set with non-published frames, the batch of 128 (BASELINE configs[2]), a 300-frame run with
+the north-star ATE criterion, and the boundary functions that carry the reference's own signatures."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import vio_ct
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_status(so, sh, f, costs=True):
+    assert int(so["solver_flag"]) == sh.solver_flag and int(so["frame_count"]) == sh.frame_count, f
+    assert int(so["n_landmarks"]) == sh.n_landmarks, (f, so["n_landmarks"], sh.n_landmarks)
+    if sh.solver_flag == 1 and sh.processed:
+        assert int(so["marginalization_flag"]) == sh.marginalization_flag, f
+        assert (int(so["n_in_problem"]), int(so["n_residuals"]), int(so["n_var_landmarks"])) == (sh.n_in_problem, sh.n_residuals, sh.n_var_landmarks), f
+        if costs:
+            # solver statistics (ceres::Solver::Summary): the same number of trust-region iterations and accepted steps, the same
+            # cost at the first linearisation point (pure factor evaluation) and at the solution
+            assert (int(so["iterations"]), int(so["successful_steps"])) == (sh.iterations, sh.successful_steps), (f, so["iterations"], sh.iterations)
+            assert abs(so["initial_cost"] - sh.initial_cost) <= 1e-6 * max(1.0, so["initial_cost"]), (f, so["initial_cost"], sh.initial_cost)
+            assert abs(so["final_cost"] - sh.final_cost) <= 1e-6 * max(1.0, so["final_cost"]), (f, so["final_cost"], sh.final_cost)
+
+
+@pytest.mark.parametrize("fix_depth", [0, 1])
+def test_landmark_table_and_solver_stats_match_oracle_every_frame(P, fix_depth):
+    """f_manager.feature after every frame: feature_id, start_frame, observation count, estimate / solve flags, is_dynamic equal;
+    estimated_depth (triangulateWithDepth, feature_manager.cpp:386-543, then setDepth after each solve) within 1e-6 relative;
+    first / last observation (point, depth) identical -- what pubPointCloud reads (visualization.cpp:333-395)."""
+    cfg = P.default_config(fix_depth=fix_depth, depth_max=10.0 if fix_depth == 0 else 6.0)
+    sc = vio_ct.synth_like(cfg)
+    seq, n_frames = 9, 34
+    lm_o = []
+    o = vio_ct.run_oracle_sequence(cfg, sc, seq, n_frames, hook=lambda f, orc: lm_o.append(orc.landmarks_ex()))
+    lm_h = []
+    b, traj, stat = vio_ct.run_hip_batch(P, cfg, sc, [seq], n_frames, [o["frames"]], hook=lambda f, bb: lm_h.append(bb.landmarks_ex(0)))
+    worst = 0.0
+    n_tri = 0
+    for f in range(n_frames):
+        _check_status(o["status"][f], stat[0][f], f)
+        a, h = lm_o[f], lm_h[f]
+        assert a.shape == h.shape, (f, a.shape, h.shape)
+        if len(a) == 0:
+            continue
+        assert np.array_equal(a[:, [0, 1, 2, 4, 5, 6]], h[:, [0, 1, 2, 4, 5, 6]]), f   # id, start, n_obs, estimate_flag, solve_flag, is_dynamic
+        assert np.array_equal(a[:, 7:12], h[:, 7:12]), f                                 # first observation point / depth, last depth
+        have = a[:, 3] > 0
+        assert np.array_equal(have, h[:, 3] > 0), f
+        if have.any():
+            rel = np.abs(a[have, 3] - h[have, 3]) / np.abs(a[have, 3])
+            worst = max(worst, float(rel.max()))
+            n_tri += int(have.sum())
+    assert n_tri > 1000 and worst < 1e-6, (n_tri, worst)
+    po = np.array([x[1] for x in o["traj"]]); ph = np.array([x[1] for x in traj[0]])
+    assert len(po) == len(ph) >= 15 and np.abs(po - ph).max() < 1e-5
+
+
+def test_reference_vio_yaml_parameters_with_unpublished_frames(P):
+    """BASELINE configs[0] parameter set (config/realsense/vio.yaml: max_cnt 30, min_dist 30, fix_depth 1, estimate_td 1, acc_n 1.0,
+    rolling shutter 33 ms, freq 10 / frontend_freq 20) on a 30 Hz stream: the nodelet's frequency control drops, tracks-only
+    (PUB_THIS_FRAME false: no RANSAC / mask / detection, feature_tracker.cpp:351) and publishes frames; the same modes go to the
+    oracle and to vio_feed_modes.  Tracker state compared after EVERY frame, estimator decisions and poses like the other tests."""
+    cfg = P.default_config(max_cnt=30, min_dist=30, fix_depth=1, estimate_td=1, acc_n=1.0, tr=0.033)
+    sc = vio_ct.synth_like(cfg, cam_rate=30.0)
+    seq, n_frames = 12, 150
+    times = vio_ct.frame_times(sc, n_frames)
+    modes = vio_ct.gate_modes(vio_ct.OracleGate(10, 20), times)
+    assert modes.count(0) > 10 and modes.count(1) > 20 and modes.count(2) > 30, (modes.count(0), modes.count(1), modes.count(2))
+    tr_o = []
+    o = vio_ct.run_oracle_sequence(cfg, sc, seq, n_frames, modes=modes, hook=lambda f, orc: tr_o.append(orc.tracks()))
+    tr_h = []
+    b, traj, stat = vio_ct.run_hip_batch(P, cfg, sc, [seq], n_frames, [o["frames"]], modes=modes, hook=lambda f, bb: tr_h.append(bb.tracks(0)))
+    for f in range(n_frames):
+        _check_status(o["status"][f], stat[0][f], f, costs=False)
+        assert bool(o["processed"][f] == 1) == bool(stat[0][f].processed), (f, modes[f])
+        a, q = tr_o[f], tr_h[f]
+        assert np.array_equal(a[0], q[0]) and np.array_equal(a[1], q[1]), (f, modes[f])          # ids, track_cnt
+        assert np.abs(a[2] - q[2]).max(initial=0) < 5e-3 and np.abs(a[4] - q[4]).max(initial=0) < 0.05, (f, modes[f])
+    assert len(traj[0]) == len(o["traj"]) >= 20
+    po = np.array([x[1] for x in o["traj"]]); ph = np.array([x[1] for x in traj[0]])
+    assert np.abs(po - ph).max() < 1e-4, float(np.abs(po - ph).max())
+    assert abs(o["oracle"].status()["td"] - b.status(0).td) < 1e-6
+    gt = np.array(o["gt"])
+    ate_o, ate_h = vio_ct.ate_rmse(po, gt), vio_ct.ate_rmse(ph, gt)
+    assert abs(ate_h - ate_o) <= max(0.01 * ate_o, 2e-4), (ate_o, ate_h)
+
+
+def _device_frames(P, sc, cfg, S, seq0, n_frames):
+    import torch
+    dev = torch.device("cuda", 0)
+    syn = P.Synth(sc)
+    gray = torch.empty((n_frames, S, cfg.height, cfg.width), dtype=torch.uint8, device=dev)
+    depth = torch.empty((n_frames, S, cfg.height, cfg.width), dtype=torch.uint16, device=dev)
+    times = vio_ct.frame_times(sc, n_frames)
+    for f in range(n_frames):
+        syn.render_device(S, seq0, float(times[f]), gray[f], depth[f])
+    torch.cuda.synchronize()
+    return gray, depth, times
+
+
+def _drive_device(P, cfg, sc, gray, depth, times, seqs, seq0, n_frames, per_frame=None):
+    """vio_feed over device-resident frames for the sequences `seqs` (global ids, a contiguous slice of the rendered batch)."""
+    syn = P.Synth(sc)
+    S = len(seqs)
+    lo = seqs[0] - seq0
+    nimu = int(n_frames / sc.cam_rate * sc.imu_rate) + 64
+    b = P.VioBatch(cfg, S, imu_capacity=nimu + 64)
+    imu = [syn.imu(s, nimu) for s in seqs]
+    tt = np.stack([x[0] for x in imu]); aa = np.stack([x[1] for x in imu]); gg = np.stack([x[2] for x in imu])
+    b.push_imu_batch(tt, aa, gg)       # all IMU up front, one call (vio_push_imu_batch)
+    for f in range(n_frames):
+        b.feed(gray[f, lo:lo + S], depth[f, lo:lo + S], np.full(S, times[f]), on_device=True)
+        if per_frame is not None:
+            per_frame(f, b)
+    return b
+
+
+def test_batch_of_128_matches_oracle_and_standalone(P):
+    """BASELINE configs[2]: 128 independent 640x480 sequences in one handle.  8 of them against the oracle on the same pixels
+    (identical decisions, window positions within 1e-5 m); all 128 bit-identical to their stand-alone (S = 1) run."""
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    S, seq0, n_frames = 128, 300, 30
+    gray, depth, times = _device_frames(P, sc, cfg, S, seq0, n_frames)
+    chk = [0, 17, 38, 59, 77, 96, 113, 127]
+    hist = {i: [] for i in chk}
+    def grab(f, b):
+        for i in chk:
+            st = b.status(i)
+            hist[i].append((st, b.window(i)[cfg.window_size, :3].copy()))
+    batch = _drive_device(P, cfg, sc, gray, depth, times, list(range(seq0, seq0 + S)), seq0, n_frames, per_frame=grab)
+    wins = [batch.window(i).copy() for i in range(S)]
+    lms = [batch.landmarks(i).copy() for i in range(S)]
+    assert all(batch.status(i).solver_flag == 1 for i in range(S))
+    for i in chk:
+        frames = [(gray[f, i].cpu().numpy(), depth[f, i].cpu().numpy()) for f in range(n_frames)]
+        o = vio_ct.run_oracle_sequence(cfg, sc, seq0 + i, n_frames, frames=frames)
+        po, ph = [], []
+        for f in range(n_frames):
+            st, pw = hist[i][f]
+            _check_status(o["status"][f], st, (i, f), costs=False)
+            if st.solver_flag == 1 and st.processed:
+                ph.append(pw)
+        po = np.array([x[1] for x in o["traj"]]); ph = np.array(ph)
+        assert po.shape == ph.shape and len(po) >= 10
+        assert np.abs(po - ph).max() < 1e-5, (i, float(np.abs(po - ph).max()))
+    for i in range(S):
+        alone = _drive_device(P, cfg, sc, gray, depth, times, [seq0 + i], seq0, n_frames)
+        assert np.array_equal(alone.window(0), wins[i]), i
+        assert np.array_equal(alone.landmarks(0), lms[i]), i
+        alone.close()
+
+
+def test_300_frames_ate_within_one_percent_of_the_oracle(P):
+    """SURVEY.md 8d sequence length (300 frames) on 8 sequences: the north-star criterion |ATE_hip - ATE_oracle| <= 1 % of the
+    oracle's ATE per sequence (or 0.2 mm, the resolution of a 1-2 cm ATE), no reboots, every frame processed on both sides.
+    Prints the worst HIP-vs-oracle distance (the two solvers take discrete decisions on round-off level differences, DESIGN.md
+    deviation 12, so it is reported rather than bounded at 1e-5 m over this length)."""
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    S, seq0, n_frames = 8, 700, 300
+    gray, depth, times = _device_frames(P, sc, cfg, S, seq0, n_frames)
+    batch = _drive_device(P, cfg, sc, gray, depth, times, list(range(seq0, seq0 + S)), seq0, n_frames)
+    syn = P.Synth(sc)
+    worst, report = 0.0, []
+    for i in range(S):
+        st = batch.status(i)
+        assert st.reboot_count == 0 and st.solver_flag == 1
+        h = batch.odometry_history(i)
+        frames = [(gray[f, i].cpu().numpy(), depth[f, i].cpu().numpy()) for f in range(n_frames)]
+        o = vio_ct.run_oracle_sequence(cfg, sc, seq0 + i, n_frames, frames=frames)
+        po = np.array([x[1] for x in o["traj"]])
+        assert len(h) == len(po) >= 280, (i, len(h), len(po))
+        assert int(o["oracle"].status()["reboot_count"]) == 0
+        gt = np.array(o["gt"])
+        ate_o, ate_h = vio_ct.ate_rmse(po, gt), vio_ct.ate_rmse(h[:, 1:4], gt)
+        dist = float(np.linalg.norm(po - h[:, 1:4], axis=1).max())
+        worst = max(worst, dist)
+        report.append((seq0 + i, ate_o, ate_h, dist))
+        assert ate_o < 0.05 and ate_h < 0.05, (i, ate_o, ate_h)
+        assert abs(ate_h - ate_o) <= max(0.01 * ate_o, 2e-4), (i, ate_o, ate_h, dist)
+    print("300-frame parity: seq, ATE oracle, ATE hip, max |p_hip - p_oracle| [m]")
+    for r in report:
+        print("  %d %.6f %.6f %.3e" % r)
+    assert worst < 0.02
+
+
+def test_process_obs_crosses_the_boundary_both_ways(P):
+    """Estimator::processImage(image, header) with a caller-supplied feature map (estimator.h:46): (a) the ORACLE tracker's maps fed to
+    the HIP back-end through vio_process_obs reproduce the oracle pipeline; (b) the HIP tracker's maps (vio_track +
+    vio_get_packaged) fed to the oracle back-end reproduce the HIP pipeline; (c) the estimator may lag the tracker (maps queued
+    like feature_buf, estimator_nodelet.cpp:380-384) without changing the result."""
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    seq, n_frames = 21, 34
+    syn = P.Synth(sc)
+    times = vio_ct.frame_times(sc, n_frames)
+    frames = [syn.render_host(seq, float(t)) for t in times]
+    ti, ai, gi = syn.imu(seq, int(n_frames / sc.cam_rate * sc.imu_rate) + 64)
+    ref = vio_ct.run_oracle_sequence(cfg, sc, seq, n_frames, frames=frames)
+    po = np.array([x[1] for x in ref["traj"]])
+    # (a) oracle tracker -> HIP back-end, with the back-end lagging two frames behind the tracker
+    o = vio_ct.OraclePipeline(cfg)
+    b = P.VioBatch(cfg, 1)
+    assert b.capacity()["tracks"] >= cfg.max_cnt
+    queue, ph, k = [], [], 0
+    def drain(upto):
+        while len(queue) > upto:
+            f, ids, obs = queue.pop(0)
+            b.process_obs(0, ids, obs, frames[f][1], times[f])
+            st = b.status(0)
+            assert st.code == 0
+            if st.solver_flag == 1 and st.processed:
+                ph.append(b.window(0)[cfg.window_size, :3].copy())
+    for f in range(n_frames):
+        k2 = vio_ct.imu_until(ti, k, times[f], sc.imu_rate)
+        o.push_imu(ti[k:k2], ai[k:k2], gi[k:k2]); b.push_imu(0, ti[k:k2], ai[k:k2], gi[k:k2]); k = k2
+        ids, obs = o.track(frames[f][0], times[f])
+        if len(ids):
+            queue.append((f, ids, obs))
+            # the oracle estimator must see the same frames so that its predictMotion (latest_Bg) stays in step
+            o.process_obs(ids, obs, frames[f][1], times[f])
+        drain(2)
+    drain(0)
+    ph = np.array(ph)
+    assert ph.shape == po.shape and np.abs(ph - po).max() < 1e-5, float(np.abs(ph - po).max())
+    # (b) HIP tracker -> oracle back-end
+    b2 = P.VioBatch(cfg, 1)
+    o2 = vio_ct.OraclePipeline(cfg)
+    b3 = P.VioBatch(cfg, 1)    # the plain HIP pipeline for comparison
+    k, pq, p3 = 0, [], []
+    first, init_pub, init_feature = True, False, False
+    for f in range(n_frames):
+        k2 = vio_ct.imu_until(ti, k, times[f], sc.imu_rate)
+        for x in (b2, b3):
+            x.push_imu(0, ti[k:k2], ai[k:k2], gi[k:k2])
+        o2.push_imu(ti[k:k2], ai[k:k2], gi[k:k2]); k = k2
+        b3.feed(frames[f][0][None], frames[f][1][None], [times[f]])
+        st3 = b3.status(0)
+        if st3.solver_flag == 1 and st3.processed:
+            p3.append(b3.window(0)[cfg.window_size, :3].copy())
+        if first:                      # estimator_nodelet.cpp:234-240 (vio_track carries no nodelet gating)
+            first = False
+            last_t = times[f]
+            continue
+        R = b2.predict_motion(0, last_t, times[f] + b2.status(0).td)
+        b2.track(frames[f][0][None], [times[f]], R_rel=R[None])
+        last_t = times[f]
+        ids, obs = b2.packaged(0)
+        if not init_pub:
+            init_pub = True
+            continue
+        if not init_feature:
+            init_feature = True
+            continue
+        if len(ids) == 0:
+            continue
+        assert np.all(np.diff(ids) > 0)
+        assert o2.process_obs(ids, obs, frames[f][1], times[f]) == 1
+        b2.process_obs(0, ids, obs, frames[f][1], times[f])   # keeps b2's latest_Bg / td in step with its own back-end
+        so = o2.status()
+        if so["solver_flag"] == 1:
+            pq.append(o2.window()[cfg.window_size, :3].copy())
+    pq, p3 = np.array(pq), np.array(p3)
+    assert pq.shape == p3.shape and len(pq) >= 15
+    assert np.abs(pq - p3).max() < 1e-5, float(np.abs(pq - p3).max())
+    assert np.abs(b2.window(0)[:, :3] - b3.window(0)[:, :3]).max() < 1e-9   # vio_track_ex + vio_process_obs == vio_feed
+
+
+def test_predict_motion_and_caller_supplied_relative_R(P, orc):
+    """Estimator::predictMotion(t0, t1) export (estimator.cpp:1790-1860) against the oracle, and readImage(img, t, relative_R)
+    honouring the caller's rotation: bit-identical tracks to the oracle tracker given the same R (non-identity)."""
+    cfg = P.default_config()
+    sc = vio_ct.synth_like(cfg)
+    syn = P.Synth(sc)
+    seq = 6
+    ti, ai, gi = syn.imu(seq, 800)
+    b = P.VioBatch(cfg, 1)
+    o = vio_ct.OraclePipeline(cfg)
+    b.push_imu(0, ti, ai, gi); o.push_imu(ti, ai, gi)
+    for (t0, t1) in [(2.0, 2.1), (2.05, 2.33), (0.0, 0.004), (3.9, 5.0)]:   # the last interval ends beyond the buffer: identity
+        Rh, Ro = b.predict_motion(0, t0, t1), o.predict_motion(t0, t1)
+        assert np.abs(Rh - Ro).max() < 1e-12, (t0, t1)
+    assert np.abs(b.predict_motion(0, 2.0, 2.3) - np.eye(3)).max() > 1e-3
+    times = 2.0 + np.arange(8) * 0.1
+    ot = vio_ct.OracleTracker(cfg)
+    bt = P.VioBatch(cfg, 1)
+    for i, t in enumerate(times):
+        g, _ = syn.render_host(seq, float(t))
+        R = o.predict_motion(times[i - 1], t) if i else np.eye(3)
+        ot.read(g, t, R, True)
+        bt.track(g[None], [t], R_rel=R[None])
+        a, q = ot.tracks(), bt.tracks(0)
+        assert np.array_equal(a[0], q[0]) and np.array_equal(a[1], q[1])
+        for kk in (2, 3, 4):
+            assert np.array_equal(a[kk].view(np.uint32), q[kk].view(np.uint32)), (i, kk)
+    assert len(a[0]) > 100
+
+
+def test_imu_from_a_second_thread_and_batched_push(P):
+    """Estimator::inputIMU is called from the ROS callback thread while the image thread runs (estimator.cpp:1749-1766): vio_push_imu
+    from a second thread concurrent with vio_feed, and vio_push_imu_batch, must reproduce the single-threaded per-sequence run."""
+    import threading
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    seqs, n = [70, 71, 72], 24
+    syn = P.Synth(sc)
+    frames = [[syn.render_host(s, float(t)) for t in vio_ct.frame_times(sc, n)] for s in seqs]
+    ref, _, _ = vio_ct.run_hip_batch(P, cfg, sc, seqs, n, frames)
+    bat, _, _ = vio_ct.run_hip_batch(P, cfg, sc, seqs, n, frames, imu_batch=True)
+    for i in range(len(seqs)):
+        assert np.array_equal(ref.window(i), bat.window(i)), i
+    b = P.VioBatch(cfg, len(seqs))
+    imu = [syn.imu(s, int(n / sc.cam_rate * sc.imu_rate) + 64) for s in seqs]
+    times = vio_ct.frame_times(sc, n)
+    pushed_to = [0.0]
+    cv = threading.Condition()
+    def imu_thread():
+        k = [0] * len(seqs)
+        for tf in times:
+            for i in range(len(seqs)):
+                k2 = vio_ct.imu_until(imu[i][0], k[i], tf, sc.imu_rate)
+                for q in range(k[i], k2):   # one sample per call, like the callback
+                    b.push_imu(i, imu[i][0][q:q + 1], imu[i][1][q:q + 1], imu[i][2][q:q + 1])
+                k[i] = k2
+            with cv:
+                pushed_to[0] = tf + 1e-9
+                cv.notify_all()
+    th = threading.Thread(target=imu_thread)
+    th.start()
+    for f, tf in enumerate(times):
+        with cv:
+            cv.wait_for(lambda: pushed_to[0] >= tf)
+        b.feed(np.stack([frames[i][f][0] for i in range(len(seqs))]), np.stack([frames[i][f][1] for i in range(len(seqs))]), [tf] * len(seqs))
+    th.join()
+    for i in range(len(seqs)):
+        assert np.array_equal(ref.window(i), b.window(i)), i
+
+
+def test_streaming_imu_reboot_is_deterministic(P):
+    """failureDetection -> clearState while IMU keeps arriving between frames: the reboot is decided inside be_solve,
+    before the next frame's front-end and IMU scatter may run, so repeated runs are bit-identical, the samples pushed after the
+    reboot are all kept, and the re-initialised trajectory matches the oracle.  Recipe as in test_gpu_edge: blank frames starve the
+    tracker while the accelerometer reports an 80 m/s^2 offset."""
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    seq, n = 11, 44
+    syn = P.Synth(sc)
+    frames = [syn.render_host(seq, float(t)) for t in vio_ct.frame_times(sc, n)]
+    blank = (np.full_like(frames[0][0], 90), frames[0][1])
+    for f in (18, 19, 20, 21, 22):
+        frames[f] = blank
+    ti, ai, gi = syn.imu(seq, int(n / sc.cam_rate * sc.imu_rate) + 64)
+    ai = ai.copy()
+    ai[(ti > 1.8) & (ti < 2.3), 0] += 80.0
+
+    def run_hip():
+        b = P.VioBatch(cfg, 1)
+        k, codes, fcs = 0, [], []
+        for f, tf in enumerate(vio_ct.frame_times(sc, n)):
+            k2 = vio_ct.imu_until(ti, k, tf, sc.imu_rate)
+            for q in range(k, k2, 7):   # several pushes between two frames, no synchronisation in between
+                b.push_imu(0, ti[q:min(q + 7, k2)], ai[q:min(q + 7, k2)], gi[q:min(q + 7, k2)])
+            k = k2
+            b.feed(frames[f][0][None], frames[f][1][None], [tf])
+            if f % 5 == 4:              # status only every fifth frame: the frames in between are enqueued back to back
+                st = b.status(0)
+                codes.append(st.code); fcs.append(st.frame_count)
+        return b, codes, fcs
+    o = vio_ct.OraclePipeline(cfg)
+    k = 0
+    for f, tf in enumerate(vio_ct.frame_times(sc, n)):
+        k2 = vio_ct.imu_until(ti, k, tf, sc.imu_rate)
+        o.push_imu(ti[k:k2], ai[k:k2], gi[k:k2]); k = k2
+        o.feed(frames[f][0], frames[f][1], tf)
+    so = o.status()
+    assert int(so["reboot_count"]) >= 1
+    first = None
+    for _ in range(3):
+        b, codes, fcs = run_hip()
+        st = b.status(0)
+        assert st.reboot_count == int(so["reboot_count"]) and st.solver_flag == int(so["solver_flag"]) and st.frame_count == int(so["frame_count"])
+        assert np.abs(b.window(0)[:, :3] - o.window()[:, :3]).max() < 1e-5
+        cur = (b.window(0).copy(), codes, fcs)
+        if first is None:
+            first = cur
+        else:
+            assert np.array_equal(cur[0], first[0]) and cur[1] == first[1] and cur[2] == first[2]
+
+
+def test_history_ring_and_capacity_flags(P):
+    """vio_get_odometry_history keeps the most recent rows when more were produced than the ring holds (documented behaviour); the
+    capacity code is per frame (a transient overflow does not stick to later frames)."""
+    cfg = P.canonical_config(max_landmarks=160)   # a landmark table that overflows while the window fills up
+    sc = vio_ct.synth_like(cfg)
+    seq, n = 3, 40
+    syn = P.Synth(sc)
+    frames = [syn.render_host(seq, float(t)) for t in vio_ct.frame_times(sc, n)]
+    b, traj, stat = vio_ct.run_hip_batch(P, cfg, sc, [seq], n, [frames])
+    codes = [s.code for s in stat[0]]
+    flags = [s.overflow_flags for s in stat[0]]
+    if any(flags):
+        assert -3 in codes
+        k = max(i for i, fl in enumerate(flags) if fl)
+        assert all(c != -3 for c, fl in zip(codes, flags) if not fl)          # the code follows the per-frame flag
+        assert b.status(0).overflow_frames == sum(1 for fl in flags if fl & ~4) or b.status(0).overflow_frames > 0
+    h_all = b.odometry_history(0)
+    h_last = b.odometry_history(0, cap=5)
+    assert len(h_last) == 5 and np.array_equal(h_last, h_all[-5:])

@@ -50,6 +50,7 @@ def test_cpp_adapter_header_compiles_standalone():
 
 def test_struct_layouts_agree(P, orc):
     assert orc.ovio_config_size() == C.sizeof(P.Config)
+    assert P.lib().vio_abi_sizeof(0) == C.sizeof(P.Config) and P.lib().vio_abi_sizeof(1) == C.sizeof(P.Status)
     a, b = P.Config(), P.Config()
     P.lib().vio_config_default(C.byref(a))
     orc.ovio_config_default(C.byref(b))

@@ -272,12 +272,12 @@ def test_sfm_window_needs_parallax_and_correspondences(sfm):
 def test_dynamic_initialisation_end_to_end(P, seq):
     """static_init: 0 branch of processImage (estimator.cpp:230-259) in the oracle: a sequence that moves from the first frame
     initialises through SfM + visual-inertial alignment as soon as the window is full and then tracks at least as well as the
-    static branch does on the same data.  (vio_config.reserved0 carries the oracle-only switch; the product rejects such
+    static branch does on the same data.  (vio_config.dynamic_init carries the oracle-only switch; the product rejects such
     configurations, see dataio.config_from_yaml.)"""
     res = {}
     for dyn in (1, 0):
         cfg = P.canonical_config()
-        cfg.reserved0 = dyn
+        cfg.dynamic_init = dyn
         sc = vio_ct.synth_like(cfg)
         sc.t_static = 0.0
         syn = P.Synth(sc)
@@ -307,7 +307,7 @@ def test_dynamic_initialisation_waits_for_parallax(P):
     all_image_frame grows beyond the window: the per-image-frame solvePnP loop and the erase in slideWindow are exercised); the
     initialisation succeeds once the camera has moved."""
     cfg = P.canonical_config()
-    cfg.reserved0 = 1
+    cfg.dynamic_init = 1
     sc = vio_ct.synth_like(cfg)
     sc.t_static = 1.5
     syn = P.Synth(sc)

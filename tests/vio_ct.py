@@ -43,10 +43,18 @@ def oracle():
         L.ovio_pipeline_create.restype = C.c_void_p
         L.ovio_tracker_create.restype = C.c_void_p
         L.ovio_preint_create.restype = C.c_void_p
+        L.ovio_gate_create.restype = C.c_void_p
         for name, args in {
             "ovio_pipeline_create": [C.c_void_p], "ovio_pipeline_destroy": [C.c_void_p],
             "ovio_push_imu_n": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
             "ovio_feed": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
+            "ovio_feed_mode": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int],
+            "ovio_track": [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
+            "ovio_process_obs": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
+            "ovio_predict_motion": [C.c_void_p, C.c_double, C.c_double, C.c_void_p],
+            "ovio_get_landmarks_ex": [C.c_void_p, C.c_int, C.c_void_p],
+            "ovio_gate_create": [C.c_int, C.c_int], "ovio_gate_destroy": [C.c_void_p], "ovio_gate_step": [C.c_void_p, C.c_double],
+            "ovio_gate_empty_map": [C.c_void_p, C.c_double],
             "ovio_get_status": [C.c_void_p, C.c_void_p], "ovio_get_window": [C.c_void_p, C.c_void_p],
             "ovio_get_extrinsic": [C.c_void_p, C.c_void_p], "ovio_get_landmarks": [C.c_void_p, C.c_int, C.c_void_p],
             "ovio_get_tracks": [C.c_void_p, C.c_int] + [C.c_void_p] * 5,
@@ -93,8 +101,30 @@ class OraclePipeline:
         t = np.ascontiguousarray(t, np.float64); acc = np.ascontiguousarray(acc, np.float64); gyr = np.ascontiguousarray(gyr, np.float64)
         self.L.ovio_push_imu_n(self.h, len(t), t.ctypes.data, acc.ctypes.data, gyr.ctypes.data)
 
-    def feed(self, gray, depth, t):
-        return self.L.ovio_feed(self.h, gray.ctypes.data, depth.ctypes.data, float(t))
+    def feed(self, gray, depth, t, mode=2):
+        return self.L.ovio_feed_mode(self.h, gray.ctypes.data, depth.ctypes.data, float(t), int(mode))
+
+    def track(self, gray, t, mode=2, R=None, cap=2048):
+        """the tracker half (process_tracker): returns (ids, obs[n][7]) of the packaged feature map (empty = nothing to process)"""
+        ids, obs = np.zeros(cap, np.int32), np.zeros((cap, 7))
+        Rp = None if R is None else np.ascontiguousarray(R, np.float64)
+        n = self.L.ovio_track(self.h, gray.ctypes.data, float(t), int(mode), None if Rp is None else Rp.ctypes.data, cap, ids.ctypes.data,
+                              obs.ctypes.data)
+        return ids[:n].copy(), obs[:n].copy()
+
+    def process_obs(self, ids, obs, depth, t):
+        ids = np.ascontiguousarray(ids, np.int32); obs = np.ascontiguousarray(obs, np.float64)
+        return self.L.ovio_process_obs(self.h, len(ids), ids.ctypes.data, obs.ctypes.data, depth.ctypes.data, float(t))
+
+    def predict_motion(self, t0, t1):
+        R = np.zeros(9)
+        self.L.ovio_predict_motion(self.h, float(t0), float(t1), R.ctypes.data)
+        return R.reshape(3, 3)
+
+    def landmarks_ex(self, cap=4096):
+        out = np.zeros((cap, 12))
+        n = self.L.ovio_get_landmarks_ex(self.h, cap, out.ctypes.data)
+        return out[:min(n, cap)]
 
     def status(self):
         s = np.zeros(16)
@@ -125,6 +155,26 @@ class OraclePipeline:
         J, r, x0, pres = np.zeros((n, n)), np.zeros(n), np.zeros(self.W * 7 + 17), np.zeros(self.W + 3, np.uint8)
         k = self.L.ovio_get_prior(self.h, J.ctypes.data, r.ctypes.data, x0.ctypes.data, pres.ctypes.data)
         return (J, r, x0, pres) if k else None
+
+
+class OracleGate:
+    """oracle restatement of the nodelet's frequency control (estimator_nodelet.cpp:234-286)"""
+    SKIP, TRACK, PUBLISH, FIRST, RESET = 0, 1, 2, 3, 4
+
+    def __init__(self, freq, frontend_freq):
+        self.L = oracle()
+        self.h = C.c_void_p(self.L.ovio_gate_create(int(freq), int(frontend_freq)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ovio_gate_destroy(self.h)
+            self.h = None
+
+    def step(self, t):
+        return self.L.ovio_gate_step(self.h, float(t))
+
+    def empty_map(self, t):
+        self.L.ovio_gate_empty_map(self.h, float(t))
 
 
 class OracleTracker:
@@ -191,8 +241,9 @@ def ate_rmse(est, gt):
     return float(np.sqrt(((al - gt) ** 2).sum(1).mean()))
 
 
-def run_oracle_sequence(cfg, sc, seq, n_frames, frames=None):
-    """Drive the oracle over n_frames of sequence seq. frames: optional list of (gray, depth) to reuse.
+def run_oracle_sequence(cfg, sc, seq, n_frames, frames=None, modes=None, hook=None):
+    """Drive the oracle over n_frames of sequence seq. frames: optional list of (gray, depth) to reuse; modes: optional per-frame
+    frame mode (0 skip / 1 track / 2 publish); hook(f, oracle): called after every frame.
     Returns dict(traj=[(frame, P(3), Q(4), V(3))], gt=..., status=[...], frames=[...])."""
     P = pkg()
     syn = P.Synth(sc)
@@ -211,13 +262,66 @@ def run_oracle_sequence(cfg, sc, seq, n_frames, frames=None):
         else:
             g, d = syn.render_host(seq, tf)
         out["frames"].append((g, d))
-        r = o.feed(g, d, tf)
+        r = o.feed(g, d, tf, 2 if modes is None else int(modes[f]))
         st = o.status()
         out["status"].append(st)
         out["processed"].append(r)
+        if hook is not None:
+            hook(f, o)
         if st["solver_flag"] == 1 and r == 1:
             w = o.window()
             out["traj"].append((f, w[cfg.window_size, :3].copy(), w[cfg.window_size, 3:7].copy(), w[cfg.window_size, 7:10].copy()))
             out["gt"].append(syn.pose(seq, tf)[0])
     out["oracle"] = o
+    return out
+
+
+def run_hip_batch(P, cfg, sc, seqs, n_frames, frames, modes=None, hook=None, imu_batch=False):
+    """Drive a VioBatch over host frames (frames[i][f] = (gray, depth) of sequence seqs[i]) with IMU pushed frame by frame.
+    modes: optional [n_frames] frame modes applied to every sequence; hook(f, batch) after every frame.
+    Returns (batch, traj, stat): per sequence [(frame, P, Q, V)] and [vio_status per frame]."""
+    syn = P.Synth(sc)
+    S = len(seqs)
+    b = P.VioBatch(cfg, S)
+    nimu = int(n_frames / sc.cam_rate * sc.imu_rate) + 64
+    imu = [syn.imu(s, nimu) for s in seqs]
+    k = [0] * S
+    traj = [[] for _ in seqs]
+    stat = [[] for _ in seqs]
+    for f, tf in enumerate(frame_times(sc, n_frames)):
+        k2 = [imu_until(imu[i][0], k[i], tf, sc.imu_rate) for i in range(S)]
+        if imu_batch:
+            stride = max(max(k2[i] - k[i] for i in range(S)), 1)
+            tt, aa, gg = np.zeros((S, stride)), np.zeros((S, stride, 3)), np.zeros((S, stride, 3))
+            for i in range(S):
+                m = k2[i] - k[i]
+                tt[i, :m] = imu[i][0][k[i]:k2[i]]; aa[i, :m] = imu[i][1][k[i]:k2[i]]; gg[i, :m] = imu[i][2][k[i]:k2[i]]
+            b.push_imu_batch(tt, aa, gg, n=[k2[i] - k[i] for i in range(S)])
+        else:
+            for i in range(S):
+                if k2[i] > k[i]:
+                    b.push_imu(i, imu[i][0][k[i]:k2[i]], imu[i][1][k[i]:k2[i]], imu[i][2][k[i]:k2[i]])
+        k = k2
+        gray = np.stack([frames[i][f][0] for i in range(S)])
+        depth = np.stack([frames[i][f][1] for i in range(S)])
+        b.feed(gray, depth, [tf] * S, modes=None if modes is None else [int(modes[f])] * S)
+        for i in range(S):
+            st = b.status(i)
+            stat[i].append(st)
+            if st.solver_flag == 1 and st.processed:
+                w = b.window(i)
+                traj[i].append((f, w[cfg.window_size, :3].copy(), w[cfg.window_size, 3:7].copy(), w[cfg.window_size, 7:10].copy()))
+        if hook is not None:
+            hook(f, b)
+    return b, traj, stat
+
+
+def gate_modes(gate, times):
+    """frame modes (0 skip / 1 track / 2 publish) a frame gate assigns to the stamps `times`; FIRST counts as publish (the
+    pipelines recognise the first image themselves), a RESET is not expected in a regular stream."""
+    out = []
+    for t in times:
+        d = gate.step(float(t))
+        assert d != 4, "unexpected stream discontinuity"
+        out.append(2 if d == 3 else d)
     return out

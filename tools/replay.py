@@ -30,7 +30,7 @@ def main():
         print("note:", n, file=sys.stderr)
     rec = io.RgbdImuDirectory(a.data)
     b = P.VioBatch(cfg, 1, imu_capacity=1 << 15)
-    rows = io.replay(b, rec, a.out)
+    rows = io.replay(b, rec, a.out, freq=extra["freq"], frontend_freq=extra["frontend_freq"])  # freq / frontend_freq: estimator_nodelet.cpp:264-286
     print("%d frames, %d odometry rows -> %s" % (len(rec), len(rows), a.out))
     if a.gt and len(rows) > 3:
         gt = np.loadtxt(a.gt, comments="#", ndmin=2)

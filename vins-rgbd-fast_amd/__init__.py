@@ -31,7 +31,7 @@ class Config(C.Structure):
     """vio_config (include/vio_abi.h); same field order as oracle ovio::Config."""
     _fields_ = [(n, C.c_int32) for n in (
         "width", "height", "max_cnt", "min_dist", "grid_rows", "grid_cols", "window_size", "max_landmarks", "fix_depth",
-        "estimate_extrinsic", "estimate_td", "max_iterations", "ransac_max_iters", "lk_max_level", "reserved0")] + \
+        "estimate_extrinsic", "estimate_td", "max_iterations", "ransac_max_iters", "lk_max_level", "dynamic_init")] + \
         [(n, C.c_double) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "focal_length", "f_threshold", "depth_min",
                                    "depth_max", "acc_n", "acc_w", "gyr_n", "gyr_w", "g_norm")] + \
         [("ric", C.c_double * 9), ("tic", C.c_double * 3)] + \
@@ -51,7 +51,11 @@ class Status(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "code", "solver_flag", "frame_count", "marginalization_flag", "n_landmarks", "last_track_num", "n_tracks", "processed",
         "iterations", "successful_steps", "n_in_problem", "n_residuals", "n_var_landmarks", "has_prior", "reboot_count",
-        "frames_processed")] + [(n, C.c_double) for n in ("initial_cost", "final_cost", "td")]
+        "frames_processed")] + [(n, C.c_double) for n in ("initial_cost", "final_cost", "td")] + \
+        [(n, C.c_int32) for n in ("overflow_flags", "overflow_frames", "iterations_total", "solves_total")]
+
+
+FRAME_SKIP, FRAME_TRACK, FRAME_PUBLISH = 0, 1, 2
 
 
 def build(verbose=False):
@@ -84,6 +88,17 @@ def lib():
         L.vio_track.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.vio_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.vio_sync.argtypes = [C.c_void_p]
+        L.vio_reset_seq.argtypes = [C.c_void_p, C.c_int]
+        L.vio_push_imu_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vio_feed_modes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.vio_track_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.vio_predict_motion.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        L.vio_process_obs.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        L.vio_process_obs_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.vio_get_packaged.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.vio_get_capacity.argtypes = [C.c_void_p, C.c_void_p]
+        L.vio_get_landmarks_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.vio_get_odometry_history.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.vio_get_stream.restype = C.c_void_p
         L.vio_get_stream.argtypes = [C.c_void_p]
         L.vio_get_status.argtypes = [C.c_void_p, C.c_int, C.POINTER(Status)]
@@ -107,6 +122,8 @@ def lib():
         L.vio_stage_imu_factor.argtypes = [C.POINTER(Config), C.c_int] + [C.c_void_p] * 14
         L.vio_stage_projection.argtypes = [C.POINTER(Config)] + [C.c_void_p] * 3 + [C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                                                                   C.c_int, C.c_void_p, C.c_void_p]
+        L.vio_stage_projection_residual.argtypes = L.vio_stage_projection.argtypes
+        L.vio_stage_imu_block.argtypes = [C.POINTER(Config), C.c_int] + [C.c_void_p] * 12
         _lib = L
     return _lib
 
@@ -209,20 +226,80 @@ class VioBatch:
         gyr = np.ascontiguousarray(gyr, np.float64).reshape(-1, 3)
         self._chk(self.L.vio_push_imu(self.h, seq, len(t), t.ctypes.data, acc.ctypes.data, gyr.ctypes.data), "vio_push_imu")
 
-    def feed(self, gray, depth, stamps, on_device=False):
+    def push_imu_batch(self, t, acc, gyr, n=None):
+        """vio_push_imu_batch: t [S][stride], acc / gyr [S][stride][3]; n = optional per-sequence counts."""
+        t = np.ascontiguousarray(t, np.float64).reshape(self.S, -1)
+        stride = t.shape[1]
+        acc = np.ascontiguousarray(acc, np.float64).reshape(self.S, stride, 3)
+        gyr = np.ascontiguousarray(gyr, np.float64).reshape(self.S, stride, 3)
+        nn = None if n is None else np.ascontiguousarray(n, np.int32).reshape(self.S)
+        self._chk(self.L.vio_push_imu_batch(self.h, None if nn is None else nn.ctypes.data, stride, t.ctypes.data, acc.ctypes.data,
+                                            gyr.ctypes.data), "vio_push_imu_batch")
+
+    def feed(self, gray, depth, stamps, on_device=False, modes=None):
         stamps = np.ascontiguousarray(stamps, np.float64).reshape(-1)
         assert len(stamps) == self.S
-        self._keep = (gray, depth, stamps)
-        self._chk(self.L.vio_feed(self.h, _ptr(gray), _ptr(depth), stamps.ctypes.data, 1 if on_device else 0), "vio_feed")
+        m = None if modes is None else np.ascontiguousarray(modes, np.uint8).reshape(self.S)
+        self._keep = (gray, depth, stamps, m)
+        self._chk(self.L.vio_feed_modes(self.h, _ptr(gray), _ptr(depth), stamps.ctypes.data, None if m is None else m.ctypes.data,
+                                        1 if on_device else 0), "vio_feed")
 
-    def track(self, gray, stamps, publish=True, on_device=False):
+    def track(self, gray, stamps, publish=True, on_device=False, modes=None, R_rel=None):
+        """vio_track / vio_track_ex: modes = per-sequence FRAME_* (default: publish for all), R_rel = caller-supplied relative
+        rotations [S][3][3] (rows of NaN = predict on the device)."""
         stamps = np.ascontiguousarray(stamps, np.float64).reshape(-1)
-        self._keep = (gray, stamps)
-        self._chk(self.L.vio_track(self.h, _ptr(gray), stamps.ctypes.data, 1 if publish else 0, 1 if on_device else 0), "vio_track")
+        if modes is None and R_rel is None:
+            self._keep = (gray, stamps)
+            self._chk(self.L.vio_track(self.h, _ptr(gray), stamps.ctypes.data, 1 if publish else 0, 1 if on_device else 0), "vio_track")
+            return
+        m = np.full(self.S, FRAME_PUBLISH if publish else FRAME_TRACK, np.uint8) if modes is None else \
+            np.ascontiguousarray(modes, np.uint8).reshape(self.S)
+        R = None if R_rel is None else np.ascontiguousarray(R_rel, np.float64).reshape(self.S, 9)
+        self._keep = (gray, stamps, m, R)
+        self._chk(self.L.vio_track_ex(self.h, _ptr(gray), stamps.ctypes.data, m.ctypes.data, None if R is None else R.ctypes.data,
+                                      1 if on_device else 0), "vio_track_ex")
+
+    def predict_motion(self, seq, t0, t1):
+        R = np.zeros(9)
+        self._chk(self.L.vio_predict_motion(self.h, seq, float(t0), float(t1), R.ctypes.data), "vio_predict_motion")
+        return R.reshape(3, 3)
 
     def process(self, depth, on_device=False):
         self._keep2 = depth
         self._chk(self.L.vio_process(self.h, _ptr(depth), 1 if on_device else 0), "vio_process")
+
+    def process_obs(self, seq, ids, obs, depth, stamp):
+        """Estimator::processImage(image, header) with a caller-supplied feature map (ids ascending, obs [n][7])."""
+        ids = np.ascontiguousarray(ids, np.int32).reshape(-1)
+        obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 7)
+        depth = np.ascontiguousarray(depth, np.uint16)
+        self._keep3 = (ids, obs, depth)
+        self._chk(self.L.vio_process_obs(self.h, seq, len(ids), ids.ctypes.data, obs.ctypes.data, depth.ctypes.data, float(stamp)),
+                  "vio_process_obs")
+
+    def process_obs_batch(self, n_obs, ids, obs, depth, stamps, on_device=False):
+        n_obs = np.ascontiguousarray(n_obs, np.int32).reshape(self.S)
+        ids = np.ascontiguousarray(ids, np.int32).reshape(self.S, -1)
+        cap = ids.shape[1]
+        obs = np.ascontiguousarray(obs, np.float64).reshape(self.S, cap, 7)
+        stamps = np.ascontiguousarray(stamps, np.float64).reshape(self.S)
+        self._keep3 = (n_obs, ids, obs, depth, stamps)
+        self._chk(self.L.vio_process_obs_batch(self.h, n_obs.ctypes.data, ids.ctypes.data, obs.ctypes.data, cap, _ptr(depth),
+                                               stamps.ctypes.data, 1 if on_device else 0), "vio_process_obs_batch")
+
+    def packaged(self, seq=0, cap=2048):
+        """The feature map packaged by the last track / feed (what the nodelet pushes to feature_buf): ids, obs [n][7]."""
+        ids, obs = np.zeros(cap, np.int32), np.zeros((cap, 7))
+        n = self._chk(self.L.vio_get_packaged(self.h, seq, cap, ids.ctypes.data, obs.ctypes.data), "vio_get_packaged")
+        return ids[:n].copy(), obs[:n].copy()
+
+    def capacity(self):
+        c = np.zeros(3, np.int32)
+        self._chk(self.L.vio_get_capacity(self.h, c.ctypes.data), "vio_get_capacity")
+        return dict(tracks=int(c[0]), landmarks=int(c[1]), imu=int(c[2]))
+
+    def reset_seq(self, seq):
+        self._chk(self.L.vio_reset_seq(self.h, seq), "vio_reset_seq")
 
     def sync(self):
         self._chk(self.L.vio_sync(self.h), "vio_sync")
@@ -250,7 +327,6 @@ class VioBatch:
 
     def odometry_history(self, seq=0, cap=2048):
         o = np.zeros((cap, 11))
-        self.L.vio_get_odometry_history.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         n = self._chk(self.L.vio_get_odometry_history(self.h, seq, cap, o.ctypes.data), "vio_get_odometry_history")
         return o[:min(n, cap)]
 
@@ -269,6 +345,11 @@ class VioBatch:
     def landmarks(self, seq=0, cap=4096):
         out = np.zeros((cap, 7))
         n = self._chk(self.L.vio_get_landmarks(self.h, seq, cap, out.ctypes.data), "vio_get_landmarks")
+        return out[:min(n, cap)]
+
+    def landmarks_ex(self, seq=0, cap=4096):
+        out = np.zeros((cap, 12))
+        n = self._chk(self.L.vio_get_landmarks_ex(self.h, seq, cap, out.ctypes.data), "vio_get_landmarks_ex")
         return out[:min(n, cap)]
 
     def prior(self, seq=0):
@@ -302,15 +383,21 @@ class FeatureTracker:
         self.ids = self.track_cnt = self.cur_pts = self.cur_un_pts = self.pts_velocity = None
 
     def readImage(self, img, cur_time, relative_R=None, publish=True):
-        """readImage(const cv::Mat&, double, const Matrix3d&): relative_R is computed on the device from the pushed IMU
-        samples (Estimator::predictMotion), so it is not an input here."""
+        """readImage(const cv::Mat&, double, const Matrix3d& relative_R = Identity) (feature_tracker.h:36-37); publish is the
+        global PUB_THIS_FRAME.  relative_R=None predicts it on the device from the pushed IMU (Estimator::predictMotion)."""
         assert self.b.S == 1, "the per-sequence mirror drives single-sequence batches"
-        self.b.track(np.ascontiguousarray(img, np.uint8), [cur_time], publish=publish)
+        R = None if relative_R is None else np.asarray(relative_R, np.float64).reshape(1, 9)
+        self.b.track(np.ascontiguousarray(img, np.uint8), [cur_time], publish=publish, R_rel=R)
         self.ids, self.track_cnt, self.cur_pts, self.cur_un_pts, self.pts_velocity = self.b.tracks(self.seq)
 
     def updateID(self, i):
         """ids are assigned on the device inside readImage; kept for call-site compatibility (estimator_nodelet.cpp:324-330)."""
         return i < len(self.ids)
+
+    def image_map(self):
+        """The feature map of estimator_nodelet.cpp:336-363 for the last published frame: {feature_id: (x, y, 1, u, v, vx, vy)}."""
+        ids, obs = self.b.packaged(self.seq)
+        return {int(i): o for i, o in zip(ids, obs)}
 
 
 class Estimator:
@@ -323,8 +410,20 @@ class Estimator:
     def inputIMU(self, t, linearAcceleration, angularVelocity):
         self.batch.push_imu(0, [t], [linearAcceleration], [angularVelocity])
 
-    def processImage(self, depth_mm):
-        """processImage(map<int, Matrix<double,7,1>>&, header): the feature map was packaged on the device by readImage."""
+    def predictMotion(self, t0, t1):
+        """Matrix3d predictMotion(double t0, double t1) (estimator.h:56, estimator.cpp:1790-1860)."""
+        return self.batch.predict_motion(0, t0, t1)
+
+    def processImage(self, image, header, depth_mm):
+        """processImage(const map<int, Matrix<double,7,1>>& image, const Header& header) (estimator.h:46) preceded by
+        f_manager.inputDepth(depth) (estimator_nodelet.cpp:537-539).  image: {feature_id: 7-vector}; header: stamp in seconds."""
+        ids = sorted(image)
+        obs = np.array([image[i] for i in ids], np.float64).reshape(-1, 7)
+        self.batch.process_obs(0, ids, obs, depth_mm, header)
+        return self.batch.status(0).code
+
+    def processLastTracked(self, depth_mm):
+        """Short cut without the host round trip: inputDepth + processImage on the map the last readImage packaged on the device."""
         self.batch.process(np.ascontiguousarray(depth_mm, np.uint16))
         return self.batch.status(0).code
 

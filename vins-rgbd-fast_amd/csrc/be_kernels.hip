@@ -180,7 +180,9 @@ __device__ void lm_compact(Ctx &c, int *flags, int *offs, int *scratch) {
 }  // namespace
 
 // ====================================================================================================== be_ingest
-__global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t *depth_base, size_t depth_stride) {
+// src.ids == NULL: the feature map packaged by the last vio_track / front-end of vio_feed (B.obs_id / B.obs / FeSeq);
+// otherwise a caller-supplied map (vio_process_obs = Estimator::processImage(image, header), estimator.h:46): n_obs[s] < 0 skips s.
+__global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t *depth_base, size_t depth_stride, IngestSrc src) {
     const int s = blockIdx.x + B.s0, t = threadIdx.x, nt = blockDim.x;
     Ctx c = make_ctx(B, s);
     const DevCfg &C = *B.cfg;
@@ -193,16 +195,22 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
     __shared__ int scratch[2 * 256 + 8];
     __shared__ double sred[256];
     __shared__ PreWork pw;
+    const bool ext = src.ids != nullptr;
+    const int ext_n = ext ? src.n_obs[s] : 0;
+    const double in_stamp = ext ? src.stamps[s] : fe.cur_time;
     if (t == 0) {
-        be.do_solve = 0; be.do_marg = 0; be.processed = 0; be.status_code = fe.n_forw == -2 ? VIO_NEED_IMU : VIO_OK; be.cur_stamp = fe.cur_time;
-        if (be.imu_count - be.imu_head > C.NIMU) be.imu_head = be.imu_count - C.NIMU;  // samples overwritten in the ring
+        be.do_solve = 0; be.do_marg = 0; be.processed = 0; be.rebooted = 0;
+        be.status_code = (!ext && fe.n_forw == -2) ? VIO_NEED_IMU : VIO_OK;
+        be.cur_stamp = in_stamp;
+        be.overflow = 0;
+        if (be.imu_count - be.imu_head > C.NIMU) { be.imu_head = be.imu_count - C.NIMU; be.overflow |= 16; }  // samples overwritten in the ring before they were consumed
     }
     __syncthreads();
-    if (fe.n_forw < 0 || !fe.publish_ok) return;
+    if (ext ? ext_n <= 0 : (fe.n_forw < 0 || !fe.publish_ok)) return;
     // ---- IMU availability (estimator.cpp:178-183, :1882-1888)
     const double *it = B.imu_t + (size_t)s * C.NIMU;
     const double *ia = B.imu_acc + (size_t)s * C.NIMU * 3, *ig = B.imu_gyr + (size_t)s * C.NIMU * 3;
-    double stamp = fe.cur_time, curTime = stamp + be.td;
+    double stamp = in_stamp, curTime = stamp + be.td;
     {
         bool have = be.imu_count > be.imu_head;
         double back_t = have ? it[(be.imu_count - 1) % C.NIMU] : -1e300;
@@ -214,9 +222,9 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
     const uint16_t *depth = depth_base + (size_t)s * depth_stride;
     const int fc = be.frame_count;
     // ---- addFeatureCheckParallax (feature_manager.cpp:56-123)
-    int nobs = fe.n_obs, nlm = be.n_lm;
-    const int *o_id = B.obs_id + (size_t)s * C.NP;
-    const double *o = B.obs + (size_t)s * C.NP * 7;
+    int nobs = ext ? min(ext_n, C.NP) : fe.n_obs, nlm = be.n_lm;
+    const int *o_id = ext ? src.ids + (size_t)s * src.cap : B.obs_id + (size_t)s * C.NP;
+    const double *o = ext ? src.obs + (size_t)s * src.cap * 7 : B.obs + (size_t)s * C.NP * 7;
     int *flag = c.lm_tmp;         // new-landmark flags per observation (NP <= NL is checked at create)
     int *offs = c.lm_pidx;        // temporary
     int tracked = 0;
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
     __syncthreads();
     for (int j = t; j < nobs; j += nt) {
         const double *p = o + (size_t)j * 7;
-        unsigned short mm = depth[(size_t)(int)p[4] * cfg.width + (int)p[3]];
+        unsigned short mm = depth[(size_t)min(max((int)p[4], 0), cfg.height - 1) * cfg.width + min(max((int)p[3], 0), cfg.width - 1)];
         double dmm = mm / 1000.0;
         int isnew = 0;
         if (!(0 < dmm && dmm < cfg.depth_min)) {
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
             if (!flag[j] || offs[j] >= can) continue;
             int slot = c.lm_free[nfree - 1 - offs[j]];
             const double *p = o + (size_t)j * 7;
-            unsigned short mm = depth[(size_t)(int)p[4] * cfg.width + (int)p[3]];
+            unsigned short mm = depth[(size_t)min(max((int)p[4], 0), cfg.height - 1) * cfg.width + min(max((int)p[3], 0), cfg.width - 1)];
             c.lm_id[slot] = o_id[j]; c.lm_start[slot] = fc; c.lm_nobs[slot] = 1; c.lm_est[slot] = 0; c.lm_solve[slot] = 0;
             c.lm_dyn[slot] = 0; c.lm_depth[slot] = -1.0;
             double *q = obs_ptr(c, slot, fc);
@@ -688,6 +696,30 @@ __device__ __forceinline__ void lm_row(const double *__restrict__ res, double *_
     }
 }
 
+// IMU factor block on the FP64 matrix cores (one wavefront): raw_l = [J_raw | r_whitened] (15 x 31, LDS), M_l = chol(cov)^-1 (15 x 15
+// lower triangular, LDS).  The rows of J are whitened on the fly (x = M J_raw, one output row per lane group) and the 31 x 31 Gram
+// matrix [Jw r]^T [Jw r] is accumulated with K = 16 (row 15 is padding): a00 = rows / cols 0-15, a10 = rows 16-31 x cols 0-15,
+// a11 = rows / cols 16-31, in the C/D layout of v_mfma_f64_16x16x4_f64 (element r of lane (lk, li) = row lk + 4 r, column li).
+__device__ __forceinline__ void imu_block_mfma(const double *raw_l, const double *M_l, int li, int lk, v4f64 &a00, v4f64 &a10, v4f64 &a11) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        const int kk = 4 * ks + lk;
+        double x0 = 0, x1 = 0;
+        if (kk < 15) {
+            const int c1 = 16 + li;
+            for (int k = 0; k <= kk; k++) {
+                double m = M_l[kk * 15 + k];
+                x0 += m * raw_l[k * 31 + li];
+                if (c1 < 30) x1 += m * raw_l[k * 31 + c1];
+            }
+            if (c1 == 30) x1 = raw_l[kk * 31 + 30];
+        }
+        a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, a00, 0, 0, 0);
+        a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, a10, 0, 0, 0);
+        a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, a11, 0, 0, 0);
+    }
+}
+
 // assemble H (P x P, ld LW), g (vec slot 0), Hpl / Hll / gl from the stored residual Jacobians.
 // work: LDS scratch (>= max(W*450, npairs*210) doubles when it fits, see be_solve); pb = frame-pair blocks (LDS or HBM)
 __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Params &X, int nres, int Fa, const int *alist, double *srp, double *work,
@@ -743,23 +775,7 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
                 __syncthreads();
                 if (act) {
                     v4f64 a00 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
-#pragma unroll
-                    for (int ks = 0; ks < 4; ks++) {
-                        const int kk = 4 * ks + lk;
-                        double x0 = 0, x1 = 0;
-                        if (kk < 15) {
-                            const int c1 = 16 + li;
-                            for (int k = 0; k <= kk; k++) {
-                                double m = M_l[kk * 15 + k];
-                                x0 += m * raw_l[k * 31 + li];
-                                if (c1 < 30) x1 += m * raw_l[k * 31 + c1];
-                            }
-                            if (c1 == 30) x1 = raw_l[kk * 31 + 30];
-                        }
-                        a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, a00, 0, 0, 0);
-                        a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, a10, 0, 0, 0);
-                        a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, a11, 0, 0, 0);
-                    }
+                    imu_block_mfma(raw_l, M_l, li, lk, a00, a10, a11);
                     auto gidx = [&](int a) {
                         return a < 6 ? 6 * i + a : (a < 15 ? 6 * (W + 1) + 9 * i + (a - 6) : (a < 21 ? 6 * (i + 1) + (a - 15) : 6 * (W + 1) + 9 * (i + 1) + (a - 21)));
                     };
@@ -1406,6 +1422,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
     // ---- write back flat parameters + double2vector (estimator.cpp:985-1111)
     if (t == 0) {
         be.final_cost = cost; be.iterations = iters_done; be.successful = succ;
+        be.iter_total += iters_done; be.solve_total++;
         be.dbg[4] = (int)(wall_clock64() - ts0);
         v3 origin_R0 = R2ypr(ldm(be.Rs[0]));
         v3 origin_P0 = ld3(be.Ps[0]);
@@ -1446,6 +1463,46 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
         c.lm_depth[slot] = d;
         c.lm_solve[slot] = d < 0 ? 2 : 1;
     }
+    __syncthreads();
+    // failureDetection + clearState() / setParameter() (estimator.cpp:345-353, 1113-1159, 43-116, 15-41).  The reference runs it
+    // after optimization() (solve + marginalisation) and throws the whole state away when it fires, so nothing the marginalisation
+    // produces survives a reboot: it is decided HERE, before the host records ev_solve, because the reset rewrites imu_head / td /
+    // ric / latest_Bg, which the next frame's front-end (fe_begin) and the IMU scatter kernel read as soon as this kernel is done.
+    if (be.solver_flag == 1) {
+        if (t == 0) {
+            int fail = 0;
+            if (nrm(ld3(be.Bas[W])) > 2.5) fail = 1;
+            if (nrm(ld3(be.Bgs[W])) > 1.0) fail = 1;
+            v3 tmpP = ld3(be.Ps[W]);
+            if (nrm(sub(tmpP, ld3(be.last_P))) > 5) fail = 1;
+            if (fabs(tmpP.z - be.last_P[2]) > 1) fail = 1;
+            sh_i[0] = fail;
+        }
+        __syncthreads();
+        if (sh_i[0]) {
+            for (int k = t; k < c.NL; k += nt) c.lm_free[k] = c.NL - 1 - k;
+            if (t == 0) {
+                for (int i = 0; i <= W + 1; i++) c.pre[i].valid = 0;
+                for (int i = 0; i <= W; i++) {
+                    for (int k = 0; k < 3; k++) { be.Ps[i][k] = 0; be.Vs[i][k] = 0; be.Bas[i][k] = 0; be.Bgs[i][k] = 0; }
+                    stm(be.Rs[i], eye());
+                    be.Headers[i] = 0;
+                    be.pre_idx[i] = i;
+                }
+                for (int k = 0; k < 9; k++) be.ric[k] = cfg.ric[k];
+                for (int k = 0; k < 3; k++) { be.tic[k] = cfg.tic[k]; be.latest_Bg[k] = 0; }
+                be.td = cfg.td;
+                be.first_imu = 0; be.frame_count = 0; be.solver_flag = 0; be.openExEstimation = 0; be.has_prior = 0;
+                be.initFirstPoseFlag = 0; be.prevTime = -1; be.n_lm = 0; be.n_free = c.NL; be.ring_base = 0;
+                be.imu_head = be.imu_count;  // clearState() empties imu_buf
+                be.reboot_count++;
+                be.status_code = VIO_REBOOTED;
+                be.rebooted = 1;
+                be.do_marg = 0;
+                be.overflow = 0;
+            }
+        }
+    }
 }
 
 // ====================================================================================================== be_marg
@@ -1458,7 +1515,7 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
     const DevCfg &C = *B.cfg;
     const vio_config &cfg = C.c;
     BeSeq &be = *c.be;
-    if (!be.do_marg || be.frame_count < c.W) return;
+    if (!be.do_marg || be.rebooted || be.frame_count < c.W) return;
     const int W = c.W, W1 = W + 1, n = c.NPR;
     const double eps = 1e-8;
     __shared__ Params X;
@@ -1911,7 +1968,7 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
     const int W = c.W, W1 = W + 1;
     __shared__ int sh_i[4];
     double *od = B.odom + (size_t)s * 11;
-    if (!be.processed) return;
+    if (!be.processed || be.rebooted) return;
     int nlm = be.n_lm;
     int *flag = c.lm_pidx, *offs = c.lm_aidx;  // free after the solve
     const int fc = be.frame_count;
@@ -1959,39 +2016,7 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
             if (cnt > 0) c.lm_dyn[slot] = (cfg.focal_length * err / cnt > 10 || err3 / cnt > 2.0) ? 1 : 0;
         }
         __syncthreads();
-        // failureDetection (estimator.cpp:1113-1159)
-        if (t == 0) {
-            int fail = 0;
-            if (nrm(ld3(be.Bas[W])) > 2.5) fail = 1;
-            if (nrm(ld3(be.Bgs[W])) > 1.0) fail = 1;
-            v3 tmpP = ld3(be.Ps[W]);
-            if (nrm(sub(tmpP, ld3(be.last_P))) > 5) fail = 1;
-            if (fabs(tmpP.z - be.last_P[2]) > 1) fail = 1;
-            sh_i[0] = fail;
-        }
-        __syncthreads();
-        if (sh_i[0]) {
-            // clearState() + setParameter() (estimator.cpp:345-353, 43-116, 15-41)
-            for (int k = t; k < c.NL; k += nt) c.lm_free[k] = c.NL - 1 - k;
-            if (t == 0) {
-                for (int i = 0; i <= W + 1; i++) c.pre[i].valid = 0;
-                for (int i = 0; i <= W; i++) {
-                    for (int k = 0; k < 3; k++) { be.Ps[i][k] = 0; be.Vs[i][k] = 0; be.Bas[i][k] = 0; be.Bgs[i][k] = 0; }
-                    stm(be.Rs[i], eye());
-                    be.Headers[i] = 0;
-                    be.pre_idx[i] = i;
-                }
-                for (int k = 0; k < 9; k++) be.ric[k] = cfg.ric[k];
-                for (int k = 0; k < 3; k++) { be.tic[k] = cfg.tic[k]; be.latest_Bg[k] = 0; }
-                be.td = cfg.td;
-                be.first_imu = 0; be.frame_count = 0; be.solver_flag = 0; be.openExEstimation = 0; be.has_prior = 0;
-                be.initFirstPoseFlag = 0; be.prevTime = -1; be.n_lm = 0; be.n_free = c.NL; be.ring_base = 0;
-                be.imu_head = be.imu_count;  // clearState() empties imu_buf
-                be.reboot_count++;
-                be.status_code = VIO_REBOOTED;
-            }
-            return;
-        }
+        // failureDetection (estimator.cpp:1113-1159) ran at the end of be_solve (see there); a sequence that rebooted never gets here
     }
     // ---- slideWindow (estimator.cpp:1580-1689)
     if (be.marginalization_flag == 0) {
@@ -2103,11 +2128,10 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
         od[4] = q.w; od[5] = q.x; od[6] = q.y; od[7] = q.z;
         od[8] = be.Vs[W][0]; od[9] = be.Vs[W][1]; od[10] = be.Vs[W][2];
         int hc = B.odom_count[s];
-        if (hc < B.hist_cap) {
-            double *hrow = B.odom_hist + ((size_t)s * B.hist_cap + hc) * 11;
-            for (int k = 0; k < 11; k++) hrow[k] = od[k];
-        }
+        double *hrow = B.odom_hist + ((size_t)s * B.hist_cap + (hc % B.hist_cap)) * 11;  // ring: the getter un-rotates it
+        for (int k = 0; k < 11; k++) hrow[k] = od[k];
         B.odom_count[s] = hc + 1;
+        if (be.overflow) be.overflow_frames++;
     }
 }
 
@@ -2150,20 +2174,56 @@ __global__ __launch_bounds__(256) void be_stage_imu_kernel(vio_config cfg, PreIn
         for (int r = 0; r < 15; r++) { J480[r * 7 + 6] = 0; J480[240 + r * 7 + 6] = 0; }
     }
 }
-__global__ void be_stage_projection_kernel(vio_config cfg, const double *in /*pi7 pj7 ex7 inv_dep td oi9 oj9*/, int use_td, double *r2, double *J46) {
+__global__ void be_stage_projection_kernel(vio_config cfg, const double *in /*pi7 pj7 ex7 inv_dep td oi9 oj9*/, int use_td, int form, double *r2, double *J46) {
     if (threadIdx.x != 0) return;
-    // the same frame-pair formulation the solver uses (evaluate()); bf::eval_projection is the per-residual form used by the
+    // form 0: the frame-pair formulation the solver uses (evaluate()); form 1: bf::eval_projection, the per-residual form used by the
     // marginalisation and by outlier rejection
     double J[40], wgt;
-    bf::PairGeo g;
-    bf::pair_geo(in, in + 7, in + 14, g);
-    double ricm[9];
-    stm(ricm, q2R(mkq(in[14 + 6], in[14 + 3], in[14 + 4], in[14 + 5])));
-    bf::eval_projection_pair(cfg, g, ricm, in + 14, in[21], in[22], in + 23, in + 32, use_td != 0, r2, J, false, &wgt);
+    if (form == 0) {
+        bf::PairGeo g;
+        bf::pair_geo(in, in + 7, in + 14, g);
+        double ricm[9];
+        stm(ricm, q2R(mkq(in[14 + 6], in[14 + 3], in[14 + 4], in[14 + 5])));
+        bf::eval_projection_pair(cfg, g, ricm, in + 14, in[21], in[22], in + 23, in + 32, use_td != 0, r2, J, false, &wgt);
+    } else
+        bf::eval_projection(cfg, in, in + 7, in + 14, in[21], in[22], in + 23, in + 32, use_td != 0, r2, J);
     for (int a = 0; a < 2; a++) {
         for (int d = 0; d < 6; d++) { J46[a * 7 + d] = J[a * 20 + d]; J46[14 + a * 7 + d] = J[a * 20 + 6 + d]; J46[28 + a * 7 + d] = J[a * 20 + 12 + d]; }
         J46[a * 7 + 6] = 0; J46[14 + a * 7 + 6] = 0; J46[28 + a * 7 + 6] = 0;
         J46[42 + a] = J[a * 20 + 19];
         J46[44 + a] = J[a * 20 + 18];
+    }
+}
+// The IMU factor exactly as evaluate() + assemble() process it in the solver: raw residual whitened by thread 0, the four raw
+// Jacobian column groups by imu_raw_jacobian_part, then [Jw r]^T [Jw r] on the matrix cores (imu_block_mfma).  One wavefront.
+// G961: the 31 x 31 Gram matrix, row-major, columns = pose_i(6) speedbias_i(9) pose_j(6) speedbias_j(9) | r.
+__global__ __launch_bounds__(64) void be_stage_imu_block_kernel(const PreInt *P, const double *par /*pi7 sbi9 pj7 sbj9*/, double g_norm, double *G961) {
+    __shared__ double raw_l[472], M_l[232];
+    const int lane = threadIdx.x;
+    const PreInt &p = *P;
+    v3 G = mk(0, 0, g_norm);
+    if (lane == 0) {
+        double raw[15];
+        bf::imu_raw_residual(p, G, par, par + 7, par + 16, par + 23, raw);
+        for (int r = 0; r < 15; r++) {
+            double sacc = 0;
+            for (int k = 0; k <= r; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k];
+            raw_l[r * 31 + 30] = sacc;
+        }
+    } else if (lane <= 4)
+        bf::imu_raw_jacobian_part(p, G, par, par + 7, par + 16, par + 23, lane - 1, raw_l, 31);
+    for (int q = lane; q < 225; q += 64) M_l[q] = p.sqrt_info[q];
+    __syncthreads();
+    const int li = lane & 15, lk = lane >> 4;
+    v4f64 a00 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
+    imu_block_mfma(raw_l, M_l, li, lk, a00, a10, a11);
+    for (int r = 0; r < 4; r++) {
+        const int row = lk + 4 * r, col = li;
+        G961[row * 31 + col] = a00[r];
+        if (16 + row < 31) {
+            G961[(16 + row) * 31 + col] = a10[r];
+            G961[col * 31 + 16 + row] = a10[r];
+            if (16 + col < 31) G961[(16 + row) * 31 + 16 + col] = a11[r];
+        }
     }
 }

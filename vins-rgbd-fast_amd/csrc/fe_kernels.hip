@@ -83,8 +83,60 @@ __device__ __forceinline__ bool in_disk(const int *hw, int r, int px, int py, in
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ fe_begin
-// grid S, 64 threads.  mode: 0 = vio_feed (nodelet gating), 1 = vio_track only (no gating)
-__global__ void fe_begin_kernel(Batch B, const double *stamps, int gate) {
+// Estimator::predictMotion(t0, t1) (estimator.cpp:1790-1860): gyro integration over the IMU ring, nothing is consumed.  The rotation
+// into the camera frame uses the CONFIGURED extrinsic (the global RIC.back(), :1852), which stays at its yaml value while
+// ESTIMATE_EXTRINSIC refines Estimator::ric.
+__device__ dm::m3 predict_motion(const Batch &B, int s, double t0, double t1) {
+    const DevCfg &C = *B.cfg;
+    const BeSeq &be = B.be[s];
+    int imu_head = be.imu_head;
+    if (be.imu_count - imu_head > C.NIMU) imu_head = be.imu_count - C.NIMU;  // ring bookkeeping: samples that were overwritten
+    const double *it = B.imu_t + (size_t)s * C.NIMU;
+    const double *ig = B.imu_gyr + (size_t)s * C.NIMU * 3;
+    const bool have = be.imu_count > imu_head;
+    const double back_t = have ? it[(be.imu_count - 1) % C.NIMU] : -1e300;
+    dm::m3 rel = dm::eye();
+    if (!(have && t1 <= back_t)) return rel;
+    int k = imu_head;
+    while (k < be.imu_count && it[k % C.NIMU] <= t0) k++;
+    bool first = true;
+    double prev_t = 0;
+    dm::v3 prev_gyr = dm::mk(0, 0, 0);
+    dm::m3 ricT = dm::tr(dm::ldm(C.c.ric));
+    dm::v3 bg = dm::ld3(be.latest_Bg);
+    while (k < be.imu_count && it[k % C.NIMU] <= t1) {
+        double tk = it[k % C.NIMU];
+        dm::v3 w = dm::ld3(ig + (size_t)(k % C.NIMU) * 3);
+        k++;
+        if (first) { prev_t = tk; first = false; prev_gyr = w; continue; }
+        double dt = tk - prev_t;
+        prev_t = tk;
+        dm::v3 un_gyr = dm::sub(dm::scl(0.5, dm::add(prev_gyr, w)), bg);
+        prev_gyr = w;
+        dm::v3 aa = dm::scl(dt, dm::mul(ricT, un_gyr));
+        double ang = dm::nrm(aa);
+        dm::m3 Rk = dm::eye();
+        if (ang > 0) {
+            dm::v3 ax = dm::scl(1.0 / ang, aa);
+            double sn = sin(ang), cs = cos(ang);
+            dm::m3 K = dm::skew(ax);
+            Rk = dm::add(dm::add(dm::eye(), dm::scl(sn, K)), dm::scl(1 - cs, dm::mul(K, K)));
+        }
+        rel = dm::mul(rel, dm::tr(Rk));
+    }
+    return rel;
+}
+// vio_predict_motion: one sequence, result to out9 (row-major)
+__global__ void fe_predict_motion_kernel(Batch B, int seq, double t0, double t1, double *out9) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    dm::stm(out9, predict_motion(B, seq, t0, t1));
+}
+
+// grid S, 64 threads.  gate: 1 = vio_feed (nodelet gating: IMU availability, first-image skip, init_pub / init_feature), 0 = vio_track.
+// modes: per-sequence frame mode (VIO_FRAME_SKIP / TRACK / PUBLISH) or NULL = `publish` for every sequence.
+// R_rel: caller-supplied relative rotations [S][9] (readImage(img, t, relative_R), feature_tracker.h:36-37) or NULL; a NaN in the
+// first element of a sequence's matrix means "predict on the device" for that sequence.
+__global__ void fe_begin_kernel(Batch B, const double *stamps, int gate, int publish, const uint8_t *modes, const double *R_rel) {
     int s = blockIdx.x + B.s0;
     if (threadIdx.x != 0) return;
     const DevCfg &C = *B.cfg;
@@ -94,14 +146,15 @@ __global__ void fe_begin_kernel(Batch B, const double *stamps, int gate) {
     fe.n_deficit = 0;
     fe.n_obs = 0;
     fe.publish_ok = 0;
-    // ring bookkeeping: drop samples that were overwritten
-    int imu_head = be.imu_head;
-    if (be.imu_count - imu_head > C.NIMU) imu_head = be.imu_count - C.NIMU;
-    const double *it = B.imu_t + (size_t)s * C.NIMU;
-    const double *ig = B.imu_gyr + (size_t)s * C.NIMU * 3;
-    bool have = be.imu_count > imu_head;
-    double back_t = have ? it[(be.imu_count - 1) % C.NIMU] : -1e300;
+    fe.overflow = 0;
+    const int mode = modes ? (int)modes[s] : (publish ? VIO_FRAME_PUBLISH : VIO_FRAME_TRACK);
+    fe.pub_req = mode == VIO_FRAME_PUBLISH;
     if (gate) {
+        int imu_head = be.imu_head;
+        if (be.imu_count - imu_head > C.NIMU) imu_head = be.imu_count - C.NIMU;
+        const double *it = B.imu_t + (size_t)s * C.NIMU;
+        bool have = be.imu_count > imu_head;
+        double back_t = have ? it[(be.imu_count - 1) % C.NIMU] : -1e300;
         // caller contract of vio_feed: IMU pushed through stamp + td (upstream busy-waits, estimator.cpp:178-183)
         if (!(have && t + be.td <= back_t)) {
             fe.n_forw = -2;  // nothing consumed; tells the later kernels to skip this sequence (be_ingest reports VIO_NEED_IMU)
@@ -114,39 +167,19 @@ __global__ void fe_begin_kernel(Batch B, const double *stamps, int gate) {
             return;
         }
     }
-    // Estimator::predictMotion(last_image_time, t + td)  estimator.cpp:1790-1860
-    dm::m3 rel = dm::eye();
-    double t0 = fe.last_image_time, t1 = t + be.td;
-    if (have && t1 <= back_t) {
-        int k = imu_head;
-        while (k < be.imu_count && it[k % C.NIMU] <= t0) k++;
-        bool first = true;
-        double prev_t = 0;
-        dm::v3 prev_gyr = dm::mk(0, 0, 0);
-        dm::m3 ricT = dm::tr(dm::ldm(be.ric));
-        dm::v3 bg = dm::ld3(be.latest_Bg);
-        while (k < be.imu_count && it[k % C.NIMU] <= t1) {
-            double tk = it[k % C.NIMU];
-            dm::v3 w = dm::ld3(ig + (size_t)(k % C.NIMU) * 3);
-            k++;
-            if (first) { prev_t = tk; first = false; prev_gyr = w; continue; }
-            double dt = tk - prev_t;
-            prev_t = tk;
-            dm::v3 un_gyr = dm::sub(dm::scl(0.5, dm::add(prev_gyr, w)), bg);
-            prev_gyr = w;
-            dm::v3 aa = dm::scl(dt, dm::mul(ricT, un_gyr));
-            double ang = dm::nrm(aa);
-            dm::m3 Rk = dm::eye();
-            if (ang > 0) {
-                dm::v3 ax = dm::scl(1.0 / ang, aa);
-                double sn = sin(ang), cs = cos(ang);
-                dm::m3 K = dm::skew(ax);
-                Rk = dm::add(dm::add(dm::eye(), dm::scl(sn, K)), dm::scl(1 - cs, dm::mul(K, K)));
-            }
-            rel = dm::mul(rel, dm::tr(Rk));
-        }
+    if (mode == VIO_FRAME_SKIP) {  // frequency control dropped the frame before readImage (estimator_nodelet.cpp:264-271): no state changes
+        fe.n_forw = -1;
+        return;
     }
-    dm::stm(fe.R_rel, rel);
+    // Estimator::predictMotion(last_image_time, t + td), unless the caller handed in relative_R
+    const double *Rc = R_rel ? R_rel + (size_t)s * 9 : nullptr;
+    if (Rc && Rc[0] == Rc[0]) {
+        for (int k = 0; k < 9; k++) fe.R_rel[k] = Rc[k];
+        fe.use_R_rel = 1;
+    } else {
+        dm::stm(fe.R_rel, predict_motion(B, s, fe.last_image_time, t + be.td));
+        fe.use_R_rel = 0;
+    }
     fe.last_image_time = t;
     fe.cur_time = t;
     fe.n_forw = 0;
@@ -662,12 +695,13 @@ __global__ __launch_bounds__(256) void fe_ransac_stage_kernel(vio_config c, int 
 
 // ------------------------------------------------------------------------------------------------ fe_select
 // grid S, 256 threads, dynamic LDS:  per point: cur(8) forw(8) un(8) id(4) cnt(4) flag(4) offs(4) perm(4) + 4 doubles
-__global__ __launch_bounds__(256) void fe_select_kernel(Batch B, int publish) {
+__global__ __launch_bounds__(256) void fe_select_kernel(Batch B) {
     const DevCfg &C = *B.cfg;
     const vio_config &c = C.c;
     const int s = blockIdx.x + B.s0, t = threadIdx.x, NP = C.NP;
     FeSeq &fe = B.fe[s];
     if (fe.n_forw < 0) return;
+    const int publish = fe.pub_req;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *X1 = (double *)smem, *Y1 = X1 + NP, *X2 = Y1 + NP, *Y2 = X2 + NP;
     float2 *cur = (float2 *)(Y2 + NP), *forw = cur + NP, *un = forw + NP, *tmp2 = un + NP;
@@ -912,7 +946,7 @@ __global__ __launch_bounds__(256) void fe_fast_kernel(Batch B) {
     const DevCfg &C = *B.cfg;
     int s = blockIdx.y + B.s0, cell = blockIdx.x;
     FeSeq &fe = B.fe[s];
-    if (fe.n_forw < 0 || fe.cell_ncand[cell] < 0) return;
+    if (fe.n_forw < 0 || !fe.pub_req || fe.cell_ncand[cell] < 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GridRect r = C.rect[cell];
     uint8_t *tile = smem, *score = tile + ((r.w * r.h + 15) & ~15);
@@ -922,7 +956,7 @@ __global__ __launch_bounds__(256) void fe_fast_kernel(Batch B) {
     uint32_t *out = B.cand + ((size_t)s * C.ncells + cell) * VIO_FAST_CAP;
     int total = fast_cell(img, C.c.width, r, tile, score, rowoff, out, VIO_FAST_CAP);
     if (threadIdx.x == 0) {
-        if (total > VIO_FAST_CAP) { total = VIO_FAST_CAP; atomicOr(&B.be[s].overflow, 4); }
+        if (total > VIO_FAST_CAP) { total = VIO_FAST_CAP; fe.overflow |= 4; }
         fe.cell_ncand[cell] = total;
     }
 }
@@ -939,12 +973,13 @@ __global__ __launch_bounds__(256) void fe_fast_stage_kernel(const uint8_t *img, 
 // Per sequence, cells in order: mask filter (runByPixelsMask), top-k by response (replace-min scan), addPoints greedy;
 // then cur <- forw, undistortedPoints, velocity, updateID, feature-map packaging in ascending id.
 // grid S, 256 threads, dynamic LDS.
-__global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int publish, int gate) {
+__global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int gate) {
     const DevCfg &C = *B.cfg;
     const vio_config &c = C.c;
     const int s = blockIdx.x + B.s0, t = threadIdx.x, NP = C.NP;
     FeSeq &fe = B.fe[s];
     if (fe.n_forw < 0) return;
+    const int publish = fe.pub_req;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int hw_s[64];                          // cv::circle half-widths (min_dist <= 63) out of the global config
     for (int k = t; k < 64; k += blockDim.x) hw_s[k] = k <= c.min_dist ? C.circle_hw[k] : 0;

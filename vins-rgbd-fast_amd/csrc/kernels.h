@@ -10,24 +10,34 @@ struct LkImages {
     int w[4], h[4];
 };
 
-__global__ void fe_begin_kernel(Batch B, const double *stamps, int gate);
+__global__ void fe_begin_kernel(Batch B, const double *stamps, int gate, int publish, const uint8_t *modes, const double *R_rel);
+__global__ void fe_predict_motion_kernel(Batch B, int seq, double t0, double t1, double *out9);
 __global__ void fe_pyrdown_kernel(Batch B, const uint8_t *src_base, size_t src_stride, int sw, int sh, int dst_level, int write_level0);
 __global__ void fe_pyrdown_stage_kernel(const uint8_t *src, int sw, int sh, uint8_t *dst);
 __global__ void fe_predict_kernel(Batch B);
 __global__ void fe_lk_kernel(Batch B);
 __global__ void fe_lk_stage_kernel(LkImages im, int maxLevel, int n, const float2 *prevPts, float2 *nextPts, uint8_t *status);
 __global__ void fe_ransac_stage_kernel(vio_config c, int n, const float2 *p1, const float2 *p2, uint8_t *status);
-__global__ void fe_select_kernel(Batch B, int publish);
+__global__ void fe_select_kernel(Batch B);
 __global__ void fe_fast_kernel(Batch B);
 __global__ void fe_fast_stage_kernel(const uint8_t *img, int W, GridRect r, uint32_t *out, int cap, int *count);
-__global__ void fe_add_kernel(Batch B, int publish, int gate);
-__global__ void be_ingest_kernel(Batch B, const uint16_t *depth_base, size_t depth_stride);
+__global__ void fe_add_kernel(Batch B, int gate);
+// feature-map source of be_ingest: ids == NULL selects the map packaged on the device by the front-end
+struct IngestSrc {
+    const int *n_obs;       // [S] entries per sequence (< 0: skip the sequence)
+    const int *ids;         // [S][cap] ascending feature ids
+    const double *obs;      // [S][cap][7] x y z u v vx vy
+    const double *stamps;   // [S] header stamps
+    int cap;
+};
+__global__ void be_ingest_kernel(Batch B, const uint16_t *depth_base, size_t depth_stride, IngestSrc src);
 __global__ void be_solve_kernel(Batch B);
 __global__ void be_solve_kernel_512(Batch B);
 __global__ void be_marg_kernel(Batch B);
 __global__ void be_prior_factor_kernel(Batch B, int seq);
 __global__ void be_stage_imu_kernel(vio_config cfg, PreInt *P, int n, const double *dt, const double *acc, const double *gyr,
                                     const double *par, double g_norm, double *preint_out, double *r15, double *J480);
-__global__ void be_stage_projection_kernel(vio_config cfg, const double *in, int use_td, double *r2, double *J46);
+__global__ void be_stage_projection_kernel(vio_config cfg, const double *in, int use_td, int form, double *r2, double *J46);
+__global__ void be_stage_imu_block_kernel(const PreInt *P, const double *par, double g_norm, double *G961);
 __global__ void imu_scatter_kernel(Batch B, int total, const int *seq_of, const double *t, const double *acc, const double *gyr);
 __global__ void synth_render_kernel(vio_synth_config c, int S, uint64_t seq0, const float *rays, const float *poses, uint8_t *gray, uint16_t *depth);

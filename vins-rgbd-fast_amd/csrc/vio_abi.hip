@@ -57,6 +57,12 @@ struct vio_batch {
     uint8_t *d_gray_stage = nullptr;
     uint16_t *d_depth_stage = nullptr;
     double *d_stamps = nullptr;
+    uint8_t *d_modes = nullptr;       // [S] frame modes of the current vio_feed_modes / vio_track_ex call
+    double *d_rrel = nullptr;         // [S][9] caller-supplied relative rotations (vio_track_ex)
+    // caller-supplied feature maps (vio_process_obs): [S] counts / stamps, [S][NP] ids, [S][NP][7] observations
+    int *d_in_n = nullptr, *d_in_ids = nullptr;
+    double *d_in_obs = nullptr, *d_in_stamps = nullptr;
+    double *d_r9 = nullptr;           // vio_predict_motion result
     // pending IMU samples (host staging)
     std::mutex imu_mu;
     std::vector<int> p_seq;
@@ -145,14 +151,15 @@ template <class T> int dalloc(vio_batch *h, T **p, size_t n) {
     return VIO_OK;
 }
 
-int init_state(vio_batch *h) {
+// (re)initialise the state of sequences [s_lo, s_hi): Estimator::clearState() + setParameter() and a fresh FeatureTracker
+int init_state(vio_batch *h, int s_lo, int s_hi) {
     const DevCfg &C = h->hc;
-    int S = h->S, W = C.W;
-    std::vector<FeSeq> fe(S);
-    std::vector<BeSeq> be(S);
-    memset(fe.data(), 0, sizeof(FeSeq) * S);
-    memset(be.data(), 0, sizeof(BeSeq) * S);
-    for (int s = 0; s < S; s++) {
+    int n = s_hi - s_lo, W = C.W;
+    std::vector<FeSeq> fe(n);
+    std::vector<BeSeq> be(n);
+    memset(fe.data(), 0, sizeof(FeSeq) * n);
+    memset(be.data(), 0, sizeof(BeSeq) * n);
+    for (int s = 0; s < n; s++) {
         FeSeq &f = fe[s];
         f.first_image_flag = 1;
         for (int k = 0; k < C.ncells; k++) f.grids_texture_status[k] = 1;
@@ -166,16 +173,28 @@ int init_state(vio_batch *h) {
         b.prevTime = -1;
         b.n_free = C.NL;
     }
-    HIPCHK(hipMemcpy(h->B.fe, fe.data(), sizeof(FeSeq) * S, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(h->B.be, be.data(), sizeof(BeSeq) * S, hipMemcpyHostToDevice));
-    std::vector<int> fr((size_t)S * C.NL);
-    for (int s = 0; s < S; s++) for (int k = 0; k < C.NL; k++) fr[(size_t)s * C.NL + k] = C.NL - 1 - k;
-    HIPCHK(hipMemcpy(h->B.lm_free, fr.data(), fr.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(h->B.pre, 0, sizeof(PreInt) * (size_t)S * (W + 2)));
-    HIPCHK(hipMemset(h->B.odom, 0, sizeof(double) * (size_t)S * 11));
-    HIPCHK(hipMemset(h->B.odom_count, 0, sizeof(int) * (size_t)S));
-    h->last_imu_t.assign(S, -1e300);
-    h->p_seq.clear(); h->p_t.clear(); h->p_acc.clear(); h->p_gyr.clear();
+    HIPCHK(hipMemcpy(h->B.fe + s_lo, fe.data(), sizeof(FeSeq) * n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->B.be + s_lo, be.data(), sizeof(BeSeq) * n, hipMemcpyHostToDevice));
+    std::vector<int> fr((size_t)n * C.NL);
+    for (int s = 0; s < n; s++) for (int k = 0; k < C.NL; k++) fr[(size_t)s * C.NL + k] = C.NL - 1 - k;
+    HIPCHK(hipMemcpy(h->B.lm_free + (size_t)s_lo * C.NL, fr.data(), fr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(h->B.lm_order + (size_t)s_lo * C.NL, 0, sizeof(int) * (size_t)n * C.NL));
+    HIPCHK(hipMemset(h->B.pre + (size_t)s_lo * (W + 2), 0, sizeof(PreInt) * (size_t)n * (W + 2)));
+    HIPCHK(hipMemset(h->B.odom + (size_t)s_lo * 11, 0, sizeof(double) * (size_t)n * 11));
+    HIPCHK(hipMemset(h->B.odom_count + s_lo, 0, sizeof(int) * (size_t)n));
+    {
+        // Estimator::clearState() empties imu_buf: drop what is still staged on the host for these sequences
+        std::lock_guard<std::mutex> lk(h->imu_mu);
+        for (int s = s_lo; s < s_hi; s++) h->last_imu_t[s] = -1e300;
+        size_t w = 0;
+        for (size_t i = 0; i < h->p_seq.size(); i++) {
+            if (h->p_seq[i] >= s_lo && h->p_seq[i] < s_hi) continue;
+            h->p_seq[w] = h->p_seq[i]; h->p_t[w] = h->p_t[i];
+            for (int k = 0; k < 3; k++) { h->p_acc[3 * w + k] = h->p_acc[3 * i + k]; h->p_gyr[3 * w + k] = h->p_gyr[3 * i + k]; }
+            w++;
+        }
+        h->p_seq.resize(w); h->p_t.resize(w); h->p_acc.resize(3 * w); h->p_gyr.resize(3 * w);
+    }
     return VIO_OK;
 }
 
@@ -263,14 +282,15 @@ int flush_imu_backend(vio_batch *h) {
     return VIO_OK;
 }
 
-int launch_frontend(vio_batch *h, vio_batch::Group &g, const uint8_t *d_gray, int publish, int gate) {
+int launch_frontend(vio_batch *h, vio_batch::Group &g, const uint8_t *d_gray, int publish, int gate, const uint8_t *d_modes = nullptr,
+                    const double *d_rrel = nullptr) {
     const DevCfg &C = h->hc;
     const int S = g.n, Wd = C.c.width, Ht = C.c.height;
     hipStream_t st = g.fe_stream;
     Batch Bg = h->B;
     Bg.s0 = g.s0;
     PEV(h, 0);
-    fe_begin_kernel<<<S, 64, 0, st>>>(Bg, h->d_stamps, gate);
+    fe_begin_kernel<<<S, 64, 0, st>>>(Bg, h->d_stamps, gate, publish, d_modes, d_rrel);
     PEV(h, 1);
     // pyramid: level 1 from the new frame (+ level-0 copy), further levels from the previous one
     {
@@ -287,32 +307,34 @@ int launch_frontend(vio_batch *h, vio_batch::Group &g, const uint8_t *d_gray, in
     PEV(h, 3);
     fe_lk_kernel<<<dim3(std::min(C.NP, C.c.max_cnt + C.c.max_cnt / 2 + 32), S), 64, 0, st>>>(Bg);  // ~1.5 x max_cnt blocks per sequence, strided over n_pts
     PEV(h, 4);
-    fe_select_kernel<<<S, 256, h->lds_select, st>>>(Bg, publish);
+    fe_select_kernel<<<S, 256, h->lds_select, st>>>(Bg);
     PEV(h, 5);
-    if (publish) fe_fast_kernel<<<dim3(C.ncells, S), 256, h->lds_fast, st>>>(Bg);
+    if (publish || d_modes) fe_fast_kernel<<<dim3(C.ncells, S), 256, h->lds_fast, st>>>(Bg);
     PEV(h, 6);
-    fe_add_kernel<<<S, 256, h->lds_add, st>>>(Bg, publish, gate);
+    fe_add_kernel<<<S, 256, h->lds_add, st>>>(Bg, gate);
     PEV(h, 7);
     HIPCHK(hipGetLastError());
     return VIO_OK;
 }
-int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth) {
+// one_seq >= 0: only that sequence (vio_process_obs), otherwise every sequence of the group
+int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, const IngestSrc &src, int one_seq = -1) {
     const DevCfg &C = h->hc;
-    const int S = g.n;
+    const int S = one_seq >= 0 ? 1 : g.n;
     hipStream_t st = g.stream;
     Batch Bg = h->B;
-    Bg.s0 = g.s0;
-    PEV(h, 8);
-    be_ingest_kernel<<<S, 256, (size_t)C.lm_hash_size * 8, st>>>(Bg, d_depth, (size_t)C.c.width * C.c.height);
-    PEV(h, 9);
+    Bg.s0 = one_seq >= 0 ? one_seq : g.s0;
+    const bool prof = one_seq < 0;
+    if (prof) PEV(h, 8);
+    be_ingest_kernel<<<S, 256, (size_t)C.lm_hash_size * 8, st>>>(Bg, d_depth, (size_t)C.c.width * C.c.height, src);
+    if (prof) PEV(h, 9);
     const int be_threads = h->be_threads;
     if (be_threads <= 512) be_solve_kernel_512<<<S, be_threads, h->lds_solve, st>>>(Bg);
     else be_solve_kernel<<<S, be_threads, h->lds_solve, st>>>(Bg);
-    PEV(h, 10);
-    (void)hipEventRecord(g.ev_solve, st);  // the next frame's front-end may start here (it only needs latest_Bg / td / ric)
-    g.have_solve_ev = true;
+    if (prof) PEV(h, 10);
+    (void)hipEventRecord(g.ev_solve, st);  // the next frame's front-end may start here (it only needs latest_Bg / td / imu_head, and a
+    g.have_solve_ev = true;                // reboot - which rewrites them - is decided at the end of be_solve)
     be_marg_kernel<<<S, h->marg_threads, h->lds_marg, st>>>(Bg);  // marginalisation + window slide (be_finish is fused into it)
-    PEV(h, 11);
+    if (prof) PEV(h, 11);
     HIPCHK(hipGetLastError());
     return VIO_OK;
 }
@@ -357,6 +379,7 @@ static int build_devcfg(const vio_config *cfg, int imu_capacity, DevCfg &C) {
     const vio_config &c = C.c;
     if (c.width < 64 || c.height < 64 || c.width > 4095 || c.height > 4095) { g_err = "image size out of range"; return VIO_EINVAL; }
     if (c.window_size < 4 || c.window_size > VIO_MAXW) { g_err = "window_size must be 4..20"; return VIO_EINVAL; }
+    if (c.dynamic_init != 0) { g_err = "dynamic_init (static_init: 0) is not built yet"; return VIO_EINVAL; }
     if (c.grid_rows < 1 || c.grid_cols < 1 || c.grid_rows * c.grid_cols > VIO_MAX_CELLS) { g_err = "too many grid cells"; return VIO_EINVAL; }
     if (c.min_dist < 1 || c.min_dist > 63) { g_err = "min_dist must be 1..63"; return VIO_EINVAL; }
     if (c.lk_max_level < 0 || c.lk_max_level > 3) { g_err = "lk_max_level must be 0..3"; return VIO_EINVAL; }
@@ -449,7 +472,8 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     if (getenv("VIO_MARG_THREADS")) h->marg_threads = std::min(512, std::max(64, atoi(getenv("VIO_MARG_THREADS")) & ~63));
     B.flags = getenv("VIO_FLAGS") ? atoi(getenv("VIO_FLAGS")) : 0;
     DA(B.odom_hist, S * (size_t)B.hist_cap * 11); DA(B.odom_count, S);
-    DA(h->d_stamps, S);
+    DA(h->d_stamps, S); DA(h->d_modes, S); DA(h->d_rrel, S * 9); DA(h->d_r9, 16);
+    DA(h->d_in_n, S); DA(h->d_in_stamps, S); DA(h->d_in_ids, S * NP); DA(h->d_in_obs, S * NP * 7);
 #undef DA
     if (rc == VIO_OK && hipMemcpy(B.cfg, &h->hc, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) { g_err = "cfg upload failed"; rc = VIO_EDEVICE; }
     if (rc == VIO_OK) {
@@ -473,7 +497,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     }
     for (int i = 0; i < 4 && rc == VIO_OK; i++)
         if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_err = "event create failed"; rc = VIO_EDEVICE; }
-    if (rc == VIO_OK) rc = init_state(h);
+    if (rc == VIO_OK) { h->last_imu_t.assign(n_seq, -1e300); rc = init_state(h, 0, n_seq); }
     if (rc == VIO_OK) for (auto &g : h->groups) (void)hipEventRecord(g.ev_be, g.stream);
     if (rc == VIO_OK) {
         h->lds_select = (size_t)C.NP * 104 + 260 * 4 + 64;
@@ -544,10 +568,13 @@ void vio_destroy(vio_batch *h) {
 int vio_reset(vio_batch *h) {
     if (!h) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
-    // zero the tracker / landmark / prior state that init_state does not rewrite
-    const DevCfg &C = h->hc;
-    HIPCHK(hipMemset(h->B.lm_order, 0, sizeof(int) * (size_t)h->S * C.NL));
-    return init_state(h);
+    return init_state(h, 0, h->S);
+}
+
+int vio_reset_seq(vio_batch *h, int seq) {
+    if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
+    { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
+    return init_state(h, seq, seq + 1);
 }
 
 int vio_push_imu(vio_batch *h, int seq, int n, const double *t, const double *acc, const double *gyr) {
@@ -594,7 +621,16 @@ static int be_wait(vio_batch::Group &g) {
     return VIO_OK;
 }
 
-int vio_feed(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, int on_device) {
+static const IngestSrc kTrackerMap = {nullptr, nullptr, nullptr, nullptr, 0};
+
+// per-call side inputs of the front-end (frame modes, caller-supplied relative rotations): group slices, on the group's fe_stream
+static int stage_side_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *modes, const double *R_rel) {
+    if (modes) HIPCHK(hipMemcpyAsync(h->d_modes + g.s0, modes + g.s0, (size_t)g.n, hipMemcpyHostToDevice, g.fe_stream));
+    if (R_rel) HIPCHK(hipMemcpyAsync(h->d_rrel + (size_t)g.s0 * 9, R_rel + (size_t)g.s0 * 9, (size_t)g.n * 9 * sizeof(double), hipMemcpyHostToDevice, g.fe_stream));
+    return VIO_OK;
+}
+
+int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, const uint8_t *modes, int on_device) {
     if (!h || !gray || !depth_mm || !stamps) return VIO_EINVAL;
     int rc = flush_imu_frontend(h);
     if (rc != VIO_OK) return rc;
@@ -604,12 +640,13 @@ int vio_feed(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const 
         const uint16_t *dd = nullptr;
         rc = stage_inputs(h, g, gray, depth_mm, stamps, on_device, &dg, &dd);
         if (rc != VIO_OK) return rc;
+        if ((rc = stage_side_inputs(h, g, modes, nullptr)) != VIO_OK) return rc;
         if (g.s0 == 0) HIPCHK(hipEventRecord(h->ev[0], g.fe_stream));
-        rc = launch_frontend(h, g, dg, 1, 1);
+        rc = launch_frontend(h, g, dg, 1, 1, modes ? h->d_modes : nullptr, nullptr);
         if (rc != VIO_OK) return rc;
         if (g.s0 == 0) HIPCHK(hipEventRecord(h->ev[1], g.fe_stream));
         if ((rc = be_wait(g)) != VIO_OK) return rc;
-        rc = launch_backend(h, g, dd);
+        rc = launch_backend(h, g, dd, kTrackerMap);
         if (rc != VIO_OK) return rc;
         if (g.s0 == 0) HIPCHK(hipEventRecord(h->ev[2], g.stream));
     }
@@ -618,7 +655,11 @@ int vio_feed(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const 
     return VIO_OK;
 }
 
-int vio_track(vio_batch *h, const uint8_t *gray, const double *stamps, int publish, int on_device) {
+int vio_feed(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, int on_device) {
+    return vio_feed_modes(h, gray, depth_mm, stamps, nullptr, on_device);
+}
+
+static int track_impl(vio_batch *h, const uint8_t *gray, const double *stamps, int publish, const uint8_t *modes, const double *R_rel, int on_device) {
     if (!h || !gray || !stamps) return VIO_EINVAL;
     int rc = flush_imu_frontend(h);
     if (rc != VIO_OK) return rc;
@@ -629,10 +670,33 @@ int vio_track(vio_batch *h, const uint8_t *gray, const double *stamps, int publi
         const uint16_t *dd = nullptr;
         rc = stage_inputs(h, g, gray, nullptr, stamps, on_device, &dg, &dd);
         if (rc != VIO_OK) return rc;
-        rc = launch_frontend(h, g, dg, publish ? 1 : 0, 0);
+        if ((rc = stage_side_inputs(h, g, modes, R_rel)) != VIO_OK) return rc;
+        rc = launch_frontend(h, g, dg, publish ? 1 : 0, 0, modes ? h->d_modes : nullptr, R_rel ? h->d_rrel : nullptr);
         if (rc != VIO_OK) return rc;
         if ((rc = be_wait(g)) != VIO_OK) return rc;
     }
+    return VIO_OK;
+}
+
+int vio_track(vio_batch *h, const uint8_t *gray, const double *stamps, int publish, int on_device) {
+    return track_impl(h, gray, stamps, publish, nullptr, nullptr, on_device);
+}
+
+int vio_track_ex(vio_batch *h, const uint8_t *gray, const double *stamps, const uint8_t *modes, const double *R_rel, int on_device) {
+    return track_impl(h, gray, stamps, 1, modes, R_rel, on_device);
+}
+
+int vio_predict_motion(vio_batch *h, int seq, double t0, double t1, double *R9) {
+    if (!h || seq < 0 || seq >= h->S || !R9) return VIO_EINVAL;
+    int rc = flush_imu_frontend(h);  // samples pushed so far must be in the ring (Estimator::predictMotion reads imu_buf)
+    if (rc != VIO_OK) return rc;
+    hipStream_t st = h->groups[0].fe_stream;
+    for (auto &g : h->groups)
+        if (seq >= g.s0 && seq < g.s0 + g.n) st = g.fe_stream;
+    fe_predict_motion_kernel<<<1, 64, 0, st>>>(h->B, seq, t0, t1, h->d_r9);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(R9, h->d_r9, 9 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return VIO_OK;
 }
 
@@ -645,11 +709,102 @@ int vio_process(vio_batch *h, const uint16_t *depth_mm, int on_device) {
         const uint16_t *dd = nullptr;
         rc = stage_inputs(h, g, nullptr, depth_mm, nullptr, on_device, &dg, &dd);
         if (rc != VIO_OK) return rc;
-        rc = launch_backend(h, g, dd);
+        rc = launch_backend(h, g, dd, kTrackerMap);
         if (rc != VIO_OK) return rc;
         HIPCHK(hipEventRecord(g.ev_be, g.stream));
     }
-    if (h->prof_cur >= 0) h->prof_cur++;
+    return VIO_OK;
+}
+
+int vio_process_obs_batch(vio_batch *h, const int32_t *n_obs, const int32_t *ids, const double *obs, int cap, const uint16_t *depth_mm,
+                          const double *stamps, int on_device) {
+    if (!h || !n_obs || !ids || !obs || !depth_mm || !stamps || cap < 1) return VIO_EINVAL;
+    const int NP = h->hc.NP;
+    for (int s = 0; s < h->S; s++)
+        if (n_obs[s] > cap || n_obs[s] > NP) { g_err = "feature map larger than the tracker capacity (vio_get_capacity)"; return VIO_ECAPACITY; }
+    int rc = flush_imu_backend(h);
+    if (rc != VIO_OK) return rc;
+    for (auto &g : h->groups) {
+        const uint8_t *dg = nullptr;
+        const uint16_t *dd = nullptr;
+        rc = stage_inputs(h, g, nullptr, depth_mm, nullptr, on_device, &dg, &dd);
+        if (rc != VIO_OK) return rc;
+        HIPCHK(hipMemcpyAsync(h->d_in_n + g.s0, n_obs + g.s0, (size_t)g.n * sizeof(int), hipMemcpyHostToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(h->d_in_stamps + g.s0, stamps + g.s0, (size_t)g.n * sizeof(double), hipMemcpyHostToDevice, g.stream));
+        for (int s = g.s0; s < g.s0 + g.n; s++) {
+            if (n_obs[s] <= 0) continue;
+            HIPCHK(hipMemcpyAsync(h->d_in_ids + (size_t)s * NP, ids + (size_t)s * cap, (size_t)n_obs[s] * sizeof(int), hipMemcpyHostToDevice, g.stream));
+            HIPCHK(hipMemcpyAsync(h->d_in_obs + (size_t)s * NP * 7, obs + (size_t)s * cap * 7, (size_t)n_obs[s] * 7 * sizeof(double), hipMemcpyHostToDevice, g.stream));
+        }
+        IngestSrc src = {h->d_in_n, h->d_in_ids, h->d_in_obs, h->d_in_stamps, NP};
+        rc = launch_backend(h, g, dd, src);
+        if (rc != VIO_OK) return rc;
+        HIPCHK(hipEventRecord(g.ev_be, g.stream));
+    }
+    return VIO_OK;
+}
+
+int vio_process_obs(vio_batch *h, int seq, int n, const int32_t *ids, const double *obs, const uint16_t *depth_mm, double stamp) {
+    if (!h || seq < 0 || seq >= h->S || n < 0 || (n > 0 && (!ids || !obs)) || !depth_mm) return VIO_EINVAL;
+    if (n == 0) return VIO_OK;  // the nodelet only queues non-empty maps (estimator_nodelet.cpp:378)
+    const DevCfg &C = h->hc;
+    const int NP = C.NP;
+    if (n > NP) { g_err = "feature map larger than the tracker capacity (vio_get_capacity)"; return VIO_ECAPACITY; }
+    int rc = flush_imu_backend(h);
+    if (rc != VIO_OK) return rc;
+    vio_batch::Group *gp = &h->groups[0];
+    for (auto &g : h->groups)
+        if (seq >= g.s0 && seq < g.s0 + g.n) gp = &g;
+    vio_batch::Group &g = *gp;
+    const size_t HW = (size_t)C.c.width * C.c.height;
+    if (!h->d_depth_stage) HIPCHK(hipMalloc((void **)&h->d_depth_stage, (size_t)h->S * HW * 2));
+    HIPCHK(hipMemcpyAsync(h->d_depth_stage + (size_t)seq * HW, depth_mm, HW * 2, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(h->d_in_n + seq, &n, sizeof(int), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(h->d_in_stamps + seq, &stamp, sizeof(double), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(h->d_in_ids + (size_t)seq * NP, ids, (size_t)n * sizeof(int), hipMemcpyHostToDevice, g.stream));
+    HIPCHK(hipMemcpyAsync(h->d_in_obs + (size_t)seq * NP * 7, obs, (size_t)n * 7 * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    IngestSrc src = {h->d_in_n, h->d_in_ids, h->d_in_obs, h->d_in_stamps, NP};
+    rc = launch_backend(h, g, h->d_depth_stage, src, seq);
+    if (rc != VIO_OK) return rc;
+    HIPCHK(hipEventRecord(g.ev_be, g.stream));
+    return VIO_OK;
+}
+
+int vio_get_packaged(vio_batch *h, int seq, int cap, int32_t *ids, double *obs) {
+    if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
+    { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
+    static thread_local FeSeq fe;
+    HIPCHK(hipMemcpy(&fe, h->B.fe + seq, sizeof(FeSeq), hipMemcpyDeviceToHost));
+    if (fe.n_forw < 0 || !fe.publish_ok) return 0;
+    int n = fe.n_obs, m = n < cap ? n : cap;
+    if (m > 0 && ids) HIPCHK(hipMemcpy(ids, h->B.obs_id + (size_t)seq * h->hc.NP, sizeof(int) * m, hipMemcpyDeviceToHost));
+    if (m > 0 && obs) HIPCHK(hipMemcpy(obs, h->B.obs + (size_t)seq * h->hc.NP * 7, sizeof(double) * 7 * m, hipMemcpyDeviceToHost));
+    return n;
+}
+
+int vio_abi_sizeof(int what) { return what == 0 ? (int)sizeof(vio_config) : (what == 1 ? (int)sizeof(vio_status) : -1); }
+
+int vio_get_capacity(vio_batch *h, int32_t *out3) {
+    if (!h || !out3) return VIO_EINVAL;
+    out3[0] = h->hc.NP; out3[1] = h->hc.NL; out3[2] = h->hc.NIMU;
+    return VIO_OK;
+}
+
+int vio_push_imu_batch(vio_batch *h, const int32_t *n, int stride, const double *t, const double *acc, const double *gyr) {
+    if (!h || stride < 0 || !t || !acc || !gyr) return VIO_EINVAL;
+    std::lock_guard<std::mutex> lk(h->imu_mu);
+    for (int s = 0; s < h->S; s++) {
+        const int ns = n ? n[s] : stride;
+        if (ns < 0 || ns > stride) return VIO_EINVAL;
+        for (int i = 0; i < ns; i++) {
+            const size_t q = (size_t)s * stride + i;
+            if (!(t[q] > h->last_imu_t[s])) continue;  // "imu message in disorder" (estimator_nodelet.cpp:110-114)
+            h->last_imu_t[s] = t[q];
+            h->p_seq.push_back(s);
+            h->p_t.push_back(t[q]);
+            for (int k = 0; k < 3; k++) { h->p_acc.push_back(acc[3 * q + k]); h->p_gyr.push_back(gyr[3 * q + k]); }
+        }
+    }
     return VIO_OK;
 }
 
@@ -666,7 +821,10 @@ int vio_get_status(vio_batch *h, int seq, vio_status *out) {
     static thread_local FeSeq fe;
     HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(&fe, h->B.fe + seq, sizeof(FeSeq), hipMemcpyDeviceToHost));
-    out->code = (be.overflow && be.status_code == VIO_OK) ? VIO_ECAPACITY : be.status_code;  // a table overflowed: results are truncated, say so
+    const int ovf = be.overflow | fe.overflow;
+    out->code = (ovf && be.status_code == VIO_OK) ? VIO_ECAPACITY : be.status_code;  // a table overflowed in the last frame: results are truncated, say so
+    out->overflow_flags = ovf; out->overflow_frames = be.overflow_frames;
+    out->iterations_total = be.iter_total; out->solves_total = be.solve_total;
     out->solver_flag = be.solver_flag; out->frame_count = be.frame_count;
     out->marginalization_flag = be.marginalization_flag; out->n_landmarks = be.n_lm; out->last_track_num = be.last_track_num;
     out->n_tracks = fe.n_pts; out->processed = be.processed; out->iterations = be.iterations; out->successful_steps = be.successful;
@@ -704,9 +862,14 @@ int vio_get_odometry_history(vio_batch *h, int seq, int cap, double *out) {
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     int n = 0;
     HIPCHK(hipMemcpy(&n, h->B.odom_count + seq, sizeof(int), hipMemcpyDeviceToHost));
-    int m = n < cap ? n : cap;
-    if (m > h->B.hist_cap) m = h->B.hist_cap;
-    if (m > 0) HIPCHK(hipMemcpy(out, h->B.odom_hist + (size_t)seq * h->B.hist_cap * 11, sizeof(double) * (size_t)m * 11, hipMemcpyDeviceToHost));
+    const int hc = h->B.hist_cap;
+    int m = std::min(std::min(n, cap), hc);  // the most recent m rows, oldest first
+    const double *base = h->B.odom_hist + (size_t)seq * hc * 11;
+    for (int done = 0; done < m;) {
+        int row = (n - m + done) % hc, run = std::min(m - done, hc - row);
+        HIPCHK(hipMemcpy(out + (size_t)done * 11, base + (size_t)row * 11, sizeof(double) * (size_t)run * 11, hipMemcpyDeviceToHost));
+        done += run;
+    }
     return n;
 }
 
@@ -738,30 +901,45 @@ int vio_get_tracks(vio_batch *h, int seq, int cap, int32_t *ids, int32_t *cnt, f
     return n;
 }
 
-int vio_get_landmarks(vio_batch *h, int seq, int cap, double *out) {
+static int get_landmarks_impl(vio_batch *h, int seq, int cap, double *out, int width) {
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local BeSeq be;
     HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
-    int NL = h->hc.NL, n = be.n_lm;
-    size_t o = (size_t)seq * NL;
-    std::vector<int> order(NL), id(NL), st(NL), no(NL), ef(NL), sf(NL), dy(NL);
+    const int NL = h->hc.NL, n = be.n_lm, W1 = h->hc.W + 1;
+    const size_t o = (size_t)seq * NL;
+    // the seven scalar tables are adjacent allocations but not one buffer: one copy each, then (ex only) the observation rows
+    std::vector<int> tab((size_t)7 * NL);
+    int *order = tab.data(), *id = order + NL, *st = id + NL, *no = st + NL, *ef = no + NL, *sf = ef + NL, *dy = sf + NL;
     std::vector<double> dep(NL);
-    HIPCHK(hipMemcpy(order.data(), h->B.lm_order + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(id.data(), h->B.lm_id + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(st.data(), h->B.lm_start + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(no.data(), h->B.lm_nobs + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(ef.data(), h->B.lm_est_flag + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(sf.data(), h->B.lm_solve_flag + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(dy.data(), h->B.lm_dyn + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(order, h->B.lm_order + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(id, h->B.lm_id + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(st, h->B.lm_start + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(no, h->B.lm_nobs + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ef, h->B.lm_est_flag + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sf, h->B.lm_solve_flag + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dy, h->B.lm_dyn + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(dep.data(), h->B.lm_depth + o, sizeof(double) * NL, hipMemcpyDeviceToHost));
+    std::vector<double> obs;
+    if (width > 7) {
+        obs.resize((size_t)NL * W1 * VIO_OBS_D);
+        HIPCHK(hipMemcpy(obs.data(), h->B.lm_obs + o * W1 * VIO_OBS_D, sizeof(double) * obs.size(), hipMemcpyDeviceToHost));
+    }
     for (int k = 0; k < n && k < cap; k++) {
         int s = order[k];
-        double *q = out + 7 * k;
+        double *q = out + (size_t)width * k;
         q[0] = id[s]; q[1] = st[s]; q[2] = no[s]; q[3] = dep[s]; q[4] = ef[s]; q[5] = sf[s]; q[6] = dy[s];
+        if (width > 7) {
+            // feature_per_frame[0] / .back(): the observation rows are ring-indexed per frame (vio_state.h lm_obs)
+            const double *f0 = &obs[((size_t)s * W1 + (st[s] + be.ring_base) % W1) * VIO_OBS_D];
+            const double *fb = &obs[((size_t)s * W1 + (st[s] + std::max(no[s], 1) - 1 + be.ring_base) % W1) * VIO_OBS_D];
+            q[7] = f0[0]; q[8] = f0[1]; q[9] = f0[2]; q[10] = f0[8]; q[11] = fb[8];
+        }
     }
     return n;
 }
+int vio_get_landmarks(vio_batch *h, int seq, int cap, double *out) { return get_landmarks_impl(h, seq, cap, out, 7); }
+int vio_get_landmarks_ex(vio_batch *h, int seq, int cap, double *out12) { return get_landmarks_impl(h, seq, cap, out12, 12); }
 
 int vio_get_prior(vio_batch *h, int seq, double *J, double *r, double *x0, uint8_t *present) {
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
@@ -830,7 +1008,7 @@ int vio_profile_begin(vio_batch *h, int max_steps) {
 int vio_profile_end(vio_batch *h, int cap, double *out_ms) {
     if (!h || !out_ms || cap < VIO_NK) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
-    int n = h->prof_cur < h->prof_steps ? h->prof_cur : h->prof_steps;
+    int n = h->prof_cur < 0 ? 0 : (h->prof_cur < h->prof_steps ? h->prof_cur : h->prof_steps);
     static const int e0[VIO_NK] = {0, 1, 2, 3, 4, 5, 6, 8, 9, 10}, e1[VIO_NK] = {1, 2, 3, 4, 5, 6, 7, 9, 10, 11};
     for (int k = 0; k < VIO_NK; k++) out_ms[k] = 0;
     for (int i = 0; i < n; i++)
@@ -951,10 +1129,11 @@ done:
     return rc;
 }
 
-int vio_stage_imu_factor(const vio_config *cfg, int n, const double *dt, const double *acc, const double *gyr, const double *acc0,
-                         const double *gyr0, const double *ba, const double *bg, const double *pose_i, const double *sb_i,
-                         const double *pose_j, const double *sb_j, double *preint_out, double *r15, double *J480) {
+static int stage_imu_impl(const vio_config *cfg, int n, const double *dt, const double *acc, const double *gyr, const double *acc0,
+                          const double *gyr0, const double *ba, const double *bg, const double *pose_i, const double *sb_i,
+                          const double *pose_j, const double *sb_j, double *preint_out, double *r15, double *J480, double *G961) {
     int rc = VIO_OK;
+    double *dG = nullptr;
     PreInt *hp = new PreInt();
     PreInt *dp = nullptr;
     double *dbuf = nullptr;
@@ -981,18 +1160,37 @@ int vio_stage_imu_factor(const vio_config *cfg, int n, const double *dt, const d
                                     dbuf + 7 * n + 32 + 461 + 15);
     STAGE_CHK(hipDeviceSynchronize());
     STAGE_CHK(hipMemcpy(hb.data(), dbuf, nd * sizeof(double), hipMemcpyDeviceToHost));
-    memcpy(preint_out, &hb[7 * n + 32], 461 * sizeof(double));
-    memcpy(r15, &hb[7 * n + 32 + 461], 15 * sizeof(double));
-    memcpy(J480, &hb[7 * n + 32 + 461 + 15], 480 * sizeof(double));
+    if (preint_out) memcpy(preint_out, &hb[7 * n + 32], 461 * sizeof(double));
+    if (r15) memcpy(r15, &hb[7 * n + 32 + 461], 15 * sizeof(double));
+    if (J480) memcpy(J480, &hb[7 * n + 32 + 461 + 15], 480 * sizeof(double));
+    if (G961) {
+        STAGE_CHK(hipMalloc((void **)&dG, 961 * sizeof(double)));
+        STAGE_CHK(hipMemset(dG, 0, 961 * sizeof(double)));
+        be_stage_imu_block_kernel<<<1, 64>>>(dp, dbuf + 7 * n, cfg->g_norm, dG);
+        STAGE_CHK(hipDeviceSynchronize());
+        STAGE_CHK(hipMemcpy(G961, dG, 961 * sizeof(double), hipMemcpyDeviceToHost));
+    }
 done:
+    if (dG) (void)hipFree(dG);
     if (dp) (void)hipFree(dp);
     if (dbuf) (void)hipFree(dbuf);
     delete hp;
     return rc;
 }
 
-int vio_stage_projection(const vio_config *cfg, const double *pose_i, const double *pose_j, const double *ex, double inv_dep, double td,
-                         const double *obs_i, const double *obs_j, int use_td, double *r2, double *J46) {
+int vio_stage_imu_factor(const vio_config *cfg, int n, const double *dt, const double *acc, const double *gyr, const double *acc0,
+                         const double *gyr0, const double *ba, const double *bg, const double *pose_i, const double *sb_i,
+                         const double *pose_j, const double *sb_j, double *preint_out, double *r15, double *J480) {
+    return stage_imu_impl(cfg, n, dt, acc, gyr, acc0, gyr0, ba, bg, pose_i, sb_i, pose_j, sb_j, preint_out, r15, J480, nullptr);
+}
+int vio_stage_imu_block(const vio_config *cfg, int n, const double *dt, const double *acc, const double *gyr, const double *acc0,
+                        const double *gyr0, const double *ba, const double *bg, const double *pose_i, const double *sb_i,
+                        const double *pose_j, const double *sb_j, double *G961) {
+    return stage_imu_impl(cfg, n, dt, acc, gyr, acc0, gyr0, ba, bg, pose_i, sb_i, pose_j, sb_j, nullptr, nullptr, nullptr, G961);
+}
+
+static int stage_projection_impl(const vio_config *cfg, const double *pose_i, const double *pose_j, const double *ex, double inv_dep, double td,
+                                 const double *obs_i, const double *obs_j, int use_td, int form, double *r2, double *J46) {
     int rc = VIO_OK;
     double hb[41 + 2 + 46];
     double *db = nullptr;
@@ -1001,7 +1199,7 @@ int vio_stage_projection(const vio_config *cfg, const double *pose_i, const doub
     memcpy(hb + 23, obs_i, 72); memcpy(hb + 32, obs_j, 72);
     STAGE_CHK(hipMalloc((void **)&db, sizeof(hb)));
     STAGE_CHK(hipMemcpy(db, hb, sizeof(hb), hipMemcpyHostToDevice));
-    be_stage_projection_kernel<<<1, 64>>>(*cfg, db, use_td, db + 41, db + 43);
+    be_stage_projection_kernel<<<1, 64>>>(*cfg, db, use_td, form, db + 41, db + 43);
     STAGE_CHK(hipDeviceSynchronize());
     STAGE_CHK(hipMemcpy(hb, db, sizeof(hb), hipMemcpyDeviceToHost));
     memcpy(r2, hb + 41, 16);
@@ -1009,6 +1207,14 @@ int vio_stage_projection(const vio_config *cfg, const double *pose_i, const doub
 done:
     if (db) (void)hipFree(db);
     return rc;
+}
+int vio_stage_projection(const vio_config *cfg, const double *pose_i, const double *pose_j, const double *ex, double inv_dep, double td,
+                         const double *obs_i, const double *obs_j, int use_td, double *r2, double *J46) {
+    return stage_projection_impl(cfg, pose_i, pose_j, ex, inv_dep, td, obs_i, obs_j, use_td, 0, r2, J46);
+}
+int vio_stage_projection_residual(const vio_config *cfg, const double *pose_i, const double *pose_j, const double *ex, double inv_dep, double td,
+                                  const double *obs_i, const double *obs_j, int use_td, double *r2, double *J46) {
+    return stage_projection_impl(cfg, pose_i, pose_j, ex, inv_dep, td, obs_i, obs_j, use_td, 1, r2, J46);
 }
 
 }  // extern "C"

@@ -71,6 +71,9 @@ struct FeSeq {
     int cell_ncand[VIO_MAX_CELLS];
     int n_accept;     // accepted mask centres (setMask survivors + unstable + added)
     int ransac_iters; // diagnostics
+    int pub_req;      // PUB_THIS_FRAME of the current frame (estimator_nodelet.cpp:274-286), set by fe_begin from the caller's frame mode
+    int overflow;     // front-end capacity flags of the current frame (bit 2: FAST candidates of a cell truncated)
+    int use_R_rel;    // 1: R_rel was supplied by the caller (readImage(img, t, relative_R)), 0: predictMotion on the device
 };
 
 struct BeSeq {
@@ -92,7 +95,11 @@ struct BeSeq {
     int pre_idx[VIO_MAXW + 1];      // window slot -> physical PreInt (pointer swaps of slideWindow)
     int do_solve, do_marg;          // decisions of the ingest stage for the later kernels
     int n_imu_frame;                // samples consumed for the current frame
-    int overflow;                   // capacity overflow flags (landmarks / imu slot)
+    int overflow;                   // capacity flags of the LAST processed frame (1 landmark table, 2 IMU slot, 8 residual list,
+                                    // 16 IMU ring overwritten before it was consumed); cleared by be_ingest, see overflow_frames
+    int overflow_frames;            // sticky diagnostic: number of frames that raised any capacity flag since the last reset / reboot
+    int iter_total, solve_total;    // solver iterations / solves since vio_create (bench.py averages them over its timed steps)
+    int rebooted;                   // failureDetection fired in this frame's solve: be_marg / be_finish skip the sequence
     double prior_c0;                // |r|^2 of the prior at its linearisation point (constant cost offset)
     int dbg[16];                    // debug counters (sweeps, ticks)
 };

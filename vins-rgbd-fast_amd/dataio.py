@@ -5,8 +5,10 @@
   * ``OdometryCsvWriter``  the result file of ``pubOdometry`` (utility/visualization.cpp:214-225), byte for byte;
   * ``RgbdImuDirectory``   a rosbag-free recording: ``rgb.txt`` / ``depth.txt`` (TUM RGB-D association files: ``stamp path``)
     plus ``imu.txt`` (``stamp ax ay az gx gy gz``), 8-bit colour or grey PNG and 16-bit depth PNG in millimetres;
+  * ``FrameGate``          the stream checks + frequency control at the top of ``process_tracker``
+    (estimator_nodelet.cpp:94-95, 234-286: first image, discontinuity restart, ``frontend_freq`` skip, ``freq`` publish rate);
   * ``replay``             feeds such a recording through the C ABI exactly like the nodelet does for one camera
-    (IMU up to the frame stamp + td, then the colour + depth pair) and writes the CSV;
+    (IMU up to the frame stamp + td, frame gate, then the colour + depth pair) and writes the CSV;
   * ``ate_rmse``           absolute trajectory error after yaw + translation alignment (gravity-aligned 4-DoF).
 
 Host-side plumbing only: every frame still ends in ``libvio_hip.so``."""
@@ -267,13 +269,69 @@ def write_recording(root, stamps, grays, depths, imu_t, imu_acc, imu_gyr):
     np.savetxt(os.path.join(root, "imu.txt"), np.c_[imu_t, imu_acc, imu_gyr], fmt="%.17g", header="stamp ax ay az gx gy gz")
 
 
-def replay(batch, rec, csv_path=None, seq=0, on_frame=None):
+class FrameGate:
+    """Stream checks + frequency control of EstimatorNodelet::process_tracker (estimator_nodelet.cpp:94-95, 234-286) as a
+    stand-alone state machine.  ``step(t)`` returns what the nodelet does with the frame stamped ``t``: FIRST (only sets the
+    time base), RESET (stream discontinuity: restart tracker + estimator, :243-262), SKIP ("Skip this frame", before
+    readImage), TRACK (readImage with PUB_THIS_FRAME false) or PUBLISH.  The first three values equal the VIO_FRAME_* modes."""
+    SKIP, TRACK, PUBLISH, FIRST, RESET = 0, 1, 2, 3, 4
+
+    def __init__(self, freq, frontend_freq):
+        self.freq = 100 if int(freq) == 0 else int(freq)     # parameters.cpp:133-134
+        self.frontend_freq = int(frontend_freq)
+        self.first_image_flag = True
+        self.first_image_time = self.last_image_time = 0.0
+        self.pub_count, self.input_count = 1, 0               # estimator_nodelet.cpp:94-95
+
+    @staticmethod
+    def _round(x):
+        return float(np.floor(abs(x) + 0.5)) * (1.0 if x >= 0 else -1.0)   # C round(): half away from zero
+
+    def step(self, t):
+        t = float(t)
+        if self.first_image_flag:
+            self.first_image_flag = False
+            self.first_image_time = self.last_image_time = t
+            return self.FIRST
+        if t - self.last_image_time > 1.0 or t < self.last_image_time:
+            self.first_image_flag = True
+            self.last_image_time = 0.0
+            self.pub_count = 1
+            return self.RESET
+        span = t - self.first_image_time
+        if self._round(np.float64(self.input_count) / span if span != 0 else np.inf) > self.frontend_freq:
+            return self.SKIP
+        self.input_count += 1
+        pub = False
+        rate = np.float64(self.pub_count) / span if span != 0 else np.inf
+        if self._round(rate) <= self.freq:
+            pub = True
+            if abs(rate - self.freq) < 0.01 * self.freq:
+                self.first_image_time = t
+                self.pub_count = 0
+                self.input_count = 0
+        self.last_image_time = t
+        if pub:
+            self.pub_count += 1
+        return self.PUBLISH if pub else self.TRACK
+
+    def empty_map(self, t):
+        """a PUBLISH frame whose feature map came out empty restarts the rate window (estimator_nodelet.cpp:386-392)"""
+        self.first_image_time = float(t)
+        self.pub_count = self.input_count = 0
+
+
+def replay(batch, rec, csv_path=None, seq=0, on_frame=None, freq=0, frontend_freq=0):
     """Feed a recording through a single-sequence slot of a VioBatch the way the nodelet does: push IMU through the frame stamp
-    (one sample beyond, so that IMUAvailable holds), feed the pair, append a CSV row whenever the estimator is NON_LINEAR.
-    Returns the rows [stamp, P, Q(wxyz), V]."""
+    (one sample beyond, so that IMUAvailable holds), run the frame gate (``freq`` / ``frontend_freq`` of the configuration file;
+    frontend_freq == 0 disables the gate: every frame is published), feed the pair with the gate's mode, append a CSV row whenever
+    the estimator is NON_LINEAR.  A stream discontinuity restarts the sequence (vio_reset_seq).  Returns the rows
+    [stamp, P, Q(wxyz), V]."""
     rows, k = [], 0
     wr = OdometryCsvWriter(csv_path, append=False) if csv_path else None
     S = batch.S
+    gate = FrameGate(freq, frontend_freq) if int(frontend_freq) > 0 else None
+    init_pub = init_feature = False   # host mirror of estimator_nodelet.cpp:365-377, only to recognise an EMPTY published map
     for f in range(len(rec)):
         t, gray, depth = rec.frame(f)
         k2 = k
@@ -283,10 +341,29 @@ def replay(batch, rec, csv_path=None, seq=0, on_frame=None):
         if k2 > k:
             batch.push_imu(seq, rec.imu_t[k:k2], rec.imu_acc[k:k2], rec.imu_gyr[k:k2])
             k = k2
+        mode = FrameGate.PUBLISH
+        if gate is not None:
+            d = gate.step(t)
+            if d == FrameGate.RESET:
+                batch.reset_seq(seq)
+                init_pub = init_feature = False
+                if on_frame:
+                    on_frame(f, batch.status(seq))
+                continue
+            mode = FrameGate.PUBLISH if d == FrameGate.FIRST else d   # the first image is recognised on the device as well
         g = np.repeat(gray[None], S, 0) if S > 1 else gray[None]
-        d = np.repeat(depth[None], S, 0) if S > 1 else depth[None]
-        batch.feed(g, d, [t] * S)
+        d_ = np.repeat(depth[None], S, 0) if S > 1 else depth[None]
+        modes = np.full(S, FrameGate.SKIP, np.uint8)
+        modes[seq] = mode
+        batch.feed(g, d_, [t] * S, modes=modes)
         st = batch.status(seq)
+        if gate is not None and mode == FrameGate.PUBLISH and d != FrameGate.FIRST:
+            if not init_pub:
+                init_pub = True
+            elif not init_feature:
+                init_feature = True
+            elif not st.processed and st.code == 0:
+                gate.empty_map(t)
         if st.solver_flag == 1 and st.processed:
             row = batch.odometry()[seq]
             rows.append(row.copy())
