@@ -7,11 +7,19 @@ Workload at N=1: BASELINE configs[2] "batch of 128 independent synthetic sequenc
 latency case and a parity test); N>1 shards 128 sequences per GPU with no data-path collective (weak scaling).
 Frames are rendered on the device outside the timed region; steady state only (after solver_flag == NON_LINEAR).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+    python bench.py --gpus N --steps K --warmup W
+
+`--gpus N` with N > 1 and no torchrun environment re-executes itself under `python -m torch.distributed.run` with N ranks (one per
+GPU) and fails loudly if fewer than N devices are visible; under torchrun (WORLD_SIZE set) N must equal WORLD_SIZE.
+The timed region is K steps bracketed by barrier + synchronize; it is repeated `--repeats` times on fresh frames and `value` is the
+MEDIAN repeat (all repeats are listed).  Prints ONE JSON line on rank 0 with `roofline` (dominant kernel), `roofline_kernels`
+(the next heaviest kernels) and `cpu_baseline` objects.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,17 +34,23 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
 def backend_flops(I, O, F, k_obs, W, S_imu):
-    """SURVEY.md §8d algorithmic FP64 flops of one back-end frame (1 FMA = 2 flop)."""
+    """SURVEY.md §8d algorithmic FP64 flops of one back-end frame (1 FMA = 2 flop), split by the kernel that does the work:
+    solve  = I x [projection eval + IMU eval + local J^T J (2x20, 15x30) + landmark Schur + dense Cholesky + back-substitution]
+    marg   = prior J^T J + marginalisation Schur; the survey's 10 n_p^3 eigen-decomposition term is listed separately because the
+             hot path does not perform it (prior kept as a quadratic form, DESIGN.md deviation 13) -- it is NOT credited to any kernel
+    ingest = pre-integration of the new frame's IMU samples."""
     P = 15 * (W + 1) + 7
     n_p = 6 * W + 16
     m = 15 + F / max(W, 1)
     per_iter = O * 1000 + W * 25000 + O * 1600 + W * 27000 + F * 2 * (6 * k_obs + 7) ** 2 + P ** 3 / 3 + 2 * P ** 2
-    return I * per_iter + 2 * n_p ** 3 + (10 * m ** 3 + 2 * (n_p * m ** 2 + n_p ** 2 * m) + 10 * n_p ** 3) + 2 * S_imu * 38000
+    return dict(solve=I * per_iter, marg=2 * n_p ** 3 + 10 * m ** 3 + 2 * (n_p * m ** 2 + n_p ** 2 * m), eig_not_done=10 * n_p ** 3,
+                ingest=2 * S_imu * 38000)
 
 
 def frontend_bytes(w, h, n, levels):
-    """SURVEY.md §8d algorithmic bytes of one front-end frame."""
-    return 2 * w * h + sum(w * h // 4 ** l for l in range(1, levels + 1)) + n * (levels + 1) * 2 * 23 * 23
+    """SURVEY.md §8d algorithmic bytes of one front-end frame, split by kernel: pyramid (read frame + write levels), FAST (read
+    frame), LK (prev + next 23x23 u8 patches per level per feature)."""
+    return dict(pyrdown=w * h + sum(w * h // 4 ** l for l in range(1, levels + 1)), fast=w * h, lk=n * (levels + 1) * 2 * 23 * 23)
 
 
 def aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K):
@@ -51,8 +65,8 @@ def aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K):
         syn.render_device(S, 0, float(times[f]), gray[f], depth[f])
     nimu = int(F / sc.cam_rate * sc.imu_rate) + 64
     b = P.VioBatch(cfg, S, imu_capacity=nimu + 64)
-    for s in range(S):
-        b.push_imu(s, *syn.imu(s, nimu))
+    imu = [syn.imu(s, nimu) for s in range(S)]
+    b.push_imu_batch(np.stack([x[0] for x in imu]), np.stack([x[1] for x in imu]), np.stack([x[2] for x in imu]))
     for f in range(n_pre + Wm):
         b.feed(gray[f], depth[f], np.full(S, times[f]), on_device=True)
     b.sync()
@@ -94,30 +108,55 @@ def _cpu_worker(job):
     return tcpu, nfr
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=3, help="the K-step timed region is run this many times (fresh frames); value = median")
     ap.add_argument("--seqs", type=int, default=128, help="sequences per GPU")
     ap.add_argument("--cpu-seqs", type=int, default=8, help="sequences replayed through the CPU oracle on rank 0 (0 = skip)")
-    ap.add_argument("--cpu-procs", type=int, default=0, help="also time the oracle as one sequence per core on this many processes "
-                    "(0 = skip; reported as cpu_baseline_multicore, the headline cpu_baseline stays the 1-core figure)")
+    ap.add_argument("--cpu-procs", type=int, default=-1, help="oracle processes for the all-core CPU baseline, one sequence each "
+                    "(-1 = every core this process may run on, 0 = skip)")
     ap.add_argument("--aux", action="store_true", help="also measure S=256 sequences per GPU (reported as aux_s256, never as value)")
     ap.add_argument("--pcie-steps", type=int, default=6, help="extra steps fed from HOST buffers after the timed region (0 = skip)")
-    ap.add_argument("--stream-steps", type=int, default=10, help="extra steps with the IMU pushed frame by frame (vio_push_imu per sequence per frame)")
+    ap.add_argument("--stream-steps", type=int, default=10, help="extra steps with the IMU pushed frame by frame")
     args = ap.parse_args()
+
+    # ---- N ranks: spawn them ourselves when the caller did not (python bench.py --gpus N), never silently run fewer
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus and os.environ.get("VIO_BENCH_DEVICE") is None:
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible" % (args.gpus, have))
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (launch one rank per GPU)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     # VIO_BENCH_DEVICE / VIO_BENCH_BACKEND exist only to dry-run the N > 1 control flow on a 1-GPU box (both ranks on cuda:0 over gloo)
     if os.environ.get("VIO_BENCH_DEVICE") is not None:
         local_rank = int(os.environ["VIO_BENCH_DEVICE"])
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d has no device (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     backend = os.environ.get("VIO_BENCH_BACKEND", "nccl")
     if world > 1:
@@ -133,12 +172,12 @@ def main():
 
     cfg = P.canonical_config()
     sc = vio_ct.synth_like(cfg)
-    S, K, Wm = args.seqs, args.steps, args.warmup
+    S, K, Wm, R = args.seqs, args.steps, args.warmup, max(args.repeats, 1)
     H, Wd = cfg.height, cfg.width
     n_pre = 16  # first-image skip + init_pub + init_feature + (window_size + 1) frames -> NON_LINEAR, + margin
     Kp = max(args.pcie_steps, 0)
     Ks = max(args.stream_steps, 0)
-    F = n_pre + Wm + K + Kp + Ks
+    F = n_pre + Wm + R * K + Kp + 2 * Ks
     seq0 = shard.sequence_shard(rank, world, S)[0]
     syn = P.Synth(sc)
     dev = torch.device("cuda", local_rank)
@@ -150,13 +189,11 @@ def main():
     nimu = int(F / sc.cam_rate * sc.imu_rate) + 64
     b = P.VioBatch(cfg, S, imu_capacity=nimu + 64)
     imu_all = [syn.imu(seq0 + s, nimu) for s in range(S)]
-    t_stream0 = times[F - Ks] if Ks > 0 else 1e300   # IMU up to (and one sample past) the last non-streaming frame goes in up front
-    imu_k = []
-    for s in range(S):
-        ti, ai, gi = imu_all[s]
-        k = vio_ct.imu_until(ti, 0, times[F - Ks - 1], sc.imu_rate) if Ks > 0 else len(ti)
-        b.push_imu(s, ti[:k], ai[:k], gi[:k])
-        imu_k.append(k)
+    f_stream0 = F - 2 * Ks                                   # first frame of the streaming legs
+    # IMU up to (and one sample past) the last non-streaming frame goes in up front, in one batched call
+    k_up = vio_ct.imu_until(imu_all[0][0], 0, times[f_stream0 - 1], sc.imu_rate) if Ks > 0 else nimu
+    b.push_imu_batch(np.stack([x[0][:k_up] for x in imu_all]), np.stack([x[1][:k_up] for x in imu_all]), np.stack([x[2][:k_up] for x in imu_all]))
+    imu_k = [k_up] * S
 
     def feed(f):
         b.feed(gray[f], depth[f], np.full(S, times[f]), on_device=True)
@@ -164,63 +201,82 @@ def main():
     for f in range(n_pre + Wm):
         feed(f)
     b.sync()
-    fp0 = np.array([b.status(s).frames_processed for s in range(S)])
-    nl = np.array([b.status(s).solver_flag for s in range(S)])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    b.profile_begin(K)
-    t0 = time.perf_counter()
-    for k in range(K):
-        feed(n_pre + Wm + k)
-    b.sync()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    if world > 1:
-        dist.barrier()
+    st0 = [b.status(s) for s in range(S)]
+    fp0 = np.array([st.frames_processed for st in st0])
+    nl = np.array([st.solver_flag for st in st0])
+    it0 = np.array([(st.iterations_total, st.solves_total) for st in st0], np.int64)
+    b.profile_begin(R * K)
+    elapsed_rep = []
+    for r in range(R):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(K):
+            feed(n_pre + Wm + r * K + k)
+        b.sync()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        if world > 1:
+            dist.barrier()
+        elapsed_rep.append(t1 - t0)
     nprof, kms = b.profile_end()
-    elapsed_local = t1 - t0
+    st1 = [b.status(s) for s in range(S)]
+    it1 = np.array([(st.iterations_total, st.solves_total) for st in st1], np.int64)
+    d_it = (it1 - it0).sum(0)
+    iters = float(d_it[0]) / max(float(d_it[1]), 1.0)          # mean solver iterations per solve over ALL timed steps and sequences
+    f_timed_end = n_pre + Wm + R * K
 
     # ---- PCIe-inclusive rate (never `value`): the same call handed pageable HOST buffers, S x 0.92 MB uploaded per step
     pcie = None
     if Kp > 0:
-        hg = [gray[n_pre + Wm + K + k].cpu().numpy() for k in range(Kp)]
-        hd = [depth[n_pre + Wm + K + k].cpu().numpy() for k in range(Kp)]
+        hg = [gray[f_timed_end + k].cpu().numpy() for k in range(Kp)]
+        hd = [depth[f_timed_end + k].cpu().numpy() for k in range(Kp)]
         torch.cuda.synchronize()
         c0 = time.perf_counter()
         for k in range(Kp):
-            b.feed(hg[k], hd[k], np.full(S, times[n_pre + Wm + K + k]), on_device=False)
+            b.feed(hg[k], hd[k], np.full(S, times[f_timed_end + k]), on_device=False)
         b.sync()
         c1 = time.perf_counter()
         pcie = dict(frames_per_s=S * Kp / (c1 - c0), ms_per_step=(c1 - c0) / Kp * 1e3, steps=Kp,
                     note="vio_feed(on_device=0): pageable numpy buffers, %.1f MB uploaded per step" % (S * H * Wd * 3 / 1e6))
 
-    # ---- streaming leg (never `value`): IMU arrives between frames, 20 samples per sequence pushed through vio_push_imu before
-    # each vio_feed, device-resident images -- the call pattern of the reference's callbacks
+    # ---- streaming legs (never `value`): IMU arrives between frames, device-resident images.  (a) the reference's callback pattern:
+    # one vio_push_imu per sequence per frame from Python; (b) one vio_push_imu_batch per frame (SoA over sequences)
     stream = None
     if Ks > 0:
-        f0 = F - Ks
-        torch.cuda.synchronize()
-        c0 = time.perf_counter()
-        for k in range(Ks):
-            f = f0 + k
-            for s in range(S):
-                ti, ai, gi = imu_all[s]
-                k2 = vio_ct.imu_until(ti, imu_k[s], times[f], sc.imu_rate)
-                if k2 > imu_k[s]:
-                    b.push_imu(s, ti[imu_k[s]:k2], ai[imu_k[s]:k2], gi[imu_k[s]:k2])
-                    imu_k[s] = k2
-            feed(f)
-        b.sync()
-        c1 = time.perf_counter()
-        stream = dict(frames_per_s=S * Ks / (c1 - c0), ms_per_step=(c1 - c0) / Ks * 1e3, steps=Ks,
-                      note="IMU pushed per sequence per frame from Python (host time of %d ctypes calls per step included)" % S)
+        legs = {}
+        for name, f0 in (("per_sequence_calls", f_stream0), ("batched_call", f_stream0 + Ks)):
+            torch.cuda.synchronize()
+            c0 = time.perf_counter()
+            for k in range(Ks):
+                f = f0 + k
+                k2 = [vio_ct.imu_until(imu_all[s][0], imu_k[s], times[f], sc.imu_rate) for s in range(S)]
+                if name == "per_sequence_calls":
+                    for s in range(S):
+                        ti, ai, gi = imu_all[s]
+                        if k2[s] > imu_k[s]:
+                            b.push_imu(s, ti[imu_k[s]:k2[s]], ai[imu_k[s]:k2[s]], gi[imu_k[s]:k2[s]])
+                else:
+                    m = max(max(k2[s] - imu_k[s] for s in range(S)), 1)
+                    tt, aa, gg = np.zeros((S, m)), np.zeros((S, m, 3)), np.zeros((S, m, 3))
+                    for s in range(S):
+                        q = k2[s] - imu_k[s]
+                        tt[s, :q] = imu_all[s][0][imu_k[s]:k2[s]]; aa[s, :q] = imu_all[s][1][imu_k[s]:k2[s]]; gg[s, :q] = imu_all[s][2][imu_k[s]:k2[s]]
+                    b.push_imu_batch(tt, aa, gg, n=[k2[s] - imu_k[s] for s in range(S)])
+                imu_k = k2
+                feed(f)
+            b.sync()
+            c1 = time.perf_counter()
+            legs[name] = dict(frames_per_s=S * Ks / (c1 - c0), ms_per_step=(c1 - c0) / Ks * 1e3, steps=Ks)
+        stream = dict(legs, note="20 IMU samples per sequence pushed before every frame (host time of the pushes included): "
+                                 "%d vio_push_imu calls per step vs one vio_push_imu_batch call" % S)
 
     # ---- validity + accuracy (outside the timed region)
     stats = [b.status(s) for s in range(S)]
     fp1 = np.array([st.frames_processed for st in stats])
-    all_processed = bool(np.all(fp1 - fp0 == K + Kp + Ks) and np.all(nl == 1))
+    all_processed = bool(np.all(fp1 - fp0 == R * K + Kp + 2 * Ks) and np.all(nl == 1))
     ates = []
     hist = {}
     for s in range(S):
@@ -231,50 +287,81 @@ def main():
         gt = np.array([syn.pose(seq0 + s, float(t))[0] for t in h[:, 0]])
         ates.append(vio_ct.ate_rmse(h[:, 1:4], gt))
     sq_err = float(np.sum([a * a for a in ates]))
-    total_frames, elapsed, sq_err_all, n_ate_all = shard.job_totals(S * K, elapsed_local, sq_err, len(ates), device=dev if backend == "nccl" else None)
+    job = [shard.job_totals(S * K, el, sq_err, len(ates), device=dev if backend == "nccl" else None) for el in elapsed_rep]
+    rates = [tf / el for (tf, el, _, _) in job]               # frames of ALL ranks / MAX-over-ranks time, per repeat
+    order = int(np.argsort(rates)[len(rates) // 2])
+    total_frames, elapsed, sq_err_all, n_ate_all = job[order]
     worst = int(np.argmax(ates)) if ates else -1
-    iters = float(np.mean([st.iterations for st in stats]))
     nres = float(np.mean([st.n_residuals for st in stats]))
     nvar = float(np.mean([st.n_var_landmarks for st in stats]))
     ninp = float(np.mean([st.n_in_problem for st in stats]))
     ntrk = float(np.mean([st.n_tracks for st in stats]))
     reboots = int(np.sum([st.reboot_count for st in stats]))
 
-    # ---- roofline of the dominant kernel (HIP events on the batch stream, averaged over the timed steps)
-    dom = max(kms, key=lambda k: kms[k])
+    # ---- rooflines: algorithmic work of ONE kernel per launch (S sequences) / its average launch duration (HIP events on the
+    # handle's own streams, averaged over the R x K timed steps)
     k_obs = nres / max(ninp, 1.0) + 1.0
-    be_flops_seq = backend_flops(max(iters, 1.0), nres, nvar, k_obs, cfg.window_size, sc.imu_rate / sc.cam_rate)
-    fe_bytes_seq = frontend_bytes(Wd, H, cfg.max_cnt, cfg.lk_max_level)
+    flops = backend_flops(max(iters, 1.0), nres, nvar, k_obs, cfg.window_size, sc.imu_rate / sc.cam_rate)
+    fbytes = frontend_bytes(Wd, H, cfg.max_cnt, cfg.lk_max_level)
     be_ms = sum(v for k, v in kms.items() if k.startswith("be_"))
     fe_ms = sum(v for k, v in kms.items() if k.startswith("fe_"))
-    ksym = dom + "_kernel"
-    if dom == "be_solve" and int(os.environ.get("VIO_BE_THREADS", "512")) <= 512:
-        ksym = "be_solve_kernel_512"  # the 512-thread build of the solve kernel (256 VGPRs per lane) is the default
-    if dom.startswith("be_"):
-        ach = be_flops_seq * S / (kms[dom] * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel=ksym, achieved=ach, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS,
-                    traffic=None, ms=kms[dom],
-                    note="FP64 path; algorithmic back-end flops per launch (SURVEY.md 8d with measured I, O, F) / average launch duration; "
-                         "peak = FP64 vector/matrix 78.6 TFLOP/s")
-    else:
-        ach = fe_bytes_seq * S / (kms[dom] * 1e-3) / 1e9
-        roof = dict(bound="hbm", kernel=ksym, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=None,
-                    ms=kms[dom], note="algorithmic front-end bytes per launch (SURVEY.md 8d) / average launch duration")
-    roof["frontend_GBps"] = fe_bytes_seq * S / (fe_ms * 1e-3) / 1e9 if fe_ms > 0 else None
-    roof["backend_TFLOPs"] = be_flops_seq * S / (be_ms * 1e-3) / 1e12 if be_ms > 0 else None
+    tj = None
+    for name in ("round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+        tpath = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(tpath):  # written by profiles/collect.sh from separate rocprofv3 --pmc passes over this same command
+            tj = (name, json.load(open(tpath)))
+            break
 
-    # ---- CPU baseline: the oracle (port of the reference algorithm, 1 thread) on the same rendered frames, rank 0 only
-    cpu = None
+    def traffic_of(kname):
+        if not tj or tj[1].get("sequences_per_gpu") != S:
+            return None
+        ent = next((v for k, v in tj[1].get("kernels", {}).items() if k.startswith(kname)), None)
+        return ent["hbm_bytes_per_launch"] if ent else None
+
+    def roof_flops(kname, sym, fl, note):
+        ach = fl * S / (kms[kname] * 1e-3) / 1e12
+        return dict(bound="mfma", kernel=sym, achieved=ach, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS, traffic=traffic_of(kname),
+                    ms=kms[kname], algorithmic_flops_per_launch=fl * S, note=note)
+
+    def roof_bytes(kname, sym, by, note):
+        ach = by * S / (kms[kname] * 1e-3) / 1e9
+        tr = traffic_of(kname)
+        return dict(bound="hbm", kernel=sym, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=tr, ms=kms[kname],
+                    algorithmic_bytes_per_launch=by * S, traffic_over_algorithmic=(tr / (by * S) if tr else None), note=note)
+
+    solve_sym = "be_solve_kernel_512" if int(os.environ.get("VIO_BE_THREADS", "512")) <= 512 else "be_solve_kernel"
+    rk = {
+        "be_solve": roof_flops("be_solve", solve_sym, flops["solve"],
+                               "FP64; solve-only algorithmic flops per launch = S x I x per-iteration flops (SURVEY.md 8d, measured I = mean "
+                               "iterations over all timed solves, O residuals, F variable landmarks) / average launch duration"),
+        "be_marg": roof_flops("be_marg", "be_marg_kernel", flops["marg"],
+                              "FP64; marginalisation flops of SURVEY.md 8d without the 10 n_p^3 eigen-decomposition the hot path does not perform"),
+        "be_ingest": roof_flops("be_ingest", "be_ingest_kernel", flops["ingest"], "FP64 vector; pre-integration flops (SURVEY.md 8d)"),
+        "fe_lk": roof_bytes("fe_lk", "fe_lk_kernel", fbytes["lk"], "algorithmic patch bytes: N x (L + 1) x 2 x 23^2 (SURVEY.md 8d)"),
+        "fe_pyrdown": roof_bytes("fe_pyrdown", "fe_pyrdown_kernel", fbytes["pyrdown"], "read the new frame + write the pyramid levels"),
+        "fe_fast": roof_bytes("fe_fast", "fe_fast_kernel", fbytes["fast"], "read the new frame once"),
+    }
+    dom = max(kms, key=lambda k: kms[k])
+    roof = dict(rk[dom]) if dom in rk else dict(rk["be_solve"])
+    if tj and roof.get("traffic") is not None:
+        roof["traffic_source"] = "profiles/%s (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)" % tj[0]
+    roof["frontend_GBps"] = sum(fbytes.values()) * S / (fe_ms * 1e-3) / 1e9 if fe_ms > 0 else None
+    roof["backend_TFLOPs"] = (flops["solve"] + flops["marg"] + flops["ingest"]) * S / (be_ms * 1e-3) / 1e12 if be_ms > 0 else None
+    roofline_kernels = [rk[k] for k in sorted(rk, key=lambda k: -kms[k]) if k != dom]
+
+    # ---- CPU baseline: the oracle (port of the reference algorithm) on the same workload, rank 0 at N = 1 only
+    cpu1 = None
     parity = None
-    if rank == 0 and args.cpu_seqs > 0:
+    if rank == 0 and world == 1 and args.cpu_seqs > 0:
         ncs = min(args.cpu_seqs, S)
+        Fc = min(F, n_pre + Wm + 44)      # bounded sample: ~44 steady-state frames per sequence
         tcpu, nfr, rm, ate_pairs = 0.0, 0, [], []
         for s in range(ncs):
             o = vio_ct.OraclePipeline(cfg)
             ti, ai, gi = syn.imu(seq0 + s, nimu)
             o.push_imu(ti, ai, gi)
             traj = []
-            for f in range(F):
+            for f in range(Fc):
                 g = gray[f, s].cpu().numpy()
                 d = depth[f, s].cpu().numpy()
                 steady = o.status()["solver_flag"] == 1
@@ -293,25 +380,32 @@ def main():
             if m >= 5:
                 gt = np.array([syn.pose(seq0 + s, float(t))[0] for t in hh[:m, 0]])
                 ate_pairs.append((vio_ct.ate_rmse(hh[:m, 1:4], gt), vio_ct.ate_rmse(np.array(traj[:m]), gt)))
-        cpu = dict(value=nfr / tcpu if tcpu > 0 else None, unit="frames/s", cores=1, kind="port",
-                   sample="%d sequences x %d steady-state frames of the same rendered workload through oracle/ (-O3, 1 thread; "
-                          "the reference binary needs ROS/OpenCV/Ceres and cannot be built here)" % (ncs, nfr // max(ncs, 1)),
-                   cpu_seconds=tcpu)
+        cpu1 = dict(value=nfr / tcpu if tcpu > 0 else None, unit="frames/s", cores=1, kind="port",
+                    sample="%d sequences x %d steady-state frames of the same rendered workload through oracle/ (-O3, 1 thread; "
+                           "the reference binary needs ROS/OpenCV/Ceres and cannot be built here)" % (ncs, nfr // max(ncs, 1)),
+                    cpu_seconds=tcpu)
         ah = float(np.mean([a for a, _ in ate_pairs])) if ate_pairs else None
-        ao = float(np.mean([b for _, b in ate_pairs])) if ate_pairs else None
+        ao = float(np.mean([b_ for _, b_ in ate_pairs])) if ate_pairs else None
+        rel = [abs(a - b_) / b_ for a, b_ in ate_pairs if b_ > 0]
         parity = dict(traj_rmse_hip_vs_oracle_m=float(np.max(rm)) if rm else None, sequences=ncs, per_sequence=rm,
                       ate_hip_m=ah, ate_oracle_m=ao, ate_rel_diff=(abs(ah - ao) / ao if ao else None),
+                      ate_rel_diff_worst_sequence=(float(np.max(rel)) if rel else None),
                       note="north-star tolerance: ATE of the HIP path within 1 % of the reference algorithm (oracle) on identical input")
+    cpu = cpu1
+    cpu_all = None
+    nproc = len(os.sched_getaffinity(0)) if args.cpu_procs < 0 else min(args.cpu_procs, os.cpu_count() or 1)
+    if rank == 0 and world == 1 and nproc > 1:
+        import multiprocessing as mp
+        c0 = time.perf_counter()
+        with mp.get_context("spawn").Pool(nproc) as pool:
+            res = pool.map(_cpu_worker, [(seq0 + 1000 + i, 46) for i in range(nproc)])
+        cpu_all = dict(value=float(sum(n / t for t, n in res if t > 0)), unit="frames/s", cores=nproc, kind="port",
+                       sample="%d oracle processes (one per host core), one sequence of 46 frames each; sum of the per-process steady-state "
+                              "rates (the reference's own effective threading is one back-end thread per estimator)" % nproc,
+                       wall_seconds=time.perf_counter() - c0)
+        cpu = dict(cpu_all)
+        cpu["one_core"] = cpu1
 
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")
-    if os.path.exists(tpath):  # written by profiles/collect.sh from separate rocprofv3 --pmc passes over this same command
-        tj = json.load(open(tpath))
-        ent = next((v for k, v in tj.get("kernels", {}).items() if k.startswith(dom)), None)  # be_solve -> be_solve_kernel_512
-        if ent and tj.get("sequences_per_gpu") == S:
-            traffic = ent["hbm_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/round1_pmc_traffic.json (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)"
-    roof["traffic"] = traffic
     out = {
         "metric": "VIO frames/sec (640x480, 150 feats, 10-KF window)",
         "value": total_frames / elapsed,
@@ -329,27 +423,24 @@ def main():
                                "150 max features, 5x6 grid, 10-keyframe window, landmarks free (fix_depth 0)" % S,
                    "sequences_per_gpu": S, "image": [Wd, H], "max_cnt": cfg.max_cnt, "window_size": cfg.window_size,
                    "parallelism": "independent sequences sharded per GPU, no data-path collective"},
+        "repeats": {"n": R, "frames_per_s": rates, "median_index": order, "spread_rel": (max(rates) - min(rates)) / (total_frames / elapsed),
+                    "timed_frames_per_sequence": R * K},
         "valid": all_processed,
         "ate_m": {"mean": float(np.mean(ates)) if ates else None, "max": float(np.max(ates)) if ates else None, "sequences": len(ates),
                   "median": float(np.median(ates)) if ates else None, "worst_sequence": seq0 + worst,
                   "job_rms": shard.ate_from_sums(sq_err_all, n_ate_all)},
-        "solver": {"mean_iterations": iters, "mean_residuals": nres, "mean_var_landmarks": nvar, "mean_tracks": ntrk, "reboots": reboots},
+        "solver": {"mean_iterations": iters, "timed_solves": int(d_it[1]), "mean_residuals": nres, "mean_var_landmarks": nvar, "mean_tracks": ntrk,
+                   "reboots": reboots},
         "kernels_ms": kms,
         "frontend_ms": fe_ms,
         "backend_ms": be_ms,
         "roofline": roof,
+        "roofline_kernels": roofline_kernels,
         "cpu_baseline": cpu,
         "parity": parity,
         "pcie_inclusive": pcie,
         "imu_streaming": stream,
     }
-    if rank == 0 and args.cpu_procs > 1:
-        import multiprocessing as mp
-        nproc = min(args.cpu_procs, os.cpu_count() or 1)
-        with mp.get_context("spawn").Pool(nproc) as pool:
-            res = pool.map(_cpu_worker, [(seq0 + 1000 + i, 46) for i in range(nproc)])
-        out["cpu_baseline_multicore"] = dict(value=float(sum(n / t for t, n in res if t > 0)), unit="frames/s", cores=nproc, kind="port",
-                                             sample="%d oracle processes, one sequence each, 46 frames; sum of the per-process steady-state rates" % nproc)
     if args.aux and rank == 0:
         out["aux_s256"] = aux_rate(P, vio_ct, torch, cfg, sc, dev, 256, n_pre, Wm, K)
     if rank == 0:

@@ -60,15 +60,15 @@ def test_landmark_table_and_solver_stats_match_oracle_every_frame(P, fix_depth):
 
 def test_reference_vio_yaml_parameters_with_unpublished_frames(P):
     """BASELINE configs[0] parameter set (config/realsense/vio.yaml: max_cnt 30, min_dist 30, fix_depth 1, estimate_td 1, acc_n 1.0,
-    rolling shutter 33 ms, freq 10 / frontend_freq 20) on a 30 Hz stream: the nodelet's frequency control drops, tracks-only
+    rolling shutter 33 ms, freq 10 / frontend_freq 20) on a 60 Hz stream: the nodelet's frequency control drops, tracks-only
     (PUB_THIS_FRAME false: no RANSAC / mask / detection, feature_tracker.cpp:351) and publishes frames; the same modes go to the
     oracle and to vio_feed_modes.  Tracker state compared after EVERY frame, estimator decisions and poses like the other tests."""
     cfg = P.default_config(max_cnt=30, min_dist=30, fix_depth=1, estimate_td=1, acc_n=1.0, tr=0.033)
-    sc = vio_ct.synth_like(cfg, cam_rate=30.0)
-    seq, n_frames = 12, 150
+    sc = vio_ct.synth_like(cfg, cam_rate=60.0)
+    seq, n_frames = 12, 240
     times = vio_ct.frame_times(sc, n_frames)
     modes = vio_ct.gate_modes(vio_ct.OracleGate(10, 20), times)
-    assert modes.count(0) > 10 and modes.count(1) > 20 and modes.count(2) > 30, (modes.count(0), modes.count(1), modes.count(2))
+    assert modes.count(0) > 60 and modes.count(1) > 40 and modes.count(2) > 30, (modes.count(0), modes.count(1), modes.count(2))
     tr_o = []
     o = vio_ct.run_oracle_sequence(cfg, sc, seq, n_frames, modes=modes, hook=lambda f, orc: tr_o.append(orc.tracks()))
     tr_h = []
