@@ -12,6 +12,7 @@
  */
 #ifndef VIO_ABI_H
 #define VIO_ABI_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -121,6 +122,12 @@ int vio_process_obs_batch(vio_batch *h, const int32_t *n_obs, const int32_t *ids
 /* The feature map packaged by the last vio_track / vio_feed for sequence seq (what the nodelet would push to feature_buf):
  * returns the count (0 when the frame was not published), ids ascending. */
 int vio_get_packaged(vio_batch *h, int seq, int cap, int32_t *ids, double *xyz_uv_vel);
+/* HBM buffers for callers that do not link HIP themselves (the on_device != 0 arguments are plain device addresses): synchronous
+ * hipMalloc / hipFree / hipMemcpy on the current device.  vio_device_alloc returns NULL on failure. */
+void *vio_device_alloc(size_t bytes);
+void vio_device_free(void *p);
+int vio_device_upload(void *dst_device, const void *src_host, size_t bytes);
+int vio_device_download(void *dst_host, const void *src_device, size_t bytes);
 /* sizeof(vio_config) (what = 0) / sizeof(vio_status) (what = 1) as compiled into the library: lets a binding check its struct mirrors */
 int vio_abi_sizeof(int what);
 /* capacities derived from the configuration: out[0] = tracker points per sequence, out[1] = landmark slots, out[2] = IMU ring */

@@ -122,6 +122,11 @@ def lib():
         L.vio_stage_imu_factor.argtypes = [C.POINTER(Config), C.c_int] + [C.c_void_p] * 14
         L.vio_stage_projection.argtypes = [C.POINTER(Config)] + [C.c_void_p] * 3 + [C.c_double, C.c_double, C.c_void_p, C.c_void_p,
                                                                                   C.c_int, C.c_void_p, C.c_void_p]
+        L.vio_device_alloc.restype = C.c_void_p
+        L.vio_device_alloc.argtypes = [C.c_size_t]
+        L.vio_device_free.argtypes = [C.c_void_p]
+        L.vio_device_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.vio_device_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.vio_stage_projection_residual.argtypes = L.vio_stage_projection.argtypes
         L.vio_stage_imu_block.argtypes = [C.POINTER(Config), C.c_int] + [C.c_void_p] * 12
         _lib = L
@@ -160,6 +165,43 @@ def _ptr(a):
     if hasattr(a, "data_ptr"):  # torch tensor (device or host)
         return a.data_ptr()
     return a
+
+
+class DeviceBuffer:
+    """A plain HBM allocation (vio_device_alloc) for the on_device = True paths when the caller has no HIP binding of its own
+    (bench.py uses torch tensors instead).  `ptr` is the device address; slices are addressed with `at(byte_offset)`."""
+
+    def __init__(self, nbytes):
+        self.L = lib()
+        self.nbytes = int(nbytes)
+        self.ptr = self.L.vio_device_alloc(self.nbytes)
+        if not self.ptr:
+            raise VioError("vio_device_alloc(%d) failed: %s" % (self.nbytes, self.L.vio_last_error().decode()))
+
+    def at(self, byte_offset):
+        return self.ptr + int(byte_offset)
+
+    def download(self, byte_offset, shape, dtype):
+        out = np.empty(shape, dtype)
+        if self.L.vio_device_download(out.ctypes.data, self.ptr + int(byte_offset), out.nbytes) != 0:
+            raise VioError("vio_device_download failed")
+        return out
+
+    def upload(self, byte_offset, arr):
+        arr = np.ascontiguousarray(arr)
+        if self.L.vio_device_upload(self.ptr + int(byte_offset), arr.ctypes.data, arr.nbytes) != 0:
+            raise VioError("vio_device_upload failed")
+
+    def free(self):
+        if self.ptr:
+            self.L.vio_device_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class Synth:

@@ -40,4 +40,5 @@ __global__ void be_stage_imu_kernel(vio_config cfg, PreInt *P, int n, const doub
 __global__ void be_stage_projection_kernel(vio_config cfg, const double *in, int use_td, int form, double *r2, double *J46);
 __global__ void be_stage_imu_block_kernel(const PreInt *P, const double *par, double g_norm, double *G961);
 __global__ void imu_scatter_kernel(Batch B, int total, const int *seq_of, const double *t, const double *acc, const double *gyr);
+__global__ void imu_commit_kernel(Batch B, int total, const int *seq_of);
 __global__ void synth_render_kernel(vio_synth_config c, int S, uint64_t seq0, const float *rays, const float *poses, uint8_t *gray, uint16_t *depth);

@@ -118,24 +118,27 @@ static int sync_all(vio_batch *h) {
     return VIO_OK;
 }
 
+// Pending IMU samples arrive grouped by sequence (counting sort on the host keeps the push order inside a sequence): sample i of
+// sequence s = seq_of[i] is the (i - off[s])-th new sample of that sequence.  One thread per sample; the ring counters are advanced
+// by imu_commit_kernel afterwards (same stream), so every thread of the scatter sees the old count.
 __global__ void imu_scatter_kernel(Batch B, int total, const int *seq_of, const double *t, const double *acc, const double *gyr) {
-    // samples are grouped by sequence in push order; one thread per sequence walks its run (keeps ring order)
-    int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= B.S) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
     const DevCfg &C = *B.cfg;
-    BeSeq &be = B.be[s];
-    int cnt = be.imu_count;
-    for (int i = 0; i < total; i++) {
-        if (seq_of[i] != s) continue;
-        int slot = cnt % C.NIMU;
-        B.imu_t[(size_t)s * C.NIMU + slot] = t[i];
-        for (int k = 0; k < 3; k++) {
-            B.imu_acc[((size_t)s * C.NIMU + slot) * 3 + k] = acc[3 * i + k];
-            B.imu_gyr[((size_t)s * C.NIMU + slot) * 3 + k] = gyr[3 * i + k];
-        }
-        cnt++;
+    const int *off = seq_of + total;  // [S + 1] offsets of each sequence's run, stored behind the sequence ids
+    const int s = seq_of[i];
+    const int slot = (B.be[s].imu_count + (i - off[s])) % C.NIMU;
+    B.imu_t[(size_t)s * C.NIMU + slot] = t[i];
+    for (int k = 0; k < 3; k++) {
+        B.imu_acc[((size_t)s * C.NIMU + slot) * 3 + k] = acc[3 * i + k];
+        B.imu_gyr[((size_t)s * C.NIMU + slot) * 3 + k] = gyr[3 * i + k];
     }
-    be.imu_count = cnt;
+}
+__global__ void imu_commit_kernel(Batch B, int total, const int *seq_of) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= B.S) return;
+    const int *off = seq_of + total;
+    B.be[s].imu_count += off[s + 1] - off[s];
 }
 
 namespace {
@@ -215,27 +218,39 @@ int flush_imu(vio_batch *h, hipStream_t st, bool *launched) {
             (void)hipHostFree(sg.h_seq); (void)hipHostFree(sg.h_t); (void)hipHostFree(sg.h_acc); (void)hipHostFree(sg.h_gyr);
             (void)hipFree(sg.d_seq); (void)hipFree(sg.d_t); (void)hipFree(sg.d_acc); (void)hipFree(sg.d_gyr);
         }
-        HIPCHK(hipHostMalloc((void **)&sg.h_seq, cap * sizeof(int), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&sg.h_seq, (cap + h->S + 1) * sizeof(int), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void **)&sg.h_t, cap * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void **)&sg.h_acc, cap * 3 * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void **)&sg.h_gyr, cap * 3 * sizeof(double), hipHostMallocDefault));
-        HIPCHK(hipMalloc((void **)&sg.d_seq, cap * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&sg.d_seq, (cap + h->S + 1) * sizeof(int)));
         HIPCHK(hipMalloc((void **)&sg.d_t, cap * sizeof(double)));
         HIPCHK(hipMalloc((void **)&sg.d_acc, cap * 3 * sizeof(double)));
         HIPCHK(hipMalloc((void **)&sg.d_gyr, cap * 3 * sizeof(double)));
         sg.cap = cap;
         if (!sg.done) HIPCHK(hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
     }
-    memcpy(sg.h_seq, h->p_seq.data(), n * sizeof(int));
-    memcpy(sg.h_t, h->p_t.data(), n * sizeof(double));
-    memcpy(sg.h_acc, h->p_acc.data(), n * 3 * sizeof(double));
-    memcpy(sg.h_gyr, h->p_gyr.data(), n * 3 * sizeof(double));
+    {
+        // stable counting sort by sequence into the pinned staging set; the S + 1 run offsets travel behind the sequence ids
+        const int S = h->S;
+        int *off = sg.h_seq + n;
+        for (int s = 0; s <= S; s++) off[s] = 0;
+        for (size_t i = 0; i < n; i++) off[h->p_seq[i] + 1]++;
+        for (int s = 0; s < S; s++) off[s + 1] += off[s];
+        std::vector<int> cur(off, off + S);
+        for (size_t i = 0; i < n; i++) {
+            const int s = h->p_seq[i], q = cur[s]++;
+            sg.h_seq[q] = s;
+            sg.h_t[q] = h->p_t[i];
+            for (int k = 0; k < 3; k++) { sg.h_acc[3 * q + k] = h->p_acc[3 * i + k]; sg.h_gyr[3 * q + k] = h->p_gyr[3 * i + k]; }
+        }
+    }
     h->p_seq.clear(); h->p_t.clear(); h->p_acc.clear(); h->p_gyr.clear();
-    HIPCHK(hipMemcpyAsync(sg.d_seq, sg.h_seq, n * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(sg.d_seq, sg.h_seq, (n + h->S + 1) * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(sg.d_t, sg.h_t, n * sizeof(double), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(sg.d_acc, sg.h_acc, n * 3 * sizeof(double), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(sg.d_gyr, sg.h_gyr, n * 3 * sizeof(double), hipMemcpyHostToDevice, st));
-    imu_scatter_kernel<<<(h->S + 63) / 64, 64, 0, st>>>(h->B, (int)n, sg.d_seq, sg.d_t, sg.d_acc, sg.d_gyr);
+    imu_scatter_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(h->B, (int)n, sg.d_seq, sg.d_t, sg.d_acc, sg.d_gyr);
+    imu_commit_kernel<<<(h->S + 63) / 64, 64, 0, st>>>(h->B, (int)n, sg.d_seq);
     HIPCHK(hipEventRecord(sg.done, st));
     sg.busy = true;
     if (launched) *launched = true;
@@ -781,6 +796,16 @@ int vio_get_packaged(vio_batch *h, int seq, int cap, int32_t *ids, double *obs) 
     if (m > 0 && obs) HIPCHK(hipMemcpy(obs, h->B.obs + (size_t)seq * h->hc.NP * 7, sizeof(double) * 7 * m, hipMemcpyDeviceToHost));
     return n;
 }
+
+// ---- HBM buffers for callers without their own HIP binding (the on_device = 1 paths take plain device addresses)
+void *vio_device_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { g_err = "hipMalloc failed"; return nullptr; }
+    return p;
+}
+void vio_device_free(void *p) { if (p) (void)hipFree(p); }
+int vio_device_upload(void *dst, const void *src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return VIO_OK; }
+int vio_device_download(void *dst, const void *src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return VIO_OK; }
 
 int vio_abi_sizeof(int what) { return what == 0 ? (int)sizeof(vio_config) : (what == 1 ? (int)sizeof(vio_status) : -1); }
 
