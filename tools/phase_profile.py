@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""In-kernel phase timers of sequence 0 (vio_debug_phases: thread 0 accumulates 100 MHz ticks per phase) on the bench workload.
+    python tools/phase_profile.py [--seqs 128] [--frames 40]
+Prints microseconds per frame for every phase slot of be_solve / be_marg (see the PH(k) markers in be_kernels.hip)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import vio_ct  # noqa: E402
+
+NAMES = {0: "vector2double", 1: "lm indexing", 2: "pair lists", 4: "evaluate(first/accepted)", 5: "assemble", 6: "prepare_point", 7: "cauchy", 8: "schur",
+         9: "cholesky", 10: "tri solves", 11: "dogleg/model", 12: "candidate evaluate", 13: "accept/bookkeeping",
+         16: "marg prior", 17: "marg imu", 18: "marg proj eval", 19: "marg lm rows", 20: "marg frame blocks+rank update", 21: "marg 15x15 + reduce",
+         22: "marg new prior + c0", 23: "marg keep data",
+         32: "asm zero", 33: "asm prior", 34: "asm imu blocks", 35: "asm pair blocks", 36: "asm element sums", 37: "asm lm rows",
+         40: "ev prior dx", 46: "ev imu", 41: "ev pair geo", 44: "ev prior matvec + proj", 45: "ev reduce"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seqs", type=int, default=128)
+    ap.add_argument("--frames", type=int, default=40)
+    a = ap.parse_args()
+    P = vio_ct.pkg()
+    L = P.lib()
+    L.vio_debug_phases.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    syn = P.Synth(sc)
+    S, n_pre = a.seqs, 20
+    F = n_pre + a.frames
+    hw = cfg.height * cfg.width
+    g = P.DeviceBuffer(F * S * hw)
+    d = P.DeviceBuffer(F * S * hw * 2)
+    times = vio_ct.frame_times(sc, F)
+    for f in range(F):
+        syn.render_device(S, 0, float(times[f]), g.at(f * S * hw), d.at(f * S * hw * 2))
+    nimu = int(F / sc.cam_rate * sc.imu_rate) + 64
+    b = P.VioBatch(cfg, S, imu_capacity=nimu + 64)
+    imu = [syn.imu(s, nimu) for s in range(S)]
+    b.push_imu_batch(np.stack([x[0] for x in imu]), np.stack([x[1] for x in imu]), np.stack([x[2] for x in imu]))
+    for f in range(n_pre):
+        b.feed(g.at(f * S * hw), d.at(f * S * hw * 2), np.full(S, times[f]), on_device=True)
+    L.vio_debug_phases(b.h, None, 1)
+    it0 = b.status(0).iterations_total
+    for f in range(n_pre, F):
+        b.feed(g.at(f * S * hw), d.at(f * S * hw * 2), np.full(S, times[f]), on_device=True)
+    out = np.zeros(64, np.float32)
+    L.vio_debug_phases(b.h, out.ctypes.data, 0)
+    st = b.status(0)
+    print("sequence 0: %.2f solver iterations per frame over %d frames" % ((st.iterations_total - it0) / a.frames, a.frames))
+    us = out / 100.0 / a.frames
+    for k in sorted(NAMES):
+        if us[k] > 0:
+            print("%3d %-28s %8.1f us/frame" % (k, NAMES[k], us[k]))
+    print("solve top-level sum %.1f us, marg sum %.1f us" % (sum(us[k] for k in (0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)), sum(us[16:24])))
+
+
+if __name__ == "__main__":
+    main()

@@ -354,10 +354,14 @@ DM_HD v3 rowmul(v3 r, const double *A) {  // row (1x3) times a 3x3 row-major mat
 }
 DM_HD v3 matvec9(const double *A, v3 v) { return mk(A[0] * v.x + A[1] * v.y + A[2] * v.z, A[3] * v.x + A[4] * v.y + A[5] * v.z, A[6] * v.x + A[7] * v.y + A[8] * v.z); }
 
-// ricm = ric (row-major 3x3), tic: extrinsic.  r[2]; J (optional) 2x20 row-major as in eval_projection.  With cauchy = true the
+// ricm = ric (row-major 3x3), tic: extrinsic.  r[2]; J (optional) 2 rows as in eval_projection.  With cauchy = true the
 // Jacobian is multiplied by the CauchyLoss(1) weight sqrt(1 / (1 + |r|^2)), which is returned in *wgt (r itself is left unweighted).
+// Row layout: rs = 20 (default): [pose_i(6) pose_j(6) ex(6) td inv_depth]; rs = 14 ("compact", ext = false): [pose_i(6) pose_j(6)
+// inv_depth -] for solves in which the extrinsic and td blocks are constant (Ceres does not evaluate Jacobians of constant blocks
+// either); the inverse-depth column sits at index lcol = rs == 20 ? 19 : 12.
 DM_HD void eval_projection_pair(const vio_config &c, const PairGeo &g, const double *ricm, const double *ticp, double inv_dep, double td,
-                                const double *oi, const double *oj, bool use_td, double *r, double *J, bool cauchy, double *wgt) {
+                                const double *oi, const double *oj, bool use_td, double *r, double *J, bool cauchy, double *wgt,
+                                const int rs = 20, const bool ext = true) {
     v3 pts_i = mk(oi[0], oi[1], oi[2]), pts_j = mk(oj[0], oj[1], oj[2]);
     v3 vel_i = mk(oi[5], oi[6], 0), vel_j = mk(oj[5], oj[6], 0);
     if (use_td) {
@@ -382,7 +386,6 @@ DM_HD void eval_projection_pair(const vio_config &c, const PairGeo &g, const dou
     // rho = red * A2, rho1 = red * A1, rhoT = red * ric^T, rhoM = red * M
     v3 a0 = rowmul(red0, g.A1), a1 = rowmul(red1, g.A1);
     v3 b0 = rowmul(red0, g.A2), b1 = rowmul(red1, g.A2);
-    v3 m0 = rowmul(red0, g.M), m1 = rowmul(red1, g.M);
     // red * ric^T : (ric^T)[k][c] = ric[c][k]
     v3 c0 = mk(red0.x * ricm[0] + red0.y * ricm[1] + red0.z * ricm[2], red0.x * ricm[3] + red0.y * ricm[4] + red0.z * ricm[5],
                red0.x * ricm[6] + red0.y * ricm[7] + red0.z * ricm[8]);
@@ -390,28 +393,31 @@ DM_HD void eval_projection_pair(const vio_config &c, const PairGeo &g, const dou
                red1.x * ricm[6] + red1.y * ricm[7] + red1.z * ricm[8]);
     v3 npi = neg(pim_i);
     // pose_i: [red A1 | red A2 (-skew(pts_imu_i))]
-    st3(J + 0, a0); st3(J + 20, a1);
-    st3(J + 3, rowskew(b0, npi)); st3(J + 23, rowskew(b1, npi));
+    st3(J + 0, a0); st3(J + rs, a1);
+    st3(J + 3, rowskew(b0, npi)); st3(J + rs + 3, rowskew(b1, npi));
     // pose_j: [-red A1 | red ric^T skew(pts_imu_j)]
-    st3(J + 6, neg(a0)); st3(J + 26, neg(a1));
-    st3(J + 9, rowskew(c0, pim_j)); st3(J + 29, rowskew(c1, pim_j));
-    // extrinsic: [red (A2 - ric^T) | red (-M skew(pc_i) + skew(pc_j))]
-    st3(J + 12, sub(b0, c0)); st3(J + 32, sub(b1, c1));
-    st3(J + 15, sub(rowskew(red0, pc_j), rowskew(m0, pc_i))); st3(J + 35, sub(rowskew(red1, pc_j), rowskew(m1, pc_i)));
+    st3(J + 6, neg(a0)); st3(J + rs + 6, neg(a1));
+    st3(J + 9, rowskew(c0, pim_j)); st3(J + rs + 9, rowskew(c1, pim_j));
     // inverse depth: red * M * pts_i * (-1 / lambda^2)
     {
         v3 v = scl(-1.0 / (inv_dep * inv_dep), matvec9(g.M, pts_i));
-        J[19] = dot(red0, v);
-        J[39] = dot(red1, v);
+        const int lcol = ext ? 19 : 12;
+        J[lcol] = dot(red0, v);
+        J[rs + lcol] = dot(red1, v);
     }
+    if (!ext) return;
+    // extrinsic: [red (A2 - ric^T) | red (-M skew(pc_i) + skew(pc_j))]
+    v3 m0 = rowmul(red0, g.M), m1 = rowmul(red1, g.M);
+    st3(J + 12, sub(b0, c0)); st3(J + rs + 12, sub(b1, c1));
+    st3(J + 15, sub(rowskew(red0, pc_j), rowskew(m0, pc_i))); st3(J + rs + 15, sub(rowskew(red1, pc_j), rowskew(m1, pc_i)));
     if (use_td) {
         v3 w0 = matvec9(g.M, vel_i);
         v3 w = mk(w0.x / inv_dep * -1.0, w0.y / inv_dep * -1.0, w0.z / inv_dep * -1.0);
         J[18] = dot(red0, w) + s * sq * vel_j.x;
-        J[38] = dot(red1, w) + s * sq * vel_j.y;
+        J[rs + 18] = dot(red1, w) + s * sq * vel_j.y;
     } else {
         J[18] = 0;
-        J[38] = 0;
+        J[rs + 18] = 0;
     }
 }
 

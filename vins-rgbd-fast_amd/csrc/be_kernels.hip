@@ -517,8 +517,10 @@ __device__ __forceinline__ int prior_map(int a, int W) {
 }
 
 // evaluate every residual at X. withJ: store weighted Jacobians/residuals for assembly. Returns total cost.
+// vext: the extrinsic and / or td block is a variable of this solve.  Otherwise the residual records are written in the compact
+// layout (28 doubles: two rows of [pose_i(6) pose_j(6) inv_depth r]) and no Jacobian is evaluated for the constant blocks.
 __device__ __forceinline__ double evaluate(const Ctx &c, const Params &X, const double *feat, bool withJ, int nres, double *sred, double *sdx, double *srp,
-                                           double *geo) {
+                                           double *geo, bool vext) {
     const int t = threadIdx.x, nt = blockDim.x, W = c.W, n = c.NPR;
     const BeSeq &be = *c.be;
     const vio_config &cfg = c.C->c;
@@ -603,15 +605,21 @@ __device__ __forceinline__ double evaluate(const Ctx &c, const Params &X, const 
             int imu_i = c.lm_start[slot], imu_j = imu_i + k;
             const bf::PairGeo &g = *(const bf::PairGeo *)(geo + (size_t)(imu_i * W1 + imu_j) * 32);
             double rr[2], wgt = 1.0;
-            double *out = c.res + (size_t)r * 42;
-            bf::eval_projection_pair(cfg, g, ricm, X.ex, feat[c.lm_pidx[slot]], X.td, obs_ptr(c, slot, imu_i), obs_ptr(c, slot, imu_j),
-                                     cfg.estimate_td != 0, rr, withJ ? out : nullptr, true, &wgt);
-            double sq = rr[0] * rr[0] + rr[1] * rr[1];
-            cost += 0.5 * log(1.0 + sq);
-            if (withJ) {
-                out[40] = wgt * rr[0];
-                out[41] = wgt * rr[1];
+            double sq;
+            if (vext) {
+                double *out = c.res + (size_t)r * 42;
+                bf::eval_projection_pair(cfg, g, ricm, X.ex, feat[c.lm_pidx[slot]], X.td, obs_ptr(c, slot, imu_i), obs_ptr(c, slot, imu_j),
+                                         cfg.estimate_td != 0, rr, withJ ? out : nullptr, true, &wgt);
+                sq = rr[0] * rr[0] + rr[1] * rr[1];
+                if (withJ) { out[40] = wgt * rr[0]; out[41] = wgt * rr[1]; }
+            } else {
+                double *out = c.res + (size_t)r * 28;
+                bf::eval_projection_pair(cfg, g, ricm, X.ex, feat[c.lm_pidx[slot]], X.td, obs_ptr(c, slot, imu_i), obs_ptr(c, slot, imu_j),
+                                         cfg.estimate_td != 0, rr, withJ ? out : nullptr, true, &wgt, 14, false);
+                sq = rr[0] * rr[0] + rr[1] * rr[1];
+                if (withJ) { out[13] = wgt * rr[0]; out[27] = wgt * rr[1]; }
             }
+            cost += 0.5 * log(1.0 + sq);
         }
     }
     PH(44);
@@ -720,10 +728,48 @@ __device__ __forceinline__ void imu_block_mfma(const double *raw_l, const double
     }
 }
 
+// The same for the compact residual records (28 doubles, no extrinsic / td columns): half 0 = pose columns, half 1 = Hll and gl.
+__device__ __forceinline__ void lm_row_compact(const double *__restrict__ res, double *__restrict__ row, double *__restrict__ Hll,
+                                               double *__restrict__ gl, int half, int st, int kend) {
+    if (half == 0) {
+        double si[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll 2
+        for (int k = 1; k < kend; k++) {
+            const double2 *J2 = (const double2 *)(res + (size_t)(k - 1) * 28);
+            double a[6], b[6], e[6], f[6];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                double2 va = J2[q], vb = J2[3 + q], ve = J2[7 + q], vf = J2[10 + q];
+                a[2 * q] = va.x; a[2 * q + 1] = va.y; b[2 * q] = vb.x; b[2 * q + 1] = vb.y;
+                e[2 * q] = ve.x; e[2 * q + 1] = ve.y; f[2 * q] = vf.x; f[2 * q + 1] = vf.y;
+            }
+            const double l0 = J2[6].x, l1 = J2[13].x;
+#pragma unroll
+            for (int d = 0; d < 6; d++) {
+                si[d] += a[d] * l0 + e[d] * l1;
+                row[6 * (st + k) + d] = b[d] * l0 + f[d] * l1;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 6; d++) row[6 * st + d] = si[d];
+    } else {
+        double hll = 0, gg = 0;
+#pragma unroll 2
+        for (int k = 1; k < kend; k++) {
+            const double2 *J2 = (const double2 *)(res + (size_t)(k - 1) * 28);
+            const double2 p0 = J2[6], p1 = J2[13];   // (inv_depth column, weighted residual) of the two rows
+            hll += p0.x * p0.x + p1.x * p1.x;
+            gg += p0.x * p0.y + p1.x * p1.y;
+        }
+        *Hll = hll;
+        *gl = gg;
+    }
+}
+
 // assemble H (P x P, ld LW), g (vec slot 0), Hpl / Hll / gl from the stored residual Jacobians.
 // work: LDS scratch (>= max(W*450, npairs*210) doubles when it fits, see be_solve); pb = frame-pair blocks (LDS or HBM)
 __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Params &X, int nres, int Fa, const int *alist, double *srp, double *work,
-                         double *pb, bool hpl_sparse) {
+                         double *pb, bool hpl_sparse, bool vext) {
     const int s = c.s;
     PH_INIT;
     const int t = threadIdx.x, nt = blockDim.x, W = c.W, P = c.P, LW = c.LW, n = c.NPR;
@@ -736,7 +782,9 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
         // landmark rows: with the column-aware Schur staging and mat-vecs (hpl_sparse) only the column tiles that hold pose or
         // extrinsic / td columns are ever read, the speed-bias columns in between need no zeros (the marginalisation kernel uses
         // this buffer as scratch, so they do hold garbage); the dense fall-back paths read whole rows
-        const int w0 = hpl_sparse ? min(LW, (6 * (W + 1) + 15) & ~15) : LW, e_lo = max(w0, (15 * (W + 1)) & ~15), wz = w0 + (LW - e_lo);
+        // (with constant extrinsic / td blocks and the column-aware paths the extrinsic tile is never read either)
+        const int w0 = hpl_sparse ? min(LW, (6 * (W + 1) + 15) & ~15) : LW, e_lo = max(w0, (15 * (W + 1)) & ~15),
+                  wz = w0 + ((hpl_sparse && !vext) ? 0 : (LW - e_lo));
         for (int i = t; i < ((Fa + 3) & ~3) * wz; i += nt) {
             const int row = i / wz, cc = i - row * wz;
             c.Hpl[(size_t)row * LW + (cc < w0 ? cc : e_lo + (cc - w0))] = 0;
@@ -817,38 +865,70 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
             // residual indices of the pair are fetched 64 at a time (one coalesced load) and broadcast with shuffles; the
             // k loop is unrolled by PB_U with unconditional (clamped) loads so that 2 * PB_U row loads are in flight per MFMA
             // batch: the phase is bound by the L2 latency of those loads (a typical pair is one or two batches), not by the MFMAs
-            for (int base = 0; base < np_; base += 64) {
-                const int nchunk = min(64, np_ - base);
-                const int myidx = c.pair_list[q0 + base + min(lane, nchunk - 1)];
-                const int Kc = 2 * nchunk;
-                for (int k0 = 0; k0 < Kc; k0 += 4 * PB_U) {
-                    double x0[PB_U], x1[PB_U];
+            if (vext) {
+                for (int base = 0; base < np_; base += 64) {
+                    const int nchunk = min(64, np_ - base);
+                    const int myidx = c.pair_list[q0 + base + min(lane, nchunk - 1)];
+                    const int Kc = 2 * nchunk;
+                    for (int k0 = 0; k0 < Kc; k0 += 4 * PB_U) {
+                        double x0[PB_U], x1[PB_U];
 #pragma unroll
-                    for (int u = 0; u < PB_U; u++) {
-                        int kk = k0 + 4 * u + lk;
-                        bool valid = kk < Kc;
-                        int ridx = __shfl(myidx, min(kk, Kc - 1) >> 1, 64);
-                        const double *Jr = c.res + (size_t)ridx * 42;
-                        int sub = kk & 1, ro = sub * 20;
-                        double v0 = Jr[ro + li];
-                        double v1 = Jr[li < 3 ? ro + 16 + li : 40 + sub];
-                        x0[u] = valid ? v0 : 0.0;
-                        x1[u] = (valid && li < 4) ? v1 : 0.0;
-                    }
+                        for (int u = 0; u < PB_U; u++) {
+                            int kk = k0 + 4 * u + lk;
+                            bool valid = kk < Kc;
+                            int ridx = __shfl(myidx, min(kk, Kc - 1) >> 1, 64);
+                            const double *Jr = c.res + (size_t)ridx * 42;
+                            int sub = kk & 1, ro = sub * 20;
+                            double v0 = Jr[ro + li];
+                            double v1 = Jr[li < 3 ? ro + 16 + li : 40 + sub];
+                            x0[u] = valid ? v0 : 0.0;
+                            x1[u] = (valid && li < 4) ? v1 : 0.0;
+                        }
 #pragma unroll
-                    for (int u = 0; u < PB_U; u++) {
-                        if (k0 + 4 * u >= Kc) break;  // wavefront-uniform: the remaining k groups of this batch are all padding
-                        a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u], x0[u], a00, 0, 0, 0);
-                        a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x0[u], a10, 0, 0, 0);
-                        a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x1[u], a11, 0, 0, 0);
+                        for (int u = 0; u < PB_U; u++) {
+                            if (k0 + 4 * u >= Kc) break;  // wavefront-uniform: the remaining k groups of this batch are all padding
+                            a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u], x0[u], a00, 0, 0, 0);
+                            a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x0[u], a10, 0, 0, 0);
+                            a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x1[u], a11, 0, 0, 0);
+                        }
                     }
                 }
-            }
-            for (int r = 0; r < 4; r++) {
-                int row = lk + 4 * r, col = li;  // C/D layout of v_mfma_f64_16x16x4_f64
-                if (col <= row) out[sym_idx(col, row)] = a00[r];
-                if (row < 4) out[sym_idx(col, 16 + row)] = a10[r];
-                if (row < 4 && col < 4 && col <= row) out[sym_idx(16 + col, 16 + row)] = a11[r];
+                for (int r = 0; r < 4; r++) {
+                    int row = lk + 4 * r, col = li;  // C/D layout of v_mfma_f64_16x16x4_f64
+                    if (col <= row) out[sym_idx(col, row)] = a00[r];
+                    if (row < 4) out[sym_idx(col, 16 + row)] = a10[r];
+                    if (row < 4 && col < 4 && col <= row) out[sym_idx(16 + col, 16 + row)] = a11[r];
+                }
+            } else {
+                // compact records: 12 pose columns + the weighted residual in one 16-wide operand (columns 13 .. 15 are padding), one
+                // accumulator.  Every output element is the same dot product, in the same k order, as in the three-accumulator form.
+                for (int base = 0; base < np_; base += 64) {
+                    const int nchunk = min(64, np_ - base);
+                    const int myidx = c.pair_list[q0 + base + min(lane, nchunk - 1)];
+                    const int Kc = 2 * nchunk;
+                    for (int k0 = 0; k0 < Kc; k0 += 4 * PB_U) {
+                        double x0[PB_U];
+#pragma unroll
+                        for (int u = 0; u < PB_U; u++) {
+                            int kk = k0 + 4 * u + lk;
+                            bool valid = kk < Kc;
+                            int ridx = __shfl(myidx, min(kk, Kc - 1) >> 1, 64);
+                            const double *Jr = c.res + (size_t)ridx * 28 + (kk & 1) * 14;
+                            double v0 = Jr[li < 12 ? li : 13];
+                            x0[u] = (valid && li < 13) ? v0 : 0.0;
+                        }
+#pragma unroll
+                        for (int u = 0; u < PB_U; u++) {
+                            if (k0 + 4 * u >= Kc) break;
+                            a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u], x0[u], a00, 0, 0, 0);
+                        }
+                    }
+                }
+                for (int r = 0; r < 4; r++) {
+                    int row = lk + 4 * r, col = li;
+                    if (row < 12) { if (col <= row) out[sym_idx(col, row)] = a00[r]; }
+                    else if (row == 12 && col <= 12) out[sym_idx(col < 12 ? col : 19, 19)] = a00[r];   // (column, residual) and (residual, residual)
+                }
             }
         }
     }
@@ -857,7 +937,7 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
     {
         // one item per unordered pair (ra <= rb) of vision rows plus one per gradient entry: H is symmetric and both mirror
         // elements receive the same sum (identical terms in identical order), so only half of the element sums are formed
-        const int nv = 6 * W1 + 7, ntri = nv * (nv + 1) / 2;
+        const int nv = 6 * W1 + (vext ? 7 : 0), ntri = nv * (nv + 1) / 2;   // constant extrinsic / td blocks get no entries at all
         for (int w = t; w < ntri + nv; w += nt) {
             int ra, rb;
             if (w < ntri) {
@@ -906,7 +986,8 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
         const int slot = alist[ka];
         const int st = c.lm_start[slot], r0 = c.lm_tmp[slot];
         const int kend = min(c.lm_nobs[slot], nres - r0 + 1);  // residual r0 + k - 1 of observation k, capped by the residual list
-        lm_row(c.res + (size_t)r0 * 42, c.Hpl + (size_t)ka * LW, c.Hll + ka, c.gl + ka, half, st, kend, 15 * W1);
+        if (vext) lm_row(c.res + (size_t)r0 * 42, c.Hpl + (size_t)ka * LW, c.Hll + ka, c.gl + ka, half, st, kend, 15 * W1);
+        else lm_row_compact(c.res + (size_t)r0 * 28, c.Hpl + (size_t)ka * LW, c.Hll + ka, c.gl + ka, half, st, kend);
     }
     __syncthreads();
     PH(37);
@@ -1146,6 +1227,8 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
     }
     __syncthreads();
     const int ex_active = sh_i[0], td_active = sh_i[1];
+    const bool vext = ex_active || td_active;   // extrinsic / td Jacobians are only evaluated when one of the blocks is a variable
+    const int ne_ext = vext ? 7 : 0;
     const int oE = 15 * W1, oT = 15 * W1 + 6;
 
     // vec slots
@@ -1158,9 +1241,9 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
     double *hsgl = c.res + (size_t)c.nres_cap * 42 - 4 * (size_t)c.NLs;   // tail of the residual buffer (nres <= nres_cap - 2 NL)
     double *yl = hsgl + c.NLs, *ul = yl + c.NLs, *tmpl = ul + c.NLs;
 
-    double cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp, work);
+    double cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp, work, vext);
     PH(4);
-    assemble(B, c, X, nres, Fa, alist, srp, work, pb, hpl_sparse);
+    assemble(B, c, X, nres, Fa, alist, srp, work, pb, hpl_sparse, vext);
     PH(5);
     if (t == 0) be.initial_cost = cost;
     // Jacobi scaling (once): 1/(1+||J_j||); constant blocks (ex / td when not estimated) get scale 0 = removed from the problem
@@ -1204,7 +1287,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
     auto compute_cauchy = [&]() {
         // Cauchy point: alpha = |grad|^2 / |J D^-1 grad|^2, and H_full * (D^-1 grad) is kept for the model evaluation
         matvec_pass(c.H, LW, P, P, nullptr, up, nullptr, tmpv, work);   // H (S sg_p): H is symmetric, row dots
-        matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, 7, ul, up, tmpv2, tmpl, work);       // Hpl^T (Sl sg_l) and Hpl (S sg_p) in one pass
+        matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, ul, up, tmpv2, tmpl, work);       // Hpl^T (Sl sg_l) and Hpl (S sg_p) in one pass
         double g2 = 0, jg2 = 0;
         for (int a = t; a < LW; a += nt) {
             double v = a < P ? sp[a] * (tmpv[a] + tmpv2[a]) : 0.0;
@@ -1231,10 +1314,10 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
         if (!reuse) {
             if (need_eval) {
                 PH(13);
-                if (!have_J) cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp, work);
+                if (!have_J) cost = evaluate(c, X, c.feat, true, nres, sred, sdx, srp, work, vext);
                 have_J = false;
                 PH(4);
-                assemble(B, c, X, nres, Fa, alist, srp, work, pb, hpl_sparse);
+                assemble(B, c, X, nres, Fa, alist, srp, work, pb, hpl_sparse, vext);
                 PH(5);
                 need_eval = false;
                 if (prepare_point() <= 1e-10) { iters_done = iter - 1; break; }
@@ -1250,7 +1333,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                     tmpl[k] = sl[k] * iv * gls[k];
                 }
                 __syncthreads();
-                matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, 7, tmpl, nullptr, tmpv, nullptr, work);  // Hpl^T (Sl gls / hll); uses the work region before S moves in
+                matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, tmpl, nullptr, tmpv, nullptr, work);  // Hpl^T (Sl gls / hll); uses the work region before S moves in
                 for (int a = t; a < LW; a += nt) xs[a] = a < P ? gs[a] - sp[a] * tmpv[a] : 0.0;
                 for (int k = t; k < Kpad; k += nt) tmpl[k] = sl[k] * sl[k] * inv[k];  // per-row factor of the rank-K update
                 __syncthreads();
@@ -1261,7 +1344,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                         unsigned colmask = 0;
                         for (int cb = 0; cb < (LW >> 4); cb++) {
                             const int c0 = 16 * cb, c1 = c0 + 15;
-                            if (c0 < 6 * W1 || (c1 >= 15 * W1 && c0 < 15 * W1 + 7)) colmask |= 1u << cb;
+                            if (c0 < 6 * W1 || (vext && c1 >= 15 * W1 && c0 < 15 * W1 + 7)) colmask |= 1u << cb;
                         }
                         if (schur_staged)
                             schur_mfma_staged<9>(c.H, c.Hpl, tmpl, dgp, sp, mu, Kpad, LW, LW, work, colmask);
@@ -1285,7 +1368,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                     if (bad == 0) {
                         for (int a = t; a < LW; a += nt) { yp[a] = xs[a]; gnp[a] = -xs[a] * dgp[a]; tmpv[a] = sp[a] * xs[a]; }
                         __syncthreads();
-                        matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, 7, nullptr, tmpv, nullptr, tmpl, nullptr);  // Hpl (S y_p)
+                        matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, nullptr, tmpv, nullptr, tmpl, nullptr);  // Hpl (S y_p)
                         for (int k = t; k < Kpad; k += nt) {
                             double y = k < Fa ? (gls[k] - sl[k] * tmpl[k]) * inv[k] : 0.0;
                             yl[k] = y;
@@ -1381,7 +1464,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
         // The candidate is evaluated WITH Jacobians (res / imu_raw / srp are only read by assemble(), which is not called again if the
         // step is rejected): an accepted point then goes straight to assemble() instead of being evaluated a second time.
         const bool cand_with_J = iter < cfg.max_iterations;
-        double ccost = evaluate(c, Xc, c.cfeat, cand_with_J, nres, sred, sdx, srp, work);
+        double ccost = evaluate(c, Xc, c.cfeat, cand_with_J, nres, sred, sdx, srp, work, vext);
         PH(12);
         // parameter tolerance
         double xn = 0, dn = 0;
