@@ -89,7 +89,15 @@ def test_yaml_keys_map_to_vio_config(P, io):
     assert y["imu_topic"] == "/imu0" and y["extrinsicRotation"].shape == (3, 3) and y["extrinsicTranslation"].shape == (3, 1)
 
 
-@pytest.mark.parametrize("line,what", [("imu: 0", "VO mode"), ("static_init: 0", "dynamic"), ("fisheye: 1", "fisheye"),
+def test_static_init_zero_selects_the_dynamic_initialisation(P, io):
+    """static_init: 0 (config/realsense/vio_campus.yaml:10, openloris_vio.yaml:10) -> vio_config.dynamic_init = 1 (parameters.cpp:167)"""
+    txt = "\n".join(l for l in YAML.splitlines() if not l.startswith("static_init:")) + "\nstatic_init: 0\n"
+    cfg, extra = io.config_from_yaml(txt, P)
+    assert cfg.dynamic_init == 1 and extra["notes"] == []
+    assert io.config_from_yaml(YAML, P)[0].dynamic_init == 0
+
+
+@pytest.mark.parametrize("line,what", [("imu: 0", "VO mode"), ("fisheye: 1", "fisheye"),
                                        ("equalize: 1", "CLAHE"), ("estimate_extrinsic: 2", "extrinsic")])
 def test_out_of_scope_settings_fail_loudly(P, io, line, what):
     key = line.split(":")[0]

@@ -179,6 +179,114 @@ __device__ void lm_compact(Ctx &c, int *flags, int *offs, int *scratch) {
 
 }  // namespace
 
+// FeatureManager::triangulateWithDepth (feature_manager.cpp:386-543), one thread per landmark of the list
+__device__ void triangulate_with_depth(Ctx &c, int nlm) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    BeSeq &be = *c.be;
+    const vio_config &cfg = c.C->c;
+        m3 ric = ldm(be.ric);
+        v3 tic = ld3(be.tic);
+        for (int k = t; k < nlm; k += nt) {
+            int slot = c.lm_order[k];
+            if (c.lm_depth[slot] > 0) continue;
+            if (!in_problem(c, slot)) continue;
+            int imu_i = c.lm_start[slot], K = c.lm_nobs[slot];
+            v3 trr = add(ld3(be.Ps[imu_i]), mul(ldm(be.Rs[imu_i]), tic));
+            m3 Rr = mul(ldm(be.Rs[imu_i]), ric);
+            double vsum = 0, rsum = 0;
+            int vn = 0, rn = 0, no_depth = 0;
+            for (int a = 0; a < K; a++) {
+                const double *oa = obs_ptr(c, slot, imu_i + a);
+                if (oa[8] == 0) { no_depth++; continue; }
+                v3 t0 = add(ld3(be.Ps[imu_i + a]), mul(ldm(be.Rs[imu_i + a]), tic));
+                m3 R0 = mul(ldm(be.Rs[imu_i + a]), ric);
+                v3 point0 = scl(oa[8], mk(oa[0], oa[1], oa[2]));
+                point0 = mk(oa[0] * oa[8], oa[1] * oa[8], oa[2] * oa[8]);
+                v3 t2r = mul(tr(Rr), sub(t0, trr));
+                m3 R2r = mul(tr(Rr), R0);
+                for (int b = 0; b < K; b++) {
+                    if (a == b) continue;
+                    const double *ob = obs_ptr(c, slot, imu_i + b);
+                    v3 t1 = add(ld3(be.Ps[imu_i + b]), mul(ldm(be.Rs[imu_i + b]), tic));
+                    m3 R1 = mul(ldm(be.Rs[imu_i + b]), ric);
+                    v3 t20 = mul(tr(R0), sub(t1, t0));
+                    m3 R20 = mul(tr(R0), R1);
+                    v3 pp = sub(mul(tr(R20), point0), mul(tr(R20), t20));
+                    double rx = ob[0] - pp.x / pp.z, ry = ob[1] - pp.y / pp.z;
+                    if (sqrt(rx * rx + ry * ry) < 10.0 / 460) {
+                        v3 pr = add(mul(R2r, point0), t2r);
+                        if (oa[8] > cfg.depth_max) { rsum += pr.z; rn++; } else { vsum += pr.z; vn++; }
+                    }
+                }
+            }
+            double dep;
+            int ef;
+            if (vn == 0) {
+                if (rn == 0) {
+                    if (no_depth == K) {
+                        double AtA[16], Vv[16];
+                        for (int q = 0; q < 16; q++) AtA[q] = 0;
+                        v3 t0 = add(ld3(be.Ps[imu_i]), mul(ldm(be.Rs[imu_i]), tic));
+                        m3 R0 = mul(ldm(be.Rs[imu_i]), ric);
+                        for (int a = 0; a < K; a++) {
+                            const double *oa = obs_ptr(c, slot, imu_i + a);
+                            v3 t1 = add(ld3(be.Ps[imu_i + a]), mul(ldm(be.Rs[imu_i + a]), tic));
+                            m3 R1 = mul(ldm(be.Rs[imu_i + a]), ric);
+                            v3 tt = mul(tr(R0), sub(t1, t0));
+                            m3 Rt = tr(mul(tr(R0), R1));
+                            v3 mt = neg(mul(Rt, tt));
+                            double Pm[12];
+                            for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) Pm[r * 4 + q] = Rt.a[r * 3 + q]; Pm[r * 4 + 3] = get(mt, r); }
+                            v3 f = mk(oa[0], oa[1], oa[2]);
+                            f = scl(1.0 / nrm(f), f);
+                            f = mk(oa[0] / nrm(mk(oa[0], oa[1], oa[2])), oa[1] / nrm(mk(oa[0], oa[1], oa[2])), oa[2] / nrm(mk(oa[0], oa[1], oa[2])));
+                            double row[8];
+                            for (int q = 0; q < 4; q++) { row[q] = f.x * Pm[8 + q] - f.z * Pm[q]; row[4 + q] = f.y * Pm[8 + q] - f.z * Pm[4 + q]; }
+                            for (int rr = 0; rr < 2; rr++)
+                                for (int x = 0; x < 4; x++) for (int y = 0; y < 4; y++) AtA[x * 4 + y] += row[rr * 4 + x] * row[rr * 4 + y];
+                        }
+                        jacobi_small(AtA, Vv, 4);
+                        int mi = 0;
+                        for (int q = 1; q < 4; q++) if (AtA[q * 5] < AtA[mi * 5]) mi = q;
+                        double svd_method = Vv[2 * 4 + mi] / Vv[3 * 4 + mi];
+                        dep = svd_method < cfg.depth_min ? cfg.depth_max : svd_method;
+                        ef = 2;
+                    } else
+                        continue;
+                } else { dep = rsum / rn; ef = 0; }
+            } else { dep = vsum / vn; ef = 1; }
+            if (dep < 0.1) { dep = cfg.init_depth; ef = 0; }
+            c.lm_depth[slot] = dep;
+            c.lm_est[slot] = ef;
+        }
+}
+
+// pre_integrations[j]->repropagate(Vector3d::Zero(), Bgs[j]) for every window slot (estimator.cpp:275-279, :829-836), block-cooperative
+__device__ void repropagate_window(Ctx &c, PreWork &pw) {
+    const int t = threadIdx.x, nt = blockDim.x, W = c.W;
+    BeSeq &be = *c.be;
+    const vio_config &cfg = c.C->c;
+    for (int j = 0; j <= W; j++) {
+            PreInt &p = c.pre[be.pre_idx[j]];
+            if (!p.valid) continue;
+            if (t == 0) {
+                int nb = p.n_buf;
+                v3 la = ld3(p.lin_acc), lg = ld3(p.lin_gyr);
+                p.sum_dt = 0;
+                st3(p.acc0, la); st3(p.gyr0, lg);
+                p.dp[0] = p.dp[1] = p.dp[2] = 0; p.dv[0] = p.dv[1] = p.dv[2] = 0;
+                p.dq[0] = 1; p.dq[1] = p.dq[2] = p.dq[3] = 0;
+                p.lin_ba[0] = p.lin_ba[1] = p.lin_ba[2] = 0;
+                st3(p.lin_bg, ld3(be.Bgs[j]));
+                p.n_buf = nb;
+            }
+            for (int i = t; i < 225; i += nt) { pw.J[i] = ((i / 15) == (i % 15)) ? 1.0 : 0.0; pw.Pm[i] = 0; }
+            __syncthreads();
+            for (int q = 0; q < p.n_buf; q++) preint_propagate(p, pw, cfg, p.dt_buf[q], ld3(p.acc_buf[q]), ld3(p.gyr_buf[q]));
+            preint_store(p, pw);
+        }
+}
+
 // ====================================================================================================== be_ingest
 // src.ids == NULL: the feature map packaged by the last vio_track / front-end of vio_feed (B.obs_id / B.obs / FeSeq);
 // otherwise a caller-supplied map (vio_process_obs = Estimator::processImage(image, header), estimator.h:46): n_obs[s] < 0 skips s.
@@ -199,7 +307,7 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
     const int ext_n = ext ? src.n_obs[s] : 0;
     const double in_stamp = ext ? src.stamps[s] : fe.cur_time;
     if (t == 0) {
-        be.do_solve = 0; be.do_marg = 0; be.processed = 0; be.rebooted = 0;
+        be.do_solve = 0; be.do_marg = 0; be.processed = 0; be.rebooted = 0; be.init_frame = 0; be.dyn_failed = 0;
         be.status_code = (!ext && fe.n_forw == -2) ? VIO_NEED_IMU : VIO_OK;
         be.cur_stamp = in_stamp;
         be.overflow = 0;
@@ -335,6 +443,7 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
         sh_i[1] = k - head + 1;  // number of samples incl. the first one with t >= curTime
         be.imu_head = k;         // that last sample is not popped
         be.n_imu_frame = sh_i[1];
+        be.imu_frame_head = head;
         if (!be.initFirstPoseFlag) {  // initFirstIMUPose :1890-1909
             v3 aver = mk(0, 0, 0);
             for (int q = 0; q < sh_i[1]; q++) aver = add(aver, ld3(ia + (size_t)((head + q) % C.NIMU) * 3));
@@ -395,90 +504,15 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
         if (t == 0) be.prevTime = curTime;
         __syncthreads();
     }
-    // ---- triangulateWithDepth (feature_manager.cpp:386-543), one thread per landmark
-    {
-        m3 ric = ldm(be.ric);
-        v3 tic = ld3(be.tic);
-        for (int k = t; k < nlm; k += nt) {
-            int slot = c.lm_order[k];
-            if (c.lm_depth[slot] > 0) continue;
-            if (!in_problem(c, slot)) continue;
-            int imu_i = c.lm_start[slot], K = c.lm_nobs[slot];
-            v3 trr = add(ld3(be.Ps[imu_i]), mul(ldm(be.Rs[imu_i]), tic));
-            m3 Rr = mul(ldm(be.Rs[imu_i]), ric);
-            double vsum = 0, rsum = 0;
-            int vn = 0, rn = 0, no_depth = 0;
-            for (int a = 0; a < K; a++) {
-                const double *oa = obs_ptr(c, slot, imu_i + a);
-                if (oa[8] == 0) { no_depth++; continue; }
-                v3 t0 = add(ld3(be.Ps[imu_i + a]), mul(ldm(be.Rs[imu_i + a]), tic));
-                m3 R0 = mul(ldm(be.Rs[imu_i + a]), ric);
-                v3 point0 = scl(oa[8], mk(oa[0], oa[1], oa[2]));
-                point0 = mk(oa[0] * oa[8], oa[1] * oa[8], oa[2] * oa[8]);
-                v3 t2r = mul(tr(Rr), sub(t0, trr));
-                m3 R2r = mul(tr(Rr), R0);
-                for (int b = 0; b < K; b++) {
-                    if (a == b) continue;
-                    const double *ob = obs_ptr(c, slot, imu_i + b);
-                    v3 t1 = add(ld3(be.Ps[imu_i + b]), mul(ldm(be.Rs[imu_i + b]), tic));
-                    m3 R1 = mul(ldm(be.Rs[imu_i + b]), ric);
-                    v3 t20 = mul(tr(R0), sub(t1, t0));
-                    m3 R20 = mul(tr(R0), R1);
-                    v3 pp = sub(mul(tr(R20), point0), mul(tr(R20), t20));
-                    double rx = ob[0] - pp.x / pp.z, ry = ob[1] - pp.y / pp.z;
-                    if (sqrt(rx * rx + ry * ry) < 10.0 / 460) {
-                        v3 pr = add(mul(R2r, point0), t2r);
-                        if (oa[8] > cfg.depth_max) { rsum += pr.z; rn++; } else { vsum += pr.z; vn++; }
-                    }
-                }
-            }
-            double dep;
-            int ef;
-            if (vn == 0) {
-                if (rn == 0) {
-                    if (no_depth == K) {
-                        double AtA[16], Vv[16];
-                        for (int q = 0; q < 16; q++) AtA[q] = 0;
-                        v3 t0 = add(ld3(be.Ps[imu_i]), mul(ldm(be.Rs[imu_i]), tic));
-                        m3 R0 = mul(ldm(be.Rs[imu_i]), ric);
-                        for (int a = 0; a < K; a++) {
-                            const double *oa = obs_ptr(c, slot, imu_i + a);
-                            v3 t1 = add(ld3(be.Ps[imu_i + a]), mul(ldm(be.Rs[imu_i + a]), tic));
-                            m3 R1 = mul(ldm(be.Rs[imu_i + a]), ric);
-                            v3 tt = mul(tr(R0), sub(t1, t0));
-                            m3 Rt = tr(mul(tr(R0), R1));
-                            v3 mt = neg(mul(Rt, tt));
-                            double Pm[12];
-                            for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) Pm[r * 4 + q] = Rt.a[r * 3 + q]; Pm[r * 4 + 3] = get(mt, r); }
-                            v3 f = mk(oa[0], oa[1], oa[2]);
-                            f = scl(1.0 / nrm(f), f);
-                            f = mk(oa[0] / nrm(mk(oa[0], oa[1], oa[2])), oa[1] / nrm(mk(oa[0], oa[1], oa[2])), oa[2] / nrm(mk(oa[0], oa[1], oa[2])));
-                            double row[8];
-                            for (int q = 0; q < 4; q++) { row[q] = f.x * Pm[8 + q] - f.z * Pm[q]; row[4 + q] = f.y * Pm[8 + q] - f.z * Pm[4 + q]; }
-                            for (int rr = 0; rr < 2; rr++)
-                                for (int x = 0; x < 4; x++) for (int y = 0; y < 4; y++) AtA[x * 4 + y] += row[rr * 4 + x] * row[rr * 4 + y];
-                        }
-                        jacobi_small(AtA, Vv, 4);
-                        int mi = 0;
-                        for (int q = 1; q < 4; q++) if (AtA[q * 5] < AtA[mi * 5]) mi = q;
-                        double svd_method = Vv[2 * 4 + mi] / Vv[3 * 4 + mi];
-                        dep = svd_method < cfg.depth_min ? cfg.depth_max : svd_method;
-                        ef = 2;
-                    } else
-                        continue;
-                } else { dep = rsum / rn; ef = 0; }
-            } else { dep = vsum / vn; ef = 1; }
-            if (dep < 0.1) { dep = cfg.init_depth; ef = 0; }
-            c.lm_depth[slot] = dep;
-            c.lm_est[slot] = ef;
-        }
-    }
+    // ---- triangulateWithDepth (feature_manager.cpp:386-543); the dynamic initialisation triangulates after its SfM instead (estimator.cpp:921-933)
+    if (!(cfg.dynamic_init && be.solver_flag == 0)) triangulate_with_depth(c, nlm);
     __syncthreads();
     if (t == 0) {
         be.processed = 1;
         be.frames_processed++;
         if (be.solver_flag == 0) {
-            if (fc == W) { be.do_solve = 1; be.do_marg = 1; }
+            // static initialisation solves once the window is full; the dynamic one is decided by the host (vio_abi.hip run_dynamic_init)
+            if (fc == W && !cfg.dynamic_init) { be.do_solve = 1; be.do_marg = 1; }
         } else { be.do_solve = 1; be.do_marg = 1; }
     }
 }
@@ -1092,25 +1126,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
             for (int i = 0; i <= W; i++) { be.Bgs[i][0] += x[0]; be.Bgs[i][1] += x[1]; be.Bgs[i][2] += x[2]; }
         }
         __syncthreads();
-        for (int j = 0; j <= W; j++) {  // pre_integrations[j]->repropagate(Vector3d::Zero(), Bgs[j])
-            PreInt &p = c.pre[be.pre_idx[j]];
-            if (!p.valid) continue;
-            if (t == 0) {
-                int nb = p.n_buf;
-                v3 la = ld3(p.lin_acc), lg = ld3(p.lin_gyr);
-                p.sum_dt = 0;
-                st3(p.acc0, la); st3(p.gyr0, lg);
-                p.dp[0] = p.dp[1] = p.dp[2] = 0; p.dv[0] = p.dv[1] = p.dv[2] = 0;
-                p.dq[0] = 1; p.dq[1] = p.dq[2] = p.dq[3] = 0;
-                p.lin_ba[0] = p.lin_ba[1] = p.lin_ba[2] = 0;
-                st3(p.lin_bg, ld3(be.Bgs[j]));
-                p.n_buf = nb;
-            }
-            for (int i = t; i < 225; i += nt) { pw.J[i] = ((i / 15) == (i % 15)) ? 1.0 : 0.0; pw.Pm[i] = 0; }
-            __syncthreads();
-            for (int q = 0; q < p.n_buf; q++) preint_propagate(p, pw, cfg, p.dt_buf[q], ld3(p.acc_buf[q]), ld3(p.gyr_buf[q]));
-            preint_store(p, pw);
-        }
+        repropagate_window(c, pw);
     }
 
     // ---- vector2double (estimator.cpp:936-981)
@@ -1551,7 +1567,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
     // after optimization() (solve + marginalisation) and throws the whole state away when it fires, so nothing the marginalisation
     // produces survives a reboot: it is decided HERE, before the host records ev_solve, because the reset rewrites imu_head / td /
     // ric / latest_Bg, which the next frame's front-end (fe_begin) and the IMU scatter kernel read as soon as this kernel is done.
-    if (be.solver_flag == 1) {
+    if (be.solver_flag == 1 && !be.init_frame) {
         if (t == 0) {
             int fail = 0;
             if (nrm(ld3(be.Bas[W])) > 2.5) fail = 1;
@@ -2057,7 +2073,15 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
     const int fc = be.frame_count;
     const int sflag0 = be.solver_flag;
     __syncthreads();
-    if (sflag0 == 0) {
+    // dynamic initialisation (static_init: 0, estimator.cpp:230-259): while INITIAL the frame counter just advances; with a full
+    // window and no (successful) attempt the window slides with INITIAL semantics (removeBack, no depth transfer)
+    const bool dyn_initial = sflag0 == 0 && cfg.dynamic_init;
+    if (dyn_initial) {
+        if (fc < W) {
+            if (t == 0) be.frame_count = fc + 1;
+            return;
+        }
+    } else if (sflag0 == 0) {
         if (fc == W && be.do_solve) {
             if (t == 0) be.solver_flag = 1;
             __syncthreads();
@@ -2071,8 +2095,8 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
             }
             return;
         }
-    } else {
-        // movingConsistencyCheck (estimator.cpp:1965-2009)
+    } else if (!be.init_frame) {
+        // movingConsistencyCheck (estimator.cpp:1965-2009); not on the frame that completed the dynamic initialisation (:243-251)
         m3 ric = ldm(be.ric);
         v3 tic = ld3(be.tic);
         for (int k = t; k < nlm; k += nt) {
@@ -2130,7 +2154,8 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
                 v3 uv_i = mk(o0[0], o0[1], o0[2]);
                 int no = c.lm_nobs[slot] - 1;
                 c.lm_nobs[slot] = no;
-                if (no < 2) keep = 0;
+                if (dyn_initial) keep = no > 0;     // FeatureManager::removeBack (feature_manager.cpp:693-708): solver_flag == INITIAL
+                else if (no < 2) keep = 0;
                 else {
                     v3 pts_i = scl(c.lm_depth[slot], uv_i);
                     v3 w_pts_i = add(mul(R0, pts_i), P0);
@@ -2194,7 +2219,8 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
         __syncthreads();
         lm_compact(c, flag, offs, scratch);
     }
-    // ---- removeFailures (feature_manager.cpp:225-233); not called on the initialisation frame (estimator.cpp:282-290)
+    if (dyn_initial) return;   // still INITIAL: nothing to publish
+    // ---- removeFailures (feature_manager.cpp:225-233); not called on the STATIC initialisation frame (estimator.cpp:282-290)
     if (sflag0 == 1) {
         nlm = be.n_lm;
         for (int k = t; k < nlm; k += nt) flag[k] = c.lm_solve[c.lm_order[k]] == 2 ? 0 : 1;
@@ -2216,6 +2242,18 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
         B.odom_count[s] = hc + 1;
         if (be.overflow) be.overflow_frames++;
     }
+}
+
+// ====================================================================================================== dynamic init hand-over
+// After a successful host-side initialStructure (dyninit_host.cpp) the host has written Ps / Rs / Vs / Bgs / Bas / g of sequence
+// `seq`: re-propagate the window pre-integrations at the new gyroscope bias (estimator.cpp:829-836) and triangulate with the new
+// poses (solveOdometry -> triangulateWithDepth, :921-933).  The regular be_solve / be_marg launches follow.
+__global__ __launch_bounds__(256) void be_dyn_finalize_kernel(Batch B, int seq) {
+    __shared__ PreWork pw;
+    Ctx c = make_ctx(B, seq);
+    repropagate_window(c, pw);
+    __syncthreads();
+    triangulate_with_depth(c, c.be->n_lm);
 }
 
 // ====================================================================================================== stage tests

@@ -8,6 +8,7 @@
 #include <string.h>
 #include <vector>
 #include "kernels.h"
+#include "dyninit_host.h"
 
 namespace {
 
@@ -63,6 +64,19 @@ struct vio_batch {
     int *d_in_n = nullptr, *d_in_ids = nullptr;
     double *d_in_obs = nullptr, *d_in_stamps = nullptr;
     double *d_r9 = nullptr;           // vio_predict_motion result
+    // ---- dynamic initialisation (static_init: 0): host mirror of Estimator::all_image_frame per sequence while it is INITIAL
+    struct DynSeq {
+        std::vector<vinit::ImageFrame> frames;
+        double initial_timestamp = 0;
+        bool nonlinear = false;       // host view of solver_flag (refreshed from h_state)
+        int attempts = 0, failures = 0, last_stage = 0;
+    };
+    std::vector<DynSeq> dyn;          // [S], only used when cfg.dynamic_init
+    bool dyn_active = false;          // some sequence is still INITIAL: the back-end runs in two halves with the host in between
+    int *h_state = nullptr;           // pinned [S]: solver_flag of every sequence after the last be_solve (async copy per frame)
+    int *d_state = nullptr;
+    hipEvent_t ev_state = nullptr;
+    bool state_pending = false;
     // pending IMU samples (host staging)
     std::mutex imu_mu;
     std::vector<int> p_seq;
@@ -186,6 +200,7 @@ int init_state(vio_batch *h, int s_lo, int s_hi) {
     HIPCHK(hipMemset(h->B.odom + (size_t)s_lo * 11, 0, sizeof(double) * (size_t)n * 11));
     HIPCHK(hipMemset(h->B.odom_count + s_lo, 0, sizeof(int) * (size_t)n));
     {
+        if (!h->dyn.empty()) { for (int s = s_lo; s < s_hi; s++) h->dyn[s] = vio_batch::DynSeq(); h->dyn_active = true; h->state_pending = false; }
         // Estimator::clearState() empties imu_buf: drop what is still staged on the host for these sequences
         std::lock_guard<std::mutex> lk(h->imu_mu);
         for (int s = s_lo; s < s_hi; s++) h->last_imu_t[s] = -1e300;
@@ -331,6 +346,122 @@ int launch_frontend(vio_batch *h, vio_batch::Group &g, const uint8_t *d_gray, in
     HIPCHK(hipGetLastError());
     return VIO_OK;
 }
+__global__ void state_gather_kernel(Batch B, int *state) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < B.S) state[s] = B.be[s].solver_flag;
+}
+
+// Host half of the dynamic initialisation for sequence s, called with the group's stream drained right after be_ingest: mirrors
+// Estimator::all_image_frame (estimator.cpp:203-206), runs initialStructure when the window is full (:230-259) and hands the result
+// to the device.  Returns through `finalize` whether be_dyn_finalize_kernel has to run for the sequence.
+int dynamic_init_step(vio_batch *h, int s, const IngestSrc &src, bool *finalize) {
+    *finalize = false;
+    const DevCfg &C = h->hc;
+    const int W = C.W, W1 = W + 1, NL = C.NL, NP = C.NP;
+    vio_batch::DynSeq &D = h->dyn[s];
+    static thread_local BeSeq be;
+    HIPCHK(hipMemcpy(&be, h->B.be + s, sizeof(BeSeq), hipMemcpyDeviceToHost));
+    if (be.solver_flag != 0) { D.nonlinear = true; return VIO_OK; }
+    if (D.nonlinear) { D = vio_batch::DynSeq(); h->dyn_active = true; }   // rebooted: clearState() dropped all_image_frame
+    if (!be.processed) return VIO_OK;
+    const int fc = be.frame_count;
+    // ---- the image frame just ingested: feature points + the pre-integration of its interval (tmp_pre_integration)
+    {
+        vinit::ImageFrame f;
+        f.stamp = be.cur_stamp;
+        int n = 0;
+        const int *d_ids;
+        const double *d_obs;
+        if (src.ids) {
+            HIPCHK(hipMemcpy(&n, src.n_obs + s, sizeof(int), hipMemcpyDeviceToHost));
+            d_ids = src.ids + (size_t)s * src.cap; d_obs = src.obs + (size_t)s * src.cap * 7;
+        } else {
+            static thread_local FeSeq fe;
+            HIPCHK(hipMemcpy(&fe, h->B.fe + s, sizeof(FeSeq), hipMemcpyDeviceToHost));
+            n = fe.n_obs;
+            d_ids = h->B.obs_id + (size_t)s * NP; d_obs = h->B.obs + (size_t)s * NP * 7;
+        }
+        n = std::max(0, std::min(n, NP));
+        std::vector<double> o((size_t)n * 7);
+        f.ids.resize(n);
+        if (n > 0) {
+            HIPCHK(hipMemcpy(f.ids.data(), d_ids, sizeof(int) * n, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(o.data(), d_obs, sizeof(double) * 7 * n, hipMemcpyDeviceToHost));
+        }
+        f.xy.resize((size_t)2 * n);
+        for (int k = 0; k < n; k++) { f.xy[2 * k] = o[7 * k]; f.xy[2 * k + 1] = o[7 * k + 1]; }
+        static thread_local PreInt p;
+        HIPCHK(hipMemcpy(&p, h->B.pre + (size_t)s * (W + 2) + be.pre_idx[fc], sizeof(PreInt), hipMemcpyDeviceToHost));
+        if (p.valid && fc != 0) {
+            for (int k = 0; k < 3; k++) { f.lin_acc[k] = p.lin_acc[k]; f.lin_gyr[k] = p.lin_gyr[k]; }
+            f.dt.assign(p.dt_buf, p.dt_buf + p.n_buf);
+            f.acc.resize((size_t)3 * p.n_buf); f.gyr.resize((size_t)3 * p.n_buf);
+            for (int k = 0; k < p.n_buf; k++) for (int q = 0; q < 3; q++) { f.acc[3 * k + q] = p.acc_buf[k][q]; f.gyr[3 * k + q] = p.gyr_buf[k][q]; }
+        }
+        for (int k = 0; k < 3; k++) f.bg_lin[k] = be.Bgs[fc][k];
+        D.frames.push_back(std::move(f));
+    }
+    if (fc < W) return VIO_OK;
+    // ---- window full: attempt (estimator.cpp:232-240), at most every 0.1 s
+    bool changed = false;
+    vinit::Result res;
+    if (be.cur_stamp - D.initial_timestamp > 0.1) {
+        D.attempts++;
+        std::vector<int> order(NL), id(NL), st(NL), no(NL);
+        const size_t o = (size_t)s * NL;
+        HIPCHK(hipMemcpy(order.data(), h->B.lm_order + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(id.data(), h->B.lm_id + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(st.data(), h->B.lm_start + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(no.data(), h->B.lm_nobs + o, sizeof(int) * NL, hipMemcpyDeviceToHost));
+        std::vector<double> obs((size_t)NL * W1 * VIO_OBS_D);
+        HIPCHK(hipMemcpy(obs.data(), h->B.lm_obs + o * W1 * VIO_OBS_D, sizeof(double) * obs.size(), hipMemcpyDeviceToHost));
+        std::vector<vinit::Landmark> lms((size_t)be.n_lm);
+        for (int k = 0; k < be.n_lm; k++) {
+            const int slot = order[k];
+            lms[k].id = id[slot]; lms[k].start = st[slot];
+            lms[k].obs.resize(no[slot]);
+            for (int a = 0; a < no[slot]; a++) {
+                const double *q = &obs[((size_t)slot * W1 + (st[slot] + a + be.ring_base) % W1) * VIO_OBS_D];
+                lms[k].obs[a] = {q[0], q[1], q[8]};
+            }
+        }
+        vinit::run(C.c, W, be.Headers, be.Bgs[0], be.ric, be.tic, D.frames, lms, res);
+        D.last_stage = res.stage;
+        if (!res.ok) D.failures++;
+        D.initial_timestamp = be.cur_stamp;
+        if (res.ok || res.stage == 4) {   // solveGyroscopeBias already moved Bgs when the alignment rejects the attempt
+            for (int i = 0; i <= W; i++) for (int k = 0; k < 3; k++) be.Bgs[i][k] += res.delta_bg[k];
+            changed = true;
+        }
+        if (res.force_margin_old) { be.marginalization_flag = 0; changed = true; }
+    }
+    if (res.ok) {
+        for (int i = 0; i <= W; i++) {
+            for (int k = 0; k < 3; k++) { be.Ps[i][k] = res.Ps[i][k]; be.Vs[i][k] = res.Vs[i][k]; if (res.set_ba) be.Bas[i][k] = res.Ba[k]; }
+            for (int k = 0; k < 9; k++) be.Rs[i][k] = res.Rs[i][k];
+        }
+        for (int k = 0; k < 3; k++) be.g[k] = res.g[k];
+        be.solver_flag = 1; be.init_frame = 1; be.do_solve = 1; be.do_marg = 1;
+        D.frames.clear();
+        D.nonlinear = true;
+        *finalize = true;
+        changed = true;
+    } else {
+        be.dyn_failed = 1;
+        changed = true;
+        if (be.marginalization_flag == 0) {   // slideWindow(MARGIN_OLD) drops every image frame up to the old frame 0 (estimator.cpp:1632-1650)
+            const double t0 = be.Headers[0];
+            size_t k = 0;
+            while (k < D.frames.size() && D.frames[k].stamp <= t0) k++;
+            bool found = false;
+            for (const auto &f : D.frames) if (f.stamp == t0) found = true;
+            if (found) D.frames.erase(D.frames.begin(), D.frames.begin() + k);
+        }
+    }
+    if (changed) HIPCHK(hipMemcpy(h->B.be + s, &be, sizeof(BeSeq), hipMemcpyHostToDevice));
+    return VIO_OK;
+}
+
 // one_seq >= 0: only that sequence (vio_process_obs), otherwise every sequence of the group
 int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, const IngestSrc &src, int one_seq = -1) {
     const DevCfg &C = h->hc;
@@ -342,15 +473,55 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
     if (prof) PEV(h, 8);
     be_ingest_kernel<<<S, 256, (size_t)C.lm_hash_size * 8, st>>>(Bg, d_depth, (size_t)C.c.width * C.c.height, src);
     if (prof) PEV(h, 9);
+    if (h->dyn_active || (C.c.dynamic_init && one_seq >= 0)) {
+        // some sequence of this handle is still INITIAL under static_init: 0: the host collects its image frame / runs the
+        // initialisation between the two halves of the back-end (once per sequence; the steady state below never synchronises)
+        HIPCHK(hipStreamSynchronize(st));
+        for (int s = Bg.s0; s < Bg.s0 + S; s++) {
+            if (h->dyn[s].nonlinear && one_seq < 0) continue;
+            bool fin = false;
+            int rc = dynamic_init_step(h, s, src, &fin);
+            if (rc != VIO_OK) return rc;
+            if (fin) be_dyn_finalize_kernel<<<1, 256, 0, st>>>(h->B, s);
+        }
+        bool any = false;
+        for (int s = 0; s < h->S; s++) any = any || !h->dyn[s].nonlinear;
+        h->dyn_active = any;
+    }
     const int be_threads = h->be_threads;
     if (be_threads <= 512) be_solve_kernel_512<<<S, be_threads, h->lds_solve, st>>>(Bg);
     else be_solve_kernel<<<S, be_threads, h->lds_solve, st>>>(Bg);
     if (prof) PEV(h, 10);
     (void)hipEventRecord(g.ev_solve, st);  // the next frame's front-end may start here (it only needs latest_Bg / td / imu_head, and a
     g.have_solve_ev = true;                // reboot - which rewrites them - is decided at the end of be_solve)
+    if (C.c.dynamic_init && one_seq < 0 && &g == &h->groups.back()) {
+        // the host must learn about reboots (a rebooted sequence is INITIAL again and needs its image frames collected from its very
+        // next frame): solver flags after this solve travel to pinned memory and are looked at when the next frame is fed
+        state_gather_kernel<<<(h->S + 255) / 256, 256, 0, st>>>(h->B, h->d_state);
+        HIPCHK(hipMemcpyAsync(h->h_state, h->d_state, sizeof(int) * h->S, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(h->ev_state, st));
+        h->state_pending = true;
+    }
     be_marg_kernel<<<S, h->marg_threads, h->lds_marg, st>>>(Bg);  // marginalisation + window slide (be_finish is fused into it)
     if (prof) PEV(h, 11);
     HIPCHK(hipGetLastError());
+    return VIO_OK;
+}
+
+// dynamic initialisation: before a frame is fed, pick up the solver flags of the previous one (see launch_backend)
+int refresh_dynamic_state(vio_batch *h) {
+    if (!h->hc.c.dynamic_init) return VIO_OK;
+    if (h->state_pending) {
+        HIPCHK(hipEventSynchronize(h->ev_state));
+        h->state_pending = false;
+        bool any = false;
+        for (int s = 0; s < h->S; s++) {
+            if (h->h_state[s] == 0 && h->dyn[s].nonlinear) h->dyn[s] = vio_batch::DynSeq();   // rebooted
+            if (h->h_state[s] != 0) h->dyn[s].nonlinear = true;
+            any = any || !h->dyn[s].nonlinear;
+        }
+        h->dyn_active = any;
+    }
     return VIO_OK;
 }
 
@@ -394,7 +565,7 @@ static int build_devcfg(const vio_config *cfg, int imu_capacity, DevCfg &C) {
     const vio_config &c = C.c;
     if (c.width < 64 || c.height < 64 || c.width > 4095 || c.height > 4095) { g_err = "image size out of range"; return VIO_EINVAL; }
     if (c.window_size < 4 || c.window_size > VIO_MAXW) { g_err = "window_size must be 4..20"; return VIO_EINVAL; }
-    if (c.dynamic_init != 0) { g_err = "dynamic_init (static_init: 0) is not built yet"; return VIO_EINVAL; }
+    if (c.dynamic_init < 0 || c.dynamic_init > 1) { g_err = "dynamic_init must be 0 or 1"; return VIO_EINVAL; }
     if (c.grid_rows < 1 || c.grid_cols < 1 || c.grid_rows * c.grid_cols > VIO_MAX_CELLS) { g_err = "too many grid cells"; return VIO_EINVAL; }
     if (c.min_dist < 1 || c.min_dist > 63) { g_err = "min_dist must be 1..63"; return VIO_EINVAL; }
     if (c.lk_max_level < 0 || c.lk_max_level > 3) { g_err = "lk_max_level must be 0..3"; return VIO_EINVAL; }
@@ -496,6 +667,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
         // the runtime has a hardware queue per stream (GPU_MAX_HW_QUEUES >= 2 x groups, default 4): measured +1.7 % at 8 groups.
         int per = getenv("VIO_GROUP_SEQS") ? atoi(getenv("VIO_GROUP_SEQS")) : n_seq;
         if (per < 1) per = 1;
+        if (C.c.dynamic_init) per = n_seq;   // the host half of the dynamic initialisation looks at one solver-flag snapshot per frame
         int ng = (n_seq + per - 1) / per;
         if (ng > 16) { ng = 16; per = (n_seq + ng - 1) / ng; ng = (n_seq + per - 1) / per; }
         h->groups.resize(ng);
@@ -509,6 +681,12 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
         }
         if (rc == VIO_OK) { h->stream = h->groups[0].stream; h->fe_stream = h->groups[0].fe_stream; }
         if (rc == VIO_OK && hipEventCreateWithFlags(&h->ev_imu, hipEventDisableTiming) != hipSuccess) { g_err = "event create failed"; rc = VIO_EDEVICE; }
+    }
+    if (rc == VIO_OK && C.c.dynamic_init) {
+        h->dyn.assign(n_seq, vio_batch::DynSeq());
+        h->dyn_active = true;
+        if (hipHostMalloc((void **)&h->h_state, sizeof(int) * n_seq, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&h->d_state, sizeof(int) * n_seq) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_state, hipEventDisableTiming) != hipSuccess) { g_err = "dynamic-init state allocation failed"; rc = VIO_EDEVICE; }
     }
     for (int i = 0; i < 4 && rc == VIO_OK; i++)
         if (hipEventCreate(&h->ev[i]) != hipSuccess) { g_err = "event create failed"; rc = VIO_EDEVICE; }
@@ -568,6 +746,9 @@ void vio_destroy(vio_batch *h) {
         if (sg.done) (void)hipEventDestroy(sg.done);
     }
     if (h->ev_imu) (void)hipEventDestroy(h->ev_imu);
+    if (h->ev_state) (void)hipEventDestroy(h->ev_state);
+    if (h->h_state) (void)hipHostFree(h->h_state);
+    if (h->d_state) (void)hipFree(h->d_state);
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
     for (auto &g : h->groups) {
         if (g.stream) (void)hipStreamDestroy(g.stream);
@@ -647,7 +828,9 @@ static int stage_side_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *m
 
 int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, const uint8_t *modes, int on_device) {
     if (!h || !gray || !depth_mm || !stamps) return VIO_EINVAL;
-    int rc = flush_imu_frontend(h);
+    int rc = refresh_dynamic_state(h);
+    if (rc != VIO_OK) return rc;
+    rc = flush_imu_frontend(h);
     if (rc != VIO_OK) return rc;
     for (auto &g : h->groups) {
         if ((rc = fe_wait(g)) != VIO_OK) return rc;
@@ -717,7 +900,9 @@ int vio_predict_motion(vio_batch *h, int seq, double t0, double t1, double *R9) 
 
 int vio_process(vio_batch *h, const uint16_t *depth_mm, int on_device) {
     if (!h || !depth_mm) return VIO_EINVAL;
-    int rc = flush_imu_backend(h);
+    int rc = refresh_dynamic_state(h);
+    if (rc != VIO_OK) return rc;
+    rc = flush_imu_backend(h);
     if (rc != VIO_OK) return rc;
     for (auto &g : h->groups) {
         const uint8_t *dg = nullptr;
@@ -737,7 +922,9 @@ int vio_process_obs_batch(vio_batch *h, const int32_t *n_obs, const int32_t *ids
     const int NP = h->hc.NP;
     for (int s = 0; s < h->S; s++)
         if (n_obs[s] > cap || n_obs[s] > NP) { g_err = "feature map larger than the tracker capacity (vio_get_capacity)"; return VIO_ECAPACITY; }
-    int rc = flush_imu_backend(h);
+    int rc = refresh_dynamic_state(h);
+    if (rc != VIO_OK) return rc;
+    rc = flush_imu_backend(h);
     if (rc != VIO_OK) return rc;
     for (auto &g : h->groups) {
         const uint8_t *dg = nullptr;

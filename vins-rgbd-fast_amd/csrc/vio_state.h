@@ -100,6 +100,9 @@ struct BeSeq {
     int overflow_frames;            // sticky diagnostic: number of frames that raised any capacity flag since the last reset / reboot
     int iter_total, solve_total;    // solver iterations / solves since vio_create (bench.py averages them over its timed steps)
     int rebooted;                   // failureDetection fired in this frame's solve: be_marg / be_finish skip the sequence
+    int init_frame;                 // this frame completed the dynamic initialisation (set by the host): no failureDetection / movingConsistencyCheck
+    int dyn_failed;                 // a dynamic initialisation attempt failed on this frame (diagnostics)
+    int imu_frame_head;             // first ring sample consumed for the current frame (absolute index), with n_imu_frame
     double prior_c0;                // |r|^2 of the prior at its linearisation point (constant cost offset)
     int dbg[16];                    // debug counters (sweeps, ticks)
 };

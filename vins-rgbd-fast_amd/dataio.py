@@ -103,7 +103,7 @@ def parse_opencv_yaml(text):
 
 def config_from_yaml(path_or_text, P=None, strict=True):
     """vio_config from a reference configuration file (parameters.cpp:81-243).  Settings that select code paths outside the
-    built hot path raise ValueError when strict (VO mode ``imu: 0``, dynamic initialisation ``static_init: 0``, fisheye,
+    built hot path raise ValueError when strict (VO mode ``imu: 0``, fisheye,
     CLAHE, ``estimate_extrinsic: 2``); with strict=False they are returned in the second element as a list of notes."""
     if P is None:
         import importlib
@@ -154,7 +154,7 @@ def config_from_yaml(path_or_text, P=None, strict=True):
     c.estimate_td = int(g("estimate_td", 0))
     c.tr = float(g("rolling_shutter_tr", 0.0)) if int(g("rolling_shutter", 0)) else 0.0
     need(int(g("imu", 1)) == 0, "imu: 0 (VO mode) is out of scope (SURVEY.md 8f rank 3)")
-    need(int(g("static_init", 1)) == 0, "static_init: 0 needs the dynamic initialisation (SURVEY.md 8f rank 1), not built yet")
+    c.dynamic_init = 0 if int(g("static_init", 1)) else 1   # parameters.cpp:167: STATIC_INIT; 0 = SfM + visual-inertial alignment
     need(int(g("fisheye", 0)) != 0, "fisheye masks are out of scope")
     need(int(g("equalize", 0)) != 0, "equalize (CLAHE) is out of scope")
     extra = dict(freq=int(g("freq", 0)), frontend_freq=int(g("frontend_freq", 0)), output_path=g("output_path", ""),
