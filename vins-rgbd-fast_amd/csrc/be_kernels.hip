@@ -1546,7 +1546,8 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
         for (int k = 0; k < 3; k++) { be.Bas[i][k] = X.sb[i * 9 + 3 + k]; be.Bgs[i][k] = X.sb[i * 9 + 6 + k]; }
         // updateLatestStates (estimator.cpp:1768-1776): latest_Bg feeds predictMotion of the next frame, whose front-end may
         // start as soon as this kernel is done (overlapping the marginalisation)
-        if (i == W) for (int k = 0; k < 3; k++) be.latest_Bg[k] = X.sb[i * 9 + 6 + k];
+        // (the frame that completes the DYNAMIC initialisation returns without updateLatestStates, estimator.cpp:241-252)
+        if (i == W && !be.init_frame) for (int k = 0; k < 3; k++) be.latest_Bg[k] = X.sb[i * 9 + 6 + k];
     }
     if (t == W + 1) {
         be.tic[0] = X.ex[0]; be.tic[1] = X.ex[1]; be.tic[2] = X.ex[2];
@@ -2248,12 +2249,37 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
 // After a successful host-side initialStructure (dyninit_host.cpp) the host has written Ps / Rs / Vs / Bgs / Bas / g of sequence
 // `seq`: re-propagate the window pre-integrations at the new gyroscope bias (estimator.cpp:829-836) and triangulate with the new
 // poses (solveOdometry -> triangulateWithDepth, :921-933).  The regular be_solve / be_marg launches follow.
-__global__ __launch_bounds__(256) void be_dyn_finalize_kernel(Batch B, int seq) {
+// `samples` = (dt, acc[3], gyr[3]) of every IMU step of window slot j in [offs[j], offs[j + 1]), rebuilt by the host from its mirror of
+// all_image_frame: slots that absorbed dropped frames (MARGIN_SECOND_NEW while INITIAL, estimator.cpp:1651-1687) hold more steps than
+// the per-slot sample buffer on the device keeps (the reference's buffers are unbounded vectors).
+__global__ __launch_bounds__(256) void be_dyn_finalize_kernel(Batch B, int seq, const double *samples, const int *offs) {
     __shared__ PreWork pw;
     Ctx c = make_ctx(B, seq);
-    repropagate_window(c, pw);
+    BeSeq &be = *c.be;
+    const vio_config &cfg = c.C->c;
+    const int t = threadIdx.x, nt = blockDim.x, W = c.W;
+    for (int j = 0; j <= W; j++) {
+        PreInt &p = c.pre[be.pre_idx[j]];
+        if (!p.valid) continue;
+        if (t == 0) {
+            v3 la = ld3(p.lin_acc), lg = ld3(p.lin_gyr);
+            p.sum_dt = 0;
+            st3(p.acc0, la); st3(p.gyr0, lg);
+            p.dp[0] = p.dp[1] = p.dp[2] = 0; p.dv[0] = p.dv[1] = p.dv[2] = 0;
+            p.dq[0] = 1; p.dq[1] = p.dq[2] = p.dq[3] = 0;
+            p.lin_ba[0] = p.lin_ba[1] = p.lin_ba[2] = 0;
+            st3(p.lin_bg, ld3(be.Bgs[j]));
+        }
+        for (int i = t; i < 225; i += nt) { pw.J[i] = ((i / 15) == (i % 15)) ? 1.0 : 0.0; pw.Pm[i] = 0; }
+        __syncthreads();
+        for (int q = offs[j]; q < offs[j + 1]; q++) {
+            const double *sm = samples + (size_t)q * 7;
+            preint_propagate(p, pw, cfg, sm[0], ld3(sm + 1), ld3(sm + 4));
+        }
+        preint_store(p, pw);
+    }
     __syncthreads();
-    triangulate_with_depth(c, c.be->n_lm);
+    triangulate_with_depth(c, be.n_lm);
 }
 
 // ====================================================================================================== stage tests

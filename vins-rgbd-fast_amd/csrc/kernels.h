@@ -35,7 +35,7 @@ __global__ void be_solve_kernel(Batch B);
 __global__ void be_solve_kernel_512(Batch B);
 __global__ void be_marg_kernel(Batch B);
 __global__ void be_prior_factor_kernel(Batch B, int seq);
-__global__ void be_dyn_finalize_kernel(Batch B, int seq);
+__global__ void be_dyn_finalize_kernel(Batch B, int seq, const double *samples, const int *offs);
 __global__ void be_stage_imu_kernel(vio_config cfg, PreInt *P, int n, const double *dt, const double *acc, const double *gyr,
                                     const double *par, double g_norm, double *preint_out, double *r15, double *J480);
 __global__ void be_stage_projection_kernel(vio_config cfg, const double *in, int use_td, int form, double *r2, double *J46);

@@ -77,6 +77,9 @@ struct vio_batch {
     int *d_state = nullptr;
     hipEvent_t ev_state = nullptr;
     bool state_pending = false;
+    double *d_dyn_samples = nullptr;  // IMU steps of the window slots handed to be_dyn_finalize_kernel (grown on demand)
+    int *d_dyn_offs = nullptr;
+    size_t dyn_samples_cap = 0;
     // pending IMU samples (host staging)
     std::mutex imu_mu;
     std::vector<int> p_seq;
@@ -442,6 +445,30 @@ int dynamic_init_step(vio_batch *h, int s, const IngestSrc &src, bool *finalize)
         }
         for (int k = 0; k < 3; k++) be.g[k] = res.g[k];
         be.solver_flag = 1; be.init_frame = 1; be.do_solve = 1; be.do_marg = 1;
+        {
+            // IMU steps of every window slot from the image-frame mirror: slot j spans the image frames in (Headers[j - 1], Headers[j]]
+            std::vector<double> samp;
+            std::vector<int> offs(VIO_MAXW + 3, 0);
+            for (int j = 1; j <= W; j++) {
+                for (const auto &f : D.frames)
+                    if (f.stamp > be.Headers[j - 1] && f.stamp <= be.Headers[j])
+                        for (size_t k = 0; k < f.dt.size(); k++) {
+                            samp.push_back(f.dt[k]);
+                            for (int q = 0; q < 3; q++) samp.push_back(f.acc[3 * k + q]);
+                            for (int q = 0; q < 3; q++) samp.push_back(f.gyr[3 * k + q]);
+                        }
+                offs[j + 1] = (int)(samp.size() / 7);
+            }
+            offs[1] = 0;
+            if (samp.size() > h->dyn_samples_cap) {
+                if (h->d_dyn_samples) (void)hipFree(h->d_dyn_samples);
+                h->dyn_samples_cap = samp.size() * 2 + 7 * 1024;
+                HIPCHK(hipMalloc((void **)&h->d_dyn_samples, h->dyn_samples_cap * sizeof(double)));
+            }
+            if (!h->d_dyn_offs) HIPCHK(hipMalloc((void **)&h->d_dyn_offs, (VIO_MAXW + 3) * sizeof(int)));
+            if (!samp.empty()) HIPCHK(hipMemcpy(h->d_dyn_samples, samp.data(), samp.size() * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(h->d_dyn_offs, offs.data(), (VIO_MAXW + 3) * sizeof(int), hipMemcpyHostToDevice));
+        }
         D.frames.clear();
         D.nonlinear = true;
         *finalize = true;
@@ -482,7 +509,7 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
             bool fin = false;
             int rc = dynamic_init_step(h, s, src, &fin);
             if (rc != VIO_OK) return rc;
-            if (fin) be_dyn_finalize_kernel<<<1, 256, 0, st>>>(h->B, s);
+            if (fin) { be_dyn_finalize_kernel<<<1, 256, 0, st>>>(h->B, s, h->d_dyn_samples, h->d_dyn_offs); HIPCHK(hipStreamSynchronize(st)); }  // (the staging buffers are shared by all sequences)
         }
         bool any = false;
         for (int s = 0; s < h->S; s++) any = any || !h->dyn[s].nonlinear;
@@ -749,6 +776,8 @@ void vio_destroy(vio_batch *h) {
     if (h->ev_state) (void)hipEventDestroy(h->ev_state);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->d_state) (void)hipFree(h->d_state);
+    if (h->d_dyn_samples) (void)hipFree(h->d_dyn_samples);
+    if (h->d_dyn_offs) (void)hipFree(h->d_dyn_offs);
     for (hipEvent_t e : h->pev) (void)hipEventDestroy(e);
     for (auto &g : h->groups) {
         if (g.stream) (void)hipStreamDestroy(g.stream);
