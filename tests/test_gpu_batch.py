@@ -133,14 +133,16 @@ def test_stream_groups_do_not_change_results(P, monkeypatch):
         assert np.array_equal(grp.landmarks(i), ref.landmarks(i)), i
 
 
-@pytest.mark.parametrize("env", [{"VIO_BE_THREADS": "1024"}, {"VIO_FLAGS": "1"}, {"VIO_MARG_THREADS": "256"}, {"VIO_MARG_THREADS": "512"}])
+@pytest.mark.parametrize("env", [{"VIO_SOLVE_MODE": "0"}, {"VIO_SOLVE_MODE": "0", "VIO_BE_THREADS": "1024"}, {"VIO_FLAGS": "1"}, {"VIO_MARG_THREADS": "256"},
+                                 {"VIO_MARG_THREADS": "512"}])
 def test_alternative_kernel_configurations_agree(P, monkeypatch, env):
-    """The non-default builds / paths kept behind environment knobs (1024-thread solve kernel, Schur complement and Cholesky in HBM
+    """The non-default builds / paths kept behind environment knobs (persistent one-workgroup-per-sequence solve kernel instead of the
+    phased solver, its 1024-thread build, Schur complement and Cholesky in HBM
     instead of LDS tiles, 256- and 512-thread marginalisation) compute the same thing in a different summation order: the trajectory must agree
     with the default configuration to round-off amplified over 24 frames (1e-6 m)."""
     cfg = P.canonical_config()
     sc = vio_ct.synth_like(cfg)
-    for k in ("VIO_BE_THREADS", "VIO_FLAGS", "VIO_MARG_THREADS"):
+    for k in ("VIO_BE_THREADS", "VIO_FLAGS", "VIO_MARG_THREADS", "VIO_SOLVE_MODE"):
         monkeypatch.delenv(k, raising=False)
     ref = _drive(P, cfg, sc, [60, 61], 24)
     ref_w = [ref.window(i).copy() for i in range(2)]

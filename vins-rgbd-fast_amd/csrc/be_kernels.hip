@@ -520,7 +520,6 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
 // ====================================================================================================== be_solve
 namespace {
 
-struct Params { double pose[(VIO_MAXW + 1) * 7], sb[(VIO_MAXW + 1) * 9], ex[7], td; };
 
 // prior residual row i at parameters X: r0 + J dx; dx assembled in LDS sdx (n)
 __device__ __forceinline__ void prior_dx(const Ctx &c, const Params &X, double *sdx, bool sync = true) {
@@ -1029,6 +1028,260 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
 
 }  // namespace
 
+namespace {
+// Everything optimization() does before the first evaluation (estimator.cpp:1161-1212, 936-981): static-initialisation extras,
+// vector2double into X, landmark / residual / frame-pair indexing, constness decisions (sh_i[0] = extrinsic variable, sh_i[1] = td
+// variable).  Shared by the persistent solve kernel and the phased solver (ps_setup_kernel).
+__device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X, int *scratch, PreWork &pw, int *sh_i, int &F, int &Fa, int &nres) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    const vio_config &cfg = c.C->c;
+    BeSeq &be = *c.be;
+    const int W = c.W, W1 = W + 1;
+    // ---- static initialisation extras (estimator.cpp:266-283): solveGyroscopeBias + repropagate
+    if (be.solver_flag == 0) {
+        if (t == 0) {
+            double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+            for (int i = 0; i < W; i++) {
+                int j = i + 1;
+                const PreInt &p = c.pre[be.pre_idx[j]];
+                quat q_ij = R2q(mul(tr(ldm(be.Rs[i])), ldm(be.Rs[j])));
+                m3 tA = bf::get33(p.jac, 15, bf::O_R, bf::O_BG);
+                v3 tb = scl(2.0, qvec(qmul(qinv(mkq(p.dq[0], p.dq[1], p.dq[2], p.dq[3])), q_ij)));
+                m3 AtA = mul(tr(tA), tA);
+                v3 Atb = mul(tr(tA), tb);
+                for (int r = 0; r < 9; r++) A[r] += AtA.a[r];
+                b[0] += Atb.x; b[1] += Atb.y; b[2] += Atb.z;
+            }
+            double M[12];
+            for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) M[r * 4 + q] = A[r * 3 + q]; M[r * 4 + 3] = b[r]; }
+            for (int i = 0; i < 3; i++) {
+                int p = i;
+                for (int r = i + 1; r < 3; r++) if (fabs(M[r * 4 + i]) > fabs(M[p * 4 + i])) p = r;
+                for (int q = 0; q < 4; q++) { double tmp = M[i * 4 + q]; M[i * 4 + q] = M[p * 4 + q]; M[p * 4 + q] = tmp; }
+                if (M[i * 4 + i] == 0) continue;
+                for (int r = i + 1; r < 3; r++) {
+                    double f = M[r * 4 + i] / M[i * 4 + i];
+                    for (int q = i; q < 4; q++) M[r * 4 + q] -= f * M[i * 4 + q];
+                }
+            }
+            double x[3] = {0, 0, 0};
+            for (int i = 2; i >= 0; i--) {
+                double sacc = M[i * 4 + 3];
+                for (int q = i + 1; q < 3; q++) sacc -= M[i * 4 + q] * x[q];
+                x[i] = M[i * 4 + i] != 0 ? sacc / M[i * 4 + i] : 0;
+            }
+            for (int i = 0; i <= W; i++) { be.Bgs[i][0] += x[0]; be.Bgs[i][1] += x[1]; be.Bgs[i][2] += x[2]; }
+        }
+        __syncthreads();
+        repropagate_window(c, pw);
+    }
+
+    // ---- vector2double (estimator.cpp:936-981)
+    if (t <= W) {
+        int i = t;
+        X.pose[i * 7 + 0] = be.Ps[i][0]; X.pose[i * 7 + 1] = be.Ps[i][1]; X.pose[i * 7 + 2] = be.Ps[i][2];
+        quat q = R2q(ldm(be.Rs[i]));
+        X.pose[i * 7 + 3] = q.x; X.pose[i * 7 + 4] = q.y; X.pose[i * 7 + 5] = q.z; X.pose[i * 7 + 6] = q.w;
+        for (int k = 0; k < 3; k++) { X.sb[i * 9 + k] = be.Vs[i][k]; X.sb[i * 9 + 3 + k] = be.Bas[i][k]; X.sb[i * 9 + 6 + k] = be.Bgs[i][k]; }
+    }
+    if (t == W + 1) {
+        X.ex[0] = be.tic[0]; X.ex[1] = be.tic[1]; X.ex[2] = be.tic[2];
+        quat q = R2q(ldm(be.ric));
+        X.ex[3] = q.x; X.ex[4] = q.y; X.ex[5] = q.z; X.ex[6] = q.w;
+        X.td = be.td;
+    }
+    // ---- landmark indexing: in-problem (para_Feature index), variable landmarks, residual list
+    const int nlm = be.n_lm;
+    int *tmpA = c.pair_list, *tmpB = c.pair_list + c.NL;       // scan temporaries (pair_list proper is built afterwards)
+    int *alist = c.pair_list + c.nres_cap - c.NL;              // variable-landmark slots, kept for the whole solve
+    int *plist = c.pair_list + c.nres_cap - 2 * c.NL;          // in-problem landmark slots in list order
+    __syncthreads();
+    for (int k = t; k < nlm; k += nt) tmpA[k] = in_problem(c, c.lm_order[k]) ? 1 : 0;
+    __syncthreads();
+    F = block_scan_flags(tmpA, nlm, tmpB, scratch);
+    for (int k = t; k < nlm; k += nt) {
+        int slot = c.lm_order[k];
+        c.lm_pidx[slot] = tmpA[k] ? tmpB[k] : -1;
+        if (tmpA[k]) { c.feat[tmpB[k]] = 1.0 / c.lm_depth[slot]; plist[tmpB[k]] = slot; }
+    }
+    __syncthreads();
+    // variable landmarks (not SetParameterBlockConstant): estimator.cpp:1278-1298
+    for (int k = t; k < nlm; k += nt) {
+        int slot = c.lm_order[k];
+        tmpA[k] = (c.lm_pidx[slot] >= 0 && !(c.lm_est[slot] == 1 && cfg.fix_depth)) ? 1 : 0;
+    }
+    __syncthreads();
+    Fa = block_scan_flags(tmpA, nlm, tmpB, scratch);
+    for (int k = t; k < nlm; k += nt) {
+        int slot = c.lm_order[k];
+        c.lm_aidx[slot] = tmpA[k] ? tmpB[k] : -1;
+        if (tmpA[k]) alist[tmpB[k]] = slot;
+    }
+    __syncthreads();
+    // residual list: (nobs-1) residuals per in-problem landmark, list order (estimator.cpp:1243-1302)
+    for (int k = t; k < nlm; k += nt) { int slot = c.lm_order[k]; tmpA[k] = c.lm_pidx[slot] >= 0 ? c.lm_nobs[slot] - 1 : 0; }
+    __syncthreads();
+    nres = block_scan_flags(tmpA, nlm, tmpB, scratch);
+    const int nres_max = c.nres_cap - 2 * c.NL;
+    if (nres > nres_max) { nres = nres_max; if (t == 0) be.overflow |= 8; }
+    for (int k = t; k < nlm; k += nt) {
+        int slot = c.lm_order[k];
+        int r0 = tmpB[k], cnt = tmpA[k];
+        c.lm_tmp[slot] = r0;  // first residual index of this landmark
+        for (int q = 0; q < cnt; q++)
+            if (r0 + q < nres) { c.res_lm[r0 + q] = slot; c.res_k[r0 + q] = q + 1; }
+    }
+    __syncthreads();
+    // frame-pair lists in deterministic (landmark list) order: one wavefront per frame pair walks the in-problem landmarks
+    {
+        const int lane = t & 63, wave = t >> 6, nw = nt >> 6;
+        for (int p = t; p <= W1 * W1; p += nt) c.pair_start[p] = 0;
+        __syncthreads();
+        for (int p = wave; p < W1 * W1; p += nw) {
+            int i = p / W1, j = p - i * W1;
+            if (!(i < j)) continue;
+            int cnt = 0;
+            for (int k0 = 0; k0 < F; k0 += 64) {
+                int k = k0 + lane;
+                bool hit = false;
+                if (k < F) { int slot = plist[k]; hit = c.lm_start[slot] == i && c.lm_nobs[slot] > j - i && c.lm_tmp[slot] + (j - i - 1) < nres; }
+                cnt += __popcll(__ballot(hit));
+            }
+            if (lane == 0) c.pair_start[p] = cnt;
+        }
+        __syncthreads();
+        if (t == 0) {
+            int acc = 0;
+            for (int p = 0; p < W1 * W1; p++) { int v = c.pair_start[p]; c.pair_start[p] = acc; acc += v; }
+            c.pair_start[W1 * W1] = acc;
+        }
+        __syncthreads();
+        for (int p = wave; p < W1 * W1; p += nw) {
+            int i = p / W1, j = p - i * W1;
+            if (!(i < j)) continue;
+            int o = c.pair_start[p];
+            for (int k0 = 0; k0 < F; k0 += 64) {
+                int k = k0 + lane;
+                bool hit = false;
+                int r = 0;
+                if (k < F) { int slot = plist[k]; r = c.lm_tmp[slot] + (j - i - 1); hit = c.lm_start[slot] == i && c.lm_nobs[slot] > j - i && r < nres; }
+                unsigned long long m = __ballot(hit);
+                if (hit) c.pair_list[o + __popcll(m & ((1ULL << lane) - 1ULL))] = r;
+                o += __popcll(m);
+            }
+        }
+        __syncthreads();
+    }
+    // constness (estimator.cpp:1187-1212)
+    if (t == 0) {
+        double v0 = nrm(ld3(be.Vs[0]));
+        int ex_active;
+        if ((cfg.estimate_extrinsic && be.frame_count == W && v0 > 0.2) || be.openExEstimation) { be.openExEstimation = 1; ex_active = 1; }
+        else ex_active = 0;
+        int td_active = cfg.estimate_td && !(v0 < 0.2);
+        sh_i[0] = ex_active; sh_i[1] = td_active;
+        be.n_in_problem = F; be.n_var_landmarks = Fa; be.n_residuals = nres;
+        be.iterations = 0; be.successful = 0;
+    }
+    __syncthreads();
+}
+
+// double2vector + setDepth + failureDetection after the solve (estimator.cpp:985-1111, feature_manager.cpp:197-223, estimator.cpp:345-353).
+// sdx: >= 12 doubles of LDS scratch.  Shared by the persistent solve kernel and the phased solver (ps_final_kernel).
+__device__ __forceinline__ void solve_epilogue(Ctx &c, const Params &X, double cost, int iters_done, int succ, long long ts0, double *sdx, double *sh_d, int *sh_i) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    const vio_config &cfg = c.C->c;
+    BeSeq &be = *c.be;
+    const int W = c.W, nlm = be.n_lm;
+    // ---- write back flat parameters + double2vector (estimator.cpp:985-1111)
+    if (t == 0) {
+        be.final_cost = cost; be.iterations = iters_done; be.successful = succ;
+        be.iter_total += iters_done; be.solve_total++;
+        be.dbg[4] = (int)(wall_clock64() - ts0);
+        v3 origin_R0 = R2ypr(ldm(be.Rs[0]));
+        v3 origin_P0 = ld3(be.Ps[0]);
+        quat q0 = mkq(X.pose[6], X.pose[3], X.pose[4], X.pose[5]);
+        v3 origin_R00 = R2ypr(q2R(q0));
+        double y_diff = origin_R0.x - origin_R00.x;
+        m3 rot_diff = ypr2R(mk(y_diff, 0, 0));
+        if (fabs(fabs(origin_R0.y) - 90) < 1.0 || fabs(fabs(origin_R00.y) - 90) < 1.0) rot_diff = mul(ldm(be.Rs[0]), tr(q2R(q0)));
+        sh_d[0] = 0;
+        for (int q = 0; q < 9; q++) sdx[q] = rot_diff.a[q];
+        sdx[9] = origin_P0.x; sdx[10] = origin_P0.y; sdx[11] = origin_P0.z;
+    }
+    __syncthreads();
+    if (t <= W) {
+        int i = t;
+        m3 rot_diff = ldm(sdx);
+        v3 origin_P0 = mk(sdx[9], sdx[10], sdx[11]);
+        quat qi = qnormalized(mkq(X.pose[i * 7 + 6], X.pose[i * 7 + 3], X.pose[i * 7 + 4], X.pose[i * 7 + 5]));
+        stm(be.Rs[i], mul(rot_diff, q2R(qi)));
+        st3(be.Ps[i], add(mul(rot_diff, mk(X.pose[i * 7] - X.pose[0], X.pose[i * 7 + 1] - X.pose[1], X.pose[i * 7 + 2] - X.pose[2])), origin_P0));
+        st3(be.Vs[i], mul(rot_diff, mk(X.sb[i * 9], X.sb[i * 9 + 1], X.sb[i * 9 + 2])));
+        for (int k = 0; k < 3; k++) { be.Bas[i][k] = X.sb[i * 9 + 3 + k]; be.Bgs[i][k] = X.sb[i * 9 + 6 + k]; }
+        // updateLatestStates (estimator.cpp:1768-1776): latest_Bg feeds predictMotion of the next frame, whose front-end may
+        // start as soon as this kernel is done (overlapping the marginalisation)
+        // (the frame that completes the DYNAMIC initialisation returns without updateLatestStates, estimator.cpp:241-252)
+        if (i == W && !be.init_frame) for (int k = 0; k < 3; k++) be.latest_Bg[k] = X.sb[i * 9 + 6 + k];
+    }
+    if (t == W + 1) {
+        be.tic[0] = X.ex[0]; be.tic[1] = X.ex[1]; be.tic[2] = X.ex[2];
+        stm(be.ric, q2R(qnormalized(mkq(X.ex[6], X.ex[3], X.ex[4], X.ex[5]))));
+        if (cfg.estimate_td) be.td = X.td;
+    }
+    // setDepth (feature_manager.cpp:197-223)
+    for (int k = t; k < nlm; k += nt) {
+        int slot = c.lm_order[k];
+        int pi = c.lm_pidx[slot];
+        if (pi < 0) continue;
+        double d = 1.0 / c.feat[pi];
+        c.lm_depth[slot] = d;
+        c.lm_solve[slot] = d < 0 ? 2 : 1;
+    }
+    __syncthreads();
+    // failureDetection + clearState() / setParameter() (estimator.cpp:345-353, 1113-1159, 43-116, 15-41).  The reference runs it
+    // after optimization() (solve + marginalisation) and throws the whole state away when it fires, so nothing the marginalisation
+    // produces survives a reboot: it is decided HERE, before the host records ev_solve, because the reset rewrites imu_head / td /
+    // ric / latest_Bg, which the next frame's front-end (fe_begin) and the IMU scatter kernel read as soon as this kernel is done.
+    if (be.solver_flag == 1 && !be.init_frame) {
+        if (t == 0) {
+            int fail = 0;
+            if (nrm(ld3(be.Bas[W])) > 2.5) fail = 1;
+            if (nrm(ld3(be.Bgs[W])) > 1.0) fail = 1;
+            v3 tmpP = ld3(be.Ps[W]);
+            if (nrm(sub(tmpP, ld3(be.last_P))) > 5) fail = 1;
+            if (fabs(tmpP.z - be.last_P[2]) > 1) fail = 1;
+            sh_i[0] = fail;
+        }
+        __syncthreads();
+        if (sh_i[0]) {
+            for (int k = t; k < c.NL; k += nt) c.lm_free[k] = c.NL - 1 - k;
+            if (t == 0) {
+                for (int i = 0; i <= W + 1; i++) c.pre[i].valid = 0;
+                for (int i = 0; i <= W; i++) {
+                    for (int k = 0; k < 3; k++) { be.Ps[i][k] = 0; be.Vs[i][k] = 0; be.Bas[i][k] = 0; be.Bgs[i][k] = 0; }
+                    stm(be.Rs[i], eye());
+                    be.Headers[i] = 0;
+                    be.pre_idx[i] = i;
+                }
+                for (int k = 0; k < 9; k++) be.ric[k] = cfg.ric[k];
+                for (int k = 0; k < 3; k++) { be.tic[k] = cfg.tic[k]; be.latest_Bg[k] = 0; }
+                be.td = cfg.td;
+                be.first_imu = 0; be.frame_count = 0; be.solver_flag = 0; be.openExEstimation = 0; be.has_prior = 0;
+                be.initFirstPoseFlag = 0; be.prevTime = -1; be.n_lm = 0; be.n_free = c.NL; be.ring_base = 0;
+                be.imu_head = be.imu_count;  // clearState() empties imu_buf
+                be.reboot_count++;
+                be.status_code = VIO_REBOOTED;
+                be.rebooted = 1;
+                be.do_marg = 0;
+                be.overflow = 0;
+            }
+        }
+    }
+}
+
+}  // namespace
+
 __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem_marg);
 __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw);
 
@@ -1090,158 +1343,12 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
 
     PH_INIT;
     const long long ts0 = wall_clock64();
-    // ---- static initialisation extras (estimator.cpp:266-283): solveGyroscopeBias + repropagate
-    if (be.solver_flag == 0) {
-        if (t == 0) {
-            double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
-            for (int i = 0; i < W; i++) {
-                int j = i + 1;
-                const PreInt &p = c.pre[be.pre_idx[j]];
-                quat q_ij = R2q(mul(tr(ldm(be.Rs[i])), ldm(be.Rs[j])));
-                m3 tA = bf::get33(p.jac, 15, bf::O_R, bf::O_BG);
-                v3 tb = scl(2.0, qvec(qmul(qinv(mkq(p.dq[0], p.dq[1], p.dq[2], p.dq[3])), q_ij)));
-                m3 AtA = mul(tr(tA), tA);
-                v3 Atb = mul(tr(tA), tb);
-                for (int r = 0; r < 9; r++) A[r] += AtA.a[r];
-                b[0] += Atb.x; b[1] += Atb.y; b[2] += Atb.z;
-            }
-            double M[12];
-            for (int r = 0; r < 3; r++) { for (int q = 0; q < 3; q++) M[r * 4 + q] = A[r * 3 + q]; M[r * 4 + 3] = b[r]; }
-            for (int i = 0; i < 3; i++) {
-                int p = i;
-                for (int r = i + 1; r < 3; r++) if (fabs(M[r * 4 + i]) > fabs(M[p * 4 + i])) p = r;
-                for (int q = 0; q < 4; q++) { double tmp = M[i * 4 + q]; M[i * 4 + q] = M[p * 4 + q]; M[p * 4 + q] = tmp; }
-                if (M[i * 4 + i] == 0) continue;
-                for (int r = i + 1; r < 3; r++) {
-                    double f = M[r * 4 + i] / M[i * 4 + i];
-                    for (int q = i; q < 4; q++) M[r * 4 + q] -= f * M[i * 4 + q];
-                }
-            }
-            double x[3] = {0, 0, 0};
-            for (int i = 2; i >= 0; i--) {
-                double sacc = M[i * 4 + 3];
-                for (int q = i + 1; q < 3; q++) sacc -= M[i * 4 + q] * x[q];
-                x[i] = M[i * 4 + i] != 0 ? sacc / M[i * 4 + i] : 0;
-            }
-            for (int i = 0; i <= W; i++) { be.Bgs[i][0] += x[0]; be.Bgs[i][1] += x[1]; be.Bgs[i][2] += x[2]; }
-        }
-        __syncthreads();
-        repropagate_window(c, pw);
-    }
-
-    // ---- vector2double (estimator.cpp:936-981)
-    if (t <= W) {
-        int i = t;
-        X.pose[i * 7 + 0] = be.Ps[i][0]; X.pose[i * 7 + 1] = be.Ps[i][1]; X.pose[i * 7 + 2] = be.Ps[i][2];
-        quat q = R2q(ldm(be.Rs[i]));
-        X.pose[i * 7 + 3] = q.x; X.pose[i * 7 + 4] = q.y; X.pose[i * 7 + 5] = q.z; X.pose[i * 7 + 6] = q.w;
-        for (int k = 0; k < 3; k++) { X.sb[i * 9 + k] = be.Vs[i][k]; X.sb[i * 9 + 3 + k] = be.Bas[i][k]; X.sb[i * 9 + 6 + k] = be.Bgs[i][k]; }
-    }
-    if (t == W + 1) {
-        X.ex[0] = be.tic[0]; X.ex[1] = be.tic[1]; X.ex[2] = be.tic[2];
-        quat q = R2q(ldm(be.ric));
-        X.ex[3] = q.x; X.ex[4] = q.y; X.ex[5] = q.z; X.ex[6] = q.w;
-        X.td = be.td;
-    }
-    PH(0);
-    // ---- landmark indexing: in-problem (para_Feature index), variable landmarks, residual list
-    int nlm = be.n_lm;
-    int *tmpA = c.pair_list, *tmpB = c.pair_list + c.NL;       // scan temporaries (pair_list proper is built afterwards)
+    int F, Fa, nres;
+    solve_prologue(B, c, X, scratch, pw, sh_i, F, Fa, nres);
+    const int nlm = be.n_lm;
     int *alist = c.pair_list + c.nres_cap - c.NL;              // variable-landmark slots, kept for the whole solve
-    int *plist = c.pair_list + c.nres_cap - 2 * c.NL;          // in-problem landmark slots in list order
-    __syncthreads();
-    for (int k = t; k < nlm; k += nt) tmpA[k] = in_problem(c, c.lm_order[k]) ? 1 : 0;
-    __syncthreads();
-    int F = block_scan_flags(tmpA, nlm, tmpB, scratch);
-    for (int k = t; k < nlm; k += nt) {
-        int slot = c.lm_order[k];
-        c.lm_pidx[slot] = tmpA[k] ? tmpB[k] : -1;
-        if (tmpA[k]) { c.feat[tmpB[k]] = 1.0 / c.lm_depth[slot]; plist[tmpB[k]] = slot; }
-    }
-    __syncthreads();
-    // variable landmarks (not SetParameterBlockConstant): estimator.cpp:1278-1298
-    for (int k = t; k < nlm; k += nt) {
-        int slot = c.lm_order[k];
-        tmpA[k] = (c.lm_pidx[slot] >= 0 && !(c.lm_est[slot] == 1 && cfg.fix_depth)) ? 1 : 0;
-    }
-    __syncthreads();
-    int Fa = block_scan_flags(tmpA, nlm, tmpB, scratch);
-    for (int k = t; k < nlm; k += nt) {
-        int slot = c.lm_order[k];
-        c.lm_aidx[slot] = tmpA[k] ? tmpB[k] : -1;
-        if (tmpA[k]) alist[tmpB[k]] = slot;
-    }
-    __syncthreads();
-    // residual list: (nobs-1) residuals per in-problem landmark, list order (estimator.cpp:1243-1302)
-    for (int k = t; k < nlm; k += nt) { int slot = c.lm_order[k]; tmpA[k] = c.lm_pidx[slot] >= 0 ? c.lm_nobs[slot] - 1 : 0; }
-    __syncthreads();
-    int nres = block_scan_flags(tmpA, nlm, tmpB, scratch);
-    const int nres_max = c.nres_cap - 2 * c.NL;
-    if (nres > nres_max) { nres = nres_max; if (t == 0) be.overflow |= 8; }
-    for (int k = t; k < nlm; k += nt) {
-        int slot = c.lm_order[k];
-        int r0 = tmpB[k], cnt = tmpA[k];
-        c.lm_tmp[slot] = r0;  // first residual index of this landmark
-        for (int q = 0; q < cnt; q++)
-            if (r0 + q < nres) { c.res_lm[r0 + q] = slot; c.res_k[r0 + q] = q + 1; }
-    }
-    __syncthreads();
-    PH(1);
-    // frame-pair lists in deterministic (landmark list) order: one wavefront per frame pair walks the in-problem landmarks
-    {
-        const int lane = t & 63, wave = t >> 6, nw = nt >> 6;
-        for (int p = t; p <= W1 * W1; p += nt) c.pair_start[p] = 0;
-        __syncthreads();
-        for (int p = wave; p < W1 * W1; p += nw) {
-            int i = p / W1, j = p - i * W1;
-            if (!(i < j)) continue;
-            int cnt = 0;
-            for (int k0 = 0; k0 < F; k0 += 64) {
-                int k = k0 + lane;
-                bool hit = false;
-                if (k < F) { int slot = plist[k]; hit = c.lm_start[slot] == i && c.lm_nobs[slot] > j - i && c.lm_tmp[slot] + (j - i - 1) < nres; }
-                cnt += __popcll(__ballot(hit));
-            }
-            if (lane == 0) c.pair_start[p] = cnt;
-        }
-        __syncthreads();
-        if (t == 0) {
-            int acc = 0;
-            for (int p = 0; p < W1 * W1; p++) { int v = c.pair_start[p]; c.pair_start[p] = acc; acc += v; }
-            c.pair_start[W1 * W1] = acc;
-        }
-        __syncthreads();
-        for (int p = wave; p < W1 * W1; p += nw) {
-            int i = p / W1, j = p - i * W1;
-            if (!(i < j)) continue;
-            int o = c.pair_start[p];
-            for (int k0 = 0; k0 < F; k0 += 64) {
-                int k = k0 + lane;
-                bool hit = false;
-                int r = 0;
-                if (k < F) { int slot = plist[k]; r = c.lm_tmp[slot] + (j - i - 1); hit = c.lm_start[slot] == i && c.lm_nobs[slot] > j - i && r < nres; }
-                unsigned long long m = __ballot(hit);
-                if (hit) c.pair_list[o + __popcll(m & ((1ULL << lane) - 1ULL))] = r;
-                o += __popcll(m);
-            }
-        }
-        __syncthreads();
-    }
-    PH(2);
-    // prior_H = J^T J ; IMU sqrt_info
     const int n = c.NPR;
-    // constness (estimator.cpp:1187-1212)
-    if (t == 0) {
-        double v0 = nrm(ld3(be.Vs[0]));
-        int ex_active;
-        if ((cfg.estimate_extrinsic && be.frame_count == W && v0 > 0.2) || be.openExEstimation) { be.openExEstimation = 1; ex_active = 1; }
-        else ex_active = 0;
-        int td_active = cfg.estimate_td && !(v0 < 0.2);
-        sh_i[0] = ex_active; sh_i[1] = td_active;
-        be.n_in_problem = F; be.n_var_landmarks = Fa; be.n_residuals = nres;
-        be.iterations = 0; be.successful = 0;
-    }
-    __syncthreads();
+    PH(2);
     const int ex_active = sh_i[0], td_active = sh_i[1];
     const bool vext = ex_active || td_active;   // extrinsic / td Jacobians are only evaluated when one of the blocks is a variable
     const int ne_ext = vext ? 7 : 0;
@@ -1518,91 +1625,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
     }
     __syncthreads();
     PH(13);
-    // ---- write back flat parameters + double2vector (estimator.cpp:985-1111)
-    if (t == 0) {
-        be.final_cost = cost; be.iterations = iters_done; be.successful = succ;
-        be.iter_total += iters_done; be.solve_total++;
-        be.dbg[4] = (int)(wall_clock64() - ts0);
-        v3 origin_R0 = R2ypr(ldm(be.Rs[0]));
-        v3 origin_P0 = ld3(be.Ps[0]);
-        quat q0 = mkq(X.pose[6], X.pose[3], X.pose[4], X.pose[5]);
-        v3 origin_R00 = R2ypr(q2R(q0));
-        double y_diff = origin_R0.x - origin_R00.x;
-        m3 rot_diff = ypr2R(mk(y_diff, 0, 0));
-        if (fabs(fabs(origin_R0.y) - 90) < 1.0 || fabs(fabs(origin_R00.y) - 90) < 1.0) rot_diff = mul(ldm(be.Rs[0]), tr(q2R(q0)));
-        sh_d[0] = 0;
-        for (int q = 0; q < 9; q++) sdx[q] = rot_diff.a[q];
-        sdx[9] = origin_P0.x; sdx[10] = origin_P0.y; sdx[11] = origin_P0.z;
-    }
-    __syncthreads();
-    if (t <= W) {
-        int i = t;
-        m3 rot_diff = ldm(sdx);
-        v3 origin_P0 = mk(sdx[9], sdx[10], sdx[11]);
-        quat qi = qnormalized(mkq(X.pose[i * 7 + 6], X.pose[i * 7 + 3], X.pose[i * 7 + 4], X.pose[i * 7 + 5]));
-        stm(be.Rs[i], mul(rot_diff, q2R(qi)));
-        st3(be.Ps[i], add(mul(rot_diff, mk(X.pose[i * 7] - X.pose[0], X.pose[i * 7 + 1] - X.pose[1], X.pose[i * 7 + 2] - X.pose[2])), origin_P0));
-        st3(be.Vs[i], mul(rot_diff, mk(X.sb[i * 9], X.sb[i * 9 + 1], X.sb[i * 9 + 2])));
-        for (int k = 0; k < 3; k++) { be.Bas[i][k] = X.sb[i * 9 + 3 + k]; be.Bgs[i][k] = X.sb[i * 9 + 6 + k]; }
-        // updateLatestStates (estimator.cpp:1768-1776): latest_Bg feeds predictMotion of the next frame, whose front-end may
-        // start as soon as this kernel is done (overlapping the marginalisation)
-        // (the frame that completes the DYNAMIC initialisation returns without updateLatestStates, estimator.cpp:241-252)
-        if (i == W && !be.init_frame) for (int k = 0; k < 3; k++) be.latest_Bg[k] = X.sb[i * 9 + 6 + k];
-    }
-    if (t == W + 1) {
-        be.tic[0] = X.ex[0]; be.tic[1] = X.ex[1]; be.tic[2] = X.ex[2];
-        stm(be.ric, q2R(qnormalized(mkq(X.ex[6], X.ex[3], X.ex[4], X.ex[5]))));
-        if (cfg.estimate_td) be.td = X.td;
-    }
-    // setDepth (feature_manager.cpp:197-223)
-    for (int k = t; k < nlm; k += nt) {
-        int slot = c.lm_order[k];
-        int pi = c.lm_pidx[slot];
-        if (pi < 0) continue;
-        double d = 1.0 / c.feat[pi];
-        c.lm_depth[slot] = d;
-        c.lm_solve[slot] = d < 0 ? 2 : 1;
-    }
-    __syncthreads();
-    // failureDetection + clearState() / setParameter() (estimator.cpp:345-353, 1113-1159, 43-116, 15-41).  The reference runs it
-    // after optimization() (solve + marginalisation) and throws the whole state away when it fires, so nothing the marginalisation
-    // produces survives a reboot: it is decided HERE, before the host records ev_solve, because the reset rewrites imu_head / td /
-    // ric / latest_Bg, which the next frame's front-end (fe_begin) and the IMU scatter kernel read as soon as this kernel is done.
-    if (be.solver_flag == 1 && !be.init_frame) {
-        if (t == 0) {
-            int fail = 0;
-            if (nrm(ld3(be.Bas[W])) > 2.5) fail = 1;
-            if (nrm(ld3(be.Bgs[W])) > 1.0) fail = 1;
-            v3 tmpP = ld3(be.Ps[W]);
-            if (nrm(sub(tmpP, ld3(be.last_P))) > 5) fail = 1;
-            if (fabs(tmpP.z - be.last_P[2]) > 1) fail = 1;
-            sh_i[0] = fail;
-        }
-        __syncthreads();
-        if (sh_i[0]) {
-            for (int k = t; k < c.NL; k += nt) c.lm_free[k] = c.NL - 1 - k;
-            if (t == 0) {
-                for (int i = 0; i <= W + 1; i++) c.pre[i].valid = 0;
-                for (int i = 0; i <= W; i++) {
-                    for (int k = 0; k < 3; k++) { be.Ps[i][k] = 0; be.Vs[i][k] = 0; be.Bas[i][k] = 0; be.Bgs[i][k] = 0; }
-                    stm(be.Rs[i], eye());
-                    be.Headers[i] = 0;
-                    be.pre_idx[i] = i;
-                }
-                for (int k = 0; k < 9; k++) be.ric[k] = cfg.ric[k];
-                for (int k = 0; k < 3; k++) { be.tic[k] = cfg.tic[k]; be.latest_Bg[k] = 0; }
-                be.td = cfg.td;
-                be.first_imu = 0; be.frame_count = 0; be.solver_flag = 0; be.openExEstimation = 0; be.has_prior = 0;
-                be.initFirstPoseFlag = 0; be.prevTime = -1; be.n_lm = 0; be.n_free = c.NL; be.ring_base = 0;
-                be.imu_head = be.imu_count;  // clearState() empties imu_buf
-                be.reboot_count++;
-                be.status_code = VIO_REBOOTED;
-                be.rebooted = 1;
-                be.do_marg = 0;
-                be.overflow = 0;
-            }
-        }
-    }
+    solve_epilogue(c, X, cost, iters_done, succ, ts0, sdx, sh_d, sh_i);
 }
 
 // ====================================================================================================== be_marg
@@ -2281,6 +2304,8 @@ __global__ __launch_bounds__(256) void be_dyn_finalize_kernel(Batch B, int seq, 
     __syncthreads();
     triangulate_with_depth(c, be.n_lm);
 }
+
+#include "be_phased.h"
 
 // ====================================================================================================== stage tests
 // IntegrationBase::push_back x n followed by IMUFactor::Evaluate, through the same device code the pipeline uses.

@@ -1,0 +1,736 @@
+// PHASED solver (included at the end of be_kernels.hip): the trust-region loop of optimization() (estimator.cpp:1161-1368) cut into
+// kernels.  The persistent kernel (be_solve_kernel_512) gives one workgroup = one CU to a sequence for the whole solve: at S = 128 half
+// of the 256 CUs idle and the other half wait on their own dependent phases.  Here every data-parallel phase is a launch that covers
+// all sequences with many workgroups each -- residual evaluation (one thread per residual), frame-pair / IMU Gram blocks on the FP64
+// matrix cores (one wavefront per block), landmark rows, H assembly (one thread per entry), landmark Schur complement (one wavefront
+// per 16 x 16 tile) -- and only the inherently serial part (Cholesky, triangular solves, dogleg, step control) runs one workgroup per
+// sequence.  A "slot" = EVAL (+ accept), ASM_A, ASM_B, SCHUR, SERIAL; the host enqueues max_iterations + 2 slots back to back (no
+// synchronisation); sequences that have converged fall through.  State between kernels: SolveSt (vio_state.h) + the vectors that
+// already live in HBM.  Same mathematics and the same iteration / acceptance logic as solve_body; sums are formed in a fixed order,
+// so results are deterministic and independent of the batch a sequence runs in.
+namespace {
+
+__device__ __forceinline__ bool ps_active(const SolveSt &st) { return st.stage != PS_IDLE && st.stage != PS_DONE; }
+__device__ __forceinline__ double *ps_imu_blk(const Ctx &c) { return c.pairblk + (size_t)((c.W + 1) * c.W / 2) * 210; }  // W x 768 doubles behind the pair blocks
+__device__ __forceinline__ unsigned ps_colmask(int W1, int LW, bool vext) {
+    unsigned m = 0;
+    for (int cb = 0; cb < (LW >> 4); cb++) {
+        const int c0 = 16 * cb, c1 = c0 + 15;
+        if (c0 < 6 * W1 || (vext && c1 >= 15 * W1 && c0 < 15 * W1 + 7)) m |= 1u << cb;
+    }
+    return m;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------- setup
+__global__ __launch_bounds__(512) void ps_setup_kernel(Batch B) {
+    const int s = blockIdx.x + B.s0, t = threadIdx.x;
+    __shared__ int scratch[2 * 512 + 8];
+    __shared__ int sh_i[8];
+    __shared__ Params X;
+    __shared__ PreWork pw;
+    Ctx c = make_ctx(B, s);
+    SolveSt &st = B.sst[s];
+    BeSeq &be = *c.be;
+    if (!be.do_solve) { if (t == 0) st.stage = PS_IDLE; return; }
+    const long long ts0 = wall_clock64();
+    int F, Fa, nres;
+    solve_prologue(B, c, X, scratch, pw, sh_i, F, Fa, nres);
+    for (int k = t; k < (int)(sizeof(Params) / sizeof(double)); k += blockDim.x) ((double *)&st.X)[k] = ((const double *)&X)[k];
+    if (t == 0) {
+        st.F = F; st.Fa = Fa; st.nres = nres;
+        st.ex_active = sh_i[0]; st.td_active = sh_i[1]; st.vext = sh_i[0] || sh_i[1];
+        st.cost = 0; st.ccost = 0; st.radius = 1e4; st.mu = 1e-8; st.alpha = 0; st.dogleg_norm = 0; st.model_change = 0;
+        st.iter = 0; st.iters_done = 0; st.succ = 0; st.invalid = 0;
+        st.point_new = 0; st.scale_pending = 1; st.retry = 0; st.cauchy_valid = 0; st.eval_with_J = 1;
+        st.n_eval_blocks = 3 + (nres + 255) / 256;
+        st.eval_done = 0;
+        st.ts0 = ts0;
+        st.stage = PS_EVAL_X0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- ACCEPT
+// Run by one wavefront once every block of the evaluation has published its partial cost: sums them in block order and takes the
+// step-acceptance decision of the loop (parameter / function tolerance, rho test, radius and mu updates: Ceres TrustRegionMinimizer
+// semantics as solve_body)
+__device__ void ps_accept(const Batch &B, int s) {
+    const int t = threadIdx.x;   // one wavefront (the first 64 threads of the block that finished the evaluation last)
+    SolveSt &st = B.sst[s];
+    Ctx c = make_ctx(B, s);
+    const vio_config &cfg = c.C->c;
+    const int W = c.W;
+    double total = 0;
+    for (int b = 0; b < st.n_eval_blocks; b++) total += ((volatile double *)st.part)[b];
+    if (st.stage == PS_EVAL_X0) {
+        if (t == 0) { st.cost = total; c.be->initial_cost = total; st.point_new = 1; st.stage = PS_ASM; }
+        return;
+    }
+    const double ccost = total, cost = st.cost;
+    const int *alist = c.pair_list + c.nres_cap - c.NL;
+    // parameter tolerance |dx| <= 1e-8 (|x| + 1e-8)
+    double xn = 0, dn = 0;
+    const Params &X = st.X, &Xc = st.Xc;
+    if (t <= W) {
+        for (int k = 0; k < 7; k++) { double v = X.pose[t * 7 + k]; xn += v * v; double d = v - Xc.pose[t * 7 + k]; dn += d * d; }
+        for (int k = 0; k < 9; k++) { double v = X.sb[t * 9 + k]; xn += v * v; double d = v - Xc.sb[t * 9 + k]; dn += d * d; }
+    }
+    if (t == W + 1) {
+        if (st.ex_active) for (int k = 0; k < 7; k++) { double v = X.ex[k]; xn += v * v; double d = v - Xc.ex[k]; dn += d * d; }
+        if (st.td_active) { xn += X.td * X.td; dn += (X.td - Xc.td) * (X.td - Xc.td); }
+    }
+    for (int k = t; k < st.Fa; k += 64) { int pi = c.lm_pidx[alist[k]]; double v = c.feat[pi]; xn += v * v; double d = v - c.cfeat[pi]; dn += d * d; }
+    xn = wave_sum_dpp(xn); dn = wave_sum_dpp(dn);
+    bool done = false, accept = false;
+    if (sqrt(dn) <= 1e-8 * (sqrt(xn) + 1e-8)) done = true;
+    else if (fabs(cost - ccost) <= 1e-6 * cost) done = true;
+    const double rel = (cost - ccost) / st.model_change;
+    if (!done && rel > 1e-3) accept = true;
+    if (accept) {
+        for (int k = t; k < (int)(sizeof(Params) / sizeof(double)); k += 64) ((double *)&st.X)[k] = ((const double *)&st.Xc)[k];
+        for (int k = t; k < st.F; k += 64) c.feat[k] = c.cfeat[k];
+    }
+    if (t == 0) {
+        if (done) st.stage = PS_DONE;
+        else if (accept) {
+            st.cost = ccost;
+            st.succ++;
+            if (rel < 0.25) st.radius *= 0.5;
+            if (rel > 0.75) st.radius = fmax(st.radius, 3.0 * st.dogleg_norm);
+            st.mu = fmax(1e-8, 2.0 * st.mu / 10.0);
+            st.point_new = 1;
+            st.stage = st.iter >= cfg.max_iterations ? PS_DONE : PS_ASM;   // the candidate of the last iteration carries no Jacobians
+        } else {
+            st.radius *= 0.5;
+            st.stage = st.iter >= cfg.max_iterations ? PS_DONE : PS_STEP;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- EVAL
+// grid (3 + ceil(max residuals / 256), S), 256 threads, dynamic LDS = pair geometry.  Block 0: prior; blocks 1, 2: IMU factors (one
+// work type per wavefront: whitened residual and the four Jacobian column groups are different code paths); block b >= 3: projection
+// residuals [256 (b - 3), 256 (b - 2)).  Evaluates X (first point) or the candidate Xc.  The block of a sequence that finishes last
+// (device-scope counter) sums the partial costs in block order and takes the step-acceptance decision (ps_accept).
+__global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
+    const int s = blockIdx.y + B.s0, t = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+    SolveSt &st = B.sst[s];
+    if (st.stage != PS_EVAL_X0 && st.stage != PS_EVAL_C) return;
+    if (b >= st.n_eval_blocks) return;
+    Ctx c = make_ctx(B, s);
+    const BeSeq &be = *c.be;
+    const vio_config &cfg = c.C->c;
+    const bool cand = st.stage == PS_EVAL_C;
+    const Params &X = cand ? st.Xc : st.X;
+    const double *feat = cand ? c.cfeat : c.feat;
+    const bool withJ = st.eval_with_J != 0, vext = st.vext != 0;
+    const int W = c.W, W1 = W + 1, n = c.NPR;
+    __shared__ double sred[64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double cost = 0;
+    if (b == 0) {
+        if (be.has_prior) {
+            prior_dx(c, X, st.sdx, true);
+            matvec_pass(c.prior_H, n, n, n, nullptr, st.sdx, nullptr, st.srp, nullptr);   // A dx: one wavefront per row
+            for (int i = t; i < n; i += nt) {
+                const double b0 = c.prior_r[i], q = b0 + st.srp[i];
+                st.srp[i] = q;
+                cost += 0.5 * st.sdx[i] * (b0 + q);
+            }
+            if (t == 0) cost += 0.5 * be.prior_c0;
+        }
+    } else if (b <= 2) {
+        const v3 G = ld3(be.g);
+        const int part_ = (b == 1 ? 0 : 4) + (t >> 6), i0 = t & 63;   // block 1: types 0 .. 3 on its four wavefronts, block 2: type 4
+        if (part_ <= 4 && !(b == 2 && (t >> 6) > 0))
+            for (int i = i0; i < W; i += 64) {
+                const int j = i + 1;
+                const PreInt &p = c.pre[be.pre_idx[j]];
+                double *out = c.imu_raw + (size_t)i * 15 * 31;
+                if (p.sum_dt > 10.0) { if (part_ == 0) for (int k = 0; k < 15; k++) out[k * 31 + 30] = 0; continue; }
+                if (part_ == 0) {
+                    double raw[15];
+                    bf::imu_raw_residual(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], raw);
+                    for (int r = 0; r < 15; r++) {
+                        double sacc = 0;
+                        for (int k = 0; k <= r; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k];
+                        out[r * 31 + 30] = sacc;
+                        cost += 0.5 * sacc * sacc;
+                    }
+                } else if (withJ)
+                    bf::imu_raw_jacobian_part(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], part_ - 1, out, 31);
+            }
+    } else {
+        double *geo = (double *)smem;
+        const int r0 = 256 * (b - 3), nres = st.nres;
+        for (int p = t; p <= W1 * W1; p += nt) {
+            if (p == W1 * W1) { stm(geo + (size_t)p * 32, q2R(mkq(X.ex[6], X.ex[3], X.ex[4], X.ex[5]))); continue; }
+            const int i = p / W1, j = p - i * W1;
+            if (!(i < j) || c.pair_start[p + 1] == c.pair_start[p]) continue;
+            bf::PairGeo g;
+            bf::pair_geo(&X.pose[i * 7], &X.pose[j * 7], X.ex, g);
+            double *o = geo + (size_t)p * 32;
+            for (int q = 0; q < 9; q++) { o[q] = g.A1[q]; o[9 + q] = g.A2[q]; o[18 + q] = g.M[q]; }
+            o[27] = g.t[0]; o[28] = g.t[1]; o[29] = g.t[2];
+        }
+        __syncthreads();
+        const double *ricm = geo + (size_t)W1 * W1 * 32;
+        const int r = r0 + t;
+        if (r < nres) {
+            const int slot = c.res_lm[r], k = c.res_k[r];
+            const int imu_i = c.lm_start[slot], imu_j = imu_i + k;
+            const bf::PairGeo &g = *(const bf::PairGeo *)(geo + (size_t)(imu_i * W1 + imu_j) * 32);
+            double rr[2], wgt = 1.0, sq;
+            if (vext) {
+                double *out = c.res + (size_t)r * 42;
+                bf::eval_projection_pair(cfg, g, ricm, X.ex, feat[c.lm_pidx[slot]], X.td, obs_ptr(c, slot, imu_i), obs_ptr(c, slot, imu_j),
+                                         cfg.estimate_td != 0, rr, withJ ? out : nullptr, true, &wgt);
+                sq = rr[0] * rr[0] + rr[1] * rr[1];
+                if (withJ) { out[40] = wgt * rr[0]; out[41] = wgt * rr[1]; }
+            } else {
+                double *out = c.res + (size_t)r * 28;
+                bf::eval_projection_pair(cfg, g, ricm, X.ex, feat[c.lm_pidx[slot]], X.td, obs_ptr(c, slot, imu_i), obs_ptr(c, slot, imu_j),
+                                         cfg.estimate_td != 0, rr, withJ ? out : nullptr, true, &wgt, 14, false);
+                sq = rr[0] * rr[0] + rr[1] * rr[1];
+                if (withJ) { out[13] = wgt * rr[0]; out[27] = wgt * rr[1]; }
+            }
+            cost += 0.5 * log(1.0 + sq);
+        }
+    }
+    cost = block_sum(cost, sred);
+    __shared__ int last;
+    if (t == 0) {
+        st.part[b] = cost;
+        __threadfence();
+        last = atomicAdd(&st.eval_done, 1) == st.n_eval_blocks - 1;
+    }
+    __syncthreads();
+    if (last && t < 64) {
+        __threadfence();
+        if (t == 0) st.eval_done = 0;
+        ps_accept(B, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- ASM_A
+// grid (NB, S), 512 threads = 8 wavefronts per block; wavefront item w = 8 blockIdx.x + wave over the whole sequence:
+//   [0, W1^2)            frame-pair Gram block G_p = [J r]^T [J r] on the FP64 matrix cores -> c.pairblk (items with i >= j idle)
+//   [W1^2, W1^2 + W)     IMU factor Gram block (imu_block_mfma) -> ps_imu_blk
+//   the rest             landmark coupling rows, Hll, gl: 32 landmarks (two threads each) per wavefront
+__global__ __launch_bounds__(512) void ps_asm_a_kernel(Batch B) {
+    const int s = blockIdx.y + B.s0, t = threadIdx.x;
+    const SolveSt &st = B.sst[s];
+    if (st.stage != PS_ASM) return;
+    Ctx c = make_ctx(B, s);
+    const BeSeq &be = *c.be;
+    const int W = c.W, W1 = W + 1, LW = c.LW;
+    const int lane = t & 63, wave = t >> 6, li = lane & 15, lk = lane >> 4;
+    const int item = 8 * blockIdx.x + wave;
+    const bool vext = st.vext != 0;
+    const int nres = st.nres, Fa = st.Fa;
+    __shared__ double imu_lds[8 * 704];
+    if (item < W1 * W1) {
+        const int p = item, i = p / W1, j = p - i * W1;
+        if (!(i < j)) return;
+        const int q0 = c.pair_start[p], np_ = c.pair_start[p + 1] - q0;
+        double *out = c.pairblk + (size_t)pair_slot(i, j, W1) * 210;
+        if (np_ == 0) { for (int e = lane; e < 210; e += 64) out[e] = 0; return; }
+        v4f64 a00 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
+        for (int base = 0; base < np_; base += 64) {
+            const int nchunk = min(64, np_ - base);
+            const int myidx = c.pair_list[q0 + base + min(lane, nchunk - 1)];
+            const int Kc = 2 * nchunk;
+            for (int k0 = 0; k0 < Kc; k0 += 4 * PB_U) {
+                double x0[PB_U], x1[PB_U];
+#pragma unroll
+                for (int u = 0; u < PB_U; u++) {
+                    const int kk = k0 + 4 * u + lk;
+                    const bool valid = kk < Kc;
+                    const int ridx = __shfl(myidx, min(kk, Kc - 1) >> 1, 64);
+                    if (vext) {
+                        const double *Jr = c.res + (size_t)ridx * 42;
+                        const int sub = kk & 1, ro = sub * 20;
+                        const double v0 = Jr[ro + li], v1 = Jr[li < 3 ? ro + 16 + li : 40 + sub];
+                        x0[u] = valid ? v0 : 0.0;
+                        x1[u] = (valid && li < 4) ? v1 : 0.0;
+                    } else {
+                        const double *Jr = c.res + (size_t)ridx * 28 + (kk & 1) * 14;
+                        const double v0 = Jr[li < 12 ? li : 13];
+                        x0[u] = (valid && li < 13) ? v0 : 0.0;
+                        x1[u] = 0.0;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < PB_U; u++) {
+                    if (k0 + 4 * u >= Kc) break;
+                    a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u], x0[u], a00, 0, 0, 0);
+                    if (vext) {
+                        a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x0[u], a10, 0, 0, 0);
+                        a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x1[u], a11, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        for (int r = 0; r < 4; r++) {
+            const int row = lk + 4 * r, col = li;
+            if (vext) {
+                if (col <= row) out[sym_idx(col, row)] = a00[r];
+                if (row < 4) out[sym_idx(col, 16 + row)] = a10[r];
+                if (row < 4 && col < 4 && col <= row) out[sym_idx(16 + col, 16 + row)] = a11[r];
+            } else {
+                if (row < 12) { if (col <= row) out[sym_idx(col, row)] = a00[r]; }
+                else if (row == 12 && col <= 12) out[sym_idx(col < 12 ? col : 19, 19)] = a00[r];
+            }
+        }
+        return;
+    }
+    if (item < W1 * W1 + W) {
+        const int i = item - W1 * W1;
+        const PreInt &pp = c.pre[be.pre_idx[i + 1]];
+        double *G = ps_imu_blk(c) + (size_t)i * 768;
+        if (pp.sum_dt > 10.0) { for (int e = lane; e < 768; e += 64) G[e] = 0; return; }
+        double *raw_l = imu_lds + wave * 704, *M_l = raw_l + 472;
+        const double *raw = c.imu_raw + (size_t)i * 15 * 31;
+        for (int q = lane; q < 465; q += 64) raw_l[q] = raw[q];
+        for (int q = lane; q < 225; q += 64) M_l[q] = pp.sqrt_info[q];
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        v4f64 a00 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
+        imu_block_mfma(raw_l, M_l, li, lk, a00, a10, a11);
+        for (int r = 0; r < 4; r++) {   // three 16 x 16 tiles, element (row, col) at row * 16 + col
+            const int e = (lk + 4 * r) * 16 + li;
+            G[e] = a00[r]; G[256 + e] = a10[r]; G[512 + e] = a11[r];
+        }
+        return;
+    }
+    // landmark rows: zero the part of the row the solver reads, then the coupling entries
+    const int w = (item - (W1 * W1 + W)) * 64 + lane;
+    const int Kpad = (Fa + 3) & ~3;
+    const int w0 = min(LW, (6 * W1 + 15) & ~15), e_lo = max(w0, (15 * W1) & ~15);
+    const int *alist = c.pair_list + c.nres_cap - c.NL;
+    if (w < 2 * Kpad) {
+        const int ka = w >> 1, half = w & 1;
+        double *row = c.Hpl + (size_t)ka * LW;
+        if (half == 0) for (int q = 0; q < w0; q++) row[q] = 0;
+        else if (vext) for (int q = e_lo; q < LW; q++) row[q] = 0;
+        if (ka < Fa) {
+            const int slot = alist[ka];
+            const int stf = c.lm_start[slot], r0 = c.lm_tmp[slot];
+            const int kend = min(c.lm_nobs[slot], nres - r0 + 1);
+            if (vext) lm_row(c.res + (size_t)r0 * 42, row, c.Hll + ka, c.gl + ka, half, stf, kend, 15 * W1);
+            else lm_row_compact(c.res + (size_t)r0 * 28, row, c.Hll + ka, c.gl + ka, half, stf, kend);
+        } else if (half == 1) { c.Hll[ka] = 0; c.gl[ka] = 0; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- ASM_B
+// grid (NB, S), 256 threads: one thread per entry (a, b) of H (both triangles, every entry of the P x LW block is written, so no
+// zero-fill pass) and per entry of g: prior block, the (at most two) IMU Gram blocks that contain both columns, then the
+// frame-pair sums -- the same terms in the same order as assemble().  The thread that owns a diagonal entry fixes the Jacobi
+// column scaling the first time round.
+__global__ __launch_bounds__(256) void ps_asm_b_kernel(Batch B) {
+    const int s = blockIdx.y + B.s0;
+    const SolveSt &st = B.sst[s];
+    if (st.stage != PS_ASM) return;
+    Ctx c = make_ctx(B, s);
+    const BeSeq &be = *c.be;
+    const int W = c.W, W1 = W + 1, P = c.P, LW = c.LW, n = c.NPR;
+    const bool vext = st.vext != 0;
+    const double *pb = c.pairblk, *ib = ps_imu_blk(c);
+    const int oE = 15 * W1, oT = 15 * W1 + 6;
+    const int total = P * (LW + 1);   // column LW stands for the gradient entry of the row
+    // IMU local column of tangent index a in factor i (-1 if absent)
+    auto imu_local = [&](int a, int i) -> int {
+        if (a < 6 * W1) { const int f = a / 6, d = a - 6 * f; return f == i ? d : (f == i + 1 ? 15 + d : -1); }
+        if (a < 15 * W1) { const int q = a - 6 * W1, f = q / 9, d = q - 9 * f; return f == i ? 6 + d : (f == i + 1 ? 21 + d : -1); }
+        return -1;
+    };
+    auto imu_get = [&](int i, int la, int lb) -> double {   // Gram entry (la, lb), la, lb in 0 .. 30 (30 = residual column)
+        const double *G = ib + (size_t)i * 768;
+        if (la < lb) { const int x = la; la = lb; lb = x; }
+        if (la < 16) return G[la * 16 + lb];
+        if (lb < 16) return G[256 + (la - 16) * 16 + lb];
+        return G[512 + (la - 16) * 16 + (lb - 16)];
+    };
+    auto prior_inv = [&](int a) -> int {   // tangent index -> prior index (-1: not in the prior layout)
+        if (a < 6 * W) return a;
+        if (a < 6 * W1) return -1;
+        if (a < 6 * W1 + 9) return 6 * W + (a - 6 * W1);
+        if (a < oE) return -1;
+        if (a < oE + 6) return 6 * W + 9 + (a - oE);
+        if (a == oT) return 6 * W + 15;
+        return -1;
+    };
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < total; w += gridDim.x * blockDim.x) {
+        const int a = w / (LW + 1), bcol = w - a * (LW + 1);
+        const bool grad = bcol == LW;
+        const int b = grad ? -1 : bcol;
+        if (!grad && b >= P) { c.H[(size_t)a * LW + b] = 0; continue; }
+        double v = 0;
+        // prior
+        if (be.has_prior) {
+            const int pa = prior_inv(a);
+            if (pa >= 0) {
+                if (grad) v = st.srp[pa];
+                else { const int pb_ = prior_inv(b); if (pb_ >= 0) v = c.prior_H[pa * n + pb_]; }
+            }
+        }
+        // IMU factors: even ones first, then odd ones (the order assemble() adds them in)
+        if (a < 15 * W1 && (grad || b < 15 * W1)) {
+            const int fa = a < 6 * W1 ? a / 6 : (a - 6 * W1) / 9;
+            for (int parity = 0; parity < 2; parity++)
+                for (int i = fa - 1; i <= fa; i++) {
+                    if (i < 0 || i >= W || (i & 1) != parity) continue;
+                    if (c.pre[be.pre_idx[i + 1]].sum_dt > 10.0) continue;
+                    const int la = imu_local(a, i);
+                    if (la < 0) continue;
+                    const int lb = grad ? 30 : imu_local(b, i);
+                    if (lb < 0) continue;
+                    v += imu_get(i, la, lb);
+                }
+        }
+        // vision: a (and b) must be a pose column or, when they are variables, an extrinsic / td column
+        const int ra = a < 6 * W1 ? a : ((vext && a >= oE && a < oE + 7) ? 6 * W1 + (a - oE) : -1);
+        const int rb = grad ? 0 : (b < 6 * W1 ? b : ((vext && b >= oE && b < oE + 7) ? 6 * W1 + (b - oE) : -1));
+        if (ra >= 0 && rb >= 0) {
+            const int fa = ra < 6 * W1 ? ra / 6 : -1, fb = grad ? -1 : (rb < 6 * W1 ? rb / 6 : -1);
+            double sacc = 0;
+            if (!grad && fa >= 0 && fb >= 0 && fa != fb) {
+                const int i = min(fa, fb), j = max(fa, fb);
+                sacc = pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(local_of(a, i, j, W), local_of(b, i, j, W))];
+            } else if (fa >= 0 || fb >= 0) {
+                const int f = fa >= 0 ? fa : fb;
+                for (int o = 0; o < W1; o++) {
+                    if (o == f) continue;
+                    const int i = min(f, o), j = max(f, o);
+                    const int la = local_of(a, i, j, W), lb = grad ? 19 : local_of(b, i, j, W);
+                    sacc += pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(la, lb)];
+                }
+            } else {
+                for (int i = 0; i < W1; i++)
+                    for (int j = i + 1; j < W1; j++) {
+                        const int la = local_of(a, i, j, W), lb = grad ? 19 : local_of(b, i, j, W);
+                        sacc += pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(la, lb)];
+                    }
+            }
+            v += sacc;
+        }
+        if (grad) c.vec[a] = v;
+        else {
+            c.H[(size_t)a * LW + b] = v;
+            if (a == b && st.scale_pending) {
+                const bool act = a < oE ? true : (a < oT ? st.ex_active != 0 : st.td_active != 0);
+                c.vec[1 * LW + a] = act ? 1.0 / (1.0 + sqrt(v)) : 0.0;   // sp
+            }
+        }
+    }
+    // padding of g / sp beyond P and the landmark scaling
+    if (blockIdx.x == 0) {
+        for (int a = P + threadIdx.x; a < LW; a += blockDim.x) { c.vec[a] = 0; if (st.scale_pending) c.vec[1 * LW + a] = 0; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------- SCHUR
+// grid (active tiles, S), 64 threads: one wavefront forms one 16 x 16 lower tile of S = S_p H S_p + mu D^2 - sum_k w_k h_k h_k^T
+// over all landmark rows, operands straight from HBM / L2 in batches of 8 k-steps, into c.Sc in the LDS tile layout.
+#define PS_SCH_U 8
+__global__ __launch_bounds__(64) void ps_schur_kernel(Batch B) {
+    const int s = blockIdx.y + B.s0;
+    const SolveSt &st = B.sst[s];
+    if (st.stage != PS_ASM && st.stage != PS_SCHUR) return;
+    Ctx c = make_ctx(B, s);
+    const int W1 = c.W + 1, LW = c.LW, nb = LW >> 4;
+    const unsigned colmask = ps_colmask(W1, LW, st.vext != 0);
+    // the blockIdx.x-th active tile (ti >= tj, both column tiles active)
+    int ti = -1, tj = -1, cnt = 0;
+    for (int a = 0; a < nb && ti < 0; a++)
+        for (int b = 0; b <= a; b++)
+            if (((colmask >> a) & 1u) && ((colmask >> b) & 1u)) { if (cnt == (int)blockIdx.x) { ti = a; tj = b; break; } cnt++; }
+    if (ti < 0) return;
+    const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
+    const double *H = c.H, *Ws = c.Hpl, *sp = c.vec + 1 * LW;
+    const double mu = st.mu;
+    const int Fa = st.Fa, Kpad = (Fa + 3) & ~3;
+    const bool first = st.scale_pending != 0;
+    v4f64 acc;
+    for (int r = 0; r < 4; r++) {
+        const int row = 16 * ti + lk + 4 * r, col = 16 * tj + li;
+        double v = sp[row] * sp[col] * H[(size_t)row * LW + col];
+        if (row == col) {
+            const double hs = row < c.P ? sp[row] * sp[row] * H[(size_t)row * LW + row] : 0.0;
+            const double d = sqrt(fmin(fmax(hs, 1e-6), 1e32));
+            v += mu * d * d;
+            if (sp[row] == 0.0) v = 1.0;
+        }
+        acc[r] = v;
+    }
+    const double *wa = Ws + 16 * ti + li, *wb = Ws + 16 * tj + li;
+    const double spa = sp[16 * ti + li], spb = sp[16 * tj + li];
+    for (int k0 = 0; k0 < Kpad; k0 += 4 * PS_SCH_U) {
+        double a[PS_SCH_U], b[PS_SCH_U];
+#pragma unroll
+        for (int u = 0; u < PS_SCH_U; u++) {
+            const int kk = k0 + 4 * u + lk;
+            const bool valid = kk < Kpad;
+            const int kc = min(kk, Kpad - 1);
+            // per-row factor sl^2 / (sl^2 Hll + mu dgl^2), sl = 1 / (1 + sqrt(Hll)) at the first linearisation
+            double hll = c.Hll[kc], slk = first ? (kc < Fa ? 1.0 / (1.0 + sqrt(hll)) : 0.0) : c.lvec[kc];
+            const double hl = kc < Fa ? slk * slk * hll : 0.0;
+            const double dl = sqrt(fmin(fmax(hl, 1e-6), 1e32));
+            const double iv = kc < Fa ? 1.0 / (hl + mu * dl * dl) : 0.0;
+            const double wk = slk * slk * iv;
+            const double va = wa[(size_t)kc * LW], vb = wb[(size_t)kc * LW];
+            a[u] = valid ? -((va * spa) * wk) : 0.0;
+            b[u] = valid ? vb * spb : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < PS_SCH_U; u++) {
+            if (k0 + 4 * u >= Kpad) break;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        }
+    }
+    for (int r = 0; r < 4; r++) c.Sc[tl_idx(ti, tj, lk + 4 * r, li)] = acc[r];
+}
+
+// ---------------------------------------------------------------------------------------------------------------- SERIAL
+// grid S, 512 threads, dynamic LDS = xs + the 16 x 16 tiles of S: prepare_point, Cholesky, triangular solves, landmark
+// back-substitution, dogleg, model decrease, candidate -- the serial spine of one trust-region iteration.
+__global__ __launch_bounds__(512) void ps_serial_kernel(Batch B) {
+    const int s = blockIdx.x + B.s0, t = threadIdx.x, nt = blockDim.x;
+    SolveSt &st = B.sst[s];
+    if (st.stage != PS_ASM && st.stage != PS_SCHUR && st.stage != PS_STEP) return;
+    Ctx c = make_ctx(B, s);
+    const vio_config &cfg = c.C->c;
+    const int W = c.W, W1 = W + 1, P = c.P, LW = c.LW;
+    __shared__ double sred[64];
+    __shared__ int sh_i[8];
+    __shared__ double chol_dinv[VIO_LWMAX];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *xs = (double *)smem, *work = xs + LW;
+    const int F = st.F, Fa = st.Fa;
+    const int ex_active = st.ex_active, td_active = st.td_active;
+    const int ne_ext = st.vext ? 7 : 0;
+    const int oE = 15 * W1, oT = 15 * W1 + 6;
+    const int *alist = c.pair_list + c.nres_cap - c.NL;
+    double *g = c.vec, *sp = c.vec + 1 * LW, *dgp = c.vec + 2 * LW, *gradp = c.vec + 3 * LW, *gnp = c.vec + 4 * LW, *stp = c.vec + 5 * LW,
+           *gs = c.vec + 6 * LW, *tmpv = c.vec + 7 * LW, *delta = c.vec + 8 * LW, *sgp = c.vec + 9 * LW, *hsgp = c.vec + 10 * LW,
+           *yp = c.vec + 11 * LW, *up = c.vec + 12 * LW, *tmpv2 = c.vec + 13 * LW;
+    double *sl = c.lvec, *dgl = c.lvec + c.NLs, *gradl = c.lvec + 2 * c.NLs, *gnl = c.lvec + 3 * c.NLs, *stl = c.lvec + 4 * c.NLs,
+           *inv = c.lvec + 5 * c.NLs, *gls = c.lvec + 6 * c.NLs, *Hlls = c.lvec + 7 * c.NLs;
+    const int Kpad = (Fa + 3) & ~3;
+    double *hsgl = c.res + (size_t)c.nres_cap * 42 - 4 * (size_t)c.NLs;
+    double *yl = hsgl + c.NLs, *ul = yl + c.NLs, *tmpl = ul + c.NLs;
+    const int stage0 = st.stage;
+    double radius = st.radius, mu = st.mu, alpha = st.alpha, dogleg_norm = st.dogleg_norm;
+    bool cauchy_valid = st.cauchy_valid != 0;
+    int invalid = st.invalid;
+    int iter = st.iter;
+    if (!st.retry) iter++;
+    __syncthreads();
+    auto finish = [&](int new_stage) {
+        __syncthreads();
+        if (t == 0) {
+            st.radius = radius; st.mu = mu; st.alpha = alpha; st.dogleg_norm = dogleg_norm; st.cauchy_valid = cauchy_valid ? 1 : 0;
+            st.invalid = invalid; st.iter = iter; st.stage = new_stage;
+        }
+    };
+    if (iter > cfg.max_iterations) { if (t == 0) st.iters_done = cfg.max_iterations; iter = cfg.max_iterations; finish(PS_DONE); return; }
+    if (t == 0) { st.iters_done = iter; st.retry = 0; }
+    if (stage0 == PS_ASM || stage0 == PS_SCHUR) {
+        if (st.scale_pending) {
+            for (int k = t; k < Kpad; k += nt) sl[k] = k < Fa ? 1.0 / (1.0 + sqrt(c.Hll[k])) : 0.0;
+            __syncthreads();
+            if (t == 0) st.scale_pending = 0;
+        }
+        if (st.point_new) {
+            // prepare_point: gradient max-norm, scaled gradient, trust-region diagonal
+            double m = 0;
+            for (int a = t; a < P; a += nt) m = fmax(m, sp[a] != 0.0 ? fabs(g[a]) : 0.0);
+            for (int k = t; k < Fa; k += nt) m = fmax(m, fabs(c.gl[k]));
+            const double gmax = block_max(m, sred);
+            for (int a = t; a < LW; a += nt) {
+                double hs = a < P ? sp[a] * sp[a] * c.H[a * LW + a] : 0.0;
+                gs[a] = a < P ? sp[a] * g[a] : 0.0;
+                dgp[a] = sqrt(fmin(fmax(hs, 1e-6), 1e32));
+                gradp[a] = gs[a] / dgp[a];
+                sgp[a] = gradp[a] / dgp[a];
+                up[a] = sp[a] * sgp[a];
+            }
+            for (int k = t; k < Kpad; k += nt) {
+                double hl = k < Fa ? sl[k] * sl[k] * c.Hll[k] : 0.0;
+                Hlls[k] = hl;
+                gls[k] = k < Fa ? sl[k] * c.gl[k] : 0.0;
+                dgl[k] = sqrt(fmin(fmax(hl, 1e-6), 1e32));
+                gradl[k] = gls[k] / dgl[k];
+                ul[k] = sl[k] * (gradl[k] / dgl[k]);
+            }
+            __syncthreads();
+            if (t == 0) st.point_new = 0;
+            if (gmax <= 1e-10) { if (t == 0) st.iters_done = iter - 1; finish(PS_DONE); return; }
+        }
+        cauchy_valid = false;
+        // Gauss-Newton step through the Schur complement formed by ps_schur_kernel at this mu
+        for (int k = t; k < Kpad; k += nt) {
+            double iv = k < Fa ? 1.0 / (Hlls[k] + mu * dgl[k] * dgl[k]) : 0.0;
+            inv[k] = iv;
+            tmpl[k] = sl[k] * iv * gls[k];
+        }
+        __syncthreads();
+        matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, tmpl, nullptr, tmpv, nullptr, work);
+        for (int a = t; a < LW; a += nt) xs[a] = a < P ? gs[a] - sp[a] * tmpv[a] : 0.0;
+        __syncthreads();
+        {
+            const unsigned colmask = ps_colmask(W1, LW, st.vext != 0);
+            const int nb = LW >> 4, ntile = nb * (nb + 1) / 2;
+            for (int w = t; w < ntile * 256; w += nt) {
+                const int tile = w >> 8, e = w & 255, r = e >> 4, cc = e & 15;
+                int ti, tj;
+                tri_decode(tile, ti, tj);
+                double v;
+                if (((colmask >> ti) & 1u) && ((colmask >> tj) & 1u)) v = c.Sc[tl_idx(ti, tj, r, cc)];
+                else {
+                    const int row = 16 * ti + r, col = 16 * tj + cc;
+                    v = sp[row] * sp[col] * c.H[(size_t)row * LW + col];
+                    if (row == col) { v += mu * dgp[row] * dgp[row]; if (sp[row] == 0.0) v = 1.0; }
+                }
+                work[tl_idx(ti, tj, r, cc)] = v;
+            }
+            __syncthreads();
+        }
+        bool ok = chol_tiles(work, LW >> 4, &sh_i[2], chol_dinv);
+        if (ok) {
+            chol_solve_tiles(work, LW >> 4, xs, chol_dinv);
+            double bad = 0;
+            for (int a = t; a < P; a += nt) if (!isfinite(xs[a])) bad += 1;
+            bad = block_sum(bad, sred);
+            ok = bad == 0;
+        }
+        if (!ok) {
+            mu *= 10.0;
+            if (mu < 1.0) { if (t == 0) st.retry = 1; finish(PS_SCHUR); return; }   // same iteration, Schur complement again at the new mu
+            finish(PS_DONE);   // "if (!ok) break"
+            return;
+        }
+        for (int a = t; a < LW; a += nt) { yp[a] = xs[a]; gnp[a] = -xs[a] * dgp[a]; tmpv[a] = sp[a] * xs[a]; }
+        __syncthreads();
+        matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, nullptr, tmpv, nullptr, tmpl, nullptr);
+        for (int k = t; k < Kpad; k += nt) {
+            double y = k < Fa ? (gls[k] - sl[k] * tmpl[k]) * inv[k] : 0.0;
+            yl[k] = y;
+            gnl[k] = -y * dgl[k];
+        }
+        __syncthreads();
+    }
+    // traditional dogleg in the D-scaled space
+    double gnorm = 0, gnn = 0, gdot = 0;
+    for (int a = t; a < P; a += nt) { gnorm += gradp[a] * gradp[a]; gnn += gnp[a] * gnp[a]; gdot += gradp[a] * gnp[a]; }
+    for (int k = t; k < Fa; k += nt) { gnorm += gradl[k] * gradl[k]; gnn += gnl[k] * gnl[k]; gdot += gradl[k] * gnl[k]; }
+    block_sum3(gnorm, gnn, gdot, sred);
+    gnorm = sqrt(gnorm);
+    gnn = sqrt(gnn);
+    double ca = 0, cb = 0;
+    if (!(gnn <= radius) && !cauchy_valid) {
+        matvec_pass(c.H, LW, P, P, nullptr, up, nullptr, tmpv, work);
+        matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, ul, up, tmpv2, tmpl, work);
+        double g2 = 0, jg2 = 0;
+        for (int a = t; a < LW; a += nt) {
+            double v = a < P ? sp[a] * (tmpv[a] + tmpv2[a]) : 0.0;
+            hsgp[a] = v;
+            if (a < P) { g2 += gradp[a] * gradp[a]; jg2 += sgp[a] * v; }
+        }
+        for (int k = t; k < Kpad; k += nt) {
+            double sgl = k < Fa ? gradl[k] / dgl[k] : 0.0;
+            double v = k < Fa ? sl[k] * tmpl[k] + Hlls[k] * sgl : 0.0;
+            hsgl[k] = v;
+            if (k < Fa) { g2 += gradl[k] * gradl[k]; jg2 += sgl * v; }
+        }
+        block_sum2(g2, jg2, sred);
+        alpha = g2 / jg2;
+        cauchy_valid = true;
+    }
+    if (gnn <= radius) { ca = 0; cb = 1; dogleg_norm = gnn; }
+    else if (gnorm * alpha >= radius) { ca = -(radius / gnorm); cb = 0; dogleg_norm = radius; }
+    else {
+        double b_dot_a = -alpha * gdot;
+        double a_sq = (alpha * gnorm) * (alpha * gnorm);
+        double bma = a_sq - 2 * b_dot_a + gnn * gnn;
+        double cc = b_dot_a - a_sq;
+        double d = sqrt(cc * cc + bma * (radius * radius - a_sq));
+        double beta = (cc <= 0) ? (d - cc) / bma : (radius * radius - a_sq) / (d + cc);
+        ca = -alpha * (1.0 - beta); cb = beta;
+        dogleg_norm = -1;
+    }
+    double n2 = 0, lin = 0, quad = 0;
+    for (int a = t; a < LW; a += nt) {
+        double v = ca * gradp[a] + cb * gnp[a];
+        double stv = a < P ? v / dgp[a] : 0.0;
+        stp[a] = stv;
+        if (a < P) {
+            n2 += v * v;
+            lin += stv * gs[a];
+            quad += stv * ((ca != 0.0 ? ca * hsgp[a] : 0.0) - cb * (gs[a] - mu * dgp[a] * dgp[a] * yp[a]));
+        }
+    }
+    for (int k = t; k < Kpad; k += nt) {
+        double v = k < Fa ? ca * gradl[k] + cb * gnl[k] : 0.0;
+        double stv = k < Fa ? v / dgl[k] : 0.0;
+        stl[k] = stv;
+        if (k < Fa) {
+            n2 += v * v;
+            lin += stv * gls[k];
+            quad += stv * ((ca != 0.0 ? ca * hsgl[k] : 0.0) - cb * (gls[k] - mu * dgl[k] * dgl[k] * yl[k]));
+        }
+    }
+    block_sum3(n2, lin, quad, sred);
+    if (dogleg_norm < 0) dogleg_norm = sqrt(n2);
+    const double model_change = -(lin + 0.5 * quad);
+    if (!(model_change > 0)) {
+        if (++invalid >= 5) { finish(PS_DONE); return; }
+        mu *= 10.0;
+        finish(PS_SCHUR);   // "reuse = false; continue": the next iteration re-forms the Schur complement at the larger mu
+        return;
+    }
+    invalid = 0;
+    // candidate = Plus(x, step .* scale)
+    for (int a = t; a < P; a += nt) delta[a] = stp[a] * sp[a];
+    __syncthreads();
+    const Params &X = st.X;
+    Params &Xc = st.Xc;
+    if (t <= W) {
+        for (int k = 0; k < 7; k++) Xc.pose[t * 7 + k] = X.pose[t * 7 + k];
+        bf::pose_plus(&Xc.pose[t * 7], &delta[6 * t]);
+        for (int k = 0; k < 9; k++) Xc.sb[t * 9 + k] = X.sb[t * 9 + k] + delta[6 * W1 + 9 * t + k];
+    }
+    if (t == W + 1) {
+        for (int k = 0; k < 7; k++) Xc.ex[k] = X.ex[k];
+        if (ex_active) bf::pose_plus(Xc.ex, &delta[oE]);
+        Xc.td = X.td + (td_active ? delta[oT] : 0.0);
+    }
+    for (int k = t; k < F; k += nt) c.cfeat[k] = c.feat[k];
+    __syncthreads();
+    for (int k = t; k < Fa; k += nt) {
+        int slot = alist[k], pi = c.lm_pidx[slot];
+        double v = c.feat[pi] + stl[k] * sl[k];
+        double ub = (c.lm_est[slot] == 2) ? 2.0 / cfg.depth_max : 1.7976931348623157e308;
+        if (v > ub) v = ub;
+        c.cfeat[pi] = v;
+    }
+    if (t == 0) { st.model_change = model_change; st.eval_with_J = iter < cfg.max_iterations ? 1 : 0; }
+    finish(PS_EVAL_C);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- FINAL
+__global__ __launch_bounds__(256) void ps_final_kernel(Batch B) {
+    const int s = blockIdx.x + B.s0, t = threadIdx.x;
+    SolveSt &st = B.sst[s];
+    if (st.stage == PS_IDLE) return;
+    Ctx c = make_ctx(B, s);
+    __shared__ Params X;
+    __shared__ double sdx[16], sh_d[8];
+    __shared__ int sh_i[8];
+    for (int k = t; k < (int)(sizeof(Params) / sizeof(double)); k += blockDim.x) ((double *)&X)[k] = ((const double *)&st.X)[k];
+    __syncthreads();
+    solve_epilogue(c, X, st.cost, st.iters_done, st.succ, st.ts0, sdx, sh_d, sh_i);
+    if (t == 0) st.stage = PS_IDLE;
+}

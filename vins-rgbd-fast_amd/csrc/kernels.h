@@ -34,6 +34,14 @@ __global__ void be_ingest_kernel(Batch B, const uint16_t *depth_base, size_t dep
 __global__ void be_solve_kernel(Batch B);
 __global__ void be_solve_kernel_512(Batch B);
 __global__ void be_marg_kernel(Batch B);
+// phased solver (be_phased.h)
+__global__ void ps_setup_kernel(Batch B);
+__global__ void ps_eval_kernel(Batch B);
+__global__ void ps_asm_a_kernel(Batch B);
+__global__ void ps_asm_b_kernel(Batch B);
+__global__ void ps_schur_kernel(Batch B);
+__global__ void ps_serial_kernel(Batch B);
+__global__ void ps_final_kernel(Batch B);
 __global__ void be_prior_factor_kernel(Batch B, int seq);
 __global__ void be_dyn_finalize_kernel(Batch B, int seq, const double *samples, const int *offs);
 __global__ void be_stage_imu_kernel(vio_config cfg, PreInt *P, int n, const double *dt, const double *acc, const double *gyr,

@@ -101,6 +101,10 @@ struct vio_batch {
     // with 6 instead of 8 wavefronts (256 VGPRs each) two SIMDs per CU keep half of their register file free and the LK wavefronts can
     // co-reside (be_marg 1.4 -> 1.6 ms, fe_lk 0.77 -> 0.60 ms; the front-end is the longer of the two, so the step gets shorter).
     int be_threads = 512, marg_threads = 384;
+    // VIO_SOLVE_MODE: 0 = persistent kernel (one workgroup per sequence for the whole solve), 1 = phased solver (be_phased.h, default)
+    int solve_mode = 1;
+    size_t lds_ps_eval = 0;
+    int ps_eval_blocks = 0, ps_asm_a_blocks = 0, ps_schur_tiles = 0;
     bool timing_valid = false;
     // per-kernel event pool (vio_profile_begin / vio_profile_end)
     std::vector<hipEvent_t> pev;
@@ -516,7 +520,20 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
         h->dyn_active = any;
     }
     const int be_threads = h->be_threads;
-    if (be_threads <= 512) be_solve_kernel_512<<<S, be_threads, h->lds_solve, st>>>(Bg);
+    if (h->solve_mode == 1) {
+        // phased solver: every data-parallel phase of the trust-region loop covers all sequences with many workgroups; max_iterations
+        // + 1 slots carry the iterations, two more absorb Cholesky retries (a converged sequence falls through the remaining launches)
+        ps_setup_kernel<<<S, 512, 0, st>>>(Bg);
+        const int slots = C.c.max_iterations + 2;
+        for (int k = 0; k < slots; k++) {
+            ps_eval_kernel<<<dim3(h->ps_eval_blocks, S), 256, h->lds_ps_eval, st>>>(Bg);
+            ps_asm_a_kernel<<<dim3(h->ps_asm_a_blocks, S), 512, 0, st>>>(Bg);
+            ps_asm_b_kernel<<<dim3(24, S), 256, 0, st>>>(Bg);
+            ps_schur_kernel<<<dim3(h->ps_schur_tiles, S), 64, 0, st>>>(Bg);
+            ps_serial_kernel<<<S, 512, h->lds_solve, st>>>(Bg);
+        }
+        ps_final_kernel<<<S, 256, 0, st>>>(Bg);
+    } else if (be_threads <= 512) be_solve_kernel_512<<<S, be_threads, h->lds_solve, st>>>(Bg);
     else be_solve_kernel<<<S, be_threads, h->lds_solve, st>>>(Bg);
     if (prof) PEV(h, 10);
     (void)hipEventRecord(g.ev_solve, st);  // the next frame's front-end may start here (it only needs latest_Bg / td / imu_head, and a
@@ -685,6 +702,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     if (getenv("VIO_MARG_THREADS")) h->marg_threads = std::min(512, std::max(64, atoi(getenv("VIO_MARG_THREADS")) & ~63));
     B.flags = getenv("VIO_FLAGS") ? atoi(getenv("VIO_FLAGS")) : 0;
     DA(B.odom_hist, S * (size_t)B.hist_cap * 11); DA(B.odom_count, S);
+    DA(B.sst, S);
     DA(h->d_stamps, S); DA(h->d_modes, S); DA(h->d_rrel, S * 9); DA(h->d_r9, 16);
     DA(h->d_in_n, S); DA(h->d_in_stamps, S); DA(h->d_in_ids, S * NP); DA(h->d_in_obs, S * NP * 7);
 #undef DA
@@ -741,6 +759,25 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
             h->lds_solve = ((size_t)C.LW + 2 + workd) * 8 + 16;
             (void)raise_lds_limit((const void *)be_solve_kernel, (size_t)(h->lds_solve));
             (void)raise_lds_limit((const void *)be_solve_kernel_512, (size_t)(h->lds_solve));
+            (void)raise_lds_limit((const void *)ps_serial_kernel, (size_t)(h->lds_solve));
+            {
+                // phased solver: needs the Schur complement as LDS tiles and the column-aware (pose + extrinsic) landmark rows
+                const size_t nb = (size_t)C.LW >> 4, tiles = nb * (nb + 1) / 2 * 256, W1 = (size_t)C.W + 1;
+                const bool eligible = tiles <= 16896 && 6 * W1 + 7 <= 128 && !(B.flags & 1) && (size_t)C.W * C.NP / 256 + 4 <= PS_MAX_EVAL_BLOCKS &&
+                                      (size_t)C.W * 768 <= (W1 * W1 - W1 * C.W / 2) * 210;
+                h->solve_mode = getenv("VIO_SOLVE_MODE") ? atoi(getenv("VIO_SOLVE_MODE")) : 1;   // phased by default where it applies (windows up to ~10 keyframes)
+                if (!eligible) h->solve_mode = 0;
+                h->lds_ps_eval = (W1 * W1 + 1) * 32 * 8 + 64;
+                (void)raise_lds_limit((const void *)ps_eval_kernel, h->lds_ps_eval);
+                h->ps_eval_blocks = (int)std::min<size_t>(PS_MAX_EVAL_BLOCKS, (size_t)C.W * C.NP / 256 + 4);
+                h->ps_asm_a_blocks = (int)((W1 * W1 + C.W + (2 * ((size_t)C.NL + 3) + 63) / 64 + 7) / 8);
+                int nact = 0;
+                for (size_t a = 0; a < nb; a++) for (size_t b2 = 0; b2 <= a; b2++) {
+                    auto act = [&](size_t cb) { const size_t c0 = 16 * cb, c1 = c0 + 15; return c0 < 6 * W1 || (c1 >= 15 * W1 && c0 < 15 * W1 + 7); };
+                    if (act(a) && act(b2)) nact++;
+                }
+                h->ps_schur_tiles = nact;
+            }
         }
         {
             size_t nbq = ((size_t)C.NPRIOR + 15) >> 4;

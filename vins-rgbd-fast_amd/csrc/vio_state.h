@@ -107,6 +107,30 @@ struct BeSeq {
     int dbg[16];                    // debug counters (sweeps, ticks)
 };
 
+// flat parameter arrays of one solve (estimator.h para_Pose / para_SpeedBias / para_Ex_Pose / para_Td): pose = p(3) q(x,y,z,w)
+struct Params { double pose[(VIO_MAXW + 1) * 7], sb[(VIO_MAXW + 1) * 9], ex[7], td; };
+
+// Per-sequence state of the PHASED solver (be_phased.h): the trust-region loop of optimization() cut into kernels that each fill the
+// whole GPU (evaluate / assemble / Schur) or run one workgroup per sequence (accept, Cholesky + dogleg); everything that the
+// persistent kernel keeps in registers / LDS across phases lives here.
+enum { PS_IDLE = 0, PS_EVAL_X0, PS_ASM, PS_SCHUR, PS_STEP, PS_EVAL_C, PS_DONE };
+#define PS_MAX_EVAL_BLOCKS 48
+struct SolveSt {
+    Params X, Xc;
+    double sdx[6 * VIO_MAXW + 16], srp[6 * VIO_MAXW + 16];   // prior tangent / gradient at the last evaluated point
+    double part[PS_MAX_EVAL_BLOCKS];                           // per-block partial costs of the last evaluation (block 0: prior + IMU)
+    double cost, ccost, radius, mu, alpha, dogleg_norm, model_change;
+    long long ts0;
+    int stage;            // PS_*: what the sequence needs next
+    int F, Fa, nres, ex_active, td_active, vext;
+    int iter, iters_done, succ, invalid;
+    int point_new;        // H / g were re-assembled since the last prepare_point
+    int scale_pending;    // the Jacobi column scaling (sp, sl) is still to be fixed from the first linearisation
+    int retry;            // the next step continues the same iteration (Cholesky failed, mu was raised)
+    int cauchy_valid, eval_with_J, n_eval_blocks;
+    int eval_done;        // blocks of the running evaluation that have published their partial cost (device-scope counter)
+};
+
 // all HBM pointers of a batch; passed to kernels by value
 struct Batch {
     DevCfg *cfg;  // device copy
@@ -157,6 +181,7 @@ struct Batch {
     int hist_cap;
     int flags;            // debug switches (VIO_FLAGS): 1 = keep the Schur complement in HBM instead of LDS tiles
     float *timings;
+    SolveSt *sst;         // [S] phased solver state
 };
 
 #define VEC_SLOTS 24
