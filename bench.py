@@ -25,6 +25,10 @@ import time
 
 import numpy as np
 
+# Runtime knobs of the product, set before HIP initialises: two stream groups per handle (the phased solver's serial
+# kernel of one half-batch overlaps the data-parallel kernels of the other) need more hardware queues than the runtime's default 4.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -173,6 +177,8 @@ def main():
     cfg = P.canonical_config()
     sc = vio_ct.synth_like(cfg)
     S, K, Wm, R = args.seqs, args.steps, args.warmup, max(args.repeats, 1)
+    if S >= 64 and S % 2 == 0:
+        os.environ.setdefault("VIO_GROUP_SEQS", str(S // 2))   # read by vio_create
     H, Wd = cfg.height, cfg.width
     n_pre = 16  # first-image skip + init_pub + init_feature + (window_size + 1) frames -> NON_LINEAR, + margin
     Kp = max(args.pcie_steps, 0)

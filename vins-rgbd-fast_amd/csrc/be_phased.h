@@ -122,32 +122,50 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
     const BeSeq &be = *c.be;
     const vio_config &cfg = c.C->c;
     const bool cand = st.stage == PS_EVAL_C;
-    const Params &X = cand ? st.Xc : st.X;
     const double *feat = cand ? c.cfeat : c.feat;
     const bool withJ = st.eval_with_J != 0, vext = st.vext != 0;
     const int W = c.W, W1 = W + 1, n = c.NPR;
     __shared__ double sred[64];
+    // the evaluation point in LDS: the factor code reads its parameters many times between stores to HBM (which the compiler must
+    // assume to alias them), and every such re-read would be a dependent global load
+    __shared__ Params X;
+    {
+        const double *src = (const double *)(cand ? &st.Xc : &st.X);
+        for (int k = t; k < (int)(sizeof(Params) / sizeof(double)); k += nt) ((double *)&X)[k] = src[k];
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double cost = 0;
+    __syncthreads();
     if (b == 0) {
         if (be.has_prior) {
-            prior_dx(c, X, st.sdx, true);
-            matvec_pass(c.prior_H, n, n, n, nullptr, st.sdx, nullptr, st.srp, nullptr);   // A dx: one wavefront per row
-            for (int i = t; i < n; i += nt) {
-                const double b0 = c.prior_r[i], q = b0 + st.srp[i];
-                st.srp[i] = q;
-                cost += 0.5 * st.sdx[i] * (b0 + q);
+            // prior gradient q = b + A dx and cost dx^T b + 1/2 dx^T A dx: one thread per row, A read by columns (it is stored exactly
+            // symmetric), dx from LDS
+            double *dxs = (double *)smem;
+            prior_dx(c, X, dxs, true);
+            double q = 0, d = 0, b0 = 0;
+            if (t < n) {
+                double acc = 0;
+                for (int j = 0; j < n; j++) acc += c.prior_H[(size_t)j * n + t] * dxs[j];
+                b0 = c.prior_r[t]; d = dxs[t];
+                q = b0 + acc;
+                st.srp[t] = q;
+                st.sdx[t] = d;
+                cost += 0.5 * d * (b0 + q);
             }
             if (t == 0) cost += 0.5 * be.prior_c0;
         }
     } else if (b <= 2) {
+        // IMU factors: pre-integration headers (state, Jacobian, whitening matrix: the first 704 doubles of PreInt) staged in LDS
+        double *pl = (double *)smem;
+        for (int q = t; q < W * 704; q += nt) { const int i = q / 704, e = q - i * 704; pl[q] = ((const double *)&c.pre[be.pre_idx[i + 1]])[e]; }
+        __syncthreads();
         const v3 G = ld3(be.g);
         const int part_ = (b == 1 ? 0 : 4) + (t >> 6), i0 = t & 63;   // block 1: types 0 .. 3 on its four wavefronts, block 2: type 4
         if (part_ <= 4 && !(b == 2 && (t >> 6) > 0))
             for (int i = i0; i < W; i += 64) {
                 const int j = i + 1;
-                const PreInt &p = c.pre[be.pre_idx[j]];
-                double *out = c.imu_raw + (size_t)i * 15 * 31;
+                const PreInt &p = *(const PreInt *)(pl + (size_t)i * 704);
+                double *__restrict__ out = c.imu_raw + (size_t)i * 15 * 31;
                 if (p.sum_dt > 10.0) { if (part_ == 0) for (int k = 0; k < 15; k++) out[k * 31 + 30] = 0; continue; }
                 if (part_ == 0) {
                     double raw[15];

@@ -767,7 +767,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
                                       (size_t)C.W * 768 <= (W1 * W1 - W1 * C.W / 2) * 210;
                 h->solve_mode = getenv("VIO_SOLVE_MODE") ? atoi(getenv("VIO_SOLVE_MODE")) : 1;   // phased by default where it applies (windows up to ~10 keyframes)
                 if (!eligible) h->solve_mode = 0;
-                h->lds_ps_eval = (W1 * W1 + 1) * 32 * 8 + 64;
+                h->lds_ps_eval = std::max((W1 * W1 + 1) * 32 * 8, (size_t)C.W * 704 * 8) + 64;   // pair geometry / staged pre-integration headers
                 (void)raise_lds_limit((const void *)ps_eval_kernel, h->lds_ps_eval);
                 h->ps_eval_blocks = (int)std::min<size_t>(PS_MAX_EVAL_BLOCKS, (size_t)C.W * C.NP / 256 + 4);
                 h->ps_asm_a_blocks = (int)((W1 * W1 + C.W + (2 * ((size_t)C.NL + 3) + 63) / 64 + 7) / 8);
