@@ -319,23 +319,31 @@ def main():
             break
 
     def traffic_of(kname):
-        if not tj or tj[1].get("sequences_per_gpu") != S:
+        if not tj or tj[1].get("sequences_per_gpu") != S or tj[1].get("sequences_per_launch", S) != S_launch:
             return None
         ent = next((v for k, v in tj[1].get("kernels", {}).items() if k.startswith(kname)), None)
         return ent["hbm_bytes_per_launch"] if ent else None
 
+    # the HIP events bracket the launches of stream group 0, which cover S / n_groups sequences each
+    per_group = int(os.environ.get("VIO_GROUP_SEQS", S))
+    n_groups = max(1, -(-S // max(per_group, 1)))
+    S_launch = min(S, per_group)
+
     def roof_flops(kname, sym, fl, note):
-        ach = fl * S / (kms[kname] * 1e-3) / 1e12
+        ach = fl * S_launch / (kms[kname] * 1e-3) / 1e12
         return dict(bound="mfma", kernel=sym, achieved=ach, peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS, traffic=traffic_of(kname),
-                    ms=kms[kname], algorithmic_flops_per_launch=fl * S, note=note)
+                    ms=kms[kname], algorithmic_flops_per_launch=fl * S_launch, sequences_per_launch=S_launch, note=note)
 
     def roof_bytes(kname, sym, by, note):
-        ach = by * S / (kms[kname] * 1e-3) / 1e9
+        ach = by * S_launch / (kms[kname] * 1e-3) / 1e9
         tr = traffic_of(kname)
         return dict(bound="hbm", kernel=sym, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=tr, ms=kms[kname],
-                    algorithmic_bytes_per_launch=by * S, traffic_over_algorithmic=(tr / (by * S) if tr else None), note=note)
+                    algorithmic_bytes_per_launch=by * S_launch, sequences_per_launch=S_launch,
+                    traffic_over_algorithmic=(tr / (by * S_launch) if tr else None), note=note)
 
-    solve_sym = "be_solve_kernel_512" if int(os.environ.get("VIO_BE_THREADS", "512")) <= 512 else "be_solve_kernel"
+    phased = os.environ.get("VIO_SOLVE_MODE", "1") != "0"
+    solve_sym = ("ps_* (phased solver: ps_setup, slots of ps_eval / ps_asm_a / ps_asm_b / ps_schur / ps_serial, ps_final)" if phased else
+                 ("be_solve_kernel_512" if int(os.environ.get("VIO_BE_THREADS", "512")) <= 512 else "be_solve_kernel"))
     rk = {
         "be_solve": roof_flops("be_solve", solve_sym, flops["solve"],
                                "FP64; solve-only algorithmic flops per launch = S x I x per-iteration flops (SURVEY.md 8d, measured I = mean "
@@ -351,8 +359,9 @@ def main():
     roof = dict(rk[dom]) if dom in rk else dict(rk["be_solve"])
     if tj and roof.get("traffic") is not None:
         roof["traffic_source"] = "profiles/%s (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)" % tj[0]
-    roof["frontend_GBps"] = sum(fbytes.values()) * S / (fe_ms * 1e-3) / 1e9 if fe_ms > 0 else None
-    roof["backend_TFLOPs"] = (flops["solve"] + flops["marg"] + flops["ingest"]) * S / (be_ms * 1e-3) / 1e12 if be_ms > 0 else None
+    roof["frontend_GBps"] = sum(fbytes.values()) * S_launch / (fe_ms * 1e-3) / 1e9 if fe_ms > 0 else None
+    roof["backend_TFLOPs"] = (flops["solve"] + flops["marg"] + flops["ingest"]) * S_launch / (be_ms * 1e-3) / 1e12 if be_ms > 0 else None
+    roof["stream_groups"] = n_groups
     roofline_kernels = [rk[k] for k in sorted(rk, key=lambda k: -kms[k]) if k != dom]
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the same workload, rank 0 at N = 1 only

@@ -44,6 +44,8 @@ typedef struct vio_config {
     int32_t dynamic_init;           /* !STATIC_INIT (parameters.cpp:167): 0 = static initialisation (gyro-bias + optimisation on the
                                        IMU-propagated window, estimator.cpp:266-283), 1 = SfM + visual-inertial alignment
                                        (initialStructure, estimator.cpp:384-579) */
+    int32_t use_imu;                /* USE_IMU (yaml key `imu`, parameters.cpp:148): 0 = visual odometry on RGB-D: no IMU factors, pose 0
+                                       constant, initFramePoseByPnP per frame, LK maxLevel = lk_max_level (3 upstream) without prediction */
     double fx, fy, cx, cy, k1, k2, p1, p2; /* pinhole projection_parameters / distortion_parameters */
     double focal_length;            /* FOCAL_LENGTH = 460 (parameters.h:11) */
     double f_threshold;             /* F_THRESHOLD */

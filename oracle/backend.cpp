@@ -673,6 +673,35 @@ void Estimator::solveGyroscopeBias() {
 }
 
 // ------------------------------------------------------------------ state <-> flat arrays
+// FeatureManager::initFramePoseByPnP + solvePoseByPnP (feature_manager.cpp:545-642): VO mode only.  Every landmark with a depth that is
+// observed in frame frameCnt gives a 3-D (world) / 2-D (normalised) pair; cv::solvePnP(ITERATIVE) starts from the previous frame's pose.
+void Estimator::initFramePoseByPnP(int frameCnt) {
+    if (frameCnt <= 0) return;
+    std::vector<V3> pts3;
+    std::vector<std::array<double, 2>> pts2;
+    for (auto &l : feature) {
+        if (!(l.estimated_depth > 0)) continue;
+        const int index = frameCnt - l.start_frame;
+        if ((int)l.obs.size() >= index + 1 && index >= 0) {
+            V3 ptsInCam = ric * (V3(l.obs[0].x, l.obs[0].y, l.obs[0].z) * l.estimated_depth) + tic;
+            V3 ptsInWorld = Rs[l.start_frame] * ptsInCam + Ps[l.start_frame];
+            pts3.push_back(ptsInWorld);
+            pts2.push_back({l.obs[index].x, l.obs[index].y});
+        }
+    }
+    M3 RCam = Rs[frameCnt - 1] * ric;
+    V3 PCam = Rs[frameCnt - 1] * tic + Ps[frameCnt - 1];
+    // solvePoseByPnP: w_T_cam -> cam_T_w, refine, back
+    M3 R_initial = T(RCam);
+    V3 P_initial = -1.0 * (R_initial * PCam);
+    if ((int)pts2.size() < 4) return;
+    if (!solve_pnp_iterative(pts3, pts2, R_initial, P_initial)) return;
+    RCam = T(R_initial);
+    PCam = RCam * (-1.0 * P_initial);
+    Rs[frameCnt] = RCam * T(ric);
+    Ps[frameCnt] = -1.0 * (RCam * (T(ric) * tic)) + PCam;
+}
+
 void Estimator::vector2double() {  // estimator.cpp:936-981
     for (int i = 0; i <= W; i++) {
         para_Pose[i][0] = Ps[i].x; para_Pose[i][1] = Ps[i].y; para_Pose[i][2] = Ps[i].z;
@@ -695,6 +724,14 @@ void Estimator::double2vector() {  // estimator.cpp:985-1111
         failure_occur = false;
     }
     auto poseQ = [&](int i) { return Q(para_Pose[i][6], para_Pose[i][3], para_Pose[i][4], para_Pose[i][5]); };
+    if (!cfg.use_imu) {   // :1060-1067: no gauge fix, no speed / bias / extrinsic / td hand-back
+        for (int i = 0; i <= W; i++) {
+            Rs[i] = toR(normalized(poseQ(i)));
+            Ps[i] = V3(para_Pose[i][0], para_Pose[i][1], para_Pose[i][2]);
+        }
+        setDepth(para_Feature);
+        return;
+    }
     V3 origin_R00 = R2ypr(toR(poseQ(0)));
     double y_diff = origin_R0.x - origin_R00.x;
     M3 rot_diff = ypr2R(V3(y_diff, 0, 0));
@@ -784,7 +821,7 @@ static void build_normal_eq(Estimator &e, const double pose[][7], const double s
         }
     }
     // IMU factors
-    for (int i = 0; i < W; i++) {
+    for (int i = 0; i < W && e.cfg.use_imu; i++) {
         int j = i + 1;
         if (e.pre_integrations[j]->sum_dt > 10.0) continue;
         double r[15], Ji[15 * 7], Jsi[15 * 9], Jj[15 * 7], Jsj[15 * 9];
@@ -879,6 +916,11 @@ void Estimator::solve() {
     bool td_active = cfg.estimate_td && !(norm(Vs[0]) < 0.2);
     for (int d = 0; d < 6; d++) active[oE + d] = ex_active;
     active[oT] = td_active;
+    if (!cfg.use_imu) {   // :1178-1185, 1204: no speed-bias / td blocks in the problem, the oldest pose is constant
+        for (int d = 0; d < 6; d++) active[d] = 0;
+        for (int a = 6 * (W + 1); a < 15 * (W + 1); a++) active[a] = 0;
+        active[oT] = 0;
+    }
     std::vector<int> act;
     for (int i = 0; i < P; i++) if (active[i]) act.push_back(i);
     const int Pa = (int)act.size();
@@ -1208,7 +1250,7 @@ void Estimator::marginalize_old() {  // estimator.cpp:1376-1502
         if (prior_present[W + 1]) present[W + 1] = 1;
         if (prior_present[W + 2]) present[W + 2] = 1;
     }
-    if (pre_integrations[1]->sum_dt < 10.0) {
+    if (cfg.use_imu && pre_integrations[1]->sum_dt < 10.0) {
         double r[15], Ji[15 * 7], Jsi[15 * 9], Jj[15 * 7], Jsj[15 * 9];
         eval_imu(*pre_integrations[1], g, para_Pose[0], para_SpeedBias[0], para_Pose[1], para_SpeedBias[1], r, Ji, Jsi, Jj, Jsj);
         double J[15 * 30];
@@ -1359,27 +1401,31 @@ void Estimator::slideWindow() {  // estimator.cpp:1580-1689
                 Headers[i] = Headers[i + 1];
                 std::swap(Ps[i], Ps[i + 1]);
                 std::swap(Rs[i], Rs[i + 1]);
-                std::swap(pre_integrations[i], pre_integrations[i + 1]);
+                if (cfg.use_imu) std::swap(pre_integrations[i], pre_integrations[i + 1]);
                 std::swap(Vs[i], Vs[i + 1]);
                 std::swap(Bas[i], Bas[i + 1]);
                 std::swap(Bgs[i], Bgs[i + 1]);
             }
             Headers[W] = Headers[W - 1];
             Ps[W] = Ps[W - 1]; Rs[W] = Rs[W - 1]; Vs[W] = Vs[W - 1]; Bas[W] = Bas[W - 1]; Bgs[W] = Bgs[W - 1];
-            delete pre_integrations[W];
-            pre_integrations[W] = new Integration(cfg, acc_0, gyr_0, Bas[W], Bgs[W]);
+            if (cfg.use_imu) {
+                delete pre_integrations[W];
+                pre_integrations[W] = new Integration(cfg, acc_0, gyr_0, Bas[W], Bgs[W]);
+            }
             slideWindowOld();
         }
     } else {
         if (frame_count == W) {
             Headers[W - 1] = Headers[W];
             Ps[W - 1] = Ps[W]; Rs[W - 1] = Rs[W];
-            Integration *last = pre_integrations[W];
-            for (size_t i = 0; i < last->dt_buf.size(); i++)
-                pre_integrations[W - 1]->push_back(last->dt_buf[i], last->acc_buf[i], last->gyr_buf[i]);
-            Vs[W - 1] = Vs[W]; Bas[W - 1] = Bas[W]; Bgs[W - 1] = Bgs[W];
-            delete pre_integrations[W];
-            pre_integrations[W] = new Integration(cfg, acc_0, gyr_0, Bas[W], Bgs[W]);
+            if (cfg.use_imu) {
+                Integration *last = pre_integrations[W];
+                for (size_t i = 0; i < last->dt_buf.size(); i++)
+                    pre_integrations[W - 1]->push_back(last->dt_buf[i], last->acc_buf[i], last->gyr_buf[i]);
+                Vs[W - 1] = Vs[W]; Bas[W - 1] = Bas[W]; Bgs[W - 1] = Bgs[W];
+                delete pre_integrations[W];
+                pre_integrations[W] = new Integration(cfg, acc_0, gyr_0, Bas[W], Bgs[W]);
+            }
             slideWindowNew();
         }
     }
@@ -1429,10 +1475,10 @@ bool Estimator::failureDetection() {  // estimator.cpp:1113-1159
 int Estimator::processImage(std::map<int, std::array<double, 7>> &image, const uint16_t *depth, double stamp) {  // :156-374
     depth_img = depth;  // FeatureManager::inputDepth
     double curTime = stamp + td;
-    if (!IMUAvailable(curTime)) return 1;  // upstream busy-waits (:178-183); the adapter keeps the wait loop
+    if (cfg.use_imu && !IMUAvailable(curTime)) return 1;  // upstream busy-waits (:178-183); the adapter keeps the wait loop
     marginalization_flag = addFeatureCheckParallax(frame_count, image, td) ? 0 : 1;
     Headers[frame_count] = stamp;
-    {
+    if (cfg.use_imu) {
         // getIMUInterval :1910-1942
         std::vector<ImuSample> v;
         while (imu_head < imu_buf.size() && imu_buf[imu_head].t <= prevTime) imu_head++;
@@ -1484,7 +1530,13 @@ int Estimator::processImage(std::map<int, std::array<double, 7>> &image, const u
     } else if (solver_flag == 0) {
         // static_init / depth branch :260-316
         triangulateWithDepth();
-        if (frame_count == W) {
+        if (!cfg.use_imu) {   // :300-310
+            if (frame_count == W) {
+                optimization();
+                solver_flag = 1;
+                slideWindow();
+            }
+        } else if (frame_count == W) {
             solveGyroscopeBias();
             for (int j = 0; j <= W; j++) pre_integrations[j]->repropagate(V3(), Bgs[j]);
             optimization();
@@ -1499,6 +1551,7 @@ int Estimator::processImage(std::map<int, std::array<double, 7>> &image, const u
             Ps[frame_count] = Ps[p]; Vs[frame_count] = Vs[p]; Rs[frame_count] = Rs[p]; Bas[frame_count] = Bas[p]; Bgs[frame_count] = Bgs[p];
         }
     } else {
+        if (!cfg.use_imu) initFramePoseByPnP(frame_count);  // :321-322
         triangulateWithDepth();
         optimization();
         movingConsistencyCheck();
@@ -1533,7 +1586,8 @@ int Pipeline::track(const uint8_t *gray, double t, int mode, const double *R_in,
     if (mode == 0) return 0;  // "Skip this frame" :266-271 (before readImage: last_image_time keeps its value)
     double R[9];
     if (R_in) for (int k = 0; k < 9; k++) R[k] = R_in[k];
-    else est.predictMotion(last_image_time, t + est.td, R);  // :309-313
+    else if (cfg.use_imu) est.predictMotion(last_image_time, t + est.td, R);  // :309-313
+    else { for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1.0 : 0.0; }   // readImage(img, t): relative_R defaults to identity (and is not used)
     tracker.readImage(gray, t, R, mode == 2);
     last_image_time = t;
     tracker.updateIDs();  // :324-330
@@ -1554,7 +1608,7 @@ int Pipeline::process(std::map<int, std::array<double, 7>> &image, const uint16_
     return 1;
 }
 int Pipeline::feed(const uint8_t *gray, const uint16_t *depth, double t, int mode) {
-    if (!est.IMUAvailable(t + est.td)) return -1;  // caller contract: IMU pushed through t + td (upstream busy-waits, estimator.cpp:178-183)
+    if (cfg.use_imu && !est.IMUAvailable(t + est.td)) return -1;  // caller contract: IMU pushed through t + td (upstream busy-waits, estimator.cpp:178-183)
     std::map<int, std::array<double, 7>> image;
     if (!track(gray, t, mode, nullptr, image)) return 0;
     return process(image, depth, t);

@@ -618,9 +618,14 @@ void Tracker::readImage(const uint8_t *img, double t, const double R[9], bool pu
 
     if (!cur_pts.empty()) {
         std::vector<uint8_t> status;
-        predictPtsInNextFrame(R);
-        forw_pts = predict_pts;
-        lk_track(cur_pyr, forw_pyr, cur_pts, forw_pts, status, maxLevel, true);
+        if (cfg.use_imu) {   // feature_tracker.cpp:298-306
+            predictPtsInNextFrame(R);
+            forw_pts = predict_pts;
+            lk_track(cur_pyr, forw_pyr, cur_pts, forw_pts, status, maxLevel, true);
+        } else {             // :307-311: calcOpticalFlowPyrLK(..., Size(21, 21), 3) without OPTFLOW_USE_INITIAL_FLOW
+            forw_pts = cur_pts;
+            lk_track(cur_pyr, forw_pyr, cur_pts, forw_pts, status, maxLevel, false);
+        }
         for (size_t i = 0; i < forw_pts.size(); i++) {
             if (!status[i] && inBorder(forw_pts[i])) unstable_pts.push_back(forw_pts[i]);
             else if (status[i] && !inBorder(forw_pts[i])) status[i] = 0;

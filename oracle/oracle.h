@@ -29,7 +29,9 @@ struct Config {
     int ransac_max_iters = 1000;
     int lk_max_level = 1;              // IMU-aided call uses maxLevel=1 (feature_tracker.cpp:303)
     int dynamic_init = 0;              // = !STATIC_INIT (parameters.cpp:167): 0 = gyro-bias + optimisation on the IMU-propagated window (the built hot
-                                       // path), 1 = SfM + visual-inertial alignment (oracle only).  Occupies vio_config.reserved0 (always 0 in the product).
+                                       // path), 1 = SfM + visual-inertial alignment
+    int use_imu = 1;                   // USE_IMU (parameters.cpp:148, yaml key `imu`): 0 = visual odometry on RGB-D (no IMU factors, pose of the
+                                       // oldest frame constant, per-frame solvePnP initial guess, LK with maxLevel 3 and no prediction)
     double fx = 604.5821781259577, fy = 604.2544712985845, cx = 321.2638233484251, cy = 239.70969315130674;
     double k1 = 0.13387871564774004, k2 = -0.2731913133377051, p1 = 0.0020296263577681264, p2 = -0.00044384544608203714;
     double focal_length = 460.0;       // FOCAL_LENGTH
@@ -223,6 +225,7 @@ struct Estimator {
     int getFeatureCount();
     void triangulateWithDepth();
     void solveGyroscopeBias();
+    void initFramePoseByPnP(int frameCnt);
     void vector2double();
     void double2vector();
     void optimization();

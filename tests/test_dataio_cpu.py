@@ -97,7 +97,15 @@ def test_static_init_zero_selects_the_dynamic_initialisation(P, io):
     assert io.config_from_yaml(YAML, P)[0].dynamic_init == 0
 
 
-@pytest.mark.parametrize("line,what", [("imu: 0", "VO mode"), ("fisheye: 1", "fisheye"),
+def test_imu_zero_selects_vo_mode(P, io):
+    """imu: 0 (config/tum_rgbd/tum_fr3.yaml:9) -> use_imu 0, LK maxLevel 3 (feature_tracker.cpp:307-311)"""
+    txt = "\n".join(l for l in YAML.splitlines() if not l.startswith("imu:")) + "\nimu: 0\n"
+    cfg, extra = io.config_from_yaml(txt, P)
+    assert (cfg.use_imu, cfg.lk_max_level, cfg.estimate_td) == (0, 3, 0) and extra["notes"] == []
+    assert io.config_from_yaml(YAML, P)[0].use_imu == 1
+
+
+@pytest.mark.parametrize("line,what", [("fisheye: 1", "fisheye"),
                                        ("equalize: 1", "CLAHE"), ("estimate_extrinsic: 2", "extrinsic")])
 def test_out_of_scope_settings_fail_loudly(P, io, line, what):
     key = line.split(":")[0]

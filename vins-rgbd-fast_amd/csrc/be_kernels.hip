@@ -179,6 +179,192 @@ __device__ void lm_compact(Ctx &c, int *flags, int *offs, int *scratch) {
 
 }  // namespace
 
+// ------------------------------------------------------------------ VO mode: FeatureManager::initFramePoseByPnP
+// cv::Rodrigues and its derivative (closed form, Gallego & Yezzi 2015), as the host side of the dynamic initialisation restates them
+__device__ m3 pnp_rodrigues(v3 r) {
+    const double th = nrm(r);
+    if (th < 2.220446049250313e-16) return eye();
+    const v3 k = scl(1.0 / th, r);
+    const double cth = cos(th), sth = sin(th), c1 = 1 - cth;
+    const m3 K = skew(k);
+    const double kk[3] = {k.x, k.y, k.z};
+    m3 R;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R.a[i * 3 + j] = (i == j ? cth : 0.0) + c1 * kk[i] * kk[j] + sth * K.a[i * 3 + j];
+    return R;
+}
+__device__ v3 pnp_rodrigues_inv(const m3 &R) {
+    v3 r = mk(R.a[7] - R.a[5], R.a[2] - R.a[6], R.a[3] - R.a[1]);
+    const double sn = sqrt(dot(r, r) * 0.25);
+    double cs = (R.a[0] + R.a[4] + R.a[8] - 1) * 0.5;
+    cs = cs > 1 ? 1 : (cs < -1 ? -1 : cs);
+    const double th = acos(cs);
+    if (sn < 1e-5) {
+        if (cs > 0) return mk(0, 0, 0);
+        v3 v;
+        v.x = sqrt(fmax((R.a[0] + 1) * 0.5, 0.0));
+        v.y = sqrt(fmax((R.a[4] + 1) * 0.5, 0.0)) * (R.a[1] < 0 ? -1.0 : 1.0);
+        v.z = sqrt(fmax((R.a[8] + 1) * 0.5, 0.0)) * (R.a[2] < 0 ? -1.0 : 1.0);
+        if (fabs(v.x) < fabs(v.y) && fabs(v.x) < fabs(v.z) && (R.a[5] > 0) != (v.y * v.z > 0)) v.z = -v.z;
+        return scl(th / nrm(v), v);
+    }
+    return scl(th / (2 * sn), r);
+}
+// FeatureManager::initFramePoseByPnP + solvePoseByPnP (feature_manager.cpp:545-642): cv::solvePnP(SOLVEPNP_ITERATIVE,
+// useExtrinsicGuess) = CvLevMarq on (rvec, tvec) with lambda = 10^k, diagonal x (1 + lambda), at most 20 iterations, FLT_EPSILON
+// on the relative parameter change.  Block-cooperative: one thread per 3-D / 2-D pair evaluates its two residual rows and 2 x 6
+// Jacobian, the 27 sums of J^T J / J^T e are reduced in a fixed order, thread 0 solves the damped 6 x 6 system through its
+// eigen-decomposition (cv::solve DECOMP_SVD).  pts: scratch in HBM, 5 doubles per pair.  sw: >= 16 * 28 + 64 doubles of LDS.
+__device__ void init_frame_pose_by_pnp(Ctx &c, int fc, double *pts, double *sw) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    BeSeq &be = *c.be;
+    if (fc <= 0) return;
+    __shared__ int sh_n;
+    __shared__ double sh_par[6], sh_prev[6], sh_flag[4];
+    if (t == 0) sh_n = 0;
+    __syncthreads();
+    const m3 ric = ldm(be.ric);
+    const v3 tic = ld3(be.tic);
+    const int nlm = be.n_lm;
+    // pairs in list order (deterministic): flags + scan
+    int *flag = c.lm_pidx, *offs = c.lm_aidx;   // free outside the solve
+    __shared__ int scan_scratch[2 * 256 + 8];
+    for (int k = t; k < nlm; k += nt) {
+        const int slot = c.lm_order[k];
+        const int index = fc - c.lm_start[slot];
+        flag[k] = (c.lm_depth[slot] > 0 && index >= 0 && c.lm_nobs[slot] >= index + 1) ? 1 : 0;
+    }
+    __syncthreads();
+    const int n = block_scan_flags(flag, nlm, offs, scan_scratch);
+    for (int k = t; k < nlm; k += nt) {
+        if (!flag[k]) continue;
+        const int slot = c.lm_order[k], st = c.lm_start[slot];
+        const double *o0 = obs_ptr(c, slot, st), *oi = obs_ptr(c, slot, fc);
+        const double d = c.lm_depth[slot];
+        const v3 pc = add(mul(ric, mk(o0[0] * d, o0[1] * d, o0[2] * d)), tic);
+        const v3 pw = add(mul(ldm(be.Rs[st]), pc), ld3(be.Ps[st]));
+        double *q = pts + (size_t)offs[k] * 5;
+        q[0] = (double)(float)pw.x; q[1] = (double)(float)pw.y; q[2] = (double)(float)pw.z;   // cv::Point3f / cv::Point2f
+        q[3] = (double)(float)oi[0]; q[4] = (double)(float)oi[1];
+    }
+    __syncthreads();
+    if (n < 4) return;
+    if (t == 0) {
+        const m3 RCam = mul(ldm(be.Rs[fc - 1]), ric);
+        const v3 PCam = add(mul(ldm(be.Rs[fc - 1]), tic), ld3(be.Ps[fc - 1]));
+        const m3 R0 = tr(RCam);
+        const v3 P0 = neg(mul(R0, PCam));
+        const v3 r = pnp_rodrigues_inv(R0);
+        sh_par[0] = r.x; sh_par[1] = r.y; sh_par[2] = r.z; sh_par[3] = P0.x; sh_par[4] = P0.y; sh_par[5] = P0.z;
+    }
+    __syncthreads();
+    // reduction of NV values per thread: wave DPP sums, then a fixed-order sum over the waves
+    auto reduce = [&](double *v, int NV) {
+        for (int q = 0; q < NV; q++) v[q] = wave_sum_dpp(v[q]);
+        __syncthreads();
+        if (lane == 0) for (int q = 0; q < NV; q++) sw[wave * 28 + q] = v[q];
+        __syncthreads();
+        for (int q = 0; q < NV; q++) { double r = 0; for (int w = 0; w < nw; w++) r += sw[w * 28 + q]; v[q] = r; }
+    };
+    // residuals (and Jacobian sums) at sh_par; every thread returns the same values
+    auto project = [&](bool jac, double *acc /*27: JtJ upper 21 + JtErr 6*/) -> double {
+        const v3 r = mk(sh_par[0], sh_par[1], sh_par[2]), tt = mk(sh_par[3], sh_par[4], sh_par[5]);
+        const m3 Rm = pnp_rodrigues(r);
+        m3 dR[3];
+        if (jac) {
+            const double th2 = dot(r, r);
+            for (int i = 0; i < 3; i++) {
+                const v3 e = mk(i == 0, i == 1, i == 2);
+                if (th2 < 1e-24) { dR[i] = skew(e); continue; }
+                const v3 w = cross(r, mul(sub(eye(), Rm), e));
+                dR[i] = scl(1.0 / th2, mul(add(scl(get(r, i), skew(r)), skew(w)), Rm));
+            }
+        }
+        double v[28];
+        for (int q = 0; q < 28; q++) v[q] = 0;
+        for (int i = t; i < n; i += nt) {
+            const double *q = pts + (size_t)i * 5;
+            const v3 Y = add(mul(Rm, mk(q[0], q[1], q[2])), tt);
+            const double iz = 1.0 / Y.z, x = Y.x * iz, y = Y.y * iz;
+            const double e0 = x - q[3], e1 = y - q[4];
+            v[27] += e0 * e0 + e1 * e1;
+            if (!jac) continue;
+            double J0[6], J1[6];
+            for (int k = 0; k < 3; k++) {
+                const v3 d = mul(dR[k], mk(q[0], q[1], q[2]));
+                J0[k] = iz * d.x - x * iz * d.z;
+                J1[k] = iz * d.y - y * iz * d.z;
+            }
+            J0[3] = iz; J0[4] = 0; J0[5] = -x * iz;
+            J1[3] = 0; J1[4] = iz; J1[5] = -y * iz;
+            int e = 0;
+            for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) v[e++] += J0[a] * J0[b] + J1[a] * J1[b];
+            for (int a = 0; a < 6; a++) v[21 + a] += J0[a] * e0 + J1[a] * e1;
+        }
+        reduce(v, jac ? 28 : 28);
+        if (jac) for (int q = 0; q < 27; q++) acc[q] = v[q];
+        return sqrt(v[27]);
+    };
+    double acc[27];
+    int lambda_lg10 = -3, iters = 0;
+    double prev_err = 0;
+    auto take_step = [&]() {   // thread 0: param = prev - pinv(JtJ with damped diagonal) JtErr
+        if (t == 0) {
+            const double lambda = exp(lambda_lg10 * 2.302585092994046);
+            double N[36], V[36];
+            int e = 0;
+            for (int a = 0; a < 6; a++) for (int b = a; b < 6; b++) { N[a * 6 + b] = acc[e]; N[b * 6 + a] = acc[e]; e++; }
+            for (int a = 0; a < 6; a++) N[a * 7] *= 1.0 + lambda;
+            jacobi_small(N, V, 6);
+            double wmax = 0;
+            for (int k = 0; k < 6; k++) wmax = fmax(wmax, fabs(N[k * 7]));
+            double d[6] = {0, 0, 0, 0, 0, 0};
+            for (int k = 0; k < 6; k++) {
+                const double wk = N[k * 7];
+                if (!(fabs(wk) > wmax * 2 * 2.220446049250313e-16 * 6)) continue;
+                double sacc = 0;
+                for (int i = 0; i < 6; i++) sacc += V[i * 6 + k] * acc[21 + i];
+                sacc /= wk;
+                for (int i = 0; i < 6; i++) d[i] += V[i * 6 + k] * sacc;
+            }
+            for (int i = 0; i < 6; i++) sh_par[i] = sh_prev[i] - d[i];
+        }
+        __syncthreads();
+    };
+    for (;;) {
+        const double e_at = project(true, acc);
+        if (t == 0) for (int i = 0; i < 6; i++) sh_prev[i] = sh_par[i];
+        __syncthreads();
+        take_step();
+        if (iters == 0) prev_err = e_at;
+        bool done = false;
+        for (;;) {
+            const double e = project(false, acc);
+            if (e > prev_err && ++lambda_lg10 <= 16) { take_step(); continue; }
+            lambda_lg10 = max(lambda_lg10 - 1, -16);
+            double dn = 0, pn = 0;
+            for (int i = 0; i < 6; i++) { dn += (sh_par[i] - sh_prev[i]) * (sh_par[i] - sh_prev[i]); pn += sh_prev[i] * sh_prev[i]; }
+            if (++iters >= 20 || sqrt(dn) / sqrt(pn) < 1.1920928955078125e-07) done = true;
+            prev_err = e;
+            break;
+        }
+        if (done) break;
+    }
+    __syncthreads();
+    if (t == 0) {
+        bool fin = true;
+        for (int i = 0; i < 6; i++) fin = fin && isfinite(sh_par[i]);
+        if (fin) {
+            const m3 Rn = pnp_rodrigues(mk(sh_par[0], sh_par[1], sh_par[2]));
+            const v3 tn = mk(sh_par[3], sh_par[4], sh_par[5]);
+            const m3 RCam = tr(Rn);
+            const v3 PCam = mul(RCam, neg(tn));
+            stm(be.Rs[fc], mul(RCam, tr(ric)));
+            st3(be.Ps[fc], add(neg(mul(RCam, mul(tr(ric), tic))), PCam));
+        }
+    }
+    __syncthreads();
+}
+
 // FeatureManager::triangulateWithDepth (feature_manager.cpp:386-543), one thread per landmark of the list
 __device__ void triangulate_with_depth(Ctx &c, int nlm) {
     const int t = threadIdx.x, nt = blockDim.x;
@@ -319,7 +505,7 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
     const double *it = B.imu_t + (size_t)s * C.NIMU;
     const double *ia = B.imu_acc + (size_t)s * C.NIMU * 3, *ig = B.imu_gyr + (size_t)s * C.NIMU * 3;
     double stamp = in_stamp, curTime = stamp + be.td;
-    {
+    if (cfg.use_imu) {
         bool have = be.imu_count > be.imu_head;
         double back_t = have ? it[(be.imu_count - 1) % C.NIMU] : -1e300;
         if (!(have && curTime <= back_t)) {
@@ -433,8 +619,8 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
         }
         __syncthreads();
     }
-    // ---- getIMUInterval + processIMU (estimator.cpp:185-200, 1910-1942, 118-154)
-    if (t == 0) {
+    // ---- getIMUInterval + processIMU (estimator.cpp:185-200, 1910-1942, 118-154); VO mode (USE_IMU == 0) has neither
+    if (cfg.use_imu && t == 0) {
         int head = be.imu_head;
         while (head < be.imu_count && it[head % C.NIMU] <= be.prevTime) head++;
         int k = head;
@@ -456,7 +642,7 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
         }
     }
     __syncthreads();
-    {
+    if (cfg.use_imu) {
         int head = sh_i[0], n = sh_i[1];
         PreInt &P = c.pre[be.pre_idx[fc]];
         if (t == 0) {
@@ -505,6 +691,7 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
         __syncthreads();
     }
     // ---- triangulateWithDepth (feature_manager.cpp:386-543); the dynamic initialisation triangulates after its SfM instead (estimator.cpp:921-933)
+    if (!cfg.use_imu && be.solver_flag == 1) init_frame_pose_by_pnp(c, fc, c.res, sred);   // estimator.cpp:321-322 (VO mode, NON_LINEAR only)
     if (!(cfg.dynamic_init && be.solver_flag == 0)) triangulate_with_depth(c, nlm);
     __syncthreads();
     if (t == 0) {
@@ -572,7 +759,7 @@ __device__ __forceinline__ double evaluate(const Ctx &c, const Params &X, const 
         const int j = i + 1;
         const PreInt &p = c.pre[be.pre_idx[j]];
         double *out = c.imu_raw + (size_t)i * 15 * 31;
-        if (p.sum_dt > 10.0) { if (part == 0) for (int k = 0; k < 15; k++) out[k * 31 + 30] = 0; return; }
+        if (!cfg.use_imu || p.sum_dt > 10.0) { if (part == 0) for (int k = 0; k < 15; k++) out[k * 31 + 30] = 0; return; }
         if (part == 0) {
             double raw[15];
             bf::imu_raw_residual(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], raw);
@@ -846,7 +1033,7 @@ __device__ __forceinline__ void assemble(const Batch &B, const Ctx &c, const Par
                 const int i = 2 * (base + wave) + parity;
                 bool act = wave < nconc && i < W;
                 const PreInt *pp = act ? &c.pre[be.pre_idx[i + 1]] : nullptr;
-                if (act && pp->sum_dt > 10.0) act = false;
+                if (act && (!c.C->c.use_imu || pp->sum_dt > 10.0)) act = false;
                 double *raw_l = work + (wave < nconc ? wave : 0) * 704, *M_l = raw_l + 472;
                 if (act) {
                     const double *raw = c.imu_raw + (size_t)i * 15 * 31;
@@ -1037,8 +1224,8 @@ __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X
     const vio_config &cfg = c.C->c;
     BeSeq &be = *c.be;
     const int W = c.W, W1 = W + 1;
-    // ---- static initialisation extras (estimator.cpp:266-283): solveGyroscopeBias + repropagate
-    if (be.solver_flag == 0) {
+    // ---- static initialisation extras (estimator.cpp:266-283): solveGyroscopeBias + repropagate (IMU mode only, :264)
+    if (be.solver_flag == 0 && cfg.use_imu) {
         if (t == 0) {
             double A[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
             for (int i = 0; i < W; i++) {
@@ -1178,7 +1365,7 @@ __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X
         int ex_active;
         if ((cfg.estimate_extrinsic && be.frame_count == W && v0 > 0.2) || be.openExEstimation) { be.openExEstimation = 1; ex_active = 1; }
         else ex_active = 0;
-        int td_active = cfg.estimate_td && !(v0 < 0.2);
+        int td_active = cfg.use_imu && cfg.estimate_td && !(v0 < 0.2);   // no td block without the IMU (estimator.cpp:1204)
         sh_i[0] = ex_active; sh_i[1] = td_active;
         be.n_in_problem = F; be.n_var_landmarks = Fa; be.n_residuals = nres;
         be.iterations = 0; be.successful = 0;
@@ -1194,6 +1381,19 @@ __device__ __forceinline__ void solve_epilogue(Ctx &c, const Params &X, double c
     BeSeq &be = *c.be;
     const int W = c.W, nlm = be.n_lm;
     // ---- write back flat parameters + double2vector (estimator.cpp:985-1111)
+    if (!cfg.use_imu) {
+        // VO mode (estimator.cpp:1060-1067, 1093, 1109): poses straight from the parameters, no gauge fix, nothing else handed back
+        if (t == 0) {
+            be.final_cost = cost; be.iterations = iters_done; be.successful = succ;
+            be.iter_total += iters_done; be.solve_total++;
+            be.dbg[4] = (int)(wall_clock64() - ts0);
+        }
+        if (t <= W) {
+            const int i = t;
+            stm(be.Rs[i], q2R(qnormalized(mkq(X.pose[i * 7 + 6], X.pose[i * 7 + 3], X.pose[i * 7 + 4], X.pose[i * 7 + 5]))));
+            be.Ps[i][0] = X.pose[i * 7]; be.Ps[i][1] = X.pose[i * 7 + 1]; be.Ps[i][2] = X.pose[i * 7 + 2];
+        }
+    } else {
     if (t == 0) {
         be.final_cost = cost; be.iterations = iters_done; be.successful = succ;
         be.iter_total += iters_done; be.solve_total++;
@@ -1229,6 +1429,7 @@ __device__ __forceinline__ void solve_epilogue(Ctx &c, const Params &X, double c
         stm(be.ric, q2R(qnormalized(mkq(X.ex[6], X.ex[3], X.ex[4], X.ex[5]))));
         if (cfg.estimate_td) be.td = X.td;
     }
+    }   // IMU mode
     // setDepth (feature_manager.cpp:197-223)
     for (int k = t; k < nlm; k += nt) {
         int slot = c.lm_order[k];
@@ -1372,6 +1573,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
     // Jacobi scaling (once): 1/(1+||J_j||); constant blocks (ex / td when not estimated) get scale 0 = removed from the problem
     for (int a = t; a < LW; a += nt) {
         bool act = a < P && (a < oE ? true : (a < oT ? ex_active != 0 : td_active != 0));
+        if (!cfg.use_imu && (a < 6 || (a >= 6 * W1 && a < oE))) act = false;   // VO mode: pose 0 constant, no speed-bias blocks (estimator.cpp:1178-1185)
         sp[a] = act ? 1.0 / (1.0 + sqrt(c.H[a * LW + a])) : 0.0;
     }
     for (int k = t; k < Kpad; k += nt) sl[k] = k < Fa ? 1.0 / (1.0 + sqrt(c.Hll[k])) : 0.0;
@@ -1717,7 +1919,7 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
     if (!second_new) {
         // IMU factor (0,1)
         PreInt &p1 = c.pre[be.pre_idx[1]];
-        if (p1.sum_dt < 10.0) {
+        if (cfg.use_imu && p1.sum_dt < 10.0) {
             double *Jw = c.pairblk;         // 15x30 whitened
             double *raw = c.imu_raw;        // 15x31
             if (t == 0) {

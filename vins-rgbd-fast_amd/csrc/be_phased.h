@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
                 const int j = i + 1;
                 const PreInt &p = *(const PreInt *)(pl + (size_t)i * 704);
                 double *__restrict__ out = c.imu_raw + (size_t)i * 15 * 31;
-                if (p.sum_dt > 10.0) { if (part_ == 0) for (int k = 0; k < 15; k++) out[k * 31 + 30] = 0; continue; }
+                if (!cfg.use_imu || p.sum_dt > 10.0) { if (part_ == 0) for (int k = 0; k < 15; k++) out[k * 31 + 30] = 0; continue; }
                 if (part_ == 0) {
                     double raw[15];
                     bf::imu_raw_residual(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], raw);
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(512) void ps_asm_a_kernel(Batch B) {
         const int i = item - W1 * W1;
         const PreInt &pp = c.pre[be.pre_idx[i + 1]];
         double *G = ps_imu_blk(c) + (size_t)i * 768;
-        if (pp.sum_dt > 10.0) { for (int e = lane; e < 768; e += 64) G[e] = 0; return; }
+        if (!c.C->c.use_imu || pp.sum_dt > 10.0) { for (int e = lane; e < 768; e += 64) G[e] = 0; return; }
         double *raw_l = imu_lds + wave * 704, *M_l = raw_l + 472;
         const double *raw = c.imu_raw + (size_t)i * 15 * 31;
         for (int q = lane; q < 465; q += 64) raw_l[q] = raw[q];
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void ps_asm_b_kernel(Batch B) {
             for (int parity = 0; parity < 2; parity++)
                 for (int i = fa - 1; i <= fa; i++) {
                     if (i < 0 || i >= W || (i & 1) != parity) continue;
-                    if (c.pre[be.pre_idx[i + 1]].sum_dt > 10.0) continue;
+                    if (!c.C->c.use_imu || c.pre[be.pre_idx[i + 1]].sum_dt > 10.0) continue;
                     const int la = imu_local(a, i);
                     if (la < 0) continue;
                     const int lb = grad ? 30 : imu_local(b, i);
@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256) void ps_asm_b_kernel(Batch B) {
         else {
             c.H[(size_t)a * LW + b] = v;
             if (a == b && st.scale_pending) {
-                const bool act = a < oE ? true : (a < oT ? st.ex_active != 0 : st.td_active != 0);
+                bool act = a < oE ? true : (a < oT ? st.ex_active != 0 : st.td_active != 0);
+                if (!c.C->c.use_imu && (a < 6 || a >= 6 * W1)) act = false;   // VO mode: pose 0 constant, no speed-bias blocks
                 c.vec[1 * LW + a] = act ? 1.0 / (1.0 + sqrt(v)) : 0.0;   // sp
             }
         }

@@ -155,8 +155,8 @@ __global__ void fe_begin_kernel(Batch B, const double *stamps, int gate, int pub
         const double *it = B.imu_t + (size_t)s * C.NIMU;
         bool have = be.imu_count > imu_head;
         double back_t = have ? it[(be.imu_count - 1) % C.NIMU] : -1e300;
-        // caller contract of vio_feed: IMU pushed through stamp + td (upstream busy-waits, estimator.cpp:178-183)
-        if (!(have && t + be.td <= back_t)) {
+        // caller contract of vio_feed: IMU pushed through stamp + td (upstream busy-waits, estimator.cpp:178-183); VO mode has no IMU
+        if (C.c.use_imu && !(have && t + be.td <= back_t)) {
             fe.n_forw = -2;  // nothing consumed; tells the later kernels to skip this sequence (be_ingest reports VIO_NEED_IMU)
             return;
         }
@@ -173,7 +173,10 @@ __global__ void fe_begin_kernel(Batch B, const double *stamps, int gate, int pub
     }
     // Estimator::predictMotion(last_image_time, t + td), unless the caller handed in relative_R
     const double *Rc = R_rel ? R_rel + (size_t)s * 9 : nullptr;
-    if (Rc && Rc[0] == Rc[0]) {
+    if (!C.c.use_imu) {   // readImage(img, t) (estimator_nodelet.cpp:315): no prediction, LK starts at the old positions
+        dm::stm(fe.R_rel, dm::eye());
+        fe.use_R_rel = 0;
+    } else if (Rc && Rc[0] == Rc[0]) {
         for (int k = 0; k < 9; k++) fe.R_rel[k] = Rc[k];
         fe.use_R_rel = 1;
     } else {
@@ -251,6 +254,7 @@ __global__ void fe_predict_kernel(Batch B) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= fe.n_pts) return;
     float2 p = B.cur_pts[(size_t)s * C.NP + i];
+    if (!C.c.use_imu) { B.forw_pts[(size_t)s * C.NP + i] = p; return; }   // feature_tracker.cpp:307-311: nextPts start at prevPts
     double x, y;
     cam_lift(C.c, p.x, p.y, x, y);
     const double *R = fe.R_rel;

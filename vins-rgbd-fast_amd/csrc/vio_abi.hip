@@ -588,6 +588,7 @@ void vio_config_default(vio_config *c) {
     c->max_iterations = 8;
     c->ransac_max_iters = 1000;
     c->lk_max_level = 1;
+    c->use_imu = 1;
     c->fx = 604.5821781259577; c->fy = 604.2544712985845; c->cx = 321.2638233484251; c->cy = 239.70969315130674;
     c->k1 = 0.13387871564774004; c->k2 = -0.2731913133377051; c->p1 = 0.0020296263577681264; c->p2 = -0.00044384544608203714;
     c->focal_length = 460.0;
@@ -610,6 +611,8 @@ static int build_devcfg(const vio_config *cfg, int imu_capacity, DevCfg &C) {
     if (c.width < 64 || c.height < 64 || c.width > 4095 || c.height > 4095) { g_err = "image size out of range"; return VIO_EINVAL; }
     if (c.window_size < 4 || c.window_size > VIO_MAXW) { g_err = "window_size must be 4..20"; return VIO_EINVAL; }
     if (c.dynamic_init < 0 || c.dynamic_init > 1) { g_err = "dynamic_init must be 0 or 1"; return VIO_EINVAL; }
+    if (c.use_imu < 0 || c.use_imu > 1) { g_err = "use_imu must be 0 or 1"; return VIO_EINVAL; }
+    if (!c.use_imu && c.dynamic_init) { g_err = "the dynamic initialisation needs the IMU (estimator.cpp:231)"; return VIO_EINVAL; }
     if (c.grid_rows < 1 || c.grid_cols < 1 || c.grid_rows * c.grid_cols > VIO_MAX_CELLS) { g_err = "too many grid cells"; return VIO_EINVAL; }
     if (c.min_dist < 1 || c.min_dist > 63) { g_err = "min_dist must be 1..63"; return VIO_EINVAL; }
     if (c.lk_max_level < 0 || c.lk_max_level > 3) { g_err = "lk_max_level must be 0..3"; return VIO_EINVAL; }

@@ -103,7 +103,7 @@ def parse_opencv_yaml(text):
 
 def config_from_yaml(path_or_text, P=None, strict=True):
     """vio_config from a reference configuration file (parameters.cpp:81-243).  Settings that select code paths outside the
-    built hot path raise ValueError when strict (VO mode ``imu: 0``, fisheye,
+    built hot path raise ValueError when strict (fisheye,
     CLAHE, ``estimate_extrinsic: 2``); with strict=False they are returned in the second element as a list of notes."""
     if P is None:
         import importlib
@@ -153,7 +153,10 @@ def config_from_yaml(path_or_text, P=None, strict=True):
     c.td = float(g("td", 0.0))
     c.estimate_td = int(g("estimate_td", 0))
     c.tr = float(g("rolling_shutter_tr", 0.0)) if int(g("rolling_shutter", 0)) else 0.0
-    need(int(g("imu", 1)) == 0, "imu: 0 (VO mode) is out of scope (SURVEY.md 8f rank 3)")
+    c.use_imu = 1 if int(g("imu", 1)) else 0
+    if not c.use_imu:
+        c.lk_max_level = 3   # calcOpticalFlowPyrLK(..., Size(21, 21), 3) without IMU prediction (feature_tracker.cpp:307-311)
+        c.estimate_td = 0    # no td block without the IMU (estimator.cpp:1204)
     c.dynamic_init = 0 if int(g("static_init", 1)) else 1   # parameters.cpp:167: STATIC_INIT; 0 = SfM + visual-inertial alignment
     need(int(g("fisheye", 0)) != 0, "fisheye masks are out of scope")
     need(int(g("equalize", 0)) != 0, "equalize (CLAHE) is out of scope")
