@@ -214,6 +214,9 @@ int vio_stage_projection(const vio_config *cfg, const double *pose_i, const doub
  * uses the frame-pair form above) */
 int vio_stage_projection_residual(const vio_config *cfg, const double *pose_i, const double *pose_j, const double *ex, double inv_dep,
                                   double td, const double *obs_i, const double *obs_j, int use_td, double *r2, double *J46);
+/* cv::solvePnP(SOLVEPNP_ITERATIVE, useExtrinsicGuess) with K = I as FeatureManager::solvePoseByPnP calls it in VO mode
+ * (feature_manager.cpp:545-588): obj[n][3], img[n][2] normalised points, rvec3 / tvec3 (Rodrigues vector, translation) in and out */
+int vio_stage_pnp(int n, const double *obj, const double *img, double *rvec3, double *tvec3);
 /* IMUFactor::Evaluate as the solver consumes it: G961 = [J r]^T [J r] (31 x 31 row-major; columns pose_i(6) speedbias_i(9) pose_j(6)
  * speedbias_j(9) | residual) through the wavefront code of the solve kernel (split raw Jacobians, on-the-fly whitening, FP64 MFMA) */
 int vio_stage_imu_block(const vio_config *cfg, int n, const double *dt, const double *acc, const double *gyr, const double *acc0,

@@ -128,6 +128,7 @@ def lib():
         L.vio_device_upload.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.vio_device_download.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.vio_stage_projection_residual.argtypes = L.vio_stage_projection.argtypes
+        L.vio_stage_pnp.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vio_stage_imu_block.argtypes = [C.POINTER(Config), C.c_int] + [C.c_void_p] * 12
         _lib = L
     return _lib

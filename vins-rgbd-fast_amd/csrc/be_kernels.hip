@@ -209,54 +209,10 @@ __device__ v3 pnp_rodrigues_inv(const m3 &R) {
     }
     return scl(th / (2 * sn), r);
 }
-// FeatureManager::initFramePoseByPnP + solvePoseByPnP (feature_manager.cpp:545-642): cv::solvePnP(SOLVEPNP_ITERATIVE,
-// useExtrinsicGuess) = CvLevMarq on (rvec, tvec) with lambda = 10^k, diagonal x (1 + lambda), at most 20 iterations, FLT_EPSILON
-// on the relative parameter change.  Block-cooperative: one thread per 3-D / 2-D pair evaluates its two residual rows and 2 x 6
-// Jacobian, the 27 sums of J^T J / J^T e are reduced in a fixed order, thread 0 solves the damped 6 x 6 system through its
-// eigen-decomposition (cv::solve DECOMP_SVD).  pts: scratch in HBM, 5 doubles per pair.  sw: >= 16 * 28 + 64 doubles of LDS.
-__device__ void init_frame_pose_by_pnp(Ctx &c, int fc, double *pts, double *sw) {
+// The Levenberg-Marquardt core of cv::solvePnP(ITERATIVE): refines par[6] = (rvec, tvec) in LDS over n pairs pts[5 n] = (X, Y, Z, u, v).
+// prev: 6 doubles of LDS, sw: >= (waves x 28) doubles of LDS.  Every thread of the block takes part.
+__device__ void pnp_refine_block(const double *pts, int n, double *sh_par, double *sh_prev, double *sw) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
-    BeSeq &be = *c.be;
-    if (fc <= 0) return;
-    __shared__ int sh_n;
-    __shared__ double sh_par[6], sh_prev[6], sh_flag[4];
-    if (t == 0) sh_n = 0;
-    __syncthreads();
-    const m3 ric = ldm(be.ric);
-    const v3 tic = ld3(be.tic);
-    const int nlm = be.n_lm;
-    // pairs in list order (deterministic): flags + scan
-    int *flag = c.lm_pidx, *offs = c.lm_aidx;   // free outside the solve
-    __shared__ int scan_scratch[2 * 256 + 8];
-    for (int k = t; k < nlm; k += nt) {
-        const int slot = c.lm_order[k];
-        const int index = fc - c.lm_start[slot];
-        flag[k] = (c.lm_depth[slot] > 0 && index >= 0 && c.lm_nobs[slot] >= index + 1) ? 1 : 0;
-    }
-    __syncthreads();
-    const int n = block_scan_flags(flag, nlm, offs, scan_scratch);
-    for (int k = t; k < nlm; k += nt) {
-        if (!flag[k]) continue;
-        const int slot = c.lm_order[k], st = c.lm_start[slot];
-        const double *o0 = obs_ptr(c, slot, st), *oi = obs_ptr(c, slot, fc);
-        const double d = c.lm_depth[slot];
-        const v3 pc = add(mul(ric, mk(o0[0] * d, o0[1] * d, o0[2] * d)), tic);
-        const v3 pw = add(mul(ldm(be.Rs[st]), pc), ld3(be.Ps[st]));
-        double *q = pts + (size_t)offs[k] * 5;
-        q[0] = (double)(float)pw.x; q[1] = (double)(float)pw.y; q[2] = (double)(float)pw.z;   // cv::Point3f / cv::Point2f
-        q[3] = (double)(float)oi[0]; q[4] = (double)(float)oi[1];
-    }
-    __syncthreads();
-    if (n < 4) return;
-    if (t == 0) {
-        const m3 RCam = mul(ldm(be.Rs[fc - 1]), ric);
-        const v3 PCam = add(mul(ldm(be.Rs[fc - 1]), tic), ld3(be.Ps[fc - 1]));
-        const m3 R0 = tr(RCam);
-        const v3 P0 = neg(mul(R0, PCam));
-        const v3 r = pnp_rodrigues_inv(R0);
-        sh_par[0] = r.x; sh_par[1] = r.y; sh_par[2] = r.z; sh_par[3] = P0.x; sh_par[4] = P0.y; sh_par[5] = P0.z;
-    }
-    __syncthreads();
     // reduction of NV values per thread: wave DPP sums, then a fixed-order sum over the waves
     auto reduce = [&](double *v, int NV) {
         for (int q = 0; q < NV; q++) v[q] = wave_sum_dpp(v[q]);
@@ -349,6 +305,58 @@ __device__ void init_frame_pose_by_pnp(Ctx &c, int fc, double *pts, double *sw) 
         }
         if (done) break;
     }
+    __syncthreads();
+}
+
+// FeatureManager::initFramePoseByPnP + solvePoseByPnP (feature_manager.cpp:545-642): cv::solvePnP(SOLVEPNP_ITERATIVE,
+// useExtrinsicGuess) = CvLevMarq on (rvec, tvec) with lambda = 10^k, diagonal x (1 + lambda), at most 20 iterations, FLT_EPSILON
+// on the relative parameter change.  Block-cooperative: one thread per 3-D / 2-D pair evaluates its two residual rows and 2 x 6
+// Jacobian, the 27 sums of J^T J / J^T e are reduced in a fixed order, thread 0 solves the damped 6 x 6 system through its
+// eigen-decomposition (cv::solve DECOMP_SVD).  pts: scratch in HBM, 5 doubles per pair.  sw: >= 16 * 28 + 64 doubles of LDS.
+__device__ void init_frame_pose_by_pnp(Ctx &c, int fc, double *pts, double *sw) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    BeSeq &be = *c.be;
+    if (fc <= 0) return;
+    __shared__ int sh_n;
+    __shared__ double sh_par[6], sh_prev[6], sh_flag[4];
+    if (t == 0) sh_n = 0;
+    __syncthreads();
+    const m3 ric = ldm(be.ric);
+    const v3 tic = ld3(be.tic);
+    const int nlm = be.n_lm;
+    // pairs in list order (deterministic): flags + scan
+    int *flag = c.lm_pidx, *offs = c.lm_aidx;   // free outside the solve
+    __shared__ int scan_scratch[2 * 256 + 8];
+    for (int k = t; k < nlm; k += nt) {
+        const int slot = c.lm_order[k];
+        const int index = fc - c.lm_start[slot];
+        flag[k] = (c.lm_depth[slot] > 0 && index >= 0 && c.lm_nobs[slot] >= index + 1) ? 1 : 0;
+    }
+    __syncthreads();
+    const int n = block_scan_flags(flag, nlm, offs, scan_scratch);
+    for (int k = t; k < nlm; k += nt) {
+        if (!flag[k]) continue;
+        const int slot = c.lm_order[k], st = c.lm_start[slot];
+        const double *o0 = obs_ptr(c, slot, st), *oi = obs_ptr(c, slot, fc);
+        const double d = c.lm_depth[slot];
+        const v3 pc = add(mul(ric, mk(o0[0] * d, o0[1] * d, o0[2] * d)), tic);
+        const v3 pw = add(mul(ldm(be.Rs[st]), pc), ld3(be.Ps[st]));
+        double *q = pts + (size_t)offs[k] * 5;
+        q[0] = (double)(float)pw.x; q[1] = (double)(float)pw.y; q[2] = (double)(float)pw.z;   // cv::Point3f / cv::Point2f
+        q[3] = (double)(float)oi[0]; q[4] = (double)(float)oi[1];
+    }
+    __syncthreads();
+    if (n < 4) return;
+    if (t == 0) {
+        const m3 RCam = mul(ldm(be.Rs[fc - 1]), ric);
+        const v3 PCam = add(mul(ldm(be.Rs[fc - 1]), tic), ld3(be.Ps[fc - 1]));
+        const m3 R0 = tr(RCam);
+        const v3 P0 = neg(mul(R0, PCam));
+        const v3 r = pnp_rodrigues_inv(R0);
+        sh_par[0] = r.x; sh_par[1] = r.y; sh_par[2] = r.z; sh_par[3] = P0.x; sh_par[4] = P0.y; sh_par[5] = P0.z;
+    }
+    __syncthreads();
+    pnp_refine_block(pts, n, sh_par, sh_prev, sw);
     __syncthreads();
     if (t == 0) {
         bool fin = true;
@@ -2505,6 +2513,15 @@ __global__ __launch_bounds__(256) void be_dyn_finalize_kernel(Batch B, int seq, 
     }
     __syncthreads();
     triangulate_with_depth(c, be.n_lm);
+}
+
+// stage test of the device solvePnP: par6 = (rvec, tvec) in / out
+__global__ __launch_bounds__(256) void be_stage_pnp_kernel(const double *pts, int n, double *par6) {
+    __shared__ double sh_par[6], sh_prev[6], sw[256];
+    if (threadIdx.x < 6) sh_par[threadIdx.x] = par6[threadIdx.x];
+    __syncthreads();
+    pnp_refine_block(pts, n, sh_par, sh_prev, sw);
+    if (threadIdx.x < 6) par6[threadIdx.x] = sh_par[threadIdx.x];
 }
 
 #include "be_phased.h"

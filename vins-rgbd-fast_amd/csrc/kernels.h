@@ -43,6 +43,7 @@ __global__ void ps_schur_kernel(Batch B);
 __global__ void ps_serial_kernel(Batch B);
 __global__ void ps_final_kernel(Batch B);
 __global__ void be_prior_factor_kernel(Batch B, int seq);
+__global__ void be_stage_pnp_kernel(const double *pts, int n, double *par6);
 __global__ void be_dyn_finalize_kernel(Batch B, int seq, const double *samples, const int *offs);
 __global__ void be_stage_imu_kernel(vio_config cfg, PreInt *P, int n, const double *dt, const double *acc, const double *gyr,
                                     const double *par, double g_norm, double *preint_out, double *r15, double *J480);

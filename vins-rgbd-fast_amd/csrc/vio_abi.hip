@@ -1489,6 +1489,32 @@ done:
     if (db) (void)hipFree(db);
     return rc;
 }
+// cv::solvePnP(SOLVEPNP_ITERATIVE, useExtrinsicGuess = 1) with K = I as FeatureManager::solvePoseByPnP calls it (feature_manager.cpp:571):
+// obj[n][3], img[n][2] (both rounded to float like cv::Point3f / Point2f), rvec / tvec in and out
+int vio_stage_pnp(int n, const double *obj, const double *img, double *rvec3, double *tvec3) {
+    int rc = VIO_OK;
+    if (n < 4) return VIO_EINVAL;
+    std::vector<double> pts((size_t)n * 5), par(6);
+    for (int i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++) pts[5 * i + k] = (double)(float)obj[3 * i + k];
+        for (int k = 0; k < 2; k++) pts[5 * i + 3 + k] = (double)(float)img[2 * i + k];
+    }
+    for (int k = 0; k < 3; k++) { par[k] = rvec3[k]; par[3 + k] = tvec3[k]; }
+    double *dp = nullptr, *dq = nullptr;
+    STAGE_CHK(hipMalloc((void **)&dp, pts.size() * sizeof(double)));
+    STAGE_CHK(hipMalloc((void **)&dq, 6 * sizeof(double)));
+    STAGE_CHK(hipMemcpy(dp, pts.data(), pts.size() * sizeof(double), hipMemcpyHostToDevice));
+    STAGE_CHK(hipMemcpy(dq, par.data(), 6 * sizeof(double), hipMemcpyHostToDevice));
+    be_stage_pnp_kernel<<<1, 256>>>(dp, n, dq);
+    STAGE_CHK(hipDeviceSynchronize());
+    STAGE_CHK(hipMemcpy(par.data(), dq, 6 * sizeof(double), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 3; k++) { rvec3[k] = par[k]; tvec3[k] = par[3 + k]; }
+done:
+    if (dp) (void)hipFree(dp);
+    if (dq) (void)hipFree(dq);
+    return rc;
+}
+
 int vio_stage_projection(const vio_config *cfg, const double *pose_i, const double *pose_j, const double *ex, double inv_dep, double td,
                          const double *obs_i, const double *obs_j, int use_td, double *r2, double *J46) {
     return stage_projection_impl(cfg, pose_i, pose_j, ex, inv_dep, td, obs_i, obs_j, use_td, 0, r2, J46);
