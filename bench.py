@@ -131,6 +131,8 @@ def main():
     ap.add_argument("--cpu-procs", type=int, default=-1, help="oracle processes for the all-core CPU baseline, one sequence each "
                     "(-1 = every core this process may run on, 0 = skip)")
     ap.add_argument("--aux", action="store_true", help="also measure S=256 sequences per GPU (reported as aux_s256, never as value)")
+    ap.add_argument("--tracker-lag", type=int, default=1, choices=[0, 1], help="vio_set_tracker_lag: 1 = the tracker of frame f+1 overlaps the "
+                    "optimisation of frame f (the reference's two threads with the estimator one frame behind), 0 = it waits for it")
     ap.add_argument("--pcie-steps", type=int, default=6, help="extra steps fed from HOST buffers after the timed region (0 = skip)")
     ap.add_argument("--stream-steps", type=int, default=10, help="extra steps with the IMU pushed frame by frame")
     args = ap.parse_args()
@@ -194,6 +196,7 @@ def main():
         syn.render_device(S, seq0, float(times[f]), gray[f], depth[f])
     nimu = int(F / sc.cam_rate * sc.imu_rate) + 64
     b = P.VioBatch(cfg, S, imu_capacity=nimu + 64)
+    b.set_tracker_lag(args.tracker_lag)
     imu_all = [syn.imu(seq0 + s, nimu) for s in range(S)]
     f_stream0 = F - 2 * Ks                                   # first frame of the streaming legs
     # IMU up to (and one sample past) the last non-streaming frame goes in up front, in one batched call
@@ -373,6 +376,7 @@ def main():
         tcpu, nfr, rm, ate_pairs = 0.0, 0, [], []
         for s in range(ncs):
             o = vio_ct.OraclePipeline(cfg)
+            o.set_tracker_lag(args.tracker_lag)
             ti, ai, gi = syn.imu(seq0 + s, nimu)
             o.push_imu(ti, ai, gi)
             traj = []
@@ -437,7 +441,11 @@ def main():
         "config": {"workload": "BASELINE configs[2]: batch of %d independent synthetic 640x480 RGB-D + 200 Hz IMU sequences per MI355X, "
                                "150 max features, 5x6 grid, 10-keyframe window, landmarks free (fix_depth 0)" % S,
                    "sequences_per_gpu": S, "image": [Wd, H], "max_cnt": cfg.max_cnt, "window_size": cfg.window_size,
-                   "parallelism": "independent sequences sharded per GPU, no data-path collective"},
+                   "parallelism": "independent sequences sharded per GPU, no data-path collective",
+                   "tracker_lag": args.tracker_lag,
+                   "tracker_lag_note": "1 = the tracker of frame f+1 overlaps the optimisation of frame f and predicts with latest_Bg / td as of "
+                                       "frame f-1 (the reference's process_tracker / process threads with the estimator one frame behind); "
+                                       "0 = it waits for the optimisation of frame f.  The oracle in `parity` runs the same ordering."},
         "repeats": {"n": R, "frames_per_s": rates, "median_index": order, "spread_rel": (max(rates) - min(rates)) / (total_frames / elapsed),
                     "timed_frames_per_sequence": R * K},
         "valid": all_processed,

@@ -3,7 +3,7 @@
 // feature_buf, estimator_nodelet.cpp:192-459) and process (pop feature_buf, inputDepth, processImage, :462-549), with the
 // estimator allowed to lag the tracker by `lag` frames like the reference's second thread does.
 // Build:  g++ -std=c++11 -Iinclude examples/adapter_demo.cpp -Lvins-rgbd-fast_amd -lvio_hip -Wl,-rpath,$PWD/vins-rgbd-fast_amd
-// Usage:  adapter_demo [seq] [n_frames] [cam_rate] [freq] [frontend_freq] [lag]
+// Usage:  adapter_demo [seq] [n_frames] [cam_rate] [freq] [frontend_freq] [lag] [use_imu]   (use_imu 0 = the reference's `imu: 0`)
 // Prints one line per NON_LINEAR frame: stamp px py pz n_tracks  (tests/test_gpu_adapter.py compares it with the oracle).
 #include <cstdio>
 #include <cstdlib>
@@ -24,12 +24,15 @@ int main(int argc, char **argv) {
     const double cam_rate = argc > 3 ? std::atof(argv[3]) : 0.0;
     const int FREQ = argc > 4 ? std::atoi(argv[4]) : 10, FRONTEND_FREQ = argc > 5 ? std::atoi(argv[5]) : 30;
     const size_t lag = argc > 6 ? (size_t)std::atoi(argv[6]) : 0;
+    const bool USE_IMU = argc > 7 ? std::atoi(argv[7]) != 0 : true;
     vio_config cfg;
     vio_config_default(&cfg);
     cfg.fix_depth = 0; cfg.depth_max = 10.0;  // the 150-feature setting used by bench.py (canonical_config)
+    if (!USE_IMU) { cfg.use_imu = 0; cfg.lk_max_level = 3; cfg.fix_depth = 1; }   // imu: 0 (parameters.cpp:98-107), 4-level LK (feature_tracker.cpp:307-311)
     vio_synth_config sc;
     vio_synth_config_default(&sc);
     if (cam_rate > 0) sc.cam_rate = cam_rate;
+    if (!USE_IMU) sc.t_static = 0.0;   // no stationary prefix: VO starts from the first frame (estimator.cpp:581-626)
     const int nimu = (int)(n_frames / sc.cam_rate * sc.imu_rate) + 64;
     std::vector<double> t(nimu), acc(3 * nimu), gyr(3 * nimu);
     vio_synth_imu(&sc, seq, nimu, t.data(), acc.data(), gyr.data());
@@ -58,7 +61,7 @@ int main(int argc, char **argv) {
         };
         for (int fi = 0; fi < n_frames; fi++) {
             const double time_color = fi / sc.cam_rate;
-            while (k < nimu && t[k] < time_color + 1.5 / sc.imu_rate) { estimator.inputIMU(t[k], &acc[3 * k], &gyr[3 * k]); k++; }  // imu_callback
+            while (USE_IMU && k < nimu && t[k] < time_color + 1.5 / sc.imu_rate) { estimator.inputIMU(t[k], &acc[3 * k], &gyr[3 * k]); k++; }  // imu_callback
             vio_synth_render_host(&sc, seq, time_color, gray.data(), depth.data());
             // ---- process_tracker
             const double last_image_time = gate.last_image_time;
@@ -73,9 +76,12 @@ int main(int argc, char **argv) {
             }
             if (d == vio_hip::FrameGate::SKIP) continue;
             const bool PUB_THIS_FRAME = d == vio_hip::FrameGate::PUBLISH;
-            double relative_R[9];
-            estimator.predictMotion(last_image_time, time_color + estimator.td, relative_R);   // :309-313
-            tracker.readImage(gray.data(), time_color, relative_R, PUB_THIS_FRAME);
+            if (USE_IMU) {
+                double relative_R[9];
+                estimator.predictMotion(last_image_time, time_color + estimator.td, relative_R);   // :309-313
+                tracker.readImage(gray.data(), time_color, relative_R, PUB_THIS_FRAME);
+            } else
+                tracker.readImage(gray.data(), time_color, nullptr, PUB_THIS_FRAME);              // :315-316
             for (unsigned i = 0;; i++) if (!tracker.updateID(i)) break;                      // :324-330
             if (PUB_THIS_FRAME) {
                 vio_hip::FeatureMap image;                                                   // :336-363

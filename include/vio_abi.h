@@ -163,6 +163,19 @@ int vio_get_odometry(vio_batch *h, double *out);
 /* CSV rows written for sequence seq.  The device keeps a ring of the last 2048 rows: out receives the most recent min(rows, 2048,
  * cap) of them in time order; returns the number of rows produced since vio_create / the last reset (may exceed what fits). */
 int vio_get_odometry_history(vio_batch *h, int seq, int cap, double *out);
+/* How far the estimator runs behind the tracker inside vio_feed / vio_feed_modes.  The reference's process_tracker and process()
+ * threads run concurrently (estimator_nodelet.cpp:192-459 / :462-549): Estimator::predictMotion of frame f+1 reads latest_Bg / td as the
+ * estimator thread left them, i.e. after frame f when the estimator keeps up and after frame f-1 when it is still optimising frame f.
+ *   lag 0 (default): the tracker of frame f+1 starts after the optimisation of frame f (estimator keeps up);
+ *   lag 1: it reads the state as of frame f-1 (a snapshot be_ingest takes) and overlaps the optimisation of frame f, which takes
+ *          the front-end off the critical path.  Results are deterministic in both modes; the oracle implements the same two
+ *          orderings (ovio_set_tracker_lag).  Not available on dynamic_init handles.  vio_track / vio_process_obs callers choose the
+ *          ordering themselves. */
+int vio_set_tracker_lag(vio_batch *h, int lag);
+/* the IMU-rate pose of pubLatestOdometry (Estimator::predict, estimator.cpp:1862-1880, fed by inputIMU :1749-1766 after
+ * updateLatestStates :1768-1788): the newest window state propagated through every IMU sample pushed after it.
+ * out11 = t, P(3), Q(w, x, y, z), V(3).  INITIAL sequences and VO mode return the window state unchanged. */
+int vio_get_latest_odometry(vio_batch *h, int seq, double *out11);
 /* tic(3), ric(9 row-major), td */
 int vio_get_extrinsic(vio_batch *h, int seq, double *out13);
 /* FeatureTracker public vectors after readImage (estimator_nodelet.cpp:337-343): returns count */

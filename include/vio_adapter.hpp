@@ -101,6 +101,9 @@ class Estimator {
     // Matrix3d predictMotion(double t0, double t1) (estimator.h:56, estimator.cpp:1790-1860): relative_R row-major
     void predictMotion(double t0, double t1, double relative_R[9]) { check(vio_predict_motion(h_, 0, t0, t1, relative_R), "vio_predict_motion"); }
 
+    // the IMU-rate pose pubLatestOdometry publishes from inputIMU (estimator.cpp:1760-1765): latest_time, latest_P, latest_Q (w x y z), latest_V
+    void latestOdometry(double out11[11]) { check(vio_get_latest_odometry(h_, 0, out11), "vio_get_latest_odometry"); }
+
     // FeatureManager::inputDepth (feature_manager.cpp:43-46): the nodelet calls estimator.f_manager.inputDepth(depth) right before
     // processImage (estimator_nodelet.cpp:537-539); the pointer must stay valid until processImage returns
     struct FeatureManagerMirror {

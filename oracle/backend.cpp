@@ -388,7 +388,8 @@ void Estimator::inputIMU(double t, const V3 &acc, const V3 &gyr) {  // :1749-176
 bool Estimator::IMUAvailable(double t) const {  // :1882-1888
     return imu_head < imu_buf.size() && t <= imu_buf.back().t;
 }
-void Estimator::predictMotion(double t0, double t1, double R[9]) {  // :1790-1860
+void Estimator::predictMotion(double t0, double t1, double R[9], const V3 *bg_override) {  // :1790-1860
+    const V3 bg_used = bg_override ? *bg_override : latest_Bg;
     M3 rel = M3::I();
     auto out = [&]() { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = rel(i, j); };
     if (imu_head >= imu_buf.size()) { out(); return; }
@@ -405,7 +406,7 @@ void Estimator::predictMotion(double t0, double t1, double R[9]) {  // :1790-186
             if (first) { prev_t = t; first = false; prev_gyr = w; continue; }
             double dt = t - prev_t;
             prev_t = t;
-            V3 un_gyr = 0.5 * (prev_gyr + w) - latest_Bg;
+            V3 un_gyr = 0.5 * (prev_gyr + w) - bg_used;
             prev_gyr = w;
             M3 RIC;  // the GLOBAL RIC.back() (estimator.cpp:1852): the configured extrinsic, not the refined Estimator::ric
             for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) RIC(i, j) = cfg.ric[i * 3 + j];
@@ -423,6 +424,32 @@ void Estimator::predictMotion(double t0, double t1, double R[9]) {  // :1790-186
         }
     }
     out();
+}
+// Estimator::predict (estimator.cpp:1862-1880) from the newest window state through every buffered sample newer than it (the pose
+// pubLatestOdometry publishes at IMU rate; every sample with its own values, see the note at be_latest_odometry_kernel)
+void Estimator::latestOdometry(double out[11]) const {
+    double latest_time = Headers[frame_count] + td;
+    V3 P = Ps[frame_count], V = Vs[frame_count], Ba = Bas[frame_count], Bg = Bgs[frame_count];
+    M3 R = Rs[frame_count];
+    V3 a0 = acc_0, g0 = gyr_0;
+    if (solver_flag == 1 && cfg.use_imu)
+        for (size_t k = imu_head; k < imu_buf.size(); k++) {
+            const double t = imu_buf[k].t;
+            if (!(t > latest_time)) continue;
+            const double dt = t - latest_time;
+            latest_time = t;
+            V3 un_acc_0 = R * (a0 - Ba) - g;
+            V3 un_gyr = 0.5 * (g0 + imu_buf[k].gyr) - Bg;
+            R = R * toR(deltaQ(un_gyr * dt));
+            V3 un_acc_1 = R * (imu_buf[k].acc - Ba) - g;
+            V3 un_acc = 0.5 * (un_acc_0 + un_acc_1);
+            P = P + dt * V + (0.5 * dt * dt) * un_acc;
+            V = V + dt * un_acc;
+            a0 = imu_buf[k].acc; g0 = imu_buf[k].gyr;
+        }
+    Q q = fromR(R);
+    out[0] = latest_time; out[1] = P.x; out[2] = P.y; out[3] = P.z; out[4] = q.w; out[5] = q.x; out[6] = q.y; out[7] = q.z;
+    out[8] = V.x; out[9] = V.y; out[10] = V.z;
 }
 void Estimator::processIMU(double dt, const V3 &acc, const V3 &gyr) {  // :118-154
     if (!first_imu) { first_imu = true; acc_0 = acc; gyr_0 = gyr; }
@@ -1576,7 +1603,7 @@ int Estimator::processImage(std::map<int, std::array<double, 7>> &image, const u
 // process_tracker for one frame (estimator_nodelet.cpp:234-393) after the stream checks: mode = outcome of the frequency control
 // (0 skip before readImage, 1 readImage with PUB_THIS_FRAME false, 2 readImage + packaging).  R_in: caller-supplied relative_R or
 // NULL = Estimator::predictMotion.  Returns 1 when `image` holds a feature map for processImage.
-int Pipeline::track(const uint8_t *gray, double t, int mode, const double *R_in, std::map<int, std::array<double, 7>> &image) {
+int Pipeline::track(const uint8_t *gray, double t, int mode, const double *R_in, std::map<int, std::array<double, 7>> &image, const V3 *bg, const double *td) {
     image.clear();
     if (first_image_flag) {  // estimator_nodelet.cpp:234-240
         first_image_flag = false;
@@ -1586,7 +1613,7 @@ int Pipeline::track(const uint8_t *gray, double t, int mode, const double *R_in,
     if (mode == 0) return 0;  // "Skip this frame" :266-271 (before readImage: last_image_time keeps its value)
     double R[9];
     if (R_in) for (int k = 0; k < 9; k++) R[k] = R_in[k];
-    else if (cfg.use_imu) est.predictMotion(last_image_time, t + est.td, R);  // :309-313
+    else if (cfg.use_imu) est.predictMotion(last_image_time, t + (td ? *td : est.td), R, bg);  // :309-313
     else { for (int k = 0; k < 9; k++) R[k] = (k % 4 == 0) ? 1.0 : 0.0; }   // readImage(img, t): relative_R defaults to identity (and is not used)
     tracker.readImage(gray, t, R, mode == 2);
     last_image_time = t;
@@ -1608,9 +1635,15 @@ int Pipeline::process(std::map<int, std::array<double, 7>> &image, const uint16_
     return 1;
 }
 int Pipeline::feed(const uint8_t *gray, const uint16_t *depth, double t, int mode) {
-    if (cfg.use_imu && !est.IMUAvailable(t + est.td)) return -1;  // caller contract: IMU pushed through t + td (upstream busy-waits, estimator.cpp:178-183)
+    // tracker_lag 1: process_tracker of this frame runs while process() still optimises the previous one (the nodelet's two threads,
+    // estimator_nodelet.cpp:192-459 / :462-549), so predictMotion sees latest_Bg / td as they were before the previous frame was
+    // processed.  The snapshot is renewed on every call, before this frame is processed.
+    const V3 bg_used = tracker_lag ? snap_bg : est.latest_Bg;
+    const double td_used = tracker_lag ? snap_td : est.td;
+    snap_bg = est.latest_Bg; snap_td = est.td;
+    if (cfg.use_imu && !est.IMUAvailable(t + td_used)) return -1;  // caller contract: IMU pushed through t + td (upstream busy-waits, estimator.cpp:178-183)
     std::map<int, std::array<double, 7>> image;
-    if (!track(gray, t, mode, nullptr, image)) return 0;
+    if (!track(gray, t, mode, nullptr, image, &bg_used, &td_used)) return 0;
     return process(image, depth, t);
 }
 

@@ -212,7 +212,7 @@ struct Estimator {
     ~Estimator();
     void clearState();
     void inputIMU(double t, const om::V3 &acc, const om::V3 &gyr);
-    void predictMotion(double t0, double t1, double R[9]);
+    void predictMotion(double t0, double t1, double R[9], const om::V3 *bg_override = nullptr);
     bool IMUAvailable(double t) const;
     // image: ascending-id map of 7-vectors (x,y,1,u,v,vx,vy); returns 0 ok, 1 need imu, 2 rebooted
     int processImage(std::map<int, std::array<double, 7>> &image, const uint16_t *depth, double stamp);
@@ -226,6 +226,7 @@ struct Estimator {
     void triangulateWithDepth();
     void solveGyroscopeBias();
     void initFramePoseByPnP(int frameCnt);
+    void latestOdometry(double out[11]) const;
     void vector2double();
     void double2vector();
     void optimization();
@@ -297,11 +298,15 @@ struct Pipeline {
     bool first_image_flag = true, init_pub = false, init_feature = false;
     double last_image_time = 0;
     int frames_processed = 0;
-    explicit Pipeline(const Config &c) : cfg(c), tracker(c), est(c) {}
+    int tracker_lag = 0;       // 0: the estimator keeps up with the tracker; 1: it runs one frame behind (see feed)
+    om::V3 snap_bg;
+    double snap_td;
+    explicit Pipeline(const Config &c) : cfg(c), tracker(c), est(c), snap_td(c.td) {}
     // returns 1 if processImage ran for this frame; mode: 0 skip, 1 track only (PUB_THIS_FRAME false), 2 publish
     int feed(const uint8_t *gray, const uint16_t *depth, double t, int mode = 2);
     // the two halves the nodelet runs on separate threads with feature_buf between them (estimator_nodelet.cpp:380-384, 539)
-    int track(const uint8_t *gray, double t, int mode, const double *R_in, std::map<int, std::array<double, 7>> &image);
+    int track(const uint8_t *gray, double t, int mode, const double *R_in, std::map<int, std::array<double, 7>> &image, const om::V3 *bg = nullptr,
+              const double *td = nullptr);
     int process(std::map<int, std::array<double, 7>> &image, const uint16_t *depth, double t);
 };
 

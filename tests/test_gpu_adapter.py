@@ -44,3 +44,25 @@ def test_cpp_nodelet_loop_matches_the_oracle(P, tmp_path, cam_rate, freq, fronte
     # 1e-5 m over the ~25 processed frames of the 10 Hz case; the 60 Hz case runs ~35 processed frames and reaches 1.5e-5 (documented
     # HIP-vs-oracle divergence, DESIGN.md deviations 10 / 12)
     assert np.abs(rows[:, 1:4] - ref[:, 1:4]).max() < (1e-5 if cam_rate <= 10 else 5e-5), float(np.abs(rows[:, 1:4] - ref[:, 1:4]).max())
+
+
+def test_cpp_nodelet_loop_in_vo_mode(P, tmp_path):
+    """imu: 0 through the C++ mirror: readImage(img, t) without relative_R (estimator_nodelet.cpp:315-316), no inputIMU at all,
+    processImage on the queued maps; against the oracle in VO mode (tolerance as in tests/test_gpu_vo.py)."""
+    exe = _build(tmp_path)
+    seq, n = 3, 36
+    out = subprocess.run([exe, str(seq), str(n), "10", "10", "30", "1", "0"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    rows = np.array([[float(x) for x in line.split()] for line in out.stdout.strip().splitlines()])
+    cfg = P.canonical_config(fix_depth=1, depth_max=10.0)
+    cfg.use_imu = 0
+    cfg.lk_max_level = 3
+    sc = vio_ct.synth_like(cfg)
+    sc.t_static = 0.0
+    times = vio_ct.frame_times(sc, n)
+    modes = vio_ct.gate_modes(vio_ct.OracleGate(10, 30), times)
+    o = vio_ct.run_oracle_sequence(cfg, sc, seq, n, modes=modes)
+    ref = np.array([np.r_[times[f], p] for (f, p, q, v) in o["traj"]])
+    assert len(rows) >= 15 and rows.shape[0] == ref.shape[0], (rows.shape, ref.shape)
+    assert np.abs(rows[:, 0] - ref[:, 0]).max() < 1e-3
+    assert np.abs(rows[:, 1:4] - ref[:, 1:4]).max() < 5e-4, float(np.abs(rows[:, 1:4] - ref[:, 1:4]).max())

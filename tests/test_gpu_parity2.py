@@ -328,6 +328,79 @@ def test_predict_motion_and_caller_supplied_relative_R(P, orc):
     assert len(a[0]) > 100
 
 
+def test_tracker_lag_one(P):
+    """vio_set_tracker_lag(1): the tracker of frame f+1 overlaps the optimisation of frame f and predicts with latest_Bg / td as of
+    frame f-1 (the nodelet's two threads with the estimator one frame behind).  (a) same ordering in the oracle -> same trajectories
+    as in the lag-0 comparison; (b) the option changes the result; (c) with real overlap (no host synchronisation between the
+    feeds, IMU streamed frame by frame) the result is bit-identical to the synchronised run."""
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    seqs, n = [2, 9, 21], 40
+    oruns = [vio_ct.run_oracle_sequence(cfg, sc, s, n, tracker_lag=1) for s in seqs]
+    frames = [o["frames"] for o in oruns]
+    b1, traj1, stat1 = vio_ct.run_hip_batch(P, cfg, sc, seqs, n, frames, tracker_lag=1)
+    b0, traj0, stat0 = vio_ct.run_hip_batch(P, cfg, sc, seqs, n, frames, tracker_lag=0)
+    differs = False
+    for i, s in enumerate(seqs):
+        po = np.array([x[1] for x in oruns[i]["traj"]]); p1 = np.array([x[1] for x in traj1[i]]); p0 = np.array([x[1] for x in traj0[i]])
+        assert po.shape == p1.shape and len(po) >= 20
+        assert np.abs(po - p1).max() < 1e-5, (s, float(np.abs(po - p1).max()))
+        for f in range(n):
+            so, sh = oruns[i]["status"][f], stat1[i][f]
+            assert (int(so["solver_flag"]), int(so["frame_count"]), int(so["n_landmarks"])) == (sh.solver_flag, sh.frame_count, sh.n_landmarks), (s, f)
+        differs |= p0.shape != p1.shape or not np.array_equal(p0, p1)
+    assert differs
+    # (c) free-running: nothing between the feeds but the IMU pushes
+    syn = P.Synth(sc)
+    S = len(seqs)
+    bb = P.VioBatch(cfg, S)
+    bb.set_tracker_lag(1)
+    nimu = int(n / sc.cam_rate * sc.imu_rate) + 64
+    imu = [syn.imu(s, nimu) for s in seqs]
+    k = [0] * S
+    for f, tf in enumerate(vio_ct.frame_times(sc, n)):
+        for i in range(S):
+            k2 = vio_ct.imu_until(imu[i][0], k[i], tf, sc.imu_rate)
+            bb.push_imu(i, imu[i][0][k[i]:k2], imu[i][1][k[i]:k2], imu[i][2][k[i]:k2]); k[i] = k2
+        bb.feed(np.stack([frames[i][f][0] for i in range(S)]), np.stack([frames[i][f][1] for i in range(S)]), [tf] * S)
+    for i in range(S):
+        h1, hf = b1.odometry_history(i), bb.odometry_history(i)
+        assert h1.shape == hf.shape and len(h1) >= 20 and np.array_equal(h1, hf), i
+
+
+def test_latest_odometry_at_imu_rate(P):
+    """pubLatestOdometry's pose (Estimator::predict after updateLatestStates, estimator.cpp:1768-1788, 1862-1880): the newest window
+    state propagated through the IMU samples pushed after the last frame, against the oracle and against ground truth."""
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    seq, n = 14, 30
+    syn = P.Synth(sc)
+    ti, ai, gi = syn.imu(seq, int(n / sc.cam_rate * sc.imu_rate) + 64)
+    b = P.VioBatch(cfg, 1)
+    o = vio_ct.OraclePipeline(cfg)
+    k = 0
+    for f, tf in enumerate(vio_ct.frame_times(sc, n)):
+        k2 = vio_ct.imu_until(ti, k, tf, sc.imu_rate)
+        b.push_imu(0, ti[k:k2], ai[k:k2], gi[k:k2]); o.push_imu(ti[k:k2], ai[k:k2], gi[k:k2]); k = k2
+        g, d = syn.render_host(seq, float(tf))
+        b.feed(g[None], d[None], [tf]); o.feed(g, d, tf)
+    assert b.status(0).solver_flag == 1
+    lo0, lh0 = o.latest_odometry(), b.latest_odometry(0)
+    assert abs(lh0[0] - lo0[0]) < 1e-12 and np.abs(lh0[1:] - lo0[1:]).max() < 1e-5
+    # 12 more samples (60 ms) arrive before the next frame
+    b.push_imu(0, ti[k:k + 12], ai[k:k + 12], gi[k:k + 12]); o.push_imu(ti[k:k + 12], ai[k:k + 12], gi[k:k + 12])
+    lo, lh = o.latest_odometry(), b.latest_odometry(0)
+    assert abs(lh[0] - ti[k + 11]) < 1e-12 and abs(lo[0] - lh[0]) < 1e-12
+    assert np.abs(lh[1:] - lo[1:]).max() < 1e-5
+    assert np.linalg.norm(lh[1:4] - lh0[1:4]) > 1e-3                                  # the pose really moved with the IMU
+    p_gt = syn.pose(seq, float(lh[0]))[0]
+    w = b.window(0)
+    # 60 ms of dead reckoning against ground truth (lengths: the estimator's world frame is not the ground-truth frame)
+    d_est = np.linalg.norm(lh[1:4] - w[cfg.window_size, :3])
+    d_gt = np.linalg.norm(p_gt - syn.pose(seq, float(w[cfg.window_size, 16]))[0])
+    assert abs(d_est - d_gt) < 0.005, (d_est, d_gt)
+
+
 def test_imu_from_a_second_thread_and_batched_push(P):
     """Estimator::inputIMU is called from the ROS callback thread while the image thread runs (estimator.cpp:1749-1766): vio_push_imu
     from a second thread concurrent with vio_feed, and vio_push_imu_batch, must reproduce the single-threaded per-sequence run."""

@@ -52,6 +52,8 @@ def oracle():
             "ovio_track": [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
             "ovio_process_obs": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
             "ovio_predict_motion": [C.c_void_p, C.c_double, C.c_double, C.c_void_p],
+            "ovio_latest_odometry": [C.c_void_p, C.c_void_p],
+            "ovio_set_tracker_lag": [C.c_void_p, C.c_int],
             "ovio_get_landmarks_ex": [C.c_void_p, C.c_int, C.c_void_p],
             "ovio_gate_create": [C.c_int, C.c_int], "ovio_gate_destroy": [C.c_void_p], "ovio_gate_step": [C.c_void_p, C.c_double],
             "ovio_gate_empty_map": [C.c_void_p, C.c_double],
@@ -120,6 +122,14 @@ class OraclePipeline:
         R = np.zeros(9)
         self.L.ovio_predict_motion(self.h, float(t0), float(t1), R.ctypes.data)
         return R.reshape(3, 3)
+
+    def set_tracker_lag(self, lag):
+        self.L.ovio_set_tracker_lag(self.h, int(lag))
+
+    def latest_odometry(self):
+        o = np.zeros(11)
+        self.L.ovio_latest_odometry(self.h, o.ctypes.data)
+        return o
 
     def landmarks_ex(self, cap=4096):
         out = np.zeros((cap, 12))
@@ -241,13 +251,15 @@ def ate_rmse(est, gt):
     return float(np.sqrt(((al - gt) ** 2).sum(1).mean()))
 
 
-def run_oracle_sequence(cfg, sc, seq, n_frames, frames=None, modes=None, hook=None):
+def run_oracle_sequence(cfg, sc, seq, n_frames, frames=None, modes=None, hook=None, tracker_lag=0):
     """Drive the oracle over n_frames of sequence seq. frames: optional list of (gray, depth) to reuse; modes: optional per-frame
     frame mode (0 skip / 1 track / 2 publish); hook(f, oracle): called after every frame.
     Returns dict(traj=[(frame, P(3), Q(4), V(3))], gt=..., status=[...], frames=[...])."""
     P = pkg()
     syn = P.Synth(sc)
     o = OraclePipeline(cfg)
+    if tracker_lag:
+        o.set_tracker_lag(tracker_lag)
     nimu = int(n_frames / sc.cam_rate * sc.imu_rate) + 64
     ti, ai, gi = syn.imu(seq, nimu)
     k = 0
@@ -276,13 +288,15 @@ def run_oracle_sequence(cfg, sc, seq, n_frames, frames=None, modes=None, hook=No
     return out
 
 
-def run_hip_batch(P, cfg, sc, seqs, n_frames, frames, modes=None, hook=None, imu_batch=False):
+def run_hip_batch(P, cfg, sc, seqs, n_frames, frames, modes=None, hook=None, imu_batch=False, tracker_lag=0):
     """Drive a VioBatch over host frames (frames[i][f] = (gray, depth) of sequence seqs[i]) with IMU pushed frame by frame.
     modes: optional [n_frames] frame modes applied to every sequence; hook(f, batch) after every frame.
     Returns (batch, traj, stat): per sequence [(frame, P, Q, V)] and [vio_status per frame]."""
     syn = P.Synth(sc)
     S = len(seqs)
     b = P.VioBatch(cfg, S)
+    if tracker_lag:
+        b.set_tracker_lag(tracker_lag)
     nimu = int(n_frames / sc.cam_rate * sc.imu_rate) + 64
     imu = [syn.imu(s, nimu) for s in seqs]
     k = [0] * S

@@ -17,7 +17,8 @@ import vio_ct  # noqa: E402
 NAMES = {0: "vector2double", 1: "lm indexing", 2: "pair lists", 4: "evaluate(first/accepted)", 5: "assemble", 6: "prepare_point", 7: "cauchy", 8: "schur",
          9: "cholesky", 10: "tri solves", 11: "dogleg/model", 12: "candidate evaluate", 13: "accept/bookkeeping",
          16: "marg prior", 17: "marg imu", 18: "marg proj eval", 19: "marg lm rows", 20: "marg frame blocks+rank update", 21: "marg 15x15 + reduce",
-         22: "marg new prior + c0", 23: "marg keep data",
+         22: "marg new prior + c0", 23: "marg keep data", 24: "  marg frame blocks (mfma)", 25: "  marg scatter", 27: "finish consistency check",
+         28: "finish slide states", 29: "finish slide landmarks", 30: "finish removeFailures + odom",
          32: "asm zero", 33: "asm prior", 34: "asm imu blocks", 35: "asm pair blocks", 36: "asm element sums", 37: "asm lm rows",
          40: "ev prior dx", 46: "ev imu", 41: "ev pair geo", 44: "ev prior matvec + proj", 45: "ev reduce"}
 
@@ -59,6 +60,7 @@ def main():
     for k in sorted(NAMES):
         if us[k] > 0:
             print("%3d %-28s %8.1f us/frame" % (k, NAMES[k], us[k]))
+    print("MARGIN_OLD frames of sequence 0: %d of %d" % (int(out[31]), a.frames))
     print("solve top-level sum %.1f us, marg sum %.1f us" % (sum(us[k] for k in (0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)), sum(us[16:24])))
 
 

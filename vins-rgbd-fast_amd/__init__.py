@@ -105,6 +105,8 @@ def lib():
         L.vio_get_window.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.vio_get_odometry.argtypes = [C.c_void_p, C.c_void_p]
         L.vio_get_extrinsic.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.vio_get_latest_odometry.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.vio_set_tracker_lag.argtypes = [C.c_void_p, C.c_int]
         L.vio_get_tracks.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.vio_get_landmarks.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.vio_get_prior.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
@@ -372,6 +374,16 @@ class VioBatch:
         o = np.zeros((cap, 11))
         n = self._chk(self.L.vio_get_odometry_history(self.h, seq, cap, o.ctypes.data), "vio_get_odometry_history")
         return o[:min(n, cap)]
+
+    def set_tracker_lag(self, lag):
+        """0: the tracker of frame f+1 waits for the optimisation of frame f; 1: it overlaps it, reading latest_Bg / td as of frame f-1"""
+        self._chk(self.L.vio_set_tracker_lag(self.h, int(lag)), "vio_set_tracker_lag")
+
+    def latest_odometry(self, seq=0):
+        """IMU-rate pose (pubLatestOdometry): t, P(3), Q(wxyz), V(3) of the newest window state propagated through the IMU pushed since"""
+        o = np.zeros(11)
+        self._chk(self.L.vio_get_latest_odometry(self.h, seq, o.ctypes.data), "vio_get_latest_odometry")
+        return o
 
     def extrinsic(self, seq=0):
         e = np.zeros(13)

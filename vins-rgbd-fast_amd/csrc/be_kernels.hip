@@ -501,6 +501,10 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
     const int ext_n = ext ? src.n_obs[s] : 0;
     const double in_stamp = ext ? src.stamps[s] : fe.cur_time;
     if (t == 0) {
+        // the state the next call's tracker sees with tracker lag 1 (that tracker runs while THIS frame is still being optimised)
+        for (int k = 0; k < 3; k++) be.track_Bg[k] = be.latest_Bg[k];
+        be.track_td = be.td;
+        be.imu_count_ingest = be.imu_count;
         be.do_solve = 0; be.do_marg = 0; be.processed = 0; be.rebooted = 0; be.init_frame = 0; be.dyn_failed = 0;
         be.status_code = (!ext && fe.n_forw == -2) ? VIO_NEED_IMU : VIO_OK;
         be.cur_stamp = in_stamp;
@@ -1478,7 +1482,8 @@ __device__ __forceinline__ void solve_epilogue(Ctx &c, const Params &X, double c
                 be.td = cfg.td;
                 be.first_imu = 0; be.frame_count = 0; be.solver_flag = 0; be.openExEstimation = 0; be.has_prior = 0;
                 be.initFirstPoseFlag = 0; be.prevTime = -1; be.n_lm = 0; be.n_free = c.NL; be.ring_base = 0;
-                be.imu_head = be.imu_count;  // clearState() empties imu_buf
+                be.imu_head = be.imu_count_ingest;  // clearState() empties imu_buf (samples pushed for the next frame while this one was
+                                                     // being optimised - tracker lag 1 - arrived after the reset)
                 be.reboot_count++;
                 be.status_code = VIO_REBOOTED;
                 be.rebooted = 1;
@@ -1930,17 +1935,19 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
         if (cfg.use_imu && p1.sum_dt < 10.0) {
             double *Jw = c.pairblk;         // 15x30 whitened
             double *raw = c.imu_raw;        // 15x31
-            if (t == 0) {
-                double r15[15], Jr[450];
+            // five work types (whitened residual + four Jacobian column groups), each on its own wavefront, like evaluate()
+            if ((t & 63) == 0) for (int part = t >> 6; part < 5; part += nt >> 6) {
                 v3 G = ld3(be.g);
-                bf::imu_raw_residual(p1, G, &X.pose[0], &X.sb[0], &X.pose[7], &X.sb[9], r15);
-                bf::imu_raw_jacobian(p1, G, &X.pose[0], &X.sb[0], &X.pose[7], &X.sb[9], Jr);
-                for (int r = 0; r < 15; r++) {
-                    double sacc = 0;
-                    for (int k = 0; k <= r; k++) sacc += p1.sqrt_info[r * 15 + k] * r15[k];
-                    raw[r * 31 + 30] = sacc;
-                    for (int q = 0; q < 30; q++) raw[r * 31 + q] = Jr[r * 30 + q];
-                }
+                if (part == 0) {
+                    double r15[15];
+                    bf::imu_raw_residual(p1, G, &X.pose[0], &X.sb[0], &X.pose[7], &X.sb[9], r15);
+                    for (int r = 0; r < 15; r++) {
+                        double sacc = 0;
+                        for (int k = 0; k <= r; k++) sacc += p1.sqrt_info[r * 15 + k] * r15[k];
+                        raw[r * 31 + 30] = sacc;
+                    }
+                } else
+                    bf::imu_raw_jacobian_part(p1, G, &X.pose[0], &X.sb[0], &X.pose[7], &X.sb[9], part - 1, raw, 31);
             }
             __syncthreads();
             for (int w = t; w < 450; w += nt) {
@@ -2010,31 +2017,46 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
         const int ldc = c.LW;
         for (int w = t; w < F0c * ldc; w += nt) Cl[w] = 0;
         __syncthreads();
-        for (int w = t; w < F0c * mq; w += nt) {
-            int li = w / mq, col = w - li * mq;
-            int slot = list0[li];
-            int no = c.lm_nobs[slot];
-            // which local column of which residuals feed q-column `col`?
-            double sacc = 0;
-            if (col < 6) { for (int k = 1; k < no; k++) { const double *Jr = c.res + (size_t)(li * per + k - 1) * 42; sacc += Jr[col] * Jr[19] + Jr[20 + col] * Jr[39]; } }
-            else if (col >= md && col < md + 6 * W) {
-                int kf = (col - md) / 6 + 1, d = (col - md) % 6;
-                if (kf < no) { const double *Jr = c.res + (size_t)(li * per + kf - 1) * 42; sacc = Jr[6 + d] * Jr[19] + Jr[26 + d] * Jr[39]; }
-            } else if (col >= rE && col < rE + 6) {
-                int e = 12 + (col - rE);
-                for (int k = 1; k < no; k++) { const double *Jr = c.res + (size_t)(li * per + k - 1) * 42; sacc += Jr[e] * Jr[19] + Jr[20 + e] * Jr[39]; }
-            } else if (col == rT && cfg.estimate_td) {
-                for (int k = 1; k < no; k++) { const double *Jr = c.res + (size_t)(li * per + k - 1) * 42; sacc += Jr[18] * Jr[19] + Jr[38] * Jr[39]; }
+        // per landmark: c_l = J_q^T J_l over its residuals, d_l = J_l^T J_l, b_l = J_l^T r.  Sixteen lanes per landmark, lane = residual
+        // (frame k = lane + 1): the columns of the lane's own frame are written directly, the columns every residual shares
+        // (oldest pose, extrinsic, td) and d_l / b_l are reduced over the sixteen lanes.
+        {
+            const int grp = t >> 4, gln = t & 15, ngrp = nt >> 4;
+            for (int li0 = 0; li0 < F0c; li0 += ngrp) {
+                const int li = li0 + grp;
+                const bool act = li < F0c;
+                const int no = act ? c.lm_nobs[list0[li]] : 0;
+                double cm[13], dsum = 0, bsum = 0;
+#pragma unroll
+                for (int q = 0; q < 13; q++) cm[q] = 0;
+                for (int k = gln + 1; k < no; k += 16) {
+                    const double *Jr = c.res + (size_t)(li * per + k - 1) * 42;
+                    const double jl0 = Jr[19], jl1 = Jr[39];
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        cm[q] += Jr[q] * jl0 + Jr[20 + q] * jl1;
+                        cm[6 + q] += Jr[12 + q] * jl0 + Jr[32 + q] * jl1;
+                        Cl[(size_t)li * ldc + md + 6 * (k - 1) + q] = Jr[6 + q] * jl0 + Jr[26 + q] * jl1;
+                    }
+                    if (cfg.estimate_td) cm[12] += Jr[18] * jl0 + Jr[38] * jl1;
+                    dsum += jl0 * jl0 + jl1 * jl1;
+                    bsum += jl0 * Jr[40] + jl1 * Jr[41];
+                }
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1) {
+#pragma unroll
+                    for (int q = 0; q < 13; q++) cm[q] += __shfl_xor(cm[q], off, 16);
+                    dsum += __shfl_xor(dsum, off, 16);
+                    bsum += __shfl_xor(bsum, off, 16);
+                }
+                if (act && gln == 0) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) { Cl[(size_t)li * ldc + q] = cm[q]; Cl[(size_t)li * ldc + rE + q] = cm[6 + q]; }
+                    if (cfg.estimate_td) Cl[(size_t)li * ldc + rT] = cm[12];
+                    c.Hll[li] = dsum;
+                    c.gl[li] = bsum;
+                }
             }
-            Cl[(size_t)li * ldc + col] = sacc;
-        }
-        for (int li = t; li < F0c; li += nt) {
-            int slot = list0[li];
-            int no = c.lm_nobs[slot];
-            double d = 0, bl = 0;
-            for (int k = 1; k < no; k++) { const double *Jr = c.res + (size_t)(li * per + k - 1) * 42; d += Jr[19] * Jr[19] + Jr[39] * Jr[39]; bl += Jr[19] * Jr[40] + Jr[39] * Jr[41]; }
-            c.Hll[li] = d;
-            c.gl[li] = bl;
         }
         __syncthreads();
         PH(19);
@@ -2077,34 +2099,44 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
         }
         for (int li = t; li < F0c; li += nt) { double d = c.Hll[li]; c.Hll[li] = d > eps ? 1.0 / d : 0.0; }  // pseudo-inverse of the diagonal block
         __syncthreads();
-        // A_qq += sum_j G_j (scattered) - C^T D^+ C ; b_q likewise.  q-column -> local column of a frame-j residual:
-        auto qloc = [&](int col, int j) -> int {
-            if (col < 6) return col;
-            if (col >= md && col < md + 6 * W) return ((col - md) / 6 + 1 == j) ? 6 + (col - md) % 6 : -1;
-            if (col >= rE && col < rE + 6) return 12 + (col - rE);
-            if (col == rT) return cfg.estimate_td ? 18 : -1;
-            return -1;
-        };
-        for (int w = t; w < mq * (mq + 1); w += nt) {
-            int a = w / (mq + 1), bb = w - a * (mq + 1);
-            bool a_vis = a < 6 || (a >= md && a < md + 6 * W) || (a >= rE);
-            if (!a_vis) continue;
-            double sacc = 0;
-            for (int j = 1; j <= W; j++) {
-                int la = qloc(a, j);
-                if (la < 0) continue;
-                int lb = bb < mq ? qloc(bb, j) : 19;
-                if (lb < 0) continue;
-                sacc += c.pairblk[(size_t)(j - 1) * 210 + sym_idx(la, lb)];
-            }
-            if (bb < mq) A[a * mq + bb] += sacc;
-            else {
-                double sub_ = 0;
-                for (int li = 0; li < F0c; li++) sub_ += Cl[(size_t)li * ldc + a] * c.gl[li] * c.Hll[li];
-                b[a] += sacc - sub_;
-            }
+        PH(24);
+        // A_qq += sum_j G_j (scattered) - C^T D^+ C ; b_q likewise.  Per q-column (and the right-hand side, index mq): the frame whose
+        // residuals carry it (0 = every residual: oldest pose, extrinsic, td, rhs; -1 = none) and its local column in a residual record
+        __shared__ signed char qfr[6 * VIO_MAXW + 40], qlc[6 * VIO_MAXW + 40];
+        __shared__ double sub_part[4][6 * VIO_MAXW + 40];
+        for (int a = t; a <= mq; a += nt) {
+            int fr = -1, lc = 0;
+            if (a == mq) { fr = 0; lc = 19; }
+            else if (a < 6) { fr = 0; lc = a; }
+            else if (a >= md && a < md + 6 * W) { fr = (a - md) / 6 + 1; lc = 6 + (a - md) % 6; }
+            else if (a >= rE && a < rE + 6) { fr = 0; lc = 12 + (a - rE); }
+            else if (a == rT && cfg.estimate_td) { fr = 0; lc = 18; }
+            qfr[a] = (signed char)fr; qlc[a] = (signed char)lc;
+        }
+        // b_q -= C^T D^+ b_l: four interleaved partial sums per column, added in a fixed order
+        for (int w = t; w < 4 * mq; w += nt) {
+            const int ch = w / mq, a = w - ch * mq;
+            double acc = 0;
+            for (int li = ch; li < F0c; li += 4) acc += Cl[(size_t)li * ldc + a] * (c.gl[li] * c.Hll[li]);
+            sub_part[ch][a] = acc;
         }
         __syncthreads();
+        for (int w = t; w < mq * (mq + 1); w += nt) {
+            const int a = w / (mq + 1), bb = w - a * (mq + 1);
+            const int fa = qfr[a], fb = qfr[bb];
+            if (fa < 0 || fb < 0) continue;
+            const int la = qlc[a], lb = qlc[bb];
+            double sacc = 0;
+            if (fa > 0 || fb > 0) {
+                if (fa > 0 && fb > 0 && fa != fb) continue;
+                sacc = c.pairblk[(size_t)((fa > 0 ? fa : fb) - 1) * 210 + sym_idx(la, lb)];
+            } else
+                for (int j = 1; j <= W; j++) sacc += c.pairblk[(size_t)(j - 1) * 210 + sym_idx(la, lb)];
+            if (bb < mq) A[a * mq + bb] += sacc;
+            else b[a] += sacc - ((sub_part[0][a] + sub_part[1][a]) + (sub_part[2][a] + sub_part[3][a]));
+        }
+        __syncthreads();
+        PH(25);
         // A_qq -= C^T D^+ C : rank-F0c update on the FP64 matrix cores, lower 16x16 tiles mirrored into the upper triangle
         {
             const int lane = t & 63, wave = t >> 6, nw = nt >> 6, li = lane & 15, lk = lane >> 4;
@@ -2147,6 +2179,7 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
         }
         __syncthreads();
     }
+    if (s == 0 && t == 0 && !second_new) B.timings[31] += 1.0f;
     PH(20);
     // ---- eliminate the m-block (md x md) with a truncated eigen-decomposition
     for (int w = t; w < md * md; w += nt) { int i = w / md, j = w - i * md; A15[w] = 0.5 * (A[i * mq + j] + A[j * mq + i]); }
@@ -2302,6 +2335,7 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
     __shared__ int sh_i[4];
     double *od = B.odom + (size_t)s * 11;
     if (!be.processed || be.rebooted) return;
+    PH_INIT;
     int nlm = be.n_lm;
     int *flag = c.lm_pidx, *offs = c.lm_aidx;  // free after the solve
     const int fc = be.frame_count;
@@ -2359,6 +2393,7 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
         __syncthreads();
         // failureDetection (estimator.cpp:1113-1159) ran at the end of be_solve (see there); a sequence that rebooted never gets here
     }
+    PH(27);
     // ---- slideWindow (estimator.cpp:1580-1689)
     if (be.marginalization_flag == 0) {
         if (t == 0) {
@@ -2376,6 +2411,7 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
             bf::preint_init(c.pre[first], ld3(be.acc_0), ld3(be.gyr_0), ld3(be.Bas[W]), ld3(be.Bgs[W]));
         }
         __syncthreads();
+        PH(28);
         // slideWindowOld -> removeBackShiftDepth (feature_manager.cpp:660-691); solver_flag is NON_LINEAR here
         m3 R0 = mul(ldm(be.back_R0), ldm(be.ric)), R1 = mul(ldm(be.Rs[0]), ldm(be.ric));
         v3 P0 = add(ld3(be.back_P0), mul(ldm(be.back_R0), ld3(be.tic))), P1 = add(ld3(be.Ps[0]), mul(ldm(be.Rs[0]), ld3(be.tic)));
@@ -2453,6 +2489,7 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
         __syncthreads();
         lm_compact(c, flag, offs, scratch);
     }
+    PH(29);
     if (dyn_initial) return;   // still INITIAL: nothing to publish
     // ---- removeFailures (feature_manager.cpp:225-233); not called on the STATIC initialisation frame (estimator.cpp:282-290)
     if (sflag0 == 1) {
@@ -2476,6 +2513,7 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
         B.odom_count[s] = hc + 1;
         if (be.overflow) be.overflow_frames++;
     }
+    PH(30);
 }
 
 // ====================================================================================================== dynamic init hand-over

@@ -103,7 +103,7 @@ __device__ dm::m3 predict_motion(const Batch &B, int s, double t0, double t1) {
     double prev_t = 0;
     dm::v3 prev_gyr = dm::mk(0, 0, 0);
     dm::m3 ricT = dm::tr(dm::ldm(C.c.ric));
-    dm::v3 bg = dm::ld3(be.latest_Bg);
+    dm::v3 bg = dm::ld3(B.tracker_lag ? be.track_Bg : be.latest_Bg);
     while (k < be.imu_count && it[k % C.NIMU] <= t1) {
         double tk = it[k % C.NIMU];
         dm::v3 w = dm::ld3(ig + (size_t)(k % C.NIMU) * 3);
@@ -126,6 +126,45 @@ __device__ dm::m3 predict_motion(const Batch &B, int s, double t0, double t1) {
     }
     return rel;
 }
+// Estimator::predict (estimator.cpp:1862-1880) applied from the newest window state through every IMU sample that arrived after it:
+// what pubLatestOdometry publishes at IMU rate (inputIMU, :1749-1766, after updateLatestStates :1768-1788).  out11 = t, P(3),
+// Q(w, x, y, z), V(3); returns the window state itself when no newer sample is in the ring.  Output only: nothing is modified.
+// (updateLatestStates replays the buffered samples with the values of the queue's FRONT sample; here every sample is
+// applied with its own values, DESIGN.md deviation 14.)
+__global__ void be_latest_odometry_kernel(Batch B, int seq, double *out11) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const DevCfg &C = *B.cfg;
+    const BeSeq &be = B.be[seq];
+    const int fc = be.frame_count;
+    double latest_time = be.Headers[fc] + be.td;
+    dm::v3 P = dm::ld3(be.Ps[fc]), V = dm::ld3(be.Vs[fc]), Ba = dm::ld3(be.Bas[fc]), Bg = dm::ld3(be.Bgs[fc]), g = dm::ld3(be.g);
+    dm::m3 R = dm::ldm(be.Rs[fc]);
+    dm::v3 acc_0 = dm::ld3(be.acc_0), gyr_0 = dm::ld3(be.gyr_0);
+    const double *it = B.imu_t + (size_t)seq * C.NIMU, *ia = B.imu_acc + (size_t)seq * C.NIMU * 3, *ig = B.imu_gyr + (size_t)seq * C.NIMU * 3;
+    int k = be.imu_head;
+    if (be.imu_count - k > C.NIMU) k = be.imu_count - C.NIMU;
+    if (be.solver_flag == 1 && C.c.use_imu)
+        for (; k < be.imu_count; k++) {
+            const int idx = k % C.NIMU;
+            const double t = it[idx];
+            if (!(t > latest_time)) continue;
+            const double dt = t - latest_time;
+            latest_time = t;
+            const dm::v3 a1 = dm::ld3(ia + (size_t)idx * 3), w1 = dm::ld3(ig + (size_t)idx * 3);
+            const dm::v3 un_acc_0 = dm::sub(dm::mul(R, dm::sub(acc_0, Ba)), g);
+            const dm::v3 un_gyr = dm::sub(dm::scl(0.5, dm::add(gyr_0, w1)), Bg);
+            R = dm::mul(R, dm::q2R(dm::deltaQ(dm::scl(dt, un_gyr))));
+            const dm::v3 un_acc_1 = dm::sub(dm::mul(R, dm::sub(a1, Ba)), g);
+            const dm::v3 un_acc = dm::scl(0.5, dm::add(un_acc_0, un_acc_1));
+            P = dm::add(dm::add(P, dm::scl(dt, V)), dm::scl(0.5 * dt * dt, un_acc));
+            V = dm::add(V, dm::scl(dt, un_acc));
+            acc_0 = a1; gyr_0 = w1;
+        }
+    const dm::quat q = dm::R2q(R);
+    out11[0] = latest_time; out11[1] = P.x; out11[2] = P.y; out11[3] = P.z;
+    out11[4] = q.w; out11[5] = q.x; out11[6] = q.y; out11[7] = q.z; out11[8] = V.x; out11[9] = V.y; out11[10] = V.z;
+}
+
 // vio_predict_motion: one sequence, result to out9 (row-major)
 __global__ void fe_predict_motion_kernel(Batch B, int seq, double t0, double t1, double *out9) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -143,6 +182,7 @@ __global__ void fe_begin_kernel(Batch B, const double *stamps, int gate, int pub
     FeSeq &fe = B.fe[s];
     const BeSeq &be = B.be[s];  // read-only here: the previous frame's marginalisation may still be running on the other stream
     double t = stamps[s];
+    const double td = B.tracker_lag ? be.track_td : be.td;
     fe.n_deficit = 0;
     fe.n_obs = 0;
     fe.publish_ok = 0;
@@ -156,7 +196,7 @@ __global__ void fe_begin_kernel(Batch B, const double *stamps, int gate, int pub
         bool have = be.imu_count > imu_head;
         double back_t = have ? it[(be.imu_count - 1) % C.NIMU] : -1e300;
         // caller contract of vio_feed: IMU pushed through stamp + td (upstream busy-waits, estimator.cpp:178-183); VO mode has no IMU
-        if (C.c.use_imu && !(have && t + be.td <= back_t)) {
+        if (C.c.use_imu && !(have && t + td <= back_t)) {
             fe.n_forw = -2;  // nothing consumed; tells the later kernels to skip this sequence (be_ingest reports VIO_NEED_IMU)
             return;
         }
@@ -180,7 +220,7 @@ __global__ void fe_begin_kernel(Batch B, const double *stamps, int gate, int pub
         for (int k = 0; k < 9; k++) fe.R_rel[k] = Rc[k];
         fe.use_R_rel = 1;
     } else {
-        dm::stm(fe.R_rel, predict_motion(B, s, fe.last_image_time, t + be.td));
+        dm::stm(fe.R_rel, predict_motion(B, s, fe.last_image_time, t + td));
         fe.use_R_rel = 0;
     }
     fe.last_image_time = t;

@@ -11,6 +11,7 @@ struct LkImages {
 };
 
 __global__ void fe_begin_kernel(Batch B, const double *stamps, int gate, int publish, const uint8_t *modes, const double *R_rel);
+__global__ void be_latest_odometry_kernel(Batch B, int seq, double *out11);
 __global__ void fe_predict_motion_kernel(Batch B, int seq, double t0, double t1, double *out9);
 __global__ void fe_pyrdown_kernel(Batch B, const uint8_t *src_base, size_t src_stride, int sw, int sh, int dst_level, int write_level0);
 __global__ void fe_pyrdown_stage_kernel(const uint8_t *src, int sw, int sh, uint8_t *dst);

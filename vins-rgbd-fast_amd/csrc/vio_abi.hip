@@ -47,10 +47,11 @@ struct vio_batch {
         int s0 = 0, n = 0;
         hipStream_t stream = nullptr;     // back-end (and uploads that feed it)
         hipStream_t fe_stream = nullptr;  // front-end: frame k+1 tracks while frame k is still being marginalised
-        hipEvent_t ev_solve = nullptr, ev_fe = nullptr, ev_be = nullptr;
-        bool have_solve_ev = false;
+        hipEvent_t ev_solve = nullptr, ev_fe = nullptr, ev_be = nullptr, ev_ingest = nullptr;
+        bool have_solve_ev = false, have_ingest_ev = false;
     };
     std::vector<Group> groups;
+    int tracker_lag = 0;              // vio_set_tracker_lag
     hipStream_t stream = nullptr;     // = groups[0].stream (returned by vio_get_stream; IMU scatter runs here)
     hipStream_t fe_stream = nullptr;  // = groups[0].fe_stream
     hipEvent_t ev[4];
@@ -193,6 +194,7 @@ int init_state(vio_batch *h, int s_lo, int s_hi) {
         for (int k = 0; k < 9; k++) b.ric[k] = C.c.ric[k];
         for (int k = 0; k < 3; k++) b.tic[k] = C.c.tic[k];
         b.td = C.c.td;
+        b.track_td = C.c.td;
         b.g[2] = C.c.g_norm;
         b.prevTime = -1;
         b.n_free = C.NL;
@@ -288,7 +290,8 @@ int flush_imu_frontend(vio_batch *h) {
     }
     hipStream_t st = h->groups[0].fe_stream;
     for (auto &g : h->groups) {
-        if (g.have_solve_ev) HIPCHK(hipStreamWaitEvent(st, g.ev_solve, 0));
+        if (h->tracker_lag) { if (g.have_ingest_ev) HIPCHK(hipStreamWaitEvent(st, g.ev_ingest, 0)); }   // be_ingest is the last reader of the rings
+        else if (g.have_solve_ev) HIPCHK(hipStreamWaitEvent(st, g.ev_solve, 0));
         HIPCHK(hipStreamWaitEvent(st, g.ev_be, 0));
     }
     bool launched = false;
@@ -504,6 +507,7 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
     if (prof) PEV(h, 8);
     be_ingest_kernel<<<S, 256, (size_t)C.lm_hash_size * 8, st>>>(Bg, d_depth, (size_t)C.c.width * C.c.height, src);
     if (prof) PEV(h, 9);
+    if (one_seq < 0) { (void)hipEventRecord(g.ev_ingest, st); g.have_ingest_ev = true; }  // tracker lag 1: the next frame's front-end starts here
     if (h->dyn_active || (C.c.dynamic_init && one_seq >= 0)) {
         // some sequence of this handle is still INITIAL under static_init: 0: the host collects its image frame / runs the
         // initialisation between the two halves of the back-end (once per sequence; the steady state below never synchronises)
@@ -725,7 +729,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
             g.n = std::min(per, n_seq - g.s0);
             if (hipStreamCreate(&g.stream) != hipSuccess || hipStreamCreate(&g.fe_stream) != hipSuccess) { g_err = "stream create failed"; rc = VIO_EDEVICE; break; }
             if (hipEventCreateWithFlags(&g.ev_solve, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g.ev_fe, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&g.ev_be, hipEventDisableTiming) != hipSuccess) { g_err = "event create failed"; rc = VIO_EDEVICE; }
+                hipEventCreateWithFlags(&g.ev_be, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g.ev_ingest, hipEventDisableTiming) != hipSuccess) { g_err = "event create failed"; rc = VIO_EDEVICE; }
         }
         if (rc == VIO_OK) { h->stream = h->groups[0].stream; h->fe_stream = h->groups[0].fe_stream; }
         if (rc == VIO_OK && hipEventCreateWithFlags(&h->ev_imu, hipEventDisableTiming) != hipSuccess) { g_err = "event create failed"; rc = VIO_EDEVICE; }
@@ -825,6 +829,7 @@ void vio_destroy(vio_batch *h) {
         if (g.ev_solve) (void)hipEventDestroy(g.ev_solve);
         if (g.ev_fe) (void)hipEventDestroy(g.ev_fe);
         if (g.ev_be) (void)hipEventDestroy(g.ev_be);
+        if (g.ev_ingest) (void)hipEventDestroy(g.ev_ingest);
     }
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
@@ -876,8 +881,10 @@ static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, 
 }
 
 // front-end of this frame may overlap the marginalisation of the previous one: it waits only for the previous solve
-static int fe_wait(vio_batch::Group &g) {
-    if (g.have_solve_ev) HIPCHK(hipStreamWaitEvent(g.fe_stream, g.ev_solve, 0));
+// (tracker lag 1: only for the previous be_ingest -- the tracker reads the state snapshot that kernel took, see vio_set_tracker_lag)
+static int fe_wait(vio_batch *h, vio_batch::Group &g) {
+    if (h->tracker_lag) { if (g.have_ingest_ev) HIPCHK(hipStreamWaitEvent(g.fe_stream, g.ev_ingest, 0)); }
+    else if (g.have_solve_ev) HIPCHK(hipStreamWaitEvent(g.fe_stream, g.ev_solve, 0));
     return VIO_OK;
 }
 static int be_wait(vio_batch::Group &g) {
@@ -902,7 +909,7 @@ int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, 
     rc = flush_imu_frontend(h);
     if (rc != VIO_OK) return rc;
     for (auto &g : h->groups) {
-        if ((rc = fe_wait(g)) != VIO_OK) return rc;
+        if ((rc = fe_wait(h, g)) != VIO_OK) return rc;
         const uint8_t *dg = nullptr;
         const uint16_t *dd = nullptr;
         rc = stage_inputs(h, g, gray, depth_mm, stamps, on_device, &dg, &dd);
@@ -931,7 +938,7 @@ static int track_impl(vio_batch *h, const uint8_t *gray, const double *stamps, i
     int rc = flush_imu_frontend(h);
     if (rc != VIO_OK) return rc;
     for (auto &g : h->groups) {
-        if ((rc = fe_wait(g)) != VIO_OK) return rc;
+        if ((rc = fe_wait(h, g)) != VIO_OK) return rc;
         HIPCHK(hipStreamWaitEvent(g.fe_stream, g.ev_be, 0));  // stand-alone use: no overlap with a pending vio_process
         const uint8_t *dg = nullptr;
         const uint16_t *dd = nullptr;
@@ -960,10 +967,34 @@ int vio_predict_motion(vio_batch *h, int seq, double t0, double t1, double *R9) 
     hipStream_t st = h->groups[0].fe_stream;
     for (auto &g : h->groups)
         if (seq >= g.s0 && seq < g.s0 + g.n) st = g.fe_stream;
-    fe_predict_motion_kernel<<<1, 64, 0, st>>>(h->B, seq, t0, t1, h->d_r9);
+    Batch Bq = h->B;
+    Bq.tracker_lag = 0;   // an explicit call reads the estimator as it is now
+    fe_predict_motion_kernel<<<1, 64, 0, st>>>(Bq, seq, t0, t1, h->d_r9);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(R9, h->d_r9, 9 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    return VIO_OK;
+}
+
+int vio_set_tracker_lag(vio_batch *h, int lag) {
+    if (!h || (lag != 0 && lag != 1)) return VIO_EINVAL;
+    if (lag && h->hc.c.dynamic_init) { g_err = "vio_set_tracker_lag: dynamic_init handles run their initialisation on the host between frames (lag 0 only)"; return VIO_EINVAL; }
+    int rc = sync_all(h);
+    if (rc != VIO_OK) return rc;
+    h->tracker_lag = lag;
+    h->B.tracker_lag = lag;
+    return VIO_OK;
+}
+
+int vio_get_latest_odometry(vio_batch *h, int seq, double *out11) {
+    if (!h || seq < 0 || seq >= h->S || !out11) return VIO_EINVAL;
+    int rc = flush_imu_backend(h);   // samples pushed so far must be in the ring
+    if (rc != VIO_OK) return rc;
+    { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
+    be_latest_odometry_kernel<<<1, 64, 0, h->stream>>>(h->B, seq, h->d_r9);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(out11, h->d_r9, 11 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return VIO_OK;
 }
 

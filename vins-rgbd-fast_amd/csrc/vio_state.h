@@ -82,6 +82,10 @@ struct BeSeq {
     double Headers[VIO_MAXW + 1];
     double acc_0[3], gyr_0[3], g[3], ric[9], tic[3], td;
     double latest_Bg[3];
+    // what the tracker of the NEXT vio_feed call reads when the handle runs with tracker lag 1 (vio_set_tracker_lag): latest_Bg / td as
+    // they were when this frame was ingested, and the IMU count a reboot decided by this frame's solve falls back to
+    double track_Bg[3], track_td;
+    int imu_count_ingest;
     double last_R[9], last_R0[9], last_P[3], last_P0[3], back_R0[9], back_P0[3];
     double para_Pose[VIO_MAXW + 1][7], para_SB[VIO_MAXW + 1][9], para_Ex[7], para_Td;
     double prevTime, cur_stamp;
@@ -136,6 +140,7 @@ struct Batch {
     DevCfg *cfg;  // device copy
     int S;
     int s0;               // first sequence of the launching group: kernels use s = blockIdx + s0
+    int tracker_lag;      // 0: fe_begin reads the live estimator state; 1: the snapshot be_ingest took one frame earlier
     FeSeq *fe;
     BeSeq *be;
     PreInt *pre;          // [S][W+2]
