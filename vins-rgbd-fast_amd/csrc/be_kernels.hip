@@ -1915,16 +1915,11 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
             A[pmap(a) * mq + pmap(bb)] += c.prior_H[w];
         }
         for (int a = t; a < n; a += nt) b[pmap(a)] += srp[a];
-        if (t == 0) {
-            if (second_new) {
-                for (int k = 0; k < W - 1; k++) newpresent[k] = be.prior_present[k];
-                newpresent[W - 1] = 0;
-                newpresent[W] = be.prior_present[W];
-            } else {
-                for (int k = 1; k < W; k++) if (be.prior_present[k]) newpresent[k - 1] = 1;
-            }
-            if (be.prior_present[W + 1]) newpresent[W + 1] = 1;
-            if (be.prior_present[W + 2]) newpresent[W + 2] = 1;
+        if (t < W + 3) {
+            const int pres = be.prior_present[t];
+            if (t > W) { if (pres) newpresent[t] = 1; }
+            else if (second_new) { if (t < W - 1 || t == W) newpresent[t] = pres; }
+            else if (t >= 1 && t < W && pres) newpresent[t - 1] = 1;
         }
         __syncthreads();
     }
@@ -2170,12 +2165,10 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
                 }
             }
         }
-        if (t == 0) {
-            for (int li = 0; li < F0c; li++) {
-                int no = c.lm_nobs[list0[li]];
-                for (int k = 1; k < no; k++) newpresent[k - 1] = 1;
-                if (no > 1) { newpresent[W + 1] = 1; if (cfg.estimate_td) newpresent[W + 2] = 1; }
-            }
+        for (int li = t; li < F0c; li += nt) {   // every writer stores the same value
+            int no = c.lm_nobs[list0[li]];
+            for (int k = 1; k < no; k++) newpresent[k - 1] = 1;
+            if (no > 1) { newpresent[W + 1] = 1; if (cfg.estimate_td) newpresent[W + 2] = 1; }
         }
         __syncthreads();
     }
@@ -2184,7 +2177,8 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
     // ---- eliminate the m-block (md x md) with a truncated eigen-decomposition
     for (int w = t; w < md * md; w += nt) { int i = w / md, j = w - i * md; A15[w] = 0.5 * (A[i * mq + j] + A[j * mq + i]); }
     __syncthreads();
-    jacobi_block(A15, V15, md, md, cs, sn, pp, qq, sred);
+    if (t < 64) jacobi_wave16(A15, V15, md, md, cs, sn, pp, qq);   // md <= 15: one wavefront, no workgroup barriers inside
+    __syncthreads();
     for (int w = t; w < md * md; w += nt) {
         int i = w / md, j = w - i * md;
         double sacc = 0;

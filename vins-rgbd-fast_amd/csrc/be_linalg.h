@@ -219,6 +219,73 @@ __device__ int jacobi_block(double *A, double *V, int n, int ld, double *cs, dou
     return sweeps_done;
 }
 
+// The same Jacobi iteration (same pairing, thresholds and rotation order as jacobi_block, hence the same result) run by ONE wavefront
+// for n <= 16, A and V in LDS: a round is three dependent phases, and wave-level ordering instead of workgroup barriers is what
+// makes the ~100 rounds of a 15 x 15 block cheap.  Call from a single wavefront; the caller synchronises the block afterwards.
+#define JW_SYNC() do { __builtin_amdgcn_wave_barrier(); __threadfence_block(); } while (0)
+__device__ int jacobi_wave16(double *A, double *V, int n, int ld, double *cs, double *sn, int *pp, int *qq) {
+    const int lane = threadIdx.x & 63;
+    int sweeps_done = 0;
+    for (int i = lane; i < n * n; i += 64) V[(i / n) * ld + (i % n)] = ((i / n) == (i % n)) ? 1.0 : 0.0;
+    JW_SYNC();
+    const int m = (n + 1) & ~1, half = m / 2;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double dmax = lane < n ? fabs(A[lane * ld + lane]) : 0.0;
+        dmax = wave_max_dpp(dmax);   // uniform over the wavefront
+        const double absfloor = 1e-18 * dmax;
+        double nrot = 0;
+        for (int round = 0; round < m - 1; round++) {
+            if (lane < half) {
+                int a = (lane == 0) ? m - 1 : (round + lane) % (m - 1);
+                int b = (round + m - 1 - lane) % (m - 1);
+                if (lane == 0) b = round % (m - 1);
+                int p = min(a, b), q = max(a, b);
+                double c1 = 1.0, s1 = 0.0;
+                if (q < n) {
+                    double apq = A[p * ld + q];
+                    double app = A[p * ld + p], aqq = A[q * ld + q];
+                    if (fabs(apq) > absfloor && fabs(apq) > 1e-15 * sqrt(fabs(app * aqq))) {
+                        nrot += 1.0;
+                        double tau = (aqq - app) / (2.0 * apq);
+                        double tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c1 = 1.0 / sqrt(1.0 + tt * tt);
+                        s1 = tt * c1;
+                    }
+                } else { p = -1; }
+                pp[lane] = p; qq[lane] = q; cs[lane] = c1; sn[lane] = s1;
+            }
+            JW_SYNC();
+            for (int w = lane; w < half * n; w += 64) {
+                int k = w / n, r = w - k * n;
+                int p = pp[k], q = qq[k];
+                if (p < 0 || sn[k] == 0.0) continue;
+                double c1 = cs[k], s1 = sn[k];
+                double akp = A[r * ld + p], akq = A[r * ld + q];
+                A[r * ld + p] = c1 * akp - s1 * akq;
+                A[r * ld + q] = s1 * akp + c1 * akq;
+                double vkp = V[r * ld + p], vkq = V[r * ld + q];
+                V[r * ld + p] = c1 * vkp - s1 * vkq;
+                V[r * ld + q] = s1 * vkp + c1 * vkq;
+            }
+            JW_SYNC();
+            for (int w = lane; w < half * n; w += 64) {
+                int k = w / n, cc = w - k * n;
+                int p = pp[k], q = qq[k];
+                if (p < 0 || sn[k] == 0.0) continue;
+                double c1 = cs[k], s1 = sn[k];
+                double apk = A[p * ld + cc], aqk = A[q * ld + cc];
+                A[p * ld + cc] = c1 * apk - s1 * aqk;
+                A[q * ld + cc] = s1 * apk + c1 * aqk;
+            }
+            JW_SYNC();
+        }
+        nrot = wave_sum_dpp(nrot);
+        sweeps_done = sweep + 1;
+        if (nrot == 0.0) break;
+    }
+    return sweeps_done;
+}
+
 // Symmetric eigen-decomposition (Householder tridiagonalisation + implicit-shift QL, the algorithm class of
 // Eigen::SelfAdjointEigenSolver used at marginalization_factor.cpp:277,298).  V (n x n, ld) holds A on entry (lower
 // triangle is read) and the eigenvectors (columns) on exit; d = eigenvalues (unsorted), e / gtmp = workspaces; all in LDS.
@@ -779,13 +846,17 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
         // (b) panel: rows of the tiles below solve x L_pp^T = a
         for (int q = t; q < 16 * (nb - 1 - p); q += nt) {
             int ti = p + 1 + (q >> 4), r = q & 15;
+            // right-looking order: as soon as x[k] is known every later column takes its term, so the sixteen accumulators advance side
+            // by side (each still receives its terms in ascending k: same result as the column-by-column form, a quarter of its
+            // dependent chain)
             double x[16];
 #pragma unroll
-            for (int cc = 0; cc < 16; cc++) {
-                double sacc = T[tl_idx(ti, p, r, cc)];
+            for (int cc = 0; cc < 16; cc++) x[cc] = T[tl_idx(ti, p, r, cc)];
 #pragma unroll
-                for (int k = 0; k < cc; k++) sacc -= x[k] * T[tl_idx(p, p, cc, k)];
-                x[cc] = sacc * dinv[16 * p + cc];
+            for (int k = 0; k < 16; k++) {
+                x[k] = x[k] * dinv[16 * p + k];
+#pragma unroll
+                for (int cc = k + 1; cc < 16; cc++) x[cc] -= x[k] * T[tl_idx(p, p, cc, k)];
             }
 #pragma unroll
             for (int cc = 0; cc < 16; cc++) T[tl_idx(ti, p, r, cc)] = x[cc];
@@ -1054,23 +1125,33 @@ __device__ __forceinline__ void matvec_pass_t(const double *M, int ld, int nrows
     double cs[NC], vv[NC];
 #pragma unroll
     for (int j = 0; j < NC; j++) { int a = lane + 64 * j; cs[j] = 0; vv[j] = (v && a < n) ? v[a] : 0.0; }
-#pragma unroll 2
-    for (int k = wave; k < nrows; k += nw) {
-        const double *r = M + (size_t)k * ld;
-        double m[NC];
+    // four rows per trip: all their loads are issued before the first use (one wavefront has nothing else to hide the latency with)
+    constexpr int RB = 4;
+    for (int k0 = wave; k0 < nrows; k0 += RB * nw) {
+        double m[RB][NC], uk[RB];
 #pragma unroll
-        for (int j = 0; j < NC; j++) { int a = lane + 64 * j; m[j] = a < n ? r[a] : 0.0; }
-        if (v) {
-            double rd = 0;
+        for (int b = 0; b < RB; b++) {
+            const int k = k0 + b * nw;
+            const double *r = M + (size_t)min(k, nrows - 1) * ld;
 #pragma unroll
-            for (int j = 0; j < NC; j++) rd += m[j] * vv[j];
-            rd = wave_sum_dpp(rd);
-            if (lane == 0) out_row[k] = rd;
+            for (int j = 0; j < NC; j++) { int a = lane + 64 * j; m[b][j] = a < n ? r[a] : 0.0; }
+            uk[b] = (u && k < nrows) ? u[k] : 0.0;
         }
-        if (u) {
-            const double uk = u[k];
 #pragma unroll
-            for (int j = 0; j < NC; j++) cs[j] += uk * m[j];
+        for (int b = 0; b < RB; b++) {
+            const int k = k0 + b * nw;
+            if (k >= nrows) break;
+            if (v) {
+                double rd = 0;
+#pragma unroll
+                for (int j = 0; j < NC; j++) rd += m[b][j] * vv[j];
+                rd = wave_sum_dpp(rd);
+                if (lane == 0) out_row[k] = rd;
+            }
+            if (u) {
+#pragma unroll
+                for (int j = 0; j < NC; j++) cs[j] += uk[b] * m[b][j];
+            }
         }
     }
     if (u) {
@@ -1102,23 +1183,32 @@ __device__ __forceinline__ void matvec_pass_2range_t(const double *M, int ld, in
         cs[j] = 0;
         vv[j] = (v && col[j] >= 0) ? v[col[j]] : 0.0;
     }
-#pragma unroll 2
-    for (int k = wave; k < nrows; k += nw) {
-        const double *r = M + (size_t)k * ld;
-        double m[NC];
+    constexpr int RB = 4;   // rows per trip, loads first (see matvec_pass_t)
+    for (int k0 = wave; k0 < nrows; k0 += RB * nw) {
+        double m[RB][NC], uk[RB];
 #pragma unroll
-        for (int j = 0; j < NC; j++) m[j] = col[j] >= 0 ? r[col[j]] : 0.0;
-        if (v) {
-            double rd = 0;
+        for (int b = 0; b < RB; b++) {
+            const int k = k0 + b * nw;
+            const double *r = M + (size_t)min(k, nrows - 1) * ld;
 #pragma unroll
-            for (int j = 0; j < NC; j++) rd += m[j] * vv[j];
-            rd = wave_sum_dpp(rd);
-            if (lane == 0) out_row[k] = rd;
+            for (int j = 0; j < NC; j++) m[b][j] = col[j] >= 0 ? r[col[j]] : 0.0;
+            uk[b] = (u && k < nrows) ? u[k] : 0.0;
         }
-        if (u) {
-            const double uk = u[k];
 #pragma unroll
-            for (int j = 0; j < NC; j++) cs[j] += uk * m[j];
+        for (int b = 0; b < RB; b++) {
+            const int k = k0 + b * nw;
+            if (k >= nrows) break;
+            if (v) {
+                double rd = 0;
+#pragma unroll
+                for (int j = 0; j < NC; j++) rd += m[b][j] * vv[j];
+                rd = wave_sum_dpp(rd);
+                if (lane == 0) out_row[k] = rd;
+            }
+            if (u) {
+#pragma unroll
+                for (int j = 0; j < NC; j++) cs[j] += uk[b] * m[b][j];
+            }
         }
     }
     if (u) {

@@ -486,6 +486,17 @@ __global__ __launch_bounds__(64) void ps_schur_kernel(Batch B) {
     }
     const double *wa = Ws + 16 * ti + li, *wb = Ws + 16 * tj + li;
     const double spa = sp[16 * ti + li], spb = sp[16 * tj + li];
+    // per-row factor sl^2 / (sl^2 Hll + mu dgl^2), sl = 1 / (1 + sqrt(Hll)) at the first linearisation: once per row into LDS (a square
+    // root and two divisions each), not once per lane and trip
+    extern __shared__ double wk_s[];
+    for (int kc = lane; kc < Kpad; kc += 64) {
+        double hll = c.Hll[kc], slk = first ? (kc < Fa ? 1.0 / (1.0 + sqrt(hll)) : 0.0) : c.lvec[kc];
+        const double hl = kc < Fa ? slk * slk * hll : 0.0;
+        const double dl = sqrt(fmin(fmax(hl, 1e-6), 1e32));
+        const double iv = kc < Fa ? 1.0 / (hl + mu * dl * dl) : 0.0;
+        wk_s[kc] = slk * slk * iv;
+    }
+    __syncthreads();
     for (int k0 = 0; k0 < Kpad; k0 += 4 * PS_SCH_U) {
         double a[PS_SCH_U], b[PS_SCH_U];
 #pragma unroll
@@ -493,12 +504,7 @@ __global__ __launch_bounds__(64) void ps_schur_kernel(Batch B) {
             const int kk = k0 + 4 * u + lk;
             const bool valid = kk < Kpad;
             const int kc = min(kk, Kpad - 1);
-            // per-row factor sl^2 / (sl^2 Hll + mu dgl^2), sl = 1 / (1 + sqrt(Hll)) at the first linearisation
-            double hll = c.Hll[kc], slk = first ? (kc < Fa ? 1.0 / (1.0 + sqrt(hll)) : 0.0) : c.lvec[kc];
-            const double hl = kc < Fa ? slk * slk * hll : 0.0;
-            const double dl = sqrt(fmin(fmax(hl, 1e-6), 1e32));
-            const double iv = kc < Fa ? 1.0 / (hl + mu * dl * dl) : 0.0;
-            const double wk = slk * slk * iv;
+            const double wk = wk_s[kc];
             const double va = wa[(size_t)kc * LW], vb = wb[(size_t)kc * LW];
             a[u] = valid ? -((va * spa) * wk) : 0.0;
             b[u] = valid ? vb * spb : 0.0;
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(64) void ps_schur_kernel(Batch B) {
 // ---------------------------------------------------------------------------------------------------------------- SERIAL
 // grid S, 512 threads, dynamic LDS = xs + the 16 x 16 tiles of S: prepare_point, Cholesky, triangular solves, landmark
 // back-substitution, dogleg, model decrease, candidate -- the serial spine of one trust-region iteration.
-__global__ __launch_bounds__(512) void ps_serial_kernel(Batch B) {
+__global__ __launch_bounds__(1024) void ps_serial_kernel(Batch B) {
     const int s = blockIdx.x + B.s0, t = threadIdx.x, nt = blockDim.x;
     SolveSt &st = B.sst[s];
     if (st.stage != PS_ASM && st.stage != PS_SCHUR && st.stage != PS_STEP) return;
@@ -547,6 +553,7 @@ __global__ __launch_bounds__(512) void ps_serial_kernel(Batch B) {
     int iter = st.iter;
     if (!st.retry) iter++;
     __syncthreads();
+    PH_INIT;
     auto finish = [&](int new_stage) {
         __syncthreads();
         if (t == 0) {
@@ -588,6 +595,7 @@ __global__ __launch_bounds__(512) void ps_serial_kernel(Batch B) {
             if (t == 0) st.point_new = 0;
             if (gmax <= 1e-10) { if (t == 0) st.iters_done = iter - 1; finish(PS_DONE); return; }
         }
+        PH(48);
         cauchy_valid = false;
         // Gauss-Newton step through the Schur complement formed by ps_schur_kernel at this mu
         for (int k = t; k < Kpad; k += nt) {
@@ -599,25 +607,44 @@ __global__ __launch_bounds__(512) void ps_serial_kernel(Batch B) {
         matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, tmpl, nullptr, tmpv, nullptr, work);
         for (int a = t; a < LW; a += nt) xs[a] = a < P ? gs[a] - sp[a] * tmpv[a] : 0.0;
         __syncthreads();
+        PH(49);
         {
             const unsigned colmask = ps_colmask(W1, LW, st.vext != 0);
             const int nb = LW >> 4, ntile = nb * (nb + 1) / 2;
-            for (int w = t; w < ntile * 256; w += nt) {
-                const int tile = w >> 8, e = w & 255, r = e >> 4, cc = e & 15;
-                int ti, tj;
-                tri_decode(tile, ti, tj);
-                double v;
-                if (((colmask >> ti) & 1u) && ((colmask >> tj) & 1u)) v = c.Sc[tl_idx(ti, tj, r, cc)];
-                else {
+            // thread = element (r, cc) of every (nt / 256)-th tile; four tiles per trip, branch-free loads so that they are in flight together
+            const int e = t & 255, r = e >> 4, cc = e & 15, tstep = nt >> 8;
+            for (int tile0 = t >> 8; tile0 < ntile; tile0 += 4 * tstep) {
+                double hv[4], sr[4], sc[4], dg[4];
+                int widx[4];
+                bool msk[4], dia[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int tile = min(tile0 + b * tstep, ntile - 1);
+                    int ti, tj;
+                    tri_decode(tile, ti, tj);
                     const int row = 16 * ti + r, col = 16 * tj + cc;
-                    v = sp[row] * sp[col] * c.H[(size_t)row * LW + col];
-                    if (row == col) { v += mu * dgp[row] * dgp[row]; if (sp[row] == 0.0) v = 1.0; }
+                    widx[b] = tl_idx(ti, tj, r, cc);
+                    msk[b] = ((colmask >> ti) & 1u) && ((colmask >> tj) & 1u);
+                    dia[b] = row == col;
+                    const double *src = msk[b] ? c.Sc + widx[b] : c.H + (size_t)row * LW + col;
+                    hv[b] = *src; sr[b] = sp[row]; sc[b] = sp[col]; dg[b] = dgp[row];
                 }
-                work[tl_idx(ti, tj, r, cc)] = v;
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    if (tile0 + b * tstep >= ntile) break;
+                    double v = hv[b];
+                    if (!msk[b]) {
+                        v = sr[b] * sc[b] * v;
+                        if (dia[b]) { v += mu * dg[b] * dg[b]; if (sr[b] == 0.0) v = 1.0; }
+                    }
+                    work[widx[b]] = v;
+                }
             }
             __syncthreads();
         }
+        PH(50);
         bool ok = chol_tiles(work, LW >> 4, &sh_i[2], chol_dinv);
+        PH(51);
         if (ok) {
             chol_solve_tiles(work, LW >> 4, xs, chol_dinv);
             double bad = 0;
@@ -641,6 +668,7 @@ __global__ __launch_bounds__(512) void ps_serial_kernel(Batch B) {
         }
         __syncthreads();
     }
+    PH(52);
     // traditional dogleg in the D-scaled space
     double gnorm = 0, gnn = 0, gdot = 0;
     for (int a = t; a < P; a += nt) { gnorm += gradp[a] * gradp[a]; gnn += gnp[a] * gnp[a]; gdot += gradp[a] * gnp[a]; }
@@ -668,6 +696,7 @@ __global__ __launch_bounds__(512) void ps_serial_kernel(Batch B) {
         alpha = g2 / jg2;
         cauchy_valid = true;
     }
+    PH(53);
     if (gnn <= radius) { ca = 0; cb = 1; dogleg_norm = gnn; }
     else if (gnorm * alpha >= radius) { ca = -(radius / gnorm); cb = 0; dogleg_norm = radius; }
     else {
@@ -711,6 +740,7 @@ __global__ __launch_bounds__(512) void ps_serial_kernel(Batch B) {
         return;
     }
     invalid = 0;
+    PH(54);
     // candidate = Plus(x, step .* scale)
     for (int a = t; a < P; a += nt) delta[a] = stp[a] * sp[a];
     __syncthreads();
@@ -737,6 +767,7 @@ __global__ __launch_bounds__(512) void ps_serial_kernel(Batch B) {
     }
     if (t == 0) { st.model_change = model_change; st.eval_with_J = iter < cfg.max_iterations ? 1 : 0; }
     finish(PS_EVAL_C);
+    PH(55);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- FINAL

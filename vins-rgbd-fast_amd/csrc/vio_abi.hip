@@ -52,6 +52,7 @@ struct vio_batch {
     };
     std::vector<Group> groups;
     int tracker_lag = 0;              // vio_set_tracker_lag
+    int serial_threads = 1024;        // ps_serial_kernel block size (VIO_SERIAL_THREADS: 512 or 1024; measured +2 % with 1024)
     hipStream_t stream = nullptr;     // = groups[0].stream (returned by vio_get_stream; IMU scatter runs here)
     hipStream_t fe_stream = nullptr;  // = groups[0].fe_stream
     hipEvent_t ev[4];
@@ -533,8 +534,8 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
             ps_eval_kernel<<<dim3(h->ps_eval_blocks, S), 256, h->lds_ps_eval, st>>>(Bg);
             ps_asm_a_kernel<<<dim3(h->ps_asm_a_blocks, S), 512, 0, st>>>(Bg);
             ps_asm_b_kernel<<<dim3(24, S), 256, 0, st>>>(Bg);
-            ps_schur_kernel<<<dim3(h->ps_schur_tiles, S), 64, 0, st>>>(Bg);
-            ps_serial_kernel<<<S, 512, h->lds_solve, st>>>(Bg);
+            ps_schur_kernel<<<dim3(h->ps_schur_tiles, S), 64, (size_t)(C.NL + 8) * sizeof(double), st>>>(Bg);
+            ps_serial_kernel<<<S, h->serial_threads, h->lds_solve, st>>>(Bg);
         }
         ps_final_kernel<<<S, 256, 0, st>>>(Bg);
     } else if (be_threads <= 512) be_solve_kernel_512<<<S, be_threads, h->lds_solve, st>>>(Bg);
@@ -706,6 +707,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     B.hist_cap = 2048;
     B.s0 = 0;
     if (getenv("VIO_BE_THREADS")) h->be_threads = std::min(1024, std::max(64, atoi(getenv("VIO_BE_THREADS")) & ~63));
+    if (getenv("VIO_SERIAL_THREADS")) h->serial_threads = atoi(getenv("VIO_SERIAL_THREADS")) >= 1024 ? 1024 : 512;
     if (getenv("VIO_MARG_THREADS")) h->marg_threads = std::min(512, std::max(64, atoi(getenv("VIO_MARG_THREADS")) & ~63));
     B.flags = getenv("VIO_FLAGS") ? atoi(getenv("VIO_FLAGS")) : 0;
     DA(B.odom_hist, S * (size_t)B.hist_cap * 11); DA(B.odom_count, S);
@@ -727,7 +729,30 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
             vio_batch::Group &g = h->groups[k];
             g.s0 = k * per;
             g.n = std::min(per, n_seq - g.s0);
-            if (hipStreamCreate(&g.stream) != hipSuccess || hipStreamCreate(&g.fe_stream) != hipSuccess) { g_err = "stream create failed"; rc = VIO_EDEVICE; break; }
+            // Compute-unit partition (hipExtStreamCreateWithCUMask, contiguous ranges = whole XCDs): the wide front-end kernels of frame
+            // f+1 overlap the latency-bound solver kernels of frame f; keeping them on their own XCDs leaves the solver's L2 slices and
+            // dispatchers alone (measured: +5 %).  VIO_FE_CUS = n (default 64, 0 = no partition): front-end streams use CUs [0, n);
+            // VIO_BE_CU_SPLIT = 1: the back-end streams of the groups share [n, 256) in equal contiguous parts instead of all using it.
+            const char *fe_cus_env = getenv("VIO_FE_CUS");
+            const int fe_cus = fe_cus_env ? atoi(fe_cus_env) : 64;
+            hipError_t e_fe, e_be;
+            if (fe_cus > 0 && fe_cus < 256) {
+                uint32_t mfe[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mbe[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                const int ng = (int)h->groups.size(), gi = (int)(&g - &h->groups[0]);
+                const bool split = getenv("VIO_BE_CU_SPLIT") && atoi(getenv("VIO_BE_CU_SPLIT")) != 0 && ng > 1;
+                const int per = (256 - fe_cus) / ng;
+                const int b0 = split ? fe_cus + gi * per : fe_cus, b1 = split ? (gi == ng - 1 ? 256 : b0 + per) : 256;
+                for (int q = 0; q < 256; q++) {
+                    if (q < fe_cus) mfe[q >> 5] |= 1u << (q & 31);
+                    if (q >= b0 && q < b1) mbe[q >> 5] |= 1u << (q & 31);
+                }
+                e_fe = hipExtStreamCreateWithCUMask(&g.fe_stream, 8, mfe);
+                e_be = getenv("VIO_BE_CU_ALL") ? hipStreamCreate(&g.stream) : hipExtStreamCreateWithCUMask(&g.stream, 8, mbe);
+            } else {
+                e_fe = hipStreamCreate(&g.fe_stream);
+                e_be = hipStreamCreate(&g.stream);
+            }
+            if (e_be != hipSuccess || e_fe != hipSuccess) { g_err = "stream create failed"; rc = VIO_EDEVICE; break; }
             if (hipEventCreateWithFlags(&g.ev_solve, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g.ev_fe, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&g.ev_be, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g.ev_ingest, hipEventDisableTiming) != hipSuccess) { g_err = "event create failed"; rc = VIO_EDEVICE; }
         }
