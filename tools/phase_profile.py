@@ -19,7 +19,8 @@ NAMES = {0: "vector2double", 1: "lm indexing", 2: "pair lists", 4: "evaluate(fir
          16: "marg prior", 17: "marg imu", 18: "marg proj eval", 19: "marg lm rows", 20: "marg frame blocks+rank update", 21: "marg 15x15 + reduce",
          22: "marg new prior + c0", 23: "marg keep data", 24: "  marg frame blocks (mfma)", 25: "  marg scatter", 27: "finish consistency check",
          48: "ser prepare_point", 49: "ser GN rhs (Hpl matvec)", 50: "ser tile load", 51: "ser cholesky", 52: "ser solves + back-subst", 53: "ser cauchy (H, Hpl matvec)",
-         54: "ser dogleg/model", 55: "ser candidate",
+         54: "ser dogleg/model", 55: "ser candidate", 56: "  ser chol_solve_tiles", 57: "  ser finite check", 58: "  ser y vectors + Hpl matvec",
+         59: "  chol panel (wave 0 view)", 60: "  chol diag + trailing (wave 0)", 61: "  chol barrier wait",
          28: "finish slide states", 29: "finish slide landmarks", 30: "finish removeFailures + odom",
          32: "asm zero", 33: "asm prior", 34: "asm imu blocks", 35: "asm pair blocks", 36: "asm element sums", 37: "asm lm rows",
          40: "ev prior dx", 46: "ev imu", 41: "ev pair geo", 44: "ev prior matvec + proj", 45: "ev reduce"}
@@ -64,7 +65,7 @@ def main():
             print("%3d %-28s %8.1f us/frame" % (k, NAMES[k], us[k]))
     print("MARGIN_OLD frames of sequence 0: %d of %d" % (int(out[31]), a.frames))
     print("solve top-level sum %.1f us, marg sum %.1f us" % (sum(us[k] for k in (0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)), sum(us[16:24])))
-    print("ps_serial sum %.1f us/frame" % sum(us[48:56]))
+    print("ps_serial sum %.1f us/frame" % sum(us[48:56]) + us[56] + us[57] + us[58])
 
 
 if __name__ == "__main__":

@@ -1689,7 +1689,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                         else schur_mfma_lds(c.H, c.Hpl, tmpl, dgp, sp, mu, Kpad, LW, LW, work);
                     }
                     PH(8);
-                    chol_ok = chol_tiles(work, LW >> 4, &sh_i[2], chol_dinv);
+                    chol_ok = chol_tiles(work, LW >> 4, &sh_i[2], chol_dinv, nullptr, xs);   // with the forward substitution
                 } else {
                     schur_mfma(c.H, c.Hpl, tmpl, dgp, sp, mu, Kpad, LW, LW, c.Sc);
                     PH(8);
@@ -1697,7 +1697,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                 }
                 PH(9);
                 if (chol_ok) {
-                    if (tiles_in_lds) chol_solve_tiles(work, LW >> 4, xs, chol_dinv);
+                    if (tiles_in_lds) chol_backward_tiles(work, LW >> 4, xs, chol_dinv);
                     else chol_solve_blocked(c.Sc, LW, LW, xs, work);
                     PH(10);
                     double bad = 0;
@@ -2237,8 +2237,7 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
         for (int i = t; i < 16 * nbq; i += nt) cq_x[i] = i < n ? br[i] : 0.0;
         __syncthreads();
         double c0 = 0;
-        if (dmax > 0 && chol_tiles(T, nbq, &cq_flag, cq_dinv)) {
-            chol_forward_tiles(T, nbq, cq_x, cq_dinv);
+        if (dmax > 0 && chol_tiles(T, nbq, &cq_flag, cq_dinv, nullptr, cq_x)) {   // c0 needs the forward substitution only
             double acc = 0;
             for (int i = t; i < n; i += nt) acc += cq_x[i] * cq_x[i];
             c0 = block_sum(acc, sred);

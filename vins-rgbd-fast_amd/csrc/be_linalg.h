@@ -797,28 +797,39 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane) {
 
 // Look-ahead: while the other wavefronts run the trailing update of step p, wavefront 0 updates tile (p+1, p+1) first and factors
 // it straight away, so the serial 16-step diagonal factorisation is off the critical path.  dinv[16 nb] receives 1 / l_jj.
-__device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, double *dinv) {
+// rhs (optional, 16 nb doubles in LDS): the forward substitution L y = rhs rides along -- the right-hand side is one more row of the
+// panel (solved against L_pp with the tile rows) and of the trailing update (last wavefront), so that only the backward half
+// (chol_backward_tiles) is left to do afterwards.  Same operations in the same order as chol_forward_tiles.
+__device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, double *dinv, float *tm = nullptr, double *rhs = nullptr) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    // 16x16 diagonal block: lanes 0..15 of wavefront 0 hold one row each in registers, shuffles broadcast pivots
+    // 16x16 diagonal block: lanes 0..15 of wavefront 0 hold one row each in registers, readlane broadcasts the pivots.  Branch-free and
+    // software-pipelined: column j+1 is updated first and its pivot's reciprocal square root (the one slow operation of a step) is
+    // started before the remaining columns take their rank-1 term, so that its latency hides behind them.
     auto factor_diag = [&](int p) {
         const int row = lane & 15;
         double a[16];
 #pragma unroll
         for (int cc = 0; cc < 16; cc++) a[cc] = T[tl_idx(p, p, row, cc)];
         bool ok = true;
+        double ajj = bcast_lane(a[0], 0);
+        double rl = rsqrt(ajj);       // l = a * rsqrt(a), 1 / l = rsqrt(a)
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            double ajj = bcast_lane(a[j], j);
-            if (!(ajj > 0.0) || !isfinite(ajj)) ok = false;
-            double rl = rsqrt(ajj);       // one slow operation per pivot: l = a * rsqrt(a), 1 / l = rsqrt(a)
-            double l = ajj * rl;
-            if (row == j) { a[j] = l; if (lane < 16) dinv[16 * p + j] = rl; }
-            else if (row > j) a[j] = a[j] * rl;
+            ok = ok && (ajj > 0.0) && isfinite(ajj);
+            const double l = ajj * rl;
+            if (lane < 16 && row == j) dinv[16 * p + j] = rl;
+            a[j] = row == j ? l : (row > j ? a[j] * rl : a[j]);
+            if (j < 15) {
+                const double an = bcast_lane(a[j], j + 1);
+                a[j + 1] = row >= j + 1 ? a[j + 1] - a[j] * an : a[j + 1];
+                ajj = bcast_lane(a[j + 1], j + 1);
+                rl = rsqrt(ajj);
 #pragma unroll
-            for (int k = j + 1; k < 16; k++) {
-                double akj = bcast_lane(a[j], k);
-                if (row >= k) a[k] -= a[j] * akj;
+                for (int k = j + 2; k < 16; k++) {
+                    const double akj = bcast_lane(a[j], k);
+                    a[k] = row >= k ? a[k] - a[j] * akj : a[k];
+                }
             }
         }
         if (lane < 16) {
@@ -837,21 +848,34 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
 #pragma unroll
         for (int r = 0; r < 4; r++) T[tl_idx(ti, tj, lk + 4 * r, li)] = acc[r];
     };
+    // right-hand side rows below tile row p: b_i -= L_ip y_p
+    auto update_rhs = [&](int p) {
+        for (int q = lane; q < 16 * (nb - 1 - p); q += 64) {
+            const int ti = p + 1 + (q >> 4), r = q & 15;
+            double sacc = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) sacc += T[tl_idx(ti, p, r, k)] * rhs[16 * p + k];
+            rhs[16 * ti + r] -= sacc;
+        }
+    };
     if (t == 0) *sh_flag = 1;
     __syncthreads();
     if (wave == 0) factor_diag(0);
     __syncthreads();
+    long long tm0 = (tm && t == 0) ? (long long)wall_clock64() : 0;
     for (int p = 0; p < nb; p++) {
         if (!*sh_flag) return false;
-        // (b) panel: rows of the tiles below solve x L_pp^T = a
-        for (int q = t; q < 16 * (nb - 1 - p); q += nt) {
-            int ti = p + 1 + (q >> 4), r = q & 15;
+        // (b) panel: rows of the tiles below (and the right-hand side) solve x L_pp^T = a
+        const int nrow = 16 * (nb - 1 - p);
+        for (int q = t; q < nrow + (rhs ? 1 : 0); q += nt) {
+            const bool is_rhs = q == nrow;
+            const int ti = p + 1 + (q >> 4), r = q & 15;
             // right-looking order: as soon as x[k] is known every later column takes its term, so the sixteen accumulators advance side
-            // by side (each still receives its terms in ascending k: same result as the column-by-column form, a quarter of its
-            // dependent chain)
+            // by side (each still receives its terms in ascending k)
             double x[16];
+            double *px[16];
 #pragma unroll
-            for (int cc = 0; cc < 16; cc++) x[cc] = T[tl_idx(ti, p, r, cc)];
+            for (int cc = 0; cc < 16; cc++) { px[cc] = is_rhs ? rhs + 16 * p + cc : T + tl_idx(ti, p, r, cc); x[cc] = *px[cc]; }
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 x[k] = x[k] * dinv[16 * p + k];
@@ -859,9 +883,10 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
                 for (int cc = k + 1; cc < 16; cc++) x[cc] -= x[k] * T[tl_idx(p, p, cc, k)];
             }
 #pragma unroll
-            for (int cc = 0; cc < 16; cc++) T[tl_idx(ti, p, r, cc)] = x[cc];
+            for (int cc = 0; cc < 16; cc++) *px[cc] = x[cc];
         }
         __syncthreads();
+        if (tm && t == 0) { long long n_ = (long long)wall_clock64(); tm[0] += (float)(n_ - tm0); tm0 = n_; }
         // (c) trailing update S22 -= L21 L21^T on the FP64 matrix cores; tile 0 = (p+1, p+1) belongs to wavefront 0
         const int m = nb - 1 - p, ntile = m * (m + 1) / 2;
         if (nw > 1) {
@@ -872,6 +897,7 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
                     factor_diag(p + 1);
                 }
             } else {
+                if (rhs && wave == nw - 1) update_rhs(p);
                 for (int tile = wave; tile < ntile; tile += nw - 1) {  // tiles 1.. over wavefronts 1..nw-1
                     int ti, tj;
                     tri_decode(tile, ti, tj);
@@ -879,6 +905,7 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
                 }
             }
         } else {
+            if (rhs) update_rhs(p);
             for (int tile = 0; tile < ntile; tile++) {
                 int ti, tj;
                 tri_decode(tile, ti, tj);
@@ -887,9 +914,37 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
             WAVE_SYNC();
             if (ntile > 0) factor_diag(p + 1);
         }
+        if (tm && t == 0) { long long n_ = (long long)wall_clock64(); tm[1] += (float)(n_ - tm0); tm0 = n_; }
         __syncthreads();
+        if (tm && t == 0) { long long n_ = (long long)wall_clock64(); tm[2] += (float)(n_ - tm0); tm0 = n_; }
     }
     return *sh_flag != 0;
+}
+
+// backward half of the solve: L^T x = y (y from the forward substitution that rode along with chol_tiles)
+__device__ __forceinline__ void chol_backward_tiles(const double *T, int nb, double *xs, const double *dinv) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6;
+    for (int p = nb - 1; p >= 0; p--) {
+        if (wave == 0) {
+            const int row = lane & 15;
+            double b = xs[16 * p + row];
+#pragma unroll
+            for (int j = 15; j >= 0; j--) {
+                double xj = bcast_lane(b, j) * dinv[16 * p + j];
+                if (row == j) b = xj; else if (row < j) b -= T[tl_idx(p, p, j, row)] * xj;
+            }
+            if (lane < 16) xs[16 * p + row] = b;
+        }
+        __syncthreads();
+        for (int q = t; q < 16 * p; q += nt) {
+            int tj = q >> 4, cc = q & 15;
+            double sacc = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) sacc += T[tl_idx(p, tj, k, cc)] * xs[16 * p + k];
+            xs[q] -= sacc;
+        }
+        __syncthreads();
+    }
 }
 
 __device__ __forceinline__ void chol_solve_tiles(const double *T, int nb, double *xs, const double *dinv) {

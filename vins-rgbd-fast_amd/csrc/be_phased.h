@@ -643,10 +643,11 @@ __global__ __launch_bounds__(1024) void ps_serial_kernel(Batch B) {
             __syncthreads();
         }
         PH(50);
-        bool ok = chol_tiles(work, LW >> 4, &sh_i[2], chol_dinv);
+        bool ok = chol_tiles(work, LW >> 4, &sh_i[2], chol_dinv, s == 0 ? B.timings + 59 : nullptr, xs);   // with the forward substitution
         PH(51);
         if (ok) {
-            chol_solve_tiles(work, LW >> 4, xs, chol_dinv);
+            chol_backward_tiles(work, LW >> 4, xs, chol_dinv);
+            PH(56);
             double bad = 0;
             for (int a = t; a < P; a += nt) if (!isfinite(xs[a])) bad += 1;
             bad = block_sum(bad, sred);
@@ -658,9 +659,11 @@ __global__ __launch_bounds__(1024) void ps_serial_kernel(Batch B) {
             finish(PS_DONE);   // "if (!ok) break"
             return;
         }
+        PH(57);
         for (int a = t; a < LW; a += nt) { yp[a] = xs[a]; gnp[a] = -xs[a] * dgp[a]; tmpv[a] = sp[a] * xs[a]; }
         __syncthreads();
         matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, nullptr, tmpv, nullptr, tmpl, nullptr);
+        PH(58);
         for (int k = t; k < Kpad; k += nt) {
             double y = k < Fa ? (gls[k] - sl[k] * tmpl[k]) * inv[k] : 0.0;
             yl[k] = y;
