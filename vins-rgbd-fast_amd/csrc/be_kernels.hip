@@ -2219,7 +2219,8 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
     for (int i = t; i < n; i += nt) c.prior_r[i] = br[i];
     {
         // c0 = |L^-1 b|^2 with L L^T = A + delta I on 16x16 LDS tiles (delta lifts the gauge directions off the round-off floor)
-        __shared__ double cq_x[EIG_LD + 16], cq_dinv[EIG_LD + 16];
+        __shared__ __attribute__((aligned(16))) double cq_x[EIG_LD + 16];   // read and written in 16-byte pairs by chol_tiles
+        __shared__ double cq_dinv[EIG_LD + 16];
         __shared__ int cq_flag;
         const int nbq = (n + 15) >> 4;
         double *T = (double *)smem_marg;

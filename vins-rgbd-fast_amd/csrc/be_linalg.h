@@ -819,17 +819,15 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
             ok = ok && (ajj > 0.0) && isfinite(ajj);
             const double l = ajj * rl;
             if (lane < 16 && row == j) dinv[16 * p + j] = rl;
-            a[j] = row == j ? l : (row > j ? a[j] * rl : a[j]);
+            // (entries above the diagonal are never read back: they take the same updates as the rest, unselected, and are dropped at the end)
+            a[j] = row == j ? l : a[j] * rl;
             if (j < 15) {
                 const double an = bcast_lane(a[j], j + 1);
-                a[j + 1] = row >= j + 1 ? a[j + 1] - a[j] * an : a[j + 1];
+                a[j + 1] -= a[j] * an;
                 ajj = bcast_lane(a[j + 1], j + 1);
                 rl = rsqrt(ajj);
 #pragma unroll
-                for (int k = j + 2; k < 16; k++) {
-                    const double akj = bcast_lane(a[j], k);
-                    a[k] = row >= k ? a[k] - a[j] * akj : a[k];
-                }
+                for (int k = j + 2; k < 16; k++) a[k] -= a[j] * bcast_lane(a[j], k);
             }
         }
         if (lane < 16) {
@@ -921,7 +919,8 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
     return *sh_flag != 0;
 }
 
-// backward half of the solve: L^T x = y (y from the forward substitution that rode along with chol_tiles)
+// backward half of the solve: L^T x = y (y from the forward substitution that rode along with chol_tiles).  (A single-wavefront
+// version without workgroup barriers was measured slower: 18 us against 16 us per solve at 11 tiles.)
 __device__ __forceinline__ void chol_backward_tiles(const double *T, int nb, double *xs, const double *dinv) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6;
     for (int p = nb - 1; p >= 0; p--) {
