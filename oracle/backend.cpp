@@ -1051,6 +1051,20 @@ void Estimator::solve() {
                 mu *= 10.0;
             }
             if (!ok) break;  // linear solver failure at max mu: give up (Ceres: LINEAR_SOLVER_FAILURE)
+            if (const char *dump = std::getenv("OVIO_DUMP_SOLVE")) {
+                // test hook (tests/test_oracle_numpy_cpu.py): the scaled linear system of this iteration and what the solver derived from
+                // it: Pa, Fa, mu, alpha, Hs (Pa^2), Hpls (Fa x Pa), Hlls, gs, gls, dgp, dgl, gnp, gnl as raw doubles (appended)
+                if (FILE *fp = std::fopen(dump, "ab")) {
+                    double hdr[4] = {(double)Pa, (double)Fa, mu, alpha};
+                    std::fwrite(hdr, 8, 4, fp);
+                    std::fwrite(Hs.d.data(), 8, (size_t)Pa * Pa, fp);
+                    std::fwrite(Hpls.d.data(), 8, (size_t)Fa * Pa, fp);
+                    std::fwrite(Hlls.data(), 8, Fa, fp); std::fwrite(gs.data(), 8, Pa, fp); std::fwrite(gls.data(), 8, Fa, fp);
+                    std::fwrite(dgp.data(), 8, Pa, fp); std::fwrite(dgl.data(), 8, Fa, fp);
+                    std::fwrite(gnp.data(), 8, Pa, fp); std::fwrite(gnl.data(), 8, Fa, fp);
+                    std::fclose(fp);
+                }
+            }
             reuse = true;
         }
         // traditional dogleg in the D-scaled space
@@ -1196,10 +1210,13 @@ void marg_finish(Estimator &e, Mat &A, std::vector<double> &b, int m, int n) {
     }
     Mat As(n, n);
     for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) As(i, j) = 0.5 * (Ar(i, j) + Ar(j, i));
-    if (const char *dump = std::getenv("OVIO_DUMP_PRIOR")) {  // test hook: append n, A_s (n x n), b_r (n) as raw doubles
+    if (const char *dump = std::getenv("OVIO_DUMP_PRIOR")) {
+        // test hook (tests/test_oracle_numpy_cpu.py): append m, n, A ((m+n)^2), b (m+n), A_s (n x n), b_r (n) as raw doubles
         if (FILE *fp = std::fopen(dump, "ab")) {
-            double nn = n;
-            std::fwrite(&nn, 8, 1, fp);
+            double hdr[2] = {(double)m, (double)n};
+            std::fwrite(hdr, 8, 2, fp);
+            std::fwrite(A.d.data(), 8, (size_t)(m + n) * (m + n), fp);
+            std::fwrite(b.data(), 8, m + n, fp);
             std::fwrite(As.d.data(), 8, (size_t)n * n, fp);
             std::fwrite(br.data(), 8, n, fp);
             std::fclose(fp);
