@@ -83,6 +83,58 @@ DM_HD PreintStep preint_midpoint(const PreInt &p, double dt, v3 acc_1, v3 gyr_1,
     return o;
 }
 
+// The two halves of preint_midpoint for the pipelined propagation of be_ingest (same expressions, hence the same bits): the state
+// recursion (serial, a few dozen operations per sample) and the F / V matrices of a step, which depend only on the state BEFORE it.
+struct PreintPre { quat dq; v3 acc0, gyr0; };   // what a step's F / V need besides (dt, acc_1, gyr_1) and the linearisation biases
+DM_HD void preint_state_step(quat &delta_q, v3 &delta_p, v3 &delta_v, v3 acc_0, v3 gyr_0, v3 lba, v3 lbg, double dt, v3 acc_1, v3 gyr_1) {
+    v3 un_acc_0 = qrot(delta_q, sub(acc_0, lba));
+    v3 un_gyr = sub(scl(0.5, add(gyr_0, gyr_1)), lbg);
+    quat rq = qmul(delta_q, mkq(1, un_gyr.x * dt / 2, un_gyr.y * dt / 2, un_gyr.z * dt / 2));
+    v3 un_acc_1 = qrot(rq, sub(acc_1, lba));
+    v3 un_acc = scl(0.5, add(un_acc_0, un_acc_1));
+    delta_p = add(add(delta_p, scl(dt, delta_v)), scl(dt * dt, scl(0.5, un_acc)));
+    delta_v = add(delta_v, scl(dt, un_acc));
+    delta_q = qnormalized(rq);
+}
+DM_HD void preint_step_FV(const PreintPre &s, v3 lba, v3 lbg, double dt, v3 acc_1, v3 gyr_1, double *F, double *V) {
+    const quat delta_q = s.dq;
+    const v3 acc_0 = s.acc0, gyr_0 = s.gyr0;
+    v3 un_gyr = sub(scl(0.5, add(gyr_0, gyr_1)), lbg);
+    quat rq = qmul(delta_q, mkq(1, un_gyr.x * dt / 2, un_gyr.y * dt / 2, un_gyr.z * dt / 2));
+    for (int i = 0; i < 225; i++) F[i] = 0;
+    for (int i = 0; i < 270; i++) V[i] = 0;
+    m3 R_w_x = skew(un_gyr), R_a_0_x = skew(sub(acc_0, lba)), R_a_1_x = skew(sub(acc_1, lba));
+    m3 Rq = q2R(delta_q), Rr = q2R(rq), I = eye();
+    m3 ImW = sub(I, scl(dt, R_w_x));
+    put33(F, 15, 0, 0, I);
+    put33(F, 15, 0, 3, add(scl(-0.25 * dt * dt, mul(Rq, R_a_0_x)), scl(-0.25 * dt * dt, mul(mul(Rr, R_a_1_x), ImW))));
+    put33(F, 15, 0, 6, scl(dt, I));
+    put33(F, 15, 0, 9, scl(-0.25 * dt * dt, add(Rq, Rr)));
+    put33(F, 15, 0, 12, scl(-0.25 * dt * dt * -dt, mul(Rr, R_a_1_x)));
+    put33(F, 15, 3, 3, ImW);
+    put33(F, 15, 3, 12, scl(-dt, I));
+    put33(F, 15, 6, 3, add(scl(-0.5 * dt, mul(Rq, R_a_0_x)), scl(-0.5 * dt, mul(mul(Rr, R_a_1_x), ImW))));
+    put33(F, 15, 6, 6, I);
+    put33(F, 15, 6, 9, scl(-0.5 * dt, add(Rq, Rr)));
+    put33(F, 15, 6, 12, scl(-0.5 * dt * -dt, mul(Rr, R_a_1_x)));
+    put33(F, 15, 9, 9, I);
+    put33(F, 15, 12, 12, I);
+    m3 V03 = scl(0.25 * dt * dt * 0.5 * dt, neg(mul(Rr, R_a_1_x)));
+    m3 V63 = scl(0.5 * dt * 0.5 * dt, neg(mul(Rr, R_a_1_x)));
+    put33(V, 18, 0, 0, scl(0.25 * dt * dt, Rq));
+    put33(V, 18, 0, 3, V03);
+    put33(V, 18, 0, 6, scl(0.25 * dt * dt, Rr));
+    put33(V, 18, 0, 9, V03);
+    put33(V, 18, 3, 3, scl(0.5 * dt, I));
+    put33(V, 18, 3, 9, scl(0.5 * dt, I));
+    put33(V, 18, 6, 0, scl(0.5 * dt, Rq));
+    put33(V, 18, 6, 3, V63);
+    put33(V, 18, 6, 6, scl(0.5 * dt, Rr));
+    put33(V, 18, 6, 9, V63);
+    put33(V, 18, 9, 12, scl(dt, I));
+    put33(V, 18, 12, 15, scl(dt, I));
+}
+
 // sqrt_info = LLT(cov^-1).matrixL().transpose()  (imu_factor.h:66-69); out row-major 15x15 upper triangular
 DM_HD void imu_sqrt_info(const double *cov, double *out) {
     double L[225], Li[225], Ci[225];

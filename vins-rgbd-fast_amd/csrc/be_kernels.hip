@@ -87,6 +87,7 @@ namespace {
 // ------------------------------------------------------------------ IntegrationBase::propagate, block-cooperative
 // LDS workspace: sJ sP sFJ sFP (225 each) sF (225) sV (270)
 struct PreWork { double J[225], Pm[225], FJ[225], FP[225], F[225], V[270]; };
+#define PI_CH 8   // samples per chunk of the pipelined propagation in be_ingest (F / V of a chunk live in LDS: 8 x 495 doubles)
 __device__ __forceinline__ void preint_load(const PreInt &p, PreWork &w) {
     for (int i = threadIdx.x; i < 225; i += blockDim.x) { w.J[i] = p.jac[i]; w.Pm[i] = p.cov[i]; }
     __syncthreads();
@@ -663,40 +664,108 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
             if (!P.valid) bf::preint_init(P, ld3(be.acc_0), ld3(be.gyr_0), ld3(be.Bas[fc]), ld3(be.Bgs[fc]));
         }
         __syncthreads();
-        if (fc != 0) preint_load(P, pw);
-        for (int q = 0; q < n; q++) {
-            int idx = (head + q) % C.NIMU;
-            double tq = it[idx];
-            double dt;
-            if (q == 0) dt = tq - be.prevTime;
-            else if (q == n - 1) dt = curTime - it[(head + q - 1) % C.NIMU];
-            else dt = tq - it[(head + q - 1) % C.NIMU];
-            v3 acc = ld3(ia + (size_t)idx * 3), gyr = ld3(ig + (size_t)idx * 3);
-            if (fc != 0) {
-                if (t == 0) {
-                    int nb = P.n_buf;
-                    if (nb < VIO_IMU_SLOT_CAP) { P.dt_buf[nb] = dt; st3(P.acc_buf[nb], acc); st3(P.gyr_buf[nb], gyr); P.n_buf = nb + 1; }
-                    else be.overflow |= 2;
+        if (fc != 0) {
+            // IntegrationBase::push_back + Estimator::processIMU for the n samples of the frame, pipelined in chunks of PI_CH samples:
+            //   A  thread 0 runs the delta-state recursion (it keeps the state before every step), thread 64 - another wavefront -
+            //      the world-state recursion of Ps / Rs / Vs[fc], the remaining threads file the samples into the slot's buffer;
+            //   B  one lane per sample builds that step's F (15 x 15) and V (15 x 18) from the state before it;
+            //   C  the jacobian / covariance recursion J <- F J, P <- F P F^T + V Q V^T consumes them step by step.
+            // The serial part of a sample shrinks from the whole midpoint step to its two short recursions; same arithmetic as
+            // preint_propagate (be_factors.h preint_state_step / preint_step_FV are the two halves of preint_midpoint).
+            preint_load(P, pw);
+            __shared__ double pi_F[PI_CH][225], pi_V[PI_CH][270];
+            __shared__ double pi_dt[PI_CH], pi_acc[PI_CH][3], pi_gyr[PI_CH][3];
+            __shared__ bf::PreintPre pi_pre[PI_CH];
+            const int nb0 = P.n_buf;
+            const v3 lba = ld3(P.lin_ba), lbg = ld3(P.lin_bg);
+            // thread 0: delta state; thread 64: world state of frame fc
+            quat s_dq = mkq(P.dq[0], P.dq[1], P.dq[2], P.dq[3]);
+            v3 s_dp = ld3(P.dp), s_dv = ld3(P.dv), s_a0 = ld3(P.acc0), s_g0 = ld3(P.gyr0);
+            double s_sum = P.sum_dt;
+            v3 w_a0 = ld3(be.acc_0), w_g0 = ld3(be.gyr_0), w_P = ld3(be.Ps[fc]), w_V = ld3(be.Vs[fc]);
+            m3 w_R = ldm(be.Rs[fc]);
+            const v3 w_Ba = ld3(be.Bas[fc]), w_Bg = ld3(be.Bgs[fc]), w_g = ld3(be.g);
+            const double prevTime = be.prevTime;
+            __syncthreads();
+            for (int q0 = 0; q0 < n; q0 += PI_CH) {
+                const int m = min(PI_CH, n - q0);
+                if (t < m) {   // stage the chunk's samples
+                    const int q = q0 + t, idx = (head + q) % C.NIMU;
+                    const double tq = it[idx];
+                    double dt;
+                    if (q == 0) dt = tq - prevTime;
+                    else if (q == n - 1) dt = curTime - it[(head + q - 1) % C.NIMU];
+                    else dt = tq - it[(head + q - 1) % C.NIMU];
+                    pi_dt[t] = dt;
+                    for (int k = 0; k < 3; k++) { pi_acc[t][k] = ia[(size_t)idx * 3 + k]; pi_gyr[t][k] = ig[(size_t)idx * 3 + k]; }
+                    const int nb = nb0 + q;
+                    if (nb < VIO_IMU_SLOT_CAP) { P.dt_buf[nb] = dt; for (int k = 0; k < 3; k++) { P.acc_buf[nb][k] = ia[(size_t)idx * 3 + k]; P.gyr_buf[nb][k] = ig[(size_t)idx * 3 + k]; } }
                 }
-                preint_propagate(P, pw, cfg, dt, acc, gyr);
+                __syncthreads();
                 if (t == 0) {
-                    int j = fc;
-                    v3 acc_0 = ld3(be.acc_0), gyr_0 = ld3(be.gyr_0), g = ld3(be.g);
-                    m3 Rj = ldm(be.Rs[j]);
-                    v3 Ba = ld3(be.Bas[j]), Bg = ld3(be.Bgs[j]);
-                    v3 un_acc_0 = sub(mul(Rj, sub(acc_0, Ba)), g);
-                    v3 un_gyr = sub(scl(0.5, add(gyr_0, gyr)), Bg);
-                    Rj = mul(Rj, q2R(deltaQ(scl(dt, un_gyr))));
-                    v3 un_acc_1 = sub(mul(Rj, sub(acc, Ba)), g);
-                    v3 un_acc = scl(0.5, add(un_acc_0, un_acc_1));
-                    v3 Pj = ld3(be.Ps[j]), Vj = ld3(be.Vs[j]);
-                    Pj = add(add(Pj, scl(dt, Vj)), scl(dt * dt, scl(0.5, un_acc)));
-                    Vj = add(Vj, scl(dt, un_acc));
-                    stm(be.Rs[j], Rj); st3(be.Ps[j], Pj); st3(be.Vs[j], Vj);
+                    for (int k = 0; k < m; k++) {
+                        const v3 acc = ld3(pi_acc[k]), gyr = ld3(pi_gyr[k]);
+                        pi_pre[k].dq = s_dq; pi_pre[k].acc0 = s_a0; pi_pre[k].gyr0 = s_g0;
+                        bf::preint_state_step(s_dq, s_dp, s_dv, s_a0, s_g0, lba, lbg, pi_dt[k], acc, gyr);
+                        s_sum += pi_dt[k];
+                        s_a0 = acc; s_g0 = gyr;
+                    }
+                } else if (t == 64) {
+                    for (int k = 0; k < m; k++) {   // Estimator::processIMU (estimator.cpp:142-152)
+                        const v3 acc = ld3(pi_acc[k]), gyr = ld3(pi_gyr[k]);
+                        const double dt = pi_dt[k];
+                        v3 un_acc_0 = sub(mul(w_R, sub(w_a0, w_Ba)), w_g);
+                        v3 un_gyr = sub(scl(0.5, add(w_g0, gyr)), w_Bg);
+                        w_R = mul(w_R, q2R(deltaQ(scl(dt, un_gyr))));
+                        v3 un_acc_1 = sub(mul(w_R, sub(acc, w_Ba)), w_g);
+                        v3 un_acc = scl(0.5, add(un_acc_0, un_acc_1));
+                        w_P = add(add(w_P, scl(dt, w_V)), scl(dt * dt, scl(0.5, un_acc)));
+                        w_V = add(w_V, scl(dt, un_acc));
+                        w_a0 = acc; w_g0 = gyr;
+                    }
+                }
+                __syncthreads();
+                if (t < m) bf::preint_step_FV(pi_pre[t], lba, lbg, pi_dt[t], ld3(pi_acc[t]), ld3(pi_gyr[t]), pi_F[t], pi_V[t]);
+                __syncthreads();
+                for (int k = 0; k < m; k++) {
+                    const double *Fk = pi_F[k], *Vk = pi_V[k];
+                    if (t < 225) {
+                        int i = t / 15, j = t - i * 15;
+                        double s1 = 0, s2 = 0;
+                        for (int u = 0; u < 15; u++) { s1 += Fk[i * 15 + u] * pw.J[u * 15 + j]; s2 += Fk[i * 15 + u] * pw.Pm[u * 15 + j]; }
+                        pw.FJ[t] = s1; pw.FP[t] = s2;
+                    }
+                    __syncthreads();
+                    if (t < 225) {
+                        int i = t / 15, j = t - i * 15;
+                        double s1 = 0;
+                        for (int u = 0; u < 15; u++) s1 += pw.FP[i * 15 + u] * Fk[j * 15 + u];
+                        double nn[6] = {cfg.acc_n * cfg.acc_n, cfg.gyr_n * cfg.gyr_n, cfg.acc_n * cfg.acc_n, cfg.gyr_n * cfg.gyr_n, cfg.acc_w * cfg.acc_w, cfg.gyr_w * cfg.gyr_w};
+                        double tt = 0;
+                        for (int u = 0; u < 18; u++) tt += Vk[i * 18 + u] * nn[u / 3] * Vk[j * 18 + u];
+                        pw.J[t] = pw.FJ[t];
+                        pw.Pm[t] = s1 + tt;
+                    }
+                    __syncthreads();
                 }
             }
-            if (t == 0) { st3(be.acc_0, acc); st3(be.gyr_0, gyr); }
+            if (t == 0) {
+                st3(P.dp, s_dp); st3(P.dv, s_dv);
+                P.dq[0] = s_dq.w; P.dq[1] = s_dq.x; P.dq[2] = s_dq.y; P.dq[3] = s_dq.z;
+                P.sum_dt = s_sum;
+                st3(P.acc0, s_a0); st3(P.gyr0, s_g0);
+                const int nb = nb0 + n;
+                if (nb > VIO_IMU_SLOT_CAP) be.overflow |= 2;
+                P.n_buf = min(nb, VIO_IMU_SLOT_CAP);
+            }
+            if (t == 64) {
+                stm(be.Rs[fc], w_R); st3(be.Ps[fc], w_P); st3(be.Vs[fc], w_V);
+                st3(be.acc_0, w_a0); st3(be.gyr_0, w_g0);
+            }
             __syncthreads();
+        } else if (t == 0) {   // frame 0: no pre-integration yet, acc_0 / gyr_0 follow the samples
+            const int idx = (head + n - 1) % C.NIMU;
+            st3(be.acc_0, ld3(ia + (size_t)idx * 3)); st3(be.gyr_0, ld3(ig + (size_t)idx * 3));
         }
         if (fc != 0) preint_store(P, pw);
         if (t == 0) be.prevTime = curTime;
