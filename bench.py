@@ -324,7 +324,8 @@ def main():
     def traffic_of(kname):
         if not tj or tj[1].get("sequences_per_gpu") != S or tj[1].get("sequences_per_launch", S) != S_launch:
             return None
-        ent = next((v for k, v in tj[1].get("kernels", {}).items() if k.startswith(kname)), None)
+        kk = "be_solve_phased" if (kname == "be_solve" and os.environ.get("VIO_SOLVE_MODE", "1") != "0") else kname
+        ent = next((v for k, v in tj[1].get("kernels", {}).items() if k.startswith(kk)), None)
         return ent["hbm_bytes_per_launch"] if ent else None
 
     # the HIP events bracket the launches of stream group 0, which cover S / n_groups sequences each
@@ -417,9 +418,9 @@ def main():
         import multiprocessing as mp
         c0 = time.perf_counter()
         with mp.get_context("spawn").Pool(nproc) as pool:
-            res = pool.map(_cpu_worker, [(seq0 + 1000 + i, 46) for i in range(nproc)])
+            res = pool.map(_cpu_worker, [(seq0 + 1000 + i, 36) for i in range(nproc)])
         cpu_all = dict(value=float(sum(n / t for t, n in res if t > 0)), unit="frames/s", cores=nproc, kind="port",
-                       sample="%d oracle processes (one per host core), one sequence of 46 frames each; sum of the per-process steady-state "
+                       sample="%d oracle processes (one per host core), one sequence of 36 frames each; sum of the per-process steady-state "
                               "rates (the reference's own effective threading is one back-end thread per estimator)" % nproc,
                        wall_seconds=time.perf_counter() - c0)
         cpu = dict(cpu_all)

@@ -45,7 +45,10 @@ def main():
         for f in find(root, sub, "counter_collection.csv"):
             for r in csv.DictReader(open(f)):
                 acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        tot = {k: {c: (sum(v[len(v) // 2:]), len(v) - len(v) // 2) for c, v in d.items()} for k, d in acc.items()}
+        pmc_totals[sub] = tot
         return {k: {c: sum(v[len(v) // 2:]) / max(1, len(v) - len(v) // 2) for c, v in d.items()} for k, d in acc.items()}
+    pmc_totals = {}
     fetch, write, sq, l2 = pmc("fetch"), pmc("write"), pmc("sq"), pmc("l2")
     kernels = {}
     for k in sorted(set(fetch) | set(write)):
@@ -60,7 +63,23 @@ def main():
             kernels[k]["hbm_GBps"] = hb / (steady[k]["steady_avg_ms"] * 1e-3) / 1e9 if steady[k]["steady_avg_ms"] > 0 else None
         if k in l2 and (l2[k].get("TCC_HIT_sum", 0) + l2[k].get("TCC_MISS_sum", 0)) > 0:
             kernels[k]["l2_hit_rate"] = l2[k]["TCC_HIT_sum"] / (l2[k]["TCC_HIT_sum"] + l2[k]["TCC_MISS_sum"])
-    json.dump(dict(round=rnd, sequences_per_gpu=seqs, note="averages over the second half of each kernel's dispatches (steady state); "
+    # the phased solver is a chain of small kernels (ps_*): its traffic per solve = everything those kernels moved in the steady half of
+    # the run / the number of steps in it (one be_marg_kernel launch per step and stream group)
+    def per_step(sub, counter):
+        tot = pmc_totals.get(sub, {})
+        steps = next((v[counter][1] for k, v in tot.items() if k.startswith("be_marg_kernel") and counter in v), 0)
+        if not steps:
+            return None
+        return sum(v[counter][0] for k, v in tot.items() if k.startswith("ps_") and counter in v) / steps
+    fs, ws = per_step("fetch", "FETCH_SIZE"), per_step("write", "WRITE_SIZE")
+    if fs is not None or ws is not None:
+        ent = dict(FETCH_SIZE_KB=fs, WRITE_SIZE_KB=ws, hbm_bytes_per_launch=(2.0 * (fs or 0.0) + (ws or 0.0)) * 1024.0,
+                   note="sum over the ps_* kernels of one solve (all iteration slots of one stream group)")
+        ms = sum(v["steady_avg_ms"] * v["calls"] for k, v in steady.items() if k.startswith("ps_")) / max(1, steady.get("be_marg_kernel", {}).get("calls", 0))
+        ent["busy_ms_per_step"] = ms
+        kernels["be_solve_phased"] = ent
+    per_launch = int(os.environ.get("VIO_GROUP_SEQS", "64"))
+    json.dump(dict(round=rnd, sequences_per_gpu=seqs, sequences_per_launch=min(seqs, per_launch), note="averages over the second half of each kernel's dispatches (steady state); "
                    "hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB, gfx950 correction per MI355X_MICROARCH.md; WRITE_SIZE uncalibrated",
                    kernels=kernels), open(os.path.join(out, rnd + "_pmc_traffic.json"), "w"), indent=1)
     json.dump(dict(round=rnd, sequences_per_gpu=seqs, steady=steady, sq=sq, l2=l2), open(os.path.join(out, rnd + "_pmc_sq.json"), "w"), indent=1)
