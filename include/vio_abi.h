@@ -170,7 +170,9 @@ int vio_get_odometry_history(vio_batch *h, int seq, int cap, double *out);
  *   lag 1: it reads the state as of frame f-1 (a snapshot be_ingest takes) and overlaps the optimisation of frame f, which takes
  *          the front-end off the critical path.  Results are deterministic in both modes; the oracle implements the same two
  *          orderings (ovio_set_tracker_lag).  Not available on dynamic_init handles.  vio_track / vio_process_obs callers choose the
- *          ordering themselves. */
+ *          ordering themselves.
+ * Changing the lag synchronises the handle and re-creates its streams (with lag 1 the front-end streams are confined to their own
+ * compute units): a stream obtained from vio_get_stream before the call is no longer valid. */
 int vio_set_tracker_lag(vio_batch *h, int lag);
 /* the IMU-rate pose of pubLatestOdometry (Estimator::predict, estimator.cpp:1862-1880, fed by inputIMU :1749-1766 after
  * updateLatestStates :1768-1788): the newest window state propagated through every IMU sample pushed after it.

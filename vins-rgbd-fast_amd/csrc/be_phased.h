@@ -61,27 +61,17 @@ __device__ void ps_accept(const Batch &B, int s) {
     Ctx c = make_ctx(B, s);
     const vio_config &cfg = c.C->c;
     const int W = c.W;
-    double total = 0;
-    for (int b = 0; b < st.n_eval_blocks; b++) total += ((volatile double *)st.part)[b];
+    // total cost: the per-block partial sums, one per lane (n_eval_blocks <= PS_MAX_EVAL_BLOCKS <= 64), reduced in a fixed tree order
+    double total = t < st.n_eval_blocks ? ((volatile double *)st.part)[t] : 0.0;
+    total = wave_sum_dpp(total);
     if (st.stage == PS_EVAL_X0) {
         if (t == 0) { st.cost = total; c.be->initial_cost = total; st.point_new = 1; st.stage = PS_ASM; }
         return;
     }
     const double ccost = total, cost = st.cost;
     const int *alist = c.pair_list + c.nres_cap - c.NL;
-    // parameter tolerance |dx| <= 1e-8 (|x| + 1e-8)
-    double xn = 0, dn = 0;
-    const Params &X = st.X, &Xc = st.Xc;
-    if (t <= W) {
-        for (int k = 0; k < 7; k++) { double v = X.pose[t * 7 + k]; xn += v * v; double d = v - Xc.pose[t * 7 + k]; dn += d * d; }
-        for (int k = 0; k < 9; k++) { double v = X.sb[t * 9 + k]; xn += v * v; double d = v - Xc.sb[t * 9 + k]; dn += d * d; }
-    }
-    if (t == W + 1) {
-        if (st.ex_active) for (int k = 0; k < 7; k++) { double v = X.ex[k]; xn += v * v; double d = v - Xc.ex[k]; dn += d * d; }
-        if (st.td_active) { xn += X.td * X.td; dn += (X.td - Xc.td) * (X.td - Xc.td); }
-    }
-    for (int k = t; k < st.Fa; k += 64) { int pi = c.lm_pidx[alist[k]]; double v = c.feat[pi]; xn += v * v; double d = v - c.cfeat[pi]; dn += d * d; }
-    xn = wave_sum_dpp(xn); dn = wave_sum_dpp(dn);
+    // parameter tolerance |dx| <= 1e-8 (|x| + 1e-8): the two norms were accumulated by ps_serial when it formed the candidate
+    const double xn = st.step_xn2, dn = st.step_dn2;
     bool done = false, accept = false;
     if (sqrt(dn) <= 1e-8 * (sqrt(xn) + 1e-8)) done = true;
     else if (fabs(cost - ccost) <= 1e-6 * cost) done = true;
@@ -135,19 +125,28 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
     }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double cost = 0;
+    PH_INIT;
     __syncthreads();
     if (b == 0) {
         if (be.has_prior) {
             // prior gradient q = b + A dx and cost dx^T b + 1/2 dx^T A dx: one thread per row, A read by columns (it is stored exactly
             // symmetric), dx from LDS
-            double *dxs = (double *)smem;
+            // (three threads per row, each over a third of the columns, partial sums added in a fixed order)
+            double *dxs = (double *)smem, *pacc = dxs + ((n + 1) & ~1);
             prior_dx(c, X, dxs, true);
-            double q = 0, d = 0, b0 = 0;
-            if (t < n) {
+            const int nch = min(3, nt / n);
+            if (t < nch * n) {
+                const int ch = t / n, row = t - ch * n;
+                const int j0 = ch * ((n + nch - 1) / nch), j1 = min(n, j0 + (n + nch - 1) / nch);
                 double acc = 0;
-                for (int j = 0; j < n; j++) acc += c.prior_H[(size_t)j * n + t] * dxs[j];
-                b0 = c.prior_r[t]; d = dxs[t];
-                q = b0 + acc;
+                for (int j = j0; j < j1; j++) acc += c.prior_H[(size_t)j * n + row] * dxs[j];
+                pacc[ch * n + row] = acc;
+            }
+            __syncthreads();
+            if (t < n) {
+                double acc = pacc[t];
+                for (int ch = 1; ch < nch; ch++) acc += pacc[ch * n + t];
+                const double b0 = c.prior_r[t], d = dxs[t], q = b0 + acc;
                 st.srp[t] = q;
                 st.sdx[t] = d;
                 cost += 0.5 * d * (b0 + q);
@@ -155,16 +154,27 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
             if (t == 0) cost += 0.5 * be.prior_c0;
         }
     } else if (b <= 2) {
-        // IMU factors: pre-integration headers (state, Jacobian, whitening matrix: the first 704 doubles of PreInt) staged in LDS
+        // IMU factors: pre-integration headers (state, Jacobian, whitening matrix: the first VIO_PREINT_HDR doubles of PreInt) staged in
+        // LDS, four loads in flight per thread
         double *pl = (double *)smem;
-        for (int q = t; q < W * 704; q += nt) { const int i = q / 704, e = q - i * 704; pl[q] = ((const double *)&c.pre[be.pre_idx[i + 1]])[e]; }
+        constexpr int PH_LD = VIO_PREINT_HDR + 1;
+        for (int q0 = t; q0 < W * PH_LD; q0 += 4 * nt) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int q = min(q0 + u * nt, W * PH_LD - 1), i = q / PH_LD, e = min(q - i * PH_LD, VIO_PREINT_HDR - 1);
+                v[u] = ((const double *)&c.pre[be.pre_idx[i + 1]])[e];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (q0 + u * nt < W * PH_LD) pl[q0 + u * nt] = v[u];
+        }
         __syncthreads();
         const v3 G = ld3(be.g);
         const int part_ = (b == 1 ? 0 : 4) + (t >> 6), i0 = t & 63;   // block 1: types 0 .. 3 on its four wavefronts, block 2: type 4
         if (part_ <= 4 && !(b == 2 && (t >> 6) > 0))
             for (int i = i0; i < W; i += 64) {
                 const int j = i + 1;
-                const PreInt &p = *(const PreInt *)(pl + (size_t)i * 704);
+                const PreInt &p = *(const PreInt *)(pl + (size_t)i * PH_LD);   // only the header fields are read
                 double *__restrict__ out = c.imu_raw + (size_t)i * 15 * 31;
                 if (!cfg.use_imu || p.sum_dt > 10.0) { if (part_ == 0) for (int k = 0; k < 15; k++) out[k * 31 + 30] = 0; continue; }
                 if (part_ == 0) {
@@ -216,6 +226,7 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
             cost += 0.5 * log(1.0 + sq);
         }
     }
+    if (b == 0) PH(62); else if (b == 1) PH(63); else if (b == 3) PH(14);
     cost = block_sum(cost, sred);
     __shared__ int last;
     if (t == 0) {
@@ -227,7 +238,9 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
     if (last && t < 64) {
         __threadfence();
         if (t == 0) st.eval_done = 0;
+        const long long ta = (s == 0 && t == 0) ? (long long)wall_clock64() : 0;
         ps_accept(B, s);
+        if (s == 0 && t == 0) B.timings[15] += (float)((long long)wall_clock64() - ta);
     }
 }
 
@@ -749,25 +762,41 @@ __global__ __launch_bounds__(1024) void ps_serial_kernel(Batch B) {
     __syncthreads();
     const Params &X = st.X;
     Params &Xc = st.Xc;
+    double xn2 = 0, dn2 = 0;   // |x|^2 and |candidate - x|^2 over the variable blocks (Ceres' parameter tolerance, checked by ps_accept)
     if (t <= W) {
-        for (int k = 0; k < 7; k++) Xc.pose[t * 7 + k] = X.pose[t * 7 + k];
-        bf::pose_plus(&Xc.pose[t * 7], &delta[6 * t]);
-        for (int k = 0; k < 9; k++) Xc.sb[t * 9 + k] = X.sb[t * 9 + k] + delta[6 * W1 + 9 * t + k];
+        double pc[7];
+        for (int k = 0; k < 7; k++) pc[k] = X.pose[t * 7 + k];
+        bf::pose_plus(pc, &delta[6 * t]);
+        for (int k = 0; k < 7; k++) { const double v = X.pose[t * 7 + k], d = v - pc[k]; xn2 += v * v; dn2 += d * d; Xc.pose[t * 7 + k] = pc[k]; }
+        for (int k = 0; k < 9; k++) {
+            const double v = X.sb[t * 9 + k], vc = v + delta[6 * W1 + 9 * t + k], d = v - vc;
+            xn2 += v * v; dn2 += d * d;
+            Xc.sb[t * 9 + k] = vc;
+        }
     }
     if (t == W + 1) {
-        for (int k = 0; k < 7; k++) Xc.ex[k] = X.ex[k];
-        if (ex_active) bf::pose_plus(Xc.ex, &delta[oE]);
-        Xc.td = X.td + (td_active ? delta[oT] : 0.0);
+        double ec[7];
+        for (int k = 0; k < 7; k++) ec[k] = X.ex[k];
+        if (ex_active) bf::pose_plus(ec, &delta[oE]);
+        const double tdc = X.td + (td_active ? delta[oT] : 0.0);
+        if (ex_active) for (int k = 0; k < 7; k++) { const double v = X.ex[k], d = v - ec[k]; xn2 += v * v; dn2 += d * d; }
+        if (td_active) { xn2 += X.td * X.td; dn2 += (X.td - tdc) * (X.td - tdc); }
+        for (int k = 0; k < 7; k++) Xc.ex[k] = ec[k];
+        Xc.td = tdc;
     }
     for (int k = t; k < F; k += nt) c.cfeat[k] = c.feat[k];
     __syncthreads();
     for (int k = t; k < Fa; k += nt) {
         int slot = alist[k], pi = c.lm_pidx[slot];
-        double v = c.feat[pi] + stl[k] * sl[k];
+        const double v0 = c.feat[pi];
+        double v = v0 + stl[k] * sl[k];
         double ub = (c.lm_est[slot] == 2) ? 2.0 / cfg.depth_max : 1.7976931348623157e308;
         if (v > ub) v = ub;
         c.cfeat[pi] = v;
+        xn2 += v0 * v0; dn2 += (v0 - v) * (v0 - v);
     }
+    block_sum2(xn2, dn2, sred);
+    if (t == 0) { st.step_xn2 = xn2; st.step_dn2 = dn2; }
     if (t == 0) { st.model_change = model_change; st.eval_with_J = iter < cfg.max_iterations ? 1 : 0; }
     finish(PS_EVAL_C);
     PH(55);

@@ -670,6 +670,38 @@ static int build_devcfg(const vio_config *cfg, int imu_capacity, DevCfg &C) {
     return VIO_OK;
 }
 
+// The two streams of a stream group.  partitioned (tracker lag 1): compute-unit partition by hipExtStreamCreateWithCUMask with
+// contiguous ranges = whole XCDs.  The wide front-end kernels of frame f+1 then overlap the latency-bound solver kernels of frame f, and
+// keeping them on their own XCDs leaves the solver's L2 slices and dispatchers alone (measured: +5 %; stream priorities and an
+// interleaved mask did nothing).  VIO_FE_CUS = n (default 64, 0 = no partition): front-end streams use CUs [0, n), back-end streams
+// the rest; VIO_BE_CU_SPLIT = 1: the back-end streams of the groups share [n, 256) in equal contiguous parts; VIO_BE_CU_ALL = 1: back-end
+// on all CUs.  With lag 0 the front-end is on the critical path itself and gets the whole device.
+static int create_group_streams(vio_batch *h, vio_batch::Group &g, bool partitioned) {
+    if (g.stream) { (void)hipStreamDestroy(g.stream); g.stream = nullptr; }
+    if (g.fe_stream) { (void)hipStreamDestroy(g.fe_stream); g.fe_stream = nullptr; }
+    const char *fe_cus_env = getenv("VIO_FE_CUS");
+    const int fe_cus = fe_cus_env ? atoi(fe_cus_env) : 64;
+    hipError_t e_fe, e_be;
+    if (partitioned && fe_cus > 0 && fe_cus < 256) {
+        uint32_t mfe[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mbe[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int ng = (int)h->groups.size(), gi = (int)(&g - &h->groups[0]);
+        const bool split = getenv("VIO_BE_CU_SPLIT") && atoi(getenv("VIO_BE_CU_SPLIT")) != 0 && ng > 1;
+        const int per = (256 - fe_cus) / ng;
+        const int b0 = split ? fe_cus + gi * per : fe_cus, b1 = split ? (gi == ng - 1 ? 256 : b0 + per) : 256;
+        for (int q = 0; q < 256; q++) {
+            if (q < fe_cus) mfe[q >> 5] |= 1u << (q & 31);
+            if (q >= b0 && q < b1) mbe[q >> 5] |= 1u << (q & 31);
+        }
+        e_fe = hipExtStreamCreateWithCUMask(&g.fe_stream, 8, mfe);
+        e_be = getenv("VIO_BE_CU_ALL") ? hipStreamCreate(&g.stream) : hipExtStreamCreateWithCUMask(&g.stream, 8, mbe);
+    } else {
+        e_fe = hipStreamCreate(&g.fe_stream);
+        e_be = hipStreamCreate(&g.stream);
+    }
+    if (e_be != hipSuccess || e_fe != hipSuccess) { g_err = "stream create failed"; return VIO_EDEVICE; }
+    return VIO_OK;
+}
+
 vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     if (!cfg || n_seq < 1) { g_err = "bad arguments"; return nullptr; }
     int ndev = 0;
@@ -729,30 +761,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
             vio_batch::Group &g = h->groups[k];
             g.s0 = k * per;
             g.n = std::min(per, n_seq - g.s0);
-            // Compute-unit partition (hipExtStreamCreateWithCUMask, contiguous ranges = whole XCDs): the wide front-end kernels of frame
-            // f+1 overlap the latency-bound solver kernels of frame f; keeping them on their own XCDs leaves the solver's L2 slices and
-            // dispatchers alone (measured: +5 %).  VIO_FE_CUS = n (default 64, 0 = no partition): front-end streams use CUs [0, n);
-            // VIO_BE_CU_SPLIT = 1: the back-end streams of the groups share [n, 256) in equal contiguous parts instead of all using it.
-            const char *fe_cus_env = getenv("VIO_FE_CUS");
-            const int fe_cus = fe_cus_env ? atoi(fe_cus_env) : 64;
-            hipError_t e_fe, e_be;
-            if (fe_cus > 0 && fe_cus < 256) {
-                uint32_t mfe[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mbe[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                const int ng = (int)h->groups.size(), gi = (int)(&g - &h->groups[0]);
-                const bool split = getenv("VIO_BE_CU_SPLIT") && atoi(getenv("VIO_BE_CU_SPLIT")) != 0 && ng > 1;
-                const int per = (256 - fe_cus) / ng;
-                const int b0 = split ? fe_cus + gi * per : fe_cus, b1 = split ? (gi == ng - 1 ? 256 : b0 + per) : 256;
-                for (int q = 0; q < 256; q++) {
-                    if (q < fe_cus) mfe[q >> 5] |= 1u << (q & 31);
-                    if (q >= b0 && q < b1) mbe[q >> 5] |= 1u << (q & 31);
-                }
-                e_fe = hipExtStreamCreateWithCUMask(&g.fe_stream, 8, mfe);
-                e_be = getenv("VIO_BE_CU_ALL") ? hipStreamCreate(&g.stream) : hipExtStreamCreateWithCUMask(&g.stream, 8, mbe);
-            } else {
-                e_fe = hipStreamCreate(&g.fe_stream);
-                e_be = hipStreamCreate(&g.stream);
-            }
-            if (e_be != hipSuccess || e_fe != hipSuccess) { g_err = "stream create failed"; rc = VIO_EDEVICE; break; }
+            if (create_group_streams(h, g, /*partitioned=*/false) != VIO_OK) { rc = VIO_EDEVICE; break; }
             if (hipEventCreateWithFlags(&g.ev_solve, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g.ev_fe, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&g.ev_be, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g.ev_ingest, hipEventDisableTiming) != hipSuccess) { g_err = "event create failed"; rc = VIO_EDEVICE; }
         }
@@ -799,7 +808,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
                                       (size_t)C.W * 768 <= (W1 * W1 - W1 * C.W / 2) * 210;
                 h->solve_mode = getenv("VIO_SOLVE_MODE") ? atoi(getenv("VIO_SOLVE_MODE")) : 1;   // phased by default where it applies (windows up to ~10 keyframes)
                 if (!eligible) h->solve_mode = 0;
-                h->lds_ps_eval = std::max((W1 * W1 + 1) * 32 * 8, (size_t)C.W * 704 * 8) + 64;   // pair geometry / staged pre-integration headers
+                h->lds_ps_eval = std::max((W1 * W1 + 1) * 32 * 8, (size_t)C.W * (VIO_PREINT_HDR + 1) * 8) + 64;   // pair geometry / staged pre-integration headers
                 (void)raise_lds_limit((const void *)ps_eval_kernel, h->lds_ps_eval);
                 h->ps_eval_blocks = (int)std::min<size_t>(PS_MAX_EVAL_BLOCKS, (size_t)C.W * C.NP / 256 + 4);
                 h->ps_asm_a_blocks = (int)((W1 * W1 + C.W + (2 * ((size_t)C.NL + 3) + 63) / 64 + 7) / 8);
@@ -1006,6 +1015,10 @@ int vio_set_tracker_lag(vio_batch *h, int lag) {
     if (lag && h->hc.c.dynamic_init) { g_err = "vio_set_tracker_lag: dynamic_init handles run their initialisation on the host between frames (lag 0 only)"; return VIO_EINVAL; }
     int rc = sync_all(h);
     if (rc != VIO_OK) return rc;
+    if (lag != h->tracker_lag) {   // the overlapping front-end gets its own compute units (see create_group_streams)
+        for (auto &g : h->groups) if ((rc = create_group_streams(h, g, lag == 1)) != VIO_OK) return rc;
+        h->stream = h->groups[0].stream; h->fe_stream = h->groups[0].fe_stream;
+    }
     h->tracker_lag = lag;
     h->B.tracker_lag = lag;
     return VIO_OK;

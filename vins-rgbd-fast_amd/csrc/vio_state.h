@@ -4,6 +4,7 @@
 // (estimator.h:117-201), FeatureManager::feature (feature_manager.h:143), IntegrationBase (integration_base.h:197-216),
 // MarginalizationInfo (marginalization_factor.h:51-76).
 #pragma once
+#include <cstddef>
 #include <stdint.h>
 #include "../../include/vio_abi.h"
 #include "dmath.h"
@@ -43,11 +44,16 @@ struct PreInt {
     double lin_acc[3], lin_gyr[3], lin_ba[3], lin_bg[3];
     double acc0[3], gyr0[3];
     double dp[3], dq[4], dv[3], sum_dt;  // dq = (w,x,y,z)
-    double jac[225], cov[225];
-    double sqrt_info[225];               // LLT(cov^-1).L^T, refreshed before each solve
+    double jac[225];
+    double sqrt_info[225];               // whitening matrix M (M^T M = cov^-1), refreshed whenever the covariance changes
+    // ---- everything above (VIO_PREINT_HDR doubles) is what evaluating the IMU factor reads: ps_eval stages exactly that in LDS
+    double cov[225];
     double dt_buf[VIO_IMU_SLOT_CAP], acc_buf[VIO_IMU_SLOT_CAP][3], gyr_buf[VIO_IMU_SLOT_CAP][3];
     int n_buf, valid;
 };
+
+#define VIO_PREINT_HDR 479
+static_assert(offsetof(PreInt, cov) == VIO_PREINT_HDR * sizeof(double), "PreInt header layout");
 
 // per-sequence tracker record (scalars); arrays live in TrackerArrays
 struct FeSeq {
@@ -124,6 +130,7 @@ struct SolveSt {
     double sdx[6 * VIO_MAXW + 16], srp[6 * VIO_MAXW + 16];   // prior tangent / gradient at the last evaluated point
     double part[PS_MAX_EVAL_BLOCKS];                           // per-block partial costs of the last evaluation (block 0: prior + IMU)
     double cost, ccost, radius, mu, alpha, dogleg_norm, model_change;
+    double step_xn2, step_dn2;   // |x|^2 and |candidate - x|^2 over the variable blocks (parameter tolerance), from ps_serial
     long long ts0;
     int stage;            // PS_*: what the sequence needs next
     int F, Fa, nres, ex_active, td_active, vext;
