@@ -185,7 +185,7 @@ def main():
     n_pre = 16  # first-image skip + init_pub + init_feature + (window_size + 1) frames -> NON_LINEAR, + margin
     Kp = max(args.pcie_steps, 0)
     Ks = max(args.stream_steps, 0)
-    F = n_pre + Wm + R * K + Kp + 2 * Ks
+    F = n_pre + Wm + R * K + 2 * Kp + 2 * Ks   # (the PCIe leg runs twice: pageable and page-locked buffers)
     seq0 = shard.sequence_shard(rank, world, S)[0]
     syn = P.Synth(sc)
     dev = torch.device("cuda", local_rank)
@@ -210,7 +210,7 @@ def main():
     for f in range(n_pre + Wm):
         feed(f)
     b.sync()
-    st0 = [b.status(s) for s in range(S)]
+    st0 = b.status_all()
     fp0 = np.array([st.frames_processed for st in st0])
     nl = np.array([st.solver_flag for st in st0])
     it0 = np.array([(st.iterations_total, st.solves_total) for st in st0], np.int64)
@@ -231,7 +231,7 @@ def main():
             dist.barrier()
         elapsed_rep.append(t1 - t0)
     nprof, kms = b.profile_end()
-    st1 = [b.status(s) for s in range(S)]
+    st1 = b.status_all()
     it1 = np.array([(st.iterations_total, st.solves_total) for st in st1], np.int64)
     d_it = (it1 - it0).sum(0)
     iters = float(d_it[0]) / max(float(d_it[1]), 1.0)          # mean solver iterations per solve over ALL timed steps and sequences
@@ -250,6 +250,21 @@ def main():
         c1 = time.perf_counter()
         pcie = dict(frames_per_s=S * Kp / (c1 - c0), ms_per_step=(c1 - c0) / Kp * 1e3, steps=Kp,
                     note="vio_feed(on_device=0): pageable numpy buffers, %.1f MB uploaded per step" % (S * H * Wd * 3 / 1e6))
+        # the same from page-locked buffers (vio_host_alloc)
+        pg = [P.PinnedArray((S, H, Wd), np.uint8) for _ in range(Kp)]
+        pd = [P.PinnedArray((S, H, Wd), np.uint16) for _ in range(Kp)]
+        for k in range(Kp):
+            pg[k].a[...] = gray[f_timed_end + Kp + k].cpu().numpy(); pd[k].a[...] = depth[f_timed_end + Kp + k].cpu().numpy()
+        b.sync()
+        c0 = time.perf_counter()
+        for k in range(Kp):
+            b.feed(pg[k].a, pd[k].a, np.full(S, times[f_timed_end + Kp + k]), on_device=False)
+        b.sync()
+        c1 = time.perf_counter()
+        pcie["pinned"] = dict(frames_per_s=S * Kp / (c1 - c0), ms_per_step=(c1 - c0) / Kp * 1e3,
+                              note="the next %d frames from vio_host_alloc (page-locked) buffers" % Kp)
+        for x in pg + pd:
+            x.free()
 
     # ---- streaming legs (never `value`): IMU arrives between frames, device-resident images.  (a) the reference's callback pattern:
     # one vio_push_imu per sequence per frame from Python; (b) one vio_push_imu_batch per frame (SoA over sequences)
@@ -283,7 +298,7 @@ def main():
                                  "%d vio_push_imu calls per step vs one vio_push_imu_batch call" % S)
 
     # ---- validity + accuracy (outside the timed region)
-    stats = [b.status(s) for s in range(S)]
+    stats = b.status_all()
     fp1 = np.array([st.frames_processed for st in stats])
     all_processed = bool(np.all(fp1 - fp0 == R * K + Kp + 2 * Ks) and np.all(nl == 1))
     ates = []

@@ -88,6 +88,8 @@ int vio_reset_seq(vio_batch *h, int seq);
  * on_device != 0: pointers are HBM addresses (no PCIe in the call); otherwise host buffers that are uploaded first.
  * stamps: S timestamps (seconds). The call is asynchronous on the batch's stream; vio_sync or any getter waits.
  * Per-sequence status codes are read back with vio_get_status. */
+/* Host buffers (on_device == 0) are uploaded by a copy stream beside the previous frame's kernels; they may be modified or freed once
+ * the NEXT vio_feed / vio_feed_modes call on the handle (or any getter / vio_sync) has returned. */
 int vio_feed(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, int on_device);
 
 /* The two halves of vio_feed, exposed separately the way the reference exposes them to its two threads.
@@ -130,6 +132,10 @@ void *vio_device_alloc(size_t bytes);
 void vio_device_free(void *p);
 int vio_device_upload(void *dst_device, const void *src_host, size_t bytes);
 int vio_device_download(void *dst_host, const void *src_device, size_t bytes);
+/* page-locked host memory for the on_device == 0 image arguments: uploads from it run at PCIe rate and asynchronously (from pageable
+ * memory the runtime stages every copy).  NULL on failure. */
+void *vio_host_alloc(size_t bytes);
+void vio_host_free(void *p);
 /* sizeof(vio_config) (what = 0) / sizeof(vio_status) (what = 1) as compiled into the library: lets a binding check its struct mirrors */
 int vio_abi_sizeof(int what);
 /* capacities derived from the configuration: out[0] = tracker points per sequence, out[1] = landmark slots, out[2] = IMU ring */
@@ -155,6 +161,8 @@ typedef struct vio_status {
     int32_t iterations_total, solves_total; /* solver iterations / solves since vio_create */
 } vio_status;
 int vio_get_status(vio_batch *h, int seq, vio_status *out);
+/* the same for every sequence of the handle in two device reads: out[n_seq] */
+int vio_get_status_all(vio_batch *h, vio_status *out);
 /* window state Ps/Rs/Vs/Bas/Bgs/Headers (estimator.h:121-135): (W+1) rows of 17 doubles
  * [P(3) Q(w,x,y,z) V(3) Ba(3) Bg(3) stamp] */
 int vio_get_window(vio_batch *h, int seq, double *out);

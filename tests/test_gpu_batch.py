@@ -152,3 +152,15 @@ def test_alternative_kernel_configurations_agree(P, monkeypatch, env):
     for i in range(2):
         assert alt.status(i).solver_flag == 1
         assert np.abs(alt.window(i)[:, :3] - ref_w[i][:, :3]).max() < 1e-6, (env, i)
+
+
+def test_status_all_equals_per_sequence_status(P):
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    b = _drive(P, cfg, sc, [70, 71, 72], 16)
+    allst = b.status_all()
+    assert len(allst) == 3
+    for i in range(3):
+        one = b.status(i)
+        for name, _ in one._fields_:
+            assert getattr(one, name) == getattr(allst[i], name), (i, name)

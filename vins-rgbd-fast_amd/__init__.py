@@ -107,6 +107,7 @@ def lib():
         L.vio_get_extrinsic.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.vio_get_latest_odometry.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.vio_set_tracker_lag.argtypes = [C.c_void_p, C.c_int]
+        L.vio_get_status_all.argtypes = [C.c_void_p, C.c_void_p]
         L.vio_get_tracks.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.vio_get_landmarks.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.vio_get_prior.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 4
@@ -168,6 +169,33 @@ def _ptr(a):
     if hasattr(a, "data_ptr"):  # torch tensor (device or host)
         return a.data_ptr()
     return a
+
+
+class PinnedArray:
+    """numpy array over page-locked host memory (vio_host_alloc): hand `.a` to feed / track / process with on_device=False"""
+
+    def __init__(self, shape, dtype):
+        self.L = lib()
+        self.L.vio_host_alloc.restype = C.c_void_p
+        self.L.vio_host_alloc.argtypes = [C.c_size_t]
+        self.L.vio_host_free.argtypes = [C.c_void_p]
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self.ptr = self.L.vio_host_alloc(n)
+        if not self.ptr:
+            raise VioError("vio_host_alloc(%d) failed" % n)
+        self.a = np.frombuffer((C.c_uint8 * n).from_address(self.ptr), dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.a = None
+            self.L.vio_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class DeviceBuffer:
@@ -285,9 +313,9 @@ class VioBatch:
         stamps = np.ascontiguousarray(stamps, np.float64).reshape(-1)
         assert len(stamps) == self.S
         m = None if modes is None else np.ascontiguousarray(modes, np.uint8).reshape(self.S)
-        self._keep = (gray, depth, stamps, m)
         self._chk(self.L.vio_feed_modes(self.h, _ptr(gray), _ptr(depth), stamps.ctypes.data, None if m is None else m.ctypes.data,
                                         1 if on_device else 0), "vio_feed")
+        self._keep = (gray, depth, stamps, m)   # host buffers stay alive until the next feed has returned (vio_abi.h)
 
     def track(self, gray, stamps, publish=True, on_device=False, modes=None, R_rel=None):
         """vio_track / vio_track_ex: modes = per-sequence FRAME_* (default: publish for all), R_rel = caller-supplied relative
@@ -359,6 +387,12 @@ class VioBatch:
         s = Status()
         self._chk(self.L.vio_get_status(self.h, seq, C.byref(s)), "vio_get_status")
         return s
+
+    def status_all(self):
+        """vio_status of every sequence (two device reads for the whole batch)"""
+        arr = (Status * self.S)()
+        self._chk(self.L.vio_get_status_all(self.h, arr), "vio_get_status_all")
+        return list(arr)
 
     def window(self, seq=0):
         w = np.zeros((self.W + 1, 17))

@@ -48,6 +48,8 @@ struct vio_batch {
         hipStream_t stream = nullptr;     // back-end (and uploads that feed it)
         hipStream_t fe_stream = nullptr;  // front-end: frame k+1 tracks while frame k is still being marginalised
         hipEvent_t ev_solve = nullptr, ev_fe = nullptr, ev_be = nullptr, ev_ingest = nullptr;
+        hipStream_t copy_stream = nullptr;   // host -> HBM uploads of vio_feed (on_device == 0), beside the kernels of the previous frame
+        hipEvent_t ev_up_gray = nullptr, ev_up_depth = nullptr;
         bool have_solve_ev = false, have_ingest_ev = false;
     };
     std::vector<Group> groups;
@@ -135,6 +137,7 @@ static int raise_lds_limit(const void *fn, size_t bytes) {
 
 static int sync_all(vio_batch *h) {
     for (auto &g : h->groups) {
+        if (g.copy_stream) HIPCHK(hipStreamSynchronize(g.copy_stream));
         HIPCHK(hipStreamSynchronize(g.fe_stream));
         HIPCHK(hipStreamSynchronize(g.stream));
     }
@@ -864,6 +867,9 @@ void vio_destroy(vio_batch *h) {
         if (g.ev_fe) (void)hipEventDestroy(g.ev_fe);
         if (g.ev_be) (void)hipEventDestroy(g.ev_be);
         if (g.ev_ingest) (void)hipEventDestroy(g.ev_ingest);
+        if (g.ev_up_gray) (void)hipEventDestroy(g.ev_up_gray);
+        if (g.ev_up_depth) (void)hipEventDestroy(g.ev_up_depth);
+        if (g.copy_stream) (void)hipStreamDestroy(g.copy_stream);
     }
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
@@ -895,20 +901,46 @@ int vio_push_imu(vio_batch *h, int seq, int n, const double *t, const double *ac
 }
 
 static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, const uint16_t *depth, const double *stamps, int on_device,
-                        const uint8_t **dg, const uint16_t **dd) {
+                        const uint8_t **dg, const uint16_t **dd, bool overlap = false) {
     // every group uploads its own slice on its own streams: in order with the kernels that consume it, no cross-group hazard
     const DevCfg &C = h->hc;
     size_t HW = (size_t)C.c.width * C.c.height, S = h->S, s0 = g.s0, n = g.n;
     if (stamps) HIPCHK(hipMemcpyAsync(h->d_stamps + s0, stamps + s0, n * sizeof(double), hipMemcpyHostToDevice, g.fe_stream));
     if (on_device) { *dg = gray; *dd = depth; return VIO_OK; }
+    // overlap (vio_feed): the uploads run on the group's copy stream as soon as the staging buffers are free (the previous frame's
+    // front-end has read the grey image, its be_ingest the depth image), i.e. beside the previous frame's optimisation, and the
+    // consumers wait for them through events.  Otherwise the copies sit in the consumer's own stream.
+    if (overlap && !g.copy_stream) {
+        HIPCHK(hipStreamCreate(&g.copy_stream));
+        HIPCHK(hipEventCreateWithFlags(&g.ev_up_gray, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&g.ev_up_depth, hipEventDisableTiming));
+    } else if (overlap) {
+        // caller contract: the host buffers of a vio_feed call may be reused once the NEXT vio_feed call has returned -- that call
+        // starts by waiting for the previous uploads (they are asynchronous when the buffers are page-locked)
+        HIPCHK(hipEventSynchronize(g.ev_up_gray));
+        HIPCHK(hipEventSynchronize(g.ev_up_depth));
+    }
     if (gray) {
         if (!h->d_gray_stage) HIPCHK(hipMalloc((void **)&h->d_gray_stage, S * HW));
-        HIPCHK(hipMemcpyAsync(h->d_gray_stage + s0 * HW, gray + s0 * HW, n * HW, hipMemcpyHostToDevice, g.fe_stream));
+        if (overlap) {
+            HIPCHK(hipStreamWaitEvent(g.copy_stream, g.ev_fe, 0));
+            HIPCHK(hipMemcpyAsync(h->d_gray_stage + s0 * HW, gray + s0 * HW, n * HW, hipMemcpyHostToDevice, g.copy_stream));
+            HIPCHK(hipEventRecord(g.ev_up_gray, g.copy_stream));
+            HIPCHK(hipStreamWaitEvent(g.fe_stream, g.ev_up_gray, 0));
+        } else
+            HIPCHK(hipMemcpyAsync(h->d_gray_stage + s0 * HW, gray + s0 * HW, n * HW, hipMemcpyHostToDevice, g.fe_stream));
         *dg = h->d_gray_stage;
     }
     if (depth) {
         if (!h->d_depth_stage) HIPCHK(hipMalloc((void **)&h->d_depth_stage, S * HW * 2));
-        HIPCHK(hipMemcpyAsync(h->d_depth_stage + s0 * HW, depth + s0 * HW, n * HW * 2, hipMemcpyHostToDevice, g.stream));
+        if (overlap) {
+            if (g.have_ingest_ev) HIPCHK(hipStreamWaitEvent(g.copy_stream, g.ev_ingest, 0));
+            HIPCHK(hipStreamWaitEvent(g.copy_stream, g.ev_be, 0));   // a vio_process* call in between reads the staging buffer too
+            HIPCHK(hipMemcpyAsync(h->d_depth_stage + s0 * HW, depth + s0 * HW, n * HW * 2, hipMemcpyHostToDevice, g.copy_stream));
+            HIPCHK(hipEventRecord(g.ev_up_depth, g.copy_stream));
+            HIPCHK(hipStreamWaitEvent(g.stream, g.ev_up_depth, 0));
+        } else
+            HIPCHK(hipMemcpyAsync(h->d_depth_stage + s0 * HW, depth + s0 * HW, n * HW * 2, hipMemcpyHostToDevice, g.stream));
         *dd = h->d_depth_stage;
     }
     return VIO_OK;
@@ -946,7 +978,7 @@ int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, 
         if ((rc = fe_wait(h, g)) != VIO_OK) return rc;
         const uint8_t *dg = nullptr;
         const uint16_t *dd = nullptr;
-        rc = stage_inputs(h, g, gray, depth_mm, stamps, on_device, &dg, &dd);
+        rc = stage_inputs(h, g, gray, depth_mm, stamps, on_device, &dg, &dd, /*overlap=*/true);
         if (rc != VIO_OK) return rc;
         if ((rc = stage_side_inputs(h, g, modes, nullptr)) != VIO_OK) return rc;
         if (g.s0 == 0) HIPCHK(hipEventRecord(h->ev[0], g.fe_stream));
@@ -1129,6 +1161,12 @@ void *vio_device_alloc(size_t bytes) {
     return p;
 }
 void vio_device_free(void *p) { if (p) (void)hipFree(p); }
+void *vio_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { g_err = "hipHostMalloc failed"; return nullptr; }
+    return p;
+}
+void vio_host_free(void *p) { if (p) (void)hipHostFree(p); }
 int vio_device_upload(void *dst, const void *src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); return VIO_OK; }
 int vio_device_download(void *dst, const void *src, size_t bytes) { HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost)); return VIO_OK; }
 
@@ -1164,13 +1202,7 @@ int vio_sync(vio_batch *h) {
 }
 void *vio_get_stream(vio_batch *h) { return h ? (void *)h->stream : nullptr; }
 
-int vio_get_status(vio_batch *h, int seq, vio_status *out) {
-    if (!h || seq < 0 || seq >= h->S || !out) return VIO_EINVAL;
-    { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
-    static thread_local BeSeq be;
-    static thread_local FeSeq fe;
-    HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(&fe, h->B.fe + seq, sizeof(FeSeq), hipMemcpyDeviceToHost));
+static void fill_status(const BeSeq &be, const FeSeq &fe, vio_status *out) {
     const int ovf = be.overflow | fe.overflow;
     out->code = (ovf && be.status_code == VIO_OK) ? VIO_ECAPACITY : be.status_code;  // a table overflowed in the last frame: results are truncated, say so
     out->overflow_flags = ovf; out->overflow_frames = be.overflow_frames;
@@ -1181,6 +1213,27 @@ int vio_get_status(vio_batch *h, int seq, vio_status *out) {
     out->n_in_problem = be.n_in_problem; out->n_residuals = be.n_residuals; out->n_var_landmarks = be.n_var_landmarks;
     out->has_prior = be.has_prior; out->reboot_count = be.reboot_count; out->frames_processed = be.frames_processed;
     out->initial_cost = be.initial_cost; out->final_cost = be.final_cost; out->td = be.td;
+}
+
+int vio_get_status(vio_batch *h, int seq, vio_status *out) {
+    if (!h || seq < 0 || seq >= h->S || !out) return VIO_EINVAL;
+    { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
+    static thread_local BeSeq be;
+    static thread_local FeSeq fe;
+    HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&fe, h->B.fe + seq, sizeof(FeSeq), hipMemcpyDeviceToHost));
+    fill_status(be, fe, out);
+    return VIO_OK;
+}
+
+int vio_get_status_all(vio_batch *h, vio_status *out) {
+    if (!h || !out) return VIO_EINVAL;
+    { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
+    std::vector<BeSeq> be((size_t)h->S);
+    std::vector<FeSeq> fe((size_t)h->S);
+    HIPCHK(hipMemcpy(be.data(), h->B.be, sizeof(BeSeq) * (size_t)h->S, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(fe.data(), h->B.fe, sizeof(FeSeq) * (size_t)h->S, hipMemcpyDeviceToHost));
+    for (int s = 0; s < h->S; s++) fill_status(be[s], fe[s], out + s);
     return VIO_OK;
 }
 
