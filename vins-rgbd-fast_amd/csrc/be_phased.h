@@ -360,8 +360,8 @@ __global__ __launch_bounds__(512) void ps_asm_a_kernel(Batch B) {
 // zero-fill pass) and per entry of g: prior block, the (at most two) IMU Gram blocks that contain both columns, then the
 // frame-pair sums -- the same terms in the same order as assemble().  The thread that owns a diagonal entry fixes the Jacobi
 // column scaling the first time round.
-__global__ __launch_bounds__(256) void ps_asm_b_kernel(Batch B) {
-    const int s = blockIdx.y + B.s0;
+#define PS_ASM_B_BLOCKS 24
+__device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s) {
     const SolveSt &st = B.sst[s];
     if (st.stage != PS_ASM) return;
     Ctx c = make_ctx(B, s);
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(256) void ps_asm_b_kernel(Batch B) {
         if (a == oT) return 6 * W + 15;
         return -1;
     };
-    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < total; w += gridDim.x * blockDim.x) {
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < total; w += PS_ASM_B_BLOCKS * blockDim.x) {
         const int a = w / (LW + 1), bcol = w - a * (LW + 1);
         const bool grad = bcol == LW;
         const int b = grad ? -1 : bcol;
@@ -467,41 +467,31 @@ __global__ __launch_bounds__(256) void ps_asm_b_kernel(Batch B) {
 // grid (active tiles, S), 64 threads: one wavefront forms one 16 x 16 lower tile of S = S_p H S_p + mu D^2 - sum_k w_k h_k h_k^T
 // over all landmark rows, operands straight from HBM / L2 in batches of 8 k-steps, into c.Sc in the LDS tile layout.
 #define PS_SCH_U 8
-__global__ __launch_bounds__(64) void ps_schur_kernel(Batch B) {
-    const int s = blockIdx.y + B.s0;
+// U = sum_k hpl_k^T hpl_k w_k, the landmark part of the Schur complement S = Sp (H - U) Sp + mu D^2, for one active 16 x 16 tile on the
+// FP64 matrix cores (one wavefront).  It needs nothing ps_asm_b produces (neither H nor the column scaling Sp), which is why the two run
+// side by side in one launch; ps_serial combines H, U, Sp and mu D^2 while it loads the tiles into LDS.
+__device__ __forceinline__ void ps_schur_body(const Batch &B, int s, int tile_index, double *wk_s) {
     const SolveSt &st = B.sst[s];
     if (st.stage != PS_ASM && st.stage != PS_SCHUR) return;
+    if (threadIdx.x >= 64) return;
     Ctx c = make_ctx(B, s);
     const int W1 = c.W + 1, LW = c.LW, nb = LW >> 4;
     const unsigned colmask = ps_colmask(W1, LW, st.vext != 0);
-    // the blockIdx.x-th active tile (ti >= tj, both column tiles active)
+    // the tile_index-th active tile (ti >= tj, both column tiles active)
     int ti = -1, tj = -1, cnt = 0;
     for (int a = 0; a < nb && ti < 0; a++)
         for (int b = 0; b <= a; b++)
-            if (((colmask >> a) & 1u) && ((colmask >> b) & 1u)) { if (cnt == (int)blockIdx.x) { ti = a; tj = b; break; } cnt++; }
+            if (((colmask >> a) & 1u) && ((colmask >> b) & 1u)) { if (cnt == tile_index) { ti = a; tj = b; break; } cnt++; }
     if (ti < 0) return;
     const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
-    const double *H = c.H, *Ws = c.Hpl, *sp = c.vec + 1 * LW;
+    const double *Ws = c.Hpl;
     const double mu = st.mu;
     const int Fa = st.Fa, Kpad = (Fa + 3) & ~3;
     const bool first = st.scale_pending != 0;
-    v4f64 acc;
-    for (int r = 0; r < 4; r++) {
-        const int row = 16 * ti + lk + 4 * r, col = 16 * tj + li;
-        double v = sp[row] * sp[col] * H[(size_t)row * LW + col];
-        if (row == col) {
-            const double hs = row < c.P ? sp[row] * sp[row] * H[(size_t)row * LW + row] : 0.0;
-            const double d = sqrt(fmin(fmax(hs, 1e-6), 1e32));
-            v += mu * d * d;
-            if (sp[row] == 0.0) v = 1.0;
-        }
-        acc[r] = v;
-    }
+    v4f64 acc = {0, 0, 0, 0};
     const double *wa = Ws + 16 * ti + li, *wb = Ws + 16 * tj + li;
-    const double spa = sp[16 * ti + li], spb = sp[16 * tj + li];
     // per-row factor sl^2 / (sl^2 Hll + mu dgl^2), sl = 1 / (1 + sqrt(Hll)) at the first linearisation: once per row into LDS (a square
     // root and two divisions each), not once per lane and trip
-    extern __shared__ double wk_s[];
     for (int kc = lane; kc < Kpad; kc += 64) {
         double hll = c.Hll[kc], slk = first ? (kc < Fa ? 1.0 / (1.0 + sqrt(hll)) : 0.0) : c.lvec[kc];
         const double hl = kc < Fa ? slk * slk * hll : 0.0;
@@ -509,7 +499,7 @@ __global__ __launch_bounds__(64) void ps_schur_kernel(Batch B) {
         const double iv = kc < Fa ? 1.0 / (hl + mu * dl * dl) : 0.0;
         wk_s[kc] = slk * slk * iv;
     }
-    __syncthreads();
+    WAVE_SYNC();
     for (int k0 = 0; k0 < Kpad; k0 += 4 * PS_SCH_U) {
         double a[PS_SCH_U], b[PS_SCH_U];
 #pragma unroll
@@ -519,8 +509,8 @@ __global__ __launch_bounds__(64) void ps_schur_kernel(Batch B) {
             const int kc = min(kk, Kpad - 1);
             const double wk = wk_s[kc];
             const double va = wa[(size_t)kc * LW], vb = wb[(size_t)kc * LW];
-            a[u] = valid ? -((va * spa) * wk) : 0.0;
-            b[u] = valid ? vb * spb : 0.0;
+            a[u] = valid ? va * wk : 0.0;
+            b[u] = valid ? vb : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < PS_SCH_U; u++) {
@@ -529,6 +519,15 @@ __global__ __launch_bounds__(64) void ps_schur_kernel(Batch B) {
         }
     }
     for (int r = 0; r < 4; r++) c.Sc[tl_idx(ti, tj, lk + 4 * r, li)] = acc[r];
+}
+
+// one launch: blocks [0, PS_ASM_B_BLOCKS) sum the entries of H and the gradient, the blocks behind them form the landmark part of the
+// Schur complement tile by tile
+__global__ __launch_bounds__(256) void ps_asm_b_schur_kernel(Batch B) {
+    const int s = blockIdx.y + B.s0;
+    extern __shared__ double ps_wk_s[];
+    if (blockIdx.x < PS_ASM_B_BLOCKS) ps_asm_b_body(B, s);
+    else ps_schur_body(B, s, (int)blockIdx.x - PS_ASM_B_BLOCKS, ps_wk_s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- SERIAL
@@ -610,7 +609,7 @@ __global__ __launch_bounds__(1024) void ps_serial_kernel(Batch B) {
         }
         PH(48);
         cauchy_valid = false;
-        // Gauss-Newton step through the Schur complement formed by ps_schur_kernel at this mu
+        // Gauss-Newton step through the Schur complement (its landmark part U comes from ps_asm_b_schur_kernel at this mu)
         for (int k = t; k < Kpad; k += nt) {
             double iv = k < Fa ? 1.0 / (Hlls[k] + mu * dgl[k] * dgl[k]) : 0.0;
             inv[k] = iv;
@@ -627,7 +626,7 @@ __global__ __launch_bounds__(1024) void ps_serial_kernel(Batch B) {
             // thread = element (r, cc) of every (nt / 256)-th tile; four tiles per trip, branch-free loads so that they are in flight together
             const int e = t & 255, r = e >> 4, cc = e & 15, tstep = nt >> 8;
             for (int tile0 = t >> 8; tile0 < ntile; tile0 += 4 * tstep) {
-                double hv[4], sr[4], sc[4], dg[4];
+                double hv[4], uv[4], sr[4], sc[4], dg[4];
                 int widx[4];
                 bool msk[4], dia[4];
 #pragma unroll
@@ -639,17 +638,15 @@ __global__ __launch_bounds__(1024) void ps_serial_kernel(Batch B) {
                     widx[b] = tl_idx(ti, tj, r, cc);
                     msk[b] = ((colmask >> ti) & 1u) && ((colmask >> tj) & 1u);
                     dia[b] = row == col;
-                    const double *src = msk[b] ? c.Sc + widx[b] : c.H + (size_t)row * LW + col;
-                    hv[b] = *src; sr[b] = sp[row]; sc[b] = sp[col]; dg[b] = dgp[row];
+                    hv[b] = row < P ? c.H[(size_t)row * LW + col] : 0.0; uv[b] = msk[b] ? c.Sc[widx[b]] : 0.0;   // rows >= P are padding
+                    sr[b] = sp[row]; sc[b] = sp[col]; dg[b] = dgp[row];
                 }
 #pragma unroll
                 for (int b = 0; b < 4; b++) {
                     if (tile0 + b * tstep >= ntile) break;
-                    double v = hv[b];
-                    if (!msk[b]) {
-                        v = sr[b] * sc[b] * v;
-                        if (dia[b]) { v += mu * dg[b] * dg[b]; if (sr[b] == 0.0) v = 1.0; }
-                    }
+                    // S = Sp (H - U) Sp + mu D^2 (U = 0 outside the tiles the landmark rows touch); unit diagonal for constant parameters
+                    double v = sr[b] * sc[b] * (hv[b] - uv[b]);
+                    if (dia[b]) { v += mu * dg[b] * dg[b]; if (sr[b] == 0.0) v = 1.0; }
                     work[widx[b]] = v;
                 }
             }

@@ -536,8 +536,7 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
         for (int k = 0; k < slots; k++) {
             ps_eval_kernel<<<dim3(h->ps_eval_blocks, S), 256, h->lds_ps_eval, st>>>(Bg);
             ps_asm_a_kernel<<<dim3(h->ps_asm_a_blocks, S), 512, 0, st>>>(Bg);
-            ps_asm_b_kernel<<<dim3(24, S), 256, 0, st>>>(Bg);
-            ps_schur_kernel<<<dim3(h->ps_schur_tiles, S), 64, (size_t)(C.NL + 8) * sizeof(double), st>>>(Bg);
+            ps_asm_b_schur_kernel<<<dim3(24 + h->ps_schur_tiles, S), 256, (size_t)(C.NL + 8) * sizeof(double), st>>>(Bg);   // PS_ASM_B_BLOCKS = 24
             ps_serial_kernel<<<S, h->serial_threads, h->lds_solve, st>>>(Bg);
         }
         ps_final_kernel<<<S, 256, 0, st>>>(Bg);
