@@ -360,8 +360,7 @@ __global__ __launch_bounds__(512) void ps_asm_a_kernel(Batch B) {
 // zero-fill pass) and per entry of g: prior block, the (at most two) IMU Gram blocks that contain both columns, then the
 // frame-pair sums -- the same terms in the same order as assemble().  The thread that owns a diagonal entry fixes the Jacobi
 // column scaling the first time round.
-#define PS_ASM_B_BLOCKS 24
-__device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s) {
+__device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int nb_b) {
     const SolveSt &st = B.sst[s];
     if (st.stage != PS_ASM) return;
     Ctx c = make_ctx(B, s);
@@ -393,7 +392,7 @@ __device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s) {
         if (a == oT) return 6 * W + 15;
         return -1;
     };
-    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < total; w += PS_ASM_B_BLOCKS * blockDim.x) {
+    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < total; w += nb_b * blockDim.x) {
         const int a = w / (LW + 1), bcol = w - a * (LW + 1);
         const bool grad = bcol == LW;
         const int b = grad ? -1 : bcol;
@@ -521,13 +520,13 @@ __device__ __forceinline__ void ps_schur_body(const Batch &B, int s, int tile_in
     for (int r = 0; r < 4; r++) c.Sc[tl_idx(ti, tj, lk + 4 * r, li)] = acc[r];
 }
 
-// one launch: blocks [0, PS_ASM_B_BLOCKS) sum the entries of H and the gradient, the blocks behind them form the landmark part of the
+// one launch: blocks [0, nb_b) sum the entries of H and the gradient, the blocks behind them form the landmark part of the
 // Schur complement tile by tile
-__global__ __launch_bounds__(256) void ps_asm_b_schur_kernel(Batch B) {
+__global__ __launch_bounds__(256) void ps_asm_b_schur_kernel(Batch B, int nb_b) {
     const int s = blockIdx.y + B.s0;
     extern __shared__ double ps_wk_s[];
-    if (blockIdx.x < PS_ASM_B_BLOCKS) ps_asm_b_body(B, s);
-    else ps_schur_body(B, s, (int)blockIdx.x - PS_ASM_B_BLOCKS, ps_wk_s);
+    if ((int)blockIdx.x < nb_b) ps_asm_b_body(B, s, nb_b);
+    else ps_schur_body(B, s, (int)blockIdx.x - nb_b, ps_wk_s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- SERIAL

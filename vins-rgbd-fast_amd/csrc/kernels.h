@@ -39,7 +39,7 @@ __global__ void be_marg_kernel(Batch B);
 __global__ void ps_setup_kernel(Batch B);
 __global__ void ps_eval_kernel(Batch B);
 __global__ void ps_asm_a_kernel(Batch B);
-__global__ void ps_asm_b_schur_kernel(Batch B);
+__global__ void ps_asm_b_schur_kernel(Batch B, int nb_b);
 __global__ void ps_serial_kernel(Batch B);
 __global__ void ps_final_kernel(Batch B);
 __global__ void be_prior_factor_kernel(Batch B, int seq);

@@ -54,6 +54,7 @@ struct vio_batch {
     };
     std::vector<Group> groups;
     int tracker_lag = 0;              // vio_set_tracker_lag
+    int ps_asm_b_blocks = 24;         // workgroups per sequence that sum the entries of H (VIO_ASM_B_BLOCKS)
     int serial_threads = 1024;        // ps_serial_kernel block size (VIO_SERIAL_THREADS: 512 or 1024; measured +2 % with 1024)
     hipStream_t stream = nullptr;     // = groups[0].stream (returned by vio_get_stream; IMU scatter runs here)
     hipStream_t fe_stream = nullptr;  // = groups[0].fe_stream
@@ -536,7 +537,7 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
         for (int k = 0; k < slots; k++) {
             ps_eval_kernel<<<dim3(h->ps_eval_blocks, S), 256, h->lds_ps_eval, st>>>(Bg);
             ps_asm_a_kernel<<<dim3(h->ps_asm_a_blocks, S), 512, 0, st>>>(Bg);
-            ps_asm_b_schur_kernel<<<dim3(24 + h->ps_schur_tiles, S), 256, (size_t)(C.NL + 8) * sizeof(double), st>>>(Bg);   // PS_ASM_B_BLOCKS = 24
+            ps_asm_b_schur_kernel<<<dim3(h->ps_asm_b_blocks + h->ps_schur_tiles, S), 256, (size_t)(C.NL + 8) * sizeof(double), st>>>(Bg, h->ps_asm_b_blocks);
             ps_serial_kernel<<<S, h->serial_threads, h->lds_solve, st>>>(Bg);
         }
         ps_final_kernel<<<S, 256, 0, st>>>(Bg);
@@ -741,6 +742,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     B.hist_cap = 2048;
     B.s0 = 0;
     if (getenv("VIO_BE_THREADS")) h->be_threads = std::min(1024, std::max(64, atoi(getenv("VIO_BE_THREADS")) & ~63));
+    if (getenv("VIO_ASM_B_BLOCKS")) h->ps_asm_b_blocks = std::max(1, std::min(256, atoi(getenv("VIO_ASM_B_BLOCKS"))));
     if (getenv("VIO_SERIAL_THREADS")) h->serial_threads = atoi(getenv("VIO_SERIAL_THREADS")) >= 1024 ? 1024 : 512;
     if (getenv("VIO_MARG_THREADS")) h->marg_threads = std::min(512, std::max(64, atoi(getenv("VIO_MARG_THREADS")) & ~63));
     B.flags = getenv("VIO_FLAGS") ? atoi(getenv("VIO_FLAGS")) : 0;
