@@ -164,3 +164,30 @@ def test_status_all_equals_per_sequence_status(P):
         one = b.status(i)
         for name, _ in one._fields_:
             assert getattr(one, name) == getattr(allst[i], name), (i, name)
+
+
+def test_page_locked_host_buffers_and_free_running_uploads(P):
+    """vio_feed with host images uploads on a copy stream beside the previous frame's kernels.  From page-locked buffers
+    (vio_host_alloc) the uploads are truly asynchronous: a buffer may be rewritten once the NEXT feed has returned, which is what this
+    test does with two alternating buffer sets and no synchronisation in between; the result must equal the synchronised numpy run."""
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    seqs, n = [80, 81], 22
+    ref = _drive(P, cfg, sc, seqs, n)
+    syn = P.Synth(sc)
+    S = len(seqs)
+    b = P.VioBatch(cfg, S)
+    nimu = int(n / sc.cam_rate * sc.imu_rate) + 64
+    imu = [syn.imu(s, nimu) for s in seqs]
+    b.push_imu_batch(np.stack([x[0] for x in imu]), np.stack([x[1] for x in imu]), np.stack([x[2] for x in imu]))
+    pg = [P.PinnedArray((S, cfg.height, cfg.width), np.uint8) for _ in range(2)]
+    pd = [P.PinnedArray((S, cfg.height, cfg.width), np.uint16) for _ in range(2)]
+    for f, tf in enumerate(vio_ct.frame_times(sc, n)):
+        g, d = pg[f & 1].a, pd[f & 1].a          # written two feeds ago: that feed's successor has returned
+        for i, s in enumerate(seqs):
+            g[i], d[i] = syn.render_host(s, float(tf))
+        b.feed(g, d, [tf] * S)
+    for i in range(S):
+        assert np.array_equal(b.window(i), ref.window(i)), i
+    for x in pg + pd:
+        x.free()
