@@ -441,8 +441,10 @@ def test_imu_from_a_second_thread_and_batched_push(P):
         assert np.array_equal(ref.window(i), b.window(i)), i
 
 
-def test_streaming_imu_reboot_is_deterministic(P):
-    """failureDetection -> clearState while IMU keeps arriving between frames: the reboot is decided inside be_solve,
+@pytest.mark.parametrize("lag", [0, 1])
+def test_streaming_imu_reboot_is_deterministic(P, lag):
+    """(lag 1: the tracker of the next frame and the IMU scatter overlap the solve that reboots; clearState must still drop exactly the
+    samples that were buffered when the rebooting frame was ingested.)  failureDetection -> clearState while IMU keeps arriving between frames: the reboot is decided inside be_solve,
     before the next frame's front-end and IMU scatter may run, so repeated runs are bit-identical, the samples pushed after the
     reboot are all kept, and the re-initialised trajectory matches the oracle.  Recipe as in test_gpu_edge: blank frames starve the
     tracker while the accelerometer reports an 80 m/s^2 offset."""
@@ -460,6 +462,7 @@ def test_streaming_imu_reboot_is_deterministic(P):
 
     def run_hip():
         b = P.VioBatch(cfg, 1)
+        b.set_tracker_lag(lag)
         k, codes, fcs = 0, [], []
         for f, tf in enumerate(vio_ct.frame_times(sc, n)):
             k2 = vio_ct.imu_until(ti, k, tf, sc.imu_rate)
@@ -472,6 +475,7 @@ def test_streaming_imu_reboot_is_deterministic(P):
                 codes.append(st.code); fcs.append(st.frame_count)
         return b, codes, fcs
     o = vio_ct.OraclePipeline(cfg)
+    o.set_tracker_lag(lag)
     k = 0
     for f, tf in enumerate(vio_ct.frame_times(sc, n)):
         k2 = vio_ct.imu_until(ti, k, tf, sc.imu_rate)
