@@ -2051,26 +2051,30 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
         // per landmark: evaluate residuals with loss correction, store J (2x20) r (2) per residual into c.res (cap checked)
         const int per = W;  // max residuals per landmark
         int F0c = min(F0, c.nres_cap / per);
+        // frame-pair form like the solver (be_factors.h eval_projection_pair): the geometry of the pairs (0, k) once, in LDS
+        __shared__ double mgeo[(VIO_MAXW + 1) * 32 + 16];
+        if (t >= 1 && t <= W) {
+            bf::PairGeo g;
+            bf::pair_geo(&X.pose[0], &X.pose[t * 7], X.ex, g);
+            double *o = mgeo + (size_t)(t - 1) * 32;
+            for (int q = 0; q < 9; q++) { o[q] = g.A1[q]; o[9 + q] = g.A2[q]; o[18 + q] = g.M[q]; }
+            o[27] = g.t[0]; o[28] = g.t[1]; o[29] = g.t[2];
+        }
+        if (t == 0) stm(mgeo + (size_t)W * 32, q2R(mkq(X.ex[6], X.ex[3], X.ex[4], X.ex[5])));
+        __syncthreads();
         for (int w = t; w < F0c * per; w += nt) {
             int li = w / per, k = w - li * per + 1;
             int slot = list0[li];
             double *out = c.res + (size_t)w * 42;
             if (k >= c.lm_nobs[slot]) { out[40] = 0; out[41] = 0; for (int q = 0; q < 40; q++) out[q] = 0; continue; }
-            double rr[2], J[40];
-            double inv_dep = 1.0 / c.lm_depth[slot];
-            bf::eval_projection(cfg, &X.pose[0], &X.pose[k * 7], X.ex, inv_dep, X.td, obs_ptr(c, slot, 0), obs_ptr(c, slot, k), cfg.estimate_td != 0, rr, J);
-            double sq_norm = rr[0] * rr[0] + rr[1] * rr[1];
-            double rho1 = 1.0 / (1.0 + sq_norm), rho2 = -rho1 * rho1;
-            double sqrt_rho1 = sqrt(rho1), residual_scaling, alpha_sq_norm;
-            if (sq_norm == 0.0 || rho2 <= 0.0) { residual_scaling = sqrt_rho1; alpha_sq_norm = 0.0; }
-            else { double D = 1.0 + 2.0 * sq_norm * rho2 / rho1; double al = 1.0 - sqrt(D); residual_scaling = sqrt_rho1 / (1 - al); alpha_sq_norm = al / sq_norm; }
-            for (int col = 0; col < 20; col++) {
-                double rtJ = rr[0] * J[col] + rr[1] * J[20 + col];
-                out[col] = sqrt_rho1 * (J[col] - alpha_sq_norm * rr[0] * rtJ);
-                out[20 + col] = sqrt_rho1 * (J[20 + col] - alpha_sq_norm * rr[1] * rtJ);
-            }
-            out[40] = rr[0] * residual_scaling;
-            out[41] = rr[1] * residual_scaling;
+            // CauchyLoss(1.0): rho'' < 0, so Ceres' corrector reduces to the scaling sqrt(rho') of residual and Jacobian (corrector.cc)
+            double rr[2], wgt = 1.0;
+            const double inv_dep = 1.0 / c.lm_depth[slot];
+            const bf::PairGeo &g = *(const bf::PairGeo *)(mgeo + (size_t)(k - 1) * 32);
+            bf::eval_projection_pair(cfg, g, mgeo + (size_t)W * 32, X.ex, inv_dep, X.td, obs_ptr(c, slot, 0), obs_ptr(c, slot, k), cfg.estimate_td != 0, rr, out,
+                                     true, &wgt);
+            out[40] = wgt * rr[0];
+            out[41] = wgt * rr[1];
         }
         __syncthreads();
         PH(18);
@@ -2246,21 +2250,38 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
     // ---- eliminate the m-block (md x md) with a truncated eigen-decomposition
     for (int w = t; w < md * md; w += nt) { int i = w / md, j = w - i * md; A15[w] = 0.5 * (A[i * mq + j] + A[j * mq + i]); }
     __syncthreads();
-    if (t < 64) jacobi_wave16(A15, V15, md, md, cs, sn, pp, qq);   // md <= 15: one wavefront, no workgroup barriers inside
-    __syncthreads();
-    for (int w = t; w < md * md; w += nt) {
-        int i = w / md, j = w - i * md;
-        double sacc = 0;
-        for (int k = 0; k < md; k++) { double ev = A15[k * md + k]; if (ev > eps) sacc += V15[i * md + k] * V15[j * md + k] / ev; }
-        Pinv[w] = sacc;
+    // Pseudo-inverse with the eigenvalues <= 1e-8 dropped.  Fast path: when a Cholesky factorisation proves every eigenvalue above 1e-6
+    // (lambda_min >= 1 / |A^-1|_F) nothing is dropped and the pseudo-inverse is the inverse, a few microseconds of one wavefront instead
+    // of ~100 Jacobi rounds; otherwise the eigen-decomposition decides.
+    __shared__ int pinv_direct;
+    __shared__ double L15[225];
+    if (t < 64) {
+        const bool okc = spd_inverse_wave16(A15, md, 1e-6, L15, V15, Pinv);
+        if (t == 0) pinv_direct = okc ? 1 : 0;
     }
     __syncthreads();
-    double *T1 = c.margW;             // n x md : A_rm * Amm_inv
+    if (!pinv_direct) {
+        if (t < 64) jacobi_wave16(A15, V15, md, md, cs, sn, pp, qq);   // md <= 15: one wavefront, no workgroup barriers inside
+        __syncthreads();
+        for (int w = t; w < md * md; w += nt) {
+            int i = w / md, j = w - i * md;
+            double sacc = 0;
+            for (int k = 0; k < md; k++) { double ev = A15[k * md + k]; if (ev > eps) sacc += V15[i * md + k] * V15[j * md + k] / ev; }
+            Pinv[w] = sacc;
+        }
+        __syncthreads();
+    }
+    if (s == 0 && t == 0 && pinv_direct) B.timings[26] += 1.0f;
+    // T1 = A_rm A_mm^+ (n x md) and the block A_mr (md x n) staged in LDS (the tile region, free until the constant term is formed): the
+    // n^2 entries of A_r = A_rr - T1 A_mr read each of them n times
+    double *T1 = (double *)smem_marg, *Amr = T1 + (size_t)n * md;
     for (int w = t; w < n * md; w += nt) {
         int i = w / md, j = w - i * md;
         double sacc = 0;
         for (int k = 0; k < md; k++) sacc += A[(md + i) * mq + k] * Pinv[k * md + j];
         T1[w] = sacc;
+        const int k2 = w / n, j2 = w - k2 * n;      // the same index range covers A_mr (md x n)
+        Amr[w] = A[k2 * mq + md + j2];
     }
     __syncthreads();
     double *Ar = c.margV;             // reuse as A_r first (n x n), eigenvectors go to margW+...
@@ -2268,7 +2289,7 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
     for (int w = t; w < n * n; w += nt) {
         int i = w / n, j = w - i * n;
         double tt = A[(md + i) * mq + md + j];
-        for (int k = 0; k < md; k++) tt -= T1[i * md + k] * A[k * mq + md + j];
+        for (int k = 0; k < md; k++) tt -= T1[i * md + k] * Amr[k * n + j];
         Ar[w] = tt;
     }
     for (int i = t; i < n; i += nt) {

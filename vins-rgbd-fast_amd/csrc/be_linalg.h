@@ -286,6 +286,54 @@ __device__ int jacobi_wave16(double *A, double *V, int n, int ld, double *cs, do
     return sweeps_done;
 }
 
+// Inverse of a symmetric positive definite n x n matrix (n <= 16, LDS) by one wavefront: A = L L^T, L^-1 column by column, A^-1 = L^-T L^-1.
+// Returns true only if the factorisation succeeded AND every eigenvalue of A is provably above `floor` (lambda_min >= 1 / |A^-1|_F):
+// the caller wants the pseudo-inverse that drops eigenvalues <= 1e-8 (marginalization_factor.cpp:281-291), which IS the inverse in that
+// case; otherwise it falls back to the eigen-decomposition.  L / Linv: n x n scratch in LDS, Ainv: result.
+__device__ bool spd_inverse_wave16(const double *A, int n, double floor, double *L, double *Linv, double *Ainv) {
+    const int lane = threadIdx.x & 63;
+    for (int q = lane; q < n * n; q += 64) L[q] = A[q];
+    JW_SYNC();
+    bool ok = true;
+    for (int j = 0; j < n; j++) {
+        const double d = L[j * n + j];
+        if (!(d > 0.0) || !isfinite(d)) { ok = false; break; }   // wave-uniform
+        const double l = sqrt(d);
+        JW_SYNC();
+        if (lane > j && lane < n) L[lane * n + j] = L[lane * n + j] / l;
+        if (lane == j) L[j * n + j] = l;
+        JW_SYNC();
+        for (int q = lane; q < n * n; q += 64) {
+            const int i = q / n, k = q - i * n;
+            if (k > j && i >= k) L[q] -= L[i * n + j] * L[k * n + j];
+        }
+        JW_SYNC();
+    }
+    if (!ok) return false;
+    if (lane < n) {   // column `lane` of L^-1
+        const int c0 = lane;
+        double x[16];
+        for (int i = 0; i < n; i++) {
+            double sacc = (i == c0) ? 1.0 : 0.0;
+            for (int k = c0; k < i; k++) sacc -= L[i * n + k] * x[k];
+            x[i] = i < c0 ? 0.0 : sacc / L[i * n + i];
+            Linv[i * n + c0] = x[i];
+        }
+    }
+    JW_SYNC();
+    double fro = 0;
+    for (int q = lane; q < n * n; q += 64) {
+        const int i = q / n, j = q - i * n;
+        double sacc = 0;
+        for (int k = (i > j ? i : j); k < n; k++) sacc += Linv[k * n + i] * Linv[k * n + j];
+        Ainv[q] = sacc;
+        fro += sacc * sacc;
+    }
+    fro = wave_sum_dpp(fro);
+    JW_SYNC();
+    return isfinite(fro) && fro > 0.0 && 1.0 / sqrt(fro) > floor;
+}
+
 // Symmetric eigen-decomposition (Householder tridiagonalisation + implicit-shift QL, the algorithm class of
 // Eigen::SelfAdjointEigenSolver used at marginalization_factor.cpp:277,298).  V (n x n, ld) holds A on entry (lower
 // triangle is read) and the eigenvectors (columns) on exit; d = eigenvalues (unsorted), e / gtmp = workspaces; all in LDS.

@@ -826,7 +826,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
         }
         {
             size_t nbq = ((size_t)C.NPRIOR + 15) >> 4;
-            h->lds_marg = nbq * (nbq + 1) / 2 * 2048 + 64;  // lower 16x16 tiles of the new prior (Cholesky for its constant term)
+            h->lds_marg = std::max((size_t)nbq * (nbq + 1) / 2 * 2048, (size_t)2 * C.NPRIOR * 15 * 8) + 64;  // lower 16x16 tiles of the new prior (Cholesky for its constant term); before that T1 and A_mr
             h->lds_factor = C.NPRIOR <= 96 ? (size_t)C.NPRIOR * (C.NPRIOR | 1) * 8 + 64 : 64;  // on-demand eigen-decomposition (vio_get_prior)
             (void)raise_lds_limit((const void *)be_prior_factor_kernel, h->lds_factor);
         }
