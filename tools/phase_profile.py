@@ -23,7 +23,7 @@ NAMES = {0: "vector2double", 1: "lm indexing", 2: "pair lists", 4: "evaluate(fir
          59: "  chol panel (wave 0 view)", 60: "  chol diag + trailing (wave 0)", 61: "  chol barrier wait",
          62: "eval block 0 (prior)", 63: "eval block 1 (imu)", 14: "eval block 3 (256 projections)", 15: "eval accept",
          28: "finish slide states", 29: "finish slide landmarks", 30: "finish removeFailures + odom",
-         32: "asm zero", 33: "asm prior", 34: "asm imu blocks", 35: "asm pair blocks", 36: "asm element sums", 37: "asm lm rows",
+         32: "asm_a pair (0,1) item", 33: "asm_a pair (0,W) item", 34: "asm_a imu item 0", 35: "asm_a landmark rows item 0", 36: "asm element sums", 37: "asm lm rows",
          40: "ev prior dx", 46: "ev imu", 41: "ev pair geo", 44: "ev prior matvec + proj", 45: "ev reduce"}
 
 

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
 //   [0, W1^2)            frame-pair Gram block G_p = [J r]^T [J r] on the FP64 matrix cores -> c.pairblk (items with i >= j idle)
 //   [W1^2, W1^2 + W)     IMU factor Gram block (imu_block_mfma) -> ps_imu_blk
 //   the rest             landmark coupling rows, Hll, gl: 32 landmarks (two threads each) per wavefront
+#define PS_ROW_WAVES 32   // wavefronts of a sequence that build landmark rows (8 landmarks each per trip)
 __global__ __launch_bounds__(512) void ps_asm_a_kernel(Batch B) {
     const int s = blockIdx.y + B.s0, t = threadIdx.x;
     const SolveSt &st = B.sst[s];
@@ -261,44 +262,65 @@ __global__ __launch_bounds__(512) void ps_asm_a_kernel(Batch B) {
     const bool vext = st.vext != 0;
     const int nres = st.nres, Fa = st.Fa;
     __shared__ double imu_lds[8 * 704];
-    if (item < W1 * W1) {
-        const int p = item, i = p / W1, j = p - i * W1;
-        if (!(i < j)) return;
+    const long long tk0 = (s == 0 && lane == 0) ? (long long)wall_clock64() : 0;
+    auto tick = [&](int slot) { if (s == 0 && lane == 0) B.timings[slot] += (float)((long long)wall_clock64() - tk0); };
+    const int npairs = W1 * (W1 - 1) / 2;
+    if (item < npairs) {
+        // item = pair_slot(i, j): the frame pairs i < j in row-major order
+        int i = 0, rem = item;
+        while (rem >= W1 - 1 - i) { rem -= W1 - 1 - i; i++; }
+        const int j = i + 1 + rem, p = i * W1 + j;
         const int q0 = c.pair_start[p], np_ = c.pair_start[p + 1] - q0;
         double *out = c.pairblk + (size_t)pair_slot(i, j, W1) * 210;
         if (np_ == 0) { for (int e = lane; e < 210; e += 64) out[e] = 0; return; }
         v4f64 a00 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
-        for (int base = 0; base < np_; base += 64) {
-            const int nchunk = min(64, np_ - base);
-            const int myidx = c.pair_list[q0 + base + min(lane, nchunk - 1)];
-            const int Kc = 2 * nchunk;
-            for (int k0 = 0; k0 < Kc; k0 += 4 * PB_U) {
-                double x0[PB_U], x1[PB_U];
+        // Straight-line trips: the record layout (42 or 28 doubles) is decided OUTSIDE the loops and the MFMAs of a trip are not guarded
+        // (rows beyond the end are zero operands).  With either test inside, every gather of a trip sat in its own basic block behind an
+        // s_waitcnt vmcnt(0): the PB_U loads of a trip were serialised (8 us per trip instead of ~1).
+        if (vext) {
+            for (int base = 0; base < np_; base += 64) {
+                const int nchunk = min(64, np_ - base);
+                const int myidx = c.pair_list[q0 + base + min(lane, nchunk - 1)];
+                const int Kc = 2 * nchunk;
+                for (int k0 = 0; k0 < Kc; k0 += 4 * PB_U) {
+                    double x0[PB_U], x1[PB_U];
 #pragma unroll
-                for (int u = 0; u < PB_U; u++) {
-                    const int kk = k0 + 4 * u + lk;
-                    const bool valid = kk < Kc;
-                    const int ridx = __shfl(myidx, min(kk, Kc - 1) >> 1, 64);
-                    if (vext) {
+                    for (int u = 0; u < PB_U; u++) {
+                        const int kk = k0 + 4 * u + lk;
+                        const bool valid = kk < Kc;
+                        const int ridx = __shfl(myidx, min(kk, Kc - 1) >> 1, 64);
                         const double *Jr = c.res + (size_t)ridx * 42;
                         const int sub = kk & 1, ro = sub * 20;
                         const double v0 = Jr[ro + li], v1 = Jr[li < 3 ? ro + 16 + li : 40 + sub];
                         x0[u] = valid ? v0 : 0.0;
                         x1[u] = (valid && li < 4) ? v1 : 0.0;
-                    } else {
-                        const double *Jr = c.res + (size_t)ridx * 28 + (kk & 1) * 14;
-                        const double v0 = Jr[li < 12 ? li : 13];
-                        x0[u] = (valid && li < 13) ? v0 : 0.0;
-                        x1[u] = 0.0;
                     }
-                }
 #pragma unroll
-                for (int u = 0; u < PB_U; u++) {
-                    if (k0 + 4 * u >= Kc) break;
-                    a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u], x0[u], a00, 0, 0, 0);
-                    if (vext) {
+                    for (int u = 0; u < PB_U; u++) {
+                        a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u], x0[u], a00, 0, 0, 0);
                         a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x0[u], a10, 0, 0, 0);
                         a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x1[u], a11, 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            const int lcol = li < 12 ? li : 13;
+            for (int base = 0; base < np_; base += 64) {
+                const int nchunk = min(64, np_ - base);
+                const int myidx = c.pair_list[q0 + base + min(lane, nchunk - 1)];
+                const int Kc = 2 * nchunk;
+                for (int k0 = 0; k0 < Kc; k0 += 4 * PB_U) {
+                    double x0[PB_U];
+#pragma unroll
+                    for (int u = 0; u < PB_U; u++) {
+                        const int kk = k0 + 4 * u + lk;
+                        const int ridx = __shfl(myidx, min(kk, Kc - 1) >> 1, 64);
+                        const double v0 = c.res[(size_t)ridx * 28 + (kk & 1) * 14 + lcol];
+                        x0[u] = (kk < Kc && li < 13) ? v0 : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < PB_U; u++) {
+                        a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u], x0[u], a00, 0, 0, 0);
                     }
                 }
             }
@@ -314,10 +336,11 @@ __global__ __launch_bounds__(512) void ps_asm_a_kernel(Batch B) {
                 else if (row == 12 && col <= 12) out[sym_idx(col < 12 ? col : 19, 19)] = a00[r];
             }
         }
+        if (item == 0) tick(32); else if (item == W - 1) tick(33);
         return;
     }
-    if (item < W1 * W1 + W) {
-        const int i = item - W1 * W1;
+    if (item < npairs + W) {
+        const int i = item - npairs;
         const PreInt &pp = c.pre[be.pre_idx[i + 1]];
         double *G = ps_imu_blk(c) + (size_t)i * 768;
         if (!c.C->c.use_imu || pp.sum_dt > 10.0) { for (int e = lane; e < 768; e += 64) G[e] = 0; return; }
@@ -333,26 +356,97 @@ __global__ __launch_bounds__(512) void ps_asm_a_kernel(Batch B) {
             const int e = (lk + 4 * r) * 16 + li;
             G[e] = a00[r]; G[256 + e] = a10[r]; G[512 + e] = a11[r];
         }
+        if (i == 0) tick(34);
         return;
     }
-    // landmark rows: zero the part of the row the solver reads, then the coupling entries
-    const int w = (item - (W1 * W1 + W)) * 64 + lane;
+    // landmark rows: the part of the row the solver reads (zeros included), Hll and gl
     const int Kpad = (Fa + 3) & ~3;
     const int w0 = min(LW, (6 * W1 + 15) & ~15), e_lo = max(w0, (15 * W1) & ~15);
     const int *alist = c.pair_list + c.nres_cap - c.NL;
-    if (w < 2 * Kpad) {
+    if (!vext) {
+        // compact records: eight lanes per landmark, lane = frame (f = l8, l8 + 8, l8 + 16): every 6-column block of the row is written
+        // exactly once -- the coupling with frame f from the one residual that observes it, the start-frame block / Hll / gl from
+        // sums over the residuals that are reduced across the eight lanes, zeros elsewhere -- with one batch of loads per lane
+        const int rw = item - (npairs + W);                      // row wavefront 0 .. PS_ROW_WAVES - 1
+        if (rw >= PS_ROW_WAVES) return;
+        const int l8 = lane & 7;
+        for (int ka = rw * 8 + (lane >> 3); ka < Kpad; ka += PS_ROW_WAVES * 8) {   // (every lane group of a wavefront makes the same number of trips or one fewer: the shuffles below stay inside a group)
+        const bool live = true, real = ka < Fa;
+        int stf = 0, kend = 0;
+        const double *rec = c.res;
+        if (real) {
+            const int slot = alist[ka];
+            const int r0 = c.lm_tmp[slot];
+            stf = c.lm_start[slot];
+            kend = min(c.lm_nobs[slot], nres - r0 + 1);
+            rec = c.res + (size_t)r0 * 28;
+        }
+        double *row = c.Hpl + (size_t)(live ? ka : 0) * LW;
+        double si[6] = {0, 0, 0, 0, 0, 0}, hll = 0, gg = 0;
+        constexpr int NH = (VIO_MAXW + 1 + 7) / 8;
+        double blk[NH][6];
+        bool has[NH];
+#pragma unroll
+        for (int h = 0; h < NH; h++) {
+            const int f = l8 + 8 * h, k = f - stf;
+            has[h] = real && f < W1 && k >= 1 && k < kend;
+            const double2 *J2 = (const double2 *)(rec + (size_t)(has[h] ? k - 1 : 0) * 28);
+            double a[6], b[6], e[6], g6[6];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const double2 va = J2[q], vb = J2[3 + q], ve = J2[7 + q], vf = J2[10 + q];
+                a[2 * q] = va.x; a[2 * q + 1] = va.y; b[2 * q] = vb.x; b[2 * q + 1] = vb.y;
+                e[2 * q] = ve.x; e[2 * q + 1] = ve.y; g6[2 * q] = vf.x; g6[2 * q + 1] = vf.y;
+            }
+            const double2 p0 = J2[6], p1 = J2[13];   // (inv_depth column, weighted residual) of the two rows
+            const double l0 = has[h] ? p0.x : 0.0, l1 = has[h] ? p1.x : 0.0;
+#pragma unroll
+            for (int d = 0; d < 6; d++) {
+                si[d] += a[d] * l0 + e[d] * l1;
+                blk[h][d] = b[d] * l0 + g6[d] * l1;
+            }
+            hll += l0 * l0 + l1 * l1;
+            gg += l0 * (has[h] ? p0.y : 0.0) + l1 * (has[h] ? p1.y : 0.0);
+        }
+#pragma unroll
+        for (int off = 4; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int d = 0; d < 6; d++) si[d] += __shfl_xor(si[d], off, 8);
+            hll += __shfl_xor(hll, off, 8);
+            gg += __shfl_xor(gg, off, 8);
+        }
+        if (live) {
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                const int f = l8 + 8 * h;
+                if (f < W1) {
+                    const bool start = real && f == stf;
+#pragma unroll
+                    for (int d = 0; d < 6; d++) row[6 * f + d] = start ? si[d] : (has[h] ? blk[h][d] : 0.0);
+                }
+            }
+            for (int q = 6 * W1 + l8; q < w0; q += 8) row[q] = 0;
+            if (l8 == 0) { c.Hll[ka] = hll; c.gl[ka] = gg; }
+        }
+        }
+        if (rw == 0) tick(35);
+        return;
+    }
+    const int rwx = item - (npairs + W);
+    if (rwx >= PS_ROW_WAVES) return;
+    for (int w = rwx * 64 + lane; w < 2 * Kpad; w += PS_ROW_WAVES * 64) {
         const int ka = w >> 1, half = w & 1;
         double *row = c.Hpl + (size_t)ka * LW;
         if (half == 0) for (int q = 0; q < w0; q++) row[q] = 0;
-        else if (vext) for (int q = e_lo; q < LW; q++) row[q] = 0;
+        else for (int q = e_lo; q < LW; q++) row[q] = 0;
         if (ka < Fa) {
             const int slot = alist[ka];
             const int stf = c.lm_start[slot], r0 = c.lm_tmp[slot];
             const int kend = min(c.lm_nobs[slot], nres - r0 + 1);
-            if (vext) lm_row(c.res + (size_t)r0 * 42, row, c.Hll + ka, c.gl + ka, half, stf, kend, 15 * W1);
-            else lm_row_compact(c.res + (size_t)r0 * 28, row, c.Hll + ka, c.gl + ka, half, stf, kend);
+            lm_row(c.res + (size_t)r0 * 42, row, c.Hll + ka, c.gl + ka, half, stf, kend, 15 * W1);
         } else if (half == 1) { c.Hll[ka] = 0; c.gl[ka] = 0; }
     }
+    if (item == W1 * W1 + W) tick(35);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- ASM_B
@@ -513,7 +607,6 @@ __device__ __forceinline__ void ps_schur_body(const Batch &B, int s, int tile_in
         }
 #pragma unroll
         for (int u = 0; u < PS_SCH_U; u++) {
-            if (k0 + 4 * u >= Kpad) break;
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
         }
     }

@@ -815,7 +815,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
                 h->lds_ps_eval = std::max((W1 * W1 + 1) * 32 * 8, (size_t)C.W * (VIO_PREINT_HDR + 1) * 8) + 64;   // pair geometry / staged pre-integration headers
                 (void)raise_lds_limit((const void *)ps_eval_kernel, h->lds_ps_eval);
                 h->ps_eval_blocks = (int)std::min<size_t>(PS_MAX_EVAL_BLOCKS, (size_t)C.W * C.NP / 256 + 4);
-                h->ps_asm_a_blocks = (int)((W1 * W1 + C.W + (2 * ((size_t)C.NL + 3) + 63) / 64 + 7) / 8);
+                h->ps_asm_a_blocks = (int)((W1 * (W1 - 1) / 2 + C.W + 32 + 7) / 8);   // pair items (i < j), IMU items, PS_ROW_WAVES = 32 landmark-row wavefronts
                 int nact = 0;
                 for (size_t a = 0; a < nb; a++) for (size_t b2 = 0; b2 <= a; b2++) {
                     auto act = [&](size_t cb) { const size_t c0 = 16 * cb, c1 = c0 + 15; return c0 < 6 * W1 || (c1 >= 15 * W1 && c0 < 15 * W1 + 7); };
