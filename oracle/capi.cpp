@@ -183,6 +183,13 @@ void ovio_lk(const uint8_t *prev, const uint8_t *next, int w, int h, int maxLeve
     lk_track(P, N, pp, np, st, maxLevel, useInitial != 0);
     for (int i = 0; i < n; i++) { nextPts[2 * i] = np[i].x; nextPts[2 * i + 1] = np[i].y; status[i] = st[i]; }
 }
+// 7 correspondences (normalised coordinates) -> up to 3 fundamental matrices (row-major 9 each); returns their number
+int ovio_seven_point(const double *x1, const double *y1, const double *x2, const double *y2, double *F27) {
+    double F[3][9];
+    int n = seven_point_models(x1, y1, x2, y2, F);
+    for (int k = 0; k < n; k++) for (int i = 0; i < 9; i++) F27[9 * k + i] = F[k][i];
+    return n;
+}
 void ovio_ransac(const Config *c, int n, const float *p1, const float *p2, uint8_t *status) {
     std::vector<P2f> a(n), b(n);
     for (int i = 0; i < n; i++) { a[i] = P2f{p1[2 * i], p1[2 * i + 1]}; b[i] = P2f{p2[2 * i], p2[2 * i + 1]}; }

@@ -360,6 +360,8 @@ static int seven_point(const double *x1, const double *y1, const double *x2, con
         for (int i = 0; i < 9; i++) F[k][i] = f1[i] + roots[k] * f2[i];
     return nr;
 }
+// test hook (tests/test_oracle_numpy_cpu.py): the 7-point solver on its own
+int seven_point_models(const double *x1, const double *y1, const double *x2, const double *y2, double F[3][9]) { return seven_point(x1, y1, x2, y2, F); }
 static int ransac_update_iters(double p, double ep, int modelPoints, int maxIters) {
     p = std::fmax(p, 0.); p = std::fmin(p, 1.);
     ep = std::fmax(ep, 0.); ep = std::fmin(ep, 1.);

@@ -69,6 +69,7 @@ int fast_corner_score(const uint8_t *p, int stride, int thr);  // returns 0 if n
 void circle_halfwidths(int radius, std::vector<int> &hw);      // cv::circle(filled) raster shape
 void lk_track(const std::vector<Image> &prev, const std::vector<Image> &next, const std::vector<P2f> &prevPts,
               std::vector<P2f> &nextPts, std::vector<uint8_t> &status, int maxLevel, bool useInitialFlow);
+int seven_point_models(const double *x1, const double *y1, const double *x2, const double *y2, double F[3][9]);
 void ransac_fundamental(const Config &c, const std::vector<P2f> &p1, const std::vector<P2f> &p2,
                         std::vector<uint8_t> &status);
 

@@ -185,3 +185,48 @@ def test_fundamental_ransac_against_numpy_geometry(P, seed):
     Fe = _eight_point(a32[st > 0].astype(float), b32[st > 0].astype(float))
     Fe /= np.linalg.norm(Fe); Fn = Ft / np.linalg.norm(Ft)
     assert min(np.abs(Fe - Fn).max(), np.abs(Fe + Fn).max()) < 0.02
+
+
+@pytest.mark.parametrize("seed", [4, 5, 6, 7])
+def test_seven_point_against_numpy_nullspace_and_roots(seed):
+    """The minimal solver inside the RANSAC (cv::findFundamentalMat's run7Point, restated with Gauss-Jordan elimination and a
+    closed-form cubic in oracle/frontend.cpp) against the textbook formulation in numpy: null space of the 7 x 9 design matrix by SVD,
+    det(F1 + l F2) = 0 by numpy.roots.  Compared up to scale: every real root has to appear on both sides, and every model has to
+    satisfy the seven epipolar constraints and have rank 2."""
+    rng = np.random.default_rng(seed)
+    X = np.c_[rng.uniform(-1.5, 1.5, 7), rng.uniform(-1, 1, 7), rng.uniform(2.0, 6.0, 7)]
+    R = scipy.linalg.expm(_skew(rng.normal(0, 0.05, 3)))
+    t = rng.normal(0, 0.2, 3)
+    X2 = X @ R.T + t
+    x1, y1 = np.ascontiguousarray(X[:, 0] / X[:, 2]), np.ascontiguousarray(X[:, 1] / X[:, 2])
+    x2, y2 = np.ascontiguousarray(X2[:, 0] / X2[:, 2]), np.ascontiguousarray(X2[:, 1] / X2[:, 2])
+    Fo = np.zeros(27)
+    L = vio_ct.oracle()
+    L.ovio_seven_point.argtypes = [C.c_void_p] * 5
+    n = L.ovio_seven_point(x1.ctypes.data, y1.ctypes.data, x2.ctypes.data, y2.ctypes.data, Fo.ctypes.data)
+    assert 1 <= n <= 3
+    Fo = Fo[:9 * n].reshape(n, 3, 3)
+    # numpy: x2^T F x1 = 0 -> rows [x2 x1, x2 y1, x2, y2 x1, y2 y1, y2, x1, y1, 1]
+    A = np.c_[x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, np.ones(7)]
+    Vt = np.linalg.svd(A)[2]
+    F1, F2 = Vt[-1].reshape(3, 3), Vt[-2].reshape(3, 3)
+    # det(F1 + l F2) as a cubic in l through four evaluations
+    ls = np.array([-1.0, 0.0, 1.0, 2.0])
+    coef = np.polyfit(ls, [np.linalg.det(F1 + l * F2) for l in ls], 3)
+    roots = np.roots(coef)
+    real = [r.real for r in roots if abs(r.imag) < 1e-9 * max(1.0, abs(r.real))]
+    Fn = [F1 + l * F2 for l in real]
+    assert len(Fn) == n, (len(Fn), n)
+
+    def unit(F):
+        F = F / np.linalg.norm(F)
+        k = np.argmax(np.abs(F))
+        return F * np.sign(F.flat[k])
+    for F in Fo:
+        h1, h2 = np.c_[x1, y1, np.ones(7)], np.c_[x2, y2, np.ones(7)]
+        assert np.abs(((h2 @ F) * h1).sum(1)).max() < 1e-9 * np.abs(F).max()          # the seven constraints
+        assert abs(np.linalg.det(F / np.linalg.norm(F))) < 1e-10                         # rank 2
+        assert min(np.abs(unit(F) - unit(G)).max() for G in Fn) < 1e-6, (unit(F), [unit(G) for G in Fn])
+    # and the true fundamental matrix of the motion is one of them
+    Ft = _skew(t) @ R
+    assert min(np.abs(unit(F) - unit(Ft)).max() for F in Fo) < 1e-6
