@@ -240,6 +240,16 @@ int vio_stage_projection_residual(const vio_config *cfg, const double *pose_i, c
 /* cv::solvePnP(SOLVEPNP_ITERATIVE, useExtrinsicGuess) with K = I as FeatureManager::solvePoseByPnP calls it in VO mode
  * (feature_manager.cpp:545-588): obj[n][3], img[n][2] normalised points, rvec3 / tvec3 (Rodrigues vector, translation) in and out */
 int vio_stage_pnp(int n, const double *obj, const double *img, double *rvec3, double *tvec3);
+/* Host-only building blocks of the dynamic (static_init: 0) initialisation (csrc/dyninit_host.cpp), callable without a GPU:
+ * cv::solvePnP(ITERATIVE, useExtrinsicGuess) (R9 / t3 in: guess, out: result; returns 1 = converged), cv::solvePnPRansac(EPNP) as
+ * solveRelativeRT_PNP uses it (solve_5pts.cpp:248-294), and relativePose + GlobalSFM::construct over a window (estimator.cpp:884-920,
+ * initial_sfm.cpp:184-412: tracks as start[nf], nobs[nf], obs = (x, y, depth) per observation; out: reference frame l, q[(W+1)*4]
+ * (w x y z), T[(W+1)*3], pts[nf*4] = (solved, X, Y, Z), stats[2] = (BA iterations, points in the BA); returns 0 ok, 1 no frame pair
+ * with enough parallax, 2 SfM failed). */
+int vio_stage_host_pnp(int n, const double *obj, const double *img, double *R9, double *t3);
+int vio_stage_host_pnp_ransac(int n, const double *obj, const double *img, int max_iters, double thresh, double confidence, double *R9, double *t3);
+int vio_stage_host_sfm_window(int window_size, int nf, const int32_t *start, const int32_t *nobs, const double *obs, int32_t *l_out, double *q_out,
+                              double *T_out, double *pts_out, double *stats_out);
 /* IMUFactor::Evaluate as the solver consumes it: G961 = [J r]^T [J r] (31 x 31 row-major; columns pose_i(6) speedbias_i(9) pose_j(6)
  * speedbias_j(9) | residual) through the wavefront code of the solve kernel (split raw Jacobians, on-the-fly whitening, FP64 MFMA) */
 int vio_stage_imu_block(const vio_config *cfg, int n, const double *dt, const double *acc, const double *gyr, const double *acc0,

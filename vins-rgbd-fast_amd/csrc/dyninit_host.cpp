@@ -1123,4 +1123,65 @@ void run(const vio_config &cfg, int W, const double *headers, const double *bgs0
     out.ok = true;
 }
 
+// ---- host-only stage entry points (vio_stage_host_*): the building blocks above on caller-supplied arrays, for parity tests that
+// need no GPU
+bool stage_pnp_ransac_epnp(int n, const double *obj, const double *img, int max_iters, double thresh, double confidence, double *R9, double *t3) {
+    std::vector<v3> o(n);
+    std::vector<std::array<double, 2>> im(n);
+    for (int i = 0; i < n; i++) { o[i] = mk(obj[3 * i], obj[3 * i + 1], obj[3 * i + 2]); im[i] = {img[2 * i], img[2 * i + 1]}; }
+    m3 R = eye();
+    v3 t = mk(0, 0, 0);
+    const bool ok = pnp_ransac_epnp(o, im, max_iters, thresh, confidence, R, t);
+    stm(R9, R); st3(t3, t);
+    return ok;
+}
+int stage_sfm_window(int window_size, int nf, const int *start, const int *nobs, const double *obs, int *l_out, double *q_out, double *T_out,
+                     double *pts_out, double *stats_out) {
+    std::vector<Track> tracks(nf);
+    size_t off = 0;
+    for (int i = 0; i < nf; i++) {
+        tracks[i].id = i; tracks[i].start = start[i];
+        for (int k = 0; k < nobs[i]; k++, off++) tracks[i].obs.push_back({obs[3 * off], obs[3 * off + 1], obs[3 * off + 2]});
+    }
+    m3 rel_R;
+    v3 rel_T;
+    int l = -1;
+    if (!relative_pose(window_size, tracks, rel_R, rel_T, l)) return 1;
+    *l_out = l;
+    std::vector<quat> Q;
+    std::vector<v3> Ts;
+    Result res;
+    if (!global_sfm(window_size + 1, Q, Ts, l, rel_R, rel_T, tracks, res)) return 2;
+    for (int i = 0; i <= window_size; i++) {
+        q_out[4 * i] = Q[i].w; q_out[4 * i + 1] = Q[i].x; q_out[4 * i + 2] = Q[i].y; q_out[4 * i + 3] = Q[i].z;
+        st3(T_out + 3 * i, Ts[i]);
+    }
+    for (int i = 0; i < nf; i++) { pts_out[4 * i] = tracks[i].solved ? 1.0 : 0.0; st3(pts_out + 4 * i + 1, tracks[i].X); }
+    stats_out[0] = res.ba_iterations; stats_out[1] = res.sfm_points;
+    return 0;
+}
+
 }  // namespace vinit
+
+extern "C" {
+int vio_stage_host_pnp(int n, const double *obj, const double *img, double *R9, double *t3) {
+    if (n < 1 || !obj || !img || !R9 || !t3) return -1;
+    std::vector<dm::v3> o(n);
+    std::vector<std::array<double, 2>> im(n);
+    for (int i = 0; i < n; i++) { o[i] = dm::mk(obj[3 * i], obj[3 * i + 1], obj[3 * i + 2]); im[i] = {img[2 * i], img[2 * i + 1]}; }
+    dm::m3 R = dm::ldm(R9);
+    dm::v3 t = dm::ld3(t3);
+    const bool ok = vinit::solve_pnp_iterative(o, im, R, t);
+    dm::stm(R9, R); dm::st3(t3, t);
+    return ok ? 1 : 0;
+}
+int vio_stage_host_pnp_ransac(int n, const double *obj, const double *img, int max_iters, double thresh, double confidence, double *R9, double *t3) {
+    if (n < 1 || !obj || !img || !R9 || !t3) return -1;
+    return vinit::stage_pnp_ransac_epnp(n, obj, img, max_iters, thresh, confidence, R9, t3) ? 1 : 0;
+}
+int vio_stage_host_sfm_window(int window_size, int nf, const int32_t *start, const int32_t *nobs, const double *obs, int32_t *l_out, double *q_out,
+                              double *T_out, double *pts_out, double *stats_out) {
+    if (window_size < 2 || window_size > VIO_MAXW || nf < 1 || !start || !nobs || !obs || !l_out || !q_out || !T_out || !pts_out || !stats_out) return -1;
+    return vinit::stage_sfm_window(window_size, nf, start, nobs, obs, l_out, q_out, T_out, pts_out, stats_out);
+}
+}
