@@ -248,6 +248,10 @@ int vio_stage_pnp(int n, const double *obj, const double *img, double *rvec3, do
  * with enough parallax, 2 SfM failed). */
 int vio_stage_host_pnp(int n, const double *obj, const double *img, double *R9, double *t3);
 int vio_stage_host_pnp_ransac(int n, const double *obj, const double *img, int max_iters, double thresh, double confidence, double *R9, double *t3);
+/* LinearAlignmentWithDepth + RefineGravityWithDepth (initial_aligment.cpp:170-244, 337-405): frames19 = n x {R[9] row-major, T[3], sum_dt,
+ * delta_p[3], delta_v[3]}; g_out3 = gravity in the SfM frame, x_out[3 n + 3] = body velocities per frame + the last correction;
+ * returns 1 when |g| came out within 1 m/s^2 of g_norm before the refinement. */
+int vio_stage_host_alignment(int n, const double *frames19, const double *tic3, double g_norm, double *g_out3, double *x_out);
 int vio_stage_host_sfm_window(int window_size, int nf, const int32_t *start, const int32_t *nobs, const double *obs, int32_t *l_out, double *q_out,
                               double *T_out, double *pts_out, double *stats_out);
 /* IMUFactor::Evaluate as the solver consumes it: G961 = [J r]^T [J r] (31 x 31 row-major; columns pose_i(6) speedbias_i(9) pose_j(6)

@@ -24,6 +24,7 @@ def host(P):
     L.vio_stage_host_pnp.argtypes = [C.c_int] + [C.c_void_p] * 4
     L.vio_stage_host_pnp_ransac.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
     L.vio_stage_host_sfm_window.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 8
+    L.vio_stage_host_alignment.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
     return L
 
 
@@ -91,3 +92,20 @@ def test_sfm_window_failure_codes_match_the_oracle(host, sfm):
         rc = host.vio_stage_host_sfm_window(W, nf, start.ctypes.data, nobs.ctypes.data, obs.ctypes.data, C.byref(l), q.ctypes.data, T.ctypes.data,
                                             pts.ctypes.data, st.ctypes.data)
         assert rc == rc_o == 1
+
+
+@pytest.mark.parametrize("n,dt,noise", [(11, 0.1, 0.0), (25, 0.05, 0.0), (21, 0.1, 2e-3)])
+def test_visual_inertial_alignment_matches_the_oracle(host, orc, n, dt, noise):
+    """LinearAlignmentWithDepth + RefineGravityWithDepth: gravity and per-frame velocities, product host code vs oracle (own LDLT each)."""
+    tic = np.array([0.05, -0.02, 0.1])
+    R_cw = oi.rot([1, 2, -1], 0.9)
+    frames, truth = oi.make_frames(n, dt, tic, R_cw, np.array([0.4, -1.0, 2.0]), noise=noise, seed=3)
+    orc.ovio_linear_alignment_with_depth.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    go, xo = np.zeros(3), np.zeros(3 * n + 3)
+    gh, xh = np.zeros(3), np.zeros(3 * n + 3)
+    tic = np.ascontiguousarray(tic)
+    ok_o = orc.ovio_linear_alignment_with_depth(n, frames.ctypes.data, tic.ctypes.data, oi.G, go.ctypes.data, xo.ctypes.data)
+    ok_h = host.vio_stage_host_alignment(n, frames.ctypes.data, tic.ctypes.data, oi.G, gh.ctypes.data, xh.ctypes.data)
+    assert ok_o == ok_h == 1
+    assert np.abs(gh - go).max() < 1e-9 and np.abs(xh[:3 * n + 2] - xo[:3 * n + 2]).max() < 1e-8
+    assert abs(np.linalg.norm(gh) - oi.G) < 1e-12

@@ -1135,6 +1135,24 @@ bool stage_pnp_ransac_epnp(int n, const double *obj, const double *img, int max_
     stm(R9, R); st3(t3, t);
     return ok;
 }
+// visual-inertial alignment: frames = n x {R[9] row-major, T[3], sum_dt, delta_p[3], delta_v[3]} (19 doubles)
+bool stage_alignment(int n, const double *frames19, const double *tic3, double g_norm, double *g_out, double *x_out) {
+    std::vector<ImageFrame> f(n);
+    for (int i = 0; i < n; i++) {
+        const double *p = frames19 + 19 * i;
+        f[i].R = ldm(p);
+        f[i].T = ld3(p + 9);
+        f[i].sum_dt = p[12];
+        f[i].delta_p = ld3(p + 13);
+        f[i].delta_v = ld3(p + 16);
+    }
+    v3 g = mk(0, 0, 0);
+    std::vector<double> x;
+    const bool ok = linear_alignment(f, ld3(tic3), g_norm, g, x);
+    st3(g_out, g);
+    for (size_t i = 0; i < x.size() && i < (size_t)(3 * n + 3); i++) x_out[i] = x[i];
+    return ok;
+}
 int stage_sfm_window(int window_size, int nf, const int *start, const int *nobs, const double *obs, int *l_out, double *q_out, double *T_out,
                      double *pts_out, double *stats_out) {
     std::vector<Track> tracks(nf);
@@ -1178,6 +1196,10 @@ int vio_stage_host_pnp(int n, const double *obj, const double *img, double *R9, 
 int vio_stage_host_pnp_ransac(int n, const double *obj, const double *img, int max_iters, double thresh, double confidence, double *R9, double *t3) {
     if (n < 1 || !obj || !img || !R9 || !t3) return -1;
     return vinit::stage_pnp_ransac_epnp(n, obj, img, max_iters, thresh, confidence, R9, t3) ? 1 : 0;
+}
+int vio_stage_host_alignment(int n, const double *frames19, const double *tic3, double g_norm, double *g_out3, double *x_out) {
+    if (n < 2 || !frames19 || !tic3 || !g_out3 || !x_out) return -1;
+    return vinit::stage_alignment(n, frames19, tic3, g_norm, g_out3, x_out) ? 1 : 0;
 }
 int vio_stage_host_sfm_window(int window_size, int nf, const int32_t *start, const int32_t *nobs, const double *obs, int32_t *l_out, double *q_out,
                               double *T_out, double *pts_out, double *stats_out) {
