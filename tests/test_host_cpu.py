@@ -155,3 +155,17 @@ def test_two_rank_sharding_gloo(tmp_path):
         got = out[0 if s < 2 else 1]["res"][str(s)]
         assert got == ref
         assert ref[-1][0] > 20  # features are actually tracked
+
+
+def test_cpp_mirror_compiles_and_links(P, tmp_path):
+    """include/vio_adapter.hpp + examples/adapter_demo.cpp build with plain g++ -std=c++11 against the C ABI and link against the shared
+    library (nothing is executed here: running needs a GPU, tests/test_gpu_adapter.py)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pk = os.path.join(root, "vins-rgbd-fast_amd")
+    P.lib()   # builds libvio_hip.so if necessary
+    exe = str(tmp_path / "adapter_demo")
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "adapter_demo.cpp"),
+                        "-L" + pk, "-lvio_hip", "-Wl,-rpath," + pk, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.path.exists(exe)
