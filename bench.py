@@ -300,7 +300,7 @@ def main():
     # ---- validity + accuracy (outside the timed region)
     stats = b.status_all()
     fp1 = np.array([st.frames_processed for st in stats])
-    all_processed = bool(np.all(fp1 - fp0 == R * K + Kp + 2 * Ks) and np.all(nl == 1))
+    all_processed = bool(np.all(fp1 - fp0 == R * K + 2 * Kp + 2 * Ks) and np.all(nl == 1))   # timed steps + both PCIe legs + both streaming legs
     ates = []
     hist = {}
     for s in range(S):

@@ -46,6 +46,14 @@ typedef struct vio_config {
                                        (initialStructure, estimator.cpp:384-579) */
     int32_t use_imu;                /* USE_IMU (yaml key `imu`, parameters.cpp:148): 0 = visual odometry on RGB-D: no IMU factors, pose 0
                                        constant, initFramePoseByPnP per frame, LK maxLevel = lk_max_level (3 upstream) without prediction */
+    int32_t reference_quirks;       /* bit 0 (VIO_QUIRK_LATEST_FRONT): vio_get_latest_odometry replays the buffered IMU the way
+                                       Estimator::updateLatestStates does (estimator.cpp:1779-1786): every step uses the values of the queue's
+                                       FRONT sample (the reference's behaviour).  0 = every sample with its own values. */
+    int32_t marg_exact;             /* 1 = the marginalisation follows MarginalizationInfo::marginalize literally (marginalization_factor.cpp:
+                                       281-315): eigen-decomposition of the FULL m x m marginalised block (pose 0, speed-bias 0 and every
+                                       landmark that starts in frame 0) with the 1e-8 cut, then eigen-decomposition of the reduced system and the
+                                       prior rebuilt from the truncated factors J = S^1/2 V^T, r = S^-1/2 V^T b.  0 (default) = the fast form
+                                       (analytic landmark elimination, prior kept as a quadratic form; DESIGN.md deviations 10 / 13). */
     double fx, fy, cx, cy, k1, k2, p1, p2; /* pinhole projection_parameters / distortion_parameters */
     double focal_length;            /* FOCAL_LENGTH = 460 (parameters.h:11) */
     double f_threshold;             /* F_THRESHOLD */
@@ -57,6 +65,8 @@ typedef struct vio_config {
     double min_parallax_px;         /* keyframe_parallax */
     double init_depth;              /* INIT_DEPTH = 5 (parameters.cpp:215) */
 } vio_config;
+
+enum { VIO_QUIRK_LATEST_FRONT = 1 };
 
 typedef struct vio_batch vio_batch; /* opaque */
 

@@ -426,26 +426,30 @@ void Estimator::predictMotion(double t0, double t1, double R[9], const V3 *bg_ov
     out();
 }
 // Estimator::predict (estimator.cpp:1862-1880) from the newest window state through every buffered sample newer than it (the pose
-// pubLatestOdometry publishes at IMU rate; every sample with its own values, see the note at be_latest_odometry_kernel)
+// pubLatestOdometry publishes at IMU rate).  Default: every sample with its own values.  cfg.reference_quirks bit 0: literally what
+// updateLatestStates does (estimator.cpp:1779-1786) -- the loop pops a COPY of the queue for the stamps but passes predict() the values of
+// the real queue's front sample every time, and predict() (:1862-1880) never advances acc_0 / gyr_0.
 void Estimator::latestOdometry(double out[11]) const {
     double latest_time = Headers[frame_count] + td;
     V3 P = Ps[frame_count], V = Vs[frame_count], Ba = Bas[frame_count], Bg = Bgs[frame_count];
     M3 R = Rs[frame_count];
     V3 a0 = acc_0, g0 = gyr_0;
+    const bool front = (cfg.reference_quirks & 1) != 0;
     if (solver_flag == 1 && cfg.use_imu)
         for (size_t k = imu_head; k < imu_buf.size(); k++) {
             const double t = imu_buf[k].t;
             if (!(t > latest_time)) continue;
             const double dt = t - latest_time;
             latest_time = t;
+            const ImuSample &v = front ? imu_buf[imu_head] : imu_buf[k];
             V3 un_acc_0 = R * (a0 - Ba) - g;
-            V3 un_gyr = 0.5 * (g0 + imu_buf[k].gyr) - Bg;
+            V3 un_gyr = 0.5 * (g0 + v.gyr) - Bg;
             R = R * toR(deltaQ(un_gyr * dt));
-            V3 un_acc_1 = R * (imu_buf[k].acc - Ba) - g;
+            V3 un_acc_1 = R * (v.acc - Ba) - g;
             V3 un_acc = 0.5 * (un_acc_0 + un_acc_1);
             P = P + dt * V + (0.5 * dt * dt) * un_acc;
             V = V + dt * un_acc;
-            a0 = imu_buf[k].acc; g0 = imu_buf[k].gyr;
+            if (!front) { a0 = v.acc; g0 = v.gyr; }
         }
     Q q = fromR(R);
     out[0] = latest_time; out[1] = P.x; out[2] = P.y; out[3] = P.z; out[4] = q.w; out[5] = q.x; out[6] = q.y; out[7] = q.z;

@@ -32,6 +32,8 @@ struct Config {
                                        // path), 1 = SfM + visual-inertial alignment
     int use_imu = 1;                   // USE_IMU (parameters.cpp:148, yaml key `imu`): 0 = visual odometry on RGB-D (no IMU factors, pose of the
                                        // oldest frame constant, per-frame solvePnP initial guess, LK with maxLevel 3 and no prediction)
+    int reference_quirks = 0;          // bit 0: latestOdometry replays the buffered IMU with the FRONT sample's values (estimator.cpp:1779-1786)
+    int marg_exact = 0;                // product-side switch (the oracle always follows marginalization_factor.cpp:281-315); layout only
     double fx = 604.5821781259577, fy = 604.2544712985845, cx = 321.2638233484251, cy = 239.70969315130674;
     double k1 = 0.13387871564774004, k2 = -0.2731913133377051, p1 = 0.0020296263577681264, p2 = -0.00044384544608203714;
     double focal_length = 460.0;       // FOCAL_LENGTH

@@ -408,6 +408,61 @@ def test_latest_odometry_at_imu_rate(P):
     assert abs(d_est - d_gt) < 0.005, (d_est, d_gt)
 
 
+def test_latest_odometry_with_the_reference_replay_quirk(P):
+    """vio_config.reference_quirks bit 0: Estimator::updateLatestStates as written (estimator.cpp:1779-1786) -- the replay loop walks the
+    buffered stamps but passes predict() the values of the queue's FRONT sample every time, and predict() (:1862-1880) never advances
+    acc_0 / gyr_0.  HIP against the oracle with the switch on, and both against an independent numpy replay from the window state; the
+    result must differ from the default (every sample with its own values) -- the switch changes the output and nothing else."""
+    cfg_q = P.canonical_config(reference_quirks=1)
+    cfg_0 = P.canonical_config()
+    sc = vio_ct.synth_like(cfg_q)
+    seq, n = 14, 30
+    syn = P.Synth(sc)
+    ti, ai, gi = syn.imu(seq, int(n / sc.cam_rate * sc.imu_rate) + 64)
+    bq, b0, oq = P.VioBatch(cfg_q, 1), P.VioBatch(cfg_0, 1), vio_ct.OraclePipeline(cfg_q)
+    k = 0
+    for f, tf in enumerate(vio_ct.frame_times(sc, n)):
+        k2 = vio_ct.imu_until(ti, k, tf, sc.imu_rate)
+        for x in (bq, b0):
+            x.push_imu(0, ti[k:k2], ai[k:k2], gi[k:k2])
+        oq.push_imu(ti[k:k2], ai[k:k2], gi[k:k2]); k = k2
+        g, d = syn.render_host(seq, float(tf))
+        bq.feed(g[None], d[None], [tf]); b0.feed(g[None], d[None], [tf]); oq.feed(g, d, tf)
+    assert np.array_equal(bq.window(0), b0.window(0))        # nothing feeds back into the estimator
+    for x in (bq, b0):
+        x.push_imu(0, ti[k:k + 12], ai[k:k + 12], gi[k:k + 12])
+    oq.push_imu(ti[k:k + 12], ai[k:k + 12], gi[k:k + 12])
+    lq, l0, lo = bq.latest_odometry(0), b0.latest_odometry(0), oq.latest_odometry()
+    assert abs(lq[0] - lo[0]) < 1e-12 and np.abs(lq[1:] - lo[1:]).max() < 1e-5
+    assert abs(lq[0] - l0[0]) < 1e-12 and np.linalg.norm(lq[1:4] - l0[1:4]) > 1e-6
+    # independent replay: window state W, stamps of the samples newer than Headers[W] + td, values of the first of them
+    w = bq.window(0)[cfg_q.window_size]
+    t0 = w[16] + bq.status(0).td
+    newer = np.nonzero(ti[:k + 12] > t0)[0]
+    # the queue's front = the first sample processImage did not pop = the first one with t >= Headers[W] + td (getIMUInterval keeps it)
+    front = int(np.nonzero(ti[:k + 12] >= t0)[0][0])
+    qw = w[3:7]
+    def q2R(q):
+        a, b_, c, d_ = q
+        return np.array([[1 - 2 * (c * c + d_ * d_), 2 * (b_ * c - a * d_), 2 * (b_ * d_ + a * c)], [2 * (b_ * c + a * d_), 1 - 2 * (b_ * b_ + d_ * d_), 2 * (c * d_ - a * b_)],
+                         [2 * (b_ * d_ - a * c), 2 * (c * d_ + a * b_), 1 - 2 * (b_ * b_ + c * c)]])
+    R, Pp, V, Ba, Bg = q2R(qw), w[0:3].copy(), w[7:10].copy(), w[10:13], w[13:16]
+    gvec = np.array([0, 0, cfg_q.g_norm])
+    # acc_0 / gyr_0 as processIMU left them: the last sample consumed for the newest frame (the first with t >= t0)
+    a0, g0 = ai[front], gi[front]
+    lt = t0
+    for i in newer:
+        dt = ti[i] - lt; lt = ti[i]
+        un_acc_0 = R @ (a0 - Ba) - gvec
+        th = (0.5 * (g0 + gi[front]) - Bg) * dt
+        dq = np.array([1.0, th[0] / 2, th[1] / 2, th[2] / 2])     # Utility::deltaQ, not normalised (utility.h:11-24)
+        R = R @ q2R(dq)                                           # Eigen's toRotationMatrix formula, no normalisation (as both implementations)
+        un_acc = 0.5 * (un_acc_0 + R @ (ai[front] - Ba) - gvec)
+        Pp = Pp + dt * V + 0.5 * dt * dt * un_acc
+        V = V + dt * un_acc
+    assert abs(lq[0] - lt) < 1e-12 and np.abs(lq[1:4] - Pp).max() < 1e-6 and np.abs(lq[8:11] - V).max() < 1e-6, (lq[1:4] - Pp, lq[8:11] - V)
+
+
 def test_imu_from_a_second_thread_and_batched_push(P):
     """Estimator::inputIMU is called from the ROS callback thread while the image thread runs (estimator.cpp:1749-1766): vio_push_imu
     from a second thread concurrent with vio_feed, and vio_push_imu_batch, must reproduce the single-threaded per-sequence run."""

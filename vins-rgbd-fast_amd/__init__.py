@@ -31,7 +31,8 @@ class Config(C.Structure):
     """vio_config (include/vio_abi.h); same field order as oracle ovio::Config."""
     _fields_ = [(n, C.c_int32) for n in (
         "width", "height", "max_cnt", "min_dist", "grid_rows", "grid_cols", "window_size", "max_landmarks", "fix_depth",
-        "estimate_extrinsic", "estimate_td", "max_iterations", "ransac_max_iters", "lk_max_level", "dynamic_init", "use_imu")] + \
+        "estimate_extrinsic", "estimate_td", "max_iterations", "ransac_max_iters", "lk_max_level", "dynamic_init", "use_imu", "reference_quirks",
+        "marg_exact")] + \
         [(n, C.c_double) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "focal_length", "f_threshold", "depth_min",
                                    "depth_max", "acc_n", "acc_w", "gyr_n", "gyr_w", "g_norm")] + \
         [("ric", C.c_double * 9), ("tic", C.c_double * 3)] + \

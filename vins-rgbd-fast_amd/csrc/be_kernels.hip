@@ -33,7 +33,7 @@ struct Ctx {
     int *res_lm, *res_k, *pair_start, *pair_list;
     double *pairblk, *imu_raw;
     double *prior_J, *prior_r, *prior_x0, *prior_H, *prior_rf;
-    double *margA, *margB, *margV, *margW;
+    double *margA, *margB, *margV, *margW, *margE;
     int nres_cap;
 };
 
@@ -67,6 +67,7 @@ __device__ Ctx make_ctx(const Batch &B, int s) {
     int mq = 15 + n;
     c.margA = B.margA + (size_t)s * mq * mq; c.margB = B.margB + (size_t)s * mq;
     c.margV = B.margV + (size_t)s * n * n; c.margW = B.margW + (size_t)s * (n + 16) * (n + 16);
+    c.margE = C.MX > 0 ? B.margE + (size_t)s * ((size_t)3 * C.MX * C.MX + (size_t)n * C.MX) : nullptr;
     return c;
 }
 
@@ -1565,7 +1566,7 @@ __device__ __forceinline__ void solve_epilogue(Ctx &c, const Params &X, double c
 
 }  // namespace
 
-__device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem_marg);
+template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem_marg);
 __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw);
 
 // solve -> marginalise -> window slide for one sequence per workgroup (1024 threads); fusing the three stages makes the
@@ -1596,7 +1597,19 @@ __global__ __launch_bounds__(512) void be_marg_kernel(Batch B) {
     __shared__ double sred[64];
     __shared__ PreWork pw;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    marg_body(B, s, scratch, sred, smem);
+    marg_body<false>(B, s, scratch, sred, smem);
+    __syncthreads();
+    finish_body(B, s, scratch, pw);
+}
+// vio_config.marg_exact: the same stage with the marginalisation of marginalization_factor.cpp:281-315 followed literally (its own kernel so
+// that the hot kernel's registers / LDS are untouched by the parity instrument)
+__global__ __launch_bounds__(512) void be_marg_exact_kernel(Batch B) {
+    const int s = blockIdx.x + B.s0;
+    __shared__ int scratch[2 * 512 + 8];
+    __shared__ double sred[64];
+    __shared__ PreWork pw;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    marg_body<true>(B, s, scratch, sred, smem);
     __syncthreads();
     finish_body(B, s, scratch, pw);
 }
@@ -1916,7 +1929,105 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
 // Marginalisation in the canonical layout. Landmarks seen first in frame 0 are eliminated analytically (their block of
 // A_mm is diagonal), then pose_0/speedbias_0 (15) through a truncated eigen-decomposition, then the kept block is
 // re-factorised as J^T J by a second (parallel Jacobi) eigen-decomposition (marginalization_factor.cpp:276-308).
-__device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem_marg) {
+// marg_exact (vio_config): elimination of the marginalised block and the new prior exactly as MarginalizationInfo::marginalize does them
+// (marginalization_factor.cpp:270-315).  In: A (mq x mq over q = [md | n]) and b with NO landmark eliminated, the landmark coupling rows
+// Cl (F0 x ldc, columns indexed like q), d_l = c.Hll (J_l^T J_l), c.gl (J_l^T r).  Marginalised block: m = md + F0 = [pose 0, speed-bias 0
+// | inverse depths of the landmarks that start in frame 0] (md = 6 and F0 = 0 for MARGIN_SECOND_NEW).  Both eigen-decompositions are the
+// threshold Jacobi of jacobi_block (the oracle's om::sym_eig is the cyclic form of the same iteration) on matrices in HBM scratch.
+__device__ void marg_exact_finish(const Ctx &c, BeSeq &be, double *A, const double *b, int md, int mq, int n, const double *Cl, int ldc, int F0,
+                                  bool second_new, double *sred, unsigned char *smem) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    const double eps = 1e-8;
+    const int MX = c.C->MX, m = md + F0;
+    double *Emm = c.margE, *EV = Emm + (size_t)MX * MX, *Einv = EV + (size_t)MX * MX, *ET1 = Einv + (size_t)MX * MX;
+    double *cs = (double *)smem, *sn = cs + 256;
+    int *pp = (int *)(sn + 256), *qq = pp + 256;
+    __shared__ double ev2[EIG_LD], vb2[EIG_LD];
+    // Amm = 0.5 (Amm + Amm^T) (:276); the landmark-landmark block is diagonal (an inverse depth only meets itself)
+    for (int w = t; w < m * m; w += nt) {
+        const int i = w / m, j = w - i * m;
+        double v;
+        if (i < md && j < md) v = 0.5 * (A[i * mq + j] + A[j * mq + i]);
+        else if (i >= md && j >= md) v = i == j ? c.Hll[i - md] : 0.0;
+        else v = Cl[(size_t)((i >= md ? i : j) - md) * ldc + (i >= md ? j : i)];
+        Emm[w] = v;
+    }
+    __syncthreads();
+    const int sw1 = jacobi_block(Emm, EV, m, m, cs, sn, pp, qq, sred);
+    // Amm_inv = V diag(lambda > eps ? 1 / lambda : 0) V^T (:281-283)
+    for (int w = t; w < m * m; w += nt) {
+        const int i = w / m, j = w - i * m;
+        double sacc = 0;
+        for (int k = 0; k < m; k++) { const double ev = Emm[(size_t)k * m + k]; if (ev > eps) sacc += EV[(size_t)i * m + k] * EV[(size_t)j * m + k] / ev; }
+        Einv[w] = sacc;
+    }
+    __syncthreads();
+    // A_rm A_mm^-1 (:288-292); column k of A_rm: q-column k for the pose / speed-bias part, the coupling row of landmark k - md otherwise
+    for (int w = t; w < n * m; w += nt) {
+        const int i = w / m, j = w - i * m;
+        double sacc = 0;
+        for (int k = 0; k < md; k++) sacc += A[(md + i) * mq + k] * Einv[(size_t)k * m + j];
+        for (int k = md; k < m; k++) sacc += Cl[(size_t)(k - md) * ldc + md + i] * Einv[(size_t)k * m + j];
+        ET1[w] = sacc;
+    }
+    __syncthreads();
+    double *Ar = c.margV, *br = c.vec;
+    for (int w = t; w < n * n; w += nt) {   // A = Arr - Arm Amm_inv Amr
+        const int i = w / n, j = w - i * n;
+        double tt = A[(md + i) * mq + md + j];
+        for (int k = 0; k < md; k++) tt -= ET1[(size_t)i * m + k] * A[k * mq + md + j];
+        for (int k = md; k < m; k++) tt -= ET1[(size_t)i * m + k] * Cl[(size_t)(k - md) * ldc + md + j];
+        Ar[w] = tt;
+    }
+    for (int i = t; i < n; i += nt) {       // b = brr - Arm Amm_inv bmm
+        double sacc = b[md + i];
+        for (int k = 0; k < md; k++) sacc -= ET1[(size_t)i * m + k] * b[k];
+        for (int k = md; k < m; k++) sacc -= ET1[(size_t)i * m + k] * c.gl[k - md];
+        br[i] = sacc;
+    }
+    __syncthreads();
+    // second eigen-decomposition (:298-311): S = eigenvalues > eps, linearized_jacobians = S^1/2 V^T, linearized_residuals = S^-1/2 V^T b
+    double *As = c.margW, *V2 = A;   // (A is free from here on)
+    for (int w = t; w < n * n; w += nt) { const int i = w / n, j = w - i * n; As[w] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
+    __syncthreads();
+    const int sw2 = jacobi_block(As, V2, n, n, cs, sn, pp, qq, sred);
+    for (int k = t; k < n; k += nt) {
+        ev2[k] = As[k * n + k];
+        double vb = 0;
+        for (int i = 0; i < n; i++) vb += V2[i * n + k] * br[i];
+        vb2[k] = vb;
+    }
+    __syncthreads();
+    for (int w = t; w < n * n; w += nt) {
+        const int k = w / n, i = w - k * n;
+        const double S = ev2[k] > eps ? ev2[k] : 0.0;
+        c.prior_J[w] = sqrt(S) * V2[i * n + k];
+    }
+    for (int k = t; k < n; k += nt) {
+        const double Sinv = ev2[k] > eps ? 1.0 / ev2[k] : 0.0;
+        c.prior_rf[k] = sqrt(Sinv) * vb2[k];
+    }
+    __syncthreads();
+    // what MarginalizationFactor::Evaluate, the solver and the next marginalisation consume of (J, r): J^T J, J^T r and |r|^2
+    for (int w = t; w < n * n; w += nt) {
+        const int a = w / n, bb = w - a * n;
+        double sacc = 0;
+        for (int k = 0; k < n; k++) sacc += c.prior_J[k * n + a] * c.prior_J[k * n + bb];
+        c.prior_H[w] = sacc;
+    }
+    for (int a = t; a < n; a += nt) {
+        double sacc = 0;
+        for (int k = 0; k < n; k++) sacc += c.prior_J[k * n + a] * c.prior_rf[k];
+        c.prior_r[a] = sacc;
+    }
+    double acc = 0;
+    for (int k = t; k < n; k += nt) acc += c.prior_rf[k] * c.prior_rf[k];
+    const double c0 = block_sum(acc, sred);
+    __syncthreads();
+    if (t == 0) { be.prior_c0 = c0; be.dbg[0] = sw1 * 100 + sw2; be.dbg[2] = second_new ? 1 : 0; be.dbg[4] = m; }
+}
+
+template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem_marg) {
     const int t = threadIdx.x, nt = blockDim.x;
     Ctx c = make_ctx(B, s);
     const DevCfg &C = *B.cfg;
@@ -1933,6 +2044,11 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
     __shared__ int newpresent[VIO_MAXW + 3];
     const bool second_new = be.marginalization_flag != 0;
     if (second_new && !(be.has_prior && be.prior_present[W - 1])) return;
+    // marg_exact: MarginalizationInfo::marginalize followed literally (marginalization_factor.cpp:281-315) -- the full m x m block of
+    // pose 0, speed-bias 0 AND the landmarks that start in frame 0 goes through one truncated eigen-decomposition, and the new prior is
+    // rebuilt from the truncated factors of the reduced system.  A parity instrument (one workgroup, Jacobi sweeps in HBM), not the hot path.
+    const bool exact = EXACT && cfg.marg_exact != 0 && c.margE != nullptr;
+    int F0x = 0;   // landmarks in the marginalised block (exact mode)
     PH_INIT;
     const long long tk0 = wall_clock64();
     // vector2double
@@ -2051,6 +2167,7 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
         // per landmark: evaluate residuals with loss correction, store J (2x20) r (2) per residual into c.res (cap checked)
         const int per = W;  // max residuals per landmark
         int F0c = min(F0, c.nres_cap / per);
+        if (exact) { F0c = min(F0c, min(C.MX - 15, 480)); F0x = F0c; }
         // frame-pair form like the solver (be_factors.h eval_projection_pair): the geometry of the pairs (0, k) once, in LDS
         __shared__ double mgeo[(VIO_MAXW + 1) * 32 + 16];
         if (t >= 1 && t <= W) {
@@ -2165,7 +2282,7 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
                 }
             }
         }
-        for (int li = t; li < F0c; li += nt) { double d = c.Hll[li]; c.Hll[li] = d > eps ? 1.0 / d : 0.0; }  // pseudo-inverse of the diagonal block
+        if (!exact) for (int li = t; li < F0c; li += nt) { double d = c.Hll[li]; c.Hll[li] = d > eps ? 1.0 / d : 0.0; }  // pseudo-inverse of the diagonal block
         __syncthreads();
         PH(24);
         // A_qq += sum_j G_j (scattered) - C^T D^+ C ; b_q likewise.  Per q-column (and the right-hand side, index mq): the frame whose
@@ -2185,7 +2302,7 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
         for (int w = t; w < 4 * mq; w += nt) {
             const int ch = w / mq, a = w - ch * mq;
             double acc = 0;
-            for (int li = ch; li < F0c; li += 4) acc += Cl[(size_t)li * ldc + a] * (c.gl[li] * c.Hll[li]);
+            if (!exact) for (int li = ch; li < F0c; li += 4) acc += Cl[(size_t)li * ldc + a] * (c.gl[li] * c.Hll[li]);
             sub_part[ch][a] = acc;
         }
         __syncthreads();
@@ -2206,7 +2323,7 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
         __syncthreads();
         PH(25);
         // A_qq -= C^T D^+ C : rank-F0c update on the FP64 matrix cores, lower 16x16 tiles mirrored into the upper triangle
-        {
+        if (!exact) {
             const int lane = t & 63, wave = t >> 6, nw = nt >> 6, li = lane & 15, lk = lane >> 4;
             const int nbq = (mq + 15) >> 4, ntile = nbq * (nbq + 1) / 2;
             for (int tile = wave; tile < ntile; tile += nw) {
@@ -2247,6 +2364,8 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
     }
     if (s == 0 && t == 0 && !second_new) B.timings[31] += 1.0f;
     PH(20);
+    if (exact) marg_exact_finish(c, be, A, b, md, mq, n, c.Hpl, c.LW, F0x, second_new, sred, smem_marg);
+    else {
     // ---- eliminate the m-block (md x md) with a truncated eigen-decomposition
     for (int w = t; w < md * md; w += nt) { int i = w / md, j = w - i * md; A15[w] = 0.5 * (A[i * mq + j] + A[j * mq + i]); }
     __syncthreads();
@@ -2336,6 +2455,7 @@ __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, uns
         }
         __syncthreads();
         if (t == 0) { be.prior_c0 = c0; be.dbg[0] = 0; be.dbg[2] = second_new ? 1 : 0; }
+    }
     }
     PH(22);
     // keep_block_data in the shifted (canonical) layout

@@ -129,8 +129,10 @@ __device__ dm::m3 predict_motion(const Batch &B, int s, double t0, double t1) {
 // Estimator::predict (estimator.cpp:1862-1880) applied from the newest window state through every IMU sample that arrived after it:
 // what pubLatestOdometry publishes at IMU rate (inputIMU, :1749-1766, after updateLatestStates :1768-1788).  out11 = t, P(3),
 // Q(w, x, y, z), V(3); returns the window state itself when no newer sample is in the ring.  Output only: nothing is modified.
-// (updateLatestStates replays the buffered samples with the values of the queue's FRONT sample; here every sample is
-// applied with its own values, DESIGN.md deviation 14.)
+// Default: every sample is applied with its own values and becomes acc_0 / gyr_0 of the next step.  vio_config.reference_quirks bit 0
+// (VIO_QUIRK_LATEST_FRONT) reproduces Estimator::updateLatestStates literally (estimator.cpp:1779-1786): the loop walks
+// the buffered stamps but hands predict() the values of the queue's FRONT sample every time, and predict() never advances acc_0 / gyr_0
+// (they stay as processIMU left them, :1862-1880).
 __global__ void be_latest_odometry_kernel(Batch B, int seq, double *out11) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const DevCfg &C = *B.cfg;
@@ -143,6 +145,8 @@ __global__ void be_latest_odometry_kernel(Batch B, int seq, double *out11) {
     const double *it = B.imu_t + (size_t)seq * C.NIMU, *ia = B.imu_acc + (size_t)seq * C.NIMU * 3, *ig = B.imu_gyr + (size_t)seq * C.NIMU * 3;
     int k = be.imu_head;
     if (be.imu_count - k > C.NIMU) k = be.imu_count - C.NIMU;
+    const bool front = (C.c.reference_quirks & VIO_QUIRK_LATEST_FRONT) != 0;
+    const int idx_front = k % C.NIMU;
     if (be.solver_flag == 1 && C.c.use_imu)
         for (; k < be.imu_count; k++) {
             const int idx = k % C.NIMU;
@@ -150,7 +154,8 @@ __global__ void be_latest_odometry_kernel(Batch B, int seq, double *out11) {
             if (!(t > latest_time)) continue;
             const double dt = t - latest_time;
             latest_time = t;
-            const dm::v3 a1 = dm::ld3(ia + (size_t)idx * 3), w1 = dm::ld3(ig + (size_t)idx * 3);
+            const int iv = front ? idx_front : idx;
+            const dm::v3 a1 = dm::ld3(ia + (size_t)iv * 3), w1 = dm::ld3(ig + (size_t)iv * 3);
             const dm::v3 un_acc_0 = dm::sub(dm::mul(R, dm::sub(acc_0, Ba)), g);
             const dm::v3 un_gyr = dm::sub(dm::scl(0.5, dm::add(gyr_0, w1)), Bg);
             R = dm::mul(R, dm::q2R(dm::deltaQ(dm::scl(dt, un_gyr))));
@@ -158,7 +163,7 @@ __global__ void be_latest_odometry_kernel(Batch B, int seq, double *out11) {
             const dm::v3 un_acc = dm::scl(0.5, dm::add(un_acc_0, un_acc_1));
             P = dm::add(dm::add(P, dm::scl(dt, V)), dm::scl(0.5 * dt * dt, un_acc));
             V = dm::add(V, dm::scl(dt, un_acc));
-            acc_0 = a1; gyr_0 = w1;
+            if (!front) { acc_0 = a1; gyr_0 = w1; }
         }
     const dm::quat q = dm::R2q(R);
     out11[0] = latest_time; out11[1] = P.x; out11[2] = P.y; out11[3] = P.z;

@@ -35,6 +35,7 @@ __global__ void be_ingest_kernel(Batch B, const uint16_t *depth_base, size_t dep
 __global__ void be_solve_kernel(Batch B);
 __global__ void be_solve_kernel_512(Batch B);
 __global__ void be_marg_kernel(Batch B);
+__global__ void be_marg_exact_kernel(Batch B);
 // phased solver (be_phased.h)
 __global__ void ps_setup_kernel(Batch B);
 __global__ void ps_eval_kernel(Batch B);

@@ -554,7 +554,8 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
         HIPCHK(hipEventRecord(h->ev_state, st));
         h->state_pending = true;
     }
-    be_marg_kernel<<<S, h->marg_threads, h->lds_marg, st>>>(Bg);  // marginalisation + window slide (be_finish is fused into it)
+    if (C.MX > 0) be_marg_exact_kernel<<<S, h->marg_threads, h->lds_marg, st>>>(Bg);   // vio_config.marg_exact (parity instrument)
+    else be_marg_kernel<<<S, h->marg_threads, h->lds_marg, st>>>(Bg);  // marginalisation + window slide (be_finish is fused into it)
     if (prof) PEV(h, 11);
     HIPCHK(hipGetLastError());
     return VIO_OK;
@@ -670,6 +671,8 @@ static int build_devcfg(const vio_config *cfg, int imu_capacity, DevCfg &C) {
         off += (sw * sh + 63) & ~63;
     }
     C.pyr_bytes = off;
+    if (c.marg_exact < 0 || c.marg_exact > 1) { g_err = "marg_exact must be 0 or 1"; return VIO_EINVAL; }
+    C.MX = c.marg_exact ? std::min(15 + C.NP, 495) : 0;   // a landmark that starts in frame 0 was packaged by the tracker in that frame: at most NP of them
     return VIO_OK;
 }
 
@@ -738,6 +741,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     DA(B.pair_start, S * (npair + 1)); DA(B.pair_list, S * nres); DA(B.pairblk, S * npair * 210);
     DA(B.imu_raw, S * C.W * 15 * 31);
     DA(B.margA, S * mq * mq); DA(B.margB, S * mq); DA(B.margV, S * n * n); DA(B.margW, S * (n + 16) * (n + 16));
+    if (C.MX > 0) DA(B.margE, S * ((size_t)3 * C.MX * C.MX + n * (size_t)C.MX));
     DA(B.odom, S * 11); DA(B.timings, 64);
     B.hist_cap = 2048;
     B.s0 = 0;
@@ -831,6 +835,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
             (void)raise_lds_limit((const void *)be_prior_factor_kernel, h->lds_factor);
         }
         (void)raise_lds_limit((const void *)be_marg_kernel, (size_t)(h->lds_marg));
+        (void)raise_lds_limit((const void *)be_marg_exact_kernel, (size_t)(h->lds_marg));
         (void)raise_lds_limit((const void *)be_ingest_kernel, (size_t)(C.lm_hash_size * 8));
 
         (void)raise_lds_limit((const void *)fe_select_kernel, (size_t)(h->lds_select));

@@ -37,6 +37,7 @@ struct DevCfg {
     int LW;             // dense row stride of the landmark coupling matrix (= P rounded up to 16)
     int lvl_w[4], lvl_h[4], lvl_off[4];  // pyramid levels >= 1 packed in one buffer
     int pyr_bytes;
+    int MX;             // marg_exact: largest marginalised block (15 + landmarks starting in frame 0) the scratch margE is sized for (0 = off)
 };
 
 // IntegrationBase (integration_base.h)
@@ -186,6 +187,7 @@ struct Batch {
     double *pairblk;                  // [S][npairs][210] packed symmetric 20x20
     double *imu_raw;                  // [S][W][15*31] raw / whitened IMU Jacobians + residual
     double *margA, *margB, *margV, *margW;  // marginalisation workspaces
+    double *margE;                          // marg_exact only: [S][3 MX^2 + NPRIOR MX] (A_mm, its eigenvectors, A_mm^+, A_rm A_mm^+)
     // ---- outputs
     double *odom;         // [S][11]
     double *odom_hist;    // [S][hist_cap][11]: one CSV row per processed NON_LINEAR frame (visualization.cpp:214-225)
