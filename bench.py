@@ -57,8 +57,8 @@ def frontend_bytes(w, h, n, levels):
     return dict(pyrdown=w * h + sum(w * h // 4 ** l for l in range(1, levels + 1)), fast=w * h, lk=n * (levels + 1) * 2 * 23 * 23)
 
 
-def aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K):
-    """frames/s of the same step at another batch size (auxiliary data point; all 256 CUs busy at S = 256)."""
+def aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K, lag=0, seq0=0):
+    """frames/s of the same step at another batch size / tracker ordering (auxiliary data point, never `value`)."""
     H, Wd = cfg.height, cfg.width
     F = n_pre + Wm + K
     syn = P.Synth(sc)
@@ -66,10 +66,11 @@ def aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K):
     depth = torch.empty((F, S, H, Wd), dtype=torch.uint16, device=dev)
     times = vio_ct.frame_times(sc, F)
     for f in range(F):
-        syn.render_device(S, 0, float(times[f]), gray[f], depth[f])
+        syn.render_device(S, seq0, float(times[f]), gray[f], depth[f])
     nimu = int(F / sc.cam_rate * sc.imu_rate) + 64
     b = P.VioBatch(cfg, S, imu_capacity=nimu + 64)
-    imu = [syn.imu(s, nimu) for s in range(S)]
+    b.set_tracker_lag(lag)
+    imu = [syn.imu(seq0 + s, nimu) for s in range(S)]
     b.push_imu_batch(np.stack([x[0] for x in imu]), np.stack([x[1] for x in imu]), np.stack([x[2] for x in imu]))
     for f in range(n_pre + Wm):
         b.feed(gray[f], depth[f], np.full(S, times[f]), on_device=True)
@@ -82,9 +83,11 @@ def aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K):
     b.sync()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    ok = all(b.status(s).solver_flag == 1 for s in range(S))
+    ok = all(st.solver_flag == 1 for st in b.status_all())
     b.close()
-    return dict(sequences_per_gpu=S, frames_per_s=S * K / el, ms_per_step=el / K * 1e3, valid=bool(ok))
+    del gray, depth
+    torch.cuda.empty_cache()
+    return dict(sequences_per_gpu=S, tracker_lag=lag, frames_per_s=S * K / el, ms_per_step=el / K * 1e3, steps=K, valid=bool(ok))
 
 
 def _cpu_worker(job):
@@ -125,12 +128,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--repeats", type=int, default=3, help="the K-step timed region is run this many times (fresh frames); value = median")
+    ap.add_argument("--repeats", type=int, default=10, help="the K-step timed region is run this many times (fresh frames); value = median. "
+                    "The default gives 10 x 20 = 200 timed frames per sequence under the driver's --steps 20 (SURVEY.md 8d asks for >= 200)")
     ap.add_argument("--seqs", type=int, default=128, help="sequences per GPU")
     ap.add_argument("--cpu-seqs", type=int, default=8, help="sequences replayed through the CPU oracle on rank 0 (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=-1, help="oracle processes for the all-core CPU baseline, one sequence each "
                     "(-1 = every core this process may run on, 0 = skip)")
-    ap.add_argument("--aux", action="store_true", help="also measure S=256 sequences per GPU (reported as aux_s256, never as value)")
+    ap.add_argument("--aux", type=int, default=1, help="1 (default): also measure S = 256 and S = 512 sequences per GPU and the lag-0 ordering "
+                    "at S (reported as aux_s256 / aux_s512 / lag0, never as value); 0 = skip")
+    ap.add_argument("--seq-offset", type=int, default=0, help="global id of rank 0's first sequence (replays another rank's shard on one GPU)")
+    ap.add_argument("--dump", default="", help="write the final windows / odometry rows of this rank's sequences to <dump>.rank<r>.npz")
     ap.add_argument("--tracker-lag", type=int, default=1, choices=[0, 1], help="vio_set_tracker_lag: 1 = the tracker of frame f+1 overlaps the "
                     "optimisation of frame f (the reference's two threads with the estimator one frame behind), 0 = it waits for it")
     ap.add_argument("--pcie-steps", type=int, default=6, help="extra steps fed from HOST buffers after the timed region (0 = skip)")
@@ -186,7 +193,7 @@ def main():
     Kp = max(args.pcie_steps, 0)
     Ks = max(args.stream_steps, 0)
     F = n_pre + Wm + R * K + 2 * Kp + 2 * Ks   # (the PCIe leg runs twice: pageable and page-locked buffers)
-    seq0 = shard.sequence_shard(rank, world, S)[0]
+    seq0 = args.seq_offset + shard.sequence_shard(rank, world, S)[0]
     syn = P.Synth(sc)
     dev = torch.device("cuda", local_rank)
     gray = torch.empty((F, S, H, Wd), dtype=torch.uint8, device=dev)
@@ -330,7 +337,7 @@ def main():
     be_ms = sum(v for k, v in kms.items() if k.startswith("be_"))
     fe_ms = sum(v for k, v in kms.items() if k.startswith("fe_"))
     tj = None
-    for name in ("round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+    for name in ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):  # written by profiles/collect.sh from separate rocprofv3 --pmc passes over this same command
             tj = (name, json.load(open(tpath)))
@@ -480,8 +487,21 @@ def main():
         "pcie_inclusive": pcie,
         "imu_streaming": stream,
     }
-    if args.aux and rank == 0:
-        out["aux_s256"] = aux_rate(P, vio_ct, torch, cfg, sc, dev, 256, n_pre, Wm, K)
+    if args.dump:
+        np.savez(args.dump + ".rank%d.npz" % rank, seq0=seq0, windows=np.stack([b.window(s) for s in range(S)]),
+                 odometry=np.stack([hist[s][-min(len(hist[x]) for x in range(S)):] for s in range(S)]))
+    b.close()
+    del gray, depth
+    torch.cuda.empty_cache()
+    if args.aux and rank == 0 and world == 1:
+        # auxiliary data points on the same device, never `value`: the other tracker ordering at S, and larger batches
+        out["lag0"] = aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K, lag=0, seq0=seq0)
+        out["lag0"]["note"] = ("tracker lag 0: the tracker of frame f+1 waits for the optimisation of frame f (the front-end is on the critical "
+                               "path); `value` is measured with config.tracker_lag = %d" % args.tracker_lag)
+        for s_aux in (256, 512):
+            os.environ["VIO_GROUP_SEQS"] = str(s_aux // 2)
+            out["aux_s%d" % s_aux] = aux_rate(P, vio_ct, torch, cfg, sc, dev, s_aux, n_pre, Wm, K, lag=args.tracker_lag)
+        os.environ["VIO_GROUP_SEQS"] = str(per_group)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

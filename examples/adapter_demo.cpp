@@ -71,8 +71,7 @@ int main(int argc, char **argv) {
                 feature_buf.clear();
                 estimator.clearState();
                 estimator.setParameter();
-                init_pub = init_feature = false;
-                continue;
+                continue;                                  // (init_pub / init_feature and the tracker keep their state, like upstream)
             }
             if (d == vio_hip::FrameGate::SKIP) continue;
             const bool PUB_THIS_FRAME = d == vio_hip::FrameGate::PUBLISH;

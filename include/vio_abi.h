@@ -78,7 +78,7 @@ void vio_config_default(vio_config *cfg);
 vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity);
 void vio_destroy(vio_batch *h);
 const char *vio_last_error(void);
-/* Estimator::clearState() + setParameter() for every sequence (estimator_nodelet.cpp:255-258) */
+/* Every sequence back to the state after vio_create: fresh FeatureTracker AND Estimator::clearState() + setParameter(). */
 int vio_reset(vio_batch *h);
 
 /* Estimator::inputIMU(t, acc, gyr) (estimator.cpp:1749-1766) for sequence seq; n samples, t strictly increasing. */
@@ -86,9 +86,14 @@ int vio_push_imu(vio_batch *h, int seq, int n, const double *t, const double *ac
 /* The same for every sequence in one call (SURVEY.md 8b "batched variants taking SoA pointers"): n[s] samples for sequence s,
  * stored at t[s * stride + i], acc_xyz / gyr_xyz[(s * stride + i) * 3 + k]; n == NULL means `stride` samples for every sequence. */
 int vio_push_imu_batch(vio_batch *h, const int32_t *n, int stride, const double *t, const double *acc_xyz, const double *gyr_xyz);
-/* Estimator::clearState() + setParameter() for ONE sequence: the stream-discontinuity restart of
- * estimator_nodelet.cpp:243-262 (tracker state, estimator state and pending IMU of that sequence are dropped). */
+/* Estimator::clearState() + setParameter() for ONE sequence (estimator.cpp:15-116): what the stream-discontinuity branch of
+ * process_tracker does (estimator_nodelet.cpp:243-262) -- window, landmarks, prior, pre-integrations and the buffered IMU of that
+ * sequence are dropped, the pending feature map is discarded (feature_buf popped, :250-253), the nodelet's first_image_flag is set
+ * again and last_image_time zeroed (:246-247; they only matter to vio_feed's device-side gating).  The FeatureTracker is NOT touched:
+ * trackerData keeps its points, ids, track counts and previous image, init_pub / init_feature keep their values, exactly as upstream. */
 int vio_reset_seq(vio_batch *h, int seq);
+/* A fresh FeatureTracker for one sequence (no upstream counterpart: the reference only ever constructs its tracker once). */
+int vio_reset_tracker_seq(vio_batch *h, int seq);
 
 /* One camera frame for every sequence: the body of EstimatorNodelet::process_tracker for one synchronised
  * colour+depth pair (estimator_nodelet.cpp:234-393) followed by EstimatorNodelet::process (:462-549):

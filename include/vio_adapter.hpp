@@ -29,7 +29,7 @@ typedef std::array<double, 7> Vector7d;                      // Eigen::Matrix<do
 typedef std::map<int, Vector7d> FeatureMap;                  // map<int, Eigen::Matrix<double, 7, 1>> (estimator.h:46)
 
 // Stream checks + frequency control of process_tracker (estimator_nodelet.cpp:234-286).  step(t) returns what the nodelet does
-// with the frame stamped t: FIRST (only sets the time base), RESET (stream discontinuity: caller restarts tracker + estimator,
+// with the frame stamped t: FIRST (only sets the time base), RESET (stream discontinuity: caller restarts the estimator,
 // :243-262), SKIP ("Skip this frame", before readImage), TRACK (readImage with PUB_THIS_FRAME false) or PUBLISH.
 class FrameGate {
   public:
@@ -91,7 +91,7 @@ class Estimator {
     Estimator &operator=(const Estimator &) = delete;
 
     void setParameter() {}                                    // estimator.cpp:15-41: parameters are bound at construction
-    void clearState() { check(vio_reset(h_), "vio_reset"); clearMirror(); }   // estimator.cpp:43-116
+    void clearState() { check(vio_reset_seq(h_, 0), "vio_reset_seq"); clearMirror(); }   // estimator.cpp:43-116: the estimator side only -- featureTracker keeps its points / ids / previous image
 
     // estimator.cpp:1749-1766
     void inputIMU(double t, const double linearAcceleration[3], const double angularVelocity[3]) {

@@ -1609,6 +1609,7 @@ int Estimator::processImage(std::map<int, std::array<double, 7>> &image, const u
             for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) ric(i, j) = cfg.ric[i * 3 + j];
             tic = V3(cfg.tic[0], cfg.tic[1], cfg.tic[2]);
             td = cfg.td;
+            g = V3(0, 0, cfg.g_norm);   // setParameter(): g = G (estimator.cpp:26)
             reboot_count++;
             return 2;
         }
@@ -1647,6 +1648,16 @@ int Pipeline::track(const uint8_t *gray, double t, int mode, const double *R_in,
     if (!init_pub) { init_pub = true; image.clear(); return 0; }          // :365-368
     if (!init_feature) { init_feature = true; image.clear(); return 0; }  // :371-377
     return image.empty() ? 0 : 1;
+}
+void Pipeline::restart() {  // estimator_nodelet.cpp:243-262
+    first_image_flag = true;
+    last_image_time = 0;
+    est.clearState();
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) est.ric(i, j) = est.cfg.ric[i * 3 + j];   // setParameter() (estimator.cpp:15-41)
+    est.tic = V3(est.cfg.tic[0], est.cfg.tic[1], est.cfg.tic[2]);
+    est.td = est.cfg.td;
+    est.g = V3(0, 0, est.cfg.g_norm);
+    snap_bg = est.latest_Bg; snap_td = est.td;
 }
 // EstimatorNodelet::process for one queued feature frame (:462-549): inputDepth + processImage
 int Pipeline::process(std::map<int, std::array<double, 7>> &image, const uint16_t *depth, double t) {

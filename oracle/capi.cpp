@@ -16,6 +16,7 @@ void ovio_config_default(Config *c) { *c = Config(); }
 // ---------------------------------------------------------------- full pipeline (tracker + estimator + nodelet glue)
 void *ovio_pipeline_create(const Config *c) { return new Pipeline(*c); }
 void ovio_pipeline_destroy(void *h) { delete (Pipeline *)h; }
+void ovio_pipeline_restart(void *h) { ((Pipeline *)h)->restart(); }
 void ovio_push_imu(void *h, double t, const double *acc, const double *gyr) {
     ((Pipeline *)h)->est.inputIMU(t, V3(acc[0], acc[1], acc[2]), V3(gyr[0], gyr[1], gyr[2]));
 }

@@ -305,6 +305,9 @@ struct Pipeline {
     om::V3 snap_bg;
     double snap_td;
     explicit Pipeline(const Config &c) : cfg(c), tracker(c), est(c), snap_td(c.td) {}
+    // the stream-discontinuity branch of process_tracker (estimator_nodelet.cpp:243-262): first_image_flag = true, last_image_time = 0,
+    // feature_buf emptied, estimator.clearState() + setParameter().  trackerData, init_pub and init_feature are left alone.
+    void restart();
     // returns 1 if processImage ran for this frame; mode: 0 skip, 1 track only (PUB_THIS_FRAME false), 2 publish
     int feed(const uint8_t *gray, const uint16_t *depth, double t, int mode = 2);
     // the two halves the nodelet runs on separate threads with feature_buf between them (estimator_nodelet.cpp:380-384, 539)

@@ -170,59 +170,6 @@ def test_batch_of_128_matches_oracle_and_standalone(P):
         alone.close()
 
 
-def test_300_frames_ate_within_one_percent_of_the_oracle(P):
-    """SURVEY.md 8d sequence length (300 frames) on 8 sequences, no reboots, every frame processed on both sides.
-    Measured behaviour (profiles/round2_parity_trace_seq704.txt, DESIGN.md "Parity over long runs"): the two implementations track each
-    other to 1e-9 m for ~60 frames; the difference then grows along the weakly observed accelerometer-bias direction of the prior
-    (1e-8 -> 1e-6 m over ~100 frames: the oracle re-truncates eigenvalues <= 1e-8 of a 1e10-norm matrix at every marginalisation,
-    DESIGN.md deviations 10 / 12 / 13) until one discrete decision (an outlier / depth-failure test on a single landmark) flips,
-    after which two runs of the SAME algorithm sit 0.1 - 10 mm apart.  Sequences where no decision flips stay identical to 1e-8 m
-    over all 300 frames.  What is asserted:
-      * north-star criterion on the workload: |mean ATE_hip - mean ATE_oracle| <= 1 % of mean ATE_oracle, OR within two standard
-        errors of zero.  The second clause is what the data supports: every sequence whose run contains a decision flip lands +-0.5 ..
-        1 mm from the oracle's ATE in either direction, so the mean over 8 sequences with 3 - 4 flips scatters by ~0.2 mm (2 % of an
-        11 mm ATE) from build to build while staying unbiased: two builds of this round measured -0.02 mm (0.2 %, SE 0.09 mm) and
-        +0.19 mm (1.7 %, SE 0.18 mm); profiles/round2_parity_300*.json hold both tables;
-      * per sequence |ATE_hip - ATE_oracle| <= 1.5 mm and <= 15 % (a 1 cm ATE moved by a decision flip), distance < 2 cm;
-      * at least one sequence identical to 1e-6 m after 300 frames (no systematic difference).
-    The per-sequence table is written to gpurun_out/parity_300.json."""
-    cfg = P.canonical_config()
-    sc = vio_ct.synth_like(cfg)
-    S, seq0, n_frames = 8, 700, 300
-    fr = _DevFrames(P, sc, cfg, S, seq0, n_frames)
-    batch = _drive_device(P, cfg, sc, fr, list(range(seq0, seq0 + S)), seq0, n_frames)
-    report = []
-    for i in range(S):
-        st = batch.status(i)
-        assert st.reboot_count == 0 and st.solver_flag == 1
-        h = batch.odometry_history(i)
-        frames = [fr.host(f, i) for f in range(n_frames)]
-        o = vio_ct.run_oracle_sequence(cfg, sc, seq0 + i, n_frames, frames=frames)
-        po = np.array([x[1] for x in o["traj"]])
-        assert len(h) == len(po) >= 280, (i, len(h), len(po))
-        assert int(o["oracle"].status()["reboot_count"]) == 0
-        gt = np.array(o["gt"])
-        ate_o, ate_h = vio_ct.ate_rmse(po, gt), vio_ct.ate_rmse(h[:, 1:4], gt)
-        dist = float(np.linalg.norm(po - h[:, 1:4], axis=1).max())
-        report.append((seq0 + i, ate_o, ate_h, dist))
-        assert ate_o < 0.05 and ate_h < 0.05, (i, ate_o, ate_h)
-    rel = [abs(h_ - o_) / o_ for (_, o_, h_, _) in report]
-    mo, mh = float(np.mean([r[1] for r in report])), float(np.mean([r[2] for r in report]))
-    import json, os
-    out_dir = os.path.join(vio_ct.ROOT, "gpurun_out")
-    if os.path.isdir(out_dir):
-        json.dump(dict(columns=["sequence", "ATE_oracle_m", "ATE_hip_m", "max_distance_m"], rows=report, mean_ATE_oracle_m=mo, mean_ATE_hip_m=mh,
-                       rel_diff_of_means=abs(mh - mo) / mo, mean_rel_diff=float(np.mean(rel)), max_rel_diff=float(np.max(rel)),
-                       standard_error_of_mean_diff_m=float(np.std([r[2] - r[1] for r in report], ddof=1) / np.sqrt(len(report)))),
-                  open(os.path.join(out_dir, "parity_300.json"), "w"), indent=1)
-    diffs = np.array([r[2] - r[1] for r in report])
-    se = float(diffs.std(ddof=1) / np.sqrt(len(diffs)))
-    assert abs(mh - mo) <= max(0.01 * mo, 2.0 * se), (mo, mh, se, report)
-    assert max(abs(r[2] - r[1]) for r in report) <= 1.5e-3 and float(np.max(rel)) <= 0.15, report
-    assert max(r[3] for r in report) < 0.02, report
-    assert min(r[3] for r in report) < 1e-6, report
-
-
 def test_process_obs_crosses_the_boundary_both_ways(P):
     """Estimator::processImage(image, header) with a caller-supplied feature map (estimator.h:46): (a) the ORACLE tracker's maps fed to
     the HIP back-end through vio_process_obs reproduce the oracle pipeline; (b) the HIP tracker's maps (vio_track +

@@ -1,0 +1,68 @@
+"""Round-3 GPU tests: the north-star ATE criterion with statistical power (128 sequences x 300 frames, strict 1 %), the literal
+marginalisation (vio_config.marg_exact) as a causality instrument for the long-run divergence, and the HIP path driven by two ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import parity_long
+import vio_ct
+
+pytestmark = pytest.mark.gpu
+
+
+def test_300_frames_128_sequences_ate_within_one_percent_strict(P):
+    """SURVEY.md 8d sequence length (300 frames) on BASELINE configs[2]'s batch (128 sequences), the oracle in a process pool (one
+    sequence per host core).  North-star criterion, asserted STRICTLY on the default build: |mean ATE_hip - mean ATE_oracle| <= 1 % of
+    mean ATE_oracle (with 128 sequences the standard error of that difference is ~0.4 % of the mean, so a 1 % bias is resolvable).  The
+    same run with vio_config.marg_exact = 1 (marginalization_factor.cpp:281-315 followed literally) is recorded next to it: the
+    per-sequence tables of both modes go to gpurun_out/parity_300_s128.json (committed as profiles/round3_parity_300_s128.json)."""
+    rep = parity_long.run(P, S=128, seq0=700, n_frames=300, lag=0, modes=("fast", "exact"))
+    out_dir = os.path.join(vio_ct.ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        json.dump(rep, open(os.path.join(out_dir, "parity_300_s128.json"), "w"), indent=1)
+    for mode in ("fast", "exact"):
+        m = rep["modes"][mode]
+        assert m["hip_reboots"] == 0, mode
+        assert all(r["same_frames"] and r["oracle_reboots"] == 0 and r["frames"] >= 280 for r in m["rows"]), mode
+        assert all(r["ate_oracle_m"] < 0.06 and r["ate_hip_m"] < 0.06 for r in m["rows"]), mode
+        sm = m["summary"]
+        assert sm["rel_diff_of_means"] <= 0.01, (mode, sm)                       # the north-star tolerance, no escape clause
+        assert sm["max_distance_m"] < 0.05, (mode, sm)                            # two realisations of the same estimator, never a failure
+        assert sm["identical_to_1um"] >= 1, (mode, sm)                           # no systematic difference
+    # the 1 % must be resolvable by this sample: standard error of the mean difference well below it
+    assert rep["modes"]["fast"]["summary"]["standard_error_rel"] < 0.01, rep["modes"]["fast"]["summary"]
+
+
+def _bench(args, env_extra, timeout=900):
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(vio_ct.ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_two_ranks_drive_the_hip_path_on_one_gpu(tmp_path):
+    """The N > 1 control flow of bench.py executed for real: two torch.distributed ranks (gloo rendezvous, both on cuda:0 -- this box has
+    one GPU) each own 16 sequences (global ids 0..15 and 16..31), no data-path collective, one reduction of the job totals.  The job
+    line must account for both shards, and rank 1's windows must be bit-identical to a single-rank run of the same global ids:
+    results do not depend on which rank / how many ranks computed them."""
+    common = ["--seqs", "16", "--steps", "8", "--warmup", "4", "--repeats", "1", "--cpu-seqs", "0", "--cpu-procs", "0", "--pcie-steps", "0",
+              "--stream-steps", "0", "--aux", "0"]
+    d2, d1 = str(tmp_path / "two"), str(tmp_path / "one")
+    j2 = _bench(["--gpus", "2"] + common + ["--dump", d2], {"VIO_BENCH_DEVICE": "0", "VIO_BENCH_BACKEND": "gloo"})
+    assert j2["n_gpus"] == 2 and j2["valid"] is True and j2["scaling"] == "weak"
+    frames = j2["value"] * j2["ms_per_step"] * 1e-3 * j2["steps"]
+    assert abs(frames - 2 * 16 * 8) < 1e-6 * frames, frames
+    assert j2["ate_m"]["sequences"] == 16                                          # rank 0's own sequences; the job RMS covers both ranks
+    j1 = _bench(["--gpus", "1"] + common + ["--seq-offset", "16", "--dump", d1], {})
+    assert j1["n_gpus"] == 1 and j1["valid"] is True
+    a, b = np.load(d2 + ".rank1.npz"), np.load(d1 + ".rank0.npz")
+    assert int(a["seq0"]) == 16 and int(b["seq0"]) == 16
+    assert np.array_equal(a["windows"], b["windows"]) and np.array_equal(a["odometry"], b["odometry"])
+    r0 = np.load(d2 + ".rank0.npz")
+    assert int(r0["seq0"]) == 0 and not np.array_equal(r0["windows"], a["windows"])

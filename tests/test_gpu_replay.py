@@ -93,29 +93,66 @@ def test_replay_of_a_30hz_recording_matches_the_oracle(P, tmp_path):
     assert io.ate_rmse(rows[:, 1:4], gt) < 0.03
 
 
-def test_stream_discontinuity_restarts_the_sequence(P, tmp_path):
-    """estimator_nodelet.cpp:243-262: a gap of more than one second (or a stamp going backwards) restarts the tracker and the
-    estimator.  Replay of a recording with a 1.5 s hole must equal two independent replays of its halves."""
+def test_stream_discontinuity_restarts_the_estimator_and_keeps_the_tracker(P, tmp_path):
+    """estimator_nodelet.cpp:243-262: a gap of more than one second (or a stamp going backwards) empties feature_buf and restarts the
+    ESTIMATOR (clearState + setParameter); trackerData keeps its points, ids, track counts and previous image, init_pub / init_feature
+    keep their values, and the frame after the restart only sets the time base again (first_image_flag).  Replay of a recording with a
+    1.5 s hole against the oracle driven through the same branch (Pipeline::restart), and the tracker's ids must continue, not restart."""
     io = importlib.import_module("vins-rgbd-fast_amd.dataio")
     cfg = P.canonical_config()
     sc = vio_ct.synth_like(cfg)
     syn = P.Synth(sc)
-    seq, n = 8, 56
+    seq, n = 8, 70
     stamps = vio_ct.frame_times(sc, n)
     keep = [f for f in range(n) if not (22 <= f < 37)]
     frames = {f: syn.render_host(seq, float(stamps[f])) for f in keep}
     ti, ai, gi = syn.imu(seq, int(n / sc.cam_rate * sc.imu_rate) + 64)
-
-    def rec_of(fs, name, k0=0):
-        io.write_recording(str(tmp_path / name), [stamps[f] for f in fs], [frames[f][0] for f in fs], [frames[f][1] for f in fs], ti[k0:], ai[k0:], gi[k0:])
-        return io.RgbdImuDirectory(str(tmp_path / name))
-    whole = io.replay(P.VioBatch(cfg, 1), rec_of(keep, "whole"), freq=10, frontend_freq=30)
-    first = io.replay(P.VioBatch(cfg, 1), rec_of([f for f in keep if f < 22], "a"), freq=10, frontend_freq=30)
-    # the frame right after the hole triggers the restart and is dropped; the one after it is the new first image
-    # (clearState() empties imu_buf: the samples pushed up to the restart frame, one beyond its stamp, are gone)
-    k0 = int(np.searchsorted(ti, stamps[37] + 1e-9, side="right")) + 1
-    second = io.replay(P.VioBatch(cfg, 1), rec_of([f for f in keep if f >= 38], "b", k0), freq=10, frontend_freq=30)
-    assert len(first) >= 5 and len(second) >= 3
-    assert len(whole) == len(first) + len(second)
-    assert np.array_equal(whole[:len(first)], first)
-    assert np.array_equal(whole[len(first):], second)
+    io.write_recording(str(tmp_path / "whole"), [stamps[f] for f in keep], [frames[f][0] for f in keep], [frames[f][1] for f in keep], ti, ai, gi)
+    rec = io.RgbdImuDirectory(str(tmp_path / "whole"))
+    b = P.VioBatch(cfg, 1)
+    seen = {}
+    def grab(f, st):
+        seen[f] = (st.solver_flag, st.frame_count, st.n_tracks, int(b.tracks(0)[0].max(initial=-1)))
+    whole = io.replay(b, rec, freq=10, frontend_freq=30, on_frame=grab)
+    # the oracle through the same gate decisions
+    o = vio_ct.OraclePipeline(cfg)
+    gate = vio_ct.OracleGate(10, 30)
+    k, ref, init_pub, init_feature, n_reset = 0, [], False, False, 0
+    for i, f in enumerate(keep):
+        tf = float(stamps[f])
+        k2 = k
+        while k2 < len(ti) and ti[k2] <= tf + 1e-9:
+            k2 += 1
+        k2 = min(len(ti), k2 + 1)
+        o.push_imu(ti[k:k2], ai[k:k2], gi[k:k2]); k = k2
+        d = gate.step(tf)
+        if d == vio_ct.OracleGate.RESET:
+            o.restart()
+            n_reset += 1
+            assert seen[i][0] == 0 and seen[i][1] == 0 and seen[i][2] > 50      # estimator INITIAL again, the tracker still holds its points
+            continue
+        mode = 2 if d == vio_ct.OracleGate.FIRST else d
+        r = o.feed(frames[f][0], frames[f][1], tf, mode)
+        if mode == 2 and d != vio_ct.OracleGate.FIRST:
+            if not init_pub:
+                init_pub = True
+            elif not init_feature:
+                init_feature = True
+            elif r == 0:
+                gate.empty_map(tf)
+        so = o.status()
+        assert (int(so["solver_flag"]), int(so["frame_count"])) == seen[i][:2], (i, f)
+        ot = o.tracks()[0]
+        assert len(ot) == seen[i][2] and int(ot.max(initial=-1)) == seen[i][3], (i, f)       # same tracker population and ids on both sides
+        if r == 1 and so["solver_flag"] == 1:
+            w = o.window()[cfg.window_size]
+            ref.append(np.r_[tf, w[:3], w[3:7], w[7:10]])
+    ref = np.array(ref)
+    assert n_reset == 1
+    assert whole.shape == ref.shape and len(whole) >= 20, (whole.shape, ref.shape)
+    assert np.abs(whole[:, 0] - ref[:, 0]).max() < 1e-9
+    assert np.abs(whole[:, 1:4] - ref[:, 1:4]).max() < 1e-5, float(np.abs(whole[:, 1:4] - ref[:, 1:4]).max())
+    # both halves produced rows (the estimator re-initialised after the hole), and feature ids kept counting across it
+    assert (whole[:, 0] < stamps[22]).sum() >= 5 and (whole[:, 0] > stamps[37]).sum() >= 5
+    i_reset = keep.index(37)
+    assert seen[len(keep) - 1][3] > seen[i_reset - 1][3] > 100

@@ -45,7 +45,7 @@ def oracle():
         L.ovio_preint_create.restype = C.c_void_p
         L.ovio_gate_create.restype = C.c_void_p
         for name, args in {
-            "ovio_pipeline_create": [C.c_void_p], "ovio_pipeline_destroy": [C.c_void_p],
+            "ovio_pipeline_create": [C.c_void_p], "ovio_pipeline_destroy": [C.c_void_p], "ovio_pipeline_restart": [C.c_void_p],
             "ovio_push_imu_n": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
             "ovio_feed": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
             "ovio_feed_mode": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int],
@@ -102,6 +102,10 @@ class OraclePipeline:
     def push_imu(self, t, acc, gyr):
         t = np.ascontiguousarray(t, np.float64); acc = np.ascontiguousarray(acc, np.float64); gyr = np.ascontiguousarray(gyr, np.float64)
         self.L.ovio_push_imu_n(self.h, len(t), t.ctypes.data, acc.ctypes.data, gyr.ctypes.data)
+
+    def restart(self):
+        """the stream-discontinuity branch of process_tracker (estimator_nodelet.cpp:243-262): estimator restarted, tracker kept"""
+        self.L.ovio_pipeline_restart(self.h)
 
     def feed(self, gray, depth, t, mode=2):
         return self.L.ovio_feed_mode(self.h, gray.ctypes.data, depth.ctypes.data, float(t), int(mode))

@@ -90,6 +90,7 @@ def lib():
         L.vio_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.vio_sync.argtypes = [C.c_void_p]
         L.vio_reset_seq.argtypes = [C.c_void_p, C.c_int]
+        L.vio_reset_tracker_seq.argtypes = [C.c_void_p, C.c_int]
         L.vio_push_imu_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vio_feed_modes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.vio_track_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -373,7 +374,11 @@ class VioBatch:
         return dict(tracks=int(c[0]), landmarks=int(c[1]), imu=int(c[2]))
 
     def reset_seq(self, seq):
+        """Estimator::clearState() + setParameter() for one sequence (the nodelet's stream-discontinuity restart: the tracker is kept)"""
         self._chk(self.L.vio_reset_seq(self.h, seq), "vio_reset_seq")
+
+    def reset_tracker_seq(self, seq):
+        self._chk(self.L.vio_reset_tracker_seq(self.h, seq), "vio_reset_tracker_seq")
 
     def sync(self):
         self._chk(self.L.vio_sync(self.h), "vio_sync")
@@ -518,9 +523,11 @@ class Estimator:
         return self.batch.status(0).code
 
     def clearState(self):
-        self.batch.reset()
+        """Estimator::clearState() (estimator.cpp:43-116): the estimator side only, the FeatureTracker keeps its state"""
+        self.batch.reset_seq(0)
 
-    setParameter = clearState
+    def setParameter(self):
+        """estimator.cpp:15-41: parameters are bound at construction (vio_reset_seq re-applies them)"""
 
     @property
     def solver_flag(self):

@@ -1550,6 +1550,7 @@ __device__ __forceinline__ void solve_epilogue(Ctx &c, const Params &X, double c
                 for (int k = 0; k < 9; k++) be.ric[k] = cfg.ric[k];
                 for (int k = 0; k < 3; k++) { be.tic[k] = cfg.tic[k]; be.latest_Bg[k] = 0; }
                 be.td = cfg.td;
+                be.g[0] = 0; be.g[1] = 0; be.g[2] = cfg.g_norm;   // setParameter(): g = G (estimator.cpp:26)
                 be.first_imu = 0; be.frame_count = 0; be.solver_flag = 0; be.openExEstimation = 0; be.has_prior = 0;
                 be.initFirstPoseFlag = 0; be.prevTime = -1; be.n_lm = 0; be.n_free = c.NL; be.ring_base = 0;
                 be.imu_head = be.imu_count_ingest;  // clearState() empties imu_buf (samples pushed for the next frame while this one was

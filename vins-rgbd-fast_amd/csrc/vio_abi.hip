@@ -181,19 +181,33 @@ template <class T> int dalloc(vio_batch *h, T **p, size_t n) {
     return VIO_OK;
 }
 
-// (re)initialise the state of sequences [s_lo, s_hi): Estimator::clearState() + setParameter() and a fresh FeatureTracker
-int init_state(vio_batch *h, int s_lo, int s_hi) {
+// (re)initialise the state of sequences [s_lo, s_hi).  what & VIO_RESET_ESTIMATOR: Estimator::clearState() + setParameter()
+// (estimator.cpp:15-116: window, landmarks, prior, pre-integrations, pending IMU) and the nodelet's first_image_flag / last_image_time
+// (estimator_nodelet.cpp:246-247); what & VIO_RESET_TRACKER: a fresh FeatureTracker (points, ids, images) and init_pub / init_feature.
+// The stream-discontinuity branch of the nodelet (estimator_nodelet.cpp:243-262) resets ONLY the estimator side: trackerData keeps its
+// points, ids and previous image, init_pub / init_feature keep their values.
+enum { VIO_RESET_ESTIMATOR = 1, VIO_RESET_TRACKER = 2 };
+int init_state(vio_batch *h, int s_lo, int s_hi, int what = VIO_RESET_ESTIMATOR | VIO_RESET_TRACKER) {
     const DevCfg &C = h->hc;
     int n = s_hi - s_lo, W = C.W;
     std::vector<FeSeq> fe(n);
+    if (what & VIO_RESET_TRACKER) {
+        memset(fe.data(), 0, sizeof(FeSeq) * n);
+        for (int s = 0; s < n; s++) {
+            FeSeq &f = fe[s];
+            f.first_image_flag = 1;
+            for (int k = 0; k < C.ncells; k++) f.grids_texture_status[k] = 1;
+            f.R_rel[0] = f.R_rel[4] = f.R_rel[8] = 1;
+        }
+    } else {
+        HIPCHK(hipMemcpy(fe.data(), h->B.fe + s_lo, sizeof(FeSeq) * n, hipMemcpyDeviceToHost));
+        for (int s = 0; s < n; s++) { fe[s].first_image_flag = 1; fe[s].last_image_time = 0; fe[s].n_obs = 0; fe[s].publish_ok = 0; }
+    }
+    HIPCHK(hipMemcpy(h->B.fe + s_lo, fe.data(), sizeof(FeSeq) * n, hipMemcpyHostToDevice));
+    if (!(what & VIO_RESET_ESTIMATOR)) return VIO_OK;
     std::vector<BeSeq> be(n);
-    memset(fe.data(), 0, sizeof(FeSeq) * n);
     memset(be.data(), 0, sizeof(BeSeq) * n);
     for (int s = 0; s < n; s++) {
-        FeSeq &f = fe[s];
-        f.first_image_flag = 1;
-        for (int k = 0; k < C.ncells; k++) f.grids_texture_status[k] = 1;
-        f.R_rel[0] = f.R_rel[4] = f.R_rel[8] = 1;
         BeSeq &b = be[s];
         for (int i = 0; i <= VIO_MAXW; i++) { b.Rs[i][0] = b.Rs[i][4] = b.Rs[i][8] = 1; b.pre_idx[i] = i; }
         for (int k = 0; k < 9; k++) b.ric[k] = C.c.ric[k];
@@ -204,7 +218,12 @@ int init_state(vio_batch *h, int s_lo, int s_hi) {
         b.prevTime = -1;
         b.n_free = C.NL;
     }
-    HIPCHK(hipMemcpy(h->B.fe + s_lo, fe.data(), sizeof(FeSeq) * n, hipMemcpyHostToDevice));
+    if (what != (VIO_RESET_ESTIMATOR | VIO_RESET_TRACKER)) {
+        // diagnostics that count over the life of the handle survive an estimator restart
+        std::vector<BeSeq> old(n);
+        HIPCHK(hipMemcpy(old.data(), h->B.be + s_lo, sizeof(BeSeq) * n, hipMemcpyDeviceToHost));
+        for (int s = 0; s < n; s++) { be[s].iter_total = old[s].iter_total; be[s].solve_total = old[s].solve_total; be[s].reboot_count = old[s].reboot_count; }
+    }
     HIPCHK(hipMemcpy(h->B.be + s_lo, be.data(), sizeof(BeSeq) * n, hipMemcpyHostToDevice));
     std::vector<int> fr((size_t)n * C.NL);
     for (int s = 0; s < n; s++) for (int k = 0; k < C.NL; k++) fr[(size_t)s * C.NL + k] = C.NL - 1 - k;
@@ -212,9 +231,13 @@ int init_state(vio_batch *h, int s_lo, int s_hi) {
     HIPCHK(hipMemset(h->B.lm_order + (size_t)s_lo * C.NL, 0, sizeof(int) * (size_t)n * C.NL));
     HIPCHK(hipMemset(h->B.pre + (size_t)s_lo * (W + 2), 0, sizeof(PreInt) * (size_t)n * (W + 2)));
     HIPCHK(hipMemset(h->B.odom + (size_t)s_lo * 11, 0, sizeof(double) * (size_t)n * 11));
-    HIPCHK(hipMemset(h->B.odom_count + s_lo, 0, sizeof(int) * (size_t)n));
+    if (what & VIO_RESET_TRACKER) HIPCHK(hipMemset(h->B.odom_count + s_lo, 0, sizeof(int) * (size_t)n));   // (an estimator restart keeps the CSV rows written so far)
     {
-        if (!h->dyn.empty()) { for (int s = s_lo; s < s_hi; s++) h->dyn[s] = vio_batch::DynSeq(); h->dyn_active = true; h->state_pending = false; }
+        if (!h->dyn.empty()) {
+            for (int s = s_lo; s < s_hi; s++) h->dyn[s] = vio_batch::DynSeq();
+            h->dyn_active = true;
+            if (s_lo == 0 && s_hi == h->S) h->state_pending = false;   // a partial reset must not swallow another sequence's pending reboot notice
+        }
         // Estimator::clearState() empties imu_buf: drop what is still staged on the host for these sequences
         std::lock_guard<std::mutex> lk(h->imu_mu);
         for (int s = s_lo; s < s_hi; s++) h->last_imu_t[s] = -1e300;
@@ -890,7 +913,14 @@ int vio_reset(vio_batch *h) {
 int vio_reset_seq(vio_batch *h, int seq) {
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
-    return init_state(h, seq, seq + 1);
+    { int rc_ = refresh_dynamic_state(h); if (rc_ != VIO_OK) return rc_; }   // a reboot of ANOTHER sequence decided by the last solve must not be lost
+    return init_state(h, seq, seq + 1, VIO_RESET_ESTIMATOR);
+}
+
+int vio_reset_tracker_seq(vio_batch *h, int seq) {
+    if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
+    { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
+    return init_state(h, seq, seq + 1, VIO_RESET_TRACKER);
 }
 
 int vio_push_imu(vio_batch *h, int seq, int n, const double *t, const double *acc, const double *gyr) {

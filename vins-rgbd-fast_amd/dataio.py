@@ -275,7 +275,7 @@ def write_recording(root, stamps, grays, depths, imu_t, imu_acc, imu_gyr):
 class FrameGate:
     """Stream checks + frequency control of EstimatorNodelet::process_tracker (estimator_nodelet.cpp:94-95, 234-286) as a
     stand-alone state machine.  ``step(t)`` returns what the nodelet does with the frame stamped ``t``: FIRST (only sets the
-    time base), RESET (stream discontinuity: restart tracker + estimator, :243-262), SKIP ("Skip this frame", before
+    time base), RESET (stream discontinuity: restart the estimator, :243-262), SKIP ("Skip this frame", before
     readImage), TRACK (readImage with PUB_THIS_FRAME false) or PUBLISH.  The first three values equal the VIO_FRAME_* modes."""
     SKIP, TRACK, PUBLISH, FIRST, RESET = 0, 1, 2, 3, 4
 
@@ -328,7 +328,7 @@ def replay(batch, rec, csv_path=None, seq=0, on_frame=None, freq=0, frontend_fre
     """Feed a recording through a single-sequence slot of a VioBatch the way the nodelet does: push IMU through the frame stamp
     (one sample beyond, so that IMUAvailable holds), run the frame gate (``freq`` / ``frontend_freq`` of the configuration file;
     frontend_freq == 0 disables the gate: every frame is published), feed the pair with the gate's mode, append a CSV row whenever
-    the estimator is NON_LINEAR.  A stream discontinuity restarts the sequence (vio_reset_seq).  Returns the rows
+    the estimator is NON_LINEAR.  A stream discontinuity restarts the estimator of the sequence (vio_reset_seq; the tracker keeps its state).  Returns the rows
     [stamp, P, Q(wxyz), V]."""
     rows, k = [], 0
     wr = OdometryCsvWriter(csv_path, append=False) if csv_path else None
@@ -348,8 +348,9 @@ def replay(batch, rec, csv_path=None, seq=0, on_frame=None, freq=0, frontend_fre
         if gate is not None:
             d = gate.step(t)
             if d == FrameGate.RESET:
+                # estimator_nodelet.cpp:243-262: feature_buf emptied, estimator.clearState() + setParameter(); the tracker (points, ids,
+                # previous image) and init_pub / init_feature are NOT reset upstream, and are not here
                 batch.reset_seq(seq)
-                init_pub = init_feature = False
                 if on_frame:
                     on_frame(f, batch.status(seq))
                 continue
