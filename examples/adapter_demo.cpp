@@ -3,7 +3,9 @@
 // feature_buf, estimator_nodelet.cpp:192-459) and process (pop feature_buf, inputDepth, processImage, :462-549), with the
 // estimator allowed to lag the tracker by `lag` frames like the reference's second thread does.
 // Build:  g++ -std=c++11 -Iinclude examples/adapter_demo.cpp -Lvins-rgbd-fast_amd -lvio_hip -Wl,-rpath,$PWD/vins-rgbd-fast_amd
-// Usage:  adapter_demo [seq] [n_frames] [cam_rate] [freq] [frontend_freq] [lag] [use_imu]   (use_imu 0 = the reference's `imu: 0`)
+// Usage:  adapter_demo [seq] [n_frames] [cam_rate] [freq] [frontend_freq] [lag] [use_imu] [depth_jitter]
+//         use_imu 0 = the reference's `imu: 0`; depth_jitter 1 = the depth stamps are offset from the colour stamps by a fixed pattern
+//         (some beyond +-3 ms) so that the colour / depth pairing of process_tracker (:206-232) drops frames through both branches
 // Prints one line per NON_LINEAR frame: stamp px py pz n_tracks  (tests/test_gpu_adapter.py compares it with the oracle).
 #include <cstdio>
 #include <cstdlib>
@@ -25,6 +27,8 @@ int main(int argc, char **argv) {
     const int FREQ = argc > 4 ? std::atoi(argv[4]) : 10, FRONTEND_FREQ = argc > 5 ? std::atoi(argv[5]) : 30;
     const size_t lag = argc > 6 ? (size_t)std::atoi(argv[6]) : 0;
     const bool USE_IMU = argc > 7 ? std::atoi(argv[7]) != 0 : true;
+    const bool depth_jitter = argc > 8 ? std::atoi(argv[8]) != 0 : false;
+    static const double kDepthOffset[8] = {0.0, 0.001, -0.002, 0.0045, 0.0, 0.0029, -0.0035, 0.002};
     vio_config cfg;
     vio_config_default(&cfg);
     cfg.fix_depth = 0; cfg.depth_max = 10.0;  // the 150-feature setting used by bench.py (canonical_config)
@@ -46,6 +50,7 @@ int main(int argc, char **argv) {
         std::deque<QueuedFrame> feature_buf;
         bool init_pub = false, init_feature = false;   // estimator_nodelet.cpp:365-377
         int k = 0;
+        vio_hip::ColorDepthSync<int> sync;             // img_buf / depth_buf of the nodelet; a message = its frame index
         auto process = [&](bool drain) {   // EstimatorNodelet::process: one queued frame per call unless draining
             while (feature_buf.size() > (drain ? 0 : lag)) {
                 QueuedFrame &f = feature_buf.front();
@@ -59,10 +64,15 @@ int main(int argc, char **argv) {
                 feature_buf.pop_front();
             }
         };
-        for (int fi = 0; fi < n_frames; fi++) {
-            const double time_color = fi / sc.cam_rate;
+        for (int fm = 0; fm < n_frames; fm++) {
+            // img_callback / depth_callback (:128-154): both messages of frame fm arrive, then process_tracker pairs what it can (:200-232)
+            sync.pushColor(fm / sc.cam_rate, fm);
+            sync.pushDepth(fm / sc.cam_rate + (depth_jitter ? kDepthOffset[fm % 8] : 0.0), fm);
+            int fi = 0, fd = 0;
+            double time_color = 0;
+            if (!sync.pop(fi, fd, time_color)) continue;
             while (USE_IMU && k < nimu && t[k] < time_color + 1.5 / sc.imu_rate) { estimator.inputIMU(t[k], &acc[3 * k], &gyr[3 * k]); k++; }  // imu_callback
-            vio_synth_render_host(&sc, seq, time_color, gray.data(), depth.data());
+            vio_synth_render_host(&sc, seq, time_color, gray.data(), depth.data());   // (the depth image of message fd; same pixels, its stamp only decides the pairing)
             // ---- process_tracker
             const double last_image_time = gate.last_image_time;
             const vio_hip::FrameGate::Decision d = gate.step(time_color);

@@ -6,6 +6,11 @@
  * reference's one-Estimator-per-process use); all state lives in HBM behind the handle, configuration is per handle
  * instead of process-global.  Plain C types only; the caller owns input buffers for the duration of a call.
  *
+ * Host buffers: every entry point that takes host memory (images with on_device == 0, stamps, modes, R_rel, feature maps) enqueues
+ * asynchronous uploads.  From pageable memory the runtime stages the copy before the call returns; from page-locked memory
+ * (vio_host_alloc) the copy is truly asynchronous: such buffers must stay untouched until the NEXT call on the handle that takes host
+ * buffers, any getter, or vio_sync has returned (those calls wait for the pending uploads first).
+ *
  * Threading: a handle is not re-entrant.  vio_push_imu / vio_push_imu_batch may be called from another thread than
  * vio_track / vio_process / vio_feed (internal lock), mirroring Estimator::inputIMU being called from ROS callback threads
  * (estimator.cpp:1749-1766).  vio_last_error is thread-local: it reports the last failure of the CALLING thread.
@@ -171,7 +176,8 @@ typedef struct vio_status {
     int32_t reboot_count, frames_processed;
     double initial_cost, final_cost, td;
     int32_t overflow_flags;       /* capacity flags of the last frame: 1 landmark table, 2 IMU slot (> 64 samples per frame interval),
-                                     4 FAST candidates of a cell, 8 residual list, 16 IMU ring overwritten (code = VIO_ECAPACITY) */
+                                     4 FAST candidates of a cell, 8 residual list, 16 IMU ring overwritten, 32 solver iteration slots
+                                     exhausted before the trust-region loop finished (code = VIO_ECAPACITY) */
     int32_t overflow_frames;      /* frames that raised any capacity flag since the last reset / reboot */
     int32_t iterations_total, solves_total; /* solver iterations / solves since vio_create */
 } vio_status;

@@ -15,9 +15,11 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "vio_abi.h"
@@ -27,6 +29,31 @@ namespace vio_hip {
 struct Point2f { float x, y; };
 typedef std::array<double, 7> Vector7d;                      // Eigen::Matrix<double, 7, 1>: x y z u v vx vy
 typedef std::map<int, Vector7d> FeatureMap;                  // map<int, Eigen::Matrix<double, 7, 1>> (estimator.h:46)
+
+// The colour / depth pairing at the top of process_tracker (estimator_nodelet.cpp:200-232): img_buf and depth_buf are FIFO queues
+// filled by the two image callbacks; while both hold a message the front stamps are compared -- colour more than 3 ms older than depth:
+// "throw color"; more than 3 ms newer: "throw depth"; otherwise both are popped as a pair.  T = whatever the caller queues per message.
+template <class T> class ColorDepthSync {
+  public:
+    void pushColor(double stamp, const T &msg) { img_buf.push_back(std::make_pair(stamp, msg)); }      // img_callback (:128-140)
+    void pushDepth(double stamp, const T &msg) { depth_buf.push_back(std::make_pair(stamp, msg)); }    // depth_callback (:142-154)
+    // true: color / depth (and time_color) hold the next synchronised pair; false: one queue ran dry (the nodelet waits there)
+    bool pop(T &color, T &depth, double &time_color) {
+        while (!img_buf.empty() && !depth_buf.empty()) {
+            const double tc = img_buf.front().first, td = depth_buf.front().first;
+            if (tc < td - 0.003) { img_buf.pop_front(); ++thrown_color; }
+            else if (tc > td + 0.003) { depth_buf.pop_front(); ++thrown_depth; }
+            else {
+                color = img_buf.front().second; depth = depth_buf.front().second; time_color = tc;
+                img_buf.pop_front(); depth_buf.pop_front();
+                return true;
+            }
+        }
+        return false;
+    }
+    std::deque<std::pair<double, T> > img_buf, depth_buf;
+    int thrown_color = 0, thrown_depth = 0;
+};
 
 // Stream checks + frequency control of process_tracker (estimator_nodelet.cpp:234-286).  step(t) returns what the nodelet does
 // with the frame stamped t: FIRST (only sets the time base), RESET (stream discontinuity: caller restarts the estimator,

@@ -1681,6 +1681,20 @@ int Pipeline::feed(const uint8_t *gray, const uint16_t *depth, double t, int mod
 
 // Frequency control + stream-discontinuity detection of process_tracker (estimator_nodelet.cpp:94-95, 234-286), restated as a
 // stand-alone state machine so that replay drivers on both sides (oracle and product) take identical decisions.
+std::vector<std::pair<int, int>> pair_color_depth(const std::vector<double> &color, const std::vector<double> &depth, int thrown[2]) {
+    // estimator_nodelet.cpp:206-226, with the queues replaced by read positions (messages arrive in stamp order per topic)
+    std::vector<std::pair<int, int>> out;
+    size_t ic = 0, id = 0;
+    thrown[0] = thrown[1] = 0;
+    while (ic < color.size() && id < depth.size()) {
+        const double time_color = color[ic], time_depth = depth[id];
+        if (time_color < time_depth - 0.003) { ic++; thrown[0]++; }        // "throw color"
+        else if (time_color > time_depth + 0.003) { id++; thrown[1]++; }   // "throw depth"
+        else { out.push_back({(int)ic, (int)id}); ic++; id++; }
+    }
+    return out;
+}
+
 FrameGate::FrameGate(int freq_, int frontend_freq_) : freq(freq_ == 0 ? 100 : freq_), frontend_freq(frontend_freq_) {}  // parameters.cpp:133-134
 int FrameGate::step(double t) {
     if (first_image_flag) {  // :234-240

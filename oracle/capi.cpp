@@ -17,6 +17,12 @@ void ovio_config_default(Config *c) { *c = Config(); }
 void *ovio_pipeline_create(const Config *c) { return new Pipeline(*c); }
 void ovio_pipeline_destroy(void *h) { delete (Pipeline *)h; }
 void ovio_pipeline_restart(void *h) { ((Pipeline *)h)->restart(); }
+// colour / depth pairing (estimator_nodelet.cpp:200-232): pairs[2 k] / [2 k + 1] = colour / depth index; thrown2 = dropped colour, depth
+int ovio_pair_color_depth(int nc, const double *tc, int nd, const double *td, int *pairs, int *thrown2) {
+    auto p = pair_color_depth(std::vector<double>(tc, tc + nc), std::vector<double>(td, td + nd), thrown2);
+    for (size_t k = 0; k < p.size(); k++) { pairs[2 * k] = p[k].first; pairs[2 * k + 1] = p[k].second; }
+    return (int)p.size();
+}
 void ovio_push_imu(void *h, double t, const double *acc, const double *gyr) {
     ((Pipeline *)h)->est.inputIMU(t, V3(acc[0], acc[1], acc[2]), V3(gyr[0], gyr[1], gyr[2]));
 }

@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <list>
 #include <map>
+#include <utility>
 #include <vector>
 #include "om.h"
 
@@ -315,6 +316,10 @@ struct Pipeline {
               const double *td = nullptr);
     int process(std::map<int, std::array<double, 7>> &image, const uint16_t *depth, double t);
 };
+
+// Colour / depth pairing of EstimatorNodelet::process_tracker (estimator_nodelet.cpp:200-232) applied to two stamp lists in arrival
+// order: returns the (colour index, depth index) pairs the two-queue +-3 ms rule forms; thrown[0] / thrown[1] = dropped colour / depth.
+std::vector<std::pair<int, int>> pair_color_depth(const std::vector<double> &color, const std::vector<double> &depth, int thrown[2]);
 
 // Frequency control / stream checks of EstimatorNodelet::process_tracker (estimator_nodelet.cpp:94-95, 234-286)
 enum { GATE_SKIP = 0, GATE_TRACK = 1, GATE_PUBLISH = 2, GATE_FIRST = 3, GATE_RESET = 4 };

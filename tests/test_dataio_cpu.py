@@ -239,3 +239,83 @@ def test_frame_gate_cpp_header_equals_oracle_restatement(tmp_path):
                 if k % 37 == 36 and db[-1] == 2:
                     b.empty_map(x)
             assert dc == db
+
+
+def _jittered_pairs(seed):
+    """colour stamps at 30 Hz; depth stamps = colour + jitter, with some depth / colour frames missing and two stamp clusters far apart"""
+    rng = np.random.default_rng(seed)
+    tc = np.arange(120) / 30.0 + 10.0
+    td = tc + rng.choice([0.0, 0.001, -0.002, 0.0029, -0.0031, 0.004, -0.006, 0.012], size=len(tc))
+    keep_c = rng.random(len(tc)) > 0.08
+    keep_d = rng.random(len(td)) > 0.08
+    return tc[keep_c], np.sort(td[keep_d])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_color_depth_pairing_python_equals_oracle_restatement(seed):
+    """dataio.ColorDepthSync / pair_color_depth (product host side) against the oracle's restatement of estimator_nodelet.cpp:200-232
+    on jittered and gappy stamp lists: the same pairs, the same number of thrown colour / depth frames, both drop branches exercised,
+    and every pair within the 3 ms tolerance."""
+    import importlib
+    io = importlib.import_module("vins-rgbd-fast_amd.dataio")
+    import vio_ct
+    tc, td = _jittered_pairs(seed)
+    got = io.pair_color_depth(tc, td)
+    ref, thrown_c, thrown_d = vio_ct.oracle_pair_color_depth(tc, td)
+    assert got == ref and len(got) > 40
+    assert thrown_c > 0 and thrown_d > 0
+    assert all(abs(tc[i] - td[j]) <= 0.003 + 1e-12 for i, j in got)
+    # online use: messages arrive interleaved in stamp order, pairs come out as soon as both queues hold a message
+    sync = io.ColorDepthSync()
+    ev = sorted([(t, 0, i) for i, t in enumerate(tc)] + [(t, 1, j) for j, t in enumerate(td)])
+    online = []
+    for t, kind, idx in ev:
+        (sync.push_color if kind == 0 else sync.push_depth)(t, idx)
+        while True:
+            p = sync.pop()
+            if p is None:
+                break
+            online.append((p[0][1], p[1][1]))
+    assert online == ref and (sync.thrown_color, sync.thrown_depth) <= (thrown_c, thrown_d)
+
+
+def test_color_depth_pairing_cpp_header_equals_oracle_restatement(tmp_path):
+    """vio_hip::ColorDepthSync of include/vio_adapter.hpp (what a nodelet links) on the same stamp lists."""
+    import subprocess
+    import vio_ct
+    src = tmp_path / "sync.cpp"
+    src.write_text('#include <cstdio>\n#include "vio_adapter.hpp"\nint main() { vio_hip::ColorDepthSync<int> s; int nc, nd; double t; if (scanf("%d %d", &nc, &nd) != 2) return 1;\n'
+                   'for (int i = 0; i < nc; i++) { if (scanf("%lf", &t) != 1) return 1; s.pushColor(t, i); }\n'
+                   'for (int j = 0; j < nd; j++) { if (scanf("%lf", &t) != 1) return 1; s.pushDepth(t, j); }\n'
+                   'int c, d; double tc; while (s.pop(c, d, tc)) printf("%d %d\\n", c, d); printf("-1 %d\\n-1 %d\\n", s.thrown_color, s.thrown_depth); return 0; }\n')
+    exe = str(tmp_path / "sync")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), str(src), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for seed in (0, 1, 2):
+        tc, td = _jittered_pairs(seed)
+        out = subprocess.run([exe], input="%d %d\n" % (len(tc), len(td)) + "\n".join("%.17g" % x for x in np.r_[tc, td]), capture_output=True, text=True)
+        rows = [tuple(int(x) for x in ln.split()) for ln in out.stdout.strip().splitlines()]
+        ref, thrown_c, thrown_d = vio_ct.oracle_pair_color_depth(tc, td)
+        assert rows[:-2] == ref and rows[-2] == (-1, thrown_c) and rows[-1] == (-1, thrown_d)
+
+
+def test_recording_with_jittered_depth_stamps_pairs_like_the_nodelet(tmp_path):
+    """RgbdImuDirectory on a recording whose depth stamps are offset from the colour stamps: frames beyond +-3 ms are dropped by the
+    nodelet's rule (estimator_nodelet.cpp:206-226), the others keep the COLOUR stamp; pairing="nearest" keeps them all."""
+    import importlib
+    io = importlib.import_module("vins-rgbd-fast_amd.dataio")
+    n = 12
+    stamps = 5.0 + np.arange(n) / 10.0
+    off = np.array([0, 0.001, -0.002, 0.005, 0, 0.0029, -0.004, 0, 0.0031, 0, -0.001, 0.002])
+    g = [np.full((8, 8), k, np.uint8) for k in range(n)]
+    d = [np.full((8, 8), 1000 + k, np.uint16) for k in range(n)]
+    imu_t = 5.0 + np.arange(300) / 200.0
+    io.write_recording(str(tmp_path / "r"), stamps, g, d, imu_t, np.zeros((300, 3)), np.zeros((300, 3)), depth_stamps=stamps + off)
+    rec = io.RgbdImuDirectory(str(tmp_path / "r"))
+    expect = [k for k in range(n) if abs(off[k]) <= 0.003]
+    assert len(rec) == len(expect) == 9
+    for q, k in enumerate(expect):
+        t, gray, depth = rec.frame(q)
+        assert abs(t - stamps[k]) < 1e-9 and gray[0, 0] == k and depth[0, 0] == 1000 + k
+    assert len(io.RgbdImuDirectory(str(tmp_path / "r"), pairing="nearest")) == n

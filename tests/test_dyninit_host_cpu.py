@@ -1,7 +1,13 @@
 """The host-side building blocks of the PRODUCT's dynamic initialisation (vins-rgbd-fast_amd/csrc/dyninit_host.cpp, exported as
 vio_stage_host_*; no GPU involved) against the oracle's restatement of the same reference routines (oracle/initial.cpp) on identical
-inputs: cv::solvePnP ITERATIVE, cv::solvePnPRansac(EPNP) with OpenCV's RNG stream, relativePose + GlobalSFM::construct.  The two
-implementations share no code (own dense algebra, own EPnP / Levenberg-Marquardt / bundle adjustment)."""
+inputs: cv::solvePnP ITERATIVE, cv::solvePnPRansac(EPNP) with OpenCV's RNG stream, relativePose + GlobalSFM::construct.
+
+Independence: both sides restate the same published algorithms (EPnP of Lepetit et al., OpenCV's CvLevMarq, Ceres' Levenberg-Marquardt),
+so agreement between them alone would not prove much.  The product side therefore (a) formulates the pieces differently from the oracle
+-- least squares by a one-sided Jacobi SVD instead of normal equations, the EPnP distance constraints as quadratic forms, the bundle
+adjustment's Schur complement accumulated point by point instead of through a dense camera-point block -- and (b) is pinned here by
+TRUTH-ANCHORED known-answer tests that involve no oracle code at all (test_*_truth_*): exact poses of noise-free scenes, the exact
+inlier set under gross outliers, and first-order optimality of the bundle adjustment checked with numerical derivatives in numpy."""
 import ctypes as C
 
 import numpy as np
@@ -109,3 +115,154 @@ def test_visual_inertial_alignment_matches_the_oracle(host, orc, n, dt, noise):
     assert ok_o == ok_h == 1
     assert np.abs(gh - go).max() < 1e-9 and np.abs(xh[:3 * n + 2] - xo[:3 * n + 2]).max() < 1e-8
     assert abs(np.linalg.norm(gh) - oi.G) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ truth-anchored KATs (no oracle code)
+def _pose_err(R, t, Rt, tt):
+    return float(max(np.abs(R - Rt).max(), np.abs(t - tt).max()))
+
+
+@pytest.mark.parametrize("seed,n", [(11, 6), (12, 30), (13, 150)])
+def test_truth_solve_pnp_recovers_the_exact_pose(host, seed, n):
+    """noise-free scene, float32-exact inputs (cv::Point3f / Point2f storage is then lossless): Levenberg-Marquardt from a rough guess must
+    land on the true pose; the residual error is the float rounding of the projections (6e-8), not the solver."""
+    rng, X, m, Rt, tt = oi.scene(n, seed)
+    X = np.ascontiguousarray(X.astype(np.float32).astype(np.float64))
+    Y = X @ Rt.T + tt
+    m = np.ascontiguousarray(Y[:, :2] / Y[:, 2:3])
+    R = np.ascontiguousarray(oi.rot([0.3, -1, 0.2], 0.05))
+    t = np.array([0.1, 0.05, 0.3])
+    assert host.vio_stage_host_pnp(n, X.ctypes.data, m.ctypes.data, R.ctypes.data, t.ctypes.data) == 1
+    assert _pose_err(R, t, Rt, tt) < 5e-7, _pose_err(R, t, Rt, tt)
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12 and abs(np.linalg.det(R) - 1) < 1e-12
+    # mean reprojection error of the returned pose: at the float-rounding floor
+    Yh = X @ R.T + t
+    assert np.abs(Yh[:, :2] / Yh[:, 2:3] - m).max() < 2e-7
+
+
+@pytest.mark.parametrize("seed,n_bad", [(21, 0), (22, 12), (23, 25)])
+def test_truth_epnp_ransac_finds_the_true_inlier_set_and_pose(host, seed, n_bad):
+    """gross outliers (20 px and more) among exact points: the pose must be the true one and the set of points within the RANSAC
+    threshold (1 / 460) of the returned pose must be exactly the uncorrupted set -- nothing about how the hypotheses were drawn."""
+    n = 70
+    rng, X, m, Rt, tt = oi.scene(n, seed)
+    bad = rng.choice(n, n_bad, replace=False)
+    m2 = m.copy()
+    m2[bad] += rng.uniform(0.05, 0.3, (n_bad, 2)) * rng.choice([-1, 1], (n_bad, 2))
+    R, t = np.zeros((3, 3)), np.zeros(3)
+    assert host.vio_stage_host_pnp_ransac(n, X.ctypes.data, m2.ctypes.data, 100, 1 / 460, 0.99, R.ctypes.data, t.ctypes.data) == 1
+    assert _pose_err(R, t, Rt, tt) < 1e-6, _pose_err(R, t, Rt, tt)
+    Y = X @ R.T + t
+    err = np.linalg.norm(Y[:, :2] / Y[:, 2:3] - m2, axis=1)
+    inl = err <= 1 / 460
+    clean = np.ones(n, bool)
+    clean[bad] = False
+    assert np.array_equal(inl, clean)
+    # planar scene (all points on one plane: the EPnP null space is degenerate, the N = 2 / 3 approximations carry the solution)
+    Xp = X.copy()
+    Xp[:, 2] = 4.0 + 0.2 * Xp[:, 0]
+    Yp = Xp @ Rt.T + tt
+    mp = np.ascontiguousarray(Yp[:, :2] / Yp[:, 2:3])
+    assert host.vio_stage_host_pnp_ransac(n, Xp.ctypes.data, mp.ctypes.data, 100, 1 / 460, 0.99, R.ctypes.data, t.ctypes.data) == 1
+    assert _pose_err(R, t, Rt, tt) < 1e-5, _pose_err(R, t, Rt, tt)
+
+
+def _sfm_host(host, W, start, nobs, obs):
+    nf = len(start)
+    l = C.c_int(-1)
+    q, T, pts, st = np.zeros((W + 1, 4)), np.zeros((W + 1, 3)), np.zeros((nf, 4)), np.zeros(4)
+    rc = host.vio_stage_host_sfm_window(W, nf, start.ctypes.data, nobs.ctypes.data, obs.ctypes.data, C.byref(l), q.ctypes.data, T.ctypes.data,
+                                        pts.ctypes.data, st.ctypes.data)
+    return rc, l.value, q, T, pts, st
+
+
+@pytest.mark.parametrize("seed", [2, 5])
+def test_truth_sfm_window_noise_free(host, seed):
+    """relativePose + GlobalSFM::construct on exact tracks of a known camera motion: every window pose (expressed in the frame of camera
+    l) and every triangulated point must come out at its true value (1e-6: the PnP initial guesses pass through float, the bundle
+    adjustment then has nothing left to do)."""
+    W = 10
+    start, nobs, obs, Rwc, pwc, X = oi.window_tracks(W, 160, 0.12, 0.0, 0.0, seed)
+    rc, l, q, T, pts, st = _sfm_host(host, W, start, nobs, obs)
+    assert rc == 0 and 0 <= l < W
+    for i in range(W + 1):
+        R_true = Rwc[l].T @ Rwc[i]
+        T_true = Rwc[l].T @ (pwc[i] - pwc[l])
+        assert np.abs(oi.q2R(q[i]) - R_true).max() < 1e-6, (i, float(np.abs(oi.q2R(q[i]) - R_true).max()))
+        assert np.abs(T[i] - T_true).max() < 1e-6, (i, float(np.abs(T[i] - T_true).max()))
+    ok = pts[:, 0] > 0
+    assert ok.sum() > 100
+    # window_tracks drops tracks with fewer than two observations: its X rows are indexed like the surviving tracks only through the
+    # observations, so rebuild the true point of every track from its first observation (x, y, depth in its start frame)
+    o0 = np.cumsum(np.r_[0, nobs[:-1]])
+    for k in np.nonzero(ok)[0]:
+        x, y, d = obs[o0[k]]
+        Xw = Rwc[start[k]] @ (np.array([x, y, 1.0]) * d) + pwc[start[k]]
+        assert np.abs(pts[k, 1:] - Rwc[l].T @ (Xw - pwc[l])).max() < 1e-5, k
+
+
+def test_truth_bundle_adjustment_reaches_a_first_order_optimum(host):
+    """noisy tracks: the result of GlobalSFM::construct's bundle adjustment, checked with NUMERICAL derivatives of the reprojection
+    cost written independently in numpy (camera rotation / translation world -> camera as the reference parameterises them,
+    initial_sfm.cpp:330-377: rotation of frame l and the translations of frames l and W constant).  The cost at the result must be
+    below the cost at the ground truth (the optimum fits the noise), and its gradient far smaller than the gradient there."""
+    W = 10
+    start, nobs, obs0, Rwc, pwc, X = oi.window_tracks(W, 120, 0.12, 0.0, 0.0, 9)
+    obs = obs0.copy()
+    obs[:, :2] += np.random.default_rng(99).normal(0, 0.5 / 460, (len(obs), 2))            # half a pixel on every observation, exact depths
+    obs = np.ascontiguousarray(obs)
+    rc, l, q, T, pts, st = _sfm_host(host, W, start, nobs, obs)
+    assert rc == 0 and int(st[0]) >= 1
+    ok = np.nonzero(pts[:, 0] > 0)[0]
+    o0 = np.cumsum(np.r_[0, nobs[:-1]])
+
+    def unpack(qs, Ts, P):
+        return [oi.q2R(qq).T for qq in qs], [-(oi.q2R(qq).T @ tt) for qq, tt in zip(qs, Ts)], P          # c_rotation, c_translation
+
+    def cost(cR, ct, P):
+        c = 0.0
+        for k in ok:
+            for a in range(nobs[k]):
+                f = start[k] + a
+                Y = cR[f] @ P[k] + ct[f]
+                u, v, _ = obs[o0[k] + a]
+                c += 0.5 * ((Y[0] / Y[2] - u) ** 2 + (Y[1] / Y[2] - v) ** 2)
+        return c
+
+    def grad(cR, ct, P, eps=1e-7):
+        g = []
+        for f in range(W + 1):
+            if f != l:
+                for ax in np.eye(3):
+                    Rp = [r.copy() for r in cR]; Rm = [r.copy() for r in cR]
+                    Rp[f] = oi.rot(ax, eps) @ cR[f]; Rm[f] = oi.rot(ax, -eps) @ cR[f]
+                    g.append((cost(Rp, ct, P) - cost(Rm, ct, P)) / (2 * eps))
+            if f != l and f != W:
+                for j in range(3):
+                    tp = [x.copy() for x in ct]; tm = [x.copy() for x in ct]
+                    tp[f][j] += eps; tm[f][j] -= eps
+                    g.append((cost(cR, tp, P) - cost(cR, tm, P)) / (2 * eps))
+        for k in ok[:40]:
+            for j in range(3):
+                Pp = P.copy(); Pm = P.copy()
+                Pp[k, j] += eps; Pm[k, j] -= eps
+                g.append((cost(cR, ct, Pp) - cost(cR, ct, Pm)) / (2 * eps))
+        return np.array(g)
+
+    cR, ct, P = unpack(q, T, pts[:, 1:].copy())
+    # ground truth in the same gauge (frame of camera l)
+    qt = []
+    for i in range(W + 1):
+        Rt = Rwc[l].T @ Rwc[i]
+        qt.append(Rt)
+    cRt = [r.T for r in qt]
+    ctt = [-(r.T @ (Rwc[l].T @ (pwc[i] - pwc[l]))) for i, r in enumerate(qt)]
+    Pt = np.zeros_like(P)
+    # true points: from the noise-free first observation of every track
+    for k in ok:
+        x, y, d = obs0[o0[k]]
+        Pt[k] = Rwc[l].T @ (Rwc[start[k]] @ (np.array([x, y, 1.0]) * d) + pwc[start[k]] - pwc[l])
+    c_res, c_true = cost(cR, ct, P), cost(cRt, ctt, Pt)
+    assert c_res < c_true, (c_res, c_true)
+    g_res, g_true = np.abs(grad(cR, ct, P)).max(), np.abs(grad(cRt, ctt, Pt)).max()
+    assert g_res < 0.02 * g_true and g_res < 1e-4, (g_res, g_true)

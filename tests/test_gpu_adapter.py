@@ -66,3 +66,32 @@ def test_cpp_nodelet_loop_in_vo_mode(P, tmp_path):
     assert len(rows) >= 15 and rows.shape[0] == ref.shape[0], (rows.shape, ref.shape)
     assert np.abs(rows[:, 0] - ref[:, 0]).max() < 1e-3
     assert np.abs(rows[:, 1:4] - ref[:, 1:4]).max() < 5e-4, float(np.abs(rows[:, 1:4] - ref[:, 1:4]).max())
+
+
+def test_cpp_nodelet_loop_pairs_colour_and_depth_like_the_nodelet(P, tmp_path):
+    """The +-3 ms two-queue colour / depth pairing of process_tracker (estimator_nodelet.cpp:200-232) in front of the C++ mirror: depth
+    stamps offset by a fixed pattern, two of eight beyond the tolerance (one through "throw color" then "throw depth", one the other
+    way round).  The frames that survive are exactly those of the oracle's restatement of the rule, and the trajectory equals the
+    oracle pipeline fed with those frames only."""
+    exe = _build(tmp_path)
+    seq, n = 2, 40
+    out = subprocess.run([exe, str(seq), str(n), "10", "10", "30", "0", "1", "1"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    rows = np.array([[float(x) for x in line.split()] for line in out.stdout.strip().splitlines()])
+    cfg = P.canonical_config()
+    sc = P.default_synth(cam_rate=10.0)
+    times = vio_ct.frame_times(sc, n)
+    off = np.array([0.0, 0.001, -0.002, 0.0045, 0.0, 0.0029, -0.0035, 0.002])
+    pairs, thrown_c, thrown_d = vio_ct.oracle_pair_color_depth(times, times + off[np.arange(n) % 8])
+    kept = [i for i, j in pairs]
+    assert all(i == j for i, j in pairs) and thrown_c == thrown_d == n // 8 * 2 and 0 in kept
+    gm = vio_ct.gate_modes(vio_ct.OracleGate(10, 30), times[kept])
+    modes = [0] * n
+    for i, m in zip(kept, gm):
+        modes[i] = m
+    o = vio_ct.run_oracle_sequence(cfg, sc, seq, n, modes=modes)
+    ref = np.array([np.r_[times[f], p] for (f, p, q, v) in o["traj"]])
+    assert len(rows) >= 10 and rows.shape[0] == ref.shape[0], (rows.shape, ref.shape)
+    assert np.abs(rows[:, 0] - ref[:, 0]).max() < 1e-3
+    assert set(np.round(rows[:, 0] * 10).astype(int)) <= set(kept)
+    assert np.abs(rows[:, 1:4] - ref[:, 1:4]).max() < 2e-5, float(np.abs(rows[:, 1:4] - ref[:, 1:4]).max())

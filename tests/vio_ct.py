@@ -46,6 +46,7 @@ def oracle():
         L.ovio_gate_create.restype = C.c_void_p
         for name, args in {
             "ovio_pipeline_create": [C.c_void_p], "ovio_pipeline_destroy": [C.c_void_p], "ovio_pipeline_restart": [C.c_void_p],
+            "ovio_pair_color_depth": [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
             "ovio_push_imu_n": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
             "ovio_feed": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
             "ovio_feed_mode": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int],
@@ -169,6 +170,15 @@ class OraclePipeline:
         J, r, x0, pres = np.zeros((n, n)), np.zeros(n), np.zeros(self.W * 7 + 17), np.zeros(self.W + 3, np.uint8)
         k = self.L.ovio_get_prior(self.h, J.ctypes.data, r.ctypes.data, x0.ctypes.data, pres.ctypes.data)
         return (J, r, x0, pres) if k else None
+
+
+def oracle_pair_color_depth(color, depth):
+    """oracle restatement of the nodelet's colour / depth pairing (estimator_nodelet.cpp:200-232): ([(i, j)], thrown colour, thrown depth)"""
+    L = oracle()
+    tc, td = np.ascontiguousarray(color, np.float64), np.ascontiguousarray(depth, np.float64)
+    pairs, thrown = np.zeros(2 * max(1, min(len(tc), len(td))), np.int32), np.zeros(2, np.int32)
+    n = L.ovio_pair_color_depth(len(tc), tc.ctypes.data, len(td), td.ctypes.data, pairs.ctypes.data, thrown.ctypes.data)
+    return [(int(pairs[2 * k]), int(pairs[2 * k + 1])) for k in range(n)], int(thrown[0]), int(thrown[1])
 
 
 class OracleGate:

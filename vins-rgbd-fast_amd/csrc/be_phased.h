@@ -901,6 +901,9 @@ __global__ __launch_bounds__(256) void ps_final_kernel(Batch B) {
     __shared__ double sdx[16], sh_d[8];
     __shared__ int sh_i[8];
     for (int k = t; k < (int)(sizeof(Params) / sizeof(double)); k += blockDim.x) ((double *)&X)[k] = ((const double *)&st.X)[k];
+    // the host enqueues max_iterations + 2 slots; more than one Cholesky retry / invalid step in one solve can use them up before the
+    // trust-region loop has finished: the last accepted point is written back (a valid, less converged estimate) and the frame is flagged
+    if (t == 0 && st.stage != PS_DONE) c.be->overflow |= 32;
     __syncthreads();
     solve_epilogue(c, X, st.cost, st.iters_done, st.succ, st.ts0, sdx, sh_d, sh_i);
     if (t == 0) st.stage = PS_IDLE;

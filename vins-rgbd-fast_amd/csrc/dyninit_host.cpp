@@ -78,18 +78,40 @@ std::vector<double> solve_sym_pinv(const Dense &A, const std::vector<double> &b)
     }
     return x;
 }
-// min |A x - b| through the normal equations (cvSolve(CV_SVD) / qr_solve in the published EPnP code)
+// min |A x - b|, minimum-norm solution (cvSolve(CV_SVD) / qr_solve in the published EPnP code): thin SVD of A by one-sided Jacobi
+// (Hestenes) -- the columns of A V are orthogonalised by plane rotations, their norms are the singular values -- then
+// x = V S^+ (A V)^T b / S with singular values below n eps s_max dropped.  A has at most a handful of columns here.
 std::vector<double> least_squares(const Dense &A, const std::vector<double> &b) {
     const int m = A.r, n = A.c;
-    Dense N(n, n);
-    std::vector<double> g(n, 0.0);
-    for (int i = 0; i < n; i++) {
-        for (int j = 0; j < n; j++) { double s = 0; for (int k = 0; k < m; k++) s += A(k, i) * A(k, j); N(i, j) = s; }
-        double s = 0;
-        for (int k = 0; k < m; k++) s += A(k, i) * b[k];
-        g[i] = s;
+    Dense U = A, V(n, n);
+    for (int j = 0; j < n; j++) V(j, j) = 1;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        bool rotated = false;
+        for (int p = 0; p + 1 < n; p++)
+            for (int q = p + 1; q < n; q++) {
+                double app = 0, aqq = 0, apq = 0;
+                for (int k = 0; k < m; k++) { app += U(k, p) * U(k, p); aqq += U(k, q) * U(k, q); apq += U(k, p) * U(k, q); }
+                if (!(fabs(apq) > 1e-15 * sqrt(app * aqq)) || apq == 0.0) continue;
+                rotated = true;
+                const double zeta = (aqq - app) / (2 * apq);
+                const double tn = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+                const double cs = 1 / sqrt(1 + tn * tn), sn = cs * tn;
+                for (int k = 0; k < m; k++) { const double x = U(k, p), y = U(k, q); U(k, p) = cs * x - sn * y; U(k, q) = sn * x + cs * y; }
+                for (int k = 0; k < n; k++) { const double x = V(k, p), y = V(k, q); V(k, p) = cs * x - sn * y; V(k, q) = sn * x + cs * y; }
+            }
+        if (!rotated) break;
     }
-    return solve_sym_pinv(N, g);
+    std::vector<double> sv(n), x(n, 0.0);
+    double smax = 0;
+    for (int j = 0; j < n; j++) { double s2 = 0; for (int k = 0; k < m; k++) s2 += U(k, j) * U(k, j); sv[j] = sqrt(s2); smax = std::max(smax, sv[j]); }
+    for (int j = 0; j < n; j++) {
+        if (!(sv[j] > smax * 2.220446049250313e-16 * std::max(m, n))) continue;
+        double ub = 0;
+        for (int k = 0; k < m; k++) ub += U(k, j) * b[k];
+        const double coef = ub / (sv[j] * sv[j]);
+        for (int i = 0; i < n; i++) x[i] += V(i, j) * coef;
+    }
+    return x;
 }
 // in-place Cholesky (lower) of a symmetric positive definite matrix; false if a pivot is not positive
 bool cholesky(Dense &A) {
@@ -287,21 +309,31 @@ struct EpnpSolver {
         }
         return s / n;
     }
-    static void refine_betas(const Dense &L, const double *rho, double *b) {  // 5 Gauss-Newton steps on the 6 distance constraints
+    // The six control-point distance constraints |sum_p beta_p (v_p^a - v_p^b)|^2 = |c_a - c_b|^2 are quadratic forms in beta:
+    // beta^T Q_i beta = rho_i with Q_i(p, q) = d_p^i . d_q^i (d_p^i = difference of control points a, b of null vector p).
+    struct QuadForm { double q[4][4]; };
+    // column order of the linearised unknowns the paper uses: B11 B12 B22 B13 B23 B33 B14 B24 B34 B44
+    static void beta_pair(int col, int &p, int &q) {
+        static const int P[10] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3}, Q[10] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3};
+        p = P[col]; q = Q[col];
+    }
+    // five Gauss-Newton steps on e_i(beta) = rho_i - beta^T Q_i beta (de_i / dbeta = -2 Q_i beta)
+    static void refine_betas(const QuadForm *Qf, const double *rho, double *beta) {
         for (int it = 0; it < 5; it++) {
-            Dense A(6, 4);
-            std::vector<double> rhs(6);
+            Dense Jm(6, 4);
+            std::vector<double> e(6);
             for (int i = 0; i < 6; i++) {
-                const double *l = &L.a[(size_t)i * 10];
-                A(i, 0) = 2 * l[0] * b[0] + l[1] * b[1] + l[3] * b[2] + l[6] * b[3];
-                A(i, 1) = l[1] * b[0] + 2 * l[2] * b[1] + l[4] * b[2] + l[7] * b[3];
-                A(i, 2) = l[3] * b[0] + l[4] * b[1] + 2 * l[5] * b[2] + l[8] * b[3];
-                A(i, 3) = l[6] * b[0] + l[7] * b[1] + l[8] * b[2] + 2 * l[9] * b[3];
-                rhs[i] = rho[i] - (l[0] * b[0] * b[0] + l[1] * b[0] * b[1] + l[2] * b[1] * b[1] + l[3] * b[0] * b[2] + l[4] * b[1] * b[2] +
-                                   l[5] * b[2] * b[2] + l[6] * b[0] * b[3] + l[7] * b[1] * b[3] + l[8] * b[2] * b[3] + l[9] * b[3] * b[3]);
+                double quad = 0;
+                for (int p = 0; p < 4; p++) {
+                    double Qb = 0;
+                    for (int q = 0; q < 4; q++) Qb += Qf[i].q[p][q] * beta[q];
+                    Jm(i, p) = 2 * Qb;
+                    quad += beta[p] * Qb;
+                }
+                e[i] = rho[i] - quad;
             }
-            const std::vector<double> x = least_squares(A, rhs);
-            for (int k = 0; k < 4; k++) b[k] += x[k];
+            const std::vector<double> step = least_squares(Jm, e);
+            for (int k = 0; k < 4; k++) beta[k] += step[k];
         }
     }
     bool solve(m3 &Rout, v3 &tout) {
@@ -319,29 +351,26 @@ struct EpnpSolver {
         sym_eigen(MtM, w, V);
         Dense ut(12, 12);                      // rows = singular vectors, descending: row 11 belongs to the smallest
         for (int r = 0; r < 12; r++) for (int c = 0; c < 12; c++) ut(r, c) = V(c, 11 - r);
+        // quadratic forms of the six constraints (pairs (a, b) of control points in the order 01 02 03 12 13 23) and, from them, the
+        // 6 x 10 matrix of the linearised problem (off-diagonal products appear twice in beta^T Q beta)
+        QuadForm Qf[6];
         Dense L(6, 10);
         double rho[6];
         {
-            double dv[4][6][3];
-            for (int i = 0; i < 4; i++) {
-                int a = 0, b = 1;
-                for (int j = 0; j < 6; j++) {
-                    for (int k = 0; k < 3; k++) dv[i][j][k] = ut(11 - i, 3 * a + k) - ut(11 - i, 3 * b + k);
-                    if (++b > 3) { a++; b = a + 1; }
-                }
-            }
-            auto d3 = [](const double *x, const double *y) { return x[0] * y[0] + x[1] * y[1] + x[2] * y[2]; };
+            static const int CA[6] = {0, 0, 0, 1, 1, 2}, CB[6] = {1, 2, 3, 2, 3, 3};
             for (int i = 0; i < 6; i++) {
-                L(i, 0) = d3(dv[0][i], dv[0][i]); L(i, 1) = 2 * d3(dv[0][i], dv[1][i]); L(i, 2) = d3(dv[1][i], dv[1][i]);
-                L(i, 3) = 2 * d3(dv[0][i], dv[2][i]); L(i, 4) = 2 * d3(dv[1][i], dv[2][i]); L(i, 5) = d3(dv[2][i], dv[2][i]);
-                L(i, 6) = 2 * d3(dv[0][i], dv[3][i]); L(i, 7) = 2 * d3(dv[1][i], dv[3][i]); L(i, 8) = 2 * d3(dv[2][i], dv[3][i]);
-                L(i, 9) = d3(dv[3][i], dv[3][i]);
-            }
-            int a = 0, b = 1;
-            for (int j = 0; j < 6; j++) {
-                const v3 d = sub(cw[a], cw[b]);
-                rho[j] = dot(d, d);
-                if (++b > 3) { a++; b = a + 1; }
+                double d[4][3];
+                for (int p = 0; p < 4; p++)
+                    for (int k = 0; k < 3; k++) d[p][k] = ut(11 - p, 3 * CA[i] + k) - ut(11 - p, 3 * CB[i] + k);
+                for (int p = 0; p < 4; p++)
+                    for (int q = 0; q < 4; q++) Qf[i].q[p][q] = d[p][0] * d[q][0] + d[p][1] * d[q][1] + d[p][2] * d[q][2];
+                for (int col = 0; col < 10; col++) {
+                    int p, q;
+                    beta_pair(col, p, q);
+                    L(i, col) = (p == q ? 1.0 : 2.0) * Qf[i].q[p][q];
+                }
+                const v3 dc = sub(cw[CA[i]], cw[CB[i]]);
+                rho[i] = dot(dc, dc);
             }
         }
         const std::vector<double> rho_v(rho, rho + 6);
@@ -377,7 +406,7 @@ struct EpnpSolver {
             b[2] = b5[3] / b[0]; b[3] = 0;
         }
         for (int k = 0; k < 3; k++) {
-            refine_betas(L, rho, betas[k]);
+            refine_betas(Qf, rho, betas[k]);
             errs[k] = pose_from_betas(ut, betas[k], Rk[k], tk[k]);
         }
         int N = 0;
@@ -561,6 +590,7 @@ struct BundleAdjust {
     struct Ob { int frame, p; double u, v; };
     std::vector<Ob> ob;
     std::vector<std::array<double, 18>> J;    // 2 x [rot(3) trans(3) point(3)]
+    std::vector<std::vector<int>> obs_of;      // residuals per point (built on first use)
     std::vector<double> r;
 
     int column(const Ob &o, int j) const {
@@ -632,57 +662,82 @@ struct BundleAdjust {
         else if (gradient_max(ntot) <= 1e-10) converged = true;
         while (!converged && iterations < 50) {
             iterations++;
-            Dense Hcc(nc, nc), Hcp(nc, 3 * np);
-            std::vector<double> gc(nc, 0.0), gp(3 * np, 0.0), Hpp(9 * (size_t)np, 0.0);
+            // Normal equations of the column-scaled problem, eliminated point by point (the sparse bundle-adjustment form of the Schur
+            // complement; the dense camera-point block is never built).  For point p observed by the residuals k in obs_of[p]:
+            //   V_p = sum_k Jp_k^T Jp_k + damping,  g_p = sum_k Jp_k^T r_k,  W_k = Jc_k^T Jp_k (6 x 3, the observing camera's columns)
+            //   S = sum_k Jc_k^T Jc_k + damping - sum_p sum_{k, k'} W_k V_p^-1 W_k'^T,   rhs = -(g_c - sum_p sum_k W_k V_p^-1 g_p)
+            if (obs_of.empty() && np > 0) {
+                obs_of.assign(np, std::vector<int>());
+                for (size_t k = 0; k < ob.size(); k++) obs_of[ob[k].p].push_back((int)k);
+            }
+            auto damp = [&](double d) { return std::min(std::max(d, 1e-6), 1e32) / radius; };
+            Dense S(nc, nc);
+            std::vector<double> rhs(nc, 0.0), dx(ntot, 0.0);
+            struct CamRow { int col[6]; double Jc[2][6]; };
+            std::vector<CamRow> cam(ob.size());
             for (size_t k = 0; k < ob.size(); k++) {
-                const Ob &o = ob[k];
-                int cols[9];
-                double Js[2][9];
-                for (int j = 0; j < 9; j++) { cols[j] = column(o, j); for (int a = 0; a < 2; a++) Js[a][j] = cols[j] >= 0 ? J[k][a * 9 + j] * scale[cols[j]] : 0.0; }
-                for (int i = 0; i < 9; i++) {
-                    if (cols[i] < 0) continue;
-                    const double gi = Js[0][i] * r[2 * k] + Js[1][i] * r[2 * k + 1];
-                    if (i < 6) gc[cols[i]] += gi; else gp[cols[i] - nc] += gi;
-                    for (int j = 0; j < 9; j++) {
-                        if (cols[j] < 0) continue;
-                        const double h = Js[0][i] * Js[0][j] + Js[1][i] * Js[1][j];
-                        if (i < 6 && j < 6) Hcc(cols[i], cols[j]) += h;
-                        else if (i < 6 && j >= 6) Hcp(cols[i], cols[j] - nc) += h;
-                        else if (i >= 6 && j >= 6) Hpp[9 * (size_t)o.p + 3 * (i - 6) + (j - 6)] += h;
+                CamRow &cr = cam[k];
+                for (int j = 0; j < 6; j++) {
+                    cr.col[j] = column(ob[k], j);
+                    for (int a = 0; a < 2; a++) cr.Jc[a][j] = cr.col[j] >= 0 ? J[k][a * 9 + j] * scale[cr.col[j]] : 0.0;
+                }
+                for (int i = 0; i < 6; i++) {
+                    if (cr.col[i] < 0) continue;
+                    rhs[cr.col[i]] -= cr.Jc[0][i] * r[2 * k] + cr.Jc[1][i] * r[2 * k + 1];
+                    for (int j = 0; j < 6; j++)
+                        if (cr.col[j] >= 0) S(cr.col[i], cr.col[j]) += cr.Jc[0][i] * cr.Jc[0][j] + cr.Jc[1][i] * cr.Jc[1][j];
+                }
+            }
+            for (int c = 0; c < nc; c++) S(c, c) += damp(S(c, c));
+            std::vector<m3> Vinv(np);
+            std::vector<v3> gpt(np);
+            std::vector<std::array<double, 18>> Wk(ob.size());   // W_k, 6 x 3 row-major
+            bool lin_ok = true;
+            for (int p = 0; p < np && lin_ok; p++) {
+                m3 Vp = zero3();
+                double gp[3] = {0, 0, 0};
+                for (int k : obs_of[p]) {
+                    double Jp[2][3];
+                    for (int a = 0; a < 2; a++) for (int j = 0; j < 3; j++) Jp[a][j] = J[k][a * 9 + 6 + j] * scale[nc + 3 * p + j];
+                    for (int i = 0; i < 3; i++) {
+                        gp[i] += Jp[0][i] * r[2 * k] + Jp[1][i] * r[2 * k + 1];
+                        for (int j = 0; j < 3; j++) Vp.a[i * 3 + j] += Jp[0][i] * Jp[0][j] + Jp[1][i] * Jp[1][j];
+                    }
+                    for (int i = 0; i < 6; i++) for (int j = 0; j < 3; j++) Wk[k][i * 3 + j] = cam[k].Jc[0][i] * Jp[0][j] + cam[k].Jc[1][i] * Jp[1][j];
+                }
+                for (int i = 0; i < 3; i++) Vp.a[i * 4] += damp(Vp.a[i * 4]);
+                if (!(fabs(det(Vp)) > 0)) { lin_ok = false; break; }
+                Vinv[p] = inverse3(Vp);
+                gpt[p] = mk(gp[0], gp[1], gp[2]);
+                for (int k : obs_of[p]) {
+                    double Y[6][3];   // W_k V_p^-1
+                    for (int i = 0; i < 6; i++) for (int j = 0; j < 3; j++)
+                        Y[i][j] = Wk[k][i * 3] * Vinv[p].a[j] + Wk[k][i * 3 + 1] * Vinv[p].a[3 + j] + Wk[k][i * 3 + 2] * Vinv[p].a[6 + j];
+                    for (int i = 0; i < 6; i++) {
+                        const int ci = cam[k].col[i];
+                        if (ci < 0) continue;
+                        rhs[ci] += Y[i][0] * gp[0] + Y[i][1] * gp[1] + Y[i][2] * gp[2];
+                        for (int k2 : obs_of[p])
+                            for (int j = 0; j < 6; j++) {
+                                const int cj = cam[k2].col[j];
+                                if (cj >= 0) S(ci, cj) -= Y[i][0] * Wk[k2][j * 3] + Y[i][1] * Wk[k2][j * 3 + 1] + Y[i][2] * Wk[k2][j * 3 + 2];
+                            }
                     }
                 }
             }
-            auto damp = [&](double d) { return std::min(std::max(d, 1e-6), 1e32) / radius; };
-            for (int c = 0; c < nc; c++) Hcc(c, c) += damp(Hcc(c, c));
-            for (int p = 0; p < np; p++) for (int i = 0; i < 3; i++) Hpp[9 * (size_t)p + 4 * i] += damp(Hpp[9 * (size_t)p + 4 * i]);
-            std::vector<m3> Hpp_inv(np);
-            bool lin_ok = true;
-            for (int p = 0; p < np && lin_ok; p++) {
-                m3 A = ldm(&Hpp[9 * (size_t)p]);
-                if (!(fabs(det(A)) > 0)) lin_ok = false;
-                else Hpp_inv[p] = inverse3(A);
-            }
-            std::vector<double> dx(ntot, 0.0);
             if (lin_ok) {
-                Dense S = Hcc;
-                std::vector<double> rhs(nc);
-                for (int c = 0; c < nc; c++) rhs[c] = -gc[c];
-                for (int p = 0; p < np; p++)
-                    for (int a = 0; a < nc; a++) {
-                        const double wa[3] = {Hcp(a, 3 * p), Hcp(a, 3 * p + 1), Hcp(a, 3 * p + 2)};
-                        if (wa[0] == 0 && wa[1] == 0 && wa[2] == 0) continue;
-                        double wi[3];
-                        for (int j = 0; j < 3; j++) wi[j] = wa[0] * Hpp_inv[p].a[j] + wa[1] * Hpp_inv[p].a[3 + j] + wa[2] * Hpp_inv[p].a[6 + j];
-                        rhs[a] += wi[0] * gp[3 * p] + wi[1] * gp[3 * p + 1] + wi[2] * gp[3 * p + 2];
-                        for (int b = 0; b < nc; b++) S(a, b) -= wi[0] * Hcp(b, 3 * p) + wi[1] * Hcp(b, 3 * p + 1) + wi[2] * Hcp(b, 3 * p + 2);
-                    }
                 if (nc > 0) { if (cholesky(S)) cholesky_solve(S, rhs); else lin_ok = false; }
                 if (lin_ok) {
                     for (int c = 0; c < nc; c++) dx[c] = rhs[c];
-                    for (int p = 0; p < np; p++) {
-                        double b3[3] = {-gp[3 * p], -gp[3 * p + 1], -gp[3 * p + 2]};
-                        for (int a = 0; a < nc; a++) for (int j = 0; j < 3; j++) b3[j] -= Hcp(a, 3 * p + j) * dx[a];
-                        for (int i = 0; i < 3; i++) dx[nc + 3 * p + i] = Hpp_inv[p].a[i * 3] * b3[0] + Hpp_inv[p].a[i * 3 + 1] * b3[1] + Hpp_inv[p].a[i * 3 + 2] * b3[2];
+                    for (int p = 0; p < np; p++) {   // back-substitution: dx_p = V_p^-1 (-g_p - sum_k W_k^T dx_cam(k))
+                        v3 b3 = neg(gpt[p]);
+                        for (int k : obs_of[p])
+                            for (int i = 0; i < 6; i++) {
+                                const int ci = cam[k].col[i];
+                                if (ci >= 0) b3 = sub(b3, scl(dx[ci], mk(Wk[k][i * 3], Wk[k][i * 3 + 1], Wk[k][i * 3 + 2])));
+                            }
+                        const v3 d = mul(Vinv[p], b3);
+                        dx[nc + 3 * p] = d.x; dx[nc + 3 * p + 1] = d.y; dx[nc + 3 * p + 2] = d.z;
                     }
                 }
             }

@@ -50,6 +50,10 @@ struct vio_batch {
         hipEvent_t ev_solve = nullptr, ev_fe = nullptr, ev_be = nullptr, ev_ingest = nullptr;
         hipStream_t copy_stream = nullptr;   // host -> HBM uploads of vio_feed (on_device == 0), beside the kernels of the previous frame
         hipEvent_t ev_up_gray = nullptr, ev_up_depth = nullptr;
+        // host -> HBM uploads enqueued on fe_stream / stream by the non-overlap entry points (vio_track, vio_process, vio_process_obs*):
+        // asynchronous when the caller's buffers are page-locked, so the next call that takes host buffers waits for them first
+        hipEvent_t ev_host_fe = nullptr, ev_host_be = nullptr;
+        bool host_fe_pending = false, host_be_pending = false;
         bool have_solve_ev = false, have_ingest_ev = false;
     };
     std::vector<Group> groups;
@@ -141,6 +145,7 @@ static int sync_all(vio_batch *h) {
         if (g.copy_stream) HIPCHK(hipStreamSynchronize(g.copy_stream));
         HIPCHK(hipStreamSynchronize(g.fe_stream));
         HIPCHK(hipStreamSynchronize(g.stream));
+        g.host_fe_pending = g.host_be_pending = false;
     }
     return VIO_OK;
 }
@@ -708,21 +713,27 @@ static int build_devcfg(const vio_config *cfg, int imu_capacity, DevCfg &C) {
 static int create_group_streams(vio_batch *h, vio_batch::Group &g, bool partitioned) {
     if (g.stream) { (void)hipStreamDestroy(g.stream); g.stream = nullptr; }
     if (g.fe_stream) { (void)hipStreamDestroy(g.fe_stream); g.fe_stream = nullptr; }
+    // the partition is sized from the device: a quarter of its compute units (64 of the MI355X's 256 = two XCDs) for the front-end by
+    // default; parts with a different CU count get the same proportion, and a split that leaves either side empty falls back to
+    // unpartitioned streams
+    int n_cu = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 0;
     const char *fe_cus_env = getenv("VIO_FE_CUS");
-    const int fe_cus = fe_cus_env ? atoi(fe_cus_env) : 64;
+    const int fe_cus = fe_cus_env ? atoi(fe_cus_env) : n_cu / 4;
     hipError_t e_fe, e_be;
-    if (partitioned && fe_cus > 0 && fe_cus < 256) {
-        uint32_t mfe[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mbe[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (partitioned && n_cu >= 8 && n_cu <= 1024 && fe_cus > 0 && fe_cus < n_cu) {
+        const int nw = (n_cu + 31) / 32;
+        std::vector<uint32_t> mfe(nw, 0u), mbe(nw, 0u);
         const int ng = (int)h->groups.size(), gi = (int)(&g - &h->groups[0]);
-        const bool split = getenv("VIO_BE_CU_SPLIT") && atoi(getenv("VIO_BE_CU_SPLIT")) != 0 && ng > 1;
-        const int per = (256 - fe_cus) / ng;
-        const int b0 = split ? fe_cus + gi * per : fe_cus, b1 = split ? (gi == ng - 1 ? 256 : b0 + per) : 256;
-        for (int q = 0; q < 256; q++) {
+        const bool split = getenv("VIO_BE_CU_SPLIT") && atoi(getenv("VIO_BE_CU_SPLIT")) != 0 && ng > 1 && (n_cu - fe_cus) / ng >= 1;
+        const int per = (n_cu - fe_cus) / ng;
+        const int b0 = split ? fe_cus + gi * per : fe_cus, b1 = split ? (gi == ng - 1 ? n_cu : b0 + per) : n_cu;
+        for (int q = 0; q < n_cu; q++) {
             if (q < fe_cus) mfe[q >> 5] |= 1u << (q & 31);
             if (q >= b0 && q < b1) mbe[q >> 5] |= 1u << (q & 31);
         }
-        e_fe = hipExtStreamCreateWithCUMask(&g.fe_stream, 8, mfe);
-        e_be = getenv("VIO_BE_CU_ALL") ? hipStreamCreate(&g.stream) : hipExtStreamCreateWithCUMask(&g.stream, 8, mbe);
+        e_fe = hipExtStreamCreateWithCUMask(&g.fe_stream, (uint32_t)nw, mfe.data());
+        e_be = getenv("VIO_BE_CU_ALL") ? hipStreamCreate(&g.stream) : hipExtStreamCreateWithCUMask(&g.stream, (uint32_t)nw, mbe.data());
     } else {
         e_fe = hipStreamCreate(&g.fe_stream);
         e_be = hipStreamCreate(&g.stream);
@@ -898,6 +909,8 @@ void vio_destroy(vio_batch *h) {
         if (g.ev_ingest) (void)hipEventDestroy(g.ev_ingest);
         if (g.ev_up_gray) (void)hipEventDestroy(g.ev_up_gray);
         if (g.ev_up_depth) (void)hipEventDestroy(g.ev_up_depth);
+        if (g.ev_host_fe) (void)hipEventDestroy(g.ev_host_fe);
+        if (g.ev_host_be) (void)hipEventDestroy(g.ev_host_be);
         if (g.copy_stream) (void)hipStreamDestroy(g.copy_stream);
     }
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -997,6 +1010,26 @@ static int be_wait(vio_batch::Group &g) {
 
 static const IngestSrc kTrackerMap = {nullptr, nullptr, nullptr, nullptr, 0};
 
+// Host buffers handed to a previous non-overlap call are free again once this returns (include/vio_abi.h "Host buffers").
+static int wait_host_uploads(vio_batch *h) {
+    for (auto &g : h->groups) {
+        if (g.host_fe_pending) { HIPCHK(hipEventSynchronize(g.ev_host_fe)); g.host_fe_pending = false; }
+        if (g.host_be_pending) { HIPCHK(hipEventSynchronize(g.ev_host_be)); g.host_be_pending = false; }
+    }
+    return VIO_OK;
+}
+static int note_host_upload(vio_batch::Group &g, bool fe, bool be) {
+    if (fe) {
+        if (!g.ev_host_fe) HIPCHK(hipEventCreateWithFlags(&g.ev_host_fe, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(g.ev_host_fe, g.fe_stream)); g.host_fe_pending = true;
+    }
+    if (be) {
+        if (!g.ev_host_be) HIPCHK(hipEventCreateWithFlags(&g.ev_host_be, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(g.ev_host_be, g.stream)); g.host_be_pending = true;
+    }
+    return VIO_OK;
+}
+
 // per-call side inputs of the front-end (frame modes, caller-supplied relative rotations): group slices, on the group's fe_stream
 static int stage_side_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *modes, const double *R_rel) {
     if (modes) HIPCHK(hipMemcpyAsync(h->d_modes + g.s0, modes + g.s0, (size_t)g.n, hipMemcpyHostToDevice, g.fe_stream));
@@ -1037,7 +1070,9 @@ int vio_feed(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const 
 
 static int track_impl(vio_batch *h, const uint8_t *gray, const double *stamps, int publish, const uint8_t *modes, const double *R_rel, int on_device) {
     if (!h || !gray || !stamps) return VIO_EINVAL;
-    int rc = flush_imu_frontend(h);
+    int rc = wait_host_uploads(h);
+    if (rc != VIO_OK) return rc;
+    rc = flush_imu_frontend(h);
     if (rc != VIO_OK) return rc;
     for (auto &g : h->groups) {
         if ((rc = fe_wait(h, g)) != VIO_OK) return rc;
@@ -1047,6 +1082,7 @@ static int track_impl(vio_batch *h, const uint8_t *gray, const double *stamps, i
         rc = stage_inputs(h, g, gray, nullptr, stamps, on_device, &dg, &dd);
         if (rc != VIO_OK) return rc;
         if ((rc = stage_side_inputs(h, g, modes, R_rel)) != VIO_OK) return rc;
+        if ((rc = note_host_upload(g, true, false)) != VIO_OK) return rc;
         rc = launch_frontend(h, g, dg, publish ? 1 : 0, 0, modes ? h->d_modes : nullptr, R_rel ? h->d_rrel : nullptr);
         if (rc != VIO_OK) return rc;
         if ((rc = be_wait(g)) != VIO_OK) return rc;
@@ -1106,7 +1142,9 @@ int vio_get_latest_odometry(vio_batch *h, int seq, double *out11) {
 
 int vio_process(vio_batch *h, const uint16_t *depth_mm, int on_device) {
     if (!h || !depth_mm) return VIO_EINVAL;
-    int rc = refresh_dynamic_state(h);
+    int rc = wait_host_uploads(h);
+    if (rc != VIO_OK) return rc;
+    rc = refresh_dynamic_state(h);
     if (rc != VIO_OK) return rc;
     rc = flush_imu_backend(h);
     if (rc != VIO_OK) return rc;
@@ -1115,6 +1153,7 @@ int vio_process(vio_batch *h, const uint16_t *depth_mm, int on_device) {
         const uint16_t *dd = nullptr;
         rc = stage_inputs(h, g, nullptr, depth_mm, nullptr, on_device, &dg, &dd);
         if (rc != VIO_OK) return rc;
+        if (!on_device && (rc = note_host_upload(g, false, true)) != VIO_OK) return rc;
         rc = launch_backend(h, g, dd, kTrackerMap);
         if (rc != VIO_OK) return rc;
         HIPCHK(hipEventRecord(g.ev_be, g.stream));
@@ -1128,7 +1167,9 @@ int vio_process_obs_batch(vio_batch *h, const int32_t *n_obs, const int32_t *ids
     const int NP = h->hc.NP;
     for (int s = 0; s < h->S; s++)
         if (n_obs[s] > cap || n_obs[s] > NP) { g_err = "feature map larger than the tracker capacity (vio_get_capacity)"; return VIO_ECAPACITY; }
-    int rc = refresh_dynamic_state(h);
+    int rc = wait_host_uploads(h);
+    if (rc != VIO_OK) return rc;
+    rc = refresh_dynamic_state(h);
     if (rc != VIO_OK) return rc;
     rc = flush_imu_backend(h);
     if (rc != VIO_OK) return rc;
@@ -1144,6 +1185,7 @@ int vio_process_obs_batch(vio_batch *h, const int32_t *n_obs, const int32_t *ids
             HIPCHK(hipMemcpyAsync(h->d_in_ids + (size_t)s * NP, ids + (size_t)s * cap, (size_t)n_obs[s] * sizeof(int), hipMemcpyHostToDevice, g.stream));
             HIPCHK(hipMemcpyAsync(h->d_in_obs + (size_t)s * NP * 7, obs + (size_t)s * cap * 7, (size_t)n_obs[s] * 7 * sizeof(double), hipMemcpyHostToDevice, g.stream));
         }
+        if ((rc = note_host_upload(g, false, true)) != VIO_OK) return rc;
         IngestSrc src = {h->d_in_n, h->d_in_ids, h->d_in_obs, h->d_in_stamps, NP};
         rc = launch_backend(h, g, dd, src);
         if (rc != VIO_OK) return rc;
@@ -1158,7 +1200,9 @@ int vio_process_obs(vio_batch *h, int seq, int n, const int32_t *ids, const doub
     const DevCfg &C = h->hc;
     const int NP = C.NP;
     if (n > NP) { g_err = "feature map larger than the tracker capacity (vio_get_capacity)"; return VIO_ECAPACITY; }
-    int rc = flush_imu_backend(h);
+    int rc = wait_host_uploads(h);
+    if (rc != VIO_OK) return rc;
+    rc = flush_imu_backend(h);
     if (rc != VIO_OK) return rc;
     vio_batch::Group *gp = &h->groups[0];
     for (auto &g : h->groups)
@@ -1171,6 +1215,7 @@ int vio_process_obs(vio_batch *h, int seq, int n, const int32_t *ids, const doub
     HIPCHK(hipMemcpyAsync(h->d_in_stamps + seq, &stamp, sizeof(double), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipMemcpyAsync(h->d_in_ids + (size_t)seq * NP, ids, (size_t)n * sizeof(int), hipMemcpyHostToDevice, g.stream));
     HIPCHK(hipMemcpyAsync(h->d_in_obs + (size_t)seq * NP * 7, obs, (size_t)n * 7 * sizeof(double), hipMemcpyHostToDevice, g.stream));
+    if ((rc = note_host_upload(g, false, true)) != VIO_OK) return rc;
     IngestSrc src = {h->d_in_n, h->d_in_ids, h->d_in_obs, h->d_in_stamps, NP};
     rc = launch_backend(h, g, h->d_depth_stage, src, seq);
     if (rc != VIO_OK) return rc;

@@ -222,21 +222,76 @@ def _read_assoc(path):
     return out
 
 
+class ColorDepthSync:
+    """The colour / depth pairing at the top of EstimatorNodelet::process_tracker (estimator_nodelet.cpp:200-232): two FIFO queues
+    (img_buf, depth_buf); while both are non-empty compare the front stamps -- colour more than 3 ms OLDER than depth: pop colour
+    ("throw color"); more than 3 ms NEWER: pop depth ("throw depth"); otherwise pop both as a pair.  `pop()` returns the next pair
+    ``(colour_item, depth_item)`` or None when one queue ran dry (the nodelet waits on its condition variable there)."""
+    TOLERANCE = 0.003
+
+    def __init__(self):
+        from collections import deque
+        self.img_buf, self.depth_buf = deque(), deque()
+        self.thrown_color = self.thrown_depth = 0
+
+    def push_color(self, stamp, item):     # img_callback (estimator_nodelet.cpp:128-140)
+        self.img_buf.append((float(stamp), item))
+
+    def push_depth(self, stamp, item):     # depth_callback (:142-154)
+        self.depth_buf.append((float(stamp), item))
+
+    def pop(self):
+        while self.img_buf and self.depth_buf:
+            time_color, time_depth = self.img_buf[0][0], self.depth_buf[0][0]
+            if time_color < time_depth - self.TOLERANCE:
+                self.img_buf.popleft()
+                self.thrown_color += 1
+            elif time_color > time_depth + self.TOLERANCE:
+                self.depth_buf.popleft()
+                self.thrown_depth += 1
+            else:
+                return self.img_buf.popleft(), self.depth_buf.popleft()
+        return None
+
+
+def pair_color_depth(color_stamps, depth_stamps):
+    """Index pairs (i, j) the nodelet's two-queue rule forms from two stamp lists in arrival order (offline use of ColorDepthSync)."""
+    sync = ColorDepthSync()
+    for i, t in enumerate(color_stamps):
+        sync.push_color(t, i)
+    for j, t in enumerate(depth_stamps):
+        sync.push_depth(t, j)
+    out = []
+    while True:
+        p = sync.pop()
+        if p is None:
+            return out
+        out.append((p[0][1], p[1][1]))
+
+
 class RgbdImuDirectory:
     """A rosbag-free recording: rgb.txt + depth.txt (``stamp relative/path.png``) and imu.txt (``stamp ax ay az gx gy gz``).
-    Colour and depth frames are paired like the nodelet's ApproximateTime synchroniser with a fixed tolerance."""
+    Colour and depth frames are paired by the nodelet's own rule (ColorDepthSync: +-3 ms, two queues, estimator_nodelet.cpp:206-232);
+    a frame's stamp is the colour stamp (:234 onwards uses time_color).  ``pairing="nearest"`` (not upstream) matches every colour
+    frame with the nearest depth frame within ``max_dt`` instead -- for datasets whose streams are not hardware-synchronised."""
 
-    def __init__(self, root, max_dt=0.02):
+    def __init__(self, root, pairing="nodelet", max_dt=0.02):
         self.root = root
         rgb, dep = _read_assoc(os.path.join(root, "rgb.txt")), _read_assoc(os.path.join(root, "depth.txt"))
-        dt = np.array([t for t, _ in dep])
         self.pairs = []
-        for t, f in rgb:
-            if len(dt) == 0:
-                break
-            k = int(np.argmin(np.abs(dt - t)))
-            if abs(dt[k] - t) <= max_dt:
-                self.pairs.append((t, f, dep[k][1]))
+        if pairing == "nodelet":
+            for i, j in pair_color_depth([t for t, _ in rgb], [t for t, _ in dep]):
+                self.pairs.append((rgb[i][0], rgb[i][1], dep[j][1]))
+        elif pairing == "nearest":
+            dt = np.array([t for t, _ in dep])
+            for t, f in rgb:
+                if len(dt) == 0:
+                    break
+                k = int(np.argmin(np.abs(dt - t)))
+                if abs(dt[k] - t) <= max_dt:
+                    self.pairs.append((t, f, dep[k][1]))
+        else:
+            raise ValueError("pairing must be 'nodelet' or 'nearest'")
         imu = np.loadtxt(os.path.join(root, "imu.txt"), comments="#", ndmin=2)
         if imu.shape[1] < 7:
             raise ValueError("imu.txt needs 7 columns: stamp ax ay az gx gy gz")
@@ -255,20 +310,21 @@ class RgbdImuDirectory:
         return t, gray, np.ascontiguousarray(depth)
 
 
-def write_recording(root, stamps, grays, depths, imu_t, imu_acc, imu_gyr):
-    """Inverse of RgbdImuDirectory (used by the tests and handy for exporting synthetic sequences)."""
+def write_recording(root, stamps, grays, depths, imu_t, imu_acc, imu_gyr, depth_stamps=None):
+    """Inverse of RgbdImuDirectory (used by the tests and handy for exporting synthetic sequences).  depth_stamps: stamps of the depth
+    frames when they differ from the colour stamps (same count)."""
     from PIL import Image
     os.makedirs(os.path.join(root, "rgb"), exist_ok=True)
     os.makedirs(os.path.join(root, "depth"), exist_ok=True)
     with open(os.path.join(root, "rgb.txt"), "w") as fr, open(os.path.join(root, "depth.txt"), "w") as fd:
         fr.write("# stamp filename\n")
         fd.write("# stamp filename\n")
-        for t, g, d in zip(stamps, grays, depths):
+        for k, (t, g, d) in enumerate(zip(stamps, grays, depths)):
             name = "%.6f.png" % t
             Image.fromarray(np.asarray(g, np.uint8)).save(os.path.join(root, "rgb", name))
             Image.fromarray(np.asarray(d, np.uint16)).save(os.path.join(root, "depth", name))
             fr.write("%.9f rgb/%s\n" % (t, name))
-            fd.write("%.9f depth/%s\n" % (t, name))
+            fd.write("%.9f depth/%s\n" % (t if depth_stamps is None else depth_stamps[k], name))
     np.savetxt(os.path.join(root, "imu.txt"), np.c_[imu_t, imu_acc, imu_gyr], fmt="%.17g", header="stamp ax ay az gx gy gz")
 
 
