@@ -76,6 +76,7 @@ def aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K, lag=0, seq0=0):
         b.feed(gray[f], depth[f], np.full(S, times[f]), on_device=True)
     b.sync()
     torch.cuda.synchronize()
+    b.profile_begin(K)
     t0 = time.perf_counter()
     for k in range(K):
         f = n_pre + Wm + k
@@ -83,11 +84,13 @@ def aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K, lag=0, seq0=0):
     b.sync()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    _, kms = b.profile_end()
     ok = all(st.solver_flag == 1 for st in b.status_all())
     b.close()
     del gray, depth
     torch.cuda.empty_cache()
-    return dict(sequences_per_gpu=S, tracker_lag=lag, frames_per_s=S * K / el, ms_per_step=el / K * 1e3, steps=K, valid=bool(ok))
+    return dict(sequences_per_gpu=S, tracker_lag=lag, frames_per_s=S * K / el, ms_per_step=el / K * 1e3, steps=K, valid=bool(ok),
+                kernels_ms={k: round(v, 4) for k, v in kms.items()})
 
 
 def _cpu_worker(job):

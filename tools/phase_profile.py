@@ -66,7 +66,7 @@ def main():
             print("%3d %-28s %8.1f us/frame" % (k, NAMES[k], us[k]))
     print("MARGIN_OLD frames of sequence 0: %d of %d; direct (Cholesky) pseudo-inverse in %d marginalisations" % (int(out[31]), a.frames, int(out[26])))
     print("solve top-level sum %.1f us, marg sum %.1f us" % (sum(us[k] for k in (0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)), sum(us[16:24])))
-    print("ps_serial sum %.1f us/frame" % sum(us[48:56]) + us[56] + us[57] + us[58])
+    print("ps_serial sum %.1f us/frame" % float(sum(us[48:56]) + us[56] + us[57] + us[58]))
 
 
 if __name__ == "__main__":
