@@ -57,8 +57,14 @@ def frontend_bytes(w, h, n, levels):
     return dict(pyrdown=w * h + sum(w * h // 4 ** l for l in range(1, levels + 1)), fast=w * h, lk=n * (levels + 1) * 2 * 23 * 23)
 
 
+def config5(P):
+    """BASELINE configs[4]: 1280x720, 300 features, 7x8 grid, 20-keyframe window (intrinsics of the canonical camera scaled x2 / x1.5)"""
+    return P.canonical_config(width=1280, height=720, max_cnt=300, window_size=20, grid_rows=7, grid_cols=8, max_landmarks=2048,
+                              fx=604.5821781259577 * 2, fy=604.2544712985845 * 1.5, cx=321.2638233484251 * 2, cy=239.70969315130674 * 1.5)
+
+
 def aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K, lag=0, seq0=0):
-    """frames/s of the same step at another batch size / tracker ordering (auxiliary data point, never `value`)."""
+    """frames/s of the same step at another batch size / tracker ordering / configuration (auxiliary data point, never `value`)."""
     H, Wd = cfg.height, cfg.width
     F = n_pre + Wm + K
     syn = P.Synth(sc)
@@ -85,12 +91,16 @@ def aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K, lag=0, seq0=0):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     _, kms = b.profile_end()
-    ok = all(st.solver_flag == 1 for st in b.status_all())
+    stats = b.status_all()
+    ok = all(st.solver_flag == 1 for st in stats)
+    sol = dict(mean_residuals=float(np.mean([st.n_residuals for st in stats])), mean_var_landmarks=float(np.mean([st.n_var_landmarks for st in stats])),
+               mean_in_problem=float(np.mean([st.n_in_problem for st in stats])), mean_iterations_last_frame=float(np.mean([st.iterations for st in stats])),
+               reboots=int(sum(st.reboot_count for st in stats)), overflow_frames=int(sum(st.overflow_frames for st in stats)))
     b.close()
     del gray, depth
     torch.cuda.empty_cache()
     return dict(sequences_per_gpu=S, tracker_lag=lag, frames_per_s=S * K / el, ms_per_step=el / K * 1e3, steps=K, valid=bool(ok),
-                kernels_ms={k: round(v, 4) for k, v in kms.items()})
+                kernels_ms={k: round(v, 4) for k, v in kms.items()}, solver=sol)
 
 
 def _cpu_worker(job):
@@ -504,6 +514,20 @@ def main():
         for s_aux in (256, 512):
             os.environ["VIO_GROUP_SEQS"] = str(s_aux // 2)
             out["aux_s%d" % s_aux] = aux_rate(P, vio_ct, torch, cfg, sc, dev, s_aux, n_pre, Wm, K, lag=args.tracker_lag)
+        # BASELINE configs[4] at its per-GPU batch (64 sequences of 1280x720 / 300 features / W = 20): the phased solver with the Schur
+        # complement in HBM / L2 (ps_serial_big_kernel)
+        os.environ["VIO_GROUP_SEQS"] = "32"
+        cfg5 = config5(P)
+        c5 = aux_rate(P, vio_ct, torch, cfg5, vio_ct.synth_like(cfg5), dev, 64, cfg5.window_size + 8, min(Wm, 6), min(K, 20), lag=args.tracker_lag)
+        sl = c5["solver"]
+        fl5 = backend_flops(max(sl["mean_iterations_last_frame"], 1.0), sl["mean_residuals"], sl["mean_var_landmarks"],
+                            sl["mean_residuals"] / max(sl["mean_in_problem"], 1.0) + 1.0, cfg5.window_size, sc.imu_rate / sc.cam_rate)
+        c5["roofline"] = dict(bound="mfma", kernel="ps_* (phased solver, HBM-resident Schur complement)", unit="TFLOP/s", peak=FP64_PEAK_TFLOPS,
+                              achieved=fl5["solve"] * 32 / (c5["kernels_ms"]["be_solve"] * 1e-3) / 1e12,
+                              frac=fl5["solve"] * 32 / (c5["kernels_ms"]["be_solve"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, sequences_per_launch=32,
+                              note="SURVEY.md 8d flops with the counts of the last timed frame")
+        c5["workload"] = "BASELINE configs[4]: 64 sequences of 1280x720, 300 features, 7x8 grid, 20-keyframe window per GPU"
+        out["config5"] = c5
         os.environ["VIO_GROUP_SEQS"] = str(per_group)
     if rank == 0:
         print(json.dumps(out))

@@ -29,12 +29,16 @@ def _oracle_worker(job):
     seq, n_frames, lag, cfg_kw = job
     import vio_ct
     P = vio_ct.pkg()
+    want_status = bool(cfg_kw.pop("_status", False)) if isinstance(cfg_kw, dict) else False
     cfg = P.canonical_config(**cfg_kw)
     sc = vio_ct.synth_like(cfg)
     o = vio_ct.run_oracle_sequence(cfg, sc, seq, n_frames, tracker_lag=lag)
     fr = np.array([x[0] for x in o["traj"]], np.int32)
     po = np.array([x[1] for x in o["traj"]])
     gt = np.array(o["gt"])
+    if want_status:   # per-frame decisions for the tests that compare them
+        keys = ("solver_flag", "frame_count", "n_landmarks", "marginalization_flag", "n_residuals", "n_in_problem", "n_var_landmarks", "iterations")
+        return seq, fr, po, gt, int(o["oracle"].status()["reboot_count"]), np.array([[st[k] for k in keys] for st in o["status"]]), np.array(o["processed"])
     return seq, fr, po, gt, int(o["oracle"].status()["reboot_count"])
 
 
@@ -46,7 +50,7 @@ def run_oracle_pool(seqs, n_frames, lag=0, cfg_kw=None, procs=None):
     return {r[0]: r[1:] for r in res}
 
 
-def run_hip(P, cfg, sc, seq0, S, n_frames, lag=0, chunk=50, check_render=True):
+def run_hip(P, cfg, sc, seq0, S, n_frames, lag=0, chunk=50, check_render=True, per_frame=None, keep=False):
     """vio_feed over S device-rendered sequences, frames rendered chunk by chunk into one HBM buffer; returns per sequence the
     odometry history rows [stamp, P(3), Q(4), V(3)], the final status, and the wall time of the feed loop"""
     import vio_ct
@@ -77,12 +81,16 @@ def run_hip(P, cfg, sc, seq0, S, n_frames, lag=0, chunk=50, check_render=True):
         c0 = time.perf_counter()
         for k in range(n):
             b.feed(g.at(k * S * hw), d.at(k * S * hw * 2), np.full(S, times[f0 + k]), on_device=True)
+            if per_frame is not None:
+                per_frame(f0 + k, b)
         b.sync()
         t_feed += time.perf_counter() - c0
     hist = [b.odometry_history(s) for s in range(S)]
     stats = b.status_all()
-    b.close()
     g.free(); d.free()
+    if keep:
+        return hist, stats, t_feed, b
+    b.close()
     return hist, stats, t_feed
 
 

@@ -66,3 +66,43 @@ def test_two_ranks_drive_the_hip_path_on_one_gpu(tmp_path):
     assert np.array_equal(a["windows"], b["windows"]) and np.array_equal(a["odometry"], b["odometry"])
     r0 = np.load(d2 + ".rank0.npz")
     assert int(r0["seq0"]) == 0 and not np.array_equal(r0["windows"], a["windows"])
+
+
+def test_config5_batch_of_64_on_the_phased_solver(P):
+    """BASELINE configs[4] at its per-GPU batch: 64 sequences x 1280x720, 300 features, 7x8 grid, 20-keyframe window (W is a compile-time
+    10 upstream, parameters.h:12; a run-time parameter here).  P = 322: the Schur complement (231 tiles) does not fit LDS, the phased
+    solver keeps it in HBM / L2 and streams it through the Cholesky one block column at a time (ps_serial_big_kernel).  Four sequences
+    against the oracle (identical decisions every frame, positions within 1e-5 m); every fourth sequence of the 64 bit-identical to its
+    stand-alone (S = 1) run."""
+    kw = dict(width=1280, height=720, max_cnt=300, window_size=20, grid_rows=7, grid_cols=8, max_landmarks=2048,
+              fx=604.5821781259577 * 2, fy=604.2544712985845 * 1.5, cx=321.2638233484251 * 2, cy=239.70969315130674 * 1.5)
+    cfg = P.canonical_config(**kw)
+    sc = vio_ct.synth_like(cfg)
+    S, seq0, n_frames = 64, 40, 44
+    chk = [0, 21, 42, 63]
+    seen = {i: [] for i in chk}
+    def grab(f, b):
+        for i in chk:
+            st = b.status(i)
+            seen[i].append((st.solver_flag, st.frame_count, st.n_landmarks, st.marginalization_flag, st.n_residuals, st.n_in_problem, st.n_var_landmarks,
+                            st.iterations, st.processed, st.code))
+    hist, stats, t_feed, b = parity_long.run_hip(P, cfg, sc, seq0, S, n_frames, chunk=11, per_frame=grab, keep=True)
+    assert all(st.solver_flag == 1 and st.reboot_count == 0 and st.overflow_frames == 0 for st in stats)
+    wins = [b.window(i).copy() for i in range(S)]
+    b.close()
+    orc = parity_long.run_oracle_pool([seq0 + i for i in chk], n_frames, cfg_kw=dict(kw, _status=True), procs=len(chk))
+    for i in chk:
+        fr, po, gt, reb, ost, oproc = orc[seq0 + i]
+        assert reb == 0 and len(po) >= 18
+        for f in range(n_frames):
+            sh = seen[i][f]
+            assert tuple(int(x) for x in ost[f][:3]) == sh[:3], (i, f, ost[f], sh)
+            if sh[0] == 1 and sh[8]:
+                assert tuple(int(x) for x in ost[f][3:8]) == sh[3:8], (i, f, ost[f], sh)      # marginalisation flag, residuals, landmarks, iterations
+        h = hist[i]
+        assert len(h) == len(po) and np.abs(h[:, 1:4] - po).max() < 1e-5, (i, float(np.abs(h[:, 1:4] - po).max()))
+        assert vio_ct.ate_rmse(h[:, 1:4], gt) < 0.03
+    for i in range(0, S, 4):
+        h1, st1, _, b1 = parity_long.run_hip(P, cfg, sc, seq0 + i, 1, n_frames, chunk=n_frames, check_render=False, keep=True)
+        assert np.array_equal(b1.window(0), wins[i]) and np.array_equal(h1[0], hist[i]), i
+        b1.close()

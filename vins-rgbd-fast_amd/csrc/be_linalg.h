@@ -843,47 +843,91 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
-// Look-ahead: while the other wavefronts run the trailing update of step p, wavefront 0 updates tile (p+1, p+1) first and factors
-// it straight away, so the serial 16-step diagonal factorisation is off the critical path.  dinv[16 nb] receives 1 / l_jj.
-// rhs (optional, 16 nb doubles in LDS): the forward substitution L y = rhs rides along -- the right-hand side is one more row of the
-// panel (solved against L_pp with the tile rows) and of the trailing update (last wavefront), so that only the backward half
-// (chol_backward_tiles) is left to do afterwards.  Same operations in the same order as chol_forward_tiles.
+// ---- pieces shared by the tile Cholesky variants.  D = one 16 x 16 tile (256 doubles, element (r, c) at (r << 4) + (c ^ r)).
+// Diagonal block by ONE wavefront on the matrix core: the tile is held SYMMETRIC in the accumulator layout of v_mfma_f64_16x16x4
+// (acc[r] = S[lk + 4 r][li]) and every pivot step is one rank-1 MFMA S -= l l^T whose operands need no cross-lane traffic: row j of the
+// symmetric tile -- which is column j -- already sits in the lanes lk == j % 4, exactly the k-slot an operand lane feeds.  Only the
+// pivot itself is broadcast (v_readlane).  Previously the rank-1 update was 14 readlane pairs + 14 multiply-subtracts per pivot
+// (~370 cycles); this is one readlane pair, the reciprocal square root, one multiply and one MFMA.
+// Input: the COMPLETE symmetric tile (every producer writes both triangles: the tile loaders, the MFMA trailing updates).
+// Output: L in the lower triangle of D (diagonal included), 1 / l_jj in dinv16, and -- computed right after by the same wavefront --
+// the strictly lower part of M = L^-1 in the strictly UPPER triangle of D (M[i][c], i > c, at row c, column i; M[c][c] = dinv16[c]).
+// With M the panel below the block is a small matrix product on the matrix core (X = A M^T) instead of a 16-step substitution per
+// row, and the triangular solves of the substitution phases are dot products.
+__device__ __forceinline__ void chol_diag_tile(double *D, double *dinv16, int *sh_flag) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    // acc = the symmetric tile S; fcc = F = E^T where E starts as the identity "panel" below the block: eliminating S from
+    // [[S, I], [I, 0]] leaves E = L^-T, i.e. the finished column j of E is row j of M = L^-1 (the panel operation applied to the identity).
+    // In the transposed form row j of F sits in the lanes lk == j % 4 like row j of S, so its update is the same kind of rank-1 MFMA.
+    v4f64 acc, fcc;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = lk + 4 * r;
+        acc[r] = D[(row << 4) + (li ^ row)];     // (diagonal tiles are stored complete: both triangles, bitwise symmetric)
+        fcc[r] = row == li ? 1.0 : 0.0;
+    }
+    bool ok = true;
+    double lcol[4], mrow[4];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const double ajj = bcast_lane(acc[j >> 2], j + 16 * (j & 3));   // S[j][j]: lane li = j, lk = j % 4, register j / 4
+        ok = ok && (ajj > 0.0) && isfinite(ajj);
+        const double rl = rsqrt(ajj);
+        const bool own = lk == (j & 3);
+        const double lj = own ? acc[j >> 2] * rl : 0.0;    // L[li][j] in the k-slot j % 4, zeros in the other three
+        const double ej = own ? fcc[j >> 2] * rl : 0.0;    // M[j][li]
+        if (own) { lcol[j >> 2] = lj; mrow[j >> 2] = ej; }
+        if (lane == j + 16 * (j & 3)) dinv16[j] = rl;
+        if (j < 15) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lj, lj, acc, 0, 0, 0);
+            fcc = __builtin_amdgcn_mfma_f64_16x16x4f64(-lj, ej, fcc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int j = lk + 4 * q;
+        if (li >= j) D[(li << 4) + (j ^ li)] = lcol[q];          // L[li][j]
+        else D[(li << 4) + (j ^ li)] = mrow[q];                   // M[j][li], li < j, at (row li, column j)
+    }
+    if (!ok && lane == 0) *sh_flag = 0;
+    WAVE_SYNC();
+}
+// element (n, k) of M = L^-1 from a factored diagonal tile (chol_diag_tile)
+__device__ __forceinline__ double chol_minv(const double *D, const double *dinv16, int n, int k) {
+    return k < n ? D[(k << 4) + (n ^ k)] : (k == n ? dinv16[n] : 0.0);
+}
+// panel tile X = A M^T on the matrix core, in place (one wavefront): X[m][n] = sum_k A[m][k] M[n][k]
+__device__ __forceinline__ void chol_panel_tile(double *A, const double *D, const double *dinv16) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    v4f64 x = {0, 0, 0, 0};
+    double a[4], b[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) { const int k = 4 * kk + lk; a[kk] = A[(li << 4) + (k ^ li)]; b[kk] = chol_minv(D, dinv16, li, k); }
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) x = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], x, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) A[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))] = x[r];
+}
+// y = M b for one 16-vector (forward substitution step of the right-hand side), lanes 0 .. 15 of the calling wavefront
+__device__ __forceinline__ void chol_rhs_block(double *b16, const double *D, const double *dinv16) {
+    const int lane = threadIdx.x & 63;
+    double y = 0;
+    if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) y += chol_minv(D, dinv16, lane, k) * b16[k];
+    }
+    WAVE_SYNC();
+    if (lane < 16) b16[lane] = y;
+    WAVE_SYNC();
+}
+
+// Right-looking tile Cholesky of S resident in LDS.  Look-ahead: while the other wavefronts run the trailing update of step p,
+// wavefront 0 updates tile (p+1, p+1) first and factors it straight away (chol_diag_tile), so the diagonal factorisation is off the
+// critical path.  dinv[16 nb] receives 1 / l_jj.  rhs (optional, 16 nb doubles in LDS): the forward substitution L y = rhs rides along.
 __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, double *dinv, float *tm = nullptr, double *rhs = nullptr) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    // 16x16 diagonal block: lanes 0..15 of wavefront 0 hold one row each in registers, readlane broadcasts the pivots.  Branch-free and
-    // software-pipelined: column j+1 is updated first and its pivot's reciprocal square root (the one slow operation of a step) is
-    // started before the remaining columns take their rank-1 term, so that its latency hides behind them.
-    auto factor_diag = [&](int p) {
-        const int row = lane & 15;
-        double a[16];
-#pragma unroll
-        for (int cc = 0; cc < 16; cc++) a[cc] = T[tl_idx(p, p, row, cc)];
-        bool ok = true;
-        double ajj = bcast_lane(a[0], 0);
-        double rl = rsqrt(ajj);       // l = a * rsqrt(a), 1 / l = rsqrt(a)
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-            ok = ok && (ajj > 0.0) && isfinite(ajj);
-            const double l = ajj * rl;
-            if (lane < 16 && row == j) dinv[16 * p + j] = rl;
-            // (entries above the diagonal are never read back: they take the same updates as the rest, unselected, and are dropped at the end)
-            a[j] = row == j ? l : a[j] * rl;
-            if (j < 15) {
-                const double an = bcast_lane(a[j], j + 1);
-                a[j + 1] -= a[j] * an;
-                ajj = bcast_lane(a[j + 1], j + 1);
-                rl = rsqrt(ajj);
-#pragma unroll
-                for (int k = j + 2; k < 16; k++) a[k] -= a[j] * bcast_lane(a[j], k);
-            }
-        }
-        if (lane < 16) {
-#pragma unroll
-            for (int cc = 0; cc < 16; cc++) if (cc <= row) T[tl_idx(p, p, row, cc)] = a[cc];
-        }
-        if (!ok && lane == 0) *sh_flag = 0;
-    };
+    auto diag = [&](int p) -> double * { return T + ((p * (p + 1) / 2 + p) << 8); };
     auto update_tile = [&](int ti, int tj, int p) {
         v4f64 acc;
 #pragma unroll
@@ -906,31 +950,14 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
     };
     if (t == 0) *sh_flag = 1;
     __syncthreads();
-    if (wave == 0) factor_diag(0);
+    if (wave == 0) chol_diag_tile(diag(0), dinv, sh_flag);
     __syncthreads();
     long long tm0 = (tm && t == 0) ? (long long)wall_clock64() : 0;
     for (int p = 0; p < nb; p++) {
         if (!*sh_flag) return false;
-        // (b) panel: rows of the tiles below (and the right-hand side) solve x L_pp^T = a
-        const int nrow = 16 * (nb - 1 - p);
-        for (int q = t; q < nrow + (rhs ? 1 : 0); q += nt) {
-            const bool is_rhs = q == nrow;
-            const int ti = p + 1 + (q >> 4), r = q & 15;
-            // right-looking order: as soon as x[k] is known every later column takes its term, so the sixteen accumulators advance side
-            // by side (each still receives its terms in ascending k)
-            double x[16];
-            double *px[16];
-#pragma unroll
-            for (int cc = 0; cc < 16; cc++) { px[cc] = is_rhs ? rhs + 16 * p + cc : T + tl_idx(ti, p, r, cc); x[cc] = *px[cc]; }
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                x[k] = x[k] * dinv[16 * p + k];
-#pragma unroll
-                for (int cc = k + 1; cc < 16; cc++) x[cc] -= x[k] * T[tl_idx(p, p, cc, k)];
-            }
-#pragma unroll
-            for (int cc = 0; cc < 16; cc++) *px[cc] = x[cc];
-        }
+        // (b) panel: the tiles below the diagonal block become A M^T (one wavefront per tile); the right-hand side block becomes M b
+        for (int ti = p + 1 + wave; ti < nb; ti += nw) chol_panel_tile(T + ((ti * (ti + 1) / 2 + p) << 8), diag(p), dinv + 16 * p);
+        if (rhs && wave == nw - 1) chol_rhs_block(rhs + 16 * p, diag(p), dinv + 16 * p);
         __syncthreads();
         if (tm && t == 0) { long long n_ = (long long)wall_clock64(); tm[0] += (float)(n_ - tm0); tm0 = n_; }
         // (c) trailing update S22 -= L21 L21^T on the FP64 matrix cores; tile 0 = (p+1, p+1) belongs to wavefront 0
@@ -940,7 +967,7 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
                 if (ntile > 0) {
                     update_tile(p + 1, p + 1, p);
                     WAVE_SYNC();
-                    factor_diag(p + 1);
+                    chol_diag_tile(diag(p + 1), dinv + 16 * (p + 1), sh_flag);
                 }
             } else {
                 if (rhs && wave == nw - 1) update_rhs(p);
@@ -958,7 +985,7 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
                 update_tile(ti + p + 1, tj + p + 1, p);
             }
             WAVE_SYNC();
-            if (ntile > 0) factor_diag(p + 1);
+            if (ntile > 0) chol_diag_tile(diag(p + 1), dinv + 16 * (p + 1), sh_flag);
         }
         if (tm && t == 0) { long long n_ = (long long)wall_clock64(); tm[1] += (float)(n_ - tm0); tm0 = n_; }
         __syncthreads();
@@ -967,20 +994,89 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
     return *sh_flag != 0;
 }
 
-// backward half of the solve: L^T x = y (y from the forward substitution that rode along with chol_tiles).  (A single-wavefront
-// version without workgroup barriers was measured slower: 18 us against 16 us per solve at 11 tiles.)
+// Cholesky of a matrix whose lower 16x16 tiles (tl_idx layout) live in HBM / L2: windows whose Schur complement does not fit LDS (P = 322
+// at W = 20 is 231 tiles = 473 KB).  Left-looking by block column: while column p is gathered into LDS (col: nb tiles) every wavefront
+// subtracts the contributions of the p finished columns from its row tiles -- MFMA operands straight from global memory, the loads of
+// two finished columns in flight per trip -- then the column is factored in LDS with the same pieces as chol_tiles (diagonal block by
+// the wavefront that owns it, as soon as it has it; panel tiles X = A M^T; the right-hand side block riding along) and written back.
+// Per element the same operations in the same order as chol_tiles (updates in ascending column order, each a chain of four MFMAs), so
+// the two factorisations agree bit for bit.  Traffic: nb^3 / 6 tile reads (3 MB at nb = 21), all of it L2 hits.
+__device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col, int *sh_flag, double *dinv, double *rhs) {
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    auto gtile = [&](int ti, int tj) -> double * { return G + ((size_t)(ti * (ti + 1) / 2 + tj) << 8); };
+    if (t == 0) *sh_flag = 1;
+    __syncthreads();
+    for (int p = 0; p < nb; p++) {
+        // (a) column p minus the finished columns, into LDS; wavefront (i - p) mod nw owns row tile i
+        for (int i = p + wave; i < nb; i += nw) {
+            const double *gi = gtile(i, p);
+            v4f64 acc;
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[r] = gi[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))];
+            const double *ai = gtile(i, 0), *bp = gtile(p, 0);   // tiles (i, j), j = 0 .. i, are consecutive
+            int j = 0;
+            for (; j + 2 <= p; j += 2) {
+                double a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int off = ((j + (u >> 2)) << 8) + (li << 4) + ((4 * (u & 3) + lk) ^ li);
+                    a[u] = ai[off]; b[u] = bp[off];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u], b[u], acc, 0, 0, 0);
+            }
+            if (j < p) {
+                double a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int off = (j << 8) + (li << 4) + ((4 * u + lk) ^ li);
+                    a[u] = ai[off]; b[u] = bp[off];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u], b[u], acc, 0, 0, 0);
+            }
+            double *ct = col + ((i - p) << 8);
+#pragma unroll
+            for (int r = 0; r < 4; r++) ct[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))] = acc[r];
+            if (i == p) { WAVE_SYNC(); chol_diag_tile(ct, dinv + 16 * p, sh_flag); }
+        }
+        __syncthreads();
+        if (!*sh_flag) return false;
+        // (b) panel tiles and the right-hand side block
+        for (int i = p + 1 + wave; i < nb; i += nw) chol_panel_tile(col + ((i - p) << 8), col, dinv + 16 * p);
+        if (rhs && wave == nw - 1) chol_rhs_block(rhs + 16 * p, col, dinv + 16 * p);
+        __syncthreads();
+        // (c) the finished column goes back to HBM; the right-hand side rows below take their term b_i -= L_ip y_p
+        for (int q = t; q < (nb - p) << 8; q += nt) gtile(p + (q >> 8), p)[q & 255] = col[q];
+        if (rhs && wave == nw - 1)
+            for (int q = lane; q < 16 * (nb - 1 - p); q += 64) {
+                const int tl = 1 + (q >> 4), r = q & 15;
+                double sacc = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) sacc += col[(tl << 8) + (r << 4) + (k ^ r)] * rhs[16 * p + k];
+                rhs[16 * (p + tl) + r] -= sacc;
+            }
+        __syncthreads();
+    }
+    return *sh_flag != 0;
+}
+
+// backward half of the solve: L^T x = y (y from the forward substitution that rode along with chol_tiles).  The diagonal blocks are
+// applied as x_p = M_p^T b_p with M = L^-1 from the strictly upper triangle of the factored tile (chol_diag_tile).
 __device__ __forceinline__ void chol_backward_tiles(const double *T, int nb, double *xs, const double *dinv) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6;
     for (int p = nb - 1; p >= 0; p--) {
         if (wave == 0) {
-            const int row = lane & 15;
-            double b = xs[16 * p + row];
+            const double *D = T + ((size_t)(p * (p + 1) / 2 + p) << 8);
+            double x = 0;
+            if (lane < 16) {
+                const int c = lane;
 #pragma unroll
-            for (int j = 15; j >= 0; j--) {
-                double xj = bcast_lane(b, j) * dinv[16 * p + j];
-                if (row == j) b = xj; else if (row < j) b -= T[tl_idx(p, p, j, row)] * xj;
+                for (int k = 0; k < 16; k++) x += (k > c ? D[(c << 4) + (k ^ c)] : (k == c ? dinv[16 * p + c] : 0.0)) * xs[16 * p + k];   // M[k][c]
             }
-            if (lane < 16) xs[16 * p + row] = b;
+            WAVE_SYNC();
+            if (lane < 16) xs[16 * p + lane] = x;
         }
         __syncthreads();
         for (int q = t; q < 16 * p; q += nt) {

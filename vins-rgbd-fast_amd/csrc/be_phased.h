@@ -8,6 +8,8 @@
 // synchronisation); sequences that have converged fall through.  State between kernels: SolveSt (vio_state.h) + the vectors that
 // already live in HBM.  Same mathematics and the same iteration / acceptance logic as solve_body; sums are formed in a fixed order,
 // so results are deterministic and independent of the batch a sequence runs in.
+#define PS_LDS_TILE_DOUBLES 16896   // 66 tiles (LW = 176, W = 10): the most ps_serial keeps resident in LDS
+
 namespace {
 
 __device__ __forceinline__ bool ps_active(const SolveSt &st) { return st.stage != PS_IDLE && st.stage != PS_DONE; }
@@ -133,7 +135,9 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
             // symmetric), dx from LDS
             // (three threads per row, each over a third of the columns, partial sums added in a fixed order)
             double *dxs = (double *)smem, *pacc = dxs + ((n + 1) & ~1);
+            PH(45);
             prior_dx(c, X, dxs, true);
+            PH(40);
             const int nch = min(3, nt / n);
             if (t < nch * n) {
                 const int ch = t / n, row = t - ch * n;
@@ -143,6 +147,7 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
                 pacc[ch * n + row] = acc;
             }
             __syncthreads();
+            PH(44);
             if (t < n) {
                 double acc = pacc[t];
                 for (int ch = 1; ch < nch; ch++) acc += pacc[ch * n + t];
@@ -169,6 +174,7 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
             for (int u = 0; u < 4; u++) if (q0 + u * nt < W * PH_LD) pl[q0 + u * nt] = v[u];
         }
         __syncthreads();
+        if (b == 1) PH(46);
         const v3 G = ld3(be.g);
         const int part_ = (b == 1 ? 0 : 4) + (t >> 6), i0 = t & 63;   // block 1: types 0 .. 3 on its four wavefronts, block 2: type 4
         if (part_ <= 4 && !(b == 2 && (t >> 6) > 0))
@@ -625,7 +631,7 @@ __global__ __launch_bounds__(256) void ps_asm_b_schur_kernel(Batch B, int nb_b) 
 // ---------------------------------------------------------------------------------------------------------------- SERIAL
 // grid S, 512 threads, dynamic LDS = xs + the 16 x 16 tiles of S: prepare_point, Cholesky, triangular solves, landmark
 // back-substitution, dogleg, model decrease, candidate -- the serial spine of one trust-region iteration.
-__global__ __launch_bounds__(1024) void ps_serial_kernel(Batch B) {
+template <bool BIG> __device__ __forceinline__ void ps_serial_body(const Batch &B) {
     const int s = blockIdx.x + B.s0, t = threadIdx.x, nt = blockDim.x;
     SolveSt &st = B.sst[s];
     if (st.stage != PS_ASM && st.stage != PS_SCHUR && st.stage != PS_STEP) return;
@@ -712,6 +718,10 @@ __global__ __launch_bounds__(1024) void ps_serial_kernel(Batch B) {
         for (int a = t; a < LW; a += nt) xs[a] = a < P ? gs[a] - sp[a] * tmpv[a] : 0.0;
         __syncthreads();
         PH(49);
+        // windows whose Schur complement does not fit LDS as tiles (W > 10): S stays in HBM / L2 (in place in c.Sc) and the Cholesky
+        // streams it through LDS one block column at a time (chol_tiles_stream)
+        constexpr bool big = BIG;
+        double *Stiles = big ? c.Sc : work;
         {
             const unsigned colmask = ps_colmask(W1, LW, st.vext != 0);
             const int nb = LW >> 4, ntile = nb * (nb + 1) / 2;
@@ -739,16 +749,18 @@ __global__ __launch_bounds__(1024) void ps_serial_kernel(Batch B) {
                     // S = Sp (H - U) Sp + mu D^2 (U = 0 outside the tiles the landmark rows touch); unit diagonal for constant parameters
                     double v = sr[b] * sc[b] * (hv[b] - uv[b]);
                     if (dia[b]) { v += mu * dg[b] * dg[b]; if (sr[b] == 0.0) v = 1.0; }
-                    work[widx[b]] = v;
+                    Stiles[widx[b]] = v;   // (big: every entry of c.Sc is read -- its U part -- and rewritten by the same thread)
                 }
             }
             __syncthreads();
         }
         PH(50);
-        bool ok = chol_tiles(work, LW >> 4, &sh_i[2], chol_dinv, s == 0 ? B.timings + 59 : nullptr, xs);   // with the forward substitution
+        bool ok = big ? chol_tiles_stream(c.Sc, LW >> 4, work, &sh_i[2], chol_dinv, xs)
+                      : chol_tiles(work, LW >> 4, &sh_i[2], chol_dinv, s == 0 ? B.timings + 59 : nullptr, xs);   // with the forward substitution
         PH(51);
         if (ok) {
-            chol_backward_tiles(work, LW >> 4, xs, chol_dinv);
+            if (big) chol_backward_tiles(c.Sc, LW >> 4, xs, chol_dinv);
+            else chol_backward_tiles(work, LW >> 4, xs, chol_dinv);
             PH(56);
             double bad = 0;
             for (int a = t; a < P; a += nt) if (!isfinite(xs[a])) bad += 1;
@@ -890,6 +902,13 @@ __global__ __launch_bounds__(1024) void ps_serial_kernel(Batch B) {
     finish(PS_EVAL_C);
     PH(55);
 }
+
+__global__ __launch_bounds__(1024) void ps_serial_kernel(Batch B) { ps_serial_body<false>(B); }
+// VIO_SERIAL_THREADS = 512: the same phase with 8 wavefronts and 256 VGPRs per lane
+__global__ __launch_bounds__(512) void ps_serial_kernel_512(Batch B) { ps_serial_body<false>(B); }
+// the same serial phase for windows whose Schur complement stays in HBM / L2 (its own kernel: the streaming Cholesky's registers must not
+// weigh on the 128-VGPR budget of the resident version); 512 threads = 256 VGPRs per lane
+__global__ __launch_bounds__(512) void ps_serial_big_kernel(Batch B) { ps_serial_body<true>(B); }
 
 // ---------------------------------------------------------------------------------------------------------------- FINAL
 __global__ __launch_bounds__(256) void ps_final_kernel(Batch B) {

@@ -42,6 +42,8 @@ __global__ void ps_eval_kernel(Batch B);
 __global__ void ps_asm_a_kernel(Batch B);
 __global__ void ps_asm_b_schur_kernel(Batch B, int nb_b);
 __global__ void ps_serial_kernel(Batch B);
+__global__ void ps_serial_big_kernel(Batch B);
+__global__ void ps_serial_kernel_512(Batch B);
 __global__ void ps_final_kernel(Batch B);
 __global__ void be_prior_factor_kernel(Batch B, int seq);
 __global__ void be_stage_pnp_kernel(const double *pts, int n, double *par6);

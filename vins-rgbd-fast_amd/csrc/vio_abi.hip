@@ -105,13 +105,14 @@ struct vio_batch {
     int imu_stage_cur = 0;
     hipEvent_t ev_imu = nullptr;
     std::vector<double> last_imu_t;
-    size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0, lds_marg = 0, lds_factor = 0;
+    size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0, lds_serial = 0, lds_marg = 0, lds_factor = 0;
     // VIO_BE_THREADS / VIO_MARG_THREADS, read at vio_create.  The marginalisation kernel runs next to the following frame's front-end:
     // with 6 instead of 8 wavefronts (256 VGPRs each) two SIMDs per CU keep half of their register file free and the LK wavefronts can
     // co-reside (be_marg 1.4 -> 1.6 ms, fe_lk 0.77 -> 0.60 ms; the front-end is the longer of the two, so the step gets shorter).
     int be_threads = 512, marg_threads = 384;
     // VIO_SOLVE_MODE: 0 = persistent kernel (one workgroup per sequence for the whole solve), 1 = phased solver (be_phased.h, default)
     int solve_mode = 1;
+    bool serial_big = false;          // the window's Schur complement does not fit LDS: ps_serial_big_kernel (HBM-resident tiles, streaming Cholesky)
     size_t lds_ps_eval = 0;
     int ps_eval_blocks = 0, ps_asm_a_blocks = 0, ps_schur_tiles = 0;
     bool timing_valid = false;
@@ -566,7 +567,9 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
             ps_eval_kernel<<<dim3(h->ps_eval_blocks, S), 256, h->lds_ps_eval, st>>>(Bg);
             ps_asm_a_kernel<<<dim3(h->ps_asm_a_blocks, S), 512, 0, st>>>(Bg);
             ps_asm_b_schur_kernel<<<dim3(h->ps_asm_b_blocks + h->ps_schur_tiles, S), 256, (size_t)(C.NL + 8) * sizeof(double), st>>>(Bg, h->ps_asm_b_blocks);
-            ps_serial_kernel<<<S, h->serial_threads, h->lds_solve, st>>>(Bg);
+            if (h->serial_big) ps_serial_big_kernel<<<S, 512, h->lds_serial, st>>>(Bg);
+            else if (h->serial_threads <= 512) ps_serial_kernel_512<<<S, 512, h->lds_serial, st>>>(Bg);
+            else ps_serial_kernel<<<S, 1024, h->lds_serial, st>>>(Bg);
         }
         ps_final_kernel<<<S, 256, 0, st>>>(Bg);
     } else if (be_threads <= 512) be_solve_kernel_512<<<S, be_threads, h->lds_solve, st>>>(Bg);
@@ -842,12 +845,22 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
             h->lds_solve = ((size_t)C.LW + 2 + workd) * 8 + 16;
             (void)raise_lds_limit((const void *)be_solve_kernel, (size_t)(h->lds_solve));
             (void)raise_lds_limit((const void *)be_solve_kernel_512, (size_t)(h->lds_solve));
-            (void)raise_lds_limit((const void *)ps_serial_kernel, (size_t)(h->lds_solve));
+            {
+                // ps_serial: xs + the work region = the resident tiles (windows up to W = 10) or one block column of them (larger
+                // windows, chol_tiles_stream), never less than the scratch of the mat-vec passes (one row of VIO_LWMAX per wavefront)
+                const size_t nb = (size_t)C.LW >> 4, tiles = nb * (nb + 1) / 2 * 256;
+                const size_t wk = std::max(tiles <= 16896 ? tiles : nb * 256, (size_t)16 * 336);
+                h->serial_big = tiles > 16896;
+                h->lds_serial = ((size_t)C.LW + 2 + wk) * 8 + 16;
+                (void)raise_lds_limit(h->serial_big ? (const void *)ps_serial_big_kernel : (const void *)ps_serial_kernel, h->lds_serial);
+                if (!h->serial_big) (void)raise_lds_limit((const void *)ps_serial_kernel_512, h->lds_serial);
+            }
             {
                 // phased solver: needs the Schur complement as LDS tiles and the column-aware (pose + extrinsic) landmark rows
                 const size_t nb = (size_t)C.LW >> 4, tiles = nb * (nb + 1) / 2 * 256, W1 = (size_t)C.W + 1;
-                const bool eligible = tiles <= 16896 && 6 * W1 + 7 <= 128 && !(B.flags & 1) && (size_t)C.W * C.NP / 256 + 4 <= PS_MAX_EVAL_BLOCKS &&
-                                      (size_t)C.W * 768 <= (W1 * W1 - W1 * C.W / 2) * 210;
+                // (larger windows run the same kernels with the Schur complement in HBM / L2 and chol_tiles_stream: W = 20 is 231 tiles)
+                const bool eligible = !(B.flags & 1) && (size_t)C.W * C.NP / 256 + 4 <= PS_MAX_EVAL_BLOCKS &&
+                                      (size_t)C.W * 768 <= (W1 * W1 - W1 * C.W / 2) * 210 && nb <= 32;
                 h->solve_mode = getenv("VIO_SOLVE_MODE") ? atoi(getenv("VIO_SOLVE_MODE")) : 1;   // phased by default where it applies (windows up to ~10 keyframes)
                 if (!eligible) h->solve_mode = 0;
                 h->lds_ps_eval = std::max((W1 * W1 + 1) * 32 * 8, (size_t)C.W * (VIO_PREINT_HDR + 1) * 8) + 64;   // pair geometry / staged pre-integration headers
