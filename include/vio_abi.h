@@ -177,7 +177,8 @@ typedef struct vio_status {
     double initial_cost, final_cost, td;
     int32_t overflow_flags;       /* capacity flags of the last frame: 1 landmark table, 2 IMU slot (> 64 samples per frame interval),
                                      4 FAST candidates of a cell, 8 residual list, 16 IMU ring overwritten, 32 solver iteration slots
-                                     exhausted before the trust-region loop finished (code = VIO_ECAPACITY) */
+                                     exhausted before the trust-region loop finished, 64 relocalisation request dropped (vio_set_relo_frame)
+                                     (code = VIO_ECAPACITY) */
     int32_t overflow_frames;      /* frames that raised any capacity flag since the last reset / reboot */
     int32_t iterations_total, solves_total; /* solver iterations / solves since vio_create */
 } vio_status;
@@ -207,6 +208,21 @@ int vio_set_tracker_lag(vio_batch *h, int lag);
  * updateLatestStates :1768-1788): the newest window state propagated through every IMU sample pushed after it.
  * out11 = t, P(3), Q(w, x, y, z), V(3).  INITIAL sequences and VO mode return the window state unchanged. */
 int vio_get_latest_odometry(vio_batch *h, int seq, double *out11);
+/* Estimator::setReloFrame(frame_stamp, frame_index, match_points, relo_t, relo_r) (estimator.h:48-49, estimator.cpp:1728-1747) for
+ * sequence seq: the window frame stamped frame_stamp has been matched with an old keyframe (pose relo_t / relo_r in the loop-closed
+ * world, relo_r row-major); match_points[n][3] = (x, y) normalised point of the old keyframe and the feature id it matched (z), in
+ * ascending id like the pose graph sends them (pose_graph/src/keyframe.cpp).  If the stamp is one of Headers[0 .. W-1] the NEXT
+ * optimisation of that sequence carries the relocalisation factors (estimator.cpp:1307-1346: ProjectionFactor(first observation,
+ * matched point) on (para_Pose[start], relo_Pose, extrinsic, inverse depth) for every in-problem landmark with start_frame <=
+ * relo_frame_local_index among the matches) and computes the drift outputs (:1034-1056); otherwise nothing happens, like upstream.
+ * Limits of this build: IMU mode, phased solver, and a solve in which the extrinsic is constant (relo_Pose borrows its six columns of
+ * the reduced system); otherwise the request is dropped and the frame carries overflow flag 64. */
+int vio_set_relo_frame(vio_batch *h, int seq, double frame_stamp, int frame_index, int n, const double *match_points, const double *relo_t3,
+                       const double *relo_r9);
+/* what pubRelocalization and the pose graph read after that solve (visualization.cpp:454-538): out30 = relo_relative_t(3),
+ * relo_relative_q(w x y z), relo_relative_yaw (degrees), drift_correct_t(3), drift_correct_r(9 row-major), relo_Pose(7: p, q x y z w),
+ * relocalization_info (1 = still pending), relo_frame_local_index, number of relocalisation factors of the last solve */
+int vio_get_relo(vio_batch *h, int seq, double *out30);
 /* tic(3), ric(9 row-major), td */
 int vio_get_extrinsic(vio_batch *h, int seq, double *out13);
 /* FeatureTracker public vectors after readImage (estimator_nodelet.cpp:337-343): returns count */

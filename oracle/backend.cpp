@@ -373,6 +373,7 @@ void Estimator::clearState() {  // estimator.cpp:43-116
     has_prior = false;
     feature.clear();
     failure_occur = false;
+    relocalization_info = false;   // :96
     initFirstPoseFlag = false;
     prevTime = -1;
     latest_Bg = V3();
@@ -733,6 +734,20 @@ void Estimator::initFramePoseByPnP(int frameCnt) {
     Ps[frameCnt] = -1.0 * (RCam * (T(ric) * tic)) + PCam;
 }
 
+void Estimator::setReloFrame(double frame_stamp, int frame_index, const std::vector<std::array<double, 3>> &mp, const V3 &relo_t, const M3 &relo_r) {  // :1728-1747
+    relo_frame_stamp = frame_stamp;
+    relo_frame_index = frame_index;
+    match_points = mp;
+    prev_relo_t = relo_t;
+    prev_relo_r = relo_r;
+    for (int i = 0; i < W; i++)
+        if (relo_frame_stamp == Headers[i]) {
+            relo_frame_local_index = i;
+            relocalization_info = true;
+            for (int j = 0; j < 7; j++) relo_Pose[j] = para_Pose[i][j];   // (para_Pose as the last vector2double left it, like upstream)
+        }
+}
+
 void Estimator::vector2double() {  // estimator.cpp:936-981
     for (int i = 0; i <= W; i++) {
         para_Pose[i][0] = Ps[i].x; para_Pose[i][1] = Ps[i].y; para_Pose[i][2] = Ps[i].z;
@@ -755,11 +770,23 @@ void Estimator::double2vector() {  // estimator.cpp:985-1111
         failure_occur = false;
     }
     auto poseQ = [&](int i) { return Q(para_Pose[i][6], para_Pose[i][3], para_Pose[i][4], para_Pose[i][5]); };
+    auto relo_outputs = [&](const M3 &relo_r, const V3 &relo_t) {   // "relative info between two loop frame" (:1046-1056 / 1080-1090)
+        const double drift_correct_yaw = R2ypr(prev_relo_r).x - R2ypr(relo_r).x;
+        drift_correct_r = ypr2R(V3(drift_correct_yaw, 0, 0));
+        drift_correct_t = prev_relo_t - drift_correct_r * relo_t;
+        relo_relative_t = T(relo_r) * (Ps[relo_frame_local_index] - relo_t);
+        relo_relative_q = fromR(T(relo_r) * Rs[relo_frame_local_index]);
+        double a = R2ypr(Rs[relo_frame_local_index]).x - R2ypr(relo_r).x;   // Utility::normalizeAngle (utility.h:131-139), degrees
+        relo_relative_yaw = a > 0 ? a - 360.0 * std::floor((a + 180.0) / 360.0) : a + 360.0 * std::floor((-a + 180.0) / 360.0);
+        relocalization_info = false;
+    };
+    auto reloQ = [&]() { return toR(normalized(Q(relo_Pose[6], relo_Pose[3], relo_Pose[4], relo_Pose[5]))); };
     if (!cfg.use_imu) {   // :1060-1067: no gauge fix, no speed / bias / extrinsic / td hand-back
         for (int i = 0; i <= W; i++) {
             Rs[i] = toR(normalized(poseQ(i)));
             Ps[i] = V3(para_Pose[i][0], para_Pose[i][1], para_Pose[i][2]);
         }
+        if (relocalization_info) relo_outputs(reloQ(), V3(relo_Pose[0], relo_Pose[1], relo_Pose[2]));
         setDepth(para_Feature);
         return;
     }
@@ -775,6 +802,9 @@ void Estimator::double2vector() {  // estimator.cpp:985-1111
         Bas[i] = V3(para_SpeedBias[i][3], para_SpeedBias[i][4], para_SpeedBias[i][5]);
         Bgs[i] = V3(para_SpeedBias[i][6], para_SpeedBias[i][7], para_SpeedBias[i][8]);
     }
+    if (relocalization_info)
+        relo_outputs(rot_diff * reloQ(),
+                     rot_diff * V3(relo_Pose[0] - para_Pose[0][0], relo_Pose[1] - para_Pose[0][1], relo_Pose[2] - para_Pose[0][2]) + origin_P0);
     tic = V3(para_Ex_Pose[0], para_Ex_Pose[1], para_Ex_Pose[2]);
     ric = toR(normalized(Q(para_Ex_Pose[6], para_Ex_Pose[3], para_Ex_Pose[4], para_Ex_Pose[5])));
     setDepth(para_Feature);
@@ -805,10 +835,12 @@ static void pose_dx(const double *x, const double *x0, double *dx) {  // margina
 
 // Evaluate all factors at the flat parameters and accumulate the (robustified) normal equations.
 // Tangent layout: pose k at 6k, speed-bias k at 6(W+1)+9k, ex at 15(W+1), td at 15(W+1)+6.
+// relo: the copy of the matched frame's pose (relo_Pose) or NULL; its 6 tangent dimensions sit behind td at index 15(W+1)+7.
 static void build_normal_eq(Estimator &e, const double pose[][7], const double sb[][9], const double *ex, double tdv,
-                            const std::vector<double> &feat, std::vector<LmRef> &lms, NormalEq &ne, bool withJ) {
+                            const std::vector<double> &feat, std::vector<LmRef> &lms, NormalEq &ne, bool withJ, const double *relo = nullptr) {
     const int W = e.W;
-    const int P = 15 * (W + 1) + 7;
+    const int oR = 15 * (W + 1) + 7;
+    const int P = oR + (relo ? 6 : 0);
     const int oP = 0, oS = 6 * (W + 1), oE = 15 * (W + 1), oT = 15 * (W + 1) + 6;
     ne.P = P; ne.F = (int)lms.size();
     if (withJ) {
@@ -915,12 +947,54 @@ static void build_normal_eq(Estimator &e, const double pose[][7], const double s
             ne.gl[lr.idx] += J[0][19] * r[0] + J[1][19] * r[1];
         }
     }
+    // relocalisation factors (estimator.cpp:1307-1346): ProjectionFactor(first observation, matched point of the old keyframe) on
+    // (para_Pose[start], relo_Pose, para_Ex_Pose, para_Feature) for every in-problem landmark with start <= relo_frame_local_index whose
+    // id is among the matches; the match list is walked with one monotone cursor exactly like upstream (both lists ascend in id)
+    int nrelo = 0;
+    if (relo) {
+        size_t cur = 0;
+        for (auto &lr : lms) {
+            Landmark &l = *lr.l;
+            if (l.start_frame > e.relo_frame_local_index) continue;
+            while (cur < e.match_points.size() && (int)e.match_points[cur][2] < l.feature_id) cur++;
+            if (cur >= e.match_points.size()) break;   // (upstream reads past the end here; nothing can match any more)
+            if ((int)e.match_points[cur][2] != l.feature_id) continue;
+            Obs oj = l.obs[0];
+            oj.x = e.match_points[cur][0]; oj.y = e.match_points[cur][1]; oj.z = 1.0;
+            cur++;
+            double r[2], Ji[14], Jj[14], Je[14], Jl[2], Jt[2];
+            eval_projection(e.cfg, pose[l.start_frame], relo, ex, feat[lr.idx], tdv, l.obs[0], oj, false, r, withJ ? Ji : nullptr, Jj, Je, Jl, Jt);
+            nrelo++;
+            const double sq = r[0] * r[0] + r[1] * r[1];
+            cost += 0.5 * std::log(1.0 + sq);
+            if (!withJ) continue;
+            const double wgt = std::sqrt(1.0 / (1.0 + sq));
+            double J[2][19];
+            int idx[18];
+            for (int a = 0; a < 2; a++) {
+                for (int d = 0; d < 6; d++) { J[a][d] = wgt * Ji[a * 7 + d]; J[a][6 + d] = wgt * Jj[a * 7 + d]; J[a][12 + d] = wgt * Je[a * 7 + d]; }
+                J[a][18] = wgt * Jl[a];
+                r[a] *= wgt;
+            }
+            for (int d = 0; d < 6; d++) { idx[d] = oP + 6 * l.start_frame + d; idx[6 + d] = oR + d; idx[12 + d] = oE + d; }
+            for (int a = 0; a < 18; a++) {
+                ne.g[idx[a]] += J[0][a] * r[0] + J[1][a] * r[1];
+                for (int b = 0; b < 18; b++) ne.H(idx[a], idx[b]) += J[0][a] * J[0][b] + J[1][a] * J[1][b];
+                ne.Hpl(lr.idx, idx[a]) += J[0][a] * J[0][18] + J[1][a] * J[1][18];
+            }
+            ne.Hll[lr.idx] += J[0][18] * J[0][18] + J[1][18] * J[1][18];
+            ne.gl[lr.idx] += J[0][18] * r[0] + J[1][18] * r[1];
+        }
+    }
+    e.relo_residuals = nrelo;
     e.last_stats.n_residuals = nres;
     ne.cost = cost;
 }
 
 void Estimator::solve() {
-    const int P = 15 * (W + 1) + 7;
+    const bool relo_on = relocalization_info;
+    const int oR = 15 * (W + 1) + 7;
+    const int P = oR + (relo_on ? 6 : 0);   // the relocalisation pose is one more 6-dof block of the reduced system (:1310-1311)
     const int oE = 15 * (W + 1), oT = 15 * (W + 1) + 6;
     // in-problem landmarks, list order (estimator.cpp:1243-1302)
     std::vector<LmRef> lms;
@@ -963,9 +1037,11 @@ void Estimator::solve() {
     double pose[MAXW + 1][7], sb[MAXW + 1][9], ex[7], tdv = cfg.estimate_td ? para_Td : td;
     std::memcpy(pose, para_Pose, sizeof(pose)); std::memcpy(sb, para_SpeedBias, sizeof(sb)); std::memcpy(ex, para_Ex_Pose, sizeof(ex));
     std::vector<double> feat = para_Feature;
+    double relo[7], crelo[7];
+    std::memcpy(relo, relo_Pose, sizeof(relo));
 
     NormalEq ne, ne2;
-    build_normal_eq(*this, pose, sb, ex, tdv, feat, lms, ne, true);
+    build_normal_eq(*this, pose, sb, ex, tdv, feat, lms, ne, true, relo_on ? relo : nullptr);
     last_stats = SolveStats();
     last_stats.initial_cost = ne.cost;
     last_stats.n_landmarks = F; last_stats.n_var_landmarks = Fa;
@@ -1135,12 +1211,14 @@ void Estimator::solve() {
         }
         if (ex_active) plus_pose(cex, &delta[oE]);
         if (td_active) ctd += delta[oT];
+        std::memcpy(crelo, relo, sizeof(relo));
+        if (relo_on) plus_pose(crelo, &delta[oR]);
         for (int k = 0; k < Fa; k++) {
             int li = lact[k];
             cfeat[li] += stl[k] * sl[k];
             if (cfeat[li] > lms[li].ub) cfeat[li] = lms[li].ub;  // projection onto the box (line search omitted)
         }
-        build_normal_eq(*this, cpose, csb, cex, ctd, cfeat, lms, ne2, true);
+        build_normal_eq(*this, cpose, csb, cex, ctd, cfeat, lms, ne2, true, relo_on ? crelo : nullptr);
         // parameter tolerance
         double xn = 0, dn = 0;
         for (int k = 0; k <= W; k++) {
@@ -1149,6 +1227,7 @@ void Estimator::solve() {
         }
         if (ex_active) for (int d = 0; d < 7; d++) { xn += ex[d] * ex[d]; double t = ex[d] - cex[d]; dn += t * t; }
         if (td_active) { xn += tdv * tdv; dn += (tdv - ctd) * (tdv - ctd); }
+        if (relo_on) for (int d = 0; d < 7; d++) { xn += relo[d] * relo[d]; double t = relo[d] - crelo[d]; dn += t * t; }
         for (int k = 0; k < Fa; k++) { int li = lact[k]; xn += feat[li] * feat[li]; double t = feat[li] - cfeat[li]; dn += t * t; }
         if (std::sqrt(dn) <= 1e-8 * (std::sqrt(xn) + 1e-8)) break;
         if (std::fabs(cost - ne2.cost) <= 1e-6 * cost) break;
@@ -1157,6 +1236,7 @@ void Estimator::solve() {
             std::memcpy(pose, cpose, sizeof(pose)); std::memcpy(sb, csb, sizeof(sb)); std::memcpy(ex, cex, sizeof(ex));
             tdv = ctd;
             feat = cfeat;
+            std::memcpy(relo, crelo, sizeof(relo));
             std::swap(ne, ne2);
             cost = ne.cost;
             last_stats.successful++;
@@ -1174,6 +1254,7 @@ void Estimator::solve() {
     std::memcpy(para_Pose, pose, sizeof(pose)); std::memcpy(para_SpeedBias, sb, sizeof(sb)); std::memcpy(para_Ex_Pose, ex, sizeof(ex));
     if (cfg.estimate_td) para_Td = tdv;
     para_Feature = feat;
+    if (relo_on) std::memcpy(relo_Pose, relo, sizeof(relo));
 }
 
 // ------------------------------------------------------------------ marginalisation (marginalization_factor.cpp:181-315)

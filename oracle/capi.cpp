@@ -17,6 +17,27 @@ void ovio_config_default(Config *c) { *c = Config(); }
 void *ovio_pipeline_create(const Config *c) { return new Pipeline(*c); }
 void ovio_pipeline_destroy(void *h) { delete (Pipeline *)h; }
 void ovio_pipeline_restart(void *h) { ((Pipeline *)h)->restart(); }
+// Estimator::setReloFrame (estimator.cpp:1728-1747): match_points[n][3] = (x, y, feature id), relo_r row-major
+void ovio_set_relo_frame(void *h, double stamp, int index, int n, const double *mp, const double *relo_t, const double *relo_r) {
+    std::vector<std::array<double, 3>> v(n);
+    for (int i = 0; i < n; i++) v[i] = {mp[3 * i], mp[3 * i + 1], mp[3 * i + 2]};
+    om::M3 R;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R(i, j) = relo_r[3 * i + j];
+    ((Pipeline *)h)->est.setReloFrame(stamp, index, v, V3(relo_t[0], relo_t[1], relo_t[2]), R);
+}
+// what pubRelocalization / the pose graph read (visualization.cpp:454-538): out30 = relo_relative_t(3) relo_relative_q(w x y z)
+// relo_relative_yaw drift_correct_t(3) drift_correct_r(9 row-major) relo_Pose(7) relocalization_info relo_frame_local_index n_relo_factors
+void ovio_get_relo(void *h, double *out30) {
+    const Estimator &e = ((Pipeline *)h)->est;
+    double *o = out30;
+    *o++ = e.relo_relative_t.x; *o++ = e.relo_relative_t.y; *o++ = e.relo_relative_t.z;
+    *o++ = e.relo_relative_q.w; *o++ = e.relo_relative_q.x; *o++ = e.relo_relative_q.y; *o++ = e.relo_relative_q.z;
+    *o++ = e.relo_relative_yaw;
+    *o++ = e.drift_correct_t.x; *o++ = e.drift_correct_t.y; *o++ = e.drift_correct_t.z;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) *o++ = e.drift_correct_r(i, j);
+    for (int k = 0; k < 7; k++) *o++ = e.relo_Pose[k];
+    *o++ = e.relocalization_info ? 1 : 0; *o++ = e.relo_frame_local_index; *o++ = e.relo_residuals;
+}
 // colour / depth pairing (estimator_nodelet.cpp:200-232): pairs[2 k] / [2 k + 1] = colour / depth index; thrown2 = dropped colour, depth
 int ovio_pair_color_depth(int nc, const double *tc, int nd, const double *td, int *pairs, int *thrown2) {
     auto p = pair_color_depth(std::vector<double>(tc, tc + nc), std::vector<double>(td, td + nd), thrown2);

@@ -197,6 +197,21 @@ struct Estimator {
     std::vector<uint8_t> prior_present;  // per block: W poses, sb0, ex, td
     SolveStats last_stats;
     int reboot_count = 0;
+    // relocalisation inside optimization() (estimator.h:173-186, estimator.cpp:1307-1346, 1034-1056 / 1071-1090, 1728-1747): the pose of
+    // the window frame matched with an old keyframe gets a copy relo_Pose that is optimised against the old keyframe's observations
+    bool relocalization_info = false;
+    double relo_frame_stamp = 0;
+    int relo_frame_index = 0, relo_frame_local_index = 0;
+    std::vector<std::array<double, 3>> match_points;   // (x, y) normalised point in the OLD keyframe, z = feature id; ascending id
+    om::V3 prev_relo_t;
+    om::M3 prev_relo_r;
+    double relo_Pose[7] = {0, 0, 0, 0, 0, 0, 1};
+    om::M3 drift_correct_r;
+    om::V3 drift_correct_t, relo_relative_t;
+    om::Q relo_relative_q;
+    double relo_relative_yaw = 0;
+    int relo_residuals = 0;        // diagnostics: relocalisation factors of the last solve
+    void setReloFrame(double frame_stamp, int frame_index, const std::vector<std::array<double, 3>> &match_points_, const om::V3 &relo_t, const om::M3 &relo_r);
     // dynamic initialisation (static_init == 0): every image frame since start-up / the oldest window frame (estimator.h all_image_frame)
     struct ImageFrameO {
         std::map<int, std::array<double, 2>> points;  // feature id -> normalised point

@@ -25,14 +25,16 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 
 def _oracle_worker(job):
-    """one oracle process (no GPU): n_frames of sequence seq rendered on the host; returns frames, positions, ground truth, reboots"""
-    seq, n_frames, lag, cfg_kw = job
+    """one oracle process (no GPU): n_frames of sequence seq rendered on the host (or the frames handed in: job[4]); returns frames,
+    positions, ground truth, reboots"""
+    seq, n_frames, lag, cfg_kw = job[:4]
+    given = job[4] if len(job) > 4 else None
     import vio_ct
     P = vio_ct.pkg()
     want_status = bool(cfg_kw.pop("_status", False)) if isinstance(cfg_kw, dict) else False
     cfg = P.canonical_config(**cfg_kw)
     sc = vio_ct.synth_like(cfg)
-    o = vio_ct.run_oracle_sequence(cfg, sc, seq, n_frames, tracker_lag=lag)
+    o = vio_ct.run_oracle_sequence(cfg, sc, seq, n_frames, tracker_lag=lag, frames=given)
     fr = np.array([x[0] for x in o["traj"]], np.int32)
     po = np.array([x[1] for x in o["traj"]])
     gt = np.array(o["gt"])
@@ -42,15 +44,17 @@ def _oracle_worker(job):
     return seq, fr, po, gt, int(o["oracle"].status()["reboot_count"])
 
 
-def run_oracle_pool(seqs, n_frames, lag=0, cfg_kw=None, procs=None):
+def run_oracle_pool(seqs, n_frames, lag=0, cfg_kw=None, procs=None, frames=None):
+    """frames: optional {seq: [(gray, depth)] * n_frames} (e.g. downloaded from the device) instead of the host renderer"""
     procs = procs or len(os.sched_getaffinity(0))
-    jobs = [(int(s), int(n_frames), int(lag), dict(cfg_kw or {})) for s in seqs]
+    jobs = [(int(s), int(n_frames), int(lag), dict(cfg_kw or {})) + ((frames[int(s)],) if frames else ()) for s in seqs]
     with mp.get_context("spawn").Pool(min(procs, len(jobs))) as pool:
         res = pool.map(_oracle_worker, jobs, chunksize=1)
     return {r[0]: r[1:] for r in res}
 
 
-def run_hip(P, cfg, sc, seq0, S, n_frames, lag=0, chunk=50, check_render=True, per_frame=None, keep=False):
+def run_hip(P, cfg, sc, seq0, S, n_frames, lag=0, chunk=50, check_render=True, per_frame=None, keep=False, grab=None):
+    # grab: {local sequence index: []} -- filled with the (gray, depth) frames of those sequences as the device rendered them
     """vio_feed over S device-rendered sequences, frames rendered chunk by chunk into one HBM buffer; returns per sequence the
     odometry history rows [stamp, P(3), Q(4), V(3)], the final status, and the wall time of the feed loop"""
     import vio_ct
@@ -78,6 +82,10 @@ def run_hip(P, cfg, sc, seq0, S, n_frames, lag=0, chunk=50, check_render=True, p
                 gh, dh = syn.render_host(seq0 + i, float(times[k]))
                 assert np.array_equal(gh, g.download((k * S + i) * hw, (H, W), np.uint8))
                 assert np.array_equal(dh, d.download((k * S + i) * hw * 2, (H, W), np.uint16))
+        if grab is not None:
+            for k in range(n):
+                for i in grab:
+                    grab[i].append((g.download((k * S + i) * hw, (H, W), np.uint8), d.download((k * S + i) * hw * 2, (H, W), np.uint16)))
         c0 = time.perf_counter()
         for k in range(n):
             b.feed(g.at(k * S * hw), d.at(k * S * hw * 2), np.full(S, times[f0 + k]), on_device=True)

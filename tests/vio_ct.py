@@ -46,6 +46,7 @@ def oracle():
         L.ovio_gate_create.restype = C.c_void_p
         for name, args in {
             "ovio_pipeline_create": [C.c_void_p], "ovio_pipeline_destroy": [C.c_void_p], "ovio_pipeline_restart": [C.c_void_p],
+            "ovio_set_relo_frame": [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p], "ovio_get_relo": [C.c_void_p, C.c_void_p],
             "ovio_pair_color_depth": [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
             "ovio_push_imu_n": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
             "ovio_feed": [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double],
@@ -107,6 +108,18 @@ class OraclePipeline:
     def restart(self):
         """the stream-discontinuity branch of process_tracker (estimator_nodelet.cpp:243-262): estimator restarted, tracker kept"""
         self.L.ovio_pipeline_restart(self.h)
+
+    def set_relo_frame(self, stamp, index, match_points, relo_t, relo_r):
+        """Estimator::setReloFrame (estimator.cpp:1728-1747): match_points[n][3] = (x, y, feature id) ascending in id"""
+        mp = np.ascontiguousarray(match_points, np.float64).reshape(-1, 3)
+        t = np.ascontiguousarray(relo_t, np.float64); R = np.ascontiguousarray(relo_r, np.float64)
+        self.L.ovio_set_relo_frame(self.h, float(stamp), int(index), len(mp), mp.ctypes.data, t.ctypes.data, R.ctypes.data)
+
+    def relo(self):
+        o = np.zeros(30)
+        self.L.ovio_get_relo(self.h, o.ctypes.data)
+        return dict(relative_t=o[0:3], relative_q=o[3:7], relative_yaw=o[7], drift_t=o[8:11], drift_r=o[11:20].reshape(3, 3), relo_pose=o[20:27],
+                    pending=int(o[27]), local_index=int(o[28]), n_factors=int(o[29]))
 
     def feed(self, gray, depth, t, mode=2):
         return self.L.ovio_feed_mode(self.h, gray.ctypes.data, depth.ctypes.data, float(t), int(mode))

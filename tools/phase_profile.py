@@ -31,14 +31,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seqs", type=int, default=128)
     ap.add_argument("--frames", type=int, default=40)
+    ap.add_argument("--config5", action="store_true", help="BASELINE configs[4] shape: 1280x720, 300 features, W = 20")
     a = ap.parse_args()
     P = vio_ct.pkg()
     L = P.lib()
     L.vio_debug_phases.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     cfg = P.canonical_config()
+    if a.config5:
+        cfg = P.canonical_config(width=1280, height=720, max_cnt=300, window_size=20, grid_rows=7, grid_cols=8, max_landmarks=2048,
+                                 fx=604.5821781259577 * 2, fy=604.2544712985845 * 1.5, cx=321.2638233484251 * 2, cy=239.70969315130674 * 1.5)
     sc = vio_ct.synth_like(cfg)
     syn = P.Synth(sc)
-    S, n_pre = a.seqs, 20
+    S, n_pre = a.seqs, cfg.window_size + 10
     F = n_pre + a.frames
     hw = cfg.height * cfg.width
     g = P.DeviceBuffer(F * S * hw)

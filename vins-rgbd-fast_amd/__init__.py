@@ -91,6 +91,8 @@ def lib():
         L.vio_sync.argtypes = [C.c_void_p]
         L.vio_reset_seq.argtypes = [C.c_void_p, C.c_int]
         L.vio_reset_tracker_seq.argtypes = [C.c_void_p, C.c_int]
+        L.vio_set_relo_frame.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.vio_get_relo.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.vio_push_imu_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vio_feed_modes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.vio_track_ex.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -424,6 +426,19 @@ class VioBatch:
         o = np.zeros(11)
         self._chk(self.L.vio_get_latest_odometry(self.h, seq, o.ctypes.data), "vio_get_latest_odometry")
         return o
+
+    def set_relo_frame(self, seq, stamp, index, match_points, relo_t, relo_r):
+        """Estimator::setReloFrame (estimator.cpp:1728-1747): match_points[n][3] = (x, y, feature id) ascending in id"""
+        mp = np.ascontiguousarray(match_points, np.float64).reshape(-1, 3)
+        t = np.ascontiguousarray(relo_t, np.float64).reshape(3)
+        R = np.ascontiguousarray(relo_r, np.float64).reshape(9)
+        self._chk(self.L.vio_set_relo_frame(self.h, seq, float(stamp), int(index), len(mp), mp.ctypes.data, t.ctypes.data, R.ctypes.data), "vio_set_relo_frame")
+
+    def relo(self, seq=0):
+        o = np.zeros(30)
+        self._chk(self.L.vio_get_relo(self.h, seq, o.ctypes.data), "vio_get_relo")
+        return dict(relative_t=o[0:3], relative_q=o[3:7], relative_yaw=o[7], drift_t=o[8:11], drift_r=o[11:20].reshape(3, 3), relo_pose=o[20:27],
+                    pending=int(o[27]), local_index=int(o[28]), n_factors=int(o[29]))
 
     def extrinsic(self, seq=0):
         e = np.zeros(13)

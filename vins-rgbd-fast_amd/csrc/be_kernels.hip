@@ -27,8 +27,8 @@ struct Ctx {
     BeSeq *be;
     FeSeq *fe;
     PreInt *pre;
-    int *lm_id, *lm_start, *lm_nobs, *lm_est, *lm_solve, *lm_dyn, *lm_order, *lm_free, *lm_tmp, *lm_pidx, *lm_aidx;
-    double *lm_depth, *lm_obs, *feat, *cfeat;
+    int *lm_id, *lm_start, *lm_nobs, *lm_est, *lm_solve, *lm_dyn, *lm_order, *lm_free, *lm_tmp, *lm_pidx, *lm_aidx, *lm_relo;
+    double *lm_depth, *lm_obs, *feat, *cfeat, *relo_xy, *relo_mp;
     double *H, *Sc, *Hpl, *vec, *Hll, *gl, *lvec, *res;
     int *res_lm, *res_k, *pair_start, *pair_list;
     double *pairblk, *imu_raw;
@@ -47,7 +47,8 @@ __device__ Ctx make_ctx(const Batch &B, int s) {
     size_t o = (size_t)s * C.NL;
     c.lm_id = B.lm_id + o; c.lm_start = B.lm_start + o; c.lm_nobs = B.lm_nobs + o; c.lm_est = B.lm_est_flag + o;
     c.lm_solve = B.lm_solve_flag + o; c.lm_dyn = B.lm_dyn + o; c.lm_order = B.lm_order + o; c.lm_free = B.lm_free + o;
-    c.lm_tmp = B.lm_tmp + o; c.lm_pidx = B.lm_pidx + o; c.lm_aidx = B.lm_aidx + o;
+    c.lm_tmp = B.lm_tmp + o; c.lm_pidx = B.lm_pidx + o; c.lm_aidx = B.lm_aidx + o; c.lm_relo = B.lm_relo + o;
+    c.relo_xy = B.relo_xy + o * 2; c.relo_mp = B.relo_mp + (size_t)s * C.NP * 3;
     c.lm_depth = B.lm_depth + o; c.feat = B.para_feat + o; c.cfeat = B.cand_feat + o;
     c.lm_obs = B.lm_obs + o * (C.W + 1) * VIO_OBS_D;
     c.H = B.H + (size_t)s * C.LW * C.LW; c.Sc = B.Sc + (size_t)s * C.LW * C.LW; c.Hpl = B.Hpl + (size_t)s * (C.NL + 8) * C.LW;
@@ -1301,7 +1302,9 @@ namespace {
 // Everything optimization() does before the first evaluation (estimator.cpp:1161-1212, 936-981): static-initialisation extras,
 // vector2double into X, landmark / residual / frame-pair indexing, constness decisions (sh_i[0] = extrinsic variable, sh_i[1] = td
 // variable).  Shared by the persistent solve kernel and the phased solver (ps_setup_kernel).
-__device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X, int *scratch, PreWork &pw, int *sh_i, int &F, int &Fa, int &nres) {
+// allow_relo: the caller can carry relocalisation factors (phased solver): sh_i[4] returns whether this solve has them
+__device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X, int *scratch, PreWork &pw, int *sh_i, int &F, int &Fa, int &nres,
+                                               const bool allow_relo = false) {
     const int t = threadIdx.x, nt = blockDim.x;
     const vio_config &cfg = c.C->c;
     BeSeq &be = *c.be;
@@ -1358,7 +1361,26 @@ __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X
         quat q = R2q(ldm(be.ric));
         X.ex[3] = q.x; X.ex[4] = q.y; X.ex[5] = q.z; X.ex[6] = q.w;
         X.td = be.td;
+        for (int k = 0; k < 7; k++) X.relo[k] = be.relo_Pose[k];
     }
+    // constness (estimator.cpp:1187-1212), decided first because the relocalisation factors borrow the columns of a CONSTANT extrinsic
+    if (t == 0) {
+        double v0 = nrm(ld3(be.Vs[0]));
+        int ex_active;
+        if ((cfg.estimate_extrinsic && be.frame_count == W && v0 > 0.2) || be.openExEstimation) { be.openExEstimation = 1; ex_active = 1; }
+        else ex_active = 0;
+        int td_active = cfg.use_imu && cfg.estimate_td && !(v0 < 0.2);   // no td block without the IMU (estimator.cpp:1204)
+        sh_i[0] = ex_active; sh_i[1] = td_active;
+        int relo_on = be.relo_info && be.solver_flag == 1;
+        if (relo_on && (!allow_relo || ex_active)) {
+            // relocalisation while the extrinsic is being optimised (or on the persistent solver) is not supported: the request is dropped
+            // and the frame flagged (overflow bit 64); optimization() without relocalization_info is what runs
+            relo_on = 0; be.relo_info = 0; be.overflow |= 64;
+        }
+        sh_i[4] = relo_on; sh_i[3] = 0;
+    }
+    __syncthreads();
+    const int relo_on = sh_i[4];
     // ---- landmark indexing: in-problem (para_Feature index), variable landmarks, residual list
     const int nlm = be.n_lm;
     int *tmpA = c.pair_list, *tmpB = c.pair_list + c.NL;       // scan temporaries (pair_list proper is built afterwards)
@@ -1387,8 +1409,26 @@ __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X
         if (tmpA[k]) alist[tmpB[k]] = slot;
     }
     __syncthreads();
+    // relocalisation factors (estimator.cpp:1307-1346): in-problem landmarks with start_frame <= relo_frame_local_index whose id is among
+    // the match points (upstream walks both ascending lists with one cursor: the same set); their factor rides as one more residual
+    // record behind the landmark's regular ones, marked res_k = 0
+    for (int k = t; k < nlm; k += nt) {
+        const int slot = c.lm_order[k];
+        int hit = 0;
+        if (relo_on && c.lm_pidx[slot] >= 0 && c.lm_start[slot] <= be.relo_local) {
+            const int id = c.lm_id[slot];
+            int lo = 0, hi = be.relo_nmatch - 1;
+            while (lo <= hi) {
+                const int mid = (lo + hi) >> 1, mi = (int)c.relo_mp[3 * mid + 2];
+                if (mi == id) { hit = 1; c.relo_xy[2 * slot] = c.relo_mp[3 * mid]; c.relo_xy[2 * slot + 1] = c.relo_mp[3 * mid + 1]; break; }
+                if (mi < id) lo = mid + 1; else hi = mid - 1;
+            }
+        }
+        c.lm_relo[slot] = hit;
+        if (hit) atomicAdd(&sh_i[3], 1);
+    }
     // residual list: (nobs-1) residuals per in-problem landmark, list order (estimator.cpp:1243-1302)
-    for (int k = t; k < nlm; k += nt) { int slot = c.lm_order[k]; tmpA[k] = c.lm_pidx[slot] >= 0 ? c.lm_nobs[slot] - 1 : 0; }
+    for (int k = t; k < nlm; k += nt) { int slot = c.lm_order[k]; tmpA[k] = c.lm_pidx[slot] >= 0 ? c.lm_nobs[slot] - 1 + c.lm_relo[slot] : 0; }
     __syncthreads();
     nres = block_scan_flags(tmpA, nlm, tmpB, scratch);
     const int nres_max = c.nres_cap - 2 * c.NL;
@@ -1397,8 +1437,9 @@ __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X
         int slot = c.lm_order[k];
         int r0 = tmpB[k], cnt = tmpA[k];
         c.lm_tmp[slot] = r0;  // first residual index of this landmark
+        const int nreg = c.lm_nobs[slot] - 1;
         for (int q = 0; q < cnt; q++)
-            if (r0 + q < nres) { c.res_lm[r0 + q] = slot; c.res_k[r0 + q] = q + 1; }
+            if (r0 + q < nres) { c.res_lm[r0 + q] = slot; c.res_k[r0 + q] = q < nreg ? q + 1 : 0; }
     }
     __syncthreads();
     // frame-pair lists in deterministic (landmark list) order: one wavefront per frame pair walks the in-problem landmarks
@@ -1413,8 +1454,13 @@ __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X
             for (int k0 = 0; k0 < F; k0 += 64) {
                 int k = k0 + lane;
                 bool hit = false;
-                if (k < F) { int slot = plist[k]; hit = c.lm_start[slot] == i && c.lm_nobs[slot] > j - i && c.lm_tmp[slot] + (j - i - 1) < nres; }
-                cnt += __popcll(__ballot(hit));
+                bool hit2 = false;   // relocalisation record: listed with the pair (start, start + 1), its pose_j columns are zero
+                if (k < F) {
+                    int slot = plist[k];
+                    hit = c.lm_start[slot] == i && c.lm_nobs[slot] > j - i && c.lm_tmp[slot] + (j - i - 1) < nres;
+                    hit2 = relo_on && j == i + 1 && c.lm_start[slot] == i && c.lm_relo[slot] && c.lm_tmp[slot] + c.lm_nobs[slot] - 1 < nres;
+                }
+                cnt += __popcll(__ballot(hit)) + __popcll(__ballot(hit2));
             }
             if (lane == 0) c.pair_start[p] = cnt;
         }
@@ -1438,18 +1484,22 @@ __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X
                 if (hit) c.pair_list[o + __popcll(m & ((1ULL << lane) - 1ULL))] = r;
                 o += __popcll(m);
             }
+            if (relo_on && j == i + 1)
+                for (int k0 = 0; k0 < F; k0 += 64) {
+                    int k = k0 + lane;
+                    bool hit = false;
+                    int r = 0;
+                    if (k < F) { int slot = plist[k]; r = c.lm_tmp[slot] + c.lm_nobs[slot] - 1; hit = c.lm_start[slot] == i && c.lm_relo[slot] && r < nres; }
+                    unsigned long long m = __ballot(hit);
+                    if (hit) c.pair_list[o + __popcll(m & ((1ULL << lane) - 1ULL))] = r;
+                    o += __popcll(m);
+                }
         }
         __syncthreads();
     }
-    // constness (estimator.cpp:1187-1212)
     if (t == 0) {
-        double v0 = nrm(ld3(be.Vs[0]));
-        int ex_active;
-        if ((cfg.estimate_extrinsic && be.frame_count == W && v0 > 0.2) || be.openExEstimation) { be.openExEstimation = 1; ex_active = 1; }
-        else ex_active = 0;
-        int td_active = cfg.use_imu && cfg.estimate_td && !(v0 < 0.2);   // no td block without the IMU (estimator.cpp:1204)
-        sh_i[0] = ex_active; sh_i[1] = td_active;
-        be.n_in_problem = F; be.n_var_landmarks = Fa; be.n_residuals = nres;
+        be.n_in_problem = F; be.n_var_landmarks = Fa; be.n_residuals = nres - sh_i[3];   // (f_m_cnt counts the regular factors)
+        be.relo_factors = sh_i[3];
         be.iterations = 0; be.successful = 0;
     }
     __syncthreads();
@@ -1472,6 +1522,7 @@ __device__ __forceinline__ void solve_epilogue(Ctx &c, const Params &X, double c
         }
         if (t <= W) {
             const int i = t;
+            for (int k = 0; k < 7; k++) be.para_Pose[i][k] = X.pose[i * 7 + k];
             stm(be.Rs[i], q2R(qnormalized(mkq(X.pose[i * 7 + 6], X.pose[i * 7 + 3], X.pose[i * 7 + 4], X.pose[i * 7 + 5]))));
             be.Ps[i][0] = X.pose[i * 7]; be.Ps[i][1] = X.pose[i * 7 + 1]; be.Ps[i][2] = X.pose[i * 7 + 2];
         }
@@ -1492,6 +1543,9 @@ __device__ __forceinline__ void solve_epilogue(Ctx &c, const Params &X, double c
         sdx[9] = origin_P0.x; sdx[10] = origin_P0.y; sdx[11] = origin_P0.z;
     }
     __syncthreads();
+    // para_Pose as the solve leaves it (estimator.h:139): what Estimator::setReloFrame copies into relo_Pose when no marginalisation
+    // re-runs vector2double afterwards (marg_body overwrites it in that case, like optimization() does)
+    if (t <= W) for (int k = 0; k < 7; k++) be.para_Pose[t][k] = X.pose[t * 7 + k];
     if (t <= W) {
         int i = t;
         m3 rot_diff = ldm(sdx);
@@ -1510,6 +1564,29 @@ __device__ __forceinline__ void solve_epilogue(Ctx &c, const Params &X, double c
         be.tic[0] = X.ex[0]; be.tic[1] = X.ex[1]; be.tic[2] = X.ex[2];
         stm(be.ric, q2R(qnormalized(mkq(X.ex[6], X.ex[3], X.ex[4], X.ex[5]))));
         if (cfg.estimate_td) be.td = X.td;
+    }
+    __syncthreads();
+    if (t == 0 && be.relo_info) {
+        // "relative info between two loop frame" (estimator.cpp:1034-1056): the relocalisation pose through the same gauge fix, the drift
+        // between this odometry frame and the old keyframe's world (yaw + translation), the relative pose the pose graph stores
+        const m3 rot_diff = ldm(sdx);
+        const v3 origin_P0 = mk(sdx[9], sdx[10], sdx[11]);
+        const m3 relo_r = mul(rot_diff, q2R(qnormalized(mkq(X.relo[6], X.relo[3], X.relo[4], X.relo[5]))));
+        const v3 relo_t = add(mul(rot_diff, mk(X.relo[0] - X.pose[0], X.relo[1] - X.pose[1], X.relo[2] - X.pose[2])), origin_P0);
+        const m3 prev_r = ldm(be.prev_relo_r);
+        const double drift_yaw = R2ypr(prev_r).x - R2ypr(relo_r).x;
+        const m3 dr = ypr2R(mk(drift_yaw, 0, 0));
+        stm(be.drift_correct_r, dr);
+        st3(be.drift_correct_t, sub(ld3(be.prev_relo_t), mul(dr, relo_t)));
+        const int li = be.relo_local;
+        const m3 Rl = ldm(be.Rs[li]);
+        st3(be.relo_relative_t, mul(tr(relo_r), sub(ld3(be.Ps[li]), relo_t)));
+        const quat qrel = R2q(mul(tr(relo_r), Rl));
+        be.relo_relative_q[0] = qrel.w; be.relo_relative_q[1] = qrel.x; be.relo_relative_q[2] = qrel.y; be.relo_relative_q[3] = qrel.z;
+        const double a = R2ypr(Rl).x - R2ypr(relo_r).x;   // Utility::normalizeAngle (utility.h:131-139), degrees
+        be.relo_relative_yaw = a > 0 ? a - 360.0 * floor((a + 180.0) / 360.0) : a + 360.0 * floor((-a + 180.0) / 360.0);
+        for (int k = 0; k < 7; k++) be.relo_Pose[k] = X.relo[k];
+        be.relo_info = 0;
     }
     }   // IMU mode
     // setDepth (feature_manager.cpp:197-223)
@@ -1555,6 +1632,7 @@ __device__ __forceinline__ void solve_epilogue(Ctx &c, const Params &X, double c
                 be.initFirstPoseFlag = 0; be.prevTime = -1; be.n_lm = 0; be.n_free = c.NL; be.ring_base = 0;
                 be.imu_head = be.imu_count_ingest;  // clearState() empties imu_buf (samples pushed for the next frame while this one was
                                                      // being optimised - tracker lag 1 - arrived after the reset)
+                be.relo_info = 0;   // relocalization_info = false (estimator.cpp:96)
                 be.reboot_count++;
                 be.status_code = VIO_REBOOTED;
                 be.rebooted = 1;
@@ -2068,6 +2146,7 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
     }
     if (t < W + 3) newpresent[t] = 0;
     __syncthreads();
+    if (t <= W) for (int k = 0; k < 7; k++) be.para_Pose[t][k] = X.pose[t * 7 + k];   // (the marginalisation's vector2double: see solve_epilogue)
     // reduced system over q = [m-block (md) | kept block (n)]
     const int md = second_new ? 6 : 15;
     const int mq = md + n;
@@ -2470,6 +2549,27 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
     if (t < W + 3) be.prior_present[t] = newpresent[t];
     if (t == 0) { be.has_prior = 1; be.dbg[3] = (int)(wall_clock64() - tk0); }
     PH(23);
+}
+
+// Estimator::setReloFrame (estimator.cpp:1728-1747) for sequence seq; the match points are already in B.relo_mp.  par = stamp, index,
+// n, relo_t(3), relo_r(9).  relo_Pose is copied from para_Pose[i] AS THE LAST optimization() LEFT IT, like upstream: after a MARGIN_OLD
+// slide that array still holds the pre-slide window (the copy is then the pose of the frame one slot older), an upstream quirk that the
+// first iterations of the relocalisation solve absorb.
+__global__ void be_set_relo_kernel(Batch B, int seq, const double *par) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    BeSeq &be = B.be[seq];
+    const int W = B.cfg->W;
+    be.relo_stamp = par[0];
+    be.relo_index = (int)par[1];
+    be.relo_nmatch = (int)par[2];
+    for (int k = 0; k < 3; k++) be.prev_relo_t[k] = par[3 + k];
+    for (int k = 0; k < 9; k++) be.prev_relo_r[k] = par[6 + k];
+    for (int i = 0; i < W; i++)
+        if (be.relo_stamp == be.Headers[i]) {
+            be.relo_local = i;
+            be.relo_info = 1;
+            for (int j = 0; j < 7; j++) be.relo_Pose[j] = be.para_Pose[i][j];
+        }
 }
 
 // ====================================================================================================== prior factorisation

@@ -38,11 +38,14 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(Batch B) {
     if (!be.do_solve) { if (t == 0) st.stage = PS_IDLE; return; }
     const long long ts0 = wall_clock64();
     int F, Fa, nres;
-    solve_prologue(B, c, X, scratch, pw, sh_i, F, Fa, nres);
+    solve_prologue(B, c, X, scratch, pw, sh_i, F, Fa, nres, /*allow_relo=*/true);
     for (int k = t; k < (int)(sizeof(Params) / sizeof(double)); k += blockDim.x) ((double *)&st.X)[k] = ((const double *)&X)[k];
     if (t == 0) {
         st.F = F; st.Fa = Fa; st.nres = nres;
-        st.ex_active = sh_i[0]; st.td_active = sh_i[1]; st.vext = sh_i[0] || sh_i[1];
+        // relocalisation (sh_i[4]): relo_Pose takes over the six tangent columns of the extrinsic, which is constant in such a solve
+        // (solve_prologue drops the request otherwise) -- the column block is active, the records use the full 42-double layout
+        st.relo = sh_i[4];
+        st.ex_active = sh_i[0] || sh_i[4]; st.td_active = sh_i[1]; st.vext = sh_i[0] || sh_i[1] || sh_i[4];
         st.cost = 0; st.ccost = 0; st.radius = 1e4; st.mu = 1e-8; st.alpha = 0; st.dogleg_norm = 0; st.model_change = 0;
         st.iter = 0; st.iters_done = 0; st.succ = 0; st.invalid = 0;
         st.point_new = 0; st.scale_pending = 1; st.retry = 0; st.cauchy_valid = 0; st.eval_with_J = 1;
@@ -80,8 +83,23 @@ __device__ void ps_accept(const Batch &B, int s) {
     const double rel = (cost - ccost) / st.model_change;
     if (!done && rel > 1e-3) accept = true;
     if (accept) {
-        for (int k = t; k < (int)(sizeof(Params) / sizeof(double)); k += 64) ((double *)&st.X)[k] = ((const double *)&st.Xc)[k];
-        for (int k = t; k < st.F; k += 64) c.feat[k] = c.cfeat[k];
+        // candidate -> current point, eight loads in flight per lane and trip (the plain loops waited for every load before the next)
+        constexpr int NPAR = (int)(sizeof(Params) / sizeof(double));
+        for (int k0 = t; k0 < NPAR; k0 += 8 * 64) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = ((const double *)&st.Xc)[min(k0 + 64 * u, NPAR - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (k0 + 64 * u < NPAR) ((double *)&st.X)[k0 + 64 * u] = v[u];
+        }
+        const int Fp = st.F;
+        for (int k0 = t; k0 < Fp; k0 += 8 * 64) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = c.cfeat[min(k0 + 64 * u, Fp - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (k0 + 64 * u < Fp) c.feat[k0 + 64 * u] = v[u];
+        }
     }
     if (t == 0) {
         if (done) st.stage = PS_DONE;
@@ -143,7 +161,15 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
                 const int ch = t / n, row = t - ch * n;
                 const int j0 = ch * ((n + nch - 1) / nch), j1 = min(n, j0 + (n + nch - 1) / nch);
                 double acc = 0;
-                for (int j = j0; j < j1; j++) acc += c.prior_H[(size_t)j * n + row] * dxs[j];
+                // eight loads in flight per trip (a runtime-bound loop issues one load per iteration and waits for it: 26 serialised round
+                // trips, 28 us of a 57 us launch); the sum keeps its order
+                for (int j = j0; j < j1; j += 8) {
+                    double hv[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) hv[u] = c.prior_H[(size_t)min(j + u, j1 - 1) * n + row];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) if (j + u < j1) acc += hv[u] * dxs[j + u];
+                }
                 pacc[ch * n + row] = acc;
             }
             __syncthreads();
@@ -163,15 +189,16 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
         // LDS, four loads in flight per thread
         double *pl = (double *)smem;
         constexpr int PH_LD = VIO_PREINT_HDR + 1;
-        for (int q0 = t; q0 < W * PH_LD; q0 += 4 * nt) {
-            double v[4];
+        // (ten loads in flight per thread and trip: the 19 loads a thread owns at W = 10 are two round trips instead of five)
+        for (int q0 = t; q0 < W * PH_LD; q0 += 10 * nt) {
+            double v[10];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 10; u++) {
                 const int q = min(q0 + u * nt, W * PH_LD - 1), i = q / PH_LD, e = min(q - i * PH_LD, VIO_PREINT_HDR - 1);
                 v[u] = ((const double *)&c.pre[be.pre_idx[i + 1]])[e];
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) if (q0 + u * nt < W * PH_LD) pl[q0 + u * nt] = v[u];
+            for (int u = 0; u < 10; u++) if (q0 + u * nt < W * PH_LD) pl[q0 + u * nt] = v[u];
         }
         __syncthreads();
         if (b == 1) PH(46);
@@ -212,16 +239,40 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
         const double *ricm = geo + (size_t)W1 * W1 * 32;
         const int r = r0 + t;
         if (r < nres) {
-            const int slot = c.res_lm[r], k = c.res_k[r];
-            const int imu_i = c.lm_start[slot], imu_j = imu_i + k;
+            const int slot = c.res_lm[r], k = c.res_k[r];   // k = 0: the landmark's relocalisation factor
+            const int imu_i = c.lm_start[slot], imu_j = imu_i + (k > 0 ? k : 1);
             const bf::PairGeo &g = *(const bf::PairGeo *)(geo + (size_t)(imu_i * W1 + imu_j) * 32);
             double rr[2], wgt = 1.0, sq;
-            if (vext) {
+            if (k == 0) {
+                // relocalisation factor (estimator.cpp:1336-1340): ProjectionFactor(first observation, matched point of the old keyframe)
+                // on (para_Pose[start], relo_Pose, ex, inverse depth).  Its record carries d r / d relo_Pose in the extrinsic's columns
+                // (lent to relo_Pose for this solve) and zeros in the pose_j columns.
+                double *out = c.res + (size_t)r * 42;
+                double J[40], oj[VIO_OBS_D];
+                const double *oi = obs_ptr(c, slot, imu_i);
+                for (int q = 0; q < VIO_OBS_D; q++) oj[q] = oi[q];
+                oj[0] = c.relo_xy[2 * slot]; oj[1] = c.relo_xy[2 * slot + 1]; oj[2] = 1.0;
+                bf::eval_projection(cfg, &X.pose[imu_i * 7], X.relo, X.ex, feat[c.lm_pidx[slot]], X.td, oi, oj, false, rr, withJ ? J : nullptr);
+                sq = rr[0] * rr[0] + rr[1] * rr[1];
+                wgt = sqrt(1.0 / (1.0 + sq));
+                if (withJ) {
+                    for (int a = 0; a < 2; a++) {
+                        for (int d = 0; d < 6; d++) { out[a * 20 + d] = wgt * J[a * 20 + d]; out[a * 20 + 6 + d] = 0.0; out[a * 20 + 12 + d] = wgt * J[a * 20 + 6 + d]; }
+                        out[a * 20 + 18] = 0.0;
+                        out[a * 20 + 19] = wgt * J[a * 20 + 19];
+                    }
+                    out[40] = wgt * rr[0]; out[41] = wgt * rr[1];
+                }
+            } else if (vext) {
                 double *out = c.res + (size_t)r * 42;
                 bf::eval_projection_pair(cfg, g, ricm, X.ex, feat[c.lm_pidx[slot]], X.td, obs_ptr(c, slot, imu_i), obs_ptr(c, slot, imu_j),
                                          cfg.estimate_td != 0, rr, withJ ? out : nullptr, true, &wgt);
                 sq = rr[0] * rr[0] + rr[1] * rr[1];
-                if (withJ) { out[40] = wgt * rr[0]; out[41] = wgt * rr[1]; }
+                if (withJ) {
+                    out[40] = wgt * rr[0]; out[41] = wgt * rr[1];
+                    // the extrinsic itself is constant while its columns serve relo_Pose: no Jacobian for it (Ceres evaluates none either)
+                    if (st.relo) for (int d = 0; d < 6; d++) { out[12 + d] = 0.0; out[32 + d] = 0.0; }
+                }
             } else {
                 double *out = c.res + (size_t)r * 28;
                 bf::eval_projection_pair(cfg, g, ricm, X.ex, feat[c.lm_pidx[slot]], X.td, obs_ptr(c, slot, imu_i), obs_ptr(c, slot, imu_j),
@@ -448,7 +499,7 @@ __global__ __launch_bounds__(512) void ps_asm_a_kernel(Batch B) {
         if (ka < Fa) {
             const int slot = alist[ka];
             const int stf = c.lm_start[slot], r0 = c.lm_tmp[slot];
-            const int kend = min(c.lm_nobs[slot], nres - r0 + 1);
+            const int kend = min(c.lm_nobs[slot] + c.lm_relo[slot], nres - r0 + 1);   // (+ the landmark's relocalisation record, if any)
             lm_row(c.res + (size_t)r0 * 42, row, c.Hll + ka, c.gl + ka, half, stf, kend, 15 * W1);
         } else if (half == 1) { c.Hll[ka] = 0; c.gl[ka] = 0; }
     }
@@ -500,10 +551,12 @@ __device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int nb_b) {
         double v = 0;
         // prior
         if (be.has_prior) {
-            const int pa = prior_inv(a);
+            // (relocalisation solve: the extrinsic's columns belong to relo_Pose, which the prior knows nothing about)
+            const bool lent_a = st.relo && a >= oE && a < oE + 6, lent_b = st.relo && b >= oE && b < oE + 6;
+            const int pa = lent_a ? -1 : prior_inv(a);
             if (pa >= 0) {
                 if (grad) v = st.srp[pa];
-                else { const int pb_ = prior_inv(b); if (pb_ >= 0) v = c.prior_H[pa * n + pb_]; }
+                else { const int pb_ = lent_b ? -1 : prior_inv(b); if (pb_ >= 0) v = c.prior_H[pa * n + pb_]; }
             }
         }
         // IMU factors: even ones first, then odd ones (the order assemble() adds them in)
@@ -530,13 +583,20 @@ __device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int nb_b) {
                 const int i = min(fa, fb), j = max(fa, fb);
                 sacc = pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(local_of(a, i, j, W), local_of(b, i, j, W))];
             } else if (fa >= 0 || fb >= 0) {
+                // one term per other frame of the window: all loads issued first (a runtime-bound loop with the load inside waits for
+                // every L2 round trip in turn -- ten of them per entry at W = 10), then summed in the same order
                 const int f = fa >= 0 ? fa : fb;
-                for (int o = 0; o < W1; o++) {
-                    if (o == f) continue;
-                    const int i = min(f, o), j = max(f, o);
+                double pv[VIO_MAXW + 1];
+#pragma unroll
+                for (int o = 0; o <= VIO_MAXW; o++) {
+                    const bool use = o < W1 && o != f;
+                    const int oo = use ? o : (f == 0 ? 1 : 0);     // unused slots read a term that exists (and drop it)
+                    const int i = min(f, oo), j = max(f, oo);
                     const int la = local_of(a, i, j, W), lb = grad ? 19 : local_of(b, i, j, W);
-                    sacc += pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(la, lb)];
+                    pv[o] = pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(la, lb)];
                 }
+#pragma unroll
+                for (int o = 0; o <= VIO_MAXW; o++) if (o < W1 && o != f) sacc += pv[o];
             } else {
                 for (int i = 0; i < W1; i++)
                     for (int j = i + 1; j < W1; j++) {
@@ -876,13 +936,15 @@ template <bool BIG> __device__ __forceinline__ void ps_serial_body(const Batch &
         }
     }
     if (t == W + 1) {
+        // the block at oE: the extrinsic, or relo_Pose when the solve carries relocalisation factors (the extrinsic is constant then)
+        const bool relo = st.relo != 0;
         double ec[7];
-        for (int k = 0; k < 7; k++) ec[k] = X.ex[k];
+        for (int k = 0; k < 7; k++) ec[k] = relo ? X.relo[k] : X.ex[k];
         if (ex_active) bf::pose_plus(ec, &delta[oE]);
         const double tdc = X.td + (td_active ? delta[oT] : 0.0);
-        if (ex_active) for (int k = 0; k < 7; k++) { const double v = X.ex[k], d = v - ec[k]; xn2 += v * v; dn2 += d * d; }
+        if (ex_active) for (int k = 0; k < 7; k++) { const double v = relo ? X.relo[k] : X.ex[k], d = v - ec[k]; xn2 += v * v; dn2 += d * d; }
         if (td_active) { xn2 += X.td * X.td; dn2 += (X.td - tdc) * (X.td - tdc); }
-        for (int k = 0; k < 7; k++) Xc.ex[k] = ec[k];
+        for (int k = 0; k < 7; k++) { Xc.ex[k] = relo ? X.ex[k] : ec[k]; Xc.relo[k] = relo ? ec[k] : X.relo[k]; }
         Xc.td = tdc;
     }
     for (int k = t; k < F; k += nt) c.cfeat[k] = c.feat[k];

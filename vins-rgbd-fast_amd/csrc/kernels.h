@@ -46,6 +46,7 @@ __global__ void ps_serial_big_kernel(Batch B);
 __global__ void ps_serial_kernel_512(Batch B);
 __global__ void ps_final_kernel(Batch B);
 __global__ void be_prior_factor_kernel(Batch B, int seq);
+__global__ void be_set_relo_kernel(Batch B, int seq, const double *par);
 __global__ void be_stage_pnp_kernel(const double *pts, int n, double *par6);
 __global__ void be_dyn_finalize_kernel(Batch B, int seq, const double *samples, const int *offs);
 __global__ void be_stage_imu_kernel(vio_config cfg, PreInt *P, int n, const double *dt, const double *acc, const double *gyr,

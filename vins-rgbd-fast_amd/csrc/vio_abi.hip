@@ -770,6 +770,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     DA(B.lm_id, S * NL); DA(B.lm_start, S * NL); DA(B.lm_nobs, S * NL); DA(B.lm_est_flag, S * NL); DA(B.lm_solve_flag, S * NL);
     DA(B.lm_dyn, S * NL); DA(B.lm_order, S * NL); DA(B.lm_free, S * NL); DA(B.lm_tmp, S * NL); DA(B.lm_pidx, S * NL); DA(B.lm_aidx, S * NL);
     DA(B.lm_depth, S * NL); DA(B.lm_obs, S * NL * W1 * VIO_OBS_D); DA(B.para_feat, S * NL); DA(B.cand_feat, S * NL);
+    DA(B.lm_relo, S * NL); DA(B.relo_xy, S * NL * 2); DA(B.relo_mp, S * NP * 3);
     const size_t n = C.NPRIOR, LW = C.LW, nres = C.NRES, npair = W1 * W1, mq = 15 + n;
     DA(B.prior_J, S * n * n); DA(B.prior_r, S * n); DA(B.prior_x0, S * (C.W * 7 + 17)); DA(B.prior_H, S * n * n); DA(B.prior_rf, S * n);
     DA(B.H, S * LW * LW); DA(B.Sc, S * LW * LW); DA(B.Hpl, S * (NL + 8) * LW); DA(B.vec, S * VEC_SLOTS * LW);
@@ -1138,6 +1139,41 @@ int vio_set_tracker_lag(vio_batch *h, int lag) {
     }
     h->tracker_lag = lag;
     h->B.tracker_lag = lag;
+    return VIO_OK;
+}
+
+int vio_set_relo_frame(vio_batch *h, int seq, double frame_stamp, int frame_index, int n, const double *match_points, const double *relo_t3,
+                       const double *relo_r9) {
+    if (!h || seq < 0 || seq >= h->S || n < 0 || (n > 0 && !match_points) || !relo_t3 || !relo_r9) return VIO_EINVAL;
+    if (n > h->hc.NP) { g_err = "more match points than the tracker holds features (vio_get_capacity)"; return VIO_ECAPACITY; }
+    for (int i = 1; i < n; i++)
+        if (!(match_points[3 * i + 2] > match_points[3 * (i - 1) + 2])) { g_err = "match points must ascend in feature id"; return VIO_EINVAL; }
+    { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
+    double par[15];
+    par[0] = frame_stamp; par[1] = frame_index; par[2] = n;
+    for (int k = 0; k < 3; k++) par[3 + k] = relo_t3[k];
+    for (int k = 0; k < 9; k++) par[6 + k] = relo_r9[k];
+    if (n > 0) HIPCHK(hipMemcpy(h->B.relo_mp + (size_t)seq * h->hc.NP * 3, match_points, sizeof(double) * 3 * (size_t)n, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_r9, par, sizeof(par), hipMemcpyHostToDevice));
+    be_set_relo_kernel<<<1, 64, 0, h->stream>>>(h->B, seq, h->d_r9);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return VIO_OK;
+}
+
+int vio_get_relo(vio_batch *h, int seq, double *out30) {
+    if (!h || seq < 0 || seq >= h->S || !out30) return VIO_EINVAL;
+    { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
+    static thread_local BeSeq be;
+    HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
+    double *o = out30;
+    for (int k = 0; k < 3; k++) *o++ = be.relo_relative_t[k];
+    for (int k = 0; k < 4; k++) *o++ = be.relo_relative_q[k];
+    *o++ = be.relo_relative_yaw;
+    for (int k = 0; k < 3; k++) *o++ = be.drift_correct_t[k];
+    for (int k = 0; k < 9; k++) *o++ = be.drift_correct_r[k];
+    for (int k = 0; k < 7; k++) *o++ = be.relo_Pose[k];
+    *o++ = be.relo_info; *o++ = be.relo_local; *o++ = be.relo_factors;
     return VIO_OK;
 }
 

@@ -115,11 +115,16 @@ struct BeSeq {
     int dyn_failed;                 // a dynamic initialisation attempt failed on this frame (diagnostics)
     int imu_frame_head;             // first ring sample consumed for the current frame (absolute index), with n_imu_frame
     double prior_c0;                // |r|^2 of the prior at its linearisation point (constant cost offset)
+    // relocalisation (estimator.h:173-186): set by vio_set_relo_frame, consumed by the next solve
+    int relo_info, relo_local, relo_index, relo_nmatch, relo_factors;
+    double relo_stamp, relo_Pose[7], prev_relo_t[3], prev_relo_r[9];
+    double relo_relative_t[3], relo_relative_q[4], relo_relative_yaw, drift_correct_t[3], drift_correct_r[9];
     int dbg[16];                    // debug counters (sweeps, ticks)
 };
 
 // flat parameter arrays of one solve (estimator.h para_Pose / para_SpeedBias / para_Ex_Pose / para_Td): pose = p(3) q(x,y,z,w)
-struct Params { double pose[(VIO_MAXW + 1) * 7], sb[(VIO_MAXW + 1) * 9], ex[7], td; };
+// relo: relo_Pose (estimator.h:179), the copy of the matched window frame's pose that the relocalisation factors act on
+struct Params { double pose[(VIO_MAXW + 1) * 7], sb[(VIO_MAXW + 1) * 9], ex[7], td, relo[7]; };
 
 // Per-sequence state of the PHASED solver (be_phased.h): the trust-region loop of optimization() cut into kernels that each fill the
 // whole GPU (evaluate / assemble / Schur) or run one workgroup per sequence (accept, Cholesky + dogleg); everything that the
@@ -141,6 +146,7 @@ struct SolveSt {
     int retry;            // the next step continues the same iteration (Cholesky failed, mu was raised)
     int cauchy_valid, eval_with_J, n_eval_blocks;
     int eval_done;        // blocks of the running evaluation that have published their partial cost (device-scope counter)
+    int relo;             // this solve carries relocalisation factors: the (constant) extrinsic's six columns are lent to relo_Pose
 };
 
 // all HBM pointers of a batch; passed to kernels by value
@@ -171,6 +177,9 @@ struct Batch {
     int *lm_aidx;         // index among variable landmarks or -1
     double *lm_depth;     // estimated_depth
     double *lm_obs;       // [S][NL][W+1][VIO_OBS_D], ring-indexed per frame
+    int *lm_relo;         // [S][NL] 1: the landmark has a relocalisation factor in the current solve
+    double *relo_xy;      // [S][NL][2] its matched point in the old keyframe
+    double *relo_mp;      // [S][NP][3] match_points of vio_set_relo_frame: (x, y, feature id), ascending id
     double *para_feat;    // [S][NL] inverse depths (para_Feature)
     double *cand_feat;    // [S][NL]
     // ---- prior (canonical layout) per sequence
