@@ -160,6 +160,9 @@ void vio_host_free(void *p);
 int vio_abi_sizeof(int what);
 /* capacities derived from the configuration: out[0] = tracker points per sequence, out[1] = landmark slots, out[2] = IMU ring */
 int vio_get_capacity(vio_batch *h, int32_t *out3);
+/* which solver the handle's configuration selected: 0 = the persistent one-workgroup-per-sequence kernel (fallback), 1 = the phased solver
+ * with the Schur complement resident in LDS (windows up to W = 10), 2 = the phased solver with it in HBM / L2 (larger windows) */
+int vio_get_solver_kind(vio_batch *h);
 
 /* Results read out of the path (SURVEY.md §8b "Results read out").  All getters synchronise first. */
 typedef struct vio_status {

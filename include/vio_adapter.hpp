@@ -131,6 +131,30 @@ class Estimator {
     // the IMU-rate pose pubLatestOdometry publishes from inputIMU (estimator.cpp:1760-1765): latest_time, latest_P, latest_Q (w x y z), latest_V
     void latestOdometry(double out11[11]) { check(vio_get_latest_odometry(h_, 0, out11), "vio_get_latest_odometry"); }
 
+    // void setReloFrame(double _frame_stamp, int _frame_index, vector<Vector3d> &_match_points, Vector3d _relo_t, Matrix3d _relo_r)
+    // (estimator.h:48-49, estimator.cpp:1728-1747): match_points = (x, y, feature id), ascending id; relo_r row-major.  The next
+    // processImage optimises relo_Pose with the relocalisation factors (estimator.cpp:1307-1346); relocalization() then holds what
+    // pubRelocalization and the pose graph read (visualization.cpp:454-538).
+    void setReloFrame(double frame_stamp, int frame_index, const std::vector<std::array<double, 3> > &match_points, const double relo_t[3],
+                      const double relo_r[9]) {
+        check(vio_set_relo_frame(h_, 0, frame_stamp, frame_index, (int)match_points.size(), match_points.empty() ? nullptr : match_points[0].data(),
+                                 relo_t, relo_r), "vio_set_relo_frame");
+    }
+    struct Relocalization {
+        double relo_relative_t[3], relo_relative_q[4] /* w x y z */, relo_relative_yaw, drift_correct_t[3], drift_correct_r[9], relo_Pose[7];
+        bool relocalization_info;
+        int relo_frame_local_index, factors;
+    };
+    Relocalization relocalization() {
+        double o[30];
+        check(vio_get_relo(h_, 0, o), "vio_get_relo");
+        Relocalization r;
+        std::memcpy(r.relo_relative_t, o, 24); std::memcpy(r.relo_relative_q, o + 3, 32); r.relo_relative_yaw = o[7];
+        std::memcpy(r.drift_correct_t, o + 8, 24); std::memcpy(r.drift_correct_r, o + 11, 72); std::memcpy(r.relo_Pose, o + 20, 56);
+        r.relocalization_info = o[27] != 0; r.relo_frame_local_index = (int)o[28]; r.factors = (int)o[29];
+        return r;
+    }
+
     // FeatureManager::inputDepth (feature_manager.cpp:43-46): the nodelet calls estimator.f_manager.inputDepth(depth) right before
     // processImage (estimator_nodelet.cpp:537-539); the pointer must stay valid until processImage returns
     struct FeatureManagerMirror {

@@ -14,27 +14,73 @@ import vio_ct
 pytestmark = pytest.mark.gpu
 
 
-def test_300_frames_128_sequences_ate_within_one_percent_strict(P):
-    """SURVEY.md 8d sequence length (300 frames) on BASELINE configs[2]'s batch (128 sequences), the oracle in a process pool (one
-    sequence per host core).  North-star criterion, asserted STRICTLY on the default build: |mean ATE_hip - mean ATE_oracle| <= 1 % of
-    mean ATE_oracle (with 128 sequences the standard error of that difference is ~0.4 % of the mean, so a 1 % bias is resolvable).  The
-    same run with vio_config.marg_exact = 1 (marginalization_factor.cpp:281-315 followed literally) is recorded next to it: the
-    per-sequence tables of both modes go to gpurun_out/parity_300_s128.json (committed as profiles/round3_parity_300_s128.json)."""
-    rep = parity_long.run(P, S=128, seq0=700, n_frames=300, lag=0, modes=("fast", "exact"))
+GOLDEN_ATE = os.path.join(vio_ct.ROOT, "tests", "golden", "oracle_ate_300.npz")
+
+
+def test_300_frames_ate_within_one_percent_strict(P):
+    """The north-star criterion -- ATE of the HIP path within 1 % of the reference algorithm's on identical input -- with the statistical
+    power it needs.  Measured (profiles/round3_parity_300_s128.json): after ~50 frames HIP and oracle are two realisations of a chaotic
+    estimator (126 of 128 sequences separate by more than 1 um within 300 frames whichever marginalisation form the HIP side uses, the
+    per-sequence ATE difference scatters with sigma = 1.65 mm around a 15.8 mm mean), so the mean over 128 sequences still carries a
+    standard error of 0.93 % -- it cannot resolve 1 %.  Over 1024 sequences the standard error is 0.33 %: the oracle's side of that
+    comparison (8 CPU hours, no GPU needed) is the committed fixture tests/golden/oracle_ate_300.npz (generator next to it), the HIP
+    side runs here, on identical pixels (device renderer == host renderer, asserted).  Asserted STRICTLY:
+        |mean ATE_hip - mean ATE_oracle| <= 1 % of mean ATE_oracle,   and that the sample can resolve it (standard error < 0.5 %)."""
+    fx = np.load(GOLDEN_ATE)
+    seq0, n_frames, ate_o = int(fx["seq0"]), int(fx["frames"]), fx["ate"]
+    N = len(ate_o)
+    assert N >= 512 and int(fx["reboots"].sum()) == 0
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    syn = P.Synth(sc)
+    ate_h, maxdist = np.zeros(N), []
+    S = 128
+    for b0 in range(0, N, S):
+        n = min(S, N - b0)
+        hist, stats, t_feed = parity_long.run_hip(P, cfg, sc, seq0 + b0, n, n_frames, lag=0, check_render=(b0 == 0))
+        assert all(st.reboot_count == 0 and st.solver_flag == 1 for st in stats)
+        for i in range(n):
+            h = hist[i]
+            assert len(h) == int(fx["n_rows"][b0 + i]), (b0 + i, len(h), int(fx["n_rows"][b0 + i]))
+            gt = np.array([syn.pose(seq0 + b0 + i, float(t))[0] for t in h[:, 0]])
+            ate_h[b0 + i] = vio_ct.ate_rmse(h[:, 1:4], gt)
+            if b0 + i < len(fx["positions"]):
+                f0 = int(fx["first_frame"][b0 + i])
+                po = fx["positions"][b0 + i][f0:f0 + len(h)]
+                maxdist.append(float(np.linalg.norm(po - h[:, 1:4], axis=1).max()))
+    d = ate_h - ate_o
+    rel = abs(ate_h.mean() - ate_o.mean()) / ate_o.mean()
+    se_rel = d.std(ddof=1) / np.sqrt(N) / ate_o.mean()
     out_dir = os.path.join(vio_ct.ROOT, "gpurun_out")
     if os.path.isdir(out_dir):
-        json.dump(rep, open(os.path.join(out_dir, "parity_300_s128.json"), "w"), indent=1)
-    for mode in ("fast", "exact"):
-        m = rep["modes"][mode]
-        assert m["hip_reboots"] == 0, mode
-        assert all(r["same_frames"] and r["oracle_reboots"] == 0 and r["frames"] >= 280 for r in m["rows"]), mode
-        assert all(r["ate_oracle_m"] < 0.06 and r["ate_hip_m"] < 0.06 for r in m["rows"]), mode
-        sm = m["summary"]
-        assert sm["rel_diff_of_means"] <= 0.01, (mode, sm)                       # the north-star tolerance, no escape clause
-        assert sm["max_distance_m"] < 0.05, (mode, sm)                            # two realisations of the same estimator, never a failure
-        assert sm["identical_to_1um"] >= 1, (mode, sm)                           # no systematic difference
-    # the 1 % must be resolvable by this sample: standard error of the mean difference well below it
-    assert rep["modes"]["fast"]["summary"]["standard_error_rel"] < 0.01, rep["modes"]["fast"]["summary"]
+        json.dump(dict(sequences=N, first_sequence=seq0, frames=n_frames, mean_ate_oracle_m=float(ate_o.mean()), mean_ate_hip_m=float(ate_h.mean()),
+                       signed_rel_diff_of_means=float((ate_h.mean() - ate_o.mean()) / ate_o.mean()), standard_error_rel=float(se_rel),
+                       std_of_pair_difference_m=float(d.std(ddof=1)), hip_better=int((d < 0).sum()), hip_worse=int((d > 0).sum()),
+                       max_distance_first_128=dict(median=float(np.median(maxdist)), max=float(np.max(maxdist)), beyond_1um=int((np.array(maxdist) > 1e-6).sum())),
+                       ate_hip_m=ate_h.tolist()), open(os.path.join(out_dir, "parity_300_s1024.json"), "w"), indent=1)
+    assert se_rel < 0.005, se_rel
+    assert rel <= 0.01, (rel, se_rel, float(ate_o.mean()), float(ate_h.mean()))
+    assert ate_h.max() < 0.1
+
+
+def test_literal_marginalisation_mode_tracks_the_oracle(P):
+    """vio_config.marg_exact = 1 (MarginalizationInfo::marginalize followed literally, marginalization_factor.cpp:281-315: full m x m
+    eigen-decomposition with the 1e-8 cut, prior rebuilt from the truncated factors) against the oracle over 70 frames x 8 sequences:
+    identical decisions, positions within 1e-5 m, no reboots -- the parity instrument behind profiles/round3_parity_300_s128.json works
+    as a marginalisation.  (What it showed there: with it 127 of 128 sequences still separate from the oracle within 300 frames, 126
+    without it -- the long-run divergence is not caused by the fast form's deviations from the reference.)"""
+    cfg = P.canonical_config(marg_exact=1)
+    sc = vio_ct.synth_like(cfg)
+    S, seq0, n_frames = 8, 700, 70
+    hist, stats, _ = parity_long.run_hip(P, cfg, sc, seq0, S, n_frames, check_render=False)
+    assert all(st.reboot_count == 0 and st.solver_flag == 1 for st in stats)
+    orc = parity_long.run_oracle_pool(range(seq0, seq0 + S), n_frames, procs=S)
+    worst = 0.0
+    for i in range(S):
+        fr, po, gt, reb = orc[seq0 + i]
+        assert reb == 0 and len(hist[i]) == len(po) >= 50
+        worst = max(worst, float(np.abs(hist[i][:, 1:4] - po).max()))
+    assert worst < 1e-5, worst
 
 
 def _bench(args, env_extra, timeout=900):
@@ -90,6 +136,7 @@ def test_config5_batch_of_64_on_the_phased_solver(P):
     frames = {i: [] for i in chk}
     hist, stats, t_feed, b = parity_long.run_hip(P, cfg, sc, seq0, S, n_frames, chunk=11, check_render=False, per_frame=grab, keep=True, grab=frames)
     assert all(st.solver_flag == 1 and st.reboot_count == 0 and st.overflow_frames == 0 for st in stats)
+    assert b.solver_kind() == 2                  # the phased solver with the HBM-resident Schur complement, not the round-1 fallback
     wins = [b.window(i).copy() for i in range(S)]
     b.close()
     orc = parity_long.run_oracle_pool([seq0 + i for i in chk], n_frames, cfg_kw=dict(kw, _status=True), procs=len(chk),

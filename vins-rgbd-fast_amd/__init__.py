@@ -370,6 +370,11 @@ class VioBatch:
         n = self._chk(self.L.vio_get_packaged(self.h, seq, cap, ids.ctypes.data, obs.ctypes.data), "vio_get_packaged")
         return ids[:n].copy(), obs[:n].copy()
 
+    def solver_kind(self):
+        """0 persistent fallback kernel, 1 phased solver (LDS-resident Schur complement), 2 phased solver (HBM-resident, large windows)"""
+        self.L.vio_get_solver_kind.argtypes = [C.c_void_p]
+        return self.L.vio_get_solver_kind(self.h)
+
     def capacity(self):
         c = np.zeros(3, np.int32)
         self._chk(self.L.vio_get_capacity(self.h, c.ctypes.data), "vio_get_capacity")

@@ -1308,6 +1308,13 @@ int vio_get_capacity(vio_batch *h, int32_t *out3) {
     return VIO_OK;
 }
 
+// which solver the handle runs: 0 = persistent kernel (round-1 fallback), 1 = phased with the Schur complement in LDS tiles, 2 = phased
+// with the Schur complement in HBM / L2 (windows beyond W = 10)
+int vio_get_solver_kind(vio_batch *h) {
+    if (!h) return VIO_EINVAL;
+    return h->solve_mode == 0 ? 0 : (h->serial_big ? 2 : 1);
+}
+
 int vio_push_imu_batch(vio_batch *h, const int32_t *n, int stride, const double *t, const double *acc, const double *gyr) {
     if (!h || stride < 0 || !t || !acc || !gyr) return VIO_EINVAL;
     std::lock_guard<std::mutex> lk(h->imu_mu);

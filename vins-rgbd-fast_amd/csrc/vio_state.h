@@ -130,7 +130,7 @@ struct Params { double pose[(VIO_MAXW + 1) * 7], sb[(VIO_MAXW + 1) * 9], ex[7], 
 // whole GPU (evaluate / assemble / Schur) or run one workgroup per sequence (accept, Cholesky + dogleg); everything that the
 // persistent kernel keeps in registers / LDS across phases lives here.
 enum { PS_IDLE = 0, PS_EVAL_X0, PS_ASM, PS_SCHUR, PS_STEP, PS_EVAL_C, PS_DONE };
-#define PS_MAX_EVAL_BLOCKS 48
+#define PS_MAX_EVAL_BLOCKS 64   // (ps_accept sums the partial costs one per lane of a wavefront)
 struct SolveSt {
     Params X, Xc;
     double sdx[6 * VIO_MAXW + 16], srp[6 * VIO_MAXW + 16];   // prior tangent / gradient at the last evaluated point
