@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
 //   [W1^2, W1^2 + W)     IMU factor Gram block (imu_block_mfma) -> ps_imu_blk
 //   the rest             landmark coupling rows, Hll, gl: 32 landmarks (two threads each) per wavefront
 #define PS_ROW_WAVES 32   // wavefronts of a sequence that build landmark rows (8 landmarks each per trip)
-__global__ __launch_bounds__(512) void ps_asm_a_kernel(Batch B) {
+__device__ __forceinline__ void ps_asm_a_body(const Batch &B) {
     const int s = blockIdx.y + B.s0, t = threadIdx.x;
     const SolveSt &st = B.sst[s];
     if (st.stage != PS_ASM) return;
@@ -505,6 +505,10 @@ __global__ __launch_bounds__(512) void ps_asm_a_kernel(Batch B) {
     }
     if (item == W1 * W1 + W) tick(35);
 }
+
+__global__ __launch_bounds__(512) void ps_asm_a_kernel(Batch B) { ps_asm_a_body(B); }
+// VIO_ASM_A_OCC = 4: the same kernel held to 128 VGPRs (20 bytes of scratch) so that two workgroups share a compute unit
+__global__ __launch_bounds__(512, 4) void ps_asm_a_kernel_occ4(Batch B) { ps_asm_a_body(B); }
 
 // ---------------------------------------------------------------------------------------------------------------- ASM_B
 // grid (NB, S), 256 threads: one thread per entry (a, b) of H (both triangles, every entry of the P x LW block is written, so no

@@ -460,16 +460,23 @@ __global__ __launch_bounds__(64) void fe_lk_kernel(Batch B) {
     __shared__ short2 der[22 * 22];
     __shared__ uint8_t jw[LK_REG * LK_REG];
     int cur = fe.cur_buf, forw = fe.has_img ? (cur ^ 1) : cur;
-    LkImages im;
+    // the pyramid table lives in LDS: as a local struct indexed by the (run-time) level it was 104 bytes of scratch per lane, written by
+    // every lane of every block (the stage kernel gets the table as a kernel argument and never had that)
+    __shared__ LkImages im;
     size_t hw = (size_t)C.c.width * C.c.height;
-    im.prev[0] = B.img + ((size_t)s * 2 + cur) * hw;
-    im.next[0] = B.img + ((size_t)s * 2 + forw) * hw;
-    im.w[0] = C.c.width; im.h[0] = C.c.height;
-    for (int l = 1; l <= C.c.lk_max_level; l++) {
-        im.prev[l] = B.pyr + ((size_t)s * 2 + cur) * C.pyr_bytes + C.lvl_off[l];
-        im.next[l] = B.pyr + ((size_t)s * 2 + forw) * C.pyr_bytes + C.lvl_off[l];
-        im.w[l] = C.lvl_w[l]; im.h[l] = C.lvl_h[l];
+    if (threadIdx.x < 4) {
+        const int l = threadIdx.x;
+        if (l == 0) {
+            im.prev[0] = B.img + ((size_t)s * 2 + cur) * hw;
+            im.next[0] = B.img + ((size_t)s * 2 + forw) * hw;
+            im.w[0] = C.c.width; im.h[0] = C.c.height;
+        } else if (l <= C.c.lk_max_level) {
+            im.prev[l] = B.pyr + ((size_t)s * 2 + cur) * C.pyr_bytes + C.lvl_off[l];
+            im.next[l] = B.pyr + ((size_t)s * 2 + forw) * C.pyr_bytes + C.lvl_off[l];
+            im.w[l] = C.lvl_w[l]; im.h[l] = C.lvl_h[l];
+        }
     }
+    __syncthreads();
     // grid.x is capped (most of the NP track slots are empty): a block walks its features with stride gridDim.x
     for (int i = blockIdx.x; i < fe.n_pts; i += gridDim.x) {
         float2 np = B.forw_pts[(size_t)s * C.NP + i];

@@ -40,6 +40,7 @@ __global__ void be_marg_exact_kernel(Batch B);
 __global__ void ps_setup_kernel(Batch B);
 __global__ void ps_eval_kernel(Batch B);
 __global__ void ps_asm_a_kernel(Batch B);
+__global__ void ps_asm_a_kernel_occ4(Batch B);
 __global__ void ps_asm_b_schur_kernel(Batch B, int nb_b);
 __global__ void ps_serial_kernel(Batch B);
 __global__ void ps_serial_big_kernel(Batch B);

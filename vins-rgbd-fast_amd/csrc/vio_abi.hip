@@ -59,7 +59,8 @@ struct vio_batch {
     std::vector<Group> groups;
     int tracker_lag = 0;              // vio_set_tracker_lag
     int ps_asm_b_blocks = 24;         // workgroups per sequence that sum the entries of H (VIO_ASM_B_BLOCKS)
-    int serial_threads = 1024;        // ps_serial_kernel block size (VIO_SERIAL_THREADS: 512 or 1024; measured +2 % with 1024)
+    int serial_threads = 512;         // ps_serial block size (VIO_SERIAL_THREADS: 512 or 1024).  Round 3: equal speed (36.2 k vs 36.4 k frames/s); the 512-thread
+                                      // build has 256 VGPRs per lane and no scratch, the 1024-thread one spills 21 registers since the matrix-core diagonal block
     hipStream_t stream = nullptr;     // = groups[0].stream (returned by vio_get_stream; IMU scatter runs here)
     hipStream_t fe_stream = nullptr;  // = groups[0].fe_stream
     hipEvent_t ev[4];
@@ -112,6 +113,7 @@ struct vio_batch {
     int be_threads = 512, marg_threads = 384;
     // VIO_SOLVE_MODE: 0 = persistent kernel (one workgroup per sequence for the whole solve), 1 = phased solver (be_phased.h, default)
     int solve_mode = 1;
+    bool asm_a_occ4 = false;          // VIO_ASM_A_OCC=4
     bool serial_big = false;          // the window's Schur complement does not fit LDS: ps_serial_big_kernel (HBM-resident tiles, streaming Cholesky)
     size_t lds_ps_eval = 0;
     int ps_eval_blocks = 0, ps_asm_a_blocks = 0, ps_schur_tiles = 0;
@@ -565,7 +567,8 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
         const int slots = C.c.max_iterations + 2;
         for (int k = 0; k < slots; k++) {
             ps_eval_kernel<<<dim3(h->ps_eval_blocks, S), 256, h->lds_ps_eval, st>>>(Bg);
-            ps_asm_a_kernel<<<dim3(h->ps_asm_a_blocks, S), 512, 0, st>>>(Bg);
+            if (h->asm_a_occ4) ps_asm_a_kernel_occ4<<<dim3(h->ps_asm_a_blocks, S), 512, 0, st>>>(Bg);
+            else ps_asm_a_kernel<<<dim3(h->ps_asm_a_blocks, S), 512, 0, st>>>(Bg);
             ps_asm_b_schur_kernel<<<dim3(h->ps_asm_b_blocks + h->ps_schur_tiles, S), 256, (size_t)(C.NL + 8) * sizeof(double), st>>>(Bg, h->ps_asm_b_blocks);
             if (h->serial_big) ps_serial_big_kernel<<<S, 512, h->lds_serial, st>>>(Bg);
             else if (h->serial_threads <= 512) ps_serial_kernel_512<<<S, 512, h->lds_serial, st>>>(Bg);
@@ -785,6 +788,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     B.s0 = 0;
     if (getenv("VIO_BE_THREADS")) h->be_threads = std::min(1024, std::max(64, atoi(getenv("VIO_BE_THREADS")) & ~63));
     if (getenv("VIO_ASM_B_BLOCKS")) h->ps_asm_b_blocks = std::max(1, std::min(256, atoi(getenv("VIO_ASM_B_BLOCKS"))));
+    if (getenv("VIO_ASM_A_OCC")) h->asm_a_occ4 = atoi(getenv("VIO_ASM_A_OCC")) >= 4;
     if (getenv("VIO_SERIAL_THREADS")) h->serial_threads = atoi(getenv("VIO_SERIAL_THREADS")) >= 1024 ? 1024 : 512;
     if (getenv("VIO_MARG_THREADS")) h->marg_threads = std::min(512, std::max(64, atoi(getenv("VIO_MARG_THREADS")) & ~63));
     B.flags = getenv("VIO_FLAGS") ? atoi(getenv("VIO_FLAGS")) : 0;
