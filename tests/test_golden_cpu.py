@@ -95,3 +95,26 @@ def test_dynamic_init_regression_fixture(P):
     Vw = np.array([x[3] for x in o["traj"]])
     assert np.abs(Pw - d["P"]).max() < 1e-8 and np.abs(Vw - d["V"]).max() < 1e-7
     assert vio_ct.ate_rmse(Pw, d["gt"]) < 0.02
+
+
+def test_oracle_ate_fixture_is_what_the_oracle_produces():
+    """tests/golden/oracle_ate_300.npz (the oracle's side of the 1024-sequence north-star comparison, 8 CPU hours to generate) is pinned to
+    the oracle: recomputing the first 45 frames of one of its sequences gives the stored positions bit for bit, and the file is
+    internally consistent (no reboots, every frame after initialisation produced a row, plausible ATEs)."""
+    import os
+    import vio_ct
+    path = os.path.join(vio_ct.ROOT, "tests", "golden", "oracle_ate_300.npz")
+    fx = np.load(path)
+    n = len(fx["ate"])
+    assert n >= 512 and int(fx["frames"]) == 300 and int(fx["reboots"].sum()) == 0
+    assert np.all(fx["n_rows"] + fx["first_frame"] == 300)
+    assert 0.005 < fx["ate"].mean() < 0.03 and fx["ate"].max() < 0.1
+    P = vio_ct.pkg()
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    k = 5
+    o = vio_ct.run_oracle_sequence(cfg, sc, int(fx["seq0"]) + k, 45)
+    fr = [x[0] for x in o["traj"]]
+    po = np.array([x[1] for x in o["traj"]])
+    assert fr[0] == int(fx["first_frame"][k]) and len(fr) >= 20
+    assert np.array_equal(po, fx["positions"][k][fr[0]:fr[0] + len(fr)])

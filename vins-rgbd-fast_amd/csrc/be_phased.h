@@ -156,20 +156,28 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
             PH(45);
             prior_dx(c, X, dxs, true);
             PH(40);
-            const int nch = min(3, nt / n);
+            // four threads per row when they fit (n <= 64), every load of a thread in flight at once: the partials took 28 us of a 57 us
+            // launch as a runtime-bound loop with one load per iteration, 15 us in batches of eight
+            const int nch = max(1, min(4, nt / n));
             if (t < nch * n) {
                 const int ch = t / n, row = t - ch * n;
-                const int j0 = ch * ((n + nch - 1) / nch), j1 = min(n, j0 + (n + nch - 1) / nch);
+                const int per = (n + nch - 1) / nch, j0 = ch * per, j1 = min(n, j0 + per);
+                constexpr int MAXJ = 32;   // columns per thread on the fast path (26 at W = 10 with three threads per row)
                 double acc = 0;
-                // eight loads in flight per trip (a runtime-bound loop issues one load per iteration and waits for it: 26 serialised round
-                // trips, 28 us of a 57 us launch); the sum keeps its order
-                for (int j = j0; j < j1; j += 8) {
-                    double hv[8];
+                if (j1 - j0 <= MAXJ) {
+                    double hv[MAXJ];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) hv[u] = c.prior_H[(size_t)min(j + u, j1 - 1) * n + row];
+                    for (int u = 0; u < MAXJ; u++) hv[u] = c.prior_H[(size_t)min(j0 + u, n - 1) * n + row];
 #pragma unroll
-                    for (int u = 0; u < 8; u++) if (j + u < j1) acc += hv[u] * dxs[j + u];
-                }
+                    for (int u = 0; u < MAXJ; u++) if (j0 + u < j1) acc += hv[u] * dxs[j0 + u];
+                } else
+                    for (int j = j0; j < j1; j += 8) {   // larger windows: eight loads in flight per trip
+                        double hv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) hv[u] = c.prior_H[(size_t)min(j + u, j1 - 1) * n + row];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) if (j + u < j1) acc += hv[u] * dxs[j + u];
+                    }
                 pacc[ch * n + row] = acc;
             }
             __syncthreads();
@@ -636,7 +644,6 @@ __device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int nb_b) {
 __device__ __forceinline__ void ps_schur_body(const Batch &B, int s, int tile_index, double *wk_s) {
     const SolveSt &st = B.sst[s];
     if (st.stage != PS_ASM && st.stage != PS_SCHUR) return;
-    if (threadIdx.x >= 64) return;
     Ctx c = make_ctx(B, s);
     const int W1 = c.W + 1, LW = c.LW, nb = LW >> 4;
     const unsigned colmask = ps_colmask(W1, LW, st.vext != 0);
@@ -646,7 +653,7 @@ __device__ __forceinline__ void ps_schur_body(const Batch &B, int s, int tile_in
         for (int b = 0; b <= a; b++)
             if (((colmask >> a) & 1u) && ((colmask >> b) & 1u)) { if (cnt == tile_index) { ti = a; tj = b; break; } cnt++; }
     if (ti < 0) return;
-    const int lane = threadIdx.x, li = lane & 15, lk = lane >> 4;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6, li = lane & 15, lk = lane >> 4;
     const double *Ws = c.Hpl;
     const double mu = st.mu;
     const int Fa = st.Fa, Kpad = (Fa + 3) & ~3;
@@ -655,15 +662,17 @@ __device__ __forceinline__ void ps_schur_body(const Batch &B, int s, int tile_in
     const double *wa = Ws + 16 * ti + li, *wb = Ws + 16 * tj + li;
     // per-row factor sl^2 / (sl^2 Hll + mu dgl^2), sl = 1 / (1 + sqrt(Hll)) at the first linearisation: once per row into LDS (a square
     // root and two divisions each), not once per lane and trip
-    for (int kc = lane; kc < Kpad; kc += 64) {
+    for (int kc = t; kc < Kpad; kc += blockDim.x) {
         double hll = c.Hll[kc], slk = first ? (kc < Fa ? 1.0 / (1.0 + sqrt(hll)) : 0.0) : c.lvec[kc];
         const double hl = kc < Fa ? slk * slk * hll : 0.0;
         const double dl = sqrt(fmin(fmax(hl, 1e-6), 1e32));
         const double iv = kc < Fa ? 1.0 / (hl + mu * dl * dl) : 0.0;
         wk_s[kc] = slk * slk * iv;
     }
-    WAVE_SYNC();
-    for (int k0 = 0; k0 < Kpad; k0 += 4 * PS_SCH_U) {
+    __syncthreads();
+    // the k range is dealt to the wavefronts of the block trip by trip (a single wavefront walking all of it was a chain of ~7 dependent
+    // L2 round trips); the partial tiles are added in wavefront order
+    for (int k0 = 4 * PS_SCH_U * wave; k0 < Kpad; k0 += 4 * PS_SCH_U * nw) {
         double a[PS_SCH_U], b[PS_SCH_U];
 #pragma unroll
         for (int u = 0; u < PS_SCH_U; u++) {
@@ -680,7 +689,15 @@ __device__ __forceinline__ void ps_schur_body(const Batch &B, int s, int tile_in
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
         }
     }
-    for (int r = 0; r < 4; r++) c.Sc[tl_idx(ti, tj, lk + 4 * r, li)] = acc[r];
+    double *part = wk_s + ((Kpad + 7) & ~7);   // [nw - 1][256] partial tiles of wavefronts 1 ..
+    if (wave > 0)
+        for (int r = 0; r < 4; r++) part[(wave - 1) * 256 + r * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < nw; w++)
+            for (int r = 0; r < 4; r++) acc[r] += part[(w - 1) * 256 + r * 64 + lane];
+        for (int r = 0; r < 4; r++) c.Sc[tl_idx(ti, tj, lk + 4 * r, li)] = acc[r];
+    }
 }
 
 // one launch: blocks [0, nb_b) sum the entries of H and the gradient, the blocks behind them form the landmark part of the
@@ -695,7 +712,8 @@ __global__ __launch_bounds__(256) void ps_asm_b_schur_kernel(Batch B, int nb_b) 
 // ---------------------------------------------------------------------------------------------------------------- SERIAL
 // grid S, 512 threads, dynamic LDS = xs + the 16 x 16 tiles of S: prepare_point, Cholesky, triangular solves, landmark
 // back-substitution, dogleg, model decrease, candidate -- the serial spine of one trust-region iteration.
-template <bool BIG> __device__ __forceinline__ void ps_serial_body(const Batch &B) {
+// TB: tiles a thread keeps in flight per trip of the tile load (4 at 1024 threads = 128 VGPRs, 8 at 512 threads)
+template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const Batch &B) {
     const int s = blockIdx.x + B.s0, t = threadIdx.x, nt = blockDim.x;
     SolveSt &st = B.sst[s];
     if (st.stage != PS_ASM && st.stage != PS_SCHUR && st.stage != PS_STEP) return;
@@ -791,12 +809,12 @@ template <bool BIG> __device__ __forceinline__ void ps_serial_body(const Batch &
             const int nb = LW >> 4, ntile = nb * (nb + 1) / 2;
             // thread = element (r, cc) of every (nt / 256)-th tile; four tiles per trip, branch-free loads so that they are in flight together
             const int e = t & 255, r = e >> 4, cc = e & 15, tstep = nt >> 8;
-            for (int tile0 = t >> 8; tile0 < ntile; tile0 += 4 * tstep) {
-                double hv[4], uv[4], sr[4], sc[4], dg[4];
-                int widx[4];
-                bool msk[4], dia[4];
+            for (int tile0 = t >> 8; tile0 < ntile; tile0 += TB * tstep) {
+                double hv[TB], uv[TB], sr[TB], sc[TB], dg[TB];
+                int widx[TB];
+                bool msk[TB], dia[TB];
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
+                for (int b = 0; b < TB; b++) {
                     const int tile = min(tile0 + b * tstep, ntile - 1);
                     int ti, tj;
                     tri_decode(tile, ti, tj);
@@ -808,7 +826,7 @@ template <bool BIG> __device__ __forceinline__ void ps_serial_body(const Batch &
                     sr[b] = sp[row]; sc[b] = sp[col]; dg[b] = dgp[row];
                 }
 #pragma unroll
-                for (int b = 0; b < 4; b++) {
+                for (int b = 0; b < TB; b++) {
                     if (tile0 + b * tstep >= ntile) break;
                     // S = Sp (H - U) Sp + mu D^2 (U = 0 outside the tiles the landmark rows touch); unit diagonal for constant parameters
                     double v = sr[b] * sc[b] * (hv[b] - uv[b]);
@@ -969,12 +987,12 @@ template <bool BIG> __device__ __forceinline__ void ps_serial_body(const Batch &
     PH(55);
 }
 
-__global__ __launch_bounds__(1024) void ps_serial_kernel(Batch B) { ps_serial_body<false>(B); }
+__global__ __launch_bounds__(1024) void ps_serial_kernel(Batch B) { ps_serial_body<false, 4>(B); }
 // VIO_SERIAL_THREADS = 512: the same phase with 8 wavefronts and 256 VGPRs per lane
-__global__ __launch_bounds__(512) void ps_serial_kernel_512(Batch B) { ps_serial_body<false>(B); }
+__global__ __launch_bounds__(512) void ps_serial_kernel_512(Batch B) { ps_serial_body<false, 8>(B); }
 // the same serial phase for windows whose Schur complement stays in HBM / L2 (its own kernel: the streaming Cholesky's registers must not
 // weigh on the 128-VGPR budget of the resident version); 512 threads = 256 VGPRs per lane
-__global__ __launch_bounds__(512) void ps_serial_big_kernel(Batch B) { ps_serial_body<true>(B); }
+__global__ __launch_bounds__(512) void ps_serial_big_kernel(Batch B) { ps_serial_body<true, 8>(B); }
 
 // ---------------------------------------------------------------------------------------------------------------- FINAL
 __global__ __launch_bounds__(256) void ps_final_kernel(Batch B) {

@@ -569,7 +569,7 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
             ps_eval_kernel<<<dim3(h->ps_eval_blocks, S), 256, h->lds_ps_eval, st>>>(Bg);
             if (h->asm_a_occ4) ps_asm_a_kernel_occ4<<<dim3(h->ps_asm_a_blocks, S), 512, 0, st>>>(Bg);
             else ps_asm_a_kernel<<<dim3(h->ps_asm_a_blocks, S), 512, 0, st>>>(Bg);
-            ps_asm_b_schur_kernel<<<dim3(h->ps_asm_b_blocks + h->ps_schur_tiles, S), 256, (size_t)(C.NL + 8) * sizeof(double), st>>>(Bg, h->ps_asm_b_blocks);
+            ps_asm_b_schur_kernel<<<dim3(h->ps_asm_b_blocks + h->ps_schur_tiles, S), 256, (size_t)(C.NL + 16 + 3 * 256) * sizeof(double), st>>>(Bg, h->ps_asm_b_blocks);   // per-row factors + the partial tiles of wavefronts 1 .. 3
             if (h->serial_big) ps_serial_big_kernel<<<S, 512, h->lds_serial, st>>>(Bg);
             else if (h->serial_threads <= 512) ps_serial_kernel_512<<<S, 512, h->lds_serial, st>>>(Bg);
             else ps_serial_kernel<<<S, 1024, h->lds_serial, st>>>(Bg);
