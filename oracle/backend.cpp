@@ -1013,6 +1013,7 @@ void Estimator::solve() {
         }
     }
     const int F = (int)lms.size();
+    for (const auto &r : lms) if (r.ub < DBL_MAX && !r.is_const) bounded_landmark_solves++;
     // constness (estimator.cpp:1187-1212)
     std::vector<uint8_t> active(P, 1);
     bool ex_active;
@@ -1216,7 +1217,7 @@ void Estimator::solve() {
         for (int k = 0; k < Fa; k++) {
             int li = lact[k];
             cfeat[li] += stl[k] * sl[k];
-            if (cfeat[li] > lms[li].ub) cfeat[li] = lms[li].ub;  // projection onto the box (line search omitted)
+            if (cfeat[li] > lms[li].ub) { cfeat[li] = lms[li].ub; bound_clamps++; }  // projection onto the box (line search omitted)
         }
         build_normal_eq(*this, cpose, csb, cex, ctd, cfeat, lms, ne2, true, relo_on ? crelo : nullptr);
         // parameter tolerance

@@ -91,6 +91,11 @@ void ovio_get_status(void *h, double *out) {
     out[11] = e.last_stats.final_cost; out[12] = e.last_stats.n_landmarks; out[13] = e.last_stats.n_residuals;
     out[14] = e.last_stats.n_var_landmarks; out[15] = e.has_prior;
 }
+// out2 = (candidate steps cut by the inverse-depth upper bound, bounded landmarks that entered solves) since construction
+void ovio_get_bound_stats(void *h, double *out2) {
+    const Estimator &e = ((Pipeline *)h)->est;
+    out2[0] = (double)e.bound_clamps; out2[1] = (double)e.bounded_landmark_solves;
+}
 // window arrays, each (W+1) rows: P(3) Q(wxyz 4) V(3) Ba(3) Bg(3) stamp(1) = 17 doubles per frame
 void ovio_get_window(void *h, double *out) {
     Estimator &e = ((Pipeline *)h)->est;

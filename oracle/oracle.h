@@ -197,6 +197,10 @@ struct Estimator {
     std::vector<uint8_t> prior_present;  // per block: W poses, sb0, ex, td
     SolveStats last_stats;
     int reboot_count = 0;
+    // how often a candidate step was cut by the inverse-depth upper bound (estimator.cpp:1282-1297) since construction, and how many
+    // bounded landmarks (estimate_flag == 2) entered solves: Ceres would run its projected line search in exactly those steps
+    // (DESIGN.md deviation 5); tests/test_oracle_kat.py measures that the canonical workload never gets there
+    long bound_clamps = 0, bounded_landmark_solves = 0;
     // relocalisation inside optimization() (estimator.h:173-186, estimator.cpp:1307-1346, 1034-1056 / 1071-1090, 1728-1747): the pose of
     // the window frame matched with an old keyframe gets a copy relo_Pose that is optimised against the old keyframe's observations
     bool relocalization_info = false;
