@@ -123,7 +123,7 @@ __device__ void ps_accept(const Batch &B, int s) {
 // work type per wavefront: whitened residual and the four Jacobian column groups are different code paths); block b >= 3: projection
 // residuals [256 (b - 3), 256 (b - 2)).  Evaluates X (first point) or the candidate Xc.  The block of a sequence that finishes last
 // (device-scope counter) sums the partial costs in block order and takes the step-acceptance decision (ps_accept).
-__global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
+__device__ __forceinline__ void ps_eval_body(const Batch &B) {
     const int s = blockIdx.y + B.s0, t = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
     SolveSt &st = B.sst[s];
     if (st.stage != PS_EVAL_X0 && st.stage != PS_EVAL_C) return;
@@ -308,6 +308,12 @@ __global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) {
         if (s == 0 && t == 0) B.timings[15] += (float)((long long)wall_clock64() - ta);
     }
 }
+
+__global__ __launch_bounds__(256) void ps_eval_kernel(Batch B) { ps_eval_body(B); }
+// VIO_EVAL_OCC = 3 / 4: the same kernel held to 168 / 128 VGPRs (scratch spills in the IMU factor code) for three / four workgroups per
+// SIMD instead of two -- an experiment switch for the occupancy question of DESIGN.md 9
+__global__ __launch_bounds__(256, 3) void ps_eval_kernel_occ3(Batch B) { ps_eval_body(B); }
+__global__ __launch_bounds__(256, 4) void ps_eval_kernel_occ4(Batch B) { ps_eval_body(B); }
 
 // ---------------------------------------------------------------------------------------------------------------- ASM_A
 // grid (NB, S), 512 threads = 8 wavefronts per block; wavefront item w = 8 blockIdx.x + wave over the whole sequence:

@@ -39,6 +39,8 @@ __global__ void be_marg_exact_kernel(Batch B);
 // phased solver (be_phased.h)
 __global__ void ps_setup_kernel(Batch B);
 __global__ void ps_eval_kernel(Batch B);
+__global__ void ps_eval_kernel_occ3(Batch B);
+__global__ void ps_eval_kernel_occ4(Batch B);
 __global__ void ps_asm_a_kernel(Batch B);
 __global__ void ps_asm_a_kernel_occ4(Batch B);
 __global__ void ps_asm_b_schur_kernel(Batch B, int nb_b);

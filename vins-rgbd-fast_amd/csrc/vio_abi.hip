@@ -114,6 +114,7 @@ struct vio_batch {
     // VIO_SOLVE_MODE: 0 = persistent kernel (one workgroup per sequence for the whole solve), 1 = phased solver (be_phased.h, default)
     int solve_mode = 1;
     bool asm_a_occ4 = false;          // VIO_ASM_A_OCC=4
+    int eval_occ = 0;                 // VIO_EVAL_OCC=3|4
     bool serial_big = false;          // the window's Schur complement does not fit LDS: ps_serial_big_kernel (HBM-resident tiles, streaming Cholesky)
     size_t lds_ps_eval = 0;
     int ps_eval_blocks = 0, ps_asm_a_blocks = 0, ps_schur_tiles = 0;
@@ -566,7 +567,9 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
         ps_setup_kernel<<<S, 512, 0, st>>>(Bg);
         const int slots = C.c.max_iterations + 2;
         for (int k = 0; k < slots; k++) {
-            ps_eval_kernel<<<dim3(h->ps_eval_blocks, S), 256, h->lds_ps_eval, st>>>(Bg);
+            if (h->eval_occ == 4) ps_eval_kernel_occ4<<<dim3(h->ps_eval_blocks, S), 256, h->lds_ps_eval, st>>>(Bg);
+            else if (h->eval_occ == 3) ps_eval_kernel_occ3<<<dim3(h->ps_eval_blocks, S), 256, h->lds_ps_eval, st>>>(Bg);
+            else ps_eval_kernel<<<dim3(h->ps_eval_blocks, S), 256, h->lds_ps_eval, st>>>(Bg);
             if (h->asm_a_occ4) ps_asm_a_kernel_occ4<<<dim3(h->ps_asm_a_blocks, S), 512, 0, st>>>(Bg);
             else ps_asm_a_kernel<<<dim3(h->ps_asm_a_blocks, S), 512, 0, st>>>(Bg);
             ps_asm_b_schur_kernel<<<dim3(h->ps_asm_b_blocks + h->ps_schur_tiles, S), 256, (size_t)(C.NL + 16 + 3 * 256) * sizeof(double), st>>>(Bg, h->ps_asm_b_blocks);   // per-row factors + the partial tiles of wavefronts 1 .. 3
@@ -788,6 +791,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     B.s0 = 0;
     if (getenv("VIO_BE_THREADS")) h->be_threads = std::min(1024, std::max(64, atoi(getenv("VIO_BE_THREADS")) & ~63));
     if (getenv("VIO_ASM_B_BLOCKS")) h->ps_asm_b_blocks = std::max(1, std::min(256, atoi(getenv("VIO_ASM_B_BLOCKS"))));
+    if (getenv("VIO_EVAL_OCC")) h->eval_occ = atoi(getenv("VIO_EVAL_OCC"));
     if (getenv("VIO_ASM_A_OCC")) h->asm_a_occ4 = atoi(getenv("VIO_ASM_A_OCC")) >= 4;
     if (getenv("VIO_SERIAL_THREADS")) h->serial_threads = atoi(getenv("VIO_SERIAL_THREADS")) >= 1024 ? 1024 : 512;
     if (getenv("VIO_MARG_THREADS")) h->marg_threads = std::min(512, std::max(64, atoi(getenv("VIO_MARG_THREADS")) & ~63));
@@ -870,6 +874,8 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
                 if (!eligible) h->solve_mode = 0;
                 h->lds_ps_eval = std::max((W1 * W1 + 1) * 32 * 8, (size_t)C.W * (VIO_PREINT_HDR + 1) * 8) + 64;   // pair geometry / staged pre-integration headers
                 (void)raise_lds_limit((const void *)ps_eval_kernel, h->lds_ps_eval);
+                (void)raise_lds_limit((const void *)ps_eval_kernel_occ3, h->lds_ps_eval);
+                (void)raise_lds_limit((const void *)ps_eval_kernel_occ4, h->lds_ps_eval);
                 h->ps_eval_blocks = (int)std::min<size_t>(PS_MAX_EVAL_BLOCKS, (size_t)C.W * C.NP / 256 + 4);
                 h->ps_asm_a_blocks = (int)((W1 * (W1 - 1) / 2 + C.W + 32 + 7) / 8);   // pair items (i < j), IMU items, PS_ROW_WAVES = 32 landmark-row wavefronts
                 int nact = 0;
