@@ -4,7 +4,7 @@
 #   pass 2..4: --pmc only (separate passes: FETCH_SIZE takes 3 TCC slots, WRITE_SIZE 2; SQ counters in their own pass)
 # Copy gpurun_out/profile_summary/* into profiles/ afterwards (gpurun_out is scratch).
 set -u
-ROUND=${ROUND:-round2}
+ROUND=${ROUND:-round3}
 REPO=$(pwd)
 export TMPDIR=/tmp
 OUT=$REPO/gpurun_out/prof_$ROUND

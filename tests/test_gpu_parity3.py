@@ -198,3 +198,35 @@ def test_relocalisation_factors_match_the_oracle_and_the_truth(P):
     # a stamp that is not in the window is ignored, like upstream
     b.set_relo_frame(0, 123.456, 1, np.array([[0.0, 0.0, 5.0]]), np.zeros(3), np.eye(3))
     assert b.relo(0)["pending"] == 0
+
+
+def test_relocalisation_request_is_dropped_while_the_extrinsic_is_optimised(P):
+    """Limit of this build (include/vio_abi.h): relo_Pose borrows the tangent columns of a CONSTANT extrinsic.  With estimate_extrinsic 1
+    the extrinsic becomes a variable of every solve once the window moves (openExEstimation, estimator.cpp:1187-1202); a relocalisation
+    request is then dropped, the frame is flagged (overflow bit 64, code VIO_ECAPACITY) and the estimator carries on exactly like a run that
+    never asked."""
+    cfg = P.canonical_config(estimate_extrinsic=1)
+    sc = vio_ct.synth_like(cfg)
+    seq, n_frames, f_set = 3, 60, 56          # (late enough for openExEstimation to have latched: the oldest window frame moves > 0.2 m/s)
+    syn = P.Synth(sc)
+    times = vio_ct.frame_times(sc, n_frames)
+    ti, ai, gi = syn.imu(seq, int(n_frames / sc.cam_rate * sc.imu_rate) + 64)
+    ba, bb = P.VioBatch(cfg, 1), P.VioBatch(cfg, 1)
+    k, flagged = 0, []
+    for f in range(n_frames):
+        tf = float(times[f])
+        k2 = vio_ct.imu_until(ti, k, tf, sc.imu_rate)
+        for x in (ba, bb):
+            x.push_imu(0, ti[k:k2], ai[k:k2], gi[k:k2])
+        k = k2
+        g, d = syn.render_host(seq, tf)
+        ba.feed(g[None], d[None], [tf]); bb.feed(g[None], d[None], [tf])
+        flagged.append(ba.status(0).overflow_flags)
+        if f == f_set:
+            w = ba.window(0)
+            ids, obs = ba.packaged(0)
+            ba.set_relo_frame(0, float(w[6, 16]), 3, np.c_[obs[:, 0], obs[:, 1], ids.astype(np.float64)], w[4, :3], np.eye(3))
+            assert ba.relo(0)["pending"] == 1
+    assert flagged[f_set + 1] & 64 and not any(x & 64 for i, x in enumerate(flagged) if i != f_set + 1)
+    assert ba.relo(0)["pending"] == 0 and ba.relo(0)["n_factors"] == 0
+    assert np.array_equal(ba.window(0), bb.window(0))          # the run that never asked
