@@ -11,7 +11,7 @@ OUT=$REPO/gpurun_out/prof_$ROUND
 rm -rf "$OUT"; mkdir -p "$OUT" "$REPO/gpurun_out/profile_summary"
 PASSES=${PASSES:-"1 2 3 4 5"}   # e.g. PASSES="1" refreshes only the kernel-trace statistics
 has() { [[ " $PASSES " == *" $1 "* ]]; }
-BENCH="python $REPO/bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-6} --repeats 1 --cpu-seqs 0 --cpu-procs 0 --pcie-steps 0 --stream-steps 0 --seqs ${SEQS:-128}"
+BENCH="python $REPO/bench.py --steps ${STEPS:-20} --warmup ${WARMUP:-6} --repeats 1 --cpu-seqs 0 --cpu-procs 0 --pcie-steps 0 --stream-steps 0 --aux 0 --seqs ${SEQS:-128}"
 cd /tmp
 has 1 && echo "== pass 1: kernel trace + stats" && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- $BENCH > "$OUT/stats.log" 2>&1; tail -1 "$OUT/stats.log" | cut -c1-300
 has 2 && echo "== pass 2: FETCH_SIZE" && timeout 900 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch -- $BENCH > "$OUT/fetch.log" 2>&1; tail -1 "$OUT/fetch.log" | cut -c1-200
