@@ -123,8 +123,23 @@ __device__ void ps_accept(const Batch &B, int s) {
 // work type per wavefront: whitened residual and the four Jacobian column groups are different code paths); block b >= 3: projection
 // residuals [256 (b - 3), 256 (b - 2)).  Evaluates X (first point) or the candidate Xc.  The block of a sequence that finishes last
 // (device-scope counter) sums the partial costs in block order and takes the step-acceptance decision (ps_accept).
+// Block -> (sequence, block of the sequence).  B.xcd_nb == 0: grid (blocks per sequence, sequences).  B.xcd_nb > 0: one-dimensional grid
+// of X * ceil(ns / X) * xcd_nb blocks, X = B.xcd_n = the XCDs the launching stream may use (its CU mask covers whole XCDs), laid out so
+// that EVERY block of sequence s0 + r lands on the r % X-th of them (observed dispatch: block L of a grid runs on the L % X-th enabled
+// XCD; a placement for speed, never for correctness): the one-block-per-sequence kernels of the same stream (ps_setup, ps_serial,
+// be_ingest, be_marg) put sequence r there as well, so the records one phase leaves behind are read by the next from the same L2.
+__device__ __forceinline__ bool ps_blk(const Batch &B, int &s, int &b) {
+    if (B.xcd_nb == 0) { s = (int)blockIdx.y + B.s0; b = (int)blockIdx.x; return true; }
+    const int L = (int)blockIdx.x, X = B.xcd_n, idx = L / X, sl = idx / B.xcd_nb, r = sl * X + (L - idx * X);
+    b = idx - sl * B.xcd_nb;
+    s = r + B.s0;
+    return r < B.ns;
+}
+
 __device__ __forceinline__ void ps_eval_body(const Batch &B) {
-    const int s = blockIdx.y + B.s0, t = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+    int s, b;
+    if (!ps_blk(B, s, b)) return;
+    const int t = threadIdx.x, nt = blockDim.x;
     SolveSt &st = B.sst[s];
     if (st.stage != PS_EVAL_X0 && st.stage != PS_EVAL_C) return;
     if (b >= st.n_eval_blocks) return;
@@ -322,14 +337,16 @@ __global__ __launch_bounds__(256, 4) void ps_eval_kernel_occ4(Batch B) { ps_eval
 //   the rest             landmark coupling rows, Hll, gl: 32 landmarks (two threads each) per wavefront
 #define PS_ROW_WAVES 32   // wavefronts of a sequence that build landmark rows (8 landmarks each per trip)
 __device__ __forceinline__ void ps_asm_a_body(const Batch &B) {
-    const int s = blockIdx.y + B.s0, t = threadIdx.x;
+    int s, bq;
+    if (!ps_blk(B, s, bq)) return;
+    const int t = threadIdx.x;
     const SolveSt &st = B.sst[s];
     if (st.stage != PS_ASM) return;
     Ctx c = make_ctx(B, s);
     const BeSeq &be = *c.be;
     const int W = c.W, W1 = W + 1, LW = c.LW;
     const int lane = t & 63, wave = t >> 6, li = lane & 15, lk = lane >> 4;
-    const int item = 8 * blockIdx.x + wave;
+    const int item = 8 * bq + wave;
     const bool vext = st.vext != 0;
     const int nres = st.nres, Fa = st.Fa;
     __shared__ double imu_lds[8 * 704];
@@ -529,7 +546,7 @@ __global__ __launch_bounds__(512, 4) void ps_asm_a_kernel_occ4(Batch B) { ps_asm
 // zero-fill pass) and per entry of g: prior block, the (at most two) IMU Gram blocks that contain both columns, then the
 // frame-pair sums -- the same terms in the same order as assemble().  The thread that owns a diagonal entry fixes the Jacobi
 // column scaling the first time round.
-__device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int nb_b) {
+__device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int blk, int nb_b) {
     const SolveSt &st = B.sst[s];
     if (st.stage != PS_ASM) return;
     Ctx c = make_ctx(B, s);
@@ -561,7 +578,7 @@ __device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int nb_b) {
         if (a == oT) return 6 * W + 15;
         return -1;
     };
-    for (int w = blockIdx.x * blockDim.x + threadIdx.x; w < total; w += nb_b * blockDim.x) {
+    for (int w = blk * blockDim.x + threadIdx.x; w < total; w += nb_b * blockDim.x) {
         const int a = w / (LW + 1), bcol = w - a * (LW + 1);
         const bool grad = bcol == LW;
         const int b = grad ? -1 : bcol;
@@ -635,7 +652,7 @@ __device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int nb_b) {
         }
     }
     // padding of g / sp beyond P and the landmark scaling
-    if (blockIdx.x == 0) {
+    if (blk == 0) {
         for (int a = P + threadIdx.x; a < LW; a += blockDim.x) { c.vec[a] = 0; if (st.scale_pending) c.vec[1 * LW + a] = 0; }
     }
 }
@@ -709,10 +726,11 @@ __device__ __forceinline__ void ps_schur_body(const Batch &B, int s, int tile_in
 // one launch: blocks [0, nb_b) sum the entries of H and the gradient, the blocks behind them form the landmark part of the
 // Schur complement tile by tile
 __global__ __launch_bounds__(256) void ps_asm_b_schur_kernel(Batch B, int nb_b) {
-    const int s = blockIdx.y + B.s0;
+    int s, b;
+    if (!ps_blk(B, s, b)) return;
     extern __shared__ double ps_wk_s[];
-    if ((int)blockIdx.x < nb_b) ps_asm_b_body(B, s, nb_b);
-    else ps_schur_body(B, s, (int)blockIdx.x - nb_b, ps_wk_s);
+    if (b < nb_b) ps_asm_b_body(B, s, b, nb_b);
+    else ps_schur_body(B, s, b - nb_b, ps_wk_s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- SERIAL

@@ -50,6 +50,11 @@ struct vio_batch {
         hipEvent_t ev_solve = nullptr, ev_fe = nullptr, ev_be = nullptr, ev_ingest = nullptr;
         hipStream_t copy_stream = nullptr;   // host -> HBM uploads of vio_feed (on_device == 0), beside the kernels of the previous frame
         hipEvent_t ev_up_gray = nullptr, ev_up_depth = nullptr;
+        // the staging images of vio_feed are double-buffered: frame n uploads into buffer n & 1 while frame n-1's kernels still read the
+        // other one, so an upload only waits for the readers of frame n-2 (ev_rd_gray / ev_rd_depth of its buffer)
+        int flip = 0;
+        hipEvent_t ev_rd_gray[2] = {nullptr, nullptr}, ev_rd_depth[2] = {nullptr, nullptr};
+        bool have_rd_gray[2] = {false, false}, have_rd_depth[2] = {false, false};
         // host -> HBM uploads enqueued on fe_stream / stream by the non-overlap entry points (vio_track, vio_process, vio_process_obs*):
         // asynchronous when the caller's buffers are page-locked, so the next call that takes host buffers waits for them first
         hipEvent_t ev_host_fe = nullptr, ev_host_be = nullptr;
@@ -58,6 +63,8 @@ struct vio_batch {
     };
     std::vector<Group> groups;
     int tracker_lag = 0;              // vio_set_tracker_lag
+    int xcd_n = 0;                    // VIO_XCD_N: override of the XCD count the map assumes (0: 8)
+    int xcd_map = 1;                  // VIO_XCD_MAP: XCD-aware block map of the multi-block ps_* kernels (be_phased.h ps_blk)
     int ps_asm_b_blocks = 24;         // workgroups per sequence that sum the entries of H (VIO_ASM_B_BLOCKS)
     int serial_threads = 512;         // ps_serial block size (VIO_SERIAL_THREADS: 512 or 1024).  Round 3: equal speed (36.2 k vs 36.4 k frames/s); the 512-thread
                                       // build has 256 VGPRs per lane and no scratch, the 1024-thread one spills 21 registers since the matrix-core diagonal block
@@ -65,8 +72,8 @@ struct vio_batch {
     hipStream_t fe_stream = nullptr;  // = groups[0].fe_stream
     hipEvent_t ev[4];
     std::vector<void *> allocs;
-    uint8_t *d_gray_stage = nullptr;
-    uint16_t *d_depth_stage = nullptr;
+    uint8_t *d_gray_stage = nullptr, *d_gray_stage1 = nullptr;       // [S][H][W] staging images of host-buffer calls; the second one only for vio_feed
+    uint16_t *d_depth_stage = nullptr, *d_depth_stage1 = nullptr;
     double *d_stamps = nullptr;
     uint8_t *d_modes = nullptr;       // [S] frame modes of the current vio_feed_modes / vio_track_ex call
     double *d_rrel = nullptr;         // [S][9] caller-supplied relative rotations (vio_track_ex)
@@ -566,13 +573,22 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
         // + 1 slots carry the iterations, two more absorb Cholesky retries (a converged sequence falls through the remaining launches)
         ps_setup_kernel<<<S, 512, 0, st>>>(Bg);
         const int slots = C.c.max_iterations + 2;
+        // XCD-aware block map (ps_blk): every block of a sequence on the XCD its one-block kernels run on
+        const bool xm = h->xcd_map && S >= 8;
+        const int XN = h->xcd_n > 0 ? h->xcd_n : 8;   // (measured with the back-end streams masked to six XCDs: 8 -> +2 %, 6 -> +0.3 %, 3 / 12 -> -1 %: the block -> XCD rotation ignores the mask)
+        const int nb_e = h->ps_eval_blocks, nb_a = h->ps_asm_a_blocks, nb_bs = h->ps_asm_b_blocks + h->ps_schur_tiles, S8 = XN * ((S + XN - 1) / XN);
+        Batch Be = Bg, Ba = Bg, Bb = Bg;
+        Be.ns = Ba.ns = Bb.ns = S;
+        Be.xcd_n = Ba.xcd_n = Bb.xcd_n = XN;
+        Be.xcd_nb = xm ? nb_e : 0; Ba.xcd_nb = xm ? nb_a : 0; Bb.xcd_nb = xm ? nb_bs : 0;
+        const dim3 g_e = xm ? dim3(S8 * nb_e) : dim3(nb_e, S), g_a = xm ? dim3(S8 * nb_a) : dim3(nb_a, S), g_b = xm ? dim3(S8 * nb_bs) : dim3(nb_bs, S);
         for (int k = 0; k < slots; k++) {
-            if (h->eval_occ == 4) ps_eval_kernel_occ4<<<dim3(h->ps_eval_blocks, S), 256, h->lds_ps_eval, st>>>(Bg);
-            else if (h->eval_occ == 3) ps_eval_kernel_occ3<<<dim3(h->ps_eval_blocks, S), 256, h->lds_ps_eval, st>>>(Bg);
-            else ps_eval_kernel<<<dim3(h->ps_eval_blocks, S), 256, h->lds_ps_eval, st>>>(Bg);
-            if (h->asm_a_occ4) ps_asm_a_kernel_occ4<<<dim3(h->ps_asm_a_blocks, S), 512, 0, st>>>(Bg);
-            else ps_asm_a_kernel<<<dim3(h->ps_asm_a_blocks, S), 512, 0, st>>>(Bg);
-            ps_asm_b_schur_kernel<<<dim3(h->ps_asm_b_blocks + h->ps_schur_tiles, S), 256, (size_t)(C.NL + 16 + 3 * 256) * sizeof(double), st>>>(Bg, h->ps_asm_b_blocks);   // per-row factors + the partial tiles of wavefronts 1 .. 3
+            if (h->eval_occ == 4) ps_eval_kernel_occ4<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
+            else if (h->eval_occ == 3) ps_eval_kernel_occ3<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
+            else ps_eval_kernel<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
+            if (h->asm_a_occ4) ps_asm_a_kernel_occ4<<<g_a, 512, 0, st>>>(Ba);
+            else ps_asm_a_kernel<<<g_a, 512, 0, st>>>(Ba);
+            ps_asm_b_schur_kernel<<<g_b, 256, (size_t)(C.NL + 16 + 3 * 256) * sizeof(double), st>>>(Bb, h->ps_asm_b_blocks);   // per-row factors + the partial tiles of wavefronts 1 .. 3
             if (h->serial_big) ps_serial_big_kernel<<<S, 512, h->lds_serial, st>>>(Bg);
             else if (h->serial_threads <= 512) ps_serial_kernel_512<<<S, 512, h->lds_serial, st>>>(Bg);
             else ps_serial_kernel<<<S, 1024, h->lds_serial, st>>>(Bg);
@@ -789,9 +805,12 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     DA(B.odom, S * 11); DA(B.timings, 64);
     B.hist_cap = 2048;
     B.s0 = 0;
+    B.ns = 0; B.xcd_nb = 0; B.xcd_n = 8;
     if (getenv("VIO_BE_THREADS")) h->be_threads = std::min(1024, std::max(64, atoi(getenv("VIO_BE_THREADS")) & ~63));
     if (getenv("VIO_ASM_B_BLOCKS")) h->ps_asm_b_blocks = std::max(1, std::min(256, atoi(getenv("VIO_ASM_B_BLOCKS"))));
     if (getenv("VIO_EVAL_OCC")) h->eval_occ = atoi(getenv("VIO_EVAL_OCC"));
+    if (getenv("VIO_XCD_MAP")) h->xcd_map = atoi(getenv("VIO_XCD_MAP"));
+    if (getenv("VIO_XCD_N")) h->xcd_n = atoi(getenv("VIO_XCD_N"));
     if (getenv("VIO_ASM_A_OCC")) h->asm_a_occ4 = atoi(getenv("VIO_ASM_A_OCC")) >= 4;
     if (getenv("VIO_SERIAL_THREADS")) h->serial_threads = atoi(getenv("VIO_SERIAL_THREADS")) >= 1024 ? 1024 : 512;
     if (getenv("VIO_MARG_THREADS")) h->marg_threads = std::min(512, std::max(64, atoi(getenv("VIO_MARG_THREADS")) & ~63));
@@ -910,6 +929,8 @@ void vio_destroy(vio_batch *h) {
     for (void *p : h->allocs) (void)hipFree(p);
     if (h->d_gray_stage) (void)hipFree(h->d_gray_stage);
     if (h->d_depth_stage) (void)hipFree(h->d_depth_stage);
+    if (h->d_gray_stage1) (void)hipFree(h->d_gray_stage1);
+    if (h->d_depth_stage1) (void)hipFree(h->d_depth_stage1);
     for (auto &sg : h->imu_stage) {
         if (sg.h_seq) {
             (void)hipHostFree(sg.h_seq); (void)hipHostFree(sg.h_t); (void)hipHostFree(sg.h_acc); (void)hipHostFree(sg.h_gyr);
@@ -933,6 +954,10 @@ void vio_destroy(vio_batch *h) {
         if (g.ev_ingest) (void)hipEventDestroy(g.ev_ingest);
         if (g.ev_up_gray) (void)hipEventDestroy(g.ev_up_gray);
         if (g.ev_up_depth) (void)hipEventDestroy(g.ev_up_depth);
+        for (int p = 0; p < 2; p++) {
+            if (g.ev_rd_gray[p]) (void)hipEventDestroy(g.ev_rd_gray[p]);
+            if (g.ev_rd_depth[p]) (void)hipEventDestroy(g.ev_rd_depth[p]);
+        }
         if (g.ev_host_fe) (void)hipEventDestroy(g.ev_host_fe);
         if (g.ev_host_be) (void)hipEventDestroy(g.ev_host_be);
         if (g.copy_stream) (void)hipStreamDestroy(g.copy_stream);
@@ -973,6 +998,14 @@ int vio_push_imu(vio_batch *h, int seq, int n, const double *t, const double *ac
     return VIO_OK;
 }
 
+// the last reader of a staging buffer has been enqueued on `st`: uploads into that buffer wait for this point
+static int note_stage_read(hipEvent_t &ev, bool &have, hipStream_t st) {
+    if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(ev, st));
+    have = true;
+    return VIO_OK;
+}
+
 static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, const uint16_t *depth, const double *stamps, int on_device,
                         const uint8_t **dg, const uint16_t **dd, bool overlap = false) {
     // every group uploads its own slice on its own streams: in order with the kernels that consume it, no cross-group hazard
@@ -980,9 +1013,10 @@ static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, 
     size_t HW = (size_t)C.c.width * C.c.height, S = h->S, s0 = g.s0, n = g.n;
     if (stamps) HIPCHK(hipMemcpyAsync(h->d_stamps + s0, stamps + s0, n * sizeof(double), hipMemcpyHostToDevice, g.fe_stream));
     if (on_device) { *dg = gray; *dd = depth; return VIO_OK; }
-    // overlap (vio_feed): the uploads run on the group's copy stream as soon as the staging buffers are free (the previous frame's
-    // front-end has read the grey image, its be_ingest the depth image), i.e. beside the previous frame's optimisation, and the
-    // consumers wait for them through events.  Otherwise the copies sit in the consumer's own stream.
+    // overlap (vio_feed): the uploads run on the group's copy stream into staging buffer g.flip as soon as that buffer is free (the
+    // front-end of two frames ago has read the grey image, its be_ingest the depth image), i.e. beside the previous frame's kernels,
+    // and the consumers wait for them through events.  Otherwise the copies sit in the consumer's own stream and use buffer 0.
+    const int p = overlap ? g.flip : 0;
     if (overlap && !g.copy_stream) {
         HIPCHK(hipStreamCreate(&g.copy_stream));
         HIPCHK(hipEventCreateWithFlags(&g.ev_up_gray, hipEventDisableTiming));
@@ -994,27 +1028,28 @@ static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, 
         HIPCHK(hipEventSynchronize(g.ev_up_depth));
     }
     if (gray) {
-        if (!h->d_gray_stage) HIPCHK(hipMalloc((void **)&h->d_gray_stage, S * HW));
+        uint8_t *&buf = p ? h->d_gray_stage1 : h->d_gray_stage;
+        if (!buf) HIPCHK(hipMalloc((void **)&buf, S * HW));
         if (overlap) {
-            HIPCHK(hipStreamWaitEvent(g.copy_stream, g.ev_fe, 0));
-            HIPCHK(hipMemcpyAsync(h->d_gray_stage + s0 * HW, gray + s0 * HW, n * HW, hipMemcpyHostToDevice, g.copy_stream));
+            if (g.have_rd_gray[p]) HIPCHK(hipStreamWaitEvent(g.copy_stream, g.ev_rd_gray[p], 0));
+            HIPCHK(hipMemcpyAsync(buf + s0 * HW, gray + s0 * HW, n * HW, hipMemcpyHostToDevice, g.copy_stream));
             HIPCHK(hipEventRecord(g.ev_up_gray, g.copy_stream));
             HIPCHK(hipStreamWaitEvent(g.fe_stream, g.ev_up_gray, 0));
         } else
-            HIPCHK(hipMemcpyAsync(h->d_gray_stage + s0 * HW, gray + s0 * HW, n * HW, hipMemcpyHostToDevice, g.fe_stream));
-        *dg = h->d_gray_stage;
+            HIPCHK(hipMemcpyAsync(buf + s0 * HW, gray + s0 * HW, n * HW, hipMemcpyHostToDevice, g.fe_stream));
+        *dg = buf;
     }
     if (depth) {
-        if (!h->d_depth_stage) HIPCHK(hipMalloc((void **)&h->d_depth_stage, S * HW * 2));
+        uint16_t *&buf = p ? h->d_depth_stage1 : h->d_depth_stage;
+        if (!buf) HIPCHK(hipMalloc((void **)&buf, S * HW * 2));
         if (overlap) {
-            if (g.have_ingest_ev) HIPCHK(hipStreamWaitEvent(g.copy_stream, g.ev_ingest, 0));
-            HIPCHK(hipStreamWaitEvent(g.copy_stream, g.ev_be, 0));   // a vio_process* call in between reads the staging buffer too
-            HIPCHK(hipMemcpyAsync(h->d_depth_stage + s0 * HW, depth + s0 * HW, n * HW * 2, hipMemcpyHostToDevice, g.copy_stream));
+            if (g.have_rd_depth[p]) HIPCHK(hipStreamWaitEvent(g.copy_stream, g.ev_rd_depth[p], 0));
+            HIPCHK(hipMemcpyAsync(buf + s0 * HW, depth + s0 * HW, n * HW * 2, hipMemcpyHostToDevice, g.copy_stream));
             HIPCHK(hipEventRecord(g.ev_up_depth, g.copy_stream));
             HIPCHK(hipStreamWaitEvent(g.stream, g.ev_up_depth, 0));
         } else
-            HIPCHK(hipMemcpyAsync(h->d_depth_stage + s0 * HW, depth + s0 * HW, n * HW * 2, hipMemcpyHostToDevice, g.stream));
-        *dd = h->d_depth_stage;
+            HIPCHK(hipMemcpyAsync(buf + s0 * HW, depth + s0 * HW, n * HW * 2, hipMemcpyHostToDevice, g.stream));
+        *dd = buf;
     }
     return VIO_OK;
 }
@@ -1078,9 +1113,14 @@ int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, 
         rc = launch_frontend(h, g, dg, 1, 1, modes ? h->d_modes : nullptr, nullptr);
         if (rc != VIO_OK) return rc;
         if (g.s0 == 0) HIPCHK(hipEventRecord(h->ev[1], g.fe_stream));
+        if (!on_device && (rc = note_stage_read(g.ev_rd_gray[g.flip], g.have_rd_gray[g.flip], g.fe_stream)) != VIO_OK) return rc;
         if ((rc = be_wait(g)) != VIO_OK) return rc;
         rc = launch_backend(h, g, dd, kTrackerMap);
         if (rc != VIO_OK) return rc;
+        if (!on_device) {
+            if ((rc = note_stage_read(g.ev_rd_depth[g.flip], g.have_rd_depth[g.flip], g.stream)) != VIO_OK) return rc;
+            g.flip ^= 1;
+        }
         if (g.s0 == 0) HIPCHK(hipEventRecord(h->ev[2], g.stream));
     }
     if (h->prof_cur >= 0) h->prof_cur++;
@@ -1109,6 +1149,7 @@ static int track_impl(vio_batch *h, const uint8_t *gray, const double *stamps, i
         if ((rc = note_host_upload(g, true, false)) != VIO_OK) return rc;
         rc = launch_frontend(h, g, dg, publish ? 1 : 0, 0, modes ? h->d_modes : nullptr, R_rel ? h->d_rrel : nullptr);
         if (rc != VIO_OK) return rc;
+        if (!on_device && (rc = note_stage_read(g.ev_rd_gray[0], g.have_rd_gray[0], g.fe_stream)) != VIO_OK) return rc;
         if ((rc = be_wait(g)) != VIO_OK) return rc;
     }
     return VIO_OK;
@@ -1216,6 +1257,7 @@ int vio_process(vio_batch *h, const uint16_t *depth_mm, int on_device) {
         rc = launch_backend(h, g, dd, kTrackerMap);
         if (rc != VIO_OK) return rc;
         HIPCHK(hipEventRecord(g.ev_be, g.stream));
+        if ((rc = note_stage_read(g.ev_rd_depth[0], g.have_rd_depth[0], g.stream)) != VIO_OK) return rc;
     }
     return VIO_OK;
 }
@@ -1249,6 +1291,7 @@ int vio_process_obs_batch(vio_batch *h, const int32_t *n_obs, const int32_t *ids
         rc = launch_backend(h, g, dd, src);
         if (rc != VIO_OK) return rc;
         HIPCHK(hipEventRecord(g.ev_be, g.stream));
+        if ((rc = note_stage_read(g.ev_rd_depth[0], g.have_rd_depth[0], g.stream)) != VIO_OK) return rc;
     }
     return VIO_OK;
 }
@@ -1279,6 +1322,7 @@ int vio_process_obs(vio_batch *h, int seq, int n, const int32_t *ids, const doub
     rc = launch_backend(h, g, h->d_depth_stage, src, seq);
     if (rc != VIO_OK) return rc;
     HIPCHK(hipEventRecord(g.ev_be, g.stream));
+    if ((rc = note_stage_read(g.ev_rd_depth[0], g.have_rd_depth[0], g.stream)) != VIO_OK) return rc;
     return VIO_OK;
 }
 

@@ -154,6 +154,7 @@ struct Batch {
     DevCfg *cfg;  // device copy
     int S;
     int s0;               // first sequence of the launching group: kernels use s = blockIdx + s0
+    int ns, xcd_nb, xcd_n; // sequences of this launch; blocks per sequence under the XCD-aware block map of the ps_* kernels (0: plain 2-D grid) -- be_phased.h ps_blk
     int tracker_lag;      // 0: fe_begin reads the live estimator state; 1: the snapshot be_ingest took one frame earlier
     FeSeq *fe;
     BeSeq *be;
