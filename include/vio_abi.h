@@ -299,6 +299,12 @@ int vio_stage_host_sfm_window(int window_size, int nf, const int32_t *start, con
 int vio_stage_imu_block(const vio_config *cfg, int n, const double *dt, const double *acc, const double *gyr, const double *acc0,
                         const double *gyr0, const double *ba, const double *bg, const double *pose_i, const double *sb_i,
                         const double *pose_j, const double *sb_j, double *G961);
+/* The dense solve at the bottom of every trust-region step (Ceres DENSE_SCHUR on the reduced camera system, estimator.cpp:1251-1263;
+ * Eigen LLT underneath) through the LDS-tile Cholesky of the solve kernels: S [16 nb][16 nb] row-major symmetric positive definite
+ * (nb <= 11), rhs [16 nb].  L_out: the lower triangle of the factor (row-major; entries above the diagonal are left as passed in),
+ * x_out = S^-1 rhs (NaN when a pivot was not positive), usec5 = {factorisation with the forward substitution riding along, backward
+ * substitution, then the factorisation as thread 0 sees it: panels, diagonal block + trailing update, barrier wait}: microseconds inside the kernel, mean over `reps` repetitions, with `blocks` identical workgroups side by side. */
+int vio_stage_chol(int nb, int reps, int blocks, const double *S, const double *rhs, double *L_out, double *x_out, double *usec5);
 
 #ifdef __cplusplus
 }

@@ -219,3 +219,29 @@ def test_imu_block_on_the_matrix_cores_matches_oracle(P, orc):
         Gref = A.T @ A
         assert np.abs(G - G.T).max() == 0.0
         assert np.abs(G - Gref).max() <= 1e-7 * np.abs(Gref).max(), float(np.abs(G - Gref).max() / np.abs(Gref).max())
+
+
+@pytest.mark.parametrize("nb", [1, 2, 7, 11])
+def test_tile_cholesky_against_numpy(P, nb):
+    """The dense solve of the reduced camera system (Ceres DENSE_SCHUR, estimator.cpp:1251-1263) through the LDS-tile Cholesky of
+    ps_serial (be_linalg.h chol_tiles / chol_backward_tiles: diagonal blocks by rank-1 updates on v_mfma_f64_16x16x4, panels as
+    A M^T with M = L^-1 of the block) against numpy on a matrix with condition 1e6: the factor to 1e-11 of its largest entry, the
+    solution to 1e-9 (cond x eps); a matrix that is not positive definite is reported, not factored."""
+    n = 16 * nb
+    rng = np.random.default_rng(40 + nb)
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    w = np.exp(rng.uniform(0, np.log(1e6), n))
+    S = (q * w) @ q.T
+    S = 0.5 * (S + S.T)
+    b = rng.standard_normal(n)
+    L = np.zeros((n, n)); x = np.zeros(n); us = np.zeros(5)
+    assert P.lib().vio_stage_chol(nb, 1, 1, S.ctypes.data, b.ctypes.data, L.ctypes.data, x.ctypes.data, us.ctypes.data) == 0
+    Lr = np.linalg.cholesky(S)
+    assert np.abs(np.triu(L, 1)).max() == 0.0
+    assert np.abs(L - Lr).max() <= 1e-11 * np.abs(Lr).max()
+    xr = np.linalg.solve(S, b)
+    assert np.abs(x - xr).max() <= 1e-9 * np.abs(xr).max()
+    S2 = S.copy()
+    S2[n - 3, n - 3] = -1.0
+    assert P.lib().vio_stage_chol(nb, 1, 1, S2.ctypes.data, b.ctypes.data, L.ctypes.data, x.ctypes.data, us.ctypes.data) == 0
+    assert np.isnan(x).all()

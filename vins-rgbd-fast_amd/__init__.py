@@ -137,6 +137,7 @@ def lib():
         L.vio_stage_projection_residual.argtypes = L.vio_stage_projection.argtypes
         L.vio_stage_pnp.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vio_stage_imu_block.argtypes = [C.POINTER(Config), C.c_int] + [C.c_void_p] * 12
+        L.vio_stage_chol.argtypes = [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5
         _lib = L
     return _lib
 

@@ -1858,7 +1858,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
                 }
                 PH(9);
                 if (chol_ok) {
-                    if (tiles_in_lds) chol_backward_tiles(work, LW >> 4, xs, chol_dinv);
+                    if (tiles_in_lds) chol_backward_tiles_wave(work, LW >> 4, xs, chol_dinv);
                     else chol_solve_blocked(c.Sc, LW, LW, xs, work);
                     PH(10);
                     double bad = 0;

@@ -901,8 +901,12 @@ __device__ __forceinline__ void chol_panel_tile(double *A, const double *D, cons
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     v4f64 x = {0, 0, 0, 0};
     double a[4], b[4];
+    // (every load unconditional -- the entry of M is picked afterwards: a load under a condition is a branch with its own s_waitcnt)
+    const double dv = dinv16[li];
 #pragma unroll
-    for (int kk = 0; kk < 4; kk++) { const int k = 4 * kk + lk; a[kk] = A[(li << 4) + (k ^ li)]; b[kk] = chol_minv(D, dinv16, li, k); }
+    for (int kk = 0; kk < 4; kk++) { const int k = 4 * kk + lk; a[kk] = A[(li << 4) + (k ^ li)]; b[kk] = D[(k << 4) + (li ^ k)]; }
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) { const int k = 4 * kk + lk; b[kk] = k < li ? b[kk] : (k == li ? dv : 0.0); }
 #pragma unroll
     for (int kk = 0; kk < 4; kk++) x = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], b[kk], x, 0, 0, 0);
 #pragma unroll
@@ -910,12 +914,14 @@ __device__ __forceinline__ void chol_panel_tile(double *A, const double *D, cons
 }
 // y = M b for one 16-vector (forward substitution step of the right-hand side), lanes 0 .. 15 of the calling wavefront
 __device__ __forceinline__ void chol_rhs_block(double *b16, const double *D, const double *dinv16) {
-    const int lane = threadIdx.x & 63;
-    double y = 0;
-    if (lane < 16) {
+    const int lane = threadIdx.x & 63, n = lane & 15;
+    double m[16], bv[16];
+    const double dv = dinv16[n];
 #pragma unroll
-        for (int k = 0; k < 16; k++) y += chol_minv(D, dinv16, lane, k) * b16[k];
-    }
+    for (int k = 0; k < 16; k++) { m[k] = D[(k << 4) + (n ^ k)]; bv[k] = b16[k]; }
+    double y = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) y += (k < n ? m[k] : (k == n ? dv : 0.0)) * bv[k];
     WAVE_SYNC();
     if (lane < 16) b16[lane] = y;
     WAVE_SYNC();
@@ -929,12 +935,16 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
     const int li = lane & 15, lk = lane >> 4;
     auto diag = [&](int p) -> double * { return T + ((p * (p + 1) / 2 + p) << 8); };
     auto update_tile = [&](int ti, int tj, int p) {
+        // (all twelve loads first: written as an expression inside the MFMA chain they were issued pair by pair, one LDS round trip
+        // per k-step)
         v4f64 acc;
+        double a[4], b[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) acc[r] = T[tl_idx(ti, tj, lk + 4 * r, li)];
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-T[tl_idx(ti, p, li, 4 * kk + lk)], T[tl_idx(tj, p, li, 4 * kk + lk)], acc, 0, 0, 0);
+        for (int kk = 0; kk < 4; kk++) { a[kk] = T[tl_idx(ti, p, li, 4 * kk + lk)]; b[kk] = T[tl_idx(tj, p, li, 4 * kk + lk)]; }
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[kk], b[kk], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; r++) T[tl_idx(ti, tj, lk + 4 * r, li)] = acc[r];
     };
@@ -948,6 +958,11 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
             rhs[16 * ti + r] -= sacc;
         }
     };
+    // the trailing tiles are handed out through a counter in LDS: wavefront 0 joins the others as soon as the next diagonal block is
+    // factored (a fixed assignment left it idle behind the short factorisation of the last steps and the others behind the 54 tiles of
+    // the first)
+    __shared__ int ctr_s;
+    int *ctr = &ctr_s;
     if (t == 0) *sh_flag = 1;
     __syncthreads();
     if (wave == 0) chol_diag_tile(diag(0), dinv, sh_flag);
@@ -958,24 +973,26 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
         // (b) panel: the tiles below the diagonal block become A M^T (one wavefront per tile); the right-hand side block becomes M b
         for (int ti = p + 1 + wave; ti < nb; ti += nw) chol_panel_tile(T + ((ti * (ti + 1) / 2 + p) << 8), diag(p), dinv + 16 * p);
         if (rhs && wave == nw - 1) chol_rhs_block(rhs + 16 * p, diag(p), dinv + 16 * p);
+        if (t == 0) *ctr = 1;
         __syncthreads();
         if (tm && t == 0) { long long n_ = (long long)wall_clock64(); tm[0] += (float)(n_ - tm0); tm0 = n_; }
         // (c) trailing update S22 -= L21 L21^T on the FP64 matrix cores; tile 0 = (p+1, p+1) belongs to wavefront 0
         const int m = nb - 1 - p, ntile = m * (m + 1) / 2;
         if (nw > 1) {
-            if (wave == 0) {
-                if (ntile > 0) {
-                    update_tile(p + 1, p + 1, p);
-                    WAVE_SYNC();
-                    chol_diag_tile(diag(p + 1), dinv + 16 * (p + 1), sh_flag);
-                }
-            } else {
-                if (rhs && wave == nw - 1) update_rhs(p);
-                for (int tile = wave; tile < ntile; tile += nw - 1) {  // tiles 1.. over wavefronts 1..nw-1
-                    int ti, tj;
-                    tri_decode(tile, ti, tj);
-                    update_tile(ti + p + 1, tj + p + 1, p);
-                }
+            if (ntile > 0 && wave == 0) {
+                update_tile(p + 1, p + 1, p);
+                WAVE_SYNC();
+                chol_diag_tile(diag(p + 1), dinv + 16 * (p + 1), sh_flag);
+            }
+            if (rhs && wave == nw - 1) update_rhs(p);
+            for (;;) {
+                int tile = 0;
+                if (lane == 0) tile = atomicAdd(ctr, 1);
+                tile = __builtin_amdgcn_readfirstlane(tile);
+                if (tile >= ntile) break;
+                int ti, tj;
+                tri_decode(tile, ti, tj);
+                update_tile(ti + p + 1, tj + p + 1, p);
             }
         } else {
             if (rhs) update_rhs(p);
@@ -1088,6 +1105,42 @@ __device__ __forceinline__ void chol_backward_tiles(const double *T, int nb, dou
         }
         __syncthreads();
     }
+}
+
+// The same backward half by wavefront 0 alone for tiles resident in LDS: no workgroup barrier inside (the 2 x nb barriers and the
+// conditional loads of chol_backward_tiles were 20 us of a 75 us solve at nb = 11), every load of a step unconditional and in flight
+// at once, per element the operations of chol_backward_tiles in the same order (bit-identical results).  Ends with one barrier.
+__device__ __forceinline__ void chol_backward_tiles_wave(const double *T, int nb, double *xs, const double *dinv) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {
+        const int c = lane & 15;
+        for (int p = nb - 1; p >= 0; p--) {
+            const double *D = T + ((size_t)(p * (p + 1) / 2 + p) << 8);
+            double m[16], b[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) { m[k] = D[(c << 4) + (k ^ c)]; b[k] = xs[16 * p + k]; }
+            const double dv = dinv[16 * p + c];
+            double x = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) x += (k > c ? m[k] : (k == c ? dv : 0.0)) * b[k];   // M[k][c]
+            WAVE_SYNC();
+            if (lane < 16) xs[16 * p + lane] = x;
+            WAVE_SYNC();
+#pragma unroll
+            for (int k = 0; k < 16; k++) b[k] = xs[16 * p + k];
+            for (int q = lane; q < 16 * p; q += 64) {
+                const int tj = q >> 4, cc = q & 15;
+#pragma unroll
+                for (int k = 0; k < 16; k++) m[k] = T[tl_idx(p, tj, k, cc)];
+                double sacc = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) sacc += m[k] * b[k];
+                xs[q] -= sacc;
+            }
+            WAVE_SYNC();
+        }
+    }
+    __syncthreads();
 }
 
 __device__ __forceinline__ void chol_solve_tiles(const double *T, int nb, double *xs, const double *dinv) {

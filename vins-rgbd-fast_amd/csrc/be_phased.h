@@ -866,7 +866,7 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
         PH(51);
         if (ok) {
             if (big) chol_backward_tiles(c.Sc, LW >> 4, xs, chol_dinv);
-            else chol_backward_tiles(work, LW >> 4, xs, chol_dinv);
+            else chol_backward_tiles_wave(work, LW >> 4, xs, chol_dinv);
             PH(56);
             double bad = 0;
             for (int a = t; a < P; a += nt) if (!isfinite(xs[a])) bad += 1;
