@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--dump", default="", help="write the final windows / odometry rows of this rank's sequences to <dump>.rank<r>.npz")
     ap.add_argument("--tracker-lag", type=int, default=1, choices=[0, 1], help="vio_set_tracker_lag: 1 = the tracker of frame f+1 overlaps the "
                     "optimisation of frame f (the reference's two threads with the estimator one frame behind), 0 = it waits for it")
-    ap.add_argument("--pcie-steps", type=int, default=10, help="extra steps fed from HOST buffers after the timed region (0 = skip)")
+    ap.add_argument("--pcie-steps", type=int, default=20, help="extra steps fed from HOST buffers after the timed region (0 = skip)")
     ap.add_argument("--stream-steps", type=int, default=10, help="extra steps with the IMU pushed frame by frame")
     args = ap.parse_args()
 

@@ -62,11 +62,6 @@ struct vio_batch {
         bool have_solve_ev = false, have_ingest_ev = false;
     };
     std::vector<Group> groups;
-    // VIO_FE_SHARED=1 (tracker lag 1, vio_feed only): ONE front-end launch set over all sequences on fe_all's stream, the stream groups keep
-    // only their back-end chains.  The command processor serves four queues at a time; with the front-end on one queue three back-end
-    // chains fit beside it.
-    Group fe_all;
-    bool fe_shared = false;
     int tracker_lag = 0;              // vio_set_tracker_lag
     int xcd_n = 0;                    // VIO_XCD_N: override of the XCD count the map assumes (0: 8)
     int xcd_map = 1;                  // VIO_XCD_MAP: XCD-aware block map of the multi-block ps_* kernels (be_phased.h ps_blk)
@@ -157,13 +152,9 @@ static int raise_lds_limit(const void *fn, size_t bytes) {
 }
 
 static int sync_all(vio_batch *h) {
-    if (h->fe_all.fe_stream) {
-        if (h->fe_all.copy_stream) HIPCHK(hipStreamSynchronize(h->fe_all.copy_stream));
-        HIPCHK(hipStreamSynchronize(h->fe_all.fe_stream));
-    }
     for (auto &g : h->groups) {
         if (g.copy_stream) HIPCHK(hipStreamSynchronize(g.copy_stream));
-        if (g.fe_stream) HIPCHK(hipStreamSynchronize(g.fe_stream));
+        HIPCHK(hipStreamSynchronize(g.fe_stream));
         HIPCHK(hipStreamSynchronize(g.stream));
         g.host_fe_pending = g.host_be_pending = false;
     }
@@ -341,7 +332,7 @@ int flush_imu_frontend(vio_batch *h) {
         std::lock_guard<std::mutex> lk(h->imu_mu);
         if (h->p_seq.empty()) return VIO_OK;
     }
-    hipStream_t st = (h->fe_shared && h->fe_all.fe_stream) ? h->fe_all.fe_stream : h->groups[0].fe_stream;
+    hipStream_t st = h->groups[0].fe_stream;
     for (auto &g : h->groups) {
         if (h->tracker_lag) { if (g.have_ingest_ev) HIPCHK(hipStreamWaitEvent(st, g.ev_ingest, 0)); }   // be_ingest is the last reader of the rings
         else if (g.have_solve_ev) HIPCHK(hipStreamWaitEvent(st, g.ev_solve, 0));
@@ -352,7 +343,7 @@ int flush_imu_frontend(vio_batch *h) {
     if (rc != VIO_OK || !launched) return rc;
     if (h->groups.size() > 1) {
         HIPCHK(hipEventRecord(h->ev_imu, st));
-        for (size_t k = 1; k < h->groups.size(); k++) if (h->groups[k].fe_stream) HIPCHK(hipStreamWaitEvent(h->groups[k].fe_stream, h->ev_imu, 0));
+        for (size_t k = 1; k < h->groups.size(); k++) HIPCHK(hipStreamWaitEvent(h->groups[k].fe_stream, h->ev_imu, 0));
     }
     return VIO_OK;
 }
@@ -766,11 +757,8 @@ static int create_group_streams(vio_batch *h, vio_batch::Group &g, bool partitio
             if (q < fe_cus) mfe[q >> 5] |= 1u << (q & 31);
             if (q >= b0 && q < b1) mbe[q >> 5] |= 1u << (q & 31);
         }
-        // (shared front-end: a stream group needs no front-end queue and fe_all no back-end queue -- every queue that exists takes a
-        // slot on one of the command processor's pipes)
-        const bool only_be = h->fe_shared && &g != &h->fe_all, only_fe = h->fe_shared && &g == &h->fe_all;
-        e_fe = only_be ? hipSuccess : hipExtStreamCreateWithCUMask(&g.fe_stream, (uint32_t)nw, mfe.data());
-        e_be = only_fe ? hipSuccess : getenv("VIO_BE_CU_ALL") ? hipStreamCreate(&g.stream) : hipExtStreamCreateWithCUMask(&g.stream, (uint32_t)nw, mbe.data());
+        e_fe = hipExtStreamCreateWithCUMask(&g.fe_stream, (uint32_t)nw, mfe.data());
+        e_be = getenv("VIO_BE_CU_ALL") ? hipStreamCreate(&g.stream) : hipExtStreamCreateWithCUMask(&g.stream, (uint32_t)nw, mbe.data());
     } else {
         e_fe = hipStreamCreate(&g.fe_stream);
         e_be = hipStreamCreate(&g.stream);
@@ -823,7 +811,6 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     if (getenv("VIO_EVAL_OCC")) h->eval_occ = atoi(getenv("VIO_EVAL_OCC"));
     if (getenv("VIO_XCD_MAP")) h->xcd_map = atoi(getenv("VIO_XCD_MAP"));
     if (getenv("VIO_XCD_N")) h->xcd_n = atoi(getenv("VIO_XCD_N"));
-    if (getenv("VIO_FE_SHARED")) h->fe_shared = atoi(getenv("VIO_FE_SHARED")) != 0;
     if (getenv("VIO_ASM_A_OCC")) h->asm_a_occ4 = atoi(getenv("VIO_ASM_A_OCC")) >= 4;
     if (getenv("VIO_SERIAL_THREADS")) h->serial_threads = atoi(getenv("VIO_SERIAL_THREADS")) >= 1024 ? 1024 : 512;
     if (getenv("VIO_MARG_THREADS")) h->marg_threads = std::min(512, std::max(64, atoi(getenv("VIO_MARG_THREADS")) & ~63));
@@ -1031,7 +1018,7 @@ static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, 
     // and the consumers wait for them through events.  Otherwise the copies sit in the consumer's own stream and use buffer 0.
     const int p = overlap ? g.flip : 0;
     if (overlap && !g.copy_stream) {
-        HIPCHK(hipStreamCreate(&g.copy_stream));
+        HIPCHK(hipStreamCreate(&g.copy_stream));   // (one per group: a copy stream shared by the groups measured 27.9 k against 33.9 k frames/s from page-locked buffers)
         HIPCHK(hipEventCreateWithFlags(&g.ev_up_gray, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&g.ev_up_depth, hipEventDisableTiming));
     } else if (overlap) {
@@ -1115,37 +1102,6 @@ int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, 
     if (rc != VIO_OK) return rc;
     rc = flush_imu_frontend(h);
     if (rc != VIO_OK) return rc;
-    if (h->fe_shared && h->tracker_lag == 1 && h->fe_all.fe_stream) {
-        vio_batch::Group &F = h->fe_all;
-        for (auto &g : h->groups) if (g.have_ingest_ev) HIPCHK(hipStreamWaitEvent(F.fe_stream, g.ev_ingest, 0));
-        const uint8_t *dg = nullptr;
-        const uint16_t *dd = nullptr;
-        rc = stage_inputs(h, F, gray, nullptr, stamps, on_device, &dg, &dd, /*overlap=*/true);
-        if (rc != VIO_OK) return rc;
-        if (on_device) dg = gray;
-        if ((rc = stage_side_inputs(h, F, modes, nullptr)) != VIO_OK) return rc;
-        HIPCHK(hipEventRecord(h->ev[0], F.fe_stream));
-        { vio_batch::Group &g = F; rc = launch_frontend(h, g, dg, 1, 1, modes ? h->d_modes : nullptr, nullptr); }
-        if (rc != VIO_OK) return rc;
-        HIPCHK(hipEventRecord(h->ev[1], F.fe_stream));
-        if (!on_device) { if ((rc = note_stage_read(F.ev_rd_gray[F.flip], F.have_rd_gray[F.flip], F.fe_stream)) != VIO_OK) return rc; F.flip ^= 1; }
-        HIPCHK(hipEventRecord(F.ev_fe, F.fe_stream));
-        for (auto &g : h->groups) {
-            HIPCHK(hipStreamWaitEvent(g.stream, F.ev_fe, 0));
-            const uint8_t *dg2 = nullptr;
-            dd = nullptr;
-            rc = stage_inputs(h, g, nullptr, depth_mm, nullptr, on_device, &dg2, &dd, /*overlap=*/true);
-            if (rc != VIO_OK) return rc;
-            if (on_device) dd = depth_mm;
-            rc = launch_backend(h, g, dd, kTrackerMap);
-            if (rc != VIO_OK) return rc;
-            if (!on_device) { if ((rc = note_stage_read(g.ev_rd_depth[g.flip], g.have_rd_depth[g.flip], g.stream)) != VIO_OK) return rc; g.flip ^= 1; }
-            if (g.s0 == 0) HIPCHK(hipEventRecord(h->ev[2], g.stream));
-        }
-        if (h->prof_cur >= 0) h->prof_cur++;
-        h->timing_valid = true;
-        return VIO_OK;
-    }
     for (auto &g : h->groups) {
         if ((rc = fe_wait(h, g)) != VIO_OK) return rc;
         const uint8_t *dg = nullptr;
@@ -1231,11 +1187,6 @@ int vio_set_tracker_lag(vio_batch *h, int lag) {
     if (lag != h->tracker_lag) {   // the overlapping front-end gets its own compute units (see create_group_streams)
         for (auto &g : h->groups) if ((rc = create_group_streams(h, g, lag == 1)) != VIO_OK) return rc;
         h->stream = h->groups[0].stream; h->fe_stream = h->groups[0].fe_stream;
-        if (h->fe_shared && lag == 1) {
-            h->fe_all.s0 = 0; h->fe_all.n = h->S;
-            if ((rc = create_group_streams(h, h->fe_all, true)) != VIO_OK) return rc;
-            if (!h->fe_all.ev_fe) HIPCHK(hipEventCreateWithFlags(&h->fe_all.ev_fe, hipEventDisableTiming));
-        }
     }
     h->tracker_lag = lag;
     h->B.tracker_lag = lag;
