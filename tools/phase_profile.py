@@ -24,6 +24,7 @@ NAMES = {0: "vector2double", 1: "lm indexing", 2: "pair lists", 4: "evaluate(fir
          62: "eval block 0 (prior)", 63: "eval block 1 (imu)", 14: "eval block 3 (256 projections)", 15: "eval accept",
          28: "finish slide states", 29: "finish slide landmarks", 30: "finish removeFailures + odom",
          32: "asm_a pair (0,1) item", 33: "asm_a pair (0,W) item", 34: "asm_a imu item 0", 35: "asm_a landmark rows item 0", 36: "asm element sums", 37: "asm lm rows",
+         36: "  marg 21a: 15x15 inverse", 37: "  marg 21b: T1 / Amr staging", 38: "  marg 22a: prior_H / prior_r stores", 39: "  marg 22b: tile fill",
          45: "  eval b0: X to LDS", 40: "  eval b0: prior dx", 44: "  eval b0: A dx partials", 46: "  eval b1: X + headers to LDS"}
 
 

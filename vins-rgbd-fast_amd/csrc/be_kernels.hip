@@ -161,6 +161,78 @@ __device__ void preint_propagate(PreInt &p, PreWork &w, const vio_config &c, dou
     __syncthreads();
 }
 
+// n propagate steps on the LDS-resident jacobian / covariance (preint_load'ed into w), pipelined in chunks of PI_CH samples like the
+// per-frame integration of be_ingest: thread 0 runs the short delta-state recursion of a chunk and keeps the state before every step,
+// one lane per sample builds that step's F and V from it, the jacobian / covariance recursion consumes them step by step.  The
+// arithmetic of n calls of preint_propagate (be_factors.h preint_state_step / preint_step_FV are the two halves of preint_midpoint)
+// with the serial part of a step shrunk from the whole midpoint step to the recursion.  append: the samples are also filed into p's
+// own buffers (IntegrationBase::push_back).  Used for the merge of MARGIN_SECOND_NEW (estimator.cpp:1651-1687), where the step-by-step
+// version was 100 of the 190 us of that branch.
+__device__ void preint_propagate_many(PreInt &p, PreWork &w, const vio_config &cfg, int n, const double *dt_src, const double (*acc_src)[3],
+                                      const double (*gyr_src)[3], bool append) {
+    const int t = threadIdx.x;
+    __shared__ double pm_F[PI_CH][225], pm_V[PI_CH][270];
+    __shared__ double pm_dt[PI_CH], pm_acc[PI_CH][3], pm_gyr[PI_CH][3];
+    __shared__ bf::PreintPre pm_pre[PI_CH];
+    const int nb0 = p.n_buf;
+    const v3 lba = ld3(p.lin_ba), lbg = ld3(p.lin_bg);
+    quat s_dq = mkq(p.dq[0], p.dq[1], p.dq[2], p.dq[3]);
+    v3 s_dp = ld3(p.dp), s_dv = ld3(p.dv), s_a0 = ld3(p.acc0), s_g0 = ld3(p.gyr0);
+    double s_sum = p.sum_dt;
+    __syncthreads();
+    for (int q0 = 0; q0 < n; q0 += PI_CH) {
+        const int m = min(PI_CH, n - q0);
+        if (t < m) {
+            const int q = q0 + t;
+            pm_dt[t] = dt_src[q];
+            for (int k = 0; k < 3; k++) { pm_acc[t][k] = acc_src[q][k]; pm_gyr[t][k] = gyr_src[q][k]; }
+            const int nb = nb0 + q;
+            if (append && nb < VIO_IMU_SLOT_CAP) { p.dt_buf[nb] = dt_src[q]; for (int k = 0; k < 3; k++) { p.acc_buf[nb][k] = acc_src[q][k]; p.gyr_buf[nb][k] = gyr_src[q][k]; } }
+        }
+        __syncthreads();
+        if (t == 0)
+            for (int k = 0; k < m; k++) {
+                const v3 acc = ld3(pm_acc[k]), gyr = ld3(pm_gyr[k]);
+                pm_pre[k].dq = s_dq; pm_pre[k].acc0 = s_a0; pm_pre[k].gyr0 = s_g0;
+                bf::preint_state_step(s_dq, s_dp, s_dv, s_a0, s_g0, lba, lbg, pm_dt[k], acc, gyr);
+                s_sum += pm_dt[k];
+                s_a0 = acc; s_g0 = gyr;
+            }
+        __syncthreads();
+        if (t < m) bf::preint_step_FV(pm_pre[t], lba, lbg, pm_dt[t], ld3(pm_acc[t]), ld3(pm_gyr[t]), pm_F[t], pm_V[t]);
+        __syncthreads();
+        for (int k = 0; k < m; k++) {
+            const double *Fk = pm_F[k], *Vk = pm_V[k];
+            if (t < 225) {
+                int i = t / 15, j = t - i * 15;
+                double s1 = 0, s2 = 0;
+                for (int u = 0; u < 15; u++) { s1 += Fk[i * 15 + u] * w.J[u * 15 + j]; s2 += Fk[i * 15 + u] * w.Pm[u * 15 + j]; }
+                w.FJ[t] = s1; w.FP[t] = s2;
+            }
+            __syncthreads();
+            if (t < 225) {
+                int i = t / 15, j = t - i * 15;
+                double s1 = 0;
+                for (int u = 0; u < 15; u++) s1 += w.FP[i * 15 + u] * Fk[j * 15 + u];
+                double nn[6] = {cfg.acc_n * cfg.acc_n, cfg.gyr_n * cfg.gyr_n, cfg.acc_n * cfg.acc_n, cfg.gyr_n * cfg.gyr_n, cfg.acc_w * cfg.acc_w, cfg.gyr_w * cfg.gyr_w};
+                double tt = 0;
+                for (int u = 0; u < 18; u++) tt += Vk[i * 18 + u] * nn[u / 3] * Vk[j * 18 + u];
+                w.J[t] = w.FJ[t];
+                w.Pm[t] = s1 + tt;
+            }
+            __syncthreads();
+        }
+    }
+    if (t == 0) {
+        st3(p.dp, s_dp); st3(p.dv, s_dv);
+        p.dq[0] = s_dq.w; p.dq[1] = s_dq.x; p.dq[2] = s_dq.y; p.dq[3] = s_dq.z;
+        p.sum_dt = s_sum;
+        st3(p.acc0, s_a0); st3(p.gyr0, s_g0);
+        if (append) p.n_buf = min(nb0 + n, VIO_IMU_SLOT_CAP);
+    }
+    __syncthreads();
+}
+
 // 4x4 / small symmetric cyclic Jacobi (row-cyclic, as oracle/om.h sym_eig); A destroyed, eigenvalues unsorted in A diag
 // stable compaction of the landmark order list; flags[k] = keep. Freed slots go back to the free stack.
 __device__ void lm_compact(Ctx &c, int *flags, int *offs, int *scratch) {
@@ -2471,6 +2543,7 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
         __syncthreads();
     }
     if (s == 0 && t == 0 && pinv_direct) B.timings[26] += 1.0f;
+    PH(36);
     // T1 = A_rm A_mm^+ (n x md) and the block A_mr (md x n) staged in LDS (the tile region, free until the constant term is formed): the
     // n^2 entries of A_r = A_rr - T1 A_mr read each of them n times
     double *T1 = (double *)smem_marg, *Amr = T1 + (size_t)n * md;
@@ -2483,6 +2556,7 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
         Amr[w] = A[k2 * mq + md + j2];
     }
     __syncthreads();
+    PH(37);
     double *Ar = c.margV;             // reuse as A_r first (n x n), eigenvectors go to margW+...
     double *br = c.vec;               // n
     for (int w = t; w < n * n; w += nt) {
@@ -2506,6 +2580,7 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
     // (DESIGN.md deviation 13).  The factored form is produced on demand by be_prior_factor_kernel (vio_get_prior).
     for (int w = t; w < n * n; w += nt) { int i = w / n, j = w - i * n; c.prior_H[w] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
     for (int i = t; i < n; i += nt) c.prior_r[i] = br[i];
+    PH(38);
     {
         // c0 = |L^-1 b|^2 with L L^T = A + delta I on 16x16 LDS tiles (delta lifts the gauge directions off the round-off floor)
         __shared__ __attribute__((aligned(16))) double cq_x[EIG_LD + 16];   // read and written in 16-byte pairs by chol_tiles
@@ -2526,6 +2601,7 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
         }
         for (int i = t; i < 16 * nbq; i += nt) cq_x[i] = i < n ? br[i] : 0.0;
         __syncthreads();
+        PH(39);
         double c0 = 0;
         if (dmax > 0 && chol_tiles(T, nbq, &cq_flag, cq_dinv, nullptr, cq_x)) {   // c0 needs the forward substitution only
             double acc = 0;
@@ -2754,16 +2830,7 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
             for (int k = 0; k < 9; k++) be.Rs[W - 1][k] = be.Rs[W][k];
         }
         preint_load(dst, pw);
-        int nsrc = src.n_buf;
-        for (int q = 0; q < nsrc; q++) {
-            double dt = src.dt_buf[q];
-            v3 acc = ld3(src.acc_buf[q]), gyr = ld3(src.gyr_buf[q]);
-            if (t == 0) {
-                int nb = dst.n_buf;
-                if (nb < VIO_IMU_SLOT_CAP) { dst.dt_buf[nb] = dt; st3(dst.acc_buf[nb], acc); st3(dst.gyr_buf[nb], gyr); dst.n_buf = nb + 1; }
-            }
-            preint_propagate(dst, pw, cfg, dt, acc, gyr);
-        }
+        preint_propagate_many(dst, pw, cfg, src.n_buf, src.dt_buf, src.acc_buf, src.gyr_buf, true);
         preint_store(dst, pw);
         if (t == 0) bf::preint_init(src, ld3(be.acc_0), ld3(be.gyr_0), ld3(be.Bas[W]), ld3(be.Bgs[W]));
         __syncthreads();

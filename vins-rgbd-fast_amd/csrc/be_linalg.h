@@ -292,32 +292,54 @@ __device__ int jacobi_wave16(double *A, double *V, int n, int ld, double *cs, do
 // case; otherwise it falls back to the eigen-decomposition.  L / Linv: n x n scratch in LDS, Ainv: result.
 __device__ bool spd_inverse_wave16(const double *A, int n, double floor, double *L, double *Linv, double *Ainv) {
     const int lane = threadIdx.x & 63;
-    for (int q = lane; q < n * n; q += 64) L[q] = A[q];
-    JW_SYNC();
+    // Factorisation in registers: lane i holds row i (n <= 16), the pivot and the entries L[k][j] travel through SGPRs (v_readlane).
+    // The operations and their order per entry are those of the LDS version it replaces (three wavefront syncs per pivot: 42 us of
+    // the 360 us marginalisation; now ~3): sqrt of the pivot, the column divided by it, a[i][k] -= L[i][j] * L[k][j] for k > j, i >= k.
+    const int ri = lane < n ? lane : 0;
+    double a[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[k] = k < n ? A[ri * n + k] : 0.0;
     bool ok = true;
-    for (int j = 0; j < n; j++) {
-        const double d = L[j * n + j];
-        if (!(d > 0.0) || !isfinite(d)) { ok = false; break; }   // wave-uniform
-        const double l = sqrt(d);
-        JW_SYNC();
-        if (lane > j && lane < n) L[lane * n + j] = L[lane * n + j] / l;
-        if (lane == j) L[j * n + j] = l;
-        JW_SYNC();
-        for (int q = lane; q < n * n; q += 64) {
-            const int i = q / n, k = q - i * n;
-            if (k > j && i >= k) L[q] -= L[i * n + j] * L[k * n + j];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        if (j < n && ok) {
+            const double d = rl_f64(a[j], j);
+            if (!(d > 0.0) || !isfinite(d)) ok = false;   // wave-uniform
+            else {
+                const double l = sqrt(d);
+                a[j] = lane > j ? a[j] / l : (lane == j ? l : a[j]);
+#pragma unroll
+                for (int k = j + 1; k < 16; k++) {
+                    if (k < n) {
+                        const double lkj = rl_f64(a[j], k);
+                        const double prod = a[j] * lkj;
+                        if (lane >= k) a[k] -= prod;
+                    }
+                }
+            }
         }
-        JW_SYNC();
     }
     if (!ok) return false;
+    if (lane < n) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) if (k < n) L[lane * n + k] = a[k];
+    }
+    JW_SYNC();
     if (lane < n) {   // column `lane` of L^-1
+        // (fully unrolled with the loop bounds as predicates: x[] indexed by runtime loop variables lived in scratch memory, a
+        // global-memory round trip per access -- most of the 40 us this routine took)
         const int c0 = lane;
         double x[16];
-        for (int i = 0; i < n; i++) {
-            double sacc = (i == c0) ? 1.0 : 0.0;
-            for (int k = c0; k < i; k++) sacc -= L[i * n + k] * x[k];
-            x[i] = i < c0 ? 0.0 : sacc / L[i * n + i];
-            Linv[i * n + c0] = x[i];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            x[i] = 0.0;
+            if (i < n) {
+                double sacc = (i == c0) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; k++) if (k >= c0) sacc -= L[i * n + k] * x[k];
+                x[i] = i < c0 ? 0.0 : sacc / L[i * n + i];
+                Linv[i * n + c0] = x[i];
+            }
         }
     }
     JW_SYNC();
