@@ -168,10 +168,12 @@ __device__ void preint_propagate(PreInt &p, PreWork &w, const vio_config &c, dou
 // with the serial part of a step shrunk from the whole midpoint step to the recursion.  append: the samples are also filed into p's
 // own buffers (IntegrationBase::push_back).  Used for the merge of MARGIN_SECOND_NEW (estimator.cpp:1651-1687), where the step-by-step
 // version was 100 of the 190 us of that branch.
+#define PREINT_MANY_LDS_DOUBLES (PI_CH * (225 + 270))   // F and V of a chunk: LDS the caller lends (the marginalisation's tile region is free by then)
 __device__ void preint_propagate_many(PreInt &p, PreWork &w, const vio_config &cfg, int n, const double *dt_src, const double (*acc_src)[3],
-                                      const double (*gyr_src)[3], bool append) {
+                                      const double (*gyr_src)[3], bool append, double *lds_fv) {
     const int t = threadIdx.x;
-    __shared__ double pm_F[PI_CH][225], pm_V[PI_CH][270];
+    double (*pm_F)[225] = (double (*)[225])lds_fv;
+    double (*pm_V)[270] = (double (*)[270])(lds_fv + PI_CH * 225);
     __shared__ double pm_dt[PI_CH], pm_acc[PI_CH][3], pm_gyr[PI_CH][3];
     __shared__ bf::PreintPre pm_pre[PI_CH];
     const int nb0 = p.n_buf;
@@ -1718,7 +1720,7 @@ __device__ __forceinline__ void solve_epilogue(Ctx &c, const Params &X, double c
 }  // namespace
 
 template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem_marg);
-__device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw);
+__device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw, unsigned char *smem_marg);
 
 // solve -> marginalise -> window slide for one sequence per workgroup (1024 threads); fusing the three stages makes the
 // step time the maximum over sequences of the *sum* of the stage times instead of the sum of per-stage maxima.
@@ -1750,7 +1752,7 @@ __global__ __launch_bounds__(512) void be_marg_kernel(Batch B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     marg_body<false>(B, s, scratch, sred, smem);
     __syncthreads();
-    finish_body(B, s, scratch, pw);
+    finish_body(B, s, scratch, pw, smem);
 }
 // vio_config.marg_exact: the same stage with the marginalisation of marginalization_factor.cpp:281-315 followed literally (its own kernel so
 // that the hot kernel's registers / LDS are untouched by the parity instrument)
@@ -1762,7 +1764,7 @@ __global__ __launch_bounds__(512) void be_marg_exact_kernel(Batch B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     marg_body<true>(B, s, scratch, sred, smem);
     __syncthreads();
-    finish_body(B, s, scratch, pw);
+    finish_body(B, s, scratch, pw, smem);
 }
 
 __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem, PreWork &pw) {
@@ -2706,7 +2708,7 @@ __global__ __launch_bounds__(512) void be_prior_factor_kernel(Batch B, int seq) 
 }
 
 // ====================================================================================================== be_finish
-__device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
+__device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw, unsigned char *smem_marg) {   // smem_marg: the marginalisation's dynamic LDS, free again (>= PREINT_MANY_LDS_DOUBLES doubles)
     const int t = threadIdx.x, nt = blockDim.x;
     Ctx c = make_ctx(B, s);
     const DevCfg &C = *B.cfg;
@@ -2830,7 +2832,7 @@ __device__ void finish_body(const Batch &B, int s, int *scratch, PreWork &pw) {
             for (int k = 0; k < 9; k++) be.Rs[W - 1][k] = be.Rs[W][k];
         }
         preint_load(dst, pw);
-        preint_propagate_many(dst, pw, cfg, src.n_buf, src.dt_buf, src.acc_buf, src.gyr_buf, true);
+        preint_propagate_many(dst, pw, cfg, src.n_buf, src.dt_buf, src.acc_buf, src.gyr_buf, true, (double *)smem_marg);
         preint_store(dst, pw);
         if (t == 0) bf::preint_init(src, ld3(be.acc_0), ld3(be.gyr_0), ld3(be.Bas[W]), ld3(be.Bgs[W]));
         __syncthreads();

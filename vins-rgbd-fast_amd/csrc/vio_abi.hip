@@ -151,6 +151,18 @@ static int raise_lds_limit(const void *fn, size_t bytes) {
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
 }
 
+// static + dynamic LDS of a kernel this handle will launch against what a workgroup may own: a configuration that does not fit fails at
+// vio_create, not with an aborted launch in the middle of a frame
+static bool lds_fits(const void *fn, size_t dynamic_bytes, const char *name) {
+    hipFuncAttributes a;
+    int dev = 0, cap = 0;
+    if (hipFuncGetAttributes(&a, fn) != hipSuccess) return true;   // (cannot tell: let the launch decide)
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || cap <= 0) cap = 160 * 1024;
+    if (a.sharedSizeBytes + dynamic_bytes <= (size_t)cap) return true;
+    g_err = std::string("configuration needs more LDS than a workgroup may own: ") + name;
+    return false;
+}
+
 static int sync_all(vio_batch *h) {
     for (auto &g : h->groups) {
         if (g.copy_stream) HIPCHK(hipStreamSynchronize(g.copy_stream));
@@ -908,7 +920,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
         }
         {
             size_t nbq = ((size_t)C.NPRIOR + 15) >> 4;
-            h->lds_marg = std::max((size_t)nbq * (nbq + 1) / 2 * 2048, (size_t)2 * C.NPRIOR * 15 * 8) + 64;  // lower 16x16 tiles of the new prior (Cholesky for its constant term); before that T1 and A_mr
+            h->lds_marg = std::max(std::max((size_t)nbq * (nbq + 1) / 2 * 2048, (size_t)2 * C.NPRIOR * 15 * 8), (size_t)8 * (225 + 270) * 8) + 64;   // (the last: F / V of a chunk of the pre-integration merge, be_kernels.hip PREINT_MANY_LDS_DOUBLES)  // lower 16x16 tiles of the new prior (Cholesky for its constant term); before that T1 and A_mr
             h->lds_factor = C.NPRIOR <= 96 ? (size_t)C.NPRIOR * (C.NPRIOR | 1) * 8 + 64 : 64;  // on-demand eigen-decomposition (vio_get_prior)
             (void)raise_lds_limit((const void *)be_prior_factor_kernel, h->lds_factor);
         }
@@ -919,6 +931,16 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
         (void)raise_lds_limit((const void *)fe_select_kernel, (size_t)(h->lds_select));
         (void)raise_lds_limit((const void *)fe_add_kernel, (size_t)(h->lds_add));
         (void)raise_lds_limit((const void *)fe_fast_kernel, (size_t)(h->lds_fast));
+        bool fits = lds_fits(C.MX > 0 ? (const void *)be_marg_exact_kernel : (const void *)be_marg_kernel, h->lds_marg, "be_marg") &&
+                    lds_fits((const void *)be_ingest_kernel, (size_t)C.lm_hash_size * 8, "be_ingest") &&
+                    lds_fits((const void *)fe_select_kernel, h->lds_select, "fe_select") && lds_fits((const void *)fe_add_kernel, h->lds_add, "fe_add") &&
+                    lds_fits((const void *)fe_fast_kernel, h->lds_fast, "fe_fast");
+        if (fits && h->solve_mode == 1)
+            fits = lds_fits((const void *)ps_eval_kernel, h->lds_ps_eval, "ps_eval") &&
+                   lds_fits(h->serial_big ? (const void *)ps_serial_big_kernel : h->serial_threads <= 512 ? (const void *)ps_serial_kernel_512 : (const void *)ps_serial_kernel, h->lds_serial, "ps_serial");
+        else if (fits)
+            fits = lds_fits(h->be_threads <= 512 ? (const void *)be_solve_kernel_512 : (const void *)be_solve_kernel, h->lds_solve, "be_solve");
+        if (!fits) rc = VIO_ECAPACITY;
     }
     if (rc != VIO_OK) { vio_destroy(h); return nullptr; }
     return h;
