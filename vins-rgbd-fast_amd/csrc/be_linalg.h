@@ -1391,15 +1391,15 @@ __device__ __forceinline__ void rowdot(const double *M, int ld, int nrows, const
 //   out_col[a] = sum_k u[k] M[k][a]   (u != nullptr)
 // One wavefront per row (lanes own columns lane, lane + 64, ...): row dots through shuffles, column sums in registers and
 // combined over the wavefronts through LDS part[nw * VIO_LWMAX].  Ends with a block barrier.
-template <int NC>
+template <int NC, int RB = 4>
 __device__ __forceinline__ void matvec_pass_t(const double *M, int ld, int nrows, int n, const double *u, const double *v, double *out_col, double *out_row,
                               double *part) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
     double cs[NC], vv[NC];
 #pragma unroll
     for (int j = 0; j < NC; j++) { int a = lane + 64 * j; cs[j] = 0; vv[j] = (v && a < n) ? v[a] : 0.0; }
-    // four rows per trip: all their loads are issued before the first use (one wavefront has nothing else to hide the latency with)
-    constexpr int RB = 4;
+    // RB rows per trip: all their loads are issued before the first use (one wavefront has nothing else to hide the latency with; a
+    // trip is one global-memory round trip, so the 512-thread serial phase with its 256 VGPRs takes eight rows per trip)
     for (int k0 = wave; k0 < nrows; k0 += RB * nw) {
         double m[RB][NC], uk[RB];
 #pragma unroll
@@ -1442,7 +1442,7 @@ __device__ __forceinline__ void matvec_pass_t(const double *M, int ld, int nrows
 // Same pass for a matrix whose rows are non-zero only in columns [0, n0) and [e0, e0 + ne) (the landmark coupling rows: pose
 // columns and extrinsic / td columns, the speed-bias columns in between are identically zero): lanes own the compacted columns,
 // a third of the loads of the dense pass.  out_col is still written for all n columns (zeros outside the two ranges).
-template <int NC>
+template <int NC, int RB = 4>
 __device__ __forceinline__ void matvec_pass_2range_t(const double *M, int ld, int nrows, int n, int n0, int e0, int ne, const double *u, const double *v,
                                                      double *out_col, double *out_row, double *part) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
@@ -1456,8 +1456,7 @@ __device__ __forceinline__ void matvec_pass_2range_t(const double *M, int ld, in
         cs[j] = 0;
         vv[j] = (v && col[j] >= 0) ? v[col[j]] : 0.0;
     }
-    constexpr int RB = 4;   // rows per trip, loads first (see matvec_pass_t)
-    for (int k0 = wave; k0 < nrows; k0 += RB * nw) {
+    for (int k0 = wave; k0 < nrows; k0 += RB * nw) {   // RB rows per trip, loads first (see matvec_pass_t)
         double m[RB][NC], uk[RB];
 #pragma unroll
         for (int b = 0; b < RB; b++) {
@@ -1497,14 +1496,16 @@ __device__ __forceinline__ void matvec_pass_2range_t(const double *M, int ld, in
     }
     __syncthreads();
 }
+template <int RB = 4>
 __device__ __forceinline__ void matvec_pass_2range(const double *M, int ld, int nrows, int n, int n0, int e0, int ne, const double *u, const double *v,
                                                    double *out_col, double *out_row, double *part) {
-    if (n0 + ne <= 128) matvec_pass_2range_t<2>(M, ld, nrows, n, n0, e0, ne, u, v, out_col, out_row, part);
+    if (n0 + ne <= 128) matvec_pass_2range_t<2, RB>(M, ld, nrows, n, n0, e0, ne, u, v, out_col, out_row, part);
     else matvec_pass_t<6>(M, ld, nrows, n, u, v, out_col, out_row, part);  // larger windows: dense pass
 }
+template <int RB = 4>
 __device__ __forceinline__ void matvec_pass(const double *M, int ld, int nrows, int n, const double *u, const double *v, double *out_col, double *out_row,
                             double *part) {
-    if (n <= 192) matvec_pass_t<3>(M, ld, nrows, n, u, v, out_col, out_row, part);
+    if (n <= 192) matvec_pass_t<3, RB>(M, ld, nrows, n, u, v, out_col, out_row, part);
     else matvec_pass_t<6>(M, ld, nrows, n, u, v, out_col, out_row, part);
 }
 

@@ -820,7 +820,7 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
             tmpl[k] = sl[k] * iv * gls[k];
         }
         __syncthreads();
-        matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, tmpl, nullptr, tmpv, nullptr, work);
+        matvec_pass_2range<TB>(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, tmpl, nullptr, tmpv, nullptr, work);
         for (int a = t; a < LW; a += nt) xs[a] = a < P ? gs[a] - sp[a] * tmpv[a] : 0.0;
         __syncthreads();
         PH(49);
@@ -882,7 +882,7 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
         PH(57);
         for (int a = t; a < LW; a += nt) { yp[a] = xs[a]; gnp[a] = -xs[a] * dgp[a]; tmpv[a] = sp[a] * xs[a]; }
         __syncthreads();
-        matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, nullptr, tmpv, nullptr, tmpl, nullptr);
+        matvec_pass_2range<TB>(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, nullptr, tmpv, nullptr, tmpl, nullptr);
         PH(58);
         for (int k = t; k < Kpad; k += nt) {
             double y = k < Fa ? (gls[k] - sl[k] * tmpl[k]) * inv[k] : 0.0;
@@ -901,8 +901,8 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
     gnn = sqrt(gnn);
     double ca = 0, cb = 0;
     if (!(gnn <= radius) && !cauchy_valid) {
-        matvec_pass(c.H, LW, P, P, nullptr, up, nullptr, tmpv, work);
-        matvec_pass_2range(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, ul, up, tmpv2, tmpl, work);
+        matvec_pass<TB>(c.H, LW, P, P, nullptr, up, nullptr, tmpv, work);
+        matvec_pass_2range<TB>(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, ul, up, tmpv2, tmpl, work);
         double g2 = 0, jg2 = 0;
         for (int a = t; a < LW; a += nt) {
             double v = a < P ? sp[a] * (tmpv[a] + tmpv2[a]) : 0.0;
