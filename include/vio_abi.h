@@ -79,7 +79,10 @@ typedef struct vio_batch vio_batch; /* opaque */
 void vio_config_default(vio_config *cfg);
 
 /* Estimator::Estimator + setParameter() (estimator.cpp:9-41) for S sequences on the current HIP device.
- * imu_capacity = ring size per sequence (samples). Returns NULL on failure (see vio_last_error). */
+ * imu_capacity = ring size per sequence (samples). Returns NULL on failure (see vio_last_error): no HIP device (there is no CPU
+ * fallback), an allocation that failed, or a configuration whose kernels would need more LDS than a workgroup may own (window size /
+ * landmark capacity / feature count beyond what a CU's 160 KB hold) -- checked here so that it cannot surface as a failed launch
+ * in the middle of a frame. */
 vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity);
 void vio_destroy(vio_batch *h);
 const char *vio_last_error(void);
