@@ -63,6 +63,7 @@ struct vio_batch {
     };
     std::vector<Group> groups;
     int tracker_lag = 0;              // vio_set_tracker_lag
+    int extra_slots = 2;              // VIO_EXTRA_SLOTS: iteration slots beyond max_iterations (1 carries the last evaluation, the second absorbs one Cholesky retry / invalid step)
     int xcd_n = 0;                    // VIO_XCD_N: override of the XCD count the map assumes (0: 8)
     int xcd_map = 1;                  // VIO_XCD_MAP: XCD-aware block map of the multi-block ps_* kernels (be_phased.h ps_blk)
     int ps_asm_b_blocks = 24;         // workgroups per sequence that sum the entries of H (VIO_ASM_B_BLOCKS)
@@ -584,7 +585,7 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
         // phased solver: every data-parallel phase of the trust-region loop covers all sequences with many workgroups; max_iterations
         // + 1 slots carry the iterations, two more absorb Cholesky retries (a converged sequence falls through the remaining launches)
         ps_setup_kernel<<<S, 512, 0, st>>>(Bg);
-        const int slots = C.c.max_iterations + 2;
+        const int slots = C.c.max_iterations + h->extra_slots;
         // XCD-aware block map (ps_blk): every block of a sequence on the XCD its one-block kernels run on
         const bool xm = h->xcd_map && S >= 8;
         const int XN = h->xcd_n > 0 ? h->xcd_n : 8;   // (measured with the back-end streams masked to six XCDs: 8 -> +2 %, 6 -> +0.3 %, 3 / 12 -> -1 %: the block -> XCD rotation ignores the mask)
@@ -823,6 +824,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     if (getenv("VIO_EVAL_OCC")) h->eval_occ = atoi(getenv("VIO_EVAL_OCC"));
     if (getenv("VIO_XCD_MAP")) h->xcd_map = atoi(getenv("VIO_XCD_MAP"));
     if (getenv("VIO_XCD_N")) h->xcd_n = atoi(getenv("VIO_XCD_N"));
+    if (getenv("VIO_EXTRA_SLOTS")) h->extra_slots = std::max(1, atoi(getenv("VIO_EXTRA_SLOTS")));
     if (getenv("VIO_ASM_A_OCC")) h->asm_a_occ4 = atoi(getenv("VIO_ASM_A_OCC")) >= 4;
     if (getenv("VIO_SERIAL_THREADS")) h->serial_threads = atoi(getenv("VIO_SERIAL_THREADS")) >= 1024 ? 1024 : 512;
     if (getenv("VIO_MARG_THREADS")) h->marg_threads = std::min(512, std::max(64, atoi(getenv("VIO_MARG_THREADS")) & ~63));
