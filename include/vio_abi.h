@@ -306,7 +306,9 @@ int vio_stage_imu_block(const vio_config *cfg, int n, const double *dt, const do
  * Eigen LLT underneath) through the LDS-tile Cholesky of the solve kernels: S [16 nb][16 nb] row-major symmetric positive definite
  * (nb <= 11), rhs [16 nb].  L_out: the lower triangle of the factor (row-major; entries above the diagonal are left as passed in),
  * x_out = S^-1 rhs (NaN when a pivot was not positive), usec5 = {factorisation with the forward substitution riding along, backward
- * substitution, then the factorisation as thread 0 sees it: panels, diagonal block + trailing update, barrier wait}: microseconds inside the kernel, mean over `reps` repetitions, with `blocks` identical workgroups side by side. */
+ * substitution, then the factorisation as thread 0 sees it: panels, diagonal block + trailing update, barrier wait}: microseconds inside the kernel, mean over `reps` repetitions, with `blocks` identical workgroups side by side.  blocks = -1 .. -6
+ * select the timing micro-modes of tools/chol_bench.py (one diagonal tile, panel tiles, dependent FP64 chains, v_mfma_f64_16x16x4 issue
+ * rates; usec5 then carries clock64 ticks / 100 in slots 1 .. 4, L_out / x_out are not written): measurement only, see stage_linalg.hip. */
 int vio_stage_chol(int nb, int reps, int blocks, const double *S, const double *rhs, double *L_out, double *x_out, double *usec5);
 
 #ifdef __cplusplus
