@@ -914,11 +914,24 @@ static void build_normal_eq(Estimator &e, const double pose[][7], const double s
     }
     // projection factors with CauchyLoss(1.0)
     int nres = 0;
-    for (auto &lr : lms) {
+    // ORACLE_PERTURB_ORDER (control experiment only, tests/oracle_control.py): the same sums accumulated in the opposite order --
+    // landmarks last to first, observations newest to oldest. Mathematically identical normal equations, different round-off; used
+    // to measure how far two arithmetically different builds of THIS restatement drift apart over a long run.
+    for (size_t lmi = 0; lmi < lms.size(); lmi++) {
+#ifdef ORACLE_PERTURB_ORDER
+        LmRef &lr = lms[lms.size() - 1 - lmi];
+#else
+        LmRef &lr = lms[lmi];
+#endif
         Landmark &l = *lr.l;
         int imu_i = l.start_frame;
         double inv_dep = feat[lr.idx];
-        for (int k = 1; k < (int)l.obs.size(); k++) {
+        for (int kk = 1; kk < (int)l.obs.size(); kk++) {
+#ifdef ORACLE_PERTURB_ORDER
+            const int k = (int)l.obs.size() - kk;
+#else
+            const int k = kk;
+#endif
             int imu_j = imu_i + k;
             double r[2], Ji[14], Jj[14], Je[14], Jl[2], Jt[2];
             eval_projection(e.cfg, pose[imu_i], pose[imu_j], ex, inv_dep, tdv, l.obs[0], l.obs[k], e.cfg.estimate_td != 0, r,
@@ -1395,7 +1408,12 @@ void Estimator::marginalize_old() {  // estimator.cpp:1376-1502
         present[0] = 1;
         present[W] = 1;
     }
-    for (size_t li = 0; li < lms.size(); li++) {
+    for (size_t lq = 0; lq < lms.size(); lq++) {
+#ifdef ORACLE_PERTURB_ORDER
+        const size_t li = lms.size() - 1 - lq;   // control experiment: opposite accumulation order (see build_normal_eq)
+#else
+        const size_t li = lq;
+#endif
         Landmark &l = *lms[li].l;
         double inv_dep = para_Feature[lms[li].idx];
         for (int k = 1; k < (int)l.obs.size(); k++) {

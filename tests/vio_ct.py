@@ -24,22 +24,24 @@ def pkg():
     return P
 
 
-def build_oracle():
-    r = subprocess.run(["make", "-C", ORACLE_DIR], capture_output=True, text=True)
+def build_oracle(target="liboracle.so"):
+    r = subprocess.run(["make", "-C", ORACLE_DIR, target], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
     return ORACLE_SO
 
 
-_orc = None
+_orc = {}
 
 
-def oracle():
-    global _orc
-    if _orc is None:
-        if not os.path.exists(ORACLE_SO):
-            build_oracle()
-        L = C.CDLL(ORACLE_SO)
+def oracle(path=None):
+    """ctypes handle of the oracle library; path: another build of the SAME sources (oracle/Makefile `control`: liboracle_fma.so,
+    liboracle_order.so), used only by the self-divergence control experiment (tests/oracle_control.py)"""
+    path = os.path.abspath(path or ORACLE_SO)
+    if path not in _orc:
+        if not os.path.exists(path):
+            build_oracle(os.path.basename(path))
+        L = C.CDLL(path)
         L.ovio_pipeline_create.restype = C.c_void_p
         L.ovio_tracker_create.restype = C.c_void_p
         L.ovio_preint_create.restype = C.c_void_p
@@ -85,13 +87,13 @@ def oracle():
         }.items():
             getattr(L, name).argtypes = args
         assert L.ovio_config_size() == C.sizeof(pkg().Config), "oracle Config and vio_config layouts differ"
-        _orc = L
-    return _orc
+        _orc[path] = L
+    return _orc[path]
 
 
 class OraclePipeline:
-    def __init__(self, cfg):
-        self.L = oracle()
+    def __init__(self, cfg, lib=None):
+        self.L = oracle(lib)
         self.cfg = cfg
         self.W = cfg.window_size
         self.h = C.c_void_p(self.L.ovio_pipeline_create(C.byref(cfg)))
@@ -284,13 +286,13 @@ def ate_rmse(est, gt):
     return float(np.sqrt(((al - gt) ** 2).sum(1).mean()))
 
 
-def run_oracle_sequence(cfg, sc, seq, n_frames, frames=None, modes=None, hook=None, tracker_lag=0):
+def run_oracle_sequence(cfg, sc, seq, n_frames, frames=None, modes=None, hook=None, tracker_lag=0, lib=None):
     """Drive the oracle over n_frames of sequence seq. frames: optional list of (gray, depth) to reuse; modes: optional per-frame
     frame mode (0 skip / 1 track / 2 publish); hook(f, oracle): called after every frame.
     Returns dict(traj=[(frame, P(3), Q(4), V(3))], gt=..., status=[...], frames=[...])."""
     P = pkg()
     syn = P.Synth(sc)
-    o = OraclePipeline(cfg)
+    o = OraclePipeline(cfg, lib)
     if tracker_lag:
         o.set_tracker_lag(tracker_lag)
     nimu = int(n_frames / sc.cam_rate * sc.imu_rate) + 64

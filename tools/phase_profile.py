@@ -25,7 +25,12 @@ NAMES = {0: "vector2double", 1: "lm indexing", 2: "pair lists", 4: "evaluate(fir
          28: "finish slide states", 29: "finish slide landmarks", 30: "finish removeFailures + odom",
          32: "asm_a pair (0,1) item", 33: "asm_a pair (0,W) item", 34: "asm_a imu item 0", 35: "asm_a landmark rows item 0", 36: "asm element sums", 37: "asm lm rows",
          36: "  marg 21a: 15x15 inverse", 37: "  marg 21b: T1 / Amr staging", 38: "  marg 22a: prior_H / prior_r stores", 39: "  marg 22b: tile fill",
-         45: "  eval b0: X to LDS", 40: "  eval b0: prior dx", 44: "  eval b0: A dx partials", 46: "  eval b1: X + headers to LDS"}
+         45: "  eval b0: X to LDS", 40: "  eval b0: prior dx", 44: "  eval b0: A dx partials", 46: "  eval b1: X + headers to LDS",
+         # front-end (fe_kernels.hip FE_PH markers)
+         64: "select load + status cull", 65: "select lift (F input)", 66: "  ransac 7-point hypotheses", 67: "  ransac inlier counts", 68: "  ransac serial best/iters",
+         69: "  ransac final inliers", 70: "select F compaction", 71: "select rank sort", 72: "select greedy setMask", 73: "select counts + stores",
+         80: "add cell mask filter", 81: "add cell scan/compact", 82: "add cell top-k", 83: "add cell addPoints", 84: "add (tail of cells)",
+         85: "add undistort + velocity", 86: "add ids", 87: "add packaging", 90: "lk: block 0 total", 91: "lk: launches counted"}
 
 
 def main():
@@ -61,7 +66,7 @@ def main():
     it0 = b.status(0).iterations_total
     for f in range(n_pre, F):
         b.feed(g.at(f * S * hw), d.at(f * S * hw * 2), np.full(S, times[f]), on_device=True)
-    out = np.zeros(64, np.float32)
+    out = np.zeros(128, np.float32)
     L.vio_debug_phases(b.h, out.ctypes.data, 0)
     st = b.status(0)
     print("sequence 0: %.2f solver iterations per frame over %d frames" % ((st.iterations_total - it0) / a.frames, a.frames))
@@ -72,6 +77,7 @@ def main():
     print("MARGIN_OLD frames of sequence 0: %d of %d; direct (Cholesky) pseudo-inverse in %d marginalisations" % (int(out[31]), a.frames, int(out[26])))
     print("solve top-level sum %.1f us, marg sum %.1f us" % (sum(us[k] for k in (0, 1, 2, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)), sum(us[16:24])))
     print("ps_serial sum %.1f us/frame" % float(sum(us[48:56]) + us[56] + us[57] + us[58]))
+    print("fe_select sum %.1f us/frame, fe_add sum %.1f us/frame" % (float(sum(us[64:74])), float(sum(us[80:88]))))
 
 
 if __name__ == "__main__":

@@ -11,6 +11,10 @@
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 
+// in-kernel phase timers of sequence 0 (thread 0, 100 MHz ticks into Batch::timings, slots 64..; tools/phase_profile.py)
+#define FE_PH_INIT long long fe_t0 = (s == 0 && threadIdx.x == 0) ? (long long)wall_clock64() : 0
+#define FE_PH(k) do { if (s == 0 && threadIdx.x == 0) { long long n_ = (long long)wall_clock64(); B.timings[k] += (float)(n_ - fe_t0); fe_t0 = n_; } } while (0)
+
 namespace {
 
 __device__ __forceinline__ int reflect101(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
@@ -40,6 +44,25 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
     v += dpp_i64(v, 2);
     v += dpp_i64(v, 3);
     return (readlane_i64(v, 0) + readlane_i64(v, 16)) + (readlane_i64(v, 32) + readlane_i64(v, 48));
+}
+
+// Exact wavefront sum of int32 partials whose 8-lane sums still fit int32 (the LK sums below: 7 products of at most 8160 * 4080 per
+// lane).  Three DPP adds in 32 bits leave the sum of every 8-lane half row in its lanes; the eight half-row sums are combined in 64
+// bits on the scalar unit.  Integer arithmetic: the order does not matter, the result is the same number the CPU code accumulates.
+__device__ __forceinline__ long long wave_sum_i32x(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
+    long long a = (long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 8);
+    long long b = (long long)__builtin_amdgcn_readlane(v, 16) + (long long)__builtin_amdgcn_readlane(v, 24);
+    long long c = (long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 40);
+    long long d = (long long)__builtin_amdgcn_readlane(v, 48) + (long long)__builtin_amdgcn_readlane(v, 56);
+    return (a + b) + (c + d);
+}
+// bilinear blend of four samples with the 14-bit fixed-point weights: every factor fits 24 bits (samples are u8 or Scharr sums of
+// at most 4080 in magnitude, weights at most 2^14), so the full-rate 24-bit multiplier gives the exact 32-bit products
+__device__ __forceinline__ int blend4(int p00, int p01, int p10, int p11, int w00, int w01, int w10, int w11) {
+    return __mul24(p00, w00) + __mul24(p01, w01) + __mul24(p10, w10) + __mul24(p11, w11);
 }
 
 // camera (camera_model/src/camera_models/PinholeCamera.cc:449-542,645-662)
@@ -310,25 +333,71 @@ __global__ void fe_predict_kernel(Batch B) {
 }
 
 // ------------------------------------------------------------------------------------------------ fe_lk
-// One wavefront (64 lanes) per feature; each lane owns 7 of the 441 window pixels.
+// One wavefront (64 lanes) per feature.  Lane L < 63 owns seven horizontally adjacent pixels of the 21 x 21 window: row L / 3,
+// columns 7 (L % 3) .. 7 (L % 3) + 6, so every LDS address of the inner loops is one per-lane base plus a compile-time offset and
+// neighbouring pixels share their samples (8 + 8 byte reads for 7 bilinear taps instead of 28).  All window sums are integers
+// (exact in any order); the float / double steps are the CPU code's, operation by operation.
 
 #define LK_MARGIN 5
-#define LK_REG (22 + 2 * LK_MARGIN)
+#define LK_REG (22 + 2 * LK_MARGIN)   // 32 x 32 search region of the next image
+#define LK_RP (LK_REG + 4)            // its LDS pitch: the region is staged from 4-byte aligned columns (up to 3 bytes of lead-in)
+#define LK_WP 28                      // LDS pitch of the 24 x 24 template window, same reason
+#define LK_WIN_BYTES (24 * LK_WP)
+#define LK_JW_BYTES (LK_REG * LK_RP)
 // BORDER_REFLECT_101 index, clamped: region pixels further than one reflection outside the image are never part of a window that
 // passes the bounds test, the clamp only keeps their address legal
 __device__ __forceinline__ int reflect101c(int i, int n) { return min(max(reflect101(i, n), 0), n - 1); }
+// a pointer every lane holds the same value of, moved to scalar registers
+template <typename T> __device__ __forceinline__ const T *uniform_ptr(const T *p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const T *)(((unsigned long long)hi << 32) | lo);
+}
+typedef const __attribute__((address_space(1))) uint8_t *gmem_u8;    // known-global pointers: global_load, not flat_load
+typedef const __attribute__((address_space(1))) uint32_t *gmem_u32;
+// Stage the ROWS x (4 NDW)-byte block of `img` whose top-left pixel is (x0a, y0), x0a a multiple of 4, into LDS (pitch 4 NDW).
+// Inside the image: one aligned 4-byte load per lane and trip (the row pitch is a multiple of 4 there); at the image border: byte
+// loads with BORDER_REFLECT_101 (`clamp` = the clamped variant).  Same bytes either way.
+template <int ROWS, int NDW, bool CLAMP>
+__device__ __forceinline__ void lk_stage(gmem_u8 img, int w, int h, int x0a, int y0, uint8_t *dst, int lane) {
+    if (x0a >= 0 && x0a + 4 * NDW <= w && y0 >= 0 && y0 + ROWS <= h && !(w & 3)) {
+        int row = lane / NDW, col = lane - row * NDW;
+        const gmem_u32 src = (gmem_u32)(img + (unsigned)(y0 * w + x0a));
+        const int w4 = w >> 2;
+        uint32_t *d32 = (uint32_t *)dst;
+#pragma unroll
+        for (int q = lane; q < ROWS * NDW; q += 64) {
+            d32[q] = src[(unsigned)(row * w4 + col)];
+            row += 64 / NDW; col += 64 % NDW;
+            if (col >= NDW) { col -= NDW; row++; }
+        }
+    } else {
+        int row = lane / (4 * NDW), col = lane - row * (4 * NDW);
+#pragma unroll 4
+        for (int q = lane; q < ROWS * 4 * NDW; q += 64) {
+            const int ry = CLAMP ? reflect101c(y0 + row, h) : reflect101(y0 + row, h), rx = CLAMP ? reflect101c(x0a + col, w) : reflect101(x0a + col, w);
+            // (columns of the alignment lead-in / tail may reflect further than any window pixel does: only their address must be legal)
+            dst[q] = img[(unsigned)(min(max(ry, 0), h - 1) * w + min(max(rx, 0), w - 1))];
+            row += 64 / (4 * NDW); col += 64 % (4 * NDW);
+            if (col >= 4 * NDW) { col -= 4 * NDW; row++; }
+        }
+    }
+}
 __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, float2 &nextPtIO, uint8_t &statusOut,
-                             uint8_t *win /*24*24*/, short2 *der /*22*22*/, uint8_t *jw /*LK_REG^2*/) {
+                             uint8_t *win /*LK_WIN_BYTES, 4-aligned*/, short2 *der /*22*22*/, uint8_t *jw /*LK_JW_BYTES, 4-aligned*/) {
     const int WIN = VIO_WIN;
     const int W_BITS = 14;
     const float FLT_SCALE = 1.f / (1 << 20);
     const int lane = threadIdx.x & 63;
+    const int prow = lane / 3, pcol = 7 * (lane - 3 * prow);   // first of this lane's seven window pixels
+    const bool act = lane < 63;
     float2 nextPts = nextPtIO;
     uint8_t status = 1;
-    short Iv[7], Ixv[7], Iyv[7];
+    int Ipk[4];    // I of the seven pixels, two 16-bit values per register
+    int Dpk[7];    // (Ix, Iy) of the seven pixels
     for (int level = maxLevel; level >= 0; level--) {
-        const uint8_t *I = im.prev[level], *J = im.next[level];
-        const int w = im.w[level], h = im.h[level];
+        const gmem_u8 I = (gmem_u8)uniform_ptr(im.prev[level]), J = (gmem_u8)uniform_ptr(im.next[level]);
+        const int w = __builtin_amdgcn_readfirstlane(im.w[level]), h = __builtin_amdgcn_readfirstlane(im.h[level]);
         float sc = (float)(1. / (1 << level));
         float2 prevPt = make_float2(prevPtIn.x * sc, prevPtIn.y * sc);
         float2 nextPt;
@@ -337,7 +406,7 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
         nextPts = nextPt;
         const float halfWin = 10.f;
         prevPt.x -= halfWin; prevPt.y -= halfWin;
-        int ipx = cv_floor(prevPt.x), ipy = cv_floor(prevPt.y);
+        const int ipx = cv_floor(prevPt.x), ipy = cv_floor(prevPt.y);
         if (ipx < -WIN || ipx >= w || ipy < -WIN || ipy >= h) {
             if (level == 0) status = 0;
             continue;
@@ -347,43 +416,60 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
         int iw01 = cv_round(a * (1.f - b) * (1 << W_BITS));
         int iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
         int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-        __syncthreads();
-        for (int q = lane; q < 24 * 24; q += 64) {
-            int wy = q / 24, wx = q - wy * 24;
-            win[q] = I[(size_t)reflect101(ipy - 1 + wy, h) * w + reflect101(ipx - 1 + wx, w)];
+        nextPt.x -= halfWin; nextPt.y -= halfWin;
+        // the 22x22 window of J comes out of a (22 + 2 LK_MARGIN)^2 region cached in LDS around the first position of this level
+        // (re-centred -- one more pass over global memory -- only when the iteration walks out of it).  Its loads are issued together
+        // with the template's so that the two global round trips overlap each other and the derivative / template arithmetic
+        int rx0 = cv_floor(nextPt.x) - LK_MARGIN, ry0 = cv_floor(nextPt.y) - LK_MARGIN;
+        bool reg_ok;
+        {
+            const int inx = rx0 + LK_MARGIN, iny = ry0 + LK_MARGIN;
+            reg_ok = !(inx < -WIN || inx >= w || iny < -WIN || iny >= h);
         }
+        const int wx0a = (ipx - 1) & ~3, wxo = (ipx - 1) - wx0a;   // aligned first column of the template block, lead-in bytes
         __syncthreads();
-        for (int q = lane; q < 22 * 22; q += 64) {
-            int dy = q / 22, dx = q - dy * 22;
-            int gx = ipx + dx, gy = ipy + dy;
-            short2 d = make_short2(0, 0);
-            if (gx >= 0 && gy >= 0 && gx < w && gy < h) {  // derivative buffer has a constant-0 border
-                const uint8_t *r0 = win + dy * 24 + dx, *r1 = r0 + 24, *r2 = r1 + 24;
-                d.x = (short)(3 * (r0[2] - r0[0]) + 10 * (r1[2] - r1[0]) + 3 * (r2[2] - r2[0]));
-                d.y = (short)(3 * (r2[0] - r0[0]) + 10 * (r2[1] - r0[1]) + 3 * (r2[2] - r0[2]));
+        lk_stage<24, LK_WP / 4, false>(I, w, h, wx0a, ipy - 1, win, lane);
+        if (reg_ok) lk_stage<LK_REG, LK_RP / 4, true>(J, w, h, rx0 & ~3, ry0, jw, lane);
+        __syncthreads();
+        {
+            int dy = lane / 22, dx = lane - dy * 22;
+#pragma unroll 2
+            for (int q = lane; q < 22 * 22; q += 64, dx += 20, dy += 2) {
+                if (dx >= 22) { dx -= 22; dy++; }
+                int gx = ipx + dx, gy = ipy + dy;
+                short2 d = make_short2(0, 0);
+                if (gx >= 0 && gy >= 0 && gx < w && gy < h) {  // derivative buffer has a constant-0 border
+                    const uint8_t *r0 = win + dy * LK_WP + wxo + dx, *r1 = r0 + LK_WP, *r2 = r1 + LK_WP;
+                    d.x = (short)(3 * (r0[2] - r0[0]) + 10 * (r1[2] - r1[0]) + 3 * (r2[2] - r2[0]));
+                    d.y = (short)(3 * (r2[0] - r0[0]) + 10 * (r2[1] - r0[1]) + 3 * (r2[2] - r0[2]));
+                }
+                der[q] = d;
             }
-            der[q] = d;
         }
         __syncthreads();
-        long long sA11 = 0, sA12 = 0, sA22 = 0;
+        // per-lane partial sums stay in 32 bits: |ix|, |iy| <= 4080 (convex blends of Scharr sums), 7 products per lane
+        int pA11 = 0, pA12 = 0, pA22 = 0;
+        if (act) {
+            const uint8_t *r = win + (prow + 1) * LK_WP + wxo + (pcol + 1);
+            const short2 *d = der + prow * 22 + pcol;
+            int t0 = r[0], t1 = r[LK_WP];
+            short2 d0 = d[0], d1 = d[22];
 #pragma unroll
-        for (int k = 0; k < 7; k++) {
-            int p = lane + 64 * k;
-            int y = p / WIN, x = p - y * WIN;
-            int iv = 0, ix = 0, iy = 0;
-            if (p < WIN * WIN) {
-                const uint8_t *r = win + (y + 1) * 24 + (x + 1);
-                iv = descale(r[0] * iw00 + r[1] * iw01 + r[24] * iw10 + r[25] * iw11, W_BITS - 5);
-                const short2 *d = der + y * 22 + x;
-                ix = descale(d[0].x * iw00 + d[1].x * iw01 + d[22].x * iw10 + d[23].x * iw11, W_BITS);
-                iy = descale(d[0].y * iw00 + d[1].y * iw01 + d[22].y * iw10 + d[23].y * iw11, W_BITS);
-                sA11 += (long long)ix * ix;
-                sA12 += (long long)ix * iy;
-                sA22 += (long long)iy * iy;
+            for (int k = 0; k < 7; k++) {
+                const int u0 = r[k + 1], u1 = r[LK_WP + k + 1];
+                const short2 e0 = d[k + 1], e1 = d[22 + k + 1];
+                const int iv = descale(blend4(t0, u0, t1, u1, iw00, iw01, iw10, iw11), W_BITS - 5);
+                const int ix = descale(blend4(d0.x, e0.x, d1.x, e1.x, iw00, iw01, iw10, iw11), W_BITS);
+                const int iy = descale(blend4(d0.y, e0.y, d1.y, e1.y, iw00, iw01, iw10, iw11), W_BITS);
+                pA11 += __mul24(ix, ix);
+                pA12 += __mul24(ix, iy);
+                pA22 += __mul24(iy, iy);
+                if (k & 1) Ipk[k >> 1] |= iv << 16; else Ipk[k >> 1] = iv & 0xFFFF;
+                Dpk[k] = (ix & 0xFFFF) | (iy << 16);
+                t0 = u0; t1 = u1; d0 = e0; d1 = e1;
             }
-            Iv[k] = (short)iv; Ixv[k] = (short)ix; Iyv[k] = (short)iy;
         }
-        sA11 = wave_sum_i64(sA11); sA12 = wave_sum_i64(sA12); sA22 = wave_sum_i64(sA22);
+        const long long sA11 = wave_sum_i32x(pA11), sA12 = wave_sum_i32x(pA12), sA22 = wave_sum_i32x(pA22);
         float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
         float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * WIN * WIN);
@@ -392,10 +478,7 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
             continue;
         }
         D = 1.f / D;
-        nextPt.x -= halfWin; nextPt.y -= halfWin;
         float2 prevDelta = make_float2(0.f, 0.f);
-        bool reg_ok = false;
-        int rx0 = 0, ry0 = 0;
         for (int j = 0; j < 30; j++) {
             int inx = cv_floor(nextPt.x), iny = cv_floor(nextPt.y);
             if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) {
@@ -407,32 +490,29 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
             iw01 = cv_round(a * (1.f - b) * (1 << W_BITS));
             iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-            // the 22x22 window of J comes out of a (22 + 2 LK_MARGIN)^2 region cached in LDS around the first position of this level;
-            // it is re-centred (one more pass over global memory) only when the iteration walks out of it
             if (!(reg_ok && inx >= rx0 && iny >= ry0 && inx <= rx0 + 2 * LK_MARGIN && iny <= ry0 + 2 * LK_MARGIN)) {
                 rx0 = inx - LK_MARGIN; ry0 = iny - LK_MARGIN;
                 __syncthreads();
-                for (int q = lane; q < LK_REG * LK_REG; q += 64) {
-                    int wy = q / LK_REG, wx = q - wy * LK_REG;
-                    jw[q] = J[(size_t)reflect101c(ry0 + wy, h) * w + reflect101c(rx0 + wx, w)];
-                }
+                lk_stage<LK_REG, LK_RP / 4, true>(J, w, h, rx0 & ~3, ry0, jw, lane);
                 __syncthreads();
                 reg_ok = true;
             }
-            const uint8_t *jbase = jw + (iny - ry0) * LK_REG + (inx - rx0);
-            long long sb1 = 0, sb2 = 0;
+            // |diff| <= 8160 (both patches are u8 * 32), |Ix|, |Iy| <= 4080: 7 products per lane and 8 lanes stay below 2^31
+            int pb1 = 0, pb2 = 0;
+            if (act) {
+                const uint8_t *r = jw + (iny - ry0 + prow) * LK_RP + (inx - (rx0 & ~3) + pcol);
+                int t0 = r[0], t1 = r[LK_RP];
 #pragma unroll
-            for (int k = 0; k < 7; k++) {
-                int p = lane + 64 * k;
-                if (p < WIN * WIN) {
-                    int y = p / WIN, x = p - y * WIN;
-                    const uint8_t *r = jbase + y * LK_REG + x;
-                    int diff = descale(r[0] * iw00 + r[1] * iw01 + r[LK_REG] * iw10 + r[LK_REG + 1] * iw11, W_BITS - 5) - Iv[k];
-                    sb1 += (long long)diff * Ixv[k];
-                    sb2 += (long long)diff * Iyv[k];
+                for (int k = 0; k < 7; k++) {
+                    const int u0 = r[k + 1], u1 = r[LK_RP + k + 1];
+                    const int iv = (k & 1) ? (Ipk[k >> 1] >> 16) : (int)(short)(Ipk[k >> 1] & 0xFFFF);
+                    const int diff = descale(blend4(t0, u0, t1, u1, iw00, iw01, iw10, iw11), W_BITS - 5) - iv;
+                    pb1 += __mul24(diff, (int)(short)(Dpk[k] & 0xFFFF));
+                    pb2 += __mul24(diff, Dpk[k] >> 16);
+                    t0 = u0; t1 = u1;
                 }
             }
-            sb1 = wave_sum_i64(sb1); sb2 = wave_sum_i64(sb2);
+            const long long sb1 = wave_sum_i32x(pb1), sb2 = wave_sum_i32x(pb2);
             float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
             float2 delta = make_float2((float)((A12 * b2 - A22 * b1) * D), (float)((A12 * b1 - A11 * b2) * D));
             nextPt.x += delta.x; nextPt.y += delta.y;
@@ -456,9 +536,9 @@ __global__ __launch_bounds__(64) void fe_lk_kernel(Batch B) {
     int s = blockIdx.y + B.s0;
     FeSeq &fe = B.fe[s];
     if (fe.n_forw < 0 || (int)blockIdx.x >= fe.n_pts) return;
-    __shared__ uint8_t win[24 * 24];
+    __shared__ __attribute__((aligned(16))) uint8_t win[LK_WIN_BYTES];
     __shared__ short2 der[22 * 22];
-    __shared__ uint8_t jw[LK_REG * LK_REG];
+    __shared__ __attribute__((aligned(16))) uint8_t jw[LK_JW_BYTES];
     int cur = fe.cur_buf, forw = fe.has_img ? (cur ^ 1) : cur;
     // the pyramid table lives in LDS: as a local struct indexed by the (run-time) level it was 104 bytes of scratch per lane, written by
     // every lane of every block (the stage kernel gets the table as a kernel argument and never had that)
@@ -477,6 +557,7 @@ __global__ __launch_bounds__(64) void fe_lk_kernel(Batch B) {
         }
     }
     __syncthreads();
+    const long long lk_t0 = (s == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? (long long)wall_clock64() : 0;
     // grid.x is capped (most of the NP track slots are empty): a block walks its features with stride gridDim.x
     for (int i = blockIdx.x; i < fe.n_pts; i += gridDim.x) {
         float2 np = B.forw_pts[(size_t)s * C.NP + i];
@@ -488,6 +569,7 @@ __global__ __launch_bounds__(64) void fe_lk_kernel(Batch B) {
         }
         __syncthreads();
     }
+    if (s == 0 && blockIdx.x == 0 && threadIdx.x == 0) { B.timings[90] += (float)((long long)wall_clock64() - lk_t0); B.timings[91] += 1.f; }
 }
 
 // stand-alone variant for the stage test: explicit images, points from arrays
@@ -495,9 +577,9 @@ __global__ __launch_bounds__(64) void fe_lk_stage_kernel(LkImages im, int maxLev
                                                          uint8_t *status) {
     int i = blockIdx.x;
     if (i >= n) return;
-    __shared__ uint8_t win[24 * 24];
+    __shared__ __attribute__((aligned(16))) uint8_t win[LK_WIN_BYTES];
     __shared__ short2 der[22 * 22];
-    __shared__ uint8_t jw[LK_REG * LK_REG];
+    __shared__ __attribute__((aligned(16))) uint8_t jw[LK_JW_BYTES];
     float2 np = nextPts[i];
     uint8_t st;
     lk_one_point(im, maxLevel, prevPts[i], np, st, win, der, jw);
@@ -555,55 +637,95 @@ __device__ int solve_cubic_det(double c3, double c2, double c1, double c0, doubl
     roots[2] = (-p - sq) * 0.5;
     return 3;
 }
-// 7-point solver on a 7x9 system stored row-major in A (destroyed). Returns #models, F[3][9]
-__device__ int seven_point(double *A /*63*/, double *F /*27*/) {
-    int perm[9];
-    for (int i = 0; i < 9; i++) perm[i] = i;
-    double amax = 0;
-    for (int i = 0; i < 63; i++) amax = fmax(amax, fabs(A[i]));
+// The 7-point solver (cv::findFundamentalMat's minimal solver) for ONE minimal sample on ONE wavefront.
+// Lane e = 9 r + c (e < 63) owns element (r, c) of the 7 x 9 epipolar system and goes through the Gauss-Jordan elimination with
+// full pivoting element-wise: the pivot is a wave-wide arg-max (first maximum in row-major order, like the scalar scan), row and
+// column exchanges are one LDS round trip, and every element performs exactly the scalar algorithm's operations on it
+// (a *= inv in the pivot row, a -= f * (pivot-row element * inv) elsewhere) -- same roundings, hence the same null space bit for bit,
+// in 7 short steps instead of a 120 us scalar elimination on private (scratch) arrays.
+// ws: 96 doubles of LDS private to the wavefront.  Fout: 27 doubles.  Returns the number of models (uniform over the wavefront).
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ int seven_point_wave(double a, double *ws, double *Fout) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane / 9, c = lane - 9 * r;   // lane 63: r = 7, never eligible
+    double *As = ws, *f1s = ws + 64, *f2s = ws + 73;
+    double amax = lane < 63 ? fabs(a) : 0.0;
+    for (int off = 32; off > 0; off >>= 1) amax = fmax(amax, __shfl_xor(amax, off, 64));
     const double tol = 1e-12 * amax;
+    unsigned long long perm = 0x876543210ULL;   // nibble i = perm[i]
     int rank = 0;
     for (int i = 0; i < 7; i++) {
-        int pr = i, pc = i;
-        double best = -1;
-        for (int r = i; r < 7; r++)
-            for (int c = i; c < 9; c++)
-                if (fabs(A[r * 9 + c]) > best) { best = fabs(A[r * 9 + c]); pr = r; pc = c; }
-        if (!(best > tol)) break;
-        if (pr != i) for (int c = 0; c < 9; c++) { double t = A[pr * 9 + c]; A[pr * 9 + c] = A[i * 9 + c]; A[i * 9 + c] = t; }
-        if (pc != i) {
-            for (int r = 0; r < 7; r++) { double t = A[r * 9 + pc]; A[r * 9 + pc] = A[r * 9 + i]; A[r * 9 + i] = t; }
-            int t = perm[pc]; perm[pc] = perm[i]; perm[i] = t;
+        double v = (lane < 63 && r >= i && c >= i) ? fabs(a) : -1.0;
+        int idx = lane;
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(v, off, 64);
+            const int oi = __shfl_xor(idx, off, 64);
+            if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
         }
-        double inv = 1.0 / A[i * 9 + i];
-        for (int c = 0; c < 9; c++) A[i * 9 + c] *= inv;
-        for (int r = 0; r < 7; r++) {
-            if (r == i) continue;
-            double f = A[r * 9 + i];
-            if (f == 0.0) continue;
-            for (int c = 0; c < 9; c++) A[r * 9 + c] -= f * A[i * 9 + c];
+        if (!(v > tol)) break;   // rank-deficient sample: the remaining columns are free
+        const int pr = idx / 9, pc = idx - 9 * pr;
+        wave_lds_sync();
+        As[lane] = a;
+        wave_lds_sync();
+        const int sr = r == i ? pr : (r == pr ? i : r);
+        const int scol = c == i ? pc : (c == pc ? i : c);
+        if (pc != i) {
+            const unsigned long long ni = (perm >> (4 * i)) & 15ULL, np_ = (perm >> (4 * pc)) & 15ULL;
+            perm = (perm & ~((15ULL << (4 * i)) | (15ULL << (4 * pc)))) | (np_ << (4 * i)) | (ni << (4 * pc));
+        }
+        if (lane < 63) {
+            const double ap = As[sr * 9 + scol];          // my element after the two exchanges
+            const double inv = 1.0 / As[pr * 9 + pc];     // the pivot
+            const double prow = As[pr * 9 + scol] * inv;  // scaled pivot-row element of my column
+            const double f = As[sr * 9 + pc];             // my row's entry in the pivot column
+            if (r == i) a = prow;
+            else if (f != 0.0) a = ap - f * prow;
+            else a = ap;
         }
         rank = i + 1;
     }
+    wave_lds_sync();
+    As[lane] = a;
+    wave_lds_sync();
+    if (lane < 9) {   // f1[perm[i]] = -A[i][7], f2[perm[i]] = -A[i][8] (i < rank); f1[perm[7]] = 1, f2[perm[8]] = 1; other free columns 0
+        int i = 0;
+        for (int k = 0; k < 9; k++) if ((int)((perm >> (4 * k)) & 15ULL) == lane) i = k;
+        double v1 = 0.0, v2 = 0.0;
+        if (i < rank) { v1 = -As[i * 9 + 7]; v2 = -As[i * 9 + 8]; }
+        if (i == 7) v1 = 1.0;
+        if (i == 8) v2 = 1.0;
+        f1s[lane] = v1; f2s[lane] = v2;
+    }
+    wave_lds_sync();
     double f1[9], f2[9];
-    for (int i = 0; i < 9; i++) f1[i] = f2[i] = 0;
-    for (int i = 0; i < rank; i++) { f1[perm[i]] = -A[i * 9 + 7]; f2[perm[i]] = -A[i * 9 + 8]; }
-    f1[perm[7]] = 1;
-    f2[perm[8]] = 1;
+#pragma unroll
+    for (int k = 0; k < 9; k++) { f1[k] = f1s[k]; f2[k] = f2s[k]; }
+    // det(f1 + l f2) = c0 + c1 l + c2 l^2 + c3 l^3 (every lane computes the same numbers)
     double c0 = det3(f1), c3 = det3(f2), c1 = 0, c2 = 0;
-    for (int r = 0; r < 3; r++) {
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) {
         double t[9];
-        for (int q = 0; q < 9; q++) t[q] = f1[q];
-        for (int c = 0; c < 3; c++) t[r * 3 + c] = f2[r * 3 + c];
+#pragma unroll
+        for (int q = 0; q < 9; q++) t[q] = (q / 3 == rr) ? f2[q] : f1[q];
         c1 += det3(t);
-        for (int q = 0; q < 9; q++) t[q] = f2[q];
-        for (int c = 0; c < 3; c++) t[r * 3 + c] = f1[r * 3 + c];
+#pragma unroll
+        for (int q = 0; q < 9; q++) t[q] = (q / 3 == rr) ? f1[q] : f2[q];
         c2 += det3(t);
     }
-    double roots[3];
-    int nr = solve_cubic_det(c3, c2, c1, c0, roots);
-    for (int k = 0; k < nr; k++)
-        for (int i = 0; i < 9; i++) F[k * 9 + i] = f1[i] + roots[k] * f2[i];
+    double roots[3] = {0.0, 0.0, 0.0};
+    const int nr = solve_cubic_det(c3, c2, c1, c0, roots);
+    if (lane < 27) {
+        const int k = lane / 9, q = lane - 9 * k;
+        double fa = f1[0], fb = f2[0];
+#pragma unroll
+        for (int j = 1; j < 9; j++) if (q == j) { fa = f1[j]; fb = f2[j]; }
+        const double rt = k == 0 ? roots[0] : (k == 1 ? roots[1] : roots[2]);
+        if (k < nr) Fout[lane] = fa + rt * fb;
+    }
     return nr;
 }
 __device__ __forceinline__ bool f_inlier(const double *f, double x1, double y1, double x2, double y2, double thr2) {
@@ -653,60 +775,85 @@ __device__ int block_exclusive_scan(const int *flags, int n, int *offs, int *scr
     return total;
 }
 
-// RANSAC over normalised correspondences held in LDS; writes status flags. All 256 threads participate.
+// RANSAC over normalised correspondences held in LDS; writes status flags.  All threads of the block participate (4 wavefronts).
+// The iterations are the sequential algorithm's (sample `it` is a function of `it` alone, the iteration bound adapts after every
+// accepted model in iteration order); they are evaluated in rounds: every wavefront solves `per` minimal samples (one in the first
+// round -- with mostly inliers the bound falls below the round size at once --, up to 4 while many iterations remain), the inliers of
+// all their models are counted by all threads (integer counts), thread 0 then replays the acceptance logic in iteration order.
+#define RS_MAXB 16   // samples per round at most
 struct RansacShared {
-    double F[64 * 27];
-    int nm[64];
-    int cnt[64 * 3];
+    double F[RS_MAXB * 27];
+    double ws[4][96];
+    int nm[RS_MAXB];
+    int cnt[RS_MAXB * 3];
     double bestF[9];
-    int niters, maxGood, base, done;
+    int niters, maxGood, base, batch;
 };
 __device__ void ransac_block(const vio_config &c, int N, const double *X1, const double *Y1, const double *X2, const double *Y2,
-                             int *status, RansacShared &R, int *iters_out) {
-    const int t = threadIdx.x;
+                             int *status, RansacShared &R, int *iters_out, float *tm = nullptr) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, nw = blockDim.x >> 6;
+    long long rt0 = (tm && t == 0) ? (long long)wall_clock64() : 0;
+#define RS_PH(k) do { if (tm && t == 0) { long long n_ = (long long)wall_clock64(); tm[k] += (float)(n_ - rt0); rt0 = n_; } } while (0)
     const double thr = c.f_threshold / c.focal_length, thr2 = thr * thr;
-    if (t == 0) { R.niters = c.ransac_max_iters; R.maxGood = 0; R.base = 0; R.done = 0; }
+    if (t == 0) { R.niters = c.ransac_max_iters; R.maxGood = 0; R.base = 0; R.batch = min(nw, 4); }
     __syncthreads();
     while (true) {
-        int base = R.base, niters = R.niters;
+        const int base = R.base, niters = R.niters, batch = R.batch;
         if (base >= niters) break;
-        if (t < 64) {
-            int it = base + t;
-            int nm = 0;
-            if (it < niters) {
-                uint64_t sd = 0x5649464D41545258ULL + (uint64_t)it * 0xD1B54A32D192ED03ULL;
-                int idx[7];
-                for (int k = 0; k < 7;) {
-                    int r = (int)(splitmix64(sd) % (uint64_t)N);
-                    bool dup = false;
-                    for (int j = 0; j < k; j++) dup |= (idx[j] == r);
-                    if (!dup) idx[k++] = r;
+        for (int p = t; p < batch * 3; p += blockDim.x) R.cnt[p] = 0;
+        if (wv < 4)
+            for (int hh = wv; hh < batch; hh += min(nw, 4)) {
+                const int it = base + hh;
+                int nm = 0;
+                if (it < niters) {
+                    uint64_t sd = 0x5649464D41545258ULL + (uint64_t)it * 0xD1B54A32D192ED03ULL;
+                    int idx[7];
+#pragma unroll
+                    for (int k = 0; k < 7; k++) {
+                        bool dup;
+                        int rr;
+                        do {
+                            rr = (int)(splitmix64(sd) % (uint64_t)N);
+                            dup = false;
+#pragma unroll
+                            for (int j = 0; j < k; j++) dup |= (idx[j] == rr);
+                        } while (dup);
+                        idx[k] = rr;
+                    }
+                    const int r = lane / 9, cc = lane - 9 * r;
+                    int my = idx[0];
+#pragma unroll
+                    for (int k = 1; k < 7; k++) if (r == k) my = idx[k];
+                    const double x1 = X1[my], y1 = Y1[my], x2 = X2[my], y2 = Y2[my];
+                    // A[i] = (x2 x1, x2 y1, x2, y2 x1, y2 y1, y2, x1, y1, 1)
+                    const double u = cc < 3 ? x2 : (cc < 6 ? y2 : 1.0);
+                    const int c3 = cc - 3 * (cc / 3);
+                    const double w_ = c3 == 0 ? x1 : (c3 == 1 ? y1 : 1.0);
+                    const double a = cc < 6 ? (c3 == 2 ? u : u * w_) : w_;
+                    nm = seven_point_wave(a, R.ws[wv], &R.F[hh * 27]);
                 }
-                double A[63];
-                for (int i = 0; i < 7; i++) {
-                    double x1 = X1[idx[i]], y1 = Y1[idx[i]], x2 = X2[idx[i]], y2 = Y2[idx[i]];
-                    A[i * 9 + 0] = x2 * x1; A[i * 9 + 1] = x2 * y1; A[i * 9 + 2] = x2;
-                    A[i * 9 + 3] = y2 * x1; A[i * 9 + 4] = y2 * y1; A[i * 9 + 5] = y2;
-                    A[i * 9 + 6] = x1;      A[i * 9 + 7] = y1;      A[i * 9 + 8] = 1.0;
-                }
-                nm = seven_point(A, &R.F[t * 27]);
+                if (lane == 0) R.nm[hh] = nm;
             }
-            R.nm[t] = nm;
+        __syncthreads();
+        RS_PH(0);
+        for (int i0 = 0; i0 < N; i0 += blockDim.x) {
+            const int i = i0 + t;
+            const bool have = i < N;
+            const double x1 = have ? X1[i] : 0.0, y1 = have ? Y1[i] : 0.0, x2 = have ? X2[i] : 0.0, y2 = have ? Y2[i] : 0.0;
+            for (int hh = 0; hh < batch; hh++) {
+                const int nm = R.nm[hh];
+                for (int m = 0; m < nm; m++) {
+                    const bool good = have && f_inlier(&R.F[hh * 27 + m * 9], x1, y1, x2, y2, thr2);
+                    const unsigned long long bal = __ballot(good);
+                    if (lane == 0 && bal) atomicAdd(&R.cnt[hh * 3 + m], __popcll(bal));
+                }
+            }
         }
         __syncthreads();
-        for (int pi = t; pi < 192; pi += blockDim.x) {
-            int hh = pi / 3, m = pi - hh * 3;
-            int good = 0;
-            if (m < R.nm[hh]) {
-                const double *f = &R.F[hh * 27 + m * 9];
-                for (int i = 0; i < N; i++) good += f_inlier(f, X1[i], Y1[i], X2[i], Y2[i], thr2) ? 1 : 0;
-            }
-            R.cnt[pi] = good;
-        }
-        __syncthreads();
+        RS_PH(1);
         if (t == 0) {
             int ni = R.niters, mg = R.maxGood;
-            for (int hh = 0; hh < 64; hh++) {
+            for (int hh = 0; hh < batch; hh++) {
                 int it = base + hh;
                 if (it >= ni) break;
                 for (int m = 0; m < R.nm[hh]; m++) {
@@ -720,14 +867,19 @@ __device__ void ransac_block(const vio_config &c, int N, const double *X1, const
             }
             R.niters = ni;
             R.maxGood = mg;
-            R.base = base + 64;
+            R.base = base + batch;
+            const int left = ni - (base + batch);
+            R.batch = left >= 4 * RS_MAXB ? RS_MAXB : (left > 8 ? 8 : 4);
         }
         __syncthreads();
+        RS_PH(2);
     }
     int mg = R.maxGood;
     for (int i = t; i < N; i += blockDim.x) status[i] = (mg > 0 && f_inlier(R.bestF, X1[i], Y1[i], X2[i], Y2[i], thr2)) ? 1 : 0;
     if (t == 0 && iters_out) *iters_out = R.niters;
     __syncthreads();
+    RS_PH(3);
+#undef RS_PH
 }
 
 }  // namespace
@@ -774,6 +926,8 @@ __global__ __launch_bounds__(256) void fe_select_kernel(Batch B) {
     int *g_id = B.ids + (size_t)s * NP, *g_cnt = B.track_cnt + (size_t)s * NP;
     float2 *g_unst = B.unstable_pts + (size_t)s * NP;
     int n = fe.n_pts;
+    FE_PH_INIT;
+    const long long wg_t0 = t == 0 ? (long long)wall_clock64() : 0;
     for (int i = t; i < n; i += blockDim.x) {
         cur[i] = g_cur[i]; forw[i] = g_forw[i]; un[i] = g_un[i]; id[i] = g_id[i]; cnt[i] = g_cnt[i];
     }
@@ -806,6 +960,7 @@ __global__ __launch_bounds__(256) void fe_select_kernel(Batch B) {
     }
     for (int i = t; i < n; i += blockDim.x) cnt[i]++;  // :348-349
     __syncthreads();
+    FE_PH(64);
 
     int n_deficit = 0;
     if (publish) {
@@ -822,7 +977,9 @@ __global__ __launch_bounds__(256) void fe_select_kernel(Batch B) {
                 X2[i] = ((double)ux - hc) / c.focal_length; Y2[i] = ((double)uy - hr) / c.focal_length;
             }
             __syncthreads();
-            ransac_block(c, n, X1, Y1, X2, Y2, flag, R, &fe.ransac_iters);
+            FE_PH(65);
+            ransac_block(c, n, X1, Y1, X2, Y2, flag, R, &fe.ransac_iters, s == 0 ? B.timings + 66 : nullptr);
+            if (s == 0 && t == 0) fe_t0 = (long long)wall_clock64();
             int total = block_exclusive_scan(flag, n, offs, scratch);
             float2 c0, f0, u0; int i0, k0;
             for (int b = 0; b < n; b += blockDim.x) {
@@ -835,6 +992,7 @@ __global__ __launch_bounds__(256) void fe_select_kernel(Batch B) {
                 __syncthreads();
             }
             n = total;
+            FE_PH(70);
         }
         // ---- setMask (:173-208): sort by track_cnt desc (ties: original order), greedy keep with MIN_DIST circles
         for (int i = t; i < n; i += blockDim.x) {
@@ -843,26 +1001,65 @@ __global__ __launch_bounds__(256) void fe_select_kernel(Batch B) {
             perm[r] = i;
         }
         __syncthreads();
-        if (t < 64) {  // one wavefront walks the sorted list; lanes test the accepted centres in parallel
-            volatile int2 *vacc = acc;
-            int nacc = 0;
+        FE_PH(71);
+        // Greedy keep in sorted order, 64 candidates at a time.  For a block of 64: all threads test every candidate against the
+        // centres accepted by earlier blocks (4 threads per candidate) and build the 64 x 64 matrix "candidate j lies in the disk of
+        // candidate i < j" of the block; wavefront 0 then replays the sequential decision on the scalar unit -- candidate j is kept
+        // iff it is not blocked from before and no KEPT candidate i < j of its block covers it -- and appends the survivors in order.
+        // Same decisions as the one-by-one walk over the mask image (mask(p) == 0 <=> p lies in the disk of an accepted centre).
+        {
+            int *blk = scratch;                          // [64] blocked by an earlier block's centre
+            unsigned *cm = (unsigned *)(scratch + 64);   // [64][2] conflict bits within the block
             const int r = c.min_dist;
-            for (int q = 0; q < n; q++) {
-                int i = perm[q];
-                int px = cv_round(forw[i].x), py = cv_round(forw[i].y);
-                bool hit = false;
-                for (int k = t; k < nacc; k += 64) hit |= in_disk(hw_s, r, px, py, vacc[k].x, vacc[k].y);
-                bool any = __any(hit);
-                if (!any) {
-                    if (t == 0) { vacc[nacc].x = px; vacc[nacc].y = py; tmpi[nacc] = i; }
-                    nacc++;
+            int nacc = 0;
+            for (int q0 = 0; q0 < n; q0 += 64) {
+                const int nb = min(64, n - q0);
+                const int j = t & 63, part = t >> 6;     // 4 threads per candidate (blockDim 256)
+                if (t < 64) { blk[t] = 0; cm[2 * t] = 0; cm[2 * t + 1] = 0; }
+                __syncthreads();
+                int px = 0, py = 0;
+                if (j < nb) { const int i = perm[q0 + j]; px = cv_round(forw[i].x); py = cv_round(forw[i].y); }
+                if (j < nb) {
+                    bool hit = false;
+                    for (int k = part; k < nacc; k += 4) hit |= in_disk(hw_s, r, px, py, acc[k].x, acc[k].y);
+                    if (hit) atomicOr(&blk[j], 1);
+                    unsigned bits = 0;
+                    const int i0 = 16 * part;
+                    for (int q = 0; q < 16; q++) {
+                        const int i2 = i0 + q;
+                        if (i2 < j) {
+                            const int ii = perm[q0 + i2];
+                            if (in_disk(hw_s, r, px, py, cv_round(forw[ii].x), cv_round(forw[ii].y))) bits |= 1u << q;
+                        }
+                    }
+                    if (bits) atomicOr(&cm[2 * j + (part >> 1)], bits << (16 * (part & 1)));
                 }
-                __builtin_amdgcn_wave_barrier();
-                __threadfence_block();
+                __syncthreads();
+                if (t < 64) {
+                    const int bj = j < nb ? blk[j] : 1;
+                    const unsigned c_lo = cm[2 * j], c_hi = cm[2 * j + 1];
+                    unsigned long long keep = 0;   // uniform: bit j = candidate j kept
+                    for (int q = 0; q < nb; q++) {
+                        const unsigned lo = __builtin_amdgcn_readlane(c_lo, q), hi = __builtin_amdgcn_readlane(c_hi, q);
+                        const int b_ = __builtin_amdgcn_readlane(bj, q);
+                        const unsigned long long cq = ((unsigned long long)hi << 32) | lo;
+                        if (!b_ && !(cq & keep)) keep |= 1ULL << q;
+                    }
+                    if (j < nb && ((keep >> j) & 1ULL)) {
+                        const int pos = nacc + __popcll(keep & ((1ULL << j) - 1ULL));
+                        acc[pos] = make_int2(px, py);
+                        tmpi[pos] = perm[q0 + j];
+                    }
+                    nacc += __popcll(keep);
+                    if (t == 0) sh_nacc = nacc;
+                }
+                __syncthreads();
+                nacc = sh_nacc;
             }
-            if (t == 0) sh_nacc = nacc;
+            if (n == 0 && t == 0) sh_nacc = 0;
         }
         __syncthreads();
+        FE_PH(72);
         int nk = sh_nacc;
         {
             float2 f0; int i0, k0;
@@ -914,7 +1111,8 @@ __global__ __launch_bounds__(256) void fe_select_kernel(Batch B) {
     }
     __syncthreads();
     for (int i = t; i < n; i += blockDim.x) { g_forw[i] = forw[i]; g_id[i] = id[i]; g_cnt[i] = cnt[i]; }
-    if (t == 0) { fe.n_forw = n; fe.n_deficit = n_deficit; fe.n_unstable = sh_nun; }
+    if (t == 0) { fe.n_forw = n; fe.n_deficit = n_deficit; fe.n_unstable = sh_nun; B.fe_ticks[s * 4 + 0] = (float)((long long)wall_clock64() - wg_t0); }
+    FE_PH(73);
 }
 
 // ------------------------------------------------------------------------------------------------ fe_fast
@@ -1026,89 +1224,161 @@ __global__ __launch_bounds__(256) void fe_fast_stage_kernel(const uint8_t *img, 
 }
 
 // ------------------------------------------------------------------------------------------------ fe_add
+#define FE_NEAR_CAP 192
 // Per sequence, cells in order: mask filter (runByPixelsMask), top-k by response (replace-min scan), addPoints greedy;
 // then cur <- forw, undistortedPoints, velocity, updateID, feature-map packaging in ascending id.
 // grid S, 256 threads, dynamic LDS.
 __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int gate) {
     const DevCfg &C = *B.cfg;
     const vio_config &c = C.c;
-    const int s = blockIdx.x + B.s0, t = threadIdx.x, NP = C.NP;
+    const int s = blockIdx.x + B.s0, t = threadIdx.x, NP = C.NP, lane = t & 63, wv = t >> 6;
     FeSeq &fe = B.fe[s];
     if (fe.n_forw < 0) return;
     const int publish = fe.pub_req;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int hw_s[64];                          // cv::circle half-widths (min_dist <= 63) out of the global config
     for (int k = t; k < 64; k += blockDim.x) hw_s[k] = k <= c.min_dist ? C.circle_hw[k] : 0;
-    int2 *acc = (int2 *)smem;                         // 2*NP
-    int *flag = (int *)(acc + 2 * NP);                // VIO_FAST_CAP
+    int2 *acc = (int2 *)smem;                         // 2*NP accepted mask centres
+    unsigned long long *pre = (unsigned long long *)(acc + 2 * NP);   // [4][FE_NEAR_CAP] int2: old centres near the cell a wavefront works on
+    int *flag = (int *)(pre + 4 * FE_NEAR_CAP);       // VIO_FAST_CAP
     int *offs = flag + VIO_FAST_CAP;                  // VIO_FAST_CAP
     uint32_t *filt = (uint32_t *)(offs + VIO_FAST_CAP);  // VIO_FAST_CAP
     int *scratch = (int *)(filt + VIO_FAST_CAP);      // 260
     uint32_t *keep = (uint32_t *)(scratch + 260);     // 64
-    __shared__ int sh_nacc, sh_n, sh_nkeep;
+    int *pid_l = (int *)(keep + 64);                  // NP   previous frame's id -> undistorted point map, staged for the velocity lookup
+    float2 *pun_l = (float2 *)(pid_l + NP);           // NP
+    __shared__ int sh_n;
+    __shared__ int mcell[VIO_MAX_CELLS];              // candidates of a deficit cell that clear the old centres
 
     float2 *g_forw = B.forw_pts + (size_t)s * NP, *g_cur = B.cur_pts + (size_t)s * NP, *g_un = B.cur_un_pts + (size_t)s * NP,
            *g_vel = B.pts_velocity + (size_t)s * NP, *g_pun = B.prev_un_pt + (size_t)s * NP;
     int *g_id = B.ids + (size_t)s * NP, *g_cnt = B.track_cnt + (size_t)s * NP, *g_pid = B.prev_un_id + (size_t)s * NP;
     int n = fe.n_forw;
+    FE_PH_INIT;
+    const long long wg_t0 = t == 0 ? (long long)wall_clock64() : 0;
+    const int nprev = fe.n_prev_map;
+    for (int k = t; k < nprev; k += blockDim.x) { pid_l[k] = g_pid[k]; pun_l[k] = g_pun[k]; }
     if (publish && fe.n_deficit > 0) {
+        // gridDetect + addPoints, cell after cell in order (feature_tracker.cpp:105-171, 220-233, 397-409).  The mask a cell's detection
+        // is filtered with = the centres accepted before the cell loop (setMask survivors + unstable points) + the points added by the
+        // earlier cells.  Step 1, all wavefronts, a deficit cell each: drop the FAST candidates an OLD centre covers (the bulk of the
+        // disk tests).  Step 2, wavefront 0 alone (no workgroup barriers), the cells in order: candidates that also clear
+        // the NEW centres, compacted in row-major order (runByPixelsMask), top-k by response with the replace-min scan's slot semantics,
+        // then addPoints among the survivors -- which by construction clear every centre accepted before them, so only their mutual
+        // conflicts remain: a K x K bit matrix resolved in slot order.
         const int2 *g_acc = B.accept_xy + (size_t)s * 2 * NP;
-        int nacc0 = fe.n_accept;
+        const int nacc0 = fe.n_accept, ndef = fe.n_deficit;
         for (int k = t; k < nacc0; k += blockDim.x) acc[k] = g_acc[k];
-        if (t == 0) { sh_nacc = nacc0; sh_n = n; }
+        if (t == 0) sh_n = n;
         __syncthreads();
         const int r = c.min_dist;
-        for (int dc = 0; dc < fe.n_deficit; dc++) {
-            int cell = fe.deficit_cells[dc];
-            GridRect rc = C.rect[cell];
-            int nc = fe.cell_ncand[cell];
-            const uint32_t *cand = B.cand + ((size_t)s * C.ncells + cell) * VIO_FAST_CAP;
-            int nacc = sh_nacc;
-            // KeyPointsFilter::runByPixelsMask
-            for (int k = t; k < nc; k += blockDim.x) {
-                uint32_t v = cand[k];
-                int px = rc.x + (int)(v & 0xFFF), py = rc.y + (int)((v >> 12) & 0xFFF);
-                bool hit = false;
-                for (int a = 0; a < nacc; a++) hit |= in_disk(hw_s, r, px, py, acc[a].x, acc[a].y);
-                flag[k] = hit ? 0 : 1;
-            }
-            __syncthreads();
-            int nf = block_exclusive_scan(flag, nc, offs, scratch);
-            for (int k = t; k < nc; k += blockDim.x) if (flag[k]) filt[offs[k]] = cand[k];
-            __syncthreads();
-            if (nf == 0) {  // :120-124
-                if (t == 0) fe.grids_texture_status[cell] = 0;
-                __syncthreads();
-                continue;
-            }
-            // top-k by response, replace-min scan (:127-167); survivors stay in slot order
-            int K = C.grids_threshold - fe.grids_track_num[cell] + 2;
-            // One wavefront replays the scan: lane k owns slot k (K <= 64), the running minimum is a DPP / readlane reduction instead
-            // of a K-long rescan by a single thread.  Same semantics as the sequential loop: first minimal slot, except that a freshly
-            // replaced slot keeps the "minimum" title when it ties with an earlier one (the rescan starts from it and uses <).
-            if (t < 64) {
-                if (nf <= K || K > 64) {
-                    if (K > 64 && nf > K) {  // never the case for the supported configurations (grids_threshold + 2 <= 64): serial fallback
-                        if (t == 0) {
-                            int min_id = 0;
-                            for (int j = 0; j < nf; j++) {
-                                uint32_t v = filt[j];
-                                int resp = (int)(v >> 24);
-                                if (j < K) { keep[j] = v; if (resp < (int)(keep[min_id] >> 24)) min_id = j; }
-                                else if (resp > (int)(keep[min_id] >> 24)) {
-                                    keep[min_id] = v;
-                                    for (int k = 0; k < K; k++) if ((int)(keep[k] >> 24) < (int)(keep[min_id] >> 24)) min_id = k;
-                                }
-                            }
-                            sh_nkeep = K;
-                        }
-                    } else {
-                        for (int k = t; k < nf; k += 64) keep[k] = filt[k];
-                        if (t == 0) sh_nkeep = nf;
+        // step 1: wavefront wv takes the deficit cells dc = wv, wv + 4, ...: the old centres whose disk can reach into the cell's
+        // rectangle are gathered into a short list first (a cell sees about a tenth of them), the cell's candidates are tested
+        // against that list and the survivors are compacted IN PLACE at the head of the cell's candidate array (row-major order kept:
+        // a survivor never moves past its own position), their number goes to mcell[dc]
+        {
+            int2 *nearl = (int2 *)pre + wv * FE_NEAR_CAP;   // [4][FE_NEAR_CAP]
+            for (int dc = wv; dc < ndef; dc += 4) {
+                const int cell = fe.deficit_cells[dc];
+                const GridRect rc = C.rect[cell];
+                const int nc = fe.cell_ncand[cell];
+                uint32_t *cand = B.cand + ((size_t)s * C.ncells + cell) * VIO_FAST_CAP;
+                const int x_lo = rc.x - r, x_hi = rc.x + rc.w - 1 + r, y_lo = rc.y - r, y_hi = rc.y + rc.h - 1 + r;
+                int nnear = 0;
+                for (int a0 = 0; a0 < nacc0; a0 += 64) {
+                    const int a = a0 + lane;
+                    int2 q = make_int2(0, 0);
+                    bool rel = false;
+                    if (a < nacc0) { q = acc[a]; rel = q.x >= x_lo && q.x <= x_hi && q.y >= y_lo && q.y <= y_hi; }
+                    const unsigned long long bal = __ballot(rel);
+                    const int pos = nnear + __popcll(bal & ((1ULL << lane) - 1ULL));
+                    if (rel && pos < FE_NEAR_CAP) nearl[pos] = q;
+                    nnear += __popcll(bal);
+                }
+                wave_lds_sync();
+                const bool use_all = nnear > FE_NEAR_CAP;   // (a crowd of centres around one cell: test against all of them)
+                const int2 *lst = use_all ? acc : nearl;
+                const int nl = use_all ? nacc0 : nnear;
+                int m = 0;
+                for (int ch = 0; ch * 64 < nc; ch++) {
+                    const int k = ch * 64 + lane;
+                    bool pass = false;
+                    uint32_t v = 0;
+                    if (k < nc) {
+                        v = cand[k];
+                        const int px = rc.x + (int)(v & 0xFFF), py = rc.y + (int)((v >> 12) & 0xFFF);
+                        bool hit = false;
+                        for (int a = 0; a < nl; a++) hit |= in_disk(hw_s, r, px, py, lst[a].x, lst[a].y);
+                        pass = !hit;
                     }
+                    const unsigned long long bal = __ballot(pass);
+                    if (pass) cand[m + __popcll(bal & ((1ULL << lane) - 1ULL))] = v;
+                    m += __popcll(bal);
+                }
+                if (lane == 0) mcell[dc] = m;
+                wave_lds_sync();
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        FE_PH(80);
+        if (t < 64) {
+            int na = nacc0, nn = n;
+            for (int dc = 0; dc < ndef; dc++) {
+                const int cell = fe.deficit_cells[dc];
+                const GridRect rc = C.rect[cell];
+                const int nc = mcell[dc];
+                const uint32_t *cand = B.cand + ((size_t)s * C.ncells + cell) * VIO_FAST_CAP;
+                // ---- KeyPointsFilter::runByPixelsMask, second half: the centres added by the earlier cells
+                int nf = 0;
+                for (int ch = 0; ch * 64 < nc; ch++) {
+                    const int k = ch * 64 + lane;
+                    bool pass = k < nc;
+                    uint32_t v = 0;
+                    if (pass) {
+                        v = cand[k];
+                        const int px = rc.x + (int)(v & 0xFFF), py = rc.y + (int)((v >> 12) & 0xFFF);
+                        bool hit = false;
+                        for (int a = nacc0; a < na; a++) hit |= in_disk(hw_s, r, px, py, acc[a].x, acc[a].y);
+                        pass = !hit;
+                    }
+                    const unsigned long long bal = __ballot(pass);
+                    if (pass) filt[nf + __popcll(bal & ((1ULL << lane) - 1ULL))] = v;
+                    nf += __popcll(bal);
+                }
+                wave_lds_sync();
+                if (nf == 0) {  // :120-124
+                    if (t == 0) fe.grids_texture_status[cell] = 0;
+                    continue;
+                }
+                // ---- top-k by response, replace-min scan (:127-167); survivors stay in slot order
+                const int K = C.grids_threshold - fe.grids_track_num[cell] + 2;
+                int nk;
+                uint32_t mine = 0xFFFFFFFFu;   // lane k owns slot k
+                if (nf <= K) {
+                    nk = nf;
+                    if (nk > 64) {   // more survivors than a wavefront has lanes (never with grids_threshold + 2 <= 64): serial addPoints below
+                        nk = -nf;
+                    } else if (lane < nf) mine = filt[lane];
+                } else if (K > 64) {
+                    // never the case for the supported configurations (grids_threshold + 2 <= 64): serial replay of the scan, in place
+                    if (t == 0) {
+                        int min_id = 0;
+                        for (int j = 0; j < nf; j++) {
+                            uint32_t v = filt[j];
+                            int resp = (int)(v >> 24);
+                            if (j < K) { filt[j] = v; if (resp < (int)(filt[min_id] >> 24)) min_id = j; }
+                            else if (resp > (int)(filt[min_id] >> 24)) {
+                                filt[min_id] = v;
+                                for (int k = 0; k < K; k++) if ((int)(filt[k] >> 24) < (int)(filt[min_id] >> 24)) min_id = k;
+                            }
+                        }
+                    }
+                    wave_lds_sync();
+                    nk = -K;
                 } else {
-                    const int lane = t;
-                    uint32_t mine = lane < K ? filt[lane] : 0xFFFFFFFFu;
+                    nk = K;
+                    mine = lane < K ? filt[lane] : 0xFFFFFFFFu;
                     // key = response * 64 + slot: the minimum key is the first slot with the smallest response
                     auto wave_min_key = [&](uint32_t val) -> int {
                         int key = lane < K ? ((int)(val >> 24) << 6) | lane : 0x7FFFFFFF;
@@ -1117,54 +1387,73 @@ __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int gate) {
                     };
                     int mk = wave_min_key(mine);
                     int min_id = mk & 63, min_resp = mk >> 6;
-                    for (int j = K; j < nf; j++) {
-                        uint32_t v = filt[j];
-                        int resp = (int)(v >> 24);
-                        if (resp > min_resp) {
-                            if (lane == min_id) mine = v;
-                            int nk2 = wave_min_key(mine);
-                            int cand_id = nk2 & 63, cand_resp = nk2 >> 6;
-                            // rescan starts at the replaced slot and only moves on a strictly smaller response
-                            if (resp == cand_resp) cand_id = min_id;
-                            min_id = cand_id; min_resp = cand_resp;
-                        }
+                    // the scan only acts on candidates whose response beats the current minimum: find the next one 64 at a time
+                    for (int j = K; j < nf;) {
+                        const int jj = j + lane;
+                        const uint32_t v = jj < nf ? filt[jj] : 0u;
+                        const unsigned long long bal = __ballot(jj < nf && (int)(v >> 24) > min_resp);
+                        if (!bal) { j += 64; continue; }
+                        const int first = __builtin_ctzll(bal);
+                        const uint32_t vv = (uint32_t)__builtin_amdgcn_readlane((int)v, first);
+                        const int resp = (int)(vv >> 24);
+                        if (lane == min_id) mine = vv;
+                        const int nk2 = wave_min_key(mine);
+                        int cand_id = nk2 & 63;
+                        const int cand_resp = nk2 >> 6;
+                        // the rescan starts at the replaced slot and only moves on a strictly smaller response
+                        if (resp == cand_resp) cand_id = min_id;
+                        min_id = cand_id; min_resp = cand_resp;
+                        j += first + 1;
                     }
-                    if (lane < K) keep[lane] = mine;
-                    if (t == 0) sh_nkeep = K;
                 }
-            }
-            __syncthreads();
-            // addPoints (:220-233), one wavefront
-            if (t < 64) {
-                volatile int2 *vacc = acc;
-                int na = sh_nacc, nn = sh_n, nk = sh_nkeep;
-                for (int q = 0; q < nk; q++) {
-                    uint32_t v = keep[q];
-                    int px = rc.x + (int)(v & 0xFFF), py = rc.y + (int)((v >> 12) & 0xFFF);
-                    bool hit = false;
-                    for (int k = t; k < na; k += 64) hit |= in_disk(hw_s, r, px, py, vacc[k].x, vacc[k].y);
-                    bool any = __any(hit);
-                    if (!any && nn < NP) {
-                        if (t == 0) {
-                            vacc[na].x = px; vacc[na].y = py;
-                                g_forw[nn] = make_float2((float)px, (float)py); g_id[nn] = -1; g_cnt[nn] = 1;
-                        }
-                        na++;
-                        nn++;
+                // ---- addPoints (:220-233): every survivor clears all centres accepted so far, only their mutual conflicts remain
+                if (nk >= 0) {
+                    const int px = lane < nk ? rc.x + (int)(mine & 0xFFF) : 0, py = lane < nk ? rc.y + (int)((mine >> 12) & 0xFFF) : 0;
+                    unsigned long long cf = 0;   // bit i: slot i < my slot covers me
+                    for (int i = 0; i < nk; i++) {
+                        const int xi = __builtin_amdgcn_readlane(px, i), yi = __builtin_amdgcn_readlane(py, i);
+                        if (i < lane && in_disk(hw_s, r, px, py, xi, yi)) cf |= 1ULL << i;
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    __threadfence_block();
+                    const unsigned c_lo = (unsigned)cf, c_hi = (unsigned)(cf >> 32);
+                    unsigned long long kept = 0;
+                    int room = NP - nn;
+                    for (int q = 0; q < nk; q++) {
+                        const unsigned long long cq = ((unsigned long long)__builtin_amdgcn_readlane(c_hi, q) << 32) | __builtin_amdgcn_readlane(c_lo, q);
+                        if (!(cq & kept) && room > 0) { kept |= 1ULL << q; room--; }
+                    }
+                    if (lane < nk && ((kept >> lane) & 1ULL)) {
+                        const int pos = __popcll(kept & ((1ULL << lane) - 1ULL));
+                        acc[na + pos] = make_int2(px, py);
+                        g_forw[nn + pos] = make_float2((float)px, (float)py); g_id[nn + pos] = -1; g_cnt[nn + pos] = 1;
+                    }
+                    const int added = __popcll(kept);
+                    na += added; nn += added;
+                } else {
+                    // more than 64 survivors: the one-by-one walk (lanes test the accepted centres in parallel)
+                    const int cnt = -nk;
+                    for (int q = 0; q < cnt; q++) {
+                        const uint32_t v = filt[q];
+                        const int px = rc.x + (int)(v & 0xFFF), py = rc.y + (int)((v >> 12) & 0xFFF);
+                        bool hit = false;
+                        for (int k = nacc0 + lane; k < na; k += 64) hit |= in_disk(hw_s, r, px, py, acc[k].x, acc[k].y);
+                        if (!__any(hit) && nn < NP) {
+                            if (t == 0) { acc[na] = make_int2(px, py); g_forw[nn] = make_float2((float)px, (float)py); g_id[nn] = -1; g_cnt[nn] = 1; }
+                            na++; nn++;
+                        }
+                        wave_lds_sync();
+                    }
                 }
-                if (t == 0) { sh_nacc = na; sh_n = nn; }
+                wave_lds_sync();
             }
-            __syncthreads();
+            if (t == 0) sh_n = nn;
         }
+        __syncthreads();
         n = sh_n;
     }
     __syncthreads();
+    FE_PH(84);
     // ---- cur <- forw; undistortedPoints (:542-593); updateID (:485-495)
     double dt = fe.cur_time - fe.prev_time;
-    int nprev = fe.n_prev_map;
     int *newflag = flag, *newoff = offs;  // n <= NP <= VIO_FAST_CAP is checked at create time
     for (int i = t; i < n; i += blockDim.x) {
         float2 p = g_forw[i];
@@ -1177,8 +1466,8 @@ __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int gate) {
         int idv = g_id[i];
         if (nprev > 0 && idv != -1) {
             for (int k = 0; k < nprev; k++)
-                if (g_pid[k] == idv) {
-                    double vx = (u.x - g_pun[k].x) / dt, vy = (u.y - g_pun[k].y) / dt;
+                if (pid_l[k] == idv) {
+                    double vx = (u.x - pun_l[k].x) / dt, vy = (u.y - pun_l[k].y) / dt;
                     vel = make_float2((float)vx, (float)vy);
                     break;
                 }
@@ -1187,6 +1476,7 @@ __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int gate) {
         newflag[i] = idv == -1 ? 1 : 0;
     }
     __syncthreads();
+    FE_PH(85);
     // prev_un_pts_map = cur_un_pts_map: ids as they are *before* updateID
     for (int i = t; i < n; i += blockDim.x) { g_pid[i] = g_id[i]; g_pun[i] = g_un[i]; }
     __syncthreads();
@@ -1194,6 +1484,7 @@ __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int gate) {
     int nid0 = fe.n_id;
     for (int i = t; i < n; i += blockDim.x) if (newflag[i]) g_id[i] = nid0 + newoff[i];
     __syncthreads();
+    FE_PH(86);
     // ---- feature-map packaging (estimator_nodelet.cpp:336-363): track_cnt > 1, ascending id (std::map order)
     int nobs = 0;
     if (publish) {
@@ -1216,7 +1507,11 @@ __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int gate) {
             q[0] = g_un[i].x; q[1] = g_un[i].y; q[2] = 1.0; q[3] = g_cur[i].x; q[4] = g_cur[i].y; q[5] = g_vel[i].x; q[6] = g_vel[i].y;
         }
     }
+    FE_PH(87);
     if (t == 0) {
+        B.fe_ticks[s * 4 + 1] = (float)((long long)wall_clock64() - wg_t0);
+        B.fe_ticks[s * 4 + 2] = (float)fe.n_deficit;
+        B.fe_ticks[s * 4 + 3] = (float)fe.ransac_iters;
         fe.n_pts = n;
         fe.n_forw = n;
         fe.n_prev_map = n;

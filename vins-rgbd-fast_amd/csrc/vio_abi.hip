@@ -815,7 +815,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     DA(B.imu_raw, S * C.W * 15 * 31);
     DA(B.margA, S * mq * mq); DA(B.margB, S * mq); DA(B.margV, S * n * n); DA(B.margW, S * (n + 16) * (n + 16));
     if (C.MX > 0) DA(B.margE, S * ((size_t)3 * C.MX * C.MX + n * (size_t)C.MX));
-    DA(B.odom, S * 11); DA(B.timings, 64);
+    DA(B.odom, S * 11); DA(B.timings, 128); DA(B.fe_ticks, S * 4);
     B.hist_cap = 2048;
     B.s0 = 0;
     B.ns = 0; B.xcd_nb = 0; B.xcd_n = 8;
@@ -867,7 +867,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     if (rc == VIO_OK) for (auto &g : h->groups) (void)hipEventRecord(g.ev_be, g.stream);
     if (rc == VIO_OK) {
         h->lds_select = (size_t)C.NP * 104 + 260 * 4 + 64;
-        h->lds_add = (size_t)C.NP * 16 + 3 * VIO_FAST_CAP * 4 + 260 * 4 + 64 * 4 + 64;
+        h->lds_add = (size_t)C.NP * 16 + (size_t)4 * 192 * 8 /* FE_NEAR_CAP */ + 3 * VIO_FAST_CAP * 4 + 260 * 4 + 64 * 4 + (size_t)C.NP * 12 + 64;
         int amax = 0;
         for (int k = 0; k < C.ncells; k++) amax = std::max(amax, ((C.rect[k].w * C.rect[k].h + 15) & ~15));
         int hmax = 0;
@@ -1602,11 +1602,19 @@ int vio_debug_seq(vio_batch *h, int seq, int *out16) {
 }
 
 // debug: accumulated in-kernel phase ticks (100 MHz) of sequence 0; reset != 0 clears them
-int vio_debug_phases(vio_batch *h, float *out64, int reset) {
+int vio_debug_phases(vio_batch *h, float *out128, int reset) {
     if (!h) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
-    if (out64) HIPCHK(hipMemcpy(out64, h->B.timings, 64 * sizeof(float), hipMemcpyDeviceToHost));
-    if (reset) HIPCHK(hipMemset(h->B.timings, 0, 64 * sizeof(float)));
+    if (out128) HIPCHK(hipMemcpy(out128, h->B.timings, 128 * sizeof(float), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(hipMemset(h->B.timings, 0, 128 * sizeof(float)));
+    return VIO_OK;
+}
+
+// debug: per-sequence in-kernel durations (100 MHz ticks) of the last frame's fe_select / fe_add: out[S][4]
+int vio_debug_fe_ticks(vio_batch *h, float *out) {
+    if (!h || !out) return VIO_EINVAL;
+    { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
+    HIPCHK(hipMemcpy(out, h->B.fe_ticks, (size_t)h->S * 4 * sizeof(float), hipMemcpyDeviceToHost));
     return VIO_OK;
 }
 

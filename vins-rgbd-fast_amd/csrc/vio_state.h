@@ -205,6 +205,7 @@ struct Batch {
     int hist_cap;
     int flags;            // debug switches (VIO_FLAGS): 1 = keep the Schur complement in HBM instead of LDS tiles
     float *timings;
+    float *fe_ticks;      // [S][4] debug: 100 MHz ticks fe_select / fe_add / fe_fast(max cell) of each sequence spent in the last frame
     SolveSt *sst;         // [S] phased solver state
 };
 
