@@ -30,7 +30,9 @@ NAMES = {0: "vector2double", 1: "lm indexing", 2: "pair lists", 4: "evaluate(fir
          64: "select load + status cull", 65: "select lift (F input)", 66: "  ransac 7-point hypotheses", 67: "  ransac inlier counts", 68: "  ransac serial best/iters",
          69: "  ransac final inliers", 70: "select F compaction", 71: "select rank sort", 72: "select greedy setMask", 73: "select counts + stores",
          80: "add cell mask filter", 81: "add cell scan/compact", 82: "add cell top-k", 83: "add cell addPoints", 84: "add (tail of cells)",
-         85: "add undistort + velocity", 86: "add ids", 87: "add packaging", 90: "lk: block 0 total", 91: "lk: launches counted"}
+         85: "add undistort + velocity", 86: "add ids", 87: "add packaging", 90: "lk: block 0 total", 91: "lk: launches counted",
+         92: "lk: iterations x100 (block 0)", 93: "lk: levels x100 (block 0)", 94: "lk: setup per frame (block 0)", 95: "lk: iterations per frame (block 0)",
+         96: "lk:   setup until staged (cumulative)", 97: "lk:   setup until derivatives (cumulative)"}
 
 
 def main():

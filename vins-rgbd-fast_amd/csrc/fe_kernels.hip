@@ -149,6 +149,86 @@ __device__ dm::m3 predict_motion(const Batch &B, int s, double t0, double t1) {
     }
     return rel;
 }
+// The same integration by one wavefront (fe_begin): the scalar version walks the IMU ring with one dependent global load per sample
+// and a sin / cos per step (65 us per frame on the front-end's critical path).  Here 64 ring entries are read at once, the first
+// sample beyond t0 is found with a ballot, every lane forms the rotation increment of its own sample (the neighbour's stamp and
+// rate come through a lane shift), and only the ordered product rel <- rel * Rk^T runs sequentially on broadcast matrices.
+// Identical operations on identical operands, hence the identical matrix.
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, src), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ dm::m3 predict_motion_wave(const Batch &B, int s, double t0, double t1) {
+    const DevCfg &C = *B.cfg;
+    const BeSeq &be = B.be[s];
+    const int lane = threadIdx.x & 63;
+    int imu_head = be.imu_head;
+    const int imu_count = be.imu_count;
+    if (imu_count - imu_head > C.NIMU) imu_head = imu_count - C.NIMU;  // ring bookkeeping: samples that were overwritten
+    const double *it = B.imu_t + (size_t)s * C.NIMU;
+    const double *ig = B.imu_gyr + (size_t)s * C.NIMU * 3;
+    const bool have = imu_count > imu_head;
+    const double back_t = have ? it[(imu_count - 1) % C.NIMU] : -1e300;
+    dm::m3 rel = dm::eye();
+    if (!(have && t1 <= back_t)) return rel;
+    // first sample with t > t0
+    int k = imu_head;
+    while (k < imu_count) {
+        const int j = k + lane;
+        const bool le = j < imu_count && it[j % C.NIMU] <= t0;
+        const unsigned long long bal = __ballot(le);
+        if (bal == ~0ULL) { k += 64; continue; }
+        k += __builtin_ctzll(~bal);   // stamps ascend: the lanes with t <= t0 are a prefix
+        break;
+    }
+    const dm::m3 ricT = dm::tr(dm::ldm(C.c.ric));
+    const dm::v3 bg = dm::ld3(B.tracker_lag ? be.track_Bg : be.latest_Bg);
+    bool first = true;
+    double prev_t = 0;
+    dm::v3 prev_gyr = dm::mk(0, 0, 0);
+    while (k < imu_count) {
+        const int j = k + lane;
+        const bool in = j < imu_count;
+        const double tk = in ? it[j % C.NIMU] : 1e300;
+        const dm::v3 w = in ? dm::ld3(ig + (size_t)(j % C.NIMU) * 3) : dm::mk(0, 0, 0);
+        const unsigned long long bal = __ballot(in && tk <= t1);
+        const int nv = bal == ~0ULL ? 64 : __builtin_ctzll(~bal);   // samples of this chunk inside (t0, t1], a prefix
+        if (nv == 0) break;
+        // the sample before mine: the neighbour lane's, or the last one of the previous chunk for lane 0
+        double pt = __shfl_up(tk, 1, 64);
+        dm::v3 pw = dm::mk(__shfl_up(w.x, 1, 64), __shfl_up(w.y, 1, 64), __shfl_up(w.z, 1, 64));
+        if (lane == 0) { pt = prev_t; pw = prev_gyr; }
+        const bool step = lane < nv && !(first && lane == 0);   // the very first sample only seeds (prev_t, prev_gyr)
+        dm::m3 RkT = dm::eye();
+        if (step) {
+            const double dt = tk - pt;
+            const dm::v3 un_gyr = dm::sub(dm::scl(0.5, dm::add(pw, w)), bg);
+            const dm::v3 aa = dm::scl(dt, dm::mul(ricT, un_gyr));
+            const double ang = dm::nrm(aa);
+            dm::m3 Rk = dm::eye();
+            if (ang > 0) {
+                const dm::v3 ax = dm::scl(1.0 / ang, aa);
+                const double sn = sin(ang), cs = cos(ang);
+                const dm::m3 K = dm::skew(ax);
+                Rk = dm::add(dm::add(dm::eye(), dm::scl(sn, K)), dm::scl(1 - cs, dm::mul(K, K)));
+            }
+            RkT = dm::tr(Rk);
+        }
+        for (int q = (first ? 1 : 0); q < nv; q++) {
+            dm::m3 Mq;
+#pragma unroll
+            for (int e = 0; e < 9; e++) Mq.a[e] = lane_bcast(RkT.a[e], q);
+            rel = dm::mul(rel, Mq);
+        }
+        first = false;
+        prev_t = lane_bcast(tk, nv - 1);
+        prev_gyr = dm::mk(lane_bcast(w.x, nv - 1), lane_bcast(w.y, nv - 1), lane_bcast(w.z, nv - 1));
+        if (nv < 64) break;
+        k += 64;
+    }
+    return rel;
+}
 // Estimator::predict (estimator.cpp:1862-1880) applied from the newest window state through every IMU sample that arrived after it:
 // what pubLatestOdometry publishes at IMU rate (inputIMU, :1749-1766, after updateLatestStates :1768-1788).  out11 = t, P(3),
 // Q(w, x, y, z), V(3); returns the window state itself when no newer sample is in the ring.  Output only: nothing is modified.
@@ -203,20 +283,24 @@ __global__ void fe_predict_motion_kernel(Batch B, int seq, double t0, double t1,
 // modes: per-sequence frame mode (VIO_FRAME_SKIP / TRACK / PUBLISH) or NULL = `publish` for every sequence.
 // R_rel: caller-supplied relative rotations [S][9] (readImage(img, t, relative_R), feature_tracker.h:36-37) or NULL; a NaN in the
 // first element of a sequence's matrix means "predict on the device" for that sequence.
-__global__ void fe_begin_kernel(Batch B, const double *stamps, int gate, int publish, const uint8_t *modes, const double *R_rel) {
+__global__ __launch_bounds__(64) void fe_begin_kernel(Batch B, const double *stamps, int gate, int publish, const uint8_t *modes, const double *R_rel) {
     int s = blockIdx.x + B.s0;
-    if (threadIdx.x != 0) return;
+    const bool w0 = threadIdx.x == 0;   // every lane follows the same (uniform) control flow, lane 0 does the stores
     const DevCfg &C = *B.cfg;
     FeSeq &fe = B.fe[s];
     const BeSeq &be = B.be[s];  // read-only here: the previous frame's marginalisation may still be running on the other stream
     double t = stamps[s];
     const double td = B.tracker_lag ? be.track_td : be.td;
-    fe.n_deficit = 0;
-    fe.n_obs = 0;
-    fe.publish_ok = 0;
-    fe.overflow = 0;
+    const int first_image = fe.first_image_flag;
+    const double last_image_time = fe.last_image_time;
+    if (w0) {
+        fe.n_deficit = 0;
+        fe.n_obs = 0;
+        fe.publish_ok = 0;
+        fe.overflow = 0;
+    }
     const int mode = modes ? (int)modes[s] : (publish ? VIO_FRAME_PUBLISH : VIO_FRAME_TRACK);
-    fe.pub_req = mode == VIO_FRAME_PUBLISH;
+    if (w0) fe.pub_req = mode == VIO_FRAME_PUBLISH;
     if (gate) {
         int imu_head = be.imu_head;
         if (be.imu_count - imu_head > C.NIMU) imu_head = be.imu_count - C.NIMU;
@@ -225,36 +309,38 @@ __global__ void fe_begin_kernel(Batch B, const double *stamps, int gate, int pub
         double back_t = have ? it[(be.imu_count - 1) % C.NIMU] : -1e300;
         // caller contract of vio_feed: IMU pushed through stamp + td (upstream busy-waits, estimator.cpp:178-183); VO mode has no IMU
         if (C.c.use_imu && !(have && t + td <= back_t)) {
-            fe.n_forw = -2;  // nothing consumed; tells the later kernels to skip this sequence (be_ingest reports VIO_NEED_IMU)
+            if (w0) fe.n_forw = -2;  // nothing consumed; tells the later kernels to skip this sequence (be_ingest reports VIO_NEED_IMU)
             return;
         }
-        if (fe.first_image_flag) {  // estimator_nodelet.cpp:234-240
-            fe.first_image_flag = 0;
-            fe.last_image_time = t;
-            fe.n_forw = -1;
+        if (first_image) {  // estimator_nodelet.cpp:234-240
+            if (w0) {
+                fe.first_image_flag = 0;
+                fe.last_image_time = t;
+                fe.n_forw = -1;
+            }
             return;
         }
     }
     if (mode == VIO_FRAME_SKIP) {  // frequency control dropped the frame before readImage (estimator_nodelet.cpp:264-271): no state changes
-        fe.n_forw = -1;
+        if (w0) fe.n_forw = -1;
         return;
     }
     // Estimator::predictMotion(last_image_time, t + td), unless the caller handed in relative_R
     const double *Rc = R_rel ? R_rel + (size_t)s * 9 : nullptr;
     if (!C.c.use_imu) {   // readImage(img, t) (estimator_nodelet.cpp:315): no prediction, LK starts at the old positions
-        dm::stm(fe.R_rel, dm::eye());
-        fe.use_R_rel = 0;
+        if (w0) { dm::stm(fe.R_rel, dm::eye()); fe.use_R_rel = 0; }
     } else if (Rc && Rc[0] == Rc[0]) {
-        for (int k = 0; k < 9; k++) fe.R_rel[k] = Rc[k];
-        fe.use_R_rel = 1;
+        if (w0) { for (int k = 0; k < 9; k++) fe.R_rel[k] = Rc[k]; fe.use_R_rel = 1; }
     } else {
-        dm::stm(fe.R_rel, predict_motion(B, s, fe.last_image_time, t + td));
-        fe.use_R_rel = 0;
+        const dm::m3 R = predict_motion_wave(B, s, last_image_time, t + td);
+        if (w0) { dm::stm(fe.R_rel, R); fe.use_R_rel = 0; }
     }
-    fe.last_image_time = t;
-    fe.cur_time = t;
-    fe.n_forw = 0;
-    fe.n_unstable = 0;
+    if (w0) {
+        fe.last_image_time = t;
+        fe.cur_time = t;
+        fe.n_forw = 0;
+        fe.n_unstable = 0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ fe_pyramid
@@ -263,26 +349,46 @@ __global__ void fe_begin_kernel(Batch B, const double *stamps, int gate, int pub
 // when copy0 != NULL the 128x32 source pixels owned by the tile are also copied to the level-0 ping-pong buffer.
 #define PD_TW 64
 #define PD_TH 16
+#define PD_PITCH (2 * PD_TW + 8)   // LDS pitch of the source tile: it is staged from the 4-byte aligned column 2 ox - 4
 __device__ void pyrdown_tile(const uint8_t *src, int sw, int sh, uint8_t *dst, uint8_t *l0) {
     int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
-    __shared__ uint8_t tile[2 * PD_TH + 3][2 * PD_TW + 4];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[2 * PD_TH + 3][PD_PITCH];
     __shared__ int hrow[2 * PD_TH + 3][PD_TW];
     int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
     int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
     const int TWS = 2 * PD_TW + 3, THS = 2 * PD_TH + 3;
-    for (int q = threadIdx.x; q < TWS * THS; q += 256) {
-        int ty = q / TWS, tx = q - ty * TWS;
-        int gx = sx0 + tx, gy = sy0 + ty;
-        // pixels further than one reflection outside the image feed no valid output: clamp only keeps the address legal
-        int ry = min(max(reflect101(gy, sh), 0), sh - 1), rx = min(max(reflect101(gx, sw), 0), sw - 1);
-        uint8_t v = src[(size_t)ry * sw + rx];
-        tile[ty][tx] = v;
-        if (l0 && tx >= 2 && tx < 2 + 2 * PD_TW && ty >= 2 && ty < 2 + 2 * PD_TH && gx < sw && gy < sh) l0[(size_t)gy * sw + gx] = v;
+    const int sxa = sx0 - 2;   // multiple of 4; tile column of source pixel gx = gx - sxa
+    if (sxa >= 0 && sxa + PD_PITCH <= sw && sy0 >= 0 && sy0 + THS <= sh && !(sw & 3) && !(((size_t)src | (size_t)l0) & 3)) {
+        // interior tile: aligned 4-byte loads (and 4-byte stores of the level-0 copy)
+        const uint32_t *s32 = (const uint32_t *)(src + (size_t)sy0 * sw + sxa);
+        const int sw4 = sw >> 2;
+        for (int q = threadIdx.x; q < THS * (PD_PITCH / 4); q += 256) {
+            const int ty = q / (PD_PITCH / 4), c4 = q - ty * (PD_PITCH / 4);
+            ((uint32_t *)&tile[ty][0])[c4] = s32[(size_t)ty * sw4 + c4];
+        }
+        __syncthreads();
+        if (l0) {   // the tile owns source pixels [2 ox, 2 ox + 128) x [2 oy, 2 oy + 32): tile columns 4 .., rows 2 ..
+            uint32_t *d32 = (uint32_t *)(l0 + (size_t)(2 * oy) * sw + 2 * ox);
+            for (int q = threadIdx.x; q < 2 * PD_TH * (2 * PD_TW / 4); q += 256) {
+                const int ty = q / (2 * PD_TW / 4), c4 = q - ty * (2 * PD_TW / 4);
+                d32[(size_t)ty * sw4 + c4] = ((const uint32_t *)&tile[ty + 2][4])[c4];
+            }
+        }
+    } else {
+        for (int q = threadIdx.x; q < TWS * THS; q += 256) {
+            int ty = q / TWS, tx = q - ty * TWS;
+            int gx = sx0 + tx, gy = sy0 + ty;
+            // pixels further than one reflection outside the image feed no valid output: clamp only keeps the address legal
+            int ry = min(max(reflect101(gy, sh), 0), sh - 1), rx = min(max(reflect101(gx, sw), 0), sw - 1);
+            uint8_t v = src[(size_t)ry * sw + rx];
+            tile[ty][tx + 2] = v;
+            if (l0 && tx >= 2 && tx < 2 + 2 * PD_TW && ty >= 2 && ty < 2 + 2 * PD_TH && gx < sw && gy < sh) l0[(size_t)gy * sw + gx] = v;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     for (int q = threadIdx.x; q < THS * PD_TW; q += 256) {
         int ty = q / PD_TW, x = q - ty * PD_TW;
-        const uint8_t *r = &tile[ty][2 * x];
+        const uint8_t *r = &tile[ty][2 * x + 2];
         hrow[ty][x] = r[0] + 4 * r[1] + 6 * r[2] + 4 * r[3] + r[4];
     }
     __syncthreads();
@@ -360,7 +466,7 @@ typedef const __attribute__((address_space(1))) uint32_t *gmem_u32;
 // loads with BORDER_REFLECT_101 (`clamp` = the clamped variant).  Same bytes either way.
 template <int ROWS, int NDW, bool CLAMP>
 __device__ __forceinline__ void lk_stage(gmem_u8 img, int w, int h, int x0a, int y0, uint8_t *dst, int lane) {
-    if (x0a >= 0 && x0a + 4 * NDW <= w && y0 >= 0 && y0 + ROWS <= h && !(w & 3)) {
+    if (x0a >= 0 && x0a + 4 * NDW <= w && y0 >= 0 && y0 + ROWS <= h && !(w & 3) && !((size_t)img & 3)) {
         int row = lane / NDW, col = lane - row * NDW;
         const gmem_u32 src = (gmem_u32)(img + (unsigned)(y0 * w + x0a));
         const int w4 = w >> 2;
@@ -384,7 +490,8 @@ __device__ __forceinline__ void lk_stage(gmem_u8 img, int w, int h, int x0a, int
     }
 }
 __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, float2 &nextPtIO, uint8_t &statusOut,
-                             uint8_t *win /*LK_WIN_BYTES, 4-aligned*/, short2 *der /*22*22*/, uint8_t *jw /*LK_JW_BYTES, 4-aligned*/) {
+                             uint8_t *win /*LK_WIN_BYTES, 4-aligned*/, short2 *der /*22*22*/, uint8_t *jw /*LK_JW_BYTES, 4-aligned*/,
+                             float *stats = nullptr /*debug: [0] iterations, [1] levels, [2] ticks before the iterations, [3] ticks in them*/) {
     const int WIN = VIO_WIN;
     const int W_BITS = 14;
     const float FLT_SCALE = 1.f / (1 << 20);
@@ -427,26 +534,38 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
             reg_ok = !(inx < -WIN || inx >= w || iny < -WIN || iny >= h);
         }
         const int wx0a = (ipx - 1) & ~3, wxo = (ipx - 1) - wx0a;   // aligned first column of the template block, lead-in bytes
+        long long lt0 = stats ? (long long)wall_clock64() : 0;
         __syncthreads();
         lk_stage<24, LK_WP / 4, false>(I, w, h, wx0a, ipy - 1, win, lane);
         if (reg_ok) lk_stage<LK_REG, LK_RP / 4, true>(J, w, h, rx0 & ~3, ry0, jw, lane);
         __syncthreads();
-        {
-            int dy = lane / 22, dx = lane - dy * 22;
-#pragma unroll 2
-            for (int q = lane; q < 22 * 22; q += 64, dx += 20, dy += 2) {
-                if (dx >= 22) { dx -= 22; dy++; }
-                int gx = ipx + dx, gy = ipy + dy;
+        if (stats && lane == 0) stats[4] += (float)((long long)wall_clock64() - lt0);
+        if (lane < 44) {
+            // Scharr derivatives of the 22 x 22 block, separably: lane -> (row lane / 2, 11 columns).  Per window column c of the three
+            // rows: s[c] = 3 a + 10 b + 3 c (vertical smoothing), v[c] = c - a (vertical difference); then
+            // Ix[x] = s[x + 2] - s[x], Iy[x] = 3 v[x] + 10 v[x + 1] + 3 v[x + 2] -- the same integers as the 3 x 3 stencil
+            const int dy = lane >> 1, x0 = 11 * (lane & 1);
+            const uint8_t *r0 = win + dy * LK_WP + wxo + x0, *r1 = r0 + LK_WP, *r2 = r1 + LK_WP;
+            const int gy = ipy + dy;
+            const bool yin = gy >= 0 && gy < h;
+            int s0 = 3 * r0[0] + 10 * r1[0] + 3 * r2[0], v0 = r2[0] - r0[0];
+            int s1 = 3 * r0[1] + 10 * r1[1] + 3 * r2[1], v1 = r2[1] - r0[1];
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const int a_ = r0[k + 2], c_ = r2[k + 2];
+                const int s2 = 3 * a_ + 10 * r1[k + 2] + 3 * c_, v2 = c_ - a_;
+                const int gx = ipx + x0 + k;
                 short2 d = make_short2(0, 0);
-                if (gx >= 0 && gy >= 0 && gx < w && gy < h) {  // derivative buffer has a constant-0 border
-                    const uint8_t *r0 = win + dy * LK_WP + wxo + dx, *r1 = r0 + LK_WP, *r2 = r1 + LK_WP;
-                    d.x = (short)(3 * (r0[2] - r0[0]) + 10 * (r1[2] - r1[0]) + 3 * (r2[2] - r2[0]));
-                    d.y = (short)(3 * (r2[0] - r0[0]) + 10 * (r2[1] - r0[1]) + 3 * (r2[2] - r0[2]));
+                if (yin && gx >= 0 && gx < w) {   // derivative buffer has a constant-0 border
+                    d.x = (short)(s2 - s0);
+                    d.y = (short)(3 * v0 + 10 * v1 + 3 * v2);
                 }
-                der[q] = d;
+                der[dy * 22 + x0 + k] = d;
+                s0 = s1; s1 = s2; v0 = v1; v1 = v2;
             }
         }
         __syncthreads();
+        if (stats && lane == 0) stats[5] += (float)((long long)wall_clock64() - lt0);
         // per-lane partial sums stay in 32 bits: |ix|, |iy| <= 4080 (convex blends of Scharr sums), 7 products per lane
         int pA11 = 0, pA12 = 0, pA22 = 0;
         if (act) {
@@ -479,7 +598,9 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
         }
         D = 1.f / D;
         float2 prevDelta = make_float2(0.f, 0.f);
+        if (stats && lane == 0) { long long n_ = (long long)wall_clock64(); stats[2] += (float)(n_ - lt0); stats[1] += 1.f; lt0 = n_; }
         for (int j = 0; j < 30; j++) {
+            if (stats && lane == 0) stats[0] += 1.f;
             int inx = cv_floor(nextPt.x), iny = cv_floor(nextPt.y);
             if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) {
                 if (level == 0) status = 0;
@@ -525,13 +646,17 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
             }
             prevDelta = delta;
         }
+        if (stats && lane == 0) stats[3] += (float)((long long)wall_clock64() - lt0);
     }
     nextPtIO = nextPts;
     statusOut = status;
 }
 
 // grid (NP, S), 64 threads
-__global__ __launch_bounds__(64) void fe_lk_kernel(Batch B) {
+#ifndef LK_WAVES
+#define LK_WAVES 4
+#endif
+__global__ __launch_bounds__(64, LK_WAVES) void fe_lk_kernel(Batch B) {
     const DevCfg &C = *B.cfg;
     int s = blockIdx.y + B.s0;
     FeSeq &fe = B.fe[s];
@@ -562,7 +687,7 @@ __global__ __launch_bounds__(64) void fe_lk_kernel(Batch B) {
     for (int i = blockIdx.x; i < fe.n_pts; i += gridDim.x) {
         float2 np = B.forw_pts[(size_t)s * C.NP + i];
         uint8_t st;
-        lk_one_point(im, C.c.lk_max_level, B.cur_pts[(size_t)s * C.NP + i], np, st, win, der, jw);
+        lk_one_point(im, C.c.lk_max_level, B.cur_pts[(size_t)s * C.NP + i], np, st, win, der, jw, (s == 0 && blockIdx.x == 0) ? B.timings + 92 : nullptr);
         if (threadIdx.x == 0) {
             B.forw_pts[(size_t)s * C.NP + i] = np;
             B.lk_status[(size_t)s * C.NP + i] = st;
@@ -1122,14 +1247,15 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t *p, int stride) {
     const int thr = 10;
     int v = p[0];
     int d[25];
-    d[0] = v - p[3 * stride];       d[1] = v - p[3 * stride + 1];   d[2] = v - p[2 * stride + 2];   d[3] = v - p[stride + 3];
-    d[4] = v - p[3];                d[5] = v - p[-stride + 3];      d[6] = v - p[-2 * stride + 2];  d[7] = v - p[-3 * stride + 1];
-    d[8] = v - p[-3 * stride];      d[9] = v - p[-3 * stride - 1];  d[10] = v - p[-2 * stride - 2]; d[11] = v - p[-stride - 3];
-    d[12] = v - p[-3];              d[13] = v - p[stride - 3];      d[14] = v - p[2 * stride - 2];  d[15] = v - p[3 * stride - 1];
-    // quick reject: any 9-arc contains at least two of the four compass pixels
+    // quick reject first, on the four compass pixels alone: any 9-arc contains at least two of them
+    d[0] = v - p[3 * stride]; d[4] = v - p[3]; d[8] = v - p[-3 * stride]; d[12] = v - p[-3];
     int nb = (d[0] < -thr) + (d[4] < -thr) + (d[8] < -thr) + (d[12] < -thr);
     int nd = (d[0] > thr) + (d[4] > thr) + (d[8] > thr) + (d[12] > thr);
     if (nb < 2 && nd < 2) return 0;
+                                    d[1] = v - p[3 * stride + 1];   d[2] = v - p[2 * stride + 2];   d[3] = v - p[stride + 3];
+                                    d[5] = v - p[-stride + 3];      d[6] = v - p[-2 * stride + 2];  d[7] = v - p[-3 * stride + 1];
+                                    d[9] = v - p[-3 * stride - 1];  d[10] = v - p[-2 * stride - 2]; d[11] = v - p[-stride - 3];
+                                    d[13] = v - p[stride - 3];      d[14] = v - p[2 * stride - 2];  d[15] = v - p[3 * stride - 1];
 #pragma unroll
     for (int k = 16; k < 25; k++) d[k] = d[k - 16];
     int best = 0;
@@ -1143,54 +1269,69 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t *p, int stride) {
     return best > thr ? best - 1 : 0;
 }
 
-__device__ int fast_cell(const uint8_t *img, int W, GridRect r, uint8_t *tile, uint8_t *score, int *rowoff, uint32_t *out, int cap) {
-    const int t = threadIdx.x;
+// FAST-9/16 + 3x3 non-maximum suppression on the ROI r of img, survivors to out[] in row-major order (cv::FAST's order).
+// LDS (fast_lds_bytes): the ROI staged from 4-byte aligned columns (pitch tp), the score plane (pitch rw), one 64-bit word of NMS
+// results per 64 interior pixels.  The ordered emission needs no serial pass: the interior pixels, in row-major order, are dealt to
+// the four wavefronts in contiguous quarters; a wavefront writes the ballot word of each of its 64-pixel chunks and counts its
+// survivors, and after one barrier re-walks its words with the running offset of the quarters before it.
+__device__ int fast_cell(const uint8_t *img, int W, GridRect r, uint8_t *smem, uint32_t *out, int cap) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int rw = r.w, rh = r.h;
-    for (int q = t; q < rw * rh; q += blockDim.x) {
-        int y = q / rw, x = q - y * rw;
-        tile[q] = img[(size_t)(r.y + y) * W + r.x + x];
-        score[q] = 0;
-    }
-    __syncthreads();
-    for (int q = t; q < (rw - 6) * (rh - 6); q += blockDim.x) {
-        int y = q / (rw - 6) + 3, x = q % (rw - 6) + 3;
-        score[y * rw + x] = (uint8_t)fast_score_lds(tile + y * rw + x, rw);
-    }
-    __syncthreads();
-    // NMS + row-major ordered emission: count per row, prefix, emit
-    for (int y = t; y < rh; y += blockDim.x) {
-        int cntr = 0;
-        if (y >= 3 && y < rh - 3)
-            for (int x = 3; x < rw - 3; x++) {
-                const uint8_t *cpt = score + y * rw + x;
-                int sc = cpt[0];
-                if (sc && sc > cpt[-1] && sc > cpt[1] && sc > cpt[-rw - 1] && sc > cpt[-rw] && sc > cpt[-rw + 1] && sc > cpt[rw - 1] &&
-                    sc > cpt[rw] && sc > cpt[rw + 1])
-                    cntr++;
-            }
-        rowoff[y] = cntr;
-    }
-    __syncthreads();
-    if (t == 0) {
-        int acc = 0;
-        for (int y = 0; y < rh; y++) { int v = rowoff[y]; rowoff[y] = acc; acc += v; }
-        rowoff[rh] = acc;
-    }
-    __syncthreads();
-    for (int y = t; y < rh; y += blockDim.x) {
-        if (y < 3 || y >= rh - 3) continue;
-        int o = rowoff[y];
-        for (int x = 3; x < rw - 3; x++) {
-            const uint8_t *cpt = score + y * rw + x;
-            int sc = cpt[0];
-            if (sc && sc > cpt[-1] && sc > cpt[1] && sc > cpt[-rw - 1] && sc > cpt[-rw] && sc > cpt[-rw + 1] && sc > cpt[rw - 1] &&
-                sc > cpt[rw] && sc > cpt[rw + 1]) {
-                if (o < cap) out[o] = (uint32_t)x | ((uint32_t)y << 12) | ((uint32_t)sc << 24);
-                o++;
-            }
+    const int xa = r.x & ~3, xo = r.x - xa, tp = (xo + rw + 3) & ~3;   // aligned first column, lead-in, tile pitch
+    uint8_t *tile = smem, *score = tile + ((tp * rh + 15) & ~15);
+    unsigned long long *words = (unsigned long long *)(score + ((rw * rh + 15) & ~15));
+    __shared__ int wtot[4];
+    if (!(W & 3) && !((size_t)img & 3)) {
+        const uint32_t *s32 = (const uint32_t *)(img + (size_t)r.y * W + xa);
+        const int W4 = W >> 2, tp4 = tp >> 2;
+        for (int q = t; q < tp4 * rh; q += blockDim.x) {
+            const int y = q / tp4, c4 = q - y * tp4;
+            ((uint32_t *)tile)[q] = s32[(size_t)y * W4 + c4];
+        }
+    } else {
+        for (int q = t; q < rw * rh; q += blockDim.x) {
+            int y = q / rw, x = q - y * rw;
+            tile[y * tp + xo + x] = img[(size_t)(r.y + y) * W + r.x + x];
         }
     }
-    int total = rowoff[rh];
+    for (int q = t; q < ((rw * rh + 3) >> 2); q += blockDim.x) ((uint32_t *)score)[q] = 0;
+    __syncthreads();
+    const int iw = rw - 6, ih = rh - 6, npx = iw * ih;
+    for (int q = t; q < npx; q += blockDim.x) {
+        int y = q / iw, x = q - y * iw;
+        score[(y + 3) * rw + x + 3] = (uint8_t)fast_score_lds(tile + (y + 3) * tp + xo + x + 3, tp);
+    }
+    __syncthreads();
+    const int nchunk = (npx + 63) >> 6, cpw = (nchunk + 3) >> 2;   // 64-pixel chunks, chunks per wavefront
+    int mine = 0;
+    for (int ch = wv * cpw; ch < min(nchunk, (wv + 1) * cpw); ch++) {
+        const int q = ch * 64 + lane;
+        bool mx = false;
+        if (q < npx) {
+            const int y = q / iw, x = q - y * iw;
+            const uint8_t *cpt = score + (y + 3) * rw + x + 3;
+            const int sc = cpt[0];
+            mx = sc && sc > cpt[-1] && sc > cpt[1] && sc > cpt[-rw - 1] && sc > cpt[-rw] && sc > cpt[-rw + 1] && sc > cpt[rw - 1] &&
+                 sc > cpt[rw] && sc > cpt[rw + 1];
+        }
+        const unsigned long long bal = __ballot(mx);
+        if (lane == 0) words[ch] = bal;
+        mine += __popcll(bal);
+    }
+    if (lane == 0) wtot[wv] = mine;
+    __syncthreads();
+    int o = 0;
+    for (int k = 0; k < wv; k++) o += wtot[k];
+    const int total = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    for (int ch = wv * cpw; ch < min(nchunk, (wv + 1) * cpw); ch++) {
+        const unsigned long long bal = words[ch];
+        if ((bal >> lane) & 1ULL) {
+            const int q = ch * 64 + lane, y = q / iw, x = q - y * iw;
+            const int pos = o + __popcll(bal & ((1ULL << lane) - 1ULL));
+            if (pos < cap) out[pos] = (uint32_t)(x + 3) | ((uint32_t)(y + 3) << 12) | ((uint32_t)score[(y + 3) * rw + x + 3] << 24);
+        }
+        o += __popcll(bal);
+    }
     __syncthreads();
     return total;
 }
@@ -1203,12 +1344,10 @@ __global__ __launch_bounds__(256) void fe_fast_kernel(Batch B) {
     if (fe.n_forw < 0 || !fe.pub_req || fe.cell_ncand[cell] < 0) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     GridRect r = C.rect[cell];
-    uint8_t *tile = smem, *score = tile + ((r.w * r.h + 15) & ~15);
-    int *rowoff = (int *)(score + ((r.w * r.h + 15) & ~15));
     int forw = fe.has_img ? (fe.cur_buf ^ 1) : fe.cur_buf;
     const uint8_t *img = B.img + ((size_t)s * 2 + forw) * (size_t)C.c.width * C.c.height;
     uint32_t *out = B.cand + ((size_t)s * C.ncells + cell) * VIO_FAST_CAP;
-    int total = fast_cell(img, C.c.width, r, tile, score, rowoff, out, VIO_FAST_CAP);
+    int total = fast_cell(img, C.c.width, r, smem, out, VIO_FAST_CAP);
     if (threadIdx.x == 0) {
         if (total > VIO_FAST_CAP) { total = VIO_FAST_CAP; fe.overflow |= 4; }
         fe.cell_ncand[cell] = total;
@@ -1217,9 +1356,7 @@ __global__ __launch_bounds__(256) void fe_fast_kernel(Batch B) {
 
 __global__ __launch_bounds__(256) void fe_fast_stage_kernel(const uint8_t *img, int W, GridRect r, uint32_t *out, int cap, int *count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint8_t *tile = smem, *score = tile + ((r.w * r.h + 15) & ~15);
-    int *rowoff = (int *)(score + ((r.w * r.h + 15) & ~15));
-    int total = fast_cell(img, W, r, tile, score, rowoff, out, cap);
+    int total = fast_cell(img, W, r, smem, out, cap);
     if (threadIdx.x == 0) *count = total;
 }
 

@@ -4,6 +4,10 @@
 #include "vio_state.h"
 #include "../../include/vio_synth.h"
 
+// dynamic LDS of fast_cell (fe_kernels.hip) for a rw x rh region: tile (pitch up to rw + 6) + score plane + NMS ballot words
+static inline size_t fast_lds_bytes(int rw, int rh) {
+    return (size_t)(((rw + 6) * rh + 15) & ~15) + (size_t)((rw * rh + 15) & ~15) + (size_t)(((rw - 6) * (rh - 6) + 63) / 64 + 2) * 8 + 16;
+}
 struct LkImages {
     const uint8_t *prev[4];
     const uint8_t *next[4];

@@ -130,6 +130,7 @@ struct vio_batch {
     // per-kernel event pool (vio_profile_begin / vio_profile_end)
     std::vector<hipEvent_t> pev;
     int prof_steps = 0, prof_cur = -1;
+    bool prof_fe_only = false;        // the profiled steps were vio_track calls: only the front-end events exist
 };
 #define VIO_NK 10  // kernels per vio_feed: fe_begin pyrdown predict lk select fast add | be_ingest solve marg(+finish)
 #define VIO_NEV 12 // events per step: 0..7 bracket the front-end kernels on fe_stream, 8..11 the back-end kernels on stream
@@ -868,11 +869,8 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     if (rc == VIO_OK) {
         h->lds_select = (size_t)C.NP * 104 + 260 * 4 + 64;
         h->lds_add = (size_t)C.NP * 16 + (size_t)4 * 192 * 8 /* FE_NEAR_CAP */ + 3 * VIO_FAST_CAP * 4 + 260 * 4 + 64 * 4 + (size_t)C.NP * 12 + 64;
-        int amax = 0;
-        for (int k = 0; k < C.ncells; k++) amax = std::max(amax, ((C.rect[k].w * C.rect[k].h + 15) & ~15));
-        int hmax = 0;
-        for (int k = 0; k < C.ncells; k++) hmax = std::max(hmax, C.rect[k].h);
-        h->lds_fast = (size_t)2 * amax + (size_t)(hmax + 2) * 4 + 16;
+        h->lds_fast = 0;
+        for (int k = 0; k < C.ncells; k++) h->lds_fast = std::max(h->lds_fast, fast_lds_bytes(C.rect[k].w, C.rect[k].h));
         {
             size_t npairs = (size_t)(C.W + 1) * C.W / 2;
             size_t workd = std::max((size_t)C.W * 450, npairs * 210 <= 12288 ? npairs * 210 : (size_t)0);
@@ -1177,6 +1175,7 @@ static int track_impl(vio_batch *h, const uint8_t *gray, const double *stamps, i
         if (!on_device && (rc = note_stage_read(g.ev_rd_gray[0], g.have_rd_gray[0], g.fe_stream)) != VIO_OK) return rc;
         if ((rc = be_wait(g)) != VIO_OK) return rc;
     }
+    if (h->prof_cur >= 0) { h->prof_cur++; h->prof_fe_only = true; }
     return VIO_OK;
 }
 
@@ -1629,6 +1628,7 @@ int vio_profile_begin(vio_batch *h, int max_steps) {
     }
     h->prof_steps = max_steps;
     h->prof_cur = 0;
+    h->prof_fe_only = false;
     return VIO_OK;
 }
 // out_ms[k] = average duration of kernel k over the recorded steps (ms); returns the number of recorded steps
@@ -1639,7 +1639,7 @@ int vio_profile_end(vio_batch *h, int cap, double *out_ms) {
     static const int e0[VIO_NK] = {0, 1, 2, 3, 4, 5, 6, 8, 9, 10}, e1[VIO_NK] = {1, 2, 3, 4, 5, 6, 7, 9, 10, 11};
     for (int k = 0; k < VIO_NK; k++) out_ms[k] = 0;
     for (int i = 0; i < n; i++)
-        for (int k = 0; k < VIO_NK; k++) {
+        for (int k = 0; k < (h->prof_fe_only ? 7 : VIO_NK); k++) {
             float ms = 0;
             HIPCHK(hipEventElapsedTime(&ms, h->pev[(size_t)i * VIO_NEV + e0[k]], h->pev[(size_t)i * VIO_NEV + e1[k]]));
             out_ms[k] += ms;
@@ -1674,8 +1674,8 @@ int vio_stage_fast_roi(const uint8_t *img, int W, int H, int rx, int ry, int rw,
     int *dcnt = nullptr;
     std::vector<uint32_t> hv;
     GridRect r{rx, ry, rw, rh};
-    size_t lds = (size_t)2 * ((rw * rh + 15) & ~15) + (size_t)(rh + 2) * 4 + 16;
     if (rw < 7 || rh < 7) return 0;
+    size_t lds = fast_lds_bytes(rw, rh);
     STAGE_CHK(hipMalloc((void **)&di, (size_t)W * H));
     STAGE_CHK(hipMalloc((void **)&dout, (size_t)cap * 4));
     STAGE_CHK(hipMalloc((void **)&dcnt, 4));
