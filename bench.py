@@ -128,6 +128,29 @@ def _cpu_worker(job):
     return tcpu, nfr
 
 
+def physical_cores():
+    """distinct (package, core) pairs of the hardware threads this process may run on (Linux sysfs); None when not readable"""
+    try:
+        seen = set()
+        for cpu in os.sched_getaffinity(0):
+            base = "/sys/devices/system/cpu/cpu%d/topology/" % cpu
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+        return len(seen)
+    except OSError:
+        return None
+
+
+def device_identity(torch, index):
+    """something that tells two physical devices apart: uuid when the runtime exposes it, PCI bus id otherwise"""
+    pr = torch.cuda.get_device_properties(index)
+    ident = dict(index=int(index), name=pr.name)
+    for k in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id"):
+        v = getattr(pr, k, None)
+        if v is not None:
+            ident[k] = str(v)
+    return ident
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -334,6 +357,19 @@ def main():
     job = [shard.job_totals(S * K, el, sq_err, len(ates), device=dev if backend == "nccl" else None) for el in elapsed_rep]
     rates = [tf / el for (tf, el, _, _) in job]               # frames of ALL ranks / MAX-over-ranks time, per repeat
     order = int(np.argsort(rates)[len(rates) // 2])
+    # per-rank table (N > 1): who ran where and how fast -- a slow or a duplicated device shows up in the record
+    mine = dict(rank=rank, device=device_identity(torch, local_rank), host=socket.gethostname(), first_sequence=int(seq0), sequences=S,
+                frames_per_s=float(S * K / elapsed_rep[order]), ms_per_step=float(elapsed_rep[order] / K * 1e3),
+                ate_rms_m=(float(np.sqrt(sq_err / len(ates))) if ates else None), valid=bool(all_processed))
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        ids = [json.dumps({k: v for k, v in r["device"].items() if k != "index"} if any(k in r["device"] for k in ("uuid", "pci_bus_id")) else r["device"],
+                          sort_keys=True) + r["host"] for r in per_rank]
+        if len(set(ids)) != world and os.environ.get("VIO_BENCH_DEVICE") is None:
+            raise SystemExit("bench.py --gpus %d: ranks share a device: %s" % (world, ids))
+    all_valid = all(r["valid"] for r in per_rank)
     total_frames, elapsed, sq_err_all, n_ate_all = job[order]
     worst = int(np.argmax(ates)) if ates else -1
     nres = float(np.mean([st.n_residuals for st in stats]))
@@ -350,7 +386,7 @@ def main():
     be_ms = sum(v for k, v in kms.items() if k.startswith("be_"))
     fe_ms = sum(v for k, v in kms.items() if k.startswith("fe_"))
     tj = None
-    for name in ("round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+    for name in ("round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):  # written by profiles/collect.sh from separate rocprofv3 --pmc passes over this same command
             tj = (name, json.load(open(tpath)))
@@ -454,14 +490,31 @@ def main():
         c0 = time.perf_counter()
         with mp.get_context("spawn").Pool(nproc) as pool:
             res = pool.map(_cpu_worker, [(seq0 + 1000 + i, 36) for i in range(nproc)])
-        cpu_all = dict(value=float(sum(n / t for t, n in res if t > 0)), unit="frames/s", cores=nproc, kind="port",
-                       sample="%d oracle processes (one per host core), one sequence of 36 frames each; sum of the per-process steady-state "
-                              "rates (the reference's own effective threading is one back-end thread per estimator)" % nproc,
+        cpu_all = dict(value=float(sum(n / t for t, n in res if t > 0)), unit="frames/s", cores=nproc, cores_are="hardware threads (SMT siblings included)",
+                       physical_cores=physical_cores(), kind="port",
+                       sample="%d oracle processes (one per hardware thread this process may run on), one sequence of 36 frames each; sum of the "
+                              "per-process steady-state rates (the reference's own effective threading is one back-end thread per estimator)" % nproc,
                        wall_seconds=time.perf_counter() - c0)
         cpu = dict(cpu_all)
         cpu["one_core"] = cpu1
 
-    out = {
+    def r3(x):
+        return None if x is None else float("%.4g" % x)
+
+    roof_c = {k: roof.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    roof_c = {k: (r3(v) if isinstance(v, float) else v) for k, v in roof_c.items()}
+    roof_c["kernel"] = "ps_* (phased dogleg solver, %d sequences per launch chain)" % S_launch if dom == "be_solve" and phased else roof.get("kernel")
+    roof_c["ms"] = r3(roof.get("ms"))
+    cpu_c = None
+    if cpu:
+        cpu_c = {k: cpu.get(k) for k in ("value", "unit", "cores", "cores_are", "physical_cores", "kind") if k in cpu}
+        cpu_c["value"] = r3(cpu_c.get("value"))
+        cpu_c["sample"] = ("one sequence of 36 frames per hardware thread, sum of steady-state rates" if cpu_all else
+                           "%d sequences of the bench workload on one core" % min(args.cpu_seqs, S))
+        if cpu_all and cpu1:
+            cpu_c["one_core_value"] = r3(cpu1["value"])
+    # ONE compact line for the driver (its record keeps the tail of stdout); everything else goes to the detail file
+    line = {
         "metric": "VIO frames/sec (640x480, 150 feats, 10-KF window)",
         "value": total_frames / elapsed,
         "unit": "frames/s",
@@ -474,6 +527,26 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
+        "valid": bool(all_valid),
+        "config": {"workload": "BASELINE configs[2]: %d independent synthetic 640x480 RGB-D + 200 Hz IMU sequences per MI355X, 150 features, "
+                               "10-keyframe window" % S, "sequences_per_gpu": S, "tracker_lag": args.tracker_lag,
+                   "parallelism": "sequences sharded per GPU, no data-path collective"},
+        "repeats": {"n": R, "frames_per_s": [round(x) for x in rates], "timed_frames_per_sequence": R * K},
+        "ate_m": {"mean": r3(float(np.mean(ates))) if ates else None, "job_rms": r3(shard.ate_from_sums(sq_err_all, n_ate_all))},
+        "solver": {"mean_iterations": r3(iters), "timed_solves": int(d_it[1]), "reboots": reboots},
+        "frontend_ms": r3(fe_ms), "backend_ms": r3(be_ms),
+        "roofline": roof_c,
+        "cpu_baseline": cpu_c,
+    }
+    if parity:
+        line["parity"] = {"sequences": parity["sequences"], "traj_rmse_hip_vs_oracle_m": r3(parity["traj_rmse_hip_vs_oracle_m"]),
+                          "ate_rel_diff": r3(parity["ate_rel_diff"])}
+    if pcie:
+        line["pcie_inclusive_frames_per_s"] = {"pageable": round(pcie["frames_per_s"]), "pinned": round(pcie["pinned"]["frames_per_s"])}
+    if world > 1:
+        line["per_rank"] = [dict(rank=r["rank"], device=r["device"].get("uuid", r["device"].get("pci_bus_id", r["device"]["index"])),
+                                 frames_per_s=round(r["frames_per_s"]), ate_rms_m=r3(r["ate_rms_m"]), valid=r["valid"]) for r in per_rank]
+    detail = {
         "config": {"workload": "BASELINE configs[2]: batch of %d independent synthetic 640x480 RGB-D + 200 Hz IMU sequences per MI355X, "
                                "150 max features, 5x6 grid, 10-keyframe window, landmarks free (fix_depth 0)" % S,
                    "sequences_per_gpu": S, "image": [Wd, H], "max_cnt": cfg.max_cnt, "window_size": cfg.window_size,
@@ -484,7 +557,8 @@ def main():
                                        "0 = it waits for the optimisation of frame f.  The oracle in `parity` runs the same ordering."},
         "repeats": {"n": R, "frames_per_s": rates, "median_index": order, "spread_rel": (max(rates) - min(rates)) / (total_frames / elapsed),
                     "timed_frames_per_sequence": R * K},
-        "valid": all_processed,
+        "valid": bool(all_valid),
+        "per_rank": per_rank,
         "ate_m": {"mean": float(np.mean(ates)) if ates else None, "max": float(np.max(ates)) if ates else None, "sequences": len(ates),
                   "median": float(np.median(ates)) if ates else None, "worst_sequence": seq0 + worst,
                   "job_rms": shard.ate_from_sums(sq_err_all, n_ate_all)},
@@ -508,12 +582,12 @@ def main():
     torch.cuda.empty_cache()
     if args.aux and rank == 0 and world == 1:
         # auxiliary data points on the same device, never `value`: the other tracker ordering at S, and larger batches
-        out["lag0"] = aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K, lag=0, seq0=seq0)
-        out["lag0"]["note"] = ("tracker lag 0: the tracker of frame f+1 waits for the optimisation of frame f (the front-end is on the critical "
-                               "path); `value` is measured with config.tracker_lag = %d" % args.tracker_lag)
+        detail["lag0"] = aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K, lag=0, seq0=seq0)
+        detail["lag0"]["note"] = ("tracker lag 0: the tracker of frame f+1 waits for the optimisation of frame f (the front-end is on the critical "
+                                  "path); `value` is measured with config.tracker_lag = %d" % args.tracker_lag)
         for s_aux in (256, 512):
             os.environ["VIO_GROUP_SEQS"] = str(s_aux // 2)
-            out["aux_s%d" % s_aux] = aux_rate(P, vio_ct, torch, cfg, sc, dev, s_aux, n_pre, Wm, K, lag=args.tracker_lag)
+            detail["aux_s%d" % s_aux] = aux_rate(P, vio_ct, torch, cfg, sc, dev, s_aux, n_pre, Wm, K, lag=args.tracker_lag)
         # BASELINE configs[4] at its per-GPU batch (64 sequences of 1280x720 / 300 features / W = 20): the phased solver with the Schur
         # complement in HBM / L2 (ps_serial_big_kernel)
         os.environ["VIO_GROUP_SEQS"] = "32"
@@ -527,10 +601,24 @@ def main():
                               frac=fl5["solve"] * 32 / (c5["kernels_ms"]["be_solve"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, sequences_per_launch=32,
                               note="SURVEY.md 8d flops with the counts of the last timed frame")
         c5["workload"] = "BASELINE configs[4]: 64 sequences of 1280x720, 300 features, 7x8 grid, 20-keyframe window per GPU"
-        out["config5"] = c5
+        detail["config5"] = c5
         os.environ["VIO_GROUP_SEQS"] = str(per_group)
+        line["aux_frames_per_s"] = {k: round(detail[k]["frames_per_s"]) for k in ("lag0", "aux_s256", "aux_s512", "config5")}
+        line["aux_valid"] = all(detail[k]["valid"] for k in ("lag0", "aux_s256", "aux_s512", "config5"))
     if rank == 0:
-        print(json.dumps(out))
+        # detail: everything the compact line summarises (per-kernel rooflines, ATE lists, PCIe / streaming legs, aux legs with their kernel
+        # times), to a side file and to stderr; the LAST line of stdout is the one JSON line of the contract
+        full = dict(line)
+        full.update(detail)
+        dpath = os.environ.get("VIO_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+        try:
+            os.makedirs(os.path.dirname(dpath), exist_ok=True)
+            json.dump(full, open(dpath, "w"))
+            line["detail_file"] = os.path.relpath(dpath, ROOT)
+        except OSError:
+            pass
+        print(json.dumps(full), file=sys.stderr)
+        print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 

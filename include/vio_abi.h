@@ -111,8 +111,9 @@ int vio_reset_tracker_seq(vio_batch *h, int seq);
  * on_device != 0: pointers are HBM addresses (no PCIe in the call); otherwise host buffers that are uploaded first.
  * stamps: S timestamps (seconds). The call is asynchronous on the batch's stream; vio_sync or any getter waits.
  * Per-sequence status codes are read back with vio_get_status. */
-/* Host buffers (on_device == 0) are uploaded by a copy stream beside the previous frame's kernels; they may be modified or freed once
- * the NEXT vio_feed / vio_feed_modes call on the handle (or any getter / vio_sync) has returned. */
+/* Host IMAGE buffers (on_device == 0) are uploaded by a copy stream beside the previous frame's kernels; they may be modified or freed once
+ * the NEXT vio_feed / vio_feed_modes call on the handle (or any getter / vio_sync) has returned.  `stamps` (and `modes`) are copied into a
+ * library-owned page-locked ring before the call returns: they are free at once, page-locked or not. */
 int vio_feed(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, int on_device);
 
 /* The two halves of vio_feed, exposed separately the way the reference exposes them to its two threads.

@@ -356,6 +356,7 @@ Estimator::~Estimator() {
 void Estimator::clearState() {  // estimator.cpp:43-116
     imu_buf.clear();
     imu_head = 0;
+    imu_at_update = 0;
     for (int i = 0; i <= MAXW; i++) {
         Rs[i] = M3::I();
         Ps[i] = Vs[i] = Bas[i] = Bgs[i] = V3();
@@ -442,7 +443,10 @@ void Estimator::latestOdometry(double out[11]) const {
             if (!(t > latest_time)) continue;
             const double dt = t - latest_time;
             latest_time = t;
-            const ImuSample &v = front ? imu_buf[imu_head] : imu_buf[k];
+            // quirk mode: the samples that were buffered when updateLatestStates ran are replayed with the FRONT sample's values
+            // (:1779-1786); the ones that arrived afterwards went through inputIMU -> predict(t, own acc, own gyr) (:1758-1764).
+            // predict() never advances acc_0 / gyr_0 either way (:1862-1880)
+            const ImuSample &v = (front && k < imu_at_update) ? imu_buf[imu_head] : imu_buf[k];
             V3 un_acc_0 = R * (a0 - Ba) - g;
             V3 un_gyr = 0.5 * (g0 + v.gyr) - Bg;
             R = R * toR(deltaQ(un_gyr * dt));
@@ -1689,6 +1693,7 @@ int Estimator::processImage(std::map<int, std::array<double, 7>> &image, const u
             for (int j = 0; j <= W; j++) pre_integrations[j]->repropagate(V3(), Bgs[j]);
             optimization();
             latest_Bg = Bgs[frame_count];  // updateLatestStates :1768-1788 (only latest_Bg feeds back into the hot path)
+            imu_at_update = imu_buf.size();
             solver_flag = 1;
             slideWindow();
             last_R = Rs[W]; last_P = Ps[W]; last_R0 = Rs[0]; last_P0 = Ps[0];
@@ -1717,6 +1722,7 @@ int Estimator::processImage(std::map<int, std::array<double, 7>> &image, const u
         removeFailures();
         last_R = Rs[W]; last_P = Ps[W]; last_R0 = Rs[0]; last_P0 = Ps[0];
         latest_Bg = Bgs[frame_count];
+        imu_at_update = imu_buf.size();
     }
     return 0;
 }

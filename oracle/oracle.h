@@ -178,6 +178,7 @@ struct Estimator {
     double prevTime = -1;
     std::vector<ImuSample> imu_buf;  // queue (front = index imu_head)
     size_t imu_head = 0;
+    size_t imu_at_update = 0;   // imu_buf.size() when updateLatestStates last ran: later samples reach predict() through inputIMU (estimator.cpp:1758-1764)
     om::V3 latest_Bg;
     om::M3 last_R, last_R0, back_R0;
     om::V3 last_P, last_P0, back_P0;

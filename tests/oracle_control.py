@@ -37,6 +37,7 @@ VARIANTS = {   # name -> (library under oracle/, tracker lag)
     "order": ("liboracle_order.so", 0),
     "lag1": ("liboracle.so", 1),
     "lag1_order": ("liboracle_order.so", 1),
+    "befma": ("liboracle_befma.so", 0),   # fused multiply-adds in the back-end only (front-end code identical to liboracle.so)
 }
 
 
@@ -143,6 +144,8 @@ def cmd_run(a):
     jobs = []
     for i in range(a.seqs):
         names = ["base", "fma", "order", "lag1", "lag1_order"] if i < a.control else ["lag1"]
+        if a.only:   # a later pass that adds variants for the control sequences into its own scratch directory (merged by assemble)
+            names = a.only.split(",")
         jobs.append((a.seq0 + i, a.frames, names, a.scratch))
     t0 = time.time()
     done = 0
@@ -156,8 +159,18 @@ def cmd_run(a):
 def cmd_assemble(a):
     import vio_ct
     have = sorted(int(f[4:9]) for f in os.listdir(a.scratch) if f.startswith("seq_") and f.endswith(".npz") and ".tmp" not in f)
-    Z = {s: np.load(os.path.join(a.scratch, "seq_%05d.npz" % s)) for s in have}
-    ctl = [s for s in have if "base_pos" in Z[s].files]
+    Z = {s: dict(np.load(os.path.join(a.scratch, "seq_%05d.npz" % s))) for s in have}
+    extra_pairs = []
+    for x in [d for d in a.extra.split(",") if d]:   # scratch directories of --only passes: their arrays join the sequence's record
+        for f in sorted(os.listdir(x)):
+            if f.startswith("seq_") and f.endswith(".npz") and ".tmp" not in f and int(f[4:9]) in Z:
+                zx = np.load(os.path.join(x, f))
+                for k in zx.files:
+                    if k not in ("gt", "gt_frames", "names"):
+                        Z[int(f[4:9])][k] = zx[k]
+    if all("befma_pos" in Z[s] for s in have if "base_pos" in Z[s]) and any("befma_pos" in Z[s] for s in have):
+        extra_pairs = [("base", "befma")]
+    ctl = [s for s in have if "base_pos" in Z[s]]
     rep = dict(what="oracle vs builds of its own sources that differ only in round-off (tests/oracle_control.py); canonical workload, "
                     "%d frames, sequences %d..%d" % (a.frames, ctl[0], ctl[-1]) if ctl else "",
                variants={k: dict(library=v[0], tracker_lag=v[1]) for k, v in VARIANTS.items()}, status_keys=list(STATUS_KEYS), pairs={})
@@ -171,7 +184,7 @@ def cmd_assemble(a):
             assert np.array_equal(fx["positions"][i][z["base_frames"]], z["base_pos"]), "base run differs from the committed fixture (seq %d)" % s
             nfx += 1
     rep["base_bit_identical_to_lag0_fixture_sequences"] = nfx
-    for na, nb in (("base", "fma"), ("base", "order"), ("fma", "order"), ("lag1", "lag1_order"), ("base", "lag1")):
+    for na, nb in [("base", "fma"), ("base", "order"), ("fma", "order"), ("lag1", "lag1_order"), ("base", "lag1")] + extra_pairs:
         rows = [pair_rows(Z[s], Z[s], na, nb, s) for s in ctl]
         rep["pairs"]["%s_vs_%s" % (na, nb)] = dict(summary=summarise(rows), rows=rows)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
@@ -179,15 +192,17 @@ def cmd_assemble(a):
     for k, v in rep["pairs"].items():
         print(k, json.dumps(v["summary"]))
     # lag-1 fixture, same layout as oracle_ate_300.npz
-    l1 = [s for s in have if "lag1_pos" in Z[s].files]
-    if l1 and l1 == list(range(l1[0], l1[0] + len(l1))):
+    l1 = [s for s in have if "lag1_pos" in Z[s]]
+    if len(l1) < a.seqs:
+        print("lag-1 fixture not written: %d of %d sequences done" % (len(l1), a.seqs))
+    elif l1 == list(range(l1[0], l1[0] + len(l1))):
         n = len(l1)
         ate = np.zeros(n); nfr = np.zeros(n, np.int32); reb = np.zeros(n, np.int32); first = np.zeros(n, np.int32)
         pos = np.zeros((min(a.keep, n), a.frames, 3))
         for i, s in enumerate(l1):
             z = Z[s]
             fr, po = z["lag1_frames"], z["lag1_pos"]
-            ate[i] = vio_ct.ate_rmse(po, z["gt"][:len(po)]) if "gt" in z.files and len(z["gt"]) == len(po) else np.nan
+            ate[i] = vio_ct.ate_rmse(po, z["gt"][:len(po)]) if "gt" in z and len(z["gt"]) == len(po) else np.nan
             nfr[i] = len(po); reb[i] = int(z["lag1_reboots"]); first[i] = fr[0]
             if i < len(pos):
                 pos[i, fr] = po
@@ -205,6 +220,8 @@ def main():
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--procs", type=int, default=6)
     ap.add_argument("--keep", type=int, default=128)
+    ap.add_argument("--only", default="", help="run: only these variants (comma separated) for every sequence of the range")
+    ap.add_argument("--extra", default="", help="assemble: scratch directories of --only passes to merge (comma separated)")
     ap.add_argument("--scratch", default=os.path.join(ROOT, "gpurun_out", "oracle_control"))
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "round4_oracle_self_divergence.json"))
     ap.add_argument("--fixture", default=os.path.join(HERE, "golden", "oracle_ate_300_lag1.npz"))

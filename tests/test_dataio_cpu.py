@@ -318,4 +318,10 @@ def test_recording_with_jittered_depth_stamps_pairs_like_the_nodelet(tmp_path):
     for q, k in enumerate(expect):
         t, gray, depth = rec.frame(q)
         assert abs(t - stamps[k]) < 1e-9 and gray[0, 0] == k and depth[0, 0] == 1000 + k
+    assert (rec.thrown_color, rec.thrown_depth) == (3, 3)
     assert len(io.RgbdImuDirectory(str(tmp_path / "r"), pairing="nearest")) == n
+    assert len(io.RgbdImuDirectory(str(tmp_path / "r"), 0.05, pairing="nearest")) == n      # max_dt is the second positional argument, as before
+    # a recording the +-3 ms rule mostly rejects says so instead of silently replaying a handful of frames
+    io.write_recording(str(tmp_path / "u"), stamps, g, d, imu_t, np.zeros((300, 3)), np.zeros((300, 3)), depth_stamps=stamps + 0.01)
+    with pytest.warns(RuntimeWarning, match="not hardware-synchronised"):
+        assert len(io.RgbdImuDirectory(str(tmp_path / "u"))) == 0

@@ -358,7 +358,7 @@ def test_latest_odometry_at_imu_rate(P):
 def test_latest_odometry_with_the_reference_replay_quirk(P):
     """vio_config.reference_quirks bit 0: Estimator::updateLatestStates as written (estimator.cpp:1779-1786) -- the replay loop walks the
     buffered stamps but passes predict() the values of the queue's FRONT sample every time, and predict() (:1862-1880) never advances
-    acc_0 / gyr_0.  HIP against the oracle with the switch on, and both against an independent numpy replay from the window state; the
+    acc_0 / gyr_0; samples that arrive after processImage go through inputIMU -> predict with their own values (:1758-1764).  HIP against the oracle with the switch on, and both against an independent numpy replay from the window state; the
     result must differ from the default (every sample with its own values) -- the switch changes the output and nothing else."""
     cfg_q = P.canonical_config(reference_quirks=1)
     cfg_0 = P.canonical_config()
@@ -398,15 +398,22 @@ def test_latest_odometry_with_the_reference_replay_quirk(P):
     # acc_0 / gyr_0 as processIMU left them: the last sample consumed for the newest frame (the first with t >= t0)
     a0, g0 = ai[front], gi[front]
     lt = t0
+    n_front = 0
     for i in newer:
         dt = ti[i] - lt; lt = ti[i]
+        # samples that were buffered when the last frame was processed (the first k) are replayed by updateLatestStates with the FRONT
+        # sample's values (:1779-1786); the 12 that arrived afterwards went through inputIMU -> predict(t, own acc, own gyr) (:1758-1764);
+        # acc_0 / gyr_0 never advance in predict() (:1862-1880)
+        src = front if i < k else i
+        n_front += i < k
         un_acc_0 = R @ (a0 - Ba) - gvec
-        th = (0.5 * (g0 + gi[front]) - Bg) * dt
+        th = (0.5 * (g0 + gi[src]) - Bg) * dt
         dq = np.array([1.0, th[0] / 2, th[1] / 2, th[2] / 2])     # Utility::deltaQ, not normalised (utility.h:11-24)
         R = R @ q2R(dq)                                           # Eigen's toRotationMatrix formula, no normalisation (as both implementations)
-        un_acc = 0.5 * (un_acc_0 + R @ (ai[front] - Ba) - gvec)
+        un_acc = 0.5 * (un_acc_0 + R @ (ai[src] - Ba) - gvec)
         Pp = Pp + dt * V + 0.5 * dt * dt * un_acc
         V = V + dt * un_acc
+    assert n_front >= 1 and len(newer) - n_front == 12
     assert abs(lq[0] - lt) < 1e-12 and np.abs(lq[1:4] - Pp).max() < 1e-6 and np.abs(lq[8:11] - V).max() < 1e-6, (lq[1:4] - Pp, lq[8:11] - V)
 
 

@@ -89,7 +89,7 @@ namespace {
 // ------------------------------------------------------------------ IntegrationBase::propagate, block-cooperative
 // LDS workspace: sJ sP sFJ sFP (225 each) sF (225) sV (270)
 struct PreWork { double J[225], Pm[225], FJ[225], FP[225], F[225], V[270]; };
-#define PI_CH 8   // samples per chunk of the pipelined propagation in be_ingest (F / V of a chunk live in LDS: 8 x 495 doubles)
+// PI_CH (kernels.h): samples per chunk of the pipelined propagation in be_ingest (F / V of a chunk live in LDS: 8 x 495 doubles)
 __device__ __forceinline__ void preint_load(const PreInt &p, PreWork &w) {
     for (int i = threadIdx.x; i < 225; i += blockDim.x) { w.J[i] = p.jac[i]; w.Pm[i] = p.cov[i]; }
     __syncthreads();
@@ -168,7 +168,7 @@ __device__ void preint_propagate(PreInt &p, PreWork &w, const vio_config &c, dou
 // with the serial part of a step shrunk from the whole midpoint step to the recursion.  append: the samples are also filed into p's
 // own buffers (IntegrationBase::push_back).  Used for the merge of MARGIN_SECOND_NEW (estimator.cpp:1651-1687), where the step-by-step
 // version was 100 of the 190 us of that branch.
-#define PREINT_MANY_LDS_DOUBLES (PI_CH * (225 + 270))   // F and V of a chunk: LDS the caller lends (the marginalisation's tile region is free by then)
+// PREINT_MANY_LDS_DOUBLES (kernels.h): F and V of a chunk, LDS the caller lends (the marginalisation's tile region is free by then)
 __device__ void preint_propagate_many(PreInt &p, PreWork &w, const vio_config &cfg, int n, const double *dt_src, const double (*acc_src)[3],
                                       const double (*gyr_src)[3], bool append, double *lds_fv) {
     const int t = threadIdx.x;
@@ -1031,7 +1031,9 @@ __device__ __forceinline__ int pair_slot(int i, int j, int W1) { return i * W1 -
 // at res + 42 (k - 1)), `row` = its Hpl row.  The arrays never overlap; the restrict qualifiers let the loads of the next
 // residual be issued ahead of the row stores of the current one (the loop is bound by the latency of those loads).
 __device__ __forceinline__ void lm_row(const double *__restrict__ res, double *__restrict__ row, double *__restrict__ Hll,
-                                       double *__restrict__ gl, int half, int st, int kend, int ext_off) {
+                                       double *__restrict__ gl, int half, int st, int kend, int ext_off, int krelo = -1) {
+    // krelo: index of the landmark's relocalisation record (rides behind the regular ones, be_phased.h) or -1.  Its pose_j group is
+    // zero by construction and it has no frame st + k of its own: no pose_j store for it (which would land on whatever columns follow)
     // residual records are 336 bytes apart and 16-byte aligned: 16-byte loads halve the number of cache-line lookups of this gather
     if (half == 0) {
         double si[6] = {0, 0, 0, 0, 0, 0};
@@ -1050,7 +1052,7 @@ __device__ __forceinline__ void lm_row(const double *__restrict__ res, double *_
 #pragma unroll
             for (int d = 0; d < 6; d++) {
                 si[d] += a[d] * l0 + e[d] * l1;
-                row[6 * (st + k) + d] = b[d] * l0 + f[d] * l1;
+                if (k != krelo) row[6 * (st + k) + d] = b[d] * l0 + f[d] * l1;
             }
         }
 #pragma unroll

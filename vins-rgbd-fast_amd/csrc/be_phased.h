@@ -531,7 +531,7 @@ __device__ __forceinline__ void ps_asm_a_body(const Batch &B) {
             const int slot = alist[ka];
             const int stf = c.lm_start[slot], r0 = c.lm_tmp[slot];
             const int kend = min(c.lm_nobs[slot] + c.lm_relo[slot], nres - r0 + 1);   // (+ the landmark's relocalisation record, if any)
-            lm_row(c.res + (size_t)r0 * 42, row, c.Hll + ka, c.gl + ka, half, stf, kend, 15 * W1);
+            lm_row(c.res + (size_t)r0 * 42, row, c.Hll + ka, c.gl + ka, half, stf, kend, 15 * W1, c.lm_relo[slot] ? c.lm_nobs[slot] : -1);
         } else if (half == 1) { c.Hll[ka] = 0; c.gl[ka] = 0; }
     }
     if (item == W1 * W1 + W) tick(35);

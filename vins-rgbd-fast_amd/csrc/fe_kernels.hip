@@ -250,6 +250,7 @@ __global__ void be_latest_odometry_kernel(Batch B, int seq, double *out11) {
     if (be.imu_count - k > C.NIMU) k = be.imu_count - C.NIMU;
     const bool front = (C.c.reference_quirks & VIO_QUIRK_LATEST_FRONT) != 0;
     const int idx_front = k % C.NIMU;
+    const int n_front = be.imu_count_ingest;
     if (be.solver_flag == 1 && C.c.use_imu)
         for (; k < be.imu_count; k++) {
             const int idx = k % C.NIMU;
@@ -257,7 +258,9 @@ __global__ void be_latest_odometry_kernel(Batch B, int seq, double *out11) {
             if (!(t > latest_time)) continue;
             const double dt = t - latest_time;
             latest_time = t;
-            const int iv = front ? idx_front : idx;
+            // quirk mode: front values only for the samples that were in the ring when the frame was taken (updateLatestStates'
+            // replay); samples pushed later went through inputIMU -> predict with their own values (estimator.cpp:1758-1764)
+            const int iv = (front && k < n_front) ? idx_front : idx;
             const dm::v3 a1 = dm::ld3(ia + (size_t)iv * 3), w1 = dm::ld3(ig + (size_t)iv * 3);
             const dm::v3 un_acc_0 = dm::sub(dm::mul(R, dm::sub(acc_0, Ba)), g);
             const dm::v3 un_gyr = dm::sub(dm::scl(0.5, dm::add(gyr_0, w1)), Bg);

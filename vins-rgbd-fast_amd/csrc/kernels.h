@@ -4,6 +4,10 @@
 #include "vio_state.h"
 #include "../../include/vio_synth.h"
 
+// pipelined pre-integration (be_kernels.hip): samples per chunk, and the LDS doubles preint_propagate_many borrows from its caller
+// (F 15x15 and V 15x18 of every sample of a chunk); the host sizes the marginalisation's dynamic LDS with the same macro
+#define PI_CH 8
+#define PREINT_MANY_LDS_DOUBLES (PI_CH * (225 + 270))
 // dynamic LDS of fast_cell (fe_kernels.hip) for a rw x rh region: tile (pitch up to rw + 6) + score plane + NMS ballot words
 static inline size_t fast_lds_bytes(int rw, int rh) {
     return (size_t)(((rw + 6) * rh + 15) & ~15) + (size_t)((rw * rh + 15) & ~15) + (size_t)(((rw - 6) * (rh - 6) + 63) / 64 + 2) * 8 + 16;

@@ -60,6 +60,13 @@ struct vio_batch {
         hipEvent_t ev_host_fe = nullptr, ev_host_be = nullptr;
         bool host_fe_pending = false, host_be_pending = false;
         bool have_solve_ev = false, have_ingest_ev = false;
+        // vio_feed: stamps / frame modes of a call bounce through a library-owned page-locked ring, so the caller's arrays are free when the
+        // call returns although the copies only run when fe_stream gets to them (tracker lag 1 holds that stream behind be_ingest)
+        static constexpr int kSideRing = 16;
+        unsigned char *side_ring = nullptr;          // [kSideRing][n * 9]: n doubles then n mode bytes
+        hipEvent_t side_ev[kSideRing] = {};
+        bool side_used[kSideRing] = {};
+        int side_pos = 0;
     };
     std::vector<Group> groups;
     int tracker_lag = 0;              // vio_set_tracker_lag
@@ -920,7 +927,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
         }
         {
             size_t nbq = ((size_t)C.NPRIOR + 15) >> 4;
-            h->lds_marg = std::max(std::max((size_t)nbq * (nbq + 1) / 2 * 2048, (size_t)2 * C.NPRIOR * 15 * 8), (size_t)8 * (225 + 270) * 8) + 64;   // (the last: F / V of a chunk of the pre-integration merge, be_kernels.hip PREINT_MANY_LDS_DOUBLES)  // lower 16x16 tiles of the new prior (Cholesky for its constant term); before that T1 and A_mr
+            h->lds_marg = std::max(std::max((size_t)nbq * (nbq + 1) / 2 * 2048, (size_t)2 * C.NPRIOR * 15 * 8), (size_t)PREINT_MANY_LDS_DOUBLES * 8) + 64;   // (the last: F / V of a chunk of the pre-integration merge)  // lower 16x16 tiles of the new prior (Cholesky for its constant term); before that T1 and A_mr
             h->lds_factor = C.NPRIOR <= 96 ? (size_t)C.NPRIOR * (C.NPRIOR | 1) * 8 + 64 : 64;  // on-demand eigen-decomposition (vio_get_prior)
             (void)raise_lds_limit((const void *)be_prior_factor_kernel, h->lds_factor);
         }
@@ -982,6 +989,7 @@ void vio_destroy(vio_batch *h) {
             if (g.ev_rd_depth[p]) (void)hipEventDestroy(g.ev_rd_depth[p]);
         }
         if (g.ev_host_fe) (void)hipEventDestroy(g.ev_host_fe);
+        if (g.side_ring) { (void)hipHostFree(g.side_ring); for (auto e : g.side_ev) if (e) (void)hipEventDestroy(e); }
         if (g.ev_host_be) (void)hipEventDestroy(g.ev_host_be);
         if (g.copy_stream) (void)hipStreamDestroy(g.copy_stream);
     }
@@ -1112,6 +1120,28 @@ static int note_host_upload(vio_batch::Group &g, bool fe, bool be) {
     return VIO_OK;
 }
 
+// vio_feed's stamps / modes through the group's page-locked ring (see Group::side_ring): a slot is reused only after its copies ran
+static int stage_side_ring(vio_batch *h, vio_batch::Group &g, const double *stamps, const uint8_t *modes) {
+    const size_t n = (size_t)g.n, slot_bytes = n * 9;
+    if (!g.side_ring) {
+        HIPCHK(hipHostMalloc((void **)&g.side_ring, slot_bytes * vio_batch::Group::kSideRing, hipHostMallocDefault));
+        for (int k = 0; k < vio_batch::Group::kSideRing; k++) HIPCHK(hipEventCreateWithFlags(&g.side_ev[k], hipEventDisableTiming));
+    }
+    const int k = g.side_pos;
+    g.side_pos = (k + 1) % vio_batch::Group::kSideRing;
+    if (g.side_used[k]) HIPCHK(hipEventSynchronize(g.side_ev[k]));   // sixteen calls ago: long done unless the caller runs that far ahead
+    unsigned char *slot = g.side_ring + (size_t)k * slot_bytes;
+    memcpy(slot, stamps + g.s0, n * sizeof(double));
+    HIPCHK(hipMemcpyAsync(h->d_stamps + g.s0, slot, n * sizeof(double), hipMemcpyHostToDevice, g.fe_stream));
+    if (modes) {
+        memcpy(slot + n * 8, modes + g.s0, n);
+        HIPCHK(hipMemcpyAsync(h->d_modes + g.s0, slot + n * 8, n, hipMemcpyHostToDevice, g.fe_stream));
+    }
+    HIPCHK(hipEventRecord(g.side_ev[k], g.fe_stream));
+    g.side_used[k] = true;
+    return VIO_OK;
+}
+
 // per-call side inputs of the front-end (frame modes, caller-supplied relative rotations): group slices, on the group's fe_stream
 static int stage_side_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *modes, const double *R_rel) {
     if (modes) HIPCHK(hipMemcpyAsync(h->d_modes + g.s0, modes + g.s0, (size_t)g.n, hipMemcpyHostToDevice, g.fe_stream));
@@ -1121,7 +1151,9 @@ static int stage_side_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *m
 
 int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, const uint8_t *modes, int on_device) {
     if (!h || !gray || !depth_mm || !stamps) return VIO_EINVAL;
-    int rc = refresh_dynamic_state(h);
+    int rc = wait_host_uploads(h);   // (pending uploads of an earlier vio_track / vio_process call; vio_feed itself leaves none, see stage_side_ring)
+    if (rc != VIO_OK) return rc;
+    rc = refresh_dynamic_state(h);
     if (rc != VIO_OK) return rc;
     rc = flush_imu_frontend(h);
     if (rc != VIO_OK) return rc;
@@ -1129,9 +1161,9 @@ int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, 
         if ((rc = fe_wait(h, g)) != VIO_OK) return rc;
         const uint8_t *dg = nullptr;
         const uint16_t *dd = nullptr;
-        rc = stage_inputs(h, g, gray, depth_mm, stamps, on_device, &dg, &dd, /*overlap=*/true);
+        rc = stage_inputs(h, g, gray, depth_mm, nullptr, on_device, &dg, &dd, /*overlap=*/true);
         if (rc != VIO_OK) return rc;
-        if ((rc = stage_side_inputs(h, g, modes, nullptr)) != VIO_OK) return rc;
+        if ((rc = stage_side_ring(h, g, stamps, modes)) != VIO_OK) return rc;
         if (g.s0 == 0) HIPCHK(hipEventRecord(h->ev[0], g.fe_stream));
         rc = launch_frontend(h, g, dg, 1, 1, modes ? h->d_modes : nullptr, nullptr);
         if (rc != VIO_OK) return rc;

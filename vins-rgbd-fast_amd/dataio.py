@@ -275,13 +275,22 @@ class RgbdImuDirectory:
     a frame's stamp is the colour stamp (:234 onwards uses time_color).  ``pairing="nearest"`` (not upstream) matches every colour
     frame with the nearest depth frame within ``max_dt`` instead -- for datasets whose streams are not hardware-synchronised."""
 
-    def __init__(self, root, pairing="nodelet", max_dt=0.02):
+    def __init__(self, root, max_dt=0.02, *, pairing="nodelet"):
+        # (max_dt keeps the position it had before the pairing rule became selectable; pairing is keyword-only)
         self.root = root
         rgb, dep = _read_assoc(os.path.join(root, "rgb.txt")), _read_assoc(os.path.join(root, "depth.txt"))
         self.pairs = []
+        self.thrown_color = self.thrown_depth = 0
         if pairing == "nodelet":
             for i, j in pair_color_depth([t for t, _ in rgb], [t for t, _ in dep]):
                 self.pairs.append((rgb[i][0], rgb[i][1], dep[j][1]))
+            self.thrown_color, self.thrown_depth = len(rgb) - len(self.pairs), len(dep) - len(self.pairs)
+            if rgb and dep and len(self.pairs) < 0.9 * min(len(rgb), len(dep)):
+                # the +-3 ms rule assumes hardware-synchronised streams (RealSense); TUM-style recordings are not
+                import warnings
+                warnings.warn("RgbdImuDirectory(%r): the nodelet's +-3 ms colour / depth pairing kept %d of %d colour and %d depth frames "
+                              "(%d / %d thrown); pass pairing='nearest' for streams that are not hardware-synchronised"
+                              % (root, len(self.pairs), len(rgb), len(dep), self.thrown_color, self.thrown_depth), RuntimeWarning, stacklevel=2)
         elif pairing == "nearest":
             dt = np.array([t for t, _ in dep])
             for t, f in rgb:
