@@ -71,7 +71,11 @@ typedef struct vio_config {
     double init_depth;              /* INIT_DEPTH = 5 (parameters.cpp:215) */
 } vio_config;
 
-enum { VIO_QUIRK_LATEST_FRONT = 1 };
+enum { VIO_QUIRK_LATEST_FRONT = 1,
+       /* TEST HOOK, not a reference behaviour: bits 8..11 = n: the first n Cholesky factorisations of EVERY solve are reported as failed
+        * (on both sides: the oracle reads the same bits), which walks the mu *= 10 retry ladder of the trust-region loop
+        * (oracle/backend.cpp solve(); be_phased.h ps_serial).  Every retry uses one iteration slot: see VIO_EXTRA_SLOTS. */
+       VIO_TEST_CHOL_FAIL_SHIFT = 8, VIO_TEST_CHOL_FAIL_MASK = 15 };
 
 typedef struct vio_batch vio_batch; /* opaque */
 

@@ -189,6 +189,15 @@ def cmd_assemble(a):
         rep["pairs"]["%s_vs_%s" % (na, nb)] = dict(summary=summarise(rows), rows=rows)
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(rep, open(a.out, "w"), indent=1)
+    # per-frame decisions + positions of the oracle for the control sequences, both tracker orderings: what tools/flip_census.py compares
+    # the HIP path with on the GPU box (gpurun_out/ does not travel)
+    if ctl:
+        dec = np.zeros((2, len(ctl), a.frames, len(STATUS_KEYS)), np.int16)   # [tracker lag][sequence][frame][STATUS_KEYS]
+        for i, s_ in enumerate(ctl):
+            for li, nm in enumerate(("base", "lag1")):
+                st = Z[s_][nm + "_status"]
+                dec[li, i, :len(st)] = st
+        np.savez_compressed(os.path.join(HERE, "golden", "oracle_decisions_300.npz"), seq0=ctl[0], frames=a.frames, keys=np.array(STATUS_KEYS), decisions=dec)
     for k, v in rep["pairs"].items():
         print(k, json.dumps(v["summary"]))
     # lag-1 fixture, same layout as oracle_ate_300.npz

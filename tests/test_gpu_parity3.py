@@ -242,3 +242,42 @@ def test_relocalisation_request_is_dropped_while_the_extrinsic_is_optimised(P):
     assert flagged[f_set + 1] & 64 and not any(x & 64 for i, x in enumerate(flagged) if i != f_set + 1)
     assert ba.relo(0)["pending"] == 0 and ba.relo(0)["n_factors"] == 0
     assert np.array_equal(ba.window(0), bb.window(0))          # the run that never asked
+
+
+def test_two_cholesky_retries_in_one_solve_follow_the_oracle(P, monkeypatch):
+    """The mu *= 10 retry ladder of the trust-region loop (oracle/backend.cpp solve(), Ceres' handling of a failed linear solve): with the
+    test hook VIO_TEST_CHOL_FAIL_SHIFT the first TWO factorisations of every solve are reported as failed on both sides.  Every retry
+    re-forms the Schur complement at the larger mu and costs the phased solver one iteration slot, so the handle is created with
+    VIO_EXTRA_SLOTS = 4 (final evaluation + three spare); iteration counts, accepted steps, costs and the window must follow the oracle
+    frame by frame.  With the default two extra slots the same run is truncated and says so (overflow flag 32) -- the documented limit."""
+    n, seqs = 26, [31, 32]
+    cfg = P.canonical_config(reference_quirks=2 << 8)
+    sc = vio_ct.synth_like(cfg)
+    oruns = [vio_ct.run_oracle_sequence(cfg, sc, s, n) for s in seqs]
+    frames = [o["frames"] for o in oruns]
+    monkeypatch.setenv("VIO_EXTRA_SLOTS", "4")
+    b, traj, stat = vio_ct.run_hip_batch(P, cfg, sc, seqs, n, frames)
+    nl = 0
+    for i in range(len(seqs)):
+        for f in range(n):
+            so, sh = oruns[i]["status"][f], stat[i][f]
+            assert (int(so["solver_flag"]), int(so["frame_count"]), int(so["n_landmarks"]), int(so["marginalization_flag"])) == \
+                   (sh.solver_flag, sh.frame_count, sh.n_landmarks, sh.marginalization_flag), (i, f)
+            if sh.solver_flag == 1 and sh.processed:
+                nl += 1
+                assert (int(so["iterations"]), int(so["successful_steps"])) == (sh.iterations, sh.successful_steps), (i, f, so["iterations"], sh.iterations)
+                assert abs(so["final_cost"] - sh.final_cost) <= 1e-6 * max(1.0, abs(so["final_cost"])), (i, f)
+            assert sh.overflow_flags & 32 == 0, (i, f)
+        wo, wh = oruns[i]["oracle"].window(), b.window(i)
+        assert np.abs(wo[:, :3] - wh[:, :3]).max() < 1e-5
+    assert nl >= 20
+    # the retries really happened: the unforced run of the same sequences ends elsewhere (mu stays higher after the forced failures)
+    cfg0 = P.canonical_config()
+    b0, _, _ = vio_ct.run_hip_batch(P, cfg0, sc, seqs, n, frames)
+    assert np.abs(b0.window(0)[:, :3] - b.window(0)[:, :3]).max() > 1e-9
+    b.close(); b0.close()
+    # default slots: one spare only -> the second forced retry exhausts them; the frame is flagged, never silently wrong
+    monkeypatch.delenv("VIO_EXTRA_SLOTS")
+    b2, _, stat2 = vio_ct.run_hip_batch(P, cfg, sc, seqs[:1], n, frames[:1])
+    assert any(s.overflow_flags & 32 for s in stat2[0] if s.solver_flag == 1)
+    b2.close()

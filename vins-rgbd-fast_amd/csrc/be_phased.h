@@ -12,6 +12,7 @@
 
 namespace {
 
+#define PS_LVEC 14   // P-sized vectors ps_serial keeps in LDS (kernels.h ps_serial_lds_bytes sizes the launch with it)
 __device__ __forceinline__ bool ps_active(const SolveSt &st) { return st.stage != PS_IDLE && st.stage != PS_DONE; }
 __device__ __forceinline__ double *ps_imu_blk(const Ctx &c) { return c.pairblk + (size_t)((c.W + 1) * c.W / 2) * 210; }  // W x 768 doubles behind the pair blocks
 __device__ __forceinline__ unsigned ps_colmask(int W1, int LW, bool vext) {
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(Batch B) {
         st.cost = 0; st.ccost = 0; st.radius = 1e4; st.mu = 1e-8; st.alpha = 0; st.dogleg_norm = 0; st.model_change = 0;
         st.iter = 0; st.iters_done = 0; st.succ = 0; st.invalid = 0;
         st.point_new = 0; st.scale_pending = 1; st.retry = 0; st.cauchy_valid = 0; st.eval_with_J = 1;
+        st.test_fail = (c.C->c.reference_quirks >> VIO_TEST_CHOL_FAIL_SHIFT) & VIO_TEST_CHOL_FAIL_MASK;
         st.n_eval_blocks = 3 + (nres + 255) / 256;
         st.eval_done = 0;
         st.ts0 = ts0;
@@ -754,9 +756,15 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
     const int ne_ext = st.vext ? 7 : 0;
     const int oE = 15 * W1, oT = 15 * W1 + 6;
     const int *alist = c.pair_list + c.nres_cap - c.NL;
-    double *g = c.vec, *sp = c.vec + 1 * LW, *dgp = c.vec + 2 * LW, *gradp = c.vec + 3 * LW, *gnp = c.vec + 4 * LW, *stp = c.vec + 5 * LW,
-           *gs = c.vec + 6 * LW, *tmpv = c.vec + 7 * LW, *delta = c.vec + 8 * LW, *sgp = c.vec + 9 * LW, *hsgp = c.vec + 10 * LW,
-           *yp = c.vec + 11 * LW, *up = c.vec + 12 * LW, *tmpv2 = c.vec + 13 * LW;
+    // The fourteen P-sized vectors of the trust-region step live in LDS for the duration of the kernel: as HBM arrays every small vector
+    // phase below paid a dependent global round trip (about 25 per iteration).  One coalesced load here, one write-back in finish();
+    // same layout as c.vec (slot 0 = g and slot 1 = sp come from ps_asm_b, the others persist between the slots of a solve).
+    const int nbk = LW >> 4;
+    const int wk_d = max(BIG ? nbk * 256 : nbk * (nbk + 1) / 2 * 256, 16 * 336);   // doubles of the work region (host: lds_serial)
+    double *lv = work + wk_d + 2;
+    double *g = lv, *sp = lv + 1 * LW, *dgp = lv + 2 * LW, *gradp = lv + 3 * LW, *gnp = lv + 4 * LW, *stp = lv + 5 * LW,
+           *gs = lv + 6 * LW, *tmpv = lv + 7 * LW, *delta = lv + 8 * LW, *sgp = lv + 9 * LW, *hsgp = lv + 10 * LW,
+           *yp = lv + 11 * LW, *up = lv + 12 * LW, *tmpv2 = lv + 13 * LW;
     double *sl = c.lvec, *dgl = c.lvec + c.NLs, *gradl = c.lvec + 2 * c.NLs, *gnl = c.lvec + 3 * c.NLs, *stl = c.lvec + 4 * c.NLs,
            *inv = c.lvec + 5 * c.NLs, *gls = c.lvec + 6 * c.NLs, *Hlls = c.lvec + 7 * c.NLs;
     const int Kpad = (Fa + 3) & ~3;
@@ -768,10 +776,13 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
     int invalid = st.invalid;
     int iter = st.iter;
     if (!st.retry) iter++;
-    __syncthreads();
     PH_INIT;
+    const bool have_lv = !(iter > cfg.max_iterations);   // (the slot that only closes a solve at the iteration cap touches none of them)
+    if (have_lv) for (int i = t; i < PS_LVEC * LW; i += nt) lv[i] = c.vec[i];
+    __syncthreads();
     auto finish = [&](int new_stage) {
         __syncthreads();
+        if (have_lv) for (int i = 2 * LW + t; i < PS_LVEC * LW; i += nt) c.vec[i] = lv[i];
         if (t == 0) {
             st.radius = radius; st.mu = mu; st.alpha = alpha; st.dogleg_norm = dogleg_norm; st.cauchy_valid = cauchy_valid ? 1 : 0;
             st.invalid = invalid; st.iter = iter; st.stage = new_stage;
@@ -864,6 +875,7 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
         bool ok = big ? chol_tiles_stream(c.Sc, LW >> 4, work, &sh_i[2], chol_dinv, xs)
                       : chol_tiles(work, LW >> 4, &sh_i[2], chol_dinv, s == 0 ? B.timings + 59 : nullptr, xs);   // with the forward substitution
         PH(51);
+        if (st.test_fail > 0) { ok = false; __syncthreads(); if (t == 0) st.test_fail--; }   // test hook: walk the retry ladder
         if (ok) {
             if (big) chol_backward_tiles(c.Sc, LW >> 4, xs, chol_dinv);
             else chol_backward_tiles_wave(work, LW >> 4, xs, chol_dinv);

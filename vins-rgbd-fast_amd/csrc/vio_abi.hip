@@ -898,7 +898,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
                 const size_t nb = (size_t)C.LW >> 4, tiles = nb * (nb + 1) / 2 * 256;
                 const size_t wk = std::max(tiles <= 16896 ? tiles : nb * 256, (size_t)16 * 336);
                 h->serial_big = tiles > 16896;
-                h->lds_serial = ((size_t)C.LW + 2 + wk) * 8 + 16;
+                h->lds_serial = ((size_t)C.LW + 2 + wk + 2 + (size_t)14 /* PS_LVEC */ * C.LW) * 8 + 16;   // + the step's vectors (be_phased.h)
                 if (getenv("VIO_SERIAL_LDS") && (size_t)atol(getenv("VIO_SERIAL_LDS")) > h->lds_serial) h->lds_serial = (size_t)atol(getenv("VIO_SERIAL_LDS"));   // experiment: a larger request keeps other workgroups off the CU
                 (void)raise_lds_limit(h->serial_big ? (const void *)ps_serial_big_kernel : (const void *)ps_serial_kernel, h->lds_serial);
                 if (!h->serial_big) (void)raise_lds_limit((const void *)ps_serial_kernel_512, h->lds_serial);

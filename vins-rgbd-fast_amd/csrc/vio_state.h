@@ -147,6 +147,7 @@ struct SolveSt {
     int cauchy_valid, eval_with_J, n_eval_blocks;
     int eval_done;        // blocks of the running evaluation that have published their partial cost (device-scope counter)
     int relo;             // this solve carries relocalisation factors: the (constant) extrinsic's six columns are lent to relo_Pose
+    int test_fail;        // test hook (VIO_TEST_CHOL_FAIL_SHIFT): Cholesky factorisations of this solve still to be reported as failed
 };
 
 // all HBM pointers of a batch; passed to kernels by value
