@@ -198,6 +198,40 @@ int ovio_fast_roi(const uint8_t *img, int W, int H, int rx, int ry, int rw, int 
     for (size_t i = 0; i < k.size() && (int)i < cap; i++) { out[3 * i] = k[i].x; out[3 * i + 1] = k[i].y; out[3 * i + 2] = k[i].response; }
     return (int)k.size();
 }
+// ---- pose_graph slice (posegraph.cpp)
+// KeyFrame::computeWindowBRIEFPoint + computeBRIEFPoint (keyframe.cpp:80-124): blur once, FAST(threshold, NMS) on the RAW image, BRIEF of
+// the window points and of the keypoints on the blurred image, normalised keypoints through the camera model.  Returns the keypoint count.
+int ovio_pg_describe(const Config *cfg, const uint8_t *gray, int n_win, const float *win_uv, const int *pattern1024, int fast_threshold,
+                     uint64_t *win_desc, int cap, float *kp_xy, uint64_t *kp_desc, float *kp_norm) {
+    const int W = cfg->width, H = cfg->height;
+    std::vector<uint8_t> blur((size_t)W * H);
+    gaussian_blur_9x9(gray, W, H, blur.data());
+    if (n_win > 0) brief_compute(blur.data(), W, H, win_uv, n_win, pattern1024, win_desc);
+    std::vector<KeyPt> k;
+    fast_detect_roi(gray, W, H, 0, 0, W, H, k, fast_threshold);
+    const int m = std::min((int)k.size(), cap);
+    std::vector<float> xy(2 * (size_t)std::max(m, 1));
+    for (int i = 0; i < m; i++) {
+        xy[2 * i] = k[i].x; xy[2 * i + 1] = k[i].y;
+        kp_xy[2 * i] = k[i].x; kp_xy[2 * i + 1] = k[i].y;
+        double x, y;
+        cam_lift(*cfg, k[i].x, k[i].y, x, y);
+        kp_norm[2 * i] = (float)x; kp_norm[2 * i + 1] = (float)y;
+    }
+    if (m > 0) brief_compute(blur.data(), W, H, xy.data(), m, pattern1024, kp_desc);
+    return (int)k.size();
+}
+void ovio_pg_blur(const uint8_t *gray, int W, int H, uint8_t *out) { gaussian_blur_9x9(gray, W, H, out); }
+void ovio_pg_match(const uint64_t *wd, int n, const uint64_t *od, int m, int *best_index, int *best_dist) { brief_match(wd, n, od, m, best_index, best_dist); }
+int ovio_pg_find_connection(int n, const float *pt3d, const float *pt_norm, const double *pt_id, const int *match, const float *old_norm,
+                            const double *vio_T, const double *vio_R, const double *qic9, const double *tic3, int min_loop_num,
+                            double *loop_info8, double *match_points, int *n_match_out, double *pnp_T3, double *pnp_R9) {
+    return find_connection(n, pt3d, pt_norm, pt_id, match, old_norm, vio_T, vio_R, qic9, tic3, min_loop_num, loop_info8, match_points, n_match_out, pnp_T3, pnp_R9);
+}
+void ovio_pg_optimize4dof(int n, const double *t_in, const double *R_in, const int *sequence, const int *loop_to, const double *loop_info,
+                          double *t_out, double *R_out, double *drift4) {
+    optimize_4dof(n, t_in, R_in, sequence, loop_to, loop_info, t_out, R_out, drift4);
+}
 void ovio_circle_hw(int radius, int *hw) {
     std::vector<int> v;
     circle_halfwidths(radius, v);

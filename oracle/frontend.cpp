@@ -98,14 +98,14 @@ int fast_corner_score(const uint8_t *p, int stride, int thr) {
     return best > thr ? best - 1 : 0;
 }
 
-void fast_detect_roi(const uint8_t *img, int W, int H, int rx, int ry, int rw, int rh, std::vector<KeyPt> &out) {
+void fast_detect_roi(const uint8_t *img, int W, int H, int rx, int ry, int rw, int rh, std::vector<KeyPt> &out, int thr) {
     (void)H;
     out.clear();
     if (rw < 7 || rh < 7) return;
     std::vector<uint8_t> score((size_t)rw * rh, 0);
     for (int i = 3; i < rh - 3; i++)
         for (int j = 3; j < rw - 3; j++)
-            score[(size_t)i * rw + j] = (uint8_t)fast_corner_score(img + (size_t)(ry + i) * W + rx + j, W, 10);
+            score[(size_t)i * rw + j] = (uint8_t)fast_corner_score(img + (size_t)(ry + i) * W + rx + j, W, thr);
     for (int i = 3; i < rh - 3; i++)
         for (int j = 3; j < rw - 3; j++) {
             int s = score[(size_t)i * rw + j];

@@ -67,7 +67,7 @@ void cam_project(const Config &c, double X, double Y, double Z, double &u, doubl
 // ------------------------------------------------------------------------------------ vision primitives
 void pyr_down(const Image &src, Image &dst);
 // FAST-9/16 threshold 10 + NMS on a ROI, row-major order, ROI-relative coordinates
-void fast_detect_roi(const uint8_t *img, int W, int H, int rx, int ry, int rw, int rh, std::vector<KeyPt> &out);
+void fast_detect_roi(const uint8_t *img, int W, int H, int rx, int ry, int rw, int rh, std::vector<KeyPt> &out, int thr = 10);
 int fast_corner_score(const uint8_t *p, int stride, int thr);  // returns 0 if not a corner
 void circle_halfwidths(int radius, std::vector<int> &hw);      // cv::circle(filled) raster shape
 void lk_track(const std::vector<Image> &prev, const std::vector<Image> &next, const std::vector<P2f> &prevPts,
@@ -75,6 +75,16 @@ void lk_track(const std::vector<Image> &prev, const std::vector<Image> &next, co
 int seven_point_models(const double *x1, const double *y1, const double *x2, const double *y2, double F[3][9]);
 void ransac_fundamental(const Config &c, const std::vector<P2f> &p1, const std::vector<P2f> &p2,
                         std::vector<uint8_t> &status);
+
+// ------------------------------------------------------------------------------------ pose_graph (posegraph.cpp; no DBoW2 query)
+void gaussian_blur_9x9(const uint8_t *src, int W, int H, uint8_t *dst);
+void brief_compute(const uint8_t *blur, int W, int H, const float *xy, int n, const int *pat, uint64_t *desc);
+void brief_match(const uint64_t *wd, int n, const uint64_t *od, int m, int *best_index, int *best_dist);
+int find_connection(int n, const float *pt3d, const float *pt_norm, const double *pt_id, const int *match, const float *old_norm,
+                    const double *vio_T, const double *vio_R, const double *qic9, const double *tic3, int min_loop_num,
+                    double *loop_info8, double *match_points, int *n_match_out, double *pnp_T3, double *pnp_R9);
+void optimize_4dof(int n, const double *t_in, const double *R_in, const int *sequence, const int *loop_to, const double *loop_info,
+                   double *t_out, double *R_out, double *drift4);
 
 // ------------------------------------------------------------------------------------ FeatureTracker
 struct Tracker {

@@ -24,7 +24,7 @@ def _declared(header):
     return sorted(set(re.findall(r"\b(vio_[a-z0-9_]+)\s*\(", src)))
 
 
-@pytest.mark.parametrize("header", ["vio_abi.h", "vio_synth.h"])
+@pytest.mark.parametrize("header", ["vio_abi.h", "vio_synth.h", "vio_posegraph.h"])
 def test_abi_exports_every_declared_symbol(P, header):
     names = _declared(header)
     assert len(names) >= (25 if header == "vio_abi.h" else 5), names
@@ -35,7 +35,7 @@ def test_abi_exports_every_declared_symbol(P, header):
 
 def test_headers_are_plain_c():
     """the boundary is a C ABI: the headers must compile as C (no C++ / torch types in the signatures)."""
-    for h in ("vio_abi.h", "vio_synth.h"):
+    for h in ("vio_abi.h", "vio_synth.h", "vio_posegraph.h"):
         r = subprocess.run(["gcc", "-std=c99", "-fsyntax-only", "-Wall", "-Werror", "-x", "c", os.path.join(ROOT, "include", h)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr

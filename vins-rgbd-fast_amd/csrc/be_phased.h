@@ -842,31 +842,38 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
         {
             const unsigned colmask = ps_colmask(W1, LW, st.vext != 0);
             const int nb = LW >> 4, ntile = nb * (nb + 1) / 2;
-            // thread = element (r, cc) of every (nt / 256)-th tile; four tiles per trip, branch-free loads so that they are in flight together
-            const int e = t & 255, r = e >> 4, cc = e & 15, tstep = nt >> 8;
-            for (int tile0 = t >> 8; tile0 < ntile; tile0 += TB * tstep) {
-                double hv[TB], uv[TB], sr[TB], sc[TB], dg[TB];
+            // thread = the element pair (r, c2), (r, c2 + 1) of every (nt / 128)-th tile, TB tiles per trip: 16-byte loads of H (row-major) and
+            // of U (tile layout: the XOR swizzle keeps an even-aligned pair adjacent, swapped in odd rows), branch-free so that all of a
+            // trip's loads are in flight together; 66 tiles = three trips of 512 threads
+            const int e = t & 127, r = e >> 3, c2 = (e & 7) << 1, tstep = nt >> 7;
+            const bool swp = (r & 1) != 0;
+            for (int tile0 = t >> 7; tile0 < ntile; tile0 += TB * tstep) {
+                double2 hv[TB], uv[TB];
+                double sr[TB], sc0[TB], sc1[TB], dg[TB];
                 int widx[TB];
-                bool msk[TB], dia[TB];
+                bool msk[TB], dia0[TB], dia1[TB];
 #pragma unroll
                 for (int b = 0; b < TB; b++) {
                     const int tile = min(tile0 + b * tstep, ntile - 1);
                     int ti, tj;
                     tri_decode(tile, ti, tj);
-                    const int row = 16 * ti + r, col = 16 * tj + cc;
-                    widx[b] = tl_idx(ti, tj, r, cc);
+                    const int row = 16 * ti + r, col = 16 * tj + c2;
+                    widx[b] = tl_idx(ti, tj, r, c2) & ~1;   // slot of the pair
                     msk[b] = ((colmask >> ti) & 1u) && ((colmask >> tj) & 1u);
-                    dia[b] = row == col;
-                    hv[b] = row < P ? c.H[(size_t)row * LW + col] : 0.0; uv[b] = msk[b] ? c.Sc[widx[b]] : 0.0;   // rows >= P are padding
-                    sr[b] = sp[row]; sc[b] = sp[col]; dg[b] = dgp[row];
+                    dia0[b] = row == col; dia1[b] = row == col + 1;
+                    hv[b] = row < P ? *(const double2 *)&c.H[(size_t)row * LW + col] : make_double2(0.0, 0.0);   // rows >= P are padding
+                    uv[b] = msk[b] ? *(const double2 *)&c.Sc[widx[b]] : make_double2(0.0, 0.0);
+                    sr[b] = sp[row]; sc0[b] = sp[col]; sc1[b] = sp[col + 1]; dg[b] = dgp[row];
                 }
 #pragma unroll
                 for (int b = 0; b < TB; b++) {
                     if (tile0 + b * tstep >= ntile) break;
                     // S = Sp (H - U) Sp + mu D^2 (U = 0 outside the tiles the landmark rows touch); unit diagonal for constant parameters
-                    double v = sr[b] * sc[b] * (hv[b] - uv[b]);
-                    if (dia[b]) { v += mu * dg[b] * dg[b]; if (sr[b] == 0.0) v = 1.0; }
-                    Stiles[widx[b]] = v;   // (big: every entry of c.Sc is read -- its U part -- and rewritten by the same thread)
+                    const double u0 = swp ? uv[b].y : uv[b].x, u1 = swp ? uv[b].x : uv[b].y;
+                    double v0 = sr[b] * sc0[b] * (hv[b].x - u0), v1 = sr[b] * sc1[b] * (hv[b].y - u1);
+                    if (dia0[b]) { v0 += mu * dg[b] * dg[b]; if (sr[b] == 0.0) v0 = 1.0; }
+                    if (dia1[b]) { v1 += mu * dg[b] * dg[b]; if (sr[b] == 0.0) v1 = 1.0; }
+                    *(double2 *)&Stiles[widx[b]] = swp ? make_double2(v1, v0) : make_double2(v0, v1);   // (big: c.Sc is read -- its U part -- and rewritten by the same thread)
                 }
             }
             __syncthreads();

@@ -442,7 +442,8 @@ int ransac_iterations(double p, double ep, int model_points, int max_iters) {  /
 }
 // cv::solvePnPRansac(EPNP) with K = I: camera_point = R X + t
 bool pnp_ransac_epnp(const std::vector<v3> &obj_in, const std::vector<std::array<double, 2>> &img_in, int max_iters, double thresh, double confidence,
-                     m3 &R, v3 &t) {
+                     m3 &R, v3 &t, std::vector<uint8_t> *inliers_out = nullptr) {
+    if (inliers_out) inliers_out->assign(obj_in.size(), 0);
     const int count = (int)obj_in.size(), model_points = 5;
     if (count < model_points) return false;
     std::vector<v3> obj(count);
@@ -492,6 +493,7 @@ bool pnp_ransac_epnp(const std::vector<v3> &obj_in, const std::vector<std::array
     if (best <= 0) return false;
     std::vector<int> in_idx;
     for (int i = 0; i < count; i++) if (best_mask[i]) in_idx.push_back(i);
+    if (inliers_out) *inliers_out = best_mask;
     if (!epnp_subset(obj, img, in_idx, R, t)) { R = bestR; t = bestt; }
     return true;
 }
@@ -1180,6 +1182,11 @@ void run(const vio_config &cfg, int W, const double *headers, const double *bgs0
 
 // ---- host-only stage entry points (vio_stage_host_*): the building blocks above on caller-supplied arrays, for parity tests that
 // need no GPU
+// the same with the inlier mask (KeyFrame::PnPRANSAC reads it, pose_graph/src/keyframe/keyframe.cpp:231-238)
+bool pnp_ransac_with_inliers(const std::vector<dm::v3> &obj, const std::vector<std::array<double, 2>> &img, int max_iters, double thresh, double confidence,
+                             dm::m3 &R, dm::v3 &t, std::vector<uint8_t> &inliers) {
+    return pnp_ransac_epnp(obj, img, max_iters, thresh, confidence, R, t, &inliers);
+}
 bool stage_pnp_ransac_epnp(int n, const double *obj, const double *img, int max_iters, double thresh, double confidence, double *R9, double *t3) {
     std::vector<v3> o(n);
     std::vector<std::array<double, 2>> im(n);

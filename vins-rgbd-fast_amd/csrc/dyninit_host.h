@@ -59,6 +59,10 @@ void run(const vio_config &cfg, int W, const double *headers, const double *bgs0
 // (FeatureManager::initFramePoseByPnP, feature_manager.cpp:590-642) and for tests.
 bool solve_pnp_iterative(const std::vector<dm::v3> &obj, const std::vector<std::array<double, 2>> &img, dm::m3 &R, dm::v3 &t);
 
+// cv::solvePnPRansac (EPnP minimal solver, refit on the inliers) on normalised points with the inlier mask: camera_point = R X + t
+bool pnp_ransac_with_inliers(const std::vector<dm::v3> &obj, const std::vector<std::array<double, 2>> &img, int max_iters, double thresh, double confidence,
+                             dm::m3 &R, dm::v3 &t, std::vector<uint8_t> &inliers);
+
 bool stage_alignment(int n, const double *frames19, const double *tic3, double g_norm, double *g_out, double *x_out);
 bool stage_pnp_ransac_epnp(int n, const double *obj, const double *img, int max_iters, double thresh, double confidence, double *R9, double *t3);
 int stage_sfm_window(int window_size, int nf, const int *start, const int *nobs, const double *obs, int *l_out, double *q_out, double *T_out,

@@ -10,9 +10,10 @@
 #include "kernels.h"
 #include "dyninit_host.h"
 
+thread_local std::string g_err;   // last failure of the calling thread (vio_last_error); also set by pg_kernels.hip / posegraph_host.cpp
+
 namespace {
 
-thread_local std::string g_err;
 #define HIPCHK(x)                                                                                        \
     do {                                                                                                 \
         hipError_t e_ = (x);                                                                             \

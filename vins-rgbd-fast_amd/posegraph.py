@@ -1,0 +1,144 @@
+"""Loop-closure slice of pose_graph (include/vio_posegraph.h): ctypes over the C ABI, shaped like the reference's KeyFrame.
+
+    kf = KeyFrame(cfg, pattern, stamp, index, vio_T, vio_R, gray, point_3d, point_2d_uv, point_2d_norm, point_id)   # keyframe.cpp:14-43
+    ok = kf.findConnection(old_kf, qic, tic)        # keyframe.cpp:252-528; on success kf.match_points / kf.loop_info are set
+    batch.set_relo_frame(seq, kf.time_stamp, kf.index, kf.match_points, old_kf.T_w_i, old_kf.R_w_i)                   # Estimator::setReloFrame
+    t, R, drift = optimize4DoF(t, R, sequence, loop_to, loop_info)                                                    # pose_graph.cpp:410-581
+
+PoseGraph::detectLoop (the DBoW2 query) is not provided: the vocabulary blob is missing from the reference tree, the caller picks old_kf.
+Descriptor extraction and matching are HIP kernels; there is no CPU fallback."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import numpy as np
+
+MIN_LOOP_NUM = 25   # pose_graph/src/utility/parameters.h
+
+
+def _lib():
+    P = importlib.import_module("vins-rgbd-fast_amd")
+    L = P.lib()
+    if not getattr(L, "_pg_bound", False):
+        L.vio_pg_describe.argtypes = [C.POINTER(P.Config), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]
+        L.vio_pg_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.vio_pg_find_connection.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_int] + [C.c_void_p] * 5
+        L.vio_pg_optimize4dof.argtypes = [C.c_int] + [C.c_void_p] * 8
+        L.vio_pg_stage_blur.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L._pg_bound = True
+    return P, L
+
+
+def _chk(P, L, rc, what):
+    if rc < 0:
+        raise P.VioError("%s failed (%d): %s" % (what, rc, L.vio_last_error().decode()))
+    return rc
+
+
+def load_brief_pattern(path):
+    """BRIEF_PATTERN_FILE (support_files/brief_pattern.yml: OpenCV FileStorage sequences x1, y1, x2, y2 of 256 integers each), or an .npz
+    holding the same four arrays: returns int32[1024] = x1 | y1 | x2 | y2 as the C ABI takes it (BriefExtractor::BriefExtractor,
+    keyframe.cpp:582-597)."""
+    if path.endswith(".npz"):
+        z = np.load(path)
+        out = np.concatenate([np.asarray(z[k], np.int32).reshape(-1) for k in ("x1", "y1", "x2", "y2")])
+    else:
+        txt = open(path).read()
+        seqs = {}
+        for name in ("x1", "y1", "x2", "y2"):
+            m = re.search(r"^%s:\s*\n((?:\s*-\s*-?\d+\s*\n)+)" % name, txt, re.M)
+            if m:
+                seqs[name] = [int(v) for v in re.findall(r"-\s*(-?\d+)", m.group(1))]
+            else:   # flow style: x1: [ 1, 2, ... ]
+                m = re.search(r"^%s:\s*\[([^\]]*)\]" % name, txt, re.M)
+                if not m:
+                    raise ValueError("%s: no sequence %s" % (path, name))
+                seqs[name] = [int(v) for v in m.group(1).replace("\n", " ").split(",") if v.strip()]
+        out = np.concatenate([np.asarray(seqs[k], np.int32) for k in ("x1", "y1", "x2", "y2")])
+    if out.shape != (1024,):
+        raise ValueError("%s: expected 4 x 256 pattern entries, got %d" % (path, out.size))
+    return np.ascontiguousarray(out)
+
+
+def describe(cfg, gray, window_uv, pattern, fast_threshold=20, cap=8192):
+    """computeWindowBRIEFPoint + computeBRIEFPoint: (window descriptors [n][4] u64, keypoints [m][2] f32, their descriptors, their normalised
+    coordinates)"""
+    P, L = _lib()
+    gray = np.ascontiguousarray(gray, np.uint8)
+    assert gray.shape == (cfg.height, cfg.width)
+    uv = np.ascontiguousarray(window_uv, np.float32).reshape(-1, 2)
+    n = len(uv)
+    wd = np.zeros((max(n, 1), 4), np.uint64)
+    kxy, kd, kn = np.zeros((cap, 2), np.float32), np.zeros((cap, 4), np.uint64), np.zeros((cap, 2), np.float32)
+    pat = np.ascontiguousarray(pattern, np.int32)
+    m = _chk(P, L, L.vio_pg_describe(C.byref(cfg), gray.ctypes.data, n, uv.ctypes.data, pat.ctypes.data, int(fast_threshold), wd.ctypes.data, cap,
+                                     kxy.ctypes.data, kd.ctypes.data, kn.ctypes.data), "vio_pg_describe")
+    m = min(m, cap)
+    return wd[:n], kxy[:m], kd[:m], kn[:m]
+
+
+def match(window_desc, old_desc):
+    """searchByBRIEFDes: (best index or -1 per window descriptor, best Hamming distance)"""
+    P, L = _lib()
+    a, b = np.ascontiguousarray(window_desc, np.uint64).reshape(-1, 4), np.ascontiguousarray(old_desc, np.uint64).reshape(-1, 4)
+    bi, bd = np.zeros(max(len(a), 1), np.int32), np.zeros(max(len(a), 1), np.int32)
+    _chk(P, L, L.vio_pg_match(a.ctypes.data, len(a), b.ctypes.data, len(b), bi.ctypes.data, bd.ctypes.data), "vio_pg_match")
+    return bi[:len(a)], bd[:len(a)]
+
+
+def find_connection(pt3d, pt_id, match_idx, old_norm, vio_T, vio_R, qic, tic, min_loop_num=MIN_LOOP_NUM):
+    """findConnection after the descriptor search: (has_loop, loop_info[8], match_points[k][3], PnP_T_old, PnP_R_old)"""
+    P, L = _lib()
+    p3 = np.ascontiguousarray(pt3d, np.float32).reshape(-1, 3)
+    n = len(p3)
+    ids, mi = np.ascontiguousarray(pt_id, np.float64).reshape(-1), np.ascontiguousarray(match_idx, np.int32).reshape(-1)
+    on = np.ascontiguousarray(old_norm, np.float32).reshape(-1, 2)
+    T, R = np.ascontiguousarray(vio_T, np.float64), np.ascontiguousarray(vio_R, np.float64)
+    q, t = np.ascontiguousarray(qic, np.float64), np.ascontiguousarray(tic, np.float64)
+    info, mp, nm, pT, pR = np.zeros(8), np.zeros((max(n, 1), 3)), np.zeros(1, np.int32), np.zeros(3), np.zeros((3, 3))
+    rc = _chk(P, L, L.vio_pg_find_connection(n, p3.ctypes.data, ids.ctypes.data, mi.ctypes.data, on.ctypes.data, T.ctypes.data, R.ctypes.data, q.ctypes.data,
+                                             t.ctypes.data, int(min_loop_num), info.ctypes.data, mp.ctypes.data, nm.ctypes.data, pT.ctypes.data, pR.ctypes.data),
+              "vio_pg_find_connection")
+    return rc == 1, info, mp[:int(nm[0])].copy(), pT, pR
+
+
+def optimize4DoF(t, R, sequence, loop_to, loop_info):
+    """PoseGraph::optimize4DoF over the nodes earliest-looped .. current: (t_out[n][3], R_out[n][3][3], (yaw_drift_deg, t_drift))"""
+    P, L = _lib()
+    t, R = np.ascontiguousarray(t, np.float64).reshape(-1, 3), np.ascontiguousarray(R, np.float64).reshape(-1, 9)
+    n = len(t)
+    sq, lt = np.ascontiguousarray(sequence, np.int32).reshape(n), np.ascontiguousarray(loop_to, np.int32).reshape(n)
+    li = np.ascontiguousarray(loop_info, np.float64).reshape(n, 8)
+    to, Ro, dr = np.zeros((n, 3)), np.zeros((n, 9)), np.zeros(4)
+    _chk(P, L, L.vio_pg_optimize4dof(n, t.ctypes.data, R.ctypes.data, sq.ctypes.data, lt.ctypes.data, li.ctypes.data, to.ctypes.data, Ro.ctypes.data,
+                                     dr.ctypes.data), "vio_pg_optimize4dof")
+    return to, Ro.reshape(n, 3, 3), (dr[0], dr[1:].copy())
+
+
+class KeyFrame:
+    """KeyFrame (pose_graph/src/keyframe/keyframe.h): the online constructor computes the window descriptors and the FAST keypoints with their
+    descriptors (keyframe.cpp:14-43), findConnection verifies a loop candidate chosen by the caller."""
+
+    def __init__(self, cfg, pattern, time_stamp, index, vio_T_w_i, vio_R_w_i, image, point_3d, point_2d_uv, point_2d_norm, point_id, sequence=1):
+        self.time_stamp, self.index, self.sequence = float(time_stamp), int(index), int(sequence)
+        self.vio_T_w_i = np.array(vio_T_w_i, np.float64); self.vio_R_w_i = np.array(vio_R_w_i, np.float64).reshape(3, 3)
+        self.T_w_i, self.R_w_i = self.vio_T_w_i.copy(), self.vio_R_w_i.copy()
+        self.origin_vio_T, self.origin_vio_R = self.vio_T_w_i.copy(), self.vio_R_w_i.copy()
+        self.point_3d = np.array(point_3d, np.float32).reshape(-1, 3)
+        self.point_2d_uv = np.array(point_2d_uv, np.float32).reshape(-1, 2)
+        self.point_2d_norm = np.array(point_2d_norm, np.float32).reshape(-1, 2)
+        self.point_id = np.array(point_id, np.float64).reshape(-1)
+        self.has_loop, self.loop_index, self.loop_info = False, -1, np.zeros(8)
+        self.match_points = np.zeros((0, 3))
+        self.window_brief_descriptors, kxy, self.brief_descriptors, kn = describe(cfg, image, self.point_2d_uv, pattern)
+        self.keypoints, self.keypoints_norm = kxy, kn
+
+    def findConnection(self, old_kf, qic, tic):
+        idx, _ = match(self.window_brief_descriptors, old_kf.brief_descriptors)
+        ok, info, mp, self.PnP_T_old, self.PnP_R_old = find_connection(self.point_3d, self.point_id, idx, old_kf.keypoints_norm, self.origin_vio_T,
+                                                                       self.origin_vio_R, qic, tic)
+        if ok:
+            self.has_loop, self.loop_index, self.loop_info, self.match_points = True, old_kf.index, info, mp
+        return ok
