@@ -876,7 +876,82 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane) {
 // the strictly lower part of M = L^-1 in the strictly UPPER triangle of D (M[i][c], i > c, at row c, column i; M[c][c] = dinv16[c]).
 // With M the panel below the block is a small matrix product on the matrix core (X = A M^T) instead of a 16-step substitution per
 // row, and the triangular solves of the substitution phases are dot products.
+// Round 4: the sixteen pivots run as FOUR blocks of four.  A pivot of the rank-1 form costs ~350 cycles -- an MFMA for S, one for F, the
+// reciprocal square root and the operand selection, all on one dependent chain -- and sixteen of them per diagonal tile were two thirds of the
+// whole factorisation's critical path.  Per block: every lane fetches the four panel entries of ITS row (and the four of F) from the four
+// lane groups (one selection MFMA each), the 4 x 4 diagonal block is read through ten lane broadcasts and factored redundantly by all lanes
+// (uniform arithmetic, four reciprocal square roots), every lane finishes its own row of the 16 x 4 panel with that factor, and ONE rank-4
+// MFMA per accumulator (all four k-slots used: slot k = column 4 kb + k, which by symmetry already sits in lane group k) applies the block.
+// Same algorithm, different association of the subtractions inside a block: results agree with the rank-1 form to round-off.
 __device__ __forceinline__ void chol_diag_tile(double *D, double *dinv16, int *sh_flag) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    v4f64 acc, fcc;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = lk + 4 * r;
+        acc[r] = D[(row << 4) + (li ^ row)];     // (diagonal tiles are stored complete: both triangles, bitwise symmetric)
+        fcc[r] = row == li ? 1.0 : 0.0;
+    }
+    bool ok = true;
+    double lcol[4], mrow[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; kb++) {
+        const int c0 = 4 * kb;
+        // p[m] = S[c0 + m][li] = panel entry (row li, column m); f[m] = F[c0 + m][li]
+        // (gathered by the matrix core itself: with A[i][k] = [k == i / 4] and B[k][j] = S[c0 + k][j] -- which is this lane's own acc[kb] as a
+        // B operand -- the product puts S[c0 + m][j] into register m of EVERY lane group; exact (ones and zeros), one MFMA instead of
+        // four cross-row lane shuffles)
+        const v4f64 zero4 = {0, 0, 0, 0};
+        const double sel = lk == (li >> 2) ? 1.0 : 0.0;     // A operand of lane (k = lk, i = li): A[li][lk]
+        const v4f64 pg = __builtin_amdgcn_mfma_f64_16x16x4f64(sel, acc[kb], zero4, 0, 0, 0);
+        const v4f64 fg = __builtin_amdgcn_mfma_f64_16x16x4f64(sel, fcc[kb], zero4, 0, 0, 0);
+        double p[4], f[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) { p[m] = pg[m]; f[m] = fg[m]; }
+        // the 4 x 4 diagonal block (lower triangle): D[a][b] = panel entry (row c0 + a, column b) = p[b] of lane li = c0 + a
+        const double d00 = bcast_lane(p[0], c0), d10 = bcast_lane(p[0], c0 + 1), d20 = bcast_lane(p[0], c0 + 2), d30 = bcast_lane(p[0], c0 + 3);
+        const double d11 = bcast_lane(p[1], c0 + 1), d21 = bcast_lane(p[1], c0 + 2), d31 = bcast_lane(p[1], c0 + 3);
+        const double d22 = bcast_lane(p[2], c0 + 2), d32 = bcast_lane(p[2], c0 + 3), d33 = bcast_lane(p[3], c0 + 3);
+        const double rl0 = rsqrt(d00);
+        const double l10 = d10 * rl0, l20 = d20 * rl0, l30 = d30 * rl0;
+        const double t11 = d11 - l10 * l10;
+        const double rl1 = rsqrt(t11);
+        const double l21 = (d21 - l20 * l10) * rl1, l31 = (d31 - l30 * l10) * rl1;
+        const double t22 = d22 - l20 * l20 - l21 * l21;
+        const double rl2 = rsqrt(t22);
+        const double l32 = (d32 - l30 * l20 - l31 * l21) * rl2;
+        const double t33 = d33 - l30 * l30 - l31 * l31 - l32 * l32;
+        const double rl3 = rsqrt(t33);
+        ok = ok && (d00 > 0.0) && (t11 > 0.0) && (t22 > 0.0) && (t33 > 0.0) && isfinite(d00) && isfinite(t11) && isfinite(t22) && isfinite(t33);
+        // my row of the panel and of E
+        const double x0 = p[0] * rl0;
+        const double x1 = (p[1] - x0 * l10) * rl1;
+        const double x2 = (p[2] - x0 * l20 - x1 * l21) * rl2;
+        const double x3 = (p[3] - x0 * l30 - x1 * l31 - x2 * l32) * rl3;
+        const double e0 = f[0] * rl0;
+        const double e1 = (f[1] - e0 * l10) * rl1;
+        const double e2 = (f[2] - e0 * l20 - e1 * l21) * rl2;
+        const double e3 = (f[3] - e0 * l30 - e1 * l31 - e2 * l32) * rl3;
+        const double xk = lk == 0 ? x0 : (lk == 1 ? x1 : (lk == 2 ? x2 : x3));   // L[li][c0 + lk]: the k-slot this lane feeds
+        const double ek = lk == 0 ? e0 : (lk == 1 ? e1 : (lk == 2 ? e2 : e3));   // M[c0 + lk][li]
+        lcol[kb] = xk; mrow[kb] = ek;
+        if (lane < 4) dinv16[c0 + lane] = lane == 0 ? rl0 : (lane == 1 ? rl1 : (lane == 2 ? rl2 : rl3));
+        if (kb < 3) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xk, xk, acc, 0, 0, 0);
+            fcc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xk, ek, fcc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int j = lk + 4 * q;
+        if (li >= j) D[(li << 4) + (j ^ li)] = lcol[q];          // L[li][j]
+        else D[(li << 4) + (j ^ li)] = mrow[q];                   // M[j][li], li < j, at (row li, column j)
+    }
+    if (!ok && lane == 0) *sh_flag = 0;
+    WAVE_SYNC();
+}
+// the rank-1 form of rounds 2 / 3 (one MFMA pair per pivot), kept for the harness (tools/chol_bench.py micro modes compare the two)
+__device__ __forceinline__ void chol_diag_tile_rank1(double *D, double *dinv16, int *sh_flag) {
     const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
     // acc = the symmetric tile S; fcc = F = E^T where E starts as the identity "panel" below the block: eliminating S from
     // [[S, I], [I, 0]] leaves E = L^-T, i.e. the finished column j of E is row j of M = L^-1 (the panel operation applied to the identity).
