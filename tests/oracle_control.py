@@ -38,6 +38,10 @@ VARIANTS = {   # name -> (library under oracle/, tracker lag)
     "lag1": ("liboracle.so", 1),
     "lag1_order": ("liboracle_order.so", 1),
     "befma": ("liboracle_befma.so", 0),   # fused multiply-adds in the back-end only (front-end code identical to liboracle.so)
+    # a perturbation of known size: every new prior's Jacobian scaled by (1 + eps) (oracle/backend.cpp marg_finish, OVIO_PERTURB_EPS)
+    "eps12": ("liboracle.so", 0, {"OVIO_PERTURB_EPS": "1e-12"}),
+    "eps9": ("liboracle.so", 0, {"OVIO_PERTURB_EPS": "1e-9"}),
+    "eps6": ("liboracle.so", 0, {"OVIO_PERTURB_EPS": "1e-6"}),
 }
 
 
@@ -51,8 +55,14 @@ def run_variants(seq, n_frames, names, cfg_kw=None):
     frames = [syn.render_host(seq, float(tf)) for tf in vio_ct.frame_times(sc, n_frames)]
     out = {}
     for name in names:
-        so, lag = VARIANTS[name]
-        o = vio_ct.run_oracle_sequence(cfg, sc, seq, n_frames, frames=frames, tracker_lag=lag, lib=os.path.join(vio_ct.ORACLE_DIR, so))
+        so, lag = VARIANTS[name][:2]
+        env = VARIANTS[name][2] if len(VARIANTS[name]) > 2 else {}
+        os.environ.update(env)
+        try:
+            o = vio_ct.run_oracle_sequence(cfg, sc, seq, n_frames, frames=frames, tracker_lag=lag, lib=os.path.join(vio_ct.ORACLE_DIR, so))
+        finally:
+            for k_ in env:
+                os.environ.pop(k_, None)
         out[name + "_frames"] = np.array([x[0] for x in o["traj"]], np.int32)
         out[name + "_pos"] = np.array([x[1] for x in o["traj"]])
         out[name + "_status"] = np.array([[st[k] for k in STATUS_KEYS] for st in o["status"]])
@@ -168,12 +178,13 @@ def cmd_assemble(a):
                 for k in zx.files:
                     if k not in ("gt", "gt_frames", "names"):
                         Z[int(f[4:9])][k] = zx[k]
-    if all("befma_pos" in Z[s] for s in have if "base_pos" in Z[s]) and any("befma_pos" in Z[s] for s in have):
-        extra_pairs = [("base", "befma")]
+    for nm in ("befma", "eps12", "eps9", "eps6"):
+        if any(nm + "_pos" in Z[s] for s in have) and all(nm + "_pos" in Z[s] for s in have if "base_pos" in Z[s]):
+            extra_pairs.append(("base", nm))
     ctl = [s for s in have if "base_pos" in Z[s]]
     rep = dict(what="oracle vs builds of its own sources that differ only in round-off (tests/oracle_control.py); canonical workload, "
                     "%d frames, sequences %d..%d" % (a.frames, ctl[0], ctl[-1]) if ctl else "",
-               variants={k: dict(library=v[0], tracker_lag=v[1]) for k, v in VARIANTS.items()}, status_keys=list(STATUS_KEYS), pairs={})
+               variants={k: dict(library=v[0], tracker_lag=v[1], env=(v[2] if len(v) > 2 else {})) for k, v in VARIANTS.items()}, status_keys=list(STATUS_KEYS), pairs={})
     # the base run must be the oracle the committed lag-0 fixture came from
     fx = np.load(os.path.join(HERE, "golden", "oracle_ate_300.npz"))
     nfx = 0

@@ -659,11 +659,21 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
 #ifndef LK_WAVES
 #define LK_WAVES 4
 #endif
+// grid: (nblk, S) -- or, XCD-aware (B.xcd_nb = nblk > 0), 1-D with 8 * ceil(S / 8) * nblk blocks: workgroup L runs on XCD L % 8 (observed
+// placement, MI355X_MICROARCH.md), so sequence 8 * ((L / 8) / nblk) + L % 8 keeps ALL its feature blocks on one XCD and its two images
+// (0.77 MB with the pyramid level) are fetched into ONE L2 instead of all of them; eight sequences are in flight at a time, one per XCD
 __global__ __launch_bounds__(64, LK_WAVES) void fe_lk_kernel(Batch B) {
     const DevCfg &C = *B.cfg;
-    int s = blockIdx.y + B.s0;
+    int s, blk0, nblk;
+    if (B.xcd_nb > 0) {
+        const int L = (int)blockIdx.x, q = L >> 3;
+        nblk = B.xcd_nb;
+        const int sl = (q / nblk) * 8 + (L & 7);
+        if (sl >= B.ns) return;
+        s = sl + B.s0; blk0 = q % nblk;
+    } else { s = blockIdx.y + B.s0; blk0 = blockIdx.x; nblk = gridDim.x; }
     FeSeq &fe = B.fe[s];
-    if (fe.n_forw < 0 || (int)blockIdx.x >= fe.n_pts) return;
+    if (fe.n_forw < 0 || blk0 >= fe.n_pts) return;
     __shared__ __attribute__((aligned(16))) uint8_t win[LK_WIN_BYTES];
     __shared__ short2 der[22 * 22];
     __shared__ __attribute__((aligned(16))) uint8_t jw[LK_JW_BYTES];
@@ -685,19 +695,19 @@ __global__ __launch_bounds__(64, LK_WAVES) void fe_lk_kernel(Batch B) {
         }
     }
     __syncthreads();
-    const long long lk_t0 = (s == 0 && blockIdx.x == 0 && threadIdx.x == 0) ? (long long)wall_clock64() : 0;
-    // grid.x is capped (most of the NP track slots are empty): a block walks its features with stride gridDim.x
-    for (int i = blockIdx.x; i < fe.n_pts; i += gridDim.x) {
+    const long long lk_t0 = (s == 0 && blk0 == 0 && threadIdx.x == 0) ? (long long)wall_clock64() : 0;
+    // the block count per sequence is capped (most of the NP track slots are empty): a block walks its features with stride nblk
+    for (int i = blk0; i < fe.n_pts; i += nblk) {
         float2 np = B.forw_pts[(size_t)s * C.NP + i];
         uint8_t st;
-        lk_one_point(im, C.c.lk_max_level, B.cur_pts[(size_t)s * C.NP + i], np, st, win, der, jw, (s == 0 && blockIdx.x == 0) ? B.timings + 92 : nullptr);
+        lk_one_point(im, C.c.lk_max_level, B.cur_pts[(size_t)s * C.NP + i], np, st, win, der, jw, (s == 0 && blk0 == 0) ? B.timings + 92 : nullptr);
         if (threadIdx.x == 0) {
             B.forw_pts[(size_t)s * C.NP + i] = np;
             B.lk_status[(size_t)s * C.NP + i] = st;
         }
         __syncthreads();
     }
-    if (s == 0 && blockIdx.x == 0 && threadIdx.x == 0) { B.timings[90] += (float)((long long)wall_clock64() - lk_t0); B.timings[91] += 1.f; }
+    if (s == 0 && blk0 == 0 && threadIdx.x == 0) { B.timings[90] += (float)((long long)wall_clock64() - lk_t0); B.timings[91] += 1.f; }
 }
 
 // stand-alone variant for the stage test: explicit images, points from arrays

@@ -74,6 +74,8 @@ struct vio_batch {
     int extra_slots = 2;              // VIO_EXTRA_SLOTS: iteration slots beyond max_iterations (1 carries the last evaluation, the second absorbs one Cholesky retry / invalid step)
     int xcd_n = 0;                    // VIO_XCD_N: override of the XCD count the map assumes (0: 8)
     int xcd_map = 1;                  // VIO_XCD_MAP: XCD-aware block map of the multi-block ps_* kernels (be_phased.h ps_blk)
+    int fe_xcd_map = 1;               // VIO_FE_XCD_MAP: the same idea for fe_lk (needs the front-end on every XCD: off under a CU partition)
+    bool fe_partitioned = false;      // the front-end streams carry a CU mask (VIO_FE_CUS > 0 with tracker lag 1)
     int ps_asm_b_blocks = 24;         // workgroups per sequence that sum the entries of H (VIO_ASM_B_BLOCKS)
     int serial_threads = 512;         // ps_serial block size (VIO_SERIAL_THREADS: 512 or 1024).  Round 3: equal speed (36.2 k vs 36.4 k frames/s); the 512-thread
                                       // build has 256 VGPRs per lane and no scratch, the 1024-thread one spills 21 registers since the matrix-core diagonal block
@@ -411,7 +413,18 @@ int launch_frontend(vio_batch *h, vio_batch::Group &g, const uint8_t *d_gray, in
     PEV(h, 2);
     fe_predict_kernel<<<dim3((C.NP + 255) / 256, S), 256, 0, st>>>(Bg);
     PEV(h, 3);
-    fe_lk_kernel<<<dim3(std::min(C.NP, C.c.max_cnt + C.c.max_cnt / 2 + 32), S), 64, 0, st>>>(Bg);  // ~1.5 x max_cnt blocks per sequence, strided over n_pts
+    {
+        const int nblk = std::min(C.NP, C.c.max_cnt + C.c.max_cnt / 2 + 32);   // ~1.5 x max_cnt blocks per sequence, strided over n_pts
+        if (h->fe_xcd_map && !h->fe_partitioned && S >= 8) {   // VIO_FE_XCD_MAP: all feature blocks of a sequence on one XCD (fe_lk_kernel)
+            Batch Bl = Bg;
+            Bl.ns = S; Bl.xcd_nb = nblk;
+            fe_lk_kernel<<<dim3((unsigned)(8 * ((S + 7) / 8) * nblk)), 64, 0, st>>>(Bl);
+        } else {
+            Batch Bl = Bg;
+            Bl.xcd_nb = 0;
+            fe_lk_kernel<<<dim3(nblk, S), 64, 0, st>>>(Bl);
+        }
+    }
     PEV(h, 4);
     fe_select_kernel<<<S, 256, h->lds_select, st>>>(Bg);
     PEV(h, 5);
@@ -766,9 +779,15 @@ static int create_group_streams(vio_batch *h, vio_batch::Group &g, bool partitio
     int n_cu = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 0;
     const char *fe_cus_env = getenv("VIO_FE_CUS");
-    const int fe_cus = fe_cus_env ? atoi(fe_cus_env) : n_cu / 4;
+    // Round 4: no partition by default.  The front-end of a 64-sequence group now takes 0.8 ms on the whole device (2.7 ms on its 64-CU
+    // partition in round 3) and no longer slows the solver chain measurably (43.4 k frames/s either way), and on every XCD the XCD-aware
+    // block map of fe_lk cuts its HBM-side traffic to a third.  VIO_FE_CUS = n > 0 restores the partition (and switches that map off: under a
+    // CU mask the workgroup -> XCD rotation it relies on does not hold).
+    const int fe_cus = fe_cus_env ? atoi(fe_cus_env) : 0;
     hipError_t e_fe, e_be;
+    h->fe_partitioned = false;
     if (partitioned && n_cu >= 8 && n_cu <= 1024 && fe_cus > 0 && fe_cus < n_cu) {
+        h->fe_partitioned = true;
         const int nw = (n_cu + 31) / 32;
         std::vector<uint32_t> mfe(nw, 0u), mbe(nw, 0u);
         const int ng = (int)h->groups.size(), gi = (int)(&g - &h->groups[0]);
@@ -832,6 +851,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     if (getenv("VIO_ASM_B_BLOCKS")) h->ps_asm_b_blocks = std::max(1, std::min(256, atoi(getenv("VIO_ASM_B_BLOCKS"))));
     if (getenv("VIO_EVAL_OCC")) h->eval_occ = atoi(getenv("VIO_EVAL_OCC"));
     if (getenv("VIO_XCD_MAP")) h->xcd_map = atoi(getenv("VIO_XCD_MAP"));
+    if (getenv("VIO_FE_XCD_MAP")) h->fe_xcd_map = atoi(getenv("VIO_FE_XCD_MAP"));
     if (getenv("VIO_XCD_N")) h->xcd_n = atoi(getenv("VIO_XCD_N"));
     if (getenv("VIO_EXTRA_SLOTS")) h->extra_slots = std::max(1, atoi(getenv("VIO_EXTRA_SLOTS")));
     if (getenv("VIO_ASM_A_OCC")) h->asm_a_occ4 = atoi(getenv("VIO_ASM_A_OCC")) >= 4;
