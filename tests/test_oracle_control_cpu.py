@@ -1,0 +1,47 @@
+"""The oracle-vs-oracle control experiment in small (tests/oracle_control.py, DESIGN.md 3 "Round 4"; the full 128 x 300 run is
+profiles/round4_oracle_self_divergence.json): other builds of the oracle's own sources, differing only in round-off, on 8 sequences x 80 frames.
+Checks the instrument, not a statistic: the base run is deterministic, the perturbed builds really differ from it, the differences start at
+round-off level (far below a micrometre over the first frames) -- and whatever they grow to within 80 frames stays a plausible trajectory."""
+import multiprocessing as mp
+import os
+
+import numpy as np
+
+import oracle_control as OC
+import vio_ct
+
+SEQS, FRAMES = list(range(700, 708)), 80
+
+
+def _job(seq):
+    return seq, OC.run_variants(seq, FRAMES, ["base", "order", "befma", "fma", "eps9"])
+
+
+def test_perturbed_builds_of_the_oracle_start_at_round_off_and_drift_apart():
+    for so in ("liboracle.so", "liboracle_order.so", "liboracle_befma.so", "liboracle_fma.so"):
+        vio_ct.oracle(os.path.join(vio_ct.ORACLE_DIR, so))          # builds the control libraries when missing (oracle/Makefile `control`)
+    with mp.get_context("spawn").Pool(min(8, len(os.sched_getaffinity(0)))) as pool:
+        res = dict(pool.map(_job, SEQS, chunksize=1))
+    again = OC.run_variants(SEQS[0], FRAMES, ["base"])
+    assert np.array_equal(again["base_pos"], res[SEQS[0]]["base_pos"])          # the oracle itself is deterministic
+    early = {"order": [], "befma": [], "fma": [], "eps9": []}
+    late = {k: [] for k in early}
+    for s in SEQS:
+        z = res[s]
+        assert len(z["base_pos"]) >= 40
+        for k in early:
+            n = min(len(z["base_pos"]), len(z[k + "_pos"]))
+            d = np.linalg.norm(z["base_pos"][:n] - z[k + "_pos"][:n], axis=1)
+            early[k].append(d[:15].max())
+            late[k].append(d.max())
+            if k != "fma":
+                assert np.array_equal(z["base_status"][:20], z[k + "_status"][:20]), (s, k)   # identical decisions while the difference is tiny
+    for k in ("order", "befma"):
+        assert 0 < max(early[k]) < 1e-9, (k, early[k])          # back-end round-off: 1e-13 ... 1e-11 m over the first frames, not zero
+        assert max(late[k]) < 0.1
+    # (fused multiply-adds in the tracker's float code move LK / RANSAC results at once: the tracks differ from the first frames on)
+    assert 0 < max(early["fma"]) < 1e-2 and max(late["fma"]) < 0.1
+    # a 1e-9 relative perturbation of the prior is visible at once (1e-10 ... 1e-8 m) and larger than the round-off ones
+    assert np.median(early["eps9"]) > np.median(early["order"]) and max(late["eps9"]) < 0.1
+    # the differences grow: somewhere within 80 frames at least one perturbed run is orders of magnitude further from the base than it started
+    assert max(max(late[k]) / max(min(early[k]), 1e-16) for k in early) > 1e3
