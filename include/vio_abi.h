@@ -59,6 +59,9 @@ typedef struct vio_config {
                                        landmark that starts in frame 0) with the 1e-8 cut, then eigen-decomposition of the reduced system and the
                                        prior rebuilt from the truncated factors J = S^1/2 V^T, r = S^-1/2 V^T b.  0 (default) = the fast form
                                        (analytic landmark elimination, prior kept as a quadratic form; DESIGN.md deviations 10 / 13). */
+    int32_t equalize;               /* EQUALIZE (yaml key `equalize`, parameters.cpp:110): 1 = cv::createCLAHE(3.0, Size(8, 8)) on every image
+                                       before tracking (feature_tracker.cpp:269-275).  Occupies what used to be alignment padding: the
+                                       offsets of all other fields are unchanged. */
     double fx, fy, cx, cy, k1, k2, p1, p2; /* pinhole projection_parameters / distortion_parameters */
     double focal_length;            /* FOCAL_LENGTH = 460 (parameters.h:11) */
     double f_threshold;             /* F_THRESHOLD */
@@ -264,6 +267,8 @@ void *vio_get_stream(vio_batch *h);
 /* ---- single stages, exposed for the parity tests (same kernels the pipeline launches) ---- */
 /* cv::pyrDown inside calcOpticalFlowPyrLK (feature_tracker.cpp:302-305) */
 int vio_stage_pyr_down(const uint8_t *src, int w, int h, uint8_t *dst);
+/* cv::createCLAHE(3.0, Size(8, 8))->apply (feature_tracker.cpp:269-275, EQUALIZE) */
+int vio_stage_clahe(const uint8_t *src, int w, int h, uint8_t *dst);
 /* FastFeatureDetector::detect on a ROI, before the mask filter (feature_tracker.cpp:109-110): returns count, out = x,y,score */
 int vio_stage_fast_roi(const uint8_t *img, int W, int H, int rx, int ry, int rw, int rh, int cap, float *out_xys);
 /* cv::calcOpticalFlowPyrLK(21x21, maxLevel, {COUNT+EPS,30,0.01}, OPTFLOW_USE_INITIAL_FLOW) */

@@ -185,6 +185,7 @@ void ovio_cam_lift(const Config *c, int n, const double *uv, double *xy) {
 void ovio_cam_project(const Config *c, int n, const double *XYZ, double *uv) {
     for (int i = 0; i < n; i++) cam_project(*c, XYZ[3 * i], XYZ[3 * i + 1], XYZ[3 * i + 2], uv[2 * i], uv[2 * i + 1]);
 }
+void ovio_clahe(const uint8_t *src, int w, int h, uint8_t *dst) { clahe_apply(src, w, h, dst, 3.0, 8); }
 void ovio_pyr_down(const uint8_t *src, int w, int h, uint8_t *dst) {
     Image s, d;
     s.w = w; s.h = h; s.d.assign(src, src + (size_t)w * h);

@@ -74,6 +74,66 @@ void pyr_down(const Image &src, Image &dst) {
     }
 }
 
+// cv::createCLAHE(clip, Size(tiles, tiles))->apply of FeatureTracker::readImage (feature_tracker.cpp:269-275; EQUALIZE).  The algorithm is
+// OpenCV's (modules/imgproc/src/clahe.cpp, not in the reference tree -- restated from its published form, parity unpinned like the other
+// OpenCV restatements): per-tile 256-bin histogram, clip at int(clip * tileArea / 256), the excess spread evenly plus one count on every
+// (256 / residual)-th bin, LUT = round(cdf * 255 / tileArea); every pixel interpolates bilinearly between the LUTs of the four nearest tile
+// centres (float arithmetic in this exact association, round-half-even).  A size that is not a multiple of `tiles` is padded at the bottom /
+// right by tiles - (size % tiles) with BORDER_REFLECT_101 -- in BOTH directions, as cv::copyMakeBorder is called there.
+void clahe_apply(const uint8_t *src, int W, int H, uint8_t *dst, double clip, int tiles) {
+    int We = W, He = H;
+    if (W % tiles != 0 || H % tiles != 0) { We = W + tiles - (W % tiles); He = H + tiles - (H % tiles); }
+    const int tw = We / tiles, th = He / tiles, area = tw * th;
+    const float lutScale = (float)(256 - 1) / area;
+    int clipLimit = 0;
+    if (clip > 0.0) { clipLimit = (int)(clip * area / 256); if (clipLimit < 1) clipLimit = 1; }
+    std::vector<uint8_t> lut((size_t)tiles * tiles * 256);
+    for (int k = 0; k < tiles * tiles; k++) {
+        const int ty = k / tiles, tx = k % tiles;
+        int hist[256] = {0};
+        for (int y = 0; y < th; y++) {
+            const int sy = reflect101(ty * th + y, H);
+            for (int x = 0; x < tw; x++) hist[src[(size_t)sy * W + reflect101(tx * tw + x, W)]]++;
+        }
+        if (clipLimit > 0) {
+            int clipped = 0;
+            for (int i = 0; i < 256; i++)
+                if (hist[i] > clipLimit) { clipped += hist[i] - clipLimit; hist[i] = clipLimit; }
+            const int batch = clipped / 256;
+            int residual = clipped - batch * 256;
+            for (int i = 0; i < 256; i++) hist[i] += batch;
+            if (residual != 0) {
+                const int step = std::max(256 / residual, 1);
+                for (int i = 0; i < 256 && residual > 0; i += step, residual--) hist[i]++;
+            }
+        }
+        int sum = 0;
+        for (int i = 0; i < 256; i++) {
+            sum += hist[i];
+            int v = cvRoundf(sum * lutScale);
+            lut[(size_t)k * 256 + i] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+        }
+    }
+    const float inv_tw = 1.0f / tw, inv_th = 1.0f / th;
+    for (int y = 0; y < H; y++) {
+        const float tyf = y * inv_th - 0.5f;
+        int ty1 = cvFloorf(tyf), ty2 = ty1 + 1;
+        const float ya = tyf - ty1, ya1 = 1.0f - ya;
+        ty1 = std::max(ty1, 0); ty2 = std::min(ty2, tiles - 1);
+        for (int x = 0; x < W; x++) {
+            const float txf = x * inv_tw - 0.5f;
+            int tx1 = cvFloorf(txf), tx2 = tx1 + 1;
+            const float xa = txf - tx1, xa1 = 1.0f - xa;
+            tx1 = std::max(tx1, 0); tx2 = std::min(tx2, tiles - 1);
+            const int v = src[(size_t)y * W + x];
+            const uint8_t *p1 = &lut[(size_t)ty1 * tiles * 256], *p2 = &lut[(size_t)ty2 * tiles * 256];
+            const float res = (p1[tx1 * 256 + v] * xa1 + p1[tx2 * 256 + v] * xa) * ya1 + (p2[tx1 * 256 + v] * xa1 + p2[tx2 * 256 + v] * xa) * ya;
+            const int r = cvRoundf(res);
+            dst[(size_t)y * W + x] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ FAST-9/16
 static const int RING_DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
 static const int RING_DY[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
@@ -608,7 +668,11 @@ void Tracker::readImage(const uint8_t *img, double t, const double R[9], bool pu
     int maxLevel = cfg.lk_max_level;
     std::vector<Image> pyr(maxLevel + 1);
     pyr[0].w = cfg.width; pyr[0].h = cfg.height;
-    pyr[0].d.assign(img, img + (size_t)cfg.width * cfg.height);
+    if (cfg.equalize) {   // :269-275
+        pyr[0].d.resize((size_t)cfg.width * cfg.height);
+        clahe_apply(img, cfg.width, cfg.height, pyr[0].d.data(), 3.0, 8);
+    } else
+        pyr[0].d.assign(img, img + (size_t)cfg.width * cfg.height);
     for (int l = 1; l <= maxLevel; l++) pyr_down(pyr[l - 1], pyr[l]);
     if (!has_img) {
         cur_pyr = pyr;

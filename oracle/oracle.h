@@ -35,6 +35,7 @@ struct Config {
                                        // oldest frame constant, per-frame solvePnP initial guess, LK with maxLevel 3 and no prediction)
     int reference_quirks = 0;          // bit 0: latestOdometry replays the buffered IMU with the FRONT sample's values (estimator.cpp:1779-1786)
     int marg_exact = 0;                // product-side switch (the oracle always follows marginalization_factor.cpp:281-315); layout only
+    int equalize = 0;                  // EQUALIZE (parameters.cpp:110): cv::createCLAHE(3.0, Size(8, 8)) on the image before tracking
     double fx = 604.5821781259577, fy = 604.2544712985845, cx = 321.2638233484251, cy = 239.70969315130674;
     double k1 = 0.13387871564774004, k2 = -0.2731913133377051, p1 = 0.0020296263577681264, p2 = -0.00044384544608203714;
     double focal_length = 460.0;       // FOCAL_LENGTH
@@ -66,6 +67,7 @@ void cam_project(const Config &c, double X, double Y, double Z, double &u, doubl
 
 // ------------------------------------------------------------------------------------ vision primitives
 void pyr_down(const Image &src, Image &dst);
+void clahe_apply(const uint8_t *src, int W, int H, uint8_t *dst, double clip = 3.0, int tiles = 8);
 // FAST-9/16 threshold 10 + NMS on a ROI, row-major order, ROI-relative coordinates
 void fast_detect_roi(const uint8_t *img, int W, int H, int rx, int ry, int rw, int rh, std::vector<KeyPt> &out, int thr = 10);
 int fast_corner_score(const uint8_t *p, int stride, int thr);  // returns 0 if not a corner

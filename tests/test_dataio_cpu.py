@@ -105,8 +105,15 @@ def test_imu_zero_selects_vo_mode(P, io):
     assert io.config_from_yaml(YAML, P)[0].use_imu == 1
 
 
-@pytest.mark.parametrize("line,what", [("fisheye: 1", "fisheye"),
-                                       ("equalize: 1", "CLAHE"), ("estimate_extrinsic: 2", "extrinsic")])
+def test_equalize_selects_clahe(P, io):
+    """equalize: 1 (parameters.cpp:110) -> vio_config.equalize, the CLAHE branch of readImage (feature_tracker.cpp:269-275)"""
+    txt = "\n".join(l for l in YAML.splitlines() if not l.startswith("equalize:")) + "\nequalize: 1\n"
+    cfg, extra = io.config_from_yaml(txt, P)
+    assert cfg.equalize == 1 and extra["notes"] == []
+    assert io.config_from_yaml(YAML, P)[0].equalize == 0
+
+
+@pytest.mark.parametrize("line,what", [("fisheye: 1", "fisheye"), ("estimate_extrinsic: 2", "extrinsic")])
 def test_out_of_scope_settings_fail_loudly(P, io, line, what):
     key = line.split(":")[0]
     txt = "\n".join(l for l in YAML.splitlines() if not l.startswith(key + ":")) + "\n" + line + "\n"

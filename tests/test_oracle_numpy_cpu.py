@@ -230,3 +230,53 @@ def test_seven_point_against_numpy_nullspace_and_roots(seed):
     # and the true fundamental matrix of the motion is one of them
     Ft = _skew(t) @ R
     assert min(np.abs(unit(F) - unit(Ft)).max() for F in Fo) < 1e-6
+
+
+def _clahe_numpy(img, clip=3.0, tiles=8):
+    """Independent (vectorised) restatement of cv::CLAHE for sizes that are multiples of `tiles`."""
+    H, W = img.shape
+    th, tw = H // tiles, W // tiles
+    area = th * tw
+    lim = max(int(clip * area / 256), 1)
+    t = img.reshape(tiles, th, tiles, tw).transpose(0, 2, 1, 3).reshape(tiles * tiles, area)
+    hist = np.stack([np.bincount(r, minlength=256) for r in t]).astype(np.int64)
+    clipped = np.maximum(hist - lim, 0).sum(1)
+    hist = np.minimum(hist, lim) + (clipped // 256)[:, None]
+    for k, res in enumerate(clipped % 256):
+        if res:
+            step = max(256 // res, 1)
+            idx = np.arange(0, 256, step)[:res]
+            hist[k, idx] += 1
+    scale = np.float32(255) / np.float32(area)
+    lut = np.clip(np.rint(np.cumsum(hist, 1).astype(np.float32) * scale), 0, 255).astype(np.uint8).reshape(tiles, tiles, 256)
+    f32 = np.float32
+    tyf = np.arange(H, dtype=f32) * (f32(1) / f32(th)) - f32(0.5)
+    txf = np.arange(W, dtype=f32) * (f32(1) / f32(tw)) - f32(0.5)
+    ty1, tx1 = np.floor(tyf).astype(int), np.floor(txf).astype(int)
+    ya, xa = (tyf - ty1.astype(f32))[:, None], (txf - tx1.astype(f32))[None, :]
+    ya1, xa1 = f32(1) - ya, f32(1) - xa
+    ty2, tx2 = np.minimum(ty1 + 1, tiles - 1)[:, None], np.minimum(tx1 + 1, tiles - 1)[None, :]
+    ty1, tx1 = np.maximum(ty1, 0)[:, None], np.maximum(tx1, 0)[None, :]
+    v = img.astype(int)
+    g = lambda a, b: lut[a, b, v].astype(f32)
+    res = (g(ty1, tx1) * xa1 + g(ty1, tx2) * xa) * ya1 + (g(ty2, tx1) * xa1 + g(ty2, tx2) * xa) * ya
+    return np.clip(np.rint(res), 0, 255).astype(np.uint8)
+
+
+def test_clahe_restatement_agrees_with_a_vectorised_one():
+    """EQUALIZE (feature_tracker.cpp:269-275).  No OpenCV here: the oracle's loop restatement against an independent numpy one, plus the
+    hand-computed case of a constant tile (4800 pixels of one value: clip 56, 4744 redistributed = 18 per bin + 1 on bins 0..135)."""
+    L = vio_ct.oracle()
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:480, 0:640]
+    imgs = [rng.integers(0, 256, (480, 640), dtype=np.uint8), (40 + 30 * np.sin(xx / 17.0) * np.cos(yy / 23.0)).astype(np.uint8),
+            rng.integers(90, 110, (720, 1280), dtype=np.uint8), np.full((480, 848), 200, np.uint8)]
+    for img in imgs:
+        out = np.zeros_like(img)
+        L.ovio_clahe(img.ctypes.data, img.shape[1], img.shape[0], out.ctypes.data)
+        assert np.array_equal(out, _clahe_numpy(img))
+    const = np.full((480, 640), 77, np.uint8)
+    out = np.zeros_like(const)
+    L.ovio_clahe(const.ctypes.data, 640, 480, out.ctypes.data)
+    cdf77 = 18 * 78 + 78 + 56          # bins 0..77: 18 each, +1 each (all below 136), +56 in bin 77
+    assert (out == int(np.rint(np.float32(cdf77) * (np.float32(255) / np.float32(4800))))).all()

@@ -71,6 +71,7 @@ def oracle(path=None):
             "ovio_cam_lift": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
             "ovio_cam_project": [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p],
             "ovio_pyr_down": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
+            "ovio_clahe": [C.c_void_p, C.c_int, C.c_int, C.c_void_p],
             "ovio_fast_score": [C.c_void_p],
             "ovio_fast_roi": [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p],
             "ovio_circle_hw": [C.c_int, C.c_void_p],

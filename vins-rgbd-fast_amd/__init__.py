@@ -32,7 +32,7 @@ class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "width", "height", "max_cnt", "min_dist", "grid_rows", "grid_cols", "window_size", "max_landmarks", "fix_depth",
         "estimate_extrinsic", "estimate_td", "max_iterations", "ransac_max_iters", "lk_max_level", "dynamic_init", "use_imu", "reference_quirks",
-        "marg_exact")] + \
+        "marg_exact", "equalize")] + \
         [(n, C.c_double) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "focal_length", "f_threshold", "depth_min",
                                    "depth_max", "acc_n", "acc_w", "gyr_n", "gyr_w", "g_norm")] + \
         [("ric", C.c_double * 9), ("tic", C.c_double * 3)] + \
@@ -123,6 +123,7 @@ def lib():
         L.vio_synth_render_host.argtypes = [C.POINTER(SynthConfig), C.c_uint64, C.c_double, C.c_void_p, C.c_void_p]
         L.vio_synth_render_device.argtypes = [C.POINTER(SynthConfig), C.c_int, C.c_uint64, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vio_stage_pyr_down.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.vio_stage_clahe.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.vio_stage_fast_roi.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.c_void_p]
         L.vio_stage_lk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.vio_stage_ransac.argtypes = [C.POINTER(Config), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -421,6 +421,115 @@ __global__ __launch_bounds__(256) void fe_pyrdown_stage_kernel(const uint8_t *sr
     pyrdown_tile(src, sw, sh, dst, nullptr);
 }
 
+// ------------------------------------------------------------------------------------------------ fe_clahe
+// EQUALIZE: cv::createCLAHE(3.0, Size(8, 8))->apply (feature_tracker.cpp:269-275), two launches per frame.
+// fe_clahe_lut: grid (64 tiles, n sequences), 256 threads = the 256 bins: histogram of the tile in LDS (integer atomics, exact in any
+// order), clip at int(3 * area / 256), even redistribution + one count on every (256 / residual)-th bin, inclusive scan, LUT byte.
+// A size that is not a multiple of 8 is padded bottom / right with BORDER_REFLECT_101 by 8 - (size % 8) in both directions.
+struct ClaheGeo { int tw, th, clip; float lut_scale; };
+__device__ __forceinline__ ClaheGeo clahe_geo(int W, int H) {
+    int We = W, He = H;
+    if ((W & 7) || (H & 7)) { We = W + 8 - (W & 7); He = H + 8 - (H & 7); }
+    ClaheGeo g;
+    g.tw = We >> 3; g.th = He >> 3;
+    const int area = g.tw * g.th;
+    g.clip = max((int)(3.0 * area / 256), 1);
+    g.lut_scale = (float)255 / area;
+    return g;
+}
+__device__ void clahe_lut_tile(const uint8_t *src, int W, int H, int k, uint8_t *lut) {
+    __shared__ int hist[256];
+    __shared__ int wsum[4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const ClaheGeo g = clahe_geo(W, H);
+    const int ty = k >> 3, tx = k & 7;
+    hist[t] = 0;
+    __syncthreads();
+    for (int i = t; i < g.tw * g.th; i += 256) {
+        const int y = i / g.tw, x = i - y * g.tw;
+        atomicAdd(&hist[src[(size_t)reflect101(ty * g.th + y, H) * W + reflect101(tx * g.tw + x, W)]], 1);
+    }
+    __syncthreads();
+    int hv = hist[t];
+    int excess = max(hv - g.clip, 0);
+    hv = min(hv, g.clip);
+    int e = excess;
+    for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
+    if (lane == 0) wsum[wv] = e;
+    __syncthreads();
+    const int clipped = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const int batch = clipped >> 8, residual = clipped - (batch << 8);
+    hv += batch;
+    if (residual != 0) {
+        const int step = max(256 / residual, 1);
+        if (t % step == 0 && t / step < residual) hv++;
+    }
+    __syncthreads();
+    // inclusive scan over the 256 bins
+    int v = hv;
+    for (int o = 1; o < 64; o <<= 1) {
+        int u = __shfl_up(v, o);
+        if (lane >= o) v += u;
+    }
+    if (lane == 63) wsum[wv] = v;
+    __syncthreads();
+    for (int w = 0; w < wv; w++) v += wsum[w];
+    const int r = (int)rintf(v * g.lut_scale);
+    lut[(size_t)k * 256 + t] = (uint8_t)min(max(r, 0), 255);
+}
+// interpolation between the LUTs of the four nearest tile centres, the float expression of the CPU code operation by operation
+__device__ __forceinline__ uint8_t clahe_pixel(const uint8_t *lut, const ClaheGeo &g, int x, int v, const uint8_t *p1, const uint8_t *p2, float ya,
+                                               float ya1, float inv_tw) {
+    const float txf = x * inv_tw - 0.5f;
+    int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+    const float xa = txf - tx1, xa1 = 1.0f - xa;
+    tx1 = max(tx1, 0); tx2 = min(tx2, 7);
+    const float res = (p1[tx1 * 256 + v] * xa1 + p1[tx2 * 256 + v] * xa) * ya1 + (p2[tx1 * 256 + v] * xa1 + p2[tx2 * 256 + v] * xa) * ya;
+    return (uint8_t)min(max((int)rintf(res), 0), 255);
+}
+__device__ void clahe_apply_rows(const uint8_t *src, int W, int H, const uint8_t *lut, uint8_t *dst) {
+    const ClaheGeo g = clahe_geo(W, H);
+    const float inv_tw = 1.0f / g.tw, inv_th = 1.0f / g.th;
+    const int y = blockIdx.y;
+    const float tyf = y * inv_th - 0.5f;
+    int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+    const float ya = tyf - ty1, ya1 = 1.0f - ya;
+    ty1 = max(ty1, 0); ty2 = min(ty2, 7);
+    const uint8_t *p1 = lut + (size_t)ty1 * 8 * 256, *p2 = lut + (size_t)ty2 * 8 * 256;
+    const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (x0 >= W) return;
+    const uint8_t *sr = src + (size_t)y * W;
+    uint8_t *dr = dst + (size_t)y * W;
+    if ((W & 3) == 0) {
+        const uint32_t px = *(const uint32_t *)(sr + x0);
+        uint32_t o = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) o |= (uint32_t)clahe_pixel(lut, g, x0 + j, (px >> (8 * j)) & 255, p1, p2, ya, ya1, inv_tw) << (8 * j);
+        *(uint32_t *)(dr + x0) = o;
+    } else {
+        for (int j = 0; j < 4 && x0 + j < W; j++) dr[x0 + j] = clahe_pixel(lut, g, x0 + j, sr[x0 + j], p1, p2, ya, ya1, inv_tw);
+    }
+}
+__global__ __launch_bounds__(256) void fe_clahe_lut_kernel(Batch B, const uint8_t *src_base, size_t stride) {
+    const DevCfg &C = *B.cfg;
+    const int s = blockIdx.y + B.s0;
+    if (B.fe[s].n_forw < 0) return;
+    clahe_lut_tile(src_base + (size_t)s * stride, C.c.width, C.c.height, blockIdx.x, B.clahe_lut + (size_t)s * 64 * 256);
+}
+// grid (ceil(W / 1024), H, n sequences), four pixels per thread
+__global__ __launch_bounds__(256) void fe_clahe_apply_kernel(Batch B, const uint8_t *src_base, size_t stride) {
+    const DevCfg &C = *B.cfg;
+    const int s = blockIdx.z + B.s0;
+    if (B.fe[s].n_forw < 0) return;
+    clahe_apply_rows(src_base + (size_t)s * stride, C.c.width, C.c.height, B.clahe_lut + (size_t)s * 64 * 256, B.clahe_img + (size_t)s * stride);
+}
+__global__ __launch_bounds__(256) void fe_clahe_lut_stage_kernel(const uint8_t *src, int W, int H, uint8_t *lut) {
+    clahe_lut_tile(src, W, H, blockIdx.x, lut);
+}
+__global__ __launch_bounds__(256) void fe_clahe_apply_stage_kernel(const uint8_t *src, int W, int H, const uint8_t *lut, uint8_t *dst) {
+    clahe_apply_rows(src, W, H, lut, dst);
+}
+
 // ------------------------------------------------------------------------------------------------ fe_predict
 // predictPtsInNextFrame (feature_tracker.cpp:595-608). grid (ceil(NP/256), S)
 __global__ void fe_predict_kernel(Batch B) {

@@ -23,6 +23,10 @@ __global__ void be_latest_odometry_kernel(Batch B, int seq, double *out11);
 __global__ void fe_predict_motion_kernel(Batch B, int seq, double t0, double t1, double *out9);
 __global__ void fe_pyrdown_kernel(Batch B, const uint8_t *src_base, size_t src_stride, int sw, int sh, int dst_level, int write_level0);
 __global__ void fe_pyrdown_stage_kernel(const uint8_t *src, int sw, int sh, uint8_t *dst);
+__global__ void fe_clahe_lut_kernel(Batch B, const uint8_t *src_base, size_t stride);
+__global__ void fe_clahe_apply_kernel(Batch B, const uint8_t *src_base, size_t stride);
+__global__ void fe_clahe_lut_stage_kernel(const uint8_t *src, int W, int H, uint8_t *lut);
+__global__ void fe_clahe_apply_stage_kernel(const uint8_t *src, int W, int H, const uint8_t *lut, uint8_t *dst);
 __global__ void fe_predict_kernel(Batch B);
 __global__ void fe_lk_kernel(Batch B);
 __global__ void fe_lk_stage_kernel(LkImages im, int maxLevel, int n, const float2 *prevPts, float2 *nextPts, uint8_t *status);

@@ -400,6 +400,12 @@ int launch_frontend(vio_batch *h, vio_batch::Group &g, const uint8_t *d_gray, in
     PEV(h, 0);
     fe_begin_kernel<<<S, 64, 0, st>>>(Bg, h->d_stamps, gate, publish, d_modes, d_rrel);
     PEV(h, 1);
+    if (C.c.equalize) {   // EQUALIZE (feature_tracker.cpp:269-275): the tracker sees the CLAHE image
+        const size_t HW = (size_t)Wd * Ht;
+        fe_clahe_lut_kernel<<<dim3(64, S), 256, 0, st>>>(Bg, d_gray, HW);
+        fe_clahe_apply_kernel<<<dim3((Wd + 1023) / 1024, Ht, S), 256, 0, st>>>(Bg, d_gray, HW);
+        d_gray = h->B.clahe_img;
+    }
     // pyramid: level 1 from the new frame (+ level-0 copy), further levels from the previous one
     {
         int sw = Wd, sh = Ht;
@@ -760,6 +766,7 @@ static int build_devcfg(const vio_config *cfg, int imu_capacity, DevCfg &C) {
     }
     C.pyr_bytes = off;
     if (c.marg_exact < 0 || c.marg_exact > 1) { g_err = "marg_exact must be 0 or 1"; return VIO_EINVAL; }
+    if (c.equalize < 0 || c.equalize > 1) { g_err = "equalize must be 0 or 1"; return VIO_EINVAL; }
     C.MX = c.marg_exact ? std::min(15 + C.NP, 495) : 0;   // a landmark that starts in frame 0 was packaged by the tracker in that frame: at most NP of them
     return VIO_OK;
 }
@@ -824,6 +831,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
 #define DA(ptr, n) if (rc == VIO_OK) rc = dalloc(h, &ptr, (size_t)(n))
     DA(B.cfg, 1); DA(B.fe, S); DA(B.be, S); DA(B.pre, S * (C.W + 2));
     DA(B.img, S * 2 * HW); DA(B.pyr, S * 2 * (size_t)C.pyr_bytes);
+    if (C.c.equalize) { DA(B.clahe_lut, S * 64 * 256); DA(B.clahe_img, S * HW); }
     DA(B.cur_pts, S * NP); DA(B.forw_pts, S * NP); DA(B.cur_un_pts, S * NP); DA(B.pts_velocity, S * NP); DA(B.prev_un_pt, S * NP);
     DA(B.unstable_pts, S * NP); DA(B.tmp_pts, S * NP);
     DA(B.ids, S * NP); DA(B.track_cnt, S * NP); DA(B.prev_un_id, S * NP); DA(B.tmp_i0, S * NP); DA(B.tmp_i1, S * NP);
@@ -1717,6 +1725,25 @@ int vio_stage_pyr_down(const uint8_t *src, int w, int h, uint8_t *dst) {
 done:
     if (ds) (void)hipFree(ds);
     if (dd) (void)hipFree(dd);
+    return rc;
+}
+
+int vio_stage_clahe(const uint8_t *src, int w, int h, uint8_t *dst) {
+    int rc = VIO_OK;
+    uint8_t *ds = nullptr, *dd = nullptr, *dl = nullptr;
+    if (!src || !dst || w < 8 || h < 8) return VIO_EINVAL;
+    STAGE_CHK(hipMalloc((void **)&ds, (size_t)w * h));
+    STAGE_CHK(hipMalloc((void **)&dd, (size_t)w * h));
+    STAGE_CHK(hipMalloc((void **)&dl, 64 * 256));
+    STAGE_CHK(hipMemcpy(ds, src, (size_t)w * h, hipMemcpyHostToDevice));
+    fe_clahe_lut_stage_kernel<<<64, 256>>>(ds, w, h, dl);
+    fe_clahe_apply_stage_kernel<<<dim3((w + 1023) / 1024, h), 256>>>(ds, w, h, dl, dd);
+    STAGE_CHK(hipDeviceSynchronize());
+    STAGE_CHK(hipMemcpy(dst, dd, (size_t)w * h, hipMemcpyDeviceToHost));
+done:
+    if (ds) (void)hipFree(ds);
+    if (dd) (void)hipFree(dd);
+    if (dl) (void)hipFree(dl);
     return rc;
 }
 

@@ -163,6 +163,8 @@ struct Batch {
     // ---- tracker arrays, stride NP per sequence
     uint8_t *img;         // [S][2][H*W] ping-pong level 0
     uint8_t *pyr;         // [S][2][pyr_bytes] levels >= 1
+    uint8_t *clahe_lut;   // vio_config.equalize only: [S][64 tiles][256] and the equalised frame [S][H*W]
+    uint8_t *clahe_img;
     float2 *cur_pts, *forw_pts, *cur_un_pts, *pts_velocity, *prev_un_pt, *unstable_pts;
     float2 *tmp_pts;
     int *ids, *track_cnt, *prev_un_id, *tmp_i0, *tmp_i1;
