@@ -207,6 +207,11 @@ int vio_get_odometry(vio_batch *h, double *out);
 /* CSV rows written for sequence seq.  The device keeps a ring of the last 2048 rows: out receives the most recent min(rows, 2048,
  * cap) of them in time order; returns the number of rows produced since vio_create / the last reset (may exceed what fits). */
 int vio_get_odometry_history(vio_batch *h, int seq, int cap, double *out);
+/* FISHEYE (parameters.cpp:111-114, estimator.cpp:29-36): FeatureTracker::setMask starts from fisheye_mask instead of an all-255 image
+ * (feature_tracker.cpp:175-176), so tracked and new features are only kept where the mask is 255 and FAST corners only where it is not 0.
+ * mask = ROW x COL u8 (the decoded config/fisheye_mask.jpg; decoding is the caller's), shared by all sequences of the handle; NULL turns
+ * the option off.  Synchronises the handle. */
+int vio_set_fisheye_mask(vio_batch *h, const uint8_t *mask, int on_device);
 /* How far the estimator runs behind the tracker inside vio_feed / vio_feed_modes.  The reference's process_tracker and process()
  * threads run concurrently (estimator_nodelet.cpp:192-459 / :462-549): Estimator::predictMotion of frame f+1 reads latest_Bg / td as the
  * estimator thread left them, i.e. after frame f when the estimator keeps up and after frame f-1 when it is still optimising frame f.

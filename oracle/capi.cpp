@@ -72,6 +72,11 @@ int ovio_process_obs(void *h, int n, const int *ids, const double *obs, const ui
     for (int i = 0; i < n; i++) { std::array<double, 7> a; for (int k = 0; k < 7; k++) a[k] = obs[7 * i + k]; image[ids[i]] = a; }
     return ((Pipeline *)h)->process(image, depth, t);
 }
+void ovio_set_fisheye_mask(void *h, const uint8_t *mask) {   // NULL = off
+    Pipeline *p = (Pipeline *)h;
+    if (mask) p->tracker.fisheye_mask.assign(mask, mask + (size_t)p->tracker.cfg.width * p->tracker.cfg.height);
+    else p->tracker.fisheye_mask.clear();
+}
 void ovio_set_tracker_lag(void *h, int lag) { ((Pipeline *)h)->tracker_lag = lag; }
 void ovio_latest_odometry(void *h, double *out11) { ((Pipeline *)h)->est.latestOdometry(out11); }
 void ovio_predict_motion(void *h, double t0, double t1, double *R9) { ((Pipeline *)h)->est.predictMotion(t0, t1, R9); }

@@ -568,7 +568,8 @@ void Tracker::rejectWithF() {  // :441-473
 }
 
 void Tracker::setMask() {  // :173-208 (std::sort ties pinned to original order = stable)
-    std::fill(mask.begin(), mask.end(), 255);
+    if (!fisheye_mask.empty()) mask = fisheye_mask;   // FISHEYE: mask = fisheye_mask.clone() (:175-176)
+    else std::fill(mask.begin(), mask.end(), 255);
     std::vector<int> order(forw_pts.size());
     for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return track_cnt[a] > track_cnt[b]; });

@@ -109,6 +109,7 @@ struct Tracker {
 
     explicit Tracker(const Config &c);
     void readImage(const uint8_t *img, double t, const double R[9], bool publish);
+    std::vector<uint8_t> fisheye_mask;   // FISHEYE (estimator.cpp:29-36, feature_tracker.h:68): ROW x COL, empty = off
     void updateIDs();
     bool inBorder(const P2f &pt) const;
     void rejectWithF();

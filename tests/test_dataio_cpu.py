@@ -113,7 +113,14 @@ def test_equalize_selects_clahe(P, io):
     assert io.config_from_yaml(YAML, P)[0].equalize == 0
 
 
-@pytest.mark.parametrize("line,what", [("fisheye: 1", "fisheye"), ("estimate_extrinsic: 2", "extrinsic")])
+def test_fisheye_names_the_mask_file(P, io):
+    """fisheye: 1 (parameters.cpp:111-114) -> the caller decodes config/fisheye_mask.jpg and hands it to VioBatch.set_fisheye_mask"""
+    txt = "\n".join(l for l in YAML.splitlines() if not l.startswith("fisheye:")) + "\nfisheye: 1\n"
+    assert io.config_from_yaml(txt, P)[1]["fisheye_mask"] == "config/fisheye_mask.jpg"
+    assert io.config_from_yaml(YAML, P)[1]["fisheye_mask"] is None
+
+
+@pytest.mark.parametrize("line,what", [("model_type: KANNALA_BRANDT", "camera model"), ("estimate_extrinsic: 2", "extrinsic")])
 def test_out_of_scope_settings_fail_loudly(P, io, line, what):
     key = line.split(":")[0]
     txt = "\n".join(l for l in YAML.splitlines() if not l.startswith(key + ":")) + "\n" + line + "\n"

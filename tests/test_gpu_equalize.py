@@ -69,3 +69,34 @@ def test_pipeline_with_equalize_follows_the_oracle(P):
     b.close(); b0.close()
     with pytest.raises(Exception):
         P.Batch(P.canonical_config(equalize=2), 1)
+
+
+def test_pipeline_with_a_fisheye_mask_follows_the_oracle(P):
+    """FISHEYE (estimator.cpp:29-36, feature_tracker.cpp:175-176): setMask starts from fisheye_mask.  A disk of 255 with a grey rim (a
+    decoded JPEG has one: `== 255` for tracked / added points, `!= 0` for the FAST filter) and 0 outside."""
+    n, seqs = 24, [43, 44]
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    yy, xx = np.mgrid[0:cfg.height, 0:cfg.width]
+    rr = np.hypot(xx - 320.0, yy - 240.0)
+    mask = np.where(rr < 210, 255, np.where(rr < 222, 128, 0)).astype(np.uint8)
+    oruns = [vio_ct.run_oracle_sequence(cfg, sc, s, n, fisheye_mask=mask) for s in seqs]
+    frames = [o["frames"] for o in oruns]
+    b, traj, stat = vio_ct.run_hip_batch(P, cfg, sc, seqs, n, frames, fisheye_mask=mask)
+    nl = 0
+    for i in range(len(seqs)):
+        for f in range(n):
+            so, sh = oruns[i]["status"][f], stat[i][f]
+            assert (int(so["solver_flag"]), int(so["frame_count"]), int(so["n_landmarks"]), int(so["marginalization_flag"]), int(so["last_track_num"])) == \
+                   (sh.solver_flag, sh.frame_count, sh.n_landmarks, sh.marginalization_flag, sh.last_track_num), (i, f)
+            nl += int(sh.solver_flag == 1 and sh.processed)
+        io, co, po = oruns[i]["oracle"].tracks()[:3]
+        ih, ch, ph = b.tracks(i)[:3]
+        assert np.array_equal(io, ih) and np.array_equal(co, ch) and np.array_equal(po, ph)
+        assert len(ih) > 30 and (mask[np.rint(ph[:, 1]).astype(int), np.rint(ph[:, 0]).astype(int)] == 255).all()
+        wo, wh = oruns[i]["oracle"].window(), b.window(i)
+        assert np.abs(wo[:, :3] - wh[:, :3]).max() < 1e-6
+    assert nl >= 16
+    # turning the option off again restores the unmasked tracker
+    b.set_fisheye_mask(None)
+    b.close()

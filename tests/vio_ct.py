@@ -58,6 +58,7 @@ def oracle(path=None):
             "ovio_predict_motion": [C.c_void_p, C.c_double, C.c_double, C.c_void_p],
             "ovio_latest_odometry": [C.c_void_p, C.c_void_p],
             "ovio_set_tracker_lag": [C.c_void_p, C.c_int],
+            "ovio_set_fisheye_mask": [C.c_void_p, C.c_void_p],
             "ovio_get_landmarks_ex": [C.c_void_p, C.c_int, C.c_void_p],
             "ovio_gate_create": [C.c_int, C.c_int], "ovio_gate_destroy": [C.c_void_p], "ovio_gate_step": [C.c_void_p, C.c_double],
             "ovio_gate_empty_map": [C.c_void_p, C.c_double],
@@ -146,6 +147,10 @@ class OraclePipeline:
 
     def set_tracker_lag(self, lag):
         self.L.ovio_set_tracker_lag(self.h, int(lag))
+
+    def set_fisheye_mask(self, mask):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.L.ovio_set_fisheye_mask(self.h, None if m is None else m.ctypes.data)
 
     def latest_odometry(self):
         o = np.zeros(11)
@@ -287,7 +292,7 @@ def ate_rmse(est, gt):
     return float(np.sqrt(((al - gt) ** 2).sum(1).mean()))
 
 
-def run_oracle_sequence(cfg, sc, seq, n_frames, frames=None, modes=None, hook=None, tracker_lag=0, lib=None):
+def run_oracle_sequence(cfg, sc, seq, n_frames, frames=None, modes=None, hook=None, tracker_lag=0, lib=None, fisheye_mask=None):
     """Drive the oracle over n_frames of sequence seq. frames: optional list of (gray, depth) to reuse; modes: optional per-frame
     frame mode (0 skip / 1 track / 2 publish); hook(f, oracle): called after every frame.
     Returns dict(traj=[(frame, P(3), Q(4), V(3))], gt=..., status=[...], frames=[...])."""
@@ -296,6 +301,8 @@ def run_oracle_sequence(cfg, sc, seq, n_frames, frames=None, modes=None, hook=No
     o = OraclePipeline(cfg, lib)
     if tracker_lag:
         o.set_tracker_lag(tracker_lag)
+    if fisheye_mask is not None:
+        o.set_fisheye_mask(fisheye_mask)
     nimu = int(n_frames / sc.cam_rate * sc.imu_rate) + 64
     ti, ai, gi = syn.imu(seq, nimu)
     k = 0
@@ -324,7 +331,7 @@ def run_oracle_sequence(cfg, sc, seq, n_frames, frames=None, modes=None, hook=No
     return out
 
 
-def run_hip_batch(P, cfg, sc, seqs, n_frames, frames, modes=None, hook=None, imu_batch=False, tracker_lag=0):
+def run_hip_batch(P, cfg, sc, seqs, n_frames, frames, modes=None, hook=None, imu_batch=False, tracker_lag=0, fisheye_mask=None):
     """Drive a VioBatch over host frames (frames[i][f] = (gray, depth) of sequence seqs[i]) with IMU pushed frame by frame.
     modes: optional [n_frames] frame modes applied to every sequence; hook(f, batch) after every frame.
     Returns (batch, traj, stat): per sequence [(frame, P, Q, V)] and [vio_status per frame]."""
@@ -333,6 +340,8 @@ def run_hip_batch(P, cfg, sc, seqs, n_frames, frames, modes=None, hook=None, imu
     b = P.VioBatch(cfg, S)
     if tracker_lag:
         b.set_tracker_lag(tracker_lag)
+    if fisheye_mask is not None:
+        b.set_fisheye_mask(fisheye_mask)
     nimu = int(n_frames / sc.cam_rate * sc.imu_rate) + 64
     imu = [syn.imu(s, nimu) for s in seqs]
     k = [0] * S

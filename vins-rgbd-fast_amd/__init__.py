@@ -111,6 +111,7 @@ def lib():
         L.vio_get_extrinsic.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.vio_get_latest_odometry.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.vio_set_tracker_lag.argtypes = [C.c_void_p, C.c_int]
+        L.vio_set_fisheye_mask.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.vio_get_status_all.argtypes = [C.c_void_p, C.c_void_p]
         L.vio_get_tracks.argtypes = [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 5
         L.vio_get_landmarks.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -427,6 +428,17 @@ class VioBatch:
     def set_tracker_lag(self, lag):
         """0: the tracker of frame f+1 waits for the optimisation of frame f; 1: it overlaps it, reading latest_Bg / td as of frame f-1"""
         self._chk(self.L.vio_set_tracker_lag(self.h, int(lag)), "vio_set_tracker_lag")
+
+    def set_fisheye_mask(self, mask):
+        """FISHEYE: the feature mask starts from `mask` (H x W u8, 255 = usable) instead of all 255 (feature_tracker.cpp:175-176); None = off"""
+        if mask is None:
+            self._chk(self.L.vio_set_fisheye_mask(self.h, None, 0), "vio_set_fisheye_mask")
+            return
+        on_dev = hasattr(mask, "data_ptr") and getattr(mask, "is_cuda", False)
+        m = mask if on_dev else np.ascontiguousarray(mask, np.uint8)
+        if not on_dev and m.shape != (self.cfg.height, self.cfg.width):
+            raise ValueError("fisheye mask must be height x width")
+        self._chk(self.L.vio_set_fisheye_mask(self.h, _ptr(m), 1 if on_dev else 0), "vio_set_fisheye_mask")
 
     def latest_odometry(self, seq=0):
         """IMU-rate pose (pubLatestOdometry): t, P(3), Q(wxyz), V(3) of the newest window state propagated through the IMU pushed since"""

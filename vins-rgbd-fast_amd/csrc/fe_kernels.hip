@@ -1269,6 +1269,7 @@ __global__ __launch_bounds__(256) void fe_select_kernel(Batch B) {
                 if (j < nb) {
                     bool hit = false;
                     for (int k = part; k < nacc; k += 4) hit |= in_disk(hw_s, r, px, py, acc[k].x, acc[k].y);
+                    if (part == 0 && B.fisheye) hit |= B.fisheye[(size_t)py * c.width + px] != 255;   // FISHEYE: mask starts as fisheye_mask (:175-176)
                     if (hit) atomicOr(&blk[j], 1);
                     unsigned bits = 0;
                     const int i0 = 16 * part;
@@ -1568,6 +1569,7 @@ __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int gate) {
                         const int px = rc.x + (int)(v & 0xFFF), py = rc.y + (int)((v >> 12) & 0xFFF);
                         bool hit = false;
                         for (int a = 0; a < nl; a++) hit |= in_disk(hw_s, r, px, py, lst[a].x, lst[a].y);
+                        if (B.fisheye) hit |= B.fisheye[(size_t)py * c.width + px] == 0;   // runByPixelsMask keeps mask != 0
                         pass = !hit;
                     }
                     const unsigned long long bal = __ballot(pass);
@@ -1674,11 +1676,13 @@ __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int gate) {
                         if (i < lane && in_disk(hw_s, r, px, py, xi, yi)) cf |= 1ULL << i;
                     }
                     const unsigned c_lo = (unsigned)cf, c_hi = (unsigned)(cf >> 32);
+                    // FISHEYE: addPoints wants mask == 255, the filter above only mask != 0
+                    const unsigned long long grey = B.fisheye ? __ballot(lane < nk && B.fisheye[(size_t)py * c.width + px] != 255) : 0ULL;
                     unsigned long long kept = 0;
                     int room = NP - nn;
                     for (int q = 0; q < nk; q++) {
                         const unsigned long long cq = ((unsigned long long)__builtin_amdgcn_readlane(c_hi, q) << 32) | __builtin_amdgcn_readlane(c_lo, q);
-                        if (!(cq & kept) && room > 0) { kept |= 1ULL << q; room--; }
+                        if (!(cq & kept) && !((grey >> q) & 1ULL) && room > 0) { kept |= 1ULL << q; room--; }
                     }
                     if (lane < nk && ((kept >> lane) & 1ULL)) {
                         const int pos = __popcll(kept & ((1ULL << lane) - 1ULL));
@@ -1695,6 +1699,7 @@ __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int gate) {
                         const int px = rc.x + (int)(v & 0xFFF), py = rc.y + (int)((v >> 12) & 0xFFF);
                         bool hit = false;
                         for (int k = nacc0 + lane; k < na; k += 64) hit |= in_disk(hw_s, r, px, py, acc[k].x, acc[k].y);
+                        if (B.fisheye) hit |= B.fisheye[(size_t)py * c.width + px] != 255;
                         if (!__any(hit) && nn < NP) {
                             if (t == 0) { acc[na] = make_int2(px, py); g_forw[nn] = make_float2((float)px, (float)py); g_id[nn] = -1; g_cnt[nn] = 1; }
                             na++; nn++;

@@ -83,6 +83,7 @@ struct vio_batch {
     hipStream_t fe_stream = nullptr;  // = groups[0].fe_stream
     hipEvent_t ev[4];
     std::vector<void *> allocs;
+    uint8_t *d_fisheye = nullptr;                                    // vio_set_fisheye_mask
     uint8_t *d_gray_stage = nullptr, *d_gray_stage1 = nullptr;       // [S][H][W] staging images of host-buffer calls; the second one only for vio_feed
     uint16_t *d_depth_stage = nullptr, *d_depth_stage1 = nullptr;
     double *d_stamps = nullptr;
@@ -987,6 +988,7 @@ void vio_destroy(vio_batch *h) {
     (void)hipDeviceSynchronize();
     for (void *p : h->allocs) (void)hipFree(p);
     if (h->d_gray_stage) (void)hipFree(h->d_gray_stage);
+    if (h->d_fisheye) (void)hipFree(h->d_fisheye);
     if (h->d_depth_stage) (void)hipFree(h->d_depth_stage);
     if (h->d_gray_stage1) (void)hipFree(h->d_gray_stage1);
     if (h->d_depth_stage1) (void)hipFree(h->d_depth_stage1);
@@ -1261,6 +1263,18 @@ int vio_predict_motion(vio_batch *h, int seq, double t0, double t1, double *R9) 
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(R9, h->d_r9, 9 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    return VIO_OK;
+}
+
+int vio_set_fisheye_mask(vio_batch *h, const uint8_t *mask, int on_device) {
+    if (!h) return VIO_EINVAL;
+    int rc = sync_all(h);
+    if (rc != VIO_OK) return rc;
+    const size_t HW = (size_t)h->hc.c.width * h->hc.c.height;
+    if (!mask) { h->B.fisheye = nullptr; return VIO_OK; }
+    if (!h->d_fisheye) HIPCHK(hipMalloc((void **)&h->d_fisheye, HW));
+    HIPCHK(hipMemcpy(h->d_fisheye, mask, HW, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    h->B.fisheye = h->d_fisheye;
     return VIO_OK;
 }
 

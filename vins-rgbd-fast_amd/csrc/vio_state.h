@@ -165,6 +165,7 @@ struct Batch {
     uint8_t *pyr;         // [S][2][pyr_bytes] levels >= 1
     uint8_t *clahe_lut;   // vio_config.equalize only: [S][64 tiles][256] and the equalised frame [S][H*W]
     uint8_t *clahe_img;
+    const uint8_t *fisheye;   // vio_set_fisheye_mask: [H*W] initial value of the feature mask (FISHEYE), nullptr = all 255
     float2 *cur_pts, *forw_pts, *cur_un_pts, *pts_velocity, *prev_un_pt, *unstable_pts;
     float2 *tmp_pts;
     int *ids, *track_cnt, *prev_un_id, *tmp_i0, *tmp_i1;

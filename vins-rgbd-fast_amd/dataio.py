@@ -103,7 +103,7 @@ def parse_opencv_yaml(text):
 
 def config_from_yaml(path_or_text, P=None, strict=True):
     """vio_config from a reference configuration file (parameters.cpp:81-243).  Settings that select code paths outside the
-    built hot path raise ValueError when strict (fisheye, ``estimate_extrinsic: 2``); with strict=False they are returned in the second element as a list of notes."""
+    built hot path raise ValueError when strict (``estimate_extrinsic: 2``, a camera model other than PINHOLE); with strict=False they are returned in the second element as a list of notes."""
     if P is None:
         import importlib
         P = importlib.import_module("vins-rgbd-fast_amd")
@@ -157,10 +157,12 @@ def config_from_yaml(path_or_text, P=None, strict=True):
         c.lk_max_level = 3   # calcOpticalFlowPyrLK(..., Size(21, 21), 3) without IMU prediction (feature_tracker.cpp:307-311)
         c.estimate_td = 0    # no td block without the IMU (estimator.cpp:1204)
     c.dynamic_init = 0 if int(g("static_init", 1)) else 1   # parameters.cpp:167: STATIC_INIT; 0 = SfM + visual-inertial alignment
-    need(int(g("fisheye", 0)) != 0, "fisheye masks are out of scope")
+    # FISHEYE (parameters.cpp:111-114): the mask file is <package>/config/fisheye_mask.jpg; decoding it is the caller's (no image codec here):
+    # hand the decoded ROW x COL u8 image to VioBatch.set_fisheye_mask
+    fisheye_mask = "config/fisheye_mask.jpg" if int(g("fisheye", 0)) == 1 else None
     c.equalize = 1 if int(g("equalize", 0)) else 0   # parameters.cpp:110: CLAHE before tracking
     extra = dict(freq=int(g("freq", 0)), frontend_freq=int(g("frontend_freq", 0)), output_path=g("output_path", ""),
-                 max_solver_time=float(g("max_solver_time", 0.0)), notes=notes)
+                 max_solver_time=float(g("max_solver_time", 0.0)), fisheye_mask=fisheye_mask, notes=notes)
     return c, extra
 
 
