@@ -1,8 +1,8 @@
-/* vio_posegraph.h -- C ABI of the loop-closure slice of pose_graph that needs no DBoW2 vocabulary.
+/* vio_posegraph.h -- C ABI of the loop-closure slice of pose_graph.
  *
  * The reference's pose_graph nodelet (pose_graph/src) builds a KeyFrame per estimator keyframe, asks DBoW2 for a loop candidate
- * (PoseGraph::detectLoop, pose_graph.cpp:308 -- NOT provided here: the vocabulary blob is missing from the reference tree, the caller supplies
- * the candidate), verifies it (KeyFrame::findConnection) and, on success, hands the estimator the match list (Estimator::setReloFrame =
+ * (PoseGraph::detectLoop, pose_graph.cpp:308 = vio_pg_detect_loop below; the vocabulary blob is missing from the reference tree, the caller
+ * supplies the file), verifies it (KeyFrame::findConnection) and, on success, hands the estimator the match list (Estimator::setReloFrame =
  * vio_set_relo_frame in vio_abi.h) and runs the 4-DoF pose-graph optimisation.  Each entry point names the reference interface it replaces.
  * Descriptor extraction and matching run as HIP kernels on the current device (no CPU fallback: VIO_EDEVICE without a GPU); the geometric
  * verification and the pose-graph optimisation are per-keyframe host code, like the reference's.  Plain C types, caller-owned buffers.
@@ -48,6 +48,37 @@ int vio_pg_find_connection(int n, const float *pt3d, const double *pt_id, const 
  * t_out[n][3], R_out[n][9] and drift[4] = (yaw_drift deg, t_drift(3)) of the newest keyframe (:547-553). */
 int vio_pg_optimize4dof(int n, const double *t, const double *R, const int32_t *sequence, const int32_t *loop_to, const double *loop_info,
                         double *t_out, double *R_out, double *drift);
+
+/* ---- place recognition: BriefVocabulary + BriefDatabase of PoseGraph (pose_graph.h:83-84; vendored DBoW2 under pose_graph/src/ThirdParty) ----
+ * The tree walk of every descriptor runs as a HIP kernel (no CPU fallback); bag-of-words vector, inverted file and L1 query are per-keyframe
+ * host code.  Only L1_NORM scoring (what brief_k10L6.bin uses) is supported; all four weightings are.  The reference tree does not contain the
+ * vocabulary blob (support_files/brief_k10L6.bin, .MISSING_LARGE_BLOBS): the caller supplies the file. */
+typedef struct vio_pg_voc vio_pg_voc;
+/* PoseGraph::loadVocabulary (pose_graph.cpp:44-47) = BriefVocabulary(path) -> TemplatedVocabulary::loadBin (TemplatedVocabulary.h:1509-1561) on the
+ * file format of VINSLoop::Vocabulary::deserialize (ThirdParty/VocabularyBinary.{hpp,cpp}): 6 x int32 (k, L, scoringType, weightingType, nNodes,
+ * nWords), nNodes x {int32 nodeId, int32 parentId, double weight, uint64 descriptor[4]}, nWords x {int32 nodeId, int32 wordId};
+ * db.setVocabulary(*voc, false, 0) (no direct index).  NULL on failure (vio_last_error). */
+vio_pg_voc *vio_pg_voc_load(const char *path);
+/* the same from arrays (tests, vocabularies kept in another container): node i = (node_id[i], parent_id[i], weight[i], desc[i][4]) in file order */
+vio_pg_voc *vio_pg_voc_create(int k, int L, int scoring, int weighting, int n_nodes, const int32_t *node_id, const int32_t *parent_id,
+                              const double *weight, const uint64_t *desc, int n_words, const int32_t *word_node, const int32_t *word_id);
+void vio_pg_voc_destroy(vio_pg_voc *v);
+/* out7 = k, L, scoring, weighting, nodes, words, database entries */
+int vio_pg_voc_info(const vio_pg_voc *v, int32_t *out7);
+/* TemplatedVocabulary::transform(feature, word_id, weight) (TemplatedVocabulary.h:1217-1260) for n descriptors desc[n][4] */
+int vio_pg_voc_transform(vio_pg_voc *v, const uint64_t *desc, int n, int32_t *word_id, double *word_weight);
+/* TemplatedVocabulary::transform(features, BowVector) (:1065-1122): ascending word ids and L1-normalised values; returns the vector's size */
+int vio_pg_voc_bow(vio_pg_voc *v, const uint64_t *desc, int n, int cap, int32_t *word_id, double *value);
+/* BriefDatabase::add (TemplatedDatabase.h:408-475; PoseGraph::addKeyFrameIntoVoc, pose_graph.cpp:395-408): returns the entry id (>= 0) */
+int vio_pg_db_add(vio_pg_voc *v, const uint64_t *desc, int n);
+/* BriefDatabase::query -> queryL1 (TemplatedDatabase.h): entries with id < max_id (or max_id == -1) and, as upstream, the newest entry; best
+ * first, at most max_results (> 0), scores in [0, 1].  Ties are ordered by entry id (upstream: std::sort, unspecified).  Returns the count. */
+int vio_pg_db_query(vio_pg_voc *v, const uint64_t *desc, int n, int max_results, int max_id, int32_t *ids, double *scores);
+/* PoseGraph::detectLoop (pose_graph.cpp:308-393) for the keyframe's FAST-keypoint descriptors (kp_desc of vio_pg_describe): query(4,
+ * frame_index - 50), add, then the score gates (best > 0.05 and another > 0.015, frame_index > 50) and the smallest candidate id.
+ * *loop_index = that id or -1; ids4 / scores4 / n_ret (each may be NULL) = the query's results.  Returns a status. */
+int vio_pg_detect_loop(vio_pg_voc *v, const uint64_t *desc, int n, int frame_index, int32_t *loop_index, int32_t *ids4, double *scores4,
+                       int32_t *n_ret);
 
 /* test entry: the blurred image alone */
 int vio_pg_stage_blur(const uint8_t *gray, int width, int height, uint8_t *out);

@@ -227,6 +227,37 @@ int ovio_pg_describe(const Config *cfg, const uint8_t *gray, int n_win, const fl
     if (m > 0) brief_compute(blur.data(), W, H, xy.data(), m, pattern1024, kp_desc);
     return (int)k.size();
 }
+// ---- place recognition (bow.cpp)
+void *ovio_bow_load(const char *path) { BowVoc *v = new BowVoc(); if (!v->load_bin(path)) { delete v; return nullptr; } return v; }
+void *ovio_bow_create(int k, int L, int scoring, int weighting, int nn, const int32_t *nid, const int32_t *pid, const double *w, const uint64_t *d, int nw,
+                      const int32_t *wn, const int32_t *wi) {
+    BowVoc *v = new BowVoc();
+    if (!v->build(k, L, scoring, weighting, nn, nid, pid, w, d, nw, wn, wi)) { delete v; return nullptr; }
+    return v;
+}
+void ovio_bow_destroy(void *h) { delete (BowVoc *)h; }
+void ovio_bow_info(void *h, int *out6) {
+    BowVoc *v = (BowVoc *)h;
+    out6[0] = v->k; out6[1] = v->L; out6[2] = v->scoring; out6[3] = v->weighting; out6[4] = (int)v->nodes.size() - 1; out6[5] = (int)v->words.size();
+}
+void ovio_bow_transform(void *h, const uint64_t *desc, int n, int *word_id, double *weight) {
+    for (int i = 0; i < n; i++) ((BowVoc *)h)->transform_one(desc + (size_t)i * 4, word_id[i], weight[i]);
+}
+int ovio_bow_vector(void *h, const uint64_t *desc, int n, int cap, int *word_id, double *value) {
+    std::map<int, double> v;
+    ((BowVoc *)h)->transform(desc, n, v);
+    int m = 0;
+    for (auto &e : v) { if (m < cap) { word_id[m] = e.first; value[m] = e.second; } m++; }
+    return m;
+}
+int ovio_bow_add(void *h, const uint64_t *desc, int n) { return ((BowVoc *)h)->add(desc, n); }
+int ovio_bow_query(void *h, const uint64_t *desc, int n, int max_results, int max_id, int *ids, double *scores) {
+    std::vector<std::pair<int, double>> ret;
+    ((BowVoc *)h)->query(desc, n, max_results, max_id, ret);
+    for (size_t i = 0; i < ret.size(); i++) { ids[i] = ret[i].first; scores[i] = ret[i].second; }
+    return (int)ret.size();
+}
+int ovio_bow_detect_loop(void *h, const uint64_t *desc, int n, int frame_index) { return ((BowVoc *)h)->detect_loop(desc, n, frame_index); }
 void ovio_pg_blur(const uint8_t *gray, int W, int H, uint8_t *out) { gaussian_blur_9x9(gray, W, H, out); }
 void ovio_pg_match(const uint64_t *wd, int n, const uint64_t *od, int m, int *best_index, int *best_dist) { brief_match(wd, n, od, m, best_index, best_dist); }
 int ovio_pg_find_connection(int n, const float *pt3d, const float *pt_norm, const double *pt_id, const int *match, const float *old_norm,

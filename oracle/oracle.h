@@ -79,6 +79,22 @@ void ransac_fundamental(const Config &c, const std::vector<P2f> &p1, const std::
                         std::vector<uint8_t> &status);
 
 // ------------------------------------------------------------------------------------ pose_graph (posegraph.cpp; no DBoW2 query)
+// place recognition (bow.cpp): BriefVocabulary + BriefDatabase of PoseGraph (pose_graph.h:83-84), L1 scoring only
+struct BowVoc {
+    struct Node { int parent = 0, word_id = 0; double weight = 0; uint64_t desc[4] = {0, 0, 0, 0}; std::vector<int> children; };
+    int k = 0, L = 0, scoring = 0, weighting = 0, nentries = 0;
+    std::vector<Node> nodes;                                  // [0] = root
+    std::vector<int> words;                                   // word id -> node id
+    std::vector<std::vector<std::pair<int, double>>> ifile;   // inverted file: word id -> (entry id, weight)
+    bool load_bin(const char *path);
+    bool build(int k, int L, int scoring, int weighting, int nn, const int32_t *nid, const int32_t *pid, const double *w, const uint64_t *d, int nw,
+               const int32_t *wn, const int32_t *wi);
+    void transform_one(const uint64_t *f, int &word_id, double &weight) const;
+    void transform(const uint64_t *desc, int n, std::map<int, double> &v) const;
+    int add(const uint64_t *desc, int n);
+    int query(const uint64_t *desc, int n, int max_results, int max_id, std::vector<std::pair<int, double>> &ret) const;
+    int detect_loop(const uint64_t *desc, int n, int frame_index);
+};
 void gaussian_blur_9x9(const uint8_t *src, int W, int H, uint8_t *dst);
 void brief_compute(const uint8_t *blur, int W, int H, const float *xy, int n, const int *pat, uint64_t *desc);
 void brief_match(const uint64_t *wd, int n, const uint64_t *od, int m, int *best_index, int *best_dist);

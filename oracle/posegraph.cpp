@@ -1,12 +1,11 @@
-// ORACLE (test infrastructure) -- CPU restatement of the loop-closure path of pose_graph that needs no DBoW2 vocabulary:
+// ORACLE (test infrastructure) -- CPU restatement of the loop-closure path of pose_graph (place recognition: bow.cpp):
 //   KeyFrame::computeWindowBRIEFPoint / computeBRIEFPoint   pose_graph/src/keyframe/keyframe.cpp:80-124
 //   DVision::BRIEF::compute                                 pose_graph/src/ThirdParty/DVision/BRIEF.cpp (GaussianBlur 9x9 sigma 2, then 256 pair tests)
 //   KeyFrame::searchInAera / searchByBRIEFDes / HammingDis  keyframe.cpp:126-169, 530
 //   KeyFrame::PnPRANSAC                                     keyframe.cpp:195-250  (cv::solvePnPRansac, restated in initial.cpp)
 //   KeyFrame::findConnection                                keyframe.cpp:252-528  (gating :404, :482-490; match list :491-520)
 //   PoseGraph::optimize4DoF                                 pose_graph/src/pose_graph/pose_graph.cpp:410-581, residuals pose_graph.h:102-256
-// PoseGraph::detectLoop (:308, the DBoW2 query) is NOT restated: the vocabulary blob is missing from the reference tree; callers supply the
-// candidate keyframe.  Parity unpinned like the rest of oracle/: OpenCV's GaussianBlur / FAST / solvePnPRansac and Ceres' LM are restated
+// PoseGraph::detectLoop (:308, the DBoW2 query) is restated in bow.cpp.  Parity unpinned like the rest of oracle/: OpenCV's GaussianBlur / FAST / solvePnPRansac and Ceres' LM are restated
 // from their published algorithms.  Only tests/ may use this file.
 #include <algorithm>
 #include <cmath>

@@ -5,8 +5,10 @@
     batch.set_relo_frame(seq, kf.time_stamp, kf.index, kf.match_points, old_kf.T_w_i, old_kf.R_w_i)                   # Estimator::setReloFrame
     t, R, drift = optimize4DoF(t, R, sequence, loop_to, loop_info)                                                    # pose_graph.cpp:410-581
 
-PoseGraph::detectLoop (the DBoW2 query) is not provided: the vocabulary blob is missing from the reference tree, the caller picks old_kf.
-Descriptor extraction and matching are HIP kernels; there is no CPU fallback."""
+    voc = Vocabulary.load("brief_k10L6.bin")        # PoseGraph::loadVocabulary (the blob is missing from the reference tree: the caller's file)
+    loop_index = voc.detectLoop(kf.brief_descriptors, kf.index)     # PoseGraph::detectLoop, pose_graph.cpp:308-393 (-1: none)
+
+Descriptor extraction, matching and the vocabulary walk are HIP kernels; there is no CPU fallback."""
 import ctypes as C
 import importlib
 import os
@@ -27,6 +29,18 @@ def _lib():
         L.vio_pg_find_connection.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_int] + [C.c_void_p] * 5
         L.vio_pg_optimize4dof.argtypes = [C.c_int] + [C.c_void_p] * 8
         L.vio_pg_stage_blur.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.vio_pg_voc_load.argtypes = [C.c_char_p]
+        L.vio_pg_voc_load.restype = C.c_void_p
+        L.vio_pg_voc_create.argtypes = [C.c_int] * 5 + [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 2
+        L.vio_pg_voc_create.restype = C.c_void_p
+        L.vio_pg_voc_destroy.argtypes = [C.c_void_p]
+        L.vio_pg_voc_destroy.restype = None
+        L.vio_pg_voc_info.argtypes = [C.c_void_p, C.c_void_p]
+        L.vio_pg_voc_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.vio_pg_voc_bow.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.vio_pg_db_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.vio_pg_db_query.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.vio_pg_detect_loop.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4
         L._pg_bound = True
     return P, L
 
@@ -142,3 +156,93 @@ class KeyFrame:
         if ok:
             self.has_loop, self.loop_index, self.loop_info, self.match_points = True, old_kf.index, info, mp
         return ok
+
+
+def write_vocabulary(path, k, L, scoring, weighting, node_id, parent_id, weight, desc, word_node, word_id):
+    """VINSLoop::Vocabulary::serialize (ThirdParty/VocabularyBinary.cpp): the file format PoseGraph::loadVocabulary reads"""
+    node_id, parent_id = np.asarray(node_id, np.int32), np.asarray(parent_id, np.int32)
+    nodes = np.zeros(len(node_id), np.dtype([("nodeId", "<i4"), ("parentId", "<i4"), ("weight", "<f8"), ("descriptor", "<u8", (4,))]))
+    nodes["nodeId"], nodes["parentId"], nodes["weight"], nodes["descriptor"] = node_id, parent_id, weight, np.asarray(desc, np.uint64).reshape(-1, 4)
+    words = np.zeros(len(word_node), np.dtype([("nodeId", "<i4"), ("wordId", "<i4")]))
+    words["nodeId"], words["wordId"] = word_node, word_id
+    with open(path, "wb") as f:
+        f.write(np.asarray([k, L, scoring, weighting, len(nodes), len(words)], "<i4").tobytes())
+        f.write(nodes.tobytes())
+        f.write(words.tobytes())
+
+
+class Vocabulary:
+    """BriefVocabulary + BriefDatabase of PoseGraph (pose_graph.h:83-84): loadVocabulary, db.add, db.query, detectLoop."""
+
+    def __init__(self, handle):
+        self.P, self.L = _lib()
+        if not handle:
+            raise self.P.VioError("vocabulary: %s" % self.L.vio_last_error().decode())
+        self.h = handle
+
+    @classmethod
+    def load(cls, path):
+        P, L = _lib()
+        return cls(L.vio_pg_voc_load(os.fsencode(path)))
+
+    @classmethod
+    def from_arrays(cls, k, L_, scoring, weighting, node_id, parent_id, weight, desc, word_node, word_id):
+        P, L = _lib()
+        a = [np.ascontiguousarray(node_id, np.int32), np.ascontiguousarray(parent_id, np.int32), np.ascontiguousarray(weight, np.float64),
+             np.ascontiguousarray(desc, np.uint64), np.ascontiguousarray(word_node, np.int32), np.ascontiguousarray(word_id, np.int32)]
+        return cls(L.vio_pg_voc_create(k, L_, scoring, weighting, len(a[0]), a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data,
+                                       len(a[4]), a[4].ctypes.data, a[5].ctypes.data))
+
+    def close(self):
+        if self.h:
+            self.L.vio_pg_voc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        o = np.zeros(7, np.int32)
+        _chk(self.P, self.L, self.L.vio_pg_voc_info(self.h, o.ctypes.data), "vio_pg_voc_info")
+        return dict(zip(("k", "L", "scoring", "weighting", "nodes", "words", "entries"), (int(x) for x in o)))
+
+    @staticmethod
+    def _desc(desc):
+        d = np.ascontiguousarray(desc, np.uint64).reshape(-1, 4)
+        return d, len(d)
+
+    def transform(self, desc):
+        """(word id, weight) of every descriptor: TemplatedVocabulary::transform(feature, ...)"""
+        d, n = self._desc(desc)
+        w, wt = np.zeros(n, np.int32), np.zeros(n)
+        _chk(self.P, self.L, self.L.vio_pg_voc_transform(self.h, d.ctypes.data, n, w.ctypes.data, wt.ctypes.data), "vio_pg_voc_transform")
+        return w, wt
+
+    def bow(self, desc):
+        """the L1-normalised bag-of-words vector: (ascending word ids, values)"""
+        d, n = self._desc(desc)
+        w, v = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1))
+        m = _chk(self.P, self.L, self.L.vio_pg_voc_bow(self.h, d.ctypes.data, n, len(w), w.ctypes.data, v.ctypes.data), "vio_pg_voc_bow")
+        return w[:m], v[:m]
+
+    def add(self, desc):
+        d, n = self._desc(desc)
+        return _chk(self.P, self.L, self.L.vio_pg_db_add(self.h, d.ctypes.data, n), "vio_pg_db_add")
+
+    def query(self, desc, max_results=4, max_id=-1):
+        d, n = self._desc(desc)
+        cap = max_results if max_results > 0 else max(self.info()["entries"], 1)
+        ids, sc = np.zeros(cap, np.int32), np.zeros(cap)
+        m = _chk(self.P, self.L, self.L.vio_pg_db_query(self.h, d.ctypes.data, n, max_results, max_id, ids.ctypes.data, sc.ctypes.data), "vio_pg_db_query")
+        return ids[:m], sc[:m]
+
+    def detectLoop(self, desc, frame_index, with_results=False):
+        """PoseGraph::detectLoop: query, add, gates; the loop candidate's index or -1"""
+        d, n = self._desc(desc)
+        loop, ids, sc, m = C.c_int32(-1), np.zeros(4, np.int32), np.zeros(4), C.c_int32(0)
+        _chk(self.P, self.L, self.L.vio_pg_detect_loop(self.h, d.ctypes.data, n, int(frame_index), C.addressof(loop), ids.ctypes.data, sc.ctypes.data,
+                                                       C.addressof(m)), "vio_pg_detect_loop")
+        return (loop.value, ids[:m.value], sc[:m.value]) if with_results else loop.value
