@@ -153,3 +153,47 @@ def reference_walk(voc, f):
                 best, bd = c, d
         node = best
     return word_of[node], float(voc["weight"][node - 1])
+
+
+_POP8 = np.array([bin(i).count("1") for i in range(256)], np.uint16)
+
+
+def _dist(desc, centre):
+    """Hamming distances of desc[M][4] (uint64) to one centre"""
+    x = np.bitwise_xor(desc, centre[None, :]).view(np.uint8)
+    return _POP8[x].sum(1)
+
+
+def train_vocabulary(desc, img, k, L, seed):
+    """A vocabulary fitted to real descriptors the way DBoW2's trainer starts (hierarchical clustering, here: k random seeds per node and one
+    assignment pass, no Lloyd iterations): desc[M][4], img[M] = image of each descriptor (for the idf weights log(N / N_i)).  Returns the
+    arrays make_vocabulary returns (TF_IDF weighting, L1 scoring)."""
+    rng = np.random.default_rng(seed)
+    desc = np.ascontiguousarray(desc, np.uint64).reshape(-1, 4)
+    n_img = int(img.max()) + 1
+    node_id, parent_id, ndesc, weight, leaves = [], [], [], [], []
+    frontier = [(0, np.arange(len(desc)), 0)]
+    nxt = 1
+    while frontier:
+        new = []
+        for (pid, members, lv) in frontier:
+            uniq = np.unique(desc[members], axis=0)
+            kk = min(k, len(uniq))
+            centres = uniq[rng.choice(len(uniq), kk, replace=False)]
+            d = np.stack([_dist(desc[members], c) for c in centres], 1)
+            lab = d.argmin(1)                                   # first smallest, like the walk
+            for c in range(kk):
+                mem = members[lab == c]
+                nid = nxt; nxt += 1
+                node_id.append(nid); parent_id.append(pid); ndesc.append(centres[c])
+                if lv + 1 == L or len(np.unique(desc[mem], axis=0)) <= 1:
+                    ni = len(np.unique(img[mem])) if len(mem) else 0
+                    weight.append(np.log(n_img / ni) if ni else 0.0)
+                    leaves.append(nid)
+                else:
+                    weight.append(0.0)
+                    new.append((nid, mem, lv + 1))
+        frontier = new
+    return dict(k=k, L=L, scoring=0, weighting=0, node_id=np.asarray(node_id, np.int32), parent_id=np.asarray(parent_id, np.int32),
+                weight=np.asarray(weight), desc=np.asarray(ndesc, np.uint64).reshape(-1, 4), word_node=np.asarray(leaves, np.int32),
+                word_id=np.arange(len(leaves), dtype=np.int32))

@@ -1,5 +1,6 @@
 """Place recognition on the GPU (vio_pg_voc_* in include/vio_posegraph.h) against the oracle's restatement of the vendored DBoW2 (oracle/bow.cpp):
 tree walk bit for bit, bag-of-words vectors, database queries and PoseGraph::detectLoop decisions identical (same summation orders)."""
+import ctypes
 import importlib
 
 import numpy as np
@@ -77,3 +78,80 @@ def test_vocabulary_errors_are_reported(pg, tmp_path):
     (tmp_path / "short.bin").write_bytes(b"\\x03\\x00\\x00\\x00" * 7)
     with pytest.raises(P.VioError):
         pg.Vocabulary.load(str(tmp_path / "short.bin"))
+
+
+def _Rz(deg):
+    a = np.deg2rad(deg)
+    return np.array([[np.cos(a), -np.sin(a), 0.0], [np.sin(a), np.cos(a), 0.0], [0.0, 0.0, 1.0]])
+
+
+def test_pose_graph_closes_a_drifting_loop_end_to_end(pg):
+    """pose_graph without ROS on rendered frames: 65 keyframes along a synthetic trajectory whose VIO poses drift (yaw and translation growing
+    with the keyframe index), then eight keyframes that revisit the viewpoints of keyframes 5 .. 12.  BRIEF descriptors (HIP) -> a vocabulary
+    trained on the first lap -> PoseGraph.addKeyFrame = detectLoop (HIP walk + database) + findConnection (HIP search + PnP RANSAC) ->
+    optimize4DoF.  The loops must be found between the right keyframes, the verified relative poses must be the scene's, and the optimised
+    poses of the revisiting keyframes must lose most of the accumulated drift."""
+    import test_oracle_posegraph_cpu as O
+    P = vio_ct.pkg()
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    syn, pat, orc = P.Synth(sc), O.pattern(), vio_ct.oracle()
+    seq = 5
+    ric, tic = np.array(list(cfg.ric)).reshape(3, 3), np.array(list(cfg.tic))
+    times = [2.0 + 0.1 * k for k in range(65)] + [2.0 + 0.1 * k + 0.02 for k in range(5, 13)]
+    partner = list(range(65)) + list(range(5, 13))
+    kfs, truth = [], []
+    for i, t in enumerate(times):
+        g, d = syn.render_host(seq, float(t))
+        p, R, _ = syn.pose(seq, float(t))
+        Dr, Dt = _Rz(0.12 * i), np.array([0.006 * i, -0.004 * i, 0.0])            # the drift of the VIO frame at keyframe i
+        p_vio, R_vio = Dr @ p + Dt, Dr @ R
+        # window points = tracked corners: every n-th FAST keypoint of the image (the estimator's features are FAST corners too)
+        _, kxy, _, _ = pg.describe(cfg, g, np.zeros((0, 2), np.float32), pat)
+        uv = kxy[:: max(1, len(kxy) // 160)].astype(np.float64)
+        xy = np.zeros_like(uv)
+        orc.ovio_cam_lift(ctypes.byref(cfg), len(uv), uv.ctypes.data, xy.ctypes.data)
+        z = d[uv[:, 1].astype(int), uv[:, 0].astype(int)].astype(np.float64) / 1000.0
+        ok = (z > 0.3) & (z < 8.0)
+        pc = np.c_[xy[ok] * z[ok, None], z[ok]]
+        pw = (R_vio @ (ric @ pc.T + tic[:, None])).T + p_vio                        # world points as the (drifting) estimator would report them
+        kfs.append(pg.KeyFrame(cfg, pat, float(t), i, p_vio, R_vio, g, pw, uv[ok], xy[ok], 1000.0 * i + np.arange(ok.sum()), sequence=1))
+        truth.append((p, R))
+    pool = np.concatenate([kf.brief_descriptors for kf in kfs[:50]])
+    img = np.concatenate([np.full(len(kf.brief_descriptors), j) for j, kf in enumerate(kfs[:50])])
+    voc = bow_util.train_vocabulary(pool, img, 10, 4, 3)
+    assert len(voc["word_node"]) > 2000
+    h = _hip(pg, voc)
+    graph = pg.PoseGraph(h, ric, tic)
+    loops = {}
+    for kf in kfs:
+        r = graph.addKeyFrame(kf)
+        if r != -1:
+            loops[kf.index] = r
+    # (detectLoop hands findConnection the OLDEST of its candidates, pose_graph.cpp:384-390: not every revisit survives the verification)
+    assert len([i for i in loops if i >= 65]) >= 3, loops
+    assert all(abs(v - partner[i]) <= 3 for i, v in loops.items() if i >= 65), loops      # the revisited viewpoint or a neighbour
+    assert not any(i < 65 for i in loops)
+    for i, v in loops.items():      # the verified relative pose is the scene's (frame i seen from the old keyframe)
+        (pi, Ri), (po, Ro) = truth[i], truth[v]
+        assert np.abs(kfs[i].loop_info[:3] - Ro.T @ (pi - po)).max() < 0.04, (i, v)
+    err_before = np.mean([np.linalg.norm(kfs[i].T_w_i - truth[i][0]) for i in range(65, 73)])
+    assert graph.optimize() and not graph.optimize()
+    err_after = np.mean([np.linalg.norm(kfs[i].T_w_i - truth[i][0]) for i in range(65, 73)])
+    first = graph.earliest_loop_index
+    anchor = np.linalg.norm(kfs[first].T_w_i - truth[first][0])                           # the graph is anchored at the earliest looped keyframe
+    # five Levenberg-Marquardt iterations spread the correction over the chain (a handful of loop edges against 4 x 70 sequential ones): most of
+    # the drift goes, not all of it -- the same behaviour test_gpu_posegraph.py pins on an analytic circuit
+    assert err_before > 0.3 and err_after < 0.5 * err_before and anchor < 0.1, (err_before, err_after, anchor)
+    # yaw: right sign, small -- a loop edge's yaw residual is weighted 1 / 10 (FourDOFWeightError, pose_graph.h:238) under HuberLoss(0.1)
+    # against the sequential edges' 1 (degrees), so five iterations move the translation, hardly the heading
+    yaw_gap = 0.12 * (72 - partner[72])                                                    # the yaw the VIO frame accumulated between the visits
+    assert -yaw_gap < graph.yaw_drift < 0, (graph.yaw_drift, yaw_gap)
+    # a keyframe added after the optimisation is published with the drift correction (pose_graph.cpp:148-153)
+    p, R, _ = syn.pose(seq, 2.0 + 0.1 * 13)
+    g, _ = syn.render_host(seq, 2.0 + 0.1 * 13)
+    Dr, Dt = _Rz(0.12 * 73), np.array([0.006 * 73, -0.004 * 73, 0.0])
+    late = pg.KeyFrame(cfg, pat, 99.0, 73, Dr @ p + Dt, Dr @ R, g, np.zeros((0, 3)), np.zeros((0, 2)), np.zeros((0, 2)), np.zeros(0), sequence=1)
+    graph.addKeyFrame(late, flag_detect_loop=False)
+    assert np.linalg.norm(late.T_w_i - p) < 0.5 * np.linalg.norm(late.vio_T_w_i - p)
+    h.close()

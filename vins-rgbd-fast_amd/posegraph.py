@@ -158,6 +158,102 @@ class KeyFrame:
         return ok
 
 
+def _ypr2R(yaw_deg):
+    y = np.deg2rad(yaw_deg)
+    return np.array([[np.cos(y), -np.sin(y), 0.0], [np.sin(y), np.cos(y), 0.0], [0.0, 0.0, 1.0]])
+
+
+def _yaw_deg(R):   # Utility::R2ypr(R).x()
+    return float(np.rad2deg(np.arctan2(R[1, 0], R[0, 0])))
+
+
+class PoseGraph:
+    """PoseGraph (pose_graph/src/pose_graph/pose_graph.{h,cpp}) for `imu: 1` without its threads, ROS messages and visualisation:
+    addKeyFrame (:49-200) = the shift into the map frame, detectLoop, findConnection, the drift-corrected pose; optimize() = one pass of the
+    optimize4DoF thread's loop body (:410-581), run by the caller instead of every two seconds.  The keyframes are this module's KeyFrame."""
+
+    def __init__(self, vocabulary, qic, tic):
+        self.voc, self.qic, self.tic = vocabulary, np.array(qic, np.float64).reshape(3, 3), np.array(tic, np.float64).reshape(3)
+        self.keyframelist, self.optimize_buf = [], []
+        self.global_index, self.sequence_cnt, self.sequence_loop, self.earliest_loop_index = 0, 0, [False], -1
+        self.t_drift, self.r_drift, self.yaw_drift = np.zeros(3), np.eye(3), 0.0
+        self.w_t_vio, self.w_r_vio = np.zeros(3), np.eye(3)
+
+    def getKeyFrame(self, index):
+        for kf in self.keyframelist:
+            if kf.index == index:
+                return kf
+        return None
+
+    def addKeyFrame(self, cur_kf, flag_detect_loop=True):
+        """returns the index of the verified loop partner or -1"""
+        if self.sequence_cnt != cur_kf.sequence:            # a new sequence starts in its own frame (:55-65)
+            self.sequence_cnt += 1
+            self.sequence_loop.append(False)
+            self.w_t_vio, self.w_r_vio = np.zeros(3), np.eye(3)
+            self.t_drift, self.r_drift = np.zeros(3), np.eye(3)
+        cur_kf.vio_T_w_i = self.w_r_vio @ cur_kf.vio_T_w_i + self.w_t_vio
+        cur_kf.vio_R_w_i = self.w_r_vio @ cur_kf.vio_R_w_i
+        cur_kf.index = self.global_index
+        self.global_index += 1
+        loop_index = -1
+        if flag_detect_loop:
+            loop_index = self.voc.detectLoop(cur_kf.brief_descriptors, cur_kf.index)
+        else:
+            self.voc.add(cur_kf.brief_descriptors)             # addKeyFrameIntoVoc
+        verified = -1
+        if loop_index != -1:
+            old_kf = self.getKeyFrame(loop_index)
+            if old_kf is not None and cur_kf.findConnection(old_kf, self.qic, self.tic):
+                verified = loop_index
+                if self.earliest_loop_index > loop_index or self.earliest_loop_index == -1:
+                    self.earliest_loop_index = loop_index
+                if old_kf.sequence != cur_kf.sequence and not self.sequence_loop[cur_kf.sequence]:   # (:120-139) align the new sequence with the map
+                    w_P_old, w_R_old = old_kf.T_w_i, old_kf.R_w_i
+                    rel_t, rel_q = cur_kf.loop_info[:3], cur_kf.loop_info[3:7]
+                    w, x, y, z = rel_q
+                    rel_R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+                    w_P_cur, w_R_cur = w_R_old @ rel_t + w_P_old, w_R_old @ rel_R
+                    shift_r = _ypr2R(_yaw_deg(w_R_cur) - _yaw_deg(cur_kf.vio_R_w_i))
+                    shift_t = w_P_cur - w_R_cur @ cur_kf.vio_R_w_i.T @ cur_kf.vio_T_w_i
+                    self.w_r_vio, self.w_t_vio = shift_r, shift_t
+                    cur_kf.vio_T_w_i = shift_r @ cur_kf.vio_T_w_i + shift_t
+                    cur_kf.vio_R_w_i = shift_r @ cur_kf.vio_R_w_i
+                    for kf in self.keyframelist:
+                        if kf.sequence == cur_kf.sequence:
+                            kf.vio_T_w_i, kf.vio_R_w_i = shift_r @ kf.vio_T_w_i + shift_t, shift_r @ kf.vio_R_w_i
+                    self.sequence_loop[cur_kf.sequence] = True
+                self.optimize_buf.append(cur_kf.index)
+        cur_kf.T_w_i = self.r_drift @ cur_kf.vio_T_w_i + self.t_drift   # (:148-153)
+        cur_kf.R_w_i = self.r_drift @ cur_kf.vio_R_w_i
+        self.keyframelist.append(cur_kf)
+        return verified
+
+    def optimize(self):
+        """one pass of optimize4DoF's loop body over the keyframes earliest_loop_index .. newest queued one; False when nothing is queued"""
+        if not self.optimize_buf:
+            return False
+        cur_index, first = self.optimize_buf[-1], self.earliest_loop_index
+        self.optimize_buf = []
+        nodes = [kf for kf in self.keyframelist if first <= kf.index <= cur_index]
+        local = {kf.index: i for i, kf in enumerate(nodes)}
+        loop_to = [local[kf.loop_index] if kf.has_loop else -1 for kf in nodes]
+        t, R, (yaw, _) = optimize4DoF([kf.vio_T_w_i for kf in nodes], [kf.vio_R_w_i for kf in nodes], [kf.sequence for kf in nodes], loop_to,
+                                      [kf.loop_info for kf in nodes])
+        for kf, ti, Ri in zip(nodes, t, R):
+            kf.T_w_i, kf.R_w_i = ti.copy(), Ri.copy()
+        cur = nodes[-1]
+        self.yaw_drift = _yaw_deg(cur.R_w_i) - _yaw_deg(cur.vio_R_w_i)          # (:547-553)
+        self.r_drift = _ypr2R(self.yaw_drift)
+        self.t_drift = cur.T_w_i - self.r_drift @ cur.vio_T_w_i
+        for kf in self.keyframelist:
+            if kf.index > cur_index:
+                kf.T_w_i, kf.R_w_i = self.r_drift @ kf.vio_T_w_i + self.t_drift, self.r_drift @ kf.vio_R_w_i
+        return True
+
+
 def write_vocabulary(path, k, L, scoring, weighting, node_id, parent_id, weight, desc, word_node, word_id):
     """VINSLoop::Vocabulary::serialize (ThirdParty/VocabularyBinary.cpp): the file format PoseGraph::loadVocabulary reads"""
     node_id, parent_id = np.asarray(node_id, np.int32), np.asarray(parent_id, np.int32)
