@@ -75,6 +75,8 @@ typedef struct vio_config {
 } vio_config;
 
 enum { VIO_QUIRK_LATEST_FRONT = 1,
+       /* bit 2 (value 4): ignored by the library; the test oracle mirrors deviation 15 (extrinsic held in a relocalisation solve) when set */
+       VIO_ORACLE_RELO_HOLDS_EXTRINSIC = 4,
        /* TEST HOOK, not a reference behaviour: bits 8..11 = n: the first n Cholesky factorisations of EVERY solve are reported as failed
         * (on both sides: the oracle reads the same bits), which walks the mu *= 10 retry ladder of the trust-region loop
         * (oracle/backend.cpp solve(); be_phased.h ps_serial).  Every retry uses one iteration slot: see VIO_EXTRA_SLOTS. */
@@ -234,8 +236,10 @@ int vio_get_latest_odometry(vio_batch *h, int seq, double *out11);
  * optimisation of that sequence carries the relocalisation factors (estimator.cpp:1307-1346: ProjectionFactor(first observation,
  * matched point) on (para_Pose[start], relo_Pose, extrinsic, inverse depth) for every in-problem landmark with start_frame <=
  * relo_frame_local_index among the matches) and computes the drift outputs (:1034-1056); otherwise nothing happens, like upstream.
- * Limits of this build: IMU mode, phased solver, and a solve in which the extrinsic is constant (relo_Pose borrows its six columns of
- * the reduced system); otherwise the request is dropped and the frame carries overflow flag 64. */
+ * relo_Pose borrows the six tangent columns of the extrinsic in the reduced system: when ESTIMATE_EXTRINSIC has opened the extrinsic it is
+ * held constant in the ONE solve that carries the factors and refined again from the next solve on (DESIGN.md deviation 15: below a
+ * millimetre against the joint optimisation).  Limits of this build: IMU mode and the phased solver; on the persistent solver (windows
+ * beyond its range) the request is dropped and the frame carries overflow flag 64. */
 int vio_set_relo_frame(vio_batch *h, int seq, double frame_stamp, int frame_index, int n, const double *match_points, const double *relo_t3,
                        const double *relo_r9);
 /* what pubRelocalization and the pose graph read after that solve (visualization.cpp:454-538): out30 = relo_relative_t(3),

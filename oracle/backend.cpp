@@ -1036,6 +1036,9 @@ void Estimator::solve() {
     bool ex_active;
     if ((cfg.estimate_extrinsic && frame_count == W && norm(Vs[0]) > 0.2) || openExEstimation) { openExEstimation = true; ex_active = true; }
     else ex_active = false;
+    // mirror of the product's deviation 15 for its parity tests (reference_quirks bit 2, NOT a reference behaviour): the extrinsic is held
+    // constant in a solve that carries relocalisation factors
+    if (relo_on && (cfg.reference_quirks & 4)) ex_active = false;
     bool td_active = cfg.estimate_td && !(norm(Vs[0]) < 0.2);
     for (int d = 0; d < 6; d++) active[oE + d] = ex_active;
     active[oT] = td_active;

@@ -1448,10 +1448,15 @@ __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X
         int td_active = cfg.use_imu && cfg.estimate_td && !(v0 < 0.2);   // no td block without the IMU (estimator.cpp:1204)
         sh_i[0] = ex_active; sh_i[1] = td_active;
         int relo_on = be.relo_info && be.solver_flag == 1;
-        if (relo_on && (!allow_relo || ex_active)) {
-            // relocalisation while the extrinsic is being optimised (or on the persistent solver) is not supported: the request is dropped
-            // and the frame flagged (overflow bit 64); optimization() without relocalization_info is what runs
+        if (relo_on && !allow_relo) {
+            // relocalisation on the persistent solver (windows beyond the phased solver's range) is not supported: the request is dropped and
+            // the frame flagged (overflow bit 64); optimization() without relocalization_info is what runs
             relo_on = 0; be.relo_info = 0; be.overflow |= 64;
+        } else if (relo_on && ex_active) {
+            // DEVIATION 15: relo_Pose borrows the six tangent columns of the extrinsic in the reduced system, so the extrinsic is held constant
+            // in the (one) solve that carries relocalisation factors even when ESTIMATE_EXTRINSIC has opened it; openExEstimation stays
+            // latched and the next solve refines it again.  The oracle mirrors this under reference_quirks bit 2 (tests).
+            ex_active = 0; sh_i[0] = 0;
         }
         sh_i[4] = relo_on; sh_i[3] = 0;
     }
