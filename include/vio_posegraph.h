@@ -49,6 +49,13 @@ int vio_pg_find_connection(int n, const float *pt3d, const double *pt_id, const 
 int vio_pg_optimize4dof(int n, const double *t, const double *R, const int32_t *sequence, const int32_t *loop_to, const double *loop_info,
                         double *t_out, double *R_out, double *drift);
 
+/* PoseGraph::optimize6DoF (pose_graph.cpp:583-740; RelativeRTError pose_graph.h:256-320), the `imu: 0` variant: full poses (quaternion with
+ * ceres::QuaternionParameterization + translation), same node / edge selection as optimize4DoF, edges = RelativeRTError(relative t, relative q,
+ * t_var 0.1, q_var 0.01) with the loop edges (loop_info[0..2] = relative t, [3..6] = relative q (w, x, y, z)) under HuberLoss(0.1), five
+ * Levenberg-Marquardt iterations.  drift12 = r_drift (9, row-major) = R_cur R_vio^T, t_drift (3) = t_cur - r_drift t_vio (:717-721). */
+int vio_pg_optimize6dof(int n, const double *t, const double *R, const int32_t *sequence, const int32_t *loop_to, const double *loop_info,
+                        double *t_out, double *R_out, double *drift12);
+
 /* ---- place recognition: BriefVocabulary + BriefDatabase of PoseGraph (pose_graph.h:83-84; vendored DBoW2 under pose_graph/src/ThirdParty) ----
  * The tree walk of every descriptor runs as a HIP kernel (no CPU fallback); bag-of-words vector, inverted file and L1 query are per-keyframe
  * host code.  Only L1_NORM scoring (what brief_k10L6.bin uses) is supported; all four weightings are.  The reference tree does not contain the

@@ -265,6 +265,10 @@ int ovio_pg_find_connection(int n, const float *pt3d, const float *pt_norm, cons
                             double *loop_info8, double *match_points, int *n_match_out, double *pnp_T3, double *pnp_R9) {
     return find_connection(n, pt3d, pt_norm, pt_id, match, old_norm, vio_T, vio_R, qic9, tic3, min_loop_num, loop_info8, match_points, n_match_out, pnp_T3, pnp_R9);
 }
+void ovio_pg_optimize6dof(int n, const double *t_in, const double *R_in, const int *sequence, const int *loop_to, const double *loop_info,
+                          double *t_out, double *R_out, double *drift12) {
+    optimize_6dof(n, t_in, R_in, sequence, loop_to, loop_info, t_out, R_out, drift12);
+}
 void ovio_pg_optimize4dof(int n, const double *t_in, const double *R_in, const int *sequence, const int *loop_to, const double *loop_info,
                           double *t_out, double *R_out, double *drift4) {
     optimize_4dof(n, t_in, R_in, sequence, loop_to, loop_info, t_out, R_out, drift4);

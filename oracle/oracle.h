@@ -101,6 +101,8 @@ void brief_match(const uint64_t *wd, int n, const uint64_t *od, int m, int *best
 int find_connection(int n, const float *pt3d, const float *pt_norm, const double *pt_id, const int *match, const float *old_norm,
                     const double *vio_T, const double *vio_R, const double *qic9, const double *tic3, int min_loop_num,
                     double *loop_info8, double *match_points, int *n_match_out, double *pnp_T3, double *pnp_R9);
+void optimize_6dof(int n, const double *t_in, const double *R_in, const int *sequence, const int *loop_to, const double *loop_info,
+                   double *t_out, double *R_out, double *drift12);
 void optimize_4dof(int n, const double *t_in, const double *R_in, const int *sequence, const int *loop_to, const double *loop_info,
                    double *t_out, double *R_out, double *drift4);
 

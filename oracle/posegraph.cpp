@@ -298,4 +298,182 @@ void optimize_4dof(int n, const double *t_in, const double *R_in, const int *seq
     }
 }
 
+// ---------------------------------------------------------------- PoseGraph::optimize6DoF (pose_graph.cpp:583-740; RelativeRTError pose_graph.h:256-320)
+// The `imu: 0` variant: every node carries a full pose (quaternion with ceres::QuaternionParameterization + translation); sequential edges to
+// the 1..4 previous nodes of the same sequence and loop edges (HuberLoss(0.1)) are RelativeRTError(relative t, relative q, t_var 0.1, q_var
+// 0.01): r = ((R_i^T (t_j - t_i) - t_m) / t_var, 2 vec(q_m^-1 (q_i^-1 q_j)) / q_var).  Node 0 and the nodes of sequence 0 are constant.
+// QuaternionParameterization::Plus(q, d) = [cos|d|, sin|d| d / |d|] * q, so the tangent is a left HALF-angle perturbation; the Jacobians
+// below are the directional derivatives along it (what autodiff times the Plus-Jacobian gives).  Same trust-region loop as optimize_4dof.
+// Output: t_out[n][3], R_out[n][9]; drift12 = r_drift (9, row-major) = R_cur R_vio^T and t_drift = t_cur - r_drift t_vio (:717-721).
+namespace {
+struct Edge6 { int i, j; V3 tm; Q qm; bool loop; };
+// residual (6) and Jacobians wrt (dtheta_i, t_i, dtheta_j, t_j): J[6][12]
+void edge6_eval(const Edge6 &e, const std::vector<Q> &q, const std::vector<double> &t, double *r, double *J) {
+    const Q qi = q[e.i], qj = q[e.j];
+    const M3 RiT = T(toR(normalized(qi)));            // ceres::QuaternionRotatePoint scales the quaternion to unit length
+    const V3 d(t[3 * e.j] - t[3 * e.i], t[3 * e.j + 1] - t[3 * e.i + 1], t[3 * e.j + 2] - t[3 * e.i + 2]);
+    const V3 tij = RiT * d;
+    const double tv = 0.1, qv = 0.01;
+    r[0] = (tij.x - e.tm.x) / tv; r[1] = (tij.y - e.tm.y) / tv; r[2] = (tij.z - e.tm.z) / tv;
+    const Q qic(qi.w, -qi.x, -qi.y, -qi.z), qmc(e.qm.w, -e.qm.x, -e.qm.y, -e.qm.z);   // QuaternionInverse of the functor = conjugate
+    const Q A = qmc * qic;
+    const Q err = A * qj;
+    r[3] = 2.0 * err.x / qv; r[4] = 2.0 * err.y / qv; r[5] = 2.0 * err.z / qv;
+    if (!J) return;
+    for (int k = 0; k < 72; k++) J[k] = 0.0;
+    // d r_t / d dtheta_i = R_i^T 2 [d]x ; / d t_i = -R_i^T ; / d t_j = R_i^T
+    const M3 dx = skew(d);
+    const M3 Jr = RiT * dx;
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+            J[a * 12 + b] = 2.0 * Jr(a, b) / tv;
+            J[a * 12 + 3 + b] = -RiT(a, b) / tv;
+            J[a * 12 + 9 + b] = RiT(a, b) / tv;
+        }
+    // d err = A * [0, dtheta_j - dtheta_i] * q_j
+    for (int b = 0; b < 3; b++) {
+        const Q unit(0.0, b == 0 ? 1.0 : 0.0, b == 1 ? 1.0 : 0.0, b == 2 ? 1.0 : 0.0);
+        const Q de = (A * unit) * qj;
+        const double v[3] = {2.0 * de.x / qv, 2.0 * de.y / qv, 2.0 * de.z / qv};
+        for (int a = 0; a < 3; a++) { J[(3 + a) * 12 + 6 + b] = v[a]; J[(3 + a) * 12 + b] = -v[a]; }
+    }
+}
+Q quat_plus(const Q &q, const double *d) {   // ceres::QuaternionParameterization::Plus
+    const double n = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (n > 0.0) {
+        const double s = std::sin(n) / n;
+        return Q(std::cos(n), s * d[0], s * d[1], s * d[2]) * q;
+    }
+    return q;
+}
+}  // namespace
+
+void optimize_6dof(int n, const double *t_in, const double *R_in, const int *sequence, const int *loop_to, const double *loop_info,
+                   double *t_out, double *R_out, double *drift12) {
+    std::vector<Q> q(n);
+    std::vector<double> t(t_in, t_in + 3 * n);
+    std::vector<uint8_t> fixed(n, 0);
+    for (int i = 0; i < n; i++) {
+        M3 R;
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) R(a, b) = R_in[9 * i + 3 * a + b];
+        q[i] = fromR(R);
+        fixed[i] = (i == 0 || sequence[i] == 0) ? 1 : 0;
+    }
+    std::vector<Edge6> edges;
+    for (int i = 0; i < n; i++) {
+        for (int j = 1; j < 5; j++)
+            if (i - j >= 0 && sequence[i] == sequence[i - j]) {
+                const Q qa = q[i - j];
+                const V3 rel = toR(inverse(qa)) * V3(t_in[3 * i] - t_in[3 * (i - j)], t_in[3 * i + 1] - t_in[3 * (i - j) + 1], t_in[3 * i + 2] - t_in[3 * (i - j) + 2]);
+                edges.push_back(Edge6{i - j, i, rel, inverse(qa) * q[i], false});
+            }
+        if (loop_to[i] >= 0)
+            edges.push_back(Edge6{loop_to[i], i, V3(loop_info[8 * i], loop_info[8 * i + 1], loop_info[8 * i + 2]),
+                                  Q(loop_info[8 * i + 3], loop_info[8 * i + 4], loop_info[8 * i + 5], loop_info[8 * i + 6]), true});
+    }
+    std::vector<int> col(n, -1);
+    int nv = 0;
+    for (int i = 0; i < n; i++) if (!fixed[i]) { col[i] = nv; nv += 6; }
+    auto cost_of = [&](const std::vector<Q> &qq, const std::vector<double> &tt) {
+        double c = 0;
+        for (const Edge6 &e : edges) {
+            double r[6];
+            edge6_eval(e, qq, tt, r, nullptr);
+            double s = 0;
+            for (int a = 0; a < 6; a++) s += r[a] * r[a];
+            c += 0.5 * (e.loop ? (s <= 0.01 ? s : 2 * 0.1 * std::sqrt(s) - 0.01) : s);
+        }
+        return c;
+    };
+    if (nv > 0) {
+        double radius = 1e4, decrease = 2.0;
+        double cost = cost_of(q, t);
+        std::vector<double> scale;
+        for (int it = 0; it < 5; it++) {
+            Mat A(nv, nv);
+            std::vector<double> g(nv, 0.0);
+            for (const Edge6 &e : edges) {
+                double r[6], J[72];
+                edge6_eval(e, q, t, r, J);
+                if (e.loop) {
+                    double s = 0;
+                    for (int a = 0; a < 6; a++) s += r[a] * r[a];
+                    const double w = s <= 0.01 ? 1.0 : std::sqrt(0.1 / std::sqrt(s));
+                    for (int a = 0; a < 6; a++) { r[a] *= w; for (int b = 0; b < 12; b++) J[a * 12 + b] *= w; }
+                }
+                const int base[2] = {col[e.i], col[e.j]};
+                for (int p = 0; p < 12; p++) {
+                    const int cp = base[p / 6];
+                    if (cp < 0) continue;
+                    double gs = 0;
+                    for (int a = 0; a < 6; a++) gs += J[a * 12 + p] * r[a];
+                    g[cp + p % 6] += gs;
+                    for (int qq = 0; qq < 12; qq++) {
+                        const int cq = base[qq / 6];
+                        if (cq < 0) continue;
+                        double s2 = 0;
+                        for (int a = 0; a < 6; a++) s2 += J[a * 12 + p] * J[a * 12 + qq];
+                        A(cp + p % 6, cq + qq % 6) += s2;
+                    }
+                }
+            }
+            if (scale.empty()) { scale.resize(nv); for (int a = 0; a < nv; a++) scale[a] = 1.0 / (1.0 + std::sqrt(A(a, a))); }
+            Mat As(nv, nv);
+            std::vector<double> gs(nv);
+            for (int a = 0; a < nv; a++) { gs[a] = scale[a] * g[a]; for (int b = 0; b < nv; b++) As(a, b) = scale[a] * scale[b] * A(a, b); }
+            double gmax = 0;
+            for (int a = 0; a < nv; a++) gmax = std::max(gmax, std::fabs(g[a]));
+            if (gmax <= 1e-10) break;
+            bool accepted = false;
+            for (int tries = 0; tries < 20 && !accepted; tries++) {
+                Mat M = As;
+                for (int a = 0; a < nv; a++) M(a, a) += std::min(std::max(As(a, a), 1e-6), 1e32) / radius;
+                std::vector<double> rhs = gs;
+                if (!chol(M)) { radius /= decrease; decrease *= 2; continue; }
+                chol_solve(M, rhs);
+                double lin = 0, quad = 0;
+                for (int a = 0; a < nv; a++) { lin += gs[a] * (-rhs[a]); double s2 = 0; for (int b = 0; b < nv; b++) s2 += As(a, b) * (-rhs[b]); quad += (-rhs[a]) * s2; }
+                const double model = -(lin + 0.5 * quad);
+                std::vector<Q> qc = q;
+                std::vector<double> tc = t;
+                for (int i = 0; i < n; i++) {
+                    if (col[i] < 0) continue;
+                    double d[3];
+                    for (int a = 0; a < 3; a++) d[a] = -rhs[col[i] + a] * scale[col[i] + a];
+                    qc[i] = quat_plus(q[i], d);
+                    for (int a = 0; a < 3; a++) tc[3 * i + a] = t[3 * i + a] - rhs[col[i] + 3 + a] * scale[col[i] + 3 + a];
+                }
+                const double cc = cost_of(qc, tc);
+                const double rho = model > 0 ? (cost - cc) / model : -1;
+                if (rho > 1e-3) {
+                    q = qc; t = tc;
+                    const double rel = std::fabs(cost - cc) / cost;
+                    cost = cc;
+                    radius = std::min(radius / std::max(1.0 / 3.0, 1.0 - std::pow(2 * rho - 1, 3)), 1e16);
+                    decrease = 2.0;
+                    accepted = true;
+                    if (rel < 1e-6) it = 5;
+                } else {
+                    radius /= decrease; decrease *= 2;
+                    it++;
+                    if (it >= 5) break;
+                }
+            }
+            if (!accepted) break;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        const M3 R = toR(q[i]);
+        for (int a = 0; a < 3; a++) { t_out[3 * i + a] = t[3 * i + a]; for (int b = 0; b < 3; b++) R_out[9 * i + 3 * a + b] = R(a, b); }
+    }
+    {
+        M3 Rv;
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Rv(a, b) = R_in[9 * (n - 1) + 3 * a + b];
+        const M3 rd = toR(q[n - 1]) * T(Rv);
+        const V3 td = V3(t[3 * (n - 1)], t[3 * (n - 1) + 1], t[3 * (n - 1) + 2]) - rd * V3(t_in[3 * (n - 1)], t_in[3 * (n - 1) + 1], t_in[3 * (n - 1) + 2]);
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) drift12[3 * a + b] = rd(a, b);
+        drift12[9] = td.x; drift12[10] = td.y; drift12[11] = td.z;
+    }
+}
+
 }  // namespace ovio

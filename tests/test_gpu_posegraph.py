@@ -89,6 +89,13 @@ def test_find_connection_and_optimize4dof_against_oracle_and_truth(P, PG):
     seq2 = seq.copy(); seq2[:10] = 0
     to2, Ro2, _ = PG.optimize4DoF(t_vio, R_vio, seq2, loop_to, info)
     assert np.abs(to2[:10] - t_vio[:10]).max() == 0
+    # 6-DoF pose graph (the `imu: 0` variant, pose_graph.cpp:583-740)
+    t_true, R_true, t_vio, R_vio, seq, loop_to, info = O._drift_graph6()
+    to_h, Ro_h, (rd_h, td_h) = PG.optimize6DoF(t_vio, R_vio, seq, loop_to, info)
+    to_o, Ro_o, dr_o = O.o_optimize6dof(t_vio, R_vio, seq, loop_to, info)
+    assert np.abs(to_h - to_o).max() < 1e-6 and np.abs(Ro_h - Ro_o).max() < 1e-7
+    assert np.abs(rd_h.ravel() - dr_o[:9]).max() < 1e-7 and np.abs(td_h - dr_o[9:]).max() < 1e-6
+    assert np.linalg.norm(to_h[-1] - t_true[-1]) < 0.85 * np.linalg.norm(t_vio[-1] - t_true[-1])
 
 
 def test_loop_verification_feeds_the_relocalisation_of_a_live_estimator(P, PG):

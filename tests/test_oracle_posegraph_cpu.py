@@ -24,6 +24,7 @@ def olib():
     L.ovio_pg_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.ovio_pg_find_connection.argtypes = [C.c_int] + [C.c_void_p] * 9 + [C.c_int] + [C.c_void_p] * 5
     L.ovio_pg_optimize4dof.argtypes = [C.c_int] + [C.c_void_p] * 8
+    L.ovio_pg_optimize6dof.argtypes = [C.c_int] + [C.c_void_p] * 8
     return L
 
 
@@ -218,3 +219,69 @@ def test_optimize4dof_closes_the_loop_towards_the_truth():
     _, _, t_vio2, R_vio2, seq2, lt2, info2 = _drift_graph(loop_back=False)
     to2, _, d2 = o_optimize4dof(t_vio2, R_vio2, seq2, lt2, info2)
     assert np.abs(to2 - t_vio2).max() < 1e-6 and abs(d2[0]) < 1e-6
+
+
+def o_optimize6dof(t, R, seq, loop_to, loop_info):
+    L = olib()
+    t, R = np.ascontiguousarray(t, np.float64).reshape(-1, 3), np.ascontiguousarray(R, np.float64).reshape(-1, 9)
+    n = len(t)
+    sq, lt, li = np.ascontiguousarray(seq, np.int32), np.ascontiguousarray(loop_to, np.int32), np.ascontiguousarray(loop_info, np.float64).reshape(n, 8)
+    to, Ro, dr = np.zeros((n, 3)), np.zeros((n, 9)), np.zeros(12)
+    L.ovio_pg_optimize6dof(n, t.ctypes.data, R.ctypes.data, sq.ctypes.data, lt.ctypes.data, li.ctypes.data, to.ctypes.data, Ro.ctypes.data, dr.ctypes.data)
+    return to, Ro.reshape(n, 3, 3), dr
+
+
+def _R2q(R):
+    w = np.sqrt(max(0.0, 1 + R[0, 0] + R[1, 1] + R[2, 2])) / 2
+    return np.array([w, (R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w)])
+
+
+def _drift_graph6(n=120):
+    """the circuit of _drift_graph with drift in all six degrees of freedom (the `imu: 0` case: nothing anchors pitch and roll) and two loop
+    edges measured truly as (relative t, relative q)"""
+    ang = np.linspace(0, 2 * np.pi, n, endpoint=False)
+    t_true = np.c_[4 * np.cos(ang), 4 * np.sin(ang), 0.2 * np.sin(2 * ang)]
+    R_true = np.array([rot_zyx(a + np.pi / 2, 0.05 * np.sin(a), 0.04 * np.cos(a)) for a in ang])
+    t_vio, R_vio = [t_true[0]], [R_true[0]]
+    for i in range(1, n):
+        dR = R_true[i - 1].T @ R_true[i]
+        dt = R_true[i - 1].T @ (t_true[i] - t_true[i - 1])
+        t_vio.append(t_vio[-1] + R_vio[-1] @ (dt * 1.003 + np.array([0.001, 0, 0.0005])))
+        R_vio.append(R_vio[-1] @ (rot_zyx(np.radians(0.03), np.radians(0.02), np.radians(-0.015)) @ dR))
+    t_vio, R_vio = np.array(t_vio), np.array(R_vio)
+    seq, loop_to, info = np.ones(n, np.int32), -np.ones(n, np.int32), np.zeros((n, 8))
+    for (i, c) in ((n - 1, 0), (n - 3, 2)):
+        info[i, :3] = R_true[c].T @ (t_true[i] - t_true[c])
+        info[i, 3:7] = _R2q(R_true[c].T @ R_true[i])
+        loop_to[i] = c
+    return t_true, R_true, t_vio, R_vio, seq, loop_to, info
+
+
+def test_optimize6dof_closes_the_loop_in_all_six_degrees_of_freedom():
+    """PoseGraph::optimize6DoF (pose_graph.cpp:583-740): RelativeRTError edges, quaternion parameterisation"""
+    t_true, R_true, t_vio, R_vio, seq, loop_to, info = _drift_graph6()
+    to, Ro, dr = o_optimize6dof(t_vio, R_vio, seq, loop_to, info)
+    e0, e1 = np.linalg.norm(t_vio - t_true, axis=1), np.linalg.norm(to - t_true, axis=1)
+    ang = lambda A, B: np.degrees(np.arccos(np.clip((np.trace(A.T @ B) - 1) / 2, -1, 1)))
+    a0, a1 = ang(R_vio[-1], R_true[-1]), ang(Ro[-1], R_true[-1])
+    assert e0[-1] > 0.2 and a0 > 3.0                                       # the drift is real, rotation included
+    # position and ATTITUDE move towards the truth (4-DoF keeps pitch / roll) -- by a quarter in five iterations: the sequential edges weigh a
+    # rotation 200 / rad (q_var 0.01) while the loop edges sit deep in the Huber regime (weight sqrt(0.1 / |r|) = 0.13 at 3.5 degrees)
+    assert e1[-1] < 0.85 * e0[-1] and a1 < 0.95 * a0, (e0[-1], e1[-1], a0, a1)
+    assert np.allclose(to[0], t_vio[0]) and np.allclose(Ro[0], R_vio[0], atol=1e-12)
+    assert np.abs(Ro @ Ro.transpose(0, 2, 1) - np.eye(3)).max() < 1e-12    # the quaternions stay unit
+    rd, td = dr[:9].reshape(3, 3), dr[9:]
+    assert np.abs(rd @ t_vio[-1] + td - to[-1]).max() < 1e-9 and np.abs(rd @ R_vio[-1] - Ro[-1]).max() < 1e-9
+    # one loop edge alone (two nodes of different sequences: no sequential edge) is solved exactly: the Jacobians are the residual's
+    R0, t0, Rm, tm = rot_zyx(0.3, 0.05, -0.02), np.array([1.0, 2.0, 0.5]), rot_zyx(0.1, -0.03, 0.04), np.array([0.3, -0.2, 0.1])
+    R1t, t1t = R0 @ Rm, t0 + R0 @ tm
+    inf2 = np.zeros((2, 8)); inf2[1, :3] = tm; inf2[1, 3:7] = _R2q(Rm)
+    tq, Rq, _ = o_optimize6dof(np.array([t0, t1t + [0.03, -0.02, 0.01]]), np.array([R0, R1t @ rot_zyx(0.02, 0.01, -0.015)]), np.array([1, 2], np.int32),
+                               np.array([-1, 0], np.int32), inf2)
+    assert np.abs(tq[1] - t1t).max() < 1e-12 and np.abs(Rq[1] - R1t).max() < 1e-12
+    # a consistent graph (VIO = truth, loops measured truly) is a fixed point; sequence 0 stays constant
+    to2, Ro2, _ = o_optimize6dof(t_true, R_true, seq, loop_to, info)
+    assert np.abs(to2 - t_true).max() < 1e-9 and np.abs(Ro2 - R_true).max() < 1e-9
+    seq0 = seq.copy(); seq0[:10] = 0
+    to3, _, _ = o_optimize6dof(t_vio, R_vio, seq0, loop_to, info)
+    assert np.abs(to3[:10] - t_vio[:10]).max() == 0

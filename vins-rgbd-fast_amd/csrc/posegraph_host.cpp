@@ -271,3 +271,186 @@ extern "C" int vio_pg_optimize4dof(int n, const double *t, const double *R, cons
     }
     return VIO_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------- optimize6DoF
+namespace {
+using namespace dm;
+
+// RelativeRTError (pose_graph.h:256-320): the pose of node b in the frame of node a against a measured (t, q); t_var 0.1, q_var 0.01
+struct Link6 { int a, b; v3 t; quat q; bool loop; };
+struct Link6Eval { double r[6]; double Ja[6][6], Jb[6][6]; };   // columns: left half-angle perturbation of the quaternion (3), translation (3)
+
+v3 qvec_of_sandwich(quat A, v3 d, quat B) {   // vector part of A * [0, d] * B
+    const v3 av = mk(A.x, A.y, A.z), bv = mk(B.x, B.y, B.z);
+    const double s = -dot(d, bv);
+    const v3 v = add(scl(B.w, d), cross(d, bv));
+    return add(add(scl(A.w, v), scl(s, av)), cross(av, v));
+}
+
+void evaluate6(const Link6 &e, const std::vector<quat> &q, const std::vector<double> &pos, Link6Eval &o, bool withJ) {
+    const double tv = 0.1, qv = 0.01;
+    const m3 RaT = tr(q2R(qnormalized(q[e.a])));     // ceres::QuaternionRotatePoint normalises
+    const v3 d = mk(pos[3 * e.b] - pos[3 * e.a], pos[3 * e.b + 1] - pos[3 * e.a + 1], pos[3 * e.b + 2] - pos[3 * e.a + 2]);
+    const v3 u = mul(RaT, d);
+    o.r[0] = (u.x - e.t.x) / tv; o.r[1] = (u.y - e.t.y) / tv; o.r[2] = (u.z - e.t.z) / tv;
+    const quat qac = mkq(q[e.a].w, -q[e.a].x, -q[e.a].y, -q[e.a].z), qmc = mkq(e.q.w, -e.q.x, -e.q.y, -e.q.z);
+    const quat A = qmul(qmc, qac), err = qmul(A, q[e.b]);
+    o.r[3] = 2.0 * err.x / qv; o.r[4] = 2.0 * err.y / qv; o.r[5] = 2.0 * err.z / qv;
+    if (!withJ) return;
+    memset(o.Ja, 0, sizeof(o.Ja)); memset(o.Jb, 0, sizeof(o.Jb));
+    // R_a -> (I + 2 [dtheta]x) R_a:  R_a^T d -> R_a^T d + 2 R_a^T [d]x dtheta
+    const m3 Rd = mul(RaT, skew(d));
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 3; c++) {
+            o.Ja[r][c] = 2.0 * Rd.a[3 * r + c] / tv;
+            o.Ja[r][3 + c] = -RaT.a[3 * r + c] / tv;
+            o.Jb[r][3 + c] = RaT.a[3 * r + c] / tv;
+        }
+    for (int c = 0; c < 3; c++) {
+        const v3 col = qvec_of_sandwich(A, mk(c == 0, c == 1, c == 2), q[e.b]);
+        const double v[3] = {2.0 * col.x / qv, 2.0 * col.y / qv, 2.0 * col.z / qv};
+        for (int r = 0; r < 3; r++) { o.Jb[3 + r][c] = v[r]; o.Ja[3 + r][c] = -v[r]; }
+    }
+}
+
+double total_cost6(const std::vector<Link6> &links, const std::vector<quat> &q, const std::vector<double> &pos) {
+    double c = 0;
+    Link6Eval ev;
+    for (const Link6 &e : links) {
+        evaluate6(e, q, pos, ev, false);
+        double s = 0;
+        for (int k = 0; k < 6; k++) s += ev.r[k] * ev.r[k];
+        c += e.loop ? huber_half(s) : 0.5 * s;
+    }
+    return c;
+}
+
+quat quat_plus(quat q, const double *d) {   // ceres::QuaternionParameterization::Plus
+    const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    if (!(n > 0.0)) return q;
+    const double s = sin(n) / n;
+    return qmul(mkq(cos(n), s * d[0], s * d[1], s * d[2]), q);
+}
+
+}  // namespace
+
+extern "C" int vio_pg_optimize6dof(int n, const double *t, const double *R, const int32_t *sequence, const int32_t *loop_to, const double *loop_info,
+                                   double *t_out, double *R_out, double *drift12) {
+    if (n < 1 || !t || !R || !sequence || !loop_to || !loop_info || !t_out || !R_out || !drift12) { g_err = "vio_pg_optimize6dof: bad argument"; return VIO_EINVAL; }
+    std::vector<quat> q(n);
+    std::vector<double> pos(t, t + 3 * (size_t)n);
+    std::vector<int> slot(n, -1);
+    int nvar = 0;
+    for (int i = 0; i < n; i++) {
+        q[i] = R2q(ldm(R + 9 * i));
+        if (!(i == 0 || sequence[i] == 0)) { slot[i] = nvar; nvar += 6; }
+    }
+    std::vector<Link6> links;
+    for (int i = 0; i < n; i++) {
+        for (int back = 1; back <= 4; back++) {
+            const int a = i - back;
+            if (a < 0 || sequence[a] != sequence[i]) continue;
+            const quat qai = qinv(q[a]);
+            links.push_back(Link6{a, i, mul(q2R(qai), mk(t[3 * i] - t[3 * a], t[3 * i + 1] - t[3 * a + 1], t[3 * i + 2] - t[3 * a + 2])), qmul(qai, q[i]), false});
+        }
+        if (loop_to[i] >= 0) {
+            if (loop_to[i] >= n) { g_err = "vio_pg_optimize6dof: loop partner out of range"; return VIO_EINVAL; }
+            links.push_back(Link6{loop_to[i], i, mk(loop_info[8 * i], loop_info[8 * i + 1], loop_info[8 * i + 2]),
+                                  mkq(loop_info[8 * i + 3], loop_info[8 * i + 4], loop_info[8 * i + 5], loop_info[8 * i + 6]), true});
+        }
+    }
+    if (nvar > 0) {   // the trust-region loop of vio_pg_optimize4dof with six columns per node
+        double radius = 1e4, shrink = 2.0, cost = total_cost6(links, q, pos);
+        std::vector<double> colscale;
+        int iterations = 0;
+        while (iterations < 5) {
+            std::vector<double> H((size_t)nvar * nvar, 0.0), g(nvar, 0.0);
+            Link6Eval ev;
+            for (const Link6 &e : links) {
+                evaluate6(e, q, pos, ev, true);
+                double w = 1.0;
+                if (e.loop) {
+                    double s = 0;
+                    for (int k = 0; k < 6; k++) s += ev.r[k] * ev.r[k];
+                    if (s > 0.01) w = sqrt(0.1 / sqrt(s));
+                }
+                const int base[2] = {slot[e.a], slot[e.b]};
+                auto J = [&](int end, int row, int c) { return w * (end == 0 ? ev.Ja[row][c] : ev.Jb[row][c]); };
+                for (int e0 = 0; e0 < 2; e0++) {
+                    if (base[e0] < 0) continue;
+                    for (int c0 = 0; c0 < 6; c0++) {
+                        double gs = 0;
+                        for (int row = 0; row < 6; row++) gs += J(e0, row, c0) * w * ev.r[row];
+                        g[base[e0] + c0] += gs;
+                        for (int e1 = 0; e1 < 2; e1++) {
+                            if (base[e1] < 0) continue;
+                            for (int c1 = 0; c1 < 6; c1++) {
+                                double hs = 0;
+                                for (int row = 0; row < 6; row++) hs += J(e0, row, c0) * J(e1, row, c1);
+                                H[(size_t)(base[e0] + c0) * nvar + base[e1] + c1] += hs;
+                            }
+                        }
+                    }
+                }
+            }
+            if (colscale.empty()) { colscale.resize(nvar); for (int a = 0; a < nvar; a++) colscale[a] = 1.0 / (1.0 + sqrt(H[(size_t)a * nvar + a])); }
+            double gmax = 0;
+            for (int a = 0; a < nvar; a++) gmax = fmax(gmax, fabs(g[a]));
+            if (gmax <= 1e-10) break;
+            std::vector<double> Hs((size_t)nvar * nvar), gsv(nvar);
+            for (int a = 0; a < nvar; a++) { gsv[a] = colscale[a] * g[a]; for (int b = 0; b < nvar; b++) Hs[(size_t)a * nvar + b] = colscale[a] * colscale[b] * H[(size_t)a * nvar + b]; }
+            bool moved = false;
+            int tries = 0;
+            while (!moved && tries++ < 20) {
+                std::vector<double> A = Hs, step = gsv;
+                for (int a = 0; a < nvar; a++) A[(size_t)a * nvar + a] += fmin(fmax(Hs[(size_t)a * nvar + a], 1e-6), 1e32) / radius;
+                if (!spd_solve(A, step, nvar)) { radius /= shrink; shrink *= 2; continue; }
+                double lin = 0, quad = 0;
+                for (int a = 0; a < nvar; a++) {
+                    double hv = 0;
+                    for (int b = 0; b < nvar; b++) hv += Hs[(size_t)a * nvar + b] * step[b];
+                    lin += gsv[a] * step[a];
+                    quad += step[a] * hv;
+                }
+                const double model = lin - 0.5 * quad;
+                std::vector<quat> qc = q;
+                std::vector<double> pc = pos;
+                for (int i = 0; i < n; i++) {
+                    if (slot[i] < 0) continue;
+                    double d[3];
+                    for (int a = 0; a < 3; a++) d[a] = -step[slot[i] + a] * colscale[slot[i] + a];
+                    qc[i] = quat_plus(q[i], d);
+                    for (int a = 0; a < 3; a++) pc[3 * i + a] = pos[3 * i + a] - step[slot[i] + 3 + a] * colscale[slot[i] + 3 + a];
+                }
+                const double cnew = total_cost6(links, qc, pc);
+                const double rho = model > 0 ? (cost - cnew) / model : -1.0;
+                if (rho > 1e-3) {
+                    const double rel = fabs(cost - cnew) / cost;
+                    q.swap(qc); pos.swap(pc); cost = cnew;
+                    radius = fmin(radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rho - 1.0, 3)), 1e16);
+                    shrink = 2.0;
+                    moved = true;
+                    iterations++;
+                    if (rel < 1e-6) iterations = 5;
+                } else {
+                    radius /= shrink; shrink *= 2;
+                    iterations++;          // an unsuccessful step counts as an iteration
+                    if (iterations >= 5) break;
+                }
+            }
+            if (!moved) break;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        for (int a = 0; a < 3; a++) t_out[3 * i + a] = pos[3 * i + a];
+        stm(R_out + 9 * i, q2R(q[i]));
+    }
+    {   // r_drift = R_cur R_vio^T, t_drift = t_cur - r_drift t_vio (pose_graph.cpp:717-721)
+        const int l = n - 1;
+        const m3 rd = mul(q2R(q[l]), tr(ldm(R + 9 * l)));
+        const v3 td = sub(mk(pos[3 * l], pos[3 * l + 1], pos[3 * l + 2]), mul(rd, mk(t[3 * l], t[3 * l + 1], t[3 * l + 2])));
+        stm(drift12, rd);
+        drift12[9] = td.x; drift12[10] = td.y; drift12[11] = td.z;
+    }
+    return VIO_OK;
+}

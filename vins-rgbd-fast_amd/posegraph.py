@@ -28,6 +28,7 @@ def _lib():
         L.vio_pg_match.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.vio_pg_find_connection.argtypes = [C.c_int] + [C.c_void_p] * 8 + [C.c_int] + [C.c_void_p] * 5
         L.vio_pg_optimize4dof.argtypes = [C.c_int] + [C.c_void_p] * 8
+        L.vio_pg_optimize6dof.argtypes = [C.c_int] + [C.c_void_p] * 8
         L.vio_pg_stage_blur.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.vio_pg_voc_load.argtypes = [C.c_char_p]
         L.vio_pg_voc_load.restype = C.c_void_p
@@ -129,6 +130,19 @@ def optimize4DoF(t, R, sequence, loop_to, loop_info):
     _chk(P, L, L.vio_pg_optimize4dof(n, t.ctypes.data, R.ctypes.data, sq.ctypes.data, lt.ctypes.data, li.ctypes.data, to.ctypes.data, Ro.ctypes.data,
                                      dr.ctypes.data), "vio_pg_optimize4dof")
     return to, Ro.reshape(n, 3, 3), (dr[0], dr[1:].copy())
+
+
+def optimize6DoF(t, R, sequence, loop_to, loop_info):
+    """PoseGraph::optimize6DoF (`imu: 0`): (t_out[n][3], R_out[n][3][3], (r_drift[3][3], t_drift[3]))"""
+    P, L = _lib()
+    t, R = np.ascontiguousarray(t, np.float64).reshape(-1, 3), np.ascontiguousarray(R, np.float64).reshape(-1, 9)
+    n = len(t)
+    sq, lt = np.ascontiguousarray(sequence, np.int32).reshape(n), np.ascontiguousarray(loop_to, np.int32).reshape(n)
+    li = np.ascontiguousarray(loop_info, np.float64).reshape(n, 8)
+    to, Ro, dr = np.zeros((n, 3)), np.zeros((n, 9)), np.zeros(12)
+    _chk(P, L, L.vio_pg_optimize6dof(n, t.ctypes.data, R.ctypes.data, sq.ctypes.data, lt.ctypes.data, li.ctypes.data, to.ctypes.data, Ro.ctypes.data,
+                                     dr.ctypes.data), "vio_pg_optimize6dof")
+    return to, Ro.reshape(n, 3, 3), (dr[:9].reshape(3, 3).copy(), dr[9:].copy())
 
 
 class KeyFrame:
