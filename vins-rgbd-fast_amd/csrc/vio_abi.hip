@@ -50,6 +50,7 @@ struct vio_batch {
         hipStream_t fe_stream = nullptr;  // front-end: frame k+1 tracks while frame k is still being marginalised
         hipEvent_t ev_solve = nullptr, ev_fe = nullptr, ev_be = nullptr, ev_ingest = nullptr;
         hipStream_t copy_stream = nullptr;   // host -> HBM uploads of vio_feed (on_device == 0), beside the kernels of the previous frame
+        hipGraphExec_t solve_graph = nullptr;   // VIO_GRAPH: setup + iteration slots + final of this group as one graph launch
         hipEvent_t ev_up_gray = nullptr, ev_up_depth = nullptr;
         // the staging images of vio_feed are double-buffered: frame n uploads into buffer n & 1 while frame n-1's kernels still read the
         // other one, so an upload only waits for the readers of frame n-2 (ev_rd_gray / ev_rd_depth of its buffer)
@@ -73,6 +74,7 @@ struct vio_batch {
     int tracker_lag = 0;              // vio_set_tracker_lag
     int extra_slots = 2;              // VIO_EXTRA_SLOTS: iteration slots beyond max_iterations (1 carries the last evaluation, the second absorbs one Cholesky retry / invalid step)
     int xcd_n = 0;                    // VIO_XCD_N: override of the XCD count the map assumes (0: 8)
+    bool use_graph = false;           // VIO_GRAPH: replay the solve chain of a group as a hipGraph (launch_backend)
     int xcd_map = 1;                  // VIO_XCD_MAP: XCD-aware block map of the multi-block ps_* kernels (be_phased.h ps_blk)
     int fe_xcd_map = 1;               // VIO_FE_XCD_MAP: the same idea for fe_lk (needs the front-end on every XCD: off under a CU partition)
     bool fe_partitioned = false;      // the front-end streams carry a CU mask (VIO_FE_CUS > 0 with tracker lag 1)
@@ -613,29 +615,45 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
     if (h->solve_mode == 1) {
         // phased solver: every data-parallel phase of the trust-region loop covers all sequences with many workgroups; max_iterations
         // + 1 slots carry the iterations, two more absorb Cholesky retries (a converged sequence falls through the remaining launches)
-        ps_setup_kernel<<<S, 512, 0, st>>>(Bg);
-        const int slots = C.c.max_iterations + h->extra_slots;
-        // XCD-aware block map (ps_blk): every block of a sequence on the XCD its one-block kernels run on
-        const bool xm = h->xcd_map && S >= 8;
-        const int XN = h->xcd_n > 0 ? h->xcd_n : 8;   // (measured with the back-end streams masked to six XCDs: 8 -> +2 %, 6 -> +0.3 %, 3 / 12 -> -1 %: the block -> XCD rotation ignores the mask)
-        const int nb_e = h->ps_eval_blocks, nb_a = h->ps_asm_a_blocks, nb_bs = h->ps_asm_b_blocks + h->ps_schur_tiles, S8 = XN * ((S + XN - 1) / XN);
-        Batch Be = Bg, Ba = Bg, Bb = Bg;
-        Be.ns = Ba.ns = Bb.ns = S;
-        Be.xcd_n = Ba.xcd_n = Bb.xcd_n = XN;
-        Be.xcd_nb = xm ? nb_e : 0; Ba.xcd_nb = xm ? nb_a : 0; Bb.xcd_nb = xm ? nb_bs : 0;
-        const dim3 g_e = xm ? dim3(S8 * nb_e) : dim3(nb_e, S), g_a = xm ? dim3(S8 * nb_a) : dim3(nb_a, S), g_b = xm ? dim3(S8 * nb_bs) : dim3(nb_bs, S);
-        for (int k = 0; k < slots; k++) {
-            if (h->eval_occ == 4) ps_eval_kernel_occ4<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
-            else if (h->eval_occ == 3) ps_eval_kernel_occ3<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
-            else ps_eval_kernel<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
-            if (h->asm_a_occ4) ps_asm_a_kernel_occ4<<<g_a, 512, 0, st>>>(Ba);
-            else ps_asm_a_kernel<<<g_a, 512, 0, st>>>(Ba);
-            ps_asm_b_schur_kernel<<<g_b, 256, (size_t)(C.NL + 16 + 3 * 256) * sizeof(double), st>>>(Bb, h->ps_asm_b_blocks);   // per-row factors + the partial tiles of wavefronts 1 .. 3
-            if (h->serial_big) ps_serial_big_kernel<<<S, 512, h->lds_serial, st>>>(Bg);
-            else if (h->serial_threads <= 512) ps_serial_kernel_512<<<S, 512, h->lds_serial, st>>>(Bg);
-            else ps_serial_kernel<<<S, 1024, h->lds_serial, st>>>(Bg);
-        }
-        ps_final_kernel<<<S, 256, 0, st>>>(Bg);
+        auto launch_phased = [&]() {
+            ps_setup_kernel<<<S, 512, 0, st>>>(Bg);
+            const int slots = C.c.max_iterations + h->extra_slots;
+            // XCD-aware block map (ps_blk): every block of a sequence on the XCD its one-block kernels run on
+            const bool xm = h->xcd_map && S >= 8;
+            const int XN = h->xcd_n > 0 ? h->xcd_n : 8;   // (measured with the back-end streams masked to six XCDs: 8 -> +2 %, 6 -> +0.3 %, 3 / 12 -> -1 %: the block -> XCD rotation ignores the mask)
+            const int nb_e = h->ps_eval_blocks, nb_a = h->ps_asm_a_blocks, nb_bs = h->ps_asm_b_blocks + h->ps_schur_tiles, S8 = XN * ((S + XN - 1) / XN);
+            Batch Be = Bg, Ba = Bg, Bb = Bg;
+            Be.ns = Ba.ns = Bb.ns = S;
+            Be.xcd_n = Ba.xcd_n = Bb.xcd_n = XN;
+            Be.xcd_nb = xm ? nb_e : 0; Ba.xcd_nb = xm ? nb_a : 0; Bb.xcd_nb = xm ? nb_bs : 0;
+            const dim3 g_e = xm ? dim3(S8 * nb_e) : dim3(nb_e, S), g_a = xm ? dim3(S8 * nb_a) : dim3(nb_a, S), g_b = xm ? dim3(S8 * nb_bs) : dim3(nb_bs, S);
+            for (int k = 0; k < slots; k++) {
+                if (h->eval_occ == 4) ps_eval_kernel_occ4<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
+                else if (h->eval_occ == 3) ps_eval_kernel_occ3<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
+                else ps_eval_kernel<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
+                if (h->asm_a_occ4) ps_asm_a_kernel_occ4<<<g_a, 512, 0, st>>>(Ba);
+                else ps_asm_a_kernel<<<g_a, 512, 0, st>>>(Ba);
+                ps_asm_b_schur_kernel<<<g_b, 256, (size_t)(C.NL + 16 + 3 * 256) * sizeof(double), st>>>(Bb, h->ps_asm_b_blocks);   // per-row factors + the partial tiles of wavefronts 1 .. 3
+                if (h->serial_big) ps_serial_big_kernel<<<S, 512, h->lds_serial, st>>>(Bg);
+                else if (h->serial_threads <= 512) ps_serial_kernel_512<<<S, 512, h->lds_serial, st>>>(Bg);
+                else ps_serial_kernel<<<S, 1024, h->lds_serial, st>>>(Bg);
+            }
+            ps_final_kernel<<<S, 256, 0, st>>>(Bg);
+        };
+        // VIO_GRAPH: the 43 launches of one solve replayed as a hipGraph captured on the group's stream at its first use (the kernel
+        // arguments -- the Batch of the group -- do not change from frame to frame; setters that change them drop the graph)
+        if (h->use_graph && one_seq < 0) {
+            if (!g.solve_graph) {
+                hipGraph_t gr = nullptr;
+                HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                launch_phased();
+                HIPCHK(hipStreamEndCapture(st, &gr));
+                HIPCHK(hipGraphInstantiate(&g.solve_graph, gr, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(gr);
+            }
+            HIPCHK(hipGraphLaunch(g.solve_graph, st));
+        } else
+            launch_phased();
     } else if (be_threads <= 512) be_solve_kernel_512<<<S, be_threads, h->lds_solve, st>>>(Bg);
     else be_solve_kernel<<<S, be_threads, h->lds_solve, st>>>(Bg);
     if (prof) PEV(h, 10);
@@ -779,6 +797,7 @@ static int build_devcfg(const vio_config *cfg, int imu_capacity, DevCfg &C) {
 // the rest; VIO_BE_CU_SPLIT = 1: the back-end streams of the groups share [n, 256) in equal contiguous parts; VIO_BE_CU_ALL = 1: back-end
 // on all CUs.  With lag 0 the front-end is on the critical path itself and gets the whole device.
 static int create_group_streams(vio_batch *h, vio_batch::Group &g, bool partitioned) {
+    if (g.solve_graph) { (void)hipGraphExecDestroy(g.solve_graph); g.solve_graph = nullptr; }   // captured on the stream that goes away
     if (g.stream) { (void)hipStreamDestroy(g.stream); g.stream = nullptr; }
     if (g.fe_stream) { (void)hipStreamDestroy(g.fe_stream); g.fe_stream = nullptr; }
     // the partition is sized from the device: a quarter of its compute units (64 of the MI355X's 256 = two XCDs) for the front-end by
@@ -859,6 +878,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
     if (getenv("VIO_BE_THREADS")) h->be_threads = std::min(1024, std::max(64, atoi(getenv("VIO_BE_THREADS")) & ~63));
     if (getenv("VIO_ASM_B_BLOCKS")) h->ps_asm_b_blocks = std::max(1, std::min(256, atoi(getenv("VIO_ASM_B_BLOCKS"))));
     if (getenv("VIO_EVAL_OCC")) h->eval_occ = atoi(getenv("VIO_EVAL_OCC"));
+    if (getenv("VIO_GRAPH")) h->use_graph = atoi(getenv("VIO_GRAPH")) != 0;
     if (getenv("VIO_XCD_MAP")) h->xcd_map = atoi(getenv("VIO_XCD_MAP"));
     if (getenv("VIO_FE_XCD_MAP")) h->fe_xcd_map = atoi(getenv("VIO_FE_XCD_MAP"));
     if (getenv("VIO_XCD_N")) h->xcd_n = atoi(getenv("VIO_XCD_N"));
@@ -1013,6 +1033,7 @@ void vio_destroy(vio_batch *h) {
         if (g.ev_fe) (void)hipEventDestroy(g.ev_fe);
         if (g.ev_be) (void)hipEventDestroy(g.ev_be);
         if (g.ev_ingest) (void)hipEventDestroy(g.ev_ingest);
+        if (g.solve_graph) (void)hipGraphExecDestroy(g.solve_graph);
         if (g.ev_up_gray) (void)hipEventDestroy(g.ev_up_gray);
         if (g.ev_up_depth) (void)hipEventDestroy(g.ev_up_depth);
         for (int p = 0; p < 2; p++) {
