@@ -245,3 +245,33 @@ def test_tile_cholesky_against_numpy(P, nb):
     S2[n - 3, n - 3] = -1.0
     assert P.lib().vio_stage_chol(nb, 1, 1, S2.ctypes.data, b.ctypes.data, L.ctypes.data, x.ctypes.data, us.ctypes.data) == 0
     assert np.isnan(x).all()
+
+
+@pytest.mark.parametrize("nb", [12, 21, 24])
+def test_streaming_tile_cholesky_against_numpy_and_the_lds_path(P, nb):
+    """ps_serial_big's factorisation for windows beyond 10 keyframes (be_linalg.h chol_tiles_stream / chol_backward_tiles: the tiles stay in
+    HBM / L2, one block column at a time goes through LDS): against numpy at the sizes only it serves, and bit for bit against the
+    LDS-resident factorisation (vio_stage_chol blocks = -7 forces the streaming path) where both apply -- the two share every arithmetic step."""
+    def spd(n, seed):
+        rng = np.random.default_rng(seed)
+        q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        S = (q * np.exp(rng.uniform(0, np.log(1e6), n))) @ q.T
+        return 0.5 * (S + S.T), rng.standard_normal(n)
+    n = 16 * nb
+    S, b = spd(n, 70 + nb)
+    L, x, us = np.zeros((n, n)), np.zeros(n), np.zeros(5)
+    assert P.lib().vio_stage_chol(nb, 1, 2, S.ctypes.data, b.ctypes.data, L.ctypes.data, x.ctypes.data, us.ctypes.data) == 0
+    Lr, xr = np.linalg.cholesky(S), np.linalg.solve(S, b)
+    assert np.abs(np.triu(L, 1)).max() == 0.0 and np.abs(L - Lr).max() <= 1e-11 * np.abs(Lr).max()
+    assert np.abs(x - xr).max() <= 1e-9 * np.abs(xr).max()
+    S2 = S.copy(); S2[n - 5, n - 5] = -1.0
+    assert P.lib().vio_stage_chol(nb, 1, 1, S2.ctypes.data, b.ctypes.data, L.ctypes.data, x.ctypes.data, us.ctypes.data) == 0
+    assert np.isnan(x).all()
+    m = 11 if nb > 12 else 6
+    S3, b3 = spd(16 * m, 90 + nb)
+    out = []
+    for mode in (1, -7):
+        Lo, xo = np.zeros_like(S3), np.zeros(16 * m)
+        assert P.lib().vio_stage_chol(m, 1, mode, S3.ctypes.data, b3.ctypes.data, Lo.ctypes.data, xo.ctypes.data, us.ctypes.data) == 0
+        out.append((Lo, xo))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])

@@ -1115,12 +1115,14 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
 // the wavefront that owns it, as soon as it has it; panel tiles X = A M^T; the right-hand side block riding along) and written back.
 // Per element the same operations in the same order as chol_tiles (updates in ascending column order, each a chain of four MFMAs), so
 // the two factorisations agree bit for bit.  Traffic: nb^3 / 6 tile reads (3 MB at nb = 21), all of it L2 hits.
-__device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col, int *sh_flag, double *dinv, double *rhs) {
+__device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col, int *sh_flag, double *dinv, double *rhs, float *tm = nullptr) {
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
     const int li = lane & 15, lk = lane >> 4;
     auto gtile = [&](int ti, int tj) -> double * { return G + ((size_t)(ti * (ti + 1) / 2 + tj) << 8); };
     if (t == 0) *sh_flag = 1;
     __syncthreads();
+    long long tm1 = tm ? (long long)wall_clock64() : 0;   // timing harness only (stage_linalg.hip), as wavefront 1 sees the phases: [0] update of the
+                                                          // column incl. the wait for the diagonal block, [1] panels, [2] write-back + right-hand side
     for (int p = 0; p < nb; p++) {
         // (a) column p minus the finished columns, into LDS; wavefront (i - p) mod nw owns row tile i
         for (int i = p + wave; i < nb; i += nw) {
@@ -1155,12 +1157,15 @@ __device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col
             for (int r = 0; r < 4; r++) ct[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))] = acc[r];
             if (i == p) { WAVE_SYNC(); chol_diag_tile(ct, dinv + 16 * p, sh_flag); }
         }
+        if (tm && t == 64) { long long n_ = (long long)wall_clock64(); tm[0] += (float)(n_ - tm1); }
         __syncthreads();
+        if (tm && t == 64) tm1 = (long long)wall_clock64();
         if (!*sh_flag) return false;
         // (b) panel tiles and the right-hand side block
         for (int i = p + 1 + wave; i < nb; i += nw) chol_panel_tile(col + ((i - p) << 8), col, dinv + 16 * p);
         if (rhs && wave == nw - 1) chol_rhs_block(rhs + 16 * p, col, dinv + 16 * p);
         __syncthreads();
+        if (tm && t == 64) { long long n_ = (long long)wall_clock64(); tm[1] += (float)(n_ - tm1); tm1 = n_; }
         // (c) the finished column goes back to HBM; the right-hand side rows below take their term b_i -= L_ip y_p
         for (int q = t; q < (nb - p) << 8; q += nt) gtile(p + (q >> 8), p)[q & 255] = col[q];
         if (rhs && wave == nw - 1)
@@ -1172,6 +1177,7 @@ __device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col
                 rhs[16 * (p + tl) + r] -= sacc;
             }
         __syncthreads();
+        if (tm && t == 64) { long long n_ = (long long)wall_clock64(); tm[2] += (float)(n_ - tm1); tm1 = n_; }
     }
     return *sh_flag != 0;
 }

@@ -127,9 +127,77 @@ __global__ __launch_bounds__(512) void be_stage_chol_kernel(int nb, int reps, in
     if (t == 0) { ticks[0] = (float)tf / reps; ticks[1] = (float)tb / reps; for (int k = 0; k < 3; k++) ticks[2 + k] = tm[k] / reps; }
 }
 
+// the streaming factorisation of ps_serial_big (windows beyond 10 keyframes): tiles in HBM / L2, one block column at a time through LDS
+__global__ __launch_bounds__(512) void be_stage_chol_stream_kernel(int nb, int reps, const double *S, const double *rhs, double *Tg, double *Lout, double *xout,
+                                                                    float *ticks) {
+    extern __shared__ __attribute__((aligned(16))) double colbuf[];
+    const int t = threadIdx.x, nt = blockDim.x, n = 16 * nb, ntile = nb * (nb + 1) / 2;
+    double *T = Tg + (size_t)blockIdx.x * ntile * 256;
+    double *xs = colbuf + (size_t)nb * 256, *dinv = xs + n;
+    __shared__ int flag;
+    __shared__ float tm[4];
+    if (t < 4) tm[t] = 0;
+    long long tf = 0, tb = 0;
+    bool ok = true;
+    for (int rep = 0; rep < reps; rep++) {
+        for (int q = t; q < ntile * 256; q += nt) {
+            int ti, tj;
+            tri_decode(q >> 8, ti, tj);
+            T[tl_idx(ti, tj, (q >> 4) & 15, q & 15)] = S[(size_t)(16 * ti + ((q >> 4) & 15)) * n + 16 * tj + (q & 15)];
+        }
+        for (int q = t; q < n; q += nt) xs[q] = rhs[q];
+        __threadfence_block();
+        __syncthreads();
+        const long long t0 = (long long)wall_clock64();
+        ok = chol_tiles_stream(T, nb, colbuf, &flag, dinv, xs, tm) && ok;
+        __syncthreads();
+        const long long t1 = (long long)wall_clock64();
+        if (ok) chol_backward_tiles(T, nb, xs, dinv);
+        __syncthreads();
+        const long long t2 = (long long)wall_clock64();
+        tf += t1 - t0; tb += t2 - t1;
+    }
+    if (blockIdx.x != 0) return;
+    for (int q = t; q < ntile * 256; q += nt) {
+        int ti, tj;
+        tri_decode(q >> 8, ti, tj);
+        const int r = (q >> 4) & 15, c = q & 15;
+        if (ti == tj && c > r) continue;
+        Lout[(size_t)(16 * ti + r) * n + 16 * tj + c] = T[tl_idx(ti, tj, r, c)];
+    }
+    for (int q = t; q < n; q += nt) xout[q] = ok ? xs[q] : nan("");
+    __syncthreads();
+    if (t == 0) { ticks[0] = (float)tf / reps; ticks[1] = (float)tb / reps; ticks[2] = tm[0] / reps; ticks[3] = tm[1] / reps; ticks[4] = tm[2] / reps; }
+}
+
 }  // namespace
 
 #define ST_CHK(x) do { if ((x) != hipSuccess) { rc = VIO_EDEVICE; goto done; } } while (0)
+
+// the streaming path (ps_serial_big): tiles in HBM, one block column in LDS; blocks = -7 forces it for nb <= 11 (bit-for-bit against the LDS path)
+static int stage_chol_stream(int nb, int reps, int blocks, const double *S, const double *rhs, double *L_out, double *x_out, double *usec2) {
+    int rc = VIO_OK;
+    const size_t n = 16 * (size_t)nb, ntile = (size_t)nb * (nb + 1) / 2, lds = ((size_t)nb * 256 + 2 * n) * sizeof(double);
+    const int nblk = blocks < 0 ? 1 : blocks;
+    double *dS = nullptr, *dr = nullptr, *dL = nullptr, *dx = nullptr, *dT = nullptr;
+    float *dt = nullptr, ht[5] = {0, 0, 0, 0, 0};
+    int rate_khz = 100000, dev = 0;
+    ST_CHK(hipFuncSetAttribute((const void *)be_stage_chol_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    ST_CHK(hipMalloc((void **)&dS, n * n * 8)); ST_CHK(hipMalloc((void **)&dr, n * 8)); ST_CHK(hipMalloc((void **)&dL, n * n * 8));
+    ST_CHK(hipMalloc((void **)&dx, n * 8)); ST_CHK(hipMalloc((void **)&dt, 32)); ST_CHK(hipMalloc((void **)&dT, (size_t)nblk * ntile * 256 * 8));
+    ST_CHK(hipMemcpy(dS, S, n * n * 8, hipMemcpyHostToDevice)); ST_CHK(hipMemcpy(dr, rhs, n * 8, hipMemcpyHostToDevice));
+    ST_CHK(hipMemcpy(dL, L_out, n * n * 8, hipMemcpyHostToDevice));
+    be_stage_chol_stream_kernel<<<nblk, 512, lds>>>(nb, reps, dS, dr, dT, dL, dx, dt);
+    ST_CHK(hipDeviceSynchronize());
+    ST_CHK(hipMemcpy(L_out, dL, n * n * 8, hipMemcpyDeviceToHost)); ST_CHK(hipMemcpy(x_out, dx, n * 8, hipMemcpyDeviceToHost));
+    ST_CHK(hipMemcpy(ht, dt, 20, hipMemcpyDeviceToHost));
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || rate_khz <= 0) rate_khz = 100000;
+    if (usec2) for (int k = 0; k < 5; k++) usec2[k] = ht[k] / (rate_khz * 1e-3);
+done:
+    if (dS) (void)hipFree(dS); if (dr) (void)hipFree(dr); if (dL) (void)hipFree(dL); if (dx) (void)hipFree(dx); if (dt) (void)hipFree(dt); if (dT) (void)hipFree(dT);
+    return rc;
+}
 
 // S: [16 nb][16 nb] row-major symmetric positive definite, rhs: [16 nb].  L_out (row-major, lower triangle written, the rest left as
 // passed in), x_out = S^-1 rhs, usec5 = {factorisation + forward substitution, backward substitution, and of the factorisation as
@@ -137,8 +205,10 @@ __global__ __launch_bounds__(512) void be_stage_chol_kernel(int nb, int reps, in
 // `blocks` identical workgroups run side by side).
 extern "C" int vio_stage_chol(int nb, int reps, int blocks, const double *S, const double *rhs, double *L_out, double *x_out, double *usec5) {
     double *usec2 = usec5;
-    if (nb < 1 || nb > 11 || reps < 1 || blocks == 0 || blocks < -6 || !S || !rhs || !L_out || !x_out) return VIO_EINVAL;
+    if (nb < 1 || nb > 24 || reps < 1 || blocks == 0 || blocks < -7 || !S || !rhs || !L_out || !x_out) return VIO_EINVAL;
+    if (nb > 11 && blocks < 0 && blocks != -7) return VIO_EINVAL;
     int rc = VIO_OK;
+    if (nb > 11 || blocks == -7) return stage_chol_stream(nb, reps, blocks, S, rhs, L_out, x_out, usec5);
     const size_t n = 16 * (size_t)nb, ntile = (size_t)nb * (nb + 1) / 2, lds = (ntile * 256 + 2 * n) * sizeof(double);
     double *dS = nullptr, *dr = nullptr, *dL = nullptr, *dx = nullptr;
     float *dt = nullptr, ht[5] = {0, 0, 0, 0, 0};
