@@ -1124,8 +1124,9 @@ __device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col
     long long tm1 = tm ? (long long)wall_clock64() : 0;   // timing harness only (stage_linalg.hip), as wavefront 1 sees the phases: [0] update of the
                                                           // column incl. the wait for the diagonal block, [1] panels, [2] write-back + right-hand side
     for (int p = 0; p < nb; p++) {
-        // (a) column p minus the finished columns, into LDS; wavefront (i - p) mod nw owns row tile i
-        for (int i = p + wave; i < nb; i += nw) {
+        // (a) column p minus the finished columns, into LDS: wavefront 0 takes the diagonal tile alone (its update and then the 2.3 us of
+        // chol_diag_tile are the phase's critical path), wavefronts 1 .. nw - 1 share the row tiles below it
+        for (int i = p + wave; i < nb; i += (wave == 0 ? nb : nw - 1)) {
             const double *gi = gtile(i, p);
             v4f64 acc;
 #pragma unroll
