@@ -75,6 +75,9 @@ def test_vocabulary_errors_are_reported(pg, tmp_path):
     voc = bow_util.make_vocabulary(3, 2, 1)
     with pytest.raises(P.VioError):   # only L1 scoring
         pg.Vocabulary.from_arrays(3, 2, 1, 0, voc["node_id"], voc["parent_id"], voc["weight"], voc["desc"], voc["word_node"], voc["word_id"])
+    bad = dict(voc); bad["parent_id"] = voc["parent_id"].copy(); bad["parent_id"][3] = voc["node_id"][3]       # a node that is its own parent
+    with pytest.raises(P.VioError):
+        pg.Vocabulary.from_arrays(3, 2, 0, 0, bad["node_id"], bad["parent_id"], bad["weight"], bad["desc"], bad["word_node"], bad["word_id"])
     (tmp_path / "short.bin").write_bytes(b"\\x03\\x00\\x00\\x00" * 7)
     with pytest.raises(P.VioError):
         pg.Vocabulary.load(str(tmp_path / "short.bin"))

@@ -165,8 +165,12 @@ vio_pg_voc *vio_pg_voc_create(int k, int L, int scoring, int weighting, int n_no
     v->k = k; v->L = L; v->scoring = scoring; v->weighting = weighting; v->n_nodes = n_nodes; v->n_words = n_words;
     const int NN = n_nodes + 1;   // + the root (TemplatedVocabulary.h:1526)
     std::vector<int> cnt((size_t)NN + 1, 0);
+    std::vector<char> seen((size_t)NN, 0);
     for (int i = 0; i < n_nodes; i++) {
         if (node_id[i] <= 0 || node_id[i] > n_nodes || parent_id[i] < 0 || parent_id[i] > n_nodes) { g_err = "vio_pg_voc_create: node id out of range"; delete v; return nullptr; }
+        // every node once and never its own parent: with one parent per node whatever the walk reaches from the root is a tree (no cycle to spin in)
+        if (seen[node_id[i]] || parent_id[i] == node_id[i]) { g_err = "vio_pg_voc_create: node listed twice or its own parent"; delete v; return nullptr; }
+        seen[node_id[i]] = 1;
         cnt[(size_t)parent_id[i] + 1]++;
     }
     v->child_begin.assign((size_t)NN + 1, 0);
