@@ -1115,15 +1115,36 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
 // the wavefront that owns it, as soon as it has it; panel tiles X = A M^T; the right-hand side block riding along) and written back.
 // Per element the same operations in the same order as chol_tiles (updates in ascending column order, each a chain of four MFMAs), so
 // the two factorisations agree bit for bit.  Traffic: nb^3 / 6 tile reads (3 MB at nb = 21), all of it L2 hits.
-__device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col, int *sh_flag, double *dinv, double *rhs, float *tm = nullptr) {
+__device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col2, int *sh_flag, double *dinv, double *rhs, float *tm = nullptr) {
+    // col2: TWO block columns of LDS (2 nb tiles).  Column p is built in buffer p & 1, and every tile goes back to HBM from the wavefront that
+    // finished it (the diagonal tile after its factorisation, a panel tile after its solve): no separate write-back phase, two barriers per
+    // column instead of three, and the right-hand side update of column p (last wavefront, reading buffer p & 1) runs beside the other
+    // wavefronts' updates of column p + 1, which fill the other buffer.
     const int t = threadIdx.x, nt = blockDim.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
     const int li = lane & 15, lk = lane >> 4;
     auto gtile = [&](int ti, int tj) -> double * { return G + ((size_t)(ti * (ti + 1) / 2 + tj) << 8); };
+    auto store_tile = [&](double *g, const double *ct) {   // one wavefront: 256 doubles
+#pragma unroll
+        for (int r = 0; r < 4; r++) g[lane + 64 * r] = ct[lane + 64 * r];
+    };
     if (t == 0) *sh_flag = 1;
     __syncthreads();
     long long tm1 = tm ? (long long)wall_clock64() : 0;   // timing harness only (stage_linalg.hip), as wavefront 1 sees the phases: [0] update of the
-                                                          // column incl. the wait for the diagonal block, [1] panels, [2] write-back + right-hand side
+                                                          // column incl. the wait for the diagonal block, [1] panels
     for (int p = 0; p < nb; p++) {
+        double *col = col2 + (size_t)(p & 1) * ((size_t)nb << 8);
+        // the right-hand side rows below block p - 1 take their term b_i -= L_i,p-1 y_p-1 (previous column's buffer)
+        if (rhs && wave == nw - 1 && p > 0) {
+            const double *pc = col2 + (size_t)((p - 1) & 1) * ((size_t)nb << 8);
+            for (int q = lane; q < 16 * (nb - p); q += 64) {
+                const int tl = 1 + (q >> 4), r = q & 15;
+                double sacc = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k++) sacc += pc[(tl << 8) + (r << 4) + (k ^ r)] * rhs[16 * (p - 1) + k];
+                rhs[16 * (p - 1 + tl) + r] -= sacc;
+            }
+            WAVE_SYNC();
+        }
         // (a) column p minus the finished columns, into LDS: wavefront 0 takes the diagonal tile alone (its update and then the 2.3 us of
         // chol_diag_tile are the phase's critical path), wavefronts 1 .. nw - 1 share the row tiles below it
         for (int i = p + wave; i < nb; i += (wave == 0 ? nb : nw - 1)) {
@@ -1133,6 +1154,16 @@ __device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col
             for (int r = 0; r < 4; r++) acc[r] = gi[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))];
             const double *ai = gtile(i, 0), *bp = gtile(p, 0);   // tiles (i, j), j = 0 .. i, are consecutive
             int j = 0;
+            for (; j + 4 <= p; j += 4) {   // four finished columns per trip: 32 loads in flight, then their 16 MFMAs
+                double a[16], b[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int off = ((j + (u >> 2)) << 8) + (li << 4) + ((4 * (u & 3) + lk) ^ li);
+                    a[u] = ai[off]; b[u] = bp[off];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u], b[u], acc, 0, 0, 0);
+            }
             for (; j + 2 <= p; j += 2) {
                 double a[8], b[8];
 #pragma unroll
@@ -1156,29 +1187,22 @@ __device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col
             double *ct = col + ((i - p) << 8);
 #pragma unroll
             for (int r = 0; r < 4; r++) ct[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))] = acc[r];
-            if (i == p) { WAVE_SYNC(); chol_diag_tile(ct, dinv + 16 * p, sh_flag); }
+            if (i == p) { WAVE_SYNC(); chol_diag_tile(ct, dinv + 16 * p, sh_flag); WAVE_SYNC(); store_tile(gtile(p, p), ct); }
         }
         if (tm && t == 64) { long long n_ = (long long)wall_clock64(); tm[0] += (float)(n_ - tm1); }
         __syncthreads();
         if (tm && t == 64) tm1 = (long long)wall_clock64();
         if (!*sh_flag) return false;
-        // (b) panel tiles and the right-hand side block
-        for (int i = p + 1 + wave; i < nb; i += nw) chol_panel_tile(col + ((i - p) << 8), col, dinv + 16 * p);
+        // (b) panel tiles (each back to HBM from the wavefront that solved it) and the right-hand side block
+        for (int i = p + 1 + wave; i < nb; i += nw) {
+            double *ct = col + ((i - p) << 8);
+            chol_panel_tile(ct, col, dinv + 16 * p);
+            WAVE_SYNC();
+            store_tile(gtile(i, p), ct);
+        }
         if (rhs && wave == nw - 1) chol_rhs_block(rhs + 16 * p, col, dinv + 16 * p);
         __syncthreads();
         if (tm && t == 64) { long long n_ = (long long)wall_clock64(); tm[1] += (float)(n_ - tm1); tm1 = n_; }
-        // (c) the finished column goes back to HBM; the right-hand side rows below take their term b_i -= L_ip y_p
-        for (int q = t; q < (nb - p) << 8; q += nt) gtile(p + (q >> 8), p)[q & 255] = col[q];
-        if (rhs && wave == nw - 1)
-            for (int q = lane; q < 16 * (nb - 1 - p); q += 64) {
-                const int tl = 1 + (q >> 4), r = q & 15;
-                double sacc = 0;
-#pragma unroll
-                for (int k = 0; k < 16; k++) sacc += col[(tl << 8) + (r << 4) + (k ^ r)] * rhs[16 * p + k];
-                rhs[16 * (p + tl) + r] -= sacc;
-            }
-        __syncthreads();
-        if (tm && t == 64) { long long n_ = (long long)wall_clock64(); tm[2] += (float)(n_ - tm1); tm1 = n_; }
     }
     return *sh_flag != 0;
 }
