@@ -3,6 +3,7 @@
 // that code.  Replaces nothing of the reference by itself: the reference reaches this arithmetic through Ceres' DENSE_SCHUR
 // (estimator.cpp:1251-1263, Eigen LLT underneath).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "../../include/vio_abi.h"
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(512) void be_stage_chol_kernel(int nb, int reps, in
 
 // the streaming factorisation of ps_serial_big (windows beyond 10 keyframes): tiles in HBM / L2, one block column at a time through LDS
 __global__ __launch_bounds__(512) void be_stage_chol_stream_kernel(int nb, int reps, const double *S, const double *rhs, double *Tg, double *Lout, double *xout,
-                                                                    float *ticks) {
+                                                                    float *ticks, int getenv_mode) {
     extern __shared__ __attribute__((aligned(16))) double colbuf[];
     const int t = threadIdx.x, nt = blockDim.x, n = 16 * nb, ntile = nb * (nb + 1) / 2;
     double *T = Tg + (size_t)blockIdx.x * ntile * 256;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(512) void be_stage_chol_stream_kernel(int nb, int r
         ok = chol_tiles_stream(T, nb, colbuf, &flag, dinv, xs, tm) && ok;
         __syncthreads();
         const long long t1 = (long long)wall_clock64();
-        if (ok) chol_backward_tiles(T, nb, xs, dinv);
+        if (ok) { if (getenv_mode) chol_backward_tiles(T, nb, xs, dinv); else chol_backward_tiles_wave(T, nb, xs, dinv); }   // (VIO_STAGE_BACKWARD_BLOCK: the all-wavefront walk, for comparison)
         __syncthreads();
         const long long t2 = (long long)wall_clock64();
         tf += t1 - t0; tb += t2 - t1;
@@ -187,7 +188,7 @@ static int stage_chol_stream(int nb, int reps, int blocks, const double *S, cons
     ST_CHK(hipMalloc((void **)&dx, n * 8)); ST_CHK(hipMalloc((void **)&dt, 32)); ST_CHK(hipMalloc((void **)&dT, (size_t)nblk * ntile * 256 * 8));
     ST_CHK(hipMemcpy(dS, S, n * n * 8, hipMemcpyHostToDevice)); ST_CHK(hipMemcpy(dr, rhs, n * 8, hipMemcpyHostToDevice));
     ST_CHK(hipMemcpy(dL, L_out, n * n * 8, hipMemcpyHostToDevice));
-    be_stage_chol_stream_kernel<<<nblk, 512, lds>>>(nb, reps, dS, dr, dT, dL, dx, dt);
+    be_stage_chol_stream_kernel<<<nblk, 512, lds>>>(nb, reps, dS, dr, dT, dL, dx, dt, getenv("VIO_STAGE_BACKWARD_BLOCK") ? 1 : 0);
     ST_CHK(hipDeviceSynchronize());
     ST_CHK(hipMemcpy(L_out, dL, n * n * 8, hipMemcpyDeviceToHost)); ST_CHK(hipMemcpy(x_out, dx, n * 8, hipMemcpyDeviceToHost));
     ST_CHK(hipMemcpy(ht, dt, 20, hipMemcpyDeviceToHost));
