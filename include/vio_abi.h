@@ -323,7 +323,9 @@ int vio_stage_imu_block(const vio_config *cfg, int n, const double *dt, const do
                         const double *pose_j, const double *sb_j, double *G961);
 /* The dense solve at the bottom of every trust-region step (Ceres DENSE_SCHUR on the reduced camera system, estimator.cpp:1251-1263;
  * Eigen LLT underneath) through the LDS-tile Cholesky of the solve kernels: S [16 nb][16 nb] row-major symmetric positive definite
- * (nb <= 11; 12 <= nb <= 24 or blocks = -7: the streaming factorisation of windows beyond 10 keyframes, tiles in HBM), rhs [16 nb].  L_out: the lower triangle of the factor (row-major; entries above the diagonal are left as passed in),
+ * (nb <= 11; 12 <= nb <= 24 or blocks = -7: the streaming factorisation of windows beyond 10 keyframes, tiles in HBM -- usec5 is then
+ * {factorisation, backward substitution, update of the block columns incl. the wait for their diagonal tiles, panels + tile stores, 0}),
+ * rhs [16 nb].  L_out: the lower triangle of the factor (row-major; entries above the diagonal are left as passed in),
  * x_out = S^-1 rhs (NaN when a pivot was not positive), usec5 = {factorisation with the forward substitution riding along, backward
  * substitution, then the factorisation as thread 0 sees it: panels, diagonal block + trailing update, barrier wait}: microseconds inside the kernel, mean over `reps` repetitions, with `blocks` identical workgroups side by side.  blocks = -1 .. -6
  * select the timing micro-modes of tools/chol_bench.py (one diagonal tile, panel tiles, dependent FP64 chains, v_mfma_f64_16x16x4 issue
