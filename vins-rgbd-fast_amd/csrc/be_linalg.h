@@ -1115,6 +1115,59 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
 // the wavefront that owns it, as soon as it has it; panel tiles X = A M^T; the right-hand side block riding along) and written back.
 // Per element the same operations in the same order as chol_tiles (updates in ascending column order, each a chain of four MFMAs), so
 // the two factorisations agree bit for bit.  Traffic: nb^3 / 6 tile reads (3 MB at nb = 21), all of it L2 hits.
+// Left-looking update of N row tiles i0, i0 + step, ... of block column p at once (one wavefront): tile(i, p) - sum_j L(i, j) L(p, j)^T over the
+// finished columns j < p, straight from HBM / L2 into `col` (LDS).  The tiles share the L(p, j) operand, their loads are in flight together and
+// their MFMA chains interleave; per tile the operations and their order are those of the one-tile walk (ascending j, four MFMAs each).
+template <int N> __device__ __forceinline__ void chol_stream_update(double *G, int p, int i0, int step, double *col) {
+    const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+    auto gtile = [&](int ti, int tj) -> double * { return G + ((size_t)(ti * (ti + 1) / 2 + tj) << 8); };
+    v4f64 acc[N];
+    const double *ai[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const double *gi = gtile(i0 + k * step, p);
+        ai[k] = gtile(i0 + k * step, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[k][r] = gi[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))];
+    }
+    const double *bp = gtile(p, 0);
+    int j = 0;
+    for (; j + 2 <= p; j += 2) {
+        double a[N][8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int off = ((j + (u >> 2)) << 8) + (li << 4) + ((4 * (u & 3) + lk) ^ li);
+            b[u] = bp[off];
+#pragma unroll
+            for (int k = 0; k < N; k++) a[k][u] = ai[k][off];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int k = 0; k < N; k++) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[k][u], b[u], acc[k], 0, 0, 0);
+    }
+    if (j < p) {
+        double a[N][4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int off = (j << 8) + (li << 4) + ((4 * u + lk) ^ li);
+            b[u] = bp[off];
+#pragma unroll
+            for (int k = 0; k < N; k++) a[k][u] = ai[k][off];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int k = 0; k < N; k++) acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[k][u], b[u], acc[k], 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        double *ct = col + ((i0 + k * step - p) << 8);
+#pragma unroll
+        for (int r = 0; r < 4; r++) ct[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))] = acc[k][r];
+    }
+}
+
 __device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col2, int *sh_flag, double *dinv, double *rhs, float *tm = nullptr) {
     // col2: TWO block columns of LDS (2 nb tiles).  Column p is built in buffer p & 1, and every tile goes back to HBM from the wavefront that
     // finished it (the diagonal tile after its factorisation, a panel tile after its solve): no separate write-back phase, two barriers per
@@ -1145,49 +1198,19 @@ __device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col
             }
             WAVE_SYNC();
         }
-        // (a) column p minus the finished columns, into LDS: wavefront 0 takes the diagonal tile alone (its update and then the 2.3 us of
-        // chol_diag_tile are the phase's critical path), wavefronts 1 .. nw - 1 share the row tiles below it
-        for (int i = p + wave; i < nb; i += (wave == 0 ? nb : nw - 1)) {
-            const double *gi = gtile(i, p);
-            v4f64 acc;
-#pragma unroll
-            for (int r = 0; r < 4; r++) acc[r] = gi[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))];
-            const double *ai = gtile(i, 0), *bp = gtile(p, 0);   // tiles (i, j), j = 0 .. i, are consecutive
-            int j = 0;
-            for (; j + 4 <= p; j += 4) {   // four finished columns per trip: 32 loads in flight, then their 16 MFMAs
-                double a[16], b[16];
-#pragma unroll
-                for (int u = 0; u < 16; u++) {
-                    const int off = ((j + (u >> 2)) << 8) + (li << 4) + ((4 * (u & 3) + lk) ^ li);
-                    a[u] = ai[off]; b[u] = bp[off];
-                }
-#pragma unroll
-                for (int u = 0; u < 16; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u], b[u], acc, 0, 0, 0);
-            }
-            for (; j + 2 <= p; j += 2) {
-                double a[8], b[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int off = ((j + (u >> 2)) << 8) + (li << 4) + ((4 * (u & 3) + lk) ^ li);
-                    a[u] = ai[off]; b[u] = bp[off];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u], b[u], acc, 0, 0, 0);
-            }
-            if (j < p) {
-                double a[4], b[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int off = (j << 8) + (li << 4) + ((4 * u + lk) ^ li);
-                    a[u] = ai[off]; b[u] = bp[off];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u], b[u], acc, 0, 0, 0);
-            }
-            double *ct = col + ((i - p) << 8);
-#pragma unroll
-            for (int r = 0; r < 4; r++) ct[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))] = acc[r];
-            if (i == p) { WAVE_SYNC(); chol_diag_tile(ct, dinv + 16 * p, sh_flag); WAVE_SYNC(); store_tile(gtile(p, p), ct); }
+        // (a) column p minus the finished columns, into LDS: wavefront 0 takes the diagonal tile alone (its update, then chol_diag_tile),
+        // wavefronts 1 .. nw - 1 share the row tiles below it and walk all of theirs at once (chol_stream_update)
+        if (wave == 0) {
+            chol_stream_update<1>(G, p, p, 1, col);
+            WAVE_SYNC(); chol_diag_tile(col, dinv + 16 * p, sh_flag); WAVE_SYNC(); store_tile(gtile(p, p), col);
+        } else {
+            const int st7 = nw - 1;
+            int i = p + wave;
+            for (; i + 3 * st7 < nb; i += 4 * st7) chol_stream_update<4>(G, p, i, st7, col);
+            const int left = i < nb ? (nb - 1 - i) / st7 + 1 : 0;
+            if (left == 3) chol_stream_update<3>(G, p, i, st7, col);
+            else if (left == 2) chol_stream_update<2>(G, p, i, st7, col);
+            else if (left == 1) chol_stream_update<1>(G, p, i, st7, col);
         }
         if (tm && t == 64) { long long n_ = (long long)wall_clock64(); tm[0] += (float)(n_ - tm1); }
         __syncthreads();
