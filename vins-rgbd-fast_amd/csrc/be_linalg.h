@@ -1169,7 +1169,7 @@ template <int N> __device__ __forceinline__ void chol_stream_update(double *G, i
 }
 
 __device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col2, int *sh_flag, double *dinv, double *rhs, float *tm = nullptr) {
-    // col2: TWO block columns of LDS (2 nb tiles).  Column p is built in buffer p & 1, and every tile goes back to HBM from the wavefront that
+    // col2: TWO block columns of LDS plus one tile (2 nb + 1 tiles; the last one carries the look-ahead diagonal tile).  Column p is built in buffer p & 1, and every tile goes back to HBM from the wavefront that
     // finished it (the diagonal tile after its factorisation, a panel tile after its solve): no separate write-back phase, two barriers per
     // column instead of three, and the right-hand side update of column p (last wavefront, reading buffer p & 1) runs beside the other
     // wavefronts' updates of column p + 1, which fill the other buffer.
@@ -1184,10 +1184,24 @@ __device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col
     __syncthreads();
     long long tm1 = tm ? (long long)wall_clock64() : 0;   // timing harness only (stage_linalg.hip), as wavefront 1 sees the phases: [0] update of the
                                                           // column incl. the wait for the diagonal block, [1] panels
+    // Look-ahead on the diagonal: wavefront 1 takes no row tiles; during the update phase of column p it accumulates tile (p + 1, p + 1) over the
+    // finished columns 0 .. p - 1 into `ahead` (LDS), so that wavefront 0 -- which owns the diagonal tile -- only adds column p's own term
+    // (from the LDS buffer) before the factorisation.  The two serial pieces of a column (the length-p chain of the diagonal tile, 2.4 us on
+    // average at nb = 21, and chol_diag_tile, 2.3 us) run side by side instead of one after the other.  Per element the terms arrive in
+    // ascending column order, four MFMAs each, as in chol_tiles: bit-identical.
+    double *ahead = col2 + ((size_t)(2 * nb) << 8);
+    const int la_wave = nw > 2 ? 1 : 0;   // (fewer than three wavefronts: wavefront 0 looks ahead itself after its factorisation)
+    if (wave == la_wave) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) ahead[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))] = gtile(0, 0)[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))];
+    }
+    __syncthreads();
+    v4f64 ahead_next = {0, 0, 0, 0};
     for (int p = 0; p < nb; p++) {
         double *col = col2 + (size_t)(p & 1) * ((size_t)nb << 8);
-        // the right-hand side rows below block p - 1 take their term b_i -= L_i,p-1 y_p-1 (previous column's buffer)
-        if (rhs && wave == nw - 1 && p > 0) {
+        // the right-hand side rows below block p - 1 take their term b_i -= L_i,p-1 y_p-1 (previous column's buffer); on the look-ahead
+        // wavefront, which has the shortest update phase (block p itself is solved by the last wavefront in the panel phase, behind a barrier)
+        if (rhs && wave == la_wave && p > 0) {
             const double *pc = col2 + (size_t)((p - 1) & 1) * ((size_t)nb << 8);
             for (int q = lane; q < 16 * (nb - p); q += 64) {
                 const int tl = 1 + (q >> 4), r = q & 15;
@@ -1200,12 +1214,54 @@ __device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col
         }
         // (a) column p minus the finished columns, into LDS: wavefront 0 takes the diagonal tile alone (its update, then chol_diag_tile),
         // wavefronts 1 .. nw - 1 share the row tiles below it and walk all of theirs at once (chol_stream_update)
+        auto look_ahead = [&]() {
+            // (reads `ahead` of this column happen in wavefront 0 right after the previous barrier; the new value is written behind the barrier
+            //  that ends this phase -- see below -- so the two never overlap)
+            v4f64 nx = {0, 0, 0, 0};
+            if (p + 1 < nb) {
+                const double *row = gtile(p + 1, 0);   // tiles (p + 1, j) are consecutive
+#pragma unroll
+                for (int r = 0; r < 4; r++) nx[r] = gtile(p + 1, p + 1)[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))];
+                int j = 0;
+                for (; j + 4 <= p; j += 4) {
+                    double a[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) a[u] = row[((j + (u >> 2)) << 8) + (li << 4) + ((4 * (u & 3) + lk) ^ li)];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) nx = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u], a[u], nx, 0, 0, 0);
+                }
+                for (; j < p; j++) {
+                    double a[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) a[u] = row[(j << 8) + (li << 4) + ((4 * u + lk) ^ li)];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) nx = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u], a[u], nx, 0, 0, 0);
+                }
+            }
+            ahead_next = nx;
+        };
         if (wave == 0) {
-            chol_stream_update<1>(G, p, p, 1, col);
+            v4f64 acc;
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[r] = ahead[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))];
+            if (p > 0) {   // column p - 1's term: tile (p, p - 1) sits in the previous buffer
+                const double *pt = col2 + (size_t)((p - 1) & 1) * ((size_t)nb << 8) + (1 << 8);
+                double a[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) a[u] = pt[(li << 4) + ((4 * u + lk) ^ li)];
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u], a[u], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) col[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))] = acc[r];
             WAVE_SYNC(); chol_diag_tile(col, dinv + 16 * p, sh_flag); WAVE_SYNC(); store_tile(gtile(p, p), col);
+            if (la_wave == 0) look_ahead();
+            if (nw == 1) for (int i = p + 1; i < nb; i++) chol_stream_update<1>(G, p, i, 1, col);   // (a lone wavefront does everything)
+        } else if (wave == la_wave) {
+            look_ahead();
         } else {
-            const int st7 = nw - 1;
-            int i = p + wave;
+            const int st7 = la_wave == 1 ? nw - 2 : nw - 1;   // the look-ahead wavefront takes no row tiles
+            int i = p + (la_wave == 1 ? wave - 1 : wave);
             for (; i + 3 * st7 < nb; i += 4 * st7) chol_stream_update<4>(G, p, i, st7, col);
             const int left = i < nb ? (nb - 1 - i) / st7 + 1 : 0;
             if (left == 3) chol_stream_update<3>(G, p, i, st7, col);
@@ -1216,6 +1272,10 @@ __device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col
         __syncthreads();
         if (tm && t == 64) tm1 = (long long)wall_clock64();
         if (!*sh_flag) return false;
+        if (wave == la_wave) {   // wavefront 0 is past its read of `ahead`: publish the next tile (visible after this column's second barrier)
+#pragma unroll
+            for (int r = 0; r < 4; r++) ahead[((lk + 4 * r) << 4) + (li ^ (lk + 4 * r))] = ahead_next[r];
+        }
         // (b) panel tiles (each back to HBM from the wavefront that solved it) and the right-hand side block
         for (int i = p + 1 + wave; i < nb; i += nw) {
             double *ct = col + ((i - p) << 8);

@@ -760,7 +760,7 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
     // phase below paid a dependent global round trip (about 25 per iteration).  One coalesced load here, one write-back in finish();
     // same layout as c.vec (slot 0 = g and slot 1 = sp come from ps_asm_b, the others persist between the slots of a solve).
     const int nbk = LW >> 4;
-    const int wk_d = max(BIG ? 2 * nbk * 256 : nbk * (nbk + 1) / 2 * 256, 16 * 336);   // doubles of the work region (host: lds_serial); BIG: two block columns (chol_tiles_stream)
+    const int wk_d = max(BIG ? (2 * nbk + 1) * 256 : nbk * (nbk + 1) / 2 * 256, 16 * 336);   // doubles of the work region (host: lds_serial); BIG: two block columns + the look-ahead tile (chol_tiles_stream)
     double *lv = work + wk_d + 2;
     double *g = lv, *sp = lv + 1 * LW, *dgp = lv + 2 * LW, *gradp = lv + 3 * LW, *gnp = lv + 4 * LW, *stp = lv + 5 * LW,
            *gs = lv + 6 * LW, *tmpv = lv + 7 * LW, *delta = lv + 8 * LW, *sgp = lv + 9 * LW, *hsgp = lv + 10 * LW,

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(512) void be_stage_chol_stream_kernel(int nb, int r
     extern __shared__ __attribute__((aligned(16))) double colbuf[];
     const int t = threadIdx.x, nt = blockDim.x, n = 16 * nb, ntile = nb * (nb + 1) / 2;
     double *T = Tg + (size_t)blockIdx.x * ntile * 256;
-    double *xs = colbuf + (size_t)2 * nb * 256, *dinv = xs + n;   // two block columns (chol_tiles_stream)
+    double *xs = colbuf + ((size_t)2 * nb + 1) * 256, *dinv = xs + n;   // two block columns + the look-ahead tile (chol_tiles_stream)
     __shared__ int flag;
     __shared__ float tm[4];
     if (t < 4) tm[t] = 0;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512) void be_stage_chol_stream_kernel(int nb, int r
 // the streaming path (ps_serial_big): tiles in HBM, one block column in LDS; blocks = -7 forces it for nb <= 11 (bit-for-bit against the LDS path)
 static int stage_chol_stream(int nb, int reps, int blocks, const double *S, const double *rhs, double *L_out, double *x_out, double *usec2) {
     int rc = VIO_OK;
-    const size_t n = 16 * (size_t)nb, ntile = (size_t)nb * (nb + 1) / 2, lds = ((size_t)2 * nb * 256 + 2 * n) * sizeof(double);
+    const size_t n = 16 * (size_t)nb, ntile = (size_t)nb * (nb + 1) / 2, lds = (((size_t)2 * nb + 1) * 256 + 2 * n) * sizeof(double);
     const int nblk = blocks < 0 ? 1 : blocks;
     double *dS = nullptr, *dr = nullptr, *dL = nullptr, *dx = nullptr, *dT = nullptr;
     float *dt = nullptr, ht[5] = {0, 0, 0, 0, 0};

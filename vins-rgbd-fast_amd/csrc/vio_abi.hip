@@ -946,7 +946,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
                 // ps_serial: xs + the work region = the resident tiles (windows up to W = 10) or one block column of them (larger
                 // windows, chol_tiles_stream), never less than the scratch of the mat-vec passes (one row of VIO_LWMAX per wavefront)
                 const size_t nb = (size_t)C.LW >> 4, tiles = nb * (nb + 1) / 2 * 256;
-                const size_t wk = std::max(tiles <= 16896 ? tiles : 2 * nb * 256, (size_t)16 * 336);   // (streaming: two block columns, chol_tiles_stream)
+                const size_t wk = std::max(tiles <= 16896 ? tiles : (2 * nb + 1) * 256, (size_t)16 * 336);   // (streaming: two block columns + the look-ahead tile, chol_tiles_stream)
                 h->serial_big = tiles > 16896;
                 h->lds_serial = ((size_t)C.LW + 2 + wk + 2 + (size_t)14 /* PS_LVEC */ * C.LW) * 8 + 16;   // + the step's vectors (be_phased.h)
                 if (getenv("VIO_SERIAL_LDS") && (size_t)atol(getenv("VIO_SERIAL_LDS")) > h->lds_serial) h->lds_serial = (size_t)atol(getenv("VIO_SERIAL_LDS"));   // experiment: a larger request keeps other workgroups off the CU
