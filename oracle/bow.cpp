@@ -7,6 +7,10 @@
 //   BowVector::addWeight / addIfNotExist / normalize   ThirdParty/DBoW/BowVector.cpp
 //   TemplatedDatabase::add / query / queryL1   ThirdParty/DBoW/TemplatedDatabase.h:408-475, :560-640 (use_di = false: PoseGraph::loadVocabulary :44-47)
 //   PoseGraph::detectLoop                      pose_graph/src/pose_graph/pose_graph.cpp:308-393;  addKeyFrameIntoVoc :395-408
+// PINNED IN PART against reference code run in this container: DBoW2::BowVector (addWeight / addIfNotExist / normalize) is the one arithmetic
+// translation unit of the reference that compiles here from its own source; `make ref` builds it where it lies into _ref/ behind a C shim
+// (ref_bowvector.cpp) and tests/test_oracle_bow_cpu.py requires the bag-of-words vectors of this file to equal the class's bit for bit.  The
+// tree walk, the inverted file and queryL1 (templates over OpenCV / boost headers) remain restatements checked by definition tests.
 // std::map containers are kept so that every floating-point sum runs in the reference's order.  One pinned choice: queryL1 sorts its results
 // with std::sort (not stable); ties in the score are ordered by entry id here.  The vocabulary blob itself (support_files/brief_k10L6.bin) is
 // missing from the reference tree: the tests use synthetic vocabularies written in the same file format.  Only tests/ may use this file.

@@ -94,3 +94,40 @@ def test_detect_loop_finds_the_revisited_place():
     for idx in range(6):
         assert o2.detect_loop(bow_util.view_of(places[0], 2000 + idx, noise_bits=4, extra=0), idx) == -1
     o.close(); o2.close()
+
+
+def _ref_bowvector():
+    """the reference's own DBoW2::BowVector compiled from where it lies (oracle/_ref, `make -C oracle ref`); None where it cannot be built"""
+    import ctypes as C
+    import os
+    import subprocess
+    so = os.path.join(vio_ct.ROOT, "oracle", "_ref", "libdbow_bowvector_ref.so")
+    if not os.path.exists(so):
+        if not os.path.isdir("/root/reference/pose_graph/src/ThirdParty/DBoW"):
+            return None
+        subprocess.run(["make", "-C", os.path.join(vio_ct.ROOT, "oracle"), "ref"], check=True, capture_output=True)
+    L = C.CDLL(so)
+    L.oref_bow_vector.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    return L
+
+
+@pytest.mark.parametrize("weighting", [0, 1, 2, 3])
+def test_bow_vector_against_the_reference_class_itself(weighting):
+    """The one piece of reference arithmetic that compiles in this image from its own source: DBoW2::BowVector (ThirdParty/DBoW/BowVector.cpp).
+    The restatement's bag-of-words vector -- accumulation per feature for TF-IDF / TF, first occurrence for IDF / BINARY, stopped words,
+    L1 normalisation -- must equal, bit for bit, what the reference's class makes of the same (word, weight) sequence."""
+    R = _ref_bowvector()
+    if R is None:
+        pytest.skip("reference tree not present and oracle/_ref not prebuilt")
+    voc = bow_util.make_vocabulary(7, 3, 40 + weighting, irregular=True, weighting=weighting, stop_fraction=0.1)
+    o = bow_util.OracleVoc(voc)
+    for seed in range(4):
+        feats = bow_util.view_of(bow_util.place_descriptors(voc, seed, 700), 50 + seed, noise_bits=30, extra=200)
+        w, wt = o.transform(feats)
+        ids, val = np.zeros(len(w), np.int32), np.zeros(len(w))
+        w32 = np.ascontiguousarray(w, np.int32)
+        m = R.oref_bow_vector(len(w), w32.ctypes.data, wt.ctypes.data, weighting, len(w), ids.ctypes.data, val.ctypes.data)
+        bw, bv = o.bow(feats)
+        assert m == len(bw) > 20 and np.array_equal(ids[:m], bw) and np.array_equal(val[:m], bv)
+        assert (np.bincount(w32).max() > 1)          # repeated words: the accumulation order matters
+    o.close()
