@@ -339,3 +339,50 @@ def test_recording_with_jittered_depth_stamps_pairs_like_the_nodelet(tmp_path):
     io.write_recording(str(tmp_path / "u"), stamps, g, d, imu_t, np.zeros((300, 3)), np.zeros((300, 3)), depth_stamps=stamps + 0.01)
     with pytest.warns(RuntimeWarning, match="not hardware-synchronised"):
         assert len(io.RgbdImuDirectory(str(tmp_path / "u"))) == 0
+
+
+def test_pose_graph_save_and_load_round_trip(tmp_path):
+    """PoseGraph::savePoseGraph / loadPoseGraph (pose_graph.cpp:849-1043): the text format of pose_graph.txt, <i>_briefdes.dat (256 characters
+    per descriptor, bit 255 first, as boost::dynamic_bitset prints) and <i>_keypoints.txt; loaded keyframes are sequence 0 with the loop-closed
+    pose as their VIO pose and go into the vocabulary database in order.  No GPU: the keyframes are built from saved fields, the vocabulary is a
+    stand-in that records what it is given."""
+    import importlib
+    pg = importlib.import_module("vins-rgbd-fast_amd.posegraph")
+
+    class Voc:
+        def __init__(self):
+            self.added = []
+
+        def add(self, d):
+            self.added.append(np.array(d, copy=True))
+    rng = np.random.default_rng(4)
+
+    def rot(a, b, c):
+        ca, sa, cb, sb, cc, sc = np.cos(a), np.sin(a), np.cos(b), np.sin(b), np.cos(c), np.sin(c)
+        return np.array([[ca, -sa, 0], [sa, ca, 0], [0, 0, 1]]) @ np.array([[cb, 0, sb], [0, 1, 0], [-sb, 0, cb]]) @ np.array([[1, 0, 0], [0, cc, -sc], [0, sc, cc]])
+    g = pg.PoseGraph(Voc(), np.eye(3), np.zeros(3))
+    for i in range(5):
+        nk = int(rng.integers(0, 40)) if i != 2 else 0
+        kf = pg.KeyFrame.from_saved(10.0 + 0.1 * i, i, rng.normal(size=3), rot(*rng.normal(size=3)), rng.normal(size=3), rot(*(3 * rng.normal(size=3))),
+                                    -1 if i < 4 else 1, rng.normal(size=8) if i == 4 else np.zeros(8), rng.uniform(0, 640, (nk, 2)), rng.normal(size=(nk, 2)),
+                                    rng.integers(0, 2 ** 63, (nk, 4), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, (nk, 4), dtype=np.uint64))
+        kf.vio_T_w_i = kf.T_w_i + 0.01 * i                       # a live graph keeps both poses
+        g.keyframelist.append(kf)
+    g.savePoseGraph(str(tmp_path))
+    line = open(tmp_path / "pose_graph.txt").readline()
+    assert line.startswith(" 0 10.000000 ") and len(line.split()) == 26
+    first = open(tmp_path / "0_briefdes.dat").readline().strip() if len(g.keyframelist[0].keypoints) else "0" * 256
+    assert len(first) == 256 and set(first) <= {"0", "1"}
+    if len(g.keyframelist[0].keypoints):
+        assert first[-1] == str(int(g.keyframelist[0].brief_descriptors[0][0]) & 1)            # bit 0 is printed last
+    h = pg.PoseGraph(Voc(), np.eye(3), np.zeros(3))
+    assert h.loadPoseGraph(str(tmp_path)) == 5 and h.global_index == 5 and h.earliest_loop_index == 1
+    for a, b in zip(g.keyframelist, h.keyframelist):
+        assert b.sequence == 0 and b.index == a.index and abs(b.time_stamp - a.time_stamp) < 1e-6
+        assert np.abs(b.T_w_i - a.T_w_i).max() < 1e-6 and np.abs(b.R_w_i - a.R_w_i).max() < 3e-6   # six decimals of t and q
+        assert np.array_equal(b.vio_T_w_i, b.T_w_i)                                                 # the load constructor's rule
+        assert b.has_loop == a.has_loop and b.loop_index == a.loop_index and np.abs(b.loop_info - a.loop_info).max() < 1e-6
+        assert np.array_equal(b.brief_descriptors, a.brief_descriptors) and b.keypoints.shape == a.keypoints.shape
+        assert len(a.keypoints) == 0 or (np.abs(b.keypoints - a.keypoints).max() < 1e-4 and np.abs(b.keypoints_norm - a.keypoints_norm).max() < 1e-5)
+    assert len(h.voc.added) == 5 and all(np.array_equal(x, kf.brief_descriptors) for x, kf in zip(h.voc.added, g.keyframelist))
+    assert h.loadPoseGraph(str(tmp_path / "nothing_here")) == 0

@@ -163,6 +163,23 @@ class KeyFrame:
         self.window_brief_descriptors, kxy, self.brief_descriptors, kn = describe(cfg, image, self.point_2d_uv, pattern)
         self.keypoints, self.keypoints_norm = kxy, kn
 
+    @classmethod
+    def from_saved(cls, time_stamp, index, vio_T_w_i, vio_R_w_i, T_w_i, R_w_i, loop_index, loop_info, keypoints, keypoints_norm, brief_descriptors):
+        """the "load previous keyframe" constructor (keyframe.cpp:46-78): the VIO pose is REPLACED by the loop-closed one, sequence 0, no window
+        points (such a keyframe can be the old side of a loop only)"""
+        kf = cls.__new__(cls)
+        kf.time_stamp, kf.index, kf.sequence = float(time_stamp), int(index), 0
+        kf.T_w_i, kf.R_w_i = np.array(T_w_i, np.float64), np.array(R_w_i, np.float64).reshape(3, 3)
+        kf.vio_T_w_i, kf.vio_R_w_i = kf.T_w_i.copy(), kf.R_w_i.copy()
+        kf.origin_vio_T, kf.origin_vio_R = kf.T_w_i.copy(), kf.R_w_i.copy()
+        kf.point_3d, kf.point_2d_uv, kf.point_2d_norm, kf.point_id = np.zeros((0, 3), np.float32), np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), np.zeros(0)
+        kf.has_loop, kf.loop_index, kf.loop_info = int(loop_index) != -1, int(loop_index), np.array(loop_info, np.float64).reshape(8)
+        kf.match_points = np.zeros((0, 3))
+        kf.window_brief_descriptors = np.zeros((0, 4), np.uint64)
+        kf.keypoints, kf.keypoints_norm = np.array(keypoints, np.float32).reshape(-1, 2), np.array(keypoints_norm, np.float32).reshape(-1, 2)
+        kf.brief_descriptors = np.ascontiguousarray(brief_descriptors, np.uint64).reshape(-1, 4)
+        return kf
+
     def findConnection(self, old_kf, qic, tic):
         idx, _ = match(self.window_brief_descriptors, old_kf.brief_descriptors)
         ok, info, mp, self.PnP_T_old, self.PnP_R_old = find_connection(self.point_3d, self.point_id, idx, old_kf.keypoints_norm, self.origin_vio_T,
@@ -179,6 +196,40 @@ def _ypr2R(yaw_deg):
 
 def _yaw_deg(R):   # Utility::R2ypr(R).x()
     return float(np.rad2deg(np.arctan2(R[1, 0], R[0, 0])))
+
+
+def _R2q_wxyz(R):   # Eigen Quaterniond(Matrix3d)
+    t = R[0, 0] + R[1, 1] + R[2, 2]
+    if t > 0:
+        w = np.sqrt(t + 1.0) * 0.5
+        f = 0.25 / w
+        return np.array([w, (R[2, 1] - R[1, 2]) * f, (R[0, 2] - R[2, 0]) * f, (R[1, 0] - R[0, 1]) * f])
+    i = int(np.argmax([R[0, 0], R[1, 1], R[2, 2]]))
+    j, k = (i + 1) % 3, (i + 2) % 3
+    q = np.zeros(4)
+    r = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+    q[1 + i] = 0.5 * r
+    r = 0.5 / r
+    q[0] = (R[k, j] - R[j, k]) * r
+    q[1 + j] = (R[j, i] + R[i, j]) * r
+    q[1 + k] = (R[k, i] + R[i, k]) * r
+    return q
+
+
+def _q2R_wxyz(q):   # Quaterniond::toRotationMatrix (no normalisation)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _bits_to_text(d):
+    """boost::dynamic_bitset operator<<: the 256 bits of a descriptor, most significant (bit 255) first"""
+    return "".join(format(int(d[w]), "064b") for w in (3, 2, 1, 0))
+
+
+def _text_to_bits(txt):
+    return np.array([int(txt[64 * (3 - w):64 * (4 - w)], 2) for w in range(4)], np.uint64)
 
 
 class PoseGraph:
@@ -244,6 +295,54 @@ class PoseGraph:
         cur_kf.R_w_i = self.r_drift @ cur_kf.vio_R_w_i
         self.keyframelist.append(cur_kf)
         return verified
+
+    def savePoseGraph(self, directory):
+        """PoseGraph::savePoseGraph (pose_graph.cpp:849-927): pose_graph.txt (one line per keyframe: index, stamp, VIO t, loop-closed t, VIO q,
+        loop-closed q (w x y z), loop_index, loop_info[8], number of keypoints; %f = six decimals like the reference), the two stamped
+        trajectory files, and per keyframe <index>_briefdes.dat (one descriptor per line as 256 characters, bit 255 first) and
+        <index>_keypoints.txt (pixel and normalised coordinates)"""
+        os.makedirs(directory, exist_ok=True)
+        with open(os.path.join(directory, "pose_graph.txt"), "w") as f, open(os.path.join(directory, "stamped_traj_estimate_mono_pg.txt"), "w") as fp, \
+                open(os.path.join(directory, "stamped_traj_estimate_mono_vio.txt"), "w") as fv:
+            for kf in self.keyframelist:
+                vq, pq = _R2q_wxyz(kf.vio_R_w_i), _R2q_wxyz(kf.R_w_i)
+                vals = [kf.time_stamp, *kf.vio_T_w_i, *kf.T_w_i, *vq, *pq]
+                f.write(" %d " % kf.index + " ".join("%f" % v for v in vals) + " %d " % kf.loop_index + " ".join("%f" % v for v in kf.loop_info) +
+                        " %d\n" % len(kf.keypoints))
+                fp.write(" ".join("%f" % v for v in [kf.time_stamp, *kf.T_w_i, pq[1], pq[2], pq[3], pq[0]]) + "\n")
+                fv.write(" ".join("%f" % v for v in [kf.time_stamp, *kf.vio_T_w_i, vq[1], vq[2], vq[3], vq[0]]) + "\n")
+                with open(os.path.join(directory, "%d_briefdes.dat" % kf.index), "wb") as fb, open(os.path.join(directory, "%d_keypoints.txt" % kf.index), "w") as fk:
+                    for d, xy, nn in zip(kf.brief_descriptors, kf.keypoints, kf.keypoints_norm):
+                        fb.write((_bits_to_text(d) + "\n").encode())
+                        fk.write("%f %f %f %f\n" % (xy[0], xy[1], nn[0], nn[1]))
+
+    def loadPoseGraph(self, directory):
+        """PoseGraph::loadPoseGraph (:929-1043) + loadKeyFrame(kf, 0) (:226-300): the saved keyframes become sequence 0 (held constant by the
+        optimisation) with their loop-closed poses, and enter the vocabulary database; returns the number of keyframes read"""
+        path = os.path.join(directory, "pose_graph.txt")
+        if not os.path.exists(path):
+            return 0
+        n = 0
+        for line in open(path):
+            v = line.split()
+            if len(v) != 26:
+                continue
+            index, stamp = int(v[0]), float(v[1])
+            vio_T, pg_T = np.array(v[2:5], np.float64), np.array(v[5:8], np.float64)
+            vio_q, pg_q = np.array(v[8:12], np.float64), np.array(v[12:16], np.float64)
+            loop_index, loop_info, nkp = int(v[16]), np.array(v[17:25], np.float64), int(v[25])
+            if loop_index != -1 and (self.earliest_loop_index > loop_index or self.earliest_loop_index == -1):
+                self.earliest_loop_index = loop_index
+            desc = [_text_to_bits(t) for t in open(os.path.join(directory, "%d_briefdes.dat" % index)).read().split()[:nkp]]
+            kp = np.loadtxt(os.path.join(directory, "%d_keypoints.txt" % index), ndmin=2)[:nkp] if nkp else np.zeros((0, 4))
+            kf = KeyFrame.from_saved(stamp, index, vio_T, _q2R_wxyz(vio_q), pg_T, _q2R_wxyz(pg_q), loop_index, loop_info, kp[:, 0:2], kp[:, 2:4],
+                                     np.array(desc, np.uint64).reshape(-1, 4))
+            kf.index = self.global_index                     # loadKeyFrame
+            self.global_index += 1
+            self.voc.add(kf.brief_descriptors)               # flag_detect_loop = 0: addKeyFrameIntoVoc
+            self.keyframelist.append(kf)
+            n += 1
+        return n
 
     def optimize(self):
         """one pass of optimize4DoF's loop body over the keyframes earliest_loop_index .. newest queued one; False when nothing is queued"""
