@@ -93,6 +93,13 @@ void vio_config_default(vio_config *cfg);
  * landmark capacity / feature count beyond what a CU's 160 KB hold) -- checked here so that it cannot surface as a failed launch
  * in the middle of a frame. */
 vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity);
+/* The same on a named HIP device (device < 0: the calling thread's current device, i.e. vio_create).  The handle OWNS its device: all of its
+ * memory, streams and events live there, and every entry point that takes the handle makes that device current for the duration of the call
+ * and restores the caller's afterwards -- so one process may drive one handle per GPU from one thread or from a thread per GPU
+ * without ever calling hipSetDevice itself.  Device pointers passed with on_device != 0 must belong to the handle's device.  No upstream
+ * counterpart (the reference is one Estimator per process on the CPU). */
+vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capacity, int device);
+int vio_get_device(vio_batch *h);   /* the device the handle lives on; VIO_EINVAL for NULL */
 void vio_destroy(vio_batch *h);
 const char *vio_last_error(void);
 /* Every sequence back to the state after vio_create: fresh FeatureTracker AND Estimator::clearState() + setParameter(). */

@@ -18,6 +18,7 @@ namespace ovio {
 using namespace om;
 
 enum { O_P = 0, O_R = 3, O_V = 6, O_BA = 9, O_BG = 12 };
+int oracle_deviations = 0;   // attribution experiment (oracle.h ODEV_*): 0 everywhere except tests/oracle_control.py's variants
 
 // ------------------------------------------------------------------ IntegrationBase (integration_base.h)
 Integration::Integration(const Config &c, const V3 &a0, const V3 &g0, const V3 &ba, const V3 &bg)
@@ -202,7 +203,10 @@ void eval_imu(const Integration &pre, const V3 &G, const double *pi, const doubl
                 for (int k = 0; k < 15; k++) s += Li(k, i) * Li(k, j);
                 Ci(i, j) = s;
             }
-        if (chol(Ci))
+        if (oracle_deviations & ODEV_IMU_WHITEN) {
+            // deviation 8 (attribution experiment): M = chol(cov)^-1, lower triangular, M^T M = cov^-1 as well
+            for (int i = 0; i < 15; i++) for (int j = 0; j <= i; j++) sqrt_info[i][j] = Li(i, j);
+        } else if (chol(Ci))
             for (int i = 0; i < 15; i++) for (int j = i; j < 15; j++) sqrt_info[i][j] = Ci(j, i);  // L^T
     }
     for (int i = 0; i < 15; i++) {
@@ -256,7 +260,8 @@ void eval_imu(const Integration &pre, const V3 &G, const double *pi, const doubl
         for (int i = 0; i < 15; i++)
             for (int j = 0; j < nc; j++) {
                 double s = 0;
-                for (int k = i; k < 15; k++) s += sqrt_info[i][k] * Jin[k * nc + j];
+                const int k0 = (oracle_deviations & ODEV_IMU_WHITEN) ? 0 : i, k1 = (oracle_deviations & ODEV_IMU_WHITEN) ? i + 1 : 15;
+                for (int k = k0; k < k1; k++) s += sqrt_info[i][k] * Jin[k * nc + j];
                 out[i * nc + j] = s;
             }
     };
@@ -282,6 +287,41 @@ void eval_projection(const Config &c, const double *pi, const double *pj, const 
         pts_j = pts_j - (td - oj.cur_td + c.tr / ROW * row_j) * vel_j;
     }
     double sq = c.focal_length / 1.5;  // sqrt_info = FOCAL_LENGTH/1.5 * I (estimator.cpp:23-24)
+    if (oracle_deviations & ODEV_PAIR_PROJECTION) {
+        // deviation 11 (attribution experiment): the same residual and Jacobians through the matrices of the frame pair,
+        // A1 = ric^T Rj^T, A2 = A1 Ri, M = A2 ric, t = A1 (Ri tic + Pi - Pj) - ric^T tic, so that pts_camera_j = M pts_camera_i + t
+        const M3 Ri = toR(Qi), Rj = toR(Qj), ric = toR(qic), ricT = T(ric);
+        const M3 A1 = ricT * T(Rj), A2 = A1 * Ri, M = A2 * ric;
+        const V3 t = A1 * (Ri * tic + (Pi - Pj)) - ricT * tic;
+        const V3 pc_i = pts_i / inv_dep;
+        const V3 pc_j = M * pc_i + t;
+        const double dep = pc_j.z;
+        r[0] = sq * (pc_j.x / dep - pts_j.x);
+        r[1] = sq * (pc_j.y / dep - pts_j.y);
+        if (!J_i) return;
+        const V3 red[2] = {V3(sq / dep, 0, -sq * pc_j.x / (dep * dep)), V3(0, sq / dep, -sq * pc_j.y / (dep * dep))};
+        const V3 pim_i = ric * pc_i + tic, pim_j = ric * pc_j + tic;
+        auto rowmul = [](const V3 &rw, const M3 &A) { return V3(rw.x * A(0, 0) + rw.y * A(1, 0) + rw.z * A(2, 0), rw.x * A(0, 1) + rw.y * A(1, 1) + rw.z * A(2, 1),
+                                                                rw.x * A(0, 2) + rw.y * A(1, 2) + rw.z * A(2, 2)); };
+        auto rowskew = [](const V3 &rw, const V3 &w) { return V3(rw.y * w.z - rw.z * w.y, rw.z * w.x - rw.x * w.z, rw.x * w.y - rw.y * w.x); };   // rw * skew(w)
+        auto put3 = [](double *o, const V3 &v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; };
+        for (int a = 0; a < 2; a++) {
+            const V3 ra1 = rowmul(red[a], A1), ra2 = rowmul(red[a], A2), rrt = rowmul(red[a], ricT), rm = rowmul(red[a], M);
+            put3(J_i + a * 7, ra1); put3(J_i + a * 7 + 3, rowskew(ra2, -pim_i)); J_i[a * 7 + 6] = 0;
+            put3(J_j + a * 7, -ra1); put3(J_j + a * 7 + 3, rowskew(rrt, pim_j)); J_j[a * 7 + 6] = 0;
+            put3(J_ex + a * 7, ra2 - rrt); put3(J_ex + a * 7 + 3, rowskew(red[a], pc_j) - rowskew(rm, pc_i)); J_ex[a * 7 + 6] = 0;
+            const V3 v = (M * pts_i) * (-1.0 / (inv_dep * inv_dep));
+            J_l[a] = red[a].x * v.x + red[a].y * v.y + red[a].z * v.z;
+            if (J_td) {
+                if (use_td) {
+                    const V3 w = (M * vel_i) / inv_dep * -1.0;
+                    J_td[a] = (red[a].x * w.x + red[a].y * w.y + red[a].z * w.z) + sq * (a == 0 ? vel_j.x : vel_j.y);
+                } else
+                    J_td[a] = 0;
+            }
+        }
+        return;
+    }
     V3 pts_camera_i = pts_i / inv_dep;
     V3 pts_imu_i = rot(qic, pts_camera_i) + tic;
     V3 pts_w = rot(Qi, pts_imu_i) + Pi;
@@ -334,6 +374,11 @@ void eval_projection(const Config &c, const double *pi, const double *pj, const 
 // ------------------------------------------------------------------ Estimator
 Estimator::Estimator(const Config &c) : cfg(c), W(c.window_size) {
     for (int i = 0; i <= MAXW; i++) pre_integrations[i] = nullptr;
+    {
+        const char *dv = std::getenv("OVIO_DEVIATIONS");
+        deviations = dv ? std::atoi(dv) : 0;
+        oracle_deviations = deviations;
+    }
     clearState();
     // readParameters() re-orthonormalises the extrinsic rotation through a normalised quaternion (parameters.cpp:202-209)
     {
@@ -418,7 +463,8 @@ void Estimator::predictMotion(double t0, double t1, double R[9], const V3 *bg_ov
             M3 Rk = M3::I();
             if (ang > 0) {
                 V3 ax = aa / ang;
-                double s = std::sin(ang), c = std::cos(ang);
+                double s, c;
+                sincos_det(ang, &s, &c);   // same bits as the device code (om.h)
                 M3 K = skew(ax);
                 Rk = M3::I() + s * K + (1 - c) * (K * K);
             }
@@ -837,6 +883,45 @@ static void pose_dx(const double *x, const double *x0, double *dx) {  // margina
     dx[3] = v.x; dx[4] = v.y; dx[5] = v.z;
 }
 
+// MarginalizationFactor::Evaluate (marginalization_factor.cpp:353-404) linearised in the prior's own index space: cost 0.5 |r + J dx|^2,
+// gradient J^T (r + J dx), Gauss-Newton block J^T J.  With ODEV_QUADRATIC_PRIOR (attribution experiment) the same three quantities from the
+// quadratic form (A, b, c0): 0.5 c0 + dx^T b + 0.5 dx^T A dx, b + A dx, A.
+static double prior_gradient(const Estimator &e, const std::vector<double> &dx, std::vector<double> &g, std::vector<double> &r) {
+    const int n = e.prior_n;
+    double cost = 0;
+    g.assign(n, 0.0);
+    if (e.deviations & ODEV_QUADRATIC_PRIOR) {
+        for (int a = 0; a < n; a++) {
+            double acc = 0;
+            for (int j = 0; j < n; j++) acc += e.prior_A(a, j) * dx[j];
+            const double q = e.prior_b[a] + acc;
+            g[a] = q;
+            cost += 0.5 * dx[a] * (e.prior_b[a] + q);
+        }
+        cost += 0.5 * e.prior_c0;
+        return cost;
+    }
+    r.assign(n, 0.0);
+    for (int i = 0; i < n; i++) {
+        double s = e.prior_r[i];
+        for (int j = 0; j < n; j++) s += e.prior_J(i, j) * dx[j];
+        r[i] = s;
+        cost += 0.5 * s * s;
+    }
+    for (int a = 0; a < n; a++) {
+        double gs = 0;
+        for (int i = 0; i < n; i++) gs += e.prior_J(i, a) * r[i];
+        g[a] = gs;
+    }
+    return cost;
+}
+static inline double prior_hessian(const Estimator &e, int a, int b) {
+    if (e.deviations & ODEV_QUADRATIC_PRIOR) return e.prior_A(a, b);
+    double s = 0;
+    for (int i = 0; i < e.prior_n; i++) s += e.prior_J(i, a) * e.prior_J(i, b);
+    return s;
+}
+
 // Evaluate all factors at the flat parameters and accumulate the (robustified) normal equations.
 // Tangent layout: pose k at 6k, speed-bias k at 6(W+1)+9k, ex at 15(W+1), td at 15(W+1)+6.
 // relo: the copy of the matched frame's pose (relo_Pose) or NULL; its 6 tangent dimensions sit behind td at index 15(W+1)+7.
@@ -867,23 +952,12 @@ static void build_normal_eq(Estimator &e, const double pose[][7], const double s
         if (!e.prior_present[W]) for (int d = 0; d < 9; d++) dx[6 * W + d] = 0;
         if (!e.prior_present[W + 1]) for (int d = 0; d < 6; d++) dx[6 * W + 9 + d] = 0;
         if (!e.prior_present[W + 2]) dx[6 * W + 15] = 0;
-        std::vector<double> r(n);
-        for (int i = 0; i < n; i++) {
-            double s = e.prior_r[i];
-            for (int j = 0; j < n; j++) s += e.prior_J(i, j) * dx[j];
-            r[i] = s;
-            cost += 0.5 * s * s;
-        }
+        std::vector<double> r, pg;
+        cost += prior_gradient(e, dx, pg, r);
         if (withJ) {
             for (int a = 0; a < n; a++) {
-                double gs = 0;
-                for (int i = 0; i < n; i++) gs += e.prior_J(i, a) * r[i];
-                ne.g[map[a]] += gs;
-                for (int b = 0; b < n; b++) {
-                    double s = 0;
-                    for (int i = 0; i < n; i++) s += e.prior_J(i, a) * e.prior_J(i, b);
-                    ne.H(map[a], map[b]) += s;
-                }
+                ne.g[map[a]] += pg[a];
+                for (int b = 0; b < n; b++) ne.H(map[a], map[b]) += prior_hessian(e, a, b);
             }
         }
     }
@@ -1284,6 +1358,29 @@ void Estimator::solve() {
 // ------------------------------------------------------------------ marginalisation (marginalization_factor.cpp:181-315)
 void marg_finish(Estimator &e, Mat &A, std::vector<double> &b, int m, int n) {
     const double eps = 1e-8;
+    if ((e.deviations & ODEV_LANDMARK_ELIM) && m > 15) {
+        // deviation 10 (attribution experiment): the landmark part of the marginalised block is diagonal (one inverse depth per landmark, no
+        // landmark-landmark terms), so it is eliminated analytically -- 1/d where d > eps, dropped otherwise -- and only the 15x15 pose /
+        // speed-bias block that remains goes through the truncated eigen-decomposition below.  Identical to the full decomposition when
+        // nothing is truncated.
+        const int F = m - 15, q = 15 + n;
+        auto qi = [&](int a) { return a < 15 ? a : a + F; };   // index of reduced row a in the full system
+        Mat A2(q, q);
+        std::vector<double> b2(q);
+        for (int a = 0; a < q; a++) {
+            double sb = b[qi(a)];
+            for (int l = 0; l < F; l++) { const double d = A(15 + l, 15 + l); if (d > eps) sb -= A(qi(a), 15 + l) * (b[15 + l] / d); }
+            b2[a] = sb;
+            for (int c = 0; c < q; c++) {
+                double sa = A(qi(a), qi(c));
+                for (int l = 0; l < F; l++) { const double d = A(15 + l, 15 + l); if (d > eps) sa -= A(qi(a), 15 + l) * A(15 + l, qi(c)) / d; }
+                A2(a, c) = sa;
+            }
+        }
+        A = A2;
+        b = b2;
+        m = 15;
+    }
     // Amm^-1 via symmetric eigen-decomposition with truncation
     Mat Amm(m, m);
     for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Amm(i, j) = 0.5 * (A(i, j) + A(j, i));
@@ -1330,6 +1427,31 @@ void marg_finish(Estimator &e, Mat &A, std::vector<double> &b, int m, int n) {
             std::fwrite(br.data(), 8, n, fp);
             std::fclose(fp);
         }
+    }
+    if (e.deviations & ODEV_QUADRATIC_PRIOR) {
+        // deviation 13 (attribution experiment): the prior kept as (A, b, c0) = (sym(A_r), b_r, b^T A^+ b); c0 = |L^-1 b|^2 with
+        // L L^T = A + delta I, delta = 64 eps n max|diag| (lifts the gauge directions off the round-off floor)
+        e.prior_n = n;
+        e.prior_A = As;
+        e.prior_b = br;
+        double dmax = 0;
+        for (int i = 0; i < n; i++) dmax = std::max(dmax, std::fabs(Ar(i, i)));
+        const double delta = 64.0 * 2.220446049250313e-16 * (double)n * dmax;
+        Mat L = As;
+        for (int i = 0; i < n; i++) L(i, i) += delta;
+        double c0 = 0;
+        if (dmax > 0 && chol(L)) {
+            std::vector<double> y(br);
+            for (int i = 0; i < n; i++) {
+                double sacc = y[i];
+                for (int k = 0; k < i; k++) sacc -= L(i, k) * y[k];
+                y[i] = sacc / L(i, i);
+                c0 += y[i] * y[i];
+            }
+            if (!std::isfinite(c0)) c0 = 0;
+        }
+        e.prior_c0 = c0;
+        return;
     }
     std::vector<double> w2;
     Mat V2;
@@ -1402,9 +1524,12 @@ void Estimator::marginalize_old() {  // estimator.cpp:1376-1502
         if (!prior_present[W]) for (int d = 0; d < 9; d++) dx[6 * W + d] = 0;
         if (!prior_present[W + 1]) for (int d = 0; d < 6; d++) dx[6 * W + 9 + d] = 0;
         if (!prior_present[W + 2]) dx[6 * W + 15] = 0;
-        std::vector<double> r(pn);
-        for (int i = 0; i < pn; i++) { double s = prior_r[i]; for (int j = 0; j < pn; j++) s += prior_J(i, j) * dx[j]; r[i] = s; }
-        accumulate(pn, pn, prior_J.d.data(), r.data(), map.data());
+        std::vector<double> r, pg;
+        prior_gradient(*this, dx, pg, r);
+        for (int a = 0; a < pn; a++) {
+            b[map[a]] += pg[a];
+            for (int c = 0; c < pn; c++) A(map[a], map[c]) += prior_hessian(*this, a, c);
+        }
         for (int k = 1; k < W; k++) if (prior_present[k]) present[k - 1] = 1;
         if (prior_present[W + 1]) present[W + 1] = 1;
         if (prior_present[W + 2]) present[W + 2] = 1;
@@ -1507,17 +1632,11 @@ void Estimator::marginalize_second_new() {  // estimator.cpp:1503-1574
     if (!prior_present[W]) for (int d = 0; d < 9; d++) dx[6 * W + d] = 0;
     if (!prior_present[W + 1]) for (int d = 0; d < 6; d++) dx[6 * W + 9 + d] = 0;
     if (!prior_present[W + 2]) dx[6 * W + 15] = 0;
-    std::vector<double> r(pn);
-    for (int i = 0; i < pn; i++) { double s = prior_r[i]; for (int j = 0; j < pn; j++) s += prior_J(i, j) * dx[j]; r[i] = s; }
+    std::vector<double> r, pg;
+    prior_gradient(*this, dx, pg, r);
     for (int a = 0; a < pn; a++) {
-        double gsum = 0;
-        for (int k = 0; k < pn; k++) gsum += prior_J(k, a) * r[k];
-        b[map[a]] += gsum;
-        for (int c = 0; c < pn; c++) {
-            double s = 0;
-            for (int k = 0; k < pn; k++) s += prior_J(k, a) * prior_J(k, c);
-            A(map[a], map[c]) += s;
-        }
+        b[map[a]] += pg[a];
+        for (int c = 0; c < pn; c++) A(map[a], map[c]) += prior_hessian(*this, a, c);
     }
     marg_finish(*this, A, b, m, n);
     std::vector<double> x0(W * 7 + 17, 0.0);

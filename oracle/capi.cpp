@@ -354,16 +354,22 @@ void ovio_marg_finish(int m, int n, const double *A, const double *b, double *J,
     for (int i = 0; i < (m + n) * (m + n); i++) M.d[i] = A[i];
     std::vector<double> bb(b, b + m + n);
     marg_finish(e, M, bb, m, n);
-    for (int i = 0; i < n * n; i++) J[i] = e.prior_J.d[i];
-    for (int i = 0; i < n; i++) r[i] = e.prior_r[i];
+    const bool quad = (e.deviations & ODEV_QUADRATIC_PRIOR) != 0;   // attribution variant (OVIO_DEVIATIONS): (A, b) come back instead of (J, r)
+    for (int i = 0; i < n * n; i++) J[i] = quad ? e.prior_A.d[i] : e.prior_J.d[i];
+    for (int i = 0; i < n; i++) r[i] = quad ? e.prior_b[i] : e.prior_r[i];
 }
+// sincos_det (om.h): n angles -> sin, cos.  And the attribution experiment's switch for the free factor functions (oracle.h ODEV_*): returns the
+// previous mask; pipelines read OVIO_DEVIATIONS themselves when they are created
+void ovio_sincos_det(int n, const double *x, double *sn, double *cs) { for (int i = 0; i < n; i++) sincos_det(x[i], &sn[i], &cs[i]); }
+int ovio_set_deviations(int mask) { int old = oracle_deviations; oracle_deviations = mask; return old; }
 // prior accessors (marginalisation tests): returns n; J (n×n row-major), r (n), present (W+3)
 int ovio_get_prior(void *h, double *J, double *r, double *x0, uint8_t *present) {
     Estimator &e = ((Pipeline *)h)->est;
     if (!e.has_prior) return 0;
     int n = e.prior_n;
-    if (J) for (int i = 0; i < n * n; i++) J[i] = e.prior_J.d[i];
-    if (r) for (int i = 0; i < n; i++) r[i] = e.prior_r[i];
+    const bool quad = (e.deviations & ODEV_QUADRATIC_PRIOR) != 0;   // attribution variant: (A, b) instead of (J, r)
+    if (J) for (int i = 0; i < n * n; i++) J[i] = quad ? e.prior_A.d[i] : e.prior_J.d[i];
+    if (r) for (int i = 0; i < n; i++) r[i] = quad ? e.prior_b[i] : e.prior_r[i];
     if (x0) for (size_t i = 0; i < e.prior_x0.size(); i++) x0[i] = e.prior_x0[i];
     if (present) for (size_t i = 0; i < e.prior_present.size(); i++) present[i] = e.prior_present[i];
     return n;

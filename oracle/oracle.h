@@ -225,6 +225,12 @@ struct Estimator {
     int prior_n = 0;
     om::Mat prior_J;              // n×n  linearized_jacobians
     std::vector<double> prior_r;  // n    linearized_residuals
+    // attribution experiment only (deviations & ODEV_QUADRATIC_PRIOR, see ORACLE_DEVIATIONS below): the prior kept as the quadratic form
+    // (A, b, c0) = (J^T J, J^T r, |r|^2) without the second eigen-decomposition; prior_J / prior_r are then unused
+    om::Mat prior_A;
+    std::vector<double> prior_b;
+    double prior_c0 = 0;
+    int deviations = 0;
     std::vector<double> prior_x0; // keep_block_data in canonical global layout: W*7 + 9 + 7 + 1
     std::vector<uint8_t> prior_present;  // per block: W poses, sb0, ex, td
     SolveStats last_stats;
@@ -300,6 +306,18 @@ struct Estimator {
     void setDepth(const std::vector<double> &x);
     std::vector<double> getDepthVector();
 };
+
+// Attribution experiment (tests/oracle_control.py, DESIGN.md 3 "Round 5"; never used as a checker): environment variable OVIO_DEVIATIONS,
+// read when an Estimator is constructed, switches this restatement to the equivalent formulations the HIP path uses, one bit each, so that the
+// difference between the two can be assigned to a deviation of DESIGN.md's table.  0 (unset) = the reference's formulation everywhere.
+enum {
+    ODEV_IMU_WHITEN = 1,        // deviation 8: sqrt_info = chol(cov)^-1 (lower triangular) instead of LLT(cov^-1).L^T (imu_factor.h:80)
+    ODEV_QUADRATIC_PRIOR = 2,   // deviation 13: the new prior kept as (A, b, c0), no factorisation J = S^1/2 V^T (marginalization_factor.cpp:293-315)
+    ODEV_LANDMARK_ELIM = 4,     // deviation 10: landmarks of the marginalised block eliminated analytically (1/d), eigen pseudo-inverse of the
+                                //               remaining 15x15 (6x6) block only (marginalization_factor.cpp:281-291)
+    ODEV_PAIR_PROJECTION = 8,   // deviation 11: projection residual / Jacobians through the frame-pair matrices A1 = ric^T Rj^T, A2 = A1 Ri, M = A2 ric
+};
+extern int oracle_deviations;   // the mask of the most recently constructed Estimator (the free factor functions read it)
 
 // factor evaluation (exposed for known-answer tests)
 // ProjectionFactor / ProjectionTdFactor: factor/projection_factor.cpp:22-130, projection_td_factor.cpp:34-150

@@ -42,7 +42,17 @@ VARIANTS = {   # name -> (library under oracle/, tracker lag)
     "eps12": ("liboracle.so", 0, {"OVIO_PERTURB_EPS": "1e-12"}),
     "eps9": ("liboracle.so", 0, {"OVIO_PERTURB_EPS": "1e-9"}),
     "eps6": ("liboracle.so", 0, {"OVIO_PERTURB_EPS": "1e-6"}),
+    # round 5, attribution of the HIP-vs-oracle difference: the oracle with the HIP path's equivalent formulations switched on one at a time
+    # and all together (oracle/oracle.h ODEV_*: 1 = IMU whitening chol(cov)^-1 (deviation 8), 2 = quadratic-form prior (13), 4 = analytic
+    # landmark elimination in the marginalisation (10), 8 = frame-pair projection factors (11))
+    "dev8": ("liboracle.so", 0, {"OVIO_DEVIATIONS": "1"}),
+    "dev13": ("liboracle.so", 0, {"OVIO_DEVIATIONS": "2"}),
+    "dev10": ("liboracle.so", 0, {"OVIO_DEVIATIONS": "4"}),
+    "dev11": ("liboracle.so", 0, {"OVIO_DEVIATIONS": "8"}),
+    "devall": ("liboracle.so", 0, {"OVIO_DEVIATIONS": "15"}),
+    "devall_lag1": ("liboracle.so", 1, {"OVIO_DEVIATIONS": "15"}),
 }
+DEV_NAMES = ("dev8", "dev13", "dev10", "dev11", "devall")
 
 
 def run_variants(seq, n_frames, names, cfg_kw=None):
@@ -231,9 +241,46 @@ def cmd_assemble(a):
         print("lag-1 fixture: %d sequences, mean ATE %.4f mm, reboots %d -> %s" % (n, ate.mean() * 1e3, reb.sum(), a.fixture))
 
 
+def early_rows(za, na, nb, n_early=30):
+    """largest distance of two runs over the first n_early published positions (the window in which implementations still agree)"""
+    pa, pb = za[na + "_pos"], za[nb + "_pos"]
+    n = min(len(pa), len(pb), n_early)
+    return float(np.linalg.norm(pa[:n] - pb[:n], axis=1).max())
+
+
+def cmd_attribution(a):
+    """round 5: base vs each single deviation and vs all of them (same statistics as the control pairs) + the early-frame distances"""
+    have = sorted(int(f[4:9]) for f in os.listdir(a.scratch) if f.startswith("seq_") and f.endswith(".npz") and ".tmp" not in f)
+    Z = {s: dict(np.load(os.path.join(a.scratch, "seq_%05d.npz" % s))) for s in have}
+    ctl = [s for s in have if "base_pos" in Z[s]]
+    fx = np.load(os.path.join(HERE, "golden", "oracle_ate_300.npz"))
+    nfx = 0
+    for s in ctl:
+        i = s - int(fx["seq0"])
+        if 0 <= i < len(fx["positions"]):
+            z = Z[s]
+            assert np.array_equal(fx["positions"][i][z["base_frames"]], z["base_pos"]), "base run differs from the committed fixture (seq %d)" % s
+            nfx += 1
+    rep = dict(what="the oracle against itself with the HIP path's equivalent formulations switched on (OVIO_DEVIATIONS, oracle/oracle.h ODEV_*), "
+                    "%d frames, sequences %d..%d, tracker lag 0" % (a.frames, ctl[0], ctl[-1]),
+               variants={k: VARIANTS[k][2] for k in DEV_NAMES}, base_bit_identical_to_lag0_fixture_sequences=nfx, pairs={})
+    names = [nm for nm in DEV_NAMES if all(nm + "_pos" in Z[s] for s in ctl)]
+    for na, nb in [("base", nm) for nm in names] + [("devall", nm) for nm in names if nm != "devall"]:
+        rows = [pair_rows(Z[s], Z[s], na, nb, s) for s in ctl]
+        e30 = np.array([early_rows(Z[s], na, nb) for s in ctl])
+        sm = summarise(rows)
+        sm.update(early_30_rows_max_distance_m=dict(median=float(np.median(e30)), p90=float(np.percentile(e30, 90)), max=float(e30.max()),
+                                                    below_1e_11=int((e30 <= 1e-11).sum()), below_1e_9=int((e30 <= 1e-9).sum())))
+        rep["pairs"]["%s_vs_%s" % (na, nb)] = dict(summary=sm, rows=rows)
+        print(na, nb, json.dumps({k: sm[k] for k in ("separated_beyond_1um", "separated_beyond_1mm", "median_max_distance_m", "median_first_frame_beyond_1um",
+                                                     "median_first_flip_frame", "signed_rel_diff_of_means", "standard_error_rel", "early_30_rows_max_distance_m")}))
+    os.makedirs(os.path.dirname(a.out), exist_ok=True)
+    json.dump(rep, open(a.out, "w"), indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("cmd", choices=("run", "assemble"))
+    ap.add_argument("cmd", choices=("run", "assemble", "attribution"))
     ap.add_argument("--seqs", type=int, default=1024)
     ap.add_argument("--control", type=int, default=128, help="leading sequences that also run the control variants")
     ap.add_argument("--seq0", type=int, default=700)
@@ -246,7 +293,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "round4_oracle_self_divergence.json"))
     ap.add_argument("--fixture", default=os.path.join(HERE, "golden", "oracle_ate_300_lag1.npz"))
     a = ap.parse_args()
-    (cmd_run if a.cmd == "run" else cmd_assemble)(a)
+    {"run": cmd_run, "assemble": cmd_assemble, "attribution": cmd_attribution}[a.cmd](a)
 
 
 if __name__ == "__main__":

@@ -136,3 +136,38 @@ def test_online_extrinsic_refinement_matches_oracle(P):
     assert np.abs(eh - eo).max() < 1e-5
     assert np.abs(eh[:3] - np.array(cfg.tic[:])).max() > 1e-4  # the extrinsic really moved
     assert np.abs(b.window(0)[:, :3] - ref["oracle"].window()[:, :3]).max() < 2e-5
+
+
+def test_handle_owns_its_device(P):
+    """vio_create_on_device: the handle records the device it was created on and every entry point binds the calling
+    thread to it (and restores the caller's device), so SURVEY.md 8e's one-process / one-thread-per-GPU driver never calls hipSetDevice.
+    On the 1-GPU box: device 0 by number and by default, an unknown device refused loudly, and a handle driven from a second host thread
+    gives the same bits as one driven from the creating thread."""
+    import ctypes as C
+    import threading
+    L = P.lib()
+    cfg = P.canonical_config()
+    b0 = P.VioBatch(cfg, 1)
+    b1 = P.VioBatch(cfg, 1, device=0)
+    assert b0.device == 0 and b1.device == 0
+    assert L.vio_create_on_device(C.byref(cfg), 1, 1024, 97) is None and b"no such HIP device" in L.vio_last_error()
+    sc = vio_ct.synth_like(cfg)
+    n, seq = 16, 3
+    syn = P.Synth(sc)
+    frames = [syn.render_host(seq, float(t)) for t in vio_ct.frame_times(sc, n)]
+    ti, ai, gi = syn.imu(seq, int(n / sc.cam_rate * sc.imu_rate) + 64)
+
+    def drive(b):
+        k = 0
+        for f, tf in enumerate(vio_ct.frame_times(sc, n)):
+            k2 = vio_ct.imu_until(ti, k, tf, sc.imu_rate)
+            if k2 > k:
+                b.push_imu(0, ti[k:k2], ai[k:k2], gi[k:k2])
+            k = k2
+            b.feed(frames[f][0][None], frames[f][1][None], [tf])
+    drive(b0)
+    th = threading.Thread(target=drive, args=(b1,))     # a thread that never touched HIP before: its current device is the runtime's default
+    th.start(); th.join()
+    assert b0.status(0).solver_flag == 1
+    assert np.array_equal(b0.window(0).view(np.uint64), b1.window(0).view(np.uint64))
+    assert np.array_equal(b0.tracks(0)[2].view(np.uint32), b1.tracks(0)[2].view(np.uint32))

@@ -98,7 +98,9 @@ def test_pipeline_matches_oracle(P, variant):
         # final feature tracks identical
         a, q = o["oracle"].tracks(), b.tracks(i)
         assert np.array_equal(a[0], q[0]) and np.array_equal(a[1], q[1])
-        assert np.abs(a[2] - q[2]).max() < 5e-3  # LK stops at 0.01 px; device sin/cos in predictMotion differ by ulps
+        # round 5: predictMotion is bit-reproducible (shared polynomial sin / cos), so the only thing that can still move a predicted point
+        # is latest_Bg, which the two back-ends agree on to ~1e-9 at this depth of the run: the tracked positions are the same floats
+        assert np.array_equal(a[2].view(np.uint32), q[2].view(np.uint32)), float(np.abs(a[2] - q[2]).max())
 
 
 def test_pipeline_config5_shape(P):

@@ -68,6 +68,7 @@ def test_no_gpu_means_loud_failure(P):
         P.VioBatch(cfg, 1)
     assert P.lib().vio_create(C.byref(cfg), 1, 1024) is None
     assert len(P.lib().vio_last_error()) > 0
+    assert P.lib().vio_create_on_device(C.byref(cfg), 1, 1024, 0) is None and P.lib().vio_get_device(None) < 0
     img = np.zeros((16, 16), np.uint8)
     out = np.zeros((8, 8), np.uint8)
     assert P.lib().vio_stage_pyr_down(img.ctypes.data, 16, 16, out.ctypes.data) != 0  # VIO_EDEVICE, never a CPU result

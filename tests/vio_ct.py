@@ -86,6 +86,7 @@ def oracle(path=None):
             "ovio_sym_eig": [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p],
             "ovio_get_prior": [C.c_void_p] * 5,
             "ovio_marg_finish": [C.c_int, C.c_int] + [C.c_void_p] * 4,
+            "ovio_sincos_det": [C.c_int] + [C.c_void_p] * 3, "ovio_set_deviations": [C.c_int],
         }.items():
             getattr(L, name).argtypes = args
         assert L.ovio_config_size() == C.sizeof(pkg().Config), "oracle Config and vio_config layouts differ"

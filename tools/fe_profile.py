@@ -4,6 +4,8 @@
 The window is first filled through vio_feed (so that track counts / ages are the steady-state ones), then `frames` frames go through
 vio_track only.  Prints the mean per-kernel time, the wall time per frame of the track loop and the distribution over sequences of
 the time one workgroup spends in fe_select / fe_add (the one-workgroup-per-sequence kernels)."""
+import os as _os
+_os.environ.setdefault("VIO_HIP_LIB", "timers")   # the build with the phase timers compiled in (default build has none)
 import argparse
 import ctypes as C
 import os

@@ -2,6 +2,8 @@
 """In-kernel phase timers of sequence 0 (vio_debug_phases: thread 0 accumulates 100 MHz ticks per phase) on the bench workload.
     python tools/phase_profile.py [--seqs 128] [--frames 40]
 Prints microseconds per frame for every phase slot of be_solve / be_marg (see the PH(k) markers in be_kernels.hip)."""
+import os as _os
+_os.environ.setdefault("VIO_HIP_LIB", "timers")   # the build with the phase timers compiled in (default build has none)
 import argparse
 import ctypes as C
 import os

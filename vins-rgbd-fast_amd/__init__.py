@@ -76,11 +76,22 @@ def lib():
     """Load libvio_hip.so (no CPU fallback: raises if the extension is missing)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
+        path = _LIB_PATH
+        if os.environ.get("VIO_HIP_LIB") == "timers":
+            # the profiling tools' build with the in-kernel phase timers compiled in (csrc/Makefile target `timers`); never the default
+            path = os.path.join(_HERE, "libvio_hip_timers.so")
+            if not os.path.exists(path):
+                r = subprocess.run(["make", "-j8", "-C", os.path.join(_HERE, "csrc"), "timers"], capture_output=True, text=True)
+                if r.returncode != 0:
+                    raise VioError("hipcc build (timers) failed:\n" + r.stdout[-4000:] + r.stderr[-4000:])
+        if not os.path.exists(path):
             raise VioError("libvio_hip.so is not built: run __graft_entry__.build() (the product path has no CPU fallback)")
-        L = C.CDLL(_LIB_PATH)
+        L = C.CDLL(path)
         L.vio_create.restype = C.c_void_p
         L.vio_create.argtypes = [C.POINTER(Config), C.c_int, C.c_int]
+        L.vio_create_on_device.restype = C.c_void_p
+        L.vio_create_on_device.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_int]
+        L.vio_get_device.argtypes = [C.c_void_p]
         L.vio_destroy.argtypes = [C.c_void_p]
         L.vio_last_error.restype = C.c_char_p
         L.vio_reset.argtypes = [C.c_void_p]
@@ -274,15 +285,21 @@ class Synth:
 class VioBatch:
     """A batch of S independent sequences resident in HBM (vio_batch)."""
 
-    def __init__(self, cfg=None, n_seq=1, imu_capacity=8192):
+    def __init__(self, cfg=None, n_seq=1, imu_capacity=8192, device=None):
+        """device: HIP device index the handle lives on (None = the calling thread's current device); the handle keeps it and every call
+        binds to it (vio_create_on_device), so handles on different GPUs can be driven from one thread or from one thread each."""
         self.L = lib()
         self.cfg = cfg or default_config()
         self.S = n_seq
         self.W = self.cfg.window_size
-        self.h = self.L.vio_create(C.byref(self.cfg), n_seq, imu_capacity)
+        self.h = self.L.vio_create_on_device(C.byref(self.cfg), n_seq, imu_capacity, -1 if device is None else int(device))
         if not self.h:
             raise VioError("vio_create failed: %s" % self.L.vio_last_error().decode())
         self.h = C.c_void_p(self.h)
+
+    @property
+    def device(self):
+        return int(self.L.vio_get_device(self.h))
 
     def close(self):
         if self.h:

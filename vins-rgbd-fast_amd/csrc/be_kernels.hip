@@ -15,8 +15,13 @@
 using namespace dm;
 
 // phase timers (debug): thread 0 of sequence 0 accumulates 100 MHz wall-clock ticks into B.timings[k]
-#define PH_INIT long long ph_t0 = (s == 0 && threadIdx.x == 0) ? (long long)wall_clock64() : 0
-#define PH(k) do { if (s == 0 && threadIdx.x == 0) { long long n_ = (long long)wall_clock64(); B.timings[k] += (float)(n_ - ph_t0); ph_t0 = n_; } } while (0)
+#if VIO_TIMERS
+#define PH_INIT long long ph_t0 = (s == 0 && threadIdx.x == 0) ? VIO_CLOCK() : 0
+#define PH(k) do { if (s == 0 && threadIdx.x == 0) { long long n_ = VIO_CLOCK(); B.timings[k] += (float)(n_ - ph_t0); ph_t0 = n_; } } while (0)
+#else
+#define PH_INIT do {} while (0)
+#define PH(k) do {} while (0)
+#endif
 
 namespace {
 
@@ -1599,7 +1604,7 @@ __device__ __forceinline__ void solve_epilogue(Ctx &c, const Params &X, double c
         if (t == 0) {
             be.final_cost = cost; be.iterations = iters_done; be.successful = succ;
             be.iter_total += iters_done; be.solve_total++;
-            be.dbg[4] = (int)(wall_clock64() - ts0);
+            be.dbg[4] = (int)(VIO_CLOCK() - ts0);
         }
         if (t <= W) {
             const int i = t;
@@ -1611,7 +1616,7 @@ __device__ __forceinline__ void solve_epilogue(Ctx &c, const Params &X, double c
     if (t == 0) {
         be.final_cost = cost; be.iterations = iters_done; be.successful = succ;
         be.iter_total += iters_done; be.solve_total++;
-        be.dbg[4] = (int)(wall_clock64() - ts0);
+        be.dbg[4] = (int)(VIO_CLOCK() - ts0);
         v3 origin_R0 = R2ypr(ldm(be.Rs[0]));
         v3 origin_P0 = ld3(be.Ps[0]);
         quat q0 = mkq(X.pose[6], X.pose[3], X.pose[4], X.pose[5]);
@@ -1798,7 +1803,7 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
     const bool hpl_sparse = schur_staged && 6 * W1 + 7 <= 128;
 
     PH_INIT;
-    const long long ts0 = wall_clock64();
+    const long long ts0 = VIO_CLOCK();
     int F, Fa, nres;
     solve_prologue(B, c, X, scratch, pw, sh_i, F, Fa, nres);
     const int nlm = be.n_lm;
@@ -2094,92 +2099,158 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
 // Cl (F0 x ldc, columns indexed like q), d_l = c.Hll (J_l^T J_l), c.gl (J_l^T r).  Marginalised block: m = md + F0 = [pose 0, speed-bias 0
 // | inverse depths of the landmarks that start in frame 0] (md = 6 and F0 = 0 for MARGIN_SECOND_NEW).  Both eigen-decompositions are the
 // threshold Jacobi of jacobi_block (the oracle's om::sym_eig is the cyclic form of the same iteration) on matrices in HBM scratch.
+// LDS layout of the literal marginalisation's eigen-decompositions: the matrix (ld = n | 1: conflict-free column access), then d / e / g and
+// the per-wavefront partial sums of sym_eig_tridiag_mt.  Host side: marg_exact_lds_bytes (vio_abi.hip) sizes the launch with the same formula.
+#define MARG_EIG_AUX_DOUBLES (11 * EIG_LD)
+// Symmetric eigen-decomposition in LDS: A (n x n, ld) -> eigenvectors in place (columns), eigenvalues in d.  Householder tridiagonalisation over
+// the whole workgroup + implicit QL on one wavefront (be_linalg.h; the same pair be_prior_factor_kernel runs).  n <= 128 (tridiag_ql_wave).
+__device__ __forceinline__ void sym_eig_lds(double *Al, int n, int ld, double *aux) {
+    double *d = aux, *e = aux + EIG_LD, *g = aux + 2 * EIG_LD, *part = aux + 3 * EIG_LD;
+    sym_eig_tridiag_mt(Al, n, ld, d, e, g, part);
+    tridiag_ql_wave(Al, n, ld, d, e);
+}
 __device__ void marg_exact_finish(const Ctx &c, BeSeq &be, double *A, const double *b, int md, int mq, int n, const double *Cl, int ldc, int F0,
                                   bool second_new, double *sred, unsigned char *smem) {
     const int t = threadIdx.x, nt = blockDim.x;
     const double eps = 1e-8;
     const int MX = c.C->MX, m = md + F0;
     double *Emm = c.margE, *EV = Emm + (size_t)MX * MX, *Einv = EV + (size_t)MX * MX, *ET1 = Einv + (size_t)MX * MX;
+    // the dynamic LDS of this kernel, declared here so that the eigen-solver below is compiled for ds_* accesses (a pointer handed down
+    // through two calls would be flat); same base address as the caller's smem
+    extern __shared__ __attribute__((aligned(16))) unsigned char marg_dyn_lds[];
     double *cs = (double *)smem, *sn = cs + 256;
     int *pp = (int *)(sn + 256), *qq = pp + 256;
     __shared__ double ev2[EIG_LD], vb2[EIG_LD];
     // Amm = 0.5 (Amm + Amm^T) (:276); the landmark-landmark block is diagonal (an inverse depth only meets itself)
-    for (int w = t; w < m * m; w += nt) {
-        const int i = w / m, j = w - i * m;
-        double v;
-        if (i < md && j < md) v = 0.5 * (A[i * mq + j] + A[j * mq + i]);
-        else if (i >= md && j >= md) v = i == j ? c.Hll[i - md] : 0.0;
-        else v = Cl[(size_t)((i >= md ? i : j) - md) * ldc + (i >= md ? j : i)];
-        Emm[w] = v;
-    }
-    __syncthreads();
-    const int sw1 = jacobi_block(Emm, EV, m, m, cs, sn, pp, qq, sred);
-    // Amm_inv = V diag(lambda > eps ? 1 / lambda : 0) V^T (:281-283)
-    for (int w = t; w < m * m; w += nt) {
-        const int i = w / m, j = w - i * m;
-        double sacc = 0;
-        for (int k = 0; k < m; k++) { const double ev = Emm[(size_t)k * m + k]; if (ev > eps) sacc += EV[(size_t)i * m + k] * EV[(size_t)j * m + k] / ev; }
-        Einv[w] = sacc;
-    }
-    __syncthreads();
-    // A_rm A_mm^-1 (:288-292); column k of A_rm: q-column k for the pose / speed-bias part, the coupling row of landmark k - md otherwise
-    for (int w = t; w < n * m; w += nt) {
-        const int i = w / m, j = w - i * m;
-        double sacc = 0;
-        for (int k = 0; k < md; k++) sacc += A[(md + i) * mq + k] * Einv[(size_t)k * m + j];
-        for (int k = md; k < m; k++) sacc += Cl[(size_t)(k - md) * ldc + md + i] * Einv[(size_t)k * m + j];
-        ET1[w] = sacc;
-    }
-    __syncthreads();
+    auto amm = [&](int i, int j) -> double {
+        if (i < md && j < md) return 0.5 * (A[i * mq + j] + A[j * mq + i]);
+        if (i >= md && j >= md) return i == j ? c.Hll[i - md] : 0.0;
+        return Cl[(size_t)((i >= md ? i : j) - md) * ldc + (i >= md ? j : i)];
+    };
+    // Both eigen-decompositions of marginalize() run LDS-resident when the block fits (m, n <= MXL): Householder + implicit QL instead of
+    // Jacobi sweeps over HBM (round 5).  ONE call site of the solver, visited twice, so that its code exists once in the kernel.
+    int sw1 = 0, sw2 = 0;
     double *Ar = c.margV, *br = c.vec;
-    for (int w = t; w < n * n; w += nt) {   // A = Arr - Arm Amm_inv Amr
-        const int i = w / n, j = w - i * n;
-        double tt = A[(md + i) * mq + md + j];
-        for (int k = 0; k < md; k++) tt -= ET1[(size_t)i * m + k] * A[k * mq + md + j];
-        for (int k = md; k < m; k++) tt -= ET1[(size_t)i * m + k] * Cl[(size_t)(k - md) * ldc + md + j];
-        Ar[w] = tt;
-    }
-    for (int i = t; i < n; i += nt) {       // b = brr - Arm Amm_inv bmm
-        double sacc = b[md + i];
-        for (int k = 0; k < md; k++) sacc -= ET1[(size_t)i * m + k] * b[k];
-        for (int k = md; k < m; k++) sacc -= ET1[(size_t)i * m + k] * c.gl[k - md];
-        br[i] = sacc;
+    double *Al = (double *)marg_dyn_lds;
+    for (int pass = 0; pass < 2; pass++) {
+        const int nn = pass == 0 ? m : n, ld = nn | 1;
+        const bool in_lds = nn <= c.C->MXL;
+        double *aux = Al + (size_t)nn * ld;
+        if (in_lds) {
+            if (pass == 0) for (int w = t; w < m * m; w += nt) { const int i = w / m, j = w - i * m; Al[i * ld + j] = amm(i, j); }
+            else for (int w = t; w < n * n; w += nt) { const int i = w / n, j = w - i * n; Al[i * ld + j] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
+            __syncthreads();
+            sym_eig_lds(Al, nn, ld, aux);   // SelfAdjointEigenSolver<MatrixXd> saes(Amm) (:281) / saes2(A) (:298)
+        }
+        if (pass == 0) {
+            if (in_lds) {
+                // Amm_inv = V diag(lambda > eps ? 1 / lambda : 0) V^T (:281-283); 1 / lambda once per column
+                for (int k = t; k < m; k += nt) { const double ev = aux[k]; aux[EIG_LD + k] = ev > eps ? 1.0 / ev : 0.0; }
+                __syncthreads();
+                for (int w = t; w < m * m; w += nt) {
+                    const int i = w / m, j = w - i * m;
+                    double sacc = 0;
+                    for (int k = 0; k < m; k++) sacc += Al[i * ld + k] * Al[j * ld + k] * aux[EIG_LD + k];
+                    Einv[w] = sacc;
+                }
+            } else {
+                for (int w = t; w < m * m; w += nt) { const int i = w / m, j = w - i * m; Emm[w] = amm(i, j); }
+                __syncthreads();
+                sw1 = jacobi_block(Emm, EV, m, m, cs, sn, pp, qq, sred);
+                for (int w = t; w < m * m; w += nt) {
+                    const int i = w / m, j = w - i * m;
+                    double sacc = 0;
+                    for (int k = 0; k < m; k++) { const double ev = Emm[(size_t)k * m + k]; if (ev > eps) sacc += EV[(size_t)i * m + k] * EV[(size_t)j * m + k] / ev; }
+                    Einv[w] = sacc;
+                }
+            }
+            __syncthreads();
+            // A_rm A_mm^-1 (:288-292); column k of A_rm: q-column k for the pose / speed-bias part, the coupling row of landmark k - md otherwise
+            for (int w = t; w < n * m; w += nt) {
+                const int i = w / m, j = w - i * m;
+                double sacc = 0;
+                for (int k = 0; k < md; k++) sacc += A[(md + i) * mq + k] * Einv[(size_t)k * m + j];
+                for (int k = md; k < m; k++) sacc += Cl[(size_t)(k - md) * ldc + md + i] * Einv[(size_t)k * m + j];
+                ET1[w] = sacc;
+            }
+            __syncthreads();
+            for (int w = t; w < n * n; w += nt) {   // A = Arr - Arm Amm_inv Amr
+                const int i = w / n, j = w - i * n;
+                double tt = A[(md + i) * mq + md + j];
+                for (int k = 0; k < md; k++) tt -= ET1[(size_t)i * m + k] * A[k * mq + md + j];
+                for (int k = md; k < m; k++) tt -= ET1[(size_t)i * m + k] * Cl[(size_t)(k - md) * ldc + md + j];
+                Ar[w] = tt;
+            }
+            for (int i = t; i < n; i += nt) {       // b = brr - Arm Amm_inv bmm
+                double sacc = b[md + i];
+                for (int k = 0; k < md; k++) sacc -= ET1[(size_t)i * m + k] * b[k];
+                for (int k = md; k < m; k++) sacc -= ET1[(size_t)i * m + k] * c.gl[k - md];
+                br[i] = sacc;
+            }
+            __syncthreads();
+            continue;
+        }
+        // second eigen-decomposition (:298-311): S = eigenvalues > eps, linearized_jacobians = S^1/2 V^T, linearized_residuals = S^-1/2 V^T b
+        if (in_lds) {
+            for (int k = t; k < n; k += nt) {
+                const double ev = aux[k];
+                double vb = 0;
+                for (int i = 0; i < n; i++) vb += Al[i * ld + k] * br[i];
+                c.prior_rf[k] = sqrt(ev > eps ? 1.0 / ev : 0.0) * vb;
+                aux[EIG_LD + k] = sqrt(ev > eps ? ev : 0.0);
+            }
+            __syncthreads();
+            // J = S^1/2 V^T: column k of the eigenvector array scaled in place, so Al[i][k] = J[k][i]
+            for (int w = t; w < n * n; w += nt) { const int i = w / n, k = w - i * n; const double v = aux[EIG_LD + k] * Al[i * ld + k]; Al[i * ld + k] = v; c.prior_J[k * n + i] = v; }
+            __syncthreads();
+            // what MarginalizationFactor::Evaluate, the solver and the next marginalisation consume of (J, r): J^T J, J^T r and |r|^2
+            for (int w = t; w < n * n; w += nt) {
+                const int a = w / n, bb = w - a * n;
+                double sacc = 0;
+                for (int k = 0; k < n; k++) sacc += Al[a * ld + k] * Al[bb * ld + k];
+                c.prior_H[w] = sacc;
+            }
+            for (int a = t; a < n; a += nt) {
+                double sacc = 0;
+                for (int k = 0; k < n; k++) sacc += Al[a * ld + k] * c.prior_rf[k];
+                c.prior_r[a] = sacc;
+            }
+        } else {
+            double *As = c.margW, *V2 = A;   // (A is free from here on)
+            for (int w = t; w < n * n; w += nt) { const int i = w / n, j = w - i * n; As[w] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
+            __syncthreads();
+            sw2 = jacobi_block(As, V2, n, n, cs, sn, pp, qq, sred);
+            for (int k = t; k < n; k += nt) {
+                ev2[k] = As[k * n + k];
+                double vb = 0;
+                for (int i = 0; i < n; i++) vb += V2[i * n + k] * br[i];
+                vb2[k] = vb;
+            }
+            __syncthreads();
+            for (int w = t; w < n * n; w += nt) {
+                const int k = w / n, i = w - k * n;
+                const double S = ev2[k] > eps ? ev2[k] : 0.0;
+                c.prior_J[w] = sqrt(S) * V2[i * n + k];
+            }
+            for (int k = t; k < n; k += nt) {
+                const double Sinv = ev2[k] > eps ? 1.0 / ev2[k] : 0.0;
+                c.prior_rf[k] = sqrt(Sinv) * vb2[k];
+            }
+            __syncthreads();
+            for (int w = t; w < n * n; w += nt) {
+                const int a = w / n, bb = w - a * n;
+                double sacc = 0;
+                for (int k = 0; k < n; k++) sacc += c.prior_J[k * n + a] * c.prior_J[k * n + bb];
+                c.prior_H[w] = sacc;
+            }
+            for (int a = t; a < n; a += nt) {
+                double sacc = 0;
+                for (int k = 0; k < n; k++) sacc += c.prior_J[k * n + a] * c.prior_rf[k];
+                c.prior_r[a] = sacc;
+            }
+        }
     }
     __syncthreads();
-    // second eigen-decomposition (:298-311): S = eigenvalues > eps, linearized_jacobians = S^1/2 V^T, linearized_residuals = S^-1/2 V^T b
-    double *As = c.margW, *V2 = A;   // (A is free from here on)
-    for (int w = t; w < n * n; w += nt) { const int i = w / n, j = w - i * n; As[w] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
-    __syncthreads();
-    const int sw2 = jacobi_block(As, V2, n, n, cs, sn, pp, qq, sred);
-    for (int k = t; k < n; k += nt) {
-        ev2[k] = As[k * n + k];
-        double vb = 0;
-        for (int i = 0; i < n; i++) vb += V2[i * n + k] * br[i];
-        vb2[k] = vb;
-    }
-    __syncthreads();
-    for (int w = t; w < n * n; w += nt) {
-        const int k = w / n, i = w - k * n;
-        const double S = ev2[k] > eps ? ev2[k] : 0.0;
-        c.prior_J[w] = sqrt(S) * V2[i * n + k];
-    }
-    for (int k = t; k < n; k += nt) {
-        const double Sinv = ev2[k] > eps ? 1.0 / ev2[k] : 0.0;
-        c.prior_rf[k] = sqrt(Sinv) * vb2[k];
-    }
-    __syncthreads();
-    // what MarginalizationFactor::Evaluate, the solver and the next marginalisation consume of (J, r): J^T J, J^T r and |r|^2
-    for (int w = t; w < n * n; w += nt) {
-        const int a = w / n, bb = w - a * n;
-        double sacc = 0;
-        for (int k = 0; k < n; k++) sacc += c.prior_J[k * n + a] * c.prior_J[k * n + bb];
-        c.prior_H[w] = sacc;
-    }
-    for (int a = t; a < n; a += nt) {
-        double sacc = 0;
-        for (int k = 0; k < n; k++) sacc += c.prior_J[k * n + a] * c.prior_rf[k];
-        c.prior_r[a] = sacc;
-    }
     double acc = 0;
     for (int k = t; k < n; k += nt) acc += c.prior_rf[k] * c.prior_rf[k];
     const double c0 = block_sum(acc, sred);
@@ -2210,7 +2281,7 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
     const bool exact = EXACT && cfg.marg_exact != 0 && c.margE != nullptr;
     int F0x = 0;   // landmarks in the marginalised block (exact mode)
     PH_INIT;
-    const long long tk0 = wall_clock64();
+    const long long tk0 = VIO_CLOCK();
     // vector2double
     if (t <= W) {
         int i = t;
@@ -2632,7 +2703,7 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
     if (t == W + 1) { for (int d = 0; d < 7; d++) c.prior_x0[W * 7 + 9 + d] = X.ex[d]; c.prior_x0[W * 7 + 16] = X.td; }
     __syncthreads();
     if (t < W + 3) be.prior_present[t] = newpresent[t];
-    if (t == 0) { be.has_prior = 1; be.dbg[3] = (int)(wall_clock64() - tk0); }
+    if (t == 0) { be.has_prior = 1; be.dbg[3] = (int)(VIO_CLOCK() - tk0); }
     PH(23);
 }
 
@@ -2670,7 +2741,7 @@ __global__ __launch_bounds__(512) void be_prior_factor_kernel(Batch B, int seq) 
     const int n = c.NPR;
     const double eps = 1e-8;
     const double *br = c.prior_r;
-    const long long tj0 = wall_clock64();
+    const long long tj0 = VIO_CLOCK();
     // symmetrised A_r and its eigenvectors live in LDS when they fit (n <= 96), else in HBM scratch
     const bool in_lds = n <= 96;
     const int ldj = in_lds ? (n | 1) : n;  // odd leading dimension: conflict-free 64-bit LDS column access
@@ -2686,18 +2757,18 @@ __global__ __launch_bounds__(512) void be_prior_factor_kernel(Batch B, int seq) 
         double *Al = (double *)smem_marg;
         if ((nt >> 6) <= 8) sym_eig_tridiag_mt(Al, n, ldj, ev_d, ev_e, ev_g, ev_part);
         else sym_eig_tridiag(Al, n, ldj, ev_d, ev_e, ev_g, sred);
-        if (t == 0) be.dbg[5] = (int)(wall_clock64() - tj0);
+        if (t == 0) be.dbg[5] = (int)(VIO_CLOCK() - tj0);
         tridiag_ql_wave(Al, n, ldj, ev_d, ev_e);
     } else {
         double *Ag = c.margA;
         if ((nt >> 6) <= 8) sym_eig_tridiag_mt(Ag, n, ldj, ev_d, ev_e, ev_g, ev_part);
         else sym_eig_tridiag(Ag, n, ldj, ev_d, ev_e, ev_g, sred);
-        if (t == 0) be.dbg[5] = (int)(wall_clock64() - tj0);
+        if (t == 0) be.dbg[5] = (int)(VIO_CLOCK() - tj0);
         tridiag_ql_wave(Ag, n, ldj, ev_d, ev_e);
     }
-    if (t == 0) be.dbg[6] = (int)(wall_clock64() - tj0);
+    if (t == 0) be.dbg[6] = (int)(VIO_CLOCK() - tj0);
     Vv = As;  // eigenvectors overwrite the matrix
-    if (t == 0) be.dbg[1] = (int)(wall_clock64() - tj0);
+    if (t == 0) be.dbg[1] = (int)(VIO_CLOCK() - tj0);
     // linearized_jacobians = sqrt(S) V^T ; linearized_residuals = S^-1/2 V^T b
     for (int w = t; w < n * n; w += nt) {
         int k = w / n, i = w - k * n;

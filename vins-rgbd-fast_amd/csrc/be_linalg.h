@@ -1064,7 +1064,7 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
     __syncthreads();
     if (wave == 0) chol_diag_tile(diag(0), dinv, sh_flag);
     __syncthreads();
-    long long tm0 = (tm && t == 0) ? (long long)wall_clock64() : 0;
+    long long tm0 = (tm && t == 0) ? VIO_CLOCK() : 0;
     for (int p = 0; p < nb; p++) {
         if (!*sh_flag) return false;
         // (b) panel: the tiles below the diagonal block become A M^T (one wavefront per tile); the right-hand side block becomes M b
@@ -1072,7 +1072,7 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
         if (rhs && wave == nw - 1) chol_rhs_block(rhs + 16 * p, diag(p), dinv + 16 * p);
         if (t == 0) *ctr = 1;
         __syncthreads();
-        if (tm && t == 0) { long long n_ = (long long)wall_clock64(); tm[0] += (float)(n_ - tm0); tm0 = n_; }
+        if (VIO_TIMERS && tm && t == 0) { long long n_ = VIO_CLOCK(); tm[0] += (float)(n_ - tm0); tm0 = n_; }
         // (c) trailing update S22 -= L21 L21^T on the FP64 matrix cores; tile 0 = (p+1, p+1) belongs to wavefront 0
         const int m = nb - 1 - p, ntile = m * (m + 1) / 2;
         if (nw > 1) {
@@ -1101,9 +1101,9 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
             WAVE_SYNC();
             if (ntile > 0) chol_diag_tile(diag(p + 1), dinv + 16 * (p + 1), sh_flag);
         }
-        if (tm && t == 0) { long long n_ = (long long)wall_clock64(); tm[1] += (float)(n_ - tm0); tm0 = n_; }
+        if (VIO_TIMERS && tm && t == 0) { long long n_ = VIO_CLOCK(); tm[1] += (float)(n_ - tm0); tm0 = n_; }
         __syncthreads();
-        if (tm && t == 0) { long long n_ = (long long)wall_clock64(); tm[2] += (float)(n_ - tm0); tm0 = n_; }
+        if (VIO_TIMERS && tm && t == 0) { long long n_ = VIO_CLOCK(); tm[2] += (float)(n_ - tm0); tm0 = n_; }
     }
     return *sh_flag != 0;
 }
@@ -1182,7 +1182,7 @@ __device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col
     };
     if (t == 0) *sh_flag = 1;
     __syncthreads();
-    long long tm1 = tm ? (long long)wall_clock64() : 0;   // timing harness only (stage_linalg.hip), as wavefront 1 sees the phases: [0] update of the
+    long long tm1 = tm ? VIO_CLOCK() : 0;   // timing harness only (stage_linalg.hip), as wavefront 1 sees the phases: [0] update of the
                                                           // column incl. the wait for the diagonal block, [1] panels
     // Look-ahead on the diagonal: wavefront 1 takes no row tiles; during the update phase of column p it accumulates tile (p + 1, p + 1) over the
     // finished columns 0 .. p - 1 into `ahead` (LDS), so that wavefront 0 -- which owns the diagonal tile -- only adds column p's own term
@@ -1268,9 +1268,9 @@ __device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col
             else if (left == 2) chol_stream_update<2>(G, p, i, st7, col);
             else if (left == 1) chol_stream_update<1>(G, p, i, st7, col);
         }
-        if (tm && t == 64) { long long n_ = (long long)wall_clock64(); tm[0] += (float)(n_ - tm1); }
+        if (VIO_TIMERS && tm && t == 64) { long long n_ = VIO_CLOCK(); tm[0] += (float)(n_ - tm1); }
         __syncthreads();
-        if (tm && t == 64) tm1 = (long long)wall_clock64();
+        if (VIO_TIMERS && tm && t == 64) tm1 = VIO_CLOCK();
         if (!*sh_flag) return false;
         if (wave == la_wave) {   // wavefront 0 is past its read of `ahead`: publish the next tile (visible after this column's second barrier)
 #pragma unroll
@@ -1285,7 +1285,7 @@ __device__ __forceinline__ bool chol_tiles_stream(double *G, int nb, double *col
         }
         if (rhs && wave == nw - 1) chol_rhs_block(rhs + 16 * p, col, dinv + 16 * p);
         __syncthreads();
-        if (tm && t == 64) { long long n_ = (long long)wall_clock64(); tm[1] += (float)(n_ - tm1); tm1 = n_; }
+        if (VIO_TIMERS && tm && t == 64) { long long n_ = VIO_CLOCK(); tm[1] += (float)(n_ - tm1); tm1 = n_; }
     }
     return *sh_flag != 0;
 }

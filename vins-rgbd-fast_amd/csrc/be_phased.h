@@ -37,7 +37,7 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(Batch B) {
     SolveSt &st = B.sst[s];
     BeSeq &be = *c.be;
     if (!be.do_solve) { if (t == 0) st.stage = PS_IDLE; return; }
-    const long long ts0 = wall_clock64();
+    const long long ts0 = VIO_CLOCK();
     int F, Fa, nres;
     solve_prologue(B, c, X, scratch, pw, sh_i, F, Fa, nres, /*allow_relo=*/true);
     for (int k = t; k < (int)(sizeof(Params) / sizeof(double)); k += blockDim.x) ((double *)&st.X)[k] = ((const double *)&X)[k];
@@ -320,9 +320,9 @@ __device__ __forceinline__ void ps_eval_body(const Batch &B) {
     if (last && t < 64) {
         __threadfence();
         if (t == 0) st.eval_done = 0;
-        const long long ta = (s == 0 && t == 0) ? (long long)wall_clock64() : 0;
+        const long long ta = (s == 0 && t == 0) ? VIO_CLOCK() : 0;
         ps_accept(B, s);
-        if (s == 0 && t == 0) B.timings[15] += (float)((long long)wall_clock64() - ta);
+        if (VIO_TIMERS && s == 0 && t == 0) B.timings[15] += (float)(VIO_CLOCK() - ta);
     }
 }
 
@@ -352,8 +352,8 @@ __device__ __forceinline__ void ps_asm_a_body(const Batch &B) {
     const bool vext = st.vext != 0;
     const int nres = st.nres, Fa = st.Fa;
     __shared__ double imu_lds[8 * 704];
-    const long long tk0 = (s == 0 && lane == 0) ? (long long)wall_clock64() : 0;
-    auto tick = [&](int slot) { if (s == 0 && lane == 0) B.timings[slot] += (float)((long long)wall_clock64() - tk0); };
+    const long long tk0 = (s == 0 && lane == 0) ? VIO_CLOCK() : 0;
+    auto tick = [&](int slot) { if (VIO_TIMERS && s == 0 && lane == 0) B.timings[slot] += (float)(VIO_CLOCK() - tk0); };
     const int npairs = W1 * (W1 - 1) / 2;
     if (item < npairs) {
         // item = pair_slot(i, j): the frame pairs i < j in row-major order

@@ -117,6 +117,27 @@ DM_HD quat R2q(const m3 &m) {  // Eigen Quaternion(Matrix3)
     }
     return q;
 }
+#define SINCOS_DET_QUAL DM_HD
+// Deterministic sin / cos for Estimator::predictMotion's AngleAxisd (estimator.cpp:1853-1856): the tracker's prediction is the one place where
+// a transcendental function feeds a bit-exact comparison, and two math libraries round sin / cos differently in the last place.  Only + - *
+// and a round-to-nearest by the 1.5 * 2^52 constant: every IEEE-754 double implementation without contraction returns the same bits.
+// Cody-Waite reduction by pi/2 in three parts (exact products for |x| < 2^20 * pi/2), then the classical minimax polynomials for
+// |r| <= pi/4 (coefficients of the Sun fdlibm kernels); < 2 ulp.  THE SAME TEXT lives in oracle/om.h and csrc/dmath.h.
+SINCOS_DET_QUAL void sincos_det(double x, double *sn, double *cs) {
+    const double kd = (x * 0.63661977236758134308 + 6755399441055744.0) - 6755399441055744.0;
+    const double r = ((x - kd * 1.57079632673412561417e+00) - kd * 6.07710050630396597660e-11) - kd * 2.02226624879595063154e-21;
+    const double z = r * r;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                      z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 +
+                      z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double s0 = r + (r * z) * ps;
+    const double c0 = (1.0 - 0.5 * z) + (z * z) * pc;
+    const int q = (int)((long long)kd & 3);
+    *sn = q == 0 ? s0 : (q == 1 ? c0 : (q == 2 ? -s0 : -c0));
+    *cs = q == 0 ? c0 : (q == 1 ? -s0 : (q == 2 ? -c0 : s0));
+}
+#undef SINCOS_DET_QUAL
 DM_HD quat deltaQ(v3 th) { return mkq(1.0, th.x / 2, th.y / 2, th.z / 2); }  // utility.h:11-24
 
 DM_HD v3 R2ypr(const m3 &R) {  // utility.h:66-81, degrees

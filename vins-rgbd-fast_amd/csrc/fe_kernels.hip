@@ -12,8 +12,13 @@
 #include "kernels.h"
 
 // in-kernel phase timers of sequence 0 (thread 0, 100 MHz ticks into Batch::timings, slots 64..; tools/phase_profile.py)
-#define FE_PH_INIT long long fe_t0 = (s == 0 && threadIdx.x == 0) ? (long long)wall_clock64() : 0
-#define FE_PH(k) do { if (s == 0 && threadIdx.x == 0) { long long n_ = (long long)wall_clock64(); B.timings[k] += (float)(n_ - fe_t0); fe_t0 = n_; } } while (0)
+#if VIO_TIMERS
+#define FE_PH_INIT long long fe_t0 = (s == 0 && threadIdx.x == 0) ? VIO_CLOCK() : 0
+#define FE_PH(k) do { if (s == 0 && threadIdx.x == 0) { long long n_ = VIO_CLOCK(); B.timings[k] += (float)(n_ - fe_t0); fe_t0 = n_; } } while (0)
+#else
+#define FE_PH_INIT do {} while (0)
+#define FE_PH(k) do {} while (0)
+#endif
 
 namespace {
 
@@ -141,7 +146,8 @@ __device__ dm::m3 predict_motion(const Batch &B, int s, double t0, double t1) {
         dm::m3 Rk = dm::eye();
         if (ang > 0) {
             dm::v3 ax = dm::scl(1.0 / ang, aa);
-            double sn = sin(ang), cs = cos(ang);
+            double sn, cs;
+            dm::sincos_det(ang, &sn, &cs);   // same bits as the CPU restatement (dmath.h)
             dm::m3 K = dm::skew(ax);
             Rk = dm::add(dm::add(dm::eye(), dm::scl(sn, K)), dm::scl(1 - cs, dm::mul(K, K)));
         }
@@ -209,7 +215,8 @@ __device__ dm::m3 predict_motion_wave(const Batch &B, int s, double t0, double t
             dm::m3 Rk = dm::eye();
             if (ang > 0) {
                 const dm::v3 ax = dm::scl(1.0 / ang, aa);
-                const double sn = sin(ang), cs = cos(ang);
+                double sn, cs;
+                dm::sincos_det(ang, &sn, &cs);
                 const dm::m3 K = dm::skew(ax);
                 Rk = dm::add(dm::add(dm::eye(), dm::scl(sn, K)), dm::scl(1 - cs, dm::mul(K, K)));
             }
@@ -646,12 +653,12 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
             reg_ok = !(inx < -WIN || inx >= w || iny < -WIN || iny >= h);
         }
         const int wx0a = (ipx - 1) & ~3, wxo = (ipx - 1) - wx0a;   // aligned first column of the template block, lead-in bytes
-        long long lt0 = stats ? (long long)wall_clock64() : 0;
+        long long lt0 = stats ? VIO_CLOCK() : 0;
         __syncthreads();
         lk_stage<24, LK_WP / 4, false>(I, w, h, wx0a, ipy - 1, win, lane);
         if (reg_ok) lk_stage<LK_REG, LK_RP / 4, true>(J, w, h, rx0 & ~3, ry0, jw, lane);
         __syncthreads();
-        if (stats && lane == 0) stats[4] += (float)((long long)wall_clock64() - lt0);
+        if (VIO_TIMERS && stats && lane == 0) stats[4] += (float)(VIO_CLOCK() - lt0);
         if (lane < 44) {
             // Scharr derivatives of the 22 x 22 block, separably: lane -> (row lane / 2, 11 columns).  Per window column c of the three
             // rows: s[c] = 3 a + 10 b + 3 c (vertical smoothing), v[c] = c - a (vertical difference); then
@@ -677,7 +684,7 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
             }
         }
         __syncthreads();
-        if (stats && lane == 0) stats[5] += (float)((long long)wall_clock64() - lt0);
+        if (VIO_TIMERS && stats && lane == 0) stats[5] += (float)(VIO_CLOCK() - lt0);
         // per-lane partial sums stay in 32 bits: |ix|, |iy| <= 4080 (convex blends of Scharr sums), 7 products per lane
         int pA11 = 0, pA12 = 0, pA22 = 0;
         if (act) {
@@ -710,9 +717,9 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
         }
         D = 1.f / D;
         float2 prevDelta = make_float2(0.f, 0.f);
-        if (stats && lane == 0) { long long n_ = (long long)wall_clock64(); stats[2] += (float)(n_ - lt0); stats[1] += 1.f; lt0 = n_; }
+        if (VIO_TIMERS && stats && lane == 0) { long long n_ = VIO_CLOCK(); stats[2] += (float)(n_ - lt0); stats[1] += 1.f; lt0 = n_; }
         for (int j = 0; j < 30; j++) {
-            if (stats && lane == 0) stats[0] += 1.f;
+            if (VIO_TIMERS && stats && lane == 0) stats[0] += 1.f;
             int inx = cv_floor(nextPt.x), iny = cv_floor(nextPt.y);
             if (inx < -WIN || inx >= w || iny < -WIN || iny >= h) {
                 if (level == 0) status = 0;
@@ -758,7 +765,7 @@ __device__ void lk_one_point(const LkImages &im, int maxLevel, float2 prevPtIn, 
             }
             prevDelta = delta;
         }
-        if (stats && lane == 0) stats[3] += (float)((long long)wall_clock64() - lt0);
+        if (VIO_TIMERS && stats && lane == 0) stats[3] += (float)(VIO_CLOCK() - lt0);
     }
     nextPtIO = nextPts;
     statusOut = status;
@@ -804,7 +811,7 @@ __global__ __launch_bounds__(64, LK_WAVES) void fe_lk_kernel(Batch B) {
         }
     }
     __syncthreads();
-    const long long lk_t0 = (s == 0 && blk0 == 0 && threadIdx.x == 0) ? (long long)wall_clock64() : 0;
+    const long long lk_t0 = (s == 0 && blk0 == 0 && threadIdx.x == 0) ? VIO_CLOCK() : 0;
     // the block count per sequence is capped (most of the NP track slots are empty): a block walks its features with stride nblk
     for (int i = blk0; i < fe.n_pts; i += nblk) {
         float2 np = B.forw_pts[(size_t)s * C.NP + i];
@@ -816,7 +823,7 @@ __global__ __launch_bounds__(64, LK_WAVES) void fe_lk_kernel(Batch B) {
         }
         __syncthreads();
     }
-    if (s == 0 && blk0 == 0 && threadIdx.x == 0) { B.timings[90] += (float)((long long)wall_clock64() - lk_t0); B.timings[91] += 1.f; }
+    if (VIO_TIMERS && s == 0 && blk0 == 0 && threadIdx.x == 0) { B.timings[90] += (float)(VIO_CLOCK() - lk_t0); B.timings[91] += 1.f; }
 }
 
 // stand-alone variant for the stage test: explicit images, points from arrays
@@ -1039,8 +1046,8 @@ struct RansacShared {
 __device__ void ransac_block(const vio_config &c, int N, const double *X1, const double *Y1, const double *X2, const double *Y2,
                              int *status, RansacShared &R, int *iters_out, float *tm = nullptr) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, nw = blockDim.x >> 6;
-    long long rt0 = (tm && t == 0) ? (long long)wall_clock64() : 0;
-#define RS_PH(k) do { if (tm && t == 0) { long long n_ = (long long)wall_clock64(); tm[k] += (float)(n_ - rt0); rt0 = n_; } } while (0)
+    long long rt0 = (tm && t == 0) ? VIO_CLOCK() : 0;
+#define RS_PH(k) do { if (VIO_TIMERS && tm && t == 0) { long long n_ = VIO_CLOCK(); tm[k] += (float)(n_ - rt0); rt0 = n_; } } while (0)
     const double thr = c.f_threshold / c.focal_length, thr2 = thr * thr;
     if (t == 0) { R.niters = c.ransac_max_iters; R.maxGood = 0; R.base = 0; R.batch = min(nw, 4); }
     __syncthreads();
@@ -1174,7 +1181,7 @@ __global__ __launch_bounds__(256) void fe_select_kernel(Batch B) {
     float2 *g_unst = B.unstable_pts + (size_t)s * NP;
     int n = fe.n_pts;
     FE_PH_INIT;
-    const long long wg_t0 = t == 0 ? (long long)wall_clock64() : 0;
+    const long long wg_t0 = t == 0 ? VIO_CLOCK() : 0;
     for (int i = t; i < n; i += blockDim.x) {
         cur[i] = g_cur[i]; forw[i] = g_forw[i]; un[i] = g_un[i]; id[i] = g_id[i]; cnt[i] = g_cnt[i];
     }
@@ -1226,7 +1233,9 @@ __global__ __launch_bounds__(256) void fe_select_kernel(Batch B) {
             __syncthreads();
             FE_PH(65);
             ransac_block(c, n, X1, Y1, X2, Y2, flag, R, &fe.ransac_iters, s == 0 ? B.timings + 66 : nullptr);
-            if (s == 0 && t == 0) fe_t0 = (long long)wall_clock64();
+#if VIO_TIMERS
+            if (s == 0 && t == 0) fe_t0 = VIO_CLOCK();
+#endif
             int total = block_exclusive_scan(flag, n, offs, scratch);
             float2 c0, f0, u0; int i0, k0;
             for (int b = 0; b < n; b += blockDim.x) {
@@ -1359,7 +1368,7 @@ __global__ __launch_bounds__(256) void fe_select_kernel(Batch B) {
     }
     __syncthreads();
     for (int i = t; i < n; i += blockDim.x) { g_forw[i] = forw[i]; g_id[i] = id[i]; g_cnt[i] = cnt[i]; }
-    if (t == 0) { fe.n_forw = n; fe.n_deficit = n_deficit; fe.n_unstable = sh_nun; B.fe_ticks[s * 4 + 0] = (float)((long long)wall_clock64() - wg_t0); }
+    if (t == 0) { fe.n_forw = n; fe.n_deficit = n_deficit; fe.n_unstable = sh_nun; if (VIO_TIMERS) B.fe_ticks[s * 4 + 0] = (float)(VIO_CLOCK() - wg_t0); }
     FE_PH(73);
 }
 
@@ -1515,7 +1524,7 @@ __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int gate) {
     int *g_id = B.ids + (size_t)s * NP, *g_cnt = B.track_cnt + (size_t)s * NP, *g_pid = B.prev_un_id + (size_t)s * NP;
     int n = fe.n_forw;
     FE_PH_INIT;
-    const long long wg_t0 = t == 0 ? (long long)wall_clock64() : 0;
+    const long long wg_t0 = t == 0 ? VIO_CLOCK() : 0;
     const int nprev = fe.n_prev_map;
     for (int k = t; k < nprev; k += blockDim.x) { pid_l[k] = g_pid[k]; pun_l[k] = g_pun[k]; }
     if (publish && fe.n_deficit > 0) {
@@ -1773,7 +1782,7 @@ __global__ __launch_bounds__(256) void fe_add_kernel(Batch B, int gate) {
     }
     FE_PH(87);
     if (t == 0) {
-        B.fe_ticks[s * 4 + 1] = (float)((long long)wall_clock64() - wg_t0);
+        if (VIO_TIMERS) B.fe_ticks[s * 4 + 1] = (float)(VIO_CLOCK() - wg_t0);
         B.fe_ticks[s * 4 + 2] = (float)fe.n_deficit;
         B.fe_ticks[s * 4 + 3] = (float)fe.ransac_iters;
         fe.n_pts = n;

@@ -42,6 +42,8 @@ struct vio_batch {
     DevCfg hc;  // host copy
     Batch B;
     int S;
+    int device = -1;   // the HIP device this handle's memory, streams and events live on (vio_create: the caller's current device; vio_create_on_device:
+                       // the one asked for).  Every entry point binds the calling thread to it for the duration of the call (DevGuard below).
     // Sequences are split into groups of contiguous sequences; every group has its own pair of streams, so the chain
     // track -> ingest -> solve -> marginalise of one group never waits for the slowest sequence of another group.
     struct Group {
@@ -178,6 +180,22 @@ static bool lds_fits(const void *fn, size_t dynamic_bytes, const char *name) {
     return false;
 }
 
+// dynamic LDS of be_marg_exact_kernel's LDS-resident eigen-decomposition of an m x m block (be_kernels.hip marg_exact_finish)
+static size_t marg_exact_lds_bytes(int m) { return ((size_t)m * (m | 1) + 11 * (size_t)(6 * VIO_MAXW + 16)) * 8 + 64; }
+
+// A handle owns its device: entry points may be called from any host thread with any device current (one host thread per GPU
+// in one process, or a caller that moves between devices); the guard makes h->device current for the call and restores the caller's on return.
+struct DevGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DevGuard(const vio_batch *h) {
+        if (!h || h->device < 0) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != h->device) switched = hipSetDevice(h->device) == hipSuccess;
+    }
+    ~DevGuard() { if (switched) (void)hipSetDevice(prev); }
+    DevGuard(const DevGuard &) = delete;
+    DevGuard &operator=(const DevGuard &) = delete;
+};
 static int sync_all(vio_batch *h) {
     for (auto &g : h->groups) {
         if (g.copy_stream) HIPCHK(hipStreamSynchronize(g.copy_stream));
@@ -835,12 +853,36 @@ static int create_group_streams(vio_batch *h, vio_batch::Group &g, bool partitio
     return VIO_OK;
 }
 
-vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
+vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) { return vio_create_on_device(cfg, n_seq, imu_capacity, -1); }
+int vio_get_device(vio_batch *h) { return h ? h->device : VIO_EINVAL; }
+
+vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capacity, int device) {
     if (!cfg || n_seq < 1) { g_err = "bad arguments"; return nullptr; }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_err = "no HIP device (the product path has no CPU fallback)"; return nullptr; }
+    if (device >= ndev) { g_err = "vio_create_on_device: no such HIP device"; return nullptr; }
+    int caller_dev = 0;
+    if (hipGetDevice(&caller_dev) != hipSuccess) { g_err = "hipGetDevice failed"; return nullptr; }
     vio_batch *h = new vio_batch();
+    h->device = device < 0 ? caller_dev : device;
+    DevGuard dev_guard(h);   // every allocation, stream and event below is created on h->device; the caller's device is current again on return
     if (build_devcfg(cfg, imu_capacity, h->hc) != VIO_OK) { delete h; return nullptr; }
+    h->hc.MXL = 0;
+    if (h->hc.MX > 0) {
+        // marg_exact: the eigen-decompositions of the literal marginalisation run LDS-resident for blocks up to MXL -- whatever the kernel's
+        // static LDS leaves of the workgroup's share (matrix with an odd leading dimension + the solver's vectors, be_kernels.hip
+        // MARG_EIG_AUX_DOUBLES), and never beyond the 128 rows tridiag_ql_wave covers
+        hipFuncAttributes fa;
+        int cap = 0;
+        if (hipDeviceGetAttribute(&cap, hipDeviceAttributeMaxSharedMemoryPerBlock, h->device) != hipSuccess || cap <= 0) cap = 160 * 1024;
+        if (hipFuncGetAttributes(&fa, (const void *)be_marg_exact_kernel) == hipSuccess) {
+            const long avail = (long)cap - (long)fa.sharedSizeBytes - 256;
+            int m = 0;
+            while (m < 128 && (long)marg_exact_lds_bytes(m + 1) <= avail) m++;
+            if (getenv("VIO_MARG_EIG_LDS")) m = std::min(m, std::max(0, atoi(getenv("VIO_MARG_EIG_LDS"))));   // 0: the round-4 HBM Jacobi everywhere (A/B timing)
+            h->hc.MXL = m;
+        }
+    }
     h->S = n_seq;
     const DevCfg &C = h->hc;
     const size_t S = (size_t)n_seq, NP = C.NP, NL = C.NL, W1 = C.W + 1, HW = (size_t)C.c.width * C.c.height;
@@ -978,6 +1020,7 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
         {
             size_t nbq = ((size_t)C.NPRIOR + 15) >> 4;
             h->lds_marg = std::max(std::max((size_t)nbq * (nbq + 1) / 2 * 2048, (size_t)2 * C.NPRIOR * 15 * 8), (size_t)PREINT_MANY_LDS_DOUBLES * 8) + 64;   // (the last: F / V of a chunk of the pre-integration merge)  // lower 16x16 tiles of the new prior (Cholesky for its constant term); before that T1 and A_mr
+            if (C.MXL > 0) h->lds_marg = std::max(h->lds_marg, marg_exact_lds_bytes(C.MXL));
             h->lds_factor = C.NPRIOR <= 96 ? (size_t)C.NPRIOR * (C.NPRIOR | 1) * 8 + 64 : 64;  // on-demand eigen-decomposition (vio_get_prior)
             (void)raise_lds_limit((const void *)be_prior_factor_kernel, h->lds_factor);
         }
@@ -1005,6 +1048,8 @@ vio_batch *vio_create(const vio_config *cfg, int n_seq, int imu_capacity) {
 
 void vio_destroy(vio_batch *h) {
     if (!h) return;
+    int caller_dev = -1;   // (not a DevGuard: the handle dies inside this function)
+    const bool dev_switched = h->device >= 0 && hipGetDevice(&caller_dev) == hipSuccess && caller_dev != h->device && hipSetDevice(h->device) == hipSuccess;
     (void)hipDeviceSynchronize();
     for (void *p : h->allocs) (void)hipFree(p);
     if (h->d_gray_stage) (void)hipFree(h->d_gray_stage);
@@ -1047,15 +1092,18 @@ void vio_destroy(vio_batch *h) {
     }
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
+    if (dev_switched) (void)hipSetDevice(caller_dev);
 }
 
 int vio_reset(vio_batch *h) {
+    DevGuard dev_guard(h);
     if (!h) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     return init_state(h, 0, h->S);
 }
 
 int vio_reset_seq(vio_batch *h, int seq) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     { int rc_ = refresh_dynamic_state(h); if (rc_ != VIO_OK) return rc_; }   // a reboot of ANOTHER sequence decided by the last solve must not be lost
@@ -1063,12 +1111,14 @@ int vio_reset_seq(vio_batch *h, int seq) {
 }
 
 int vio_reset_tracker_seq(vio_batch *h, int seq) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     return init_state(h, seq, seq + 1, VIO_RESET_TRACKER);
 }
 
 int vio_push_imu(vio_batch *h, int seq, int n, const double *t, const double *acc, const double *gyr) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S || n < 0) return VIO_EINVAL;
     std::lock_guard<std::mutex> lk(h->imu_mu);
     for (int i = 0; i < n; i++) {
@@ -1202,6 +1252,7 @@ static int stage_side_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *m
 }
 
 int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, const uint8_t *modes, int on_device) {
+    DevGuard dev_guard(h);
     if (!h || !gray || !depth_mm || !stamps) return VIO_EINVAL;
     int rc = wait_host_uploads(h);   // (pending uploads of an earlier vio_track / vio_process call; vio_feed itself leaves none, see stage_side_ring)
     if (rc != VIO_OK) return rc;
@@ -1236,6 +1287,7 @@ int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, 
 }
 
 int vio_feed(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, int on_device) {
+    DevGuard dev_guard(h);
     return vio_feed_modes(h, gray, depth_mm, stamps, nullptr, on_device);
 }
 
@@ -1264,14 +1316,17 @@ static int track_impl(vio_batch *h, const uint8_t *gray, const double *stamps, i
 }
 
 int vio_track(vio_batch *h, const uint8_t *gray, const double *stamps, int publish, int on_device) {
+    DevGuard dev_guard(h);
     return track_impl(h, gray, stamps, publish, nullptr, nullptr, on_device);
 }
 
 int vio_track_ex(vio_batch *h, const uint8_t *gray, const double *stamps, const uint8_t *modes, const double *R_rel, int on_device) {
+    DevGuard dev_guard(h);
     return track_impl(h, gray, stamps, 1, modes, R_rel, on_device);
 }
 
 int vio_predict_motion(vio_batch *h, int seq, double t0, double t1, double *R9) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S || !R9) return VIO_EINVAL;
     int rc = flush_imu_frontend(h);  // samples pushed so far must be in the ring (Estimator::predictMotion reads imu_buf)
     if (rc != VIO_OK) return rc;
@@ -1288,6 +1343,7 @@ int vio_predict_motion(vio_batch *h, int seq, double t0, double t1, double *R9) 
 }
 
 int vio_set_fisheye_mask(vio_batch *h, const uint8_t *mask, int on_device) {
+    DevGuard dev_guard(h);
     if (!h) return VIO_EINVAL;
     int rc = sync_all(h);
     if (rc != VIO_OK) return rc;
@@ -1300,6 +1356,7 @@ int vio_set_fisheye_mask(vio_batch *h, const uint8_t *mask, int on_device) {
 }
 
 int vio_set_tracker_lag(vio_batch *h, int lag) {
+    DevGuard dev_guard(h);
     if (!h || (lag != 0 && lag != 1)) return VIO_EINVAL;
     if (lag && h->hc.c.dynamic_init) { g_err = "vio_set_tracker_lag: dynamic_init handles run their initialisation on the host between frames (lag 0 only)"; return VIO_EINVAL; }
     int rc = sync_all(h);
@@ -1315,6 +1372,7 @@ int vio_set_tracker_lag(vio_batch *h, int lag) {
 
 int vio_set_relo_frame(vio_batch *h, int seq, double frame_stamp, int frame_index, int n, const double *match_points, const double *relo_t3,
                        const double *relo_r9) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S || n < 0 || (n > 0 && !match_points) || !relo_t3 || !relo_r9) return VIO_EINVAL;
     if (n > h->hc.NP) { g_err = "more match points than the tracker holds features (vio_get_capacity)"; return VIO_ECAPACITY; }
     for (int i = 1; i < n; i++)
@@ -1333,6 +1391,7 @@ int vio_set_relo_frame(vio_batch *h, int seq, double frame_stamp, int frame_inde
 }
 
 int vio_get_relo(vio_batch *h, int seq, double *out30) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S || !out30) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local BeSeq be;
@@ -1349,6 +1408,7 @@ int vio_get_relo(vio_batch *h, int seq, double *out30) {
 }
 
 int vio_get_latest_odometry(vio_batch *h, int seq, double *out11) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S || !out11) return VIO_EINVAL;
     int rc = flush_imu_backend(h);   // samples pushed so far must be in the ring
     if (rc != VIO_OK) return rc;
@@ -1361,6 +1421,7 @@ int vio_get_latest_odometry(vio_batch *h, int seq, double *out11) {
 }
 
 int vio_process(vio_batch *h, const uint16_t *depth_mm, int on_device) {
+    DevGuard dev_guard(h);
     if (!h || !depth_mm) return VIO_EINVAL;
     int rc = wait_host_uploads(h);
     if (rc != VIO_OK) return rc;
@@ -1384,6 +1445,7 @@ int vio_process(vio_batch *h, const uint16_t *depth_mm, int on_device) {
 
 int vio_process_obs_batch(vio_batch *h, const int32_t *n_obs, const int32_t *ids, const double *obs, int cap, const uint16_t *depth_mm,
                           const double *stamps, int on_device) {
+    DevGuard dev_guard(h);
     if (!h || !n_obs || !ids || !obs || !depth_mm || !stamps || cap < 1) return VIO_EINVAL;
     const int NP = h->hc.NP;
     for (int s = 0; s < h->S; s++)
@@ -1417,6 +1479,7 @@ int vio_process_obs_batch(vio_batch *h, const int32_t *n_obs, const int32_t *ids
 }
 
 int vio_process_obs(vio_batch *h, int seq, int n, const int32_t *ids, const double *obs, const uint16_t *depth_mm, double stamp) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S || n < 0 || (n > 0 && (!ids || !obs)) || !depth_mm) return VIO_EINVAL;
     if (n == 0) return VIO_OK;  // the nodelet only queues non-empty maps (estimator_nodelet.cpp:378)
     const DevCfg &C = h->hc;
@@ -1447,6 +1510,7 @@ int vio_process_obs(vio_batch *h, int seq, int n, const int32_t *ids, const doub
 }
 
 int vio_get_packaged(vio_batch *h, int seq, int cap, int32_t *ids, double *obs) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local FeSeq fe;
@@ -1477,6 +1541,7 @@ int vio_device_download(void *dst, const void *src, size_t bytes) { HIPCHK(hipMe
 int vio_abi_sizeof(int what) { return what == 0 ? (int)sizeof(vio_config) : (what == 1 ? (int)sizeof(vio_status) : -1); }
 
 int vio_get_capacity(vio_batch *h, int32_t *out3) {
+    DevGuard dev_guard(h);
     if (!h || !out3) return VIO_EINVAL;
     out3[0] = h->hc.NP; out3[1] = h->hc.NL; out3[2] = h->hc.NIMU;
     return VIO_OK;
@@ -1485,11 +1550,13 @@ int vio_get_capacity(vio_batch *h, int32_t *out3) {
 // which solver the handle runs: 0 = persistent kernel (round-1 fallback), 1 = phased with the Schur complement in LDS tiles, 2 = phased
 // with the Schur complement in HBM / L2 (windows beyond W = 10)
 int vio_get_solver_kind(vio_batch *h) {
+    DevGuard dev_guard(h);
     if (!h) return VIO_EINVAL;
     return h->solve_mode == 0 ? 0 : (h->serial_big ? 2 : 1);
 }
 
 int vio_push_imu_batch(vio_batch *h, const int32_t *n, int stride, const double *t, const double *acc, const double *gyr) {
+    DevGuard dev_guard(h);
     if (!h || stride < 0 || !t || !acc || !gyr) return VIO_EINVAL;
     std::lock_guard<std::mutex> lk(h->imu_mu);
     for (int s = 0; s < h->S; s++) {
@@ -1508,10 +1575,11 @@ int vio_push_imu_batch(vio_batch *h, const int32_t *n, int stride, const double 
 }
 
 int vio_sync(vio_batch *h) {
+    DevGuard dev_guard(h);
     if (!h) return VIO_EINVAL;
     return sync_all(h);
 }
-void *vio_get_stream(vio_batch *h) { return h ? (void *)h->stream : nullptr; }
+void *vio_get_stream(vio_batch *h) { DevGuard dev_guard(h); return h ? (void *)h->stream : nullptr; }
 
 static void fill_status(const BeSeq &be, const FeSeq &fe, vio_status *out) {
     const int ovf = be.overflow | fe.overflow;
@@ -1527,6 +1595,7 @@ static void fill_status(const BeSeq &be, const FeSeq &fe, vio_status *out) {
 }
 
 int vio_get_status(vio_batch *h, int seq, vio_status *out) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S || !out) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local BeSeq be;
@@ -1538,6 +1607,7 @@ int vio_get_status(vio_batch *h, int seq, vio_status *out) {
 }
 
 int vio_get_status_all(vio_batch *h, vio_status *out) {
+    DevGuard dev_guard(h);
     if (!h || !out) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     std::vector<BeSeq> be((size_t)h->S);
@@ -1549,6 +1619,7 @@ int vio_get_status_all(vio_batch *h, vio_status *out) {
 }
 
 int vio_get_window(vio_batch *h, int seq, double *out) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S || !out) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local BeSeq be;
@@ -1565,6 +1636,7 @@ int vio_get_window(vio_batch *h, int seq, double *out) {
 }
 
 int vio_get_odometry(vio_batch *h, double *out) {
+    DevGuard dev_guard(h);
     if (!h || !out) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     HIPCHK(hipMemcpy(out, h->B.odom, sizeof(double) * (size_t)h->S * 11, hipMemcpyDeviceToHost));
@@ -1572,6 +1644,7 @@ int vio_get_odometry(vio_batch *h, double *out) {
 }
 
 int vio_get_odometry_history(vio_batch *h, int seq, int cap, double *out) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S || !out) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     int n = 0;
@@ -1588,6 +1661,7 @@ int vio_get_odometry_history(vio_batch *h, int seq, int cap, double *out) {
 }
 
 int vio_get_extrinsic(vio_batch *h, int seq, double *out13) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S || !out13) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local BeSeq be;
@@ -1599,6 +1673,7 @@ int vio_get_extrinsic(vio_batch *h, int seq, double *out13) {
 }
 
 int vio_get_tracks(vio_batch *h, int seq, int cap, int32_t *ids, int32_t *cnt, float *cur, float *un, float *vel) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local FeSeq fe;
@@ -1652,10 +1727,11 @@ static int get_landmarks_impl(vio_batch *h, int seq, int cap, double *out, int w
     }
     return n;
 }
-int vio_get_landmarks(vio_batch *h, int seq, int cap, double *out) { return get_landmarks_impl(h, seq, cap, out, 7); }
-int vio_get_landmarks_ex(vio_batch *h, int seq, int cap, double *out12) { return get_landmarks_impl(h, seq, cap, out12, 12); }
+int vio_get_landmarks(vio_batch *h, int seq, int cap, double *out) { DevGuard dev_guard(h); return get_landmarks_impl(h, seq, cap, out, 7); }
+int vio_get_landmarks_ex(vio_batch *h, int seq, int cap, double *out12) { DevGuard dev_guard(h); return get_landmarks_impl(h, seq, cap, out12, 12); }
 
 int vio_get_prior(vio_batch *h, int seq, double *J, double *r, double *x0, uint8_t *present) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local BeSeq be;
@@ -1677,6 +1753,7 @@ int vio_get_prior(vio_batch *h, int seq, double *J, double *r, double *x0, uint8
 }
 
 int vio_get_timings(vio_batch *h, int cap, double *out_ms) {
+    DevGuard dev_guard(h);
     if (!h || !out_ms || cap < 3) return VIO_EINVAL;
     if (!h->timing_valid) return 0;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
@@ -1688,6 +1765,7 @@ int vio_get_timings(vio_batch *h, int cap, double *out_ms) {
 }
 
 int vio_debug_seq(vio_batch *h, int seq, int *out16) {
+    DevGuard dev_guard(h);
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local BeSeq be;
@@ -1698,6 +1776,7 @@ int vio_debug_seq(vio_batch *h, int seq, int *out16) {
 
 // debug: accumulated in-kernel phase ticks (100 MHz) of sequence 0; reset != 0 clears them
 int vio_debug_phases(vio_batch *h, float *out128, int reset) {
+    DevGuard dev_guard(h);
     if (!h) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     if (out128) HIPCHK(hipMemcpy(out128, h->B.timings, 128 * sizeof(float), hipMemcpyDeviceToHost));
@@ -1707,6 +1786,7 @@ int vio_debug_phases(vio_batch *h, float *out128, int reset) {
 
 // debug: per-sequence in-kernel durations (100 MHz ticks) of the last frame's fe_select / fe_add: out[S][4]
 int vio_debug_fe_ticks(vio_batch *h, float *out) {
+    DevGuard dev_guard(h);
     if (!h || !out) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     HIPCHK(hipMemcpy(out, h->B.fe_ticks, (size_t)h->S * 4 * sizeof(float), hipMemcpyDeviceToHost));
@@ -1715,6 +1795,7 @@ int vio_debug_fe_ticks(vio_batch *h, float *out) {
 
 // per-kernel HIP-event profile of the next max_steps vio_feed calls (events sit on the batch stream)
 int vio_profile_begin(vio_batch *h, int max_steps) {
+    DevGuard dev_guard(h);
     if (!h || max_steps < 1) return VIO_EINVAL;
     size_t need = (size_t)max_steps * VIO_NEV;
     while (h->pev.size() < need) {
@@ -1729,6 +1810,7 @@ int vio_profile_begin(vio_batch *h, int max_steps) {
 }
 // out_ms[k] = average duration of kernel k over the recorded steps (ms); returns the number of recorded steps
 int vio_profile_end(vio_batch *h, int cap, double *out_ms) {
+    DevGuard dev_guard(h);
     if (!h || !out_ms || cap < VIO_NK) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     int n = h->prof_cur < 0 ? 0 : (h->prof_cur < h->prof_steps ? h->prof_cur : h->prof_steps);

@@ -4,6 +4,16 @@
 // (estimator.h:117-201), FeatureManager::feature (feature_manager.h:143), IntegrationBase (integration_base.h:197-216),
 // MarginalizationInfo (marginalization_factor.h:51-76).
 #pragma once
+// In-kernel phase timers (tools/phase_profile.py, tools/fe_profile.py): compiled OUT of the default build.  `make -C csrc timers` builds
+// libvio_hip_timers.so with -DVIO_PHASE_TIMERS; the tools load it through VIO_HIP_LIB.  VIO_CLOCK() is the only spelling of the clock read in
+// the product kernels, and every accumulation into Batch::timings is behind VIO_TIMERS, so the default build carries neither.
+#ifdef VIO_PHASE_TIMERS
+#define VIO_TIMERS 1
+#define VIO_CLOCK() ((long long)wall_clock64())
+#else
+#define VIO_TIMERS 0
+#define VIO_CLOCK() 0LL
+#endif
 #include <cstddef>
 #include <stdint.h>
 #include "../../include/vio_abi.h"
@@ -38,6 +48,7 @@ struct DevCfg {
     int lvl_w[4], lvl_h[4], lvl_off[4];  // pyramid levels >= 1 packed in one buffer
     int pyr_bytes;
     int MX;             // marg_exact: largest marginalised block (15 + landmarks starting in frame 0) the scratch margE is sized for (0 = off)
+    int MXL;            // marg_exact: largest block whose eigen-decomposition runs LDS-resident (Householder + implicit QL); larger ones use the HBM Jacobi
 };
 
 // IntegrationBase (integration_base.h)
