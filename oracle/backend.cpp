@@ -1384,16 +1384,42 @@ void marg_finish(Estimator &e, Mat &A, std::vector<double> &b, int m, int n) {
     // Amm^-1 via symmetric eigen-decomposition with truncation
     Mat Amm(m, m);
     for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) Amm(i, j) = 0.5 * (A(i, j) + A(j, i));
-    std::vector<double> w;
-    Mat V;
-    sym_eig(Amm, w, V);
     Mat Ainv(m, m);
-    for (int i = 0; i < m; i++)
-        for (int j = 0; j < m; j++) {
-            double s = 0;
-            for (int k = 0; k < m; k++) if (w[k] > eps) s += V(i, k) * V(j, k) / w[k];
-            Ainv(i, j) = s;
+    bool direct = false;
+    if ((e.deviations & ODEV_CHOL_PINV) && m <= 16) {
+        // attribution experiment: A^-1 = L^-T L^-1 from a Cholesky factorisation, accepted when 1 / |A^-1|_F > 1e-6 (then no eigenvalue is
+        // anywhere near the 1e-8 cut and the pseudo-inverse is the inverse)
+        Mat L = Amm;
+        if (chol(L)) {
+            Mat Li(m, m);
+            for (int c0 = 0; c0 < m; c0++)
+                for (int i = 0; i < m; i++) {
+                    double sacc = (i == c0) ? 1.0 : 0.0;
+                    for (int k = c0; k < i; k++) sacc -= L(i, k) * Li(k, c0);
+                    Li(i, c0) = i < c0 ? 0.0 : sacc / L(i, i);
+                }
+            double fro = 0;
+            for (int i = 0; i < m; i++)
+                for (int j = 0; j < m; j++) {
+                    double sacc = 0;
+                    for (int k = (i > j ? i : j); k < m; k++) sacc += Li(k, i) * Li(k, j);
+                    Ainv(i, j) = sacc;
+                    fro += sacc * sacc;
+                }
+            direct = std::isfinite(fro) && fro > 0.0 && 1.0 / std::sqrt(fro) > 1e-6;
         }
+    }
+    if (!direct) {
+        std::vector<double> w;
+        Mat V;
+        sym_eig(Amm, w, V);
+        for (int i = 0; i < m; i++)
+            for (int j = 0; j < m; j++) {
+                double s = 0;
+                for (int k = 0; k < m; k++) if (w[k] > eps) s += V(i, k) * V(j, k) / w[k];
+                Ainv(i, j) = s;
+            }
+    }
     // Arm * Amm_inv
     Mat T1(n, m);
     for (int i = 0; i < n; i++)

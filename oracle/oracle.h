@@ -316,6 +316,9 @@ enum {
     ODEV_LANDMARK_ELIM = 4,     // deviation 10: landmarks of the marginalised block eliminated analytically (1/d), eigen pseudo-inverse of the
                                 //               remaining 15x15 (6x6) block only (marginalization_factor.cpp:281-291)
     ODEV_PAIR_PROJECTION = 8,   // deviation 11: projection residual / Jacobians through the frame-pair matrices A1 = ric^T Rj^T, A2 = A1 Ri, M = A2 ric
+    ODEV_CHOL_PINV = 16,        // (part of deviation 10) the pseudo-inverse of the 15x15 / 6x6 block that remains after the analytic landmark elimination
+                                //               is the Cholesky inverse whenever that proves every eigenvalue above 1e-6 (lambda_min >= 1 / |A^-1|_F), so
+                                //               nothing would be truncated; only otherwise the eigen-decomposition decides (be_linalg.h spd_inverse_wave16)
 };
 extern int oracle_deviations;   // the mask of the most recently constructed Estimator (the free factor functions read it)
 

@@ -50,9 +50,11 @@ VARIANTS = {   # name -> (library under oracle/, tracker lag)
     "dev10": ("liboracle.so", 0, {"OVIO_DEVIATIONS": "4"}),
     "dev11": ("liboracle.so", 0, {"OVIO_DEVIATIONS": "8"}),
     "devall": ("liboracle.so", 0, {"OVIO_DEVIATIONS": "15"}),
+    "dev10c": ("liboracle.so", 0, {"OVIO_DEVIATIONS": "20"}),     # analytic landmark elimination + Cholesky inverse of the remaining block (oracle.h ODEV_CHOL_PINV)
+    "devallc": ("liboracle.so", 0, {"OVIO_DEVIATIONS": "31"}),    # every formulation of the HIP path
     "devall_lag1": ("liboracle.so", 1, {"OVIO_DEVIATIONS": "15"}),
 }
-DEV_NAMES = ("dev8", "dev13", "dev10", "dev11", "devall")
+DEV_NAMES = ("dev8", "dev13", "dev10", "dev11", "devall", "dev10c", "devallc")
 
 
 def run_variants(seq, n_frames, names, cfg_kw=None):
@@ -264,8 +266,16 @@ def cmd_attribution(a):
     rep = dict(what="the oracle against itself with the HIP path's equivalent formulations switched on (OVIO_DEVIATIONS, oracle/oracle.h ODEV_*), "
                     "%d frames, sequences %d..%d, tracker lag 0" % (a.frames, ctl[0], ctl[-1]),
                variants={k: VARIANTS[k][2] for k in DEV_NAMES}, base_bit_identical_to_lag0_fixture_sequences=nfx, pairs={})
+    for x in [d for d in a.extra.split(",") if d]:   # scratch directories of later --only passes (more variants of the same sequences)
+        for f in sorted(os.listdir(x)):
+            if f.startswith("seq_") and f.endswith(".npz") and ".tmp" not in f and int(f[4:9]) in Z:
+                zx = np.load(os.path.join(x, f))
+                for k in zx.files:
+                    if k not in ("gt", "gt_frames", "names"):
+                        Z[int(f[4:9])][k] = zx[k]
     names = [nm for nm in DEV_NAMES if all(nm + "_pos" in Z[s] for s in ctl)]
-    for na, nb in [("base", nm) for nm in names] + [("devall", nm) for nm in names if nm != "devall"]:
+    top = "devallc" if "devallc" in names else "devall"
+    for na, nb in [("base", nm) for nm in names] + [(top, nm) for nm in names if nm != top]:
         rows = [pair_rows(Z[s], Z[s], na, nb, s) for s in ctl]
         e30 = np.array([early_rows(Z[s], na, nb) for s in ctl])
         sm = summarise(rows)

@@ -114,7 +114,7 @@ def compare(hist, orc, seq0, times):
         sep = np.nonzero(dist > 1e-6)[0]
         rows.append(dict(sequence=seq0 + i, frames=int(n), same_frames=bool(same_frames), oracle_reboots=reb,
                          ate_oracle_m=vio_ct.ate_rmse(po[:n], gt[:n]), ate_hip_m=vio_ct.ate_rmse(h[:n, 1:4], gt[:n]),
-                         max_distance_m=float(dist.max()), final_distance_m=float(dist[-1]),
+                         max_distance_m=float(dist.max()), final_distance_m=float(dist[-1]), early30_max_distance_m=float(dist[:30].max()),
                          first_frame_beyond_1um=(int(fr[sep[0]]) if len(sep) else None)))
     return rows
 
@@ -122,8 +122,12 @@ def compare(hist, orc, seq0, times):
 def summarise(rows):
     ao = np.array([r["ate_oracle_m"] for r in rows]); ah = np.array([r["ate_hip_m"] for r in rows])
     md = np.array([r["max_distance_m"] for r in rows])
+    e30 = np.array([r.get("early30_max_distance_m", np.nan) for r in rows])
+    fs = [r["first_frame_beyond_1um"] for r in rows if r["first_frame_beyond_1um"] is not None]
     diff = ah - ao
-    return dict(sequences=len(rows), mean_ate_oracle_m=float(ao.mean()), mean_ate_hip_m=float(ah.mean()),
+    return dict(sequences=len(rows), early30_max_distance_m=dict(median=float(np.median(e30)), p90=float(np.percentile(e30, 90)), max=float(e30.max()),
+                                                                 below_1e_11=int((e30 <= 1e-11).sum()), below_1e_9=int((e30 <= 1e-9).sum())),
+                median_first_frame_beyond_1um=(float(np.median(fs)) if fs else None), mean_ate_oracle_m=float(ao.mean()), mean_ate_hip_m=float(ah.mean()),
                 rel_diff_of_means=float(abs(ah.mean() - ao.mean()) / ao.mean()), signed_rel_diff_of_means=float((ah.mean() - ao.mean()) / ao.mean()),
                 standard_error_of_mean_diff_m=float(diff.std(ddof=1) / np.sqrt(len(diff))) if len(diff) > 1 else None,
                 standard_error_rel=float(diff.std(ddof=1) / np.sqrt(len(diff)) / ao.mean()) if len(diff) > 1 else None,
@@ -132,7 +136,9 @@ def summarise(rows):
                 identical_to_1um=int((md <= 1e-6).sum()))
 
 
-def run(P, S=128, seq0=700, n_frames=300, lag=0, modes=("fast", "exact"), procs=None, cfg_kw=None):
+def run(P, S=128, seq0=700, n_frames=300, lag=0, modes=("fast", "exact"), procs=None, cfg_kw=None, oracle_devs=(0,)):
+    """oracle_devs: OVIO_DEVIATIONS masks of the oracle runs to compare with (0 = the reference's formulation; 15 = every equivalent
+    formulation the HIP path uses switched on, oracle/oracle.h ODEV_*: the attribution experiment of round 5)"""
     import vio_ct
     cfg_kw = dict(cfg_kw or {})
     cfg0 = P.canonical_config(**cfg_kw)
@@ -145,13 +151,22 @@ def run(P, S=128, seq0=700, n_frames=300, lag=0, modes=("fast", "exact"), procs=
         hist, stats, t_feed = run_hip(P, cfg, sc, seq0, S, n_frames, lag=lag, check_render=(mode == modes[0]))
         hip[mode] = (hist, stats, t_feed)
     c0 = time.perf_counter()
-    orc = run_oracle_pool(range(seq0, seq0 + S), n_frames, lag=lag, cfg_kw=cfg_kw, procs=procs)
+    for dv in oracle_devs:
+        if dv:
+            os.environ["OVIO_DEVIATIONS"] = str(int(dv))     # inherited by the spawned oracle processes
+        else:
+            os.environ.pop("OVIO_DEVIATIONS", None)
+        try:
+            orc = run_oracle_pool(range(seq0, seq0 + S), n_frames, lag=lag, cfg_kw=cfg_kw, procs=procs)
+        finally:
+            os.environ.pop("OVIO_DEVIATIONS", None)
+        for mode in modes:
+            hist, stats, t_feed = hip[mode]
+            rows = compare(hist, orc, seq0, times)
+            out["modes"][mode if not dv else "%s_vs_oracle_dev%d" % (mode, dv)] = dict(
+                summary=summarise(rows), hip_feed_wall_s=t_feed, hip_frames_per_s=S * n_frames / t_feed,
+                hip_reboots=int(sum(st.reboot_count for st in stats)), oracle_deviations=int(dv), rows=rows)
     out["oracle_wall_s"] = time.perf_counter() - c0
-    for mode in modes:
-        hist, stats, t_feed = hip[mode]
-        rows = compare(hist, orc, seq0, times)
-        out["modes"][mode] = dict(summary=summarise(rows), hip_feed_wall_s=t_feed, hip_frames_per_s=S * n_frames / t_feed,
-                                  hip_reboots=int(sum(st.reboot_count for st in stats)), rows=rows)
     if "fast" in hip and "exact" in hip:
         # the two HIP modes against each other: where deviations 10 / 13 alone move the trajectory
         d = [float(np.linalg.norm(a[:min(len(a), len(b_)), 1:4] - b_[:min(len(a), len(b_)), 1:4], axis=1).max()) for a, b_ in zip(hip["fast"][0], hip["exact"][0])]
@@ -167,11 +182,12 @@ def main():
     ap.add_argument("--lag", type=int, default=0)
     ap.add_argument("--modes", default="fast,exact")
     ap.add_argument("--procs", type=int, default=0)
+    ap.add_argument("--oracle-devs", default="0", help="comma separated OVIO_DEVIATIONS masks of the oracle runs (0 = reference formulation, 15 = all HIP formulations)")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "gpurun_out", "parity_300_s128.json"))
     a = ap.parse_args()
     import vio_ct
     P = vio_ct.pkg()
-    rep = run(P, a.seqs, a.seq0, a.frames, a.lag, tuple(a.modes.split(",")), a.procs or None)
+    rep = run(P, a.seqs, a.seq0, a.frames, a.lag, tuple(a.modes.split(",")), a.procs or None, oracle_devs=tuple(int(x) for x in a.oracle_devs.split(",")))
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(rep, open(a.out, "w"), indent=1)
     for m, v in rep["modes"].items():

@@ -58,7 +58,7 @@ def _run_both(P, cfg, sc, seq, n_frames, frames):
     return o, lm_o, b, traj[0], stat[0], lm_h
 
 
-def _compare(o, lm_o, traj, stat, lm_h, n_frames, pos_tol, depth_tol=1e-6):
+def _compare(o, lm_o, traj, stat, lm_h, n_frames, pos_tol, depth_tol=1e-6, exact_frames=30):
     """tables equal every frame; returns (bounded landmark-solves counted from the HIP tables, worst relative depth difference)"""
     worst, n_tri, bounded_h = 0.0, 0, 0
     for f in range(n_frames):
@@ -73,7 +73,14 @@ def _compare(o, lm_o, traj, stat, lm_h, n_frames, pos_tol, depth_tol=1e-6):
         if len(a) == 0:
             continue
         assert np.array_equal(a[:, [0, 1, 2, 4, 5, 6]], h[:, [0, 1, 2, 4, 5, 6]]), f   # id, start, n_obs, estimate_flag, solve_flag, is_dynamic
-        assert np.array_equal(a[:, 7:12], h[:, 7:12]), f
+        # first observation (x, y, z), its depth, the last depth.  Identical while the trackers are (the first ~25 frames after the static
+        # start, test_gpu_pipeline.py); later a tracked position may differ in its last float digits (LK stops at 0.01 px), which moves a
+        # normalised coordinate by ~1e-6 and, at a depth edge, the depth pixel it reads
+        if f < exact_frames:
+            assert np.array_equal(a[:, 7:12], h[:, 7:12]), f
+        else:
+            assert np.abs(a[:, 7:10] - h[:, 7:10]).max() < 2e-5, f
+            assert (np.abs(a[:, 10:12] - h[:, 10:12]) > 1e-9).mean() < 0.02, f
         have = a[:, 3] > 0
         assert np.array_equal(have, h[:, 3] > 0), f
         if have.any():

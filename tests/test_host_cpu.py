@@ -170,3 +170,36 @@ def test_cpp_mirror_compiles_and_links(P, tmp_path):
                         "-L" + pk, "-lvio_hip", "-Wl,-rpath," + pk, "-o", exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert os.path.exists(exe)
+
+
+def test_pose_graph_optimisers_are_host_code_with_envelope_normal_equations(P):
+    """vio_pg_optimize4dof / 6dof need no GPU.  (a) against the oracle's dense restatement on the drift circuits of the pose_graph tests
+    (1e-6, as the GPU-box test asserts); (b) the normal equations are kept in envelope form since round 5 (dense (4n)^2 /
+    (6n)^2 matrices were 3 GB and minutes per solve at 3000 keyframes): a 3000-keyframe circuit with a handful of loop edges solves in
+    seconds, and moves towards the truth."""
+    import importlib
+    import time
+    import test_oracle_posegraph_cpu as O
+    PG = importlib.import_module("vins-rgbd-fast_amd.posegraph")
+    t_true, R_true, t_vio, R_vio, seq, loop_to, info = O._drift_graph()
+    to_h, Ro_h, (yd_h, td_h) = PG.optimize4DoF(t_vio, R_vio, seq, loop_to, info)
+    to_o, Ro_o, dr_o = O.o_optimize4dof(t_vio, R_vio, seq, loop_to, info)
+    assert np.abs(to_h - to_o).max() < 1e-6 and np.abs(Ro_h - Ro_o).max() < 1e-7 and abs(yd_h - dr_o[0]) < 1e-6
+    t_true, R_true, t_vio, R_vio, seq, loop_to, info = O._drift_graph6()
+    to_h, Ro_h, _ = PG.optimize6DoF(t_vio, R_vio, seq, loop_to, info)
+    to_o, Ro_o, _ = O.o_optimize6dof(t_vio, R_vio, seq, loop_to, info)
+    assert np.abs(to_h - to_o).max() < 1e-6 and np.abs(Ro_h - Ro_o).max() < 1e-7
+    # a long run: 3000 keyframes, loop edges every 500 keyframes back to the start of the lap
+    t_true, R_true, t_vio, R_vio, seq, loop_to, info = O._drift_graph(n=3000)
+    yaw = lambda R: np.degrees(np.arctan2(R[1, 0], R[0, 0]))
+    for i in range(600, 3000, 500):
+        c = i - 550
+        info[i, :3] = R_true[c].T @ (t_true[i] - t_true[c])
+        info[i, 7] = ((yaw(R_true[i]) - yaw(R_true[c]) + 180) % 360) - 180
+        loop_to[i] = c
+    t0 = time.time()
+    to_h, _, _ = PG.optimize4DoF(t_vio, R_vio, seq, loop_to, info)
+    el = time.time() - t0
+    e0, e1 = np.linalg.norm(t_vio - t_true, axis=1), np.linalg.norm(to_h - t_true, axis=1)
+    assert el < 20.0, el
+    assert e1[-1] < 0.6 * e0[-1], (e0[-1], e1[-1])

@@ -2132,6 +2132,7 @@ __device__ void marg_exact_finish(const Ctx &c, BeSeq &be, double *A, const doub
     int sw1 = 0, sw2 = 0;
     double *Ar = c.margV, *br = c.vec;
     double *Al = (double *)marg_dyn_lds;
+    const long long tx0 = VIO_CLOCK();   // (timers build only: dbg[7..10] = ticks to the end of eig 1 / the Schur products / eig 2 / the prior; tools/marg_exact_probe.py)
     for (int pass = 0; pass < 2; pass++) {
         const int nn = pass == 0 ? m : n, ld = nn | 1;
         const bool in_lds = nn <= c.C->MXL;
@@ -2141,6 +2142,7 @@ __device__ void marg_exact_finish(const Ctx &c, BeSeq &be, double *A, const doub
             else for (int w = t; w < n * n; w += nt) { const int i = w / n, j = w - i * n; Al[i * ld + j] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
             __syncthreads();
             sym_eig_lds(Al, nn, ld, aux);   // SelfAdjointEigenSolver<MatrixXd> saes(Amm) (:281) / saes2(A) (:298)
+            if (VIO_TIMERS && t == 0) be.dbg[pass == 0 ? 7 : 9] = (int)(VIO_CLOCK() - tx0);
         }
         if (pass == 0) {
             if (in_lds) {
@@ -2188,6 +2190,7 @@ __device__ void marg_exact_finish(const Ctx &c, BeSeq &be, double *A, const doub
                 br[i] = sacc;
             }
             __syncthreads();
+            if (VIO_TIMERS && t == 0) be.dbg[8] = (int)(VIO_CLOCK() - tx0);
             continue;
         }
         // second eigen-decomposition (:298-311): S = eigenvalues > eps, linearized_jacobians = S^1/2 V^T, linearized_residuals = S^-1/2 V^T b
@@ -2256,6 +2259,7 @@ __device__ void marg_exact_finish(const Ctx &c, BeSeq &be, double *A, const doub
     const double c0 = block_sum(acc, sred);
     __syncthreads();
     if (t == 0) { be.prior_c0 = c0; be.dbg[0] = sw1 * 100 + sw2; be.dbg[2] = second_new ? 1 : 0; be.dbg[4] = m; }
+    if (VIO_TIMERS && t == 0) be.dbg[10] = (int)(VIO_CLOCK() - tx0);
 }
 
 template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scratch, double *sred, unsigned char *smem_marg) {

@@ -659,6 +659,125 @@ __device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int blk, in
     }
 }
 
+// Round 5: the same sums organised by BLOCK PAIRS of the tangent space instead of by entries.  The per-entry version above spends ~330 vector
+// instructions per entry on finding out which prior / IMU / frame-pair blocks contain it (9.9 M VALU instructions per launch,
+// profiles/round4_pmc_sq.json) -- 55 % of the solver's thread-time at large batches.  Here one wavefront takes one pair of parameter blocks
+// (pose k: 6 columns, speed-bias k: 9, extrinsic: 6, td: 1; lower triangle + one gradient item per block = 324 items at W = 10): which sources
+// contribute is decided once per item on the scalar unit, a lane only adds (row, column) within the block, and the upper triangle is written
+// as the mirror image.  Same terms in the same order as ps_asm_b_body, hence the same H and g.
+__device__ __forceinline__ void ps_tblock(int q, int W1, int &off, int &sz, int &kind, int &frame) {
+    if (q < W1) { off = 6 * q; sz = 6; kind = 0; frame = q; }
+    else if (q < 2 * W1) { off = 6 * W1 + 9 * (q - W1); sz = 9; kind = 1; frame = q - W1; }
+    else if (q == 2 * W1) { off = 15 * W1; sz = 6; kind = 2; frame = -1; }
+    else { off = 15 * W1 + 6; sz = 1; kind = 3; frame = -1; }
+}
+__device__ __forceinline__ void ps_asm_b_blocks(const Batch &B, int s, int blk, int nb_b) {
+    const SolveSt &st = B.sst[s];
+    if (st.stage != PS_ASM) return;
+    Ctx c = make_ctx(B, s);
+    const BeSeq &be = *c.be;
+    const int W = c.W, W1 = W + 1, P = c.P, LW = c.LW, n = c.NPR;
+    const bool vext = st.vext != 0, relo = st.relo != 0, has_prior = be.has_prior != 0;
+    const double *pb = c.pairblk, *ib = ps_imu_blk(c);
+    const int oE = 15 * W1, oT = oE + 6;
+    const int NBLK = 2 * W1 + 2, NTRI = NBLK * (NBLK + 1) / 2, NITEM = NTRI + NBLK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    // IMU factors that exist (estimator.cpp:1212-1220 skips pre-integrations longer than 10 s): one lane per factor, then a mask
+    const bool f_ok = lane < W && c.C->c.use_imu && !(c.pre[be.pre_idx[min(lane, W - 1) + 1]].sum_dt > 10.0);
+    const unsigned imu_ok = (unsigned)__ballot(f_ok);
+    const bool scale_pending = st.scale_pending != 0;
+    for (int item0 = blk * nw + wave; item0 < NITEM; item0 += nb_b * nw) {
+        const int item = __builtin_amdgcn_readfirstlane(item0);
+        const bool grad = item >= NTRI;
+        int br, bc;
+        if (grad) { br = item - NTRI; bc = 0; } else tri_decode(item, br, bc);   // br >= bc
+        int ro, rs, kr, fr, co, cs, kc, fc;
+        ps_tblock(br, W1, ro, rs, kr, fr);
+        ps_tblock(bc, W1, co, cs, kc, fc);
+        if (grad) { cs = 1; kc = 4; fc = -1; }
+        // prior (relocalisation solve: the extrinsic's columns belong to relo_Pose, which the prior knows nothing about)
+        auto prior_base = [&](int kind, int f) -> int {
+            if (kind == 0) return f < W ? 6 * f : -1;
+            if (kind == 1) return f == 0 ? 6 * W : -1;
+            if (kind == 2) return relo ? -1 : 6 * W + 9;
+            return 6 * W + 15;
+        };
+        const int pr = has_prior ? prior_base(kr, fr) : -1, pc = grad ? 0 : (has_prior ? prior_base(kc, fc) : -1);
+        // IMU factors that contain both blocks, even factors first (the order assemble() adds them in)
+        // (of the two factors fr - 1 and fr that touch frame fr one is even, one odd: two fixed slots in that order, no indexed arrays)
+        const int fi0 = (fr & 1) ? fr - 1 : fr, fi1 = (fr & 1) ? fr : fr - 1;
+        auto imu_slot = [&](int i, int &la0, int &lb0) -> bool {
+            if (!(kr <= 1 && (grad || kc <= 1)) || i < 0 || i >= W || !((imu_ok >> i) & 1u)) return false;
+            lb0 = 30;
+            if (!grad) { if (fc != i && fc != i + 1) return false; lb0 = (kc == 0 ? 0 : 6) + (fc == i ? 0 : 15); }
+            la0 = (kr == 0 ? 0 : 6) + (fr == i ? 0 : 15);
+            return true;
+        };
+        int la_0 = 0, lb_0 = 0, la_1 = 0, lb_1 = 0;
+        const bool imu0 = imu_slot(fi0, la_0, lb_0), imu1 = imu_slot(fi1, la_1, lb_1);
+        auto imu_get = [&](int i, int la, int lb) -> double {   // Gram entry (la, lb) of factor i, la, lb in 0 .. 30 (30 = residual column)
+            const double *G = ib + (size_t)i * 768;
+            if (la < lb) { const int x = la; la = lb; lb = x; }
+            return la < 16 ? G[la * 16 + lb] : (lb < 16 ? G[256 + (la - 16) * 16 + lb] : G[512 + (la - 16) * 16 + (lb - 16)]);
+        };
+        // vision: 0 none, 1 one frame pair, 2 one term per other frame of the window, 3 every frame pair
+        const bool vr = kr == 0 || (vext && kr >= 2), vc = grad || kc == 0 || (vext && (kc == 2 || kc == 3));
+        int vmode = 0, vf = -1;
+        if (vr && vc) {
+            if (!grad && kr == 0 && kc == 0 && fr != fc) vmode = 1;
+            else if (kr == 0 || kc == 0) { vmode = 2; vf = kr == 0 ? fr : fc; }
+            else vmode = 3;
+        }
+        const int la_fix = kr == 2 ? 12 : 18, lb_fix = grad ? 19 : (kc == 2 ? 12 : 18);   // local column of a non-pose block in any frame pair
+        for (int e = lane; e < rs * cs; e += 64) {
+            const int r = cs == 6 ? e / 6 : (cs == 9 ? e / 9 : e), cc = e - r * cs, a = ro + r, b = co + cc;   // (constant divisors)
+            double v = 0;
+            if (pr >= 0 && pc >= 0) v = grad ? st.srp[pr + r] : c.prior_H[(pr + r) * n + pc + cc];
+            if (imu0) v += imu_get(fi0, la_0 + r, lb_0 + (grad ? 0 : cc));
+            if (imu1) v += imu_get(fi1, la_1 + r, lb_1 + (grad ? 0 : cc));
+            if (vmode == 1) {
+                const int i = min(fr, fc), j = max(fr, fc);
+                v += pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx((fr == i ? 0 : 6) + r, (fc == i ? 0 : 6) + cc)];
+            } else if (vmode == 2) {
+                // one term per other frame of the window: all loads issued first, then summed in frame order
+                double pv[VIO_MAXW + 1];
+#pragma unroll
+                for (int o = 0; o <= VIO_MAXW; o++) {
+                    const bool use = o < W1 && o != vf;
+                    const int oo = use ? o : (vf == 0 ? 1 : 0);     // unused slots read a term that exists (and drop it)
+                    const int i = min(vf, oo), j = max(vf, oo), lf = vf == i ? 0 : 6;
+                    const int la = (kr == 0 ? lf : la_fix) + r, lb = (grad ? 19 : (kc == 0 ? lf : lb_fix) + cc);
+                    pv[o] = pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(la, lb)];
+                }
+                double sacc = 0;
+#pragma unroll
+                for (int o = 0; o <= VIO_MAXW; o++) if (o < W1 && o != vf) sacc += pv[o];
+                v += sacc;
+            } else if (vmode == 3) {
+                double sacc = 0;
+                const int li = sym_idx(la_fix + r, lb_fix + (grad ? 0 : cc));
+                for (int q = 0; q < W1 * W / 2; q++) sacc += pb[(size_t)q * 210 + li];   // pair slots in (i, j) order
+                v += sacc;
+            }
+            if (grad) c.vec[a] = v;
+            else {
+                c.H[(size_t)a * LW + b] = v;
+                if (br != bc) c.H[(size_t)b * LW + a] = v;
+                else if (a == b && scale_pending) {
+                    bool act = a < oE ? true : (a < oT ? st.ex_active != 0 : st.td_active != 0);
+                    if (!c.C->c.use_imu && (a < 6 || a >= 6 * W1)) act = false;   // VO mode: pose 0 constant, no speed-bias blocks
+                    c.vec[1 * LW + a] = act ? 1.0 / (1.0 + sqrt(v)) : 0.0;   // sp
+                }
+            }
+        }
+    }
+    // padding: columns P .. LW - 1 of H, g / sp beyond P
+    if (blk == 0) {
+        for (int w = threadIdx.x; w < P * (LW - P); w += blockDim.x) { const int a = w / (LW - P), b = P + (w - a * (LW - P)); c.H[(size_t)a * LW + b] = 0; }
+        for (int a = P + threadIdx.x; a < LW; a += blockDim.x) { c.vec[a] = 0; if (scale_pending) c.vec[1 * LW + a] = 0; }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- SCHUR
 // grid (active tiles, S), 64 threads: one wavefront forms one 16 x 16 lower tile of S = S_p H S_p + mu D^2 - sum_k w_k h_k h_k^T
 // over all landmark rows, operands straight from HBM / L2 in batches of 8 k-steps, into c.Sc in the LDS tile layout.
@@ -727,11 +846,11 @@ __device__ __forceinline__ void ps_schur_body(const Batch &B, int s, int tile_in
 
 // one launch: blocks [0, nb_b) sum the entries of H and the gradient, the blocks behind them form the landmark part of the
 // Schur complement tile by tile
-__global__ __launch_bounds__(256) void ps_asm_b_schur_kernel(Batch B, int nb_b) {
+__global__ __launch_bounds__(256) void ps_asm_b_schur_kernel(Batch B, int nb_b, int by_blocks) {
     int s, b;
     if (!ps_blk(B, s, b)) return;
     extern __shared__ double ps_wk_s[];
-    if (b < nb_b) ps_asm_b_body(B, s, b, nb_b);
+    if (b < nb_b) { if (by_blocks) ps_asm_b_blocks(B, s, b, nb_b); else ps_asm_b_body(B, s, b, nb_b); }
     else ps_schur_body(B, s, b - nb_b, ps_wk_s);
 }
 

@@ -145,7 +145,7 @@ __device__ dm::m3 predict_motion(const Batch &B, int s, double t0, double t1) {
         double ang = dm::nrm(aa);
         dm::m3 Rk = dm::eye();
         if (ang > 0) {
-            dm::v3 ax = dm::scl(1.0 / ang, aa);
+            dm::v3 ax = dm::mk(aa.x / ang, aa.y / ang, aa.z / ang);   // angle_axis.normalized(): a division per coefficient (Eigen 3.3), like the oracle
             double sn, cs;
             dm::sincos_det(ang, &sn, &cs);   // same bits as the CPU restatement (dmath.h)
             dm::m3 K = dm::skew(ax);
@@ -214,7 +214,7 @@ __device__ dm::m3 predict_motion_wave(const Batch &B, int s, double t0, double t
             const double ang = dm::nrm(aa);
             dm::m3 Rk = dm::eye();
             if (ang > 0) {
-                const dm::v3 ax = dm::scl(1.0 / ang, aa);
+                const dm::v3 ax = dm::mk(aa.x / ang, aa.y / ang, aa.z / ang);
                 double sn, cs;
                 dm::sincos_det(ang, &sn, &cs);
                 const dm::m3 K = dm::skew(ax);

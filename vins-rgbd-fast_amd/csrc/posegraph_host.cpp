@@ -84,23 +84,78 @@ double total_cost(const std::vector<Link> &links, const std::vector<double> &yaw
     return c;
 }
 
-// symmetric positive definite solve, in place lower Cholesky of the packed row-major square; false if a pivot is not positive
-bool spd_solve(std::vector<double> &A, std::vector<double> &x, int n) {
-    for (int j = 0; j < n; j++) {
-        double d = A[(size_t)j * n + j];
-        for (int k = 0; k < j; k++) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
-        if (!(d > 0.0) || !isfinite(d)) return false;
-        const double l = sqrt(d);
-        A[(size_t)j * n + j] = l;
-        for (int i = j + 1; i < n; i++) {
-            double v = A[(size_t)i * n + j];
-            for (int k = 0; k < j; k++) v -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
-            A[(size_t)i * n + j] = v / l;
+// The normal equations of a pose graph are banded -- a node meets its four predecessors -- plus one long row per loop edge (the reference hands the
+// problem to SPARSE_NORMAL_CHOLESKY, pose_graph.cpp:421).  They are kept in ENVELOPE form: row i of the lower triangle from its first structural
+// non-zero first[i] to the diagonal.  A Cholesky factor has the envelope of its matrix, so the factorisation costs O(sum of len_i * band) and the
+// storage O(n * band + loop spans) instead of the dense n^3 / n^2 (3000 keyframes were 3 GB and minutes per solve).  Every sum runs over
+// the same terms in the same order as the dense row-oriented Cholesky minus its exact zeros: the factor has the same bits.
+struct SkyMat {
+    int n = 0;
+    std::vector<int> first;        // first stored column of row i
+    std::vector<size_t> off;       // v[off[i] + (j - first[i])] = A(i, j), first[i] <= j <= i
+    std::vector<double> v;
+    void init(const std::vector<int> &first_col) {
+        n = (int)first_col.size();
+        first = first_col;
+        off.resize(n + 1);
+        off[0] = 0;
+        for (int i = 0; i < n; i++) off[i + 1] = off[i] + (size_t)(i - first[i] + 1);
+        v.assign(off[n], 0.0);
+    }
+    double &at(int i, int j) { return v[off[i] + (size_t)(j - first[i])]; }          // i >= j >= first[i]
+    double get(int i, int j) const { if (i < j) { int q = i; i = j; j = q; } return j < first[i] ? 0.0 : v[off[i] + (size_t)(j - first[i])]; }
+    void add_sym(int r, int c, double x) { if (r >= c) at(r, c) += x; }               // callers visit (r, c) and (c, r): the lower one is kept
+    void matvec(const std::vector<double> &x, std::vector<double> &y) const {
+        y.assign(n, 0.0);
+        for (int i = 0; i < n; i++) {
+            const double *row = &v[off[i]];
+            double acc = 0;
+            for (int j = first[i]; j < i; j++) { acc += row[j - first[i]] * x[j]; y[j] += row[j - first[i]] * x[i]; }
+            y[i] += acc + row[i - first[i]] * x[i];
         }
     }
-    for (int i = 0; i < n; i++) { double v = x[i]; for (int k = 0; k < i; k++) v -= A[(size_t)i * n + k] * x[k]; x[i] = v / A[(size_t)i * n + i]; }
-    for (int i = n - 1; i >= 0; i--) { double v = x[i]; for (int k = i + 1; k < n; k++) v -= A[(size_t)k * n + i] * x[k]; x[i] = v / A[(size_t)i * n + i]; }
-    return true;
+    // in-place L L^T and the solve of L L^T x = b; false if a pivot is not positive
+    bool chol_solve(std::vector<double> &x) {
+        for (int i = 0; i < n; i++) {
+            double *ri = &v[off[i]];
+            const int fi = first[i];
+            for (int j = fi; j < i; j++) {
+                const double *rj = &v[off[j]];
+                const int fj = first[j], k0 = fi > fj ? fi : fj;
+                double acc = ri[j - fi];
+                for (int k = k0; k < j; k++) acc -= ri[k - fi] * rj[k - fj];
+                ri[j - fi] = acc / rj[j - fj];
+            }
+            double d = ri[i - fi];
+            for (int k = fi; k < i; k++) d -= ri[k - fi] * ri[k - fi];
+            if (!(d > 0.0) || !isfinite(d)) return false;
+            ri[i - fi] = sqrt(d);
+        }
+        for (int i = 0; i < n; i++) {
+            const double *ri = &v[off[i]];
+            double acc = x[i];
+            for (int k = first[i]; k < i; k++) acc -= ri[k - first[i]] * x[k];
+            x[i] = acc / ri[i - first[i]];
+        }
+        for (int i = n - 1; i >= 0; i--) {
+            const double *ri = &v[off[i]];
+            x[i] /= ri[i - first[i]];
+            for (int k = first[i]; k < i; k++) x[k] -= ri[k - first[i]] * x[i];
+        }
+        return true;
+    }
+};
+// envelope of the normal equations: a row of node b's block starts at the first column of the lowest-slot node b shares an edge with
+template <class L> std::vector<int> envelope_of(const std::vector<L> &links, const std::vector<int> &slot, int nvar, int dof) {
+    std::vector<int> first(nvar);
+    for (int a = 0; a < nvar; a++) first[a] = a - a % dof;
+    for (const L &e : links) {
+        const int sa = slot[e.a], sb = slot[e.b];
+        if (sa < 0 || sb < 0) continue;
+        const int lo = sa < sb ? sa : sb, hi = sa < sb ? sb : sa;
+        for (int c = 0; c < dof; c++) if (first[hi + c] > lo) first[hi + c] = lo;
+    }
+    return first;
 }
 
 }  // namespace
@@ -185,10 +240,13 @@ extern "C" int vio_pg_optimize4dof(int n, const double *t, const double *R, cons
         // Levenberg-Marquardt as Ceres runs it by default: (J^T J + diag(J^T J) / radius) step = -J^T r in Jacobi-scaled variables, step quality
         // rho against the quadratic model, radius / max(1/3, 1 - (2 rho - 1)^3) on success, radius / 2, / 4, ... on failure; 5 iterations
         double radius = 1e4, shrink = 2.0, cost = total_cost(links, yaw, pos);
+        const std::vector<int> env = envelope_of(links, slot, nvar, 4);
         std::vector<double> colscale;
         int iterations = 0;
         while (iterations < 5) {
-            std::vector<double> H((size_t)nvar * nvar, 0.0), g(nvar, 0.0);
+            SkyMat H;
+            H.init(env);
+            std::vector<double> g(nvar, 0.0);
             LinkEval ev;
             for (const Link &e : links) {
                 evaluate(e, yaw, pos, ev);
@@ -211,30 +269,28 @@ extern "C" int vio_pg_optimize4dof(int n, const double *t, const double *R, cons
                             for (int c1 = 0; c1 < 4; c1++) {
                                 double hs = 0;
                                 for (int row = 0; row < 4; row++) hs += J(e0, row, c0) * J(e1, row, c1);
-                                H[(size_t)(base[e0] + c0) * nvar + base[e1] + c1] += hs;
+                                H.add_sym(base[e0] + c0, base[e1] + c1, hs);
                             }
                         }
                     }
                 }
             }
-            if (colscale.empty()) { colscale.resize(nvar); for (int a = 0; a < nvar; a++) colscale[a] = 1.0 / (1.0 + sqrt(H[(size_t)a * nvar + a])); }
+            if (colscale.empty()) { colscale.resize(nvar); for (int a = 0; a < nvar; a++) colscale[a] = 1.0 / (1.0 + sqrt(H.at(a, a))); }
             double gmax = 0;
             for (int a = 0; a < nvar; a++) gmax = fmax(gmax, fabs(g[a]));
             if (gmax <= 1e-10) break;
-            std::vector<double> Hs((size_t)nvar * nvar), gsv(nvar);
-            for (int a = 0; a < nvar; a++) { gsv[a] = colscale[a] * g[a]; for (int b = 0; b < nvar; b++) Hs[(size_t)a * nvar + b] = colscale[a] * colscale[b] * H[(size_t)a * nvar + b]; }
+            SkyMat Hs = H;
+            std::vector<double> gsv(nvar), hv;
+            for (int a = 0; a < nvar; a++) { gsv[a] = colscale[a] * g[a]; for (int b = Hs.first[a]; b <= a; b++) Hs.at(a, b) = colscale[a] * colscale[b] * H.at(a, b); }
             bool moved = false;
             while (!moved && iterations < 5) {
-                std::vector<double> A = Hs, step = gsv;
-                for (int a = 0; a < nvar; a++) A[(size_t)a * nvar + a] += fmin(fmax(Hs[(size_t)a * nvar + a], 1e-6), 1e32) / radius;
-                if (!spd_solve(A, step, nvar)) { radius /= shrink; shrink *= 2; iterations++; continue; }
+                SkyMat A = Hs;
+                std::vector<double> step = gsv;
+                for (int a = 0; a < nvar; a++) A.at(a, a) += fmin(fmax(Hs.at(a, a), 1e-6), 1e32) / radius;
+                if (!A.chol_solve(step)) { radius /= shrink; shrink *= 2; iterations++; continue; }
                 double lin = 0, quad = 0;
-                for (int a = 0; a < nvar; a++) {
-                    double hv = 0;
-                    for (int b = 0; b < nvar; b++) hv += Hs[(size_t)a * nvar + b] * step[b];
-                    lin += gsv[a] * step[a];
-                    quad += step[a] * hv;
-                }
+                Hs.matvec(step, hv);
+                for (int a = 0; a < nvar; a++) { lin += gsv[a] * step[a]; quad += step[a] * hv[a]; }
                 const double model = lin - 0.5 * quad;   // decrease predicted for x - step
                 std::vector<double> yc = yaw, pc = pos;
                 for (int i = 0; i < n; i++) {
@@ -361,10 +417,13 @@ extern "C" int vio_pg_optimize6dof(int n, const double *t, const double *R, cons
     }
     if (nvar > 0) {   // the trust-region loop of vio_pg_optimize4dof with six columns per node
         double radius = 1e4, shrink = 2.0, cost = total_cost6(links, q, pos);
+        const std::vector<int> env = envelope_of(links, slot, nvar, 6);
         std::vector<double> colscale;
         int iterations = 0;
         while (iterations < 5) {
-            std::vector<double> H((size_t)nvar * nvar, 0.0), g(nvar, 0.0);
+            SkyMat H;
+            H.init(env);
+            std::vector<double> g(nvar, 0.0);
             Link6Eval ev;
             for (const Link6 &e : links) {
                 evaluate6(e, q, pos, ev, true);
@@ -387,31 +446,29 @@ extern "C" int vio_pg_optimize6dof(int n, const double *t, const double *R, cons
                             for (int c1 = 0; c1 < 6; c1++) {
                                 double hs = 0;
                                 for (int row = 0; row < 6; row++) hs += J(e0, row, c0) * J(e1, row, c1);
-                                H[(size_t)(base[e0] + c0) * nvar + base[e1] + c1] += hs;
+                                H.add_sym(base[e0] + c0, base[e1] + c1, hs);
                             }
                         }
                     }
                 }
             }
-            if (colscale.empty()) { colscale.resize(nvar); for (int a = 0; a < nvar; a++) colscale[a] = 1.0 / (1.0 + sqrt(H[(size_t)a * nvar + a])); }
+            if (colscale.empty()) { colscale.resize(nvar); for (int a = 0; a < nvar; a++) colscale[a] = 1.0 / (1.0 + sqrt(H.at(a, a))); }
             double gmax = 0;
             for (int a = 0; a < nvar; a++) gmax = fmax(gmax, fabs(g[a]));
             if (gmax <= 1e-10) break;
-            std::vector<double> Hs((size_t)nvar * nvar), gsv(nvar);
-            for (int a = 0; a < nvar; a++) { gsv[a] = colscale[a] * g[a]; for (int b = 0; b < nvar; b++) Hs[(size_t)a * nvar + b] = colscale[a] * colscale[b] * H[(size_t)a * nvar + b]; }
+            SkyMat Hs = H;
+            std::vector<double> gsv(nvar), hv;
+            for (int a = 0; a < nvar; a++) { gsv[a] = colscale[a] * g[a]; for (int b = Hs.first[a]; b <= a; b++) Hs.at(a, b) = colscale[a] * colscale[b] * H.at(a, b); }
             bool moved = false;
             int tries = 0;
             while (!moved && tries++ < 20) {
-                std::vector<double> A = Hs, step = gsv;
-                for (int a = 0; a < nvar; a++) A[(size_t)a * nvar + a] += fmin(fmax(Hs[(size_t)a * nvar + a], 1e-6), 1e32) / radius;
-                if (!spd_solve(A, step, nvar)) { radius /= shrink; shrink *= 2; continue; }
+                SkyMat A = Hs;
+                std::vector<double> step = gsv;
+                for (int a = 0; a < nvar; a++) A.at(a, a) += fmin(fmax(Hs.at(a, a), 1e-6), 1e32) / radius;
+                if (!A.chol_solve(step)) { radius /= shrink; shrink *= 2; continue; }
                 double lin = 0, quad = 0;
-                for (int a = 0; a < nvar; a++) {
-                    double hv = 0;
-                    for (int b = 0; b < nvar; b++) hv += Hs[(size_t)a * nvar + b] * step[b];
-                    lin += gsv[a] * step[a];
-                    quad += step[a] * hv;
-                }
+                Hs.matvec(step, hv);
+                for (int a = 0; a < nvar; a++) { lin += gsv[a] * step[a]; quad += step[a] * hv[a]; }
                 const double model = lin - 0.5 * quad;
                 std::vector<quat> qc = q;
                 std::vector<double> pc = pos;

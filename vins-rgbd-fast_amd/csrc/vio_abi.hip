@@ -53,6 +53,7 @@ struct vio_batch {
         hipEvent_t ev_solve = nullptr, ev_fe = nullptr, ev_be = nullptr, ev_ingest = nullptr;
         hipStream_t copy_stream = nullptr;   // host -> HBM uploads of vio_feed (on_device == 0), beside the kernels of the previous frame
         hipGraphExec_t solve_graph = nullptr;   // VIO_GRAPH: setup + iteration slots + final of this group as one graph launch
+        uint64_t solve_graph_key = 0;           // hash of the arguments the capture baked in (Batch by value + launch knobs)
         hipEvent_t ev_up_gray = nullptr, ev_up_depth = nullptr;
         // the staging images of vio_feed are double-buffered: frame n uploads into buffer n & 1 while frame n-1's kernels still read the
         // other one, so an upload only waits for the readers of frame n-2 (ev_rd_gray / ev_rd_depth of its buffer)
@@ -81,6 +82,7 @@ struct vio_batch {
     int fe_xcd_map = 1;               // VIO_FE_XCD_MAP: the same idea for fe_lk (needs the front-end on every XCD: off under a CU partition)
     bool fe_partitioned = false;      // the front-end streams carry a CU mask (VIO_FE_CUS > 0 with tracker lag 1)
     int ps_asm_b_blocks = 24;         // workgroups per sequence that sum the entries of H (VIO_ASM_B_BLOCKS)
+    int asm_b_by_blocks = 1;          // VIO_ASM_B_MODE: 1 (default) = H summed by pairs of parameter blocks (round 5), 0 = one thread per entry
     int serial_threads = 512;         // ps_serial block size (VIO_SERIAL_THREADS: 512 or 1024).  Round 3: equal speed (36.2 k vs 36.4 k frames/s); the 512-thread
                                       // build has 256 VGPRs per lane and no scratch, the 1024-thread one spills 21 registers since the matrix-core diagonal block
     hipStream_t stream = nullptr;     // = groups[0].stream (returned by vio_get_stream; IMU scatter runs here)
@@ -651,7 +653,7 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
                 else ps_eval_kernel<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
                 if (h->asm_a_occ4) ps_asm_a_kernel_occ4<<<g_a, 512, 0, st>>>(Ba);
                 else ps_asm_a_kernel<<<g_a, 512, 0, st>>>(Ba);
-                ps_asm_b_schur_kernel<<<g_b, 256, (size_t)(C.NL + 16 + 3 * 256) * sizeof(double), st>>>(Bb, h->ps_asm_b_blocks);   // per-row factors + the partial tiles of wavefronts 1 .. 3
+                ps_asm_b_schur_kernel<<<g_b, 256, (size_t)(C.NL + 16 + 3 * 256) * sizeof(double), st>>>(Bb, h->ps_asm_b_blocks, h->asm_b_by_blocks);   // per-row factors + the partial tiles of wavefronts 1 .. 3
                 if (h->serial_big) ps_serial_big_kernel<<<S, 512, h->lds_serial, st>>>(Bg);
                 else if (h->serial_threads <= 512) ps_serial_kernel_512<<<S, 512, h->lds_serial, st>>>(Bg);
                 else ps_serial_kernel<<<S, 1024, h->lds_serial, st>>>(Bg);
@@ -659,8 +661,19 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
             ps_final_kernel<<<S, 256, 0, st>>>(Bg);
         };
         // VIO_GRAPH: the 43 launches of one solve replayed as a hipGraph captured on the group's stream at its first use (the kernel
-        // arguments -- the Batch of the group -- do not change from frame to frame; setters that change them drop the graph)
+        // arguments -- the Batch of the group -- normally do not change from frame to frame)
         if (h->use_graph && one_seq < 0) {
+            // the capture bakes in the Batch (by value) and the launch knobs: key it on their bytes, so that any setter that touches h->B
+            // (vio_set_tracker_lag, vio_set_fisheye_mask, ...) or a knob makes the next solve re-capture instead of replaying stale arguments
+            uint64_t key = 1469598103934665603ULL;
+            auto mixin = [&](const void *p, size_t nbytes) { const unsigned char *q = (const unsigned char *)p; for (size_t i = 0; i < nbytes; i++) { key ^= q[i]; key *= 1099511628211ULL; } };
+            mixin(&Bg, sizeof(Bg));
+            const int knobs[12] = {C.c.max_iterations + h->extra_slots, h->eval_occ, h->asm_a_occ4 ? 1 : 0, h->serial_big ? 1 : 0, h->serial_threads, h->ps_eval_blocks, h->ps_asm_a_blocks,
+                                   h->ps_asm_b_blocks + 1000 * h->asm_b_by_blocks, h->ps_schur_tiles, h->xcd_map, h->xcd_n, (int)h->lds_serial};
+            mixin(knobs, sizeof(knobs));
+            mixin(&h->lds_ps_eval, sizeof(h->lds_ps_eval));
+            if (g.solve_graph && g.solve_graph_key != key) { (void)hipGraphExecDestroy(g.solve_graph); g.solve_graph = nullptr; }
+            g.solve_graph_key = key;
             if (!g.solve_graph) {
                 hipGraph_t gr = nullptr;
                 HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -918,6 +931,7 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
     B.s0 = 0;
     B.ns = 0; B.xcd_nb = 0; B.xcd_n = 8;
     if (getenv("VIO_BE_THREADS")) h->be_threads = std::min(1024, std::max(64, atoi(getenv("VIO_BE_THREADS")) & ~63));
+    if (getenv("VIO_ASM_B_MODE")) h->asm_b_by_blocks = atoi(getenv("VIO_ASM_B_MODE")) != 0 ? 1 : 0;
     if (getenv("VIO_ASM_B_BLOCKS")) h->ps_asm_b_blocks = std::max(1, std::min(256, atoi(getenv("VIO_ASM_B_BLOCKS"))));
     if (getenv("VIO_EVAL_OCC")) h->eval_occ = atoi(getenv("VIO_EVAL_OCC"));
     if (getenv("VIO_GRAPH")) h->use_graph = atoi(getenv("VIO_GRAPH")) != 0;

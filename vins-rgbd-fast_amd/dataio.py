@@ -160,6 +160,11 @@ def config_from_yaml(path_or_text, P=None, strict=True):
     # FISHEYE (parameters.cpp:111-114): the mask file is <package>/config/fisheye_mask.jpg; decoding it is the caller's (no image codec here):
     # hand the decoded ROW x COL u8 image to VioBatch.set_fisheye_mask
     fisheye_mask = "config/fisheye_mask.jpg" if int(g("fisheye", 0)) == 1 else None
+    if fisheye_mask is not None:
+        notes.append("fisheye: 1 -- the mask image (%s, relative to the vins_estimator package) is NOT applied by config_from_yaml: decode it and call "
+                     "VioBatch.set_fisheye_mask, otherwise the tracker runs unmasked and diverges from the reference" % fisheye_mask)
+        import warnings
+        warnings.warn(notes[-1], stacklevel=2)
     c.equalize = 1 if int(g("equalize", 0)) else 0   # parameters.cpp:110: CLAHE before tracking
     extra = dict(freq=int(g("freq", 0)), frontend_freq=int(g("frontend_freq", 0)), output_path=g("output_path", ""),
                  max_solver_time=float(g("max_solver_time", 0.0)), fisheye_mask=fisheye_mask, notes=notes)

@@ -90,7 +90,10 @@ def describe(cfg, gray, window_uv, pattern, fast_threshold=20, cap=8192):
     pat = np.ascontiguousarray(pattern, np.int32)
     m = _chk(P, L, L.vio_pg_describe(C.byref(cfg), gray.ctypes.data, n, uv.ctypes.data, pat.ctypes.data, int(fast_threshold), wd.ctypes.data, cap,
                                      kxy.ctypes.data, kd.ctypes.data, kn.ctypes.data), "vio_pg_describe")
-    m = min(m, cap)
+    if m > cap:
+        # cv::FAST has no cap (keyframe.cpp:94-103): the compaction is row-major, a truncated list would lose the bottom of the image -- run
+        # again with room for all of them
+        return describe(cfg, gray, window_uv, pattern, fast_threshold, cap=int(m))
     return wd[:n], kxy[:m], kd[:m], kn[:m]
 
 
@@ -274,7 +277,7 @@ class PoseGraph:
                 if self.earliest_loop_index > loop_index or self.earliest_loop_index == -1:
                     self.earliest_loop_index = loop_index
                 if old_kf.sequence != cur_kf.sequence and not self.sequence_loop[cur_kf.sequence]:   # (:120-139) align the new sequence with the map
-                    w_P_old, w_R_old = old_kf.T_w_i, old_kf.R_w_i
+                    w_P_old, w_R_old = old_kf.vio_T_w_i, old_kf.vio_R_w_i     # old_kf->getVioPose (pose_graph.cpp:122), not the drift-corrected pose
                     rel_t, rel_q = cur_kf.loop_info[:3], cur_kf.loop_info[3:7]
                     w, x, y, z = rel_q
                     rel_R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
