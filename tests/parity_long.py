@@ -29,6 +29,10 @@ def _oracle_worker(job):
     positions, ground truth, reboots"""
     seq, n_frames, lag, cfg_kw = job[:4]
     given = job[4] if len(job) > 4 else None
+    if isinstance(given, str):   # a directory of per-sequence frame files written by run_hip(dump_dir=...): the frames the DEVICE rendered
+        G = np.load(os.path.join(given, "seq_%05d_gray.npy" % seq), mmap_mode="r")
+        D = np.load(os.path.join(given, "seq_%05d_depth.npy" % seq), mmap_mode="r")
+        given = [(np.ascontiguousarray(G[f]), np.ascontiguousarray(D[f])) for f in range(n_frames)]
     import vio_ct
     P = vio_ct.pkg()
     want_status = bool(cfg_kw.pop("_status", False)) if isinstance(cfg_kw, dict) else False
@@ -47,13 +51,16 @@ def _oracle_worker(job):
 def run_oracle_pool(seqs, n_frames, lag=0, cfg_kw=None, procs=None, frames=None):
     """frames: optional {seq: [(gray, depth)] * n_frames} (e.g. downloaded from the device) instead of the host renderer"""
     procs = procs or len(os.sched_getaffinity(0))
-    jobs = [(int(s), int(n_frames), int(lag), dict(cfg_kw or {})) + ((frames[int(s)],) if frames else ()) for s in seqs]
+    jobs = [(int(s), int(n_frames), int(lag), dict(cfg_kw or {})) + ((frames if isinstance(frames, str) else frames[int(s)],) if frames else ()) for s in seqs]
     with mp.get_context("spawn").Pool(min(procs, len(jobs))) as pool:
         res = pool.map(_oracle_worker, jobs, chunksize=1)
     return {r[0]: r[1:] for r in res}
 
 
-def run_hip(P, cfg, sc, seq0, S, n_frames, lag=0, chunk=50, check_render=True, per_frame=None, keep=False, grab=None):
+def run_hip(P, cfg, sc, seq0, S, n_frames, lag=0, chunk=50, check_render=True, per_frame=None, keep=False, grab=None, dump_dir=None):
+    # dump_dir: every frame of every sequence as the device rendered it goes to <dump_dir>/seq_%05d_{gray,depth}.npy (memory-mapped arrays
+    # [n_frames][H][W]) so that the oracle processes can be fed the IDENTICAL pixels (run_oracle_pool(frames=dump_dir)): the device and the host
+    # renderer agree on almost every pixel but not on all of them (float sinf / expf of two math libraries), see DESIGN.md 3 "Round 5"
     # grab: {local sequence index: []} -- filled with the (gray, depth) frames of those sequences as the device rendered them
     """vio_feed over S device-rendered sequences, frames rendered chunk by chunk into one HBM buffer; returns per sequence the
     odometry history rows [stamp, P(3), Q(4), V(3)], the final status, and the wall time of the feed loop"""
@@ -82,6 +89,22 @@ def run_hip(P, cfg, sc, seq0, S, n_frames, lag=0, chunk=50, check_render=True, p
                 gh, dh = syn.render_host(seq0 + i, float(times[k]))
                 assert np.array_equal(gh, g.download((k * S + i) * hw, (H, W), np.uint8))
                 assert np.array_equal(dh, d.download((k * S + i) * hw * 2, (H, W), np.uint16))
+        if dump_dir is not None:
+            if f0 == 0:
+                os.makedirs(dump_dir, exist_ok=True)
+                dump = [(np.lib.format.open_memmap(os.path.join(dump_dir, "seq_%05d_gray.npy" % (seq0 + i)), mode="w+", dtype=np.uint8, shape=(n_frames, H, W)),
+                         np.lib.format.open_memmap(os.path.join(dump_dir, "seq_%05d_depth.npy" % (seq0 + i)), mode="w+", dtype=np.uint16, shape=(n_frames, H, W)))
+                        for i in range(S)]
+            for k in range(n):
+                gk = g.download(k * S * hw, (S, H, W), np.uint8)
+                dk = d.download(k * S * hw * 2, (S, H, W), np.uint16)
+                for i in range(S):
+                    dump[i][0][f0 + k] = gk[i]
+                    dump[i][1][f0 + k] = dk[i]
+            if f0 + n >= n_frames:
+                for a_, b_ in dump:
+                    a_.flush(); b_.flush()
+                dump = None
         if grab is not None:
             for k in range(n):
                 for i in grab:
@@ -136,7 +159,7 @@ def summarise(rows):
                 identical_to_1um=int((md <= 1e-6).sum()))
 
 
-def run(P, S=128, seq0=700, n_frames=300, lag=0, modes=("fast", "exact"), procs=None, cfg_kw=None, oracle_devs=(0,)):
+def run(P, S=128, seq0=700, n_frames=300, lag=0, modes=("fast", "exact"), procs=None, cfg_kw=None, oracle_devs=(0,), same_frames=False):
     """oracle_devs: OVIO_DEVIATIONS masks of the oracle runs to compare with (0 = the reference's formulation; 15 = every equivalent
     formulation the HIP path uses switched on, oracle/oracle.h ODEV_*: the attribution experiment of round 5)"""
     import vio_ct
@@ -146,10 +169,28 @@ def run(P, S=128, seq0=700, n_frames=300, lag=0, modes=("fast", "exact"), procs=
     times = vio_ct.frame_times(sc, n_frames)
     out = dict(config=dict(sequences=S, first_sequence=seq0, frames=n_frames, tracker_lag=lag, **cfg_kw), modes={})
     hip = {}
+    dump_dir = None
+    if same_frames:   # same_frames: the oracle consumes the frames the device rendered (pixel-identical input on both sides)
+        import tempfile
+        dump_dir = tempfile.mkdtemp(prefix="vio_frames_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    out["config"]["same_frames"] = bool(same_frames)
     for mode in modes:
         cfg = P.canonical_config(marg_exact=1 if mode == "exact" else 0, **cfg_kw)
-        hist, stats, t_feed = run_hip(P, cfg, sc, seq0, S, n_frames, lag=lag, check_render=(mode == modes[0]))
+        hist, stats, t_feed = run_hip(P, cfg, sc, seq0, S, n_frames, lag=lag, check_render=(mode == modes[0] and not same_frames),
+                                      dump_dir=(dump_dir if mode == modes[0] else None))
         hip[mode] = (hist, stats, t_feed)
+    if same_frames:
+        # how different are the two renderers?  host-render a sample and count the pixels that differ from what the device produced
+        syn = P.Synth(sc)
+        tms = vio_ct.frame_times(sc, n_frames)
+        ng = nd = npx = 0
+        for i in range(0, S, max(1, S // 8)):
+            G = np.load(os.path.join(dump_dir, "seq_%05d_gray.npy" % (seq0 + i)), mmap_mode="r")
+            D = np.load(os.path.join(dump_dir, "seq_%05d_depth.npy" % (seq0 + i)), mmap_mode="r")
+            for f in range(0, n_frames, max(1, n_frames // 12)):
+                gh, dh = syn.render_host(seq0 + i, float(tms[f]))
+                ng += int((gh != G[f]).sum()); nd += int((dh != D[f]).sum()); npx += gh.size
+        out["renderer_difference_sample"] = dict(pixels=npx, gray_pixels_differing=ng, depth_pixels_differing=nd)
     c0 = time.perf_counter()
     for dv in oracle_devs:
         if dv:
@@ -157,7 +198,7 @@ def run(P, S=128, seq0=700, n_frames=300, lag=0, modes=("fast", "exact"), procs=
         else:
             os.environ.pop("OVIO_DEVIATIONS", None)
         try:
-            orc = run_oracle_pool(range(seq0, seq0 + S), n_frames, lag=lag, cfg_kw=cfg_kw, procs=procs)
+            orc = run_oracle_pool(range(seq0, seq0 + S), n_frames, lag=lag, cfg_kw=cfg_kw, procs=procs, frames=dump_dir)
         finally:
             os.environ.pop("OVIO_DEVIATIONS", None)
         for mode in modes:
@@ -167,6 +208,9 @@ def run(P, S=128, seq0=700, n_frames=300, lag=0, modes=("fast", "exact"), procs=
                 summary=summarise(rows), hip_feed_wall_s=t_feed, hip_frames_per_s=S * n_frames / t_feed,
                 hip_reboots=int(sum(st.reboot_count for st in stats)), oracle_deviations=int(dv), rows=rows)
     out["oracle_wall_s"] = time.perf_counter() - c0
+    if dump_dir:
+        import shutil
+        shutil.rmtree(dump_dir, ignore_errors=True)
     if "fast" in hip and "exact" in hip:
         # the two HIP modes against each other: where deviations 10 / 13 alone move the trajectory
         d = [float(np.linalg.norm(a[:min(len(a), len(b_)), 1:4] - b_[:min(len(a), len(b_)), 1:4], axis=1).max()) for a, b_ in zip(hip["fast"][0], hip["exact"][0])]
@@ -182,17 +226,19 @@ def main():
     ap.add_argument("--lag", type=int, default=0)
     ap.add_argument("--modes", default="fast,exact")
     ap.add_argument("--procs", type=int, default=0)
+    ap.add_argument("--same-frames", type=int, default=0, help="1: the oracle is fed the frames the device rendered (identical pixels on both sides)")
     ap.add_argument("--oracle-devs", default="0", help="comma separated OVIO_DEVIATIONS masks of the oracle runs (0 = reference formulation, 15 = all HIP formulations)")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(HERE), "gpurun_out", "parity_300_s128.json"))
     a = ap.parse_args()
     import vio_ct
     P = vio_ct.pkg()
-    rep = run(P, a.seqs, a.seq0, a.frames, a.lag, tuple(a.modes.split(",")), a.procs or None, oracle_devs=tuple(int(x) for x in a.oracle_devs.split(",")))
+    rep = run(P, a.seqs, a.seq0, a.frames, a.lag, tuple(a.modes.split(",")), a.procs or None, oracle_devs=tuple(int(x) for x in a.oracle_devs.split(",")), same_frames=bool(a.same_frames))
     os.makedirs(os.path.dirname(a.out), exist_ok=True)
     json.dump(rep, open(a.out, "w"), indent=1)
     for m, v in rep["modes"].items():
         print(m, json.dumps(v["summary"]))
     print("fast vs exact", rep.get("fast_vs_exact_max_distance_m"))
+    print("renderer", rep.get("renderer_difference_sample"))
 
 
 if __name__ == "__main__":

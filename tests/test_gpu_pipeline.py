@@ -117,6 +117,40 @@ def test_pipeline_matches_oracle(P, variant):
         assert np.abs(a[2] - q[2]).max() < 5e-3
 
 
+@pytest.mark.parametrize("seq", [781, 783, 730, 5])
+def test_pipeline_equals_the_oracle_with_matched_formulations_to_round_off(P, monkeypatch, seq):
+    """Round 5: the oracle with every equivalent formulation of the HIP path switched on (OVIO_DEVIATIONS = 31, oracle/oracle.h
+    ODEV_*: IMU whitening by chol(cov)^-1, quadratic-form prior, analytic landmark elimination, Cholesky inverse of the remaining 15 x 15 block,
+    frame-pair projection factors) and the HIP path on IDENTICAL frames: what is left is summation order, and the trajectories agree to 1e-11 ..
+    6e-11 m over 50 frames (bar: 5e-10), with every solver decision equal.  Against the oracle as the reference formulates these steps the same
+    run agrees to 1e-9 .. 1e-5 (test_pipeline_matches_oracle): the difference between the two is the arithmetic noise of the reference's own
+    eigen-decompositions (profiles/round5_deviation_attribution.json), not an error of the HIP path.  Sequences 781 / 783 / 730 are the ones that
+    separated EARLIEST in the 128-sequence runs of rounds 3 - 4 -- because those runs compared device-rendered with host-rendered frames."""
+    monkeypatch.setenv("OVIO_DEVIATIONS", "31")
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    n_frames = 50
+    try:
+        o = vio_ct.run_oracle_sequence(cfg, sc, seq, n_frames)
+    finally:
+        monkeypatch.delenv("OVIO_DEVIATIONS")
+        vio_ct.oracle().ovio_set_deviations(0)     # (the free factor functions read the mask of the last estimator constructed)
+    b, traj, stat = _run_hip(P, cfg, sc, [seq], n_frames, [o["frames"]])
+    assert len(traj[0]) == len(o["traj"]) >= 30
+    for f in range(n_frames):
+        so, sh = o["status"][f], stat[0][f]
+        assert (int(so["solver_flag"]), int(so["frame_count"]), int(so["n_landmarks"])) == (sh.solver_flag, sh.frame_count, sh.n_landmarks), f
+        if sh.solver_flag == 1 and sh.processed:
+            assert (int(so["iterations"]), int(so["successful_steps"]), int(so["n_residuals"]), int(so["marginalization_flag"])) == \
+                   (sh.iterations, sh.successful_steps, sh.n_residuals, sh.marginalization_flag), f
+    po = np.array([x[1] for x in o["traj"]]); ph = np.array([x[1] for x in traj[0]])
+    worst = float(np.abs(po - ph).max())
+    print("sequence %d: HIP vs oracle with matched formulations, %d solved frames: max |dP| = %.2e m" % (seq, len(po), worst))
+    assert worst < 5e-10, worst
+    a, q = o["oracle"].tracks(), b.tracks(0)
+    assert np.array_equal(a[0], q[0]) and np.array_equal(a[2].view(np.uint32), q[2].view(np.uint32))   # the trackers stay the same floats throughout
+
+
 def test_pipeline_config5_shape(P):
     """BASELINE configs[4] shape on one sequence: 1280x720, 300 features, 20-keyframe window, 7x8 grid (intrinsics scaled x2 / x1.5).
     Exercises the large-window code paths (Schur complement / Cholesky in HBM instead of LDS tiles, 210 frame pairs, n_prior = 136).

@@ -149,7 +149,10 @@ def test_deviation_variants_track_the_base_oracle_on_a_sequence(P):
     small and stays within micrometres -- the variants differ from the base by round-off amplified by the estimator, nothing else"""
     import oracle_control as OC
     names = ["base", "dev8", "dev13", "dev10", "dev11", "devall"]
-    z = OC.run_variants(703, 45, names)
+    try:
+        z = OC.run_variants(703, 45, names)
+    finally:
+        vio_ct.oracle().ovio_set_deviations(0)
     assert len(z["base_pos"]) >= 25
     for k in names[1:]:
         n = min(len(z["base_pos"]), len(z[k + "_pos"]))

@@ -34,13 +34,18 @@ def build_oracle(target="liboracle.so"):
 _orc = {}
 
 
+def _stale(lib_path):
+    t = os.path.getmtime(lib_path)
+    return any(os.path.getmtime(os.path.join(ORACLE_DIR, f)) > t + 1.0 for f in os.listdir(ORACLE_DIR) if f.endswith((".cpp", ".h")))
+
+
 def oracle(path=None):
     """ctypes handle of the oracle library; path: another build of the SAME sources (oracle/Makefile `control`: liboracle_fma.so,
     liboracle_order.so), used only by the self-divergence control experiment (tests/oracle_control.py)"""
     path = os.path.abspath(path or ORACLE_SO)
     if path not in _orc:
-        if not os.path.exists(path):
-            build_oracle(os.path.basename(path))
+        if os.path.dirname(path) == os.path.abspath(ORACLE_DIR) and (not os.path.exists(path) or _stale(path)):
+            build_oracle(os.path.basename(path))   # missing, or older than a source file of oracle/ (a control build left over from before an edit)
         L = C.CDLL(path)
         L.ovio_pipeline_create.restype = C.c_void_p
         L.ovio_tracker_create.restype = C.c_void_p
