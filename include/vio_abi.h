@@ -9,7 +9,9 @@
  * Host buffers: every entry point that takes host memory (images with on_device == 0, stamps, modes, R_rel, feature maps) enqueues
  * asynchronous uploads.  From pageable memory the runtime stages the copy before the call returns; from page-locked memory
  * (vio_host_alloc) the copy is truly asynchronous: such buffers must stay untouched until the NEXT call on the handle that takes host
- * buffers, any getter, or vio_sync has returned (those calls wait for the pending uploads first).
+ * buffers, any getter, or vio_sync has returned (those calls wait for the pending uploads first).  Exception (round 5): the IMAGES handed to
+ * vio_feed / vio_feed_modes keep TWO uploads in flight -- they are free when vio_host_buffers_done(h, calls_ago) returns 1, and at the latest
+ * when the second next vio_feed, any getter or vio_sync has returned (rotate three page-locked image sets, or poll the query).
  *
  * Threading: a handle is not re-entrant.  vio_push_imu / vio_push_imu_batch may be called from another thread than
  * vio_track / vio_process / vio_feed (internal lock), mirroring Estimator::inputIMU being called from ROS callback threads
@@ -127,10 +129,15 @@ int vio_reset_tracker_seq(vio_batch *h, int seq);
  * on_device != 0: pointers are HBM addresses (no PCIe in the call); otherwise host buffers that are uploaded first.
  * stamps: S timestamps (seconds). The call is asynchronous on the batch's stream; vio_sync or any getter waits.
  * Per-sequence status codes are read back with vio_get_status. */
-/* Host IMAGE buffers (on_device == 0) are uploaded by a copy stream beside the previous frame's kernels; they may be modified or freed once
- * the NEXT vio_feed / vio_feed_modes call on the handle (or any getter / vio_sync) has returned.  `stamps` (and `modes`) are copied into a
- * library-owned page-locked ring before the call returns: they are free at once, page-locked or not. */
+/* Host IMAGE buffers (on_device == 0) are uploaded by a copy stream beside the previous frames' kernels, two uploads in flight: pageable
+ * buffers are free when the call returns (the runtime stages them), page-locked ones (vio_host_alloc) when vio_host_buffers_done says so and at
+ * the latest once the SECOND next vio_feed / vio_feed_modes call on the handle (or any getter / vio_sync) has returned.  `stamps` (and `modes`)
+ * are copied into a library-owned page-locked ring before the call returns: they are free at once, page-locked or not. */
 int vio_feed(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, int on_device);
+/* Non-blocking: 1 if the image uploads of the vio_feed call issued `calls_ago` calls ago (0 = the latest) have completed and its host buffers
+ * may be rewritten, 0 if they are still in flight; calls_ago >= 2 is always 1.  No upstream counterpart (the reference's images arrive as ROS
+ * messages it owns). */
+int vio_host_buffers_done(vio_batch *h, int calls_ago);
 
 /* The two halves of vio_feed, exposed separately the way the reference exposes them to its two threads.
  * vio_track   = predictMotion + readImage(img, t, relative_R) + updateID + packaging; publish = PUB_THIS_FRAME.

@@ -197,13 +197,23 @@ def test_page_locked_host_buffers_and_free_running_uploads(P):
     nimu = int(n / sc.cam_rate * sc.imu_rate) + 64
     imu = [syn.imu(s, nimu) for s in seqs]
     b.push_imu_batch(np.stack([x[0] for x in imu]), np.stack([x[1] for x in imu]), np.stack([x[2] for x in imu]))
-    pg = [P.PinnedArray((S, cfg.height, cfg.width), np.uint8) for _ in range(2)]
-    pd = [P.PinnedArray((S, cfg.height, cfg.width), np.uint16) for _ in range(2)]
+    # round 5: two uploads in flight -- a page-locked image set is free once the SECOND next feed has returned (three sets in rotation), or
+    # earlier when vio_host_buffers_done says so (polled here for the odd frames instead of relying on the rotation)
+    pg = [P.PinnedArray((S, cfg.height, cfg.width), np.uint8) for _ in range(3)]
+    pd = [P.PinnedArray((S, cfg.height, cfg.width), np.uint16) for _ in range(3)]
+    polled = 0
     for f, tf in enumerate(vio_ct.frame_times(sc, n)):
-        g, d = pg[f & 1].a, pd[f & 1].a          # written two feeds ago: that feed's successor has returned
+        if f >= 2 and f % 2 == 1:
+            k = (f - 2) % 3                      # the set handed over two feeds ago = calls_ago 1 now: reuse it as soon as its upload is done
+            while not b.host_buffers_done(1):
+                polled += 1
+        else:
+            k = f % 3                            # handed over three feeds ago: two feeds have returned since
+        g, d = pg[k].a, pd[k].a
         for i, s in enumerate(seqs):
             g[i], d[i] = syn.render_host(s, float(tf))
         b.feed(g, d, [tf] * S)
+    assert b.host_buffers_done(2) and b.host_buffers_done(5)
     for i in range(S):
         assert np.array_equal(b.window(i), ref.window(i)), i
     for x in pg + pd:

@@ -92,6 +92,7 @@ def lib():
         L.vio_create_on_device.restype = C.c_void_p
         L.vio_create_on_device.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_int]
         L.vio_get_device.argtypes = [C.c_void_p]
+        L.vio_host_buffers_done.argtypes = [C.c_void_p, C.c_int]
         L.vio_destroy.argtypes = [C.c_void_p]
         L.vio_last_error.restype = C.c_char_p
         L.vio_reset.argtypes = [C.c_void_p]
@@ -300,6 +301,10 @@ class VioBatch:
     @property
     def device(self):
         return int(self.L.vio_get_device(self.h))
+
+    def host_buffers_done(self, calls_ago=0):
+        """vio_host_buffers_done: have the page-locked image buffers of the feed issued `calls_ago` feeds ago been uploaded?"""
+        return self._chk(self.L.vio_host_buffers_done(self.h, int(calls_ago)), "vio_host_buffers_done") == 1
 
     def close(self):
         if self.h:

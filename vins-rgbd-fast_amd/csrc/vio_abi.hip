@@ -54,7 +54,10 @@ struct vio_batch {
         hipStream_t copy_stream = nullptr;   // host -> HBM uploads of vio_feed (on_device == 0), beside the kernels of the previous frame
         hipGraphExec_t solve_graph = nullptr;   // VIO_GRAPH: setup + iteration slots + final of this group as one graph launch
         uint64_t solve_graph_key = 0;           // hash of the arguments the capture baked in (Batch by value + launch knobs)
-        hipEvent_t ev_up_gray = nullptr, ev_up_depth = nullptr;
+        // vio_feed uploads from host buffers: one event pair per staging buffer (g.flip), so that TWO uploads may be in flight -- the call that
+        // reuses a staging buffer waits for the upload of two calls ago, not for the previous one (round 5; vio_host_buffers_done)
+        hipEvent_t ev_up_gray[2] = {nullptr, nullptr}, ev_up_depth[2] = {nullptr, nullptr};
+        bool up_used[2] = {false, false};
         // the staging images of vio_feed are double-buffered: frame n uploads into buffer n & 1 while frame n-1's kernels still read the
         // other one, so an upload only waits for the readers of frame n-2 (ev_rd_gray / ev_rd_depth of its buffer)
         int flip = 0;
@@ -1093,8 +1096,10 @@ void vio_destroy(vio_batch *h) {
         if (g.ev_be) (void)hipEventDestroy(g.ev_be);
         if (g.ev_ingest) (void)hipEventDestroy(g.ev_ingest);
         if (g.solve_graph) (void)hipGraphExecDestroy(g.solve_graph);
-        if (g.ev_up_gray) (void)hipEventDestroy(g.ev_up_gray);
-        if (g.ev_up_depth) (void)hipEventDestroy(g.ev_up_depth);
+        for (int p = 0; p < 2; p++) {
+            if (g.ev_up_gray[p]) (void)hipEventDestroy(g.ev_up_gray[p]);
+            if (g.ev_up_depth[p]) (void)hipEventDestroy(g.ev_up_depth[p]);
+        }
         for (int p = 0; p < 2; p++) {
             if (g.ev_rd_gray[p]) (void)hipEventDestroy(g.ev_rd_gray[p]);
             if (g.ev_rd_depth[p]) (void)hipEventDestroy(g.ev_rd_depth[p]);
@@ -1166,22 +1171,29 @@ static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, 
     const int p = overlap ? g.flip : 0;
     if (overlap && !g.copy_stream) {
         HIPCHK(hipStreamCreate(&g.copy_stream));   // (one per group: a copy stream shared by the groups measured 27.9 k against 33.9 k frames/s from page-locked buffers)
-        HIPCHK(hipEventCreateWithFlags(&g.ev_up_gray, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&g.ev_up_depth, hipEventDisableTiming));
-    } else if (overlap) {
-        // caller contract: the host buffers of a vio_feed call may be reused once the NEXT vio_feed call has returned -- that call
-        // starts by waiting for the previous uploads (they are asynchronous when the buffers are page-locked)
-        HIPCHK(hipEventSynchronize(g.ev_up_gray));
-        HIPCHK(hipEventSynchronize(g.ev_up_depth));
+        for (int q = 0; q < 2; q++) {
+            HIPCHK(hipEventCreateWithFlags(&g.ev_up_gray[q], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&g.ev_up_depth[q], hipEventDisableTiming));
+        }
     }
+    if (overlap && g.up_used[p]) {
+        // caller contract (include/vio_abi.h "Host buffers"): the page-locked buffers of a vio_feed call are free once vio_host_buffers_done
+        // says so, and at the latest when the SECOND next vio_feed has returned -- this call is about to reuse staging buffer p, whose last
+        // upload came from the call before the previous one.  The previous call's upload (buffer p ^ 1) may still be in flight: two uploads
+        // overlap with the enqueueing of the kernels (until round 4 every call waited for its predecessor's upload: 28 k against 36 k frames/s
+        // from pageable memory)
+        HIPCHK(hipEventSynchronize(g.ev_up_gray[p]));
+        HIPCHK(hipEventSynchronize(g.ev_up_depth[p]));
+    }
+    if (overlap) g.up_used[p] = true;
     if (gray) {
         uint8_t *&buf = p ? h->d_gray_stage1 : h->d_gray_stage;
         if (!buf) HIPCHK(hipMalloc((void **)&buf, S * HW));
         if (overlap) {
             if (g.have_rd_gray[p]) HIPCHK(hipStreamWaitEvent(g.copy_stream, g.ev_rd_gray[p], 0));
             HIPCHK(hipMemcpyAsync(buf + s0 * HW, gray + s0 * HW, n * HW, hipMemcpyHostToDevice, g.copy_stream));
-            HIPCHK(hipEventRecord(g.ev_up_gray, g.copy_stream));
-            HIPCHK(hipStreamWaitEvent(g.fe_stream, g.ev_up_gray, 0));
+            HIPCHK(hipEventRecord(g.ev_up_gray[p], g.copy_stream));
+            HIPCHK(hipStreamWaitEvent(g.fe_stream, g.ev_up_gray[p], 0));
         } else
             HIPCHK(hipMemcpyAsync(buf + s0 * HW, gray + s0 * HW, n * HW, hipMemcpyHostToDevice, g.fe_stream));
         *dg = buf;
@@ -1192,8 +1204,8 @@ static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, 
         if (overlap) {
             if (g.have_rd_depth[p]) HIPCHK(hipStreamWaitEvent(g.copy_stream, g.ev_rd_depth[p], 0));
             HIPCHK(hipMemcpyAsync(buf + s0 * HW, depth + s0 * HW, n * HW * 2, hipMemcpyHostToDevice, g.copy_stream));
-            HIPCHK(hipEventRecord(g.ev_up_depth, g.copy_stream));
-            HIPCHK(hipStreamWaitEvent(g.stream, g.ev_up_depth, 0));
+            HIPCHK(hipEventRecord(g.ev_up_depth[p], g.copy_stream));
+            HIPCHK(hipStreamWaitEvent(g.stream, g.ev_up_depth[p], 0));
         } else
             HIPCHK(hipMemcpyAsync(buf + s0 * HW, depth + s0 * HW, n * HW * 2, hipMemcpyHostToDevice, g.stream));
         *dd = buf;
@@ -1298,6 +1310,23 @@ int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, 
     if (h->prof_cur >= 0) h->prof_cur++;
     h->timing_valid = true;
     return VIO_OK;
+}
+
+int vio_host_buffers_done(vio_batch *h, int calls_ago) {
+    DevGuard dev_guard(h);
+    if (!h || calls_ago < 0) return VIO_EINVAL;
+    if (calls_ago > 1) return 1;   // (a later vio_feed has already waited for them)
+    for (auto &g : h->groups) {
+        if (!g.copy_stream) continue;
+        const int p = (g.flip ^ 1 ^ calls_ago) & 1;     // g.flip = the buffer the NEXT call will use; the latest call used g.flip ^ 1
+        if (!g.up_used[p]) continue;
+        for (hipEvent_t e : {g.ev_up_gray[p], g.ev_up_depth[p]}) {
+            const hipError_t q = hipEventQuery(e);
+            if (q == hipErrorNotReady) return 0;
+            if (q != hipSuccess) { g_err = "hipEventQuery failed"; return VIO_EDEVICE; }
+        }
+    }
+    return 1;
 }
 
 int vio_feed(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, int on_device) {
