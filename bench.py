@@ -386,7 +386,7 @@ def main():
     be_ms = sum(v for k, v in kms.items() if k.startswith("be_"))
     fe_ms = sum(v for k, v in kms.items() if k.startswith("fe_"))
     tj = None
-    for name in ("round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
+    for name in ("round5_pmc_traffic.json", "round4_pmc_traffic.json", "round3_pmc_traffic.json", "round2_pmc_traffic.json", "round1_pmc_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", name)
         if os.path.exists(tpath):  # written by profiles/collect.sh from separate rocprofv3 --pmc passes over this same command
             tj = (name, json.load(open(tpath)))

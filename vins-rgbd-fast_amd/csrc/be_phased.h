@@ -51,7 +51,7 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(Batch B) {
         st.iter = 0; st.iters_done = 0; st.succ = 0; st.invalid = 0;
         st.point_new = 0; st.scale_pending = 1; st.retry = 0; st.cauchy_valid = 0; st.eval_with_J = 1;
         st.test_fail = (c.C->c.reference_quirks >> VIO_TEST_CHOL_FAIL_SHIFT) & VIO_TEST_CHOL_FAIL_MASK;
-        st.n_eval_blocks = 3 + (nres + 255) / 256;
+        st.n_eval_blocks = 3 + (nres + 256 * B.eval_rpt - 1) / (256 * B.eval_rpt);
         st.eval_done = 0;
         st.ts0 = ts0;
         st.stage = PS_EVAL_X0;
@@ -249,7 +249,7 @@ __device__ __forceinline__ void ps_eval_body(const Batch &B) {
             }
     } else {
         double *geo = (double *)smem;
-        const int r0 = 256 * (b - 3), nres = st.nres;
+        const int rpt = B.eval_rpt, r0 = 256 * rpt * (b - 3), nres = st.nres;
         for (int p = t; p <= W1 * W1; p += nt) {
             if (p == W1 * W1) { stm(geo + (size_t)p * 32, q2R(mkq(X.ex[6], X.ex[3], X.ex[4], X.ex[5]))); continue; }
             const int i = p / W1, j = p - i * W1;
@@ -262,8 +262,11 @@ __device__ __forceinline__ void ps_eval_body(const Batch &B) {
         }
         __syncthreads();
         const double *ricm = geo + (size_t)W1 * W1 * 32;
-        const int r = r0 + t;
-        if (r < nres) {
+        // (round 5: rpt residuals per thread -- with two, the 7 projection workgroups of a sequence become 4 and a 64-sequence launch fits the
+        // device's wave slots at this kernel's 216 VGPRs in one round instead of two)
+        for (int u = 0; u < rpt; u++) {
+            const int r = r0 + t + 256 * u;
+            if (r >= nres) break;
             const int slot = c.res_lm[r], k = c.res_k[r];   // k = 0: the landmark's relocalisation factor
             const int imu_i = c.lm_start[slot], imu_j = imu_i + (k > 0 ? k : 1);
             const bf::PairGeo &g = *(const bf::PairGeo *)(geo + (size_t)(imu_i * W1 + imu_j) * 32);

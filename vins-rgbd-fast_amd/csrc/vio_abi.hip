@@ -52,6 +52,7 @@ struct vio_batch {
         hipStream_t fe_stream = nullptr;  // front-end: frame k+1 tracks while frame k is still being marginalised
         hipEvent_t ev_solve = nullptr, ev_fe = nullptr, ev_be = nullptr, ev_ingest = nullptr;
         hipStream_t copy_stream = nullptr;   // host -> HBM uploads of vio_feed (on_device == 0), beside the kernels of the previous frame
+        hipStream_t copy_stream2 = nullptr;  // the depth images on a stream of their own: two DMA engines per group (one stream moves ~25 GB/s from page-locked memory)
         hipGraphExec_t solve_graph = nullptr;   // VIO_GRAPH: setup + iteration slots + final of this group as one graph launch
         uint64_t solve_graph_key = 0;           // hash of the arguments the capture baked in (Batch by value + launch knobs)
         // vio_feed uploads from host buffers: one event pair per staging buffer (g.flip), so that TWO uploads may be in flight -- the call that
@@ -204,6 +205,7 @@ struct DevGuard {
 static int sync_all(vio_batch *h) {
     for (auto &g : h->groups) {
         if (g.copy_stream) HIPCHK(hipStreamSynchronize(g.copy_stream));
+        if (g.copy_stream2) HIPCHK(hipStreamSynchronize(g.copy_stream2));
         HIPCHK(hipStreamSynchronize(g.fe_stream));
         HIPCHK(hipStreamSynchronize(g.stream));
         g.host_fe_pending = g.host_be_pending = false;
@@ -1024,7 +1026,8 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
                 (void)raise_lds_limit((const void *)ps_eval_kernel, h->lds_ps_eval);
                 (void)raise_lds_limit((const void *)ps_eval_kernel_occ3, h->lds_ps_eval);
                 (void)raise_lds_limit((const void *)ps_eval_kernel_occ4, h->lds_ps_eval);
-                h->ps_eval_blocks = (int)std::min<size_t>(PS_MAX_EVAL_BLOCKS, (size_t)C.W * C.NP / 256 + 4);
+                B.eval_rpt = getenv("VIO_EVAL_RPT") ? std::max(1, std::min(4, atoi(getenv("VIO_EVAL_RPT")))) : 2;
+                h->ps_eval_blocks = (int)std::min<size_t>(PS_MAX_EVAL_BLOCKS, (size_t)C.W * C.NP / (256 * (size_t)B.eval_rpt) + 4);
                 h->ps_asm_a_blocks = (int)((W1 * (W1 - 1) / 2 + C.W + 32 + 7) / 8);   // pair items (i < j), IMU items, PS_ROW_WAVES = 32 landmark-row wavefronts
                 int nact = 0;
                 for (size_t a = 0; a < nb; a++) for (size_t b2 = 0; b2 <= a; b2++) {
@@ -1108,6 +1111,7 @@ void vio_destroy(vio_batch *h) {
         if (g.side_ring) { (void)hipHostFree(g.side_ring); for (auto e : g.side_ev) if (e) (void)hipEventDestroy(e); }
         if (g.ev_host_be) (void)hipEventDestroy(g.ev_host_be);
         if (g.copy_stream) (void)hipStreamDestroy(g.copy_stream);
+        if (g.copy_stream2) (void)hipStreamDestroy(g.copy_stream2);
     }
     for (int i = 0; i < 4; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
     delete h;
@@ -1171,6 +1175,7 @@ static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, 
     const int p = overlap ? g.flip : 0;
     if (overlap && !g.copy_stream) {
         HIPCHK(hipStreamCreate(&g.copy_stream));   // (one per group: a copy stream shared by the groups measured 27.9 k against 33.9 k frames/s from page-locked buffers)
+        if (!(getenv("VIO_COPY_STREAMS") && atoi(getenv("VIO_COPY_STREAMS")) == 1)) HIPCHK(hipStreamCreate(&g.copy_stream2));
         for (int q = 0; q < 2; q++) {
             HIPCHK(hipEventCreateWithFlags(&g.ev_up_gray[q], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&g.ev_up_depth[q], hipEventDisableTiming));
@@ -1202,9 +1207,10 @@ static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, 
         uint16_t *&buf = p ? h->d_depth_stage1 : h->d_depth_stage;
         if (!buf) HIPCHK(hipMalloc((void **)&buf, S * HW * 2));
         if (overlap) {
-            if (g.have_rd_depth[p]) HIPCHK(hipStreamWaitEvent(g.copy_stream, g.ev_rd_depth[p], 0));
-            HIPCHK(hipMemcpyAsync(buf + s0 * HW, depth + s0 * HW, n * HW * 2, hipMemcpyHostToDevice, g.copy_stream));
-            HIPCHK(hipEventRecord(g.ev_up_depth[p], g.copy_stream));
+            hipStream_t cs2 = g.copy_stream2 ? g.copy_stream2 : g.copy_stream;
+            if (g.have_rd_depth[p]) HIPCHK(hipStreamWaitEvent(cs2, g.ev_rd_depth[p], 0));
+            HIPCHK(hipMemcpyAsync(buf + s0 * HW, depth + s0 * HW, n * HW * 2, hipMemcpyHostToDevice, cs2));
+            HIPCHK(hipEventRecord(g.ev_up_depth[p], cs2));
             HIPCHK(hipStreamWaitEvent(g.stream, g.ev_up_depth[p], 0));
         } else
             HIPCHK(hipMemcpyAsync(buf + s0 * HW, depth + s0 * HW, n * HW * 2, hipMemcpyHostToDevice, g.stream));

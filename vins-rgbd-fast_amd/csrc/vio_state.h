@@ -168,6 +168,7 @@ struct Batch {
     int s0;               // first sequence of the launching group: kernels use s = blockIdx + s0
     int ns, xcd_nb, xcd_n; // sequences of this launch; blocks per sequence under the XCD-aware block map of the ps_* kernels (0: plain 2-D grid) -- be_phased.h ps_blk
     int tracker_lag;      // 0: fe_begin reads the live estimator state; 1: the snapshot be_ingest took one frame earlier
+    int eval_rpt;         // projection residuals per thread of ps_eval (VIO_EVAL_RPT: 1 = 256 per workgroup; 2 halves the workgroups of the launch)
     FeSeq *fe;
     BeSeq *be;
     PreInt *pre;          // [S][W+2]
