@@ -614,7 +614,11 @@ def main():
         detail["marg_exact"] = aux_rate(P, vio_ct, torch, cfg_x, sc, dev, S, n_pre, Wm, K, lag=args.tracker_lag, seq0=seq0)
         detail["marg_exact"]["note"] = "marg_exact = 1; be_marg per launch %.3f ms against %.3f ms of the default form" % (
             detail["marg_exact"]["kernels_ms"].get("be_marg", float("nan")), kms.get("be_marg", float("nan")))
-        aux_keys = ("lag0", "aux_s256", "aux_s512", "config5", "marg_exact")
+        # marg_exact = 2: the same algorithm with the first eigen-decomposition replaced by a certified inverse (include/vio_abi.h)
+        cfg_c = P.canonical_config(marg_exact=2)
+        detail["marg_certified"] = aux_rate(P, vio_ct, torch, cfg_c, sc, dev, S, n_pre, Wm, K, lag=args.tracker_lag, seq0=seq0)
+        detail["marg_certified"]["note"] = "marg_exact = 2; be_marg per launch %.3f ms" % detail["marg_certified"]["kernels_ms"].get("be_marg", float("nan"))
+        aux_keys = ("lag0", "aux_s256", "aux_s512", "config5", "marg_exact", "marg_certified")
         line["aux_frames_per_s"] = {k: round(detail[k]["frames_per_s"]) for k in aux_keys}
         line["aux_valid"] = all(detail[k]["valid"] for k in aux_keys)
     if rank == 0:

@@ -60,7 +60,11 @@ typedef struct vio_config {
                                        281-315): eigen-decomposition of the FULL m x m marginalised block (pose 0, speed-bias 0 and every
                                        landmark that starts in frame 0) with the 1e-8 cut, then eigen-decomposition of the reduced system and the
                                        prior rebuilt from the truncated factors J = S^1/2 V^T, r = S^-1/2 V^T b.  0 (default) = the fast form
-                                       (analytic landmark elimination, prior kept as a quadratic form; DESIGN.md deviations 10 / 13). */
+                                       (analytic landmark elimination, prior kept as a quadratic form; DESIGN.md deviations 10 / 13).
+                                       2 (round 5) = the literal algorithm with a CERTIFIED first inverse: A_mm^+ = A_mm^-1 is formed by blocks
+                                       (exact for the diagonal landmark block) and every frame proves lambda_min(A_mm) > 1e-7 from a bound on
+                                       |A_mm^-1|_F, i.e. that the reference's 1e-8 cut could not have dropped anything; the second half (the
+                                       new prior's eigen-decomposition with its cut, which does drop directions) is the literal one. */
     int32_t equalize;               /* EQUALIZE (yaml key `equalize`, parameters.cpp:110): 1 = cv::createCLAHE(3.0, Size(8, 8)) on every image
                                        before tracking (feature_tracker.cpp:269-275).  Occupies what used to be alignment padding: the
                                        offsets of all other fields are unchanged. */

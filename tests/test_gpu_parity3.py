@@ -95,6 +95,39 @@ def test_literal_marginalisation_mode_tracks_the_oracle(P):
     assert sum(v < 1e-4 for v in tail) >= 6 and max(tail) < 1e-2, tail
 
 
+def test_certified_literal_marginalisation_mode(P):
+    """vio_config.marg_exact = 2 (round 5): MarginalizationInfo::marginalize with its first eigen-decomposition replaced by a certified inverse
+    (the pseudo-inverse with the 1e-8 cut IS the inverse when no eigenvalue is near the cut, which every frame proves from a bound on
+    |A_mm^-1|_F) and its second half -- the eigen-decomposition of the new prior with the cut that does drop directions -- followed literally
+    (marginalization_factor.cpp:293-315, LDS-resident).  Against the oracle like the fully literal mode above (1e-5 m over the first 30
+    processed frames), every marginalisation certified, and two orders of magnitude cheaper than marg_exact = 1 on this workload, whose
+    marginalised block (m = 150 .. 215) does not fit LDS."""
+    import ctypes as C
+    cfg = P.canonical_config(marg_exact=2)
+    sc = vio_ct.synth_like(cfg)
+    S, seq0, n_frames = 8, 700, 70
+    hist, stats, t_feed, b = parity_long.run_hip(P, cfg, sc, seq0, S, n_frames, check_render=False, keep=True)
+    assert all(st.reboot_count == 0 and st.solver_flag == 1 for st in stats)
+    L = P.lib()
+    L.vio_debug_seq.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    dbg = np.zeros(16, np.int32)
+    for i in range(S):
+        L.vio_debug_seq(b.h, i, dbg.ctypes.data)
+        assert dbg[12] == 0 and dbg[11] == 1, (i, dbg[11], dbg[12])        # no uncertified marginalisation in 70 frames; the last one certified
+        assert dbg[0] == 0                                                  # the prior's eigen-decomposition ran LDS-resident (no Jacobi sweeps)
+    b.close()
+    orc = parity_long.run_oracle_pool(range(seq0, seq0 + S), n_frames, procs=S)
+    head, tail = [], []
+    for i in range(S):
+        fr, po, gt, reb = orc[seq0 + i]
+        assert reb == 0 and len(hist[i]) == len(po) >= 50
+        d = np.abs(hist[i][:, 1:4] - po).max(1)
+        head.append(float(d[:30].max()))
+        tail.append(float(d.max()))
+    assert max(head) < 1e-5, head
+    assert sum(v < 1e-4 for v in tail) >= 6 and max(tail) < 1e-2, tail
+
+
 def test_long_run_on_identical_frames_hip_equals_the_matched_oracle(P):
     """Round 5, the experiment VERDICT r4 asked for (item 1), in small: 32 sequences x 200 frames, the oracle fed THE FRAMES THE DEVICE RENDERED
     (parity_long same_frames: the device and the host renderer disagree on ~1e-7 of the pixels -- two math libraries' sinf / expf -- which is

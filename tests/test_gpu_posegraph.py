@@ -31,7 +31,7 @@ def _q2R(q):
 def test_descriptors_keypoints_and_search_are_bit_exact(P, PG):
     """KeyFrame::computeWindowBRIEFPoint / computeBRIEFPoint / searchByBRIEFDes (keyframe.cpp:80-169): blur, FAST(20, NMS) keypoints in
     row-major order, 256-bit descriptors, normalised keypoints and the Hamming search -- identical to the oracle on rendered frames and on a
-    noise image (thousands of keypoints, capacity clipping)."""
+    noise image (tens of thousands of keypoints, more than the caller made room for)."""
     cfg = P.canonical_config()
     sc = vio_ct.synth_like(cfg)
     syn = P.Synth(sc)
@@ -42,10 +42,12 @@ def test_descriptors_keypoints_and_search_are_bit_exact(P, PG):
     descs = []
     for k, img in enumerate(imgs):
         uv = np.c_[rng.uniform(-2, cfg.width + 2, 150), rng.uniform(-2, cfg.height + 2, 150)].astype(np.float32)   # incl. points at / beyond the border
+        # the noise image has ~30 000 keypoints: cv::FAST has no cap, so PG.describe, started with room for 1000, must come back with ALL of them
+        # (round 5, ADVICE r4: it used to truncate in row-major order, i.e. drop the bottom of the image); the oracle gets room for all at once
         cap = 8192 if k < 2 else 1000
         wd_h, kxy_h, kd_h, kn_h = PG.describe(cfg, img, uv, pat, cap=cap)
-        wd_o, kxy_o, kd_o, kn_o = O.o_describe(cfg, img, uv, pat, cap=cap)
-        assert len(kxy_h) == len(kxy_o) and (len(kxy_h) > 100 if k < 2 else len(kxy_h) == 1000)
+        wd_o, kxy_o, kd_o, kn_o = O.o_describe(cfg, img, uv, pat, cap=cap if k < 2 else 40000)
+        assert len(kxy_h) == len(kxy_o) and (len(kxy_h) > 100 if k < 2 else len(kxy_h) > 20000)
         assert np.array_equal(wd_h, wd_o) and np.array_equal(kxy_h, kxy_o) and np.array_equal(kd_h, kd_o)
         assert np.array_equal(kn_h.view(np.uint32), kn_o.view(np.uint32))        # liftProjective, bitwise
         descs.append((wd_h, kd_h))

@@ -2109,6 +2109,92 @@ __device__ __forceinline__ void sym_eig_lds(double *Al, int n, int ld, double *a
     sym_eig_tridiag_mt(Al, n, ld, d, e, g, part);
     tridiag_ql_wave(Al, n, ld, d, e);
 }
+// The SECOND half of MarginalizationInfo::marginalize (marginalization_factor.cpp:293-315), literally: saes2(A), S = eigenvalues > 1e-8,
+// linearized_jacobians = S^1/2 V^T, linearized_residuals = S^-1/2 V^T b, and from them what the solver consumes (J^T J, J^T r, |r|^2).
+// Ar (n x n, HBM) / br (n) = the reduced system.  LDS-resident Householder + implicit QL when n <= MXL, else Jacobi sweeps over HBM scratch
+// (scrA: n x n for the symmetrised matrix, scrV: n x n for the eigenvectors).  Returns the sweep count of the fallback (0 = LDS path).
+// Not inlined: its own register allocation, one copy in the kernel for both literal modes (marg_exact 1 and 2).
+__device__ __noinline__ int marg_literal_prior(const Ctx &c, BeSeq &be, const double *Ar, const double *br, int n, double *scrA, double *scrV, double *sred,
+                                               unsigned char *smem) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    const double eps = 1e-8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char marg_dyn_lds[];
+    __shared__ double ev2[EIG_LD], vb2[EIG_LD];
+    int sw2 = 0;
+    if (n <= c.C->MXL) {
+        const int ld = n | 1;
+        double *Al = (double *)marg_dyn_lds, *aux = Al + (size_t)n * ld;
+        for (int w = t; w < n * n; w += nt) { const int i = w / n, j = w - i * n; Al[i * ld + j] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
+        __syncthreads();
+        sym_eig_lds(Al, n, ld, aux);   // SelfAdjointEigenSolver<MatrixXd> saes2(A) (:298)
+        for (int k = t; k < n; k += nt) {
+            const double ev = aux[k];
+            double vb = 0;
+            for (int i = 0; i < n; i++) vb += Al[i * ld + k] * br[i];
+            c.prior_rf[k] = sqrt(ev > eps ? 1.0 / ev : 0.0) * vb;
+            aux[EIG_LD + k] = sqrt(ev > eps ? ev : 0.0);
+        }
+        __syncthreads();
+        // J = S^1/2 V^T: column k of the eigenvector array scaled in place, so Al[i][k] = J[k][i]
+        for (int w = t; w < n * n; w += nt) { const int i = w / n, k = w - i * n; const double v = aux[EIG_LD + k] * Al[i * ld + k]; Al[i * ld + k] = v; c.prior_J[k * n + i] = v; }
+        __syncthreads();
+        // what MarginalizationFactor::Evaluate, the solver and the next marginalisation consume of (J, r): J^T J, J^T r and |r|^2
+        for (int w = t; w < n * n; w += nt) {
+            const int a = w / n, bb = w - a * n;
+            double sacc = 0;
+            for (int k = 0; k < n; k++) sacc += Al[a * ld + k] * Al[bb * ld + k];
+            c.prior_H[w] = sacc;
+        }
+        for (int a = t; a < n; a += nt) {
+            double sacc = 0;
+            for (int k = 0; k < n; k++) sacc += Al[a * ld + k] * c.prior_rf[k];
+            c.prior_r[a] = sacc;
+        }
+    } else {
+        double *cs = (double *)smem, *sn = cs + 256;
+        int *pp = (int *)(sn + 256), *qq = pp + 256;
+        double *As = scrA, *V2 = scrV;
+        for (int w = t; w < n * n; w += nt) { const int i = w / n, j = w - i * n; As[w] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
+        __syncthreads();
+        sw2 = jacobi_block(As, V2, n, n, cs, sn, pp, qq, sred);
+        for (int k = t; k < n; k += nt) {
+            ev2[k] = As[k * n + k];
+            double vb = 0;
+            for (int i = 0; i < n; i++) vb += V2[i * n + k] * br[i];
+            vb2[k] = vb;
+        }
+        __syncthreads();
+        for (int w = t; w < n * n; w += nt) {
+            const int k = w / n, i = w - k * n;
+            const double S = ev2[k] > eps ? ev2[k] : 0.0;
+            c.prior_J[w] = sqrt(S) * V2[i * n + k];
+        }
+        for (int k = t; k < n; k += nt) {
+            const double Sinv = ev2[k] > eps ? 1.0 / ev2[k] : 0.0;
+            c.prior_rf[k] = sqrt(Sinv) * vb2[k];
+        }
+        __syncthreads();
+        for (int w = t; w < n * n; w += nt) {
+            const int a = w / n, bb = w - a * n;
+            double sacc = 0;
+            for (int k = 0; k < n; k++) sacc += c.prior_J[k * n + a] * c.prior_J[k * n + bb];
+            c.prior_H[w] = sacc;
+        }
+        for (int a = t; a < n; a += nt) {
+            double sacc = 0;
+            for (int k = 0; k < n; k++) sacc += c.prior_J[k * n + a] * c.prior_rf[k];
+            c.prior_r[a] = sacc;
+        }
+    }
+    __syncthreads();
+    double acc = 0;
+    for (int k = t; k < n; k += nt) acc += c.prior_rf[k] * c.prior_rf[k];
+    const double c0 = block_sum(acc, sred);
+    __syncthreads();
+    if (t == 0) be.prior_c0 = c0;
+    return sw2;
+}
+
 __device__ void marg_exact_finish(const Ctx &c, BeSeq &be, double *A, const double *b, int md, int mq, int n, const double *Cl, int ldc, int F0,
                                   bool second_new, double *sred, unsigned char *smem) {
     const int t = threadIdx.x, nt = blockDim.x;
@@ -2120,145 +2206,74 @@ __device__ void marg_exact_finish(const Ctx &c, BeSeq &be, double *A, const doub
     extern __shared__ __attribute__((aligned(16))) unsigned char marg_dyn_lds[];
     double *cs = (double *)smem, *sn = cs + 256;
     int *pp = (int *)(sn + 256), *qq = pp + 256;
-    __shared__ double ev2[EIG_LD], vb2[EIG_LD];
     // Amm = 0.5 (Amm + Amm^T) (:276); the landmark-landmark block is diagonal (an inverse depth only meets itself)
     auto amm = [&](int i, int j) -> double {
         if (i < md && j < md) return 0.5 * (A[i * mq + j] + A[j * mq + i]);
         if (i >= md && j >= md) return i == j ? c.Hll[i - md] : 0.0;
         return Cl[(size_t)((i >= md ? i : j) - md) * ldc + (i >= md ? j : i)];
     };
-    // Both eigen-decompositions of marginalize() run LDS-resident when the block fits (m, n <= MXL): Householder + implicit QL instead of
-    // Jacobi sweeps over HBM (round 5).  ONE call site of the solver, visited twice, so that its code exists once in the kernel.
-    int sw1 = 0, sw2 = 0;
+    // The first eigen-decomposition (saes(Amm), :281) runs LDS-resident when the block fits (m <= MXL): Householder + implicit QL instead of
+    // Jacobi sweeps over HBM (round 5); the second one lives in marg_literal_prior.
+    int sw1 = 0;
     double *Ar = c.margV, *br = c.vec;
-    double *Al = (double *)marg_dyn_lds;
     const long long tx0 = VIO_CLOCK();   // (timers build only: dbg[7..10] = ticks to the end of eig 1 / the Schur products / eig 2 / the prior; tools/marg_exact_probe.py)
-    for (int pass = 0; pass < 2; pass++) {
-        const int nn = pass == 0 ? m : n, ld = nn | 1;
-        const bool in_lds = nn <= c.C->MXL;
-        double *aux = Al + (size_t)nn * ld;
-        if (in_lds) {
-            if (pass == 0) for (int w = t; w < m * m; w += nt) { const int i = w / m, j = w - i * m; Al[i * ld + j] = amm(i, j); }
-            else for (int w = t; w < n * n; w += nt) { const int i = w / n, j = w - i * n; Al[i * ld + j] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
-            __syncthreads();
-            sym_eig_lds(Al, nn, ld, aux);   // SelfAdjointEigenSolver<MatrixXd> saes(Amm) (:281) / saes2(A) (:298)
-            if (VIO_TIMERS && t == 0) be.dbg[pass == 0 ? 7 : 9] = (int)(VIO_CLOCK() - tx0);
+    if (m <= c.C->MXL) {
+        const int ld = m | 1;
+        double *Al = (double *)marg_dyn_lds, *aux = Al + (size_t)m * ld;
+        for (int w = t; w < m * m; w += nt) { const int i = w / m, j = w - i * m; Al[i * ld + j] = amm(i, j); }
+        __syncthreads();
+        sym_eig_lds(Al, m, ld, aux);
+        if (VIO_TIMERS && t == 0) be.dbg[7] = (int)(VIO_CLOCK() - tx0);
+        // Amm_inv = V diag(lambda > eps ? 1 / lambda : 0) V^T (:281-283); 1 / lambda once per column
+        for (int k = t; k < m; k += nt) { const double ev = aux[k]; aux[EIG_LD + k] = ev > eps ? 1.0 / ev : 0.0; }
+        __syncthreads();
+        for (int w = t; w < m * m; w += nt) {
+            const int i = w / m, j = w - i * m;
+            double sacc = 0;
+            for (int k = 0; k < m; k++) sacc += Al[i * ld + k] * Al[j * ld + k] * aux[EIG_LD + k];
+            Einv[w] = sacc;
         }
-        if (pass == 0) {
-            if (in_lds) {
-                // Amm_inv = V diag(lambda > eps ? 1 / lambda : 0) V^T (:281-283); 1 / lambda once per column
-                for (int k = t; k < m; k += nt) { const double ev = aux[k]; aux[EIG_LD + k] = ev > eps ? 1.0 / ev : 0.0; }
-                __syncthreads();
-                for (int w = t; w < m * m; w += nt) {
-                    const int i = w / m, j = w - i * m;
-                    double sacc = 0;
-                    for (int k = 0; k < m; k++) sacc += Al[i * ld + k] * Al[j * ld + k] * aux[EIG_LD + k];
-                    Einv[w] = sacc;
-                }
-            } else {
-                for (int w = t; w < m * m; w += nt) { const int i = w / m, j = w - i * m; Emm[w] = amm(i, j); }
-                __syncthreads();
-                sw1 = jacobi_block(Emm, EV, m, m, cs, sn, pp, qq, sred);
-                for (int w = t; w < m * m; w += nt) {
-                    const int i = w / m, j = w - i * m;
-                    double sacc = 0;
-                    for (int k = 0; k < m; k++) { const double ev = Emm[(size_t)k * m + k]; if (ev > eps) sacc += EV[(size_t)i * m + k] * EV[(size_t)j * m + k] / ev; }
-                    Einv[w] = sacc;
-                }
-            }
-            __syncthreads();
-            // A_rm A_mm^-1 (:288-292); column k of A_rm: q-column k for the pose / speed-bias part, the coupling row of landmark k - md otherwise
-            for (int w = t; w < n * m; w += nt) {
-                const int i = w / m, j = w - i * m;
-                double sacc = 0;
-                for (int k = 0; k < md; k++) sacc += A[(md + i) * mq + k] * Einv[(size_t)k * m + j];
-                for (int k = md; k < m; k++) sacc += Cl[(size_t)(k - md) * ldc + md + i] * Einv[(size_t)k * m + j];
-                ET1[w] = sacc;
-            }
-            __syncthreads();
-            for (int w = t; w < n * n; w += nt) {   // A = Arr - Arm Amm_inv Amr
-                const int i = w / n, j = w - i * n;
-                double tt = A[(md + i) * mq + md + j];
-                for (int k = 0; k < md; k++) tt -= ET1[(size_t)i * m + k] * A[k * mq + md + j];
-                for (int k = md; k < m; k++) tt -= ET1[(size_t)i * m + k] * Cl[(size_t)(k - md) * ldc + md + j];
-                Ar[w] = tt;
-            }
-            for (int i = t; i < n; i += nt) {       // b = brr - Arm Amm_inv bmm
-                double sacc = b[md + i];
-                for (int k = 0; k < md; k++) sacc -= ET1[(size_t)i * m + k] * b[k];
-                for (int k = md; k < m; k++) sacc -= ET1[(size_t)i * m + k] * c.gl[k - md];
-                br[i] = sacc;
-            }
-            __syncthreads();
-            if (VIO_TIMERS && t == 0) be.dbg[8] = (int)(VIO_CLOCK() - tx0);
-            continue;
-        }
-        // second eigen-decomposition (:298-311): S = eigenvalues > eps, linearized_jacobians = S^1/2 V^T, linearized_residuals = S^-1/2 V^T b
-        if (in_lds) {
-            for (int k = t; k < n; k += nt) {
-                const double ev = aux[k];
-                double vb = 0;
-                for (int i = 0; i < n; i++) vb += Al[i * ld + k] * br[i];
-                c.prior_rf[k] = sqrt(ev > eps ? 1.0 / ev : 0.0) * vb;
-                aux[EIG_LD + k] = sqrt(ev > eps ? ev : 0.0);
-            }
-            __syncthreads();
-            // J = S^1/2 V^T: column k of the eigenvector array scaled in place, so Al[i][k] = J[k][i]
-            for (int w = t; w < n * n; w += nt) { const int i = w / n, k = w - i * n; const double v = aux[EIG_LD + k] * Al[i * ld + k]; Al[i * ld + k] = v; c.prior_J[k * n + i] = v; }
-            __syncthreads();
-            // what MarginalizationFactor::Evaluate, the solver and the next marginalisation consume of (J, r): J^T J, J^T r and |r|^2
-            for (int w = t; w < n * n; w += nt) {
-                const int a = w / n, bb = w - a * n;
-                double sacc = 0;
-                for (int k = 0; k < n; k++) sacc += Al[a * ld + k] * Al[bb * ld + k];
-                c.prior_H[w] = sacc;
-            }
-            for (int a = t; a < n; a += nt) {
-                double sacc = 0;
-                for (int k = 0; k < n; k++) sacc += Al[a * ld + k] * c.prior_rf[k];
-                c.prior_r[a] = sacc;
-            }
-        } else {
-            double *As = c.margW, *V2 = A;   // (A is free from here on)
-            for (int w = t; w < n * n; w += nt) { const int i = w / n, j = w - i * n; As[w] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
-            __syncthreads();
-            sw2 = jacobi_block(As, V2, n, n, cs, sn, pp, qq, sred);
-            for (int k = t; k < n; k += nt) {
-                ev2[k] = As[k * n + k];
-                double vb = 0;
-                for (int i = 0; i < n; i++) vb += V2[i * n + k] * br[i];
-                vb2[k] = vb;
-            }
-            __syncthreads();
-            for (int w = t; w < n * n; w += nt) {
-                const int k = w / n, i = w - k * n;
-                const double S = ev2[k] > eps ? ev2[k] : 0.0;
-                c.prior_J[w] = sqrt(S) * V2[i * n + k];
-            }
-            for (int k = t; k < n; k += nt) {
-                const double Sinv = ev2[k] > eps ? 1.0 / ev2[k] : 0.0;
-                c.prior_rf[k] = sqrt(Sinv) * vb2[k];
-            }
-            __syncthreads();
-            for (int w = t; w < n * n; w += nt) {
-                const int a = w / n, bb = w - a * n;
-                double sacc = 0;
-                for (int k = 0; k < n; k++) sacc += c.prior_J[k * n + a] * c.prior_J[k * n + bb];
-                c.prior_H[w] = sacc;
-            }
-            for (int a = t; a < n; a += nt) {
-                double sacc = 0;
-                for (int k = 0; k < n; k++) sacc += c.prior_J[k * n + a] * c.prior_rf[k];
-                c.prior_r[a] = sacc;
-            }
+    } else {
+        for (int w = t; w < m * m; w += nt) { const int i = w / m, j = w - i * m; Emm[w] = amm(i, j); }
+        __syncthreads();
+        sw1 = jacobi_block(Emm, EV, m, m, cs, sn, pp, qq, sred);
+        if (VIO_TIMERS && t == 0) be.dbg[7] = (int)(VIO_CLOCK() - tx0);
+        for (int w = t; w < m * m; w += nt) {
+            const int i = w / m, j = w - i * m;
+            double sacc = 0;
+            for (int k = 0; k < m; k++) { const double ev = Emm[(size_t)k * m + k]; if (ev > eps) sacc += EV[(size_t)i * m + k] * EV[(size_t)j * m + k] / ev; }
+            Einv[w] = sacc;
         }
     }
     __syncthreads();
-    double acc = 0;
-    for (int k = t; k < n; k += nt) acc += c.prior_rf[k] * c.prior_rf[k];
-    const double c0 = block_sum(acc, sred);
+    // A_rm A_mm^-1 (:288-292); column k of A_rm: q-column k for the pose / speed-bias part, the coupling row of landmark k - md otherwise
+    for (int w = t; w < n * m; w += nt) {
+        const int i = w / m, j = w - i * m;
+        double sacc = 0;
+        for (int k = 0; k < md; k++) sacc += A[(md + i) * mq + k] * Einv[(size_t)k * m + j];
+        for (int k = md; k < m; k++) sacc += Cl[(size_t)(k - md) * ldc + md + i] * Einv[(size_t)k * m + j];
+        ET1[w] = sacc;
+    }
     __syncthreads();
-    if (t == 0) { be.prior_c0 = c0; be.dbg[0] = sw1 * 100 + sw2; be.dbg[2] = second_new ? 1 : 0; be.dbg[4] = m; }
+    for (int w = t; w < n * n; w += nt) {   // A = Arr - Arm Amm_inv Amr
+        const int i = w / n, j = w - i * n;
+        double tt = A[(md + i) * mq + md + j];
+        for (int k = 0; k < md; k++) tt -= ET1[(size_t)i * m + k] * A[k * mq + md + j];
+        for (int k = md; k < m; k++) tt -= ET1[(size_t)i * m + k] * Cl[(size_t)(k - md) * ldc + md + j];
+        Ar[w] = tt;
+    }
+    for (int i = t; i < n; i += nt) {       // b = brr - Arm Amm_inv bmm
+        double sacc = b[md + i];
+        for (int k = 0; k < md; k++) sacc -= ET1[(size_t)i * m + k] * b[k];
+        for (int k = md; k < m; k++) sacc -= ET1[(size_t)i * m + k] * c.gl[k - md];
+        br[i] = sacc;
+    }
+    __syncthreads();
+    if (VIO_TIMERS && t == 0) be.dbg[8] = (int)(VIO_CLOCK() - tx0);
+    // second eigen-decomposition and the prior (:293-315); A is free from here on (the fallback's eigenvector scratch)
+    const int sw2 = marg_literal_prior(c, be, Ar, br, n, c.margW, A, sred, smem);
+    if (VIO_TIMERS && t == 0) be.dbg[9] = (int)(VIO_CLOCK() - tx0);
+    if (t == 0) { be.dbg[0] = sw1 * 100 + sw2; be.dbg[2] = second_new ? 1 : 0; be.dbg[4] = m; }
     if (VIO_TIMERS && t == 0) be.dbg[10] = (int)(VIO_CLOCK() - tx0);
 }
 
@@ -2282,8 +2297,16 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
     // marg_exact: MarginalizationInfo::marginalize followed literally (marginalization_factor.cpp:281-315) -- the full m x m block of
     // pose 0, speed-bias 0 AND the landmarks that start in frame 0 goes through one truncated eigen-decomposition, and the new prior is
     // rebuilt from the truncated factors of the reduced system.  A parity instrument (one workgroup, Jacobi sweeps in HBM), not the hot path.
-    const bool exact = EXACT && cfg.marg_exact != 0 && c.margE != nullptr;
+    const bool exact = EXACT && cfg.marg_exact == 1 && c.margE != nullptr;
+    // marg_exact = 2 (round 5): the literal algorithm with its first eigen-decomposition replaced by a CERTIFIED inverse.  A_mm^+ of the
+    // reference (:281-283) equals A_mm^-1 whenever no eigenvalue of A_mm is at or below the 1e-8 cut; this mode eliminates the marginalised
+    // block exactly like the default one (landmarks analytically, the 15 x 15 / 6 x 6 rest by a Cholesky inverse) and PROVES per frame that
+    // nothing could have been truncated: lambda_min(A_mm) >= 1 / |A_mm^-1|_F, bounded from the blocks of the inverse (below).  The second
+    // half -- the factorisation of the new prior with its 1e-8 truncation, which does drop directions routinely -- is the literal one
+    // (marg_literal_prior).  Frames whose certificate fails are counted (BeSeq::dbg[12]) and take the same route.
+    const bool lit2 = EXACT && cfg.marg_exact == 2;
     int F0x = 0;   // landmarks in the marginalised block (exact mode)
+    int F0k = 0;   // landmarks eliminated analytically (the other modes)
     PH_INIT;
     const long long tk0 = VIO_CLOCK();
     // vector2double
@@ -2404,6 +2427,7 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
         const int per = W;  // max residuals per landmark
         int F0c = min(F0, c.nres_cap / per);
         if (exact) { F0c = min(F0c, min(C.MX - 15, 480)); F0x = F0c; }
+        F0k = F0c;
         // frame-pair form like the solver (be_factors.h eval_projection_pair): the geometry of the pairs (0, k) once, in LDS
         __shared__ double mgeo[(VIO_MAXW + 1) * 32 + 16];
         if (t >= 1 && t <= W) {
@@ -2656,6 +2680,45 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
     }
     __syncthreads();
     PH(21);
+    if (lit2) {
+        // certificate: |A_mm^-1|_F <= |S^-1|_F + 2 |T|_F + |D^-1|_F + |D^-1 B|_F |T|_F with A_mm = [[P, B^T], [B, D]], S = P - B^T D^-1 B (the
+        // block A15 above), T = S^-1 B^T D^-1; it needs D invertible (every landmark's d > eps) and the direct inverse of S
+        __shared__ int cert_bad;
+        if (t == 0) cert_bad = pinv_direct ? 0 : 1;
+        __syncthreads();
+        double n_t = 0, n_d = 0, n_db = 0;
+        if (!second_new) {
+            const double *Cl = c.Hpl;
+            const int ldc = c.LW;
+            for (int li = t; li < F0k; li += nt) {
+                const double dinv = c.Hll[li];           // 1 / d, or 0 where d <= eps (pseudo-inverse of the diagonal block)
+                if (!(dinv > 0.0)) cert_bad = 1;         // (benign race: every writer stores 1)
+                n_d += dinv * dinv;
+                for (int a = 0; a < md; a++) {
+                    double tt = 0;
+                    for (int bq = 0; bq < md; bq++) tt += Pinv[a * md + bq] * Cl[(size_t)li * ldc + bq];
+                    tt *= dinv;
+                    n_t += tt * tt;
+                    const double db = dinv * Cl[(size_t)li * ldc + a];
+                    n_db += db * db;
+                }
+            }
+        }
+        block_sum3(n_t, n_d, n_db, sred);
+        double n_s = 0;
+        for (int w = t; w < md * md; w += nt) n_s += Pinv[w] * Pinv[w];
+        n_s = block_sum(n_s, sred);
+        __syncthreads();
+        if (t == 0) {
+            const double bound = sqrt(n_s) + 2.0 * sqrt(n_t) + sqrt(n_d) + sqrt(n_db) * sqrt(n_t);
+            const bool certified = !cert_bad && isfinite(bound) && bound > 0.0 && 1.0 / bound > 1e-7;   // ten times the cut
+            be.dbg[11] = certified ? 1 : 0;
+            if (!certified) be.dbg[12] += 1;
+        }
+        __syncthreads();
+        const int sw2 = marg_literal_prior(c, be, Ar, br, n, c.margW, A, sred, smem_marg);
+        if (t == 0) { be.dbg[0] = sw2; be.dbg[2] = second_new ? 1 : 0; be.dbg[4] = md; }
+    } else {
     // ---- the new prior, kept as the quadratic form the solver consumes: A = sym(A_r), b = b_r, c0 = b^T A^+ b.
     // The reference factors A = V S V^T, drops eigenvalues <= 1e-8 and stores J = S^1/2 V^T, r = S^-1/2 V^T b
     // (marginalization_factor.cpp:293-315); J^T J, J^T r and |r|^2 are all the solver and the next marginalisation ever use, and
@@ -2695,6 +2758,7 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
         }
         __syncthreads();
         if (t == 0) { be.prior_c0 = c0; be.dbg[0] = 0; be.dbg[2] = second_new ? 1 : 0; }
+    }
     }
     }
     PH(22);

@@ -820,9 +820,11 @@ static int build_devcfg(const vio_config *cfg, int imu_capacity, DevCfg &C) {
         off += (sw * sh + 63) & ~63;
     }
     C.pyr_bytes = off;
-    if (c.marg_exact < 0 || c.marg_exact > 1) { g_err = "marg_exact must be 0 or 1"; return VIO_EINVAL; }
+    if (c.marg_exact < 0 || c.marg_exact > 2) { g_err = "marg_exact must be 0, 1 or 2"; return VIO_EINVAL; }
     if (c.equalize < 0 || c.equalize > 1) { g_err = "equalize must be 0 or 1"; return VIO_EINVAL; }
-    C.MX = c.marg_exact ? std::min(15 + C.NP, 495) : 0;   // a landmark that starts in frame 0 was packaged by the tracker in that frame: at most NP of them
+    // marg_exact 1: scratch for the full marginalised block (a landmark that starts in frame 0 was packaged by the tracker in that frame: at most NP
+    // of them); marg_exact 2 never forms that block (MX = 16 only selects be_marg_exact_kernel and its LDS budget)
+    C.MX = c.marg_exact == 1 ? std::min(15 + C.NP, 495) : (c.marg_exact == 2 ? 16 : 0);
     return VIO_OK;
 }
 
@@ -1175,7 +1177,9 @@ static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, 
     const int p = overlap ? g.flip : 0;
     if (overlap && !g.copy_stream) {
         HIPCHK(hipStreamCreate(&g.copy_stream));   // (one per group: a copy stream shared by the groups measured 27.9 k against 33.9 k frames/s from page-locked buffers)
-        if (!(getenv("VIO_COPY_STREAMS") && atoi(getenv("VIO_COPY_STREAMS")) == 1)) HIPCHK(hipStreamCreate(&g.copy_stream2));
+        // VIO_COPY_STREAMS = 2: the depth images on a second copy stream per group (measured: no gain, 26.4 k against 27.4 k frames/s from
+        // page-locked buffers -- the uploads of a step take 4.7 ms for 118 MB however they are spread over streams)
+        if (getenv("VIO_COPY_STREAMS") && atoi(getenv("VIO_COPY_STREAMS")) == 2) HIPCHK(hipStreamCreate(&g.copy_stream2));
         for (int q = 0; q < 2; q++) {
             HIPCHK(hipEventCreateWithFlags(&g.ev_up_gray[q], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&g.ev_up_depth[q], hipEventDisableTiming));
