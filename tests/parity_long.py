@@ -175,7 +175,7 @@ def run(P, S=128, seq0=700, n_frames=300, lag=0, modes=("fast", "exact"), procs=
         dump_dir = tempfile.mkdtemp(prefix="vio_frames_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     out["config"]["same_frames"] = bool(same_frames)
     for mode in modes:
-        cfg = P.canonical_config(marg_exact=1 if mode == "exact" else 0, **cfg_kw)
+        cfg = P.canonical_config(marg_exact={"exact": 1, "certified": 2}.get(mode, 0), **cfg_kw)   # fast / exact / certified = vio_config.marg_exact 0 / 1 / 2
         hist, stats, t_feed = run_hip(P, cfg, sc, seq0, S, n_frames, lag=lag, check_render=(mode == modes[0] and not same_frames),
                                       dump_dir=(dump_dir if mode == modes[0] else None))
         hip[mode] = (hist, stats, t_feed)
