@@ -21,11 +21,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seqs", type=int, default=16)
     ap.add_argument("--frames", type=int, default=24)
+    ap.add_argument("--mode", type=int, default=1, help="vio_config.marg_exact: 1 = every eigen-decomposition literal, 2 = certified first inverse")
     a = ap.parse_args()
     P = vio_ct.pkg()
     L = P.lib()
     L.vio_debug_seq.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-    cfg = P.canonical_config(marg_exact=1)
+    cfg = P.canonical_config(marg_exact=a.mode)
     sc = vio_ct.synth_like(cfg)
     syn = P.Synth(sc)
     S, n_pre = a.seqs, 26
@@ -55,8 +56,9 @@ def main():
     for row in rows[:: max(1, len(rows) // 60)]:
         print("%3d %3d %4d %5d %d | %8.0f | %8.0f %8.0f %8.0f %8.0f" % row)
     old = r[r[:, 4] == 0]
-    print("MARGIN_OLD frames: m mean %.0f max %.0f; share with m <= 104: %.2f; marg us mean %.0f max %.0f" % (
-        old[:, 2].mean(), old[:, 2].max(), (old[:, 2] <= 104).mean(), old[:, 5].mean(), old[:, 5].max()))
+    if len(old):
+        print("MARGIN_OLD frames: m mean %.0f max %.0f; share with m <= 104: %.2f; marg us mean %.0f max %.0f" % (
+            old[:, 2].mean(), old[:, 2].max(), (old[:, 2] <= 104).mean(), old[:, 5].mean(), old[:, 5].max()))
     print("all frames: marg us mean %.0f p90 %.0f max %.0f" % (r[:, 5].mean(), np.percentile(r[:, 5], 90), r[:, 5].max()))
 
 

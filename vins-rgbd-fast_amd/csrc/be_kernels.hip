@@ -2104,9 +2104,10 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
 #define MARG_EIG_AUX_DOUBLES (11 * EIG_LD)
 // Symmetric eigen-decomposition in LDS: A (n x n, ld) -> eigenvectors in place (columns), eigenvalues in d.  Householder tridiagonalisation over
 // the whole workgroup + implicit QL on one wavefront (be_linalg.h; the same pair be_prior_factor_kernel runs).  n <= 128 (tridiag_ql_wave).
-__device__ __forceinline__ void sym_eig_lds(double *Al, int n, int ld, double *aux) {
+__device__ __forceinline__ void sym_eig_lds(double *Al, int n, int ld, double *aux, bool one_wave) {
     double *d = aux, *e = aux + EIG_LD, *g = aux + 2 * EIG_LD, *part = aux + 3 * EIG_LD;
-    sym_eig_tridiag_mt(Al, n, ld, d, e, g, part);
+    if (one_wave) sym_eig_tridiag(Al, n, ld, d, e, g, part);   // one wavefront, wave-level ordering only (the others wait at its final barrier)
+    else sym_eig_tridiag_mt(Al, n, ld, d, e, g, part);
     tridiag_ql_wave(Al, n, ld, d, e);
 }
 // The SECOND half of MarginalizationInfo::marginalize (marginalization_factor.cpp:293-315), literally: saes2(A), S = eigenvalues > 1e-8,
@@ -2126,7 +2127,7 @@ __device__ __noinline__ int marg_literal_prior(const Ctx &c, BeSeq &be, const do
         double *Al = (double *)marg_dyn_lds, *aux = Al + (size_t)n * ld;
         for (int w = t; w < n * n; w += nt) { const int i = w / n, j = w - i * n; Al[i * ld + j] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
         __syncthreads();
-        sym_eig_lds(Al, n, ld, aux);   // SelfAdjointEigenSolver<MatrixXd> saes2(A) (:298)
+        sym_eig_lds(Al, n, ld, aux, c.C->eig_one_wave != 0);   // SelfAdjointEigenSolver<MatrixXd> saes2(A) (:298)
         for (int k = t; k < n; k += nt) {
             const double ev = aux[k];
             double vb = 0;
@@ -2222,7 +2223,7 @@ __device__ void marg_exact_finish(const Ctx &c, BeSeq &be, double *A, const doub
         double *Al = (double *)marg_dyn_lds, *aux = Al + (size_t)m * ld;
         for (int w = t; w < m * m; w += nt) { const int i = w / m, j = w - i * m; Al[i * ld + j] = amm(i, j); }
         __syncthreads();
-        sym_eig_lds(Al, m, ld, aux);
+        sym_eig_lds(Al, m, ld, aux, c.C->eig_one_wave != 0);
         if (VIO_TIMERS && t == 0) be.dbg[7] = (int)(VIO_CLOCK() - tx0);
         // Amm_inv = V diag(lambda > eps ? 1 / lambda : 0) V^T (:281-283); 1 / lambda once per column
         for (int k = t; k < m; k += nt) { const double ev = aux[k]; aux[EIG_LD + k] = ev > eps ? 1.0 / ev : 0.0; }

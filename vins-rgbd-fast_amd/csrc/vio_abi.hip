@@ -161,16 +161,20 @@ struct vio_batch {
 // configurations alive, keep the largest value ever requested (monotonic), otherwise the handle created last would shrink the
 // limit under the others.
 static int raise_lds_limit(const void *fn, size_t bytes) {
+    // the attribute belongs to the function ON THE CURRENT DEVICE (a handle per GPU in one process sets it once per device)
+    struct Seen { const void *fn; int dev; size_t bytes; };
     static std::mutex mu;
-    static std::vector<std::pair<const void *, size_t>> seen;
+    static std::vector<Seen> seen;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lk(mu);
     for (auto &e : seen)
-        if (e.first == fn) {
-            if (bytes <= e.second) return 0;
-            e.second = bytes;
+        if (e.fn == fn && e.dev == dev) {
+            if (bytes <= e.bytes) return 0;
+            e.bytes = bytes;
             return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
         }
-    seen.push_back({fn, bytes});
+    seen.push_back({fn, dev, bytes});
     return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess ? 0 : -1;
 }
 
@@ -888,6 +892,7 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
     DevGuard dev_guard(h);   // every allocation, stream and event below is created on h->device; the caller's device is current again on return
     if (build_devcfg(cfg, imu_capacity, h->hc) != VIO_OK) { delete h; return nullptr; }
     h->hc.MXL = 0;
+    h->hc.eig_one_wave = getenv("VIO_EIG_ONE_WAVE") ? (atoi(getenv("VIO_EIG_ONE_WAVE")) != 0) : 0;
     if (h->hc.MX > 0) {
         // marg_exact: the eigen-decompositions of the literal marginalisation run LDS-resident for blocks up to MXL -- whatever the kernel's
         // static LDS leaves of the workgroup's share (matrix with an odd leading dimension + the solver's vectors, be_kernels.hip
