@@ -59,8 +59,9 @@ def _run_both(P, cfg, sc, seq, n_frames, frames):
 
 
 def _compare(o, lm_o, traj, stat, lm_h, n_frames, pos_tol, depth_tol=1e-6, exact_frames=30):
-    """tables equal every frame; returns (bounded landmark-solves counted from the HIP tables, worst relative depth difference)"""
-    worst, n_tri, bounded_h = 0.0, 0, 0
+    """status and landmark tables equal after every frame (flags, dynamic marks, observation counts; depths to depth_tol), positions to pos_tol;
+    returns the worst relative depth difference"""
+    worst, n_tri = 0.0, 0
     for f in range(n_frames):
         so, sh = o["status"][f], stat[f]
         assert (int(so["solver_flag"]), int(so["frame_count"]), int(so["n_landmarks"])) == (sh.solver_flag, sh.frame_count, sh.n_landmarks), f
