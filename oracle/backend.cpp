@@ -1104,7 +1104,10 @@ void Estimator::solve() {
         }
     }
     const int F = (int)lms.size();
-    for (const auto &r : lms) if (r.ub < DBL_MAX && !r.is_const) bounded_landmark_solves++;
+    // Ceres: Program::IsBoundsConstrained() of the reduced program -- any NON-constant block with a finite bound (estimator.cpp:1282-1297)
+    bool constrained = false;
+    for (const auto &r : lms) if (r.ub < DBL_MAX && !r.is_const) { bounded_landmark_solves++; constrained = true; }
+    if (cfg.reference_quirks & 8) constrained = false;   // test switch (NOT a reference behaviour): rounds 1 - 5's clamp-only treatment of the bound
     // constness (estimator.cpp:1187-1212)
     std::vector<uint8_t> active(P, 1);
     bool ex_active;
@@ -1134,6 +1137,23 @@ void Estimator::solve() {
     std::vector<double> feat = para_Feature;
     double relo[7], crelo[7];
     std::memcpy(relo, relo_Pose, sizeof(relo));
+    auto plus_pose = [](double *x, const double *d) {  // PoseLocalParameterization::Plus
+        x[0] += d[0]; x[1] += d[1]; x[2] += d[2];
+        Q q(x[6], x[3], x[4], x[5]);
+        Q r = normalized(q * deltaQ(V3(d[3], d[4], d[5])));
+        x[3] = r.x; x[4] = r.y; x[5] = r.z; x[6] = r.w;
+    };
+    if (constrained) {
+        // TrustRegionMinimizer::IterationZero on a bounds-constrained program: x <- Plus(x, 0), i.e. every non-constant block goes through its
+        // local parameterisation once (the quaternions are re-normalised) and is PROJECTED onto the box (ParameterBlock::Plus) before the
+        // first evaluation -- a depth-less landmark triangulated nearer than DEPTH_MAX_DIST / 2 starts the solve on the bound
+        const double zero6[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = 0; k <= W; k++) if (cfg.use_imu || k > 0) plus_pose(pose[k], zero6);
+        if (ex_active) plus_pose(ex, zero6);
+        if (relo_on) plus_pose(relo, zero6);
+        for (int li = 0; li < F; li++)
+            if (!lms[li].is_const && feat[li] > lms[li].ub) { feat[li] = lms[li].ub; bound_clamps++; }
+    }
 
     NormalEq ne, ne2;
     build_normal_eq(*this, pose, sb, ex, tdv, feat, lms, ne, true, relo_on ? relo : nullptr);
@@ -1291,32 +1311,80 @@ void Estimator::solve() {
             continue;
         }
         invalid = 0;
-        // candidate = Plus(x, step .* scale)
+        // candidate = Plus(x, alpha * step .* scale), projected onto the box (ParameterBlock::Plus clamps to the bounds)
         double cpose[MAXW + 1][7], csb[MAXW + 1][9], cex[7], ctd = tdv;
-        std::memcpy(cpose, pose, sizeof(pose)); std::memcpy(csb, sb, sizeof(sb)); std::memcpy(cex, ex, sizeof(ex));
-        std::vector<double> cfeat = feat;
-        std::vector<double> delta(P, 0.0);
+        std::vector<double> cfeat;
+        std::vector<double> delta(P, 0.0), dlm(Fa);
         for (int a = 0; a < Pa; a++) delta[act[a]] = stp[a] * sp[a];
-        auto plus_pose = [](double *x, const double *d) {  // PoseLocalParameterization::Plus
-            x[0] += d[0]; x[1] += d[1]; x[2] += d[2];
-            Q q(x[6], x[3], x[4], x[5]);
-            Q r = normalized(q * deltaQ(V3(d[3], d[4], d[5])));
-            x[3] = r.x; x[4] = r.y; x[5] = r.z; x[6] = r.w;
+        for (int k = 0; k < Fa; k++) dlm[k] = stl[k] * sl[k];
+        auto make_candidate = [&](double alpha) {
+            std::memcpy(cpose, pose, sizeof(pose)); std::memcpy(csb, sb, sizeof(sb)); std::memcpy(cex, ex, sizeof(ex));
+            ctd = tdv;
+            cfeat = feat;
+            std::vector<double> sd(P);
+            for (int a = 0; a < P; a++) sd[a] = alpha * delta[a];   // LineSearchFunction: scaled_direction = x * direction (alpha = 1: delta itself)
+            for (int k = 0; k <= W; k++) {
+                plus_pose(cpose[k], &sd[6 * k]);
+                for (int d = 0; d < 9; d++) csb[k][d] += sd[6 * (W + 1) + 9 * k + d];
+            }
+            if (ex_active) plus_pose(cex, &sd[oE]);
+            if (td_active) ctd += sd[oT];
+            std::memcpy(crelo, relo, sizeof(relo));
+            if (relo_on) plus_pose(crelo, &sd[oR]);
+            for (int k = 0; k < Fa; k++) {
+                int li = lact[k];
+                cfeat[li] += alpha * dlm[k];
+                if (cfeat[li] > lms[li].ub) { cfeat[li] = lms[li].ub; bound_clamps++; }  // projection onto the box
+            }
         };
-        for (int k = 0; k <= W; k++) {
-            plus_pose(cpose[k], &delta[6 * k]);
-            for (int d = 0; d < 9; d++) csb[k][d] += delta[6 * (W + 1) + 9 * k + d];
+        bool have_ne2 = false;
+        if (constrained) {
+            // TrustRegionMinimizer::DoLineSearch -> ArmijoLineSearch::DoSearch (line_search.cc; Solver::Options defaults: CUBIC interpolation,
+            // sufficient decrease 1e-4, contraction in [1e-3, 0.6], at most 20 iterations, min step 1e-9): the step is shortened until
+            // f(Plus(x, a delta)) <= f(x) + 1e-4 a g^T delta; on success delta *= a, on failure delta is left as it was.  The model cost
+            // change and the dogleg norm of the FULL step keep driving the trust-region logic below, as in Ceres.
+            double g0 = 0, dmax = 0;   // initial_gradient = gradient . delta; LineSearchFunction::DirectionInfinityNorm
+            for (int a = 0; a < Pa; a++) { g0 += delta[act[a]] * ne.g[act[a]]; dmax = std::max(dmax, std::fabs(delta[act[a]])); }
+            for (int k = 0; k < Fa; k++) { g0 += dlm[k] * ne.gl[lact[k]]; dmax = std::max(dmax, std::fabs(dlm[k])); }
+            LsSample lower = {0.0, cost, g0, 1}, previous = {0, 0, 0, 0}, current = {0, 0, 0, 0};
+            auto ls_eval = [&](double a) {
+                make_candidate(a);
+                build_normal_eq(*this, cpose, csb, cex, ctd, cfeat, lms, ne2, true, relo_on ? crelo : nullptr);
+                line_search_evals++;
+                double gd = 0;
+                for (int q = 0; q < Pa; q++) gd += delta[act[q]] * ne2.g[act[q]];
+                for (int k = 0; k < Fa; k++) gd += dlm[k] * ne2.gl[lact[k]];
+                current.x = a; current.value = ne2.cost; current.gradient = gd;
+                current.valid = std::isfinite(ne2.cost) && std::isfinite(gd);
+            };
+            // test hook (tests/test_oracle_linesearch_cpu.py): every search as raw doubles -- header (-1, cost, g0, dmax, candidates clamped at
+            // alpha = 1), one row (alpha, value, gradient, valid, 0) per trial, trailer (-2, chosen alpha, success, 0, 0)
+            FILE *lsfp = nullptr;
+            if (const char *dump = std::getenv("OVIO_DUMP_LS")) lsfp = std::fopen(dump, "ab");
+            const long clamps_before = bound_clamps;
+            ls_eval(1.0);
+            if (lsfp) { double row[5] = {-1.0, cost, g0, dmax, (double)(bound_clamps - clamps_before)}; std::fwrite(row, 8, 5, lsfp); }
+            auto dump_trial = [&]() { if (lsfp) { double row[5] = {current.x, current.value, current.gradient, (double)current.valid, 0.0}; std::fwrite(row, 8, 5, lsfp); } };
+            dump_trial();
+            int ls_it = 0;
+            bool ls_ok = true;
+            while (!current.valid || current.value > cost + 1e-4 * g0 * current.x) {
+                if (++ls_it >= 20) { ls_ok = false; break; }
+                const double a = ls_next_step(lower, previous, current, 1e-3 * current.x, 0.6 * current.x);
+                if (a * dmax < 1e-9) { ls_ok = false; break; }
+                previous = current;
+                ls_eval(a);
+                dump_trial();
+                line_search_contractions++;
+            }
+            if (lsfp) { double row[5] = {-2.0, ls_ok ? current.x : 1.0, ls_ok ? 1.0 : 0.0, 0.0, 0.0}; std::fwrite(row, 8, 5, lsfp); std::fclose(lsfp); }
+            // success: the candidate IS the last sample (same vector alpha * delta, same Plus); failure: the full step, evaluated again
+            have_ne2 = ls_ok || current.x == 1.0;
         }
-        if (ex_active) plus_pose(cex, &delta[oE]);
-        if (td_active) ctd += delta[oT];
-        std::memcpy(crelo, relo, sizeof(relo));
-        if (relo_on) plus_pose(crelo, &delta[oR]);
-        for (int k = 0; k < Fa; k++) {
-            int li = lact[k];
-            cfeat[li] += stl[k] * sl[k];
-            if (cfeat[li] > lms[li].ub) { cfeat[li] = lms[li].ub; bound_clamps++; }  // projection onto the box (line search omitted)
+        if (!have_ne2) {
+            make_candidate(1.0);
+            build_normal_eq(*this, cpose, csb, cex, ctd, cfeat, lms, ne2, true, relo_on ? crelo : nullptr);
         }
-        build_normal_eq(*this, cpose, csb, cex, ctd, cfeat, lms, ne2, true, relo_on ? crelo : nullptr);
         // parameter tolerance
         double xn = 0, dn = 0;
         for (int k = 0; k <= W; k++) {

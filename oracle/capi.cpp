@@ -101,6 +101,18 @@ void ovio_get_bound_stats(void *h, double *out2) {
     const Estimator &e = ((Pipeline *)h)->est;
     out2[0] = (double)e.bound_clamps; out2[1] = (double)e.bounded_landmark_solves;
 }
+// out2 = (trial evaluations, shortened steps) of the Armijo line search of bounds-constrained solves since construction
+void ovio_get_line_search_stats(void *h, double *out2) {
+    const Estimator &e = ((Pipeline *)h)->est;
+    out2[0] = (double)e.line_search_evals; out2[1] = (double)e.line_search_contractions;
+}
+// the scalar step of the line search on its own (tests): samples = rows (x, value, gradient, valid) lower / previous / current
+double ovio_ls_next_step(const double *lower, const double *previous, const double *current, double lo, double hi) {
+    om::LsSample a = {lower[0], lower[1], lower[2], (int)lower[3]}, b = {previous[0], previous[1], previous[2], (int)previous[3]},
+                 c = {current[0], current[1], current[2], (int)current[3]};
+    return om::ls_next_step(a, b, c, lo, hi);
+}
+int ovio_poly_roots_real(const double *c, int n, double *re) { return om::ls_poly_roots_real(c, n, re); }
 // window arrays, each (W+1) rows: P(3) Q(wxyz 4) V(3) Ba(3) Bg(3) stamp(1) = 17 doubles per frame
 void ovio_get_window(void *h, double *out) {
     Estimator &e = ((Pipeline *)h)->est;

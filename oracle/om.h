@@ -160,6 +160,148 @@ SINCOS_DET_QUAL void sincos_det(double x, double *sn, double *cs) {
     *cs = q == 0 ? c0 : (q == 1 ? -s0 : (q == 2 ? -c0 : s0));
 }
 #undef SINCOS_DET_QUAL
+#define LS1D_QUAL inline
+// ---- LS1D: the one-dimensional part of Ceres' projected Armijo line search (bounds-constrained programs) ----------------------------------
+// TrustRegionMinimizer::DoLineSearch runs ArmijoLineSearch (line_search.cc) with CUBIC interpolation along the trust-region step whenever the
+// program has a bounded parameter (estimator.cpp:1282-1297 puts an upper bound on the inverse depth of depth-less landmarks).  This block is
+// the scalar machinery of that search -- LineSearch::InterpolatingPolynomialMinimizingStepSize, polynomial.cc FindInterpolatingPolynomial /
+// MinimizePolynomial / FindPolynomialRoots -- restated from Ceres 2.x's published algorithm (Ceres is not in the image).  Samples
+// carry value AND gradient (CUBIC): two samples give a cubic, three a quintic.  Ceres finds the critical points as the eigenvalues of the
+// balanced companion matrix; here degree 1 and 2 use Ceres' closed forms and degree 3 / 4 a Durand-Kerner iteration on the monic polynomial
+// (same roots to ~1e-15; like Ceres, the REAL PARTS of all roots are candidates).  Only + - * / sqrt: the same bits on the host and on gfx950.
+// THE SAME TEXT lives in oracle/om.h and csrc/dmath.h.
+struct LsSample { double x, value, gradient; int valid; };
+LS1D_QUAL double ls_poly_eval(const double *c, int n, double x) {   // n coefficients, highest degree first (Horner, EvaluatePolynomial)
+    double v = 0.0;
+    for (int i = 0; i < n; i++) v = v * x + c[i];
+    return v;
+}
+// real parts of all roots of the polynomial c[0 .. n-1] (highest degree first, n <= 5); returns how many
+LS1D_QUAL int ls_poly_roots_real(const double *cin, int nin, double *re) {
+    int lead = 0;
+    while (lead < nin - 1 && cin[lead] == 0.0) lead++;   // RemoveLeadingZeros
+    const double *c = cin + lead;
+    const int deg = nin - lead - 1;
+    if (deg <= 0) return 0;
+    if (deg == 1) { re[0] = -c[1] / c[0]; return 1; }
+    if (deg == 2) {   // FindQuadraticPolynomialRoots (BKP Horn's stable form)
+        const double a = c[0], b = c[1], cc = c[2];
+        const double D = b * b - 4 * a * cc;
+        const double sD = sqrt(fabs(D));
+        if (D >= 0) {
+            if (b >= 0) { re[0] = (-b - sD) / (2.0 * a); re[1] = (2.0 * cc) / (-b - sD); }
+            else { re[0] = (2.0 * cc) / (-b + sD); re[1] = (-b + sD) / (2.0 * a); }
+        } else { re[0] = -b / (2.0 * a); re[1] = -b / (2.0 * a); }
+        return 2;
+    }
+    // degree 3 / 4: Durand-Kerner on the monic polynomial, start points on a circle of the Cauchy root bound
+    double m[5];
+    double bound = 0.0;
+    for (int i = 0; i <= deg; i++) { m[i] = c[i] / c[0]; if (i > 0 && fabs(m[i]) > bound) bound = fabs(m[i]); }
+    bound = 1.0 + bound;
+    double zr[4], zi[4];
+    {
+        double pr = 1.0, pi = 0.0;   // powers of 0.4 + 0.9 i (not a root of unity, not real)
+        for (int k = 0; k < deg; k++) { zr[k] = bound * pr; zi[k] = bound * pi; const double nr = pr * 0.4 - pi * 0.9, ni = pr * 0.9 + pi * 0.4; pr = nr; pi = ni; }
+    }
+    for (int it = 0; it < 500; it++) {
+        double change = 0.0, size = 0.0;
+        for (int k = 0; k < deg; k++) {
+            double vr = 1.0, vi = 0.0;   // p(z_k), Horner in complex arithmetic
+            for (int i = 1; i <= deg; i++) { const double nr = vr * zr[k] - vi * zi[k] + m[i], ni = vr * zi[k] + vi * zr[k]; vr = nr; vi = ni; }
+            double dr = 1.0, di = 0.0;   // prod_{j != k} (z_k - z_j)
+            for (int j = 0; j < deg; j++) {
+                if (j == k) continue;
+                const double er = zr[k] - zr[j], ei = zi[k] - zi[j];
+                const double nr = dr * er - di * ei, ni = dr * ei + di * er;
+                dr = nr; di = ni;
+            }
+            const double dn = dr * dr + di * di;
+            if (dn == 0.0) continue;
+            const double qr = (vr * dr + vi * di) / dn, qi = (vi * dr - vr * di) / dn;
+            zr[k] -= qr; zi[k] -= qi;
+            change += fabs(qr) + fabs(qi);
+            size += fabs(zr[k]) + fabs(zi[k]);
+        }
+        if (change <= 1e-16 * size) break;
+    }
+    for (int k = 0; k < deg; k++) re[k] = zr[k];
+    return deg;
+}
+// FindInterpolatingPolynomial: value and gradient of ns samples (ns = 2, 3) -> 2 ns coefficients, highest degree first; Gaussian elimination
+// with full pivoting (Eigen::FullPivLU with threshold 0)
+LS1D_QUAL void ls_fit_poly(const LsSample *s, int ns, double *coef) {
+    const int n = 2 * ns, degree = n - 1;
+    double A[6][7];
+    for (int i = 0; i < ns; i++) {
+        for (int j = 0; j <= degree; j++) {
+            double pw = 1.0;
+            for (int e = 0; e < degree - j; e++) pw *= s[i].x;
+            A[2 * i][j] = pw;
+            double pd = 0.0;
+            if (j < degree) { pd = (double)(degree - j); for (int e = 0; e < degree - j - 1; e++) pd *= s[i].x; }
+            A[2 * i + 1][j] = pd;
+        }
+        A[2 * i][n] = s[i].value;
+        A[2 * i + 1][n] = s[i].gradient;
+    }
+    int colp[6];
+    for (int j = 0; j < n; j++) colp[j] = j;
+    for (int k = 0; k < n; k++) {
+        int pr = k, pc = k;
+        double best = -1.0;
+        for (int i = k; i < n; i++) for (int j = k; j < n; j++) if (fabs(A[i][j]) > best) { best = fabs(A[i][j]); pr = i; pc = j; }
+        if (best <= 0.0) break;
+        if (pr != k) for (int j = 0; j <= n; j++) { const double t = A[k][j]; A[k][j] = A[pr][j]; A[pr][j] = t; }
+        if (pc != k) { for (int i = 0; i < n; i++) { const double t = A[i][k]; A[i][k] = A[i][pc]; A[i][pc] = t; } const int t = colp[k]; colp[k] = colp[pc]; colp[pc] = t; }
+        for (int i = k + 1; i < n; i++) {
+            const double f = A[i][k] / A[k][k];
+            for (int j = k; j <= n; j++) A[i][j] -= f * A[k][j];
+        }
+    }
+    double y[6];
+    for (int k = n - 1; k >= 0; k--) {
+        double acc = A[k][n];
+        for (int j = k + 1; j < n; j++) acc -= A[k][j] * y[j];
+        y[k] = A[k][k] != 0.0 ? acc / A[k][k] : 0.0;
+    }
+    for (int k = 0; k < n; k++) coef[colp[k]] = y[k];
+}
+// LineSearch::InterpolatingPolynomialMinimizingStepSize (CUBIC) + MinimizeInterpolatingPolynomial: the next trial step in [lo, hi]
+LS1D_QUAL double ls_next_step(const LsSample &lower, const LsSample &previous, const LsSample &current, double lo, double hi) {
+    if (!current.valid) { const double h = current.x * 0.5; return h < lo ? (lo < hi ? lo : hi) : (h < hi ? h : hi); }   // min(max(x / 2, lo), hi)
+    LsSample smp[3];
+    int ns = 0;
+    smp[ns++] = lower;
+    smp[ns++] = current;
+    if (previous.valid) smp[ns++] = previous;
+    double coef[6];
+    ls_fit_poly(smp, ns, coef);
+    const int n = 2 * ns;
+    // MinimizePolynomial: the middle of the interval first, then the ends, then the critical points inside
+    double best_x = (lo + hi) / 2.0, best_v = ls_poly_eval(coef, n, best_x);
+    const double vlo = ls_poly_eval(coef, n, lo);
+    if (vlo < best_v) { best_v = vlo; best_x = lo; }
+    const double vhi = ls_poly_eval(coef, n, hi);
+    if (vhi < best_v) { best_v = vhi; best_x = hi; }
+    double der[5], roots[4];
+    for (int i = 0; i < n - 1; i++) der[i] = (double)(n - 1 - i) * coef[i];   // DifferentiatePolynomial
+    const int nr = ls_poly_roots_real(der, n - 1, roots);
+    for (int i = 0; i < nr; i++) {
+        const double r = roots[i];
+        if (r < lo || r > hi) continue;
+        const double v = ls_poly_eval(coef, n, r);
+        if (v < best_v) { best_v = v; best_x = r; }
+    }
+    for (int i = 0; i < ns; i++) {   // MinimizeInterpolatingPolynomial: the samples themselves
+        if (smp[i].x < lo || smp[i].x > hi) continue;
+        const double v = ls_poly_eval(coef, n, smp[i].x);
+        if (v < best_v) { best_v = v; best_x = smp[i].x; }
+    }
+    return best_x;
+}
+// ---- end LS1D ----------------------------------------------------------------------------------------------------------------------------
+#undef LS1D_QUAL
 inline Q deltaQ(const V3 &theta) { return Q(1.0, theta.x / 2, theta.y / 2, theta.z / 2); }  // utility.h:11-24 (unnormalised)
 
 inline V3 R2ypr(const M3 &R) {  // utility.h:66-81 (degrees)

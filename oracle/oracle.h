@@ -239,6 +239,7 @@ struct Estimator {
     // bounded landmarks (estimate_flag == 2) entered solves: Ceres would run its projected line search in exactly those steps
     // (DESIGN.md deviation 5); tests/test_oracle_kat.py measures that the canonical workload never gets there
     long bound_clamps = 0, bounded_landmark_solves = 0;
+    long line_search_evals = 0, line_search_contractions = 0;   // Armijo line search of bounds-constrained solves (trial evaluations, shortened steps)
     // relocalisation inside optimization() (estimator.h:173-186, estimator.cpp:1307-1346, 1034-1056 / 1071-1090, 1728-1747): the pose of
     // the window frame matched with an old keyframe gets a copy relo_Pose that is optimised against the old keyframe's observations
     bool relocalization_info = false;

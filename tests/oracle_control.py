@@ -161,7 +161,7 @@ def summarise(rows):
 def cmd_run(a):
     os.makedirs(a.scratch, exist_ok=True)
     import vio_ct
-    for so in {v[0] for v in VARIANTS.values()}:
+    for so in {v[0] for k, v in VARIANTS.items() if not a.only or k in a.only.split(",")}:
         vio_ct.oracle(os.path.join(vio_ct.ORACLE_DIR, so))   # build what is missing before the pool starts
     jobs = []
     for i in range(a.seqs):
@@ -243,6 +243,39 @@ def cmd_assemble(a):
         print("lag-1 fixture: %d sequences, mean ATE %.4f mm, reboots %d -> %s" % (n, ate.mean() * 1e3, reb.sum(), a.fixture))
 
 
+def cmd_fixtures(a):
+    """round 6 (one deterministic renderer + the projected line search in the oracle): the three committed fixtures from ONE pass that ran
+    `run --only base,lag1` over all sequences -- tests/golden/oracle_ate_300.npz (lag 0), oracle_ate_300_lag1.npz (lag 1) and the per-frame
+    decisions of the first --control sequences (oracle_decisions_300.npz, what tools/flip_census.py compares the HIP path with)"""
+    import vio_ct
+    have = sorted(int(f[4:9]) for f in os.listdir(a.scratch) if f.startswith("seq_") and f.endswith(".npz") and ".tmp" not in f)
+    assert have == list(range(a.seq0, a.seq0 + a.seqs)), "scratch holds %d sequences, wanted %d from %d" % (len(have), a.seqs, a.seq0)
+    Z = {s: dict(np.load(os.path.join(a.scratch, "seq_%05d.npz" % s))) for s in have}
+    n = len(have)
+    for nm, lag, path in (("base", 0, os.path.join(HERE, "golden", "oracle_ate_300.npz")), ("lag1", 1, a.fixture)):
+        ate = np.zeros(n); nfr = np.zeros(n, np.int32); reb = np.zeros(n, np.int32); first = np.zeros(n, np.int32)
+        pos = np.zeros((min(a.keep, n), a.frames, 3))
+        for i, s_ in enumerate(have):
+            z = Z[s_]
+            fr, po = z[nm + "_frames"], z[nm + "_pos"]
+            gt = z["gt"] if len(z["gt"]) == len(po) else None
+            assert gt is not None and np.array_equal(z["gt_frames"], fr), s_
+            ate[i] = vio_ct.ate_rmse(po, gt); nfr[i] = len(po); reb[i] = int(z[nm + "_reboots"]); first[i] = fr[0]
+            if i < len(pos):
+                pos[i, fr] = po
+        assert np.isfinite(ate).all()
+        kw = dict(tracker_lag=1) if lag else {}
+        np.savez_compressed(path, seq0=have[0], frames=a.frames, ate=ate, n_rows=nfr, reboots=reb, first_frame=first, positions=pos, **kw)
+        print("lag-%d fixture: %d sequences, mean ATE %.4f mm, reboots %d -> %s" % (lag, n, ate.mean() * 1e3, reb.sum(), path))
+    ctl = have[:a.control]
+    dec = np.zeros((2, len(ctl), a.frames, len(STATUS_KEYS)), np.int16)   # [tracker lag][sequence][frame][STATUS_KEYS]
+    for i, s_ in enumerate(ctl):
+        for li, nm in enumerate(("base", "lag1")):
+            st = Z[s_][nm + "_status"]
+            dec[li, i, :len(st)] = st
+    np.savez_compressed(os.path.join(HERE, "golden", "oracle_decisions_300.npz"), seq0=ctl[0], frames=a.frames, keys=np.array(STATUS_KEYS), decisions=dec)
+
+
 def early_rows(za, na, nb, n_early=30):
     """largest distance of two runs over the first n_early published positions (the window in which implementations still agree)"""
     pa, pb = za[na + "_pos"], za[nb + "_pos"]
@@ -290,7 +323,7 @@ def cmd_attribution(a):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("cmd", choices=("run", "assemble", "attribution"))
+    ap.add_argument("cmd", choices=("run", "assemble", "attribution", "fixtures"))
     ap.add_argument("--seqs", type=int, default=1024)
     ap.add_argument("--control", type=int, default=128, help="leading sequences that also run the control variants")
     ap.add_argument("--seq0", type=int, default=700)
@@ -303,7 +336,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "round4_oracle_self_divergence.json"))
     ap.add_argument("--fixture", default=os.path.join(HERE, "golden", "oracle_ate_300_lag1.npz"))
     a = ap.parse_args()
-    {"run": cmd_run, "assemble": cmd_assemble, "attribution": cmd_attribution}[a.cmd](a)
+    {"run": cmd_run, "assemble": cmd_assemble, "attribution": cmd_attribution, "fixtures": cmd_fixtures}[a.cmd](a)
 
 
 if __name__ == "__main__":

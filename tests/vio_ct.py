@@ -67,7 +67,7 @@ def oracle(path=None):
             "ovio_get_landmarks_ex": [C.c_void_p, C.c_int, C.c_void_p],
             "ovio_gate_create": [C.c_int, C.c_int], "ovio_gate_destroy": [C.c_void_p], "ovio_gate_step": [C.c_void_p, C.c_double],
             "ovio_gate_empty_map": [C.c_void_p, C.c_double],
-            "ovio_get_status": [C.c_void_p, C.c_void_p], "ovio_get_bound_stats": [C.c_void_p, C.c_void_p], "ovio_get_window": [C.c_void_p, C.c_void_p],
+            "ovio_get_status": [C.c_void_p, C.c_void_p], "ovio_get_bound_stats": [C.c_void_p, C.c_void_p], "ovio_get_line_search_stats": [C.c_void_p, C.c_void_p], "ovio_get_window": [C.c_void_p, C.c_void_p],
             "ovio_get_extrinsic": [C.c_void_p, C.c_void_p], "ovio_get_landmarks": [C.c_void_p, C.c_int, C.c_void_p],
             "ovio_get_tracks": [C.c_void_p, C.c_int] + [C.c_void_p] * 5,
             "ovio_tracker_create": [C.c_void_p], "ovio_tracker_destroy": [C.c_void_p],
@@ -172,6 +172,12 @@ class OraclePipeline:
         """(candidate steps cut by the inverse-depth upper bound, bounded landmarks that entered solves) since construction"""
         o = np.zeros(2)
         self.L.ovio_get_bound_stats(self.h, o.ctypes.data)
+        return int(o[0]), int(o[1])
+
+    def line_search_stats(self):
+        """(trial evaluations, shortened steps) of the Armijo line search of bounds-constrained solves since construction"""
+        o = np.zeros(2)
+        self.L.ovio_get_line_search_stats(self.h, o.ctypes.data)
         return int(o[0]), int(o[1])
 
     def status(self):

@@ -2,6 +2,7 @@
 #include "synth_scene.h"
 #include <string.h>
 #include <vector>
+#include <mutex>
 
 using namespace vsyn;
 
@@ -139,11 +140,41 @@ void vio_synth_render_host(const vio_synth_config *c, uint64_t seq, double t, ui
         cp.p[i] = (float)(p[i] + R[i * 3 + 0] * c->tic[0] + R[i * 3 + 1] * c->tic[1] + R[i * 3 + 2] * c->tic[2]);
     }
     uint32_t seed = (uint32_t)((c->seed + seq) & 0xFFFFFFFFu);
+    // the undistorted ray of every pixel depends on the camera only: computed once per camera (the device renderer keeps the same table)
+    static std::mutex mu;
+    static std::vector<float> rays;
+    static vio_synth_config key;
+    static bool valid = false;
+    const float *rp;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        const bool same = valid && key.width == c->width && key.height == c->height && key.fx == c->fx && key.fy == c->fy && key.cx == c->cx &&
+                          key.cy == c->cy && key.k1 == c->k1 && key.k2 == c->k2 && key.p1 == c->p1 && key.p2 == c->p2;
+        if (!same) {
+            // (a new table, never resized in place: another thread may still be rendering from the old one -- it keeps its copy alive below)
+            std::vector<float> nr((size_t)c->width * c->height * 2);
+            for (int y = 0; y < c->height; y++)
+                for (int x = 0; x < c->width; x++) {
+                    double rx, ry;
+                    syn_lift(c, (double)x, (double)y, &rx, &ry);
+                    nr[2 * ((size_t)y * c->width + x)] = (float)rx;
+                    nr[2 * ((size_t)y * c->width + x) + 1] = (float)ry;
+                }
+            rays.swap(nr);
+            key = *c;
+            valid = true;
+        }
+    }
+    std::vector<float> mine;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        mine = rays;   // 2.4 MB copy per frame (a frame costs ~100 ms): no lifetime questions when cameras alternate between threads
+    }
+    rp = mine.data();
     for (int y = 0; y < c->height; y++)
         for (int x = 0; x < c->width; x++) {
-            double rx, ry;
-            syn_lift(c, (double)x, (double)y, &rx, &ry);
-            render_pixel(seed, cp, (float)rx, (float)ry, &gray[(size_t)y * c->width + x], &depth_mm[(size_t)y * c->width + x]);
+            const size_t i = (size_t)y * c->width + x;
+            render_pixel(seed, cp, rp[2 * i], rp[2 * i + 1], &gray[i], &depth_mm[i]);
         }
 }
 

@@ -29,6 +29,48 @@ VIO_HD uint32_t hash4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
 }
 VIO_HD float u01(uint32_t h) { return (float)(h >> 8) * (1.0f / 16777216.0f); }
 
+// Deterministic transcendental functions of the texture (round 6: ONE renderer).  sinf / expf of two math libraries (glibc on the host,
+// ocml on the device) round differently in the last place, which flipped 4 of 29.5 M rendered pixels between vio_synth_render_host and
+// vio_synth_render_device.  These forms use only IEEE-754 double + - * (no contraction: -ffp-contract=off), a round-to-nearest by the
+// 1.5 * 2^52 constant and an exponent built from bits, so every conforming implementation returns the same float.
+VIO_HD float sin_det(float xf) {   // |x| < 2^20 * pi / 2; the scheme of dmath.h's sincos_det (Cody-Waite by pi / 2, fdlibm kernel polynomials)
+    const double x = (double)xf;
+    const double kd = (x * 0.63661977236758134308 + 6755399441055744.0) - 6755399441055744.0;
+    const double r = ((x - kd * 1.57079632673412561417e+00) - kd * 6.07710050630396597660e-11) - kd * 2.02226624879595063154e-21;
+    const double z = r * r;
+    const double ps = -1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                      z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10))));
+    const double pc = 4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 +
+                      z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11))));
+    const double s0 = r + (r * z) * ps;
+    const double c0 = (1.0 - 0.5 * z) + (z * z) * pc;
+    const int q = (int)((long long)kd & 3);
+    return (float)(q == 0 ? s0 : (q == 1 ? c0 : (q == 2 ? -s0 : -c0)));
+}
+VIO_HD float exp_det(float xf) {   // -80 < x <= 0 (the dots evaluate it on (-12, 0])
+    const double x = (double)xf;
+    const double kd = (x * 1.44269504088896338700e+00 + 6755399441055744.0) - 6755399441055744.0;
+    const double r = (x - kd * 6.93147180369123816490e-01) - kd * 1.90821492927058770002e-10;   // |r| <= ln 2 / 2
+    // Taylor polynomial of degree 13 (truncation 0.347^14 / 14! = 4e-18 relative), Horner
+    double p = 1.0 / 6227020800.0;
+    p = 1.0 / 479001600.0 + r * p;
+    p = 1.0 / 39916800.0 + r * p;
+    p = 1.0 / 3628800.0 + r * p;
+    p = 1.0 / 362880.0 + r * p;
+    p = 1.0 / 40320.0 + r * p;
+    p = 1.0 / 5040.0 + r * p;
+    p = 1.0 / 720.0 + r * p;
+    p = 1.0 / 120.0 + r * p;
+    p = 1.0 / 24.0 + r * p;
+    p = 1.0 / 6.0 + r * p;
+    p = 0.5 + r * p;
+    p = 1.0 + r * p;
+    p = 1.0 + r * p;
+    union { uint64_t u; double d; } sc;
+    sc.u = (uint64_t)(1023 + (int)kd) << 52;   // 2^k, k in [-116, 0]: a normal double, the product is exact up to the one rounding
+    return (float)(p * sc.d);
+}
+
 // room: x in [-4,4], y in [-3,3], z in [0,3]
 VIO_HD float smooth01(float x) {
     x = x < 0.f ? 0.f : (x > 1.f ? 1.f : x);
@@ -69,10 +111,10 @@ VIO_HD float scene_texture(uint32_t seed, int wall, float u, float v) {
                 float a = (h0 & 0x100) ? 70.f : -70.f;
                 float dx = u - ox, dy = v - oy;
                 float q = (dx * dx + dy * dy) / (2.f * sg * sg);
-                if (q < 12.f) val += a * expf(-q);
+                if (q < 12.f) val += a * exp_det(-q);
             }
     }
-    val += 10.f * sinf(2.1f * u + (float)wall) * sinf(1.7f * v + 0.5f * (float)wall);
+    val += 10.f * sin_det(2.1f * u + (float)wall) * sin_det(1.7f * v + 0.5f * (float)wall);
     return val;
 }
 
