@@ -83,6 +83,11 @@ typedef struct vio_config {
 enum { VIO_QUIRK_LATEST_FRONT = 1,
        /* bit 2 (value 4): ignored by the library; the test oracle mirrors deviation 15 (extrinsic held in a relocalisation solve) when set */
        VIO_ORACLE_RELO_HOLDS_EXTRINSIC = 4,
+       /* bit 3 (value 8), TEST SWITCH, not a reference behaviour (both sides read it): the inverse-depth bound of depth-less landmarks
+        * (estimator.cpp:1282-1297) is honoured by clamping candidates only, as rounds 1 - 5 did (former deviation 5).  0 = Ceres'
+        * treatment of a bounds-constrained program: x0 projected before the first evaluation, projected Armijo line search along every
+        * trust-region step (be_phased.h ps_eval; oracle/backend.cpp solve()). */
+       VIO_QUIRK_BOUND_CLAMP_ONLY = 8,
        /* TEST HOOK, not a reference behaviour: bits 8..11 = n: the first n Cholesky factorisations of EVERY solve are reported as failed
         * (on both sides: the oracle reads the same bits), which walks the mu *= 10 retry ladder of the trust-region loop
         * (oracle/backend.cpp solve(); be_phased.h ps_serial).  Every retry uses one iteration slot: see VIO_EXTRA_SLOTS. */
@@ -194,6 +199,11 @@ int vio_get_capacity(vio_batch *h, int32_t *out3);
 /* which solver the handle's configuration selected: 0 = the persistent one-workgroup-per-sequence kernel (fallback), 1 = the phased solver
  * with the Schur complement resident in LDS (windows up to W = 10), 2 = the phased solver with it in HBM / L2 (larger windows) */
 int vio_get_solver_kind(vio_batch *h);
+/* Bounds-constrained solves (estimator.cpp:1282-1297: SetParameterUpperBound(para_Feature, 0, 2 / DEPTH_MAX_DIST) on landmarks triangulated
+ * without a depth measurement, which makes Ceres project x0 onto the box and run its Armijo line search along every step).  Counters of
+ * sequence seq since vio_create / vio_reset: out4 = {inverse depths cut by the bound while a point was formed, bounded landmarks that
+ * entered solves, trial evaluations of the line search, shortened steps}.  Synchronises the device. */
+int vio_get_bound_stats(vio_batch *h, int seq, int64_t *out4);
 
 /* Results read out of the path (SURVEY.md §8b "Results read out").  All getters synchronise first. */
 typedef struct vio_status {

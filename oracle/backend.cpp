@@ -1370,7 +1370,8 @@ void Estimator::solve() {
             bool ls_ok = true;
             while (!current.valid || current.value > cost + 1e-4 * g0 * current.x) {
                 if (++ls_it >= 20) { ls_ok = false; break; }
-                const double a = ls_next_step(lower, previous, current, 1e-3 * current.x, 0.6 * current.x);
+                double ls_ws[96];
+                const double a = ls_next_step(lower, previous, current, 1e-3 * current.x, 0.6 * current.x, ls_ws);
                 if (a * dmax < 1e-9) { ls_ok = false; break; }
                 previous = current;
                 ls_eval(a);

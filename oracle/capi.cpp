@@ -110,9 +110,10 @@ void ovio_get_line_search_stats(void *h, double *out2) {
 double ovio_ls_next_step(const double *lower, const double *previous, const double *current, double lo, double hi) {
     om::LsSample a = {lower[0], lower[1], lower[2], (int)lower[3]}, b = {previous[0], previous[1], previous[2], (int)previous[3]},
                  c = {current[0], current[1], current[2], (int)current[3]};
-    return om::ls_next_step(a, b, c, lo, hi);
+    double ws[96];
+    return om::ls_next_step(a, b, c, lo, hi, ws);
 }
-int ovio_poly_roots_real(const double *c, int n, double *re) { return om::ls_poly_roots_real(c, n, re); }
+int ovio_poly_roots_real(const double *c, int n, double *re) { double ws[16]; return om::ls_poly_roots_real(c, n, re, ws); }
 // window arrays, each (W+1) rows: P(3) Q(wxyz 4) V(3) Ba(3) Bg(3) stamp(1) = 17 doubles per frame
 void ovio_get_window(void *h, double *out) {
     Estimator &e = ((Pipeline *)h)->est;

@@ -169,15 +169,16 @@ SINCOS_DET_QUAL void sincos_det(double x, double *sn, double *cs) {
 // carry value AND gradient (CUBIC): two samples give a cubic, three a quintic.  Ceres finds the critical points as the eigenvalues of the
 // balanced companion matrix; here degree 1 and 2 use Ceres' closed forms and degree 3 / 4 a Durand-Kerner iteration on the monic polynomial
 // (same roots to ~1e-15; like Ceres, the REAL PARTS of all roots are candidates).  Only + - * / sqrt: the same bits on the host and on gfx950.
-// THE SAME TEXT lives in oracle/om.h and csrc/dmath.h.
+// Everything that is indexed at run time lives in the caller's workspace ws (>= 96 doubles; an LDS region on the GPU, so that the kernel
+// that carries the search keeps no private-memory arrays).  THE SAME TEXT lives in oracle/om.h and csrc/dmath.h.
 struct LsSample { double x, value, gradient; int valid; };
 LS1D_QUAL double ls_poly_eval(const double *c, int n, double x) {   // n coefficients, highest degree first (Horner, EvaluatePolynomial)
     double v = 0.0;
     for (int i = 0; i < n; i++) v = v * x + c[i];
     return v;
 }
-// real parts of all roots of the polynomial c[0 .. n-1] (highest degree first, n <= 5); returns how many
-LS1D_QUAL int ls_poly_roots_real(const double *cin, int nin, double *re) {
+// real parts of all roots of the polynomial cin[0 .. nin-1] (highest degree first, nin <= 5); returns how many.  ws: >= 13 doubles
+LS1D_QUAL int ls_poly_roots_real(const double *cin, int nin, double *re, double *ws) {
     int lead = 0;
     while (lead < nin - 1 && cin[lead] == 0.0) lead++;   // RemoveLeadingZeros
     const double *c = cin + lead;
@@ -195,11 +196,10 @@ LS1D_QUAL int ls_poly_roots_real(const double *cin, int nin, double *re) {
         return 2;
     }
     // degree 3 / 4: Durand-Kerner on the monic polynomial, start points on a circle of the Cauchy root bound
-    double m[5];
+    double *m = ws, *zr = ws + 5, *zi = ws + 9;
     double bound = 0.0;
     for (int i = 0; i <= deg; i++) { m[i] = c[i] / c[0]; if (i > 0 && fabs(m[i]) > bound) bound = fabs(m[i]); }
     bound = 1.0 + bound;
-    double zr[4], zi[4];
     {
         double pr = 1.0, pi = 0.0;   // powers of 0.4 + 0.9 i (not a root of unity, not real)
         for (int k = 0; k < deg; k++) { zr[k] = bound * pr; zi[k] = bound * pi; const double nr = pr * 0.4 - pi * 0.9, ni = pr * 0.9 + pi * 0.4; pr = nr; pi = ni; }
@@ -228,55 +228,53 @@ LS1D_QUAL int ls_poly_roots_real(const double *cin, int nin, double *re) {
     for (int k = 0; k < deg; k++) re[k] = zr[k];
     return deg;
 }
-// FindInterpolatingPolynomial: value and gradient of ns samples (ns = 2, 3) -> 2 ns coefficients, highest degree first; Gaussian elimination
-// with full pivoting (Eigen::FullPivLU with threshold 0)
-LS1D_QUAL void ls_fit_poly(const LsSample *s, int ns, double *coef) {
-    const int n = 2 * ns, degree = n - 1;
-    double A[6][7];
+// FindInterpolatingPolynomial: value and gradient of ns samples (ns = 2, 3; smp = rows x, value, gradient) -> 2 ns coefficients, highest
+// degree first; Gaussian elimination with full pivoting (Eigen::FullPivLU with threshold 0).  ws: >= 54 doubles
+LS1D_QUAL void ls_fit_poly(const double *smp, int ns, double *coef, double *ws) {
+    const int n = 2 * ns, degree = n - 1, ld = 7;
+    double *A = ws, *colp = ws + 42, *y = ws + 48;
     for (int i = 0; i < ns; i++) {
+        const double x = smp[3 * i];
         for (int j = 0; j <= degree; j++) {
             double pw = 1.0;
-            for (int e = 0; e < degree - j; e++) pw *= s[i].x;
-            A[2 * i][j] = pw;
+            for (int e = 0; e < degree - j; e++) pw *= x;
+            A[(2 * i) * ld + j] = pw;
             double pd = 0.0;
-            if (j < degree) { pd = (double)(degree - j); for (int e = 0; e < degree - j - 1; e++) pd *= s[i].x; }
-            A[2 * i + 1][j] = pd;
+            if (j < degree) { pd = (double)(degree - j); for (int e = 0; e < degree - j - 1; e++) pd *= x; }
+            A[(2 * i + 1) * ld + j] = pd;
         }
-        A[2 * i][n] = s[i].value;
-        A[2 * i + 1][n] = s[i].gradient;
+        A[(2 * i) * ld + n] = smp[3 * i + 1];
+        A[(2 * i + 1) * ld + n] = smp[3 * i + 2];
     }
-    int colp[6];
-    for (int j = 0; j < n; j++) colp[j] = j;
+    for (int j = 0; j < n; j++) colp[j] = (double)j;
     for (int k = 0; k < n; k++) {
         int pr = k, pc = k;
         double best = -1.0;
-        for (int i = k; i < n; i++) for (int j = k; j < n; j++) if (fabs(A[i][j]) > best) { best = fabs(A[i][j]); pr = i; pc = j; }
+        for (int i = k; i < n; i++) for (int j = k; j < n; j++) if (fabs(A[i * ld + j]) > best) { best = fabs(A[i * ld + j]); pr = i; pc = j; }
         if (best <= 0.0) break;
-        if (pr != k) for (int j = 0; j <= n; j++) { const double t = A[k][j]; A[k][j] = A[pr][j]; A[pr][j] = t; }
-        if (pc != k) { for (int i = 0; i < n; i++) { const double t = A[i][k]; A[i][k] = A[i][pc]; A[i][pc] = t; } const int t = colp[k]; colp[k] = colp[pc]; colp[pc] = t; }
+        if (pr != k) for (int j = 0; j <= n; j++) { const double t = A[k * ld + j]; A[k * ld + j] = A[pr * ld + j]; A[pr * ld + j] = t; }
+        if (pc != k) { for (int i = 0; i < n; i++) { const double t = A[i * ld + k]; A[i * ld + k] = A[i * ld + pc]; A[i * ld + pc] = t; } const double t = colp[k]; colp[k] = colp[pc]; colp[pc] = t; }
         for (int i = k + 1; i < n; i++) {
-            const double f = A[i][k] / A[k][k];
-            for (int j = k; j <= n; j++) A[i][j] -= f * A[k][j];
+            const double f = A[i * ld + k] / A[k * ld + k];
+            for (int j = k; j <= n; j++) A[i * ld + j] -= f * A[k * ld + j];
         }
     }
-    double y[6];
     for (int k = n - 1; k >= 0; k--) {
-        double acc = A[k][n];
-        for (int j = k + 1; j < n; j++) acc -= A[k][j] * y[j];
-        y[k] = A[k][k] != 0.0 ? acc / A[k][k] : 0.0;
+        double acc = A[k * ld + n];
+        for (int j = k + 1; j < n; j++) acc -= A[k * ld + j] * y[j];
+        y[k] = A[k * ld + k] != 0.0 ? acc / A[k * ld + k] : 0.0;
     }
-    for (int k = 0; k < n; k++) coef[colp[k]] = y[k];
+    for (int k = 0; k < n; k++) coef[(int)colp[k]] = y[k];
 }
 // LineSearch::InterpolatingPolynomialMinimizingStepSize (CUBIC) + MinimizeInterpolatingPolynomial: the next trial step in [lo, hi]
-LS1D_QUAL double ls_next_step(const LsSample &lower, const LsSample &previous, const LsSample &current, double lo, double hi) {
+LS1D_QUAL double ls_next_step(const LsSample &lower, const LsSample &previous, const LsSample &current, double lo, double hi, double *ws) {
     if (!current.valid) { const double h = current.x * 0.5; return h < lo ? (lo < hi ? lo : hi) : (h < hi ? h : hi); }   // min(max(x / 2, lo), hi)
-    LsSample smp[3];
-    int ns = 0;
-    smp[ns++] = lower;
-    smp[ns++] = current;
-    if (previous.valid) smp[ns++] = previous;
-    double coef[6];
-    ls_fit_poly(smp, ns, coef);
+    double *smp = ws, *coef = ws + 9, *der = ws + 15, *roots = ws + 20, *sub = ws + 24;
+    int ns = 2;
+    smp[0] = lower.x; smp[1] = lower.value; smp[2] = lower.gradient;
+    smp[3] = current.x; smp[4] = current.value; smp[5] = current.gradient;
+    if (previous.valid) { smp[6] = previous.x; smp[7] = previous.value; smp[8] = previous.gradient; ns = 3; }
+    ls_fit_poly(smp, ns, coef, sub);
     const int n = 2 * ns;
     // MinimizePolynomial: the middle of the interval first, then the ends, then the critical points inside
     double best_x = (lo + hi) / 2.0, best_v = ls_poly_eval(coef, n, best_x);
@@ -284,9 +282,8 @@ LS1D_QUAL double ls_next_step(const LsSample &lower, const LsSample &previous, c
     if (vlo < best_v) { best_v = vlo; best_x = lo; }
     const double vhi = ls_poly_eval(coef, n, hi);
     if (vhi < best_v) { best_v = vhi; best_x = hi; }
-    double der[5], roots[4];
     for (int i = 0; i < n - 1; i++) der[i] = (double)(n - 1 - i) * coef[i];   // DifferentiatePolynomial
-    const int nr = ls_poly_roots_real(der, n - 1, roots);
+    const int nr = ls_poly_roots_real(der, n - 1, roots, sub);
     for (int i = 0; i < nr; i++) {
         const double r = roots[i];
         if (r < lo || r > hi) continue;
@@ -294,9 +291,10 @@ LS1D_QUAL double ls_next_step(const LsSample &lower, const LsSample &previous, c
         if (v < best_v) { best_v = v; best_x = r; }
     }
     for (int i = 0; i < ns; i++) {   // MinimizeInterpolatingPolynomial: the samples themselves
-        if (smp[i].x < lo || smp[i].x > hi) continue;
-        const double v = ls_poly_eval(coef, n, smp[i].x);
-        if (v < best_v) { best_v = v; best_x = smp[i].x; }
+        const double x = smp[3 * i];
+        if (x < lo || x > hi) continue;
+        const double v = ls_poly_eval(coef, n, x);
+        if (v < best_v) { best_v = v; best_x = x; }
     }
     return best_x;
 }

@@ -400,6 +400,14 @@ class VioBatch:
         self.L.vio_get_solver_kind.argtypes = [C.c_void_p]
         return self.L.vio_get_solver_kind(self.h)
 
+    def bound_stats(self, seq=0):
+        """(inverse depths cut by the upper bound, bounded landmarks that entered solves, line-search trial evaluations, shortened steps) of
+        sequence seq since creation (estimator.cpp:1282-1297; Ceres' projected Armijo line search on the bounds-constrained program)"""
+        o = np.zeros(4, np.int64)
+        self.L.vio_get_bound_stats.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self._chk(self.L.vio_get_bound_stats(self.h, int(seq), o.ctypes.data), "vio_get_bound_stats")
+        return tuple(int(x) for x in o)
+
     def capacity(self):
         c = np.zeros(3, np.int32)
         self._chk(self.L.vio_get_capacity(self.h, c.ctypes.data), "vio_get_capacity")

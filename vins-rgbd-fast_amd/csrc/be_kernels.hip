@@ -1806,6 +1806,15 @@ __device__ __forceinline__ void solve_body(const Batch &B, int s, int *scratch, 
     const long long ts0 = VIO_CLOCK();
     int F, Fa, nres;
     solve_prologue(B, c, X, scratch, pw, sh_i, F, Fa, nres);
+    {
+        // The persistent solver (VIO_SOLVE_MODE=0 and the fallback for residual counts beyond the phased solver's range) honours the inverse-depth
+        // bound by clamping candidates only; Ceres' treatment of the bounds-constrained program (projection of x0, Armijo line search) lives in
+        // the phased solver (be_phased.h).  A frame that meets a bounded landmark here is flagged (overflow bit 128).
+        const int *al = c.pair_list + c.nres_cap - c.NL;
+        bool hit = false;
+        for (int k = t; k < Fa; k += nt) hit = hit || c.lm_est[al[k]] == 2;
+        if (hit) atomicOr(&c.be->overflow, 128);
+    }
     const int nlm = be.n_lm;
     int *alist = c.pair_list + c.nres_cap - c.NL;              // variable-landmark slots, kept for the whole solve
     const int n = c.NPR;

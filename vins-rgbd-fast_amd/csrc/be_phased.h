@@ -12,6 +12,7 @@
 
 namespace {
 
+#define PS_LS_HEAD_DOUBLES (((int)(sizeof(Params) / sizeof(double)) + 1 & ~1) + 176)   // ps_line_search: evaluation point + scalar workspace + partial costs ahead of the roles' region
 #define PS_LVEC 14   // P-sized vectors ps_serial keeps in LDS (kernels.h ps_serial_lds_bytes sizes the launch with it)
 __device__ __forceinline__ bool ps_active(const SolveSt &st) { return st.stage != PS_IDLE && st.stage != PS_DONE; }
 __device__ __forceinline__ double *ps_imu_blk(const Ctx &c) { return c.pairblk + (size_t)((c.W + 1) * c.W / 2) * 210; }  // W x 768 doubles behind the pair blocks
@@ -33,6 +34,7 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(Batch B) {
     __shared__ int sh_i[8];
     __shared__ Params X;
     __shared__ PreWork pw;
+    __shared__ double setup_red[64];
     Ctx c = make_ctx(B, s);
     SolveSt &st = B.sst[s];
     BeSeq &be = *c.be;
@@ -40,6 +42,33 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(Batch B) {
     const long long ts0 = VIO_CLOCK();
     int F, Fa, nres;
     solve_prologue(B, c, X, scratch, pw, sh_i, F, Fa, nres, /*allow_relo=*/true);
+    // Bounds (estimator.cpp:1282-1297: SetParameterUpperBound(para_Feature, 0, 2 / DEPTH_MAX_DIST) on landmarks triangulated without a depth
+    // measurement).  Ceres: Program::IsBoundsConstrained() of the reduced program -- any VARIABLE block with a finite bound -- switches the
+    // trust-region loop to its constrained form: TrustRegionMinimizer::IterationZero sends x through Plus(x, 0) before the first evaluation
+    // (every local parameterisation once: the quaternions are re-normalised; ParameterBlock::Plus projects onto the box), and every step goes
+    // through the projected Armijo line search (ps_eval).  reference_quirks bit 3 keeps rounds 1 - 5's clamp-only treatment (tests).
+    {
+        const int *alist = c.pair_list + c.nres_cap - c.NL;
+        const vio_config &cfg = c.C->c;
+        const double ub = 2.0 / cfg.depth_max;
+        double nb = 0, ncl = 0;
+        for (int k = t; k < Fa; k += blockDim.x) if (c.lm_est[alist[k]] == 2) nb += 1;
+        nb = block_sum(nb, setup_red);
+        const bool constrained = nb > 0 && !(cfg.reference_quirks & VIO_QUIRK_BOUND_CLAMP_ONLY);
+        if (constrained) {
+            const double zero6[6] = {0, 0, 0, 0, 0, 0};
+            if (t <= c.W && (cfg.use_imu || t > 0)) bf::pose_plus(&X.pose[t * 7], zero6);
+            if (t == c.W + 1 && sh_i[0]) bf::pose_plus(X.ex, zero6);
+            if (t == c.W + 2 && sh_i[4]) bf::pose_plus(X.relo, zero6);
+            for (int k = t; k < Fa; k += blockDim.x) {
+                const int slot = alist[k], pi = c.lm_pidx[slot];
+                if (c.lm_est[slot] == 2 && c.feat[pi] > ub) { c.feat[pi] = ub; ncl += 1; }
+            }
+            ncl = block_sum(ncl, setup_red);
+        }
+        __syncthreads();
+        if (t == 0) { st.constrained = constrained ? 1 : 0; st.ls_pending = 0; be.bounded_solves += (int)nb; be.bound_clamps += (int)ncl; }
+    }
     for (int k = t; k < (int)(sizeof(Params) / sizeof(double)); k += blockDim.x) ((double *)&st.X)[k] = ((const double *)&X)[k];
     if (t == 0) {
         st.F = F; st.Fa = Fa; st.nres = nres;
@@ -120,6 +149,60 @@ __device__ void ps_accept(const Batch &B, int s) {
     }
 }
 
+// candidate = Plus(x, alpha * delta): every variable block through its local parameterisation (PoseLocalParameterization::Plus) and PROJECTED
+// onto the box (ParameterBlock::Plus: the inverse depth of a depth-less landmark is cut at 2 / DEPTH_MAX_DIST) -> st.Xc, c.cfeat and the two
+// norms of Ceres' parameter tolerance.  alpha = 1 is the trust-region step itself (1.0 * delta is exact); the line search of a
+// bounds-constrained solve calls it again with shorter steps (LineSearchFunction::Evaluate: scaled_direction = alpha * direction, then Plus).
+// delta: the P tangent entries of the unscaled step (LDS in ps_serial, c.vec slot 8 in ps_eval); stl, sl: landmark step and column scaling.
+__device__ __forceinline__ void ps_form_candidate(const Ctx &c, SolveSt &st, const double alpha, const double *delta, const double *stl, const double *sl, double *sred) {
+    const int t = threadIdx.x, nt = blockDim.x;
+    const vio_config &cfg = c.C->c;
+    const int W = c.W, W1 = W + 1, oE = 15 * W1, oT = 15 * W1 + 6;
+    const int F = st.F, Fa = st.Fa, ex_active = st.ex_active, td_active = st.td_active;
+    const int *alist = c.pair_list + c.nres_cap - c.NL;
+    const Params &X = st.X;
+    Params &Xc = st.Xc;
+    double xn2 = 0, dn2 = 0, ncl = 0;   // |x|^2 and |candidate - x|^2 over the variable blocks (Ceres' parameter tolerance, checked by ps_accept)
+    if (t <= W) {
+        double pc[7], d6[6];
+        for (int k = 0; k < 7; k++) pc[k] = X.pose[t * 7 + k];
+        for (int k = 0; k < 6; k++) d6[k] = alpha * delta[6 * t + k];
+        bf::pose_plus(pc, d6);
+        for (int k = 0; k < 7; k++) { const double v = X.pose[t * 7 + k], d = v - pc[k]; xn2 += v * v; dn2 += d * d; Xc.pose[t * 7 + k] = pc[k]; }
+        for (int k = 0; k < 9; k++) {
+            const double v = X.sb[t * 9 + k], vc = v + alpha * delta[6 * W1 + 9 * t + k], d = v - vc;
+            xn2 += v * v; dn2 += d * d;
+            Xc.sb[t * 9 + k] = vc;
+        }
+    }
+    if (t == W + 1) {
+        // the block at oE: the extrinsic, or relo_Pose when the solve carries relocalisation factors (the extrinsic is constant then)
+        const bool relo = st.relo != 0;
+        double ec[7], d6[6];
+        for (int k = 0; k < 7; k++) ec[k] = relo ? X.relo[k] : X.ex[k];
+        for (int k = 0; k < 6; k++) d6[k] = alpha * delta[oE + k];
+        if (ex_active) bf::pose_plus(ec, d6);
+        const double tdc = X.td + (td_active ? alpha * delta[oT] : 0.0);
+        if (ex_active) for (int k = 0; k < 7; k++) { const double v = relo ? X.relo[k] : X.ex[k], d = v - ec[k]; xn2 += v * v; dn2 += d * d; }
+        if (td_active) { xn2 += X.td * X.td; dn2 += (X.td - tdc) * (X.td - tdc); }
+        for (int k = 0; k < 7; k++) { Xc.ex[k] = relo ? X.ex[k] : ec[k]; Xc.relo[k] = relo ? ec[k] : X.relo[k]; }
+        Xc.td = tdc;
+    }
+    for (int k = t; k < F; k += nt) c.cfeat[k] = c.feat[k];
+    __syncthreads();
+    for (int k = t; k < Fa; k += nt) {
+        int slot = alist[k], pi = c.lm_pidx[slot];
+        const double v0 = c.feat[pi];
+        double v = v0 + alpha * (stl[k] * sl[k]);
+        double ub = (c.lm_est[slot] == 2) ? 2.0 / cfg.depth_max : 1.7976931348623157e308;
+        if (v > ub) { v = ub; ncl += 1; }
+        c.cfeat[pi] = v;
+        xn2 += v0 * v0; dn2 += (v0 - v) * (v0 - v);
+    }
+    block_sum3(xn2, dn2, ncl, sred);
+    if (t == 0) { st.step_xn2 = xn2; st.step_dn2 = dn2; if (ncl > 0) c.be->bound_clamps += (int)ncl; }
+}
+
 // ---------------------------------------------------------------------------------------------------------------- EVAL
 // grid (3 + ceil(max residuals / 256), S), 256 threads, dynamic LDS = pair geometry.  Block 0: prior; blocks 1, 2: IMU factors (one
 // work type per wavefront: whitened residual and the four Jacobian column groups are different code paths); block b >= 3: projection
@@ -136,6 +219,198 @@ __device__ __forceinline__ bool ps_blk(const Batch &B, int &s, int &b) {
     b = idx - sl * B.xcd_nb;
     s = r + B.s0;
     return r < B.ns;
+}
+
+// ONE evaluation role of a sequence ("block b" of ps_eval's grid) on 256 threads: b = 0 the prior, 1 / 2 the IMU factors (one work type per
+// wavefront), b >= 3 the projection residuals [256 rpt (b - 3), 256 rpt (b - 2)).  Returns the calling thread's share of the cost (the caller
+// block-sums it).  t = thread index within the role, act = the thread takes part: ps_eval runs a role per workgroup (all 256 threads active);
+// the line search of a bounds-constrained solve (ps_line_search, inside ps_serial's 512-thread workgroup) runs the roles one after the other on
+// its first 256 threads -- the barriers are unconditional, inactive threads only pass through them -- and gets the same bits.  LS = true adds
+// the directional derivative gradient . delta of the role's factors to gd (the IMU factors' share is formed by the caller from c.imu_raw)
+// and leaves the prior's vectors st.srp / st.sdx alone (they belong to the point ps_asm_b assembles).
+template <bool LS>
+__device__ __forceinline__ double ps_eval_role(const Batch &B, const int s, const Ctx &c, SolveSt &st, const Params &X, const double *feat, const bool withJ,
+                                               const int b, const int t, const bool act, unsigned char *smem, const double *dlt, const double *lstl,
+                                               const double *lsl, double &gd) {
+    const int nt = 256;
+    const BeSeq &be = *c.be;
+    const vio_config &cfg = c.C->c;
+    const bool vext = st.vext != 0;
+    const int W = c.W, W1 = W + 1, n = c.NPR;
+    double cost = 0;
+    PH_INIT;
+    if (b == 0) {
+        if (be.has_prior) {
+            // prior gradient q = b + A dx and cost dx^T b + 1/2 dx^T A dx: one thread per row, A read by columns (it is stored exactly
+            // symmetric), dx from LDS
+            // (three threads per row, each over a third of the columns, partial sums added in a fixed order)
+            double *dxs = (double *)smem, *pacc = dxs + ((n + 1) & ~1);
+            PH(45);
+            prior_dx(c, X, dxs, true);
+            PH(40);
+            // four threads per row when they fit (n <= 64), every load of a thread in flight at once: the partials took 28 us of a 57 us
+            // launch as a runtime-bound loop with one load per iteration, 15 us in batches of eight
+            const int nch = max(1, min(4, nt / n));
+            if (act && t < nch * n) {
+                const int ch = t / n, row = t - ch * n;
+                const int per = (n + nch - 1) / nch, j0 = ch * per, j1 = min(n, j0 + per);
+                constexpr int MAXJ = 32;   // columns per thread on the fast path (26 at W = 10 with three threads per row)
+                double acc = 0;
+                if (j1 - j0 <= MAXJ) {
+                    double hv[MAXJ];
+#pragma unroll
+                    for (int u = 0; u < MAXJ; u++) hv[u] = c.prior_H[(size_t)min(j0 + u, n - 1) * n + row];
+#pragma unroll
+                    for (int u = 0; u < MAXJ; u++) if (j0 + u < j1) acc += hv[u] * dxs[j0 + u];
+                } else
+                    for (int j = j0; j < j1; j += 8) {   // larger windows: eight loads in flight per trip
+                        double hv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) hv[u] = c.prior_H[(size_t)min(j + u, j1 - 1) * n + row];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) if (j + u < j1) acc += hv[u] * dxs[j + u];
+                    }
+                pacc[ch * n + row] = acc;
+            }
+            __syncthreads();
+            PH(44);
+            if (act && t < n) {
+                double acc = pacc[t];
+                for (int ch = 1; ch < nch; ch++) acc += pacc[ch * n + t];
+                const double b0 = c.prior_r[t], d = dxs[t], q = b0 + acc;
+                cost += 0.5 * d * (b0 + q);
+                if (LS) {
+                    // (relocalisation solve: the extrinsic's columns are lent to relo_Pose, the prior does not act on them -- ps_asm_b)
+                    const int a = prior_map(t, W);
+                    if (!(st.relo && a >= 15 * W1 && a < 15 * W1 + 6)) gd += q * dlt[a];
+                } else { st.srp[t] = q; st.sdx[t] = d; }
+            }
+            if (act && t == 0) cost += 0.5 * be.prior_c0;
+        }
+    } else if (b <= 2) {
+        // IMU factors: pre-integration headers (state, Jacobian, whitening matrix: the first VIO_PREINT_HDR doubles of PreInt) staged in
+        // LDS, four loads in flight per thread
+        double *pl = (double *)smem;
+        constexpr int PH_LD = VIO_PREINT_HDR + 1;
+        // (ten loads in flight per thread and trip: the 19 loads a thread owns at W = 10 are two round trips instead of five)
+        for (int q0 = act ? t : W * PH_LD; q0 < W * PH_LD; q0 += 10 * nt) {
+            double v[10];
+#pragma unroll
+            for (int u = 0; u < 10; u++) {
+                const int q = min(q0 + u * nt, W * PH_LD - 1), i = q / PH_LD, e = min(q - i * PH_LD, VIO_PREINT_HDR - 1);
+                v[u] = ((const double *)&c.pre[be.pre_idx[i + 1]])[e];
+            }
+#pragma unroll
+            for (int u = 0; u < 10; u++) if (q0 + u * nt < W * PH_LD) pl[q0 + u * nt] = v[u];
+        }
+        __syncthreads();
+        if (b == 1) PH(46);
+        const v3 G = ld3(be.g);
+        const int part_ = (b == 1 ? 0 : 4) + (t >> 6), i0 = t & 63;   // block 1: types 0 .. 3 on its four wavefronts, block 2: type 4
+        if (act && part_ <= 4 && !(b == 2 && (t >> 6) > 0))
+            for (int i = i0; i < W; i += 64) {
+                const int j = i + 1;
+                const PreInt &p = *(const PreInt *)(pl + (size_t)i * PH_LD);   // only the header fields are read
+                double *__restrict__ out = c.imu_raw + (size_t)i * 15 * 31;
+                if (!cfg.use_imu || p.sum_dt > 10.0) { if (part_ == 0) for (int k = 0; k < 15; k++) out[k * 31 + 30] = 0; continue; }
+                if (part_ == 0) {
+                    double raw[15];
+                    bf::imu_raw_residual(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], raw);
+                    for (int r = 0; r < 15; r++) {
+                        double sacc = 0;
+                        for (int k = 0; k <= r; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k];
+                        out[r * 31 + 30] = sacc;
+                        cost += 0.5 * sacc * sacc;
+                    }
+                } else if (withJ)
+                    bf::imu_raw_jacobian_part(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], part_ - 1, out, 31);
+            }
+    } else {
+        double *geo = (double *)smem;
+        const int rpt = B.eval_rpt, r0 = 256 * rpt * (b - 3), nres = st.nres;
+        for (int p = act ? t : W1 * W1 + 1; p <= W1 * W1; p += nt) {
+            if (p == W1 * W1) { stm(geo + (size_t)p * 32, q2R(mkq(X.ex[6], X.ex[3], X.ex[4], X.ex[5]))); continue; }
+            const int i = p / W1, j = p - i * W1;
+            if (!(i < j) || c.pair_start[p + 1] == c.pair_start[p]) continue;
+            bf::PairGeo g;
+            bf::pair_geo(&X.pose[i * 7], &X.pose[j * 7], X.ex, g);
+            double *o = geo + (size_t)p * 32;
+            for (int q = 0; q < 9; q++) { o[q] = g.A1[q]; o[9 + q] = g.A2[q]; o[18 + q] = g.M[q]; }
+            o[27] = g.t[0]; o[28] = g.t[1]; o[29] = g.t[2];
+        }
+        __syncthreads();
+        const double *ricm = geo + (size_t)W1 * W1 * 32;
+        // (round 5: rpt residuals per thread -- with two, the 7 projection workgroups of a sequence become 4 and a 64-sequence launch fits the
+        // device's wave slots at this kernel's 216 VGPRs in one round instead of two)
+        for (int u = 0; u < rpt; u++) {
+            const int r = r0 + t + 256 * u;
+            if (!act || r >= nres) break;
+            const int slot = c.res_lm[r], k = c.res_k[r];   // k = 0: the landmark's relocalisation factor
+            const int imu_i = c.lm_start[slot], imu_j = imu_i + (k > 0 ? k : 1);
+            const bf::PairGeo &g = *(const bf::PairGeo *)(geo + (size_t)(imu_i * W1 + imu_j) * 32);
+            double rr[2], wgt = 1.0, sq;
+            if (k == 0) {
+                // relocalisation factor (estimator.cpp:1336-1340): ProjectionFactor(first observation, matched point of the old keyframe)
+                // on (para_Pose[start], relo_Pose, ex, inverse depth).  Its record carries d r / d relo_Pose in the extrinsic's columns
+                // (lent to relo_Pose for this solve) and zeros in the pose_j columns.
+                double *out = c.res + (size_t)r * 42;
+                double J[40], oj[VIO_OBS_D];
+                const double *oi = obs_ptr(c, slot, imu_i);
+                for (int q = 0; q < VIO_OBS_D; q++) oj[q] = oi[q];
+                oj[0] = c.relo_xy[2 * slot]; oj[1] = c.relo_xy[2 * slot + 1]; oj[2] = 1.0;
+                bf::eval_projection(cfg, &X.pose[imu_i * 7], X.relo, X.ex, feat[c.lm_pidx[slot]], X.td, oi, oj, false, rr, withJ ? J : nullptr);
+                sq = rr[0] * rr[0] + rr[1] * rr[1];
+                wgt = sqrt(1.0 / (1.0 + sq));
+                if (withJ) {
+                    for (int a = 0; a < 2; a++) {
+                        for (int d = 0; d < 6; d++) { out[a * 20 + d] = wgt * J[a * 20 + d]; out[a * 20 + 6 + d] = 0.0; out[a * 20 + 12 + d] = wgt * J[a * 20 + 6 + d]; }
+                        out[a * 20 + 18] = 0.0;
+                        out[a * 20 + 19] = wgt * J[a * 20 + 19];
+                    }
+                    out[40] = wgt * rr[0]; out[41] = wgt * rr[1];
+                }
+            } else if (vext) {
+                double *out = c.res + (size_t)r * 42;
+                bf::eval_projection_pair(cfg, g, ricm, X.ex, feat[c.lm_pidx[slot]], X.td, obs_ptr(c, slot, imu_i), obs_ptr(c, slot, imu_j),
+                                         cfg.estimate_td != 0, rr, withJ ? out : nullptr, true, &wgt);
+                sq = rr[0] * rr[0] + rr[1] * rr[1];
+                if (withJ) {
+                    out[40] = wgt * rr[0]; out[41] = wgt * rr[1];
+                    // the extrinsic itself is constant while its columns serve relo_Pose: no Jacobian for it (Ceres evaluates none either)
+                    if (st.relo) for (int d = 0; d < 6; d++) { out[12 + d] = 0.0; out[32 + d] = 0.0; }
+                }
+            } else {
+                double *out = c.res + (size_t)r * 28;
+                bf::eval_projection_pair(cfg, g, ricm, X.ex, feat[c.lm_pidx[slot]], X.td, obs_ptr(c, slot, imu_i), obs_ptr(c, slot, imu_j),
+                                         cfg.estimate_td != 0, rr, withJ ? out : nullptr, true, &wgt, 14, false);
+                sq = rr[0] * rr[0] + rr[1] * rr[1];
+                if (withJ) { out[13] = wgt * rr[0]; out[27] = wgt * rr[1]; }
+            }
+            cost += 0.5 * log(1.0 + sq);
+            if (LS) {
+                // directional derivative of this factor from the record just written: (w r)^T (w J) delta over its parameter blocks
+                const int oE = 15 * W1, oT = 15 * W1 + 6, ka = c.lm_aidx[slot];
+                const double dl = ka >= 0 ? lstl[ka] * lsl[ka] : 0.0;
+                if (k == 0 || vext) {
+                    const double *out = c.res + (size_t)r * 42;
+                    for (int a = 0; a < 2; a++) {
+                        double jd = out[a * 20 + 18] * dlt[oT] + out[a * 20 + 19] * dl;
+                        for (int d = 0; d < 6; d++) jd += out[a * 20 + d] * dlt[6 * imu_i + d] + out[a * 20 + 6 + d] * dlt[6 * imu_j + d] + out[a * 20 + 12 + d] * dlt[oE + d];
+                        gd += out[40 + a] * jd;
+                    }
+                } else {
+                    const double *out = c.res + (size_t)r * 28;
+                    for (int a = 0; a < 2; a++) {
+                        double jd = out[a * 14 + 12] * dl;
+                        for (int d = 0; d < 6; d++) jd += out[a * 14 + d] * dlt[6 * imu_i + d] + out[a * 14 + 6 + d] * dlt[6 * imu_j + d];
+                        gd += out[a * 14 + 13] * jd;
+                    }
+                }
+            }
+        }
+    }
+    if (b == 0) PH(62); else if (b == 1) PH(63); else if (b == 3) PH(14);
+    return cost;
 }
 
 __device__ __forceinline__ void ps_eval_body(const Batch &B) {
@@ -1106,47 +1381,11 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
     invalid = 0;
     PH(54);
     // candidate = Plus(x, step .* scale)
-    for (int a = t; a < P; a += nt) delta[a] = stp[a] * sp[a];
+    for (int a = t; a < LW; a += nt) delta[a] = a < P ? stp[a] * sp[a] : 0.0;
     __syncthreads();
-    const Params &X = st.X;
-    Params &Xc = st.Xc;
-    double xn2 = 0, dn2 = 0;   // |x|^2 and |candidate - x|^2 over the variable blocks (Ceres' parameter tolerance, checked by ps_accept)
-    if (t <= W) {
-        double pc[7];
-        for (int k = 0; k < 7; k++) pc[k] = X.pose[t * 7 + k];
-        bf::pose_plus(pc, &delta[6 * t]);
-        for (int k = 0; k < 7; k++) { const double v = X.pose[t * 7 + k], d = v - pc[k]; xn2 += v * v; dn2 += d * d; Xc.pose[t * 7 + k] = pc[k]; }
-        for (int k = 0; k < 9; k++) {
-            const double v = X.sb[t * 9 + k], vc = v + delta[6 * W1 + 9 * t + k], d = v - vc;
-            xn2 += v * v; dn2 += d * d;
-            Xc.sb[t * 9 + k] = vc;
-        }
-    }
-    if (t == W + 1) {
-        // the block at oE: the extrinsic, or relo_Pose when the solve carries relocalisation factors (the extrinsic is constant then)
-        const bool relo = st.relo != 0;
-        double ec[7];
-        for (int k = 0; k < 7; k++) ec[k] = relo ? X.relo[k] : X.ex[k];
-        if (ex_active) bf::pose_plus(ec, &delta[oE]);
-        const double tdc = X.td + (td_active ? delta[oT] : 0.0);
-        if (ex_active) for (int k = 0; k < 7; k++) { const double v = relo ? X.relo[k] : X.ex[k], d = v - ec[k]; xn2 += v * v; dn2 += d * d; }
-        if (td_active) { xn2 += X.td * X.td; dn2 += (X.td - tdc) * (X.td - tdc); }
-        for (int k = 0; k < 7; k++) { Xc.ex[k] = relo ? X.ex[k] : ec[k]; Xc.relo[k] = relo ? ec[k] : X.relo[k]; }
-        Xc.td = tdc;
-    }
-    for (int k = t; k < F; k += nt) c.cfeat[k] = c.feat[k];
-    __syncthreads();
-    for (int k = t; k < Fa; k += nt) {
-        int slot = alist[k], pi = c.lm_pidx[slot];
-        const double v0 = c.feat[pi];
-        double v = v0 + stl[k] * sl[k];
-        double ub = (c.lm_est[slot] == 2) ? 2.0 / cfg.depth_max : 1.7976931348623157e308;
-        if (v > ub) v = ub;
-        c.cfeat[pi] = v;
-        xn2 += v0 * v0; dn2 += (v0 - v) * (v0 - v);
-    }
-    block_sum2(xn2, dn2, sred);
-    if (t == 0) { st.step_xn2 = xn2; st.step_dn2 = dn2; }
+    ps_form_candidate(c, st, 1.0, delta, stl, sl, sred);
+    // a bounds-constrained solve: this candidate is only the first trial of Ceres' projected line search (ps_ls_kernel, next launch)
+    if (t == 0) st.ls_pending = st.constrained;
     if (t == 0) { st.model_change = model_change; st.eval_with_J = iter < cfg.max_iterations ? 1 : 0; }
     finish(PS_EVAL_C);
     PH(55);
@@ -1158,6 +1397,106 @@ __global__ __launch_bounds__(512) void ps_serial_kernel_512(Batch B) { ps_serial
 // the same serial phase for windows whose Schur complement stays in HBM / L2 (its own kernel: the streaming Cholesky's registers must not
 // weigh on the 128-VGPR budget of the resident version); 512 threads = 256 VGPRs per lane
 __global__ __launch_bounds__(512) void ps_serial_big_kernel(Batch B) { ps_serial_body<true, 8>(B); }
+
+// Ceres' projected Armijo line search of a bounds-constrained solve (TrustRegionMinimizer::DoLineSearch -> ArmijoLineSearch::DoSearch,
+// line_search.cc; Solver::Options defaults: CUBIC interpolation, sufficient decrease 1e-4, contraction in [1e-3, 0.6], at most 20 iterations,
+// min step 1e-9).  Its own kernel, grid S x 256 threads, launched behind ps_serial in every slot: one workgroup per sequence, which exits at once
+// unless ps_serial has just formed the alpha = 1 candidate of a CONSTRAINED solve (st.ls_pending).  Every trial evaluates cost and slope
+// gradient(x_a) . delta at Plus(x, a delta) -- the evaluation roles of ps_eval one after the other, same sums as the multi-block evaluation --
+// until f(x_a) <= f(x) + 1e-4 a g^T delta; the step is then shortened to a (the candidate stays in st.Xc / c.cfeat), or, when the search fails
+// (20 trials, or a |delta|_inf < 1e-9), left as it was.  The next ps_eval evaluates whatever candidate stands, as Ceres evaluates the candidate
+// again after its search; model_change, dogleg_norm and the radius logic keep the FULL step's values.  (Kept out of ps_serial / ps_eval on
+// purpose: inlined there its stack objects gave the two hottest kernels of the solve a private segment.)
+__global__ __launch_bounds__(256) void ps_ls_kernel(Batch B) {
+    const int s = blockIdx.x + B.s0, t = threadIdx.x, nt = blockDim.x;
+    SolveSt &st = B.sst[s];
+    if (st.stage != PS_EVAL_C || !st.ls_pending) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ double sred[64];
+    Ctx c = make_ctx(B, s);
+    const BeSeq &be = *c.be;
+    const vio_config &cfg = c.C->c;
+    const int W = c.W, W1 = W + 1, P = c.P, Fa = st.Fa, nblk = st.n_eval_blocks;
+    constexpr int XD = ((int)(sizeof(Params) / sizeof(double)) + 1) & ~1;
+    Params &X = *(Params *)lds;
+    double *lsw = (double *)lds + XD, *lpart = lsw + 104;                 // scalar workspace (96) + broadcast slot, partial costs (64)
+    unsigned char *role_smem = (unsigned char *)(lsw + PS_LS_HEAD_DOUBLES - XD);
+    const double *stl = c.lvec + 4 * (size_t)c.NLs, *sl = c.lvec;
+    const double *delta = c.vec + 8 * (size_t)c.LW;   // the unscaled tangent step ps_serial left in slot 8 of the step vectors
+    const bool act = true;
+    double g0 = 0, dmax = 0;
+    for (int a = t; a < P; a += nt) { const double d = delta[a]; g0 += d * c.vec[a]; dmax = fmax(dmax, fabs(d)); }   // initial_gradient = gradient . delta
+    for (int k = t; k < Fa; k += nt) { const double d = stl[k] * sl[k]; g0 += d * c.gl[k]; dmax = fmax(dmax, fabs(d)); }
+    g0 = block_sum(g0, sred);
+    dmax = block_max(dmax, sred);   // LineSearchFunction::DirectionInfinityNorm
+    LsSample lower = {0.0, st.cost, g0, 1}, previous = {0, 0, 0, 0}, current = {0, 0, 0, 0};
+    double alpha = 1.0;
+    int it = 0, evals = 0;
+    for (;;) {
+        __syncthreads();
+        for (int k = t; k < (int)(sizeof(Params) / sizeof(double)); k += nt) ((double *)&X)[k] = ((const double *)&st.Xc)[k];
+        __syncthreads();
+        double gd = 0;
+        for (int vb = 0; vb < nblk; vb++) {
+            double cost = ps_eval_role<true>(B, s, c, st, X, c.cfeat, true, vb, t, act, role_smem, delta, stl, sl, gd);
+            cost = block_sum(cost, sred);
+            if (t == 0) lpart[vb] = cost;
+            __threadfence_block();
+            __syncthreads();   // the next role reuses the region; the IMU pass below reads c.imu_raw back
+        }
+        {
+            // the IMU factors' share of the slope: whitened residual . M (J_raw delta), raw Jacobians and residuals from c.imu_raw
+            double *vj = (double *)role_smem;   // [W][15]
+            for (int q = t; q < 15 * W; q += nt) {
+                const int i = q / 15, r = q - 15 * i;
+                const PreInt &p = c.pre[be.pre_idx[i + 1]];
+                double acc = 0;
+                if (cfg.use_imu && !(p.sum_dt > 10.0)) {
+                    const double *Jr = c.imu_raw + (size_t)i * 15 * 31 + r * 31;
+                    for (int d = 0; d < 6; d++) acc += Jr[d] * delta[6 * i + d] + Jr[15 + d] * delta[6 * (i + 1) + d];
+                    for (int d = 0; d < 9; d++) acc += Jr[6 + d] * delta[6 * W1 + 9 * i + d] + Jr[21 + d] * delta[6 * W1 + 9 * (i + 1) + d];
+                }
+                vj[q] = acc;
+            }
+            __syncthreads();
+            for (int q = t; q < 15 * W; q += nt) {
+                const int i = q / 15, r = q - 15 * i;
+                const PreInt &p = c.pre[be.pre_idx[i + 1]];
+                if (!cfg.use_imu || p.sum_dt > 10.0) continue;
+                double mu_r = 0;
+                for (int k = 0; k <= r; k++) mu_r += p.sqrt_info[r * 15 + k] * vj[15 * i + k];
+                gd += c.imu_raw[(size_t)i * 15 * 31 + r * 31 + 30] * mu_r;
+            }
+        }
+        gd = block_sum(gd, sred);
+        double total = (t & 63) < nblk ? lpart[t & 63] : 0.0;   // the sum ps_accept forms from the partial costs, on every wavefront
+        total = wave_sum_dpp(total);
+        evals++;
+        current.x = alpha; current.value = total; current.gradient = gd; current.valid = (isfinite(total) && isfinite(gd)) ? 1 : 0;
+        // one turn of ArmijoLineSearch::DoSearch's loop (uniform over the workgroup: every thread holds the same samples)
+        if (current.valid && !(current.value > st.cost + 1e-4 * g0 * current.x)) break;   // sufficient decrease: delta *= alpha, the candidate stands
+        bool fail = ++it >= 20;
+        double a_next = 1.0;
+        if (!fail) {
+            __syncthreads();
+            if (t == 0) lsw[96] = ls_next_step(lower, previous, current, 1e-3 * current.x, 0.6 * current.x, lsw);   // run-time indexed arrays in LDS
+            __syncthreads();
+            a_next = lsw[96];
+            if (a_next * dmax < 1e-9) fail = true;
+        }
+        if (fail) {
+            // "Line search failed": the step goes to the trust-region test unshortened
+            if (alpha != 1.0) { __syncthreads(); ps_form_candidate(c, st, 1.0, delta, stl, sl, sred); }
+            break;
+        }
+        previous = current;
+        alpha = a_next;
+        __syncthreads();
+        ps_form_candidate(c, st, alpha, delta, stl, sl, sred);
+        __threadfence_block();
+    }
+    if (t == 0) { st.ls_pending = 0; c.be->ls_evals += evals; c.be->ls_contractions += evals - 1; }
+}
 
 // ---------------------------------------------------------------------------------------------------------------- FINAL
 __global__ __launch_bounds__(256) void ps_final_kernel(Batch B) {

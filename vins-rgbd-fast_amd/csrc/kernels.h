@@ -12,6 +12,13 @@
 static inline size_t fast_lds_bytes(int rw, int rh) {
     return (size_t)(((rw + 6) * rh + 15) & ~15) + (size_t)((rw * rh + 15) & ~15) + (size_t)(((rw - 6) * (rh - 6) + 63) / 64 + 2) * 8 + 16;
 }
+// dynamic LDS of one evaluation role of ps_eval (be_phased.h): frame-pair geometry / staged pre-integration headers
+__host__ __device__ static inline size_t ps_eval_lds_bytes(int W) {
+    const size_t W1 = (size_t)W + 1, a = (W1 * W1 + 1) * 32 * 8, b = (size_t)W * (VIO_PREINT_HDR + 1) * 8;
+    return (a > b ? a : b) + 64;
+}
+// dynamic LDS of ps_ls_kernel: evaluation point + scalar workspace + partial costs (PS_LS_HEAD_DOUBLES) ahead of one evaluation role's region
+static inline size_t ps_ls_lds_bytes(int W) { return ((((sizeof(Params) / sizeof(double)) + 1) & ~(size_t)1) + 176) * 8 + ps_eval_lds_bytes(W) + 16; }
 struct LkImages {
     const uint8_t *prev[4];
     const uint8_t *next[4];
@@ -60,6 +67,7 @@ __global__ void ps_serial_kernel(Batch B);
 __global__ void ps_serial_big_kernel(Batch B);
 __global__ void ps_serial_kernel_512(Batch B);
 __global__ void ps_final_kernel(Batch B);
+__global__ void ps_ls_kernel(Batch B);
 __global__ void be_prior_factor_kernel(Batch B, int seq);
 __global__ void be_set_relo_kernel(Batch B, int seq, const double *par);
 __global__ void be_stage_pnp_kernel(const double *pts, int n, double *par6);

@@ -135,7 +135,8 @@ struct vio_batch {
     int imu_stage_cur = 0;
     hipEvent_t ev_imu = nullptr;
     std::vector<double> last_imu_t;
-    size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0, lds_serial = 0, lds_marg = 0, lds_factor = 0;
+    size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0, lds_serial = 0, lds_marg = 0, lds_factor = 0, lds_ps_ls = 0;
+    bool line_search = true;           // ps_ls_kernel behind every ps_serial (Ceres' projected line search on bounds-constrained solves)
     // VIO_BE_THREADS / VIO_MARG_THREADS, read at vio_create.  The marginalisation kernel runs next to the following frame's front-end:
     // with 6 instead of 8 wavefronts (256 VGPRs each) two SIMDs per CU keep half of their register file free and the LK wavefronts can
     // co-reside (be_marg 1.4 -> 1.6 ms, fe_lk 0.77 -> 0.60 ms; the front-end is the longer of the two, so the step gets shorter).
@@ -666,6 +667,9 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
                 if (h->serial_big) ps_serial_big_kernel<<<S, 512, h->lds_serial, st>>>(Bg);
                 else if (h->serial_threads <= 512) ps_serial_kernel_512<<<S, 512, h->lds_serial, st>>>(Bg);
                 else ps_serial_kernel<<<S, 1024, h->lds_serial, st>>>(Bg);
+                // Ceres' projected line search of bounds-constrained solves (one workgroup per sequence, idle otherwise); the candidate of the
+                // last slot is never evaluated, so no search follows it
+                if (h->line_search && k + 1 < slots) ps_ls_kernel<<<S, 256, h->lds_ps_ls, st>>>(Bg);
             }
             ps_final_kernel<<<S, 256, 0, st>>>(Bg);
         };
@@ -677,6 +681,7 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
             uint64_t key = 1469598103934665603ULL;
             auto mixin = [&](const void *p, size_t nbytes) { const unsigned char *q = (const unsigned char *)p; for (size_t i = 0; i < nbytes; i++) { key ^= q[i]; key *= 1099511628211ULL; } };
             mixin(&Bg, sizeof(Bg));
+            mixin(&h->line_search, sizeof(h->line_search));
             const int knobs[12] = {C.c.max_iterations + h->extra_slots, h->eval_occ, h->asm_a_occ4 ? 1 : 0, h->serial_big ? 1 : 0, h->serial_threads, h->ps_eval_blocks, h->ps_asm_a_blocks,
                                    h->ps_asm_b_blocks + 1000 * h->asm_b_by_blocks, h->ps_schur_tiles, h->xcd_map, h->xcd_n, (int)h->lds_serial};
             mixin(knobs, sizeof(knobs));
@@ -1029,8 +1034,12 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
                                       (size_t)C.W * 768 <= (W1 * W1 - W1 * C.W / 2) * 210 && nb <= 32;
                 h->solve_mode = getenv("VIO_SOLVE_MODE") ? atoi(getenv("VIO_SOLVE_MODE")) : 1;   // phased by default where it applies (windows up to ~10 keyframes)
                 if (!eligible) h->solve_mode = 0;
-                h->lds_ps_eval = std::max((W1 * W1 + 1) * 32 * 8, (size_t)C.W * (VIO_PREINT_HDR + 1) * 8) + 64;   // pair geometry / staged pre-integration headers
+                h->lds_ps_eval = ps_eval_lds_bytes(C.W);   // pair geometry / staged pre-integration headers
                 (void)raise_lds_limit((const void *)ps_eval_kernel, h->lds_ps_eval);
+                h->lds_ps_ls = ps_ls_lds_bytes(C.W);
+                (void)raise_lds_limit((const void *)ps_ls_kernel, h->lds_ps_ls);
+                // reference_quirks bit 3 (tests) / VIO_LINE_SEARCH=0 (measurement): the clamp-only treatment of the inverse-depth bound, no search launches
+                h->line_search = !(C.c.reference_quirks & VIO_QUIRK_BOUND_CLAMP_ONLY) && !(getenv("VIO_LINE_SEARCH") && atoi(getenv("VIO_LINE_SEARCH")) == 0);
                 (void)raise_lds_limit((const void *)ps_eval_kernel_occ3, h->lds_ps_eval);
                 (void)raise_lds_limit((const void *)ps_eval_kernel_occ4, h->lds_ps_eval);
                 B.eval_rpt = getenv("VIO_EVAL_RPT") ? std::max(1, std::min(4, atoi(getenv("VIO_EVAL_RPT")))) : 2;
@@ -1063,7 +1072,7 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
                     lds_fits((const void *)fe_select_kernel, h->lds_select, "fe_select") && lds_fits((const void *)fe_add_kernel, h->lds_add, "fe_add") &&
                     lds_fits((const void *)fe_fast_kernel, h->lds_fast, "fe_fast");
         if (fits && h->solve_mode == 1)
-            fits = lds_fits((const void *)ps_eval_kernel, h->lds_ps_eval, "ps_eval") &&
+            fits = lds_fits((const void *)ps_eval_kernel, h->lds_ps_eval, "ps_eval") && lds_fits((const void *)ps_ls_kernel, h->lds_ps_ls, "ps_ls") &&
                    lds_fits(h->serial_big ? (const void *)ps_serial_big_kernel : h->serial_threads <= 512 ? (const void *)ps_serial_kernel_512 : (const void *)ps_serial_kernel, h->lds_serial, "ps_serial");
         else if (fits)
             fits = lds_fits(h->be_threads <= 512 ? (const void *)be_solve_kernel_512 : (const void *)be_solve_kernel, h->lds_solve, "be_solve");
@@ -1611,6 +1620,18 @@ int vio_get_solver_kind(vio_batch *h) {
     DevGuard dev_guard(h);
     if (!h) return VIO_EINVAL;
     return h->solve_mode == 0 ? 0 : (h->serial_big ? 2 : 1);
+}
+
+// bounds-constrained solves of sequence seq since vio_create / vio_reset (estimator.cpp:1282-1297): out4 = inverse depths cut by the bound
+// while a point was formed, bounded landmarks that entered solves, trial evaluations and shortened steps of the projected Armijo line search
+int vio_get_bound_stats(vio_batch *h, int seq, int64_t *out4) {
+    DevGuard dev_guard(h);
+    if (!h || !out4 || seq < 0 || seq >= h->S) return VIO_EINVAL;
+    HIPCHK(hipDeviceSynchronize());
+    BeSeq be;
+    HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
+    out4[0] = be.bound_clamps; out4[1] = be.bounded_solves; out4[2] = be.ls_evals; out4[3] = be.ls_contractions;
+    return VIO_OK;
 }
 
 int vio_push_imu_batch(vio_batch *h, const int32_t *n, int stride, const double *t, const double *acc, const double *gyr) {

@@ -132,6 +132,9 @@ struct BeSeq {
     double relo_stamp, relo_Pose[7], prev_relo_t[3], prev_relo_r[9];
     double relo_relative_t[3], relo_relative_q[4], relo_relative_yaw, drift_correct_t[3], drift_correct_r[9];
     int dbg[16];                    // debug counters (sweeps, ticks)
+    // bounds-constrained solves (estimator.cpp:1282-1297), sticky since vio_create / vio_reset: inverse depths cut by the bound while a point was
+    // formed, bounded landmarks that entered solves, trial evaluations and shortened steps of the projected Armijo line search (vio_get_bound_stats)
+    int bound_clamps, bounded_solves, ls_evals, ls_contractions;
 };
 
 // flat parameter arrays of one solve (estimator.h para_Pose / para_SpeedBias / para_Ex_Pose / para_Td): pose = p(3) q(x,y,z,w)
@@ -160,6 +163,8 @@ struct SolveSt {
     int eval_done;        // blocks of the running evaluation that have published their partial cost (device-scope counter)
     int relo;             // this solve carries relocalisation factors: the (constant) extrinsic's six columns are lent to relo_Pose
     int test_fail;        // test hook (VIO_TEST_CHOL_FAIL_SHIFT): Cholesky factorisations of this solve still to be reported as failed
+    int constrained;      // Program::IsBoundsConstrained(): a variable landmark carries the inverse-depth bound -> Ceres' projected line search
+    int ls_pending;       // ps_serial has formed the alpha = 1 candidate of a constrained solve: ps_ls_kernel runs the search before the next ps_eval
 };
 
 // all HBM pointers of a batch; passed to kernels by value
