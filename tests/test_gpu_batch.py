@@ -8,7 +8,7 @@ import vio_ct
 pytestmark = pytest.mark.gpu
 
 
-def _drive(P, cfg, sc, seqs, n):
+def _drive(P, cfg, sc, seqs, n, hook=None):
     syn = P.Synth(sc)
     S = len(seqs)
     b = P.VioBatch(cfg, S)
@@ -23,6 +23,8 @@ def _drive(P, cfg, sc, seqs, n):
             k[i] = k2
         fr = [syn.render_host(s, float(tf)) for s in seqs]
         b.feed(np.stack([x[0] for x in fr]), np.stack([x[1] for x in fr]), [tf] * S)
+        if hook is not None:
+            hook(f, b)
     return b
 
 
@@ -134,7 +136,7 @@ def test_stream_groups_do_not_change_results(P, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"VIO_SOLVE_MODE": "0"}, {"VIO_SOLVE_MODE": "0", "VIO_BE_THREADS": "1024"}, {"VIO_FLAGS": "1"}, {"VIO_MARG_THREADS": "256"},
-                                 {"VIO_MARG_THREADS": "512"}])
+                                 {"VIO_MARG_THREADS": "512"}, {"VIO_FUSE": "0"}, {"VIO_LINE_SEARCH": "0"}])
 def test_alternative_kernel_configurations_agree(P, monkeypatch, env):
     """The non-default builds / paths kept behind environment knobs (persistent one-workgroup-per-sequence solve kernel instead of the
     phased solver, its 1024-thread build, Schur complement and Cholesky in HBM
@@ -142,7 +144,7 @@ def test_alternative_kernel_configurations_agree(P, monkeypatch, env):
     with the default configuration to round-off amplified over 24 frames (1e-6 m)."""
     cfg = P.canonical_config()
     sc = vio_ct.synth_like(cfg)
-    for k in ("VIO_BE_THREADS", "VIO_FLAGS", "VIO_MARG_THREADS", "VIO_SOLVE_MODE"):
+    for k in ("VIO_BE_THREADS", "VIO_FLAGS", "VIO_MARG_THREADS", "VIO_SOLVE_MODE", "VIO_FUSE", "VIO_LINE_SEARCH"):
         monkeypatch.delenv(k, raising=False)
     ref = _drive(P, cfg, sc, [60, 61], 24)
     ref_w = [ref.window(i).copy() for i in range(2)]
@@ -169,6 +171,30 @@ def test_block_pair_assembly_of_H_equals_the_entrywise_one(P, monkeypatch, kw):
     for i in range(3):
         assert alt.status(i).solver_flag == 1 and alt.status(i).has_prior == 1
         assert np.array_equal(alt.window(i).view(np.uint64), ref_w[i].view(np.uint64)), (i, float(np.abs(alt.window(i) - ref_w[i]).max()))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(estimate_extrinsic=1, estimate_td=1)])
+def test_fused_evaluate_and_assemble_equals_the_two_kernel_path(P, monkeypatch, kw):
+    """round 6: ps_evalf_kernel evaluates the residuals into LDS records and forms the frame-pair Gram blocks, the IMU blocks and the landmark
+    rows from there (the rows double-buffered: a rejected candidate must not touch the current ones); VIO_FUSE = 0 keeps ps_eval + ps_asm_a with
+    the records in HBM.  Same mathematics; where a frame pair's residuals span two chunks the partial blocks are added in chunk order instead
+    of accumulated in one MFMA chain, so the windows agree to round-off amplified over the run, not bit for bit: 40 frames in motion (3 - 4
+    chunks per solve, rejected steps included), 1e-6 m, the same iteration counts in (almost) every frame.  With the extrinsic / td blocks
+    variable the solves leave the fused path as soon as those blocks open (42-double records) and fall back, inside the same handle."""
+    cfg = P.canonical_config(**kw)
+    sc = vio_ct.synth_like(cfg)
+    seqs, n = [60, 61, 62, 63], 40
+    monkeypatch.setenv("VIO_FUSE", "0")
+    its_ref, its_alt = [], []
+    ref = _drive(P, cfg, sc, seqs, n, hook=lambda f, b: its_ref.append([b.status(i).iterations for i in range(len(seqs))]))
+    ref_w = [ref.window(i).copy() for i in range(len(seqs))]
+    monkeypatch.setenv("VIO_FUSE", "1")
+    alt = _drive(P, cfg, sc, seqs, n, hook=lambda f, b: its_alt.append([b.status(i).iterations for i in range(len(seqs))]))
+    for i in range(len(seqs)):
+        assert alt.status(i).solver_flag == 1 and alt.status(i).has_prior == 1 and alt.status(i).overflow_flags == 0
+        assert np.abs(alt.window(i)[:, :3] - ref_w[i][:, :3]).max() < 1e-6, (kw, i, float(np.abs(alt.window(i)[:, :3] - ref_w[i][:, :3]).max()))
+    same = np.mean(np.array(its_ref) == np.array(its_alt))
+    assert same > 0.95, same
 
 
 def test_status_all_equals_per_sequence_status(P):

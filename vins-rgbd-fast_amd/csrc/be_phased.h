@@ -25,6 +25,16 @@ __device__ __forceinline__ unsigned ps_colmask(int W1, int LW, bool vext) {
     return m;
 }
 
+// The landmark rows (Hpl, Hll, gl) are double-buffered: the fused evaluate + assemble kernel builds the rows of the point it evaluates -- a
+// candidate that may still be rejected -- into the half that is NOT current (st.rowbuf ^ 1), ps_accept flips st.rowbuf when the point is taken.
+// Second half = the same arrays one handle-size further (vio_abi.hip allocates them twice).  Everything else uses half 0 / st.rowbuf.
+__device__ __forceinline__ int fis_early(const SolveSt &st, int chunk, int pslot) { return st.fi[chunk][pslot]; }
+__device__ __forceinline__ void ps_sel_rows(const Batch &B, Ctx &c, int buf) {
+    if (!buf) return;
+    const size_t S = (size_t)B.S, n8 = (size_t)c.NL + 8;
+    c.Hpl += S * n8 * c.LW; c.Hll += S * n8; c.gl += S * n8;
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------- setup
@@ -69,6 +79,63 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(Batch B) {
         __syncthreads();
         if (t == 0) { st.constrained = constrained ? 1 : 0; st.ls_pending = 0; be.bounded_solves += (int)nb; be.bound_clamps += (int)ncl; }
     }
+    // Fused evaluate + assemble (ps_evalf_kernel): the projection residuals are cut into chunks of whole landmarks -- chunk b starts at the first
+    // in-problem landmark whose first residual index is >= b C, C = PS_FUSE_CAP - W (a landmark has at most W residuals, so no chunk exceeds
+    // PS_FUSE_CAP); every boundary is an independent binary search.  A frame pair whose residuals fall into several chunks gets one partial Gram
+    // block per chunk (pm_np); the chunk that publishes the last one sums them in chunk order.
+    {
+        const int *plist = c.pair_list + c.nres_cap - 2 * c.NL;
+        const int Cc = PS_FUSE_CAP - c.W, nblk = (nres + Cc - 1) / Cc, W1f = c.W + 1;
+        const bool fused = B.fuse > 0 && !(sh_i[0] || sh_i[1] || sh_i[4]) && c.W <= PS_FUSE_MAXW && nblk <= PS_FUSE_MAXBLK && c.C->c.use_imu;   // (B.fuse = chunk workgroups per sequence in the grid; they loop when there are more chunks)
+        if (fused) {
+            if (t <= nblk) {
+                int lo = 0, hi = F;   // first in-problem landmark (list position) whose first residual index is >= t C
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (c.lm_tmp[plist[mid]] >= t * Cc) hi = mid; else lo = mid + 1; }
+                if (t == nblk) lo = F;
+                int k = lo;
+                while (k < F && c.lm_aidx[plist[k]] < 0) k++;   // (constant landmarks carry no row)
+                st.blk_p[t] = lo;
+                st.blk_r[t] = lo < F ? min(c.lm_tmp[plist[lo]], nres) : nres;
+                st.blk_ka[t] = k < F ? c.lm_aidx[plist[k]] : Fa;
+            }
+            __syncthreads();
+            // per frame pair (one wavefront each): which part of its residual list (ascending indices) falls into which chunk -- fixed for the
+            // whole solve, so the fused kernel finds its work in a table instead of scanning lists every iteration
+            const int lane = t & 63, wave = t >> 6, nw = blockDim.x >> 6;
+            int br[PS_FUSE_MAXBLK + 1];
+#pragma unroll
+            for (int b2 = 0; b2 <= PS_FUSE_MAXBLK; b2++) br[b2] = ((volatile int *)st.blk_r)[min(b2, nblk)];
+            for (int p = wave; p < W1f * W1f; p += nw) {
+                const int i = p / W1f, j = p - i * W1f;
+                if (!(i < j)) continue;
+                const int q0 = c.pair_start[p], np_ = c.pair_start[p + 1] - q0, ps_ = pair_slot(i, j, W1f);
+                int lo[PS_FUSE_MAXBLK + 1];
+#pragma unroll
+                for (int b2 = 0; b2 <= PS_FUSE_MAXBLK; b2++) lo[b2] = 0;
+                for (int base = 0; base < np_; base += 64) {
+                    const bool valid = base + lane < np_;
+                    const int r = c.pair_list[q0 + min(base + lane, np_ - 1)];
+#pragma unroll
+                    for (int b2 = 0; b2 <= PS_FUSE_MAXBLK; b2++) lo[b2] += __popcll(__ballot(valid && b2 <= nblk && r < br[b2]));
+                }
+                int rank = 0;
+#pragma unroll
+                for (int b2 = 0; b2 < PS_FUSE_MAXBLK; b2++) {
+                    const int cnt = b2 < nblk ? lo[b2 + 1] - lo[b2] : 0;
+                    if (lane == 0) st.fi[b2][ps_] = (q0 + lo[b2]) | (cnt << 16) | (rank << 26);
+                    rank += cnt > 0 ? 1 : 0;
+                }
+                if (lane == 0) st.pm_np[ps_] = rank;
+            }
+        }
+        __syncthreads();
+        // (B.fuse < 0: the handle launches ONLY the fused kernel -- its configuration cannot produce anything else; should a solve still not
+        // qualify it is flagged, overflow bit 256, rather than left waiting for kernels that never come)
+        // -- and left out of this frame's optimisation (PS_DONE at once: ps_final hands the unoptimised window back)
+        if (t == 0 && !fused && B.fuse_only) be.overflow |= 256;
+        if (!fused && B.fuse_only) { __syncthreads(); if (t == 0) { st.fused = 0; st.nblk = 0; st.rowbuf = 0; st.chunk_done = 0; st.stage = PS_DONE; st.cost = 0; st.iters_done = 0; st.succ = 0; st.ts0 = ts0; } return; }
+        if (t == 0) { st.fused = fused ? 1 : 0; st.nblk = fused ? nblk : 0; st.rowbuf = 0; st.chunk_done = 0; }
+    }
     for (int k = t; k < (int)(sizeof(Params) / sizeof(double)); k += blockDim.x) ((double *)&st.X)[k] = ((const double *)&X)[k];
     if (t == 0) {
         st.F = F; st.Fa = Fa; st.nres = nres;
@@ -80,7 +147,8 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(Batch B) {
         st.iter = 0; st.iters_done = 0; st.succ = 0; st.invalid = 0;
         st.point_new = 0; st.scale_pending = 1; st.retry = 0; st.cauchy_valid = 0; st.eval_with_J = 1;
         st.test_fail = (c.C->c.reference_quirks >> VIO_TEST_CHOL_FAIL_SHIFT) & VIO_TEST_CHOL_FAIL_MASK;
-        st.n_eval_blocks = 3 + (nres + 256 * B.eval_rpt - 1) / (256 * B.eval_rpt);
+        // (fused: workgroup 0 = prior, 1 = IMU factors, then one per chunk of projection residuals)
+        st.n_eval_blocks = st.fused ? 2 + min(st.nblk, B.fuse) : 3 + (nres + 256 * B.eval_rpt - 1) / (256 * B.eval_rpt);
         st.eval_done = 0;
         st.ts0 = ts0;
         st.stage = PS_EVAL_X0;
@@ -101,7 +169,7 @@ __device__ void ps_accept(const Batch &B, int s) {
     double total = t < st.n_eval_blocks ? ((volatile double *)st.part)[t] : 0.0;
     total = wave_sum_dpp(total);
     if (st.stage == PS_EVAL_X0) {
-        if (t == 0) { st.cost = total; c.be->initial_cost = total; st.point_new = 1; st.stage = PS_ASM; }
+        if (t == 0) { st.cost = total; c.be->initial_cost = total; st.point_new = 1; st.stage = PS_ASM; if (st.fused) st.rowbuf ^= 1; }
         return;
     }
     const double ccost = total, cost = st.cost;
@@ -141,6 +209,7 @@ __device__ void ps_accept(const Batch &B, int s) {
             if (rel > 0.75) st.radius = fmax(st.radius, 3.0 * st.dogleg_norm);
             st.mu = fmax(1e-8, 2.0 * st.mu / 10.0);
             st.point_new = 1;
+            if (st.fused && st.eval_with_J) st.rowbuf ^= 1;   // the rows the fused kernel built for this candidate become the current ones
             st.stage = st.iter >= cfg.max_iterations ? PS_DONE : PS_ASM;   // the candidate of the last iteration carries no Jacobians
         } else {
             st.radius *= 0.5;
@@ -419,7 +488,7 @@ __device__ __forceinline__ void ps_eval_body(const Batch &B) {
     const int t = threadIdx.x, nt = blockDim.x;
     SolveSt &st = B.sst[s];
     if (st.stage != PS_EVAL_X0 && st.stage != PS_EVAL_C) return;
-    if (b >= st.n_eval_blocks) return;
+    if (st.fused || b >= st.n_eval_blocks) return;   // (fused solves are evaluated by ps_evalf_kernel)
     Ctx c = make_ctx(B, s);
     const BeSeq &be = *c.be;
     const vio_config &cfg = c.C->c;
@@ -621,8 +690,9 @@ __device__ __forceinline__ void ps_asm_a_body(const Batch &B) {
     if (!ps_blk(B, s, bq)) return;
     const int t = threadIdx.x;
     const SolveSt &st = B.sst[s];
-    if (st.stage != PS_ASM) return;
+    if (st.stage != PS_ASM || st.fused) return;   // (the fused kernel has already built a fused solve's blocks and rows)
     Ctx c = make_ctx(B, s);
+    ps_sel_rows(B, c, st.rowbuf);
     const BeSeq &be = *c.be;
     const int W = c.W, W1 = W + 1, LW = c.LW;
     const int lane = t & 63, wave = t >> 6, li = lane & 15, lk = lane >> 4;
@@ -820,6 +890,367 @@ __device__ __forceinline__ void ps_asm_a_body(const Batch &B) {
 __global__ __launch_bounds__(512) void ps_asm_a_kernel(Batch B) { ps_asm_a_body(B); }
 // VIO_ASM_A_OCC = 4: the same kernel held to 128 VGPRs (20 bytes of scratch) so that two workgroups share a compute unit
 __global__ __launch_bounds__(512, 4) void ps_asm_a_kernel_occ4(Batch B) { ps_asm_a_body(B); }
+
+// ---------------------------------------------------------------------------------------------------------------- EVAL + ASM_A fused
+// Round 6: evaluation and the first half of the assembly in ONE kernel, so that the residual records (28 doubles per residual: 0.42 MB per
+// sequence and iteration, written by ps_eval and read back twice by ps_asm_a) never leave the compute unit.  Grid (2 + chunks, S), 256
+// threads, two workgroups per CU (78 KB of LDS each).  Workgroup 0 of a sequence: the prior (ps_eval's block 0).  Workgroup 1: the IMU factors,
+// one work type per wavefront, raw Jacobians into LDS, then the ten IMU Gram blocks on the matrix cores.  Workgroup b >= 2: chunk b - 2 of the
+// projection residuals (whole landmarks, at most PS_FUSE_CAP residuals, cut by ps_setup): thread = residual, record into LDS; then, from LDS,
+//   * the frame-pair Gram blocks [J r]^T [J r] of the pairs the chunk holds (one wavefront per pair, the MFMA sequence of ps_asm_a; a pair
+//     whose residuals span chunks gets one partial block per chunk and the chunk that publishes the last one sums them in chunk order:
+//     deterministic, whichever finishes last), and
+//   * the landmark rows of the chunk's landmarks (eight lanes per landmark, ps_asm_a's code on LDS records) -- into the half of the
+//     double-buffered rows that is NOT current: the evaluated point may still be rejected (ps_sel_rows, ps_accept).
+// Same mathematics as ps_eval + ps_asm_a: identical rows and IMU blocks, identical pair blocks where a pair sits in one chunk, a different
+// association of the same sums where it is split.  Only solves with compact records take this path (extrinsic / td constant, no
+// relocalisation factors, W <= PS_FUSE_MAXW: st.fused, ps_setup); the others keep ps_eval + ps_asm_a, whose launches idle for fused solves.
+__global__ __launch_bounds__(256) void ps_evalf_kernel(Batch B) {
+    // Block -> (sequence, role).  ROLE-major over the launch (every sequence's IMU workgroup first -- the longest --, then the priors, then chunk
+    // 0 of every sequence, chunk 1, ...): with two workgroups per CU a 64-sequence launch has 576 workgroups for 512 slots, and in sequence-
+    // major order the last eight sequences started -- IMU workgroup included -- when the first ones had finished (kernel = two full rounds,
+    // 82 us median); now the overflow is the last chunk of every sequence, which many sequences do not even have.  The stride between roles is a
+    // multiple of the XCD count, so every workgroup of sequence r still runs on XCD r % X (ps_blk).
+    int s, b;
+    if (B.xcd_nb == 0) { s = (int)blockIdx.y + B.s0; b = (int)blockIdx.x; }
+    else {
+        const int X = B.xcd_n, S8 = X * ((B.ns + X - 1) / X), L = (int)blockIdx.x, role = L / S8, r = L - role * S8;
+        if (r >= B.ns) return;
+        s = r + B.s0;
+        b = role == 0 ? 1 : (role == 1 ? 0 : role);
+    }
+    const int t = threadIdx.x, nt = 256;
+    constexpr int NW = 4;   // wavefronts
+    SolveSt &st = B.sst[s];
+    if (st.stage != PS_EVAL_X0 && st.stage != PS_EVAL_C) return;
+    if (!st.fused || b >= st.n_eval_blocks) return;
+    Ctx c = make_ctx(B, s);
+    ps_sel_rows(B, c, st.rowbuf ^ 1);   // the rows of the point under evaluation
+    const BeSeq &be = *c.be;
+    const vio_config &cfg = c.C->c;
+    const bool cand = st.stage == PS_EVAL_C;
+    const double *feat = cand ? c.cfeat : c.feat;
+    const bool withJ = st.eval_with_J != 0;
+    const int W = c.W, W1 = W + 1, n = c.NPR, LW = c.LW;
+    const int lane = t & 63, wave = t >> 6, li = lane & 15, lk = lane >> 4;
+    __shared__ double sred[64];
+    __shared__ Params X;
+    {
+        const double *src = (const double *)(cand ? &st.Xc : &st.X);
+        for (int k = t; k < (int)(sizeof(Params) / sizeof(double)); k += nt) ((double *)&X)[k] = src[k];
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double cost = 0;
+    PH_INIT;
+    __syncthreads();
+    if (b == 0) {
+        // ---- prior gradient q = b + A dx and cost dx^T b + 1/2 dx^T A dx (the code of ps_eval's block 0), and the zero Gram blocks of frame pairs
+        // without residuals (ps_asm_b reads every pair)
+        double *dxs = (double *)smem, *pacc = dxs + ((n + 1) & ~1);
+        if (withJ)
+            for (int p = wave; p < W1 * W1; p += NW) {
+                const int i = p / W1, j = p - i * W1;
+                if (i < j && c.pair_start[p + 1] == c.pair_start[p]) { double *o = c.pairblk + (size_t)pair_slot(i, j, W1) * 210; for (int e = lane; e < 210; e += 64) o[e] = 0; }
+            }
+        if (be.has_prior) {
+            prior_dx(c, X, dxs, true);
+            const int nch = max(1, min(4, nt / n));
+            if (t < nch * n) {
+                // up to four threads per row, each over a share of the columns, every load of a thread in flight at once
+                const int ch = t / n, row = t - ch * n;
+                const int per = (n + nch - 1) / nch, j0 = ch * per, j1 = min(n, j0 + per);
+                constexpr int MAXJ = 32;
+                double acc = 0;
+                if (j1 - j0 <= MAXJ) {
+                    double hv[MAXJ];
+#pragma unroll
+                    for (int u = 0; u < MAXJ; u++) hv[u] = c.prior_H[(size_t)min(j0 + u, n - 1) * n + row];
+#pragma unroll
+                    for (int u = 0; u < MAXJ; u++) if (j0 + u < j1) acc += hv[u] * dxs[j0 + u];
+                } else
+                    for (int j = j0; j < j1; j += 8) {
+                        double hv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) hv[u] = c.prior_H[(size_t)min(j + u, j1 - 1) * n + row];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) if (j + u < j1) acc += hv[u] * dxs[j + u];
+                    }
+                pacc[ch * n + row] = acc;
+            }
+            __syncthreads();
+            if (t < n) {
+                double acc = pacc[t];
+                for (int ch = 1; ch < nch; ch++) acc += pacc[ch * n + t];
+                const double b0 = c.prior_r[t], d = dxs[t], q = b0 + acc;
+                st.srp[t] = q;
+                st.sdx[t] = d;
+                cost += 0.5 * d * (b0 + q);
+            }
+            if (t == 0) cost += 0.5 * be.prior_c0;
+        }
+        PH(62);
+    } else if (b == 1) {
+        // ---- IMU factors: headers staged in LDS, one work type per wavefront (whitened residual | d / d pose_i | d / d speed-bias_i | d / d pose_j and
+        // d / d speed-bias_j -- the last one is three copies of two matrices), lane = factor, raw Jacobians into LDS; then the Gram blocks
+        double *pl = (double *)smem;
+        constexpr int PH_LD = VIO_PREINT_HDR + 1;
+        double *rawl = pl + (size_t)W * PH_LD;                               // [W][15 x 31] raw Jacobians | whitened residual
+        for (int q0 = t; q0 < W * PH_LD; q0 += 10 * nt) {   // (ten loads in flight per thread and trip)
+            double v[10];
+#pragma unroll
+            for (int u = 0; u < 10; u++) {
+                const int q = min(q0 + u * nt, W * PH_LD - 1), i = q / PH_LD, e = min(q - i * PH_LD, VIO_PREINT_HDR - 1);
+                v[u] = ((const double *)&c.pre[be.pre_idx[i + 1]])[e];
+            }
+#pragma unroll
+            for (int u = 0; u < 10; u++) if (q0 + u * nt < W * PH_LD) pl[q0 + u * nt] = v[u];
+        }
+        __syncthreads();
+        {
+            const v3 G = ld3(be.g);
+            const int wt = wave;
+            for (int i = lane; i < W; i += 64) {
+                const int j = i + 1;
+                const PreInt &p = *(const PreInt *)(pl + (size_t)i * PH_LD);   // only the header fields are read
+                double *out = rawl + (size_t)i * 465;
+                if (p.sum_dt > 10.0) { if (wt == 0) for (int k = 0; k < 15; k++) out[k * 31 + 30] = 0; continue; }
+                if (wt == 0) {
+                    double raw[15];
+                    bf::imu_raw_residual(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], raw);
+                    for (int r = 0; r < 15; r++) {
+                        double sacc = 0;
+                        for (int k = 0; k <= r; k++) sacc += p.sqrt_info[r * 15 + k] * raw[k];
+                        out[r * 31 + 30] = sacc;
+                        cost += 0.5 * sacc * sacc;
+                    }
+                } else if (withJ) {
+                    bf::imu_raw_jacobian_part(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], wt - 1, out, 31);
+                    if (wt == 3) bf::imu_raw_jacobian_part(p, G, &X.pose[i * 7], &X.sb[i * 9], &X.pose[j * 7], &X.sb[j * 9], 3, out, 31);
+                }
+            }
+        }
+        __syncthreads();
+        if (withJ)
+            for (int i = wave; i < W; i += NW) {   // IMU Gram blocks [Jw r]^T [Jw r] on the matrix cores, one wavefront per factor
+                const PreInt &p = *(const PreInt *)(pl + (size_t)i * PH_LD);
+                double *G = ps_imu_blk(c) + (size_t)i * 768;
+                if (p.sum_dt > 10.0) { for (int e = lane; e < 768; e += 64) G[e] = 0; continue; }
+                v4f64 a00 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
+                imu_block_mfma(rawl + (size_t)i * 465, p.sqrt_info, li, lk, a00, a10, a11);
+                for (int r = 0; r < 4; r++) {
+                    const int e = (lk + 4 * r) * 16 + li;
+                    G[e] = a00[r]; G[256 + e] = a10[r]; G[512 + e] = a11[r];
+                }
+            }
+        PH(63);
+    } else {
+        // ---- chunks b - 2, b - 2 + G, ... of the projection residuals (G = B.fuse chunk workgroups per sequence in the grid: one chunk each in
+        // the steady state, a second pass for the longer residual lists right after the initialisation): evaluate into LDS records, then Gram
+        // blocks and landmark rows from LDS
+        const int nblk = st.nblk;
+        __shared__ int fis[PS_FUSE_MAXPAIRS];                      // this chunk's row of the pair table
+        auto chunk = [&](const int pb) {
+        const int r0 = st.blk_r[pb], r1 = st.blk_r[pb + 1], nin = r1 - r0, nres = st.nres;
+        double *rec = (double *)smem;                              // [PS_FUSE_CAP][28]
+        double *geo = rec + (size_t)PS_FUSE_CAP * 28;              // [W1 W / 2 + 1][32] frame-pair geometry by pair slot (i < j), then ric
+        int (*lmm)[3] = (int (*)[3])(geo + (size_t)(W1 * W / 2 + 1) * 32);   // per variable landmark of the chunk (each has a residual: at most PS_FUSE_CAP): first record, start frame, observations
+        const int Fa_ = st.Fa, ka_lo = st.blk_ka[pb], ka_n = min(min(st.blk_ka[pb + 1], Fa_) - ka_lo, PS_FUSE_CAP);
+        if (t < W1 * W / 2) fis[t] = st.fi[pb][t];
+        if (withJ && t < ka_n) {
+            const int slot = (c.pair_list + c.nres_cap - c.NL)[ka_lo + t];
+            lmm[t][0] = c.lm_tmp[slot]; lmm[t][1] = c.lm_start[slot]; lmm[t][2] = c.lm_nobs[slot];
+        }
+        // this thread's residual: its indices and inputs are fetched before the barrier (a chain of three dependent loads hidden behind the staging)
+        int slot_r = 0, k_r = 1, imu_i = 0;
+        double inv_dep = 1.0;
+        const double *oi_p = nullptr, *oj_p = nullptr;
+        if (t < nin) {
+            slot_r = c.res_lm[r0 + t]; k_r = c.res_k[r0 + t];
+            imu_i = c.lm_start[slot_r];
+            inv_dep = feat[c.lm_pidx[slot_r]];
+            oi_p = obs_ptr(c, slot_r, imu_i); oj_p = obs_ptr(c, slot_r, imu_i + k_r);
+        }
+        const int npairs = W1 * W / 2;
+        for (int q = t; q <= npairs; q += nt) {
+            if (q == npairs) { stm(geo + (size_t)q * 32, q2R(mkq(X.ex[6], X.ex[3], X.ex[4], X.ex[5]))); continue; }
+            if (((fis_early(st, pb, q) >> 16) & 0x3FF) == 0) continue;   // (only the pairs this chunk evaluates)
+            int i = 0, rem = q;
+            while (rem >= W1 - 1 - i) { rem -= W1 - 1 - i; i++; }
+            const int j = i + 1 + rem;
+            bf::PairGeo g;
+            bf::pair_geo(&X.pose[i * 7], &X.pose[j * 7], X.ex, g);
+            double *o = geo + (size_t)q * 32;
+            for (int e = 0; e < 9; e++) { o[e] = g.A1[e]; o[9 + e] = g.A2[e]; o[18 + e] = g.M[e]; }
+            o[27] = g.t[0]; o[28] = g.t[1]; o[29] = g.t[2];
+        }
+        __syncthreads();
+        const double *ricm = geo + (size_t)npairs * 32;
+        if (t < nin) {
+            const int imu_j = imu_i + k_r;
+            const bf::PairGeo &g = *(const bf::PairGeo *)(geo + (size_t)pair_slot(imu_i, imu_j, W1) * 32);
+            double rr[2], wgt = 1.0;
+            double *out = rec + (size_t)t * 28;
+            bf::eval_projection_pair(cfg, g, ricm, X.ex, inv_dep, X.td, oi_p, oj_p, cfg.estimate_td != 0, rr, withJ ? out : nullptr, true, &wgt, 14, false);
+            const double sq = rr[0] * rr[0] + rr[1] * rr[1];
+            if (withJ) { out[13] = wgt * rr[0]; out[27] = wgt * rr[1]; }
+            cost += 0.5 * log(1.0 + sq);
+        }
+        PH(14);
+        __syncthreads();
+        if (withJ) {
+            // (1) frame-pair Gram blocks of the pairs that have residuals in this chunk (table from ps_setup, staged in LDS before the evaluation);
+            // one wavefront per pair
+            {
+                for (int slot_p = wave; slot_p < W1 * W / 2; slot_p += NW) {
+                    const int e_ = fis[slot_p], cnt = (e_ >> 16) & 0x3FF;
+                    if (cnt == 0) continue;
+                    const int qlo = e_ & 0xFFFF, rank = (e_ >> 26) & 15;
+                    v4f64 a00 = {0, 0, 0, 0};
+                    const int lcol = li < 12 ? li : 13;
+                    for (int base = 0; base < cnt; base += 64) {
+                        const int nchunk = min(64, cnt - base);
+                        const int myidx = c.pair_list[qlo + base + min(lane, nchunk - 1)] - r0;   // record index within the chunk
+                        const int Kc = 2 * nchunk;
+                        for (int k0 = 0; k0 < Kc; k0 += 4 * PB_U) {
+                            double x0[PB_U];
+#pragma unroll
+                            for (int u = 0; u < PB_U; u++) {
+                                const int kk = k0 + 4 * u + lk;
+                                const int ridx = __shfl(myidx, min(kk, Kc - 1) >> 1, 64);
+                                const double v0 = rec[(size_t)ridx * 28 + (kk & 1) * 14 + lcol];
+                                x0[u] = (kk < Kc && li < 13) ? v0 : 0.0;
+                            }
+#pragma unroll
+                            for (int u = 0; u < PB_U; u++) a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u], x0[u], a00, 0, 0, 0);
+                        }
+                    }
+                    const int npart = st.pm_np[slot_p];
+                    double *part0 = B.pairpart + ((size_t)s * PS_FUSE_MAXPAIRS + slot_p) * PS_FUSE_MAXBLK * 210;
+                    double *out = npart <= 1 ? c.pairblk + (size_t)slot_p * 210 : part0 + (size_t)rank * 210;
+                    for (int r = 0; r < 4; r++) {
+                        const int row = lk + 4 * r, col = li;
+                        if (row < 12) { if (col <= row) out[sym_idx(col, row)] = a00[r]; }
+                        else if (row == 12 && col <= 12) out[sym_idx(col < 12 ? col : 19, 19)] = a00[r];
+                    }
+                    // (a pair whose residuals span chunks: this is one of its partial blocks; the chunk that finishes last adds them up, below)
+                }
+            }
+            PH(32);
+            // (2) landmark rows of the chunk's variable landmarks (the last chunk also writes the zero rows that pad to a multiple of four):
+            // eight lanes per landmark, lane = frame (f = l8, l8 + 8) -- the coupling with frame f from the one residual that observes it, the
+            // start-frame block / Hll / gl from sums over the residuals that are reduced across the eight lanes, zeros elsewhere
+            {
+                const int Fa = Fa_, Kpad = (Fa + 3) & ~3;
+                const int ka_hi = pb == nblk - 1 ? Kpad : st.blk_ka[pb + 1];
+                const int w0 = min(LW, (6 * W1 + 15) & ~15);
+                const int l8 = lane & 7;
+                for (int ka = ka_lo + wave * 8 + (lane >> 3); ka < ka_hi; ka += 8 * NW) {
+                    const bool real = ka < Fa;
+                    int stf = 0, kend = 0;
+                    const double *lrec = rec;
+                    if (real) {
+                        const int rl = lmm[ka - ka_lo][0];
+                        stf = lmm[ka - ka_lo][1];
+                        kend = min(lmm[ka - ka_lo][2], nres - rl + 1);
+                        lrec = rec + (size_t)(rl - r0) * 28;
+                    }
+                    double *row = c.Hpl + (size_t)ka * LW;
+                    double si[6] = {0, 0, 0, 0, 0, 0}, hll = 0, gg = 0;
+                    constexpr int NH = (PS_FUSE_MAXW + 1 + 7) / 8;
+                    double blk[NH][6];
+                    bool has[NH];
+#pragma unroll
+                    for (int h = 0; h < NH; h++) {
+                        const int f = l8 + 8 * h, k = f - stf;
+                        has[h] = real && f < W1 && k >= 1 && k < kend;
+                        const double2 *J2 = (const double2 *)(lrec + (size_t)(has[h] ? k - 1 : 0) * 28);
+                        double a[6], bb[6], e[6], g6[6];
+#pragma unroll
+                        for (int q = 0; q < 3; q++) {
+                            const double2 va = J2[q], vb = J2[3 + q], ve = J2[7 + q], vf = J2[10 + q];
+                            a[2 * q] = va.x; a[2 * q + 1] = va.y; bb[2 * q] = vb.x; bb[2 * q + 1] = vb.y;
+                            e[2 * q] = ve.x; e[2 * q + 1] = ve.y; g6[2 * q] = vf.x; g6[2 * q + 1] = vf.y;
+                        }
+                        const double2 p0 = J2[6], p1 = J2[13];   // (inv_depth column, weighted residual) of the two rows
+                        const double l0 = has[h] ? p0.x : 0.0, l1 = has[h] ? p1.x : 0.0;
+#pragma unroll
+                        for (int d = 0; d < 6; d++) {
+                            si[d] += a[d] * l0 + e[d] * l1;
+                            blk[h][d] = bb[d] * l0 + g6[d] * l1;
+                        }
+                        hll += l0 * l0 + l1 * l1;
+                        gg += l0 * (has[h] ? p0.y : 0.0) + l1 * (has[h] ? p1.y : 0.0);
+                    }
+#pragma unroll
+                    for (int off = 4; off >= 1; off >>= 1) {
+#pragma unroll
+                        for (int d = 0; d < 6; d++) si[d] += __shfl_xor(si[d], off, 8);
+                        hll += __shfl_xor(hll, off, 8);
+                        gg += __shfl_xor(gg, off, 8);
+                    }
+#pragma unroll
+                    for (int h = 0; h < NH; h++) {
+                        const int f = l8 + 8 * h;
+                        if (f < W1) {
+                            const bool start = real && f == stf;
+#pragma unroll
+                            for (int d = 0; d < 6; d++) row[6 * f + d] = start ? si[d] : (has[h] ? blk[h][d] : 0.0);
+                        }
+                    }
+                    for (int q = 6 * W1 + l8; q < w0; q += 8) row[q] = 0;
+                    if (l8 == 0) { c.Hll[ka] = hll; c.gl[ka] = gg; }
+                }
+            }
+            PH(35);
+        }
+        };
+        // (the first chunk as straight-line code: as a general loop the kernel was 6 % slower)
+        chunk(b - 2);
+        for (int pb = b - 2 + B.fuse; pb < nblk; pb += B.fuse) { __syncthreads(); chunk(pb); }   // (the previous chunk's records are still being read)
+    }
+    cost = block_sum(cost, sred);
+    // ONE device-scope release per workgroup (on gfx950 a fence at agent scope writes the XCD's L2 back: a fence per published partial block
+    // made every workgroup on the device seven times slower): partial cost, partial Gram blocks and -- for the kernels that follow -- rows
+    __shared__ int last, lastc;
+    if (t == 0) {
+        st.part[b] = cost;
+        __threadfence();
+        const int mine = b >= 2 ? (st.nblk - (b - 2) + B.fuse - 1) / B.fuse : 0;   // chunks this workgroup took
+        lastc = (mine > 0 && withJ) ? (atomicAdd(&st.chunk_done, mine) == st.nblk - mine) : 0;
+        last = atomicAdd(&st.eval_done, 1) == st.n_eval_blocks - 1;
+    }
+    __syncthreads();
+    if (lastc) {
+        // the chunk that finished last: frame pairs whose residuals span chunks have one partial Gram block per chunk -- added up in chunk
+        // order (deterministic whichever chunk gets here), one wavefront per pair
+        __threadfence();
+        if (t == 0) st.chunk_done = 0;
+        // (this is a serial tail of the kernel: every load of a pair in flight at once -- as a chain of volatile loads it took 25 us)
+        for (int slot_p = wave; slot_p < W1 * W / 2; slot_p += NW) {
+            const int npart = st.pm_np[slot_p];
+            if (npart <= 1) continue;
+            const double *part0 = B.pairpart + ((size_t)s * PS_FUSE_MAXPAIRS + slot_p) * PS_FUSE_MAXBLK * 210;
+            double *dst = c.pairblk + (size_t)slot_p * 210;
+            double v[PS_FUSE_MAXBLK][4];
+#pragma unroll
+            for (int q = 0; q < PS_FUSE_MAXBLK; q++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[q][u] = part0[(size_t)min(q, npart - 1) * 210 + min(lane + 64 * u, 209)];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                double acc = v[0][u];
+#pragma unroll
+                for (int q = 1; q < PS_FUSE_MAXBLK; q++) if (q < npart) acc += v[q][u];
+                if (lane + 64 * u < 210) dst[lane + 64 * u] = acc;
+            }
+        }
+    }
+    if (last && t < 64) {
+        __threadfence();
+        if (t == 0) st.eval_done = 0;
+        ps_accept(B, s);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------------------------- ASM_B
 // grid (NB, S), 256 threads: one thread per entry (a, b) of H (both triangles, every entry of the P x LW block is written, so no
@@ -1067,6 +1498,7 @@ __device__ __forceinline__ void ps_schur_body(const Batch &B, int s, int tile_in
     const SolveSt &st = B.sst[s];
     if (st.stage != PS_ASM && st.stage != PS_SCHUR) return;
     Ctx c = make_ctx(B, s);
+    ps_sel_rows(B, c, st.rowbuf);
     const int W1 = c.W + 1, LW = c.LW, nb = LW >> 4;
     const unsigned colmask = ps_colmask(W1, LW, st.vext != 0);
     // the tile_index-th active tile (ti >= tj, both column tiles active)
@@ -1141,6 +1573,7 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
     SolveSt &st = B.sst[s];
     if (st.stage != PS_ASM && st.stage != PS_SCHUR && st.stage != PS_STEP) return;
     Ctx c = make_ctx(B, s);
+    ps_sel_rows(B, c, st.rowbuf);
     const vio_config &cfg = c.C->c;
     const int W = c.W, W1 = W + 1, P = c.P, LW = c.LW;
     __shared__ double sred[64];
@@ -1414,6 +1847,7 @@ __global__ __launch_bounds__(256) void ps_ls_kernel(Batch B) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ double sred[64];
     Ctx c = make_ctx(B, s);
+    ps_sel_rows(B, c, st.rowbuf);
     const BeSeq &be = *c.be;
     const vio_config &cfg = c.C->c;
     const int W = c.W, W1 = W + 1, P = c.P, Fa = st.Fa, nblk = st.n_eval_blocks;

@@ -68,6 +68,13 @@ __global__ void ps_serial_big_kernel(Batch B);
 __global__ void ps_serial_kernel_512(Batch B);
 __global__ void ps_final_kernel(Batch B);
 __global__ void ps_ls_kernel(Batch B);
+__global__ void ps_evalf_kernel(Batch B);
+// dynamic LDS of ps_evalf_kernel: a chunk's records + the frame-pair geometry (by pair slot), (+ the chunk's landmark table), or (workgroup 1) staged pre-integration headers + raw IMU
+// Jacobians, or (workgroup 0) the prior's vectors
+static inline size_t ps_evalf_lds_bytes(int W) {
+    const size_t W1 = (size_t)W + 1, a = ((size_t)PS_FUSE_CAP * 28 + (W1 * W / 2 + 1) * 32) * 8 + (size_t)PS_FUSE_CAP * 12, b = ((size_t)W * (VIO_PREINT_HDR + 1) + (size_t)W * 465) * 8;
+    return (a > b ? a : b) + 16;
+}
 __global__ void be_prior_factor_kernel(Batch B, int seq);
 __global__ void be_set_relo_kernel(Batch B, int seq, const double *par);
 __global__ void be_stage_pnp_kernel(const double *pts, int n, double *par6);

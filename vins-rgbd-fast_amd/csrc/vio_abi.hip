@@ -135,7 +135,10 @@ struct vio_batch {
     int imu_stage_cur = 0;
     hipEvent_t ev_imu = nullptr;
     std::vector<double> last_imu_t;
-    size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0, lds_serial = 0, lds_marg = 0, lds_factor = 0, lds_ps_ls = 0;
+    size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0, lds_serial = 0, lds_marg = 0, lds_factor = 0, lds_ps_ls = 0, lds_ps_evalf = 0;
+    int ps_evalf_blocks = 0;           // workgroups per sequence of ps_evalf_kernel (2 + B.fuse)
+    int fuse_min_group = 128;          // sequences per stream group from which the fused evaluate + assemble kernel is used (0 when VIO_FUSE is set)
+    int relo_frames = 0;               // frames for which the two-kernel solver path is launched beside the fused kernel (armed by vio_set_relo_frame)
     bool line_search = true;           // ps_ls_kernel behind every ps_serial (Ceres' projected line search on bounds-constrained solves)
     // VIO_BE_THREADS / VIO_MARG_THREADS, read at vio_create.  The marginalisation kernel runs next to the following frame's front-end:
     // with 6 instead of 8 wavefronts (256 VGPRs each) two SIMDs per CU keep half of their register file free and the LK wavefronts can
@@ -645,6 +648,18 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
     if (h->solve_mode == 1) {
         // phased solver: every data-parallel phase of the trust-region loop covers all sequences with many workgroups; max_iterations
         // + 1 slots carry the iterations, two more absorb Cholesky retries (a converged sequence falls through the remaining launches)
+        // The two-kernel path (ps_eval + ps_asm_a) is launched beside the fused kernel only where a solve of this handle can need it: the
+        // extrinsic / td blocks may open (42-double records), the handle has ever been handed a relocalisation request (vio_set_relo_frame; the request waits on the device for its sequence's next solve), or the
+        // residual list can plausibly outgrow the fused kernel's PS_FUSE_MAXBLK chunks (a solve that does so anyway on a fused-only handle is skipped and
+        // flagged, overflow bit 256).  Decided on the host from the configuration: deterministic, no device feedback.
+        // Which solves take the fused kernel: measured on the canonical workload it moves 28 % less data (0.80 against 1.11 GB per 64-sequence solve)
+        // and wins where the device is throughput-bound (S = 256: +2.5 %, S = 512: +2 %), but at 64 sequences per stream group, where the chain
+        // of dependent launches bounds the step, the two-kernel path is 2 % faster (its smaller workgroups share the CUs better with the other
+        // group's kernels).  Default: fused from 128 sequences per stream group; VIO_FUSE = 0 / 1 forces either path at any size.
+        if (S < h->fuse_min_group) Bg.fuse = 0;
+        const bool fuse_only = Bg.fuse > 0 && !C.c.estimate_extrinsic && !C.c.estimate_td && h->relo_frames <= 0 &&
+                               (size_t)(C.W + 1) * C.c.max_cnt * 12 / 10 <= (size_t)PS_FUSE_MAXBLK * (PS_FUSE_CAP - C.W);
+        Bg.fuse_only = fuse_only ? 1 : 0;
         auto launch_phased = [&]() {
             ps_setup_kernel<<<S, 512, 0, st>>>(Bg);
             const int slots = C.c.max_iterations + h->extra_slots;
@@ -657,12 +672,21 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
             Be.xcd_n = Ba.xcd_n = Bb.xcd_n = XN;
             Be.xcd_nb = xm ? nb_e : 0; Ba.xcd_nb = xm ? nb_a : 0; Bb.xcd_nb = xm ? nb_bs : 0;
             const dim3 g_e = xm ? dim3(S8 * nb_e) : dim3(nb_e, S), g_a = xm ? dim3(S8 * nb_a) : dim3(nb_a, S), g_b = xm ? dim3(S8 * nb_bs) : dim3(nb_bs, S);
+            Batch Bf = Bg;
+            Bf.ns = S; Bf.xcd_n = XN; Bf.xcd_nb = xm ? h->ps_evalf_blocks : 0;
+            const dim3 g_f = xm ? dim3(S8 * h->ps_evalf_blocks) : dim3(h->ps_evalf_blocks, S);
             for (int k = 0; k < slots; k++) {
-                if (h->eval_occ == 4) ps_eval_kernel_occ4<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
-                else if (h->eval_occ == 3) ps_eval_kernel_occ3<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
-                else ps_eval_kernel<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
-                if (h->asm_a_occ4) ps_asm_a_kernel_occ4<<<g_a, 512, 0, st>>>(Ba);
-                else ps_asm_a_kernel<<<g_a, 512, 0, st>>>(Ba);
+                // fused evaluate + assemble for the solves that qualify (st.fused); ps_eval / ps_asm_a serve the others and idle for these
+                if (Bg.fuse) ps_evalf_kernel<<<g_f, 256, h->lds_ps_evalf, st>>>(Bf);
+                if (!fuse_only) {
+                    // (idle launches are not free here: their workgroups ask for 40 KB of LDS each and queue behind the other stream group's
+                    // fused workgroups, which fill the CUs' LDS -- 15 us per idle launch, measured)
+                    if (h->eval_occ == 4) ps_eval_kernel_occ4<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
+                    else if (h->eval_occ == 3) ps_eval_kernel_occ3<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
+                    else ps_eval_kernel<<<g_e, 256, h->lds_ps_eval, st>>>(Be);
+                    if (h->asm_a_occ4) ps_asm_a_kernel_occ4<<<g_a, 512, 0, st>>>(Ba);
+                    else ps_asm_a_kernel<<<g_a, 512, 0, st>>>(Ba);
+                }
                 ps_asm_b_schur_kernel<<<g_b, 256, (size_t)(C.NL + 16 + 3 * 256) * sizeof(double), st>>>(Bb, h->ps_asm_b_blocks, h->asm_b_by_blocks);   // per-row factors + the partial tiles of wavefronts 1 .. 3
                 if (h->serial_big) ps_serial_big_kernel<<<S, 512, h->lds_serial, st>>>(Bg);
                 else if (h->serial_threads <= 512) ps_serial_kernel_512<<<S, 512, h->lds_serial, st>>>(Bg);
@@ -682,6 +706,7 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
             auto mixin = [&](const void *p, size_t nbytes) { const unsigned char *q = (const unsigned char *)p; for (size_t i = 0; i < nbytes; i++) { key ^= q[i]; key *= 1099511628211ULL; } };
             mixin(&Bg, sizeof(Bg));
             mixin(&h->line_search, sizeof(h->line_search));
+            mixin(&fuse_only, sizeof(fuse_only));
             const int knobs[12] = {C.c.max_iterations + h->extra_slots, h->eval_occ, h->asm_a_occ4 ? 1 : 0, h->serial_big ? 1 : 0, h->serial_threads, h->ps_eval_blocks, h->ps_asm_a_blocks,
                                    h->ps_asm_b_blocks + 1000 * h->asm_b_by_blocks, h->ps_schur_tiles, h->xcd_map, h->xcd_n, (int)h->lds_serial};
             mixin(knobs, sizeof(knobs));
@@ -936,8 +961,10 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
     DA(B.lm_relo, S * NL); DA(B.relo_xy, S * NL * 2); DA(B.relo_mp, S * NP * 3);
     const size_t n = C.NPRIOR, LW = C.LW, nres = C.NRES, npair = W1 * W1, mq = 15 + n;
     DA(B.prior_J, S * n * n); DA(B.prior_r, S * n); DA(B.prior_x0, S * (C.W * 7 + 17)); DA(B.prior_H, S * n * n); DA(B.prior_rf, S * n);
-    DA(B.H, S * LW * LW); DA(B.Sc, S * LW * LW); DA(B.Hpl, S * (NL + 8) * LW); DA(B.vec, S * VEC_SLOTS * LW);
-    DA(B.Hll, S * (NL + 8)); DA(B.gl, S * (NL + 8)); DA(B.lvec, S * (NL + 8) * 8);
+    // (the landmark rows Hpl / Hll / gl twice: be_phased.h ps_sel_rows -- the fused evaluate + assemble kernel builds a candidate's rows beside the current ones)
+    DA(B.H, S * LW * LW); DA(B.Sc, S * LW * LW); DA(B.Hpl, 2 * S * (NL + 8) * LW); DA(B.vec, S * VEC_SLOTS * LW);
+    DA(B.Hll, 2 * S * (NL + 8)); DA(B.gl, 2 * S * (NL + 8)); DA(B.lvec, S * (NL + 8) * 8);
+    if (C.W <= PS_FUSE_MAXW) DA(B.pairpart, S * PS_FUSE_MAXPAIRS * PS_FUSE_MAXBLK * 210);
     DA(B.res, S * nres * 42); DA(B.res_lm, S * nres); DA(B.res_k, S * nres); DA(B.res_pair, S);
     DA(B.pair_start, S * (npair + 1)); DA(B.pair_list, S * nres); DA(B.pairblk, S * npair * 210);
     DA(B.imu_raw, S * C.W * 15 * 31);
@@ -1036,6 +1063,21 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
                 if (!eligible) h->solve_mode = 0;
                 h->lds_ps_eval = ps_eval_lds_bytes(C.W);   // pair geometry / staged pre-integration headers
                 (void)raise_lds_limit((const void *)ps_eval_kernel, h->lds_ps_eval);
+                // fused evaluate + assemble (VIO_FUSE, default on): workgroups 0 / 1 (prior, IMU) + one workgroup per chunk of at most PS_FUSE_CAP - W residuals; a
+                // frame observes at most max_cnt landmarks, so a window holds at most (W + 1) max_cnt observations.  B.fuse = chunks the grid covers
+                // (ps_setup sends solves that need more, or whose records are not compact, down the ps_eval + ps_asm_a path)
+                h->lds_ps_evalf = ps_evalf_lds_bytes(C.W);
+                {
+                    const int want = getenv("VIO_FUSE") ? atoi(getenv("VIO_FUSE")) : 1;
+                    if (getenv("VIO_FUSE")) h->fuse_min_group = 0;
+                    // (the tracker holds a little over max_cnt features per frame -- every grid cell may add k + 2 -- hence the 10 %; residual lists that
+                    // need more chunks than the grid has workgroups make them loop, up to PS_FUSE_MAXBLK chunks)
+                    int chunks = (int)std::min<size_t>(PS_FUSE_MAXBLK, (W1 * (size_t)C.c.max_cnt * 11 / 10 + (PS_FUSE_CAP - C.W) - 1) / (PS_FUSE_CAP - C.W));
+                    if (want > 1) chunks = std::min(PS_FUSE_MAXBLK, want);
+                    B.fuse = (want && C.W <= PS_FUSE_MAXW && C.c.use_imu && B.pairpart) ? std::max(1, chunks) : 0;
+                    if (B.fuse && raise_lds_limit((const void *)ps_evalf_kernel, h->lds_ps_evalf) != 0) B.fuse = 0;
+                    h->ps_evalf_blocks = 2 + B.fuse;
+                }
                 h->lds_ps_ls = ps_ls_lds_bytes(C.W);
                 (void)raise_lds_limit((const void *)ps_ls_kernel, h->lds_ps_ls);
                 // reference_quirks bit 3 (tests) / VIO_LINE_SEARCH=0 (measurement): the clamp-only treatment of the inverse-depth bound, no search launches
@@ -1445,6 +1487,7 @@ int vio_set_relo_frame(vio_batch *h, int seq, double frame_stamp, int frame_inde
     for (int i = 1; i < n; i++)
         if (!(match_points[3 * i + 2] > match_points[3 * (i - 1) + 2])) { g_err = "match points must ascend in feature id"; return VIO_EINVAL; }
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
+    h->relo_frames = 1 << 30;   // relocalisation factors use the 42-double records: from now on the two-kernel solver path is launched too (launch_backend)
     double par[15];
     par[0] = frame_stamp; par[1] = frame_index; par[2] = n;
     for (int k = 0; k < 3; k++) par[3 + k] = relo_t3[k];

@@ -146,6 +146,11 @@ struct Params { double pose[(VIO_MAXW + 1) * 7], sb[(VIO_MAXW + 1) * 9], ex[7], 
 // persistent kernel keeps in registers / LDS across phases lives here.
 enum { PS_IDLE = 0, PS_EVAL_X0, PS_ASM, PS_SCHUR, PS_STEP, PS_EVAL_C, PS_DONE };
 #define PS_MAX_EVAL_BLOCKS 64   // (ps_accept sums the partial costs one per lane of a wavefront)
+// fused evaluate + assemble kernel (be_phased.h ps_evalf_kernel): residuals per projection workgroup, most workgroups / frame pairs per sequence
+#define PS_FUSE_CAP 256
+#define PS_FUSE_MAXBLK 12
+#define PS_FUSE_MAXW 10
+#define PS_FUSE_MAXPAIRS ((PS_FUSE_MAXW + 1) * PS_FUSE_MAXW / 2)
 struct SolveSt {
     Params X, Xc;
     double sdx[6 * VIO_MAXW + 16], srp[6 * VIO_MAXW + 16];   // prior tangent / gradient at the last evaluated point
@@ -163,6 +168,15 @@ struct SolveSt {
     int eval_done;        // blocks of the running evaluation that have published their partial cost (device-scope counter)
     int relo;             // this solve carries relocalisation factors: the (constant) extrinsic's six columns are lent to relo_Pose
     int test_fail;        // test hook (VIO_TEST_CHOL_FAIL_SHIFT): Cholesky factorisations of this solve still to be reported as failed
+    // fused evaluate + assemble (ps_evalf_kernel): the projection residuals in landmark-aligned chunks of at most PS_FUSE_CAP, one workgroup each
+    int fused;            // this solve runs it (compact records: extrinsic / td constant, no relocalisation factors; W <= PS_FUSE_MAXW)
+    int rowbuf;           // which half of the double-buffered landmark rows (Hpl / Hll / gl) belongs to the CURRENT point: the fused kernel
+                          // builds the rows of the point it evaluates into the other half, ps_accept flips when that point is taken
+    int nblk;             // projection workgroups
+    int blk_p[PS_FUSE_MAXBLK + 1], blk_r[PS_FUSE_MAXBLK + 1], blk_ka[PS_FUSE_MAXBLK + 1];   // chunk b: in-problem landmarks, residuals, variable landmarks [b], [b + 1])
+    int fi[PS_FUSE_MAXBLK][PS_FUSE_MAXPAIRS];   // chunk b, frame pair p: first index into pair_list | residuals in the chunk << 16 | rank among the pair's chunks << 26
+    int pm_np[PS_FUSE_MAXPAIRS];    // chunks that hold residuals of frame pair p (> 1: partial Gram blocks, summed by the last chunk to finish)
+    int chunk_done;                 // chunks of the running evaluation whose Gram blocks are written (device-scope counter; the last one sums the partial blocks)
     int constrained;      // Program::IsBoundsConstrained(): a variable landmark carries the inverse-depth bound -> Ceres' projected line search
     int ls_pending;       // ps_serial has formed the alpha = 1 candidate of a constrained solve: ps_ls_kernel runs the search before the next ps_eval
 };
@@ -217,6 +231,9 @@ struct Batch {
     int *res_pair, *res_lm, *res_k;   // pair id / landmark slot / obs index per residual
     int *pair_start, *pair_list;      // counting sort by frame pair
     double *pairblk;                  // [S][npairs][210] packed symmetric 20x20
+    double *pairpart;                 // fused kernel: [S][PS_FUSE_MAXPAIRS][PS_FUSE_MAXBLK][210] partial Gram blocks of frame pairs whose residuals span chunks
+    int fuse;                         // VIO_FUSE (default 1): solves that qualify run ps_evalf_kernel instead of ps_eval + ps_asm_a; value = chunks the grid covers
+    int fuse_only;                    // this launch sequence carries no ps_eval / ps_asm_a (every solve of the handle's configuration qualifies)
     double *imu_raw;                  // [S][W][15*31] raw / whitened IMU Jacobians + residual
     double *margA, *margB, *margV, *margW;  // marginalisation workspaces
     double *margE;                          // marg_exact only: [S][3 MX^2 + NPRIOR MX] (A_mm, its eigenvectors, A_mm^+, A_rm A_mm^+)
