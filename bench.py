@@ -103,29 +103,69 @@ def aux_rate(P, vio_ct, torch, cfg, sc, dev, S, n_pre, Wm, K, lag=0, seq0=0):
                 kernels_ms={k: round(v, 4) for k, v in kms.items()}, solver=sol)
 
 
+_CPU_BARRIER = None
+
+
+def _cpu_init(barrier):
+    global _CPU_BARRIER
+    _CPU_BARRIER = barrier
+
+
 def _cpu_worker(job):
-    """One oracle process (spawned, no GPU): replays `n_frames` of sequence `seq` rendered on the host (identical pixels to the device
-    renderer) and returns (steady-state seconds inside Pipeline::feed, frames)."""
-    seq, n_frames = job
+    """One oracle process (spawned; loads ONLY oracle/liboracle.so -- neither the HIP library nor a HIP runtime): the frames of its sequence
+    were rendered by the parent into /dev/shm and are read into memory first, then every worker waits at a barrier so that all of them run
+    their steady-state frames at the same time; returns (steady-state seconds inside Pipeline::feed, frames)."""
+    path, cfg_bytes = job
+    import importlib
+    import threading
     import vio_ct
-    P = vio_ct.pkg()
-    cfg = P.canonical_config()
-    sc = vio_ct.synth_like(cfg)
-    syn = P.Synth(sc)
+    P = importlib.import_module("vins-rgbd-fast_amd")   # the module only (ctypes struct definitions); lib() is never called here
+    cfg = P.Config.from_buffer_copy(cfg_bytes)
+    z = np.load(path)
+    gray, depth, times, it, ia, ig = z["gray"], z["depth"], z["times"], z["imu_t"], z["imu_acc"], z["imu_gyr"]
     o = vio_ct.OraclePipeline(cfg)
-    nimu = int(n_frames / sc.cam_rate * sc.imu_rate) + 64
-    o.push_imu(*syn.imu(seq, nimu))
+    o.push_imu(it, ia, ig)
+    first = True
     tcpu, nfr = 0.0, 0
-    for f, tf in enumerate(vio_ct.frame_times(sc, n_frames)):
-        g, d = syn.render_host(seq, float(tf))
+    for f in range(len(times)):
         steady = o.status()["solver_flag"] == 1
+        if steady and first:
+            first = False
+            if _CPU_BARRIER is not None:
+                try:
+                    _CPU_BARRIER.wait(timeout=300)      # (the initialisation frames are behind every worker: the timed frames of all workers overlap)
+                except threading.BrokenBarrierError:
+                    pass
         c0 = time.perf_counter()
-        r = o.feed(g, d, float(tf))
+        r = o.feed(np.ascontiguousarray(gray[f]), np.ascontiguousarray(depth[f]), float(times[f]))
         c1 = time.perf_counter()
         if steady and r == 1:
             tcpu += c1 - c0
             nfr += 1
     return tcpu, nfr
+
+
+def effective_cores():
+    """(cores this process can actually use, how that was determined): the scheduler affinity capped by the cgroup CPU quota -- the GPU
+    boxes expose 256 hardware threads to a container whose cpu.max is 16 CPUs"""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if quota is None:
+        return aff, "sched_getaffinity (%d); no cgroup CPU quota" % aff
+    return max(1, min(aff, int(quota + 0.5))), "min(sched_getaffinity = %d, cgroup cpu.max = %.1f CPUs)" % (aff, quota)
 
 
 def physical_cores():
@@ -484,17 +524,44 @@ def main():
                       note="north-star tolerance: ATE of the HIP path within 1 % of the reference algorithm (oracle) on identical input")
     cpu = cpu1
     cpu_all = None
-    nproc = len(os.sched_getaffinity(0)) if args.cpu_procs < 0 else min(args.cpu_procs, os.cpu_count() or 1)
+    eff, eff_how = effective_cores()
+    nproc = eff if args.cpu_procs < 0 else min(args.cpu_procs, os.cpu_count() or 1)
     if rank == 0 and world == 1 and nproc > 1:
+        # all-core leg: one oracle process per EFFECTIVE core (cgroup quota, not the 256 hardware threads the box shows), the frames rendered
+        # beforehand by the parent, every worker past its initialisation before any of them is timed
         import multiprocessing as mp
-        c0 = time.perf_counter()
-        with mp.get_context("spawn").Pool(nproc) as pool:
-            res = pool.map(_cpu_worker, [(seq0 + 1000 + i, 36) for i in range(nproc)])
-        cpu_all = dict(value=float(sum(n / t for t, n in res if t > 0)), unit="frames/s", cores=nproc, cores_are="hardware threads (SMT siblings included)",
-                       physical_cores=physical_cores(), kind="port",
-                       sample="%d oracle processes (one per hardware thread this process may run on), one sequence of 36 frames each; sum of the "
-                              "per-process steady-state rates (the reference's own effective threading is one back-end thread per estimator)" % nproc,
-                       wall_seconds=time.perf_counter() - c0)
+        import shutil
+        import tempfile
+        from concurrent.futures import ThreadPoolExecutor
+        n_cf = 36
+        shm = tempfile.mkdtemp(prefix="vio_cpu_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            ctimes = vio_ct.frame_times(sc, n_cf)
+            nimu_c = int(n_cf / sc.cam_rate * sc.imu_rate) + 64
+
+            def _prep(i):
+                seq = seq0 + 1000 + i
+                fr = [syn.render_host(seq, float(tf)) for tf in ctimes]
+                ti, ai, gi = syn.imu(seq, nimu_c)
+                pth = os.path.join(shm, "seq_%d.npz" % i)
+                np.savez(pth, gray=np.stack([x[0] for x in fr]), depth=np.stack([x[1] for x in fr]), times=np.asarray(ctimes), imu_t=ti, imu_acc=ai, imu_gyr=gi)
+                return pth
+            with ThreadPoolExecutor(max_workers=nproc) as tp:
+                paths = list(tp.map(_prep, range(nproc)))
+            cfg_bytes = bytes(cfg)
+            ctx = mp.get_context("spawn")
+            c0 = time.perf_counter()
+            with ctx.Pool(nproc, initializer=_cpu_init, initargs=(ctx.Barrier(nproc),)) as pool:
+                res = pool.map(_cpu_worker, [(pth, cfg_bytes) for pth in paths], chunksize=1)
+            wall = time.perf_counter() - c0
+        finally:
+            shutil.rmtree(shm, ignore_errors=True)
+        cpu_all = dict(value=float(sum(n / t for t, n in res if t > 0)), unit="frames/s", cores=nproc, cores_are="effective cores: " + eff_how,
+                       hardware_threads_visible=len(os.sched_getaffinity(0)), physical_cores=physical_cores(), kind="port",
+                       sample="%d oracle processes (one per effective core; they load only oracle/liboracle.so), one pre-rendered sequence of %d frames each, "
+                              "timed frames started behind a barrier; sum of the per-process steady-state rates (the reference's own effective threading is "
+                              "one back-end thread per estimator)" % (nproc, n_cf),
+                       wall_seconds=wall)
         cpu = dict(cpu_all)
         cpu["one_core"] = cpu1
 
@@ -512,9 +579,9 @@ def main():
                              "note": "all %d stream groups: S x back-end flops per frame / ms_per_step" % n_groups}
     cpu_c = None
     if cpu:
-        cpu_c = {k: cpu.get(k) for k in ("value", "unit", "cores", "cores_are", "physical_cores", "kind") if k in cpu}
+        cpu_c = {k: cpu.get(k) for k in ("value", "unit", "cores", "cores_are", "hardware_threads_visible", "physical_cores", "kind") if k in cpu}
         cpu_c["value"] = r3(cpu_c.get("value"))
-        cpu_c["sample"] = ("one sequence of 36 frames per hardware thread, sum of steady-state rates" if cpu_all else
+        cpu_c["sample"] = ("one pre-rendered sequence of 36 frames per effective core, timed behind a barrier, sum of steady-state rates" if cpu_all else
                            "%d sequences of the bench workload on one core" % min(args.cpu_seqs, S))
         if cpu_all and cpu1:
             cpu_c["one_core_value"] = r3(cpu1["value"])
@@ -593,6 +660,17 @@ def main():
         for s_aux in (256, 512):
             os.environ["VIO_GROUP_SEQS"] = str(s_aux // 2)
             detail["aux_s%d" % s_aux] = aux_rate(P, vio_ct, torch, cfg, sc, dev, s_aux, n_pre, Wm, K, lag=args.tracker_lag)
+        # round 6: the fused evaluate + assemble kernel (VIO_FUSE = 1, read at vio_create; default off -- DESIGN.md 4) at the three batch sizes
+        had_fuse = os.environ.get("VIO_FUSE")
+        os.environ["VIO_FUSE"] = "1"
+        for s_aux in (S, 256, 512):
+            os.environ["VIO_GROUP_SEQS"] = str(s_aux // 2)
+            detail["fused_s%d" % s_aux] = aux_rate(P, vio_ct, torch, cfg, sc, dev, s_aux, n_pre, Wm, K, lag=args.tracker_lag)
+            detail["fused_s%d" % s_aux]["note"] = "VIO_FUSE = 1: ps_evalf_kernel instead of ps_eval + ps_asm_a (residual records stay in LDS)"
+        if had_fuse is None:
+            del os.environ["VIO_FUSE"]
+        else:
+            os.environ["VIO_FUSE"] = had_fuse
         # BASELINE configs[4] at its per-GPU batch (64 sequences of 1280x720 / 300 features / W = 20): the phased solver with the Schur
         # complement in HBM / L2 (ps_serial_big_kernel)
         os.environ["VIO_GROUP_SEQS"] = "32"
@@ -618,7 +696,7 @@ def main():
         cfg_c = P.canonical_config(marg_exact=2)
         detail["marg_certified"] = aux_rate(P, vio_ct, torch, cfg_c, sc, dev, S, n_pre, Wm, K, lag=args.tracker_lag, seq0=seq0)
         detail["marg_certified"]["note"] = "marg_exact = 2; be_marg per launch %.3f ms" % detail["marg_certified"]["kernels_ms"].get("be_marg", float("nan"))
-        aux_keys = ("lag0", "aux_s256", "aux_s512", "config5", "marg_exact", "marg_certified")
+        aux_keys = ("lag0", "aux_s256", "aux_s512", "fused_s%d" % S, "fused_s256", "fused_s512", "config5", "marg_exact", "marg_certified")
         line["aux_frames_per_s"] = {k: round(detail[k]["frames_per_s"]) for k in aux_keys}
         line["aux_valid"] = all(detail[k]["valid"] for k in aux_keys)
     if rank == 0:

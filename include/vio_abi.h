@@ -11,7 +11,10 @@
  * (vio_host_alloc) the copy is truly asynchronous: such buffers must stay untouched until the NEXT call on the handle that takes host
  * buffers, any getter, or vio_sync has returned (those calls wait for the pending uploads first).  Exception (round 5): the IMAGES handed to
  * vio_feed / vio_feed_modes keep TWO uploads in flight -- they are free when vio_host_buffers_done(h, calls_ago) returns 1, and at the latest
- * when the second next vio_feed, any getter or vio_sync has returned (rotate three page-locked image sets, or poll the query).
+ * when the second next vio_feed THAT TAKES HOST IMAGES, any getter or vio_sync has returned (rotate three page-locked image sets, or poll the
+ * query; feeds of device-resident frames in between do not count).  This is a BREAKING change against the round-4 contract ("free when the
+ * next vio_feed has returned"): a caller that ping-pongs TWO page-locked image sets must move to three or poll.  vio_abi_version() tells the
+ * contracts apart (>= 5: this one); VIO_UPLOADS_IN_FLIGHT=1 in the environment restores the old wait (one upload in flight, two sets suffice).
  *
  * Threading: a handle is not re-entrant.  vio_push_imu / vio_push_imu_batch may be called from another thread than
  * vio_track / vio_process / vio_feed (internal lock), mirroring Estimator::inputIMU being called from ROS callback threads
@@ -194,6 +197,9 @@ void *vio_host_alloc(size_t bytes);
 void vio_host_free(void *p);
 /* sizeof(vio_config) (what = 0) / sizeof(vio_status) (what = 1) as compiled into the library: lets a binding check its struct mirrors */
 int vio_abi_sizeof(int what);
+/* Contract version of this header: 4 = a vio_feed host image set is free when the next vio_feed has returned; 5 = two uploads in flight (see
+ * "Host buffers" above, vio_host_buffers_done); 6 = + vio_get_bound_stats, the inverse-depth bound handled as Ceres does (projected line search). */
+int vio_abi_version(void);
 /* capacities derived from the configuration: out[0] = tracker points per sequence, out[1] = landmark slots, out[2] = IMU ring */
 int vio_get_capacity(vio_batch *h, int32_t *out3);
 /* which solver the handle's configuration selected: 0 = the persistent one-workgroup-per-sequence kernel (fallback), 1 = the phased solver
@@ -204,6 +210,10 @@ int vio_get_solver_kind(vio_batch *h);
  * sequence seq since vio_create / vio_reset: out4 = {inverse depths cut by the bound while a point was formed, bounded landmarks that
  * entered solves, trial evaluations of the line search, shortened steps}.  Synchronises the device. */
 int vio_get_bound_stats(vio_batch *h, int seq, int64_t *out4);
+/* vio_config.marg_exact = 2 only: out2 = {marginalisations of sequence seq whose certificate FAILED since vio_create / vio_reset (such a frame
+ * keeps the block inverse without the proof that the reference's 1e-8 eigenvalue cut of marginalization_factor.cpp:281-291 drops nothing),
+ * 1 if the last marginalisation was certified}.  Synchronises the device. */
+int vio_get_marg_certificate(vio_batch *h, int seq, int32_t *out2);
 
 /* Results read out of the path (SURVEY.md §8b "Results read out").  All getters synchronise first. */
 typedef struct vio_status {

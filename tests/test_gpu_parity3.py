@@ -114,6 +114,7 @@ def test_certified_literal_marginalisation_mode(P):
     for i in range(S):
         L.vio_debug_seq(b.h, i, dbg.ctypes.data)
         assert dbg[12] == 0 and dbg[11] == 1, (i, dbg[11], dbg[12])        # no uncertified marginalisation in 70 frames; the last one certified
+        assert b.marg_certificate(i) == (0, True)                          # ... and the same through the C ABI (vio_get_marg_certificate)
         assert dbg[0] == 0                                                  # the prior's eigen-decomposition ran LDS-resident (no Jacobi sweeps)
     b.close()
     orc = parity_long.run_oracle_pool(range(seq0, seq0 + S), n_frames, procs=S)

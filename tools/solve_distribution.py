@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Per-sequence duration of be_solve (in-kernel 100 MHz ticks, BeSeq.dbg[4]) and of be_marg (dbg[3]) on the bench workload: shows how far the
 kernel time (= slowest sequence) sits above the mean.   python tools/solve_distribution.py [--seqs 128] [--frames 30]"""
+import os as _os
+_os.environ.setdefault("VIO_HIP_LIB", "timers")   # dbg[3] / dbg[4] are tick counts of the build with the phase timers compiled in (the default build has none)
 import argparse
 import ctypes as C
 import os

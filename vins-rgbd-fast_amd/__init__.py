@@ -408,6 +408,13 @@ class VioBatch:
         self._chk(self.L.vio_get_bound_stats(self.h, int(seq), o.ctypes.data), "vio_get_bound_stats")
         return tuple(int(x) for x in o)
 
+    def marg_certificate(self, seq=0):
+        """marg_exact = 2: (marginalisations whose certificate failed since creation, last one certified?)"""
+        o = np.zeros(2, np.int32)
+        self.L.vio_get_marg_certificate.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self._chk(self.L.vio_get_marg_certificate(self.h, int(seq), o.ctypes.data), "vio_get_marg_certificate")
+        return int(o[0]), bool(o[1])
+
     def capacity(self):
         c = np.zeros(3, np.int32)
         self._chk(self.L.vio_get_capacity(self.h, c.ctypes.data), "vio_get_capacity")

@@ -2632,7 +2632,7 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
         }
         __syncthreads();
     }
-    if (s == 0 && t == 0 && !second_new) B.timings[31] += 1.0f;
+    if (VIO_TIMERS && s == 0 && t == 0 && !second_new) B.timings[31] += 1.0f;
     PH(20);
     if (exact) marg_exact_finish(c, be, A, b, md, mq, n, c.Hpl, c.LW, F0x, second_new, sred, smem_marg);
     else {
@@ -2660,7 +2660,7 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
         }
         __syncthreads();
     }
-    if (s == 0 && t == 0 && pinv_direct) B.timings[26] += 1.0f;
+    if (VIO_TIMERS && s == 0 && t == 0 && pinv_direct) B.timings[26] += 1.0f;
     PH(36);
     // T1 = A_rm A_mm^+ (n x md) and the block A_mr (md x n) staged in LDS (the tile region, free until the constant term is formed): the
     // n^2 entries of A_r = A_rr - T1 A_mr read each of them n times

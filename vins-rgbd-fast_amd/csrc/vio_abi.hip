@@ -137,7 +137,7 @@ struct vio_batch {
     std::vector<double> last_imu_t;
     size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0, lds_serial = 0, lds_marg = 0, lds_factor = 0, lds_ps_ls = 0, lds_ps_evalf = 0;
     int ps_evalf_blocks = 0;           // workgroups per sequence of ps_evalf_kernel (2 + B.fuse)
-    int fuse_min_group = 128;          // sequences per stream group from which the fused evaluate + assemble kernel is used (0 when VIO_FUSE is set)
+    int uploads_in_flight = 2;         // VIO_UPLOADS_IN_FLIGHT: page-locked image uploads of vio_feed that may be pending when a call returns
     int relo_frames = 0;               // frames for which the two-kernel solver path is launched beside the fused kernel (armed by vio_set_relo_frame)
     bool line_search = true;           // ps_ls_kernel behind every ps_serial (Ceres' projected line search on bounds-constrained solves)
     // VIO_BE_THREADS / VIO_MARG_THREADS, read at vio_create.  The marginalisation kernel runs next to the following frame's front-end:
@@ -202,9 +202,11 @@ static size_t marg_exact_lds_bytes(int m) { return ((size_t)m * (m | 1) + 11 * (
 struct DevGuard {
     int prev = -1;
     bool switched = false;
+    bool failed = false;   // the handle's device could not be made current: the entry point must not run on the caller's device instead
     explicit DevGuard(const vio_batch *h) {
         if (!h || h->device < 0) return;
-        if (hipGetDevice(&prev) == hipSuccess && prev != h->device) switched = hipSetDevice(h->device) == hipSuccess;
+        if (hipGetDevice(&prev) != hipSuccess) { failed = true; return; }
+        if (prev != h->device) { switched = hipSetDevice(h->device) == hipSuccess; failed = !switched; }
     }
     ~DevGuard() { if (switched) (void)hipSetDevice(prev); }
     DevGuard(const DevGuard &) = delete;
@@ -652,11 +654,10 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
         // extrinsic / td blocks may open (42-double records), the handle has ever been handed a relocalisation request (vio_set_relo_frame; the request waits on the device for its sequence's next solve), or the
         // residual list can plausibly outgrow the fused kernel's PS_FUSE_MAXBLK chunks (a solve that does so anyway on a fused-only handle is skipped and
         // flagged, overflow bit 256).  Decided on the host from the configuration: deterministic, no device feedback.
-        // Which solves take the fused kernel: measured on the canonical workload it moves 28 % less data (0.80 against 1.11 GB per 64-sequence solve)
-        // and wins where the device is throughput-bound (S = 256: +2.5 %, S = 512: +2 %), but at 64 sequences per stream group, where the chain
-        // of dependent launches bounds the step, the two-kernel path is 2 % faster (its smaller workgroups share the CUs better with the other
-        // group's kernels).  Default: fused from 128 sequences per stream group; VIO_FUSE = 0 / 1 forces either path at any size.
-        if (S < h->fuse_min_group) Bg.fuse = 0;
+        // (VIO_FUSE, default 0: measured on the canonical workload the fused kernel moves 28 % less data -- 0.80 against 1.11 GB per 64-sequence solve --
+        // and wins where the device is throughput-bound (S = 256: +2.5 %, S = 512: +2 %), but at 64 sequences per stream group, where the chain of
+        // dependent launches bounds the step, the two-kernel path is 2 % faster: its smaller workgroups share the CUs better with the other group's
+        // kernels.  One path per handle whatever the batch size, so that a sequence's result never depends on the batch it runs in.)
         const bool fuse_only = Bg.fuse > 0 && !C.c.estimate_extrinsic && !C.c.estimate_td && h->relo_frames <= 0 &&
                                (size_t)(C.W + 1) * C.c.max_cnt * 12 / 10 <= (size_t)PS_FUSE_MAXBLK * (PS_FUSE_CAP - C.W);
         Bg.fuse_only = fuse_only ? 1 : 0;
@@ -920,6 +921,7 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
     vio_batch *h = new vio_batch();
     h->device = device < 0 ? caller_dev : device;
     DevGuard dev_guard(h);   // every allocation, stream and event below is created on h->device; the caller's device is current again on return
+    if (dev_guard.failed) { g_err = "vio_create_on_device: hipSetDevice failed"; delete h; return nullptr; }
     if (build_devcfg(cfg, imu_capacity, h->hc) != VIO_OK) { delete h; return nullptr; }
     h->hc.MXL = 0;
     h->hc.eig_one_wave = getenv("VIO_EIG_ONE_WAVE") ? (atoi(getenv("VIO_EIG_ONE_WAVE")) != 0) : 0;
@@ -982,6 +984,7 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
     if (getenv("VIO_XCD_MAP")) h->xcd_map = atoi(getenv("VIO_XCD_MAP"));
     if (getenv("VIO_FE_XCD_MAP")) h->fe_xcd_map = atoi(getenv("VIO_FE_XCD_MAP"));
     if (getenv("VIO_XCD_N")) h->xcd_n = atoi(getenv("VIO_XCD_N"));
+    if (getenv("VIO_UPLOADS_IN_FLIGHT")) h->uploads_in_flight = atoi(getenv("VIO_UPLOADS_IN_FLIGHT")) == 1 ? 1 : 2;
     if (getenv("VIO_EXTRA_SLOTS")) h->extra_slots = std::max(1, atoi(getenv("VIO_EXTRA_SLOTS")));
     if (getenv("VIO_ASM_A_OCC")) h->asm_a_occ4 = atoi(getenv("VIO_ASM_A_OCC")) >= 4;
     if (getenv("VIO_SERIAL_THREADS")) h->serial_threads = atoi(getenv("VIO_SERIAL_THREADS")) >= 1024 ? 1024 : 512;
@@ -1063,13 +1066,12 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
                 if (!eligible) h->solve_mode = 0;
                 h->lds_ps_eval = ps_eval_lds_bytes(C.W);   // pair geometry / staged pre-integration headers
                 (void)raise_lds_limit((const void *)ps_eval_kernel, h->lds_ps_eval);
-                // fused evaluate + assemble (VIO_FUSE, default on): workgroups 0 / 1 (prior, IMU) + one workgroup per chunk of at most PS_FUSE_CAP - W residuals; a
+                // fused evaluate + assemble (VIO_FUSE = 1; default off, see launch_backend): workgroups 0 / 1 (prior, IMU) + one workgroup per chunk of at most PS_FUSE_CAP - W residuals; a
                 // frame observes at most max_cnt landmarks, so a window holds at most (W + 1) max_cnt observations.  B.fuse = chunks the grid covers
                 // (ps_setup sends solves that need more, or whose records are not compact, down the ps_eval + ps_asm_a path)
                 h->lds_ps_evalf = ps_evalf_lds_bytes(C.W);
                 {
-                    const int want = getenv("VIO_FUSE") ? atoi(getenv("VIO_FUSE")) : 1;
-                    if (getenv("VIO_FUSE")) h->fuse_min_group = 0;
+                    const int want = getenv("VIO_FUSE") ? atoi(getenv("VIO_FUSE")) : 0;
                     // (the tracker holds a little over max_cnt features per frame -- every grid cell may add k + 2 -- hence the 10 %; residual lists that
                     // need more chunks than the grid has workgroups make them loop, up to PS_FUSE_MAXBLK chunks)
                     int chunks = (int)std::min<size_t>(PS_FUSE_MAXBLK, (W1 * (size_t)C.c.max_cnt * 11 / 10 + (PS_FUSE_CAP - C.W) - 1) / (PS_FUSE_CAP - C.W));
@@ -1178,6 +1180,7 @@ void vio_destroy(vio_batch *h) {
 
 int vio_reset(vio_batch *h) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     return init_state(h, 0, h->S);
@@ -1185,6 +1188,7 @@ int vio_reset(vio_batch *h) {
 
 int vio_reset_seq(vio_batch *h, int seq) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     { int rc_ = refresh_dynamic_state(h); if (rc_ != VIO_OK) return rc_; }   // a reboot of ANOTHER sequence decided by the last solve must not be lost
@@ -1193,6 +1197,7 @@ int vio_reset_seq(vio_batch *h, int seq) {
 
 int vio_reset_tracker_seq(vio_batch *h, int seq) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     return init_state(h, seq, seq + 1, VIO_RESET_TRACKER);
@@ -1200,6 +1205,7 @@ int vio_reset_tracker_seq(vio_batch *h, int seq) {
 
 int vio_push_imu(vio_batch *h, int seq, int n, const double *t, const double *acc, const double *gyr) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || seq < 0 || seq >= h->S || n < 0) return VIO_EINVAL;
     std::lock_guard<std::mutex> lk(h->imu_mu);
     for (int i = 0; i < n; i++) {
@@ -1249,6 +1255,11 @@ static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, 
         // from pageable memory)
         HIPCHK(hipEventSynchronize(g.ev_up_gray[p]));
         HIPCHK(hipEventSynchronize(g.ev_up_depth[p]));
+    }
+    if (overlap && h->uploads_in_flight == 1 && g.up_used[p ^ 1]) {
+        // VIO_UPLOADS_IN_FLIGHT=1: the round-4 contract (the previous call's images are free when this call returns)
+        HIPCHK(hipEventSynchronize(g.ev_up_gray[p ^ 1]));
+        HIPCHK(hipEventSynchronize(g.ev_up_depth[p ^ 1]));
     }
     if (overlap) g.up_used[p] = true;
     if (gray) {
@@ -1345,6 +1356,7 @@ static int stage_side_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *m
 
 int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, const uint8_t *modes, int on_device) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || !gray || !depth_mm || !stamps) return VIO_EINVAL;
     int rc = wait_host_uploads(h);   // (pending uploads of an earlier vio_track / vio_process call; vio_feed itself leaves none, see stage_side_ring)
     if (rc != VIO_OK) return rc;
@@ -1378,13 +1390,33 @@ int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, 
     return VIO_OK;
 }
 
+int vio_abi_version(void) { return 6; }
+
+// marg_exact = 2 (the literal marginalisation with a CERTIFIED first inverse): out2 = {marginalisations of sequence seq whose certificate failed
+// since vio_create / vio_reset -- those frames used the block inverse WITHOUT the proof that the reference's 1e-8 cut drops nothing --, 1 if the
+// last marginalisation was certified}.  A parity run asserts out2[0] == 0; a deployment that sees it grow should switch to marg_exact = 1.
+int vio_get_marg_certificate(vio_batch *h, int seq, int32_t *out2) {
+    DevGuard dev_guard(h);
+    if (!h || !out2 || seq < 0 || seq >= h->S) return VIO_EINVAL;
+    if (dev_guard.failed) { g_err = "hipSetDevice failed"; return VIO_EDEVICE; }
+    HIPCHK(hipDeviceSynchronize());
+    BeSeq be;
+    HIPCHK(hipMemcpy(&be, h->B.be + seq, sizeof(BeSeq), hipMemcpyDeviceToHost));
+    out2[0] = be.dbg[12]; out2[1] = be.dbg[11];
+    return VIO_OK;
+}
+
 int vio_host_buffers_done(vio_batch *h, int calls_ago) {
     DevGuard dev_guard(h);
     if (!h || calls_ago < 0) return VIO_EINVAL;
-    if (calls_ago > 1) return 1;   // (a later vio_feed has already waited for them)
+    if (dev_guard.failed) { g_err = "hipSetDevice failed"; return VIO_EDEVICE; }
+    // calls_ago counts vio_feed calls that took HOST images (on_device = 0): feeds of device-resident frames in between neither use nor wait for
+    // the staging buffers.  Only the two most recent host feeds can still be uploading (the third-last was waited for when its staging
+    // buffer was reused) -- and that is checked against the events, not assumed.
+    if (calls_ago > 1) return 1;
     for (auto &g : h->groups) {
         if (!g.copy_stream) continue;
-        const int p = (g.flip ^ 1 ^ calls_ago) & 1;     // g.flip = the buffer the NEXT call will use; the latest call used g.flip ^ 1
+        const int p = (g.flip ^ 1 ^ calls_ago) & 1;     // g.flip = the buffer the NEXT host feed will use; the latest host feed used g.flip ^ 1
         if (!g.up_used[p]) continue;
         for (hipEvent_t e : {g.ev_up_gray[p], g.ev_up_depth[p]}) {
             const hipError_t q = hipEventQuery(e);
@@ -1397,6 +1429,7 @@ int vio_host_buffers_done(vio_batch *h, int calls_ago) {
 
 int vio_feed(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, const double *stamps, int on_device) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     return vio_feed_modes(h, gray, depth_mm, stamps, nullptr, on_device);
 }
 
@@ -1426,16 +1459,19 @@ static int track_impl(vio_batch *h, const uint8_t *gray, const double *stamps, i
 
 int vio_track(vio_batch *h, const uint8_t *gray, const double *stamps, int publish, int on_device) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     return track_impl(h, gray, stamps, publish, nullptr, nullptr, on_device);
 }
 
 int vio_track_ex(vio_batch *h, const uint8_t *gray, const double *stamps, const uint8_t *modes, const double *R_rel, int on_device) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     return track_impl(h, gray, stamps, 1, modes, R_rel, on_device);
 }
 
 int vio_predict_motion(vio_batch *h, int seq, double t0, double t1, double *R9) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || seq < 0 || seq >= h->S || !R9) return VIO_EINVAL;
     int rc = flush_imu_frontend(h);  // samples pushed so far must be in the ring (Estimator::predictMotion reads imu_buf)
     if (rc != VIO_OK) return rc;
@@ -1453,6 +1489,7 @@ int vio_predict_motion(vio_batch *h, int seq, double t0, double t1, double *R9) 
 
 int vio_set_fisheye_mask(vio_batch *h, const uint8_t *mask, int on_device) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h) return VIO_EINVAL;
     int rc = sync_all(h);
     if (rc != VIO_OK) return rc;
@@ -1466,6 +1503,7 @@ int vio_set_fisheye_mask(vio_batch *h, const uint8_t *mask, int on_device) {
 
 int vio_set_tracker_lag(vio_batch *h, int lag) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || (lag != 0 && lag != 1)) return VIO_EINVAL;
     if (lag && h->hc.c.dynamic_init) { g_err = "vio_set_tracker_lag: dynamic_init handles run their initialisation on the host between frames (lag 0 only)"; return VIO_EINVAL; }
     int rc = sync_all(h);
@@ -1502,6 +1540,7 @@ int vio_set_relo_frame(vio_batch *h, int seq, double frame_stamp, int frame_inde
 
 int vio_get_relo(vio_batch *h, int seq, double *out30) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || seq < 0 || seq >= h->S || !out30) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local BeSeq be;
@@ -1519,6 +1558,7 @@ int vio_get_relo(vio_batch *h, int seq, double *out30) {
 
 int vio_get_latest_odometry(vio_batch *h, int seq, double *out11) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || seq < 0 || seq >= h->S || !out11) return VIO_EINVAL;
     int rc = flush_imu_backend(h);   // samples pushed so far must be in the ring
     if (rc != VIO_OK) return rc;
@@ -1532,6 +1572,7 @@ int vio_get_latest_odometry(vio_batch *h, int seq, double *out11) {
 
 int vio_process(vio_batch *h, const uint16_t *depth_mm, int on_device) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || !depth_mm) return VIO_EINVAL;
     int rc = wait_host_uploads(h);
     if (rc != VIO_OK) return rc;
@@ -1590,6 +1631,7 @@ int vio_process_obs_batch(vio_batch *h, const int32_t *n_obs, const int32_t *ids
 
 int vio_process_obs(vio_batch *h, int seq, int n, const int32_t *ids, const double *obs, const uint16_t *depth_mm, double stamp) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || seq < 0 || seq >= h->S || n < 0 || (n > 0 && (!ids || !obs)) || !depth_mm) return VIO_EINVAL;
     if (n == 0) return VIO_OK;  // the nodelet only queues non-empty maps (estimator_nodelet.cpp:378)
     const DevCfg &C = h->hc;
@@ -1621,6 +1663,7 @@ int vio_process_obs(vio_batch *h, int seq, int n, const int32_t *ids, const doub
 
 int vio_get_packaged(vio_batch *h, int seq, int cap, int32_t *ids, double *obs) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local FeSeq fe;
@@ -1652,6 +1695,7 @@ int vio_abi_sizeof(int what) { return what == 0 ? (int)sizeof(vio_config) : (wha
 
 int vio_get_capacity(vio_batch *h, int32_t *out3) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || !out3) return VIO_EINVAL;
     out3[0] = h->hc.NP; out3[1] = h->hc.NL; out3[2] = h->hc.NIMU;
     return VIO_OK;
@@ -1661,6 +1705,7 @@ int vio_get_capacity(vio_batch *h, int32_t *out3) {
 // with the Schur complement in HBM / L2 (windows beyond W = 10)
 int vio_get_solver_kind(vio_batch *h) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h) return VIO_EINVAL;
     return h->solve_mode == 0 ? 0 : (h->serial_big ? 2 : 1);
 }
@@ -1669,6 +1714,7 @@ int vio_get_solver_kind(vio_batch *h) {
 // while a point was formed, bounded landmarks that entered solves, trial evaluations and shortened steps of the projected Armijo line search
 int vio_get_bound_stats(vio_batch *h, int seq, int64_t *out4) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || !out4 || seq < 0 || seq >= h->S) return VIO_EINVAL;
     HIPCHK(hipDeviceSynchronize());
     BeSeq be;
@@ -1679,6 +1725,7 @@ int vio_get_bound_stats(vio_batch *h, int seq, int64_t *out4) {
 
 int vio_push_imu_batch(vio_batch *h, const int32_t *n, int stride, const double *t, const double *acc, const double *gyr) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || stride < 0 || !t || !acc || !gyr) return VIO_EINVAL;
     std::lock_guard<std::mutex> lk(h->imu_mu);
     for (int s = 0; s < h->S; s++) {
@@ -1698,6 +1745,7 @@ int vio_push_imu_batch(vio_batch *h, const int32_t *n, int stride, const double 
 
 int vio_sync(vio_batch *h) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h) return VIO_EINVAL;
     return sync_all(h);
 }
@@ -1718,6 +1766,7 @@ static void fill_status(const BeSeq &be, const FeSeq &fe, vio_status *out) {
 
 int vio_get_status(vio_batch *h, int seq, vio_status *out) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || seq < 0 || seq >= h->S || !out) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local BeSeq be;
@@ -1730,6 +1779,7 @@ int vio_get_status(vio_batch *h, int seq, vio_status *out) {
 
 int vio_get_status_all(vio_batch *h, vio_status *out) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || !out) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     std::vector<BeSeq> be((size_t)h->S);
@@ -1742,6 +1792,7 @@ int vio_get_status_all(vio_batch *h, vio_status *out) {
 
 int vio_get_window(vio_batch *h, int seq, double *out) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || seq < 0 || seq >= h->S || !out) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local BeSeq be;
@@ -1759,6 +1810,7 @@ int vio_get_window(vio_batch *h, int seq, double *out) {
 
 int vio_get_odometry(vio_batch *h, double *out) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || !out) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     HIPCHK(hipMemcpy(out, h->B.odom, sizeof(double) * (size_t)h->S * 11, hipMemcpyDeviceToHost));
@@ -1767,6 +1819,7 @@ int vio_get_odometry(vio_batch *h, double *out) {
 
 int vio_get_odometry_history(vio_batch *h, int seq, int cap, double *out) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || seq < 0 || seq >= h->S || !out) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     int n = 0;
@@ -1784,6 +1837,7 @@ int vio_get_odometry_history(vio_batch *h, int seq, int cap, double *out) {
 
 int vio_get_extrinsic(vio_batch *h, int seq, double *out13) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || seq < 0 || seq >= h->S || !out13) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local BeSeq be;
@@ -1796,6 +1850,7 @@ int vio_get_extrinsic(vio_batch *h, int seq, double *out13) {
 
 int vio_get_tracks(vio_batch *h, int seq, int cap, int32_t *ids, int32_t *cnt, float *cur, float *un, float *vel) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local FeSeq fe;
@@ -1854,6 +1909,7 @@ int vio_get_landmarks_ex(vio_batch *h, int seq, int cap, double *out12) { DevGua
 
 int vio_get_prior(vio_batch *h, int seq, double *J, double *r, double *x0, uint8_t *present) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local BeSeq be;
@@ -1876,6 +1932,7 @@ int vio_get_prior(vio_batch *h, int seq, double *J, double *r, double *x0, uint8
 
 int vio_get_timings(vio_batch *h, int cap, double *out_ms) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || !out_ms || cap < 3) return VIO_EINVAL;
     if (!h->timing_valid) return 0;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
@@ -1888,6 +1945,7 @@ int vio_get_timings(vio_batch *h, int cap, double *out_ms) {
 
 int vio_debug_seq(vio_batch *h, int seq, int *out16) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || seq < 0 || seq >= h->S) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     static thread_local BeSeq be;
@@ -1899,6 +1957,7 @@ int vio_debug_seq(vio_batch *h, int seq, int *out16) {
 // debug: accumulated in-kernel phase ticks (100 MHz) of sequence 0; reset != 0 clears them
 int vio_debug_phases(vio_batch *h, float *out128, int reset) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     if (out128) HIPCHK(hipMemcpy(out128, h->B.timings, 128 * sizeof(float), hipMemcpyDeviceToHost));
@@ -1909,6 +1968,7 @@ int vio_debug_phases(vio_batch *h, float *out128, int reset) {
 // debug: per-sequence in-kernel durations (100 MHz ticks) of the last frame's fe_select / fe_add: out[S][4]
 int vio_debug_fe_ticks(vio_batch *h, float *out) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || !out) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     HIPCHK(hipMemcpy(out, h->B.fe_ticks, (size_t)h->S * 4 * sizeof(float), hipMemcpyDeviceToHost));
@@ -1918,6 +1978,7 @@ int vio_debug_fe_ticks(vio_batch *h, float *out) {
 // per-kernel HIP-event profile of the next max_steps vio_feed calls (events sit on the batch stream)
 int vio_profile_begin(vio_batch *h, int max_steps) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || max_steps < 1) return VIO_EINVAL;
     size_t need = (size_t)max_steps * VIO_NEV;
     while (h->pev.size() < need) {
@@ -1933,6 +1994,7 @@ int vio_profile_begin(vio_batch *h, int max_steps) {
 // out_ms[k] = average duration of kernel k over the recorded steps (ms); returns the number of recorded steps
 int vio_profile_end(vio_batch *h, int cap, double *out_ms) {
     DevGuard dev_guard(h);
+    if (dev_guard.failed) { g_err = "hipSetDevice failed for the handle's device"; return VIO_EDEVICE; }
     if (!h || !out_ms || cap < VIO_NK) return VIO_EINVAL;
     { int rc_ = sync_all(h); if (rc_ != VIO_OK) return rc_; }
     int n = h->prof_cur < 0 ? 0 : (h->prof_cur < h->prof_steps ? h->prof_cur : h->prof_steps);
