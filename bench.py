@@ -550,6 +550,10 @@ def main():
                 paths = list(tp.map(_prep, range(nproc)))
             cfg_bytes = bytes(cfg)
             ctx = mp.get_context("spawn")
+            # the same worker alone on the machine first: the one-core rate of THIS harness (the `one_core` leg above runs inside the bench process,
+            # on the bench's own sequences, beside the HIP runtime's threads)
+            with ctx.Pool(1, initializer=_cpu_init, initargs=(None,)) as pool:
+                res1 = pool.map(_cpu_worker, [(paths[0], cfg_bytes)], chunksize=1)
             c0 = time.perf_counter()
             with ctx.Pool(nproc, initializer=_cpu_init, initargs=(ctx.Barrier(nproc),)) as pool:
                 res = pool.map(_cpu_worker, [(pth, cfg_bytes) for pth in paths], chunksize=1)
@@ -561,7 +565,8 @@ def main():
                        sample="%d oracle processes (one per effective core; they load only oracle/liboracle.so), one pre-rendered sequence of %d frames each, "
                               "timed frames started behind a barrier; sum of the per-process steady-state rates (the reference's own effective threading is "
                               "one back-end thread per estimator)" % (nproc, n_cf),
-                       wall_seconds=wall)
+                       wall_seconds=wall,
+                       one_worker_alone=(float(res1[0][1] / res1[0][0]) if res1[0][0] > 0 else None))
         cpu = dict(cpu_all)
         cpu["one_core"] = cpu1
 
@@ -579,7 +584,9 @@ def main():
                              "note": "all %d stream groups: S x back-end flops per frame / ms_per_step" % n_groups}
     cpu_c = None
     if cpu:
-        cpu_c = {k: cpu.get(k) for k in ("value", "unit", "cores", "cores_are", "hardware_threads_visible", "physical_cores", "kind") if k in cpu}
+        cpu_c = {k: cpu.get(k) for k in ("value", "unit", "cores", "cores_are", "hardware_threads_visible", "physical_cores", "kind", "one_worker_alone") if k in cpu}
+        if cpu_c.get("one_worker_alone"):
+            cpu_c["one_worker_alone"] = r3(cpu_c["one_worker_alone"])
         cpu_c["value"] = r3(cpu_c.get("value"))
         cpu_c["sample"] = ("one pre-rendered sequence of 36 frames per effective core, timed behind a barrier, sum of steady-state rates" if cpu_all else
                            "%d sequences of the bench workload on one core" % min(args.cpu_seqs, S))
