@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <mutex>
+#include <chrono>
 #include <string>
 #include <string.h>
 #include <vector>
@@ -137,6 +138,7 @@ struct vio_batch {
     std::vector<double> last_imu_t;
     size_t lds_select = 0, lds_add = 0, lds_fast = 0, lds_solve = 0, lds_serial = 0, lds_marg = 0, lds_factor = 0, lds_ps_ls = 0, lds_ps_evalf = 0;
     int ps_evalf_blocks = 0;           // workgroups per sequence of ps_evalf_kernel (2 + B.fuse)
+    bool feed_throttle = true;         // VIO_FEED_THROTTLE: host-fed vio_feed waits for the back-end of two feeds ago before it enqueues (stage_inputs)
     int uploads_in_flight = 2;         // VIO_UPLOADS_IN_FLIGHT: page-locked image uploads of vio_feed that may be pending when a call returns
     int relo_frames = 0;               // frames for which the two-kernel solver path is launched beside the fused kernel (armed by vio_set_relo_frame)
     bool line_search = true;           // ps_ls_kernel behind every ps_serial (Ceres' projected line search on bounds-constrained solves)
@@ -984,6 +986,7 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
     if (getenv("VIO_XCD_MAP")) h->xcd_map = atoi(getenv("VIO_XCD_MAP"));
     if (getenv("VIO_FE_XCD_MAP")) h->fe_xcd_map = atoi(getenv("VIO_FE_XCD_MAP"));
     if (getenv("VIO_XCD_N")) h->xcd_n = atoi(getenv("VIO_XCD_N"));
+    if (getenv("VIO_FEED_THROTTLE")) h->feed_throttle = atoi(getenv("VIO_FEED_THROTTLE")) != 0;
     if (getenv("VIO_UPLOADS_IN_FLIGHT")) h->uploads_in_flight = atoi(getenv("VIO_UPLOADS_IN_FLIGHT")) == 1 ? 1 : 2;
     if (getenv("VIO_EXTRA_SLOTS")) h->extra_slots = std::max(1, atoi(getenv("VIO_EXTRA_SLOTS")));
     if (getenv("VIO_ASM_A_OCC")) h->asm_a_occ4 = atoi(getenv("VIO_ASM_A_OCC")) >= 4;
@@ -1247,6 +1250,9 @@ static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, 
             HIPCHK(hipEventCreateWithFlags(&g.ev_up_depth[q], hipEventDisableTiming));
         }
     }
+    static const bool si_trace = getenv("VIO_FEED_TRACE") && atoi(getenv("VIO_FEED_TRACE")) != 0;
+    auto si_now = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double si0 = si_trace ? si_now() : 0;
     if (overlap && g.up_used[p]) {
         // caller contract (include/vio_abi.h "Host buffers"): the page-locked buffers of a vio_feed call are free once vio_host_buffers_done
         // says so, and at the latest when the SECOND next vio_feed has returned -- this call is about to reuse staging buffer p, whose last
@@ -1261,7 +1267,15 @@ static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, 
         HIPCHK(hipEventSynchronize(g.ev_up_gray[p ^ 1]));
         HIPCHK(hipEventSynchronize(g.ev_up_depth[p ^ 1]));
     }
+    if (overlap && h->feed_throttle && g.have_rd_depth[p]) {
+        // Host-fed feeds are THROTTLED to two frames of lead: wait until the back-end of the frame that last used staging buffer p (two host feeds
+        // ago) has finished.  Without it the host runs many frames ahead, the runtime's copy path eventually pushes back -- hipMemcpyAsync blocks
+        // for ~7 ms at a time (VIO_FEED_TRACE) -- and the device idles while the host refills its queues: 26 k frames/s from page-locked buffers
+        // against 44 k resident.  With one frame of work always queued behind the wait the device never runs dry.
+        HIPCHK(hipEventSynchronize(g.ev_rd_depth[p]));
+    }
     if (overlap) g.up_used[p] = true;
+    const double si1 = si_trace ? si_now() : 0;
     if (gray) {
         uint8_t *&buf = p ? h->d_gray_stage1 : h->d_gray_stage;
         if (!buf) HIPCHK(hipMalloc((void **)&buf, S * HW));
@@ -1274,6 +1288,7 @@ static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, 
             HIPCHK(hipMemcpyAsync(buf + s0 * HW, gray + s0 * HW, n * HW, hipMemcpyHostToDevice, g.fe_stream));
         *dg = buf;
     }
+    const double si2 = si_trace ? si_now() : 0;
     if (depth) {
         uint16_t *&buf = p ? h->d_depth_stage1 : h->d_depth_stage;
         if (!buf) HIPCHK(hipMalloc((void **)&buf, S * HW * 2));
@@ -1287,6 +1302,7 @@ static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, 
             HIPCHK(hipMemcpyAsync(buf + s0 * HW, depth + s0 * HW, n * HW * 2, hipMemcpyHostToDevice, g.stream));
         *dd = buf;
     }
+    if (si_trace && !on_device) fprintf(stderr, "  stage_inputs group %d: wait for the staging buffer's last upload %.0f us, grey copy call %.0f us, depth copy call %.0f us\n", (int)s0, si1 - si0, si2 - si1, si_now() - si2);
     return VIO_OK;
 }
 
@@ -1364,12 +1380,17 @@ int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, 
     if (rc != VIO_OK) return rc;
     rc = flush_imu_frontend(h);
     if (rc != VIO_OK) return rc;
+    // VIO_FEED_TRACE=1 (diagnostic): host time of every section of the call on stderr -- where an "asynchronous" feed blocks
+    static const bool feed_trace = getenv("VIO_FEED_TRACE") && atoi(getenv("VIO_FEED_TRACE")) != 0;
+    auto now_us = []() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (auto &g : h->groups) {
+        const double tt0 = feed_trace ? now_us() : 0;
         if ((rc = fe_wait(h, g)) != VIO_OK) return rc;
         const uint8_t *dg = nullptr;
         const uint16_t *dd = nullptr;
         rc = stage_inputs(h, g, gray, depth_mm, nullptr, on_device, &dg, &dd, /*overlap=*/true);
         if (rc != VIO_OK) return rc;
+        const double tt1 = feed_trace ? now_us() : 0;
         if ((rc = stage_side_ring(h, g, stamps, modes)) != VIO_OK) return rc;
         if (g.s0 == 0) HIPCHK(hipEventRecord(h->ev[0], g.fe_stream));
         rc = launch_frontend(h, g, dg, 1, 1, modes ? h->d_modes : nullptr, nullptr);
@@ -1384,6 +1405,7 @@ int vio_feed_modes(vio_batch *h, const uint8_t *gray, const uint16_t *depth_mm, 
             g.flip ^= 1;
         }
         if (g.s0 == 0) HIPCHK(hipEventRecord(h->ev[2], g.stream));
+        if (feed_trace) fprintf(stderr, "vio_feed group %d: stage_inputs %.0f us, rest (side ring + %s launches) %.0f us, t = %.0f\n", g.s0, tt1 - tt0, "all", now_us() - tt1, tt0);
     }
     if (h->prof_cur >= 0) h->prof_cur++;
     h->timing_valid = true;
