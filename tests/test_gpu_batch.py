@@ -197,6 +197,23 @@ def test_fused_evaluate_and_assemble_equals_the_two_kernel_path(P, monkeypatch, 
     assert same > 0.95, same
 
 
+def test_fused_kernel_with_fewer_workgroups_than_chunks_is_bit_identical(P, monkeypatch):
+    """VIO_FUSE = n sets the chunk workgroups per sequence in ps_evalf_kernel's grid; a solve with more chunks than that makes them loop
+    (right after the initialisation the residual list is at its longest).  The chunk partition, the partial Gram blocks and the order they
+    are added in do not depend on which workgroup takes which chunk: three workgroups (every solve loops) must give the same BITS as the default
+    eight."""
+    cfg = P.canonical_config()
+    sc = vio_ct.synth_like(cfg)
+    monkeypatch.setenv("VIO_FUSE", "1")
+    ref = _drive(P, cfg, sc, [60, 61, 62], 32)
+    ref_w = [ref.window(i).copy() for i in range(3)]
+    monkeypatch.setenv("VIO_FUSE", "3")
+    alt = _drive(P, cfg, sc, [60, 61, 62], 32)
+    for i in range(3):
+        assert alt.status(i).solver_flag == 1 and alt.status(i).has_prior == 1 and alt.status(i).overflow_flags == 0
+        assert np.array_equal(alt.window(i).view(np.uint64), ref_w[i].view(np.uint64)), (i, float(np.abs(alt.window(i) - ref_w[i]).max()))
+
+
 def test_status_all_equals_per_sequence_status(P):
     cfg = P.canonical_config()
     sc = vio_ct.synth_like(cfg)

@@ -501,15 +501,13 @@ def test_end_to_end_accuracy_against_ground_truth(P):
 
 
 def test_inverse_depth_bound_is_never_active_on_the_canonical_workload(P):
-    """DESIGN.md deviation 5: Ceres handles the upper bound on the inverse depth of landmarks triangulated WITHOUT a depth measurement
-    (SetParameterUpperBound, estimator.cpp:1282-1297) by projecting the step onto the box and a line search along the projected step;
-    oracle and HIP path project only.  The two differ only in a step that actually hits the bound.  Measured here instead of asserted
-    in prose: on the canonical RGB-D workload (depth image valid everywhere) no candidate step is ever cut, in fact no bounded landmark
-    even enters a solve; with the depth sensor blinded beyond its configured range (DEPTH_MAX_DIST = 3 m: every farther landmark is
-    triangulated from parallax only, estimate_flag 2) thousands of bounded landmarks enter the solves and the projection still never
-    engages -- a landmark beyond the sensor range has an inverse depth below 1 / DEPTH_MAX_DIST, half the bound 2 / DEPTH_MAX_DIST.
-    (It does engage when the configuration contradicts the sensor, e.g. a sensor blind beyond 2.5 m declared to reach 10 m: landmarks at
-    2.5 - 5 m then violate "depth >= DEPTH_MAX_DIST / 2" all the time; there the two treatments would differ.)"""
+    """Ceres handles the upper bound on the inverse depth of landmarks triangulated WITHOUT a depth measurement (SetParameterUpperBound,
+    estimator.cpp:1282-1297) as a bounds-constrained program: x0 projected onto the box, projected Armijo line search along every step
+    (restated since round 6; tests/test_oracle_linesearch_cpu.py).  Measured here: on the canonical RGB-D workload (depth image
+    valid everywhere) no bounded landmark even enters a solve, so that machinery is never entered; with the depth sensor blinded beyond its
+    configured range (DEPTH_MAX_DIST = 3 m: every farther landmark is triangulated from parallax only, estimate_flag 2) thousands of bounded
+    landmarks enter the solves, every solve is constrained and runs the search -- and the bound itself cuts only a handful of points (a landmark
+    beyond the sensor range has an inverse depth below 1 / DEPTH_MAX_DIST, half the bound 2 / DEPTH_MAX_DIST)."""
     cfg = P.canonical_config()
     sc = vio_ct.synth_like(cfg)
     clamps = bounded = 0
@@ -530,4 +528,6 @@ def test_inverse_depth_bound_is_never_active_on_the_canonical_workload(P):
     o = vio_ct.run_oracle_sequence(cfg3, sc, 2, 60, frames=frames)
     c, b = o["oracle"].bound_stats()
     assert b > 1000 and len(o["traj"]) >= 30, b
-    assert c == 0, (c, b)
+    evals, contractions = o["oracle"].line_search_stats()
+    assert evals > 300 and contractions < evals, (evals, contractions)     # the search runs in every constrained solve ...
+    assert c < b / 10, (c, b)                                               # ... while the projection itself rarely cuts anything here
