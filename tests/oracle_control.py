@@ -276,6 +276,24 @@ def cmd_fixtures(a):
     np.savez_compressed(os.path.join(HERE, "golden", "oracle_decisions_300.npz"), seq0=ctl[0], frames=a.frames, keys=np.array(STATUS_KEYS), decisions=dec)
 
 
+def cmd_census_fixture(a):
+    """tests/golden/oracle_dev31_300.npz: positions of the oracle with every HIP formulation switched on (variant devallc, OVIO_DEVIATIONS = 31)
+    for the --seqs sequences of a `run --only devallc` pass: what tests/test_gpu_parity3.py::test_census_128_sequences_against_the_matched_oracle
+    compares the HIP path with."""
+    have = sorted(int(f[4:9]) for f in os.listdir(a.scratch) if f.startswith("seq_") and f.endswith(".npz") and ".tmp" not in f)
+    assert have == list(range(a.seq0, a.seq0 + a.seqs)), (len(have), a.seqs)
+    n = len(have)
+    pos = np.zeros((n, a.frames, 3)); nfr = np.zeros(n, np.int32); first = np.zeros(n, np.int32); reb = np.zeros(n, np.int32)
+    for i, s_ in enumerate(have):
+        z = np.load(os.path.join(a.scratch, "seq_%05d.npz" % s_))
+        fr, po = z["devallc_frames"], z["devallc_pos"]
+        pos[i, fr] = po; nfr[i] = len(po); first[i] = fr[0]; reb[i] = int(z["devallc_reboots"])
+    assert reb.sum() == 0
+    out = os.path.join(HERE, "golden", "oracle_dev31_300.npz")
+    np.savez_compressed(out, seq0=have[0], frames=a.frames, deviations=31, n_rows=nfr, first_frame=first, positions=pos)
+    print("census fixture: %d sequences -> %s" % (n, out))
+
+
 def early_rows(za, na, nb, n_early=30):
     """largest distance of two runs over the first n_early published positions (the window in which implementations still agree)"""
     pa, pb = za[na + "_pos"], za[nb + "_pos"]
@@ -323,7 +341,7 @@ def cmd_attribution(a):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("cmd", choices=("run", "assemble", "attribution", "fixtures"))
+    ap.add_argument("cmd", choices=("run", "assemble", "attribution", "fixtures", "census-fixture"))
     ap.add_argument("--seqs", type=int, default=1024)
     ap.add_argument("--control", type=int, default=128, help="leading sequences that also run the control variants")
     ap.add_argument("--seq0", type=int, default=700)
@@ -336,7 +354,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "round4_oracle_self_divergence.json"))
     ap.add_argument("--fixture", default=os.path.join(HERE, "golden", "oracle_ate_300_lag1.npz"))
     a = ap.parse_args()
-    {"run": cmd_run, "assemble": cmd_assemble, "attribution": cmd_attribution, "fixtures": cmd_fixtures}[a.cmd](a)
+    {"run": cmd_run, "assemble": cmd_assemble, "attribution": cmd_attribution, "fixtures": cmd_fixtures, "census-fixture": cmd_census_fixture}[a.cmd](a)
 
 
 if __name__ == "__main__":

@@ -129,11 +129,10 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(Batch B) {
             }
         }
         __syncthreads();
-        // (B.fuse < 0: the handle launches ONLY the fused kernel -- its configuration cannot produce anything else; should a solve still not
+        // (B.fuse_only: the handle launches ONLY the fused kernel -- its configuration cannot produce anything else; should a solve still not
         // qualify it is flagged, overflow bit 256, rather than left waiting for kernels that never come)
         // -- and left out of this frame's optimisation (PS_DONE at once: ps_final hands the unoptimised window back)
         if (t == 0 && !fused && B.fuse_only) be.overflow |= 256;
-        if (!fused && B.fuse_only) { __syncthreads(); if (t == 0) { st.fused = 0; st.nblk = 0; st.rowbuf = 0; st.chunk_done = 0; st.stage = PS_DONE; st.cost = 0; st.iters_done = 0; st.succ = 0; st.ts0 = ts0; } return; }
         if (t == 0) { st.fused = fused ? 1 : 0; st.nblk = fused ? nblk : 0; st.rowbuf = 0; st.chunk_done = 0; }
     }
     for (int k = t; k < (int)(sizeof(Params) / sizeof(double)); k += blockDim.x) ((double *)&st.X)[k] = ((const double *)&X)[k];
@@ -151,7 +150,8 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(Batch B) {
         st.n_eval_blocks = st.fused ? 2 + min(st.nblk, B.fuse) : 3 + (nres + 256 * B.eval_rpt - 1) / (256 * B.eval_rpt);
         st.eval_done = 0;
         st.ts0 = ts0;
-        st.stage = PS_EVAL_X0;
+        // (a solve that cannot take the fused path on a handle that launches nothing else: closed at once with the point it started from)
+        st.stage = (!st.fused && B.fuse_only) ? PS_DONE : PS_EVAL_X0;
     }
 }
 
