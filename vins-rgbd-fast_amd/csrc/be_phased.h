@@ -166,7 +166,9 @@ __device__ void ps_accept(const Batch &B, int s) {
     const vio_config &cfg = c.C->c;
     const int W = c.W;
     // total cost: the per-block partial sums, one per lane (n_eval_blocks <= PS_MAX_EVAL_BLOCKS <= 64), reduced in a fixed tree order
-    double total = t < st.n_eval_blocks ? ((volatile double *)st.part)[t] : 0.0;
+    // (a device-scope read-modify-write as the load: it returns the value at the coherence point, whatever sits in this XCD's L2 -- no cache-wide
+    // invalidate needed, see the tail of ps_eval_body)
+    double total = t < st.n_eval_blocks ? __longlong_as_double((long long)atomicOr((unsigned long long *)&st.part[t], 0ull)) : 0.0;
     total = wave_sum_dpp(total);
     if (st.stage == PS_EVAL_X0) {
         if (t == 0) { st.cost = total; c.be->initial_cost = total; st.point_new = 1; st.stage = PS_ASM; if (st.fused) st.rowbuf ^= 1; }
@@ -657,15 +659,22 @@ __device__ __forceinline__ void ps_eval_body(const Batch &B) {
     }
     if (b == 0) PH(62); else if (b == 1) PH(63); else if (b == 3) PH(14);
     cost = block_sum(cost, sred);
+    // Hand-over of the partial cost to the block that finishes last WITHOUT __threadfence(): on gfx950 that fence is `buffer_wbl2 sc1` +
+    // `buffer_inv sc1` -- a write-back AND an invalidate of the XCD's whole L2, 448 + 64 of them per 64-sequence launch, each one throwing out
+    // the lines every other workgroup on the XCD was about to hit (round 6: found when a fence per partial Gram block made the fused kernel's
+    // workgroups seven times slower).  The only data that crosses workgroups inside this kernel is part[b] (everything else ps_accept reads was
+    // written by earlier kernels): it is published by a returning device-scope atomic exchange, the counter increment depends on the value that
+    // exchange returns (so it is issued after the exchange has been performed at the coherence point), and ps_accept reads part[] with
+    // device-scope read-modify-writes.
     __shared__ int last;
     if (t == 0) {
-        st.part[b] = cost;
-        __threadfence();
-        last = atomicAdd(&st.eval_done, 1) == st.n_eval_blocks - 1;
+        const unsigned long long old = atomicExch((unsigned long long *)&st.part[b], (unsigned long long)__double_as_longlong(cost));
+        int zero;   // 0, computed from the exchange's return value in a way the compiler cannot fold: the increment below waits for that value
+        asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"((int)(old >> 32)));
+        last = atomicAdd(&st.eval_done, 1 + zero) == st.n_eval_blocks - 1;
     }
     __syncthreads();
     if (last && t < 64) {
-        __threadfence();
         if (t == 0) st.eval_done = 0;
         const long long ta = (s == 0 && t == 0) ? VIO_CLOCK() : 0;
         ps_accept(B, s);
@@ -1127,12 +1136,16 @@ __global__ __launch_bounds__(256) void ps_evalf_kernel(Batch B) {
                     const int npart = st.pm_np[slot_p];
                     double *part0 = B.pairpart + ((size_t)s * PS_FUSE_MAXPAIRS + slot_p) * PS_FUSE_MAXBLK * 210;
                     double *out = npart <= 1 ? c.pairblk + (size_t)slot_p * 210 : part0 + (size_t)rank * 210;
+                    // (a pair whose residuals span chunks: this is one of its partial blocks; the chunk that finishes last adds them up, below.  Partial
+                    // blocks cross workgroups inside this kernel: device-scope atomic stores -- write-through to the coherence point -- instead of a
+                    // cache-wide fence, see the tail)
                     for (int r = 0; r < 4; r++) {
                         const int row = lk + 4 * r, col = li;
-                        if (row < 12) { if (col <= row) out[sym_idx(col, row)] = a00[r]; }
-                        else if (row == 12 && col <= 12) out[sym_idx(col < 12 ? col : 19, 19)] = a00[r];
+                        int e = -1;
+                        if (row < 12) { if (col <= row) e = sym_idx(col, row); }
+                        else if (row == 12 && col <= 12) e = sym_idx(col < 12 ? col : 19, 19);
+                        if (e >= 0) { if (npart > 1) __hip_atomic_store(&out[e], a00[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else out[e] = a00[r]; }
                     }
-                    // (a pair whose residuals span chunks: this is one of its partial blocks; the chunk that finishes last adds them up, below)
                 }
             }
             PH(32);
@@ -1209,21 +1222,24 @@ __global__ __launch_bounds__(256) void ps_evalf_kernel(Batch B) {
         for (int pb = b - 2 + B.fuse; pb < nblk; pb += B.fuse) { __syncthreads(); chunk(pb); }   // (the previous chunk's records are still being read)
     }
     cost = block_sum(cost, sred);
-    // ONE device-scope release per workgroup (on gfx950 a fence at agent scope writes the XCD's L2 back: a fence per published partial block
-    // made every workgroup on the device seven times slower): partial cost, partial Gram blocks and -- for the kernels that follow -- rows
+    // No cache-wide fence (on gfx950 __threadfence() is buffer_wbl2 sc1 + buffer_inv sc1: the XCD's whole L2 written back AND invalidated -- a
+    // fence per published partial block made every workgroup on the device seven times slower, and even one per workgroup costs 10 % of the
+    // whole pipeline, see ps_eval_body).  What crosses workgroups inside this kernel: the partial cost (published by a returning device-scope
+    // exchange; the counter increments depend on its return value) and the partial Gram blocks (device-scope atomic stores above, drained by
+    // the barriers of block_sum before thread 0 gets here; read back with device-scope atomic loads).  Rows and blocks go to later kernels.
     __shared__ int last, lastc;
     if (t == 0) {
-        st.part[b] = cost;
-        __threadfence();
+        const unsigned long long old = atomicExch((unsigned long long *)&st.part[b], (unsigned long long)__double_as_longlong(cost));
+        int zero;
+        asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"((int)(old >> 32)));
         const int mine = b >= 2 ? (st.nblk - (b - 2) + B.fuse - 1) / B.fuse : 0;   // chunks this workgroup took
-        lastc = (mine > 0 && withJ) ? (atomicAdd(&st.chunk_done, mine) == st.nblk - mine) : 0;
-        last = atomicAdd(&st.eval_done, 1) == st.n_eval_blocks - 1;
+        lastc = (mine > 0 && withJ) ? (atomicAdd(&st.chunk_done, mine + zero) == st.nblk - mine) : 0;
+        last = atomicAdd(&st.eval_done, 1 + zero) == st.n_eval_blocks - 1;
     }
     __syncthreads();
     if (lastc) {
         // the chunk that finished last: frame pairs whose residuals span chunks have one partial Gram block per chunk -- added up in chunk
         // order (deterministic whichever chunk gets here), one wavefront per pair
-        __threadfence();
         if (t == 0) st.chunk_done = 0;
         // (this is a serial tail of the kernel: every load of a pair in flight at once -- as a chain of volatile loads it took 25 us)
         for (int slot_p = wave; slot_p < W1 * W / 2; slot_p += NW) {
@@ -1235,7 +1251,7 @@ __global__ __launch_bounds__(256) void ps_evalf_kernel(Batch B) {
 #pragma unroll
             for (int q = 0; q < PS_FUSE_MAXBLK; q++)
 #pragma unroll
-                for (int u = 0; u < 4; u++) v[q][u] = part0[(size_t)min(q, npart - 1) * 210 + min(lane + 64 * u, 209)];
+                for (int u = 0; u < 4; u++) v[q][u] = __hip_atomic_load(&part0[(size_t)min(q, npart - 1) * 210 + min(lane + 64 * u, 209)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 double acc = v[0][u];
@@ -1246,7 +1262,6 @@ __global__ __launch_bounds__(256) void ps_evalf_kernel(Batch B) {
         }
     }
     if (last && t < 64) {
-        __threadfence();
         if (t == 0) st.eval_done = 0;
         ps_accept(B, s);
     }
