@@ -1855,7 +1855,7 @@ __global__ __launch_bounds__(512) void ps_serial_big_kernel(Batch B) { ps_serial
 // (20 trials, or a |delta|_inf < 1e-9), left as it was.  The next ps_eval evaluates whatever candidate stands, as Ceres evaluates the candidate
 // again after its search; model_change, dogleg_norm and the radius logic keep the FULL step's values.  (Kept out of ps_serial / ps_eval on
 // purpose: inlined there its stack objects gave the two hottest kernels of the solve a private segment.)
-__global__ __launch_bounds__(256) void ps_ls_kernel(Batch B) {
+__global__ __launch_bounds__(256, 4) void ps_ls_kernel(Batch B) {   // (held to 128 VGPRs -- the search itself spills, it is the rare path: an idle workgroup of 400 VGPRs per lane waits for register space on every CU it lands on)
     const int s = blockIdx.x + B.s0, t = threadIdx.x, nt = blockDim.x;
     SolveSt &st = B.sst[s];
     if (st.stage != PS_EVAL_C || !st.ls_pending) return;
@@ -1869,7 +1869,10 @@ __global__ __launch_bounds__(256) void ps_ls_kernel(Batch B) {
     constexpr int XD = ((int)(sizeof(Params) / sizeof(double)) + 1) & ~1;
     Params &X = *(Params *)lds;
     double *lsw = (double *)lds + XD, *lpart = lsw + 104;                 // scalar workspace (96) + broadcast slot, partial costs (64)
-    unsigned char *role_smem = (unsigned char *)(lsw + PS_LS_HEAD_DOUBLES - XD);
+    // the evaluation roles' staging region (frame-pair geometry / pre-integration headers, 38 KB) lives in HBM / L2 here, not in LDS: an IDLE
+    // launch of this kernel -- every slot of every unconstrained solve -- must ask for next to nothing, or its workgroups queue behind the LDS
+    // the other stream group's kernels hold (measured with the region in LDS: 9 us per idle launch at S = 128, 30 us at S = 512)
+    unsigned char *role_smem = B.ls_scratch + (size_t)s * ps_eval_lds_bytes(c.W);
     const double *stl = c.lvec + 4 * (size_t)c.NLs, *sl = c.lvec;
     const double *delta = c.vec + 8 * (size_t)c.LW;   // the unscaled tangent step ps_serial left in slot 8 of the step vectors
     const bool act = true;

@@ -17,8 +17,8 @@ __host__ __device__ static inline size_t ps_eval_lds_bytes(int W) {
     const size_t W1 = (size_t)W + 1, a = (W1 * W1 + 1) * 32 * 8, b = (size_t)W * (VIO_PREINT_HDR + 1) * 8;
     return (a > b ? a : b) + 64;
 }
-// dynamic LDS of ps_ls_kernel: evaluation point + scalar workspace + partial costs (PS_LS_HEAD_DOUBLES) ahead of one evaluation role's region
-static inline size_t ps_ls_lds_bytes(int W) { return ((((sizeof(Params) / sizeof(double)) + 1) & ~(size_t)1) + 176) * 8 + ps_eval_lds_bytes(W) + 16; }
+// dynamic LDS of ps_ls_kernel: evaluation point + scalar workspace + partial costs (PS_LS_HEAD_DOUBLES); the evaluation roles' region is in HBM (Batch::ls_scratch)
+static inline size_t ps_ls_lds_bytes(int W) { (void)W; return ((((sizeof(Params) / sizeof(double)) + 1) & ~(size_t)1) + 176) * 8 + 16; }
 struct LkImages {
     const uint8_t *prev[4];
     const uint8_t *next[4];

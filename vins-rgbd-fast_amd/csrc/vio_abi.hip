@@ -969,6 +969,7 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
     DA(B.H, S * LW * LW); DA(B.Sc, S * LW * LW); DA(B.Hpl, 2 * S * (NL + 8) * LW); DA(B.vec, S * VEC_SLOTS * LW);
     DA(B.Hll, 2 * S * (NL + 8)); DA(B.gl, 2 * S * (NL + 8)); DA(B.lvec, S * (NL + 8) * 8);
     if (C.W <= PS_FUSE_MAXW) DA(B.pairpart, S * PS_FUSE_MAXPAIRS * PS_FUSE_MAXBLK * 210);
+    DA(B.ls_scratch, S * ps_eval_lds_bytes(C.W));
     DA(B.res, S * nres * 42); DA(B.res_lm, S * nres); DA(B.res_k, S * nres); DA(B.res_pair, S);
     DA(B.pair_start, S * (npair + 1)); DA(B.pair_list, S * nres); DA(B.pairblk, S * npair * 210);
     DA(B.imu_raw, S * C.W * 15 * 31);
