@@ -1839,8 +1839,7 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
     PH(55);
 }
 
-__global__ __launch_bounds__(1024) void ps_serial_kernel(Batch B) { ps_serial_body<false, 4>(B); }
-// VIO_SERIAL_THREADS = 512: the same phase with 8 wavefronts and 256 VGPRs per lane
+// 8 wavefronts, 256 VGPRs per lane, no scratch (the 1024-thread / 128-VGPR build of rounds 2 - 5 was removed in round 6: it had gone wrong unnoticed)
 __global__ __launch_bounds__(512) void ps_serial_kernel_512(Batch B) { ps_serial_body<false, 8>(B); }
 // the same serial phase for windows whose Schur complement stays in HBM / L2 (its own kernel: the streaming Cholesky's registers must not
 // weigh on the 128-VGPR budget of the resident version); 512 threads = 256 VGPRs per lane

@@ -63,7 +63,6 @@ __global__ void ps_eval_kernel_occ4(Batch B);
 __global__ void ps_asm_a_kernel(Batch B);
 __global__ void ps_asm_a_kernel_occ4(Batch B);
 __global__ void ps_asm_b_schur_kernel(Batch B, int nb_b, int by_blocks);
-__global__ void ps_serial_kernel(Batch B);
 __global__ void ps_serial_big_kernel(Batch B);
 __global__ void ps_serial_kernel_512(Batch B);
 __global__ void ps_final_kernel(Batch B);
