@@ -157,6 +157,22 @@ def test_alternative_kernel_configurations_agree(P, monkeypatch, env):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(estimate_extrinsic=1, estimate_td=1)])
+def test_mirrored_assembly_of_H_equals_the_entrywise_one(P, monkeypatch, kw):
+    """round 6: VIO_ASM_B_MODE = 2 forms only the entries a >= b of H and stores the mirror image too (half the index arithmetic and gathers of the
+    entrywise kernel; H's terms are symmetric source by source and added in the same order): the windows must be the same BITS as mode 0."""
+    cfg = P.canonical_config(**kw)
+    sc = vio_ct.synth_like(cfg)
+    monkeypatch.setenv("VIO_ASM_B_MODE", "0")
+    ref = _drive(P, cfg, sc, [60, 61, 62], 30)
+    ref_w = [ref.window(i).copy() for i in range(3)]
+    monkeypatch.setenv("VIO_ASM_B_MODE", "2")
+    alt = _drive(P, cfg, sc, [60, 61, 62], 30)
+    for i in range(3):
+        assert alt.status(i).solver_flag == 1 and alt.status(i).has_prior == 1
+        assert np.array_equal(alt.window(i).view(np.uint64), ref_w[i].view(np.uint64)), (i, float(np.abs(alt.window(i) - ref_w[i]).max()))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(estimate_extrinsic=1, estimate_td=1)])
 def test_block_pair_assembly_of_H_equals_the_entrywise_one(P, monkeypatch, kw):
     """round 5: ps_asm_b sums H and the gradient by pairs of parameter blocks (scalar index decisions, mirrored upper triangle) instead of one
     thread per entry; VIO_ASM_B_MODE = 0 keeps the entrywise kernel.  Same terms in the same order: the windows must be the same BITS, with the

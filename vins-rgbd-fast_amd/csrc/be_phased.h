@@ -1272,7 +1272,10 @@ __global__ __launch_bounds__(256) void ps_evalf_kernel(Batch B) {
 // zero-fill pass) and per entry of g: prior block, the (at most two) IMU Gram blocks that contain both columns, then the
 // frame-pair sums -- the same terms in the same order as assemble().  The thread that owns a diagonal entry fixes the Jacobi
 // column scaling the first time round.
-__device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int blk, int nb_b) {
+// tri = true (VIO_ASM_B_MODE = 2, round 6): only the entries a >= b are formed (and the gradient); every thread stores its entry and the mirror
+// image.  H's terms are symmetric source by source -- prior_H is stored exactly symmetric, the Gram blocks are read through sym_idx -- and are added
+// in the same order for (a, b) and (b, a), so the mirrored H is the same bits with half the index arithmetic and half the gathers.
+__device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int blk, int nb_b, const bool tri = false) {
     const SolveSt &st = B.sst[s];
     if (st.stage != PS_ASM) return;
     Ctx c = make_ctx(B, s);
@@ -1304,8 +1307,19 @@ __device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int blk, in
         if (a == oT) return 6 * W + 15;
         return -1;
     };
-    for (int w = blk * blockDim.x + threadIdx.x; w < total; w += nb_b * blockDim.x) {
-        const int a = w / (LW + 1), bcol = w - a * (LW + 1);
+    const int ntri = P * (P + 1) / 2, total_t = ntri + P + P * (LW - P);   // tri: lower triangle, gradient, zero padding columns
+    for (int w = blk * blockDim.x + threadIdx.x; w < (tri ? total_t : total); w += nb_b * blockDim.x) {
+        int a, bcol;
+        if (tri) {
+            if (w < ntri) {   // w = a (a + 1) / 2 + b, b <= a: closed form with a one-step correction of the float square root
+                a = (int)((sqrtf(8.0f * (float)w + 1.0f) - 1.0f) * 0.5f);
+                if (a * (a + 1) / 2 > w) a--;
+                if ((a + 1) * (a + 2) / 2 <= w) a++;
+                bcol = w - a * (a + 1) / 2;
+            }
+            else if (w < ntri + P) { a = w - ntri; bcol = LW; }
+            else { const int q = w - ntri - P; a = q / (LW - P); bcol = P + (q - a * (LW - P)); }
+        } else { a = w / (LW + 1); bcol = w - a * (LW + 1); }
         const bool grad = bcol == LW;
         const int b = grad ? -1 : bcol;
         if (!grad && b >= P) { c.H[(size_t)a * LW + b] = 0; continue; }
@@ -1370,6 +1384,7 @@ __device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int blk, in
         if (grad) c.vec[a] = v;
         else {
             c.H[(size_t)a * LW + b] = v;
+            if (tri && a != b) c.H[(size_t)b * LW + a] = v;
             if (a == b && st.scale_pending) {
                 bool act = a < oE ? true : (a < oT ? st.ex_active != 0 : st.td_active != 0);
                 if (!c.C->c.use_imu && (a < 6 || a >= 6 * W1)) act = false;   // VO mode: pose 0 constant, no speed-bias blocks
@@ -1575,7 +1590,7 @@ __global__ __launch_bounds__(256) void ps_asm_b_schur_kernel(Batch B, int nb_b, 
     int s, b;
     if (!ps_blk(B, s, b)) return;
     extern __shared__ double ps_wk_s[];
-    if (b < nb_b) { if (by_blocks) ps_asm_b_blocks(B, s, b, nb_b); else ps_asm_b_body(B, s, b, nb_b); }
+    if (b < nb_b) { if (by_blocks == 1) ps_asm_b_blocks(B, s, b, nb_b); else if (by_blocks == 2) ps_asm_b_body(B, s, b, nb_b, true); else ps_asm_b_body(B, s, b, nb_b, false); }
     else ps_schur_body(B, s, b - nb_b, ps_wk_s);
 }
 

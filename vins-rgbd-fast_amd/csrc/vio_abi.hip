@@ -87,7 +87,7 @@ struct vio_batch {
     int fe_xcd_map = 1;               // VIO_FE_XCD_MAP: the same idea for fe_lk (needs the front-end on every XCD: off under a CU partition)
     bool fe_partitioned = false;      // the front-end streams carry a CU mask (VIO_FE_CUS > 0 with tracker lag 1)
     int ps_asm_b_blocks = 24;         // workgroups per sequence that sum the entries of H (VIO_ASM_B_BLOCKS)
-    int asm_b_by_blocks = 0;          // VIO_ASM_B_MODE: 0 (default) = one thread per entry of H, 1 = H summed by pairs of parameter blocks (round 5: same bits, 1 - 2 % slower)
+    int asm_b_by_blocks = 2;          // VIO_ASM_B_MODE: 2 (default since round 6) = one thread per entry a >= b of H, mirror image stored too (same bits as 0, +5 % frames/s); 0 = one thread per entry of H; 1 = H summed by pairs of parameter blocks (round 5: same bits, 1 - 2 % slower)
     int serial_threads = 512;         // ps_serial block size (VIO_SERIAL_THREADS: 512 or 1024).  Round 3: equal speed (36.2 k vs 36.4 k frames/s); the 512-thread
                                       // build has 256 VGPRs per lane and no scratch, the 1024-thread one spills 21 registers since the matrix-core diagonal block
     hipStream_t stream = nullptr;     // = groups[0].stream (returned by vio_get_stream; IMU scatter runs here)
@@ -979,7 +979,7 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
     B.s0 = 0;
     B.ns = 0; B.xcd_nb = 0; B.xcd_n = 8;
     if (getenv("VIO_BE_THREADS")) h->be_threads = std::min(1024, std::max(64, atoi(getenv("VIO_BE_THREADS")) & ~63));
-    if (getenv("VIO_ASM_B_MODE")) h->asm_b_by_blocks = atoi(getenv("VIO_ASM_B_MODE")) != 0 ? 1 : 0;
+    if (getenv("VIO_ASM_B_MODE")) h->asm_b_by_blocks = std::max(0, std::min(2, atoi(getenv("VIO_ASM_B_MODE"))));
     if (getenv("VIO_ASM_B_BLOCKS")) h->ps_asm_b_blocks = std::max(1, std::min(256, atoi(getenv("VIO_ASM_B_BLOCKS"))));
     if (getenv("VIO_EVAL_OCC")) h->eval_occ = atoi(getenv("VIO_EVAL_OCC"));
     if (getenv("VIO_GRAPH")) h->use_graph = atoi(getenv("VIO_GRAPH")) != 0;
