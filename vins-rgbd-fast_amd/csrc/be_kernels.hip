@@ -44,7 +44,9 @@ struct Ctx {
 
 __device__ Ctx make_ctx(const Batch &B, int s) {
     Ctx c;
-    const DevCfg &C = *B.cfg;
+    // (round 6: the dimensions come from the kernel arguments -- as fields of *B.cfg they were one dependent global round trip at the top of every
+    // workgroup of every kernel before the first useful address could be formed)
+    struct { int W, P, LW, NL, NP, NRES, NPRIOR, MX; } C = {B.gW, B.gP, B.gLW, B.gNL, B.gNP, B.gNRES, B.gNPRIOR, B.gMX};
     c.timings = B.timings;
     c.C = B.cfg; c.s = s; c.W = C.W; c.P = C.P; c.LW = C.LW; c.NL = C.NL; c.NLs = C.NL + 8; c.NPR = C.NPRIOR;
     c.be = B.be + s; c.fe = B.fe + s;

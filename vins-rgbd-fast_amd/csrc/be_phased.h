@@ -1307,6 +1307,10 @@ __device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int blk, in
         if (a == oT) return 6 * W + 15;
         return -1;
     };
+    // IMU factors that exist (estimator.cpp:1212-1220 skips pre-integrations longer than 10 s): one lane per factor, then a mask -- looked up per
+    // entry it was two dependent global loads (pre_idx, then sum_dt) in front of every IMU term
+    const bool f_ok = (int)(threadIdx.x & 63) < W && c.C->c.use_imu && !(c.pre[be.pre_idx[min((int)(threadIdx.x & 63), W - 1) + 1]].sum_dt > 10.0);
+    const unsigned imu_ok = (unsigned)__ballot(f_ok);
     const int ntri = P * (P + 1) / 2, total_t = ntri + P + P * (LW - P);   // tri: lower triangle, gradient, zero padding columns
     for (int w = blk * blockDim.x + threadIdx.x; w < (tri ? total_t : total); w += nb_b * blockDim.x) {
         int a, bcol;
@@ -1340,7 +1344,7 @@ __device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int blk, in
             for (int parity = 0; parity < 2; parity++)
                 for (int i = fa - 1; i <= fa; i++) {
                     if (i < 0 || i >= W || (i & 1) != parity) continue;
-                    if (!c.C->c.use_imu || c.pre[be.pre_idx[i + 1]].sum_dt > 10.0) continue;
+                    if (!((imu_ok >> i) & 1u)) continue;
                     const int la = imu_local(a, i);
                     if (la < 0) continue;
                     const int lb = grad ? 30 : imu_local(b, i);

@@ -999,6 +999,7 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
     DA(h->d_stamps, S); DA(h->d_modes, S); DA(h->d_rrel, S * 9); DA(h->d_r9, 16);
     DA(h->d_in_n, S); DA(h->d_in_stamps, S); DA(h->d_in_ids, S * NP); DA(h->d_in_obs, S * NP * 7);
 #undef DA
+    B.gW = h->hc.W; B.gP = h->hc.P; B.gLW = h->hc.LW; B.gNL = h->hc.NL; B.gNP = h->hc.NP; B.gNRES = h->hc.NRES; B.gNPRIOR = h->hc.NPRIOR; B.gMX = h->hc.MX;
     if (rc == VIO_OK && hipMemcpy(B.cfg, &h->hc, sizeof(DevCfg), hipMemcpyHostToDevice) != hipSuccess) { g_err = "cfg upload failed"; rc = VIO_EDEVICE; }
     if (rc == VIO_OK) {
         // group size: VIO_GROUP_SEQS sequences per group (at most 16 groups).  Default: one group.  More groups only pay off when

@@ -233,6 +233,8 @@ struct Batch {
     double *pairblk;                  // [S][npairs][210] packed symmetric 20x20
     unsigned char *ls_scratch;        // ps_ls_kernel: [S][ps_eval_lds_bytes(W)] staging region of the evaluation roles
     double *pairpart;                 // fused kernel: [S][PS_FUSE_MAXPAIRS][PS_FUSE_MAXBLK][210] partial Gram blocks of frame pairs whose residuals span chunks
+    // the dimensions make_ctx needs, as kernel arguments (scalar registers) instead of a dependent load from *cfg at the top of every workgroup
+    int gW, gP, gLW, gNL, gNP, gNRES, gNPRIOR, gMX;
     int fuse;                         // VIO_FUSE (default 1): solves that qualify run ps_evalf_kernel instead of ps_eval + ps_asm_a; value = chunks the grid covers
     int fuse_only;                    // this launch sequence carries no ps_eval / ps_asm_a (every solve of the handle's configuration qualifies)
     double *imu_raw;                  // [S][W][15*31] raw / whitened IMU Jacobians + residual
