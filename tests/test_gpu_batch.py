@@ -172,6 +172,28 @@ def test_mirrored_assembly_of_H_equals_the_entrywise_one(P, monkeypatch, kw):
         assert np.array_equal(alt.window(i).view(np.uint64), ref_w[i].view(np.uint64)), (i, float(np.abs(alt.window(i) - ref_w[i]).max()))
 
 
+@pytest.mark.parametrize("kw", [dict(window_size=12), dict(window_size=20), dict(window_size=12, estimate_extrinsic=1, estimate_td=1),
+                                dict(window_size=20, estimate_extrinsic=1, estimate_td=1)])
+def test_schur_launch_forming_S_itself_equals_the_load_in_ps_serial(P, monkeypatch, kw):
+    """round 6, windows beyond W = 10 (Schur complement in HBM, ps_serial_big): with VIO_FORM_S = 1 (their default) ps_asm_b_schur writes
+    S = Sp (H - U) Sp + mu D^2 itself -- the tiles the landmark rows touch by their Schur block, which sums their entries of H too, the others by the
+    thread that sums the entry -- and ps_serial_big skips its load of H and U.  Same expressions on the same operands: the windows must be the
+    same BITS as with VIO_FORM_S = 0, with the extrinsic / td columns constant and variable (their tiles hold the padding rows beyond P)."""
+    cfg = P.canonical_config(**kw)
+    sc = vio_ct.synth_like(cfg)
+    n = cfg.window_size + 14
+    monkeypatch.setenv("VIO_FORM_S", "0")
+    ref = _drive(P, cfg, sc, [60, 61, 62], n)
+    ref_w = [ref.window(i).copy() for i in range(3)]
+    ref_it = [ref.status(i).iterations_total for i in range(3)]
+    monkeypatch.setenv("VIO_FORM_S", "1")
+    alt = _drive(P, cfg, sc, [60, 61, 62], n)
+    for i in range(3):
+        assert alt.status(i).solver_flag == 1 and alt.status(i).has_prior == 1
+        assert alt.status(i).iterations_total == ref_it[i] and ref_it[i] > 3 * (n - cfg.window_size)
+        assert np.array_equal(alt.window(i).view(np.uint64), ref_w[i].view(np.uint64)), (i, float(np.abs(alt.window(i) - ref_w[i]).max()))
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(estimate_extrinsic=1, estimate_td=1)])
 def test_block_pair_assembly_of_H_equals_the_entrywise_one(P, monkeypatch, kw):
     """round 5: ps_asm_b sums H and the gradient by pairs of parameter blocks (scalar index decisions, mirrored upper triangle) instead of one

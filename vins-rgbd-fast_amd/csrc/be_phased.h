@@ -334,12 +334,12 @@ __device__ __forceinline__ double ps_eval_role(const Batch &B, const int s, cons
 #pragma unroll
                     for (int u = 0; u < MAXJ; u++) if (j0 + u < j1) acc += hv[u] * dxs[j0 + u];
                 } else
-                    for (int j = j0; j < j1; j += 8) {   // larger windows: eight loads in flight per trip
-                        double hv[8];
+                    for (int j = j0; j < j1; j += MAXJ) {   // larger windows: the same batches, several trips (eight loads per trip made 17 dependent round trips of the 136 columns at W = 20: 21 us)
+                        double hv[MAXJ];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) hv[u] = c.prior_H[(size_t)min(j + u, j1 - 1) * n + row];
+                        for (int u = 0; u < MAXJ; u++) hv[u] = c.prior_H[(size_t)min(j + u, j1 - 1) * n + row];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) if (j + u < j1) acc += hv[u] * dxs[j + u];
+                        for (int u = 0; u < MAXJ; u++) if (j + u < j1) acc += hv[u] * dxs[j + u];
                     }
                 pacc[ch * n + row] = acc;
             }
@@ -534,12 +534,12 @@ __device__ __forceinline__ void ps_eval_body(const Batch &B) {
 #pragma unroll
                     for (int u = 0; u < MAXJ; u++) if (j0 + u < j1) acc += hv[u] * dxs[j0 + u];
                 } else
-                    for (int j = j0; j < j1; j += 8) {   // larger windows: eight loads in flight per trip
-                        double hv[8];
+                    for (int j = j0; j < j1; j += MAXJ) {   // larger windows: the same batches, several trips (eight loads per trip made 17 dependent round trips of the 136 columns at W = 20: 21 us)
+                        double hv[MAXJ];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) hv[u] = c.prior_H[(size_t)min(j + u, j1 - 1) * n + row];
+                        for (int u = 0; u < MAXJ; u++) hv[u] = c.prior_H[(size_t)min(j + u, j1 - 1) * n + row];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) if (j + u < j1) acc += hv[u] * dxs[j + u];
+                        for (int u = 0; u < MAXJ; u++) if (j + u < j1) acc += hv[u] * dxs[j + u];
                     }
                 pacc[ch * n + row] = acc;
             }
@@ -1275,16 +1275,21 @@ __global__ __launch_bounds__(256) void ps_evalf_kernel(Batch B) {
 // tri = true (VIO_ASM_B_MODE = 2, round 6): only the entries a >= b are formed (and the gradient); every thread stores its entry and the mirror
 // image.  H's terms are symmetric source by source -- prior_H is stored exactly symmetric, the Gram blocks are read through sym_idx -- and are added
 // in the same order for (a, b) and (b, a), so the mirrored H is the same bits with half the index arithmetic and half the gathers.
-__device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int blk, int nb_b, const bool tri = false) {
-    const SolveSt &st = B.sst[s];
-    if (st.stage != PS_ASM) return;
-    Ctx c = make_ctx(B, s);
-    const BeSeq &be = *c.be;
-    const int W = c.W, W1 = W + 1, P = c.P, LW = c.LW, n = c.NPR;
+// One entry of H (bcol < LW) or of the gradient (bcol == LW): the prior block, the (at most two) IMU Gram blocks that contain both columns, then the
+// frame-pair sums -- the same terms in the same order as assemble().  Shared by ps_asm_b_body and by the Schur tiles that form S themselves
+// (ps_schur_body, B.form_s).  imu_ok: ps_imu_ok_mask.
+__device__ __forceinline__ unsigned ps_imu_ok_mask(const Ctx &c, const BeSeq &be) {
+    // IMU factors that exist (estimator.cpp:1212-1220 skips pre-integrations longer than 10 s): one lane per factor, then a mask -- looked up per
+    // entry it was two dependent global loads (pre_idx, then sum_dt) in front of every IMU term
+    const int W = c.W;
+    const bool f_ok = (int)(threadIdx.x & 63) < W && c.C->c.use_imu && !(c.pre[be.pre_idx[min((int)(threadIdx.x & 63), W - 1) + 1]].sum_dt > 10.0);
+    return (unsigned)__ballot(f_ok);
+}
+__device__ __forceinline__ double ps_h_entry(const Ctx &c, const SolveSt &st, const BeSeq &be, const unsigned imu_ok, const int a, const int bcol) {
+    const int W = c.W, W1 = W + 1, LW = c.LW, n = c.NPR;
     const bool vext = st.vext != 0;
     const double *pb = c.pairblk, *ib = ps_imu_blk(c);
     const int oE = 15 * W1, oT = 15 * W1 + 6;
-    const int total = P * (LW + 1);   // column LW stands for the gradient entry of the row
     // IMU local column of tangent index a in factor i (-1 if absent)
     auto imu_local = [&](int a, int i) -> int {
         if (a < 6 * W1) { const int f = a / 6, d = a - 6 * f; return f == i ? d : (f == i + 1 ? 15 + d : -1); }
@@ -1307,11 +1312,89 @@ __device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int blk, in
         if (a == oT) return 6 * W + 15;
         return -1;
     };
-    // IMU factors that exist (estimator.cpp:1212-1220 skips pre-integrations longer than 10 s): one lane per factor, then a mask -- looked up per
-    // entry it was two dependent global loads (pre_idx, then sum_dt) in front of every IMU term
-    const bool f_ok = (int)(threadIdx.x & 63) < W && c.C->c.use_imu && !(c.pre[be.pre_idx[min((int)(threadIdx.x & 63), W - 1) + 1]].sum_dt > 10.0);
-    const unsigned imu_ok = (unsigned)__ballot(f_ok);
+    const bool grad = bcol == LW;
+    const int b = grad ? -1 : bcol;
+    double v = 0;
+    // prior
+    if (be.has_prior) {
+        // (relocalisation solve: the extrinsic's columns belong to relo_Pose, which the prior knows nothing about)
+        const bool lent_a = st.relo && a >= oE && a < oE + 6, lent_b = st.relo && b >= oE && b < oE + 6;
+        const int pa = lent_a ? -1 : prior_inv(a);
+        if (pa >= 0) {
+            if (grad) v = st.srp[pa];
+            else { const int pb_ = lent_b ? -1 : prior_inv(b); if (pb_ >= 0) v = c.prior_H[pa * n + pb_]; }
+        }
+    }
+    // IMU factors: even ones first, then odd ones (the order assemble() adds them in)
+    if (a < 15 * W1 && (grad || b < 15 * W1)) {
+        const int fa = a < 6 * W1 ? a / 6 : (a - 6 * W1) / 9;
+        for (int parity = 0; parity < 2; parity++)
+            for (int i = fa - 1; i <= fa; i++) {
+                if (i < 0 || i >= W || (i & 1) != parity) continue;
+                if (!((imu_ok >> i) & 1u)) continue;
+                const int la = imu_local(a, i);
+                if (la < 0) continue;
+                const int lb = grad ? 30 : imu_local(b, i);
+                if (lb < 0) continue;
+                v += imu_get(i, la, lb);
+            }
+    }
+    // vision: a (and b) must be a pose column or, when they are variables, an extrinsic / td column
+    const int ra = a < 6 * W1 ? a : ((vext && a >= oE && a < oE + 7) ? 6 * W1 + (a - oE) : -1);
+    const int rb = grad ? 0 : (b < 6 * W1 ? b : ((vext && b >= oE && b < oE + 7) ? 6 * W1 + (b - oE) : -1));
+    if (ra >= 0 && rb >= 0) {
+        const int fa = ra < 6 * W1 ? ra / 6 : -1, fb = grad ? -1 : (rb < 6 * W1 ? rb / 6 : -1);
+        double sacc = 0;
+        if (!grad && fa >= 0 && fb >= 0 && fa != fb) {
+            const int i = min(fa, fb), j = max(fa, fb);
+            sacc = pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(local_of(a, i, j, W), local_of(b, i, j, W))];
+        } else if (fa >= 0 || fb >= 0) {
+            // one term per other frame of the window: all loads issued first (a runtime-bound loop with the load inside waits for
+            // every L2 round trip in turn -- ten of them per entry at W = 10), then summed in the same order
+            const int f = fa >= 0 ? fa : fb;
+            double pv[VIO_MAXW + 1];
+#pragma unroll
+            for (int o = 0; o <= VIO_MAXW; o++) {
+                const bool use = o < W1 && o != f;
+                const int oo = use ? o : (f == 0 ? 1 : 0);     // unused slots read a term that exists (and drop it)
+                const int i = min(f, oo), j = max(f, oo);
+                const int la = local_of(a, i, j, W), lb = grad ? 19 : local_of(b, i, j, W);
+                pv[o] = pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(la, lb)];
+            }
+#pragma unroll
+            for (int o = 0; o <= VIO_MAXW; o++) if (o < W1 && o != f) sacc += pv[o];
+        } else {
+            for (int i = 0; i < W1; i++)
+                for (int j = i + 1; j < W1; j++) {
+                    const int la = local_of(a, i, j, W), lb = grad ? 19 : local_of(b, i, j, W);
+                    sacc += pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(la, lb)];
+                }
+        }
+        v += sacc;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int blk, int nb_b, const bool tri = false) {
+    const SolveSt &st = B.sst[s];
+    if (st.stage != PS_ASM) return;
+    Ctx c = make_ctx(B, s);
+    const BeSeq &be = *c.be;
+    const int W = c.W, W1 = W + 1, P = c.P, LW = c.LW, n = c.NPR;
+    const bool vext = st.vext != 0;
+    const double *pb = c.pairblk, *ib = ps_imu_blk(c);
+    const int oE = 15 * W1, oT = 15 * W1 + 6;
+    const int total = P * (LW + 1);   // column LW stands for the gradient entry of the row
+    const unsigned imu_ok = ps_imu_ok_mask(c, be);
     const int ntri = P * (P + 1) / 2, total_t = ntri + P + P * (LW - P);   // tri: lower triangle, gradient, zero padding columns
+    // B.form_s (round 6, windows whose Schur complement stays in HBM): once the column scaling is fixed, S = Sp (H - U) Sp + mu D^2 is formed HERE,
+    // entry by entry as H is summed, instead of by ps_serial's one workgroup per sequence (its "tile load": 39 of 242 us per iteration at W = 20).
+    // The tiles the landmark rows touch (ps_colmask) belong to their Schur block, which sums their entries of H itself and subtracts U; every
+    // other tile of S is written below.  Same expressions on the same operands as ps_serial's load, hence the same bits.
+    const bool form_s = tri && B.form_s && !st.scale_pending;
+    const unsigned colmask = ps_colmask(W1, LW, vext);
+    const double mu = st.mu;
+    const double *spv = c.vec + LW;
     for (int w = blk * blockDim.x + threadIdx.x; w < (tri ? total_t : total); w += nb_b * blockDim.x) {
         int a, bcol;
         if (tri) {
@@ -1327,68 +1410,24 @@ __device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int blk, in
         const bool grad = bcol == LW;
         const int b = grad ? -1 : bcol;
         if (!grad && b >= P) { c.H[(size_t)a * LW + b] = 0; continue; }
-        double v = 0;
-        // prior
-        if (be.has_prior) {
-            // (relocalisation solve: the extrinsic's columns belong to relo_Pose, which the prior knows nothing about)
-            const bool lent_a = st.relo && a >= oE && a < oE + 6, lent_b = st.relo && b >= oE && b < oE + 6;
-            const int pa = lent_a ? -1 : prior_inv(a);
-            if (pa >= 0) {
-                if (grad) v = st.srp[pa];
-                else { const int pb_ = lent_b ? -1 : prior_inv(b); if (pb_ >= 0) v = c.prior_H[pa * n + pb_]; }
-            }
-        }
-        // IMU factors: even ones first, then odd ones (the order assemble() adds them in)
-        if (a < 15 * W1 && (grad || b < 15 * W1)) {
-            const int fa = a < 6 * W1 ? a / 6 : (a - 6 * W1) / 9;
-            for (int parity = 0; parity < 2; parity++)
-                for (int i = fa - 1; i <= fa; i++) {
-                    if (i < 0 || i >= W || (i & 1) != parity) continue;
-                    if (!((imu_ok >> i) & 1u)) continue;
-                    const int la = imu_local(a, i);
-                    if (la < 0) continue;
-                    const int lb = grad ? 30 : imu_local(b, i);
-                    if (lb < 0) continue;
-                    v += imu_get(i, la, lb);
-                }
-        }
-        // vision: a (and b) must be a pose column or, when they are variables, an extrinsic / td column
-        const int ra = a < 6 * W1 ? a : ((vext && a >= oE && a < oE + 7) ? 6 * W1 + (a - oE) : -1);
-        const int rb = grad ? 0 : (b < 6 * W1 ? b : ((vext && b >= oE && b < oE + 7) ? 6 * W1 + (b - oE) : -1));
-        if (ra >= 0 && rb >= 0) {
-            const int fa = ra < 6 * W1 ? ra / 6 : -1, fb = grad ? -1 : (rb < 6 * W1 ? rb / 6 : -1);
-            double sacc = 0;
-            if (!grad && fa >= 0 && fb >= 0 && fa != fb) {
-                const int i = min(fa, fb), j = max(fa, fb);
-                sacc = pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(local_of(a, i, j, W), local_of(b, i, j, W))];
-            } else if (fa >= 0 || fb >= 0) {
-                // one term per other frame of the window: all loads issued first (a runtime-bound loop with the load inside waits for
-                // every L2 round trip in turn -- ten of them per entry at W = 10), then summed in the same order
-                const int f = fa >= 0 ? fa : fb;
-                double pv[VIO_MAXW + 1];
-#pragma unroll
-                for (int o = 0; o <= VIO_MAXW; o++) {
-                    const bool use = o < W1 && o != f;
-                    const int oo = use ? o : (f == 0 ? 1 : 0);     // unused slots read a term that exists (and drop it)
-                    const int i = min(f, oo), j = max(f, oo);
-                    const int la = local_of(a, i, j, W), lb = grad ? 19 : local_of(b, i, j, W);
-                    pv[o] = pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(la, lb)];
-                }
-#pragma unroll
-                for (int o = 0; o <= VIO_MAXW; o++) if (o < W1 && o != f) sacc += pv[o];
-            } else {
-                for (int i = 0; i < W1; i++)
-                    for (int j = i + 1; j < W1; j++) {
-                        const int la = local_of(a, i, j, W), lb = grad ? 19 : local_of(b, i, j, W);
-                        sacc += pb[(size_t)pair_slot(i, j, W1) * 210 + sym_idx(la, lb)];
-                    }
-            }
-            v += sacc;
-        }
+        const int ti = a >> 4, tj = b >> 4;
+        if (form_s && !grad && ((colmask >> ti) & 1u) && ((colmask >> tj) & 1u)) continue;   // (its Schur block's)
+        const double v = ps_h_entry(c, st, be, imu_ok, a, bcol);
         if (grad) c.vec[a] = v;
         else {
             c.H[(size_t)a * LW + b] = v;
             if (tri && a != b) c.H[(size_t)b * LW + a] = v;
+            if (form_s) {
+                const double sa = spv[a], sb = spv[b];
+                double sv = sa * sb * (v - 0.0);
+                if (a == b) {
+                    const double hs = sa * sa * v, dg = sqrt(fmin(fmax(hs, 1e-6), 1e32));
+                    sv += mu * dg * dg;
+                    if (sa == 0.0) sv = 1.0;
+                }
+                c.Sc[tl_idx(ti, tj, a & 15, b & 15)] = sv;
+                if (ti == tj && a != b) c.Sc[tl_idx(ti, ti, b & 15, a & 15)] = sv;
+            }
             if (a == b && st.scale_pending) {
                 bool act = a < oE ? true : (a < oT ? st.ex_active != 0 : st.td_active != 0);
                 if (!c.C->c.use_imu && (a < 6 || a >= 6 * W1)) act = false;   // VO mode: pose 0 constant, no speed-bias blocks
@@ -1399,6 +1438,15 @@ __device__ __forceinline__ void ps_asm_b_body(const Batch &B, int s, int blk, in
     // padding of g / sp beyond P and the landmark scaling
     if (blk == 0) {
         for (int a = P + threadIdx.x; a < LW; a += blockDim.x) { c.vec[a] = 0; if (st.scale_pending) c.vec[1 * LW + a] = 0; }
+        if (form_s && P < LW) {
+            // rows / columns P .. LW - 1 of the last row of tiles: unit diagonal, zeros elsewhere (what ps_serial's load makes of sp = 0)
+            const int nbt = LW >> 4, tl = nbt - 1;
+            for (int q = threadIdx.x; q < nbt * 256; q += blockDim.x) {
+                const int tj = q >> 8, r = (q >> 4) & 15, cc = q & 15, row = 16 * tl + r, col = 16 * tj + cc;
+                if ((row < P && col < P) || (((colmask >> tl) & 1u) && ((colmask >> tj) & 1u))) continue;
+                c.Sc[tl_idx(tl, tj, r, cc)] = row == col ? 1.0 : 0.0;
+            }
+        }
     }
 }
 
@@ -1548,6 +1596,19 @@ __device__ __forceinline__ void ps_schur_body(const Batch &B, int s, int tile_in
     const bool first = st.scale_pending != 0;
     v4f64 acc = {0, 0, 0, 0};
     const double *wa = Ws + 16 * ti + li, *wb = Ws + 16 * tj + li;
+    // B.form_s: this block also sums its tile's entries of H (one per thread; ps_asm_b_body skips them) and stores S instead of U -- see
+    // ps_asm_b_body.  The gathers are issued ahead of the landmark-row walk below.
+    const bool form_s = B.form_s && st.stage == PS_ASM && !first;
+    double *hbuf = wk_s + ((Kpad + 7) & ~7) + 3 * 256;
+    if (form_s) {
+        const BeSeq &be = *c.be;
+        const unsigned imu_ok = ps_imu_ok_mask(c, be);
+        const int r = t >> 4, cc = t & 15, row = 16 * ti + r, col = 16 * tj + cc, P = c.P;
+        const int a = max(row, col), b = min(row, col);
+        const double h = a < P ? ps_h_entry(c, st, be, imu_ok, a, b) : 0.0;
+        hbuf[t] = h;
+        if (a < P) { c.H[(size_t)row * LW + col] = h; if (ti != tj) c.H[(size_t)col * LW + row] = h; }
+    }
     // per-row factor sl^2 / (sl^2 Hll + mu dgl^2), sl = 1 / (1 + sqrt(Hll)) at the first linearisation: once per row into LDS (a square
     // root and two divisions each), not once per lane and trip
     for (int kc = t; kc < Kpad; kc += blockDim.x) {
@@ -1584,6 +1645,21 @@ __device__ __forceinline__ void ps_schur_body(const Batch &B, int s, int tile_in
     if (wave == 0) {
         for (int w = 1; w < nw; w++)
             for (int r = 0; r < 4; r++) acc[r] += part[(w - 1) * 256 + r * 64 + lane];
+        if (form_s) {
+            const double *spv = c.vec + LW;
+            const double sc = spv[16 * tj + li];
+            for (int r = 0; r < 4; r++) {
+                const int rl = lk + 4 * r, row = 16 * ti + rl, col = 16 * tj + li;
+                const double sr = spv[row], h = hbuf[rl * 16 + li];
+                double sv = sr * sc * (h - acc[r]);
+                if (row == col) {
+                    const double hs = sr * sr * h, dg = sqrt(fmin(fmax(hs, 1e-6), 1e32));
+                    sv += mu * dg * dg;
+                    if (sr == 0.0) sv = 1.0;
+                }
+                acc[r] = sv;
+            }
+        }
         for (int r = 0; r < 4; r++) c.Sc[tl_idx(ti, tj, lk + 4 * r, li)] = acc[r];
     }
 }
@@ -1635,6 +1711,8 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
     double *hsgl = c.res + (size_t)c.nres_cap * 42 - 4 * (size_t)c.NLs;
     double *yl = hsgl + c.NLs, *ul = yl + c.NLs, *tmpl = ul + c.NLs;
     const int stage0 = st.stage;
+    // (B.form_s: ps_asm_b_schur has left S itself in c.Sc -- whenever it ran at PS_ASM with the column scaling already fixed)
+    const bool s_formed = BIG && B.form_s && stage0 == PS_ASM && st.scale_pending == 0;
     double radius = st.radius, mu = st.mu, alpha = st.alpha, dogleg_norm = st.dogleg_norm;
     bool cauchy_valid = st.cauchy_valid != 0;
     int invalid = st.invalid;
@@ -1703,7 +1781,7 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
         // streams it through LDS one block column at a time (chol_tiles_stream)
         constexpr bool big = BIG;
         double *Stiles = big ? c.Sc : work;
-        {
+        if (!s_formed) {
             const unsigned colmask = ps_colmask(W1, LW, st.vext != 0);
             const int nb = LW >> 4, ntile = nb * (nb + 1) / 2;
             // thread = the element pair (r, c2), (r, c2 + 1) of every (nt / 128)-th tile, TB tiles per trip: 16-byte loads of H (row-major) and

@@ -690,7 +690,7 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
                     if (h->asm_a_occ4) ps_asm_a_kernel_occ4<<<g_a, 512, 0, st>>>(Ba);
                     else ps_asm_a_kernel<<<g_a, 512, 0, st>>>(Ba);
                 }
-                ps_asm_b_schur_kernel<<<g_b, 256, (size_t)(C.NL + 16 + 3 * 256) * sizeof(double), st>>>(Bb, h->ps_asm_b_blocks, h->asm_b_by_blocks);   // per-row factors + the partial tiles of wavefronts 1 .. 3
+                ps_asm_b_schur_kernel<<<g_b, 256, (size_t)(C.NL + 16 + 4 * 256) * sizeof(double), st>>>(Bb, h->ps_asm_b_blocks, h->asm_b_by_blocks);   // per-row factors + the partial tiles of wavefronts 1 .. 3 + the tile of H (form_s)
                 if (h->serial_big) ps_serial_big_kernel<<<S, 512, h->lds_serial, st>>>(Bg);
                 else ps_serial_kernel_512<<<S, 512, h->lds_serial, st>>>(Bg);
                 // Ceres' projected line search of bounds-constrained solves (one workgroup per sequence, idle otherwise); the candidate of the
@@ -1056,6 +1056,8 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
                 const size_t nb = (size_t)C.LW >> 4, tiles = nb * (nb + 1) / 2 * 256;
                 const size_t wk = std::max(tiles <= 16896 ? tiles : (2 * nb + 1) * 256, (size_t)16 * 336);   // (streaming: two block columns + the look-ahead tile, chol_tiles_stream)
                 h->serial_big = tiles > 16896;
+                // the Schur-complement launch leaves S itself behind (ps_asm_b_body): default on where ps_serial's load of H and U is the slow one
+                h->B.form_s = (getenv("VIO_FORM_S") ? atoi(getenv("VIO_FORM_S")) != 0 : h->serial_big) && h->serial_big && h->asm_b_by_blocks == 2;
                 h->lds_serial = ((size_t)C.LW + 2 + wk + 2 + (size_t)14 /* PS_LVEC */ * C.LW) * 8 + 16;   // + the step's vectors (be_phased.h)
                 if (getenv("VIO_SERIAL_LDS") && (size_t)atol(getenv("VIO_SERIAL_LDS")) > h->lds_serial) h->lds_serial = (size_t)atol(getenv("VIO_SERIAL_LDS"));   // experiment: a larger request keeps other workgroups off the CU
                 (void)raise_lds_limit(h->serial_big ? (const void *)ps_serial_big_kernel : (const void *)ps_serial_kernel_512, h->lds_serial);
