@@ -12,7 +12,7 @@ out=open('gpurun_out/c5_stats.txt','w')
 for r in rows[:25]:
     out.write("%-60s calls %6s avg %10.1f us total %8.1f ms pct %s\n"%(r['Name'][:60],r['Calls'],float(r['AverageNs'])/1e3,float(r['TotalDurationNs'])/1e6,r['Percentage']))
 PY
-python tools/trace_chain.py $(ls gpurun_out/c5prof/*/*kernel_trace.csv gpurun_out/c5prof/*kernel_trace.csv 2>/dev/null | head -1) 3 > gpurun_out/c5_chain.txt 2>&1
+python tools/trace_chain.py $(ls gpurun_out/c5prof/*/*kernel_trace.csv gpurun_out/c5prof/*kernel_trace.csv 2>/dev/null | head -1) 3 -v > gpurun_out/c5_chain.txt 2>&1
 rm -rf gpurun_out/c5prof
 cat gpurun_out/c5_chain.txt
 tail -3 gpurun_out/c5_rate.txt; cat gpurun_out/c5_stats.txt

@@ -2350,9 +2350,18 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
     // prior
     if (be.has_prior) {
         prior_dx(c, X, sdx);
-        for (int i = t; i < n; i += nt) {  // prior gradient at the current state: b + A dx
+        // (round 6: the loops of this kernel that walked HBM one dependent load at a time -- a load behind a store the compiler must assume to
+        //  alias, or a runtime-bound loop with the load inside -- now issue their loads in batches; same terms in the same order, same bits.
+        //  At W = 20 the kernel took 1.1 ms, none of its phases more than 0.2.)
+        for (int i = t; i < n; i += nt) {  // prior gradient at the current state: b + A dx (A is stored exactly symmetric: read by columns, coalesced)
             double sacc = c.prior_r[i];
-            for (int j = 0; j < n; j++) sacc += c.prior_H[i * n + j] * sdx[j];
+            for (int j0 = 0; j0 < n; j0 += 32) {
+                double hv[32];
+#pragma unroll
+                for (int u = 0; u < 32; u++) hv[u] = c.prior_H[(size_t)min(j0 + u, n - 1) * n + i];
+#pragma unroll
+                for (int u = 0; u < 32; u++) if (j0 + u < n) sacc += hv[u] * sdx[j0 + u];
+            }
             srp[i] = sacc;
         }
         __syncthreads();
@@ -2366,9 +2375,15 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
             if (a < 6 * W + 15) return rE + (a - 6 * W - 9);
             return rT;
         };
-        for (int w = t; w < n * n; w += nt) {  // J^T J of the prior is kept next to J (prior_H, written when the prior was built)
-            int a = w / n, bb = w - a * n;
-            A[pmap(a) * mq + pmap(bb)] += c.prior_H[w];
+        for (int w0 = t; w0 < n * n; w0 += 8 * nt) {  // J^T J of the prior is kept next to J (prior_H, written when the prior was built); A is still zero here
+            double pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) pv[u] = c.prior_H[min(w0 + u * nt, n * n - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int w = w0 + u * nt;
+                if (w < n * n) { const int a = w / n, bb = w - a * n; A[pmap(a) * mq + pmap(bb)] = 0.0 + pv[u]; }
+            }
         }
         for (int a = t; a < n; a += nt) b[pmap(a)] += srp[a];
         if (t < W + 3) {
@@ -2487,7 +2502,10 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
 #pragma unroll
                 for (int q = 0; q < 13; q++) cm[q] = 0;
                 for (int k = gln + 1; k < no; k += 16) {
-                    const double *Jr = c.res + (size_t)(li * per + k - 1) * 42;
+                    const double *Jg = c.res + (size_t)(li * per + k - 1) * 42;
+                    double Jr[42];   // the whole record first: the stores to Cl below would otherwise sit between its loads
+#pragma unroll
+                    for (int q = 0; q < 42; q++) Jr[q] = Jg[q];
                     const double jl0 = Jr[19], jl1 = Jr[39];
 #pragma unroll
                     for (int q = 0; q < 6; q++) {
@@ -2524,10 +2542,10 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
             for (int j = 1 + wave; j <= W; j += nw) {
                 v4f64 a00 = {0, 0, 0, 0}, a10 = {0, 0, 0, 0}, a11 = {0, 0, 0, 0};
                 const int K = 2 * F0c;
-                for (int k0 = 0; k0 < K; k0 += 16) {
-                    double x0[4], x1[4];
+                for (int k0 = 0; k0 < K; k0 += 64) {   // four 16-row trips' loads in flight at once, the matrix-core steps in the order of the one-trip loop
+                    double x0[16], x1[16];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < 16; u++) {
                         int kk = k0 + 4 * u + lk;
                         bool valid = kk < K;
                         int lm = min(kk, K - 1) >> 1, sub = kk & 1;
@@ -2538,7 +2556,8 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
                         x1[u] = (valid && li < 4) ? v1 : 0.0;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < 16; u++) {
+                        if (k0 + 16 * (u >> 2) >= K) break;
                         a00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[u], x0[u], a00, 0, 0, 0);
                         a10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x0[u], a10, 0, 0, 0);
                         a11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1[u], x1[u], a11, 0, 0, 0);
@@ -2578,19 +2597,39 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
             sub_part[ch][a] = acc;
         }
         __syncthreads();
-        for (int w = t; w < mq * (mq + 1); w += nt) {
-            const int a = w / (mq + 1), bb = w - a * (mq + 1);
-            const int fa = qfr[a], fb = qfr[bb];
-            if (fa < 0 || fb < 0) continue;
-            const int la = qlc[a], lb = qlc[bb];
-            double sacc = 0;
-            if (fa > 0 || fb > 0) {
-                if (fa > 0 && fb > 0 && fa != fb) continue;
-                sacc = c.pairblk[(size_t)((fa > 0 ? fa : fb) - 1) * 210 + sym_idx(la, lb)];
-            } else
-                for (int j = 1; j <= W; j++) sacc += c.pairblk[(size_t)(j - 1) * 210 + sym_idx(la, lb)];
-            if (bb < mq) A[a * mq + bb] += sacc;
-            else b[a] += sacc - ((sub_part[0][a] + sub_part[1][a]) + (sub_part[2][a] + sub_part[3][a]));
+        for (int w0 = t; w0 < mq * (mq + 1); w0 += 4 * nt) {   // four entries per thread and trip: their gathers and the entries of A they add to in flight together
+            bool use[4], multi[4], rhs[4];
+            int dst[4], row[4], sidx[4];
+            double pv[4], av[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int w = min(w0 + u * nt, mq * (mq + 1) - 1);
+                const int a = w / (mq + 1), bb = w - a * (mq + 1);
+                const int fa = qfr[a], fb = qfr[bb];
+                const int la = qlc[a], lb = qlc[bb];
+                use[u] = w0 + u * nt < mq * (mq + 1) && fa >= 0 && fb >= 0 && !(fa > 0 && fb > 0 && fa != fb);
+                multi[u] = use[u] && fa == 0 && fb == 0;
+                rhs[u] = bb == mq; row[u] = a; dst[u] = a * mq + bb;
+                sidx[u] = sym_idx(la, lb);
+                const int f1 = fa > 0 ? fa : (fb > 0 ? fb : 1);
+                pv[u] = use[u] ? c.pairblk[(size_t)(f1 - 1) * 210 + sidx[u]] : 0.0;
+                av[u] = use[u] ? (rhs[u] ? b[a] : A[dst[u]]) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (!use[u]) continue;
+                double sacc = pv[u];
+                if (multi[u]) {   // a column every residual carries against another such: one term per frame, all loads first
+                    double fv[VIO_MAXW];
+#pragma unroll
+                    for (int j = 0; j < VIO_MAXW; j++) fv[j] = c.pairblk[(size_t)min(j, W - 1) * 210 + sidx[u]];
+                    sacc = 0;
+#pragma unroll
+                    for (int j = 0; j < VIO_MAXW; j++) if (j < W) sacc += fv[j];
+                }
+                if (!rhs[u]) A[dst[u]] = av[u] + sacc;
+                else b[row[u]] = av[u] + (sacc - ((sub_part[0][row[u]] + sub_part[1][row[u]]) + (sub_part[2][row[u]] + sub_part[3][row[u]])));
+            }
         }
         __syncthreads();
         PH(25);
@@ -2603,10 +2642,10 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
                 tri_decode(tile, ti, tj);
                 v4f64 acc = {0, 0, 0, 0};
                 const int ca = min(16 * ti + li, ldc - 1), cb = min(16 * tj + li, ldc - 1);
-                for (int k0 = 0; k0 < F0c; k0 += 16) {
-                    double xa[4], xb[4];
+                for (int k0 = 0; k0 < F0c; k0 += 64) {   // (four trips' loads in flight, as above)
+                    double xa[16], xb[16];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
+                    for (int u = 0; u < 16; u++) {
                         int kk = k0 + 4 * u + lk;
                         bool valid = kk < F0c;
                         int kc = min(kk, F0c - 1);
@@ -2615,7 +2654,10 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
                         xb[u] = valid ? vb : 0.0;
                     }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], xb[u], acc, 0, 0, 0);
+                    for (int u = 0; u < 16; u++) {
+                        if (k0 + 16 * (u >> 2) >= F0c) break;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[u], xb[u], acc, 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
@@ -2679,11 +2721,19 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
     PH(37);
     double *Ar = c.margV;             // reuse as A_r first (n x n), eigenvectors go to margW+...
     double *br = c.vec;               // n
-    for (int w = t; w < n * n; w += nt) {
-        int i = w / n, j = w - i * n;
-        double tt = A[(md + i) * mq + md + j];
-        for (int k = 0; k < md; k++) tt -= T1[i * md + k] * Amr[k * n + j];
-        Ar[w] = tt;
+    for (int w0 = t; w0 < n * n; w0 += 8 * nt) {
+        double av[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int w = min(w0 + u * nt, n * n - 1), i = w / n, j = w - i * n; av[u] = A[(md + i) * mq + md + j]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int w = w0 + u * nt;
+            if (w >= n * n) break;
+            const int i = w / n, j = w - i * n;
+            double tt = av[u];
+            for (int k = 0; k < md; k++) tt -= T1[i * md + k] * Amr[k * n + j];
+            Ar[w] = tt;
+        }
     }
     for (int i = t; i < n; i += nt) {
         double sacc = b[md + i];
@@ -2737,7 +2787,13 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
     // they equal (A, b, c0) up to the dropped directions: measured on the canonical workload b has a 1e-12 relative component
     // there, A changes by < 1e-8 absolute (1e-16 relative) and the weakly observed directions contribute < 1e-5 of c0
     // (DESIGN.md deviation 13).  The factored form is produced on demand by be_prior_factor_kernel (vio_get_prior).
-    for (int w = t; w < n * n; w += nt) { int i = w / n, j = w - i * n; c.prior_H[w] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
+    for (int w0 = t; w0 < n * n; w0 += 8 * nt) {
+        double x[8], y[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int w = min(w0 + u * nt, n * n - 1), i = w / n, j = w - i * n; x[u] = Ar[i * n + j]; y[u] = Ar[j * n + i]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (w0 + u * nt < n * n) c.prior_H[w0 + u * nt] = 0.5 * (x[u] + y[u]);
+    }
     for (int i = t; i < n; i += nt) c.prior_r[i] = br[i];
     PH(38);
     {
@@ -2751,12 +2807,25 @@ template <bool EXACT> __device__ void marg_body(const Batch &B, int s, int *scra
         for (int i = t; i < n; i += nt) dmax = fmax(dmax, fabs(Ar[i * n + i]));
         dmax = block_max(dmax, sred);
         const double delta = 64.0 * 2.220446049250313e-16 * (double)n * dmax;
-        for (int w = t; w < nbq * (nbq + 1) / 2 * 256; w += nt) {
-            int tile = w >> 8, e = w & 255, r = e >> 4, cc = e & 15, ti, tj;
-            tri_decode(tile, ti, tj);
-            int i = 16 * ti + r, j = 16 * tj + cc;
-            double v = (i < n && j < n) ? 0.5 * (Ar[i * n + j] + Ar[j * n + i]) + (i == j ? delta : 0.0) : (i == j ? 1.0 : 0.0);
-            T[tl_idx(ti, tj, r, cc)] = v;
+        const int ntl = nbq * (nbq + 1) / 2 * 256;
+        for (int w0 = t; w0 < ntl; w0 += 4 * nt) {
+            double x[4], y[4];
+            int ii[4], jj[4], dd[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int w = min(w0 + u * nt, ntl - 1);
+                int tile = w >> 8, e = w & 255, r = e >> 4, cc = e & 15, ti, tj;
+                tri_decode(tile, ti, tj);
+                const int i = 16 * ti + r, j = 16 * tj + cc, ic = min(i, n - 1), jc = min(j, n - 1);
+                ii[u] = i; jj[u] = j; dd[u] = tl_idx(ti, tj, r, cc);
+                x[u] = Ar[ic * n + jc]; y[u] = Ar[jc * n + ic];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (w0 + u * nt >= ntl) break;
+                const int i = ii[u], j = jj[u];
+                T[dd[u]] = (i < n && j < n) ? 0.5 * (x[u] + y[u]) + (i == j ? delta : 0.0) : (i == j ? 1.0 : 0.0);
+            }
         }
         for (int i = t; i < 16 * nbq; i += nt) cq_x[i] = i < n ? br[i] : 0.0;
         __syncthreads();
