@@ -172,12 +172,13 @@ def test_mirrored_assembly_of_H_equals_the_entrywise_one(P, monkeypatch, kw):
         assert np.array_equal(alt.window(i).view(np.uint64), ref_w[i].view(np.uint64)), (i, float(np.abs(alt.window(i) - ref_w[i]).max()))
 
 
-@pytest.mark.parametrize("kw", [dict(window_size=12), dict(window_size=20), dict(window_size=12, estimate_extrinsic=1, estimate_td=1),
-                                dict(window_size=20, estimate_extrinsic=1, estimate_td=1)])
+@pytest.mark.parametrize("kw", [dict(), dict(estimate_extrinsic=1, estimate_td=1), dict(window_size=12), dict(window_size=20),
+                                dict(window_size=12, estimate_extrinsic=1, estimate_td=1), dict(window_size=20, estimate_extrinsic=1, estimate_td=1)])
 def test_schur_launch_forming_S_itself_equals_the_load_in_ps_serial(P, monkeypatch, kw):
-    """round 6, windows beyond W = 10 (Schur complement in HBM, ps_serial_big): with VIO_FORM_S = 1 (their default) ps_asm_b_schur writes
+    """round 6: with VIO_FORM_S = 1 (the default) ps_asm_b_schur writes
     S = Sp (H - U) Sp + mu D^2 itself -- the tiles the landmark rows touch by their Schur block, which sums their entries of H too, the others by the
-    thread that sums the entry -- and ps_serial_big skips its load of H and U.  Same expressions on the same operands: the windows must be the
+    thread that sums the entry -- and ps_serial only copies the tiles into LDS (W <= 10) or, with the Schur complement in HBM (ps_serial_big,
+    larger windows), skips its load of H and U altogether.  Same expressions on the same operands: the windows must be the
     same BITS as with VIO_FORM_S = 0, with the extrinsic / td columns constant and variable (their tiles hold the padding rows beyond P)."""
     cfg = P.canonical_config(**kw)
     sc = vio_ct.synth_like(cfg)

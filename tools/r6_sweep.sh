@@ -3,5 +3,8 @@
 run() { env "$@" python bench.py --seqs ${SEQS:-128} --steps 20 --warmup 5 --repeats ${REP:-10} --aux 0 --cpu-seqs 0 --cpu-procs 0 --pcie-steps 0 --stream-steps 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('S=${SEQS:-128}', '$*', round(d['value']), d.get('valid'), round(d['solver']['mean_iterations'],2))" >> gpurun_out/sweep.txt; }
 rm -f gpurun_out/sweep.txt
 run A=base
+run VIO_FORM_S=1
 run A=base2
+run VIO_FORM_S=1
 SEQS=512 REP=5 run A=base
+SEQS=512 REP=5 run VIO_FORM_S=1

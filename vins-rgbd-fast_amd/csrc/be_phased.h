@@ -1712,7 +1712,7 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
     double *yl = hsgl + c.NLs, *ul = yl + c.NLs, *tmpl = ul + c.NLs;
     const int stage0 = st.stage;
     // (B.form_s: ps_asm_b_schur has left S itself in c.Sc -- whenever it ran at PS_ASM with the column scaling already fixed)
-    const bool s_formed = BIG && B.form_s && stage0 == PS_ASM && st.scale_pending == 0;
+    const bool s_formed = B.form_s && stage0 == PS_ASM && st.scale_pending == 0;
     double radius = st.radius, mu = st.mu, alpha = st.alpha, dogleg_norm = st.dogleg_norm;
     bool cauchy_valid = st.cauchy_valid != 0;
     int invalid = st.invalid;
@@ -1781,7 +1781,22 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
         // streams it through LDS one block column at a time (chol_tiles_stream)
         constexpr bool big = BIG;
         double *Stiles = big ? c.Sc : work;
-        if (!s_formed) {
+        if (s_formed) {
+            // S is in c.Sc already (tile layout): the LDS-resident Cholesky only needs it copied, 16 bytes per load, eight loads in flight per thread
+            if (!big) {
+                const int nd2 = (LW >> 4) * ((LW >> 4) + 1) / 2 * 128;   // double2 elements
+                const double2 *src = (const double2 *)c.Sc;
+                double2 *dst = (double2 *)work;
+                for (int i0 = t; i0 < nd2; i0 += 8 * nt) {
+                    double2 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) v[u] = src[min(i0 + u * nt, nd2 - 1)];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) if (i0 + u * nt < nd2) dst[i0 + u * nt] = v[u];
+                }
+                __syncthreads();
+            }
+        } else {
             const unsigned colmask = ps_colmask(W1, LW, st.vext != 0);
             const int nb = LW >> 4, ntile = nb * (nb + 1) / 2;
             // thread = the element pair (r, c2), (r, c2 + 1) of every (nt / 128)-th tile, TB tiles per trip: 16-byte loads of H (row-major) and

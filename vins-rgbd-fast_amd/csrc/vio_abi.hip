@@ -1056,8 +1056,9 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
                 const size_t nb = (size_t)C.LW >> 4, tiles = nb * (nb + 1) / 2 * 256;
                 const size_t wk = std::max(tiles <= 16896 ? tiles : (2 * nb + 1) * 256, (size_t)16 * 336);   // (streaming: two block columns + the look-ahead tile, chol_tiles_stream)
                 h->serial_big = tiles > 16896;
-                // the Schur-complement launch leaves S itself behind (ps_asm_b_body): default on where ps_serial's load of H and U is the slow one
-                h->B.form_s = (getenv("VIO_FORM_S") ? atoi(getenv("VIO_FORM_S")) != 0 : h->serial_big) && h->serial_big && h->asm_b_by_blocks == 2;
+                // the Schur-complement launch leaves S itself behind (ps_asm_b_body; VIO_FORM_S = 0: ps_serial combines H, U, Sp and mu D^2 as in rounds 2 - 5).
+                // W = 20: ps_serial_big 242 -> 213 us per iteration; W = 10: +0.6 % frames/s at 128 sequences, -0.5 % at 512
+                h->B.form_s = (getenv("VIO_FORM_S") ? atoi(getenv("VIO_FORM_S")) != 0 : true) && h->asm_b_by_blocks == 2;
                 h->lds_serial = ((size_t)C.LW + 2 + wk + 2 + (size_t)14 /* PS_LVEC */ * C.LW) * 8 + 16;   // + the step's vectors (be_phased.h)
                 if (getenv("VIO_SERIAL_LDS") && (size_t)atol(getenv("VIO_SERIAL_LDS")) > h->lds_serial) h->lds_serial = (size_t)atol(getenv("VIO_SERIAL_LDS"));   // experiment: a larger request keeps other workgroups off the CU
                 (void)raise_lds_limit(h->serial_big ? (const void *)ps_serial_big_kernel : (const void *)ps_serial_kernel_512, h->lds_serial);
