@@ -28,6 +28,9 @@ NAMES = {0: "vector2double", 1: "lm indexing", 2: "pair lists", 4: "evaluate(fir
          32: "asm_a pair (0,1) item", 33: "asm_a pair (0,W) item", 34: "asm_a imu item 0", 35: "asm_a landmark rows item 0", 36: "asm element sums", 37: "asm lm rows",
          36: "  marg 21a: 15x15 inverse", 37: "  marg 21b: T1 / Amr staging", 38: "  marg 22a: prior_H / prior_r stores", 39: "  marg 22b: tile fill",
          45: "  eval b0: X to LDS", 40: "  eval b0: prior dx", 44: "  eval b0: A dx partials", 46: "  eval b1: X + headers to LDS",
+         100: "setup: init extras + vector2double", 101: "setup: landmark indexing (2 scans)", 102: "setup: relo + residual list", 103: "setup: pair counts",
+         104: "setup: pair lists", 106: "ingest: hash + matching", 107: "ingest: new landmarks", 108: "ingest: parallax", 109: "ingest: IMU pre-integration",
+         110: "ingest: triangulate", 111: "  imu: interval + load", 112: "  imu: stage + state recursions", 113: "  imu: F / V of the samples", 114: "  imu: J / P recursion",
          # front-end (fe_kernels.hip FE_PH markers)
          64: "select load + status cull", 65: "select lift (F input)", 66: "  ransac 7-point hypotheses", 67: "  ransac inlier counts", 68: "  ransac serial best/iters",
          69: "  ransac final inliers", 70: "select F compaction", 71: "select rank sort", 72: "select greedy setMask", 73: "select counts + stores",

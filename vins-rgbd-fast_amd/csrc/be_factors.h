@@ -96,13 +96,15 @@ DM_HD void preint_state_step(quat &delta_q, v3 &delta_p, v3 &delta_v, v3 acc_0, 
     delta_v = add(delta_v, scl(dt, un_acc));
     delta_q = qnormalized(rq);
 }
-DM_HD void preint_step_FV(const PreintPre &s, v3 lba, v3 lbg, double dt, v3 acc_1, v3 gyr_1, double *F, double *V) {
+DM_HD void preint_step_FV(const PreintPre &s, v3 lba, v3 lbg, double dt, v3 acc_1, v3 gyr_1, double *F, double *V, const bool zero = true) {
     const quat delta_q = s.dq;
     const v3 acc_0 = s.acc0, gyr_0 = s.gyr0;
     v3 un_gyr = sub(scl(0.5, add(gyr_0, gyr_1)), lbg);
     quat rq = qmul(delta_q, mkq(1, un_gyr.x * dt / 2, un_gyr.y * dt / 2, un_gyr.z * dt / 2));
-    for (int i = 0; i < 225; i++) F[i] = 0;
-    for (int i = 0; i < 270; i++) V[i] = 0;
+    if (zero) {   // (be_ingest clears the matrices with all its threads beforehand: 495 stores of one lane otherwise)
+        for (int i = 0; i < 225; i++) F[i] = 0;
+        for (int i = 0; i < 270; i++) V[i] = 0;
+    }
     m3 R_w_x = skew(un_gyr), R_a_0_x = skew(sub(acc_0, lba)), R_a_1_x = skew(sub(acc_1, lba));
     m3 Rq = q2R(delta_q), Rr = q2R(rq), I = eye();
     m3 ImW = sub(I, scl(dt, R_w_x));

@@ -581,6 +581,7 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
     __shared__ int scratch[2 * 256 + 8];
     __shared__ double sred[256];
     __shared__ PreWork pw;
+    PH_INIT;
     const bool ext = src.ids != nullptr;
     const int ext_n = ext ? src.n_obs[s] : 0;
     const double in_stamp = ext ? src.stamps[s] : fe.cur_time;
@@ -659,6 +660,7 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
         flag[j] = isnew;
     }
     __syncthreads();
+    PH(106);
     {
         double tr = block_sum((double)tracked, sred);
         if (t == 0) be.last_track_num = (int)tr;
@@ -687,6 +689,7 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
         __syncthreads();
         nlm = be.n_lm;
     }
+    PH(107);
     // parallax (:100-122, :732-768)
     {
         double psum = 0, pnum = 0;
@@ -715,12 +718,33 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
         }
         __syncthreads();
     }
+    PH(108);
     // ---- getIMUInterval + processIMU (estimator.cpp:185-200, 1910-1942, 118-154); VO mode (USE_IMU == 0) has neither
-    if (cfg.use_imu && t == 0) {
+    if (cfg.use_imu && t < 64) {
+        // head = the first sample later than prevTime, k = the first one at or after curTime: 64 samples per trip, one lane each (the two scalar
+        // loops were a chain of dependent loads, ~14 of them per frame at 200 Hz)
+        const int cnt_all = be.imu_count;
+        const double prevT = be.prevTime;
         int head = be.imu_head;
-        while (head < be.imu_count && it[head % C.NIMU] <= be.prevTime) head++;
+        for (;;) {
+            const int idx = head + t;
+            const bool pass = idx < cnt_all && it[idx % C.NIMU] <= prevT;
+            const unsigned long long stop = ~__ballot(pass);
+            if (stop) { head += __ffsll((long long)stop) - 1; break; }
+            head += 64;
+        }
         int k = head;
-        while (k < be.imu_count && it[k % C.NIMU] < curTime) k++;
+        for (;;) {
+            const int idx = k + t;
+            const bool pass = idx < cnt_all && it[idx % C.NIMU] < curTime;
+            const unsigned long long stop = ~__ballot(pass);
+            if (stop) { k += __ffsll((long long)stop) - 1; break; }
+            k += 64;
+        }
+        sh_i[6] = head; sh_i[7] = k;
+    }
+    if (cfg.use_imu && t == 0) {
+        const int head = sh_i[6], k = sh_i[7];
         sh_i[0] = head;          // first sample of the interval
         sh_i[1] = k - head + 1;  // number of samples incl. the first one with t >= curTime
         be.imu_head = k;         // that last sample is not popped
@@ -770,6 +794,7 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
             const v3 w_Ba = ld3(be.Bas[fc]), w_Bg = ld3(be.Bgs[fc]), w_g = ld3(be.g);
             const double prevTime = be.prevTime;
             __syncthreads();
+            PH(111);
             for (int q0 = 0; q0 < n; q0 += PI_CH) {
                 const int m = min(PI_CH, n - q0);
                 if (t < m) {   // stage the chunk's samples
@@ -806,10 +831,15 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
                         w_V = add(w_V, scl(dt, un_acc));
                         w_a0 = acc; w_g0 = gyr;
                     }
+                } else if (t >= 128) {   // (idle otherwise during the two recursions: clear the chunk's F / V for preint_step_FV)
+                    for (int q = t - 128; q < m * 225; q += nt - 128) (&pi_F[0][0])[q] = 0;
+                    for (int q = t - 128; q < m * 270; q += nt - 128) (&pi_V[0][0])[q] = 0;
                 }
                 __syncthreads();
-                if (t < m) bf::preint_step_FV(pi_pre[t], lba, lbg, pi_dt[t], ld3(pi_acc[t]), ld3(pi_gyr[t]), pi_F[t], pi_V[t]);
+                PH(112);
+                if (t < m) bf::preint_step_FV(pi_pre[t], lba, lbg, pi_dt[t], ld3(pi_acc[t]), ld3(pi_gyr[t]), pi_F[t], pi_V[t], false);
                 __syncthreads();
+                PH(113);
                 for (int k = 0; k < m; k++) {
                     const double *Fk = pi_F[k], *Vk = pi_V[k];
                     if (t < 225) {
@@ -823,14 +853,16 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
                         int i = t / 15, j = t - i * 15;
                         double s1 = 0;
                         for (int u = 0; u < 15; u++) s1 += pw.FP[i * 15 + u] * Fk[j * 15 + u];
-                        double nn[6] = {cfg.acc_n * cfg.acc_n, cfg.gyr_n * cfg.gyr_n, cfg.acc_n * cfg.acc_n, cfg.gyr_n * cfg.gyr_n, cfg.acc_w * cfg.acc_w, cfg.gyr_w * cfg.gyr_w};
+                        const double nn[6] = {cfg.acc_n * cfg.acc_n, cfg.gyr_n * cfg.gyr_n, cfg.acc_n * cfg.acc_n, cfg.gyr_n * cfg.gyr_n, cfg.acc_w * cfg.acc_w, cfg.gyr_w * cfg.gyr_w};
                         double tt = 0;
+#pragma unroll
                         for (int u = 0; u < 18; u++) tt += Vk[i * 18 + u] * nn[u / 3] * Vk[j * 18 + u];
                         pw.J[t] = pw.FJ[t];
                         pw.Pm[t] = s1 + tt;
                     }
                     __syncthreads();
                 }
+                PH(114);
             }
             if (t == 0) {
                 st3(P.dp, s_dp); st3(P.dv, s_dv);
@@ -854,10 +886,12 @@ __global__ __launch_bounds__(256) void be_ingest_kernel(Batch B, const uint16_t 
         if (t == 0) be.prevTime = curTime;
         __syncthreads();
     }
+    PH(109);
     // ---- triangulateWithDepth (feature_manager.cpp:386-543); the dynamic initialisation triangulates after its SfM instead (estimator.cpp:921-933)
     if (!cfg.use_imu && be.solver_flag == 1) init_frame_pose_by_pnp(c, fc, c.res, sred);   // estimator.cpp:321-322 (VO mode, NON_LINEAR only)
     if (!(cfg.dynamic_init && be.solver_flag == 0)) triangulate_with_depth(c, nlm);
     __syncthreads();
+    PH(110);
     if (t == 0) {
         be.processed = 1;
         be.frames_processed++;
@@ -1387,11 +1421,13 @@ namespace {
 // variable).  Shared by the persistent solve kernel and the phased solver (ps_setup_kernel).
 // allow_relo: the caller can carry relocalisation factors (phased solver): sh_i[4] returns whether this solve has them
 __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X, int *scratch, PreWork &pw, int *sh_i, int &F, int &Fa, int &nres,
-                                               const bool allow_relo = false) {
+                                               const bool allow_relo = false, unsigned *lmkey = nullptr, const int lmkey_cap = 0) {
     const int t = threadIdx.x, nt = blockDim.x;
     const vio_config &cfg = c.C->c;
     BeSeq &be = *c.be;
     const int W = c.W, W1 = W + 1;
+    const int s = c.s;
+    PH_INIT;
     // ---- static initialisation extras (estimator.cpp:266-283): solveGyroscopeBias + repropagate (IMU mode only, :264)
     if (be.solver_flag == 0 && cfg.use_imu) {
         if (t == 0) {
@@ -1469,6 +1505,7 @@ __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X
     }
     __syncthreads();
     const int relo_on = sh_i[4];
+    PH(100);
     // ---- landmark indexing: in-problem (para_Feature index), variable landmarks, residual list
     const int nlm = be.n_lm;
     int *tmpA = c.pair_list, *tmpB = c.pair_list + c.NL;       // scan temporaries (pair_list proper is built afterwards)
@@ -1497,6 +1534,7 @@ __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X
         if (tmpA[k]) alist[tmpB[k]] = slot;
     }
     __syncthreads();
+    PH(101);
     // relocalisation factors (estimator.cpp:1307-1346): in-problem landmarks with start_frame <= relo_frame_local_index whose id is among
     // the match points (upstream walks both ascending lists with one cursor: the same set); their factor rides as one more residual
     // record behind the landmark's regular ones, marked res_k = 0
@@ -1530,11 +1568,25 @@ __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X
             if (r0 + q < nres) { c.res_lm[r0 + q] = slot; c.res_k[r0 + q] = q < nreg ? q + 1 : 0; }
     }
     __syncthreads();
+    PH(102);
     // frame-pair lists in deterministic (landmark list) order: one wavefront per frame pair walks the in-problem landmarks
     {
         const int lane = t & 63, wave = t >> 6, nw = nt >> 6;
         for (int p = t; p <= W1 * W1; p += nt) c.pair_start[p] = 0;
+        // (round 6) what the walks below need of a landmark -- start frame, observation count, relocalisation mark, first residual index -- packed
+        // into one word of LDS per in-problem landmark: every frame pair walks the whole list twice, W1 W / 2 pairs x F / 64 trips x 2, and from HBM
+        // each trip was a chain of two dependent loads (the slot, then its fields): 214 us of ps_setup at W = 20, 55 at W = 10
+        const bool keys = lmkey != nullptr && F <= lmkey_cap && c.nres_cap < (1 << 19);
+        if (keys)
+            for (int k = t; k < F; k += nt) {
+                const int slot = plist[k];
+                lmkey[k] = (unsigned)c.lm_start[slot] | ((unsigned)c.lm_nobs[slot] << 6) | ((unsigned)(c.lm_relo[slot] ? 1 : 0) << 12) | ((unsigned)c.lm_tmp[slot] << 13);
+            }
         __syncthreads();
+        auto lm_fields = [&](int k, int &st_, int &no_, int &rl_, int &r0_) {
+            if (keys) { const unsigned key = lmkey[k]; st_ = key & 63u; no_ = (key >> 6) & 63u; rl_ = (key >> 12) & 1u; r0_ = (int)(key >> 13); }
+            else { const int slot = plist[k]; st_ = c.lm_start[slot]; no_ = c.lm_nobs[slot]; rl_ = c.lm_relo[slot]; r0_ = c.lm_tmp[slot]; }
+        };
         for (int p = wave; p < W1 * W1; p += nw) {
             int i = p / W1, j = p - i * W1;
             if (!(i < j)) continue;
@@ -1544,19 +1596,45 @@ __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X
                 bool hit = false;
                 bool hit2 = false;   // relocalisation record: listed with the pair (start, start + 1), its pose_j columns are zero
                 if (k < F) {
-                    int slot = plist[k];
-                    hit = c.lm_start[slot] == i && c.lm_nobs[slot] > j - i && c.lm_tmp[slot] + (j - i - 1) < nres;
-                    hit2 = relo_on && j == i + 1 && c.lm_start[slot] == i && c.lm_relo[slot] && c.lm_tmp[slot] + c.lm_nobs[slot] - 1 < nres;
+                    int st_, no_, rl_, r0_;
+                    lm_fields(k, st_, no_, rl_, r0_);
+                    hit = st_ == i && no_ > j - i && r0_ + (j - i - 1) < nres;
+                    hit2 = relo_on && j == i + 1 && st_ == i && rl_ && r0_ + no_ - 1 < nres;
                 }
                 cnt += __popcll(__ballot(hit)) + __popcll(__ballot(hit2));
             }
             if (lane == 0) c.pair_start[p] = cnt;
         }
         __syncthreads();
-        if (t == 0) {
-            int acc = 0;
-            for (int p = 0; p < W1 * W1; p++) { int v = c.pair_start[p]; c.pair_start[p] = acc; acc += v; }
-            c.pair_start[W1 * W1] = acc;
+        PH(103);
+        {
+            // exclusive prefix sum of the W1^2 counts (one thread walking them was 441 dependent loads at W = 20): chunks per thread, Hillis-Steele
+            // over the chunk sums in `scratch` (2 nt ints), as block_scan_flags does
+            const int np = W1 * W1, chunk = (np + nt - 1) / nt, b0 = min(np, t * chunk), e0 = min(np, b0 + chunk);
+            int vals[4], sum = 0;   // chunk <= 4: np <= 441 at W = 20 needs nt >= 111
+            if (chunk <= 4) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) { vals[q] = b0 + q < e0 ? c.pair_start[b0 + q] : 0; sum += vals[q]; }
+                int *cur = scratch, *nxt = scratch + nt;
+                __syncthreads();
+                cur[t] = sum;
+                __syncthreads();
+                for (int off = 1; off < nt; off <<= 1) {
+                    int v = cur[t];
+                    if (t >= off) v += cur[t - off];
+                    nxt[t] = v;
+                    __syncthreads();
+                    int *tmp = cur; cur = nxt; nxt = tmp;
+                }
+                int o = cur[t] - sum;
+#pragma unroll
+                for (int q = 0; q < 4; q++) if (b0 + q < e0) { c.pair_start[b0 + q] = o; o += vals[q]; }
+                if (t == nt - 1) c.pair_start[np] = cur[nt - 1];
+            } else if (t == 0) {
+                int acc = 0;
+                for (int p = 0; p < np; p++) { int v = c.pair_start[p]; c.pair_start[p] = acc; acc += v; }
+                c.pair_start[np] = acc;
+            }
         }
         __syncthreads();
         for (int p = wave; p < W1 * W1; p += nw) {
@@ -1567,7 +1645,7 @@ __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X
                 int k = k0 + lane;
                 bool hit = false;
                 int r = 0;
-                if (k < F) { int slot = plist[k]; r = c.lm_tmp[slot] + (j - i - 1); hit = c.lm_start[slot] == i && c.lm_nobs[slot] > j - i && r < nres; }
+                if (k < F) { int st_, no_, rl_, r0_; lm_fields(k, st_, no_, rl_, r0_); r = r0_ + (j - i - 1); hit = st_ == i && no_ > j - i && r < nres; }
                 unsigned long long m = __ballot(hit);
                 if (hit) c.pair_list[o + __popcll(m & ((1ULL << lane) - 1ULL))] = r;
                 o += __popcll(m);
@@ -1577,7 +1655,7 @@ __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X
                     int k = k0 + lane;
                     bool hit = false;
                     int r = 0;
-                    if (k < F) { int slot = plist[k]; r = c.lm_tmp[slot] + c.lm_nobs[slot] - 1; hit = c.lm_start[slot] == i && c.lm_relo[slot] && r < nres; }
+                    if (k < F) { int st_, no_, rl_, r0_; lm_fields(k, st_, no_, rl_, r0_); r = r0_ + no_ - 1; hit = st_ == i && rl_ && r < nres; }
                     unsigned long long m = __ballot(hit);
                     if (hit) c.pair_list[o + __popcll(m & ((1ULL << lane) - 1ULL))] = r;
                     o += __popcll(m);
@@ -1585,6 +1663,7 @@ __device__ __forceinline__ void solve_prologue(const Batch &B, Ctx &c, Params &X
         }
         __syncthreads();
     }
+    PH(104);
     if (t == 0) {
         be.n_in_problem = F; be.n_var_landmarks = Fa; be.n_residuals = nres - sh_i[3];   // (f_m_cnt counts the regular factors)
         be.relo_factors = sh_i[3];

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(512) void ps_setup_kernel(Batch B) {
     if (!be.do_solve) { if (t == 0) st.stage = PS_IDLE; return; }
     const long long ts0 = VIO_CLOCK();
     int F, Fa, nres;
-    solve_prologue(B, c, X, scratch, pw, sh_i, F, Fa, nres, /*allow_relo=*/true);
+    __shared__ unsigned lmkey[2048];
+    solve_prologue(B, c, X, scratch, pw, sh_i, F, Fa, nres, /*allow_relo=*/true, lmkey, 2048);
     // Bounds (estimator.cpp:1282-1297: SetParameterUpperBound(para_Feature, 0, 2 / DEPTH_MAX_DIST) on landmarks triangulated without a depth
     // measurement).  Ceres: Program::IsBoundsConstrained() of the reduced program -- any VARIABLE block with a finite bound -- switches the
     // trust-region loop to its constrained form: TrustRegionMinimizer::IterationZero sends x through Plus(x, 0) before the first evaluation
