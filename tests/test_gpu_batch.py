@@ -191,7 +191,7 @@ def test_schur_launch_forming_S_itself_equals_the_load_in_ps_serial(P, monkeypat
     alt = _drive(P, cfg, sc, [60, 61, 62], n)
     for i in range(3):
         assert alt.status(i).solver_flag == 1 and alt.status(i).has_prior == 1
-        assert alt.status(i).iterations_total == ref_it[i] and ref_it[i] > 3 * (n - cfg.window_size)
+        assert alt.status(i).iterations_total == ref_it[i] and ref_it[i] > n - cfg.window_size, (ref_it, alt.status(i).iterations_total)
         assert np.array_equal(alt.window(i).view(np.uint64), ref_w[i].view(np.uint64)), (i, float(np.abs(alt.window(i) - ref_w[i]).max()))
 
 
