@@ -195,6 +195,27 @@ def test_schur_launch_forming_S_itself_equals_the_load_in_ps_serial(P, monkeypat
         assert np.array_equal(alt.window(i).view(np.uint64), ref_w[i].view(np.uint64)), (i, float(np.abs(alt.window(i) - ref_w[i]).max()))
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(estimate_extrinsic=1, estimate_td=1), dict(window_size=20), dict(window_size=20, estimate_extrinsic=1, estimate_td=1)])
+def test_gauss_newton_rhs_formed_in_the_schur_launch_equals_ps_serials(P, monkeypatch, kw):
+    """round 6: with VIO_GN_EXT = 1 (the default) one more workgroup of the Schur launch forms Hpl^T (sl inv gls), the landmark term of the Gauss-Newton
+    right-hand side, playing ps_serial's eight wavefronts on four (ps_colsum_as_eight_waves: same rows per wavefront, same order of the partial
+    sums) -- on the two-range pass (W = 10; W = 20 with the extrinsic constant) and on its dense fallback (W = 20 with the extrinsic variable).
+    The windows must be the same BITS as with VIO_GN_EXT = 0."""
+    cfg = P.canonical_config(**kw)
+    sc = vio_ct.synth_like(cfg)
+    n = cfg.window_size + 14
+    monkeypatch.setenv("VIO_GN_EXT", "0")
+    ref = _drive(P, cfg, sc, [60, 61, 62], n)
+    ref_w = [ref.window(i).copy() for i in range(3)]
+    ref_it = [ref.status(i).iterations_total for i in range(3)]
+    monkeypatch.setenv("VIO_GN_EXT", "1")
+    alt = _drive(P, cfg, sc, [60, 61, 62], n)
+    for i in range(3):
+        assert alt.status(i).solver_flag == 1 and alt.status(i).has_prior == 1
+        assert alt.status(i).iterations_total == ref_it[i] and ref_it[i] > n - cfg.window_size, (ref_it, alt.status(i).iterations_total)
+        assert np.array_equal(alt.window(i).view(np.uint64), ref_w[i].view(np.uint64)), (i, float(np.abs(alt.window(i) - ref_w[i]).max()))
+
+
 @pytest.mark.parametrize("kw", [dict(), dict(estimate_extrinsic=1, estimate_td=1)])
 def test_block_pair_assembly_of_H_equals_the_entrywise_one(P, monkeypatch, kw):
     """round 5: ps_asm_b sums H and the gradient by pairs of parameter blocks (scalar index decisions, mirrored upper triangle) instead of one

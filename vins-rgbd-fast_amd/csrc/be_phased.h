@@ -1665,13 +1665,84 @@ __device__ __forceinline__ void ps_schur_body(const Batch &B, int s, int tile_in
     }
 }
 
+// Column sums out[a] = sum_k u[k] M[k][a] of the landmark rows, with the BITS of matvec_pass_2range / matvec_pass_t run by ps_serial's eight wavefronts:
+// wavefront w of this 256-thread block plays wavefronts w and w + 4 of that pass one after the other (rows k = w', w' + 8, ..., RB of them per trip,
+// accumulated in that order), then the eight partial sums are added in wavefront order.  RANGE: only the columns [0, n0) and [e0, e0 + ne).
+template <int NC, int RB, bool RANGE>
+__device__ __forceinline__ void ps_colsum_as_eight_waves(const double *M, int ld, int nrows, int n, int n0, int e0, int ne, const double *u, double *out_col, double *part) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int ncomp = n0 + ne;
+    int col[NC];
+#pragma unroll
+    for (int j = 0; j < NC; j++) { const int q = lane + 64 * j; col[j] = RANGE ? (q < n0 ? q : (q < ncomp ? e0 + (q - n0) : -1)) : (q < n ? q : -1); }
+    for (int vw = wave; vw < 8; vw += 4) {
+        double cs[NC];
+#pragma unroll
+        for (int j = 0; j < NC; j++) cs[j] = 0;
+        for (int k0 = vw; k0 < nrows; k0 += RB * 8) {
+            double m[RB][NC], uk[RB];
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                const int k = k0 + b * 8;
+                const double *r = M + (size_t)min(k, nrows - 1) * ld;
+#pragma unroll
+                for (int j = 0; j < NC; j++) m[b][j] = col[j] >= 0 ? r[col[j]] : 0.0;
+                uk[b] = k < nrows ? u[k] : 0.0;
+            }
+#pragma unroll
+            for (int b = 0; b < RB; b++) {
+                if (k0 + b * 8 >= nrows) break;
+#pragma unroll
+                for (int j = 0; j < NC; j++) cs[j] += uk[b] * m[b][j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NC; j++) if (col[j] >= 0) part[vw * VIO_LWMAX + col[j]] = cs[j];
+    }
+    __syncthreads();
+    for (int a = t; a < n; a += blockDim.x) {
+        double sacc = 0;
+        if (!RANGE || a < n0 || (a >= e0 && a < e0 + ne))
+            for (int q = 0; q < 8; q++) sacc += part[q * VIO_LWMAX + a];
+        out_col[a] = sacc;
+    }
+}
+// B.gn_ext (round 6): the landmark term of the Gauss-Newton right-hand side, Hpl^T (sl inv gls), needs nothing of this launch's H or of ps_serial's
+// prepare_point beyond what the Schur tiles use (Hll, gl, the landmark scaling and mu) -- one more workgroup of the Schur launch forms it (into the
+// tmpv slot of c.vec) beside the tiles instead of ps_serial's one workgroup per sequence in front of its Cholesky (7 of 93 us per iteration).
+__device__ __forceinline__ void ps_gn_rhs_body(const Batch &B, int s, double *wk_s) {
+    const SolveSt &st = B.sst[s];
+    if (st.stage != PS_ASM && st.stage != PS_SCHUR) return;
+    Ctx c = make_ctx(B, s);
+    ps_sel_rows(B, c, st.rowbuf);
+    const int W1 = c.W + 1, LW = c.LW, P = c.P, t = threadIdx.x;
+    const double mu = st.mu;
+    const int Fa = st.Fa, Kpad = (Fa + 3) & ~3;
+    const bool first = st.scale_pending != 0;
+    for (int kc = t; kc < Kpad; kc += blockDim.x) {   // (the expressions of ps_serial's prepare_point and Gauss-Newton step)
+        const double hll = c.Hll[kc], slk = first ? (kc < Fa ? 1.0 / (1.0 + sqrt(hll)) : 0.0) : c.lvec[kc];
+        const double hl = kc < Fa ? slk * slk * hll : 0.0;
+        const double gls = kc < Fa ? slk * c.gl[kc] : 0.0;
+        const double dl = sqrt(fmin(fmax(hl, 1e-6), 1e32));
+        const double iv = kc < Fa ? 1.0 / (hl + mu * dl * dl) : 0.0;
+        wk_s[kc] = slk * iv * gls;
+    }
+    __syncthreads();
+    double *part = wk_s + ((Kpad + 7) & ~7);
+    double *out = c.vec + 7 * LW;   // tmpv (ps_serial_body's slot 7)
+    const int n0 = 6 * W1, e0 = 15 * W1, ne = st.vext ? 7 : 0;
+    if (n0 + ne <= 128) ps_colsum_as_eight_waves<2, 8, true>(c.Hpl, LW, Fa, P, n0, e0, ne, wk_s, out, part);   // matvec_pass_2range<8>
+    else ps_colsum_as_eight_waves<6, 4, false>(c.Hpl, LW, Fa, P, n0, e0, ne, wk_s, out, part);                  // its dense fallback, matvec_pass_t<6> (RB = 4)
+}
+
 // one launch: blocks [0, nb_b) sum the entries of H and the gradient, the blocks behind them form the landmark part of the
-// Schur complement tile by tile
+// Schur complement tile by tile (and, B.gn_ext, one more the landmark term of the Gauss-Newton right-hand side)
 __global__ __launch_bounds__(256) void ps_asm_b_schur_kernel(Batch B, int nb_b, int by_blocks) {
     int s, b;
     if (!ps_blk(B, s, b)) return;
     extern __shared__ double ps_wk_s[];
-    if (b < nb_b) { if (by_blocks == 1) ps_asm_b_blocks(B, s, b, nb_b); else if (by_blocks == 2) ps_asm_b_body(B, s, b, nb_b, true); else ps_asm_b_body(B, s, b, nb_b, false); }
+    if (B.gn_ext && b == nb_b + B.n_schur) ps_gn_rhs_body(B, s, ps_wk_s);
+    else if (b < nb_b) { if (by_blocks == 1) ps_asm_b_blocks(B, s, b, nb_b); else if (by_blocks == 2) ps_asm_b_body(B, s, b, nb_b, true); else ps_asm_b_body(B, s, b, nb_b, false); }
     else ps_schur_body(B, s, b - nb_b, ps_wk_s);
 }
 
@@ -1771,10 +1842,11 @@ template <bool BIG, int TB> __device__ __forceinline__ void ps_serial_body(const
         for (int k = t; k < Kpad; k += nt) {
             double iv = k < Fa ? 1.0 / (Hlls[k] + mu * dgl[k] * dgl[k]) : 0.0;
             inv[k] = iv;
-            tmpl[k] = sl[k] * iv * gls[k];
+            if (!B.gn_ext) tmpl[k] = sl[k] * iv * gls[k];
         }
         __syncthreads();
-        matvec_pass_2range<TB>(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, tmpl, nullptr, tmpv, nullptr, work);
+        // (B.gn_ext: tmpv = Hpl^T (sl inv gls) came in with the vectors, formed by ps_gn_rhs_body in the Schur launch at this mu)
+        if (!B.gn_ext) matvec_pass_2range<TB>(c.Hpl, LW, Fa, P, 6 * W1, 15 * W1, ne_ext, tmpl, nullptr, tmpv, nullptr, work);
         for (int a = t; a < LW; a += nt) xs[a] = a < P ? gs[a] - sp[a] * tmpv[a] : 0.0;
         __syncthreads();
         PH(49);
@@ -1967,7 +2039,7 @@ __global__ __launch_bounds__(512) void ps_serial_big_kernel(Batch B) { ps_serial
 // (20 trials, or a |delta|_inf < 1e-9), left as it was.  The next ps_eval evaluates whatever candidate stands, as Ceres evaluates the candidate
 // again after its search; model_change, dogleg_norm and the radius logic keep the FULL step's values.  (Kept out of ps_serial / ps_eval on
 // purpose: inlined there its stack objects gave the two hottest kernels of the solve a private segment.)
-__global__ __launch_bounds__(256, 4) void ps_ls_kernel(Batch B) {   // (held to 128 VGPRs -- the search itself spills, it is the rare path: an idle workgroup of 400 VGPRs per lane waits for register space on every CU it lands on)
+__global__ __launch_bounds__(256, 2) void ps_ls_kernel(Batch B) {   // (held to 128 VGPRs -- the search itself spills, it is the rare path: an idle workgroup of 400 VGPRs per lane waits for register space on every CU it lands on)
     const int s = blockIdx.x + B.s0, t = threadIdx.x, nt = blockDim.x;
     SolveSt &st = B.sst[s];
     if (st.stage != PS_EVAL_C || !st.ls_pending) return;

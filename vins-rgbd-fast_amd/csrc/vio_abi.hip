@@ -669,7 +669,7 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
             // XCD-aware block map (ps_blk): every block of a sequence on the XCD its one-block kernels run on
             const bool xm = h->xcd_map && S >= 8;
             const int XN = h->xcd_n > 0 ? h->xcd_n : 8;   // (measured with the back-end streams masked to six XCDs: 8 -> +2 %, 6 -> +0.3 %, 3 / 12 -> -1 %: the block -> XCD rotation ignores the mask)
-            const int nb_e = h->ps_eval_blocks, nb_a = h->ps_asm_a_blocks, nb_bs = h->ps_asm_b_blocks + h->ps_schur_tiles, S8 = XN * ((S + XN - 1) / XN);
+            const int nb_e = h->ps_eval_blocks, nb_a = h->ps_asm_a_blocks, nb_bs = h->ps_asm_b_blocks + h->ps_schur_tiles + (Bg.gn_ext ? 1 : 0), S8 = XN * ((S + XN - 1) / XN);
             Batch Be = Bg, Ba = Bg, Bb = Bg;
             Be.ns = Ba.ns = Bb.ns = S;
             Be.xcd_n = Ba.xcd_n = Bb.xcd_n = XN;
@@ -690,7 +690,7 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
                     if (h->asm_a_occ4) ps_asm_a_kernel_occ4<<<g_a, 512, 0, st>>>(Ba);
                     else ps_asm_a_kernel<<<g_a, 512, 0, st>>>(Ba);
                 }
-                ps_asm_b_schur_kernel<<<g_b, 256, (size_t)(C.NL + 16 + 4 * 256) * sizeof(double), st>>>(Bb, h->ps_asm_b_blocks, h->asm_b_by_blocks);   // per-row factors + the partial tiles of wavefronts 1 .. 3 + the tile of H (form_s)
+                ps_asm_b_schur_kernel<<<g_b, 256, (size_t)(C.NL + 16 + 8 * 336 /* VIO_LWMAX: eight partial rows of ps_gn_rhs_body */) * sizeof(double), st>>>(Bb, h->ps_asm_b_blocks, h->asm_b_by_blocks);   // per-row factors + the partial tiles of wavefronts 1 .. 3 + the tile of H (form_s)
                 if (h->serial_big) ps_serial_big_kernel<<<S, 512, h->lds_serial, st>>>(Bg);
                 else ps_serial_kernel_512<<<S, 512, h->lds_serial, st>>>(Bg);
                 // Ceres' projected line search of bounds-constrained solves (one workgroup per sequence, idle otherwise); the candidate of the
@@ -1102,6 +1102,8 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
                     if (act(a) && act(b2)) nact++;
                 }
                 h->ps_schur_tiles = nact;
+                h->B.n_schur = nact;
+                h->B.gn_ext = getenv("VIO_GN_EXT") ? (atoi(getenv("VIO_GN_EXT")) != 0) : 1;
             }
         }
         {

@@ -235,6 +235,7 @@ struct Batch {
     double *pairpart;                 // fused kernel: [S][PS_FUSE_MAXPAIRS][PS_FUSE_MAXBLK][210] partial Gram blocks of frame pairs whose residuals span chunks
     // the dimensions make_ctx needs, as kernel arguments (scalar registers) instead of a dependent load from *cfg at the top of every workgroup
     int gW, gP, gLW, gNL, gNP, gNRES, gNPRIOR, gMX;
+    int gn_ext, n_schur;   // one more workgroup of the Schur launch (behind its n_schur tiles) forms the landmark term of the Gauss-Newton right-hand side (VIO_GN_EXT)
     int form_s;   // ps_asm_b_schur forms S = Sp (H - U) Sp + mu D^2 itself (windows on ps_serial_big, VIO_FORM_S)
     int fuse;                         // VIO_FUSE (default 1): solves that qualify run ps_evalf_kernel instead of ps_eval + ps_asm_a; value = chunks the grid covers
     int fuse_only;                    // this launch sequence carries no ps_eval / ps_asm_a (every solve of the handle's configuration qualifies)
