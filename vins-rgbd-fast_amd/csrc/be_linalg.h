@@ -1058,29 +1058,37 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
     // the trailing tiles are handed out through a counter in LDS: wavefront 0 joins the others as soon as the next diagonal block is
     // factored (a fixed assignment left it idle behind the short factorisation of the last steps and the others behind the 54 tiles of
     // the first)
-    __shared__ int ctr_s;
+    __shared__ int ctr_s, pdone_s;
     int *ctr = &ctr_s;
-    if (t == 0) *sh_flag = 1;
+    volatile int *pdone = &pdone_s;
+    if (t == 0) { *sh_flag = 1; pdone_s = 0; }
     __syncthreads();
     if (wave == 0) chol_diag_tile(diag(0), dinv, sh_flag);
     __syncthreads();
     long long tm0 = (tm && t == 0) ? VIO_CLOCK() : 0;
     for (int p = 0; p < nb; p++) {
         if (!*sh_flag) return false;
+        if (nw > 1 && t == 0) *ctr = 1;   // (everybody is behind the barrier that ended step p - 1; published with wavefront 0's panel count below)
         // (b) panel: the tiles below the diagonal block become A M^T (one wavefront per tile); the right-hand side block becomes M b
         for (int ti = p + 1 + wave; ti < nb; ti += nw) chol_panel_tile(T + ((ti * (ti + 1) / 2 + p) << 8), diag(p), dinv + 16 * p);
         if (rhs && wave == nw - 1) chol_rhs_block(rhs + 16 * p, diag(p), dinv + 16 * p);
-        if (t == 0) *ctr = 1;
-        __syncthreads();
-        if (VIO_TIMERS && tm && t == 0) { long long n_ = VIO_CLOCK(); tm[0] += (float)(n_ - tm0); tm0 = n_; }
         // (c) trailing update S22 -= L21 L21^T on the FP64 matrix cores; tile 0 = (p+1, p+1) belongs to wavefront 0
         const int m = nb - 1 - p, ntile = m * (m + 1) / 2;
         if (nw > 1) {
+            // Round 6: no workgroup barrier between the panel and the trailing update.  Every wavefront counts its panel tiles in (pdone, LDS) and the
+            // trailing update waits for the count -- except wavefront 0's first piece: tile (p+1, p+1) takes column p's term from panel tile (p+1, p),
+            // which wavefront 0 has just solved ITSELF, so it goes on to that update and to the factorisation of the next diagonal block at once
+            // (2.5 us, the longest piece of a step) instead of first waiting for everybody's panel tiles.  Same tile operations, same order per tile.
+            WAVE_SYNC();
+            if (lane == 0) atomicAdd((int *)&pdone_s, 1);
             if (ntile > 0 && wave == 0) {
                 update_tile(p + 1, p + 1, p);
                 WAVE_SYNC();
                 chol_diag_tile(diag(p + 1), dinv + 16 * (p + 1), sh_flag);
             }
+            while (*pdone < nw * (p + 1)) __builtin_amdgcn_s_sleep(1);
+            __threadfence_block();
+            if (VIO_TIMERS && tm && t == 0) { long long n_ = VIO_CLOCK(); tm[0] += (float)(n_ - tm0); tm0 = n_; }
             if (rhs && wave == nw - 1) update_rhs(p);
             for (;;) {
                 int tile = 0;
@@ -1092,6 +1100,7 @@ __device__ __forceinline__ bool chol_tiles(double *T, int nb, int *sh_flag, doub
                 update_tile(ti + p + 1, tj + p + 1, p);
             }
         } else {
+            WAVE_SYNC();
             if (rhs) update_rhs(p);
             for (int tile = 0; tile < ntile; tile++) {
                 int ti, tj;
