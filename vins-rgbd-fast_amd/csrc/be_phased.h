@@ -2039,7 +2039,7 @@ __global__ __launch_bounds__(512) void ps_serial_big_kernel(Batch B) { ps_serial
 // (20 trials, or a |delta|_inf < 1e-9), left as it was.  The next ps_eval evaluates whatever candidate stands, as Ceres evaluates the candidate
 // again after its search; model_change, dogleg_norm and the radius logic keep the FULL step's values.  (Kept out of ps_serial / ps_eval on
 // purpose: inlined there its stack objects gave the two hottest kernels of the solve a private segment.)
-__global__ __launch_bounds__(256, 2) void ps_ls_kernel(Batch B) {   // (held to 128 VGPRs -- the search itself spills, it is the rare path: an idle workgroup of 400 VGPRs per lane waits for register space on every CU it lands on)
+__global__ __launch_bounds__(256, 2) void ps_ls_kernel(Batch B) {   // (held to 256 VGPRs -- the search itself spills, it is the rare path: an idle workgroup of 400 VGPRs per lane waits for register space on every CU it lands on; 128 measured the same when idle and slower when it runs)
     const int s = blockIdx.x + B.s0, t = threadIdx.x, nt = blockDim.x;
     SolveSt &st = B.sst[s];
     if (st.stage != PS_EVAL_C || !st.ls_pending) return;
