@@ -1667,14 +1667,16 @@ __device__ __forceinline__ void ps_schur_body(const Batch &B, int s, int tile_in
 
 // Column sums out[a] = sum_k u[k] M[k][a] of the landmark rows, with the BITS of matvec_pass_2range / matvec_pass_t run by ps_serial's eight wavefronts:
 // wavefront w of this 256-thread block plays wavefronts w and w + 4 of that pass one after the other (rows k = w', w' + 8, ..., RB of them per trip,
-// accumulated in that order), then the eight partial sums are added in wavefront order.  RANGE: only the columns [0, n0) and [e0, e0 + ne).
-template <int NC, int RB, bool RANGE>
+// accumulated in that order), then the eight partial sums are added in wavefront order.  Only the columns [0, n0) and [e0, e0 + ne) are walked (the
+// others of a landmark row are identically zero: the dense pass ps_serial falls back to beyond 128 such columns sums exact zeros there, so its result
+// is the same bits too); the partial rows are kept compact, 64 NC doubles each.
+template <int NC, int RB>
 __device__ __forceinline__ void ps_colsum_as_eight_waves(const double *M, int ld, int nrows, int n, int n0, int e0, int ne, const double *u, double *out_col, double *part) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int ncomp = n0 + ne;
     int col[NC];
 #pragma unroll
-    for (int j = 0; j < NC; j++) { const int q = lane + 64 * j; col[j] = RANGE ? (q < n0 ? q : (q < ncomp ? e0 + (q - n0) : -1)) : (q < n ? q : -1); }
+    for (int j = 0; j < NC; j++) { const int q = lane + 64 * j; col[j] = q < n0 ? q : (q < ncomp ? e0 + (q - n0) : -1); }
     for (int vw = wave; vw < 8; vw += 4) {
         double cs[NC];
 #pragma unroll
@@ -1697,13 +1699,14 @@ __device__ __forceinline__ void ps_colsum_as_eight_waves(const double *M, int ld
             }
         }
 #pragma unroll
-        for (int j = 0; j < NC; j++) if (col[j] >= 0) part[vw * VIO_LWMAX + col[j]] = cs[j];
+        for (int j = 0; j < NC; j++) if (col[j] >= 0) part[vw * (64 * NC) + lane + 64 * j] = cs[j];
     }
     __syncthreads();
     for (int a = t; a < n; a += blockDim.x) {
         double sacc = 0;
-        if (!RANGE || a < n0 || (a >= e0 && a < e0 + ne))
-            for (int q = 0; q < 8; q++) sacc += part[q * VIO_LWMAX + a];
+        const int qa = a < n0 ? a : ((a >= e0 && a < e0 + ne) ? n0 + (a - e0) : -1);
+        if (qa >= 0)
+            for (int q = 0; q < 8; q++) sacc += part[q * (64 * NC) + qa];
         out_col[a] = sacc;
     }
 }
@@ -1731,13 +1734,14 @@ __device__ __forceinline__ void ps_gn_rhs_body(const Batch &B, int s, double *wk
     double *part = wk_s + ((Kpad + 7) & ~7);
     double *out = c.vec + 7 * LW;   // tmpv (ps_serial_body's slot 7)
     const int n0 = 6 * W1, e0 = 15 * W1, ne = st.vext ? 7 : 0;
-    if (n0 + ne <= 128) ps_colsum_as_eight_waves<2, 8, true>(c.Hpl, LW, Fa, P, n0, e0, ne, wk_s, out, part);   // matvec_pass_2range<8>
-    else ps_colsum_as_eight_waves<6, 4, false>(c.Hpl, LW, Fa, P, n0, e0, ne, wk_s, out, part);                  // its dense fallback, matvec_pass_t<6> (RB = 4)
+    if (n0 + ne <= 128) ps_colsum_as_eight_waves<2, 8>(c.Hpl, LW, Fa, P, n0, e0, ne, wk_s, out, part);   // matvec_pass_2range<8>
+    else ps_colsum_as_eight_waves<3, 8>(c.Hpl, LW, Fa, P, n0, e0, ne, wk_s, out, part);                  // (ps_serial: the dense matvec_pass_t<6>; 6 (W + 1) + 7 <= 133 columns here)
 }
 
 // one launch: blocks [0, nb_b) sum the entries of H and the gradient, the blocks behind them form the landmark part of the
 // Schur complement tile by tile (and, B.gn_ext, one more the landmark term of the Gauss-Newton right-hand side)
-__global__ __launch_bounds__(256) void ps_asm_b_schur_kernel(Batch B, int nb_b, int by_blocks) {
+// five workgroups per CU (96 VGPRs, two spilled; 30 KB of LDS each): the launch is 2 944 workgroups at S = 64 and ran in three rounds of 1 024 at 112 VGPRs
+__global__ __launch_bounds__(256, 5) void ps_asm_b_schur_kernel(Batch B, int nb_b, int by_blocks) {
     int s, b;
     if (!ps_blk(B, s, b)) return;
     extern __shared__ double ps_wk_s[];

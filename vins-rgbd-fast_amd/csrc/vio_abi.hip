@@ -690,7 +690,7 @@ int launch_backend(vio_batch *h, vio_batch::Group &g, const uint16_t *d_depth, c
                     if (h->asm_a_occ4) ps_asm_a_kernel_occ4<<<g_a, 512, 0, st>>>(Ba);
                     else ps_asm_a_kernel<<<g_a, 512, 0, st>>>(Ba);
                 }
-                ps_asm_b_schur_kernel<<<g_b, 256, (size_t)(C.NL + 16 + 8 * 336 /* VIO_LWMAX: eight partial rows of ps_gn_rhs_body */) * sizeof(double), st>>>(Bb, h->ps_asm_b_blocks, h->asm_b_by_blocks);   // per-row factors + the partial tiles of wavefronts 1 .. 3 + the tile of H (form_s)
+                ps_asm_b_schur_kernel<<<g_b, 256, (size_t)(C.NL + 16 + (6 * (C.W + 1) + 7 <= 128 ? 8 * 128 : 8 * 192) /* eight compact partial rows of ps_gn_rhs_body (>= the 4 x 256 of a Schur tile) */) * sizeof(double), st>>>(Bb, h->ps_asm_b_blocks, h->asm_b_by_blocks);   // per-row factors + the partial tiles of wavefronts 1 .. 3 + the tile of H (form_s)
                 if (h->serial_big) ps_serial_big_kernel<<<S, 512, h->lds_serial, st>>>(Bg);
                 else ps_serial_kernel_512<<<S, 512, h->lds_serial, st>>>(Bg);
                 // Ceres' projected line search of bounds-constrained solves (one workgroup per sequence, idle otherwise); the candidate of the
