@@ -84,25 +84,23 @@ __device__ __forceinline__ double block_max(double v, double *sred) {
     return r;
 }
 __device__ int block_scan_flags(const int *flags, int n, int *offs, int *scratch /* 2*blockDim + 2 ints */) {
-    int nt = blockDim.x, t = threadIdx.x;
-    int chunk = (n + nt - 1) / nt;
-    int b = t * chunk, e = min(n, b + chunk);
+    // exclusive prefix sums of flags[0 .. n) into offs, the total returned.  Round 6: a wavefront scan (six shuffle steps) plus the wavefront totals
+    // through LDS -- three barriers; the Hillis-Steele scan over blockDim entries it replaces took log2(blockDim) + 3 of them, and this runs seven
+    // times per frame in the one-workgroup-per-sequence kernels of the chain (be_ingest, ps_setup x 3, be_marg x 3)
+    const int nt = blockDim.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
+    const int chunk = (n + nt - 1) / nt;
+    const int b = t * chunk, e = min(n, b + chunk);
     int sum = 0;
     for (int i = b; i < e; i++) sum += flags[i];
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+    __syncthreads();   // (the previous user of scratch is done)
+    if (lane == 63) scratch[wave] = incl;
     __syncthreads();
-    int *cur = scratch, *nxt = scratch + nt;
-    cur[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < nt; off <<= 1) {  // Hillis-Steele inclusive scan
-        int v = cur[t];
-        if (t >= off) v += cur[t - off];
-        nxt[t] = v;
-        __syncthreads();
-        int *tmp = cur; cur = nxt; nxt = tmp;
-    }
-    int incl = cur[t];
-    int total = cur[nt - 1];
-    int o = incl - sum;
+    int base = 0, total = 0;
+    for (int w = 0; w < nw; w++) { const int v = scratch[w]; if (w < wave) base += v; total += v; }
+    int o = base + incl - sum;
     for (int i = b; i < e; i++) { offs[i] = o; o += flags[i]; }
     __syncthreads();
     return total;
