@@ -884,7 +884,11 @@ static int create_group_streams(vio_batch *h, vio_batch::Group &g, bool partitio
     // partition in round 3) and no longer slows the solver chain measurably (43.4 k frames/s either way), and on every XCD the XCD-aware
     // block map of fe_lk cuts its HBM-side traffic to a third.  VIO_FE_CUS = n > 0 restores the partition (and switches that map off: under a
     // CU mask the workgroup -> XCD rotation it relies on does not hold).
-    const int fe_cus = fe_cus_env ? atoi(fe_cus_env) : 0;
+    // Round 6 (second half): with the solver chain a fifth shorter the wide front-end kernels of the next frame disturb it again where the device is
+    // NOT full -- up to 128 sequences per handle a quarter of the CUs (two XCDs) for the front-end streams is back as the default: 54.3 -> 56.5 k
+    // frames/s at 128 sequences, +4 % at 64, nothing at 16 or 1, nothing at tracker lag 0; beyond 128 sequences the partition costs throughput
+    // (192: -2.3 %, 256: -3.7 %, 512: -6.7 %) and stays off.  Scheduling only: the results do not depend on it.
+    const int fe_cus = fe_cus_env ? atoi(fe_cus_env) : (h->S <= 128 ? n_cu / 4 : 0);
     hipError_t e_fe, e_be;
     h->fe_partitioned = false;
     if (partitioned && n_cu >= 8 && n_cu <= 1024 && fe_cus > 0 && fe_cus < n_cu) {
