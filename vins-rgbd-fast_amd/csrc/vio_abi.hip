@@ -984,6 +984,10 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
     B.ns = 0; B.xcd_nb = 0; B.xcd_n = 8;
     if (getenv("VIO_BE_THREADS")) h->be_threads = std::min(1024, std::max(64, atoi(getenv("VIO_BE_THREADS")) & ~63));
     if (getenv("VIO_ASM_B_MODE")) h->asm_b_by_blocks = std::max(0, std::min(2, atoi(getenv("VIO_ASM_B_MODE"))));
+    // (round 6: 12 for windows up to W = 10 -- with the mirrored assembly and the Schur tiles summing their own entries a launch of 24 left two entries per
+    //  thread, and fewer, longer workgroups fill the back-end's CUs in fewer rounds: 56.5 -> 57.1 k at 128 sequences, 76.5 -> 78.0 k at 512; W = 20: 24 stays,
+    //  12 / 16 / 48 measured 11.8 / 12.0 / 12.2 k against 12.2 k)
+    h->ps_asm_b_blocks = h->hc.W <= 10 ? 12 : 24;
     if (getenv("VIO_ASM_B_BLOCKS")) h->ps_asm_b_blocks = std::max(1, std::min(256, atoi(getenv("VIO_ASM_B_BLOCKS"))));
     if (getenv("VIO_EVAL_OCC")) h->eval_occ = atoi(getenv("VIO_EVAL_OCC"));
     if (getenv("VIO_GRAPH")) h->use_graph = atoi(getenv("VIO_GRAPH")) != 0;
