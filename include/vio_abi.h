@@ -369,6 +369,11 @@ int vio_stage_imu_block(const vio_config *cfg, int n, const double *dt, const do
  * select the timing micro-modes of tools/chol_bench.py (one diagonal tile, panel tiles, dependent FP64 chains, v_mfma_f64_16x16x4 issue
  * rates; usec5 then carries clock64 ticks / 100 in slots 1 .. 4, L_out / x_out are not written): measurement only, see stage_linalg.hip. */
 int vio_stage_chol(int nb, int reps, int blocks, const double *S, const double *rhs, double *L_out, double *x_out, double *usec5);
+/* Harness of the HBM-resident symmetric eigen-solver of the literal marginalisation (marg_exact = 1, blocks beyond the LDS-resident size: Householder
+ * tridiagonalisation + implicit QL by one workgroup, be_linalg.h sym_eig_hbm; Eigen::SelfAdjointEigenSolver at marginalization_factor.cpp:281, :298 is
+ * what it stands in for).  A: symmetric n x n, row-major, 2 <= n <= 512.  evals[n] unsorted, evecs[i * n + k] = component i of the eigenvector of
+ * evals[k], usec (may be NULL; FOUR doubles) = device time of the decomposition and of its tridiagonalisation / accumulation / QL phases. */
+int vio_stage_sym_eig(int n, const double *A, double *evals, double *evecs, double *usec);
 
 #ifdef __cplusplus
 }

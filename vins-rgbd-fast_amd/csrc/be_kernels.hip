@@ -2247,9 +2247,12 @@ __device__ __noinline__ int marg_literal_prior(const Ctx &c, BeSeq &be, const do
         double *As = scrA, *V2 = scrV;
         for (int w = t; w < n * n; w += nt) { const int i = w / n, j = w - i * n; As[w] = 0.5 * (Ar[i * n + j] + Ar[j * n + i]); }
         __syncthreads();
-        sw2 = jacobi_block(As, V2, n, n, cs, sn, pp, qq, sred);
+        // round 6: Householder + implicit QL on the matrix where it lies (sym_eig_hbm) instead of cyclic Jacobi sweeps over HBM (VIO_MARG_EIG_JACOBI = 1)
+        const bool hbm_ql = !c.C->eig_jacobi;
+        if (hbm_ql) { sym_eig_hbm(As, n, n, (double *)marg_dyn_lds, sred); V2 = As; }
+        else sw2 = jacobi_block(As, V2, n, n, cs, sn, pp, qq, sred);
         for (int k = t; k < n; k += nt) {
-            ev2[k] = As[k * n + k];
+            ev2[k] = hbm_ql ? ((const double *)marg_dyn_lds)[k] : As[k * n + k];
             double vb = 0;
             for (int i = 0; i < n; i++) vb += V2[i * n + k] * br[i];
             vb2[k] = vb;
@@ -2327,6 +2330,27 @@ __device__ void marg_exact_finish(const Ctx &c, BeSeq &be, double *A, const doub
     } else {
         for (int w = t; w < m * m; w += nt) { const int i = w / m, j = w - i * m; Emm[w] = amm(i, j); }
         __syncthreads();
+        if (!c.C->eig_jacobi) {
+            // round 6: Householder + implicit QL on the matrix where it lies (be_linalg.h sym_eig_hbm; 23 ms at m = 185 against 50 - 100 ms of Jacobi sweeps)
+            double *ewk = (double *)marg_dyn_lds;
+            sym_eig_hbm(Emm, m, m, ewk, sred);
+            if (VIO_TIMERS && t == 0) be.dbg[7] = (int)(VIO_CLOCK() - tx0);
+            for (int k = t; k < m; k += nt) { const double ev = ewk[k]; ewk[SYM_EIG_HBM_MAX + k] = ev > eps ? 1.0 / ev : 0.0; }
+            __syncthreads();
+            for (int w = t; w < m * m; w += nt) {   // Amm_inv = V diag(lambda > eps ? 1 / lambda : 0) V^T: rows i and j of V, sixteen columns per trip
+                const int i = w / m, j = w - i * m;
+                const double *vi = Emm + (size_t)i * m, *vj = Emm + (size_t)j * m;
+                double sacc = 0;
+                for (int k0 = 0; k0 < m; k0 += 16) {
+                    double a[16], b[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) { const int k = min(k0 + u, m - 1); a[u] = vi[k]; b[u] = vj[k]; }
+#pragma unroll
+                    for (int u = 0; u < 16; u++) if (k0 + u < m) sacc += a[u] * b[u] * ewk[SYM_EIG_HBM_MAX + k0 + u];
+                }
+                Einv[w] = sacc;
+            }
+        } else {
         sw1 = jacobi_block(Emm, EV, m, m, cs, sn, pp, qq, sred);
         if (VIO_TIMERS && t == 0) be.dbg[7] = (int)(VIO_CLOCK() - tx0);
         for (int w = t; w < m * m; w += nt) {
@@ -2335,6 +2359,7 @@ __device__ void marg_exact_finish(const Ctx &c, BeSeq &be, double *A, const doub
             for (int k = 0; k < m; k++) { const double ev = Emm[(size_t)k * m + k]; if (ev > eps) sacc += EV[(size_t)i * m + k] * EV[(size_t)j * m + k] / ev; }
             Einv[w] = sacc;
         }
+        }
     }
     __syncthreads();
     // A_rm A_mm^-1 (:288-292); column k of A_rm: q-column k for the pose / speed-bias part, the coupling row of landmark k - md otherwise
@@ -2342,7 +2367,13 @@ __device__ void marg_exact_finish(const Ctx &c, BeSeq &be, double *A, const doub
         const int i = w / m, j = w - i * m;
         double sacc = 0;
         for (int k = 0; k < md; k++) sacc += A[(md + i) * mq + k] * Einv[(size_t)k * m + j];
-        for (int k = md; k < m; k++) sacc += Cl[(size_t)(k - md) * ldc + md + i] * Einv[(size_t)k * m + j];
+        for (int k0 = md; k0 < m; k0 += 16) {   // (sixteen terms' loads in flight; same order of the sum)
+            double a[16], b[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) { const int k = min(k0 + u, m - 1); a[u] = Cl[(size_t)(k - md) * ldc + md + i]; b[u] = Einv[(size_t)k * m + j]; }
+#pragma unroll
+            for (int u = 0; u < 16; u++) if (k0 + u < m) sacc += a[u] * b[u];
+        }
         ET1[w] = sacc;
     }
     __syncthreads();
@@ -2350,7 +2381,13 @@ __device__ void marg_exact_finish(const Ctx &c, BeSeq &be, double *A, const doub
         const int i = w / n, j = w - i * n;
         double tt = A[(md + i) * mq + md + j];
         for (int k = 0; k < md; k++) tt -= ET1[(size_t)i * m + k] * A[k * mq + md + j];
-        for (int k = md; k < m; k++) tt -= ET1[(size_t)i * m + k] * Cl[(size_t)(k - md) * ldc + md + j];
+        for (int k0 = md; k0 < m; k0 += 16) {
+            double a[16], b[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) { const int k = min(k0 + u, m - 1); a[u] = ET1[(size_t)i * m + k]; b[u] = Cl[(size_t)(k - md) * ldc + md + j]; }
+#pragma unroll
+            for (int u = 0; u < 16; u++) if (k0 + u < m) tt -= a[u] * b[u];
+        }
         Ar[w] = tt;
     }
     for (int i = t; i < n; i += nt) {       // b = brr - Arm Amm_inv bmm

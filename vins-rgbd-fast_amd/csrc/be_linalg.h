@@ -84,23 +84,25 @@ __device__ __forceinline__ double block_max(double v, double *sred) {
     return r;
 }
 __device__ int block_scan_flags(const int *flags, int n, int *offs, int *scratch /* 2*blockDim + 2 ints */) {
-    // exclusive prefix sums of flags[0 .. n) into offs, the total returned.  Round 6: a wavefront scan (six shuffle steps) plus the wavefront totals
-    // through LDS -- three barriers; the Hillis-Steele scan over blockDim entries it replaces took log2(blockDim) + 3 of them, and this runs seven
-    // times per frame in the one-workgroup-per-sequence kernels of the chain (be_ingest, ps_setup x 3, be_marg x 3)
-    const int nt = blockDim.x, t = threadIdx.x, lane = t & 63, wave = t >> 6, nw = nt >> 6;
-    const int chunk = (n + nt - 1) / nt;
-    const int b = t * chunk, e = min(n, b + chunk);
+    int nt = blockDim.x, t = threadIdx.x;
+    int chunk = (n + nt - 1) / nt;
+    int b = t * chunk, e = min(n, b + chunk);
     int sum = 0;
     for (int i = b; i < e; i++) sum += flags[i];
-    int incl = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
-    __syncthreads();   // (the previous user of scratch is done)
-    if (lane == 63) scratch[wave] = incl;
     __syncthreads();
-    int base = 0, total = 0;
-    for (int w = 0; w < nw; w++) { const int v = scratch[w]; if (w < wave) base += v; total += v; }
-    int o = base + incl - sum;
+    int *cur = scratch, *nxt = scratch + nt;
+    cur[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < nt; off <<= 1) {  // Hillis-Steele inclusive scan
+        int v = cur[t];
+        if (t >= off) v += cur[t - off];
+        nxt[t] = v;
+        __syncthreads();
+        int *tmp = cur; cur = nxt; nxt = tmp;
+    }
+    int incl = cur[t];
+    int total = cur[nt - 1];
+    int o = incl - sum;
     for (int i = b; i < e; i++) { offs[i] = o; o += flags[i]; }
     __syncthreads();
     return total;
@@ -641,6 +643,273 @@ __device__ __forceinline__ void tridiag_ql_wave(double *V, int n, int ld, double
 }
 
 // in-place lower Cholesky of the n x n matrix A (ld), right-looking; returns false if a pivot is not positive
+// Symmetric eigen-decomposition of a matrix that lives in HBM / L2, by the whole workgroup, n <= SYM_EIG_HBM_MAX (round 6: the blocks of the literal
+// marginalisation, marg_exact = 1, that do not fit LDS -- m = 155 .. 197 on the canonical workload -- went through cyclic Jacobi sweeps over HBM, 50 - 100 ms
+// each).  Householder tridiagonalisation with accumulation + implicit QL (EISPACK tred2 / tql2, the recurrences of sym_eig_tridiag / tridiag_ql_wave
+// above), organised for a matrix that is NOT in LDS:
+//   * every O(i^2) piece of a step is ONE THREAD PER COLUMN walking down the rows, thirty-two loads in flight per trip: a wavefront's load is then one
+//     contiguous 512-byte row segment (a thread per row touches 64 cache lines per load instruction, and a runtime-bound loop with the load inside waits
+//     for every L2 round trip in turn).  For that the active block is kept SYMMETRIC in both triangles (tred2 only needs the lower one; the mirror image
+//     costs the rank-2 update twice the arithmetic and makes the matrix-vector product a column walk too; mirrored entries are the same bits);
+//   * a QL sweep does not interleave the rotation recurrence with the eigenvector update: wavefront 0 runs the scalar recurrence of the whole sweep (d, e in
+//     LDS) and leaves the rotations (c_i, s_i) in LDS, then every thread applies the sweep's rotations to ITS component of all eigenvectors -- on the
+//     TRANSPOSED eigenvector array (row i = vector i), again a walk down the rows with the rotated element carried in a register.
+// V: n x n row-major, leading dimension ld, the COMPLETE symmetric matrix on entry, the eigenvectors on exit (V[i * ld + k] = component i of vector k).
+// wk: LDS, SYM_EIG_HBM_LDS_DOUBLES = 7 * SYM_EIG_HBM_MAX doubles; the eigenvalues (unsorted) are left in wk[0 .. n).  sred: 64 doubles of LDS.  blockDim >= 128.
+#define SYM_EIG_HBM_MAX 512
+#define SYM_EIG_HBM_LDS_DOUBLES (7 * SYM_EIG_HBM_MAX)
+__device__ __forceinline__ void sym_eig_hbm_transpose(double *V, int n, int ld) {
+    // in place: one thread per pair of 16-element row segments would be the coalesced way; at n <= 512 the plain element swap is 0.1 ms and runs twice
+    const int t = threadIdx.x, nt = blockDim.x;
+    for (int w0 = t; w0 < n * n; w0 += 4 * nt) {
+        double a[4], b[4];
+        int ia[4], ib[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int w = min(w0 + u * nt, n * n - 1), i = w / n, j = w - i * n;
+            ia[u] = i * ld + j; ib[u] = j * ld + i;
+            a[u] = V[ia[u]]; b[u] = V[ib[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int w = w0 + u * nt;
+            if (w < n * n && ia[u] < ib[u]) { V[ia[u]] = b[u]; V[ib[u]] = a[u]; }   // (i < j: each pair once)
+        }
+    }
+    __syncthreads();
+}
+__device__ __noinline__ void sym_eig_hbm(double *V, int n, int ld, double *wk, double *sred, float *tm = nullptr) {   // tm (harness): ticks of the tridiagonalisation, the accumulation, the QL phase
+    const int t = threadIdx.x, nt = blockDim.x, lane = t & 63;
+    long long tm0 = tm ? (long long)wall_clock64() : 0;
+    double *d = wk, *e = wk + SYM_EIG_HBM_MAX, *gt = wk + 2 * SYM_EIG_HBM_MAX, *cs = wk + 3 * SYM_EIG_HBM_MAX, *sn = wk + 4 * SYM_EIG_HBM_MAX;
+    for (int j = t; j < n; j += nt) d[j] = V[(size_t)(n - 1) * ld + j];
+    __syncthreads();
+    for (int i = n - 1; i > 0; i--) {
+        double sc = 0;
+        for (int k = t; k < i; k += nt) sc += fabs(d[k]);
+        sc = block_sum(sc, sred);
+        if (sc == 0.0) {
+            const double dim1 = d[i - 1];
+            __syncthreads();
+            if (t == 0) e[i] = dim1;
+            for (int j = t; j < i; j += nt) { d[j] = V[(size_t)(i - 1) * ld + j]; V[(size_t)i * ld + j] = 0.0; V[(size_t)j * ld + i] = 0.0; }
+            if (t == 0) d[i] = 0.0;
+            __syncthreads();
+            continue;
+        }
+        double h = 0;
+        for (int k = t; k < i; k += nt) { const double v = d[k] / sc; d[k] = v; h += v * v; }
+        h = block_sum(h, sred);
+        __syncthreads();
+        const double f = d[i - 1];
+        double g = sqrt(h);
+        if (f > 0) g = -g;
+        h -= f * g;
+        __syncthreads();
+        if (t == 0) { e[i] = sc * g; d[i - 1] = f - g; }
+        __syncthreads();
+        // e[j] = (A_sub d)[j] / h: column j of the symmetric active block, rows 0 .. i - 1
+        for (int j = t; j < i; j += nt) {
+            double acc = 0;
+            for (int k0 = 0; k0 < i; k0 += 32) {
+                double v[32];
+#pragma unroll
+                for (int u = 0; u < 32; u++) v[u] = V[(size_t)min(k0 + u, i - 1) * ld + j];
+#pragma unroll
+                for (int u = 0; u < 32; u++) if (k0 + u < i) acc += v[u] * d[k0 + u];
+            }
+            e[j] = acc / h;
+        }
+        __syncthreads();
+        double ff = 0;
+        for (int j = t; j < i; j += nt) ff += e[j] * d[j];
+        ff = block_sum(ff, sred);
+        const double hh = ff / (h + h);
+        __syncthreads();
+        for (int j = t; j < i; j += nt) e[j] -= hh * d[j];
+        __syncthreads();
+        // rank-2 update of the whole active block (both triangles), column j per thread; row i - 1 is read back as the next d below
+        for (int j = t; j < i; j += nt) {
+            const double dj = d[j], ej = e[j];
+            for (int k0 = 0; k0 < i; k0 += 32) {
+                double v[32];
+#pragma unroll
+                for (int u = 0; u < 32; u++) v[u] = V[(size_t)min(k0 + u, i - 1) * ld + j];
+#pragma unroll
+                for (int u = 0; u < 32; u++) if (k0 + u < i) V[(size_t)(k0 + u) * ld + j] = v[u] - (dj * e[k0 + u] + ej * d[k0 + u]);
+            }
+        }
+        __syncthreads();
+        // the Householder vector goes to column i (rows j < i), row i is cleared, the next d is row i - 1 of the updated block
+        for (int j = t; j < i; j += nt) { const double dj = d[j]; d[j] = V[(size_t)(i - 1) * ld + j]; V[(size_t)j * ld + i] = dj; V[(size_t)i * ld + j] = 0.0; }
+        __syncthreads();
+        if (t == 0) d[i] = h;
+        __syncthreads();
+    }
+    if (tm && t == 0) { const long long n_ = (long long)wall_clock64(); tm[1] = (float)(n_ - tm0); tm0 = n_; }
+    // accumulate the Householder transformations
+    for (int i = 0; i < n - 1; i++) {
+        if (t == 0) { V[(size_t)(n - 1) * ld + i] = V[(size_t)i * ld + i]; V[(size_t)i * ld + i] = 1.0; }
+        const double h = d[i + 1];
+        __syncthreads();
+        if (h != 0.0) {
+            for (int k = t; k <= i; k += nt) { const double u = V[(size_t)k * ld + i + 1]; cs[k] = u; d[k] = u / h; }   // (cs: the vector itself, free until the QL phase)
+            __syncthreads();
+            for (int j = t; j <= i; j += nt) {
+                double g = 0;
+                for (int k0 = 0; k0 <= i; k0 += 32) {
+                    double b[32];
+#pragma unroll
+                    for (int u = 0; u < 32; u++) b[u] = V[(size_t)min(k0 + u, i) * ld + j];
+#pragma unroll
+                    for (int u = 0; u < 32; u++) if (k0 + u <= i) g += cs[k0 + u] * b[u];
+                }
+                // V[k][j] -= g d[k] down the same column
+                for (int k0 = 0; k0 <= i; k0 += 32) {
+                    double v[32];
+#pragma unroll
+                    for (int u = 0; u < 32; u++) v[u] = V[(size_t)min(k0 + u, i) * ld + j];
+#pragma unroll
+                    for (int u = 0; u < 32; u++) if (k0 + u <= i) V[(size_t)(k0 + u) * ld + j] = v[u] - g * d[k0 + u];
+                }
+            }
+            __syncthreads();
+        }
+        for (int k = t; k <= i; k += nt) V[(size_t)k * ld + i + 1] = 0.0;
+        __syncthreads();
+    }
+    for (int j = t; j < n; j += nt) { d[j] = V[(size_t)(n - 1) * ld + j]; V[(size_t)(n - 1) * ld + j] = 0.0; }
+    __syncthreads();
+    if (t == 0) { V[(size_t)(n - 1) * ld + n - 1] = 1.0; e[0] = 0.0; }
+    __syncthreads();
+    if (tm && t == 0) { const long long n_ = (long long)wall_clock64(); tm[2] = (float)(n_ - tm0); tm0 = n_; }
+    // implicit QL on the transposed array: row i = basis vector i, thread k = component k
+    sym_eig_hbm_transpose(V, n, ld);
+    {
+        double sh[(SYM_EIG_HBM_MAX + 63) / 64];   // e shifted down by one: read all, then write
+#pragma unroll
+        for (int q = 0; q < (SYM_EIG_HBM_MAX + 63) / 64; q++) sh[q] = 0;
+        if (t < 64) {
+#pragma unroll
+            for (int q = 0; q < (SYM_EIG_HBM_MAX + 63) / 64; q++) { const int i = 1 + lane + 64 * q; sh[q] = i < n ? e[i] : 0.0; }
+        }
+        __syncthreads();
+        if (t < 64) {
+#pragma unroll
+            for (int q = 0; q < (SYM_EIG_HBM_MAX + 63) / 64; q++) { const int i = 1 + lane + 64 * q; if (i < n) e[i - 1] = sh[q]; }
+            if (lane == 0) e[n - 1] = 0.0;
+        }
+        __syncthreads();
+    }
+    // Wavefront 0 PRODUCES sweeps -- the whole QL control flow and the rotation recurrences, which touch only d and e -- and the other wavefronts APPLY them
+    // to the eigenvector array one sweep behind (rotations double-buffered in LDS, one workgroup barrier per sweep: it publishes sweep k and, the appliers
+    // arriving there after sweep k - 1, frees that sweep's buffer).  A sweep then costs max(recurrence, application) instead of their sum; the recurrence
+    // (a dependent chain of ~400 cycles per rotation: reciprocal square root, eight multiply-adds) is the longer one.
+    __shared__ int ql_desc[2][2];   // per buffer: l (-1 = no more sweeps), m
+    const int wave = t >> 6;
+    if (wave == 0) {
+        int pb = 0;
+        double f = 0.0, tst1 = 0.0;
+        const double eps = 2.220446049250313e-16;
+        for (int l = 0; l < n; l++) {
+            tst1 = fmax(tst1, fabs(d[l]) + fabs(e[l]));
+            int m = l;
+            while (m < n) { if (fabs(e[m]) <= eps * tst1) break; m++; }
+            if (m > l) {
+                int iter = 0;
+                bool again;
+                do {
+                    iter++;
+                    const double g0 = d[l];
+                    double p = (d[l + 1] - g0) / (2.0 * e[l]);
+                    double r = sqrt(p * p + 1.0);
+                    if (p < 0) r = -r;
+                    const double dl = e[l] / (p + r), dl1 = e[l] * (p + r);
+                    const double h = g0 - dl;
+                    WAVE_SYNC();
+                    if (lane == 0) { d[l] = dl; d[l + 1] = dl1; }
+                    for (int i = l + 2 + lane; i < n; i += 64) d[i] -= h;
+                    WAVE_SYNC();
+                    f += h;
+                    double *csb = cs + (size_t)pb * 2 * SYM_EIG_HBM_MAX, *snb = csb + SYM_EIG_HBM_MAX;
+                    // e[l .. m) and d[l .. m) staged in registers (element l + q + 64 rg in lane q of register rg) and handed to the recurrence by lane
+                    // broadcasts: no LDS read sits on the chain
+                    const int len = m - l;
+                    double er[SYM_EIG_HBM_MAX / 64], dr[SYM_EIG_HBM_MAX / 64];
+#pragma unroll
+                    for (int rg = 0; rg < SYM_EIG_HBM_MAX / 64; rg++) { const int q = lane + 64 * rg; er[rg] = q < len ? e[l + q] : 0.0; dr[rg] = q < len ? d[l + q] : 0.0; }
+                    p = d[m];
+                    double c = 1.0, c2 = 1.0, c3 = 1.0, s = 0.0, s2 = 0.0;
+                    const double el1 = e[l + 1];
+#pragma unroll
+                    for (int rg = SYM_EIG_HBM_MAX / 64 - 1; rg >= 0; rg--) {
+                        if (64 * rg >= len) continue;
+                        for (int q = min(63, len - 1 - 64 * rg); q >= 0; q--) {
+                            const int i = l + 64 * rg + q;
+                            c3 = c2; c2 = c; s2 = s;
+                            const double ei = rl_f64(er[rg], q), di = rl_f64(dr[rg], q);
+                            const double g = c * ei;
+                            const double hc = c * p;
+                            const double rr2 = p * p + ei * ei;
+                            const double rinv = rr2 > 0.0 ? rsqrt(rr2) : 0.0;
+                            r = rr2 * rinv;
+                            const double e_ip1 = s * r;
+                            s = ei * rinv;
+                            c = p * rinv;
+                            p = c * di - s * g;
+                            const double d_ip1 = hc + s * (c * g + s * di);
+                            if (lane == 0) { e[i + 1] = e_ip1; d[i + 1] = d_ip1; csb[i] = c; snb[i] = s; }
+                        }
+                    }
+                    p = -s * s2 * c3 * el1 * rl_f64(er[0], 0) / dl1;
+                    WAVE_SYNC();
+                    if (lane == 0) { e[l] = s * p; d[l] = c * p; ql_desc[pb][0] = l; ql_desc[pb][1] = m; }
+                    WAVE_SYNC();
+                    again = fabs(e[l]) > eps * tst1 && iter < 60;
+                    __syncthreads();   // sweep published; the appliers are done with the other buffer
+                    pb ^= 1;
+                } while (again);
+            }
+            WAVE_SYNC();
+            if (lane == 0) { d[l] = d[l] + f; e[l] = 0.0; }
+            WAVE_SYNC();
+        }
+        if (lane == 0) ql_desc[pb][0] = -1;
+        __syncthreads();
+    } else {
+        int cb = 0;
+        const int na = nt - 64;
+        for (;;) {
+            __syncthreads();
+            const int l = ql_desc[cb][0], m = ql_desc[cb][1];
+            if (l < 0) break;
+            const double *csb = cs + (size_t)cb * 2 * SYM_EIG_HBM_MAX, *snb = csb + SYM_EIG_HBM_MAX;
+            // the sweep's rotations applied to component k of the vectors m .. l (rows of the transposed array)
+            for (int k = t - 64; k < n; k += na) {
+                double car = V[(size_t)m * ld + k];
+                for (int i0 = m - 1; i0 >= l; i0 -= 32) {
+                    double v[32];
+#pragma unroll
+                    for (int u = 0; u < 32; u++) v[u] = V[(size_t)max(i0 - u, l) * ld + k];
+#pragma unroll
+                    for (int u = 0; u < 32; u++) {
+                        const int ii = i0 - u;
+                        if (ii < l) break;
+                        const double c = csb[ii], s = snb[ii];
+                        V[(size_t)(ii + 1) * ld + k] = s * v[u] + c * car;
+                        car = c * v[u] - s * car;
+                    }
+                }
+                V[(size_t)l * ld + k] = car;
+            }
+            cb ^= 1;
+        }
+    }
+    __syncthreads();
+    sym_eig_hbm_transpose(V, n, ld);
+    if (tm && t == 0) { const long long n_ = (long long)wall_clock64(); tm[3] = (float)(n_ - tm0); }
+}
+
 __device__ bool chol_block(double *A, int n, int ld, int *sh_flag) {
     const int t = threadIdx.x, nt = blockDim.x;
     if (t == 0) *sh_flag = 1;

@@ -200,6 +200,40 @@ done:
     return rc;
 }
 
+// Harness of sym_eig_hbm (be_linalg.h): one workgroup decomposes the symmetric n x n matrix A (row-major, n <= 512) in place in HBM.  evals[n] (unsorted),
+// evecs[n * n] (evecs[i * n + k] = component i of the eigenvector of evals[k]), usec = the decomposition's time on the device.
+namespace {
+__global__ __launch_bounds__(512) void be_stage_sym_eig_kernel(double *A, int n, double *evals, float *ticks) {
+    __shared__ double sred[64];
+    extern __shared__ __attribute__((aligned(16))) double eig_wk[];
+    const long long t0 = (long long)wall_clock64();
+    sym_eig_hbm(A, n, n, eig_wk, sred, ticks);
+    for (int j = threadIdx.x; j < n; j += blockDim.x) evals[j] = eig_wk[j];
+    __syncthreads();
+    if (threadIdx.x == 0) ticks[0] = (float)((long long)wall_clock64() - t0);
+}
+}  // namespace
+extern "C" int vio_stage_sym_eig(int n, const double *A, double *evals, double *evecs, double *usec) {   // usec[4]: total, tridiagonalisation, accumulation, QL
+    if (n < 2 || n > SYM_EIG_HBM_MAX || !A || !evals || !evecs) return VIO_EINVAL;
+    int rc = VIO_OK;
+    const size_t lds = (size_t)SYM_EIG_HBM_LDS_DOUBLES * sizeof(double);
+    double *dA = nullptr, *dv = nullptr;
+    float *dt = nullptr, ht[4] = {0, 0, 0, 0};
+    int rate_khz = 100000, dev = 0;
+    ST_CHK(hipMalloc((void **)&dA, (size_t)n * n * 8)); ST_CHK(hipMalloc((void **)&dv, (size_t)n * 8)); ST_CHK(hipMalloc((void **)&dt, 16));
+    ST_CHK(hipMemcpy(dA, A, (size_t)n * n * 8, hipMemcpyHostToDevice));
+    be_stage_sym_eig_kernel<<<1, 512, lds>>>(dA, n, dv, dt);
+    ST_CHK(hipDeviceSynchronize());
+    ST_CHK(hipMemcpy(evecs, dA, (size_t)n * n * 8, hipMemcpyDeviceToHost)); ST_CHK(hipMemcpy(evals, dv, (size_t)n * 8, hipMemcpyDeviceToHost));
+    ST_CHK(hipMemcpy(ht, dt, 16, hipMemcpyDeviceToHost));
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&rate_khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || rate_khz <= 0) rate_khz = 100000;
+    if (usec) for (int k = 0; k < 4; k++) usec[k] = ht[k] / (rate_khz * 1e-3);
+done:
+    if (dA) (void)hipFree(dA); if (dv) (void)hipFree(dv); if (dt) (void)hipFree(dt);
+    return rc;
+}
+
 // S: [16 nb][16 nb] row-major symmetric positive definite, rhs: [16 nb].  L_out (row-major, lower triangle written, the rest left as
 // passed in), x_out = S^-1 rhs, usec5 = {factorisation + forward substitution, backward substitution, and of the factorisation as
 // thread 0 sees it: panel phases, diagonal block + trailing update, barrier wait} in microseconds of one workgroup (mean over reps;

@@ -930,6 +930,7 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
     if (build_devcfg(cfg, imu_capacity, h->hc) != VIO_OK) { delete h; return nullptr; }
     h->hc.MXL = 0;
     h->hc.eig_one_wave = getenv("VIO_EIG_ONE_WAVE") ? (atoi(getenv("VIO_EIG_ONE_WAVE")) != 0) : 0;
+    h->hc.eig_jacobi = getenv("VIO_MARG_EIG_JACOBI") ? (atoi(getenv("VIO_MARG_EIG_JACOBI")) != 0) : 0;
     if (h->hc.MX > 0) {
         // marg_exact: the eigen-decompositions of the literal marginalisation run LDS-resident for blocks up to MXL -- whatever the kernel's
         // static LDS leaves of the workgroup's share (matrix with an odd leading dimension + the solver's vectors, be_kernels.hip
@@ -1118,6 +1119,7 @@ vio_batch *vio_create_on_device(const vio_config *cfg, int n_seq, int imu_capaci
             size_t nbq = ((size_t)C.NPRIOR + 15) >> 4;
             h->lds_marg = std::max(std::max((size_t)nbq * (nbq + 1) / 2 * 2048, (size_t)2 * C.NPRIOR * 15 * 8), (size_t)PREINT_MANY_LDS_DOUBLES * 8) + 64;   // (the last: F / V of a chunk of the pre-integration merge)  // lower 16x16 tiles of the new prior (Cholesky for its constant term); before that T1 and A_mr
             if (C.MXL > 0) h->lds_marg = std::max(h->lds_marg, marg_exact_lds_bytes(C.MXL));
+            if (C.MX > 0) h->lds_marg = std::max(h->lds_marg, (size_t)7 * 512 * 8 + 64);   // sym_eig_hbm's vectors (SYM_EIG_HBM_LDS_DOUBLES)
             h->lds_factor = C.NPRIOR <= 96 ? (size_t)C.NPRIOR * (C.NPRIOR | 1) * 8 + 64 : 64;  // on-demand eigen-decomposition (vio_get_prior)
             (void)raise_lds_limit((const void *)be_prior_factor_kernel, h->lds_factor);
         }

@@ -49,6 +49,7 @@ struct DevCfg {
     int pyr_bytes;
     int MX;             // marg_exact: largest marginalised block (15 + landmarks starting in frame 0) the scratch margE is sized for (0 = off)
     int MXL;            // marg_exact: largest block whose eigen-decomposition runs LDS-resident (Householder + implicit QL); larger ones use the HBM Jacobi
+    int eig_jacobi;     // VIO_MARG_EIG_JACOBI: the eigen-decompositions of the literal marginalisation that do not fit LDS by cyclic Jacobi sweeps over HBM (rounds 3 - 5) instead of sym_eig_hbm
     int eig_one_wave;   // VIO_EIG_ONE_WAVE: the Householder tridiagonalisation of the LDS-resident eigen-decompositions on ONE wavefront (no workgroup barriers) instead of the whole workgroup
 };
 
