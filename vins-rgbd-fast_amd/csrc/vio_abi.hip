@@ -1258,9 +1258,10 @@ static int stage_inputs(vio_batch *h, vio_batch::Group &g, const uint8_t *gray, 
     const int p = overlap ? g.flip : 0;
     if (overlap && !g.copy_stream) {
         HIPCHK(hipStreamCreate(&g.copy_stream));   // (one per group: a copy stream shared by the groups measured 27.9 k against 33.9 k frames/s from page-locked buffers)
-        // VIO_COPY_STREAMS = 2: the depth images on a second copy stream per group (measured: no gain, 26.4 k against 27.4 k frames/s from
-        // page-locked buffers -- the uploads of a step take 4.7 ms for 118 MB however they are spread over streams)
-        if (getenv("VIO_COPY_STREAMS") && atoi(getenv("VIO_COPY_STREAMS")) == 2) HIPCHK(hipStreamCreate(&g.copy_stream2));
+        // The depth images go on a second copy stream per group (VIO_COPY_STREAMS = 1: one stream for both).  Rounds 4 - 5 measured no gain (26.4 k against
+        // 27.4 k frames/s from page-locked buffers); with the paced feed and the shorter device step of round 6 the second stream is worth 14 %:
+        // 38.0 -> 43.4 k from page-locked buffers, 47.2 -> 49.3 k from pageable ones (tools/pcie_sweep.sh, 60 host-fed steps)
+        if (!(getenv("VIO_COPY_STREAMS") && atoi(getenv("VIO_COPY_STREAMS")) == 1)) HIPCHK(hipStreamCreate(&g.copy_stream2));
         for (int q = 0; q < 2; q++) {
             HIPCHK(hipEventCreateWithFlags(&g.ev_up_gray[q], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&g.ev_up_depth[q], hipEventDisableTiming));
